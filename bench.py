@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- clip-seqs/sec of the EgoPack multi-task training step on MI355X.
+
+Workload (BASELINE.json metric / configs[2] at N GPUs): AR + LTA + PNR multi-task
+pre-training, per GPU and per task B=64 sequences of T=32 clip nodes, 3 x 1536-d Omnivore-shaped
+features per node, hidden 1024, TRN hidden 1024 (dropout 0.5), backbone depth 3, temporal radius
+k=1, Adam.  A step = zero_grad -> fused backbone forward over the three task batches -> heads ->
+sum_t w_t * loss_t.mean() -> backward -> (gradient all-reduce) -> Adam, inputs resident in HBM.
+One process per GPU (torchrun env), weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` (dominant kernel,
+HIP-event timings taken by the library on the launch stream) and ``cpu_baseline`` (the CPU oracle
+timed on the host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md: chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def build_workload(args, rank, device):
+    from egopack_amd import data as D
+    from egopack_amd.criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper
+    from egopack_amd.models import Graph
+    from egopack_amd.models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+
+    torch.manual_seed(1)  # identical initial parameters on every rank (defaults.yaml:2)
+    H, HP, F_IN, S, heads = args.hidden, args.trn_hidden, 1536, 3, (115, 478)
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": args.dropout,
+           "hidden_size": HP}
+    model = Graph(F_IN, hidden_size=H, depth=3, pre_dropout=0, temporal_pooling=trn, num_segments=S)
+    tasks = {"ar": RecognitionTask(H, H, heads), "oscc": OSCCTask(H, H), "lta": LTATask(H, H, heads), "pnr": PNRTask(H, H)}
+
+    class DS:
+        has_joint_label, num_labels = False, 2
+    crit = {"ar": MetricSelectorWrapper(CrossEntropyNone(), DS()), "lta": MetricSelectorWrapper(CrossEntropyNone(), DS()),
+            "oscc": CrossEntropyNone(), "pnr": BCEWithLogitsNone()}
+    weights = {"ar": 1.0, "oscc": 0.0, "lta": 1.0, "pnr": 1.0}
+
+    # synthetic batches: labels / positions / edges from the host-side dataset logic, features N(0,1)
+    # generated straight into HBM (seed 1 + rank: SURVEY 8d)
+    host = {}
+    for t in ("ar", "lta", "pnr"):
+        ds = D.SyntheticTaskDataset(t, args.batch, args.T, S, 8, heads, k=1, seed=1 + rank)  # tiny x, replaced below
+        host[t] = D.collate([ds[i] for i in range(args.batch)])
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1 + rank)
+    dev = {}
+    for t, b in host.items():
+        b.x = torch.empty(0)
+        d = b.to(device)
+        d.x = torch.randn(args.batch * args.T, S, F_IN, device=device, generator=gen)
+        dev[t] = d
+    merged = D.merge_batches([host[t] for t in ("ar", "lta", "pnr")]).to(device)
+    merged.x = [dev[t].x for t in ("ar", "lta", "pnr")]
+    return model, tasks, crit, weights, dev, merged
+
+
+def cpu_baseline(sds, names, dev, weights, budget_s=20.0):
+    """The CPU oracle (oracle/path.py, checker code) timed on the host cores: same shapes, fp32,
+    forward + backward + torch.optim.Adam; as many steps as fit the time budget (>= 1)."""
+    from oracle import path as O
+    from oracle import pyg_ops as P
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    leaf = {g: {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("frequency") else v.clone())
+                for k, v in sd.items()} for g, sd in sds.items()}
+    batches = {t: P.OData(x=d.x.cpu(), pos=d.pos.cpu(), edge_index=d.edge_index.cpu(), y=d.y.cpu(), batch=d.batch.cpu(),
+                          num_graphs=d.num_graphs) for t, d in dev.items()}
+    flat = [p for g in leaf.values() for p in g.values() if p.requires_grad]
+    opt = torch.optim.Adam(flat, lr=1e-5, weight_decay=1e-5)
+    seqs = sum(b.num_graphs for b in batches.values())
+
+    def one():
+        opt.zero_grad()
+        total, _ = O.mtl_objective(leaf["temporal_graph"], {t: leaf[n] for t, n in names.items()}, batches, weights)
+        total.backward()
+        opt.step()
+
+    t0 = time.perf_counter()
+    one()  # warm-up (also sizes the sample)
+    first = time.perf_counter() - t0
+    n = max(1, min(20, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": seqs / dt, "unit": "clip-seqs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} step(s) after 1 warm-up of the same step (3 tasks x B={batches['ar'].num_graphs} x "
+                      f"T={batches['ar'].x.shape[0] // batches['ar'].num_graphs}), fp32 torch CPU oracle, "
+                      f"{dt * 1e3:.0f} ms/step"}
+
+
+def roofline(ops, step_fn, compute, n_steps=3):
+    """Profile ``n_steps`` eager steps with the library's HIP-event timers; report the dominant kernel."""
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for _ in range(n_steps):
+        step_fn()
+    torch.cuda.synchronize()
+    ops.prof_enable(False)
+    rep = ops.prof_report()
+    ops.prof_reset()
+    if not rep:
+        return None, {}
+    name, r = max(rep.items(), key=lambda kv: kv[1]["total_ms"])
+    avg_ms = r["total_ms"] / r["launches"]
+    if name.startswith("gemm"):
+        achieved = r["flops"] / (r["total_ms"] * 1e-3) / 1e12
+        peak = PEAK["bf16" if "bf16" in name else "f32"]
+        out = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}
+    else:
+        achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
+        out = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS}
+    out.update({"traffic": None, "kernel": name, "launches_per_step": r["launches"] / n_steps, "avg_launch_us": avg_ms * 1e3,
+                "alg_per_launch": (r["flops"] if name.startswith("gemm") else r["bytes"]) / r["launches"]})
+    table = {k: {"launches_per_step": v["launches"] / n_steps, "ms_per_step": v["total_ms"] / n_steps,
+                 "tflops": (v["flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["flops"] and v["total_ms"] else None,
+                 "gbs": (v["bytes"] / (v["total_ms"] * 1e-3) / 1e9) if v["bytes"] and v["total_ms"] else None}
+             for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}
+    return out, table
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per task per GPU")
+    ap.add_argument("--T", type=int, default=32, help="clip nodes per sequence")
+    ap.add_argument("--hidden", type=int, default=1024)
+    ap.add_argument("--trn-hidden", type=int, default=1024)
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--compute", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--no-fused-backbone", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
+    args = ap.parse_args()
+
+    from egopack_amd import dist as edist
+    rank, local_rank, world = edist.init_from_env()
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from egopack_amd import engine, ops
+    from egopack_amd.optim import FlatAdam
+    ops.set_compute(args.compute)
+    ops.manual_seed(1000 + rank)  # dropout streams differ per rank
+
+    model, tasks, crit, weights, dev, merged = build_workload(args, rank, device)
+    names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
+    sds = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sds = {"temporal_graph": {k: v.clone() for k, v in model.state_dict().items()}}
+        for t, n in names.items():
+            sds[n] = {k: v.clone() for k, v in tasks[t].state_dict().items()}
+    model.to(device).train()
+    for t in tasks.values():
+        t.to(device).train()
+    params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
+    opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
+    sync = edist.GradSync(world) if world > 1 else None
+    step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync)
+    fused_merged = None if args.no_fused_backbone else merged
+
+    def eager_step():
+        step.step(dev, fused_merged)
+
+    if args.mode == "graph":
+        step.capture(dev, fused_merged, warmup=2)
+        run = step.replay
+    else:
+        eager_step()  # materialise the flat buffers
+        run = eager_step
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    barrier()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    if world > 1:
+        t = torch.tensor([ms], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = t.item()
+
+    seqs_per_step = world * 3 * args.batch
+    rl, table = (None, {})
+    if rank == 0 and not args.no_roofline:
+        try:
+            rl, table = roofline(ops, eager_step, args.compute)
+        except Exception as e:  # the headline number must still be printed
+            rl = {"error": repr(e)}
+    cb = None
+    if sds is not None:
+        try:
+            cb = cpu_baseline(sds, names, dev, weights)
+        except Exception as e:
+            cb = {"error": repr(e)}
+
+    if rank == 0:
+        n_params = opt.flat_p.numel()
+        out = {
+            "metric": "clip-seqs/sec training, AR+LTA+PNR multi-task", "value": seqs_per_step / (ms * 1e-3),
+            "unit": "clip-seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"MTL pre-train AR+LTA+PNR, per GPU B={args.batch} seqs/task x T={args.T} nodes, "
+                                   f"3x1536-d Omnivore-shaped features, H={args.hidden}, TRN hidden {args.trn_hidden} "
+                                   f"(dropout {args.dropout}), depth 3, k=1, Adam; {args.mode} mode, "
+                                   f"{'fused' if not args.no_fused_backbone else 'per-task'} backbone pass",
+                       "global_batch": seqs_per_step, "nodes_per_step": seqs_per_step * args.T,
+                       "parallelism": f"dp{world}", "trainable_params": n_params,
+                       "master_weights": "f32", "mfma": args.compute},
+            "roofline": rl, "cpu_baseline": cb,
+        }
+        if args.kernel_table and table:
+            print(json.dumps(table, indent=1), file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""ctypes binding of libegopack_hip.so -- the reference-side stub a maintainer adds.
+
+The library is the product: if it is missing this module raises, there is no fallback of any
+kind (the CPU oracle under oracle/ is test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libegopack_hip.so"
+HEADER = HERE.parent / "include" / "egopack_hip.h"
+
+vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    """struct egk_gemm_desc (include/egopack_hip.h)."""
+    _fields_ = [
+        ("M", i32), ("N", i32), ("K1", i32), ("K2", i32),
+        ("A1", vp), ("A2", vp), ("B1", vp), ("B2", vp),
+        ("lda1", i64), ("lda2", i64), ("ldb1", i64), ("ldb2", i64),
+        ("transA", i32), ("transB", i32), ("a_dtype", i32), ("b_dtype", i32),
+        ("compute", i32),
+        ("C", vp), ("ldc", i64), ("c_dtype", i32),
+        ("accumulate", i32), ("act", i32), ("alpha", f32),
+        ("bias", vp), ("residual", vp), ("ldr", i64),
+        ("splitk", i32), ("ws", vp), ("ws_bytes", i64),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/egopack_hip.h one to one
+SIGNATURES = {
+    "egk_version": (C.c_int, []),
+    "egk_last_error": (C.c_char_p, []),
+    "egk_prof_enable": (C.c_int, [C.c_int]),
+    "egk_prof_reset": (C.c_int, []),
+    "egk_prof_count": (C.c_int, []),
+    "egk_prof_get": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(i64), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
+    "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),
+    "egk_colsum_ws_len": (C.c_int, [i32, i32]),
+    "egk_colsum": (C.c_int, [vp, vp, i64, i32, i32, vp, i32, vp]),
+    "egk_rowln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, f32, u64, u64, vp]),
+    "egk_rowln_bwd_ws_rows": (C.c_int, [i32]),
+    "egk_rowln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32]),
+    "egk_graphln_ws_bytes": (i64, [i32, i32, i32]),
+    "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp]),
+    "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp]),
+    "egk_pe_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
+    "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32]),
+    "egk_gather_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),
+    "egk_gather_max_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32]),
+    "egk_segment_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
+    "egk_segment_max_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
+    "egk_row_inv_norm": (C.c_int, [vp, vp, vp, i32, i32]),
+    "egk_cos_dist": (C.c_int, [vp, vp, i64, vp, vp, vp, i32, i32]),
+    "egk_topk_smallest": (C.c_int, [vp, vp, i64, vp, vp, vp, i32, i32, i32]),
+    "egk_scatter_add_rows_f64": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64]),
+    "egk_ce_fwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, i32, i32, f32, i32]),
+    "egk_ce_bwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, f32]),
+    "egk_bce_fwd": (C.c_int, [vp, vp, vp, vp, i32]),
+    "egk_bce_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32]),
+    "egk_dropout_fwd": (C.c_int, [vp, vp, vp, vp, i64, f32, u64, u64, vp]),
+    "egk_dropout_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32]),
+    "egk_relu_gate": (C.c_int, [vp, vp, vp, vp, i64]),
+    "egk_axpby": (C.c_int, [vp, vp, vp, vp, i64, f32, f32]),
+    "egk_fill_scaled": (C.c_int, [vp, vp, f32, vp, i64]),
+    "egk_sum_scale": (C.c_int, [vp, vp, vp, i64, f32, i32]),
+    "egk_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32]),
+}
+
+
+def header_symbols() -> list:
+    """Every function name declared in include/egopack_hip.h."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(egk_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m egopack_amd.build` "
+            "(or __graft_entry__.build()).  egopack_amd has no CPU / eager fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().egk_last_error().decode(errors="replace")

@@ -1,0 +1,373 @@
+// MFMA contraction kernel for gfx950: C = epilogue(op(A) . op(B)^T), two-source K, split-K slabs.
+//
+// Geometry (one workgroup = 256 threads = 4 waves as 2(M) x 2(N); one output tile 128 x 128):
+//   * both operands are staged as K-contiguous LDS images  [128 rows][128 B]  whatever their
+//     layout in memory: a row-major operand is loaded 16/32 B per lane along K, a transposed
+//     operand ([K][rows] in memory: weights for dX, activations/gradients for dW) is loaded
+//     16 B per lane along its contiguous "rows" axis and transposed in registers, so no
+//     transposed copies of weights or activations ever exist in HBM;
+//   * f32 sources are converted to bf16 while staging (EGK_COMPUTE_BF16: v_mfma_f32_16x16x32_bf16,
+//     64-element K-tile) or kept (EGK_COMPUTE_F32: v_mfma_f32_16x16x4_f32, exact fmaf chain,
+//     32-element K-tile).  One 16-byte LDS chunk per lane feeds one bf16 MFMA or four f32 MFMAs;
+//   * the 16-byte chunk index of a row is XOR-swizzled with (row>>1)&7 so that the
+//     ds_read_b128 of a 16-lane group (16 rows, one chunk column) hits 16 distinct 16-B slots
+//     of the 256-B bank row (MI355X_MICROARCH.md, LDS table);
+//   * register prefetch: the global loads of K-tile t+1 are issued before the MFMAs of tile t
+//     and written to LDS after the barrier (T14 split), single LDS image of 32 KiB;
+//   * the MFMA is issued as D^T = B.A^T so each lane owns 4 CONSECUTIVE columns of one output
+//     row: bias / residual / C traffic is 16 B per lane;
+//   * blockIdx is remapped so that each XCD owns a contiguous range of M-tiles (the activation
+//     rows are the large operand; the weights are re-read from every XCD's L2).
+#include "common.h"
+
+namespace egk {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int BM = 128, BN = 128, ROWB = 128;  // LDS row = 128 bytes = 8 chunks of 16 B
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+    int M, N;
+    int K[2];
+    const float* A[2];
+    const float* B[2];
+    long long lda[2], ldb[2];
+    int a_vec[2], b_vec[2];  // 16-byte vector loads legal for this source
+    float* C;
+    long long ldc;
+    int c_vec;
+    int accumulate, act;
+    float alpha;
+    const float* bias;
+    const float* residual;
+    long long ldr;
+    int r_vec;
+    int splitk;
+    float* ws;  // [splitk][M][N] partial slabs when splitk > 1
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+    return __builtin_bit_cast(uint4, v);
+}
+
+// Row-major operand ([rows][K], ld): chunk ids tid + 256*i -> (row = id>>3, chunk = id&7).
+template <bool BF16>
+__device__ __forceinline__ void load_rowmajor(const float* __restrict__ base, long long ld, int rows_total, int row0,
+                                              int k0, int klim, bool vec, uint4 (&out)[4]) {
+    constexpr int CE = BF16 ? 8 : 4;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + NTHREADS * i;
+        const int r = id >> 3, c = id & 7;
+        const int grow = row0 + r, gk = k0 + c * CE;
+        float f[8];
+        const bool row_ok = grow < rows_total;
+        const float* p = base + (long long)grow * ld + gk;
+        if (row_ok && vec && gk + CE <= klim) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p);
+            f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+            if constexpr (BF16) {
+                const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+                f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CE; ++j) f[j] = (row_ok && gk + j < klim) ? p[j] : 0.0f;
+        }
+        if constexpr (BF16) out[i] = pack8(f);
+        else out[i] = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+}
+
+// Transposed operand ([K][rows], ld): thread -> row quad q = tid&31 (rows 4q..4q+3), chunk kc = tid>>5.
+template <bool BF16>
+__device__ __forceinline__ void load_transposed(const float* __restrict__ base, long long ld, int rows_total, int row0,
+                                                int k0, int klim, bool vec, uint4 (&out)[4]) {
+    constexpr int CE = BF16 ? 8 : 4;
+    const int tid = threadIdx.x;
+    const int q = tid & 31, kc = tid >> 5;
+    const int grow = row0 + 4 * q, gk = k0 + kc * CE;
+    float f[CE][4];
+#pragma unroll
+    for (int j = 0; j < CE; ++j) {
+        const float* p = base + (long long)(gk + j) * ld + grow;
+        const bool k_ok = gk + j < klim;
+        if (k_ok && vec && grow + 4 <= rows_total) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            f[j][0] = v.x; f[j][1] = v.y; f[j][2] = v.z; f[j][3] = v.w;
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) f[j][rr] = (k_ok && grow + rr < rows_total) ? p[rr] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        if constexpr (BF16) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = f[j][rr];
+            out[rr] = pack8(t);
+        } else {
+            out[rr] = make_uint4(__float_as_uint(f[0][rr]), __float_as_uint(f[1][rr]), __float_as_uint(f[2][rr]),
+                                 __float_as_uint(f[3][rr]));
+        }
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void store_lds(unsigned char* lds, const uint4 (&v)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, chunk;
+        if constexpr (TR) {
+            row = 4 * (tid & 31) + i;
+            chunk = tid >> 5;
+        } else {
+            const int id = tid + NTHREADS * i;
+            row = id >> 3;
+            chunk = id & 7;
+        }
+        *reinterpret_cast<uint4*>(lds + lds_off(row, chunk)) = v[i];
+    }
+}
+
+template <bool BF16, bool TA, bool TB>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * ROWB];
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + BM * ROWB;
+    constexpr int KT = BF16 ? 64 : 32;
+
+    // XCD-aware tile id: blocks b, b+8, ... share an XCD; give each XCD a contiguous id range.
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nkt0 = (g.K[0] + KT - 1) / KT, nkt1 = (g.K[1] + KT - 1) / KT;
+    const int nkt = nkt0 + nkt1;
+    // split-K: this block handles K-tiles [t_begin, t_end)
+    const int z = blockIdx.y;
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int t) {
+        const int src = t < nkt0 ? 0 : 1;
+        const int k0 = (src == 0 ? t : t - nkt0) * KT;
+        if constexpr (TA) load_transposed<BF16>(g.A[src], g.lda[src], g.M, m0, k0, g.K[src], g.a_vec[src], ra);
+        else load_rowmajor<BF16>(g.A[src], g.lda[src], g.M, m0, k0, g.K[src], g.a_vec[src], ra);
+        if constexpr (TB) load_transposed<BF16>(g.B[src], g.ldb[src], g.N, n0, k0, g.K[src], g.b_vec[src], rb);
+        else load_rowmajor<BF16>(g.B[src], g.ldb[src], g.N, n0, k0, g.K[src], g.b_vec[src], rb);
+    };
+
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();  // every wave finished reading the previous image
+        store_lds<TA>(ldsA, ra);
+        store_lds<TB>(ldsB, rb);
+        __syncthreads();
+        if (t + 1 < t_end) load_tile(t + 1);  // in flight under the MFMAs below
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const uint4*>(ldsA + lds_off(wm * 64 + i * 16 + lr, s * 4 + lg));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const uint4*>(ldsB + lds_off(wn * 64 + j * 16 + lr, s * 4 + lg));
+            if constexpr (BF16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                            __builtin_bit_cast(bf16x8, a[i]),
+                                                                            acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float av = __uint_as_float(q == 0 ? a[i].x : q == 1 ? a[i].y : q == 2 ? a[i].z : a[i].w);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float bv =
+                                __uint_as_float(q == 0 ? b[j].x : q == 1 ? b[j].y : q == 2 ? b[j].z : b[j].w);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // Epilogue.  D^T layout: lane holds C[m = .. + lr][n = .. + 4*lg + t], t = 0..3.
+    const bool slab = g.splitk > 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + lr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+            if (n >= g.N) continue;
+            f32x4 v = acc[i][j];
+            if (slab) {
+                float* p = g.ws + ((long long)z * g.M + m) * g.N + n;
+                if (n + 4 <= g.N && (g.N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) p[t] = v[t];
+                continue;
+            }
+            float* cp = g.C + (long long)m * g.ldc + n;
+            const bool full = n + 4 <= g.N;
+            float o[4] = {v[0] * g.alpha, v[1] * g.alpha, v[2] * g.alpha, v[3] * g.alpha};
+            if (g.accumulate) {
+                if (full && g.c_vec) {
+                    const float4 c = *reinterpret_cast<const float4*>(cp);
+                    o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
+                } else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += cp[t];
+            }
+            if (g.bias)
+                for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += g.bias[n + t];
+            if (g.act == EGK_ACT_RELU)
+                for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+            if (g.residual) {
+                const float* rp = g.residual + (long long)m * g.ldr + n;
+                if (full && g.r_vec) {
+                    const float4 r = *reinterpret_cast<const float4*>(rp);
+                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                } else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += rp[t];
+            }
+            if (full && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+            else
+                for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = o[t];
+        }
+    }
+}
+
+// Sum the split-K slabs in slab order (bitwise reproducible) and apply the epilogue.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+        float s = 0.f;
+        for (int z = 0; z < g.splitk; ++z) s += g.ws[(long long)z * total + idx];
+        float o = s * g.alpha;
+        float* cp = g.C + (long long)m * g.ldc + n;
+        if (g.accumulate) o += *cp;
+        if (g.bias) o += g.bias[n];
+        if (g.act == EGK_ACT_RELU) o = fmaxf(o, 0.f);
+        if (g.residual) o += g.residual[(long long)m * g.ldr + n];
+        *cp = o;
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace egk
+
+using namespace egk;
+
+// Split-K policy (host side, deterministic): slabs when the tile grid alone would leave most of
+// the 256 CUs idle and K is deep (the dW contractions: 64 tiles, K = nodes in the batch).
+extern "C" int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute) {
+    const int KT = compute == EGK_COMPUTE_BF16 ? 64 : 32;
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    const int nkt = cdiv(K, KT);
+    if (tiles >= 128 || nkt < 16) return 1;
+    int s = 256 / tiles;
+    if (s > nkt / 8) s = nkt / 8;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
+    EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
+    EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
+    EGK_REQUIRE(d->a_dtype == EGK_F32 && d->b_dtype == EGK_F32 && d->c_dtype == EGK_F32,
+                "egk_gemm: only f32 matrices in memory are supported");
+    EGK_REQUIRE(d->compute == EGK_COMPUTE_F32 || d->compute == EGK_COMPUTE_BF16, "egk_gemm: bad compute type");
+    EGK_REQUIRE(d->C != nullptr || d->M == 0 || d->N == 0, "egk_gemm: null C");
+    EGK_REQUIRE(d->K1 == 0 || (d->A1 && d->B1), "egk_gemm: null A1/B1");
+    EGK_REQUIRE(d->K2 == 0 || (d->A2 && d->B2), "egk_gemm: null A2/B2");
+    if (d->M == 0 || d->N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+
+    GemmArgs g;
+    g.M = d->M; g.N = d->N;
+    g.K[0] = d->K1; g.K[1] = d->K2;
+    g.A[0] = (const float*)d->A1; g.A[1] = (const float*)d->A2;
+    g.B[0] = (const float*)d->B1; g.B[1] = (const float*)d->B2;
+    g.lda[0] = d->lda1; g.lda[1] = d->lda2; g.ldb[0] = d->ldb1; g.ldb[1] = d->ldb2;
+    for (int i = 0; i < 2; ++i) {
+        g.a_vec[i] = g.A[i] && aligned16(g.A[i]) && (g.lda[i] % 4 == 0);
+        g.b_vec[i] = g.B[i] && aligned16(g.B[i]) && (g.ldb[i] % 4 == 0);
+    }
+    g.C = (float*)d->C; g.ldc = d->ldc;
+    g.c_vec = aligned16(g.C) && (g.ldc % 4 == 0);
+    g.accumulate = d->accumulate; g.act = d->act; g.alpha = d->alpha;
+    g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
+    g.r_vec = g.residual && aligned16(g.residual) && (g.ldr % 4 == 0);
+    g.splitk = d->splitk > 1 ? d->splitk : 1;
+    g.ws = (float*)d->ws;
+    if (g.splitk > 1)
+        EGK_REQUIRE(g.ws && d->ws_bytes >= (int64_t)g.splitk * d->M * d->N * 4, "egk_gemm: split-K workspace too small");
+    g.tiles_m = cdiv(g.M, BM); g.tiles_n = cdiv(g.N, BN);
+
+    const int K = d->K1 + d->K2;
+    const double flops = 2.0 * d->M * d->N * K;
+    const double bytes = 4.0 * ((double)d->M * K + (double)d->N * K + (double)d->M * d->N);
+    const int bf = d->compute == EGK_COMPUTE_BF16;
+    const int kid = (bf ? KID_GEMM_BF16_NN : KID_GEMM_F32_NN) + (d->transA ? (d->transB ? 2 : 3) : (d->transB ? 1 : 0));
+    ProfScope prof(kid, s, flops, bytes);
+
+    dim3 grid(g.tiles_m * g.tiles_n, g.splitk), block(NTHREADS);
+#define EGK_LAUNCH(BF, TA, TB) hipLaunchKernelGGL((gemm_kernel<BF, TA, TB>), grid, block, 0, s, g)
+    if (bf) {
+        if (!d->transA && !d->transB) EGK_LAUNCH(true, false, false);
+        else if (!d->transA && d->transB) EGK_LAUNCH(true, false, true);
+        else if (d->transA && d->transB) EGK_LAUNCH(true, true, true);
+        else EGK_LAUNCH(true, true, false);
+    } else {
+        if (!d->transA && !d->transB) EGK_LAUNCH(false, false, false);
+        else if (!d->transA && d->transB) EGK_LAUNCH(false, false, true);
+        else if (d->transA && d->transB) EGK_LAUNCH(false, true, true);
+        else EGK_LAUNCH(false, true, false);
+    }
+#undef EGK_LAUNCH
+    if (g.splitk > 1) {
+        const long long total = (long long)g.M * g.N;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, g);
+    }
+    return check_launch("egk_gemm");
+}

@@ -1,0 +1,383 @@
+// Message-passing and prototype kernels: positional encoding add, CSR row gather (SAGE mean
+// forward/backward), GraphONE gather-max, per-sequence max pool, cosine k-NN selection and the
+// float64 prototype-bank scatter-add.
+//
+// All row kernels use the one-wave-per-row layout (16 B per lane, 1 KiB per wave-instruction):
+// a 1024-wide fp32 feature row is 4 wave-instructions.  Neighbour rows of the banded temporal
+// graph and the prototype bank (K*H*4 = 16.8 MB at K = 4096) are re-read from L2 / Infinity
+// Cache, so the algorithmic HBM bytes are one read + one write of the [N, H] tensor.
+#include <math.h>
+
+#include "common.h"
+
+namespace egk {
+
+constexpr int WPB = 4;
+
+__device__ __forceinline__ float4 ld4(const float* __restrict__ p, int c, int cols, bool vec) {
+    if (vec && c + 4 <= cols) return *reinterpret_cast<const float4*>(p + c);
+    float4 v;
+    v.x = c + 0 < cols ? p[c + 0] : 0.f;
+    v.y = c + 1 < cols ? p[c + 1] : 0.f;
+    v.z = c + 2 < cols ? p[c + 2] : 0.f;
+    v.w = c + 3 < cols ? p[c + 3] : 0.f;
+    return v;
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, int c, int cols, bool vec, float4 v) {
+    if (vec && c + 4 <= cols) {
+        *reinterpret_cast<float4*>(p + c) = v;
+        return;
+    }
+    if (c + 0 < cols) p[c + 0] = v.x;
+    if (c + 1 < cols) p[c + 1] = v.y;
+    if (c + 2 < cols) p[c + 2] = v.z;
+    if (c + 3 < cols) p[c + 3] = v.w;
+}
+
+// ---- positional encoding ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pe_add_kernel(const float* __restrict__ x, const long long* __restrict__ pos,
+                                                     const float* __restrict__ freq, float* __restrict__ y, int rows,
+                                                     int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    const int half = cols >> 1;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const float p = (float)pos[row];
+        const float* xr = x + (long long)row * cols;
+        float* yr = y + (long long)row * cols;
+        for (int c = lane * 4; c < cols; c += 256) {
+            float4 v = ld4(xr, c, cols, vec);
+            float e[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cc = c + t;
+                if (cc < cols) {
+                    const bool is_sin = cc < half;
+                    const float a = p * freq[is_sin ? cc : cc - half];
+                    e[t] = is_sin ? sinf(a) : cosf(a);
+                } else
+                    e[t] = 0.f;
+            }
+            v.x += e[0]; v.y += e[1]; v.z += e[2]; v.w += e[3];
+            st4(yr, c, cols, vec, v);
+        }
+    }
+}
+
+// ---- CSR gather ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_gather_kernel(const float* __restrict__ x, const int* __restrict__ rowptr,
+                                                         const int* __restrict__ col, const float* __restrict__ wgt,
+                                                         const float* __restrict__ gate, float* __restrict__ out, int rows,
+                                                         int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        const float mean_w = e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f;
+        for (int c = lane * 4; c < cols; c += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e0; e < e1; ++e) {
+                const float4 v = ld4(x + (long long)col[e] * cols, c, cols, vec);
+                if (wgt) {
+                    const float we = wgt[e];
+                    acc.x += we * v.x; acc.y += we * v.y; acc.z += we * v.z; acc.w += we * v.w;
+                } else {
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+            if (!wgt) {  // mean = sum / count, as scatter_add / clamp(count, 1)
+                acc.x *= mean_w; acc.y *= mean_w; acc.z *= mean_w; acc.w *= mean_w;
+            }
+            if (gate) {
+                const float4 g = ld4(gate + (long long)row * cols, c, cols, vec);
+                acc.x = g.x > 0.f ? acc.x : 0.f; acc.y = g.y > 0.f ? acc.y : 0.f;
+                acc.z = g.z > 0.f ? acc.z : 0.f; acc.w = g.w > 0.f ? acc.w : 0.f;
+            }
+            st4(out + (long long)row * cols, c, cols, vec, acc);
+        }
+    }
+}
+
+// ---- GraphONE gather-max ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __restrict__ f, const float* __restrict__ bank,
+                                                             const long long* __restrict__ nn, float* __restrict__ m,
+                                                             uint8_t* __restrict__ arg, int rows, int cols, int k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        for (int c = lane * 4; c < cols; c += 256) {
+            // message order of the reference: prototype edges first, the self loop appended last
+            // (add_remaining_self_loops); first maximum wins on ties.
+            float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            uint32_t a4 = 0;
+            for (int j = 0; j <= k; ++j) {
+                const float* src = j < k ? bank + nn[(long long)row * k + j] * cols : f + (long long)row * cols;
+                const float4 v = ld4(src, c, cols, vec);
+                if (v.x > best.x) { best.x = v.x; a4 = (a4 & ~0x000000ffu) | (uint32_t)j; }
+                if (v.y > best.y) { best.y = v.y; a4 = (a4 & ~0x0000ff00u) | ((uint32_t)j << 8); }
+                if (v.z > best.z) { best.z = v.z; a4 = (a4 & ~0x00ff0000u) | ((uint32_t)j << 16); }
+                if (v.w > best.w) { best.w = v.w; a4 = (a4 & ~0xff000000u) | ((uint32_t)j << 24); }
+            }
+            st4(m + (long long)row * cols, c, cols, vec, best);
+            uint8_t* ap = arg + (long long)row * cols + c;
+            if (vec && c + 4 <= cols) *reinterpret_cast<uint32_t*>(ap) = a4;
+            else
+                for (int t = 0; t < 4 && c + t < cols; ++t) ap[t] = (a4 >> (8 * t)) & 0xff;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __restrict__ dm, const uint8_t* __restrict__ arg,
+                                                             float* __restrict__ df, long long n, int k, int accumulate) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+         i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            const float4 g = *reinterpret_cast<const float4*>(dm + i);
+            const uint32_t a4 = *reinterpret_cast<const uint32_t*>(arg + i);
+            float4 o;
+            o.x = ((a4 >> 0) & 0xff) == (uint32_t)k ? g.x : 0.f;
+            o.y = ((a4 >> 8) & 0xff) == (uint32_t)k ? g.y : 0.f;
+            o.z = ((a4 >> 16) & 0xff) == (uint32_t)k ? g.z : 0.f;
+            o.w = ((a4 >> 24) & 0xff) == (uint32_t)k ? g.w : 0.f;
+            if (accumulate) {
+                const float4 d = *reinterpret_cast<const float4*>(df + i);
+                o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+            }
+            *reinterpret_cast<float4*>(df + i) = o;
+        } else {
+            for (long long j = i; j < n; ++j) {
+                const float o = arg[j] == k ? dm[j] : 0.f;
+                df[j] = accumulate ? df[j] + o : o;
+            }
+        }
+    }
+}
+
+// ---- per-sequence max pool ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segmax_fwd_kernel(const float* __restrict__ x, const int* __restrict__ ptr,
+                                                         float* __restrict__ out, int* __restrict__ arg, int n_seg,
+                                                         int cols) {
+    const int sg = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = ptr[sg], r1 = ptr[sg + 1];
+    float best = 0.f;  // empty segment -> 0 (scatter 'amax' into zeros, include_self=False)
+    int a = -1;
+    for (int r = r0; r < r1; ++r) {
+        const float v = x[(long long)r * cols + c];
+        if (a < 0 || v > best) {
+            best = v;
+            a = r;
+        }
+    }
+    out[(long long)sg * cols + c] = best;
+    arg[(long long)sg * cols + c] = a;
+}
+
+__global__ __launch_bounds__(256) void segmax_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
+                                                         const int* __restrict__ ptr, float* __restrict__ dx, int n_seg,
+                                                         int cols) {
+    const int sg = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = ptr[sg], r1 = ptr[sg + 1];
+    const int a = arg[(long long)sg * cols + c];
+    const float g = dout[(long long)sg * cols + c];
+    for (int r = r0; r < r1; ++r) dx[(long long)r * cols + c] = r == a ? g : 0.f;
+}
+
+// ---- cosine k-NN ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ x, float* __restrict__ inv, int rows,
+                                                           int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        float s = 0.f;
+        for (int c = lane * 4; c < cols; c += 256) {
+            const float4 v = ld4(x + (long long)row * cols, c, cols, vec);
+            s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) inv[row] = 1.f / sqrtf(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void cos_dist_kernel(const float* __restrict__ dot, long long ldd,
+                                                       const float* __restrict__ f_inv, const float* __restrict__ b_inv,
+                                                       float* __restrict__ dist, int rows, int K) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (j < K) dist[(long long)r * K + j] = 1.f - dot[(long long)r * ldd + j] * f_inv[r] * b_inv[j];
+}
+
+// one wave per row: k rounds of a lexicographic (distance, index) arg-min over the row.
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot, long long ldd,
+                                                   const float* __restrict__ f_inv, const float* __restrict__ b_inv,
+                                                   long long* __restrict__ nn, int rows, int K, int k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const float* dr = dot + (long long)row * ldd;
+        const float fi = f_inv[row];
+        float last_v = -INFINITY;
+        int last_i = -1;
+        for (int sel = 0; sel < k; ++sel) {
+            float bv = INFINITY;
+            int bi = 0x7fffffff;
+            for (int j = lane; j < K; j += 64) {
+                const float d = 1.f - dr[j] * fi * b_inv[j];
+                const bool eligible = d > last_v || (d == last_v && j > last_i);
+                if (eligible && (d < bv || (d == bv && j < bi))) {
+                    bv = d;
+                    bi = j;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov < bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) nn[(long long)row * k + sel] = bi == 0x7fffffff ? 0 : bi;
+            last_v = bv;
+            last_i = bi;
+        }
+    }
+}
+
+// ---- prototype bank scatter-add (fp64) --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_add_f64_kernel(const float* __restrict__ x, const long long* __restrict__ label,
+                                                              double* __restrict__ bank, long long* __restrict__ count,
+                                                              int rows, int cols, long long n_labels) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const long long lb = label[row];
+        if (lb < 0 || lb >= n_labels) continue;
+        if (lane == 0 && count) atomicAdd(reinterpret_cast<unsigned long long*>(count + lb), 1ull);
+        for (int c = lane; c < cols; c += 64) atomicAdd(bank + lb * cols + c, (double)x[(long long)row * cols + c]);
+    }
+}
+
+static inline int row_grid(int rows) {
+    int g = cdiv(rows, WPB);
+    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+}  // namespace egk
+
+using namespace egk;
+
+extern "C" {
+
+int egk_pe_add(egk_stream_t stream, const float* x, const int64_t* pos, const float* freq, float* y, int32_t rows,
+               int32_t cols) {
+    EGK_REQUIRE(x && pos && freq && y, "egk_pe_add: null pointer");
+    EGK_REQUIRE((cols & 1) == 0, "egk_pe_add: odd channel count");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_PE_ADD, s, 0, 8.0 * rows * cols);
+    hipLaunchKernelGGL(pe_add_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, (const long long*)pos, freq, y, rows, cols);
+    return check_launch("egk_pe_add");
+}
+
+int egk_csr_gather(egk_stream_t stream, const float* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
+                   const float* relu_gate, float* out, int32_t rows, int32_t cols) {
+    EGK_REQUIRE(x && rowptr && out, "egk_csr_gather: null pointer");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CSR_GATHER, s, 0, (relu_gate ? 12.0 : 8.0) * rows * cols);
+    hipLaunchKernelGGL(csr_gather_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows,
+                       cols);
+    return check_launch("egk_csr_gather");
+}
+
+int egk_gather_max_fwd(egk_stream_t stream, const float* f, const float* bank, const int64_t* nn, float* m, uint8_t* arg,
+                       int32_t rows, int32_t cols, int32_t k) {
+    EGK_REQUIRE(f && bank && nn && m && arg, "egk_gather_max_fwd: null pointer");
+    EGK_REQUIRE(k >= 0 && k < 255, "egk_gather_max_fwd: k out of range");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_GATHER_MAX_FWD, s, 0, (4.0 * (k + 2) + 1.0) * rows * cols);
+    hipLaunchKernelGGL(gather_max_fwd_kernel, dim3(row_grid(rows)), dim3(256), 0, s, f, bank, (const long long*)nn, m, arg,
+                       rows, cols, k);
+    return check_launch("egk_gather_max_fwd");
+}
+
+int egk_gather_max_bwd(egk_stream_t stream, const float* dm, const uint8_t* arg, float* df, int32_t rows, int32_t cols,
+                       int32_t k, int32_t accumulate) {
+    EGK_REQUIRE(dm && arg && df, "egk_gather_max_bwd: null pointer");
+    const long long n = (long long)rows * cols;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_GATHER_MAX_BWD, s, 0, 9.0 * n);
+    const long long blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(gather_max_bwd_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
+                       s, dm, arg, df, n, k, accumulate);
+    return check_launch("egk_gather_max_bwd");
+}
+
+int egk_segment_max_fwd(egk_stream_t stream, const float* x, const int32_t* ptr, float* out, int32_t* arg, int32_t n_seg,
+                        int32_t cols) {
+    EGK_REQUIRE(x && ptr && out && arg, "egk_segment_max_fwd: null pointer");
+    if (n_seg == 0 || cols == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_SEGMAX_FWD, s, 0, 0);
+    hipLaunchKernelGGL(segmax_fwd_kernel, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, x, ptr, out, arg, n_seg, cols);
+    return check_launch("egk_segment_max_fwd");
+}
+
+int egk_segment_max_bwd(egk_stream_t stream, const float* dout, const int32_t* arg, const int32_t* ptr, float* dx,
+                        int32_t n_seg, int32_t rows, int32_t cols) {
+    EGK_REQUIRE(dout && arg && ptr && dx, "egk_segment_max_bwd: null pointer");
+    if (n_seg == 0 || cols == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_SEGMAX_BWD, s, 0, 0);
+    hipLaunchKernelGGL(segmax_bwd_kernel, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, dout, arg, ptr, dx, n_seg, cols);
+    return check_launch("egk_segment_max_bwd");
+}
+
+int egk_row_inv_norm(egk_stream_t stream, const float* x, float* inv_norm, int32_t rows, int32_t cols) {
+    EGK_REQUIRE(x && inv_norm, "egk_row_inv_norm: null pointer");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_ROW_INV_NORM, s, 0, 4.0 * rows * cols);
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, inv_norm, rows, cols);
+    return check_launch("egk_row_inv_norm");
+}
+
+int egk_cos_dist(egk_stream_t stream, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv, float* dist,
+                 int32_t rows, int32_t K) {
+    EGK_REQUIRE(dot && f_inv && b_inv && dist, "egk_cos_dist: null pointer");
+    if (rows == 0 || K == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_TOPK, s, 0, 8.0 * rows * K);
+    hipLaunchKernelGGL(cos_dist_kernel, dim3(cdiv(K, 256), rows), dim3(256), 0, s, dot, (long long)ldd, f_inv, b_inv, dist,
+                       rows, K);
+    return check_launch("egk_cos_dist");
+}
+
+int egk_topk_smallest(egk_stream_t stream, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv,
+                      int64_t* nn, int32_t rows, int32_t K, int32_t k) {
+    EGK_REQUIRE(dot && f_inv && b_inv && nn, "egk_topk_smallest: null pointer");
+    EGK_REQUIRE(k >= 1 && k <= 16 && k <= K, "egk_topk_smallest: k must be in [1, min(16, K)]");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_TOPK, s, 0, 4.0 * rows * K);
+    hipLaunchKernelGGL(topk_kernel, dim3(row_grid(rows)), dim3(256), 0, s, dot, (long long)ldd, f_inv, b_inv, (long long*)nn,
+                       rows, K, k);
+    return check_launch("egk_topk_smallest");
+}
+
+int egk_scatter_add_rows_f64(egk_stream_t stream, const float* x, const int64_t* label, double* bank, int64_t* count,
+                             int32_t rows, int32_t cols, int64_t n_labels) {
+    EGK_REQUIRE(x && label && bank, "egk_scatter_add_rows_f64: null pointer");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_SCATTER_ADD_F64, s, 0, 4.0 * rows * cols + 16.0 * rows * cols);
+    hipLaunchKernelGGL(scatter_add_f64_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, (const long long*)label, bank,
+                       (long long*)count, rows, cols, (long long)n_labels);
+    return check_launch("egk_scatter_add_rows_f64");
+}
+}

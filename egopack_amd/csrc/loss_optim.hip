@@ -1,0 +1,324 @@
+// Loss kernels (cross-entropy with ignore_index / label smoothing, BCE-with-logits), small
+// elementwise helpers (dropout, axpby, scaled sum) and the single-launch Adam step over the flat
+// parameter buffer.  All HBM-bound / latency-bound.
+#include <math.h>
+
+#include "common.h"
+
+namespace egk {
+
+constexpr int WPB = 4;
+
+// ---- cross entropy: one wave per row ------------------------------------------------------------
+// loss = lse - (1-eps)*x_y - eps/C * sum_c x_c     (0 for y == -1)
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long long ld,
+                                                     const long long* __restrict__ y, long long ys, float* __restrict__ loss,
+                                                     float* __restrict__ lse, int rows, int C, float smoothing,
+                                                     int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const float* lr = logits + (long long)row * ld;
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+        mx = wave_max(mx);
+        float se = 0.f, sx = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = lr[c];
+            se += expf(v - mx);
+            sx += v;
+        }
+        se = wave_sum(se);
+        sx = wave_sum(sx);
+        if (lane == 0) {
+            const float l = mx + logf(se);
+            lse[row] = l;
+            const long long t = y[(long long)row * ys];
+            float o = 0.f;
+            if (t >= 0 && t < C) o = l - (1.f - smoothing) * lr[t] - (smoothing > 0.f ? smoothing / C * sx : 0.f);
+            loss[row] = accumulate ? loss[row] + o : o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long long ld,
+                                                     const long long* __restrict__ y, long long ys,
+                                                     const float* __restrict__ lse, const float* __restrict__ gloss,
+                                                     float* __restrict__ dlogits, long long ldd, int rows, int C,
+                                                     float smoothing) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const float* lr = logits + (long long)row * ld;
+        float* dr = dlogits + (long long)row * ldd;
+        const long long t = y[(long long)row * ys];
+        const bool live = t >= 0 && t < C;
+        const float g = live ? gloss[row] : 0.f;
+        const float l = lse[row];
+        const float sm = smoothing > 0.f ? smoothing / C : 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float d = 0.f;
+            if (live) d = g * (expf(lr[c] - l) - (c == t ? 1.f - smoothing : 0.f) - sm);
+            dr[c] = d;
+        }
+    }
+}
+
+// ---- BCE with logits ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const long long* __restrict__ y,
+                                                      float* __restrict__ loss, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i], t = (float)y[i];
+    // torch: (1 - t) * x + max(-x, 0) + log1p(exp(-|x|))
+    loss[i] = (1.f - t) * v + fmaxf(-v, 0.f) + log1pf(expf(-fabsf(v)));
+}
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const long long* __restrict__ y,
+                                                      const float* __restrict__ gloss, float* __restrict__ dx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    dx[i] = (1.f / (1.f + expf(-v)) - (float)y[i]) * gloss[i];
+}
+
+// ---- dropout ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ mask, long long n, float p, uint64_t seed,
+                                                          uint64_t offset, const uint64_t* __restrict__ dev_offset) {
+    if (dev_offset) offset += dev_offset[0];
+    const float inv = 1.f / (1.f - p);
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (long long)gridDim.x * blockDim.x) {
+        const uint4 r = philox4x32_10(offset + (uint64_t)q, seed);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+        for (int t = 0; t < 4; ++t) {
+            const long long i = q * 4 + t;
+            if (i < n) {
+                const bool keep = u01(rr[t]) >= p;
+                mask[i] = keep;
+                y[i] = keep ? x[i] * inv : 0.f;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ dx, long long n, float p) {
+    const float inv = 1.f / (1.f - p);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dx[i] = mask[i] ? dy[i] * inv : 0.f;
+}
+
+__global__ __launch_bounds__(256) void relu_gate_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        float* __restrict__ dx, long long n, int vec) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+         i += (long long)gridDim.x * blockDim.x * 4) {
+        if (vec && i + 4 <= n) {
+            const float4 g = *reinterpret_cast<const float4*>(dy + i);
+            const float4 v = *reinterpret_cast<const float4*>(y + i);
+            *reinterpret_cast<float4*>(dx + i) =
+                make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+        } else
+            for (long long j = i; j < n && j < i + 4; ++j) dx[j] = y[j] > 0.f ? dy[j] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                    float* __restrict__ out, long long n, float a, float b, int vec) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+         i += (long long)gridDim.x * blockDim.x * 4) {
+        if (vec && i + 4 <= n) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + i);
+            float4 o = make_float4(a * xv.x, a * xv.y, a * xv.z, a * xv.w);
+            if (y) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + i);
+                o.x += b * yv.x; o.y += b * yv.y; o.z += b * yv.z; o.w += b * yv.w;
+            }
+            *reinterpret_cast<float4*>(out + i) = o;
+        } else
+            for (long long j = i; j < n && j < i + 4; ++j) out[j] = a * x[j] + (y ? b * y[j] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_scaled_kernel(const float* __restrict__ scalar, float coef,
+                                                          float* __restrict__ out, long long n) {
+    const float v = scalar[0] * coef;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = v;
+}
+
+// single workgroup, fixed-order tree: bitwise reproducible loss scalars
+__global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict__ x, float* __restrict__ out, long long n,
+                                                         float scale, int accumulate) {
+    __shared__ float part[16];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += part[i];
+        t *= scale;
+        out[0] = accumulate ? out[0] + t : t;
+    }
+}
+
+// ---- Adam (torch.optim.Adam single-tensor formulas, L2 weight decay) ----------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, const float* __restrict__ hyper,
+                                                   float b1, float b2, float eps, float wd) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
+    const float step = lr / bc1;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+         i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            float4 pv = *reinterpret_cast<float4*>(p + i);
+            const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            float4 mv = *reinterpret_cast<float4*>(m + i);
+            float4 vv = *reinterpret_cast<float4*>(v + i);
+            float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float gg = gp[t] * gs + wd * pp[t];
+                mp[t] = mp[t] + (gg - mp[t]) * (1.f - b1);   // exp_avg.lerp_(grad, 1 - beta1)
+                vp[t] = vp[t] * b2 + (1.f - b2) * gg * gg;   // mul_(beta2).addcmul_(g, g, 1 - beta2)
+                const float denom = sqrtf(vp[t]) / bc2s + eps;
+                pp[t] = pp[t] - step * (mp[t] / denom);
+            }
+            *reinterpret_cast<float4*>(p + i) = pv;
+            *reinterpret_cast<float4*>(m + i) = mv;
+            *reinterpret_cast<float4*>(v + i) = vv;
+        } else {
+            for (long long j = i; j < n; ++j) {
+                const float gg = g[j] * gs + wd * p[j];
+                m[j] = m[j] + (gg - m[j]) * (1.f - b1);
+                v[j] = v[j] * b2 + (1.f - b2) * gg * gg;
+                p[j] = p[j] - step * (m[j] / (sqrtf(v[j]) / bc2s + eps));
+            }
+        }
+    }
+}
+
+static inline unsigned ew_grid(long long n, int per_thread) {
+    long long b = (n / per_thread + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : b > 4096 ? 4096 : b);
+}
+static inline int row_grid(int rows) {
+    int g = cdiv(rows, WPB);
+    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+}  // namespace egk
+
+using namespace egk;
+
+extern "C" {
+
+int egk_ce_fwd(egk_stream_t stream, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, float* loss,
+               float* lse, int32_t rows, int32_t C, float smoothing, int32_t accumulate) {
+    EGK_REQUIRE(logits && y && loss && lse, "egk_ce_fwd: null pointer");
+    EGK_REQUIRE(C >= 1, "egk_ce_fwd: C must be >= 1");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CE_FWD, s, 0, 4.0 * rows * C);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(row_grid(rows)), dim3(256), 0, s, logits, (long long)ld, (const long long*)y,
+                       (long long)y_stride, loss, lse, rows, C, smoothing, accumulate);
+    return check_launch("egk_ce_fwd");
+}
+
+int egk_ce_bwd(egk_stream_t stream, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, const float* lse,
+               const float* gloss, float* dlogits, int64_t ldd, int32_t rows, int32_t C, float smoothing) {
+    EGK_REQUIRE(logits && y && lse && gloss && dlogits, "egk_ce_bwd: null pointer");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CE_BWD, s, 0, 8.0 * rows * C);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(row_grid(rows)), dim3(256), 0, s, logits, (long long)ld, (const long long*)y,
+                       (long long)y_stride, lse, gloss, dlogits, (long long)ldd, rows, C, smoothing);
+    return check_launch("egk_ce_bwd");
+}
+
+int egk_bce_fwd(egk_stream_t stream, const float* logits, const int64_t* y, float* loss, int32_t n) {
+    EGK_REQUIRE(logits && y && loss, "egk_bce_fwd: null pointer");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_BCE_FWD, s, 0, 16.0 * n);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, (const long long*)y, loss, n);
+    return check_launch("egk_bce_fwd");
+}
+
+int egk_bce_bwd(egk_stream_t stream, const float* logits, const int64_t* y, const float* gloss, float* dlogits, int32_t n) {
+    EGK_REQUIRE(logits && y && gloss && dlogits, "egk_bce_bwd: null pointer");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_BCE_BWD, s, 0, 20.0 * n);
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, (const long long*)y, gloss, dlogits, n);
+    return check_launch("egk_bce_bwd");
+}
+
+int egk_dropout_fwd(egk_stream_t stream, const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                    uint64_t offset, const uint64_t* dev_offset) {
+    EGK_REQUIRE(x && y && mask, "egk_dropout_fwd: null pointer");
+    EGK_REQUIRE(p >= 0.f && p < 1.f, "egk_dropout_fwd: p out of range");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_DROPOUT_FWD, s, 0, 9.0 * n);
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, x, y, mask, (long long)n, p, seed, offset, dev_offset);
+    return check_launch("egk_dropout_fwd");
+}
+
+int egk_dropout_bwd(egk_stream_t stream, const float* dy, const uint8_t* mask, float* dx, int64_t n, float p) {
+    EGK_REQUIRE(dy && mask && dx, "egk_dropout_bwd: null pointer");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_DROPOUT_BWD, s, 0, 9.0 * n);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, dy, mask, dx, (long long)n, p);
+    return check_launch("egk_dropout_bwd");
+}
+
+int egk_relu_gate(egk_stream_t stream, const float* dy, const float* y, float* dx, int64_t n) {
+    EGK_REQUIRE(dy && y && dx, "egk_relu_gate: null pointer");
+    if (n == 0) return 0;
+    const int vec = (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15) == 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_RELU_GATE, s, 0, 12.0 * n);
+    hipLaunchKernelGGL(relu_gate_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, dy, y, dx, (long long)n, vec);
+    return check_launch("egk_relu_gate");
+}
+
+int egk_axpby(egk_stream_t stream, const float* x, const float* y, float* out, int64_t n, float a, float b) {
+    EGK_REQUIRE(x && out, "egk_axpby: null pointer");
+    if (n == 0) return 0;
+    const int vec = ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_AXPBY, s, 0, (y ? 12.0 : 8.0) * n);
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, x, y, out, (long long)n, a, b, vec);
+    return check_launch("egk_axpby");
+}
+
+int egk_fill_scaled(egk_stream_t stream, const float* scalar, float coef, float* out, int64_t n) {
+    EGK_REQUIRE(scalar && out, "egk_fill_scaled: null pointer");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_AXPBY, s, 0, 4.0 * n);
+    hipLaunchKernelGGL(fill_scaled_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, scalar, coef, out, (long long)n);
+    return check_launch("egk_fill_scaled");
+}
+
+int egk_sum_scale(egk_stream_t stream, const float* x, float* out, int64_t n, float scale, int32_t accumulate) {
+    EGK_REQUIRE(x && out, "egk_sum_scale: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_SUM_SCALE, s, 0, 4.0 * n);
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, s, x, out, (long long)n, scale, accumulate);
+    return check_launch("egk_sum_scale");
+}
+
+int egk_adam_step(egk_stream_t stream, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                  float beta1, float beta2, float eps, float weight_decay) {
+    EGK_REQUIRE(p && g && m && v && hyper, "egk_adam_step: null pointer");
+    EGK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                "egk_adam_step: buffers must be 16-byte aligned");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_ADAM, s, 0, 28.0 * n);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, p, g, m, v, (long long)n, hyper, beta1, beta2, eps,
+                       weight_decay);
+    return check_launch("egk_adam_step");
+}
+}

@@ -1,0 +1,590 @@
+// Normalisation kernels: per-row LayerNorm(+ReLU+dropout), graph-mode LayerNorm(+LeakyReLU)
+// with per-segment global statistics, and column sums (bias gradients).
+//
+// Common shape: ONE WAVE PER ROW, 4 waves per workgroup, the row held in registers as NV float4
+// per lane (column of element t of chunk i of lane l = (i*64 + l)*4 + t), so that
+//   * every HBM access is a 1-KiB coalesced wave-instruction (16 B per lane),
+//   * row reductions are wavefront shuffles (no LDS, no barrier),
+//   * column reductions (dw/db) accumulate in registers across the rows a wave walks, because the
+//     lane->column map is the same for every row, and are finished by a small second launch that
+//     sums the per-workgroup partials in a fixed order (bitwise reproducible, no atomics).
+// All of these are HBM-bound: algorithmic bytes are listed per kernel in DESIGN.md.
+#include "common.h"
+
+namespace egk {
+
+constexpr int WPB = 4;  // waves (rows in flight) per workgroup
+
+template <int NV>
+struct Row {
+    float4 v[NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int cols, bool vec, int lane, Row<NV>& r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (vec && c + 4 <= cols) r.v[i] = *reinterpret_cast<const float4*>(p + c);
+        else {
+            r.v[i].x = c + 0 < cols ? p[c + 0] : 0.f;
+            r.v[i].y = c + 1 < cols ? p[c + 1] : 0.f;
+            r.v[i].z = c + 2 < cols ? p[c + 2] : 0.f;
+            r.v[i].w = c + 3 < cols ? p[c + 3] : 0.f;
+        }
+    }
+}
+template <int NV>
+__device__ __forceinline__ void store_row(float* __restrict__ p, int cols, bool vec, int lane, const Row<NV>& r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (vec && c + 4 <= cols) *reinterpret_cast<float4*>(p + c) = r.v[i];
+        else {
+            if (c + 0 < cols) p[c + 0] = r.v[i].x;
+            if (c + 1 < cols) p[c + 1] = r.v[i].y;
+            if (c + 2 < cols) p[c + 2] = r.v[i].z;
+            if (c + 3 < cols) p[c + 3] = r.v[i].w;
+        }
+    }
+}
+__device__ __forceinline__ float& el(float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+__device__ __forceinline__ float el(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+
+// -------------------------------------------------------------------------------------------
+// row LayerNorm (+ReLU, +dropout)
+// -------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void rowln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        uint8_t* __restrict__ mask, int rows, int cols, float eps, int relu,
+                                                        float p, uint64_t seed, uint64_t offset,
+                                                        const uint64_t* __restrict__ dev_offset) {
+    if (dev_offset) offset += dev_offset[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    Row<NV> wv, bv;
+    load_row<NV>(w, cols, vec, lane, wv);
+    load_row<NV>(b, cols, vec, lane, bv);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        Row<NV> r;
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+        const float mu = wave_sum(s) / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = (i * 64 + lane) * 4 + t;
+                const float d = c < cols ? el(r.v[i], t) - mu : 0.f;
+                q += d * d;
+            }
+        const float rs = rsqrtf(wave_sum(q) / cols + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c0 = (i * 64 + lane) * 4;
+            uint4 rnd = make_uint4(0, 0, 0, 0);
+            if (p > 0.f) rnd = philox4x32_10(offset + (uint64_t)row * (NV * 64) + (i * 64 + lane), seed);
+            uint32_t keep4 = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float o = (el(r.v[i], t) - mu) * rs * el(wv.v[i], t) + el(bv.v[i], t);
+                if (relu) o = fmaxf(o, 0.f);
+                if (p > 0.f) {
+                    const uint32_t rr = t == 0 ? rnd.x : t == 1 ? rnd.y : t == 2 ? rnd.z : rnd.w;
+                    const bool keep = u01(rr) >= p;
+                    o = keep ? o * inv_keep : 0.f;
+                    keep4 |= (keep ? 1u : 0u) << (8 * t);
+                }
+                el(r.v[i], t) = o;
+            }
+            if (p > 0.f && c0 < cols) {
+                uint8_t* mp = mask + (long long)row * cols + c0;
+                if (vec) *reinterpret_cast<uint32_t*>(mp) = keep4;
+                else
+                    for (int t = 0; t < 4 && c0 + t < cols; ++t) mp[t] = (keep4 >> (8 * t)) & 1;
+            }
+        }
+        store_row<NV>(y + (long long)row * cols, cols, vec, lane, r);
+    }
+}
+
+// dx for one row + per-wave column partials of dw/db, combined per workgroup through LDS.
+template <int NV>
+__global__ __launch_bounds__(256) void rowln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                                        float* __restrict__ ws, int rows, int cols, int relu, float p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [WPB][2][NV*256]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    Row<NV> wv, bv, dwp, dbp;
+    load_row<NV>(w, cols, vec, lane, wv);
+    load_row<NV>(b, cols, vec, lane, bv);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dwp.v[i] = dbp.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        Row<NV> g, xr;
+        load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c0 = (i * 64 + lane) * 4;
+            uint32_t keep4 = 0x01010101u;
+            if (p > 0.f && c0 < cols) {
+                const uint8_t* mp = mask + (long long)row * cols + c0;
+                if (vec) keep4 = *reinterpret_cast<const uint32_t*>(mp);
+                else {
+                    keep4 = 0;
+                    for (int t = 0; t < 4 && c0 + t < cols; ++t) keep4 |= (uint32_t)mp[t] << (8 * t);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool in = c0 + t < cols;
+                const float xh = in ? (el(xr.v[i], t) - mu) * rs : 0.f;
+                float gg = in ? el(g.v[i], t) : 0.f;
+                if (p > 0.f) gg = ((keep4 >> (8 * t)) & 1) ? gg * inv_keep : 0.f;
+                if (relu && !(xh * el(wv.v[i], t) + el(bv.v[i], t) > 0.f)) gg = 0.f;
+                el(dwp.v[i], t) += gg * xh;
+                el(dbp.v[i], t) += gg;
+                const float dxh = gg * el(wv.v[i], t);
+                s1 += dxh;
+                s2 += dxh * xh;
+                el(g.v[i], t) = dxh;
+                el(xr.v[i], t) = xh;
+            }
+        }
+        s1 = wave_sum(s1) / cols;
+        s2 = wave_sum(s2) / cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) el(g.v[i], t) = rs * (el(g.v[i], t) - s1 - el(xr.v[i], t) * s2);
+        store_row<NV>(dx + (long long)row * cols, cols, vec, lane, g);
+    }
+    // combine the 4 waves' column partials in wave order, write this workgroup's partial row
+    const int stride = NV * 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(red + (wave * 2 + 0) * stride + c) = dwp.v[i];
+        *reinterpret_cast<float4*>(red + (wave * 2 + 1) * stride + c) = dbp.v[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float a = 0.f, d = 0.f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < WPB; ++wv_) {
+            a += red[(wv_ * 2 + 0) * stride + c];
+            d += red[(wv_ * 2 + 1) * stride + c];
+        }
+        ws[((long long)blockIdx.x * 2 + 0) * cols + c] = a;
+        ws[((long long)blockIdx.x * 2 + 1) * cols + c] = d;
+    }
+}
+
+// out_a[c] += sum_b ws[b][0][c]; out_b[c] += sum_b ws[b][1][c]   (fixed order)
+__global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __restrict__ ws, float* __restrict__ oa,
+                                                              float* __restrict__ ob, int nblk, int cols) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f, d = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        a += ws[((long long)k * 2 + 0) * cols + c];
+        d += ws[((long long)k * 2 + 1) * cols + c];
+    }
+    if (oa) oa[c] += a;
+    if (ob) ob[c] += d;
+}
+
+// -------------------------------------------------------------------------------------------
+// graph-mode LayerNorm + LeakyReLU (statistics over all elements of a row segment)
+// -------------------------------------------------------------------------------------------
+constexpr int MAXSEG = 16;
+
+__device__ __forceinline__ int seg_of(const int* __restrict__ seg_ptr, int n_seg, int row) {
+    int s = 0;
+    while (s + 1 < n_seg && row >= seg_ptr[s + 1]) ++s;
+    return s;
+}
+
+// pass 1: per-workgroup per-segment (sum, sumsq) in double -> ws[blk][seg][2]
+template <int NV>
+__global__ __launch_bounds__(256) void graphln_stats_kernel(const float* __restrict__ x, const int* __restrict__ seg_ptr,
+                                                            int n_seg, int rows, int cols, double* __restrict__ ws) {
+    __shared__ double acc[WPB][MAXSEG][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    if (lane < n_seg) acc[wave][lane][0] = acc[wave][lane][1] = 0.0;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        Row<NV> r;
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = el(r.v[i], t);  // out-of-range columns were loaded as 0
+                s += v;
+                q += v * v;
+            }
+        const double ds = wave_sum((double)s), dq = wave_sum((double)q);
+        if (lane == 0) {
+            const int sg = seg_of(seg_ptr, n_seg, row);
+            acc[wave][sg][0] += ds;
+            acc[wave][sg][1] += dq;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_seg * 2) {
+        const int sg = threadIdx.x >> 1, k = threadIdx.x & 1;
+        double t = 0.0;
+        for (int wv_ = 0; wv_ < WPB; ++wv_) t += acc[wv_][sg][k];
+        ws[((long long)blockIdx.x * n_seg + sg) * 2 + k] = t;
+    }
+}
+
+// every workgroup re-derives (mean, 1/(std+eps)) of every segment from the partials (fixed order)
+__device__ __forceinline__ void graphln_finish_stats(const double* __restrict__ ws, int nblk, const int* __restrict__ seg_ptr,
+                                                     int n_seg, int cols, float eps, float (*st)[2]) {
+    if (threadIdx.x < n_seg) {
+        const int sg = threadIdx.x;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nblk; ++k) {
+            s += ws[((long long)k * n_seg + sg) * 2 + 0];
+            q += ws[((long long)k * n_seg + sg) * 2 + 1];
+        }
+        const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
+        const double mu = n > 0 ? s / n : 0.0;
+        double var = n > 0 ? q / n - mu * mu : 0.0;
+        if (var < 0) var = 0;
+        st[sg][0] = (float)mu;
+        st[sg][1] = (float)(1.0 / (sqrt(var) + (double)eps));
+    }
+    __syncthreads();
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void graphln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y,
+                                                          float* __restrict__ stats, const int* __restrict__ seg_ptr,
+                                                          int n_seg, int rows, int cols, float eps, float slope,
+                                                          const double* __restrict__ ws, int nblk_stats) {
+    __shared__ float st[MAXSEG][2];
+    graphln_finish_stats(ws, nblk_stats, seg_ptr, n_seg, cols, eps, st);
+    if (blockIdx.x == 0 && threadIdx.x < n_seg * 2) stats[threadIdx.x] = st[threadIdx.x >> 1][threadIdx.x & 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    Row<NV> wv, bv;
+    load_row<NV>(w, cols, vec, lane, wv);
+    load_row<NV>(b, cols, vec, lane, bv);
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const int sg = seg_of(seg_ptr, n_seg, row);
+        const float mu = st[sg][0], ri = st[sg][1];
+        Row<NV> r;
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float o = (el(r.v[i], t) - mu) * ri * el(wv.v[i], t) + el(bv.v[i], t);
+                el(r.v[i], t) = o > 0.f ? o : o * slope;
+            }
+        store_row<NV>(y + (long long)row * cols, cols, vec, lane, r);
+    }
+}
+
+// bwd pass 1: per-segment S1 = sum(dxhat), S2 = sum(dxhat*xhat) (double) + column partials of dw/db
+template <int NV>
+__global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                const float* __restrict__ stats,
+                                                                const int* __restrict__ seg_ptr, int n_seg, int rows,
+                                                                int cols, float slope, double* __restrict__ ws_seg,
+                                                                float* __restrict__ ws_col) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [WPB][2][NV*256]
+    __shared__ double acc[WPB][MAXSEG][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    if (lane < n_seg) acc[wave][lane][0] = acc[wave][lane][1] = 0.0;
+    Row<NV> wv, bv, dwp, dbp;
+    load_row<NV>(w, cols, vec, lane, wv);
+    load_row<NV>(b, cols, vec, lane, bv);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dwp.v[i] = dbp.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const int sg = seg_of(seg_ptr, n_seg, row);
+        const float mu = stats[sg * 2 + 0], ri = stats[sg * 2 + 1];
+        Row<NV> g, xr;
+        load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool in = (i * 64 + lane) * 4 + t < cols;
+                const float xh = in ? (el(xr.v[i], t) - mu) * ri : 0.f;
+                const float pre = xh * el(wv.v[i], t) + el(bv.v[i], t);
+                const float gg = in ? el(g.v[i], t) * (pre > 0.f ? 1.f : slope) : 0.f;
+                el(dwp.v[i], t) += gg * xh;
+                el(dbp.v[i], t) += gg;
+                const float dxh = gg * el(wv.v[i], t);
+                s1 += dxh;
+                s2 += dxh * xh;
+            }
+        const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+        if (lane == 0) {
+            acc[wave][sg][0] += d1;
+            acc[wave][sg][1] += d2;
+        }
+    }
+    const int stride = NV * 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(red + (wave * 2 + 0) * stride + c) = dwp.v[i];
+        *reinterpret_cast<float4*>(red + (wave * 2 + 1) * stride + c) = dbp.v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < n_seg * 2) {
+        const int sg = threadIdx.x >> 1, k = threadIdx.x & 1;
+        double t = 0.0;
+        for (int wv_ = 0; wv_ < WPB; ++wv_) t += acc[wv_][sg][k];
+        ws_seg[((long long)blockIdx.x * n_seg + sg) * 2 + k] = t;
+    }
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float a = 0.f, d = 0.f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < WPB; ++wv_) {
+            a += red[(wv_ * 2 + 0) * stride + c];
+            d += red[(wv_ * 2 + 1) * stride + c];
+        }
+        ws_col[((long long)blockIdx.x * 2 + 0) * cols + c] = a;
+        ws_col[((long long)blockIdx.x * 2 + 1) * cols + c] = d;
+    }
+}
+
+// bwd pass 2: dx = r*dxhat - r*S1/n - xhat*S2/(n*sigma),  sigma = 1/r - eps
+template <int NV>
+__global__ __launch_bounds__(256) void graphln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ stats, float* __restrict__ dx,
+                                                          const int* __restrict__ seg_ptr, int n_seg, int rows, int cols,
+                                                          float eps, float slope, const double* __restrict__ ws_seg,
+                                                          int nblk_stats) {
+    __shared__ float sc[MAXSEG][4];  // mean, r, r*S1/n, S2/(n*sigma)
+    if (threadIdx.x < n_seg) {
+        const int sg = threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nblk_stats; ++k) {
+            s1 += ws_seg[((long long)k * n_seg + sg) * 2 + 0];
+            s2 += ws_seg[((long long)k * n_seg + sg) * 2 + 1];
+        }
+        const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
+        const double r = stats[sg * 2 + 1];
+        const double sigma = 1.0 / r - (double)eps;
+        sc[sg][0] = stats[sg * 2 + 0];
+        sc[sg][1] = (float)r;
+        sc[sg][2] = n > 0 ? (float)(r * s1 / n) : 0.f;
+        sc[sg][3] = (n > 0 && sigma > 0) ? (float)(s2 / (n * sigma)) : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    Row<NV> wv, bv;
+    load_row<NV>(w, cols, vec, lane, wv);
+    load_row<NV>(b, cols, vec, lane, bv);
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const int sg = seg_of(seg_ptr, n_seg, row);
+        const float mu = sc[sg][0], ri = sc[sg][1], c1 = sc[sg][2], c2 = sc[sg][3];
+        Row<NV> g, xr;
+        load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float xh = (el(xr.v[i], t) - mu) * ri;
+                const float pre = xh * el(wv.v[i], t) + el(bv.v[i], t);
+                const float dxh = el(g.v[i], t) * (pre > 0.f ? 1.f : slope) * el(wv.v[i], t);
+                el(g.v[i], t) = ri * dxh - c1 - xh * c2;
+            }
+        store_row<NV>(dx + (long long)row * cols, cols, vec, lane, g);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// column sum: stage 1 partials over row chunks, stage 2 fixed-order sum
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long ldx, int M, int N,
+                                                             float* __restrict__ ws, int rows_per) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        s0 += x[(long long)(r + 0) * ldx + c];
+        s1 += x[(long long)(r + 1) * ldx + c];
+        s2 += x[(long long)(r + 2) * ldx + c];
+        s3 += x[(long long)(r + 3) * ldx + c];
+    }
+    for (; r < r1; ++r) s0 += x[(long long)r * ldx + c];
+    ws[(long long)blockIdx.y * N + c] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int N,
+                                                           int nchunk, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += ws[(long long)k * N + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
+static inline int row_grid(int rows) {
+    int g = cdiv(rows, WPB);
+    return g < 1 ? 1 : (g > 512 ? 512 : g);
+}
+
+}  // namespace egk
+
+using namespace egk;
+
+#define DISPATCH_NV(cols, CALL)                                         \
+    switch (nv_for(cols)) {                                             \
+        case 1: { constexpr int NV = 1; CALL; } break;                  \
+        case 4: { constexpr int NV = 4; CALL; } break;                  \
+        case 16: { constexpr int NV = 16; CALL; } break;                \
+        default: set_error("row width %d > 4096 unsupported", cols); return EGK_EUNSUPPORTED; \
+    }
+
+extern "C" {
+
+int egk_colsum_ws_len(int32_t M, int32_t N) {
+    int chunks = cdiv(M, 64);
+    if (chunks > 128) chunks = 128;
+    if (chunks < 1) chunks = 1;
+    return chunks * N;
+}
+
+int egk_colsum(egk_stream_t stream, const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+               float* ws) {
+    EGK_REQUIRE(x && out && ws, "egk_colsum: null pointer");
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = cdiv(M, 64);
+    if (chunks > 128) chunks = 128;
+    if (chunks < 1) chunks = 1;
+    const int rows_per = cdiv(M, chunks);
+    ProfScope prof(KID_COLSUM, s, 0, 4.0 * M * N);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 256), chunks), dim3(256), 0, s, x, (long long)ldx, M, N, ws,
+                       rows_per);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, out, N, chunks, accumulate);
+    return check_launch("egk_colsum");
+}
+
+int egk_rowln_fwd(egk_stream_t stream, const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                  uint8_t* mask, int32_t rows, int32_t cols, float eps, int32_t relu, float p, uint64_t seed,
+                  uint64_t offset, const uint64_t* dev_offset) {
+    EGK_REQUIRE(x && w && b && y && mean && rstd, "egk_rowln_fwd: null pointer");
+    EGK_REQUIRE(p == 0.f || mask, "egk_rowln_fwd: dropout needs a mask buffer");
+    EGK_REQUIRE(p >= 0.f && p < 1.f, "egk_rowln_fwd: p out of range");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_ROWLN_FWD, s, 0, 8.0 * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
+    DISPATCH_NV(cols, hipLaunchKernelGGL(rowln_fwd_kernel<NV>, dim3(row_grid(rows)), dim3(256), 0, s, x, w, b, y, mean, rstd,
+                                         mask, rows, cols, eps, relu, p, seed, offset, dev_offset));
+    return check_launch("egk_rowln_fwd");
+}
+
+int egk_rowln_bwd_ws_rows(int32_t rows) { return row_grid(rows); }
+
+int egk_rowln_bwd(egk_stream_t stream, const float* dy, const float* x, const float* w, const float* b, const float* mean,
+                  const float* rstd, const uint8_t* mask, float* dx, float* dw, float* db, float* ws, int32_t rows,
+                  int32_t cols, int32_t relu, float p) {
+    EGK_REQUIRE(dy && x && w && b && mean && rstd && dx && ws, "egk_rowln_bwd: null pointer");
+    EGK_REQUIRE(p == 0.f || mask, "egk_rowln_bwd: dropout needs the mask");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    {
+        ProfScope prof(KID_ROWLN_BWD, s, 0, 12.0 * rows * cols);
+        DISPATCH_NV(cols, hipLaunchKernelGGL(rowln_bwd_kernel<NV>, dim3(grid), dim3(256), WPB * 2 * NV * 256 * sizeof(float), s,
+                                             dy, x, w, b, mean, rstd, mask, dx, ws, rows, cols, relu, p));
+    }
+    {
+        ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws, dw, db, grid, cols);
+    }
+    return check_launch("egk_rowln_bwd");
+}
+
+int64_t egk_graphln_ws_bytes(int32_t rows, int32_t cols, int32_t n_seg) {
+    const int64_t g = row_grid(rows);
+    return g * n_seg * 2 * 8 + g * 2 * (int64_t)cols * 4;
+}
+
+int egk_graphln_fwd(egk_stream_t stream, const float* x, const float* w, const float* b, float* y, float* stats,
+                    const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope, void* ws) {
+    EGK_REQUIRE(x && w && b && y && stats && seg_ptr && ws, "egk_graphln_fwd: null pointer");
+    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG, "egk_graphln_fwd: n_seg must be in [1,%d]", MAXSEG);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    {
+        ProfScope prof(KID_GRAPHLN_STATS, s, 0, 4.0 * rows * cols);
+        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_stats_kernel<NV>, dim3(grid), dim3(256), 0, s, x, seg_ptr, n_seg, rows,
+                                             cols, (double*)ws));
+    }
+    {
+        ProfScope prof(KID_GRAPHLN_FWD, s, 0, 8.0 * rows * cols);
+        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, s, x, w, b, y, stats, seg_ptr,
+                                             n_seg, rows, cols, eps, slope, (const double*)ws, grid));
+    }
+    return check_launch("egk_graphln_fwd");
+}
+
+int egk_graphln_bwd(egk_stream_t stream, const float* dy, const float* x, const float* w, const float* b,
+                    const float* stats, float* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
+                    int32_t rows, int32_t cols, float eps, float slope, void* ws) {
+    EGK_REQUIRE(dy && x && w && b && stats && dx && seg_ptr && ws, "egk_graphln_bwd: null pointer");
+    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG, "egk_graphln_bwd: n_seg must be in [1,%d]", MAXSEG);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    double* ws_seg = (double*)ws;
+    float* ws_col = (float*)((char*)ws + (int64_t)grid * n_seg * 2 * 8);
+    {
+        ProfScope prof(KID_GRAPHLN_BWD_STATS, s, 0, 8.0 * rows * cols);
+        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_bwd_stats_kernel<NV>, dim3(grid), dim3(256),
+                                             WPB * 2 * NV * 256 * sizeof(float), s, dy, x, w, b, stats, seg_ptr, n_seg, rows,
+                                             cols, slope, ws_seg, ws_col));
+    }
+    {
+        ProfScope prof(KID_GRAPHLN_BWD, s, 0, 12.0 * rows * cols);
+        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_bwd_kernel<NV>, dim3(grid), dim3(256), 0, s, dy, x, w, b, stats, dx,
+                                             seg_ptr, n_seg, rows, cols, eps, slope, ws_seg, grid));
+    }
+    if (dw || db) {
+        ProfScope prof(KID_GRAPHLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
+    }
+    return check_launch("egk_graphln_bwd");
+}
+}

@@ -1,0 +1,123 @@
+// Library runtime: error strings and the built-in per-kernel HIP-event profiler.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace egk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static const char* const kNames[KID_COUNT] = {
+    "gemm_bf16_nn", "gemm_bf16_nt", "gemm_bf16_tt", "gemm_bf16_tn",
+    "gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tt", "gemm_f32_tn",
+    "colsum", "rowln_fwd", "rowln_bwd", "rowln_bwd_reduce",
+    "graphln_stats", "graphln_fwd", "graphln_bwd_stats", "graphln_bwd", "graphln_bwd_reduce",
+    "pe_add", "csr_gather", "gather_max_fwd", "gather_max_bwd", "segmax_fwd", "segmax_bwd",
+    "row_inv_norm", "topk", "scatter_add_f64", "ce_fwd", "ce_bwd", "bce_fwd", "bce_bwd",
+    "dropout_fwd", "dropout_bwd", "relu_gate", "axpby", "sum_scale", "adam"};
+
+struct Pending {
+    int kid;
+    hipEvent_t a, b;
+};
+struct Totals {
+    int64_t launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+
+static std::mutex g_mu;
+static bool g_on = false;
+static std::vector<Pending> g_pending;
+static std::vector<hipEvent_t> g_free;
+static Totals g_tot[KID_COUNT];
+static thread_local Pending g_cur;
+
+bool prof_on() { return g_on; }
+
+static hipEvent_t get_event() {
+    if (!g_free.empty()) {
+        hipEvent_t e = g_free.back();
+        g_free.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(int kid, hipStream_t s, double flops, double bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cur.kid = kid;
+    g_cur.a = get_event();
+    g_cur.b = get_event();
+    g_tot[kid].launches += 1;
+    g_tot[kid].flops += flops;
+    g_tot[kid].bytes += bytes;
+    (void)hipEventRecord(g_cur.a, s);
+}
+
+void prof_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_cur.b, s);
+    g_pending.push_back(g_cur);
+}
+
+static void drain() {
+    for (auto& p : g_pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) g_tot[p.kid].ms += ms;
+        g_free.push_back(p.a);
+        g_free.push_back(p.b);
+    }
+    g_pending.clear();
+}
+
+}  // namespace egk
+
+using namespace egk;
+
+extern "C" {
+
+int egk_version(void) { return 100; }
+const char* egk_last_error(void) { return g_err; }
+
+int egk_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return 0;
+}
+int egk_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain();
+    for (auto& t : g_tot) t = Totals();
+    return 0;
+}
+int egk_prof_count(void) { return KID_COUNT; }
+int egk_prof_get(int id, char* name, int name_len, int64_t* launches, double* total_ms, double* alg_flops,
+                 double* alg_bytes) {
+    if (id < 0 || id >= KID_COUNT) return EGK_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain();
+    if (name && name_len > 0) {
+        strncpy(name, kNames[id], name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (launches) *launches = g_tot[id].launches;
+    if (total_ms) *total_ms = g_tot[id].ms;
+    if (alg_flops) *alg_flops = g_tot[id].flops;
+    if (alg_bytes) *alg_bytes = g_tot[id].bytes;
+    return 0;
+}
+}

@@ -1,0 +1,321 @@
+"""Host-side data plumbing of the hot path: sample / batch containers, temporal edge builders,
+CSR construction, collation, the multi-task loader and synthetic Omnivore-shaped datasets.
+
+Everything here is integer / index work on the host (the reference does it in PyG dataloader
+workers): results are bit-exact with the reference semantics.
+No torch_geometric dependency.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+
+
+# --------------------------------------------------------------------------------------------
+# containers
+# --------------------------------------------------------------------------------------------
+class Data:
+    """Attribute bag with the fields the reference reads from a PyG ``Data``/``Batch``:
+    x [N,S,F], pos [N], y, edge_index [2,E], batch [N], ptr [B+1], num_graphs, plus the cached
+    ``graph`` (CSRGraph) the HIP aggregation kernels consume."""
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def __contains__(self, key):
+        return getattr(self, key, None) is not None
+
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None]
+
+    def to(self, device, non_blocking: bool = False):
+        out = Data()
+        for k, v in self.__dict__.items():
+            if torch.is_tensor(v) or isinstance(v, CSRGraph):
+                v = v.to(device, non_blocking=non_blocking)
+            elif isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
+                v = [t.to(device, non_blocking=non_blocking) for t in v]
+            setattr(out, k, v)
+        return out
+
+    def pin_memory(self):
+        for k, v in self.__dict__.items():
+            if torch.is_tensor(v) or isinstance(v, CSRGraph):
+                setattr(self, k, v.pin_memory())
+        return self
+
+
+@dataclass
+class CSRGraph:
+    """Both orientations of an edge list as int32 CSR.
+
+    rowptr/col : in-edges grouped by TARGET (col = source)      -> forward mean aggregation
+    t_rowptr/t_col/t_wgt : out-edges grouped by SOURCE (t_col = target, t_wgt = 1/in_degree(target))
+                                                               -> its backward, also a gather
+    Inside a row, entries keep the edge_index order (stable sort), i.e. the order in which the
+    reference's scatter would visit them."""
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    t_rowptr: torch.Tensor
+    t_col: torch.Tensor
+    t_wgt: torch.Tensor
+    num_nodes: int
+
+    def to(self, device, non_blocking: bool = False):
+        return CSRGraph(*(t.to(device, non_blocking=non_blocking) for t in
+                          (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)), self.num_nodes)
+
+    def pin_memory(self):
+        return CSRGraph(*(t.pin_memory() for t in (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)),
+                        self.num_nodes)
+
+
+def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
+    """edge_index [2,E] (row 0 = source j, row 1 = target i; flow source->target)."""
+    dev = edge_index.device
+    src, tgt = edge_index[0].long(), edge_index[1].long()
+    deg_in = torch.bincount(tgt, minlength=num_nodes)
+    order = torch.argsort(tgt, stable=True)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(deg_in, 0)
+    col = src[order]
+    deg_out = torch.bincount(src, minlength=num_nodes)
+    t_order = torch.argsort(src, stable=True)
+    t_rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
+    t_rowptr[1:] = torch.cumsum(deg_out, 0)
+    t_col = tgt[t_order]
+    t_wgt = 1.0 / deg_in[t_col].clamp(min=1).to(torch.float32)
+    return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes))
+
+
+# --------------------------------------------------------------------------------------------
+# edge builders (reference a17)
+# --------------------------------------------------------------------------------------------
+def radius_band_edges(pos: torch.Tensor, k: int, max_num_neighbors: int = 32) -> torch.Tensor:
+    """RadiusGraph(r=k+0.5, loop=False) on the 1-D clip positions of ONE sample (reference
+    main_temporal.py:168): all (j -> i), i != j, |pos_i - pos_j| <= k.  Grouped by target, ascending
+    source inside a group, at most ``max_num_neighbors`` per target."""
+    p = pos.reshape(-1).to(torch.int64)
+    n = p.numel()
+    d = (p.view(-1, 1) - p.view(1, -1)).abs()
+    adj = (d.to(torch.float64) <= (k + 0.5)) & ~torch.eye(n, dtype=torch.bool)
+    tgt, src = adj.nonzero(as_tuple=True)
+    if max_num_neighbors is not None and n > max_num_neighbors:
+        deg = torch.bincount(tgt, minlength=n)
+        start = torch.cumsum(deg, 0) - deg
+        keep = (torch.arange(tgt.numel()) - start[tgt]) < max_num_neighbors
+        tgt, src = tgt[keep], src[keep]
+    return torch.stack([src, tgt])
+
+
+def lta_connectivity_edges(pos: torch.Tensor, y: torch.Tensor, r: float) -> torch.Tensor:
+    """LTATemporalConnectivity (reference models/transforms/lta_temp_connectivity.py:30-56): radius
+    band of radius r plus (last floor(r) input clips) -> (forecast clips), coalesced (sorted by
+    source*N+target, duplicates removed).  n_forecast counts ``y[:,0] > 0`` exactly as the reference
+    does (a verb label 0 is not counted)."""
+    n = pos.shape[0]
+    band = radius_band_edges(pos, int(math.floor(r)))
+    n_in = int((y[:, 0] == -1).sum())
+    n_f = int((y[:, 0] > 0).sum())
+    lo = max(math.ceil(n_in - r), 0)
+    src = torch.arange(lo, n_in, dtype=torch.long).repeat_interleave(n_f)
+    tgt = torch.arange(n_in, n_in + n_f, dtype=torch.long).repeat(min(math.floor(r), n_in))
+    ei = torch.cat([torch.stack([src, tgt]), band], dim=-1)
+    key = torch.unique(ei[0] * n + ei[1], sorted=True)
+    return torch.stack([key // n, key % n])
+
+
+class RadiusGraph:
+    """Callable transform with the constructor of torch_geometric.transforms.RadiusGraph."""
+
+    def __init__(self, r: float, loop: bool = False, max_num_neighbors: int = 32, flow: str = "source_to_target"):
+        if loop or flow != "source_to_target":
+            raise ValueError("only loop=False, flow='source_to_target' are on the hot path")
+        self.r, self.max_num_neighbors = r, max_num_neighbors
+
+    def __call__(self, data: Data) -> Data:
+        data.edge_attr = None
+        data.edge_index = radius_band_edges(data.pos, int(math.floor(self.r)), self.max_num_neighbors)
+        return data
+
+
+class LTATemporalConnectivity:
+    """Same constructor / call contract as the reference transform."""
+
+    def __init__(self, r: float, loop: bool = False, max_num_neighbors: int = 32, flow: str = "source_to_target",
+                 num_workers: int = 1):
+        self.r = r
+
+    def __call__(self, data: Data) -> Data:
+        if getattr(data, "batch", None) is not None:
+            raise ValueError("This transform expects no batched graphs.")
+        data.edge_attr = None
+        data.edge_index = lta_connectivity_edges(data.pos, data.y, self.r)
+        return data
+
+
+# --------------------------------------------------------------------------------------------
+# collation (reference a18: PyG Batch.from_data_list)
+# --------------------------------------------------------------------------------------------
+def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
+    xs, ys, poss, eis, batch, ptr = [], [], [], [], [], [0]
+    off = 0
+    for b, s in enumerate(samples):
+        n = s.x.shape[0]
+        xs.append(s.x)
+        poss.append(s.pos)
+        ys.append(s.y if torch.is_tensor(s.y) else torch.tensor([s.y]))
+        eis.append(s.edge_index + off)
+        batch.append(torch.full((n,), b, dtype=torch.long))
+        off += n
+        ptr.append(off)
+    ei = torch.cat(eis, dim=1)
+    out = Data(x=torch.cat(xs), y=torch.cat(ys), pos=torch.cat(poss), edge_index=ei, batch=torch.cat(batch),
+               ptr=torch.tensor(ptr, dtype=torch.long), num_graphs=len(samples))
+    out.graph = build_csr(ei, off) if with_csr else None
+    out.ptr32 = out.ptr.to(torch.int32)
+    return out
+
+
+def merge_batches(batches: Sequence[Data]) -> Data:
+    """Merged view of several task batches for the fused backbone pass (host side, before the move
+    to the device): ``x`` stays a LIST of the per-task feature blocks (no copy of the 1536-d rows),
+    positions / edges are concatenated with node offsets, and ``seg_ptr`` keeps the per-task row
+    segments so that graph-LayerNorm statistics stay per task batch, as in the reference where every
+    task batch is a separate backbone call (main_temporal.py:87-90)."""
+    poss, eis, seg = [], [], [0]
+    off = 0
+    for b in batches:
+        poss.append(b.pos)
+        eis.append(b.edge_index + off)
+        off += b.pos.shape[0]
+        seg.append(off)
+    ei = torch.cat(eis, dim=1)
+    out = Data(x=[b.x for b in batches], pos=torch.cat(poss), edge_index=ei)
+    out.graph = build_csr(ei, off)
+    out.seg_ptr = torch.tensor(seg, dtype=torch.int32)
+    out.num_segments = len(batches)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# loaders
+# --------------------------------------------------------------------------------------------
+class multiloader:
+    """Zip several loaders; restart exhausted ones until every enabled loader has completed once
+    (reference utils/dataloading.py:8-47).  Loaders that are None or have weight <= 0 yield None."""
+
+    def __init__(self, loaders, weights):
+        self.loaders, self.weights = loaders, weights
+        self.iterators = [iter(l) if (l is not None and w > 0) else None for l, w in zip(loaders, weights)]
+        self.completed = [it is None for it in self.iterators]
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        out = []
+        for i in range(len(self.loaders)):
+            if self.iterators[i] is None:
+                out.append(None)
+                continue
+            try:
+                out.append(next(self.iterators[i]))
+            except StopIteration:
+                self.completed[i] = True
+                if all(self.completed):
+                    raise StopIteration
+                self.iterators[i] = iter(self.loaders[i])
+                out.append(next(self.iterators[i]))
+        return tuple(out)
+
+
+class BatchLoader:
+    """Minimal seeded loader: shuffles sample indices with a torch.Generator (re-drawn per epoch),
+    shards them by rank (rank-strided over the common permutation), collates ``batch_size`` samples.
+    Stands in for utils/dataloading.build_dataloader + PyG DataLoader (reference :56-70)."""
+
+    def __init__(self, dataset, batch_size: int, shuffle: bool, drop_last: bool, seed: int = 0, rank: int = 0,
+                 world_size: int = 1, pin_memory: bool = False):
+        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        self.rank, self.world_size, self.pin_memory = rank, world_size, pin_memory
+        self.gen = torch.Generator()
+        self.gen.manual_seed(seed)
+
+    def _indices(self) -> List[int]:
+        n = len(self.dataset)
+        idx = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+        if self.world_size > 1:  # equal share per rank so that every rank runs the same number of steps
+            per = n // self.world_size
+            idx = idx[: per * self.world_size][self.rank:: self.world_size]
+        return idx
+
+    def __len__(self):
+        n = len(self.dataset) // self.world_size if self.world_size > 1 else len(self.dataset)
+        return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
+
+    def __iter__(self):
+        idx = self._indices()
+        for i in range(0, len(idx), self.batch_size):
+            chunk = idx[i: i + self.batch_size]
+            if len(chunk) < self.batch_size and self.drop_last:
+                return
+            b = collate([self.dataset[j] for j in chunk])
+            yield b.pin_memory() if self.pin_memory else b
+
+
+def build_dataloader(dataset, batch_size, shuffle, num_workers, drop_last, seed=0, rank=0, world_size=1):
+    """Signature of the reference's build_dataloader (num_workers accepted, collation is in-process)."""
+    return BatchLoader(dataset, batch_size, shuffle, drop_last, seed, rank, world_size)
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic Omnivore-shaped datasets: no Ego4D data is available or needed
+# --------------------------------------------------------------------------------------------
+class SyntheticTaskDataset:
+    """Deterministic synthetic samples with the shapes / label conventions of the Ego4D datasets:
+    x ~ N(0,1) [T, S, F]; AR: only the centre node labelled; LTA: first 2 nodes unlabelled inputs;
+    OSCC: one label per sequence; PNR: one positive node per sequence."""
+
+    has_joint_label = False
+    num_labels = 2
+
+    def __init__(self, task: str, length: int, T: int, num_segments: int = 3, features_size: int = 1536,
+                 num_class_labels=(115, 478), k: int = 1, seed: int = 1, transform=None):
+        self.task, self.length, self.T, self.S, self.features_size = task, length, T, num_segments, features_size
+        self.num_class_labels, self.seed = tuple(num_class_labels), seed
+        if transform is None:
+            transform = LTATemporalConnectivity(r=k + 0.5) if task == "lta" else RadiusGraph(r=k + 0.5)
+        self.transform = transform
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i: int) -> Data:
+        g = torch.Generator()
+        g.manual_seed(self.seed * 1000003 + i)
+        T, V, Nn = self.T, *self.num_class_labels
+        x = torch.randn(T, self.S, self.features_size, generator=g)
+        if self.task == "ar":
+            pos = torch.arange(T) - T // 2
+            y = torch.full((T, 2), -1, dtype=torch.long)
+            y[T // 2, 0] = torch.randint(0, V, (1,), generator=g)
+            y[T // 2, 1] = torch.randint(0, Nn, (1,), generator=g)
+        elif self.task == "lta":
+            pos = torch.arange(T)
+            y = torch.stack([torch.randint(0, V, (T,), generator=g), torch.randint(0, Nn, (T,), generator=g)], 1)
+            y[:2] = -1
+        elif self.task == "oscc":
+            pos = torch.arange(T)
+            y = int(torch.randint(0, 2, (1,), generator=g))
+        elif self.task == "pnr":
+            pos = torch.arange(T)
+            y = torch.zeros(T, dtype=torch.long)
+            y[int(torch.randint(0, T, (1,), generator=g))] = 1
+        else:
+            raise ValueError(self.task)
+        return self.transform(Data(x=x, pos=pos, y=y, batch=None))

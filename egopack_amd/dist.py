@@ -1,0 +1,79 @@
+"""Data parallelism: one process per GPU, gradients exchanged with RCCL (torch.distributed backend
+"nccl" on ROCm) over xGMI.
+
+The reference is single-process; this is new.  The batch is sharded by rank
+(data.BatchLoader), banks and parameters are replicated, and the only data-path collective is the
+gradient all-reduce.  Gradients live in ONE flat fp32 buffer (optim.FlatAdam), so the exchange is a
+few large all-reduces of contiguous slices launched on a side stream; the 1/world_size average is
+folded into the Adam kernel's grad_scale.  Chunks are issued in REVERSE buffer order: the flat
+buffer is laid out backbone-first, heads-last, and backward produces head gradients first."""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """(rank, local_rank, world_size) from the torchrun environment; initialises the process group
+    when WORLD_SIZE > 1.  backend defaults to 'nccl' (= RCCL) on GPU, 'gloo' on CPU."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def chunk_bounds(n: int, chunk_elems: int) -> List[tuple]:
+    """[(begin, end)] covering [0, n) in chunks of ``chunk_elems`` (last one shorter), reverse order."""
+    out = [(b, min(n, b + chunk_elems)) for b in range(0, n, chunk_elems)]
+    return out[::-1]
+
+
+class GradSync:
+    """All-reduce(sum) of a flat gradient buffer in large chunks.
+
+    On GPU the collectives are enqueued on a side stream that waits for the event recorded after
+    backward, so the first chunks overlap whatever the compute stream does next, and the optimiser
+    waits for ``done`` before it reads the buffer."""
+
+    def __init__(self, world_size: int, chunk_mb: float = 32.0, group=None):
+        self.world, self.group = world_size, group
+        self.chunk_elems = max(1, int(chunk_mb * (1 << 20) / 4))
+        self._side = None
+
+    def broadcast_(self, flat: torch.Tensor, src: int = 0):
+        if self.world > 1:
+            dist.broadcast(flat, src=src, group=self.group)
+
+    def all_reduce_(self, flat_g: torch.Tensor):
+        """In place sum over ranks; returns when the work is ENQUEUED (GPU) or done (CPU/gloo)."""
+        if self.world <= 1:
+            return
+        bounds = chunk_bounds(flat_g.numel(), self.chunk_elems)
+        if flat_g.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=flat_g.device)
+            main = torch.cuda.current_stream(flat_g.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                for b, e in bounds:
+                    dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+            main.wait_stream(self._side)
+        else:
+            for b, e in bounds:
+                dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+
+
+def sync_parameters(optimizer, sync: GradSync):
+    """Make every rank start from rank 0's parameters (after FlatAdam has materialised)."""
+    sync.broadcast_(optimizer.flat_p)

@@ -1,0 +1,190 @@
+"""Training steps of the hot path (reference main_temporal.train :49-134, main_egopack.train
+:64-159 and train_step_task :45-61) re-designed for MI355X:
+
+  * the backbone runs ONCE per step over the node sets of all enabled task batches (fused pass,
+    per-task graph-LayerNorm statistics), then each task's head / loss runs on its row slice;
+  * the objective ``sum_t weight_t * loss_t.mean()`` is one deterministic reduction chain;
+  * gradients accumulate inside the backward kernels into the optimiser's flat buffer, are
+    exchanged by dist.GradSync (RCCL) when world_size > 1, and Adam is one launch;
+  * ``capture()`` records forward + backward (+ Adam when single-GPU) of a fixed-shape step into a
+    hipGraph (torch.cuda.CUDAGraph) so a replayed step costs one graph launch instead of ~300
+    kernel launches from Python.
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping, Optional, Sequence
+
+import torch
+
+from . import ops
+from .data import Data, merge_batches
+from .dist import GradSync
+
+TASK_ORDER = ("ar", "lta", "oscc", "pnr")  # order of the loss terms in main_temporal.train
+
+
+class MTLStep:
+    """One multi-task pre-training step (BASELINE configs 2, 3, 5)."""
+
+    def __init__(self, model, tasks: Mapping[str, torch.nn.Module], criteria: Mapping[str, torch.nn.Module],
+                 weights: Mapping[str, float], optimizer, fused_backbone: bool = True, sync: Optional[GradSync] = None):
+        self.model, self.tasks, self.criteria = model, dict(tasks), dict(criteria)
+        self.weights = {t: float(w) for t, w in weights.items()}
+        self.optimizer, self.fused, self.sync = optimizer, fused_backbone, sync
+        self.enabled = [t for t in TASK_ORDER if self.weights.get(t, 0) > 0 and t in self.tasks]
+        self._graph = None
+        self._static_out = None
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:
+        live = [t for t in self.enabled if batches.get(t) is not None]
+        if self.fused and len(live) > 1:
+            if merged is None:
+                merged = merge_batches([batches[t] for t in live])
+                dev = batches[live[0]].pos.device
+                merged = merged.to(dev)
+            feat = self.model(merged)
+            seg = [0]
+            for t in live:
+                seg.append(seg[-1] + batches[t].pos.shape[0])
+            return {t: feat[seg[i]:seg[i + 1]] for i, t in enumerate(live)}
+        return {t: self.model(batches[t]) for t in live}
+
+    def losses(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
+        feats = self.features(batches, merged)
+        vectors, logits_out = {}, {}
+        for t, feat in feats.items():
+            task, d = self.tasks[t], batches[t]
+            f = task.forward_features(feat)
+            if t == "oscc":
+                logits = task.forward_logits(f, d)
+                loss = self.criteria[t](logits, d.y)
+            elif t == "pnr":
+                logits = task.forward_logits(f)
+                loss = self.criteria[t](logits, d.y)
+            else:
+                logits = task.forward_logits(f)
+                loss = self.criteria[t](logits, d.y)
+            vectors[t], logits_out[t] = loss, logits
+        order = [t for t in self.enabled if t in vectors]
+        total = ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
+        return total, vectors, logits_out
+
+    # ---- eager step -------------------------------------------------------------------------------------
+    def forward_backward(self, batches, merged=None):
+        self.optimizer.zero_grad()
+        total, vectors, _ = self.losses(batches, merged)
+        total.backward()
+        return total, vectors
+
+    def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
+        total, vectors = self.forward_backward(batches, merged)
+        self._exchange_and_update()
+        return total.detach(), {t: v.detach() for t, v in vectors.items()}
+
+    def _exchange_and_update(self):
+        opt = self.optimizer
+        if hasattr(opt, "materialised") and not opt.materialised:
+            opt._materialise()
+        if self.sync is not None and self.sync.world > 1:
+            self.sync.all_reduce_(opt.flat_g)
+            opt.grad_scale = 1.0 / self.sync.world
+        opt.step()
+
+    # ---- hipGraph capture ---------------------------------------------------------------------------------
+    def capture(self, batches: Mapping[str, Data], merged: Optional[Data] = None, warmup: int = 2):
+        """Capture forward+backward(+Adam if no gradient exchange) for THESE device tensors (static
+        shapes and addresses: refill them in place between replays)."""
+        opt = self.optimizer
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):  # also materialises the flat buffers
+                self.step(batches, merged)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        fuse_adam = self.sync is None or self.sync.world <= 1
+        g = torch.cuda.CUDAGraph()
+        opt.prepare_hyper()
+        with torch.cuda.graph(g):
+            opt.flat_g.zero_()
+            total, vectors, _ = self.losses(batches, merged)
+            total.backward()
+            if fuse_adam:
+                opt.launch()
+        self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
+        return g
+
+    def replay(self):
+        """One training step from the captured graph."""
+        opt = self.optimizer
+        ops.advance_rng_device(opt.flat_p.device)
+        if self._fuse_adam:
+            opt.prepare_hyper()
+            self._graph.replay()
+            opt.step_count += 1
+        else:
+            self._graph.replay()
+            self.sync.all_reduce_(opt.flat_g)
+            opt.grad_scale = 1.0 / self.sync.world
+            opt.step()
+        return self._static_out[0]
+
+
+class EgoPackStep:
+    """One novel-task step of main_egopack.train with late fusion (BASELINE configs 4, 5): backbone
+    (train/eval mode and grad mode as configured) -> primary projection; aux projections DETACHED ->
+    GraphONE.interact -> fused logits -> primary.compute_loss."""
+
+    def __init__(self, model, tasks: Mapping[str, torch.nn.Module], graphone, weights: Mapping[str, float], optimizer,
+                 backprop_temporal_graph: bool = True, temporal_graph_train_mode: bool = False,
+                 sync: Optional[GradSync] = None):
+        self.model, self.tasks, self.graphone = model, dict(tasks), graphone
+        self.weights = {t: float(w) for t, w in weights.items()}
+        self.optimizer, self.sync = optimizer, sync
+        self.backprop, self.train_mode = backprop_temporal_graph, temporal_graph_train_mode
+        self.enabled = [t for t in ("ar", "oscc", "lta", "pnr") if self.weights.get(t, 0) > 0]  # egopack order
+
+    def task_loss(self, primary: str, feat, data):
+        task = self.tasks[primary]
+        others = [t for t in ("ar", "lta", "oscc", "pnr") if t != primary and t in self.graphone.task_labels]
+        # reference orders: ar:[lta,oscc,pnr] oscc:[ar,lta,pnr] lta:[ar,oscc,pnr] pnr:[ar,oscc,lta]
+        order = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
+                 "pnr": ("ar", "oscc", "lta")}[primary]
+        others = [t for t in order if t in others]
+        f_primary = task.forward_features(feat)
+        with torch.no_grad():
+            aux_in = {t: self.tasks[t].forward_features(feat) for t in others}
+        aux, closest = self.graphone.interact(aux_in)
+        if primary == "oscc":
+            logits = task.forward_logits(features=f_primary, batch=data, aux_features=aux)
+        else:
+            logits = task.forward_logits(features=f_primary, batch=getattr(data, "batch", None), aux_features=aux)
+        return task.compute_loss(logits, data.y), logits, aux, closest
+
+    def losses(self, batches: Mapping[str, Data]):
+        self.model.train(self.train_mode)
+        for t in self.tasks.values():
+            t.train(True)
+        self.graphone.train()
+        vectors = {}
+        with torch.set_grad_enabled(self.backprop):
+            feats = {t: self.model(batches[t]) for t in self.enabled if batches.get(t) is not None}
+        for t, feat in feats.items():
+            vectors[t], _, _, _ = self.task_loss(t, feat, batches[t])
+        order = [t for t in self.enabled if t in vectors]
+        total = ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
+        return total, vectors
+
+    def step(self, batches: Mapping[str, Data]):
+        self.optimizer.zero_grad()
+        total, vectors = self.losses(batches)
+        total.backward()
+        opt = self.optimizer
+        if hasattr(opt, "materialised") and not opt.materialised:
+            opt._materialise()
+        if self.sync is not None and self.sync.world > 1:
+            self.sync.all_reduce_(opt.flat_g)
+            opt.grad_scale = 1.0 / self.sync.world
+        opt.step()
+        return total.detach(), {t: v.detach() for t, v in vectors.items()}

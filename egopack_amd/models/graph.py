@@ -1,0 +1,91 @@
+"""Temporal backbone ``Graph``: TRN pooling -> depth x (SAGEConv-mean -> graph LayerNorm ->
+LeakyReLU) -> Linear, with a residual.
+
+Mirror of reference models/graph.py:15-65: same constructor, ``forward(data)`` reading
+``x, pos, edge_index, batch``, ``configure_optimizers``, and PyG's ``net.module_<i>`` state-dict
+keys.  MI355X-first differences (results identical up to fp summation order):
+  * SAGE ``lin_l(agg) + lin_r(x)`` is one two-source MFMA contraction; bias / ReLU / residual live
+    in contraction epilogues; LayerNorm+LeakyReLU and the neighbour mean are single launches;
+  * ``forward`` accepts a MERGED batch (egopack_amd.data.merge_batches) holding the node sets of
+    several task batches: GEMMs then run at M = sum of nodes while the graph-LayerNorm statistics
+    stay per task batch (``data.seg_ptr``), which is exactly what the reference computes with one
+    backbone call per task batch (main_temporal.py:87-90).
+"""
+from __future__ import annotations
+
+import logging
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..data import build_csr
+from .layers import Dropout, GraphLayerNorm, Linear, PositionalEncoding, SAGEConv
+
+logger = logging.getLogger(__name__)
+
+
+def _instantiate(cfg, *args, **kwargs):
+    try:  # the real hydra when the caller's environment has it
+        from hydra.utils import instantiate
+    except ImportError:
+        from ..config import instantiate
+    return instantiate(cfg, *args, **kwargs)
+
+
+class Graph(torch.nn.Module):
+    def __init__(self, input_size: int, hidden_size: int = 1024, depth: int = 3, pre_dropout: float = 0,
+                 temporal_pooling=None, num_segments: int = 8, *args, **kwargs):
+        super().__init__()
+        self.num_segments, self.hidden_size, self.depth = num_segments, hidden_size, depth
+        self.pre_dropout = Dropout(pre_dropout)
+        self.temporal_pooling = (_instantiate(temporal_pooling, input_size, hidden_size, num_segments)
+                                 if temporal_pooling else None)
+        self.positional_encoding = PositionalEncoding(hidden_size)
+        if depth > 0:
+            self.net = nn.Module()  # children named as PyG's gnn.Sequential names them
+            for d in range(depth):
+                setattr(self.net, f"module_{3 * d}", SAGEConv(hidden_size, hidden_size, project=True))
+                setattr(self.net, f"module_{3 * d + 1}", GraphLayerNorm(hidden_size))
+                setattr(self.net, f"module_{3 * d + 2}", nn.LeakyReLU(negative_slope=0.2))
+            setattr(self.net, f"module_{3 * depth}", Linear(hidden_size, hidden_size))
+
+    def configure_optimizers(self, _):
+        return self.parameters()
+
+    @staticmethod
+    def _graph_of(data):
+        g = getattr(data, "graph", None)
+        if g is None:  # plain PyG-style batch: derive both CSR orientations from edge_index
+            g = build_csr(data.edge_index, data.pos.shape[0])
+            if g.rowptr.device != data.pos.device:
+                g = g.to(data.pos.device)
+            try:
+                data.graph = g
+            except Exception:
+                pass
+        return g
+
+    def forward(self, data, *args, **kwargs):
+        """``data``: one batch (reference contract) or an egopack_amd.data merged batch whose ``x`` is a
+        list of per-task feature blocks (``merge_meta``): the fused multi-task pass."""
+        x = data.x
+        x = [self.pre_dropout(b) for b in x] if isinstance(x, (list, tuple)) else self.pre_dropout(x)
+        if self.temporal_pooling is not None:
+            x = self.temporal_pooling(x, getattr(data, "batch", None), data.pos)
+        if not hasattr(self, "net"):
+            return x
+        graph = self._graph_of(data)
+        seg_ptr = getattr(data, "seg_ptr", None)
+        if seg_ptr is None:
+            seg_ptr = torch.tensor([0, x.shape[0]], dtype=torch.int32, device=x.device)
+        h = self.positional_encoding.add_to(x, data.pos)
+        for d in range(self.depth):
+            conv = getattr(self.net, f"module_{3 * d}")
+            norm = getattr(self.net, f"module_{3 * d + 1}")
+            slope = getattr(self.net, f"module_{3 * d + 2}").negative_slope
+            xp = conv.lin(h, relu=True)                       # relu(lin(x)): ReLU in the epilogue
+            agg = ops.csr_mean_aggregate(xp, graph)           # mean over in-neighbours
+            h = norm(conv.combine(agg, h), seg_ptr, slope)    # [agg|x].[Wl|Wr]^T + b -> graph-LN -> LeakyReLU
+        last = getattr(self.net, f"module_{3 * self.depth}")
+        return last(h, residual=x)                            # x + Linear(h): residual in the epilogue

@@ -1,0 +1,103 @@
+"""Cross-task prototype GNN ``GraphONE``.
+
+Mirror of reference models/graphONE/graphONE.py:13-151: same constructor (extra config keys are
+swallowed), ``embeddings`` / ``conv_stages.<task>.<d>.module_{0,1,3}`` state-dict layout,
+``interact(dict) -> (dict, dict)``.
+
+What the reference computes per aux task and depth d (graphONE.py:94-115):
+    edges  = k nearest prototypes of the ORIGINAL features (cosine), recomputed every depth
+    graph  = cat([bank, f]); SAGEConv(max) over graph with self loops; LayerNorm; ReLU; Linear
+    f      = graph[-N:] (+ f if residual)
+Only the last N rows are kept and the bank is frozen, so the K prototype rows of the stage are
+dead work, and the edges are identical at every depth.  Here, per aux task:
+    nn = cosine_topk(f0, bank)              ONCE  (exact-f32 MFMA similarity + wave top-k)
+    per depth:  m = gather_max(f, bank, nn) (max over the k prototype rows and the self row)
+                h = [m | f].[Wl | Wr]^T -> LayerNorm+ReLU -> Linear (+ f residual in the epilogue)
+which gives the same N output rows.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, List, Literal, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..layers import LayerNorm, Linear, SAGEConv
+
+logger = logging.getLogger(__name__)
+
+
+class GraphONE(nn.Module):
+    def __init__(self, graphone: Dict[str, torch.Tensor], features_size: int = 1024, hidden_size: int = 1024,
+                 freeze: bool = True, k: int = 8, depth: int = 3, distance_func: Literal["l2", "cosine"] = "cosine",
+                 residual: bool = False, mix_strategy: Literal["mean", "max", "transformer"] = "max",
+                 update_edges_interval: int = 1, share_params: bool = False, *args, **kwargs) -> None:
+        super().__init__()
+        self.feature_size = features_size
+        self.k, self.distance_func, self.residual, self.mix_strategy = k, distance_func, residual, mix_strategy
+        self.update_edges_interval, self.share_cnn_params = update_edges_interval, share_params
+        self.depth = depth
+        logger.info("GraphONE: %d tasks, depth=%d, K=%d", len(graphone), depth, k)
+        if not freeze:
+            logger.warning("GraphONE initialized with trainable prototypes.")
+        self.freeze = freeze
+        self.task_labels = sorted(graphone.keys())
+        self.embeddings = nn.ModuleDict({t: nn.Embedding.from_pretrained(graphone[t], freeze=freeze)
+                                         for t in self.task_labels})
+        stages = {}
+        for t in self.task_labels:
+            per_depth = []
+            for _ in range(depth):
+                stage = nn.Module()
+                stage.module_0 = SAGEConv(features_size, hidden_size, aggr="max", project=False, bias=False)
+                stage.module_1 = LayerNorm(hidden_size)
+                stage.module_2 = nn.ReLU()
+                stage.module_3 = Linear(hidden_size, features_size)
+                per_depth.append(stage)
+            stages[t] = nn.ModuleList(per_depth)
+        self.conv_stages = nn.ModuleDict(stages)
+        self._bank_inv_norm: Dict[str, torch.Tensor] = {}
+
+    def _inv_norm(self, task: str) -> torch.Tensor:
+        bank = self.embeddings[task].weight
+        cached = self._bank_inv_norm.get(task)
+        if (cached is None or cached.device != bank.device or cached.shape[0] != bank.shape[0]
+                or not self.freeze or cached._version_of != bank._version):
+            cached = ops.row_inv_norm(bank.detach())
+            cached._version_of = bank._version
+            self._bank_inv_norm[task] = cached
+        return cached
+
+    def interact(self, features: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], Dict[str, List[torch.Tensor]]]:
+        if self.distance_func != "cosine":
+            raise ValueError(f"Unknown distance function: {self.distance_func}" if self.distance_func != "l2"
+                             else "distance_func='l2' is outside the hot path (experiments use cosine)")
+        if not self.freeze:
+            raise NotImplementedError("trainable prototypes are outside the hot path (freeze=True in every experiment)")
+        output, closest = {}, {}
+        for task, f in features.items():
+            output[task], closest[task] = self._task_interaction(task, f)
+        return output, closest
+
+    def _task_interaction(self, task: str, features: torch.Tensor):
+        bank = self.embeddings[task].weight
+        nn_idx = ops.cosine_topk(features.detach(), bank.detach(), self.k, self._inv_norm(task))
+        assignments = [nn_idx[:, 0]] * self.depth  # the reference recomputes identical edges per depth
+        f = features
+        for stage in self.conv_stages[task]:
+            m = ops.gather_max(f, bank, nn_idx)
+            h = stage.module_0.combine(m, f)
+            h = stage.module_1(h, relu=True)
+            f = stage.module_3(h, residual=f if self.residual else None)
+        return f, assignments
+
+
+def cos_dissimilarity(g1: torch.Tensor, g2: torch.Tensor) -> torch.Tensor:
+    """1 - cosine similarity [N, K] (reference graphONE.py:148-151) on the exact-f32 MFMA path."""
+    inv1, inv2 = ops.row_inv_norm(g1), ops.row_inv_norm(g2)
+    dot = torch.empty((g1.shape[0], g2.shape[0]), dtype=torch.float32, device=g1.device)
+    ops.gemm(g1.shape[0], g2.shape[0], g1.contiguous(), g1.shape[1], g2.contiguous(), g2.shape[1], g1.shape[1], dot,
+             g2.shape[0], compute=ops.F32)
+    return ops.scaled_one_minus(dot, inv1, inv2)

@@ -1,0 +1,44 @@
+"""Shared projection head of every task (reference models/tasks/task.py:8-26).
+
+``net`` keeps the reference's Sequential layout (keys net.{1,2,4}; ``net[-1].out_features`` is read
+by the prototype builder) but the forward is 2 MFMA contractions + 1 fused LayerNorm+ReLU launch."""
+from __future__ import annotations
+
+from typing import Dict, List, Literal, Optional
+
+import torch
+import torch.nn as nn
+
+from ..layers import Dropout, LayerNorm, Linear
+
+TaskLiteral = Literal["ar", "oscc", "lta", "pnr", "ant"]
+
+
+class ProjectionTask(torch.nn.Module):
+    def __init__(self, name: str, input_size: int, features_size: int = 1024, dropout: float = 0):
+        super().__init__()
+        self.name, self.input_size, self.features_size = name, input_size, features_size
+        self.net = nn.Sequential(Dropout(dropout), Linear(input_size, features_size), LayerNorm(features_size),
+                                 nn.ReLU(), Linear(features_size, features_size))
+
+    def forward_features(self, x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        n = self.net
+        return n[4](n[2](n[1](n[0](x)), relu=True))
+
+    def configure_optimizers(self, _):
+        return self.parameters()
+
+
+def build_classifier(features_size: int, out: int, head_dropout: float) -> nn.Sequential:
+    return nn.Sequential(Dropout(head_dropout), Linear(features_size, out))
+
+
+def apply_classifier(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    return seq[1](seq[0](x))
+
+
+def fuse_logits(primary: torch.Tensor, aux: List[torch.Tensor], average: bool) -> torch.Tensor:
+    """stack([primary, *aux]).sum(0) / .mean(0) of the reference (recognition.py:53-57) without the
+    stacked copy: a running axpby over the (small) logit tensors."""
+    from ... import ops
+    return ops.sum_tensors([primary, *aux], scale=(1.0 / (1 + len(aux))) if average else 1.0)

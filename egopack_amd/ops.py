@@ -1,0 +1,738 @@
+"""torch.autograd.Functions over the C ABI of libegopack_hip.so.
+
+PyTorch is used for device memory, the current HIP stream and autograd bookkeeping only: every
+piece of arithmetic below is a launch of a hand-written gfx950 kernel through ctypes.  There is
+no CPU path: tensors must live on a ROCm device, otherwise a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1  # EGK_COMPUTE_*
+
+_state = {"compute": BF16}
+
+
+def set_compute(mode: str) -> None:
+    """'bf16' (default: v_mfma_f32_16x16x32_bf16, f32 accumulate) or 'f32' (exact f32 MFMA)."""
+    _state["compute"] = {"bf16": BF16, "f32": F32}[mode]
+
+
+def get_compute() -> str:
+    return "bf16" if _state["compute"] == BF16 else "f32"
+
+
+class compute_mode:
+    """Context manager: ``with ops.compute_mode('f32'): ...``"""
+
+    def __init__(self, mode):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        self.prev = get_compute()
+        set_compute(self.mode)
+
+    def __exit__(self, *a):
+        set_compute(self.prev)
+
+
+# ---- plumbing -----------------------------------------------------------------------------------
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "egopack_amd: the HIP path needs tensors on a ROCm device (got a CPU tensor); there is "
+                "no CPU fallback -- the CPU oracle under oracle/ is test infrastructure only")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ck(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream).  Every kernel that takes a workspace uses it
+    only inside one API call, so sharing it between calls on one stream is safe."""
+    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+_rng = {"seed": 0x5EED_E60, "offset": 0}
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the Philox dropout streams (per process; ranks should use different seeds)."""
+    _rng["seed"], _rng["offset"] = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+
+
+def _next_rng(n_elems: int):
+    off = _rng["offset"]
+    _rng["offset"] += (n_elems + 3) // 4 + 64
+    return _rng["seed"], off
+
+
+_rng_dev = {}
+
+
+def rng_device_offset(device) -> torch.Tensor:
+    """Device-resident uint64 added to every dropout launch's Philox offset.  Captured graphs bake the
+    host-side (seed, offset) into their kernel arguments; advancing this word between replays
+    (``advance_rng_device``) gives every replayed step fresh masks."""
+    key = torch.device(device).index
+    t = _rng_dev.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _rng_dev[key] = t
+    return t
+
+
+def advance_rng_device(device, stride: int = 1 << 40):
+    rng_device_offset(device).add_(stride)
+
+
+# ---- raw GEMM ------------------------------------------------------------------------------------
+def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
+         transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
+         allow_splitk=True):
+    lib = _lib.load()
+    compute = _state["compute"] if compute is None else compute
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K1, d.K2 = M, N, K1, K2
+    d.A1, d.A2, d.B1, d.B2 = _p(A1), _p(A2), _p(B1), _p(B2)
+    d.lda1, d.lda2, d.ldb1, d.ldb2 = lda1, lda2, ldb1, ldb2
+    d.transA, d.transB = int(transA), int(transB)
+    d.a_dtype = d.b_dtype = d.c_dtype = 0
+    d.compute = compute
+    d.C, d.ldc = _p(out), ldc
+    d.accumulate, d.act, d.alpha = int(accumulate), act, alpha
+    d.bias, d.residual, d.ldr = _p(bias), _p(residual), ldr
+    sk = lib.egk_gemm_splitk(M, N, K1 + K2, compute) if allow_splitk else 1
+    d.splitk = sk
+    if sk > 1:
+        need = sk * M * N * 4
+        ws = workspace(need, out.device)
+        d.ws, d.ws_bytes = _p(ws), ws.numel()
+    _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
+
+
+def _colsum_into(x2d: torch.Tensor, out: torch.Tensor, accumulate: bool):
+    lib = _lib.load()
+    M, N = x2d.shape
+    ws = workspace(lib.egk_colsum_ws_len(M, N) * 4, x2d.device)
+    _ck(lib.egk_colsum(_stream(), _p(x2d), x2d.stride(0), M, N, _p(out), int(accumulate), _p(ws)), "egk_colsum")
+
+
+def _grad_slot(param: Optional[torch.Tensor]):
+    """Fused weight-gradient accumulation: if the parameter already owns a contiguous .grad (the
+    flat gradient buffer of egopack_amd.optim.FlatAdam), backward kernels accumulate into it and
+    autograd gets None for that input."""
+    if param is None:
+        return None
+    g = getattr(param, "grad", None)
+    if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda:
+        return g
+    return None
+
+
+# ---- Linear (two-source, fused bias / ReLU / residual) ----------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, x2, W2, residual, relu, compute):
+        _need_gpu(x, W)
+        x = _f32c(x)
+        M, K1 = x.shape
+        N = W.shape[0]
+        Wc = _f32c(W)
+        K2 = 0
+        if x2 is not None:
+            x2 = _f32c(x2)
+            K2 = x2.shape[1]
+            W2c = _f32c(W2)
+        res = _f32c(residual) if residual is not None else None
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm(M, N, x, K1, Wc, K1, K1, y, N, A2=x2, lda2=K2, B2=W2c if K2 else None, ldb2=K2, K2=K2,
+             bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
+        ctx.relu, ctx.compute = relu, compute
+        ctx.has = (b is not None, x2 is not None, residual is not None)
+        ctx.params = (W, b, W2)
+        ctx.save_for_backward(x, Wc, x2, W2c if K2 else None, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, x2, W2, y = ctx.saved_tensors
+        Wp, bp, W2p = ctx.params
+        has_b, has_x2, has_res = ctx.has
+        dy = _f32c(dy)
+        M, N = dy.shape
+        K1 = x.shape[1]
+        lib = _lib.load()
+        if ctx.relu:
+            assert not has_res
+            g = torch.empty_like(dy)
+            _ck(lib.egk_relu_gate(_stream(), _p(dy), _p(y), _p(g), dy.numel()), "egk_relu_gate")
+        else:
+            g = dy
+        needs = ctx.needs_input_grad
+        dx = dW = db = dx2 = dW2 = None
+        if needs[0]:
+            dx = torch.empty_like(x)
+            gemm(M, K1, g, N, W, K1, N, dx, K1, transB=True, compute=ctx.compute)
+        if needs[1]:
+            slot = _grad_slot(Wp)
+            out = slot if slot is not None else torch.zeros_like(W)
+            gemm(N, K1, g, N, x, K1, M, out, K1, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+            dW = None if slot is not None else out
+        if has_b and needs[2]:
+            slot = _grad_slot(bp)
+            out = slot if slot is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+            _colsum_into(g, out, True)
+            db = None if slot is not None else out
+        if has_x2:
+            K2 = x2.shape[1]
+            if needs[3]:
+                dx2 = torch.empty_like(x2)
+                gemm(M, K2, g, N, W2, K2, N, dx2, K2, transB=True, compute=ctx.compute)
+            if needs[4]:
+                slot = _grad_slot(W2p)
+                out = slot if slot is not None else torch.zeros_like(W2)
+                gemm(N, K2, g, N, x2, K2, M, out, K2, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+                dW2 = None if slot is not None else out
+        dres = dy if (has_res and needs[5]) else None
+        return dx, dW, db, dx2, dW2, dres, None, None
+
+
+def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None):
+    """y = relu?(x @ W.T (+ x2 @ W2.T) + b) (+ residual): one MFMA launch."""
+    return _Linear.apply(x, W, b, x2, W2, residual, relu, _state["compute"] if compute is None else compute)
+
+
+class _MultiLinear(torch.autograd.Function):
+    """y = cat_i(x_i) @ W.T + b without materialising the concatenation: one contraction per input
+    block writing its row slice of the shared output (the 1536-d feature rows of every task batch are
+    read where the loader put them)."""
+
+    @staticmethod
+    def forward(ctx, W, b, compute, *xs):
+        _need_gpu(W, *xs)
+        xs = [_f32c(x) for x in xs]
+        Wc = _f32c(W)
+        N, K = Wc.shape
+        rows = [x.shape[0] for x in xs]
+        y = torch.empty((sum(rows), N), dtype=torch.float32, device=W.device)
+        bc = _f32c(b) if b is not None else None
+        off = 0
+        for x, m in zip(xs, rows):
+            gemm(m, N, x, K, Wc, K, K, y[off:off + m], N, bias=bc, compute=compute)
+            off += m
+        ctx.compute, ctx.rows, ctx.params = compute, rows, (W, b)
+        ctx.save_for_backward(Wc, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        Wc, *xs = ctx.saved_tensors
+        Wp, bp = ctx.params
+        dy = _f32c(dy)
+        N, K = Wc.shape
+        needs = ctx.needs_input_grad
+        dW = db = None
+        if needs[0]:
+            slot = _grad_slot(Wp)
+            out = slot if slot is not None else torch.zeros_like(Wc)
+            off = 0
+            for x, m in zip(xs, ctx.rows):
+                gemm(N, K, dy[off:off + m], N, x, K, m, out, K, transA=True, transB=True, accumulate=True,
+                     compute=ctx.compute)
+                off += m
+            dW = None if slot is not None else out
+        if bp is not None and needs[1]:
+            slot = _grad_slot(bp)
+            out = slot if slot is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+            _colsum_into(dy, out, True)
+            db = None if slot is not None else out
+        dxs = []
+        off = 0
+        for i, (x, m) in enumerate(zip(xs, ctx.rows)):
+            if needs[3 + i]:
+                dx = torch.empty_like(x)
+                gemm(m, K, dy[off:off + m], N, Wc, K, N, dx, K, transB=True, compute=ctx.compute)
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+            off += m
+        return (dW, db, None, *dxs)
+
+
+def multi_linear(xs, W, b=None, compute=None):
+    return _MultiLinear.apply(W, b, _state["compute"] if compute is None else compute, *xs)
+
+
+# ---- row LayerNorm (+ReLU, +dropout) ------------------------------------------------------------------
+class _RowLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, relu, p, training):
+        _need_gpu(x, w)
+        lib = _lib.load()
+        x = _f32c(x)
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        p_eff = float(p) if training else 0.0
+        mask = torch.empty((rows, cols), dtype=torch.uint8, device=x.device) if p_eff > 0 else None
+        seed, off = _next_rng(rows * max(cols, 4096)) if p_eff > 0 else (0, 0)
+        wc, bc = _f32c(w), _f32c(b)
+        _ck(lib.egk_rowln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(mean), _p(rstd), _p(mask), rows, cols, eps,
+                              int(relu), p_eff, seed, off, _p(rng_device_offset(x.device)) if p_eff > 0 else None),
+            "egk_rowln_fwd")
+        ctx.relu, ctx.p = relu, p_eff
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, wc, bc, mean, rstd, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, b, mean, rstd, mask = ctx.saved_tensors
+        wp, bp = ctx.params
+        rows, cols = x.shape
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
+        dw = slot_w if slot_w is not None else torch.zeros_like(w)
+        db = slot_b if slot_b is not None else torch.zeros_like(b)
+        ws = workspace(2 * lib.egk_rowln_bwd_ws_rows(rows) * cols * 4, x.device)
+        _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), _p(dw), _p(db),
+                              _p(ws), rows, cols, int(ctx.relu), ctx.p), "egk_rowln_bwd")
+        return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None, None
+
+
+def row_layernorm(x, w, b, eps=1e-5, relu=False, p=0.0, training=False):
+    """dropout(relu(LayerNorm(x))) in one launch (nn.LayerNorm -> nn.ReLU -> nn.Dropout)."""
+    return _RowLN.apply(x, w, b, float(eps), bool(relu), float(p), bool(training))
+
+
+def last_rowln_mask(y: torch.Tensor):
+    """Keep-mask (uint8) saved by the row_layernorm that produced ``y`` (tests feed it to the oracle)."""
+    return y.grad_fn.saved_tensors[5] if y.grad_fn is not None else None
+
+
+# ---- graph-mode LayerNorm + LeakyReLU -------------------------------------------------------------------
+class _GraphLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, seg_ptr, eps, slope):
+        _need_gpu(x, w, seg_ptr)
+        lib = _lib.load()
+        x = _f32c(x)
+        rows, cols = x.shape
+        n_seg = seg_ptr.numel() - 1
+        y = torch.empty_like(x)
+        stats = torch.empty(n_seg * 2, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
+        wc, bc = _f32c(w), _f32c(b)
+        _ck(lib.egk_graphln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
+                                slope, _p(ws)), "egk_graphln_fwd")
+        ctx.eps, ctx.slope = eps, slope
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, wc, bc, stats, seg_ptr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, b, stats, seg_ptr = ctx.saved_tensors
+        wp, bp = ctx.params
+        rows, cols = x.shape
+        n_seg = seg_ptr.numel() - 1
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
+        dw = slot_w if slot_w is not None else torch.zeros_like(w)
+        db = slot_b if slot_b is not None else torch.zeros_like(b)
+        ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
+        _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(seg_ptr),
+                                n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws)), "egk_graphln_bwd")
+        return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None
+
+
+def graph_layernorm_lrelu(x, w, b, seg_ptr, eps=1e-5, slope=0.2):
+    """LeakyReLU(gnn.LayerNorm(mode='graph')(x)) with statistics per row segment (int32 seg_ptr)."""
+    return _GraphLN.apply(x, w, b, seg_ptr, float(eps), float(slope))
+
+
+# ---- positional encoding add --------------------------------------------------------------------------
+class _PEAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos, freq):
+        _need_gpu(x, pos, freq)
+        x = _f32c(x)
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        _ck(_lib.load().egk_pe_add(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(y), rows, cols), "egk_pe_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+def pe_add(x, pos, freq):
+    if pos.dtype != torch.int64:
+        pos = pos.to(torch.int64)
+    return _PEAdd.apply(x, pos, freq)
+
+
+# ---- CSR mean aggregation -------------------------------------------------------------------------------
+class _CSRMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rowptr, col, t_rowptr, t_col, t_wgt):
+        _need_gpu(x, rowptr, col)
+        x = _f32c(x)
+        rows, cols = x.shape
+        out = torch.empty_like(x)
+        _ck(_lib.load().egk_csr_gather(_stream(), _p(x), _p(rowptr), _p(col), None, None, _p(out), rows, cols), "egk_csr_gather")
+        ctx.save_for_backward(t_rowptr, t_col, t_wgt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        t_rowptr, t_col, t_wgt = ctx.saved_tensors
+        dout = _f32c(dout)
+        rows, cols = dout.shape
+        dx = torch.empty_like(dout)
+        _ck(_lib.load().egk_csr_gather(_stream(), _p(dout), _p(t_rowptr), _p(t_col), _p(t_wgt), None, _p(dx), rows, cols),
+            "egk_csr_gather")
+        return dx, None, None, None, None, None
+
+
+def csr_mean_aggregate(x, graph):
+    """agg[i] = mean_{j->i} x[j] (0 without in-edges); ``graph`` = egopack_amd.data.CSRGraph."""
+    return _CSRMean.apply(x, graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt)
+
+
+# ---- GraphONE gather-max ------------------------------------------------------------------------------
+class _GatherMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, bank, nn):
+        _need_gpu(f, bank, nn)
+        f, bank = _f32c(f), _f32c(bank)
+        rows, cols = f.shape
+        k = nn.shape[1]
+        m = torch.empty_like(f)
+        arg = torch.empty((rows, cols), dtype=torch.uint8, device=f.device)
+        _ck(_lib.load().egk_gather_max_fwd(_stream(), _p(f), _p(bank), _p(nn.contiguous()), _p(m), _p(arg), rows, cols, k),
+            "egk_gather_max_fwd")
+        ctx.k = k
+        ctx.save_for_backward(arg)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        (arg,) = ctx.saved_tensors
+        dm = _f32c(dm)
+        rows, cols = dm.shape
+        df = torch.empty_like(dm)
+        _ck(_lib.load().egk_gather_max_bwd(_stream(), _p(dm), _p(arg), _p(df), rows, cols, ctx.k, 0), "egk_gather_max_bwd")
+        return df, None, None
+
+
+def gather_max(f, bank, nn):
+    """m[n] = max(f[n], bank[nn[n, :]]) elementwise (frozen bank: no gradient to it)."""
+    return _GatherMax.apply(f, bank, nn)
+
+
+# ---- per-sequence max pool --------------------------------------------------------------------------------
+class _SegMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ptr):
+        _need_gpu(x, ptr)
+        x = _f32c(x)
+        rows, cols = x.shape
+        n_seg = ptr.numel() - 1
+        out = torch.empty((n_seg, cols), dtype=torch.float32, device=x.device)
+        arg = torch.empty((n_seg, cols), dtype=torch.int32, device=x.device)
+        _ck(_lib.load().egk_segment_max_fwd(_stream(), _p(x), _p(ptr), _p(out), _p(arg), n_seg, cols), "egk_segment_max_fwd")
+        ctx.rows = rows
+        ctx.save_for_backward(arg, ptr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, ptr = ctx.saved_tensors
+        dout = _f32c(dout)
+        n_seg, cols = dout.shape
+        dx = torch.empty((ctx.rows, cols), dtype=torch.float32, device=dout.device)
+        _ck(_lib.load().egk_segment_max_bwd(_stream(), _p(dout), _p(arg), _p(ptr), _p(dx), n_seg, ctx.rows, cols),
+            "egk_segment_max_bwd")
+        return dx, None
+
+
+def segment_max(x, ptr):
+    """global_max_pool over contiguous sequences; ``ptr`` int32 [B+1]."""
+    return _SegMax.apply(x, ptr)
+
+
+# ---- losses ---------------------------------------------------------------------------------------------
+class _CE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, smoothing, y, *logits):
+        # loss[n] = sum_h CE(logits[h][n], y[n, h]) with ignore_index -1 (y: [N] or [N, heads] int64)
+        _need_gpu(y, *logits)
+        lib = _lib.load()
+        rows = logits[0].shape[0]
+        loss = torch.empty(rows, dtype=torch.float32, device=logits[0].device)
+        y = y.contiguous()
+        ystride = 1 if y.dim() == 1 else y.shape[1]
+        saved = []
+        for h, l in enumerate(logits):
+            l = _f32c(l)
+            lse = torch.empty(rows, dtype=torch.float32, device=l.device)
+            yh = y if y.dim() == 1 else y[:, h]
+            _ck(lib.egk_ce_fwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ystride, _p(loss), _p(lse), rows,
+                               l.shape[1], smoothing, int(h > 0)), "egk_ce_fwd")
+            saved += [l, lse]
+        ctx.smoothing, ctx.ystride, ctx.nh = smoothing, ystride, len(logits)
+        ctx.save_for_backward(y, *saved)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        lib = _lib.load()
+        y, *saved = ctx.saved_tensors
+        gloss = _f32c(gloss)
+        grads = []
+        for h in range(ctx.nh):
+            l, lse = saved[2 * h], saved[2 * h + 1]
+            rows, Cn = l.shape
+            d = torch.empty_like(l)
+            yh = y if y.dim() == 1 else y[:, h]
+            _ck(lib.egk_ce_bwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ctx.ystride, _p(lse), _p(gloss),
+                               _p(d), d.stride(0), rows, Cn, ctx.smoothing), "egk_ce_bwd")
+            grads.append(d)
+        return (None, None, *grads)
+
+
+def cross_entropy(logits, y, smoothing: float = 0.0):
+    """Per-row CrossEntropy(reduction='none', ignore_index=-1), summed over heads when ``logits`` is
+    a tuple and y is [N, heads]."""
+    if torch.is_tensor(logits):
+        logits = (logits,)
+    return _CE.apply(float(smoothing), y, *logits)
+
+
+class _BCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y):
+        _need_gpu(logits, y)
+        logits = _f32c(logits)
+        y = y.contiguous()
+        loss = torch.empty_like(logits)
+        _ck(_lib.load().egk_bce_fwd(_stream(), _p(logits), _p(y), _p(loss), logits.numel()), "egk_bce_fwd")
+        ctx.save_for_backward(logits, y)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, y = ctx.saved_tensors
+        g = _f32c(g)
+        d = torch.empty_like(logits)
+        _ck(_lib.load().egk_bce_bwd(_stream(), _p(logits), _p(y), _p(g), _p(d), logits.numel()), "egk_bce_bwd")
+        return d, None
+
+
+def bce_with_logits(logits, y):
+    """BCEWithLogitsLoss(reduction='none') against y.float(); y int64 of the same shape."""
+    if y.dtype != torch.int64:
+        y = y.to(torch.int64)
+    return _BCE.apply(logits, y)
+
+
+# ---- dropout / reductions -----------------------------------------------------------------------------------
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        _need_gpu(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        seed, off = _next_rng(x.numel())
+        _ck(_lib.load().egk_dropout_fwd(_stream(), _p(x), _p(y), _p(mask), x.numel(), p, seed, off,
+                                        _p(rng_device_offset(x.device))), "egk_dropout_fwd")
+        ctx.p = p
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        _ck(_lib.load().egk_dropout_bwd(_stream(), _p(dy), _p(mask), _p(dx), dy.numel(), ctx.p), "egk_dropout_bwd")
+        return dx, None
+
+
+def dropout(x, p: float, training: bool):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p))
+
+
+class _WeightedMeanSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *vectors):
+        _need_gpu(*vectors)
+        lib = _lib.load()
+        out = torch.empty(1, dtype=torch.float32, device=vectors[0].device)
+        coefs = []
+        for i, (w, v) in enumerate(zip(weights, vectors)):
+            v = _f32c(v)
+            n = v.numel()
+            coefs.append(w / max(n, 1))
+            _ck(lib.egk_sum_scale(_stream(), _p(v), _p(out), n, coefs[-1], int(i > 0)), "egk_sum_scale")
+        ctx.coefs, ctx.shapes = coefs, [v.shape for v in vectors]
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g = _f32c(g.reshape(1))
+        grads = []
+        for coef, shape in zip(ctx.coefs, ctx.shapes):
+            d = torch.empty(shape, dtype=torch.float32, device=g.device)
+            _ck(lib.egk_fill_scaled(_stream(), _p(g), coef, _p(d), d.numel()), "egk_fill_scaled")
+            grads.append(d)
+        return (None, *grads)
+
+
+def weighted_mean_sum(vectors, weights):
+    """sum_i weights[i] * vectors[i].mean()  -- the training objective of main_temporal.py:99-128
+    (``torch.stack([w * l.mean() ...]).sum()``) as deterministic single-workgroup reductions."""
+    return _WeightedMeanSum.apply(tuple(float(w) for w in weights), *vectors)
+
+
+class _SumTensors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, *ts):
+        _need_gpu(*ts)
+        lib = _lib.load()
+        ts = [_f32c(t) for t in ts]
+        out = torch.empty_like(ts[0])
+        n = out.numel()
+        if len(ts) == 1:
+            _ck(lib.egk_axpby(_stream(), _p(ts[0]), None, _p(out), n, scale, 0.0), "egk_axpby")
+        else:
+            _ck(lib.egk_axpby(_stream(), _p(ts[0]), _p(ts[1]), _p(out), n, scale, scale), "egk_axpby")
+            for t in ts[2:]:
+                _ck(lib.egk_axpby(_stream(), _p(out), _p(t), _p(out), n, 1.0, scale), "egk_axpby")
+        ctx.scale, ctx.n = scale, len(ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.scale == 1.0:
+            return (None, *([g] * ctx.n))
+        g = _f32c(g)
+        d = torch.empty_like(g)
+        _ck(_lib.load().egk_axpby(_stream(), _p(g), None, _p(d), g.numel(), ctx.scale, 0.0), "egk_axpby")
+        return (None, *([d] * ctx.n))
+
+
+def sum_tensors(ts, scale: float = 1.0):
+    """scale * sum(ts): logit fusion ``stack([...]).sum(0)`` / ``.mean(0)`` without the stacked copy."""
+    return _SumTensors.apply(float(scale), *ts)
+
+
+@torch.no_grad()
+def scaled_one_minus(dot, f_inv, b_inv):
+    _need_gpu(dot)
+    out = torch.empty_like(dot)
+    _ck(_lib.load().egk_cos_dist(_stream(), _p(dot), dot.stride(0), _p(f_inv), _p(b_inv), _p(out), dot.shape[0],
+                                 dot.shape[1]), "egk_cos_dist")
+    return out
+
+
+# ---- cosine k-NN (no grad) ------------------------------------------------------------------------------------
+@torch.no_grad()
+def row_inv_norm(x):
+    _need_gpu(x)
+    x = _f32c(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _ck(_lib.load().egk_row_inv_norm(_stream(), _p(x), _p(out), x.shape[0], x.shape[1]), "egk_row_inv_norm")
+    return out
+
+
+@torch.no_grad()
+def cosine_topk(f, bank, k, bank_inv_norm=None):
+    """Indices [N, k] (int64, ascending cosine distance) of the k nearest bank rows of every row of f.
+    The similarity product always runs on the exact-f32 MFMA path so that index selection does not
+    depend on the bf16 setting (hard parts)."""
+    _need_gpu(f, bank)
+    lib = _lib.load()
+    f, bank = _f32c(f), _f32c(bank)
+    N, H = f.shape
+    K = bank.shape[0]
+    if bank_inv_norm is None:
+        bank_inv_norm = row_inv_norm(bank)
+    f_inv = row_inv_norm(f)
+    dot = torch.empty((N, K), dtype=torch.float32, device=f.device)
+    gemm(N, K, f, H, bank, H, H, dot, K, compute=F32)
+    nn = torch.empty((N, k), dtype=torch.int64, device=f.device)
+    _ck(lib.egk_topk_smallest(_stream(), _p(dot), K, _p(f_inv), _p(bank_inv_norm), _p(nn), N, K, k), "egk_topk_smallest")
+    return nn
+
+
+@torch.no_grad()
+def scatter_add_rows_f64(x, label, bank, count):
+    _need_gpu(x, label, bank)
+    x = _f32c(x)
+    _ck(_lib.load().egk_scatter_add_rows_f64(_stream(), _p(x), _p(label.contiguous()), _p(bank), _p(count), x.shape[0],
+                                            x.shape[1], bank.shape[0]), "egk_scatter_add_rows_f64")
+
+
+# ---- profiling --------------------------------------------------------------------------------------------------
+def prof_enable(on: bool):
+    _lib.load().egk_prof_enable(int(on))
+
+
+def prof_reset():
+    _lib.load().egk_prof_reset()
+
+
+def prof_report():
+    """{kernel: dict(launches, total_ms, flops, bytes)} for kernels launched while profiling was on."""
+    lib = _lib.load()
+    out = {}
+    name = C.create_string_buffer(64)
+    n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    for i in range(lib.egk_prof_count()):
+        lib.egk_prof_get(i, name, 64, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+        if n.value:
+            out[name.value.decode()] = dict(launches=n.value, total_ms=ms.value, flops=fl.value, bytes=by.value)
+    return out

@@ -1,0 +1,105 @@
+"""Flat-buffer Adam: torch.optim.Adam semantics (L2 weight decay) in ONE kernel launch.
+
+All trainable parameters that actually receive gradients are re-homed as views of one contiguous
+fp32 buffer (``flat_p``); their ``.grad`` are views of ``flat_g``.  The backward kernels accumulate
+weight gradients straight into those views (ops._grad_slot), ``zero_grad`` is one memset, the step
+is one ``egk_adam_step`` launch and the data-parallel gradient exchange all-reduces slices of the
+same buffer (dist.GradSync).  Mirrors ``_target_: torch.optim.Adam`` of configs/defaults.yaml:17-20.
+
+Parameters whose gradient is None after the first backward (disabled tasks, detached aux heads,
+frozen prototypes) are left alone, exactly as torch.optim.Adam skips ``grad is None``."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Iterable, List
+
+import torch
+
+from . import _lib
+from .ops import _ck, _p, _stream
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable[torch.Tensor], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        params = [p for p in params]
+        if len({id(p) for p in params}) != len(params):  # the reference passes some parameters twice
+            seen, uniq = set(), []
+            for p in params:
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    uniq.append(p)
+            params = uniq
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self.active: List[torch.Tensor] = []
+        self.step_count = 0
+        self.grad_scale = 1.0
+        self._hyper = None
+        self._hyper_host = None
+
+    # -- construction of the flat buffers (first step, once the set of live gradients is known) -------
+    def _materialise(self):
+        group = self.param_groups[0]
+        live = [p for p in group["params"] if p.requires_grad and p.grad is not None]
+        if not live:
+            raise RuntimeError("FlatAdam.step(): no parameter has a gradient")
+        dev = live[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam needs parameters on a ROCm device (no CPU fallback)")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in live]  # 16-byte aligned slots
+        total = sum(sizes)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p, sz in zip(live, sizes):
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+                self.flat_g[off:off + n].copy_(p.grad.reshape(-1))
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+                off += sz
+        self.active = live
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+
+    @property
+    def materialised(self) -> bool:
+        return self.flat_p is not None
+
+    def zero_grad(self, set_to_none: bool = False):
+        if not self.materialised:
+            return super().zero_grad(set_to_none=True)
+        self.flat_g.zero_()
+
+    def prepare_hyper(self):
+        """Host -> device copy of {lr, 1-b1^t, sqrt(1-b2^t), grad_scale} for the NEXT step; kept outside
+        any captured graph so that lr schedules and step counts keep advancing under replay."""
+        g = self.param_groups[0]
+        t = self.step_count + 1
+        b1, b2 = g["betas"]
+        self._hyper_host[0] = g["lr"]
+        self._hyper_host[1] = 1.0 - b1 ** t
+        self._hyper_host[2] = math.sqrt(1.0 - b2 ** t)
+        self._hyper_host[3] = self.grad_scale
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def launch(self):
+        """The kernel launch alone (capturable)."""
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
+                                      self.flat_p.numel(), _p(self._hyper), b1, b2, g["eps"], g["weight_decay"]),
+            "egk_adam_step")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self.materialised:
+            self._materialise()
+        self.prepare_hyper()
+        self.launch()
+        self.step_count += 1

@@ -1,0 +1,210 @@
+/*
+ * egopack_hip.h -- C ABI of libegopack_hip.so: the MI355X (gfx950) kernels behind the
+ * EgoPack training hot path.
+ *
+ * Boundary rules (last row):
+ *   - plain C: raw device pointers, sizes, an opaque stream handle; no torch / C++ types;
+ *   - every launcher is stream-ordered, re-entrant, allocates nothing, never synchronises
+ *     (so a caller may capture it into a hipGraph); the caller owns every buffer;
+ *   - return value: 0 = ok, negative = EGK_E* argument error, positive = hipError_t;
+ *     egk_last_error() returns a thread-local message.  No exception crosses the ABI.
+ *   - all matrices are row-major; "ld*" = leading dimension in ELEMENTS.
+ *
+ * Each entry point names the reference interface it replaces (path:line relative to the
+ * reference repository sapeirone/EgoPack).  The reference has no FFI of its own (it is pure
+ * Python on torch/torch_geometric); the binding a maintainer adds is the ctypes loader shown
+ * in INTEGRATION.md (egopack_amd/_lib.py is that loader).
+ */
+#ifndef EGOPACK_HIP_H
+#define EGOPACK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* egk_stream_t; /* a hipStream_t */
+
+enum { EGK_OK = 0, EGK_EINVAL = -1, EGK_EUNSUPPORTED = -2 };
+enum { EGK_F32 = 0, EGK_BF16 = 1 };                 /* element type of a matrix in memory      */
+enum { EGK_COMPUTE_F32 = 0, EGK_COMPUTE_BF16 = 1 }; /* MFMA type: exact f32 16x16x4 | bf16 16x16x32 (f32 accumulate) */
+enum { EGK_ACT_NONE = 0, EGK_ACT_RELU = 1 };
+
+/* ---- library ------------------------------------------------------------------------- */
+int egk_version(void);
+const char* egk_last_error(void);
+
+/* Built-in per-kernel timing with HIP events recorded on the launch stream (bench.py's
+ * roofline leg).  Enable only outside graph capture.  egk_prof_get() synchronises the
+ * recorded events and returns the totals for kernel id in [0, egk_prof_count()). */
+int egk_prof_enable(int on);
+int egk_prof_reset(void);
+int egk_prof_count(void);
+int egk_prof_get(int id, char* name, int name_len, int64_t* launches, double* total_ms,
+                 double* alg_flops, double* alg_bytes);
+
+/* ---- dense contractions (MFMA) ---------------------------------------------------------
+ * C[M,N] = act(alpha * (op(A) . op(B)^T) + (accumulate ? C : 0) + bias[n]) + residual[m,n]
+ * where the contraction runs over K = K1 + K2 with a two-source split:
+ *   k <  K1 : A1 / B1      k >= K1 : A2 / B2     (K2 = 0 -> single source)
+ * op(A)[m,k] = transA ? A[k*lda + m] : A[m*lda + k];  op(B)[n,k] = transB ? B[k*ldb + n] : B[n*ldb + k].
+ * Replaces every torch.nn.Linear / gnn.Linear forward and its autograd backward on the path:
+ *   models/temporal_pooling/trn_pooling.py:30-40 (TRN MLP), models/graph.py:42,46 (SAGEConv
+ *   lin / [lin_l|lin_r] as ONE two-source contraction, final Linear + residual),
+ *   models/tasks/task.py:17-23, recognition.py:42, lta.py:42, oscc.py:71, pnr.py:64
+ *   (projections and classifiers), models/graphONE/graphONE.py:60-63,148-151 (stage linears,
+ *   cosine-similarity product).
+ */
+typedef struct egk_gemm_desc {
+    int32_t M, N, K1, K2;
+    const void *A1, *A2;
+    const void *B1, *B2;
+    int64_t lda1, lda2, ldb1, ldb2;
+    int32_t transA, transB;
+    int32_t a_dtype, b_dtype; /* EGK_F32 (EGK_BF16 in memory: reserved) */
+    int32_t compute;          /* EGK_COMPUTE_* */
+    void* C;
+    int64_t ldc;
+    int32_t c_dtype;          /* EGK_F32 */
+    int32_t accumulate;
+    int32_t act;
+    float alpha;
+    const float* bias;     /* [N] or NULL */
+    const float* residual; /* [M, ldr] or NULL */
+    int64_t ldr;
+    /* split-K: splitk > 1 writes f32 partial slabs [splitk][M][N] to ws (plain stores) and a
+     * second launch sums them in slab order and applies the epilogue (bitwise reproducible, no
+     * atomics).  ws_bytes >= splitk*M*N*4.  egk_gemm_splitk() is the library's policy. */
+    int32_t splitk;
+    void* ws;
+    int64_t ws_bytes;
+} egk_gemm_desc;
+int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
+int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute);
+
+/* out[n] (+)= sum_m x[m, n] : bias gradients of every Linear above.  Two launches (row-chunk
+ * partials in ws, then a fixed-order sum); ws: float[egk_colsum_ws_len(M, N)]. */
+int egk_colsum_ws_len(int32_t M, int32_t N);
+int egk_colsum(egk_stream_t s, const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+               float* ws);
+
+/* ---- row LayerNorm (+ReLU, +dropout)  nn.LayerNorm -> ReLU -> Dropout -----------------
+ * trn_pooling.py:31-33,36-38; task.py:19-20; graphONE.py:61-62.
+ * y = dropout(relu((x-mean_row)*rstd_row*w + b)); saves mean/rstd per row; keep mask (u8, 1=keep)
+ * is written when p>0 (Philox4x32-10 keyed by seed, counter = element index + offset).
+ * relu=0 disables the activation. mask may be NULL iff p==0.
+ * dev_offset (device, uint64[1], may be NULL) is added to ``offset`` inside the kernel: a caller
+ * that replays a captured graph advances it between replays so every step draws a fresh mask. */
+int egk_rowln_fwd(egk_stream_t s, const float* x, const float* w, const float* b, float* y, float* mean,
+                  float* rstd, uint8_t* mask, int32_t rows, int32_t cols, float eps, int32_t relu, float p,
+                  uint64_t seed, uint64_t offset, const uint64_t* dev_offset);
+/* dx; dw/db are ACCUMULATED into dw[cols], db[cols] through per-block partials in ws
+ * (ws: float[2 * egk_rowln_bwd_ws_rows(rows) * cols]). */
+int egk_rowln_bwd_ws_rows(int32_t rows);
+int egk_rowln_bwd(egk_stream_t s, const float* dy, const float* x, const float* w, const float* b, const float* mean,
+                  const float* rstd, const uint8_t* mask, float* dx, float* dw, float* db, float* ws, int32_t rows,
+                  int32_t cols, int32_t relu, float p);
+
+/* ---- graph-mode LayerNorm + LeakyReLU  gnn.LayerNorm(mode='graph', batch=None) -> LeakyReLU
+ * models/graph.py:43-44.  Statistics span all rows*cols elements of one SEGMENT of rows; seg_ptr
+ * [n_seg+1] gives row ranges (one segment per task batch: the reference runs one backbone pass
+ * per task batch, main_temporal.py:87-90; here the passes are fused and the statistics stay
+ * per task batch).  y = lrelu((x-mean_s)/(std_s+eps)*w+b, slope).
+ * stats: float[n_seg*2] = (mean, 1/(std+eps)) written by fwd, read by bwd.
+ * ws: egk_graphln_ws_bytes(rows, cols, n_seg) bytes of scratch, 16-byte aligned.
+ * bwd ACCUMULATES dw/db (either may be NULL).  n_seg <= 16. */
+int64_t egk_graphln_ws_bytes(int32_t rows, int32_t cols, int32_t n_seg);
+int egk_graphln_fwd(egk_stream_t s, const float* x, const float* w, const float* b, float* y, float* stats,
+                    const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope,
+                    void* ws);
+int egk_graphln_bwd(egk_stream_t s, const float* dy, const float* x, const float* w, const float* b,
+                    const float* stats, float* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
+                    int32_t rows, int32_t cols, float eps, float slope, void* ws);
+
+/* ---- positional encoding  gnn.PositionalEncoding + add   models/graph.py:37,63 ----------
+ * y[n, c] = x[n, c] + (c < C/2 ? sin(pos[n]*freq[c]) : cos(pos[n]*freq[c-C/2])) */
+int egk_pe_add(egk_stream_t s, const float* x, const int64_t* pos, const float* freq, float* y, int32_t rows,
+               int32_t cols);
+
+/* ---- CSR row gathers (message passing) ------------------------------------------------
+ * out[i,:] = sum_{e in [rowptr[i], rowptr[i+1])} w_e * x[col[e], :]
+ *   w_e = wgt ? wgt[e] : 1/(rowptr[i+1]-rowptr[i])      (mean; empty rows give 0)
+ * if relu_gate != NULL the result row i is multiplied by (relu_gate[i,:] > 0) (fuses the
+ * ReLU backward of SAGEConv's projection).  One launch = SAGEConv mean aggregation forward
+ * (CSR by target, wgt NULL) or its backward (CSR by source, wgt = 1/deg(target)):
+ * models/graph.py:42 (PyG SAGEConv.propagate + MeanAggregation).  No atomics:
+ * bitwise reproducible. */
+int egk_csr_gather(egk_stream_t s, const float* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
+                   const float* relu_gate, float* out, int32_t rows, int32_t cols);
+
+/* GraphONE SAGEConv(aggr='max') over cat([bank, f]) restricted to the N feature rows that are
+ * kept (graphONE.py:104-115): m[n,:] = max(f[n,:], bank[nn[n,0..k),:]); arg[n,c] = winner
+ * (0..k-1 = neighbour slot, k = self).  bwd: df[n,c] = (arg==k) ? dm[n,c] : 0  (bank frozen). */
+int egk_gather_max_fwd(egk_stream_t s, const float* f, const float* bank, const int64_t* nn, float* m, uint8_t* arg,
+                       int32_t rows, int32_t cols, int32_t k);
+int egk_gather_max_bwd(egk_stream_t s, const float* dm, const uint8_t* arg, float* df, int32_t rows, int32_t cols,
+                       int32_t k, int32_t accumulate);
+
+/* global_max_pool over contiguous sequences (oscc.py:68,85): out[b,:] = max_{n in [ptr[b],ptr[b+1])} x[n,:];
+ * arg[b,c] = winning row.  bwd scatters dout to the winners (dx zero elsewhere). */
+int egk_segment_max_fwd(egk_stream_t s, const float* x, const int32_t* ptr, float* out, int32_t* arg, int32_t n_seg,
+                        int32_t cols);
+int egk_segment_max_bwd(egk_stream_t s, const float* dout, const int32_t* arg, const int32_t* ptr, float* dx,
+                        int32_t n_seg, int32_t rows, int32_t cols);
+
+/* ---- cosine k-NN   GraphONE.__compute_edges + cos_dissimilarity  graphONE.py:119-151 ----
+ * inv_norm[r] = 1/||x[r,:]||  (rows of features or of the bank) */
+int egk_row_inv_norm(egk_stream_t s, const float* x, float* inv_norm, int32_t rows, int32_t cols);
+/* dist[n,j] = 1 - dot[n,j]*f_inv[n]*b_inv[j]  (cos_dissimilarity, graphONE.py:148-151) */
+int egk_cos_dist(egk_stream_t s, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv, float* dist,
+                 int32_t rows, int32_t K);
+/* dist[n,j] = 1 - dot[n,j]*fin[n]*bin[j]; nn[n,0..k) = indices of the k smallest distances,
+ * ascending, ties -> lower index (what a stable argsort gives). k <= 16. */
+int egk_topk_smallest(egk_stream_t s, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv,
+                      int64_t* nn, int32_t rows, int32_t K, int32_t k);
+
+/* ---- prototype bank accumulation  graphone.py:53,55 (scatter(..., reduce='sum') in float64
+ * + bincount).  bank[label[n],:] += x[n,:] (fp64), count[label[n]] += 1.  Rows with label<0
+ * are skipped. */
+int egk_scatter_add_rows_f64(egk_stream_t s, const float* x, const int64_t* label, double* bank, int64_t* count,
+                             int32_t rows, int32_t cols, int64_t n_labels);
+
+/* ---- losses ---------------------------------------------------------------------------
+ * nn.CrossEntropyLoss(reduction='none', ignore_index=-1[, label_smoothing]) criterion/wrapper.py:67-82,
+ * recognition.py:63, oscc.py:90.  loss[n] (+)= CE(logits[n,:], y[n*y_stride]); lse[n] saved.
+ * bwd: dlogits[n,c] = gscale[n] * (softmax - target_dist)   (0 for ignored rows). */
+int egk_ce_fwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, float* loss,
+               float* lse, int32_t rows, int32_t C, float smoothing, int32_t accumulate);
+int egk_ce_bwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, const float* lse,
+               const float* gloss, float* dlogits, int64_t ldd, int32_t rows, int32_t C, float smoothing);
+/* nn.BCEWithLogitsLoss(reduction='none') on y.float()  main_temporal.py:123,298; pnr.py:82-83 */
+int egk_bce_fwd(egk_stream_t s, const float* logits, const int64_t* y, float* loss, int32_t n);
+int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const float* gloss, float* dlogits, int32_t n);
+
+/* ---- small elementwise helpers ----------------------------------------------------------- */
+/* y = keep ? x/(1-p) : 0 with a fresh Philox mask (nn.Dropout: task.py:18, graph.py:30, heads) */
+int egk_dropout_fwd(egk_stream_t s, const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                    uint64_t offset, const uint64_t* dev_offset);
+int egk_dropout_bwd(egk_stream_t s, const float* dy, const uint8_t* mask, float* dx, int64_t n, float p);
+/* dx = y > 0 ? dy : 0  -- backward of a ReLU fused into a contraction epilogue (graph.py:42 project) */
+int egk_relu_gate(egk_stream_t s, const float* dy, const float* y, float* dx, int64_t n);
+/* out = a*x + b*y (y may be NULL) */
+int egk_axpby(egk_stream_t s, const float* x, const float* y, float* out, int64_t n, float a, float b);
+/* out[i] = scalar[0] * coef  -- backward of the scaled mean below */
+int egk_fill_scaled(egk_stream_t s, const float* scalar, float coef, float* out, int64_t n);
+/* out[0] (+)= scale * sum(x[0..n))  -- loss.mean() * weight, deterministic single-block tree */
+int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float scale, int32_t accumulate);
+
+/* ---- optimiser  torch.optim.Adam (L2 weight decay)  configs/defaults.yaml:17-20 ----------
+ * One launch over the flat parameter / gradient / moment buffers.  hyper (device, float[4]) =
+ * {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale}: rewritten by the host between graph replays.
+ * g' = g*grad_scale + wd*p; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2;
+ * p -= (lr/bc1) * m / (sqrt(v)/bc2_sqrt + eps) */
+int egk_adam_step(egk_stream_t s, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                  float beta1, float beta2, float eps, float weight_decay);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGOPACK_HIP_H */

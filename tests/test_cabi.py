@@ -1,0 +1,49 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/egopack_hip.h declares
+(no compute calls without a GPU)."""
+import ctypes
+
+from egopack_amd import _lib
+
+
+def test_library_is_built_and_loads():
+    lib = _lib.load()
+    assert lib.egk_version() >= 100
+    assert isinstance(_lib.last_error(), str)
+
+
+def test_every_header_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    declared = _lib.header_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/egopack_hip.h but not exported"
+    assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
+
+
+def test_gemm_descriptor_layout_matches_header():
+    # field order / count of struct egk_gemm_desc as declared in the header
+    import re
+    text = _lib.HEADER.read_text()
+    body = re.search(r"typedef struct egk_gemm_desc \{(.*?)\} egk_gemm_desc;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+    assert names == [f[0] for f in _lib.GemmDesc._fields_]
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _lib.load()
+    assert lib.egk_gemm(None, None) == -1  # EGK_EINVAL: null descriptor
+    assert "null descriptor" in _lib.last_error()
+    assert lib.egk_prof_count() > 30
+    assert lib.egk_gemm_splitk(128, 256, 4096, 1) > 1 and lib.egk_gemm_splitk(6144, 1024, 1024, 1) == 1
+    assert lib.egk_rowln_bwd_ws_rows(6144) >= 1 and lib.egk_graphln_ws_bytes(6144, 1024, 3) > 0
+    name = ctypes.create_string_buffer(64)
+    n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    assert lib.egk_prof_get(0, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)) == 0
+    assert name.value.decode().startswith("gemm")

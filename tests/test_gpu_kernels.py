@@ -1,0 +1,483 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle / plain torch fp32-fp64 references.
+
+Tolerances (stated per test):
+  * exact-f32 MFMA contractions and all non-GEMM kernels: rtol 1e-4 / atol 1e-5 (summation order);
+  * bf16 MFMA contractions: compared with a reference computed from bf16-ROUNDED operands in fp64
+    (the only error left is fp32 accumulation order): rtol 1e-3 / atol 1e-3;
+  * integer / index outputs (arg-max, k-NN indices, masks, counts): bit-exact.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pyg_ops as P  # noqa: E402
+from oracle import path as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda"
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------------
+SHAPES = [(130, 70, 40), (257, 129, 144), (64, 7, 32), (33, 1, 32), (300, 256, 200), (128, 128, 64)]
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("transA,transB", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_layouts(ops, compute, transA, transB, M, N, K):
+    g = gen(M * 1000 + N * 10 + K)
+    A = torch.randn((K, M) if transA else (M, K), generator=g)
+    B = torch.randn((K, N) if transB else (N, K), generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    opA = (A.t() if transA else A).double()
+    opB = (B.t() if transB else B).double()
+    if compute == "bf16":
+        opA, opB = bf16_round(opA.float()), bf16_round(opB.float())
+        tol = dict(rtol=1e-3, atol=1e-3)
+    else:
+        tol = dict(rtol=1e-4, atol=1e-4)
+    ref = (opA @ opB.t() + bias.double()).float() + res
+    out = torch.empty(M, N, device=DEV)
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    ops.gemm(M, N, Ad, A.shape[1], Bd, B.shape[1], K, out, N, transA=transA, transB=transB, bias=bias.to(DEV),
+             residual=res.to(DEV), ldr=N, compute=ops.BF16 if compute == "bf16" else ops.F32)
+    torch.testing.assert_close(out.cpu(), ref, **tol)
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_gemm_two_source_relu_accumulate(ops, compute):
+    g = gen(7)
+    M, N, K1, K2 = 150, 96, 40, 72
+    A1, A2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    B1, B2 = torch.randn(N, K1, generator=g), torch.randn(N, K2, generator=g)
+    bias, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    rnd = bf16_round if compute == "bf16" else (lambda t: t.double())
+    ref = torch.relu(0.5 * (rnd(A1) @ rnd(B1).t() + rnd(A2) @ rnd(B2).t()) + C0.double() + bias.double()).float()
+    out = C0.clone().to(DEV)
+    ops.gemm(M, N, A1.to(DEV), K1, B1.to(DEV), K1, K1, out, N, A2=A2.to(DEV), lda2=K2, B2=B2.to(DEV), ldb2=K2, K2=K2,
+             bias=bias.to(DEV), act=1, accumulate=True, alpha=0.5, compute=ops.BF16 if compute == "bf16" else ops.F32)
+    tol = dict(rtol=1e-3, atol=1e-3) if compute == "bf16" else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.cpu(), ref, **tol)
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_gemm_splitk_matches_single_pass(ops, compute):
+    """dW-shaped contraction (few tiles, deep K): the library picks split-K slabs; compare with fp64."""
+    from egopack_amd import _lib
+    g = gen(11)
+    M, N, K = 128, 256, 4096
+    c = ops.BF16 if compute == "bf16" else ops.F32
+    assert _lib.load().egk_gemm_splitk(M, N, K, c) > 1
+    A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)  # both transposed (dW form)
+    C0 = torch.randn(M, N, generator=g)
+    rnd = bf16_round if compute == "bf16" else (lambda t: t.double())
+    ref = (rnd(A).t() @ rnd(B) + C0.double()).float()
+    out = C0.clone().to(DEV)
+    ops.gemm(M, N, A.to(DEV), M, B.to(DEV), N, K, out, N, transA=True, transB=True, accumulate=True, compute=c)
+    tol = dict(rtol=2e-3, atol=5e-3) if compute == "bf16" else dict(rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(out.cpu(), ref, **tol)
+    out2 = C0.clone().to(DEV)
+    ops.gemm(M, N, A.to(DEV), M, B.to(DEV), N, K, out2, N, transA=True, transB=True, accumulate=True, compute=c)
+    assert torch.equal(out, out2)  # slab reduction is order-fixed: bitwise reproducible
+
+
+def test_gemm_linearity_full_size(ops):
+    """Size-independent property at the bench shape (M=6144, K=4608, N=1024): A.(B1+B2)^T == A.B1^T + A.B2^T
+    on the exact-f32 path (no CPU reference needed)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M, N, K = 6144, 1024, 4608
+    A = torch.randn(M, K, device=DEV, generator=g)
+    B1 = torch.randn(N, K, device=DEV, generator=g)
+    B2 = torch.randn(N, K, device=DEV, generator=g)
+    o1, o2, o3 = (torch.empty(M, N, device=DEV) for _ in range(3))
+    ops.gemm(M, N, A, K, B1, K, K, o1, N, compute=ops.F32)
+    ops.gemm(M, N, A, K, B2, K, K, o2, N, compute=ops.F32)
+    ops.gemm(M, N, A, K, B1 + B2, K, K, o3, N, compute=ops.F32)
+    torch.testing.assert_close(o3, o1 + o2, rtol=1e-3, atol=2e-2)
+    rows = torch.tensor([0, 17, 4095, 6143])
+    ref = (A[rows].double().cpu() @ B1.double().cpu().t()).float()
+    torch.testing.assert_close(o1[rows].cpu(), ref, rtol=1e-4, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# autograd Linear
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("compute,tol", [("f32", 1e-4), ("bf16", 3e-2)])
+def test_linear_autograd_two_source_residual(ops, compute, tol):
+    g = gen(21)
+    M, K1, K2, N = 70, 40, 32, 24
+    x, x2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    W, W2, b = torch.randn(N, K1, generator=g), torch.randn(N, K2, generator=g), torch.randn(N, generator=g)
+    r, w = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    cpu = [t.clone().requires_grad_(True) for t in (x, W, b, x2, W2, r)]
+    ref = F.linear(cpu[0], cpu[1], cpu[2]) + F.linear(cpu[3], cpu[4]) + cpu[5]
+    (ref * w).sum().backward()
+    dev = [t.clone().to(DEV).requires_grad_(True) for t in (x, W, b, x2, W2, r)]
+    with ops.compute_mode(compute):
+        out = ops.linear(dev[0], dev[1], dev[2], x2=dev[3], W2=dev[4], residual=dev[5])
+        (out * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=tol, atol=tol * 10)
+    for a, c in zip(dev, cpu):
+        torch.testing.assert_close(a.grad.cpu(), c.grad, rtol=tol, atol=tol * 20)
+
+
+def test_linear_relu_and_fused_grad_slot(ops):
+    g = gen(22)
+    M, K, N = 50, 32, 40
+    x, W, b, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    cx, cW, cb = (t.clone().requires_grad_(True) for t in (x, W, b))
+    (torch.relu(F.linear(cx, cW, cb)) * w).sum().backward()
+    dx, dW, db = (t.clone().to(DEV).requires_grad_(True) for t in (x, W, b))
+    dW.grad = torch.full_like(dW, 2.0)  # pre-existing contiguous grad: backward accumulates into it in place
+    db.grad = torch.zeros_like(db)
+    slot = dW.grad
+    with ops.compute_mode("f32"):
+        out = ops.linear(dx, dW, db, relu=True)
+        (out * w.to(DEV)).sum().backward()
+    assert dW.grad is slot
+    torch.testing.assert_close(dW.grad.cpu(), cW.grad + 2.0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.grad.cpu(), cb.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dx.grad.cpu(), cx.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_multi_linear_matches_concatenation(ops):
+    g = gen(23)
+    xs = [torch.randn(m, 48, generator=g) for m in (30, 17, 64)]
+    W, b = torch.randn(40, 48, generator=g), torch.randn(40, generator=g)
+    cW, cb = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.linear(torch.cat(xs), cW, cb)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    dW, db = W.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    with ops.compute_mode("f32"):
+        out = ops.multi_linear([x.to(DEV) for x in xs], dW, db)
+        (out * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dW.grad.cpu(), cW.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.grad.cpu(), cb.grad, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# normalisation
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(37, 40), (64, 32), (130, 1024), (9, 4096), (5, 250)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_rowln_fwd_bwd(ops, rows, cols, relu):
+    g = gen(rows * cols)
+    x = torch.randn(rows, cols, generator=g) * 2 + 0.3
+    w, b = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    wt = torch.randn(rows, cols, generator=g)
+    cx, cw, cb = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.layer_norm(cx, (cols,), cw, cb, 1e-5)
+    ref = torch.relu(ref) if relu else ref
+    (ref * wt).sum().backward()
+    dx, dw, db = (t.clone().to(DEV).requires_grad_(True) for t in (x, w, b))
+    out = ops.row_layernorm(dx, dw, db, 1e-5, relu=relu)
+    (out * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dx.grad.cpu(), cx.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(dw.grad.cpu(), cw.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db.grad.cpu(), cb.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_rowln_dropout_mask_semantics(ops):
+    """Dropout inside the fused LayerNorm launch: the oracle applied with the kernel's own keep-mask must
+    reproduce output and gradients; the mask keeps ~ (1-p) of the elements and differs between calls."""
+    g = gen(5)
+    rows, cols, p = 64, 1024, 0.5
+    x, w, b = torch.randn(rows, cols, generator=g), torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    wt = torch.randn(rows, cols, generator=g)
+    ops.manual_seed(1234)
+    dx = x.clone().to(DEV).requires_grad_(True)
+    out = ops.row_layernorm(dx, w.to(DEV), b.to(DEV), 1e-5, relu=True, p=p, training=True)
+    mask = ops.last_rowln_mask(out).cpu()
+    assert mask.dtype == torch.uint8 and set(mask.unique().tolist()) <= {0, 1}
+    assert abs(mask.float().mean().item() - (1 - p)) < 0.02
+    cx = x.clone().requires_grad_(True)
+    ref = torch.relu(F.layer_norm(cx, (cols,), w, b, 1e-5)) * mask.float() / (1 - p)
+    (ref * wt).sum().backward()
+    (out * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dx.grad.cpu(), cx.grad, rtol=1e-3, atol=1e-4)
+    out2 = ops.row_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, relu=True, p=p, training=True)
+    assert not torch.equal((out2 != 0), (out.detach() != 0))
+    out3 = ops.row_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, relu=True, p=p, training=False)
+    torch.testing.assert_close(out3.cpu(), torch.relu(F.layer_norm(x, (cols,), w, b, 1e-5)), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,cols,segs", [(40, 32, [0, 40]), (64, 1024, [0, 10, 64]), (300, 256, [0, 100, 101, 300])])
+def test_graphln_lrelu_fwd_bwd(ops, rows, cols, segs):
+    g = gen(rows + cols)
+    x = torch.randn(rows, cols, generator=g) * 1.5 + 0.2
+    w, b = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    wt = torch.randn(rows, cols, generator=g)
+    cx, cw, cb = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = torch.cat([F.leaky_relu(P.graph_layer_norm(cx[s:e], cw, cb), 0.2) for s, e in zip(segs[:-1], segs[1:])])
+    (ref * wt).sum().backward()
+    dx, dw, db = (t.clone().to(DEV).requires_grad_(True) for t in (x, w, b))
+    seg = torch.tensor(segs, dtype=torch.int32, device=DEV)
+    out = ops.graph_layernorm_lrelu(dx, dw, db, seg, 1e-5, 0.2)
+    (out * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dx.grad.cpu(), cx.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(dw.grad.cpu(), cw.grad, rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(db.grad.cpu(), cb.grad, rtol=1e-3, atol=2e-3)
+
+
+def test_graphln_full_size_properties(ops):
+    """[6144, 1024], 3 segments: each output segment (before the affine/LeakyReLU, w=1,b=0,slope=1) has
+    mean 0 and population std 1/(1+eps/std) -- the defining property, checked on the GPU in fp64."""
+    x = torch.randn(6144, 1024, device=DEV) * 3 + 1
+    seg = torch.tensor([0, 2048, 4096, 6144], dtype=torch.int32, device=DEV)
+    y = ops.graph_layernorm_lrelu(x, torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV), seg, 1e-5, 1.0)
+    for s in range(3):
+        blk = y[s * 2048:(s + 1) * 2048].double()
+        assert abs(blk.mean().item()) < 1e-5
+        assert abs(blk.std(unbiased=False).item() - 1.0) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# graph ops
+# ---------------------------------------------------------------------------------------------------------
+def test_pe_add(ops):
+    g = gen(9)
+    x = torch.randn(50, 64, generator=g)
+    pos = torch.randint(-128, 128, (50,), generator=g)
+    freq = P.positional_encoding_frequency(64)
+    out = ops.pe_add(x.to(DEV), pos.to(DEV), freq.to(DEV))
+    torch.testing.assert_close(out.cpu(), x + P.positional_encoding(pos, freq), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("cols", [32, 1024, 250])
+def test_csr_mean_aggregate_fwd_bwd(ops, cols):
+    from egopack_amd.data import build_csr, lta_connectivity_edges, radius_band_edges
+    g = gen(cols)
+    # two sequences: a band graph and an LTA graph (irregular degrees, isolated-free)
+    e1 = radius_band_edges(torch.arange(9) - 4, 2)
+    y = torch.stack([torch.randint(1, 5, (12,), generator=g), torch.randint(0, 5, (12,), generator=g)], 1)
+    y[:2] = -1
+    e2 = lta_connectivity_edges(torch.arange(12), y, 1.5) + 9
+    extra_isolated = 3  # rows without in-edges -> 0
+    n = 9 + 12 + extra_isolated
+    ei = torch.cat([e1, e2], 1)
+    x = torch.randn(n, cols, generator=g)
+    wt = torch.randn(n, cols, generator=g)
+    cx = x.clone().requires_grad_(True)
+    ref = P.scatter_mean(cx.index_select(0, ei[0]), ei[1], n)
+    (ref * wt).sum().backward()
+    graph = build_csr(ei, n).to(DEV)
+    dx = x.clone().to(DEV).requires_grad_(True)
+    out = ops.csr_mean_aggregate(dx, graph)
+    (out * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dx.grad.cpu(), cx.grad, rtol=1e-5, atol=1e-6)
+    assert torch.equal(out[-extra_isolated:].cpu(), torch.zeros(extra_isolated, cols))
+
+
+def test_gather_max_fwd_bwd(ops):
+    g = gen(31)
+    N, K, H, k = 40, 37, 1024, 4
+    f, bank = torch.randn(N, H, generator=g), torch.randn(K, H, generator=g)
+    nn = torch.stack([torch.randperm(K, generator=g)[:k] for _ in range(N)])
+    wt = torch.randn(N, H, generator=g)
+    cf = f.clone().requires_grad_(True)
+    stack = torch.cat([bank[nn], cf.unsqueeze(1)], 1)  # [N, k+1, H]
+    ref = stack.max(1).values
+    (ref * wt).sum().backward()
+    df = f.clone().to(DEV).requires_grad_(True)
+    out = ops.gather_max(df, bank.to(DEV), nn.to(DEV))
+    (out * wt.to(DEV)).sum().backward()
+    assert torch.equal(out.detach().cpu(), ref.detach())  # max is exact
+    assert torch.equal(df.grad.cpu(), cf.grad)
+
+
+def test_segment_max_fwd_bwd(ops):
+    g = gen(32)
+    ptr = torch.tensor([0, 4, 4, 9, 20], dtype=torch.int32)  # one empty sequence -> zeros
+    x = torch.randn(20, 96, generator=g)
+    wt = torch.randn(4, 96, generator=g)
+    batch = torch.repeat_interleave(torch.arange(4), (ptr[1:] - ptr[:-1]).long())
+    cx = x.clone().requires_grad_(True)
+    ref = P.global_max_pool(cx, batch, 4)
+    (ref * wt).sum().backward()
+    dx = x.clone().to(DEV).requires_grad_(True)
+    out = ops.segment_max(dx, ptr.to(DEV))
+    (out * wt.to(DEV)).sum().backward()
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    assert torch.equal(dx.grad.cpu(), cx.grad)
+
+
+@pytest.mark.parametrize("N,K,H,k", [(14, 37, 32, 4), (64, 4096, 1024, 4), (33, 500, 256, 8)])
+def test_cosine_topk_indices(ops, N, K, H, k):
+    g = gen(N + K)
+    f, bank = torch.randn(N, H, generator=g), torch.randn(K, H, generator=g)
+    edges, closest = O.compute_edges(f, bank, k)
+    nn = ops.cosine_topk(f.to(DEV), bank.to(DEV), k).cpu()
+    dist = O.cos_dissimilarity(f, bank)
+    srt = dist.sort(dim=-1).values
+    gap = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values  # smallest gap among the first k+1 distances
+    safe = gap > 1e-5  # rows whose ranking cannot flip under fp32 summation-order noise
+    assert safe.float().mean() > 0.9
+    assert torch.equal(nn[safe], closest[safe])  # index op: exact wherever the ranking is well defined
+    picked = torch.gather(dist, 1, nn)  # everywhere: the selected distances are the k smallest up to noise
+    torch.testing.assert_close(picked, srt[:, :k], rtol=0, atol=2e-5)
+
+
+def test_topk_tie_breaks_to_lower_index(ops):
+    bank = torch.tensor([[1., 0.], [1., 0.], [0., 1.], [1., 0.]])
+    f = torch.tensor([[2., 0.]])
+    nn = ops.cosine_topk(f.to(DEV), bank.to(DEV), 3).cpu()
+    assert nn.tolist() == [[0, 1, 3]]
+
+
+def test_scatter_add_rows_f64(ops):
+    g = gen(41)
+    rows, cols, L = 200, 1024, 35
+    x = torch.randn(rows, cols, generator=g)
+    label = torch.randint(-1, L, (rows,), generator=g)
+    bank = torch.zeros(L, cols, dtype=torch.float64, device=DEV)
+    count = torch.zeros(L, dtype=torch.int64, device=DEV)
+    ops.scatter_add_rows_f64(x.to(DEV), label.to(DEV), bank, count)
+    keep = label >= 0
+    ref = P.scatter_sum(x[keep].double(), label[keep], L)
+    torch.testing.assert_close(bank.cpu(), ref, rtol=1e-12, atol=1e-12)
+    assert torch.equal(count.cpu(), torch.bincount(label[keep], minlength=L))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses / optimiser
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("smoothing", [0.0, 0.1])
+def test_cross_entropy_heads_ignore_index(ops, smoothing):
+    g = gen(51)
+    N = 77
+    l1, l2 = torch.randn(N, 115, generator=g) * 3, torch.randn(N, 478, generator=g) * 3
+    y = torch.stack([torch.randint(0, 115, (N,), generator=g), torch.randint(0, 478, (N,), generator=g)], 1)
+    y[::3] = -1
+    wt = torch.randn(N, generator=g)
+    c1, c2 = l1.clone().requires_grad_(True), l2.clone().requires_grad_(True)
+    ref = (F.cross_entropy(c1, y[:, 0], ignore_index=-1, reduction="none", label_smoothing=smoothing)
+           + F.cross_entropy(c2, y[:, 1], ignore_index=-1, reduction="none", label_smoothing=smoothing))
+    (ref * wt).sum().backward()
+    d1, d2 = l1.clone().to(DEV).requires_grad_(True), l2.clone().to(DEV).requires_grad_(True)
+    out = ops.cross_entropy((d1, d2), y.to(DEV), smoothing)
+    (out * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(d1.grad.cpu(), c1.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(d2.grad.cpu(), c2.grad, rtol=1e-4, atol=1e-6)
+    assert torch.equal(out.detach().cpu()[::3], torch.zeros(len(range(0, N, 3))))
+
+
+def test_cross_entropy_single_head_1d_targets(ops):
+    g = gen(52)
+    l = torch.randn(9, 2, generator=g)
+    y = torch.tensor([0, 1, -1, 1, 0, 0, 1, -1, 1])
+    out = ops.cross_entropy(l.to(DEV), y.to(DEV), 0.1)
+    ref = F.cross_entropy(l, y, ignore_index=-1, reduction="none", label_smoothing=0.1)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_bce_with_logits(ops):
+    g = gen(53)
+    x = torch.randn(333, generator=g) * 4
+    y = torch.randint(0, 2, (333,), generator=g)
+    wt = torch.randn(333, generator=g)
+    cx = x.clone().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(cx, y.float(), reduction="none")
+    (ref * wt).sum().backward()
+    dx = x.clone().to(DEV).requires_grad_(True)
+    out = ops.bce_with_logits(dx, y.to(DEV))
+    (out * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dx.grad.cpu(), cx.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_weighted_mean_sum_and_sum_tensors(ops):
+    g = gen(54)
+    a, b = torch.randn(100, generator=g), torch.randn(37, generator=g)
+    ca, cb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = 0.5 * ca.mean() + 2.0 * cb.mean()
+    ref.backward()
+    da, db = a.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    out = ops.weighted_mean_sum([da, db], [0.5, 2.0])
+    out.backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(da.grad.cpu(), ca.grad)
+    torch.testing.assert_close(db.grad.cpu(), cb.grad)
+    ts = [torch.randn(13, 7, generator=g) for _ in range(4)]
+    for scale in (1.0, 0.25):
+        dts = [t.clone().to(DEV).requires_grad_(True) for t in ts]
+        s = ops.sum_tensors(dts, scale)
+        torch.testing.assert_close(s.detach().cpu(), torch.stack(ts).sum(0) * scale, rtol=1e-6, atol=1e-6)
+        s.sum().backward()
+        torch.testing.assert_close(dts[2].grad.cpu(), torch.full((13, 7), scale))
+
+
+def test_dropout_op(ops):
+    x = torch.ones(1 << 16, device=DEV, requires_grad=True)
+    ops.manual_seed(7)
+    y = ops.dropout(x, 0.25, True)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.01
+    torch.testing.assert_close(y[y != 0], torch.full_like(y[y != 0], 1 / 0.75))
+    y.sum().backward()
+    assert torch.equal((x.grad != 0), (y != 0))
+    assert ops.dropout(x, 0.25, False) is x
+
+
+def test_flat_adam_matches_torch_adam(ops):
+    from egopack_amd.optim import FlatAdam
+    g = gen(61)
+    shapes = [(33, 7), (5,), (64, 64), (3,)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(3)]
+    cpu = [p.clone().requires_grad_(True) for p in ps]
+    unused_cpu = torch.randn(4, generator=g).requires_grad_(True)
+    ref = torch.optim.Adam(cpu + [unused_cpu], lr=1e-2, weight_decay=1e-3)
+    dev = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    unused = unused_cpu.detach().clone().to(DEV).requires_grad_(True)
+    opt = FlatAdam(dev + [unused], lr=1e-2, weight_decay=1e-3)
+    for it in range(3):
+        ref.zero_grad()
+        opt.zero_grad()
+        for c, d, gr in zip(cpu, dev, grads[it]):
+            c.grad = gr.clone()
+            if d.grad is None:
+                d.grad = gr.clone().to(DEV)
+            else:
+                d.grad.copy_(gr)
+        ref.step()
+        opt.step()
+        if it == 0:
+            assert all(d.data.data_ptr() >= opt.flat_p.data_ptr() for d in dev)  # re-homed into the flat buffer
+    for c, d in zip(cpu, dev):
+        torch.testing.assert_close(d.detach().cpu(), c.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(unused.detach().cpu(), unused_cpu.detach())  # grad None -> skipped, as torch does
+
+
+def test_ops_reject_cpu_tensors(ops):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.randn(4, 4), torch.randn(4, 4))

@@ -1,0 +1,339 @@
+"""GPU parity of the model mirror (egopack_amd.models.*, engine steps) against the golden vectors
+produced by the REFERENCE's own Python (tests/golden/, oracle/make_golden.py) and the CPU oracle.
+
+Two compute modes are checked:
+  * 'f32'  : exact-f32 MFMA.  Tolerance rtol 2e-4 / atol 2e-4 on features, logits and losses
+             (summation-order noise through ~12 chained contractions and 5 normalisations).
+  * 'bf16' : bf16 MFMA inputs, f32 accumulate -- the benchmark mode.  Tolerance: logits/features
+             within 6e-2 absolute at these O(1) magnitudes, loss vectors within 5e-2.
+Index outputs (k-NN assignments) are exact.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import path as O  # noqa: E402
+from oracle import pyg_ops as P  # noqa: E402
+
+DEV = "cuda"
+F32_TOL = dict(rtol=2e-4, atol=2e-4)
+BF16_TOL = dict(rtol=6e-2, atol=6e-2)
+TRN_CFG = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": 40}
+
+
+@pytest.fixture(scope="module")
+def A():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import egopack_amd.data as data
+    import egopack_amd.engine as engine
+    import egopack_amd.ops as ops
+    from egopack_amd.criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper
+    from egopack_amd.graphone import build_graphone
+    from egopack_amd.models import Graph
+    from egopack_amd.models.graphONE.graphONE import GraphONE
+    from egopack_amd.models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+    from egopack_amd.optim import FlatAdam
+
+    class NS:
+        pass
+    ns = NS()
+    ns.__dict__.update(locals())
+    return ns
+
+
+def to_data(A, d):
+    b = A.data.Data(**{k: v for k, v in d.items()})
+    b.graph = A.data.build_csr(b.edge_index, b.x.shape[0])
+    b.ptr32 = b.ptr.to(torch.int32)
+    return b.to(DEV)
+
+
+def make_graph(A, sd, depth=3):
+    m = A.Graph(48, hidden_size=32, depth=depth, pre_dropout=0, temporal_pooling=TRN_CFG, num_segments=3)
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", F32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("case", ["ar_T9_k1", "lta_T22_k1", "oscc_T4_k2", "pnr_T16_k2"])
+def test_graph_forward_backward_vs_reference(A, golden, mode, tol, case):
+    G = golden("graph_forward")
+    c = G["cases"][case]
+    m = make_graph(A, G["sd"], G["depth"])
+    with A.ops.compute_mode(mode):
+        out = m(to_data(A, c["data"]))
+        (out * c["w"].to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), c["out"], **tol)
+    gtol = dict(rtol=2e-3, atol=2e-3) if mode == "f32" else dict(rtol=0.1, atol=0.25)
+    named = dict(m.named_parameters())
+    for k, g in c["grads"].items():
+        torch.testing.assert_close(named[k].grad.cpu(), g, **gtol, msg=lambda s: f"{k}: {s}")
+
+
+def test_graph_accepts_plain_batch_without_csr(A, golden):
+    """Drop-in contract: a batch that only carries x / pos / edge_index / batch (what PyG's loader gives)."""
+    G = golden("graph_forward")
+    c = G["cases"]["ar_T9_k1"]
+    m = make_graph(A, G["sd"])
+    d = A.data.Data(x=c["data"]["x"].to(DEV), pos=c["data"]["pos"].to(DEV), edge_index=c["data"]["edge_index"].to(DEV),
+                    batch=c["data"]["batch"].to(DEV))
+    with A.ops.compute_mode("f32"):
+        out = m(d)
+    torch.testing.assert_close(out.detach().cpu(), c["out"], **F32_TOL)
+
+
+def test_fused_multitask_backbone_equals_separate_passes(A, golden):
+    """The fused pass over several task batches (per-task graph-LN statistics) reproduces the separate
+    per-batch passes of the reference (main_temporal.py:87-90)."""
+    G = golden("graph_forward")
+    m = make_graph(A, G["sd"])
+    names = ["ar_T9_k1", "lta_T22_k1", "pnr_T16_k2"]
+    batches = [to_data(A, G["cases"][n]["data"]) for n in names]
+    host = [A.data.Data(**G["cases"][n]["data"]) for n in names]
+    merged = A.data.merge_batches(host).to(DEV)
+    merged.x = [b.x for b in batches]
+    with A.ops.compute_mode("f32"):
+        fused = m(merged)
+        m.zero_grad()
+        w = torch.cat([G["cases"][n]["w"] for n in names]).to(DEV)
+        (fused * w).sum().backward()
+    off = 0
+    for n in names:
+        ref = G["cases"][n]["out"]
+        torch.testing.assert_close(fused[off:off + ref.shape[0]].detach().cpu(), ref, **F32_TOL)
+        off += ref.shape[0]
+    named = dict(m.named_parameters())
+    for k in G["cases"][names[0]]["grads"]:
+        ref = sum(G["cases"][n]["grads"][k] for n in names)
+        torch.testing.assert_close(named[k].grad.cpu(), ref, rtol=2e-3, atol=2e-3, msg=lambda s: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", F32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("key", ["ar_avg0", "ar_avg1", "lta_avg0", "lta_avg1"])
+def test_multihead_tasks_vs_reference(A, golden, mode, tol, key):
+    G = golden("heads")
+    c = G[key]
+    cls = A.RecognitionTask if key.startswith("ar") else A.LTATask
+    t = cls(32, 32, (7, 11), aux_tasks=tuple(c["aux"].keys()), average_logits=key.endswith("1"))
+    t.load_state_dict(c["sd"])
+    t = t.to(DEV).eval()
+    with A.ops.compute_mode(mode):
+        f = t.forward_features(G["feat"].to(DEV))
+        plain = t.forward_logits(f)
+        fused = t.forward_logits(f, None, {k: v.to(DEV) for k, v in c["aux"].items()})
+        loss = t.compute_loss(fused, G["y2"].to(DEV))
+    torch.testing.assert_close(f.detach().cpu(), c["features"], **tol)
+    for a, b in zip(plain, c["logits"]):
+        torch.testing.assert_close(a.detach().cpu(), b, **tol)
+    for a, b in zip(fused, c["logits_fused"]):
+        torch.testing.assert_close(a.detach().cpu(), b, rtol=tol["rtol"], atol=tol["atol"] * 3)
+    ltol = F32_TOL if mode == "f32" else dict(rtol=5e-2, atol=0.15)
+    torch.testing.assert_close(loss.detach().cpu(), c["loss"], **ltol)
+
+
+def test_metric_selector_wrapper(A, golden):
+    G = golden("heads")
+
+    class DS:
+        has_joint_label = False
+        num_labels = 2
+    crit = A.MetricSelectorWrapper(A.CrossEntropyNone(), DS())
+    logits = tuple(l.to(DEV) for l in G["selector"]["logits"])
+    torch.testing.assert_close(crit(logits, G["y2"].to(DEV)).cpu(), G["selector"]["loss"], rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        crit(logits[:1], G["y2"].to(DEV))
+
+
+@pytest.mark.parametrize("avg", [0, 1])
+def test_oscc_task_vs_reference(A, golden, avg):
+    G = golden("heads")
+    c = G[f"oscc_ce_avg{avg}"]
+    t = A.OSCCTask(32, 32, 0, 0, loss_func="ce", aux_tasks=("ar", "lta", "pnr"), average_logits=bool(avg))
+    t.load_state_dict(c["sd"])
+    t = t.to(DEV).eval()
+    batch = G["batch"].to(DEV)
+    with A.ops.compute_mode("f32"):
+        f = t.forward_features(G["feat"].to(DEV))
+        plain = t.forward_logits(f, batch)
+        fused = t.forward_logits(f, batch, {k: v.to(DEV) for k, v in c["aux"].items()})
+        loss = t.compute_loss(fused, c["y"].to(DEV))
+    torch.testing.assert_close(plain.detach().cpu(), c["logits"], **F32_TOL)
+    torch.testing.assert_close(fused.detach().cpu(), c["logits_fused"], **F32_TOL)
+    torch.testing.assert_close(loss.detach().cpu(), c["loss"], **F32_TOL)
+    with pytest.raises(ValueError):
+        A.OSCCTask(32, 32).to(DEV).forward_aux_logits(f, batch, "ar")
+
+
+@pytest.mark.parametrize("avg", [0, 1])
+def test_pnr_task_vs_reference(A, golden, avg):
+    G = golden("heads")
+    c = G[f"pnr_avg{avg}"]
+    t = A.PNRTask(32, 32, 0, 0, aux_tasks=("ar", "oscc", "lta"), average_logits=bool(avg))
+    t.load_state_dict(c["sd"])
+    t = t.to(DEV).eval()
+    with A.ops.compute_mode("f32"):
+        f = t.forward_features(G["feat"].to(DEV))
+        plain = t.forward_logits(f)
+        fused = t.forward_logits(f, {k: v.to(DEV) for k, v in c["aux"].items()})
+        loss = t.compute_loss(fused, c["y"].to(DEV))
+    assert plain.shape == c["logits"].shape
+    torch.testing.assert_close(plain.detach().cpu(), c["logits"], **F32_TOL)
+    torch.testing.assert_close(fused.detach().cpu(), c["logits_fused"], **F32_TOL)
+    torch.testing.assert_close(loss.detach().cpu(), c["loss"], **F32_TOL)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("residual", [0, 1])
+def test_graphone_vs_reference(A, golden, mode, residual):
+    G = golden("graphone")
+    c = G[f"residual{residual}"]
+    m = A.GraphONE({k: v.clone() for k, v in G["banks"].items()}, features_size=32, hidden_size=32, k=G["k"],
+                   depth=c["depth"], residual=bool(residual), dropout=0, output_dropout=0, output_projection=True)
+    m.load_state_dict(c["sd"])
+    m = m.to(DEV)
+    feats = {t: f.clone().to(DEV).requires_grad_(True) for t, f in c["features"].items()}
+    with A.ops.compute_mode(mode):
+        out, closest = m.interact(feats)
+        sum((out[t] * c["w"][t].to(DEV)).sum() for t in feats).backward()
+    tol = F32_TOL if mode == "f32" else dict(rtol=6e-2, atol=0.1)
+    for t in feats:
+        for a, b in zip(closest[t], c["closest"][t]):
+            assert torch.equal(a.cpu(), b)  # k-NN runs on the exact path in both modes: indices exact
+        torch.testing.assert_close(out[t].detach().cpu(), c["out"][t], **tol)
+    if mode == "f32":
+        for t in feats:
+            torch.testing.assert_close(feats[t].grad.cpu(), c["grad_features"][t], rtol=2e-3, atol=2e-3)
+        named = dict(m.named_parameters())
+        for k, g in c["grads"].items():
+            torch.testing.assert_close(named[k].grad.cpu(), g, rtol=2e-3, atol=2e-3, msg=lambda s: f"{k}: {s}")
+    assert all(not p.requires_grad for n, p in m.named_parameters() if n.startswith("embeddings."))
+
+
+def test_build_graphone_vs_reference(A, golden):
+    G = golden("build_graphone")
+    model = make_graph(A, G["backbone"])
+    ar = A.RecognitionTask(32, 32, G["n_classes"])
+    lta = A.LTATask(32, 32, G["n_classes"])
+    pnr = A.PNRTask(32, 32)
+    for t, k in ((ar, "ar"), (lta, "lta"), (pnr, "pnr")):
+        t.load_state_dict(G["tasks"][k])
+        t.to(DEV)
+    batches = [A.data.Data(**b) for b in G["batches"]]
+    with A.ops.compute_mode("f32"):
+        banks = A.build_graphone(model, ar, [ar, lta, pnr], batches, device=DEV)
+    assert set(banks) == set(G["banks"])
+    for k in banks:
+        assert banks[k].dtype == torch.float32 and banks[k].shape == G["banks"][k].shape
+        torch.testing.assert_close(banks[k].cpu(), G["banks"][k], **F32_TOL)
+
+
+def _load_all(A, G, aux=False):
+    model = make_graph(A, G["before"]["temporal_graph"])
+    if aux:
+        ar = A.RecognitionTask(32, 32, (7, 11), aux_tasks=("oscc", "lta", "pnr"))
+        oscc = A.OSCCTask(32, 32, aux_tasks=("ar", "lta", "pnr"), average_logits=True)
+        lta = A.LTATask(32, 32, (7, 11), aux_tasks=("ar", "oscc", "pnr"))
+        pnr = A.PNRTask(32, 32, aux_tasks=("ar", "oscc", "lta"))
+    else:
+        ar, oscc, lta, pnr = A.RecognitionTask(32, 32, (7, 11)), A.OSCCTask(32, 32), A.LTATask(32, 32, (7, 11)), A.PNRTask(32, 32)
+    tasks = {"ar": ar, "oscc": oscc, "lta": lta, "pnr": pnr}
+    names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
+    for t, n in names.items():
+        tasks[t].load_state_dict(G["before"][n])
+        tasks[t].to(DEV)
+    return model, tasks, names
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_mtl_train_two_iterations_vs_reference(A, golden, fused):
+    """Two iterations of the multi-task step (AR + LTA + PNR enabled, OSCC weight 0) with FlatAdam reproduce
+    the parameters the reference's main_temporal.train + torch.optim.Adam produced (exact-f32 mode)."""
+    G = golden("mtl_train")
+    model, tasks, names = _load_all(A, G)
+
+    class DS:
+        has_joint_label = False
+        num_labels = 2
+    crit = {"ar": A.MetricSelectorWrapper(A.CrossEntropyNone(), DS()), "lta": A.MetricSelectorWrapper(A.CrossEntropyNone(), DS()),
+            "oscc": A.CrossEntropyNone(), "pnr": A.BCEWithLogitsNone()}
+    params = [*model.parameters(), *(p for t in ("ar", "oscc", "lta", "pnr") for p in tasks[t].parameters())]
+    opt = A.FlatAdam(params, lr=G["lr"], weight_decay=G["weight_decay"])
+    step = A.engine.MTLStep(model, tasks, crit, G["weights"], opt, fused_backbone=fused)
+    model.train()
+    for t in tasks.values():
+        t.train()
+    with A.ops.compute_mode("f32"):
+        for it in range(2):
+            batches = {t: to_data(A, G["batches"][t][it]) for t in ("ar", "lta", "oscc", "pnr")}
+            total, vectors = step.step(batches)
+            for t in ("ar", "lta", "pnr"):
+                torch.testing.assert_close(vectors[t].cpu(), G["loss_vectors"][t][it], rtol=1e-3, atol=1e-3)
+            assert "oscc" not in vectors
+    for grp, mod in [("temporal_graph", model)] + [(n, tasks[t]) for t, n in names.items()]:
+        sd = mod.state_dict()
+        for k, v in G["after"][grp].items():
+            # Adam normalises the update: a parameter moves by ~lr per step whatever the gradient scale, so the
+            # comparison is absolute, at a small fraction of the 2*lr = 2e-3 total movement
+            torch.testing.assert_close(sd[k].cpu(), v, rtol=0, atol=1.5e-4, msg=lambda s: f"{grp}/{k}: {s}")
+    for k, v in G["before"]["task/oscc"].items():
+        assert torch.equal(tasks["oscc"].state_dict()[k].cpu(), v)  # disabled task untouched
+
+
+def test_egopack_train_two_iterations_vs_reference(A, golden):
+    G = golden("egopack_train")
+    model, tasks, names = _load_all(A, G, aux=True)
+    sd = G["before"]["graphone"]
+    banks = {t: sd[f"embeddings.{t}.weight"].clone() for t in ("ar", "lta", "pnr")}
+    gone = A.GraphONE(banks, features_size=32, hidden_size=32, k=G["k"], depth=G["depth"], residual=G["residual"],
+                      dropout=0, output_dropout=0, output_projection=True)
+    gone.load_state_dict(sd)
+    gone = gone.to(DEV)
+    params = [*model.parameters(), *(p for t in ("ar", "oscc", "lta", "pnr") for p in tasks[t].parameters()),
+              *gone.parameters()]
+    opt = A.FlatAdam(params, lr=G["lr"], weight_decay=G["weight_decay"])
+    step = A.engine.EgoPackStep(model, tasks, gone, {"oscc": 1.0}, opt, backprop_temporal_graph=True,
+                                temporal_graph_train_mode=False)
+    with A.ops.compute_mode("f32"):
+        for it in range(2):
+            total, vectors = step.step({"oscc": to_data(A, G["batches"]["oscc"][it])})
+            torch.testing.assert_close(vectors["oscc"].cpu(), G["loss_vectors"]["oscc"][it], rtol=1e-3, atol=1e-3)
+    mods = [("temporal_graph", model), ("graphone", gone)] + [(n, tasks[t]) for t, n in names.items()]
+    for grp, mod in mods:
+        cur = mod.state_dict()
+        for k, v in G["after"][grp].items():
+            torch.testing.assert_close(cur[k].cpu(), v, rtol=0, atol=1.5e-4, msg=lambda s: f"{grp}/{k}: {s}")
+
+
+def test_captured_step_equals_eager_step(A, golden):
+    """hipGraph replay of forward+backward+Adam gives the same parameters as the eager step."""
+    G = golden("mtl_train")
+
+    class DS:
+        has_joint_label = False
+        num_labels = 2
+
+    def run(use_graph):
+        model, tasks, names = _load_all(A, G)
+        crit = {"ar": A.MetricSelectorWrapper(A.CrossEntropyNone(), DS()), "lta": A.MetricSelectorWrapper(A.CrossEntropyNone(), DS()),
+                "oscc": A.CrossEntropyNone(), "pnr": A.BCEWithLogitsNone()}
+        live = [*model.parameters(), *(p for t in ("ar", "lta", "pnr") for p in tasks[t].parameters())]
+        opt = A.FlatAdam(live, lr=1e-3, weight_decay=1e-5)
+        step = A.engine.MTLStep(model, tasks, crit, G["weights"], opt, fused_backbone=True)
+        batches = {t: to_data(A, G["batches"][t][0]) for t in ("ar", "lta", "pnr")}
+        with A.ops.compute_mode("f32"):
+            if use_graph:
+                step.capture(batches, warmup=2)
+                for _ in range(3):
+                    step.replay()
+            else:
+                for _ in range(5):
+                    step.step(batches)
+        torch.cuda.synchronize()
+        return opt.flat_p.clone().cpu(), opt.step_count
+
+    p_eager, n_eager = run(False)
+    p_graph, n_graph = run(True)
+    assert n_eager == n_graph == 5
+    torch.testing.assert_close(p_graph, p_eager, rtol=0, atol=1e-6)
