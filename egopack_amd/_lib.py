@@ -9,6 +9,12 @@ import ctypes as C
 import re
 from pathlib import Path
 
+# torch must be imported BEFORE the library is dlopen'ed: the PyTorch-ROCm wheel bundles its own HIP /
+# HSA runtime; loading ours first would pull the system copies into the process and the second runtime
+# then fails with "no ROCm-capable device is detected".  With torch first, the library's
+# libamdhip64 dependency resolves to the runtime torch already loaded (one runtime, shared streams).
+import torch  # noqa: F401
+
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "libegopack_hip.so"
 HEADER = HERE.parent / "include" / "egopack_hip.h"

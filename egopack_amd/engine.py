@@ -96,6 +96,9 @@ class MTLStep:
         """Capture forward+backward(+Adam if no gradient exchange) for THESE device tensors (static
         shapes and addresses: refill them in place between replays)."""
         opt = self.optimizer
+        live = [t for t in self.enabled if batches.get(t) is not None]
+        if self.fused and len(live) > 1 and merged is None:  # index work must stay outside the capture
+            merged = merge_batches([batches[t] for t in live]).to(batches[live[0]].pos.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -34,8 +34,11 @@ def build_graphone(model, ar_task, tasks: List, dataloader, device="cuda") -> Di
         # label = verb * |nouns| + noun for labelled nodes, -1 (skipped by the kernel) otherwise
         y = data.y
         labels = torch.where(y[:, 0] != -1, y[:, 0] * n_classes[1] + y[:, 1], torch.full_like(y[:, 0], -1))
-        for i, t in enumerate(tasks):
-            ops.scatter_add_rows_f64(t.forward_features(feat), labels, banks[t.name], count if i == 0 else None)
+        for t in tasks:
+            # the label count is incremented once PER TASK, as in the reference where
+            # ``all_labels.append(labels)`` sits inside the task loop (graphone.py:50-52): every bank is the
+            # per-label mean divided by len(tasks).  Kept for parity (prototypes are L2-normalised downstream).
+            ops.scatter_add_rows_f64(t.forward_features(feat), labels, banks[t.name], count)
     seen = count > 0
     cnt = count[seen].to(torch.float64).unsqueeze(1)
     return {name: (bank[seen] / cnt).float() for name, bank in banks.items()}

