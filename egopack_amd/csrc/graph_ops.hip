@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256) void pe_add_kernel(const float* __restrict__ x
 }
 
 // ---- CSR gather ----------------------------------------------------------------------------------
+// The output row lives in NV float4 registers per lane; per edge the NV loads of the neighbour row are
+// independent (one index load, then NV wide loads in flight) instead of a chunk-outer / edge-inner walk.
+template <int NV>
 __global__ __launch_bounds__(256) void csr_gather_kernel(const float* __restrict__ x, const int* __restrict__ rowptr,
                                                          const int* __restrict__ col, const float* __restrict__ wgt,
                                                          const float* __restrict__ gate, float* __restrict__ out, int rows,
@@ -74,26 +77,30 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const float* __restrict
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const int e0 = rowptr[row], e1 = rowptr[row + 1];
         const float mean_w = e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f;
-        for (int c = lane * 4; c < cols; c += 256) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = e0; e < e1; ++e) {
-                const float4 v = ld4(x + (long long)col[e] * cols, c, cols, vec);
-                if (wgt) {
-                    const float we = wgt[e];
-                    acc.x += we * v.x; acc.y += we * v.y; acc.z += we * v.z; acc.w += we * v.w;
-                } else {
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                }
+        float4 acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = e0; e < e1; ++e) {
+            const float* src = x + (long long)col[e] * cols;
+            const float we = wgt ? wgt[e] : 1.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 v = ld4(src, (i * 64 + lane) * 4, cols, vec);
+                acc[i].x += we * v.x; acc[i].y += we * v.y; acc[i].z += we * v.z; acc[i].w += we * v.w;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
             if (!wgt) {  // mean = sum / count, as scatter_add / clamp(count, 1)
-                acc.x *= mean_w; acc.y *= mean_w; acc.z *= mean_w; acc.w *= mean_w;
+                acc[i].x *= mean_w; acc[i].y *= mean_w; acc[i].z *= mean_w; acc[i].w *= mean_w;
             }
             if (gate) {
                 const float4 g = ld4(gate + (long long)row * cols, c, cols, vec);
-                acc.x = g.x > 0.f ? acc.x : 0.f; acc.y = g.y > 0.f ? acc.y : 0.f;
-                acc.z = g.z > 0.f ? acc.z : 0.f; acc.w = g.w > 0.f ? acc.w : 0.f;
+                acc[i].x = g.x > 0.f ? acc[i].x : 0.f; acc[i].y = g.y > 0.f ? acc[i].y : 0.f;
+                acc[i].z = g.z > 0.f ? acc[i].z : 0.f; acc[i].w = g.w > 0.f ? acc[i].w : 0.f;
             }
-            st4(out + (long long)row * cols, c, cols, vec, acc);
+            st4(out + (long long)row * cols, c, cols, vec, acc[i]);
         }
     }
 }
@@ -288,8 +295,13 @@ int egk_csr_gather(egk_stream_t stream, const float* x, const int32_t* rowptr, c
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CSR_GATHER, s, 0, (relu_gate ? 12.0 : 8.0) * rows * cols);
-    hipLaunchKernelGGL(csr_gather_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows,
-                       cols);
+    EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
+    if (cols <= 256)
+        hipLaunchKernelGGL(csr_gather_kernel<1>, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows, cols);
+    else if (cols <= 1024)
+        hipLaunchKernelGGL(csr_gather_kernel<4>, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows, cols);
+    else
+        hipLaunchKernelGGL(csr_gather_kernel<16>, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows, cols);
     return check_launch("egk_csr_gather");
 }
 

@@ -198,17 +198,27 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const float* __restrict_
 }
 
 // out_a[c] += sum_b ws[b][0][c]; out_b[c] += sum_b ws[b][1][c]   (fixed order)
+// workgroup = 64 columns x 4 row groups; the 4 partial sums of a column are combined in LDS in group order.
 __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __restrict__ ws, float* __restrict__ oa,
                                                               float* __restrict__ ob, int nblk, int cols) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[2][4][64];
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cg;
     float a = 0.f, d = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        a += ws[((long long)k * 2 + 0) * cols + c];
-        d += ws[((long long)k * 2 + 1) * cols + c];
+    if (c < cols)
+        for (int k = rg; k < nblk; k += 4) {
+            a += ws[((long long)k * 2 + 0) * cols + c];
+            d += ws[((long long)k * 2 + 1) * cols + c];
+        }
+    red[0][rg][cg] = a;
+    red[1][rg][cg] = d;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        a = (red[0][0][cg] + red[0][1][cg]) + (red[0][2][cg] + red[0][3][cg]);
+        d = (red[1][0][cg] + red[1][1][cg]) + (red[1][2][cg] + red[1][3][cg]);
+        if (oa) oa[c] += a;
+        if (ob) ob[c] += d;
     }
-    if (oa) oa[c] += a;
-    if (ob) ob[c] += d;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -258,22 +268,34 @@ __global__ __launch_bounds__(256) void graphln_stats_kernel(const float* __restr
     }
 }
 
-// every workgroup re-derives (mean, 1/(std+eps)) of every segment from the partials (fixed order)
+// block-wide sum of the per-workgroup double partials ws[k][sg][j], k < nblk, in a fixed order
+// (thread-strided partial sums, wave shuffle tree, 4 waves combined in wave order): bitwise reproducible.
+__device__ __forceinline__ double block_sum_partials(const double* __restrict__ ws, int nblk, int n_seg, int sg, int j,
+                                                     double* scratch /* [4] */) {
+    double v = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 256) v += ws[((long long)k * n_seg + sg) * 2 + j];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// every workgroup re-derives (mean, 1/(std+eps)) of every segment from the partials
 __device__ __forceinline__ void graphln_finish_stats(const double* __restrict__ ws, int nblk, const int* __restrict__ seg_ptr,
                                                      int n_seg, int cols, float eps, float (*st)[2]) {
-    if (threadIdx.x < n_seg) {
-        const int sg = threadIdx.x;
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < nblk; ++k) {
-            s += ws[((long long)k * n_seg + sg) * 2 + 0];
-            q += ws[((long long)k * n_seg + sg) * 2 + 1];
+    __shared__ double scratch[4];
+    for (int sg = 0; sg < n_seg; ++sg) {
+        const double s = block_sum_partials(ws, nblk, n_seg, sg, 0, scratch);
+        const double q = block_sum_partials(ws, nblk, n_seg, sg, 1, scratch);
+        if (threadIdx.x == 0) {
+            const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
+            const double mu = n > 0 ? s / n : 0.0;
+            double var = n > 0 ? q / n - mu * mu : 0.0;
+            if (var < 0) var = 0;
+            st[sg][0] = (float)mu;
+            st[sg][1] = (float)(1.0 / (sqrt(var) + (double)eps));
         }
-        const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
-        const double mu = n > 0 ? s / n : 0.0;
-        double var = n > 0 ? q / n - mu * mu : 0.0;
-        if (var < 0) var = 0;
-        st[sg][0] = (float)mu;
-        st[sg][1] = (float)(1.0 / (sqrt(var) + (double)eps));
     }
     __syncthreads();
 }
@@ -388,20 +410,19 @@ __global__ __launch_bounds__(256) void graphln_bwd_kernel(const float* __restric
                                                           float eps, float slope, const double* __restrict__ ws_seg,
                                                           int nblk_stats) {
     __shared__ float sc[MAXSEG][4];  // mean, r, r*S1/n, S2/(n*sigma)
-    if (threadIdx.x < n_seg) {
-        const int sg = threadIdx.x;
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nblk_stats; ++k) {
-            s1 += ws_seg[((long long)k * n_seg + sg) * 2 + 0];
-            s2 += ws_seg[((long long)k * n_seg + sg) * 2 + 1];
+    __shared__ double scratch[4];
+    for (int sg = 0; sg < n_seg; ++sg) {
+        const double s1 = block_sum_partials(ws_seg, nblk_stats, n_seg, sg, 0, scratch);
+        const double s2 = block_sum_partials(ws_seg, nblk_stats, n_seg, sg, 1, scratch);
+        if (threadIdx.x == 0) {
+            const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
+            const double r = stats[sg * 2 + 1];
+            const double sigma = 1.0 / r - (double)eps;
+            sc[sg][0] = stats[sg * 2 + 0];
+            sc[sg][1] = (float)r;
+            sc[sg][2] = n > 0 ? (float)(r * s1 / n) : 0.f;
+            sc[sg][3] = (n > 0 && sigma > 0) ? (float)(s2 / (n * sigma)) : 0.f;
         }
-        const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
-        const double r = stats[sg * 2 + 1];
-        const double sigma = 1.0 / r - (double)eps;
-        sc[sg][0] = stats[sg * 2 + 0];
-        sc[sg][1] = (float)r;
-        sc[sg][2] = n > 0 ? (float)(r * s1 / n) : 0.f;
-        sc[sg][3] = (n > 0 && sigma > 0) ? (float)(s2 / (n * sigma)) : 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -457,7 +478,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 
 static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
-static inline int row_grid(int rows) {
+static inline int row_grid(int rows) {  // <= 2 workgroups per CU: keeps the partial buffers small
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > 512 ? 512 : g);
 }
@@ -530,7 +551,7 @@ int egk_rowln_bwd(egk_stream_t stream, const float* dy, const float* x, const fl
     }
     {
         ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, ws, dw, db, grid, cols);
     }
     return check_launch("egk_rowln_bwd");
 }
@@ -583,7 +604,7 @@ int egk_graphln_bwd(egk_stream_t stream, const float* dy, const float* x, const 
     }
     if (dw || db) {
         ProfScope prof(KID_GRAPHLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
     }
     return check_launch("egk_graphln_bwd");
 }

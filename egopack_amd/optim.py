@@ -37,7 +37,6 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_scale = 1.0
         self._hyper = None
-        self._hyper_host = None
 
     # -- construction of the flat buffers (first step, once the set of live gradients is known) -------
     def _materialise(self):
@@ -65,7 +64,6 @@ class FlatAdam(torch.optim.Optimizer):
                 off += sz
         self.active = live
         self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
 
     @property
     def materialised(self) -> bool:
@@ -82,11 +80,15 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         t = self.step_count + 1
         b1, b2 = g["betas"]
-        self._hyper_host[0] = g["lr"]
-        self._hyper_host[1] = 1.0 - b1 ** t
-        self._hyper_host[2] = math.sqrt(1.0 - b2 ** t)
-        self._hyper_host[3] = self.grad_scale
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        # a FRESH pinned staging buffer per step: torch's caching host allocator does not hand a pinned
+        # block out again before the async copy that read it has completed, so a later step can never
+        # overwrite values an earlier, still queued, copy is about to read.
+        host = torch.empty(4, dtype=torch.float32, pin_memory=True)
+        host[0] = g["lr"]
+        host[1] = 1.0 - b1 ** t
+        host[2] = math.sqrt(1.0 - b2 ** t)
+        host[3] = self.grad_scale
+        self._hyper.copy_(host, non_blocking=True)
 
     def launch(self):
         """The kernel launch alone (capturable)."""

@@ -71,10 +71,39 @@ def test_graph_forward_backward_vs_reference(A, golden, mode, tol, case):
         if mode == "f32":
             torch.testing.assert_close(named[k].grad.cpu(), g, rtol=2e-3, atol=2e-3, msg=lambda s: f"{k}: {s}")
         else:
-            # bf16 operands through ~12 chained contractions: per-element errors scale with the tensor, so the
-            # gradient check is the relative Frobenius error of the whole tensor (< 6 %)
+            # bf16 operands through ~15 chained contractions, 5 normalisations and ReLU / LeakyReLU gates that
+            # flip for near-zero pre-activations: per-element errors scale with the tensor, so the gradient check
+            # is the relative Frobenius error of the whole tensor.  At these toy widths (H=32, <= 44 nodes) a
+            # single flipped gate is a visible fraction of a gradient: bound 20 % here; the moderate-size test
+            # below bounds it much tighter where errors average out.
             rel = (named[k].grad.cpu() - g).norm() / g.norm().clamp(min=1e-6)
-            assert rel < 6e-2, f"{k}: relative error {rel:.3f}"
+            assert rel < 0.2, f"{k}: relative error {rel:.3f}"
+
+
+def test_bf16_backbone_vs_oracle_moderate_size(A):
+    """bf16 MFMA mode against the fp32 CPU oracle at a width where rounding noise averages out
+    (F=128, S=3, Hp=H=256, 8 sequences x 16 nodes): features within 3 % and every parameter gradient
+    within 8 % relative Frobenius error."""
+    torch.manual_seed(0)
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": 256}
+    m = A.Graph(128, hidden_size=256, depth=3, temporal_pooling=trn, num_segments=3)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    ds = A.data.SyntheticTaskDataset("pnr", 8, 16, 3, 128, k=1, seed=9)
+    host = A.data.collate([ds[i] for i in range(8)])
+    w = torch.randn(128, 256)
+    leaf = {k: (v.clone().requires_grad_(True) if not k.endswith("frequency") else v) for k, v in sd.items()}
+    ref = O.graph_forward(leaf, host.x, host.pos, host.edge_index, 3)
+    (ref * w).sum().backward()
+    m = m.to(DEV)
+    with A.ops.compute_mode("bf16"):
+        out = m(host.to(DEV))
+        (out * w.to(DEV)).sum().backward()
+    rel = (out.detach().cpu() - ref.detach()).norm() / ref.detach().norm()
+    assert rel < 3e-2, f"features: {rel:.4f}"
+    for k, p in m.named_parameters():
+        g = leaf[k].grad
+        r = (p.grad.cpu() - g).norm() / g.norm().clamp(min=1e-6)
+        assert r < 8e-2, f"{k}: {r:.4f}"
 
 
 def test_graph_accepts_plain_batch_without_csr(A, golden):
