@@ -1,0 +1,115 @@
+"""Shared pieces of the two entry points (main_temporal.py / main_egopack.py): config loading, dataset
+and loader construction, checkpoints with the reference's key layout, schedulers, per-epoch loops."""
+from __future__ import annotations
+
+import logging
+import os
+import sys
+from pathlib import Path
+from typing import Dict, Optional
+
+import torch
+
+from . import data as D
+from . import dist as edist
+from . import ops
+from .config import Cfg, compose, instantiate
+from .criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper
+from .optim import FlatAdam
+
+logger = logging.getLogger("egopack")
+TASKS = ("ar", "oscc", "lta", "pnr")
+CKPT_KEYS = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
+DSET_GROUP = {"ar": "dataset_recognition", "oscc": "dataset_oscc", "lta": "dataset_lta", "pnr": "dataset_pnr"}
+
+
+def load_config(argv=None, config_dir: Optional[Path] = None) -> Cfg:
+    """``python main_*.py key=value group/sub=name ...`` (Hydra override syntax)."""
+    argv = sys.argv[1:] if argv is None else argv
+    config_dir = config_dir or Path(__file__).resolve().parents[1] / "configs"
+    return compose(config_dir, "defaults", [a for a in argv if "=" in a])
+
+
+def seed_everything(cfg, rank: int):
+    if cfg.seed > 0:
+        import numpy as np
+        np.random.seed(cfg.seed)
+        torch.manual_seed(cfg.seed)  # identical parameter init on every rank
+        ops.manual_seed(cfg.seed * 7919 + rank)  # dropout streams differ per rank
+
+
+def task_weights(cfg) -> Dict[str, float]:
+    return {t: float(cfg[f"weight_{t}"]) if t in cfg.enabled_tasks else 0.0 for t in TASKS}
+
+
+def build_datasets(cfg, split: str):
+    """One dataset per task with the reference's transforms: RadiusGraph(r=k+0.5) for AR / OSCC / PNR,
+    LTATemporalConnectivity(r=k+0.5) for LTA (main_temporal.py:168-235)."""
+    out = {}
+    for t in TASKS:
+        tf = D.LTATemporalConnectivity(r=cfg.k + 0.5, loop=False) if t == "lta" else D.RadiusGraph(r=cfg.k + 0.5, loop=False)
+        dcfg = dict(cfg[DSET_GROUP[t]])
+        if dcfg["_target_"].endswith("SyntheticTaskDataset"):
+            dcfg.update(length=cfg.synthetic_samples if split == "train" else max(cfg.synthetic_samples // 4, 1),
+                        seed=cfg.seed + (0 if split == "train" else 10_000), k=cfg.k)
+            out[t] = instantiate(dcfg, transform=tf)
+        else:
+            out[t] = instantiate(dcfg, split=split, transform=tf)
+    return out
+
+
+def build_loaders(cfg, dsets, train: bool, rank: int, world: int, batch_size: Optional[int] = None):
+    bs = batch_size or cfg.batch_size
+    return {t: D.build_dataloader(ds, bs, train, cfg.num_workers, train, seed=cfg.seed, rank=rank, world_size=world)
+            for t, ds in dsets.items()}
+
+
+def build_criteria(dsets):
+    return {"ar": MetricSelectorWrapper(CrossEntropyNone(), dsets["ar"]),
+            "lta": MetricSelectorWrapper(CrossEntropyNone(), dsets["lta"]),
+            "oscc": CrossEntropyNone(), "pnr": BCEWithLogitsNone()}
+
+
+def build_optimizer(cfg, params):
+    """``_target_: torch.optim.Adam`` of the config is served by the flat-buffer Adam (same arithmetic)."""
+    ocfg = dict(cfg.optimizer)
+    target = ocfg.pop("_target_")
+    if target != "torch.optim.Adam":
+        raise ValueError(f"optimizer {target}: only torch.optim.Adam is on the hot path")
+    return FlatAdam(params, **ocfg)
+
+
+def build_scheduler(cfg, optimizer):
+    sched = instantiate(cfg.lr_scheduler, optimizer=optimizer)
+    if cfg.use_warmup:
+        sched = torch.optim.lr_scheduler.ChainedScheduler(
+            [torch.optim.lr_scheduler.LinearLR(optimizer, 0.001, 1, 5), sched])
+    return sched
+
+
+def save_checkpoint(path: Path, model, tasks, epoch: int, graphone=None, optimizer=None):
+    """Reference key layout (main_temporal.py:410-417, main_egopack.py:453-460) + optional optimiser state."""
+    path.parent.mkdir(parents=True, exist_ok=True)
+    ckpt = {"temporal_graph": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "epoch": epoch}
+    for t, key in CKPT_KEYS.items():
+        ckpt[key] = {k: v.detach().cpu().clone() for k, v in tasks[t].state_dict().items()}
+    if graphone is not None:
+        ckpt["graphone"] = {k: v.detach().cpu().clone() for k, v in graphone.state_dict().items()}
+    if optimizer is not None and getattr(optimizer, "materialised", False):
+        ckpt["optimizer"] = {"m": optimizer.flat_m.cpu(), "v": optimizer.flat_v.cpu(), "step": optimizer.step_count}
+    torch.save(ckpt, path)
+    logger.info("saved %s", path)
+
+
+def load_checkpoint(path, model, tasks, strict_tasks: bool = True, device="cpu"):
+    ckpt = torch.load(path, map_location=device, weights_only=False)
+    model.load_state_dict(ckpt["temporal_graph"])
+    for t, key in CKPT_KEYS.items():
+        if ckpt.get(key) is not None:
+            tasks[t].load_state_dict(ckpt[key], strict=strict_tasks)
+    return ckpt
+
+
+def setup_logging(rank: int):
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING,
+                        format="[%(asctime)s][%(name)s][%(levelname)s] %(message)s")

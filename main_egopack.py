@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""EgoPack novel-task training (entry point of the reference's main_egopack.py).
+
+    python main_egopack.py enable_graphone=True resume_from=checkpoints/MTL_ar-lta-pnr/checkpoint.pth \
+        enabled_tasks=[oscc] graphone.k=4 graphone.depth=3 graphone.residual=True
+
+Loads the multi-task checkpoint (task heads with strict=False: the auxiliary classifiers are new),
+builds the frozen per-task prototype banks with ``build_graphone`` over the AR training set
+(batch 256, shuffle False, drop_last True), wraps them in ``GraphONE`` and trains the novel task with
+late fusion.  ``resume_from`` is a local checkpoint path; as in the reference its STRING also selects
+which tasks feed the prototype banks (substring match on the task names, main_egopack.py:301)."""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import torch
+
+from egopack_amd import dist as edist
+from egopack_amd import engine, ops, train as T
+from egopack_amd.config import instantiate
+from egopack_amd.data import build_dataloader, multiloader
+from graphone import build_graphone
+from models.graphONE.graphONE import GraphONE
+from models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+
+logger = logging.getLogger("main_egopack")
+
+
+def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda"):
+    """One epoch (reference main_egopack.train :64-159)."""
+    order = ("ar", "lta", "oscc", "pnr")
+    it = 0
+    for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]):
+        batches = {t: b.to(device) for t, b in zip(order, batch) if b is not None}
+        total, _ = step.step(batches)
+        it += 1
+    logger.info("epoch %d: %d iterations, last objective %.4f", epoch, it, float(total))
+    return it
+
+
+def main(argv=None):
+    cfg = T.load_config(argv)
+    if not cfg.enable_graphone:
+        logging.warning("Invalid configuration. Aborting!")
+        return
+    rank, local_rank, world = edist.init_from_env()
+    T.setup_logging(rank)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    T.seed_everything(cfg, rank)
+    ops.set_compute(cfg.compute)
+    weights = T.task_weights(cfg)
+
+    dsets_train = T.build_datasets(cfg, "train")
+    dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
+    H = cfg.model.hidden_size
+    model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,
+                        num_segments=cfg.dataset_recognition.num_segments, _recursive_=False).to(device)
+    kw = dict(dropout=cfg.task_dropout, head_dropout=cfg.task_head_dropout)
+    tasks = {
+        "ar": RecognitionTask(H, H, heads=dsets_train["ar"].num_class_labels, aux_tasks=("oscc", "lta", "pnr"), **kw),
+        "oscc": OSCCTask(H, H, aux_tasks=("ar", "lta", "pnr"), average_logits=True, **kw),
+        "lta": LTATask(H, H, heads=dsets_train["lta"].num_class_labels, aux_tasks=("ar", "oscc", "pnr"), **kw),
+        "pnr": PNRTask(H, H, aux_tasks=("ar", "oscc", "lta"), **kw),
+    }
+    for t in tasks.values():
+        t.to(device)
+    if cfg.resume_from:
+        logger.info("resuming from %s", cfg.resume_from)
+        T.load_checkpoint(cfg.resume_from, model, tasks, strict_tasks=False, device=device)
+
+    bank_tasks = [tasks[t] for t in ("ar", "oscc", "lta", "pnr") if tasks[t].name in str(cfg.resume_from)]
+    banks = build_graphone(model, tasks["ar"], bank_tasks,
+                           dataloader=build_dataloader(dsets_train["ar"], 256, False, cfg.num_workers, True, cfg.seed),
+                           device=device)
+    graphone = GraphONE(banks, **cfg.graphone).to(device)
+
+    wd = cfg.optimizer.weight_decay
+    params = [*model.configure_optimizers(wd), *(p for t in ("ar", "oscc", "lta", "pnr") for p in tasks[t].configure_optimizers(wd)),
+              *graphone.parameters()]
+    optimizer = T.build_optimizer(cfg, params)
+    scheduler = T.build_scheduler(cfg, optimizer)
+    sync = edist.GradSync(world) if world > 1 else None
+    step = engine.EgoPackStep(model, tasks, graphone, weights, optimizer,
+                              backprop_temporal_graph=cfg.backprop_temporal_graph,
+                              temporal_graph_train_mode=cfg.temporal_graph_train_mode, sync=sync)
+    for epoch in range(1, cfg.num_epochs + 1):
+        train(epoch, step, dl_train, weights, device)
+        scheduler.step()
+    if cfg.save_model and rank == 0:
+        name = f"{cfg.artifact_prefix}_egopack_" + "-".join(sorted(t for t, w in weights.items() if w > 0))
+        T.save_checkpoint(Path(cfg.checkpoint_dir) / name / "checkpoint.pth", model, tasks, cfg.num_epochs,
+                          graphone=graphone, optimizer=optimizer)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

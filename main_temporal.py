@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Multi-task pre-training of the temporal backbone (entry point of the reference's main_temporal.py).
+
+    python main_temporal.py k=1 batch_size=16 num_epochs=40 model.temporal_pooling.hidden_size=1024 \
+        enabled_tasks=[ar,lta,pnr] save_model=True
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 main_temporal.py ...      # data parallel
+
+Same configuration keys and training semantics as the reference (zero_grad -> backbone forward for
+every enabled task batch -> head -> weight * loss.mean() summed -> backward -> Adam; cosine schedule
+stepped per epoch; ``multiloader`` restarts exhausted loaders).  W&B logging, torchmetrics meters and
+the task-metric validation of the last epochs are outside the hot path: per-task
+validation LOSSES are reported instead, and checkpoints are written locally with the reference's
+key layout."""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import torch
+
+from egopack_amd import dist as edist
+from egopack_amd import engine, ops, train as T
+from egopack_amd.config import instantiate
+from egopack_amd.data import multiloader
+from models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+
+logger = logging.getLogger("main_temporal")
+
+
+def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
+    """One epoch (reference main_temporal.train :49-134)."""
+    step.model.train()
+    for t in step.tasks.values():
+        t.train()
+    order = ("ar", "lta", "oscc", "pnr")
+    it, sums, counts = 0, {t: 0.0 for t in order}, {t: 0 for t in order}
+    for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]):
+        batches = {t: b.to(device, non_blocking=True) for t, b in zip(order, batch) if b is not None}
+        total, vectors = step.step(batches)
+        for t, v in vectors.items():
+            sums[t] += float(v.sum())
+            counts[t] += v.numel()
+        it += 1
+    logger.info("epoch %d: %d iterations, train loss %s", epoch, it,
+                {t: round(sums[t] / max(counts[t], 1), 4) for t in order if counts[t]})
+    return it
+
+
+@torch.no_grad()
+def validate_losses(step: engine.MTLStep, loaders, device="cuda"):
+    step.model.eval()
+    for t in step.tasks.values():
+        t.eval()
+    out = {}
+    for t in step.enabled:
+        s, n = 0.0, 0
+        for b in loaders[t]:
+            _, vectors, _ = step.losses({t: b.to(device)})
+            s += float(vectors[t].sum())
+            n += vectors[t].numel()
+        out[t] = s / max(n, 1)
+    return out
+
+
+def main(argv=None):
+    cfg = T.load_config(argv)
+    rank, local_rank, world = edist.init_from_env()
+    T.setup_logging(rank)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    T.seed_everything(cfg, rank)
+    ops.set_compute(cfg.compute)
+    weights = T.task_weights(cfg)
+    logger.info("task weights: %s", weights)
+    artifact = f"{cfg.artifact_prefix}_" + "-".join(sorted(t for t, w in weights.items() if w > 0))
+
+    dsets_train, dsets_val = T.build_datasets(cfg, "train"), T.build_datasets(cfg, cfg.validation_split)
+    assert len({d.features_size for d in dsets_train.values()}) == 1, "all tasks must share the input feature size"
+    dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
+    dl_val = T.build_loaders(cfg, dsets_val, False, 0, 1)
+
+    H = cfg.model.hidden_size
+    model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,
+                        num_segments=cfg.dataset_recognition.num_segments, _recursive_=False).to(device)
+    tasks = {
+        "ar": RecognitionTask(H, H, heads=dsets_train["ar"].num_class_labels, dropout=cfg.task_dropout, head_dropout=cfg.task_head_dropout),
+        "oscc": OSCCTask(H, cfg.oscc_feat_size, dropout=cfg.task_dropout, head_dropout=cfg.task_head_dropout, loss_func=cfg.oscc_loss),
+        "lta": LTATask(H, H, heads=dsets_train["lta"].num_class_labels, dropout=cfg.task_dropout, head_dropout=cfg.task_head_dropout),
+        "pnr": PNRTask(H, H, dropout=cfg.task_dropout, head_dropout=cfg.task_head_dropout),
+    }
+    for t in tasks.values():
+        t.to(device)
+    wd = cfg.optimizer.weight_decay
+    params = [*model.configure_optimizers(wd), *(p for t in ("ar", "oscc", "lta", "pnr") for p in tasks[t].configure_optimizers(wd))]
+    if world > 1:
+        for p in params:  # same start everywhere (seeded identically; broadcast makes it unconditional)
+            torch.distributed.broadcast(p.data, src=0)
+    optimizer = T.build_optimizer(cfg, params)
+    scheduler = T.build_scheduler(cfg, optimizer)
+    sync = edist.GradSync(world) if world > 1 else None
+    step = engine.MTLStep(model, tasks, T.build_criteria(dsets_train), weights, optimizer,
+                          fused_backbone=cfg.fused_backbone, sync=sync)
+
+    for epoch in range(1, cfg.num_epochs + 1):
+        train(epoch, step, dl_train, weights, device)
+        scheduler.step()
+        logger.info("learning rate -> %.6g", scheduler.get_last_lr()[0])
+        if epoch >= cfg.num_epochs - 5 and rank == 0:
+            logger.info("validation losses: %s", validate_losses(step, dl_val, device))
+    if cfg.save_model and rank == 0:
+        T.save_checkpoint(Path(cfg.checkpoint_dir) / artifact / "checkpoint.pth", model, tasks, cfg.num_epochs,
+                          optimizer=optimizer)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
