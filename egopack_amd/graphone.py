@@ -40,5 +40,8 @@ def build_graphone(model, ar_task, tasks: List, dataloader, device="cuda") -> Di
             # per-label mean divided by len(tasks).  Kept for parity (prototypes are L2-normalised downstream).
             ops.scatter_add_rows_f64(t.forward_features(feat), labels, banks[t.name], count)
     seen = count > 0
+    if not bool(seen.any()):
+        raise RuntimeError("build_graphone: the loader produced no labelled node (empty loader? the reference uses "
+                           "batch 256 with drop_last=True, so the AR split needs at least 256 samples)")
     cnt = count[seen].to(torch.float64).unsqueeze(1)
     return {name: (bank[seen] / cnt).float() for name, bank in banks.items()}

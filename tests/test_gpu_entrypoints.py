@@ -22,6 +22,7 @@ def test_main_temporal_then_main_egopack(tmp_path):
     assert {"temporal_graph", "task/recognition", "task/oscc", "task/lta", "task/pnr", "epoch"} <= set(ckpt)
     assert "net.module_0.lin_l.weight" in ckpt["temporal_graph"] and ckpt["epoch"] == 2
     assert all(torch.isfinite(v).all() for v in ckpt["temporal_graph"].values())
+    common[3] = "synthetic_samples=256"  # build_graphone reads the AR split with batch 256, drop_last=True
     main_egopack.main(common + ["enabled_tasks=[oscc]", "enable_graphone=True", f"resume_from={ckpt_path}", "graphone.k=4",
                                 "graphone.depth=2", "graphone.residual=True", "graphone.hidden_size=64",
                                 "+graphone.features_size=64", "artifact_prefix=EGO"])
