@@ -63,6 +63,8 @@ def build_workload(args, rank, device):
         b.x = torch.empty(0)
         d = b.to(device)
         d.x = torch.randn(args.batch * args.T, S, F_IN, device=device, generator=gen)
+        if args.compute == "bf16":  # Omnivore features stored in bf16 for the bf16 configs
+            d.x = d.x.to(torch.bfloat16)
         dev[t] = d
     merged = D.merge_batches([host[t] for t in ("ar", "lta", "pnr")]).to(device)
     merged.x = [dev[t].x for t in ("ar", "lta", "pnr")]
@@ -101,7 +103,7 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=16, budget_s=20.0):
         ei = d.edge_index.cpu()
         ei = ei[:, (ei[0] < rows) & (ei[1] < rows)]
         y = d.y.cpu()
-        batches[t] = P.OData(x=d.x[:rows].cpu(), pos=d.pos[:rows].cpu(), edge_index=ei, batch=d.batch[:rows].cpu(),
+        batches[t] = P.OData(x=d.x[:rows].float().cpu(), pos=d.pos[:rows].cpu(), edge_index=ei, batch=d.batch[:rows].cpu(),
                              y=y[:b] if y.shape[0] == B else y[:rows], num_graphs=b)
     flat = [p for g in leaf.values() for p in g.values() if p.requires_grad]
     opt = torch.optim.Adam(flat, lr=1e-5, weight_decay=1e-5)
@@ -171,7 +173,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--trn-hidden", type=int, default=1024)
     ap.add_argument("--dropout", type=float, default=0.5)
-    ap.add_argument("--compute", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--compute", choices=["bf16", "bf16_f32act", "f32"], default="bf16")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--no-fused-backbone", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -256,14 +258,15 @@ def main():
             "metric": "clip-seqs/sec training, AR+LTA+PNR multi-task", "value": seqs_per_step / (ms * 1e-3),
             "unit": "clip-seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
+            "dtype": "f32" if args.compute == "f32" else "bf16", "data": "synthetic",
             "config": {"workload": f"MTL pre-train AR+LTA+PNR, per GPU B={args.batch} seqs/task x T={args.T} nodes, "
                                    f"3x1536-d Omnivore-shaped features, H={args.hidden}, TRN hidden {args.trn_hidden} "
                                    f"(dropout {args.dropout}), depth 3, k=1, Adam; {args.mode} mode, "
                                    f"{'fused' if not args.no_fused_backbone else 'per-task'} backbone pass",
                        "global_batch": seqs_per_step, "nodes_per_step": seqs_per_step * args.T,
                        "parallelism": f"dp{world}", "trainable_params": n_params,
-                       "master_weights": "f32", "mfma": args.compute},
+                       "master_weights": "f32", "mode": args.compute,
+                       "activations": "bf16" if args.compute == "bf16" else "f32"},
             "roofline": rl, "cpu_baseline": cb,
         }
         if args.kernel_table and table:

@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("compute", i32),
         ("C", vp), ("ldc", i64), ("c_dtype", i32),
         ("accumulate", i32), ("act", i32), ("alpha", f32),
-        ("bias", vp), ("residual", vp), ("ldr", i64),
+        ("bias", vp), ("residual", vp), ("ldr", i64), ("r_dtype", i32),
         ("splitk", i32), ("ws", vp), ("ws_bytes", i64),
     ]
 
@@ -49,34 +49,35 @@ SIGNATURES = {
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
     "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),
     "egk_colsum_ws_len": (C.c_int, [i32, i32]),
-    "egk_colsum": (C.c_int, [vp, vp, i64, i32, i32, vp, i32, vp]),
-    "egk_rowln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, f32, u64, u64, vp]),
+    "egk_colsum": (C.c_int, [vp, vp, i64, i32, i32, vp, i32, vp, i32]),
+    "egk_rowln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, f32, u64, u64, vp, i32]),
     "egk_rowln_bwd_ws_rows": (C.c_int, [i32]),
-    "egk_rowln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32]),
+    "egk_rowln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
     "egk_graphln_ws_bytes": (i64, [i32, i32, i32]),
-    "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp]),
-    "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp]),
-    "egk_pe_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
-    "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32]),
-    "egk_gather_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),
-    "egk_gather_max_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32]),
-    "egk_segment_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
-    "egk_segment_max_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
-    "egk_row_inv_norm": (C.c_int, [vp, vp, vp, i32, i32]),
+    "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
+    "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
+    "egk_pe_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
+    "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32]),
+    "egk_gather_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    "egk_gather_max_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),
+    "egk_segment_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
+    "egk_segment_max_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    "egk_row_inv_norm": (C.c_int, [vp, vp, vp, i32, i32, i32]),
     "egk_cos_dist": (C.c_int, [vp, vp, i64, vp, vp, vp, i32, i32]),
     "egk_topk_smallest": (C.c_int, [vp, vp, i64, vp, vp, vp, i32, i32, i32]),
-    "egk_scatter_add_rows_f64": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64]),
+    "egk_scatter_add_rows_f64": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i32]),
     "egk_ce_fwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, i32, i32, f32, i32]),
-    "egk_ce_bwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, f32]),
+    "egk_ce_bwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, f32, i32]),
     "egk_bce_fwd": (C.c_int, [vp, vp, vp, vp, i32]),
-    "egk_bce_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32]),
-    "egk_dropout_fwd": (C.c_int, [vp, vp, vp, vp, i64, f32, u64, u64, vp]),
-    "egk_dropout_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32]),
-    "egk_relu_gate": (C.c_int, [vp, vp, vp, vp, i64]),
+    "egk_bce_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
+    "egk_dropout_fwd": (C.c_int, [vp, vp, vp, vp, i64, f32, u64, u64, vp, i32]),
+    "egk_dropout_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32, i32]),
+    "egk_relu_gate": (C.c_int, [vp, vp, vp, vp, i64, i32]),
+    "egk_cast": (C.c_int, [vp, vp, i32, vp, i32, i64]),
     "egk_axpby": (C.c_int, [vp, vp, vp, vp, i64, f32, f32]),
     "egk_fill_scaled": (C.c_int, [vp, vp, f32, vp, i64]),
     "egk_sum_scale": (C.c_int, [vp, vp, vp, i64, f32, i32]),
-    "egk_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32]),
+    "egk_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]),
 }
 
 

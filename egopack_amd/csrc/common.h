@@ -63,6 +63,7 @@ enum KernelId {
     KID_DROPOUT_FWD,
     KID_DROPOUT_BWD,
     KID_RELU_GATE,
+    KID_CAST,
     KID_AXPBY,
     KID_SUM_SCALE,
     KID_ADAM,
@@ -121,5 +122,71 @@ __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- activation element types: float or bf16 (stored as unsigned short), always computed in f32 -------------
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+
+// 4 consecutive elements starting at column c of a row (zero beyond cols); vec = aligned wide access allowed
+__device__ __forceinline__ float4 ld4t(const float* __restrict__ p, int c, int cols, bool vec) {
+    if (vec && c + 4 <= cols) return *reinterpret_cast<const float4*>(p + c);
+    float4 v;
+    v.x = c + 0 < cols ? p[c + 0] : 0.f;
+    v.y = c + 1 < cols ? p[c + 1] : 0.f;
+    v.z = c + 2 < cols ? p[c + 2] : 0.f;
+    v.w = c + 3 < cols ? p[c + 3] : 0.f;
+    return v;
+}
+__device__ __forceinline__ float4 ld4t(const bf16_t* __restrict__ p, int c, int cols, bool vec) {
+    float4 v;
+    if (vec && c + 4 <= cols) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p + c);
+        v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
+        v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
+        return v;
+    }
+    v.x = c + 0 < cols ? bf2f(p[c + 0]) : 0.f;
+    v.y = c + 1 < cols ? bf2f(p[c + 1]) : 0.f;
+    v.z = c + 2 < cols ? bf2f(p[c + 2]) : 0.f;
+    v.w = c + 3 < cols ? bf2f(p[c + 3]) : 0.f;
+    return v;
+}
+__device__ __forceinline__ void st4t(float* __restrict__ p, int c, int cols, bool vec, float4 v) {
+    if (vec && c + 4 <= cols) {
+        *reinterpret_cast<float4*>(p + c) = v;
+        return;
+    }
+    if (c + 0 < cols) p[c + 0] = v.x;
+    if (c + 1 < cols) p[c + 1] = v.y;
+    if (c + 2 < cols) p[c + 2] = v.z;
+    if (c + 3 < cols) p[c + 3] = v.w;
+}
+__device__ __forceinline__ void st4t(bf16_t* __restrict__ p, int c, int cols, bool vec, float4 v) {
+    if (vec && c + 4 <= cols) {
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+        *reinterpret_cast<uint2*>(p + c) = pk;
+        return;
+    }
+    if (c + 0 < cols) p[c + 0] = f2bf(v.x);
+    if (c + 1 < cols) p[c + 1] = f2bf(v.y);
+    if (c + 2 < cols) p[c + 2] = f2bf(v.z);
+    if (c + 3 < cols) p[c + 3] = f2bf(v.w);
+}
+__device__ __forceinline__ float ld1t(const float* p) { return *p; }
+__device__ __forceinline__ float ld1t(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void st1t(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1t(bf16_t* p, float v) { *p = f2bf(v); }
+
+// host-side dispatch on an EGK_F32 / EGK_BF16 activation type: ``using T = ...`` inside CALL
+#define EGK_DISPATCH_T(dtype, ...)                                               \
+    do {                                                                         \
+        if ((dtype) == EGK_BF16) { using T = ::egk::bf16_t; __VA_ARGS__; }       \
+        else if ((dtype) == EGK_F32) { using T = float; __VA_ARGS__; }           \
+        else { ::egk::set_error("unknown activation dtype %d", (int)(dtype)); return EGK_EINVAL; } \
+    } while (0)
 
 }  // namespace egk

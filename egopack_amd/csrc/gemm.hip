@@ -2,28 +2,29 @@
 //
 // Geometry (one workgroup = 256 threads = 4 waves as 2(M) x 2(N); one output tile 128 x 128):
 //   * both operands are staged as K-contiguous LDS images  [128 rows][128 B]  whatever their
-//     layout in memory: a row-major operand is loaded 16/32 B per lane along K, a transposed
-//     operand ([K][rows] in memory: weights for dX, activations/gradients for dW) is loaded
-//     16 B per lane along its contiguous "rows" axis and transposed in registers, so no
-//     transposed copies of weights or activations ever exist in HBM;
-//   * f32 sources are converted to bf16 while staging (EGK_COMPUTE_BF16: v_mfma_f32_16x16x32_bf16,
-//     64-element K-tile) or kept (EGK_COMPUTE_F32: v_mfma_f32_16x16x4_f32, exact fmaf chain,
-//     32-element K-tile).  One 16-byte LDS chunk per lane feeds one bf16 MFMA or four f32 MFMAs;
-//   * the 16-byte chunk index of a row is XOR-swizzled with (row>>1)&7 so that the
-//     ds_read_b128 of a 16-lane group (16 rows, one chunk column) hits 16 distinct 16-B slots
-//     of the 256-B bank row (MI355X_MICROARCH.md, LDS table);
-//   * register prefetch: the global loads of K-tile t+1 are issued before the MFMAs of tile t
-//     and written to LDS after the barrier (T14 split), single LDS image of 32 KiB;
-//   * the MFMA is issued as D^T = B.A^T so each lane owns 4 CONSECUTIVE columns of one output
-//     row: bias / residual / C traffic is 16 B per lane;
-//   * blockIdx is remapped so that each XCD owns a contiguous range of M-tiles (the activation
-//     rows are the large operand; the weights are re-read from every XCD's L2).
+//     layout and element type in memory:
+//       - row-major f32   : 2 x 16-B loads per lane along K, converted to bf16 while staging
+//       - row-major bf16  : 1 x 16-B load per lane along K (no conversion: the fast path)
+//       - transposed f32  ([K][rows]): 16 B per lane along the contiguous "rows" axis, 4x8 register transpose
+//       - transposed bf16 ([K][rows]): 8 x 16-B loads per lane, 8x8 16-bit register transpose (v_perm_b32)
+//     so no transposed copies of weights, activations or gradients ever exist in HBM;
+//   * EGK_COMPUTE_BF16: v_mfma_f32_16x16x32_bf16 (64-element K-tile); EGK_COMPUTE_F32:
+//     v_mfma_f32_16x16x4_f32 on f32 operands (exact fmaf chain, 32-element K-tile).  One 16-byte LDS chunk
+//     per lane feeds one bf16 MFMA or four f32 MFMAs;
+//   * the 16-byte chunk index of a row is XOR-swizzled with (row>>1)&7 so that the ds_read_b128 of a
+//     16-lane group (16 rows, one chunk column) hits 16 distinct 16-B slots of the 256-B bank row;
+//   * register prefetch: the global loads of K-tile t+1 are issued before the MFMAs of tile t and written
+//     to LDS after the barrier (T14 split), single LDS image of 32 KiB;
+//   * the MFMA is issued as D^T = B.A^T so each lane owns 4 CONSECUTIVE columns of one output row: bias /
+//     residual / C traffic is 16 B (f32) or 8 B (bf16) per lane;
+//   * blockIdx is remapped so that each XCD owns a contiguous range of M-tiles.
 #include "common.h"
 
 namespace egk {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned short bf16_t;  // storage type of a bf16 element in memory
 
 constexpr int BM = 128, BN = 128, ROWB = 128;  // LDS row = 128 bytes = 8 chunks of 16 B
 constexpr int NTHREADS = 256;
@@ -31,19 +32,19 @@ constexpr int NTHREADS = 256;
 struct GemmArgs {
     int M, N;
     int K[2];
-    const float* A[2];
-    const float* B[2];
+    const void* A[2];
+    const void* B[2];
     long long lda[2], ldb[2];
     int a_vec[2], b_vec[2];  // 16-byte vector loads legal for this source
-    float* C;
+    void* C;
     long long ldc;
-    int c_vec;
+    int c_vec, c_bf16;
     int accumulate, act;
     float alpha;
     const float* bias;
-    const float* residual;
+    const void* residual;
     long long ldr;
-    int r_vec;
+    int r_vec, r_bf16;
     int splitk;
     float* ws;  // [splitk][M][N] partial slabs when splitk > 1
     int tiles_m, tiles_n;
@@ -57,42 +58,57 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
     return __builtin_bit_cast(uint4, v);
 }
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
-// Row-major operand ([rows][K], ld): chunk ids tid + 256*i -> (row = id>>3, chunk = id&7).
-template <bool BF16>
-__device__ __forceinline__ void load_rowmajor(const float* __restrict__ base, long long ld, int rows_total, int row0,
-                                              int k0, int klim, bool vec, uint4 (&out)[4]) {
-    constexpr int CE = BF16 ? 8 : 4;
+// ---- staging loaders: produce this thread's share of a [128 rows][KT] K-contiguous tile -------------------------
+
+// Row-major operand ([rows][K], ld): 4 slots: ids tid + 256*i -> (row = id>>3, chunk = id&7).
+template <bool BF16C, typename T>
+__device__ __forceinline__ void load_rowmajor(const T* __restrict__ base, long long ld, int rows_total, int row0, int k0,
+                                              int klim, bool vec, uint4 (&out)[8]) {
+    constexpr int CE = BF16C ? 8 : 4;  // elements per 16-byte LDS chunk
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = tid + NTHREADS * i;
         const int r = id >> 3, c = id & 7;
         const int grow = row0 + r, gk = k0 + c * CE;
-        float f[8];
         const bool row_ok = grow < rows_total;
-        const float* p = base + (long long)grow * ld + gk;
-        if (row_ok && vec && gk + CE <= klim) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p);
-            f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
-            if constexpr (BF16) {
-                const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
-                f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+        const T* p = base + (long long)grow * ld + gk;
+        if constexpr (sizeof(T) == 2) {  // bf16 in memory (BF16C only)
+            if (row_ok && vec && gk + 8 <= klim) out[i] = *reinterpret_cast<const uint4*>(p);
+            else {
+                unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (row_ok && gk + j < klim) w[j >> 1] |= (unsigned)p[j] << (16 * (j & 1));
+                out[i] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         } else {
+            float f[8];
+            if (row_ok && vec && gk + CE <= klim) {
+                const float4 v0 = *reinterpret_cast<const float4*>(p);
+                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+                if constexpr (BF16C) {
+                    const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+                    f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < CE; ++j) f[j] = (row_ok && gk + j < klim) ? p[j] : 0.0f;
+                for (int j = 0; j < CE; ++j) f[j] = (row_ok && gk + j < klim) ? p[j] : 0.0f;
+            }
+            if constexpr (BF16C) out[i] = pack8(f);
+            else out[i] = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
         }
-        if constexpr (BF16) out[i] = pack8(f);
-        else out[i] = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
     }
 }
 
-// Transposed operand ([K][rows], ld): thread -> row quad q = tid&31 (rows 4q..4q+3), chunk kc = tid>>5.
-template <bool BF16>
-__device__ __forceinline__ void load_transposed(const float* __restrict__ base, long long ld, int rows_total, int row0,
-                                                int k0, int klim, bool vec, uint4 (&out)[4]) {
-    constexpr int CE = BF16 ? 8 : 4;
+// Transposed f32 operand ([K][rows], ld): thread -> row quad q = tid&31 (rows 4q..4q+3), chunk kc = tid>>5: 4 slots.
+template <bool BF16C>
+__device__ __forceinline__ void load_transposed_f32(const float* __restrict__ base, long long ld, int rows_total, int row0,
+                                                    int k0, int klim, bool vec, uint4 (&out)[8]) {
+    constexpr int CE = BF16C ? 8 : 4;
     const int tid = threadIdx.x;
     const int q = tid & 31, kc = tid >> 5;
     const int grow = row0 + 4 * q, gk = k0 + kc * CE;
@@ -111,7 +127,7 @@ __device__ __forceinline__ void load_transposed(const float* __restrict__ base, 
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-        if constexpr (BF16) {
+        if constexpr (BF16C) {
             float t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) t[j] = f[j][rr];
@@ -123,30 +139,88 @@ __device__ __forceinline__ void load_transposed(const float* __restrict__ base, 
     }
 }
 
-template <bool TR>
-__device__ __forceinline__ void store_lds(unsigned char* lds, const uint4 (&v)[4]) {
+// Transposed bf16 operand ([K][rows], ld): an 8(k) x 8(rows) block per thread: row octet o = t&15, chunk kc = t>>4,
+// t = tid & 127 -- only HALF of the workgroup (``half`` = 0: waves 0-1, 1: waves 2-3) stages it: 8 slots.
+__device__ __forceinline__ void load_transposed_bf16(const bf16_t* __restrict__ base, long long ld, int rows_total, int row0,
+                                                     int k0, int klim, bool vec, int half, uint4 (&out)[8]) {
     const int tid = threadIdx.x;
+    if ((tid >> 7) != half) return;
+    const int t = tid & 127;
+    const int o = t & 15, kc = t >> 4;
+    const int grow = row0 + 8 * o, gk = k0 + kc * 8;
+    uint4 v[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int row, chunk;
-        if constexpr (TR) {
-            row = 4 * (tid & 31) + i;
-            chunk = tid >> 5;
-        } else {
-            const int id = tid + NTHREADS * i;
-            row = id >> 3;
-            chunk = id & 7;
+    for (int j = 0; j < 8; ++j) {
+        const bf16_t* p = base + (long long)(gk + j) * ld + grow;
+        const bool k_ok = gk + j < klim;
+        if (k_ok && vec && grow + 8 <= rows_total) v[j] = *reinterpret_cast<const uint4*>(p);
+        else {
+            unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                if (k_ok && grow + rr < rows_total) w[rr >> 1] |= (unsigned)p[rr] << (16 * (rr & 1));
+            v[j] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        *reinterpret_cast<uint4*>(lds + lds_off(row, chunk)) = v[i];
+    }
+    // out[r].dword[e] = { lo: v[2e] elem r, hi: v[2e+1] elem r }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        unsigned d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint4& lo = v[2 * e];
+            const uint4& hi = v[2 * e + 1];
+            const unsigned s1 = (r >> 1) == 0 ? lo.x : (r >> 1) == 1 ? lo.y : (r >> 1) == 2 ? lo.z : lo.w;
+            const unsigned s0 = (r >> 1) == 0 ? hi.x : (r >> 1) == 1 ? hi.y : (r >> 1) == 2 ? hi.z : hi.w;
+            d[e] = __builtin_amdgcn_perm(s0, s1, (r & 1) ? 0x07060302u : 0x05040100u);
+        }
+        out[r] = make_uint4(d[0], d[1], d[2], d[3]);
     }
 }
 
-template <bool BF16, bool TA, bool TB>
+// LDS store of what the matching loader produced.
+template <bool TR, bool MEM16>
+__device__ __forceinline__ void store_lds(unsigned char* lds, const uint4 (&v)[8], int half) {
+    const int tid = threadIdx.x;
+    if constexpr (TR && MEM16) {
+        if ((tid >> 7) != half) return;
+        const int t = tid & 127;
+        const int o = t & 15, kc = t >> 4;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<uint4*>(lds + lds_off(8 * o + r, kc)) = v[r];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row, chunk;
+            if constexpr (TR) {
+                row = 4 * (tid & 31) + i;
+                chunk = tid >> 5;
+            } else {
+                const int id = tid + NTHREADS * i;
+                row = id >> 3;
+                chunk = id & 7;
+            }
+            *reinterpret_cast<uint4*>(lds + lds_off(row, chunk)) = v[i];
+        }
+    }
+}
+
+template <bool BF16C, bool TR, typename T>
+__device__ __forceinline__ void load_operand(const void* base, long long ld, int rows_total, int row0, int k0, int klim,
+                                             bool vec, int half, uint4 (&out)[8]) {
+    if constexpr (TR && sizeof(T) == 2) load_transposed_bf16((const bf16_t*)base, ld, rows_total, row0, k0, klim, vec, half, out);
+    else if constexpr (TR) load_transposed_f32<BF16C>((const float*)base, ld, rows_total, row0, k0, klim, vec, out);
+    else load_rowmajor<BF16C, T>((const T*)base, ld, rows_total, row0, k0, klim, vec, out);
+}
+
+// BF16C: bf16 MFMA (else exact f32).  TA/TB: operand transposed in memory.  AT/BT: element type in memory.
+template <bool BF16C, bool TA, bool TB, typename AT, typename BT>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * ROWB];
     unsigned char* ldsA = lds;
     unsigned char* ldsB = lds + BM * ROWB;
-    constexpr int KT = BF16 ? 64 : 32;
+    constexpr int KT = BF16C ? 64 : 32;
+    constexpr bool A16 = sizeof(AT) == 2, B16 = sizeof(BT) == 2;
 
     // XCD-aware tile id: blocks b, b+8, ... share an XCD; give each XCD a contiguous id range.
     const int nwg = g.tiles_m * g.tiles_n;
@@ -160,8 +234,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
 
     const int nkt0 = (g.K[0] + KT - 1) / KT, nkt1 = (g.K[1] + KT - 1) / KT;
     const int nkt = nkt0 + nkt1;
-    // split-K: this block handles K-tiles [t_begin, t_end)
-    const int z = blockIdx.y;
+    const int z = blockIdx.y;  // split-K: this block handles K-tiles [t_begin, t_end)
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
 
@@ -175,21 +248,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rb[4];
+    uint4 ra[8], rb[8];
     auto load_tile = [&](int t) {
         const int src = t < nkt0 ? 0 : 1;
         const int k0 = (src == 0 ? t : t - nkt0) * KT;
-        if constexpr (TA) load_transposed<BF16>(g.A[src], g.lda[src], g.M, m0, k0, g.K[src], g.a_vec[src], ra);
-        else load_rowmajor<BF16>(g.A[src], g.lda[src], g.M, m0, k0, g.K[src], g.a_vec[src], ra);
-        if constexpr (TB) load_transposed<BF16>(g.B[src], g.ldb[src], g.N, n0, k0, g.K[src], g.b_vec[src], rb);
-        else load_rowmajor<BF16>(g.B[src], g.ldb[src], g.N, n0, k0, g.K[src], g.b_vec[src], rb);
+        load_operand<BF16C, TA, AT>(g.A[src], g.lda[src], g.M, m0, k0, g.K[src], g.a_vec[src], 0, ra);
+        load_operand<BF16C, TB, BT>(g.B[src], g.ldb[src], g.N, n0, k0, g.K[src], g.b_vec[src], 1, rb);
     };
 
     if (t_begin < t_end) load_tile(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();  // every wave finished reading the previous image
-        store_lds<TA>(ldsA, ra);
-        store_lds<TB>(ldsB, rb);
+        store_lds<TA, A16>(ldsA, ra, 0);
+        store_lds<TB, B16>(ldsB, rb, 1);
         __syncthreads();
         if (t + 1 < t_end) load_tile(t + 1);  // in flight under the MFMAs below
 #pragma unroll
@@ -201,7 +272,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 b[j] = *reinterpret_cast<const uint4*>(ldsB + lds_off(wn * 64 + j * 16 + lr, s * 4 + lg));
-            if constexpr (BF16) {
+            if constexpr (BF16C) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -238,17 +309,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
             const int n = n0 + wn * 64 + j * 16 + 4 * lg;
             if (n >= g.N) continue;
             f32x4 v = acc[i][j];
+            const bool full = n + 4 <= g.N;
             if (slab) {
                 float* p = g.ws + ((long long)z * g.M + m) * g.N + n;
-                if (n + 4 <= g.N && (g.N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                if (full && (g.N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
                 else
                     for (int t = 0; t < 4 && n + t < g.N; ++t) p[t] = v[t];
                 continue;
             }
-            float* cp = g.C + (long long)m * g.ldc + n;
-            const bool full = n + 4 <= g.N;
             float o[4] = {v[0] * g.alpha, v[1] * g.alpha, v[2] * g.alpha, v[3] * g.alpha};
-            if (g.accumulate) {
+            if (g.accumulate) {  // C is f32 when accumulating (checked on the host)
+                const float* cp = (const float*)g.C + (long long)m * g.ldc + n;
                 if (full && g.c_vec) {
                     const float4 c = *reinterpret_cast<const float4*>(cp);
                     o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
@@ -260,16 +331,38 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
             if (g.act == EGK_ACT_RELU)
                 for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
             if (g.residual) {
-                const float* rp = g.residual + (long long)m * g.ldr + n;
-                if (full && g.r_vec) {
-                    const float4 r = *reinterpret_cast<const float4*>(rp);
-                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-                } else
-                    for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += rp[t];
+                if (g.r_bf16) {
+                    const bf16_t* rp = (const bf16_t*)g.residual + (long long)m * g.ldr + n;
+                    if (full && g.r_vec) {
+                        const uint2 r = *reinterpret_cast<const uint2*>(rp);
+                        o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xffff0000u);
+                        o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xffff0000u);
+                    } else
+                        for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += bf16_to_f32(rp[t]);
+                } else {
+                    const float* rp = (const float*)g.residual + (long long)m * g.ldr + n;
+                    if (full && g.r_vec) {
+                        const float4 r = *reinterpret_cast<const float4*>(rp);
+                        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                    } else
+                        for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += rp[t];
+                }
             }
-            if (full && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
-            else
-                for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = o[t];
+            if (g.c_bf16) {
+                bf16_t* cp = (bf16_t*)g.C + (long long)m * g.ldc + n;
+                if (full && g.c_vec) {
+                    uint2 pk;
+                    pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+                    *reinterpret_cast<uint2*>(cp) = pk;
+                } else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = f32_to_bf16(o[t]);
+            } else {
+                float* cp = (float*)g.C + (long long)m * g.ldc + n;
+                if (full && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+                else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = o[t];
+            }
         }
     }
 }
@@ -283,16 +376,27 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs g) {
         float s = 0.f;
         for (int z = 0; z < g.splitk; ++z) s += g.ws[(long long)z * total + idx];
         float o = s * g.alpha;
-        float* cp = g.C + (long long)m * g.ldc + n;
-        if (g.accumulate) o += *cp;
+        if (g.accumulate) o += ((const float*)g.C)[(long long)m * g.ldc + n];
         if (g.bias) o += g.bias[n];
         if (g.act == EGK_ACT_RELU) o = fmaxf(o, 0.f);
-        if (g.residual) o += g.residual[(long long)m * g.ldr + n];
-        *cp = o;
+        if (g.residual)
+            o += g.r_bf16 ? bf16_to_f32(((const bf16_t*)g.residual)[(long long)m * g.ldr + n])
+                          : ((const float*)g.residual)[(long long)m * g.ldr + n];
+        if (g.c_bf16) ((bf16_t*)g.C)[(long long)m * g.ldc + n] = f32_to_bf16(o);
+        else ((float*)g.C)[(long long)m * g.ldc + n] = o;
     }
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool BF16C, typename AT, typename BT>
+static void launch_layout(const egk_gemm_desc* d, dim3 grid, hipStream_t s, const GemmArgs& g) {
+    dim3 block(NTHREADS);
+    if (!d->transA && !d->transB) hipLaunchKernelGGL((gemm_kernel<BF16C, false, false, AT, BT>), grid, block, 0, s, g);
+    else if (!d->transA && d->transB) hipLaunchKernelGGL((gemm_kernel<BF16C, false, true, AT, BT>), grid, block, 0, s, g);
+    else if (d->transA && d->transB) hipLaunchKernelGGL((gemm_kernel<BF16C, true, true, AT, BT>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<BF16C, true, false, AT, BT>), grid, block, 0, s, g);
+}
 
 }  // namespace egk
 
@@ -314,9 +418,15 @@ extern "C" int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute)
 extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
     EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
-    EGK_REQUIRE(d->a_dtype == EGK_F32 && d->b_dtype == EGK_F32 && d->c_dtype == EGK_F32,
-                "egk_gemm: only f32 matrices in memory are supported");
     EGK_REQUIRE(d->compute == EGK_COMPUTE_F32 || d->compute == EGK_COMPUTE_BF16, "egk_gemm: bad compute type");
+    const bool a16 = d->a_dtype == EGK_BF16, b16 = d->b_dtype == EGK_BF16;
+    EGK_REQUIRE((d->a_dtype == EGK_F32 || a16) && (d->b_dtype == EGK_F32 || b16) &&
+                    (d->c_dtype == EGK_F32 || d->c_dtype == EGK_BF16) &&
+                    (d->r_dtype == EGK_F32 || d->r_dtype == EGK_BF16),
+                "egk_gemm: unknown element type");
+    EGK_REQUIRE(a16 == b16, "egk_gemm: A and B must have the same element type in memory");
+    EGK_REQUIRE(!(a16 && d->compute == EGK_COMPUTE_F32), "egk_gemm: bf16 operands need EGK_COMPUTE_BF16");
+    EGK_REQUIRE(!(d->accumulate && d->c_dtype != EGK_F32), "egk_gemm: accumulate needs an f32 C");
     EGK_REQUIRE(d->C != nullptr || d->M == 0 || d->N == 0, "egk_gemm: null C");
     EGK_REQUIRE(d->K1 == 0 || (d->A1 && d->B1), "egk_gemm: null A1/B1");
     EGK_REQUIRE(d->K2 == 0 || (d->A2 && d->B2), "egk_gemm: null A2/B2");
@@ -326,18 +436,22 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     GemmArgs g;
     g.M = d->M; g.N = d->N;
     g.K[0] = d->K1; g.K[1] = d->K2;
-    g.A[0] = (const float*)d->A1; g.A[1] = (const float*)d->A2;
-    g.B[0] = (const float*)d->B1; g.B[1] = (const float*)d->B2;
+    g.A[0] = d->A1; g.A[1] = d->A2;
+    g.B[0] = d->B1; g.B[1] = d->B2;
     g.lda[0] = d->lda1; g.lda[1] = d->lda2; g.ldb[0] = d->ldb1; g.ldb[1] = d->ldb2;
+    const int ea = a16 ? 8 : 4, eb = b16 ? 8 : 4;  // elements per 16 bytes
     for (int i = 0; i < 2; ++i) {
-        g.a_vec[i] = g.A[i] && aligned16(g.A[i]) && (g.lda[i] % 4 == 0);
-        g.b_vec[i] = g.B[i] && aligned16(g.B[i]) && (g.ldb[i] % 4 == 0);
+        g.a_vec[i] = g.A[i] && aligned16(g.A[i]) && (g.lda[i] % ea == 0);
+        g.b_vec[i] = g.B[i] && aligned16(g.B[i]) && (g.ldb[i] % eb == 0);
     }
-    g.C = (float*)d->C; g.ldc = d->ldc;
-    g.c_vec = aligned16(g.C) && (g.ldc % 4 == 0);
+    g.C = d->C; g.ldc = d->ldc;
+    g.c_bf16 = d->c_dtype == EGK_BF16;
+    g.c_vec = g.c_bf16 ? ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0 && g.ldc % 4 == 0) : (aligned16(g.C) && g.ldc % 4 == 0);
     g.accumulate = d->accumulate; g.act = d->act; g.alpha = d->alpha;
     g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
-    g.r_vec = g.residual && aligned16(g.residual) && (g.ldr % 4 == 0);
+    g.r_bf16 = d->r_dtype == EGK_BF16;
+    g.r_vec = g.residual && (g.r_bf16 ? ((reinterpret_cast<uintptr_t>(g.residual) & 7) == 0 && g.ldr % 4 == 0)
+                                      : (aligned16(g.residual) && g.ldr % 4 == 0));
     g.splitk = d->splitk > 1 ? d->splitk : 1;
     g.ws = (float*)d->ws;
     if (g.splitk > 1)
@@ -346,28 +460,19 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
 
     const int K = d->K1 + d->K2;
     const double flops = 2.0 * d->M * d->N * K;
-    const double bytes = 4.0 * ((double)d->M * K + (double)d->N * K + (double)d->M * d->N);
+    const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
     const int bf = d->compute == EGK_COMPUTE_BF16;
     const int kid = (bf ? KID_GEMM_BF16_NN : KID_GEMM_F32_NN) + (d->transA ? (d->transB ? 2 : 3) : (d->transB ? 1 : 0));
     ProfScope prof(kid, s, flops, bytes);
 
-    dim3 grid(g.tiles_m * g.tiles_n, g.splitk), block(NTHREADS);
-#define EGK_LAUNCH(BF, TA, TB) hipLaunchKernelGGL((gemm_kernel<BF, TA, TB>), grid, block, 0, s, g)
-    if (bf) {
-        if (!d->transA && !d->transB) EGK_LAUNCH(true, false, false);
-        else if (!d->transA && d->transB) EGK_LAUNCH(true, false, true);
-        else if (d->transA && d->transB) EGK_LAUNCH(true, true, true);
-        else EGK_LAUNCH(true, true, false);
-    } else {
-        if (!d->transA && !d->transB) EGK_LAUNCH(false, false, false);
-        else if (!d->transA && d->transB) EGK_LAUNCH(false, false, true);
-        else if (d->transA && d->transB) EGK_LAUNCH(false, true, true);
-        else EGK_LAUNCH(false, true, false);
-    }
-#undef EGK_LAUNCH
+    dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
+    if (!bf) launch_layout<false, float, float>(d, grid, s, g);
+    else if (a16) launch_layout<true, bf16_t, bf16_t>(d, grid, s, g);
+    else launch_layout<true, float, float>(d, grid, s, g);
     if (g.splitk > 1) {
         const long long total = (long long)g.M * g.N;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
+                           dim3(256), 0, s, g);
     }
     return check_launch("egk_gemm");
 }

@@ -14,37 +14,21 @@ namespace egk {
 
 constexpr int WPB = 4;
 
-__device__ __forceinline__ float4 ld4(const float* __restrict__ p, int c, int cols, bool vec) {
-    if (vec && c + 4 <= cols) return *reinterpret_cast<const float4*>(p + c);
-    float4 v;
-    v.x = c + 0 < cols ? p[c + 0] : 0.f;
-    v.y = c + 1 < cols ? p[c + 1] : 0.f;
-    v.z = c + 2 < cols ? p[c + 2] : 0.f;
-    v.w = c + 3 < cols ? p[c + 3] : 0.f;
-    return v;
-}
-__device__ __forceinline__ void st4(float* __restrict__ p, int c, int cols, bool vec, float4 v) {
-    if (vec && c + 4 <= cols) {
-        *reinterpret_cast<float4*>(p + c) = v;
-        return;
-    }
-    if (c + 0 < cols) p[c + 0] = v.x;
-    if (c + 1 < cols) p[c + 1] = v.y;
-    if (c + 2 < cols) p[c + 2] = v.z;
-    if (c + 3 < cols) p[c + 3] = v.w;
-}
+#define ld4 ld4t
+#define st4 st4t
 
 // ---- positional encoding ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pe_add_kernel(const float* __restrict__ x, const long long* __restrict__ pos,
-                                                     const float* __restrict__ freq, float* __restrict__ y, int rows,
+template <typename T>
+__global__ __launch_bounds__(256) void pe_add_kernel(const T* __restrict__ x, const long long* __restrict__ pos,
+                                                     const float* __restrict__ freq, T* __restrict__ y, int rows,
                                                      int cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
     const int half = cols >> 1;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const float p = (float)pos[row];
-        const float* xr = x + (long long)row * cols;
-        float* yr = y + (long long)row * cols;
+        const T* xr = x + (long long)row * cols;
+        T* yr = y + (long long)row * cols;
         for (int c = lane * 4; c < cols; c += 256) {
             float4 v = ld4(xr, c, cols, vec);
             float e[4];
@@ -67,10 +51,10 @@ __global__ __launch_bounds__(256) void pe_add_kernel(const float* __restrict__ x
 // ---- CSR gather ----------------------------------------------------------------------------------
 // The output row lives in NV float4 registers per lane; per edge the NV loads of the neighbour row are
 // independent (one index load, then NV wide loads in flight) instead of a chunk-outer / edge-inner walk.
-template <int NV>
-__global__ __launch_bounds__(256) void csr_gather_kernel(const float* __restrict__ x, const int* __restrict__ rowptr,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x, const int* __restrict__ rowptr,
                                                          const int* __restrict__ col, const float* __restrict__ wgt,
-                                                         const float* __restrict__ gate, float* __restrict__ out, int rows,
+                                                         const T* __restrict__ gate, T* __restrict__ out, int rows,
                                                          int cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
@@ -81,7 +65,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = e0; e < e1; ++e) {
-            const float* src = x + (long long)col[e] * cols;
+            const T* src = x + (long long)col[e] * cols;
             const float we = wgt ? wgt[e] : 1.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -106,8 +90,9 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const float* __restrict
 }
 
 // ---- GraphONE gather-max ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __restrict__ f, const float* __restrict__ bank,
-                                                             const long long* __restrict__ nn, float* __restrict__ m,
+template <typename T>
+__global__ __launch_bounds__(256) void gather_max_fwd_kernel(const T* __restrict__ f, const float* __restrict__ bank,
+                                                             const long long* __restrict__ nn, T* __restrict__ m,
                                                              uint8_t* __restrict__ arg, int rows, int cols, int k) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
@@ -118,8 +103,8 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __rest
             float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             uint32_t a4 = 0;
             for (int j = 0; j <= k; ++j) {
-                const float* src = j < k ? bank + nn[(long long)row * k + j] * cols : f + (long long)row * cols;
-                const float4 v = ld4(src, c, cols, vec);
+                const float4 v = j < k ? ld4(bank + nn[(long long)row * k + j] * cols, c, cols, vec)
+                                       : ld4(f + (long long)row * cols, c, cols, vec);
                 if (v.x > best.x) { best.x = v.x; a4 = (a4 & ~0x000000ffu) | (uint32_t)j; }
                 if (v.y > best.y) { best.y = v.y; a4 = (a4 & ~0x0000ff00u) | ((uint32_t)j << 8); }
                 if (v.z > best.z) { best.z = v.z; a4 = (a4 & ~0x00ff0000u) | ((uint32_t)j << 16); }
@@ -134,12 +119,13 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __restrict__ dm, const uint8_t* __restrict__ arg,
-                                                             float* __restrict__ df, long long n, int k, int accumulate) {
+template <typename T>
+__global__ __launch_bounds__(256) void gather_max_bwd_kernel(const T* __restrict__ dm, const uint8_t* __restrict__ arg,
+                                                             T* __restrict__ df, long long n, int k, int accumulate) {
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
          i += (long long)gridDim.x * blockDim.x * 4) {
         if (i + 4 <= n) {
-            const float4 g = *reinterpret_cast<const float4*>(dm + i);
+            const float4 g = ld4(dm + i, 0, 4, true);
             const uint32_t a4 = *reinterpret_cast<const uint32_t*>(arg + i);
             float4 o;
             o.x = ((a4 >> 0) & 0xff) == (uint32_t)k ? g.x : 0.f;
@@ -147,22 +133,23 @@ __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __rest
             o.z = ((a4 >> 16) & 0xff) == (uint32_t)k ? g.z : 0.f;
             o.w = ((a4 >> 24) & 0xff) == (uint32_t)k ? g.w : 0.f;
             if (accumulate) {
-                const float4 d = *reinterpret_cast<const float4*>(df + i);
+                const float4 d = ld4(df + i, 0, 4, true);
                 o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
             }
-            *reinterpret_cast<float4*>(df + i) = o;
+            st4(df + i, 0, 4, true, o);
         } else {
             for (long long j = i; j < n; ++j) {
-                const float o = arg[j] == k ? dm[j] : 0.f;
-                df[j] = accumulate ? df[j] + o : o;
+                const float o = arg[j] == k ? ld1t(dm + j) : 0.f;
+                st1t(df + j, accumulate ? ld1t(df + j) + o : o);
             }
         }
     }
 }
 
 // ---- per-sequence max pool ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void segmax_fwd_kernel(const float* __restrict__ x, const int* __restrict__ ptr,
-                                                         float* __restrict__ out, int* __restrict__ arg, int n_seg,
+template <typename T>
+__global__ __launch_bounds__(256) void segmax_fwd_kernel(const T* __restrict__ x, const int* __restrict__ ptr,
+                                                         T* __restrict__ out, int* __restrict__ arg, int n_seg,
                                                          int cols) {
     const int sg = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -171,30 +158,32 @@ __global__ __launch_bounds__(256) void segmax_fwd_kernel(const float* __restrict
     float best = 0.f;  // empty segment -> 0 (scatter 'amax' into zeros, include_self=False)
     int a = -1;
     for (int r = r0; r < r1; ++r) {
-        const float v = x[(long long)r * cols + c];
+        const float v = ld1t(x + (long long)r * cols + c);
         if (a < 0 || v > best) {
             best = v;
             a = r;
         }
     }
-    out[(long long)sg * cols + c] = best;
+    st1t(out + (long long)sg * cols + c, best);
     arg[(long long)sg * cols + c] = a;
 }
 
-__global__ __launch_bounds__(256) void segmax_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
-                                                         const int* __restrict__ ptr, float* __restrict__ dx, int n_seg,
+template <typename T>
+__global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ dout, const int* __restrict__ arg,
+                                                         const int* __restrict__ ptr, T* __restrict__ dx, int n_seg,
                                                          int cols) {
     const int sg = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
     const int r0 = ptr[sg], r1 = ptr[sg + 1];
     const int a = arg[(long long)sg * cols + c];
-    const float g = dout[(long long)sg * cols + c];
-    for (int r = r0; r < r1; ++r) dx[(long long)r * cols + c] = r == a ? g : 0.f;
+    const float g = ld1t(dout + (long long)sg * cols + c);
+    for (int r = r0; r < r1; ++r) st1t(dx + (long long)r * cols + c, r == a ? g : 0.f);
 }
 
 // ---- cosine k-NN ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ x, float* __restrict__ inv, int rows,
+template <typename T>
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const T* __restrict__ x, float* __restrict__ inv, int rows,
                                                            int cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
@@ -255,7 +244,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
 }
 
 // ---- prototype bank scatter-add (fp64) --------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scatter_add_f64_kernel(const float* __restrict__ x, const long long* __restrict__ label,
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_f64_kernel(const T* __restrict__ x, const long long* __restrict__ label,
                                                               double* __restrict__ bank, long long* __restrict__ count,
                                                               int rows, int cols, long long n_labels) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -263,7 +253,18 @@ __global__ __launch_bounds__(256) void scatter_add_f64_kernel(const float* __res
         const long long lb = label[row];
         if (lb < 0 || lb >= n_labels) continue;
         if (lane == 0 && count) atomicAdd(reinterpret_cast<unsigned long long*>(count + lb), 1ull);
-        for (int c = lane; c < cols; c += 64) atomicAdd(bank + lb * cols + c, (double)x[(long long)row * cols + c]);
+        for (int c = lane; c < cols; c += 64) atomicAdd(bank + lb * cols + c, (double)ld1t(x + (long long)row * cols + c));
+    }
+}
+
+// element-type conversion f32 <-> bf16 (inputs of the bf16 pipeline, f32 views for the exact k-NN path)
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n, int vec) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+         i += (long long)gridDim.x * blockDim.x * 4) {
+        if (vec && i + 4 <= n) st4t(dst + i, 0, 4, true, ld4t(src + i, 0, 4, true));
+        else
+            for (long long j = i; j < n && j < i + 4; ++j) st1t(dst + j, ld1t(src + j));
     }
 }
 
@@ -278,84 +279,105 @@ using namespace egk;
 
 extern "C" {
 
-int egk_pe_add(egk_stream_t stream, const float* x, const int64_t* pos, const float* freq, float* y, int32_t rows,
-               int32_t cols) {
+int egk_cast(egk_stream_t stream, const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n) {
+    EGK_REQUIRE(src && dst, "egk_cast: null pointer");
+    EGK_REQUIRE(src_dtype != dst_dtype, "egk_cast: source and destination types are equal");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CAST, s, 0, 6.0 * n);
+    const int vec = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    long long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+    if (src_dtype == EGK_F32 && dst_dtype == EGK_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, (long long)n, vec);
+    else if (src_dtype == EGK_BF16 && dst_dtype == EGK_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, (long long)n, vec);
+    else {
+        set_error("egk_cast: unsupported type pair %d -> %d", src_dtype, dst_dtype);
+        return EGK_EUNSUPPORTED;
+    }
+    return check_launch("egk_cast");
+}
+
+int egk_pe_add(egk_stream_t stream, const void* x, const int64_t* pos, const float* freq, void* y, int32_t rows,
+               int32_t cols, int32_t dtype) {
     EGK_REQUIRE(x && pos && freq && y, "egk_pe_add: null pointer");
     EGK_REQUIRE((cols & 1) == 0, "egk_pe_add: odd channel count");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(KID_PE_ADD, s, 0, 8.0 * rows * cols);
-    hipLaunchKernelGGL(pe_add_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, (const long long*)pos, freq, y, rows, cols);
+    ProfScope prof(KID_PE_ADD, s, 0, (dtype == EGK_BF16 ? 4.0 : 8.0) * rows * cols);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(pe_add_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
+                                             (const long long*)pos, freq, (T*)y, rows, cols));
     return check_launch("egk_pe_add");
 }
 
-int egk_csr_gather(egk_stream_t stream, const float* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
-                   const float* relu_gate, float* out, int32_t rows, int32_t cols) {
+int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
+                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype) {
     EGK_REQUIRE(x && rowptr && out, "egk_csr_gather: null pointer");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(KID_CSR_GATHER, s, 0, (relu_gate ? 12.0 : 8.0) * rows * cols);
+    ProfScope prof(KID_CSR_GATHER, s, 0, (dtype == EGK_BF16 ? 0.5 : 1.0) * (relu_gate ? 12.0 : 8.0) * rows * cols);
     EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
-    if (cols <= 256)
-        hipLaunchKernelGGL(csr_gather_kernel<1>, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows, cols);
-    else if (cols <= 1024)
-        hipLaunchKernelGGL(csr_gather_kernel<4>, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows, cols);
-    else
-        hipLaunchKernelGGL(csr_gather_kernel<16>, dim3(row_grid(rows)), dim3(256), 0, s, x, rowptr, col, wgt, relu_gate, out, rows, cols);
+#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols)
+    EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
+#undef EGK_CSR
     return check_launch("egk_csr_gather");
 }
 
-int egk_gather_max_fwd(egk_stream_t stream, const float* f, const float* bank, const int64_t* nn, float* m, uint8_t* arg,
-                       int32_t rows, int32_t cols, int32_t k) {
+int egk_gather_max_fwd(egk_stream_t stream, const void* f, const float* bank, const int64_t* nn, void* m, uint8_t* arg,
+                       int32_t rows, int32_t cols, int32_t k, int32_t dtype) {
     EGK_REQUIRE(f && bank && nn && m && arg, "egk_gather_max_fwd: null pointer");
     EGK_REQUIRE(k >= 0 && k < 255, "egk_gather_max_fwd: k out of range");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_GATHER_MAX_FWD, s, 0, (4.0 * (k + 2) + 1.0) * rows * cols);
-    hipLaunchKernelGGL(gather_max_fwd_kernel, dim3(row_grid(rows)), dim3(256), 0, s, f, bank, (const long long*)nn, m, arg,
-                       rows, cols, k);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(gather_max_fwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)f, bank,
+                                             (const long long*)nn, (T*)m, arg, rows, cols, k));
     return check_launch("egk_gather_max_fwd");
 }
 
-int egk_gather_max_bwd(egk_stream_t stream, const float* dm, const uint8_t* arg, float* df, int32_t rows, int32_t cols,
-                       int32_t k, int32_t accumulate) {
+int egk_gather_max_bwd(egk_stream_t stream, const void* dm, const uint8_t* arg, void* df, int32_t rows, int32_t cols,
+                       int32_t k, int32_t accumulate, int32_t dtype) {
     EGK_REQUIRE(dm && arg && df, "egk_gather_max_bwd: null pointer");
     const long long n = (long long)rows * cols;
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_GATHER_MAX_BWD, s, 0, 9.0 * n);
     const long long blocks = (n / 4 + 255) / 256;
-    hipLaunchKernelGGL(gather_max_bwd_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
-                       s, dm, arg, df, n, k, accumulate);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(gather_max_bwd_kernel<T>, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)),
+                                             dim3(256), 0, s, (const T*)dm, arg, (T*)df, n, k, accumulate));
     return check_launch("egk_gather_max_bwd");
 }
 
-int egk_segment_max_fwd(egk_stream_t stream, const float* x, const int32_t* ptr, float* out, int32_t* arg, int32_t n_seg,
-                        int32_t cols) {
+int egk_segment_max_fwd(egk_stream_t stream, const void* x, const int32_t* ptr, void* out, int32_t* arg, int32_t n_seg,
+                        int32_t cols, int32_t dtype) {
     EGK_REQUIRE(x && ptr && out && arg, "egk_segment_max_fwd: null pointer");
     if (n_seg == 0 || cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_SEGMAX_FWD, s, 0, 0);
-    hipLaunchKernelGGL(segmax_fwd_kernel, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, x, ptr, out, arg, n_seg, cols);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_fwd_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)x, ptr,
+                                             (T*)out, arg, n_seg, cols));
     return check_launch("egk_segment_max_fwd");
 }
 
-int egk_segment_max_bwd(egk_stream_t stream, const float* dout, const int32_t* arg, const int32_t* ptr, float* dx,
-                        int32_t n_seg, int32_t rows, int32_t cols) {
+int egk_segment_max_bwd(egk_stream_t stream, const void* dout, const int32_t* arg, const int32_t* ptr, void* dx,
+                        int32_t n_seg, int32_t rows, int32_t cols, int32_t dtype) {
     EGK_REQUIRE(dout && arg && ptr && dx, "egk_segment_max_bwd: null pointer");
     if (n_seg == 0 || cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_SEGMAX_BWD, s, 0, 0);
-    hipLaunchKernelGGL(segmax_bwd_kernel, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, dout, arg, ptr, dx, n_seg, cols);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_bwd_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)dout,
+                                             arg, ptr, (T*)dx, n_seg, cols));
     return check_launch("egk_segment_max_bwd");
 }
 
-int egk_row_inv_norm(egk_stream_t stream, const float* x, float* inv_norm, int32_t rows, int32_t cols) {
+int egk_row_inv_norm(egk_stream_t stream, const void* x, float* inv_norm, int32_t rows, int32_t cols, int32_t dtype) {
     EGK_REQUIRE(x && inv_norm, "egk_row_inv_norm: null pointer");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_ROW_INV_NORM, s, 0, 4.0 * rows * cols);
-    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, inv_norm, rows, cols);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(row_inv_norm_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, inv_norm,
+                                             rows, cols));
     return check_launch("egk_row_inv_norm");
 }
 
@@ -382,14 +404,14 @@ int egk_topk_smallest(egk_stream_t stream, const float* dot, int64_t ldd, const 
     return check_launch("egk_topk_smallest");
 }
 
-int egk_scatter_add_rows_f64(egk_stream_t stream, const float* x, const int64_t* label, double* bank, int64_t* count,
-                             int32_t rows, int32_t cols, int64_t n_labels) {
+int egk_scatter_add_rows_f64(egk_stream_t stream, const void* x, const int64_t* label, double* bank, int64_t* count,
+                             int32_t rows, int32_t cols, int64_t n_labels, int32_t dtype) {
     EGK_REQUIRE(x && label && bank, "egk_scatter_add_rows_f64: null pointer");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_SCATTER_ADD_F64, s, 0, 4.0 * rows * cols + 16.0 * rows * cols);
-    hipLaunchKernelGGL(scatter_add_f64_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, (const long long*)label, bank,
-                       (long long*)count, rows, cols, (long long)n_labels);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(scatter_add_f64_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
+                                             (const long long*)label, bank, (long long*)count, rows, cols, (long long)n_labels));
     return check_launch("egk_scatter_add_rows_f64");
 }
 }

@@ -40,15 +40,16 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long long ld,
                                                      const long long* __restrict__ y, long long ys,
                                                      const float* __restrict__ lse, const float* __restrict__ gloss,
-                                                     float* __restrict__ dlogits, long long ldd, int rows, int C,
+                                                     T* __restrict__ dlogits, long long ldd, int rows, int C,
                                                      float smoothing) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const float* lr = logits + (long long)row * ld;
-        float* dr = dlogits + (long long)row * ldd;
+        T* dr = dlogits + (long long)row * ldd;
         const long long t = y[(long long)row * ys];
         const bool live = t >= 0 && t < C;
         const float g = live ? gloss[row] : 0.f;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
         for (int c = lane; c < C; c += 64) {
             float d = 0.f;
             if (live) d = g * (expf(lr[c] - l) - (c == t ? 1.f - smoothing : 0.f) - sm);
-            dr[c] = d;
+            st1t(dr + c, d);
         }
     }
 }
@@ -71,16 +72,18 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     // torch: (1 - t) * x + max(-x, 0) + log1p(exp(-|x|))
     loss[i] = (1.f - t) * v + fmaxf(-v, 0.f) + log1pf(expf(-fabsf(v)));
 }
+template <typename T>
 __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const long long* __restrict__ y,
-                                                      const float* __restrict__ gloss, float* __restrict__ dx, int n) {
+                                                      const float* __restrict__ gloss, T* __restrict__ dx, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    dx[i] = (1.f / (1.f + expf(-v)) - (float)y[i]) * gloss[i];
+    st1t(dx + i, (1.f / (1.f + expf(-v)) - (float)y[i]) * gloss[i]);
 }
 
 // ---- dropout ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           uint8_t* __restrict__ mask, long long n, float p, uint64_t seed,
                                                           uint64_t offset, const uint64_t* __restrict__ dev_offset) {
     if (dev_offset) offset += dev_offset[0];
@@ -93,29 +96,31 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restric
             if (i < n) {
                 const bool keep = u01(rr[t]) >= p;
                 mask[i] = keep;
-                y[i] = keep ? x[i] * inv : 0.f;
+                st1t(y + i, keep ? ld1t(x + i) * inv : 0.f);
             }
         }
     }
 }
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
-                                                          float* __restrict__ dx, long long n, float p) {
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                          T* __restrict__ dx, long long n, float p) {
     const float inv = 1.f / (1.f - p);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        dx[i] = mask[i] ? dy[i] * inv : 0.f;
+        st1t(dx + i, mask[i] ? ld1t(dy + i) * inv : 0.f);
 }
 
-__global__ __launch_bounds__(256) void relu_gate_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                        float* __restrict__ dx, long long n, int vec) {
+template <typename T>
+__global__ __launch_bounds__(256) void relu_gate_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                        T* __restrict__ dx, long long n, int vec) {
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
          i += (long long)gridDim.x * blockDim.x * 4) {
         if (vec && i + 4 <= n) {
-            const float4 g = *reinterpret_cast<const float4*>(dy + i);
-            const float4 v = *reinterpret_cast<const float4*>(y + i);
-            *reinterpret_cast<float4*>(dx + i) =
-                make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+            const float4 g = ld4t(dy + i, 0, 4, true);
+            const float4 v = ld4t(y + i, 0, 4, true);
+            st4t(dx + i, 0, 4, true,
+                 make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f));
         } else
-            for (long long j = i; j < n && j < i + 4; ++j) dx[j] = y[j] > 0.f ? dy[j] : 0.f;
+            for (long long j = i; j < n && j < i + 4; ++j) st1t(dx + j, ld1t(y + j) > 0.f ? ld1t(dy + j) : 0.f);
     }
 }
 
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict
 // ---- Adam (torch.optim.Adam single-tensor formulas, L2 weight decay) ----------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, const float* __restrict__ hyper,
-                                                   float b1, float b2, float eps, float wd) {
+                                                   float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow) {
     const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
     const float step = lr / bc1;
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
@@ -185,12 +190,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             *reinterpret_cast<float4*>(p + i) = pv;
             *reinterpret_cast<float4*>(m + i) = mv;
             *reinterpret_cast<float4*>(v + i) = vv;
+            if (shadow) st4t(shadow + i, 0, 4, true, pv);
         } else {
             for (long long j = i; j < n; ++j) {
                 const float gg = g[j] * gs + wd * p[j];
                 m[j] = m[j] + (gg - m[j]) * (1.f - b1);
                 v[j] = v[j] * b2 + (1.f - b2) * gg * gg;
                 p[j] = p[j] - step * (m[j] / (sqrtf(v[j]) / bc2s + eps));
+                if (shadow) shadow[j] = f2bf(p[j]);
             }
         }
     }
@@ -224,13 +231,14 @@ int egk_ce_fwd(egk_stream_t stream, const float* logits, int64_t ld, const int64
 }
 
 int egk_ce_bwd(egk_stream_t stream, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, const float* lse,
-               const float* gloss, float* dlogits, int64_t ldd, int32_t rows, int32_t C, float smoothing) {
+               const float* gloss, void* dlogits, int64_t ldd, int32_t rows, int32_t C, float smoothing, int32_t dtype) {
     EGK_REQUIRE(logits && y && lse && gloss && dlogits, "egk_ce_bwd: null pointer");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CE_BWD, s, 0, 8.0 * rows * C);
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(row_grid(rows)), dim3(256), 0, s, logits, (long long)ld, (const long long*)y,
-                       (long long)y_stride, lse, gloss, dlogits, (long long)ldd, rows, C, smoothing);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(ce_bwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, logits, (long long)ld,
+                                             (const long long*)y, (long long)y_stride, lse, gloss, (T*)dlogits, (long long)ldd, rows,
+                                             C, smoothing));
     return check_launch("egk_ce_bwd");
 }
 
@@ -243,42 +251,47 @@ int egk_bce_fwd(egk_stream_t stream, const float* logits, const int64_t* y, floa
     return check_launch("egk_bce_fwd");
 }
 
-int egk_bce_bwd(egk_stream_t stream, const float* logits, const int64_t* y, const float* gloss, float* dlogits, int32_t n) {
+int egk_bce_bwd(egk_stream_t stream, const float* logits, const int64_t* y, const float* gloss, void* dlogits, int32_t n,
+                int32_t dtype) {
     EGK_REQUIRE(logits && y && gloss && dlogits, "egk_bce_bwd: null pointer");
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_BCE_BWD, s, 0, 20.0 * n);
-    hipLaunchKernelGGL(bce_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, (const long long*)y, gloss, dlogits, n);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(bce_bwd_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, (const long long*)y,
+                                             gloss, (T*)dlogits, n));
     return check_launch("egk_bce_bwd");
 }
 
-int egk_dropout_fwd(egk_stream_t stream, const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
-                    uint64_t offset, const uint64_t* dev_offset) {
+int egk_dropout_fwd(egk_stream_t stream, const void* x, void* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                    uint64_t offset, const uint64_t* dev_offset, int32_t dtype) {
     EGK_REQUIRE(x && y && mask, "egk_dropout_fwd: null pointer");
     EGK_REQUIRE(p >= 0.f && p < 1.f, "egk_dropout_fwd: p out of range");
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_DROPOUT_FWD, s, 0, 9.0 * n);
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, x, y, mask, (long long)n, p, seed, offset, dev_offset);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_fwd_kernel<T>, dim3(ew_grid(n, 4)), dim3(256), 0, s, (const T*)x, (T*)y, mask,
+                                             (long long)n, p, seed, offset, dev_offset));
     return check_launch("egk_dropout_fwd");
 }
 
-int egk_dropout_bwd(egk_stream_t stream, const float* dy, const uint8_t* mask, float* dx, int64_t n, float p) {
+int egk_dropout_bwd(egk_stream_t stream, const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, int32_t dtype) {
     EGK_REQUIRE(dy && mask && dx, "egk_dropout_bwd: null pointer");
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_DROPOUT_BWD, s, 0, 9.0 * n);
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, s, dy, mask, dx, (long long)n, p);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_bwd_kernel<T>, dim3(ew_grid(n, 1)), dim3(256), 0, s, (const T*)dy, mask,
+                                             (T*)dx, (long long)n, p));
     return check_launch("egk_dropout_bwd");
 }
 
-int egk_relu_gate(egk_stream_t stream, const float* dy, const float* y, float* dx, int64_t n) {
+int egk_relu_gate(egk_stream_t stream, const void* dy, const void* y, void* dx, int64_t n, int32_t dtype) {
     EGK_REQUIRE(dy && y && dx, "egk_relu_gate: null pointer");
     if (n == 0) return 0;
     const int vec = (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15) == 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_RELU_GATE, s, 0, 12.0 * n);
-    hipLaunchKernelGGL(relu_gate_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, dy, y, dx, (long long)n, vec);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(relu_gate_kernel<T>, dim3(ew_grid(n, 4)), dim3(256), 0, s, (const T*)dy, (const T*)y,
+                                             (T*)dx, (long long)n, vec));
     return check_launch("egk_relu_gate");
 }
 
@@ -310,15 +323,16 @@ int egk_sum_scale(egk_stream_t stream, const float* x, float* out, int64_t n, fl
 }
 
 int egk_adam_step(egk_stream_t stream, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                  float beta1, float beta2, float eps, float weight_decay) {
+                  float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow) {
     EGK_REQUIRE(p && g && m && v && hyper, "egk_adam_step: null pointer");
     EGK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "egk_adam_step: buffers must be 16-byte aligned");
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(KID_ADAM, s, 0, 28.0 * n);
+    EGK_REQUIRE(!bf16_shadow || ((uintptr_t)bf16_shadow & 7) == 0, "egk_adam_step: shadow must be 8-byte aligned");
+    ProfScope prof(KID_ADAM, s, 0, (bf16_shadow ? 30.0 : 28.0) * n);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, p, g, m, v, (long long)n, hyper, beta1, beta2, eps,
-                       weight_decay);
+                       weight_decay, (bf16_t*)bf16_shadow);
     return check_launch("egk_adam_step");
 }
 }

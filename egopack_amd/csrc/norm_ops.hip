@@ -20,33 +20,15 @@ struct Row {
     float4 v[NV];
 };
 
-template <int NV>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, int cols, bool vec, int lane, Row<NV>& r) {
+template <int NV, typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, int cols, bool vec, int lane, Row<NV>& r) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (vec && c + 4 <= cols) r.v[i] = *reinterpret_cast<const float4*>(p + c);
-        else {
-            r.v[i].x = c + 0 < cols ? p[c + 0] : 0.f;
-            r.v[i].y = c + 1 < cols ? p[c + 1] : 0.f;
-            r.v[i].z = c + 2 < cols ? p[c + 2] : 0.f;
-            r.v[i].w = c + 3 < cols ? p[c + 3] : 0.f;
-        }
-    }
+    for (int i = 0; i < NV; ++i) r.v[i] = ld4t(p, (i * 64 + lane) * 4, cols, vec);
 }
-template <int NV>
-__device__ __forceinline__ void store_row(float* __restrict__ p, int cols, bool vec, int lane, const Row<NV>& r) {
+template <int NV, typename T>
+__device__ __forceinline__ void store_row(T* __restrict__ p, int cols, bool vec, int lane, const Row<NV>& r) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (vec && c + 4 <= cols) *reinterpret_cast<float4*>(p + c) = r.v[i];
-        else {
-            if (c + 0 < cols) p[c + 0] = r.v[i].x;
-            if (c + 1 < cols) p[c + 1] = r.v[i].y;
-            if (c + 2 < cols) p[c + 2] = r.v[i].z;
-            if (c + 3 < cols) p[c + 3] = r.v[i].w;
-        }
-    }
+    for (int i = 0; i < NV; ++i) st4t(p, (i * 64 + lane) * 4, cols, vec, r.v[i]);
 }
 __device__ __forceinline__ float& el(float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 __device__ __forceinline__ float el(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
@@ -54,9 +36,9 @@ __device__ __forceinline__ float el(const float4& v, int t) { return t == 0 ? v.
 // -------------------------------------------------------------------------------------------
 // row LayerNorm (+ReLU, +dropout)
 // -------------------------------------------------------------------------------------------
-template <int NV>
-__global__ __launch_bounds__(256) void rowln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float* __restrict__ y,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, T* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         uint8_t* __restrict__ mask, int rows, int cols, float eps, int relu,
                                                         float p, uint64_t seed, uint64_t offset,
@@ -119,11 +101,11 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const float* __restrict_
 }
 
 // dx for one row + per-wave column partials of dw/db, combined per workgroup through LDS.
-template <int NV>
-__global__ __launch_bounds__(256) void rowln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                                        const uint8_t* __restrict__ mask, T* __restrict__ dx,
                                                         float* __restrict__ ws, int rows, int cols, int relu, float p) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [WPB][2][NV*256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,8 +215,8 @@ __device__ __forceinline__ int seg_of(const int* __restrict__ seg_ptr, int n_seg
 }
 
 // pass 1: per-workgroup per-segment (sum, sumsq) in double -> ws[blk][seg][2]
-template <int NV>
-__global__ __launch_bounds__(256) void graphln_stats_kernel(const float* __restrict__ x, const int* __restrict__ seg_ptr,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict__ x, const int* __restrict__ seg_ptr,
                                                             int n_seg, int rows, int cols, double* __restrict__ ws) {
     __shared__ double acc[WPB][MAXSEG][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -300,9 +282,9 @@ __device__ __forceinline__ void graphln_finish_stats(const double* __restrict__ 
     __syncthreads();
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void graphln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ b, float* __restrict__ y,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void graphln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, T* __restrict__ y,
                                                           float* __restrict__ stats, const int* __restrict__ seg_ptr,
                                                           int n_seg, int rows, int cols, float eps, float slope,
                                                           const double* __restrict__ ws, int nblk_stats) {
@@ -331,8 +313,8 @@ __global__ __launch_bounds__(256) void graphln_fwd_kernel(const float* __restric
 }
 
 // bwd pass 1: per-segment S1 = sum(dxhat), S2 = sum(dxhat*xhat) (double) + column partials of dw/db
-template <int NV>
-__global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                 const float* __restrict__ w, const float* __restrict__ b,
                                                                 const float* __restrict__ stats,
                                                                 const int* __restrict__ seg_ptr, int n_seg, int rows,
@@ -402,10 +384,10 @@ __global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const float* __r
 }
 
 // bwd pass 2: dx = r*dxhat - r*S1/n - xhat*S2/(n*sigma),  sigma = 1/r - eps
-template <int NV>
-__global__ __launch_bounds__(256) void graphln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ b,
-                                                          const float* __restrict__ stats, float* __restrict__ dx,
+                                                          const float* __restrict__ stats, T* __restrict__ dx,
                                                           const int* __restrict__ seg_ptr, int n_seg, int rows, int cols,
                                                           float eps, float slope, const double* __restrict__ ws_seg,
                                                           int nblk_stats) {
@@ -452,7 +434,8 @@ __global__ __launch_bounds__(256) void graphln_bwd_kernel(const float* __restric
 // -------------------------------------------------------------------------------------------
 // column sum: stage 1 partials over row chunks, stage 2 fixed-order sum
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long ldx, int M, int N,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long long ldx, int M, int N,
                                                              float* __restrict__ ws, int rows_per) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
@@ -460,12 +443,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = r0;
     for (; r + 4 <= r1; r += 4) {
-        s0 += x[(long long)(r + 0) * ldx + c];
-        s1 += x[(long long)(r + 1) * ldx + c];
-        s2 += x[(long long)(r + 2) * ldx + c];
-        s3 += x[(long long)(r + 3) * ldx + c];
+        s0 += ld1t(x + (long long)(r + 0) * ldx + c);
+        s1 += ld1t(x + (long long)(r + 1) * ldx + c);
+        s2 += ld1t(x + (long long)(r + 2) * ldx + c);
+        s3 += ld1t(x + (long long)(r + 3) * ldx + c);
     }
-    for (; r < r1; ++r) s0 += x[(long long)r * ldx + c];
+    for (; r < r1; ++r) s0 += ld1t(x + (long long)r * ldx + c);
     ws[(long long)blockIdx.y * N + c] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int N,
@@ -487,13 +470,15 @@ static inline int row_grid(int rows) {  // <= 2 workgroups per CU: keeps the par
 
 using namespace egk;
 
-#define DISPATCH_NV(cols, CALL)                                         \
+#define DISPATCH_NV_(cols, ...)                                         \
     switch (nv_for(cols)) {                                             \
-        case 1: { constexpr int NV = 1; CALL; } break;                  \
-        case 4: { constexpr int NV = 4; CALL; } break;                  \
-        case 16: { constexpr int NV = 16; CALL; } break;                \
+        case 1: { constexpr int NV = 1; __VA_ARGS__; } break;           \
+        case 4: { constexpr int NV = 4; __VA_ARGS__; } break;           \
+        case 16: { constexpr int NV = 16; __VA_ARGS__; } break;         \
         default: set_error("row width %d > 4096 unsupported", cols); return EGK_EUNSUPPORTED; \
     }
+// NV (registers per lane) x T (activation element type)
+#define DISPATCH_NV(cols, dtype, ...) EGK_DISPATCH_T(dtype, DISPATCH_NV_(cols, __VA_ARGS__))
 
 extern "C" {
 
@@ -504,8 +489,8 @@ int egk_colsum_ws_len(int32_t M, int32_t N) {
     return chunks * N;
 }
 
-int egk_colsum(egk_stream_t stream, const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
-               float* ws) {
+int egk_colsum(egk_stream_t stream, const void* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+               float* ws, int32_t dtype) {
     EGK_REQUIRE(x && out && ws, "egk_colsum: null pointer");
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -513,41 +498,43 @@ int egk_colsum(egk_stream_t stream, const float* x, int64_t ldx, int32_t M, int3
     if (chunks > 128) chunks = 128;
     if (chunks < 1) chunks = 1;
     const int rows_per = cdiv(M, chunks);
-    ProfScope prof(KID_COLSUM, s, 0, 4.0 * M * N);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 256), chunks), dim3(256), 0, s, x, (long long)ldx, M, N, ws,
-                       rows_per);
+    ProfScope prof(KID_COLSUM, s, 0, (dtype == EGK_BF16 ? 2.0 : 4.0) * M * N);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(cdiv(N, 256), chunks), dim3(256), 0, s,
+                                             (const T*)x, (long long)ldx, M, N, ws, rows_per));
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, out, N, chunks, accumulate);
     return check_launch("egk_colsum");
 }
 
-int egk_rowln_fwd(egk_stream_t stream, const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
                   uint8_t* mask, int32_t rows, int32_t cols, float eps, int32_t relu, float p, uint64_t seed,
-                  uint64_t offset, const uint64_t* dev_offset) {
+                  uint64_t offset, const uint64_t* dev_offset, int32_t dtype) {
     EGK_REQUIRE(x && w && b && y && mean && rstd, "egk_rowln_fwd: null pointer");
     EGK_REQUIRE(p == 0.f || mask, "egk_rowln_fwd: dropout needs a mask buffer");
     EGK_REQUIRE(p >= 0.f && p < 1.f, "egk_rowln_fwd: p out of range");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(KID_ROWLN_FWD, s, 0, 8.0 * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
-    DISPATCH_NV(cols, hipLaunchKernelGGL(rowln_fwd_kernel<NV>, dim3(row_grid(rows)), dim3(256), 0, s, x, w, b, y, mean, rstd,
-                                         mask, rows, cols, eps, relu, p, seed, offset, dev_offset));
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T>), dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, w, b,
+                                                 (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset));
     return check_launch("egk_rowln_fwd");
 }
 
 int egk_rowln_bwd_ws_rows(int32_t rows) { return row_grid(rows); }
 
-int egk_rowln_bwd(egk_stream_t stream, const float* dy, const float* x, const float* w, const float* b, const float* mean,
-                  const float* rstd, const uint8_t* mask, float* dx, float* dw, float* db, float* ws, int32_t rows,
-                  int32_t cols, int32_t relu, float p) {
+int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b, const float* mean,
+                  const float* rstd, const uint8_t* mask, void* dx, float* dw, float* db, float* ws, int32_t rows,
+                  int32_t cols, int32_t relu, float p, int32_t dtype) {
     EGK_REQUIRE(dy && x && w && b && mean && rstd && dx && ws, "egk_rowln_bwd: null pointer");
     EGK_REQUIRE(p == 0.f || mask, "egk_rowln_bwd: dropout needs the mask");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows);
     {
-        ProfScope prof(KID_ROWLN_BWD, s, 0, 12.0 * rows * cols);
-        DISPATCH_NV(cols, hipLaunchKernelGGL(rowln_bwd_kernel<NV>, dim3(grid), dim3(256), WPB * 2 * NV * 256 * sizeof(float), s,
-                                             dy, x, w, b, mean, rstd, mask, dx, ws, rows, cols, relu, p));
+        ProfScope prof(KID_ROWLN_BWD, s, 0, (dtype == EGK_BF16 ? 6.0 : 12.0) * rows * cols);
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_bwd_kernel<NV, T>), dim3(grid), dim3(256),
+                                                     WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, mean,
+                                                     rstd, mask, (T*)dx, ws, rows, cols, relu, p));
     }
     {
         ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
@@ -561,46 +548,50 @@ int64_t egk_graphln_ws_bytes(int32_t rows, int32_t cols, int32_t n_seg) {
     return g * n_seg * 2 * 8 + g * 2 * (int64_t)cols * 4;
 }
 
-int egk_graphln_fwd(egk_stream_t stream, const float* x, const float* w, const float* b, float* y, float* stats,
-                    const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope, void* ws) {
+int egk_graphln_fwd(egk_stream_t stream, const void* x, const float* w, const float* b, void* y, float* stats,
+                    const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope, void* ws,
+                    int32_t dtype) {
     EGK_REQUIRE(x && w && b && y && stats && seg_ptr && ws, "egk_graphln_fwd: null pointer");
     EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG, "egk_graphln_fwd: n_seg must be in [1,%d]", MAXSEG);
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows);
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     {
-        ProfScope prof(KID_GRAPHLN_STATS, s, 0, 4.0 * rows * cols);
-        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_stats_kernel<NV>, dim3(grid), dim3(256), 0, s, x, seg_ptr, n_seg, rows,
-                                             cols, (double*)ws));
+        ProfScope prof(KID_GRAPHLN_STATS, s, 0, eb * rows * cols);
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_stats_kernel<NV, T>), dim3(grid), dim3(256), 0, s, (const T*)x, seg_ptr,
+                                                     n_seg, rows, cols, (double*)ws));
     }
     {
-        ProfScope prof(KID_GRAPHLN_FWD, s, 0, 8.0 * rows * cols);
-        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, s, x, w, b, y, stats, seg_ptr,
-                                             n_seg, rows, cols, eps, slope, (const double*)ws, grid));
+        ProfScope prof(KID_GRAPHLN_FWD, s, 0, 2 * eb * rows * cols);
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T>), dim3(grid), dim3(256), 0, s, (const T*)x, w, b,
+                                                     (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)ws, grid));
     }
     return check_launch("egk_graphln_fwd");
 }
 
-int egk_graphln_bwd(egk_stream_t stream, const float* dy, const float* x, const float* w, const float* b,
-                    const float* stats, float* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
-                    int32_t rows, int32_t cols, float eps, float slope, void* ws) {
+int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b,
+                    const float* stats, void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
+                    int32_t rows, int32_t cols, float eps, float slope, void* ws, int32_t dtype) {
     EGK_REQUIRE(dy && x && w && b && stats && dx && seg_ptr && ws, "egk_graphln_bwd: null pointer");
     EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG, "egk_graphln_bwd: n_seg must be in [1,%d]", MAXSEG);
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows);
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     double* ws_seg = (double*)ws;
     float* ws_col = (float*)((char*)ws + (int64_t)grid * n_seg * 2 * 8);
     {
-        ProfScope prof(KID_GRAPHLN_BWD_STATS, s, 0, 8.0 * rows * cols);
-        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_bwd_stats_kernel<NV>, dim3(grid), dim3(256),
-                                             WPB * 2 * NV * 256 * sizeof(float), s, dy, x, w, b, stats, seg_ptr, n_seg, rows,
-                                             cols, slope, ws_seg, ws_col));
+        ProfScope prof(KID_GRAPHLN_BWD_STATS, s, 0, 2 * eb * rows * cols);
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_stats_kernel<NV, T>), dim3(grid), dim3(256),
+                                                     WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, stats,
+                                                     seg_ptr, n_seg, rows, cols, slope, ws_seg, ws_col));
     }
     {
-        ProfScope prof(KID_GRAPHLN_BWD, s, 0, 12.0 * rows * cols);
-        DISPATCH_NV(cols, hipLaunchKernelGGL(graphln_bwd_kernel<NV>, dim3(grid), dim3(256), 0, s, dy, x, w, b, stats, dx,
-                                             seg_ptr, n_seg, rows, cols, eps, slope, ws_seg, grid));
+        ProfScope prof(KID_GRAPHLN_BWD, s, 0, 3 * eb * rows * cols);
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_kernel<NV, T>), dim3(grid), dim3(256), 0, s, (const T*)dy,
+                                                     (const T*)x, w, b, stats, (T*)dx, seg_ptr, n_seg, rows, cols, eps, slope,
+                                                     ws_seg, grid));
     }
     if (dw || db) {
         ProfScope prof(KID_GRAPHLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);

@@ -25,7 +25,7 @@ static const char* const kNames[KID_COUNT] = {
     "graphln_stats", "graphln_fwd", "graphln_bwd_stats", "graphln_bwd", "graphln_bwd_reduce",
     "pe_add", "csr_gather", "gather_max_fwd", "gather_max_bwd", "segmax_fwd", "segmax_bwd",
     "row_inv_norm", "topk", "scatter_add_f64", "ce_fwd", "ce_bwd", "bce_fwd", "bce_bwd",
-    "dropout_fwd", "dropout_bwd", "relu_gate", "axpby", "sum_scale", "adam"};
+    "dropout_fwd", "dropout_bwd", "relu_gate", "cast", "axpby", "sum_scale", "adam"};
 
 struct Pending {
     int kid;

@@ -44,10 +44,8 @@ class MTLStep:
                 dev = batches[live[0]].pos.device
                 merged = merged.to(dev)
             feat = self.model(merged)
-            seg = [0]
-            for t in live:
-                seg.append(seg[-1] + batches[t].pos.shape[0])
-            return {t: feat[seg[i]:seg[i + 1]] for i, t in enumerate(live)}
+            parts = ops.split_rows(feat, [batches[t].pos.shape[0] for t in live])
+            return dict(zip(live, parts))
         return {t: self.model(batches[t]) for t in live}
 
     def losses(self, batches: Mapping[str, Data], merged: Optional[Data] = None):

@@ -73,6 +73,8 @@ class Graph(torch.nn.Module):
         x = [self.pre_dropout(b) for b in x] if isinstance(x, (list, tuple)) else self.pre_dropout(x)
         if self.temporal_pooling is not None:
             x = self.temporal_pooling(x, getattr(data, "batch", None), data.pos)
+        elif not isinstance(x, (list, tuple)):
+            x = ops.to_act(x)
         if not hasattr(self, "net"):
             return x
         graph = self._graph_of(data)

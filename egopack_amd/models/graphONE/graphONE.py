@@ -85,7 +85,7 @@ class GraphONE(nn.Module):
         bank = self.embeddings[task].weight
         nn_idx = ops.cosine_topk(features.detach(), bank.detach(), self.k, self._inv_norm(task))
         assignments = [nn_idx[:, 0]] * self.depth  # the reference recomputes identical edges per depth
-        f = features
+        f = ops.to_act(features)
         for stage in self.conv_stages[task]:
             m = ops.gather_max(f, bank, nn_idx)
             h = stage.module_0.combine(m, f)

@@ -11,8 +11,8 @@ class Linear(nn.Linear):
     """nn.Linear / gnn.Linear parameters (kaiming-uniform(a=sqrt 5), bias U(+-1/sqrt(fan_in)));
     forward = one MFMA launch with the bias (and optional ReLU / residual) in the epilogue."""
 
-    def forward(self, x, residual=None, relu=False):
-        return ops.linear(x, self.weight, self.bias, residual=residual, relu=relu)
+    def forward(self, x, residual=None, relu=False, out_f32=False):
+        return ops.linear(x, self.weight, self.bias, residual=residual, relu=relu, out_f32=out_f32)
 
 
 class LayerNorm(nn.LayerNorm):

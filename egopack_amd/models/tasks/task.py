@@ -22,8 +22,9 @@ class ProjectionTask(torch.nn.Module):
                                  nn.ReLU(), Linear(features_size, features_size))
 
     def forward_features(self, x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        from ... import ops
         n = self.net
-        return n[4](n[2](n[1](n[0](x)), relu=True))
+        return n[4](n[2](n[1](n[0](ops.to_act(x))), relu=True))
 
     def configure_optimizers(self, _):
         return self.parameters()
@@ -34,7 +35,8 @@ def build_classifier(features_size: int, out: int, head_dropout: float) -> nn.Se
 
 
 def apply_classifier(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    return seq[1](seq[0](x))
+    """Dropout -> Linear; logits are kept in f32 whatever the activation element type."""
+    return seq[1](seq[0](x), out_f32=True)
 
 
 def fuse_logits(primary: torch.Tensor, aux: List[torch.Tensor], average: bool) -> torch.Tensor:

@@ -35,7 +35,7 @@ class TRNPooling(TemporalPooling):
             if x.shape[1] != self.num_segments or x.shape[2] != self.input_size:
                 raise ValueError(f"expected [N, {self.num_segments}, {self.input_size}], got {tuple(x.shape)}")
             x = x.reshape(x.shape[0], -1)  # 'bs segments h -> bs (segments h)': a view of contiguous rows
-        return x
+        return ops.to_act(x)  # no-op when the loader already delivers the mode's element type
 
     def forward(self, x, *_):
         """``x``: [N, S, F] or a list of such blocks (fused multi-task pass: rows are concatenated in

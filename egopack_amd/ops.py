@@ -3,6 +3,14 @@
 PyTorch is used for device memory, the current HIP stream and autograd bookkeeping only: every
 piece of arithmetic below is a launch of a hand-written gfx950 kernel through ctypes.  There is
 no CPU path: tensors must live on a ROCm device, otherwise a RuntimeError is raised.
+
+Numeric modes (``set_compute``):
+  'bf16'         bf16 MFMA (f32 accumulate); activations, activation gradients and the weight operands
+                 (bf16 shadows written by the Adam kernel) are bf16 in HBM; statistics, losses, parameters,
+                 parameter gradients and optimiser state are f32.  The benchmark mode.
+  'bf16_f32act'  bf16 MFMA with f32 activations / weights in HBM (converted while staging).
+  'f32'          exact f32 MFMA, everything f32: the tight-parity mode.
+Every op is polymorphic in the activation element type: it follows the dtype of its activation input.
 """
 from __future__ import annotations
 
@@ -13,18 +21,23 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1  # EGK_COMPUTE_*
+F32, BF16 = 0, 1  # EGK_COMPUTE_* and EGK_F32 / EGK_BF16 element types
 
-_state = {"compute": BF16}
+_MODES = {"bf16": (BF16, torch.bfloat16), "bf16_f32act": (BF16, torch.float32), "f32": (F32, torch.float32)}
+_state = {"mode": "bf16", "compute": BF16, "act": torch.bfloat16}
 
 
 def set_compute(mode: str) -> None:
-    """'bf16' (default: v_mfma_f32_16x16x32_bf16, f32 accumulate) or 'f32' (exact f32 MFMA)."""
-    _state["compute"] = {"bf16": BF16, "f32": F32}[mode]
+    comp, act = _MODES[mode]
+    _state.update(mode=mode, compute=comp, act=act)
 
 
 def get_compute() -> str:
-    return "bf16" if _state["compute"] == BF16 else "f32"
+    return _state["mode"]
+
+
+def act_dtype() -> torch.dtype:
+    return _state["act"]
 
 
 class compute_mode:
@@ -61,6 +74,20 @@ def _stream():
 def _ck(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"expected a float32 or bfloat16 activation, got {t.dtype}")
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    """contiguous activation (f32 or bf16)"""
+    _dt(t)
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -116,27 +143,74 @@ def advance_rng_device(device, stride: int = 1 << 40):
     rng_device_offset(device).add_(stride)
 
 
+# ---- element-type conversion ---------------------------------------------------------------------------
+def cast_raw(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Plain (non-differentiable) f32 <-> bf16 conversion on the HIP path."""
+    if src.dtype == dtype:
+        return src
+    _need_gpu(src)
+    src = _c(src)
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _ck(_lib.load().egk_cast(_stream(), _p(src), _dt(src), _p(dst), _dt(dst), src.numel()), "egk_cast")
+    return dst
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return cast_raw(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast_raw(g, ctx.src), None
+
+
+def to_act(x: torch.Tensor) -> torch.Tensor:
+    """Bring an activation to the element type of the current mode (no-op when it already has it)."""
+    want = _state["act"]
+    if x.dtype == want:
+        return x
+    return _Cast.apply(x, want) if x.requires_grad else cast_raw(x, want)
+
+
+def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """The tensor a contraction reads for parameter ``W``: W itself (f32) or its bf16 shadow.  Shadows are
+    owned and kept fresh by optim.FlatAdam (written by the Adam kernel); without one the weight is
+    converted on the fly."""
+    if dtype == torch.float32:
+        return _f32c(W)
+    sh = getattr(W, "_egk_shadow", None)
+    if sh is not None and sh.shape == W.shape:
+        return sh
+    return cast_raw(W.detach(), torch.bfloat16)
+
+
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
          transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
          allow_splitk=True):
     lib = _lib.load()
-    compute = _state["compute"] if compute is None else compute
+    op_dt = _dt(A1)
+    if _dt(B1) != op_dt or (A2 is not None and (_dt(A2) != op_dt or _dt(B2) != op_dt)):
+        raise TypeError("gemm: all A / B operands must share one element type")
+    compute = (BF16 if op_dt == BF16 else _state["compute"]) if compute is None else compute
     d = _lib.GemmDesc()
     d.M, d.N, d.K1, d.K2 = M, N, K1, K2
     d.A1, d.A2, d.B1, d.B2 = _p(A1), _p(A2), _p(B1), _p(B2)
     d.lda1, d.lda2, d.ldb1, d.ldb2 = lda1, lda2, ldb1, ldb2
     d.transA, d.transB = int(transA), int(transB)
-    d.a_dtype = d.b_dtype = d.c_dtype = 0
+    d.a_dtype = d.b_dtype = op_dt
+    d.c_dtype = _dt(out)
     d.compute = compute
     d.C, d.ldc = _p(out), ldc
     d.accumulate, d.act, d.alpha = int(accumulate), act, alpha
     d.bias, d.residual, d.ldr = _p(bias), _p(residual), ldr
+    d.r_dtype = _dt(residual) if residual is not None else F32
     sk = lib.egk_gemm_splitk(M, N, K1 + K2, compute) if allow_splitk else 1
     d.splitk = sk
     if sk > 1:
-        need = sk * M * N * 4
-        ws = workspace(need, out.device)
+        ws = workspace(sk * M * N * 4, out.device)
         d.ws, d.ws_bytes = _p(ws), ws.numel()
     _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
 
@@ -145,11 +219,11 @@ def _colsum_into(x2d: torch.Tensor, out: torch.Tensor, accumulate: bool):
     lib = _lib.load()
     M, N = x2d.shape
     ws = workspace(lib.egk_colsum_ws_len(M, N) * 4, x2d.device)
-    _ck(lib.egk_colsum(_stream(), _p(x2d), x2d.stride(0), M, N, _p(out), int(accumulate), _p(ws)), "egk_colsum")
+    _ck(lib.egk_colsum(_stream(), _p(x2d), x2d.stride(0), M, N, _p(out), int(accumulate), _p(ws), _dt(x2d)), "egk_colsum")
 
 
 def _grad_slot(param: Optional[torch.Tensor]):
-    """Fused weight-gradient accumulation: if the parameter already owns a contiguous .grad (the
+    """Fused weight-gradient accumulation: if the parameter already owns a contiguous f32 .grad (the
     flat gradient buffer of egopack_amd.optim.FlatAdam), backward kernels accumulate into it and
     autograd gets None for that input."""
     if param is None:
@@ -160,28 +234,37 @@ def _grad_slot(param: Optional[torch.Tensor]):
     return None
 
 
+def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    g = _c(g)
+    return g if g.dtype == dtype else cast_raw(g, dtype)
+
+
 # ---- Linear (two-source, fused bias / ReLU / residual) ----------------------------------------------
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, W2, residual, relu, compute):
+    def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32):
         _need_gpu(x, W)
-        x = _f32c(x)
+        x = _c(x)
         M, K1 = x.shape
         N = W.shape[0]
-        Wc = _f32c(W)
+        Wop = weight_operand(W, x.dtype)
         K2 = 0
+        W2op = None
         if x2 is not None:
-            x2 = _f32c(x2)
+            x2 = _match(x2, x.dtype)
             K2 = x2.shape[1]
-            W2c = _f32c(W2)
-        res = _f32c(residual) if residual is not None else None
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        gemm(M, N, x, K1, Wc, K1, K1, y, N, A2=x2, lda2=K2, B2=W2c if K2 else None, ldb2=K2, K2=K2,
+            W2op = weight_operand(W2, x.dtype)
+        res = _c(residual) if residual is not None else None
+        y = torch.empty((M, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        gemm(M, N, x, K1, Wop, K1, K1, y, N, A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2,
              bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
         ctx.relu, ctx.compute = relu, compute
         ctx.has = (b is not None, x2 is not None, residual is not None)
+        ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.params = (W, b, W2)
-        ctx.save_for_backward(x, Wc, x2, W2c if K2 else None, y if relu else None)
+        ctx.save_for_backward(x, Wop, x2, W2op, y if relu else None)
+        if out_f32:
+            y._egk_grad_dtype = x.dtype  # lets the loss emit its gradient in the operand type
         return y
 
     @staticmethod
@@ -189,16 +272,15 @@ class _Linear(torch.autograd.Function):
         x, W, x2, W2, y = ctx.saved_tensors
         Wp, bp, W2p = ctx.params
         has_b, has_x2, has_res = ctx.has
-        dy = _f32c(dy)
-        M, N = dy.shape
+        g = _match(dy, x.dtype)
+        M, N = g.shape
         K1 = x.shape[1]
         lib = _lib.load()
         if ctx.relu:
             assert not has_res
-            g = torch.empty_like(dy)
-            _ck(lib.egk_relu_gate(_stream(), _p(dy), _p(y), _p(g), dy.numel()), "egk_relu_gate")
-        else:
-            g = dy
+            gg = torch.empty_like(g)
+            _ck(lib.egk_relu_gate(_stream(), _p(g), _p(_match(y, g.dtype)), _p(gg), g.numel(), _dt(g)), "egk_relu_gate")
+            g = gg
         needs = ctx.needs_input_grad
         dx = dW = db = dx2 = dW2 = None
         if needs[0]:
@@ -206,12 +288,12 @@ class _Linear(torch.autograd.Function):
             gemm(M, K1, g, N, W, K1, N, dx, K1, transB=True, compute=ctx.compute)
         if needs[1]:
             slot = _grad_slot(Wp)
-            out = slot if slot is not None else torch.zeros_like(W)
+            out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
             gemm(N, K1, g, N, x, K1, M, out, K1, transA=True, transB=True, accumulate=True, compute=ctx.compute)
             dW = None if slot is not None else out
         if has_b and needs[2]:
             slot = _grad_slot(bp)
-            out = slot if slot is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+            out = slot if slot is not None else torch.zeros(N, dtype=torch.float32, device=g.device)
             _colsum_into(g, out, True)
             db = None if slot is not None else out
         if has_x2:
@@ -221,16 +303,21 @@ class _Linear(torch.autograd.Function):
                 gemm(M, K2, g, N, W2, K2, N, dx2, K2, transB=True, compute=ctx.compute)
             if needs[4]:
                 slot = _grad_slot(W2p)
-                out = slot if slot is not None else torch.zeros_like(W2)
+                out = slot if slot is not None else torch.zeros(W2.shape, dtype=torch.float32, device=g.device)
                 gemm(N, K2, g, N, x2, K2, M, out, K2, transA=True, transB=True, accumulate=True, compute=ctx.compute)
                 dW2 = None if slot is not None else out
-        dres = dy if (has_res and needs[5]) else None
-        return dx, dW, db, dx2, dW2, dres, None, None
+        dres = _match(dy, ctx.res_dtype) if (has_res and needs[5]) else None
+        return dx, dW, db, dx2, dW2, dres, None, None, None
 
 
-def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None):
-    """y = relu?(x @ W.T (+ x2 @ W2.T) + b) (+ residual): one MFMA launch."""
-    return _Linear.apply(x, W, b, x2, W2, residual, relu, _state["compute"] if compute is None else compute)
+def _compute_for(x):
+    return BF16 if x.dtype == torch.bfloat16 else _state["compute"]
+
+
+def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False):
+    """y = relu?(x @ W.T (+ x2 @ W2.T) + b) (+ residual): one MFMA launch.  ``out_f32`` keeps the result
+    in f32 whatever the activation type (logits)."""
+    return _Linear.apply(x, W, b, x2, W2, residual, relu, _compute_for(x) if compute is None else compute, out_f32)
 
 
 class _MultiLinear(torch.autograd.Function):
@@ -241,31 +328,32 @@ class _MultiLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, b, compute, *xs):
         _need_gpu(W, *xs)
-        xs = [_f32c(x) for x in xs]
-        Wc = _f32c(W)
-        N, K = Wc.shape
+        xs = [_c(x) for x in xs]
+        dt = xs[0].dtype
+        Wop = weight_operand(W, dt)
+        N, K = Wop.shape
         rows = [x.shape[0] for x in xs]
-        y = torch.empty((sum(rows), N), dtype=torch.float32, device=W.device)
+        y = torch.empty((sum(rows), N), dtype=dt, device=W.device)
         bc = _f32c(b) if b is not None else None
         off = 0
         for x, m in zip(xs, rows):
-            gemm(m, N, x, K, Wc, K, K, y[off:off + m], N, bias=bc, compute=compute)
+            gemm(m, N, x, K, Wop, K, K, y[off:off + m], N, bias=bc, compute=compute)
             off += m
         ctx.compute, ctx.rows, ctx.params = compute, rows, (W, b)
-        ctx.save_for_backward(Wc, *xs)
+        ctx.save_for_backward(Wop, *xs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        Wc, *xs = ctx.saved_tensors
+        Wop, *xs = ctx.saved_tensors
         Wp, bp = ctx.params
-        dy = _f32c(dy)
-        N, K = Wc.shape
+        dy = _match(dy, xs[0].dtype)
+        N, K = Wop.shape
         needs = ctx.needs_input_grad
         dW = db = None
         if needs[0]:
             slot = _grad_slot(Wp)
-            out = slot if slot is not None else torch.zeros_like(Wc)
+            out = slot if slot is not None else torch.zeros(Wop.shape, dtype=torch.float32, device=dy.device)
             off = 0
             for x, m in zip(xs, ctx.rows):
                 gemm(N, K, dy[off:off + m], N, x, K, m, out, K, transA=True, transB=True, accumulate=True,
@@ -282,7 +370,7 @@ class _MultiLinear(torch.autograd.Function):
         for i, (x, m) in enumerate(zip(xs, ctx.rows)):
             if needs[3 + i]:
                 dx = torch.empty_like(x)
-                gemm(m, K, dy[off:off + m], N, Wc, K, N, dx, K, transB=True, compute=ctx.compute)
+                gemm(m, K, dy[off:off + m], N, Wop, K, N, dx, K, transB=True, compute=ctx.compute)
                 dxs.append(dx)
             else:
                 dxs.append(None)
@@ -291,7 +379,7 @@ class _MultiLinear(torch.autograd.Function):
 
 
 def multi_linear(xs, W, b=None, compute=None):
-    return _MultiLinear.apply(W, b, _state["compute"] if compute is None else compute, *xs)
+    return _MultiLinear.apply(W, b, _compute_for(xs[0]) if compute is None else compute, *xs)
 
 
 # ---- row LayerNorm (+ReLU, +dropout) ------------------------------------------------------------------
@@ -300,7 +388,7 @@ class _RowLN(torch.autograd.Function):
     def forward(ctx, x, w, b, eps, relu, p, training):
         _need_gpu(x, w)
         lib = _lib.load()
-        x = _f32c(x)
+        x = _c(x)
         rows, cols = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -310,7 +398,7 @@ class _RowLN(torch.autograd.Function):
         seed, off = _next_rng(rows * max(cols, 4096)) if p_eff > 0 else (0, 0)
         wc, bc = _f32c(w), _f32c(b)
         _ck(lib.egk_rowln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(mean), _p(rstd), _p(mask), rows, cols, eps,
-                              int(relu), p_eff, seed, off, _p(rng_device_offset(x.device)) if p_eff > 0 else None),
+                              int(relu), p_eff, seed, off, _p(rng_device_offset(x.device)) if p_eff > 0 else None, _dt(x)),
             "egk_rowln_fwd")
         ctx.relu, ctx.p = relu, p_eff
         ctx.params = (w, b)
@@ -323,14 +411,14 @@ class _RowLN(torch.autograd.Function):
         x, w, b, mean, rstd, mask = ctx.saved_tensors
         wp, bp = ctx.params
         rows, cols = x.shape
-        dy = _f32c(dy)
+        dy = _match(dy, x.dtype)
         dx = torch.empty_like(x)
         slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
         dw = slot_w if slot_w is not None else torch.zeros_like(w)
         db = slot_b if slot_b is not None else torch.zeros_like(b)
         ws = workspace(2 * lib.egk_rowln_bwd_ws_rows(rows) * cols * 4, x.device)
         _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), _p(dw), _p(db),
-                              _p(ws), rows, cols, int(ctx.relu), ctx.p), "egk_rowln_bwd")
+                              _p(ws), rows, cols, int(ctx.relu), ctx.p, _dt(x)), "egk_rowln_bwd")
         return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None, None
 
 
@@ -350,7 +438,7 @@ class _GraphLN(torch.autograd.Function):
     def forward(ctx, x, w, b, seg_ptr, eps, slope):
         _need_gpu(x, w, seg_ptr)
         lib = _lib.load()
-        x = _f32c(x)
+        x = _c(x)
         rows, cols = x.shape
         n_seg = seg_ptr.numel() - 1
         y = torch.empty_like(x)
@@ -358,7 +446,7 @@ class _GraphLN(torch.autograd.Function):
         ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
         wc, bc = _f32c(w), _f32c(b)
         _ck(lib.egk_graphln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
-                                slope, _p(ws)), "egk_graphln_fwd")
+                                slope, _p(ws), _dt(x)), "egk_graphln_fwd")
         ctx.eps, ctx.slope = eps, slope
         ctx.params = (w, b)
         ctx.save_for_backward(x, wc, bc, stats, seg_ptr)
@@ -371,14 +459,14 @@ class _GraphLN(torch.autograd.Function):
         wp, bp = ctx.params
         rows, cols = x.shape
         n_seg = seg_ptr.numel() - 1
-        dy = _f32c(dy)
+        dy = _match(dy, x.dtype)
         dx = torch.empty_like(x)
         slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
         dw = slot_w if slot_w is not None else torch.zeros_like(w)
         db = slot_b if slot_b is not None else torch.zeros_like(b)
         ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
         _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(seg_ptr),
-                                n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws)), "egk_graphln_bwd")
+                                n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws), _dt(x)), "egk_graphln_bwd")
         return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None
 
 
@@ -392,10 +480,11 @@ class _PEAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, freq):
         _need_gpu(x, pos, freq)
-        x = _f32c(x)
+        x = _c(x)
         rows, cols = x.shape
         y = torch.empty_like(x)
-        _ck(_lib.load().egk_pe_add(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(y), rows, cols), "egk_pe_add")
+        _ck(_lib.load().egk_pe_add(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(y), rows, cols, _dt(x)),
+            "egk_pe_add")
         return y
 
     @staticmethod
@@ -414,21 +503,22 @@ class _CSRMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rowptr, col, t_rowptr, t_col, t_wgt):
         _need_gpu(x, rowptr, col)
-        x = _f32c(x)
+        x = _c(x)
         rows, cols = x.shape
         out = torch.empty_like(x)
-        _ck(_lib.load().egk_csr_gather(_stream(), _p(x), _p(rowptr), _p(col), None, None, _p(out), rows, cols), "egk_csr_gather")
+        _ck(_lib.load().egk_csr_gather(_stream(), _p(x), _p(rowptr), _p(col), None, None, _p(out), rows, cols, _dt(x)),
+            "egk_csr_gather")
         ctx.save_for_backward(t_rowptr, t_col, t_wgt)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         t_rowptr, t_col, t_wgt = ctx.saved_tensors
-        dout = _f32c(dout)
+        dout = _c(dout)
         rows, cols = dout.shape
         dx = torch.empty_like(dout)
-        _ck(_lib.load().egk_csr_gather(_stream(), _p(dout), _p(t_rowptr), _p(t_col), _p(t_wgt), None, _p(dx), rows, cols),
-            "egk_csr_gather")
+        _ck(_lib.load().egk_csr_gather(_stream(), _p(dout), _p(t_rowptr), _p(t_col), _p(t_wgt), None, _p(dx), rows, cols,
+                                       _dt(dout)), "egk_csr_gather")
         return dx, None, None, None, None, None
 
 
@@ -442,13 +532,13 @@ class _GatherMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f, bank, nn):
         _need_gpu(f, bank, nn)
-        f, bank = _f32c(f), _f32c(bank)
+        f, bank = _c(f), _f32c(bank)
         rows, cols = f.shape
         k = nn.shape[1]
         m = torch.empty_like(f)
         arg = torch.empty((rows, cols), dtype=torch.uint8, device=f.device)
-        _ck(_lib.load().egk_gather_max_fwd(_stream(), _p(f), _p(bank), _p(nn.contiguous()), _p(m), _p(arg), rows, cols, k),
-            "egk_gather_max_fwd")
+        _ck(_lib.load().egk_gather_max_fwd(_stream(), _p(f), _p(bank), _p(nn.contiguous()), _p(m), _p(arg), rows, cols, k,
+                                           _dt(f)), "egk_gather_max_fwd")
         ctx.k = k
         ctx.save_for_backward(arg)
         return m
@@ -456,15 +546,16 @@ class _GatherMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dm):
         (arg,) = ctx.saved_tensors
-        dm = _f32c(dm)
+        dm = _c(dm)
         rows, cols = dm.shape
         df = torch.empty_like(dm)
-        _ck(_lib.load().egk_gather_max_bwd(_stream(), _p(dm), _p(arg), _p(df), rows, cols, ctx.k, 0), "egk_gather_max_bwd")
+        _ck(_lib.load().egk_gather_max_bwd(_stream(), _p(dm), _p(arg), _p(df), rows, cols, ctx.k, 0, _dt(dm)),
+            "egk_gather_max_bwd")
         return df, None, None
 
 
 def gather_max(f, bank, nn):
-    """m[n] = max(f[n], bank[nn[n, :]]) elementwise (frozen bank: no gradient to it)."""
+    """m[n] = max(f[n], bank[nn[n, :]]) elementwise (frozen f32 bank: no gradient to it)."""
     return _GatherMax.apply(f, bank, nn)
 
 
@@ -473,12 +564,13 @@ class _SegMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ptr):
         _need_gpu(x, ptr)
-        x = _f32c(x)
+        x = _c(x)
         rows, cols = x.shape
         n_seg = ptr.numel() - 1
-        out = torch.empty((n_seg, cols), dtype=torch.float32, device=x.device)
+        out = torch.empty((n_seg, cols), dtype=x.dtype, device=x.device)
         arg = torch.empty((n_seg, cols), dtype=torch.int32, device=x.device)
-        _ck(_lib.load().egk_segment_max_fwd(_stream(), _p(x), _p(ptr), _p(out), _p(arg), n_seg, cols), "egk_segment_max_fwd")
+        _ck(_lib.load().egk_segment_max_fwd(_stream(), _p(x), _p(ptr), _p(out), _p(arg), n_seg, cols, _dt(x)),
+            "egk_segment_max_fwd")
         ctx.rows = rows
         ctx.save_for_backward(arg, ptr)
         return out
@@ -486,10 +578,10 @@ class _SegMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         arg, ptr = ctx.saved_tensors
-        dout = _f32c(dout)
+        dout = _c(dout)
         n_seg, cols = dout.shape
-        dx = torch.empty((ctx.rows, cols), dtype=torch.float32, device=dout.device)
-        _ck(_lib.load().egk_segment_max_bwd(_stream(), _p(dout), _p(arg), _p(ptr), _p(dx), n_seg, ctx.rows, cols),
+        dx = torch.empty((ctx.rows, cols), dtype=dout.dtype, device=dout.device)
+        _ck(_lib.load().egk_segment_max_bwd(_stream(), _p(dout), _p(arg), _p(ptr), _p(dx), n_seg, ctx.rows, cols, _dt(dout)),
             "egk_segment_max_bwd")
         return dx, None
 
@@ -500,9 +592,13 @@ def segment_max(x, ptr):
 
 
 # ---- losses ---------------------------------------------------------------------------------------------
+def _grad_dtype_of(t: torch.Tensor) -> torch.dtype:
+    return getattr(t, "_egk_grad_dtype", torch.float32)
+
+
 class _CE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, smoothing, y, *logits):
+    def forward(ctx, smoothing, y, gdt, *logits):
         # loss[n] = sum_h CE(logits[h][n], y[n, h]) with ignore_index -1 (y: [N] or [N, heads] int64)
         _need_gpu(y, *logits)
         lib = _lib.load()
@@ -518,7 +614,7 @@ class _CE(torch.autograd.Function):
             _ck(lib.egk_ce_fwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ystride, _p(loss), _p(lse), rows,
                                l.shape[1], smoothing, int(h > 0)), "egk_ce_fwd")
             saved += [l, lse]
-        ctx.smoothing, ctx.ystride, ctx.nh = smoothing, ystride, len(logits)
+        ctx.smoothing, ctx.ystride, ctx.nh, ctx.gdt = smoothing, ystride, len(logits), gdt
         ctx.save_for_backward(y, *saved)
         return loss
 
@@ -531,30 +627,32 @@ class _CE(torch.autograd.Function):
         for h in range(ctx.nh):
             l, lse = saved[2 * h], saved[2 * h + 1]
             rows, Cn = l.shape
-            d = torch.empty_like(l)
+            d = torch.empty((rows, Cn), dtype=ctx.gdt[h], device=l.device)
             yh = y if y.dim() == 1 else y[:, h]
             _ck(lib.egk_ce_bwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ctx.ystride, _p(lse), _p(gloss),
-                               _p(d), d.stride(0), rows, Cn, ctx.smoothing), "egk_ce_bwd")
+                               _p(d), d.stride(0), rows, Cn, ctx.smoothing, _dt(d)), "egk_ce_bwd")
             grads.append(d)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 def cross_entropy(logits, y, smoothing: float = 0.0):
     """Per-row CrossEntropy(reduction='none', ignore_index=-1), summed over heads when ``logits`` is
-    a tuple and y is [N, heads]."""
+    a tuple and y is [N, heads].  Logits are f32; their gradient is emitted in the element type the
+    producing contraction wants (bf16 in 'bf16' mode)."""
     if torch.is_tensor(logits):
         logits = (logits,)
-    return _CE.apply(float(smoothing), y, *logits)
+    return _CE.apply(float(smoothing), y, tuple(_grad_dtype_of(l) for l in logits), *logits)
 
 
 class _BCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, y):
+    def forward(ctx, logits, y, gdt):
         _need_gpu(logits, y)
         logits = _f32c(logits)
         y = y.contiguous()
         loss = torch.empty_like(logits)
         _ck(_lib.load().egk_bce_fwd(_stream(), _p(logits), _p(y), _p(loss), logits.numel()), "egk_bce_fwd")
+        ctx.gdt = gdt
         ctx.save_for_backward(logits, y)
         return loss
 
@@ -562,16 +660,16 @@ class _BCE(torch.autograd.Function):
     def backward(ctx, g):
         logits, y = ctx.saved_tensors
         g = _f32c(g)
-        d = torch.empty_like(logits)
-        _ck(_lib.load().egk_bce_bwd(_stream(), _p(logits), _p(y), _p(g), _p(d), logits.numel()), "egk_bce_bwd")
-        return d, None
+        d = torch.empty(logits.shape, dtype=ctx.gdt, device=logits.device)
+        _ck(_lib.load().egk_bce_bwd(_stream(), _p(logits), _p(y), _p(g), _p(d), logits.numel(), _dt(d)), "egk_bce_bwd")
+        return d, None, None
 
 
 def bce_with_logits(logits, y):
     """BCEWithLogitsLoss(reduction='none') against y.float(); y int64 of the same shape."""
     if y.dtype != torch.int64:
         y = y.to(torch.int64)
-    return _BCE.apply(logits, y)
+    return _BCE.apply(logits, y, _grad_dtype_of(logits))
 
 
 # ---- dropout / reductions -----------------------------------------------------------------------------------
@@ -579,12 +677,12 @@ class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p):
         _need_gpu(x)
-        x = _f32c(x)
+        x = _c(x)
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         seed, off = _next_rng(x.numel())
         _ck(_lib.load().egk_dropout_fwd(_stream(), _p(x), _p(y), _p(mask), x.numel(), p, seed, off,
-                                        _p(rng_device_offset(x.device))), "egk_dropout_fwd")
+                                        _p(rng_device_offset(x.device)), _dt(x)), "egk_dropout_fwd")
         ctx.p = p
         ctx.save_for_backward(mask)
         return y
@@ -592,9 +690,9 @@ class _Dropout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
-        dy = _f32c(dy)
+        dy = _c(dy)
         dx = torch.empty_like(dy)
-        _ck(_lib.load().egk_dropout_bwd(_stream(), _p(dy), _p(mask), _p(dx), dy.numel(), ctx.p), "egk_dropout_bwd")
+        _ck(_lib.load().egk_dropout_bwd(_stream(), _p(dy), _p(mask), _p(dx), dy.numel(), ctx.p, _dt(dy)), "egk_dropout_bwd")
         return dx, None
 
 
@@ -652,21 +750,72 @@ class _SumTensors(torch.autograd.Function):
             for t in ts[2:]:
                 _ck(lib.egk_axpby(_stream(), _p(out), _p(t), _p(out), n, 1.0, scale), "egk_axpby")
         ctx.scale, ctx.n = scale, len(ts)
+        gd = [_grad_dtype_of(t) for t in ts]
+        if all(d == gd[0] for d in gd):
+            out._egk_grad_dtype = gd[0]
         return out
 
     @staticmethod
     def backward(ctx, g):
         if ctx.scale == 1.0:
             return (None, *([g] * ctx.n))
-        g = _f32c(g)
-        d = torch.empty_like(g)
-        _ck(_lib.load().egk_axpby(_stream(), _p(g), None, _p(d), g.numel(), ctx.scale, 0.0), "egk_axpby")
-        return (None, *([d] * ctx.n))
+        g = _c(g)
+        d = cast_raw(g, torch.float32) if g.dtype != torch.float32 else g
+        o = torch.empty_like(d)
+        _ck(_lib.load().egk_axpby(_stream(), _p(d), None, _p(o), d.numel(), ctx.scale, 0.0), "egk_axpby")
+        return (None, *([o] * ctx.n))
 
 
 def sum_tensors(ts, scale: float = 1.0):
-    """scale * sum(ts): logit fusion ``stack([...]).sum(0)`` / ``.mean(0)`` without the stacked copy."""
+    """scale * sum(ts): logit fusion ``stack([...]).sum(0)`` / ``.mean(0)`` without the stacked copy (f32 logits)."""
     return _SumTensors.apply(float(scale), *ts)
+
+
+class _SplitRows(torch.autograd.Function):
+    """Row slices of the fused backbone output, one per task batch.  Backward writes the incoming slice
+    gradients into ONE buffer (a copy per slice) instead of autograd's fill + copy + add per slice."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        ctx.sizes, ctx.shape, ctx.dtype = sizes, x.shape, x.dtype
+        outs, off = [], 0
+        for s in sizes:
+            outs.append(x[off:off + s])
+            off += s
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = _lib.load()
+        dev = next(g.device for g in gs if g is not None)
+        out = torch.empty(ctx.shape, dtype=ctx.dtype, device=dev)
+        off = 0
+        for s, g in zip(ctx.sizes, gs):
+            dst = out[off:off + s]
+            if g is None:
+                dst.zero_()
+            else:
+                g = _match(g, ctx.dtype)
+                if ctx.dtype == torch.float32:
+                    _ck(lib.egk_axpby(_stream(), _p(g), None, _p(dst), g.numel(), 1.0, 0.0), "egk_axpby")
+                else:
+                    dst.copy_(g)  # device-to-device memcpy of a contiguous block
+            off += s
+        return out, None
+
+
+def split_rows(x, sizes):
+    return _SplitRows.apply(x, tuple(int(s) for s in sizes))
+
+
+# ---- cosine k-NN (no grad) ------------------------------------------------------------------------------------
+@torch.no_grad()
+def row_inv_norm(x):
+    _need_gpu(x)
+    x = _c(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _ck(_lib.load().egk_row_inv_norm(_stream(), _p(x), _p(out), x.shape[0], x.shape[1], _dt(x)), "egk_row_inv_norm")
+    return out
 
 
 @torch.no_grad()
@@ -678,24 +827,16 @@ def scaled_one_minus(dot, f_inv, b_inv):
     return out
 
 
-# ---- cosine k-NN (no grad) ------------------------------------------------------------------------------------
-@torch.no_grad()
-def row_inv_norm(x):
-    _need_gpu(x)
-    x = _f32c(x)
-    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-    _ck(_lib.load().egk_row_inv_norm(_stream(), _p(x), _p(out), x.shape[0], x.shape[1]), "egk_row_inv_norm")
-    return out
-
-
 @torch.no_grad()
 def cosine_topk(f, bank, k, bank_inv_norm=None):
     """Indices [N, k] (int64, ascending cosine distance) of the k nearest bank rows of every row of f.
-    The similarity product always runs on the exact-f32 MFMA path so that index selection does not
-    depend on the bf16 setting (hard parts)."""
+    The similarity product always runs on the exact-f32 MFMA path (bf16 features are widened first) so
+    that index selection depends on the stored feature values only, not on the MFMA type."""
     _need_gpu(f, bank)
     lib = _lib.load()
-    f, bank = _f32c(f), _f32c(bank)
+    f, bank = _c(f), _f32c(bank)
+    if f.dtype != torch.float32:
+        f = cast_raw(f, torch.float32)
     N, H = f.shape
     K = bank.shape[0]
     if bank_inv_norm is None:
@@ -711,9 +852,9 @@ def cosine_topk(f, bank, k, bank_inv_norm=None):
 @torch.no_grad()
 def scatter_add_rows_f64(x, label, bank, count):
     _need_gpu(x, label, bank)
-    x = _f32c(x)
+    x = _c(x)
     _ck(_lib.load().egk_scatter_add_rows_f64(_stream(), _p(x), _p(label.contiguous()), _p(bank), _p(count), x.shape[0],
-                                            x.shape[1], bank.shape[0]), "egk_scatter_add_rows_f64")
+                                            x.shape[1], bank.shape[0], _dt(x)), "egk_scatter_add_rows_f64")
 
 
 # ---- profiling --------------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ from typing import Iterable, List
 import torch
 
 from . import _lib
+from . import ops
 from .ops import _ck, _p, _stream
 
 
@@ -32,7 +33,7 @@ class FlatAdam(torch.optim.Optimizer):
                     uniq.append(p)
             params = uniq
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self.flat_p = self.flat_g = self.flat_m = self.flat_v = self.flat_w16 = None
         self.active: List[torch.Tensor] = []
         self.step_count = 0
         self.grad_scale = 1.0
@@ -47,12 +48,13 @@ class FlatAdam(torch.optim.Optimizer):
         dev = live[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam needs parameters on a ROCm device (no CPU fallback)")
-        sizes = [(p.numel() + 3) // 4 * 4 for p in live]  # 16-byte aligned slots
+        sizes = [(p.numel() + 7) // 8 * 8 for p in live]  # slots aligned to 16 bytes in the bf16 shadow (32 B in f32)
         total = sum(sizes)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_w16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)  # bf16 operand copies of the weights
         off = 0
         with torch.no_grad():
             for p, sz in zip(live, sizes):
@@ -61,9 +63,17 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat_g[off:off + n].copy_(p.grad.reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
+                p._egk_shadow = self.flat_w16[off:off + n].view(p.shape)
                 off += sz
         self.active = live
+        self.refresh_shadows()
         self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def refresh_shadows(self):
+        """Re-derive the bf16 operand copies from the f32 parameters (after load_state_dict or any other
+        write to the parameters that did not go through ``step``)."""
+        if self.flat_w16 is not None:
+            _ck(_lib.load().egk_cast(_stream(), _p(self.flat_p), 0, _p(self.flat_w16), 1, self.flat_p.numel()), "egk_cast")
 
     @property
     def materialised(self) -> bool:
@@ -95,7 +105,8 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
-                                      self.flat_p.numel(), _p(self._hyper), b1, b2, g["eps"], g["weight_decay"]),
+                                      self.flat_p.numel(), _p(self._hyper), b1, b2, g["eps"], g["weight_decay"],
+                                      _p(self.flat_w16)),
             "egk_adam_step")
 
     @torch.no_grad()

@@ -107,7 +107,7 @@ def load_checkpoint(path, model, tasks, strict_tasks: bool = True, device="cpu")
     for t, key in CKPT_KEYS.items():
         if ckpt.get(key) is not None:
             tasks[t].load_state_dict(ckpt[key], strict=strict_tasks)
-    return ckpt
+    return ckpt  # NOTE: after FlatAdam has materialised, follow a load with optimizer.refresh_shadows()
 
 
 def setup_logging(rank: int):

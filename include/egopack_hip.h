@@ -62,17 +62,18 @@ typedef struct egk_gemm_desc {
     const void *B1, *B2;
     int64_t lda1, lda2, ldb1, ldb2;
     int32_t transA, transB;
-    int32_t a_dtype, b_dtype; /* EGK_F32 (EGK_BF16 in memory: reserved) */
+    int32_t a_dtype, b_dtype; /* element type in memory: EGK_F32 or EGK_BF16 (same for A and B; bf16 needs EGK_COMPUTE_BF16) */
     int32_t compute;          /* EGK_COMPUTE_* */
     void* C;
     int64_t ldc;
-    int32_t c_dtype;          /* EGK_F32 */
+    int32_t c_dtype;          /* EGK_F32 or EGK_BF16 (accumulate needs EGK_F32) */
     int32_t accumulate;
     int32_t act;
     float alpha;
     const float* bias;     /* [N] or NULL */
-    const float* residual; /* [M, ldr] or NULL */
+    const void* residual;  /* [M, ldr] of r_dtype, or NULL */
     int64_t ldr;
+    int32_t r_dtype;
     /* split-K: splitk > 1 writes f32 partial slabs [splitk][M][N] to ws (plain stores) and a
      * second launch sums them in slab order and applies the epilogue (bitwise reproducible, no
      * atomics).  ws_bytes >= splitk*M*N*4.  egk_gemm_splitk() is the library's policy. */
@@ -86,8 +87,8 @@ int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute);
 /* out[n] (+)= sum_m x[m, n] : bias gradients of every Linear above.  Two launches (row-chunk
  * partials in ws, then a fixed-order sum); ws: float[egk_colsum_ws_len(M, N)]. */
 int egk_colsum_ws_len(int32_t M, int32_t N);
-int egk_colsum(egk_stream_t s, const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
-               float* ws);
+int egk_colsum(egk_stream_t s, const void* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+               float* ws, int32_t dtype);
 
 /* ---- row LayerNorm (+ReLU, +dropout)  nn.LayerNorm -> ReLU -> Dropout -----------------
  * trn_pooling.py:31-33,36-38; task.py:19-20; graphONE.py:61-62.
@@ -96,15 +97,15 @@ int egk_colsum(egk_stream_t s, const float* x, int64_t ldx, int32_t M, int32_t N
  * relu=0 disables the activation. mask may be NULL iff p==0.
  * dev_offset (device, uint64[1], may be NULL) is added to ``offset`` inside the kernel: a caller
  * that replays a captured graph advances it between replays so every step draws a fresh mask. */
-int egk_rowln_fwd(egk_stream_t s, const float* x, const float* w, const float* b, float* y, float* mean,
+int egk_rowln_fwd(egk_stream_t s, const void* x, const float* w, const float* b, void* y, float* mean,
                   float* rstd, uint8_t* mask, int32_t rows, int32_t cols, float eps, int32_t relu, float p,
-                  uint64_t seed, uint64_t offset, const uint64_t* dev_offset);
+                  uint64_t seed, uint64_t offset, const uint64_t* dev_offset, int32_t dtype);
 /* dx; dw/db are ACCUMULATED into dw[cols], db[cols] through per-block partials in ws
  * (ws: float[2 * egk_rowln_bwd_ws_rows(rows) * cols]). */
 int egk_rowln_bwd_ws_rows(int32_t rows);
-int egk_rowln_bwd(egk_stream_t s, const float* dy, const float* x, const float* w, const float* b, const float* mean,
-                  const float* rstd, const uint8_t* mask, float* dx, float* dw, float* db, float* ws, int32_t rows,
-                  int32_t cols, int32_t relu, float p);
+int egk_rowln_bwd(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b, const float* mean,
+                  const float* rstd, const uint8_t* mask, void* dx, float* dw, float* db, float* ws, int32_t rows,
+                  int32_t cols, int32_t relu, float p, int32_t dtype);
 
 /* ---- graph-mode LayerNorm + LeakyReLU  gnn.LayerNorm(mode='graph', batch=None) -> LeakyReLU
  * models/graph.py:43-44.  Statistics span all rows*cols elements of one SEGMENT of rows; seg_ptr
@@ -115,17 +116,17 @@ int egk_rowln_bwd(egk_stream_t s, const float* dy, const float* x, const float* 
  * ws: egk_graphln_ws_bytes(rows, cols, n_seg) bytes of scratch, 16-byte aligned.
  * bwd ACCUMULATES dw/db (either may be NULL).  n_seg <= 16. */
 int64_t egk_graphln_ws_bytes(int32_t rows, int32_t cols, int32_t n_seg);
-int egk_graphln_fwd(egk_stream_t s, const float* x, const float* w, const float* b, float* y, float* stats,
+int egk_graphln_fwd(egk_stream_t s, const void* x, const float* w, const float* b, void* y, float* stats,
                     const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope,
-                    void* ws);
-int egk_graphln_bwd(egk_stream_t s, const float* dy, const float* x, const float* w, const float* b,
-                    const float* stats, float* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
-                    int32_t rows, int32_t cols, float eps, float slope, void* ws);
+                    void* ws, int32_t dtype);
+int egk_graphln_bwd(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b,
+                    const float* stats, void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
+                    int32_t rows, int32_t cols, float eps, float slope, void* ws, int32_t dtype);
 
 /* ---- positional encoding  gnn.PositionalEncoding + add   models/graph.py:37,63 ----------
  * y[n, c] = x[n, c] + (c < C/2 ? sin(pos[n]*freq[c]) : cos(pos[n]*freq[c-C/2])) */
-int egk_pe_add(egk_stream_t s, const float* x, const int64_t* pos, const float* freq, float* y, int32_t rows,
-               int32_t cols);
+int egk_pe_add(egk_stream_t s, const void* x, const int64_t* pos, const float* freq, void* y, int32_t rows,
+               int32_t cols, int32_t dtype);
 
 /* ---- CSR row gathers (message passing) ------------------------------------------------
  * out[i,:] = sum_{e in [rowptr[i], rowptr[i+1])} w_e * x[col[e], :]
@@ -135,27 +136,27 @@ int egk_pe_add(egk_stream_t s, const float* x, const int64_t* pos, const float* 
  * (CSR by target, wgt NULL) or its backward (CSR by source, wgt = 1/deg(target)):
  * models/graph.py:42 (PyG SAGEConv.propagate + MeanAggregation).  No atomics:
  * bitwise reproducible. */
-int egk_csr_gather(egk_stream_t s, const float* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
-                   const float* relu_gate, float* out, int32_t rows, int32_t cols);
+int egk_csr_gather(egk_stream_t s, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
+                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype);
 
 /* GraphONE SAGEConv(aggr='max') over cat([bank, f]) restricted to the N feature rows that are
  * kept (graphONE.py:104-115): m[n,:] = max(f[n,:], bank[nn[n,0..k),:]); arg[n,c] = winner
  * (0..k-1 = neighbour slot, k = self).  bwd: df[n,c] = (arg==k) ? dm[n,c] : 0  (bank frozen). */
-int egk_gather_max_fwd(egk_stream_t s, const float* f, const float* bank, const int64_t* nn, float* m, uint8_t* arg,
-                       int32_t rows, int32_t cols, int32_t k);
-int egk_gather_max_bwd(egk_stream_t s, const float* dm, const uint8_t* arg, float* df, int32_t rows, int32_t cols,
-                       int32_t k, int32_t accumulate);
+int egk_gather_max_fwd(egk_stream_t s, const void* f, const float* bank, const int64_t* nn, void* m, uint8_t* arg,
+                       int32_t rows, int32_t cols, int32_t k, int32_t dtype);
+int egk_gather_max_bwd(egk_stream_t s, const void* dm, const uint8_t* arg, void* df, int32_t rows, int32_t cols,
+                       int32_t k, int32_t accumulate, int32_t dtype);
 
 /* global_max_pool over contiguous sequences (oscc.py:68,85): out[b,:] = max_{n in [ptr[b],ptr[b+1])} x[n,:];
  * arg[b,c] = winning row.  bwd scatters dout to the winners (dx zero elsewhere). */
-int egk_segment_max_fwd(egk_stream_t s, const float* x, const int32_t* ptr, float* out, int32_t* arg, int32_t n_seg,
-                        int32_t cols);
-int egk_segment_max_bwd(egk_stream_t s, const float* dout, const int32_t* arg, const int32_t* ptr, float* dx,
-                        int32_t n_seg, int32_t rows, int32_t cols);
+int egk_segment_max_fwd(egk_stream_t s, const void* x, const int32_t* ptr, void* out, int32_t* arg, int32_t n_seg,
+                        int32_t cols, int32_t dtype);
+int egk_segment_max_bwd(egk_stream_t s, const void* dout, const int32_t* arg, const int32_t* ptr, void* dx,
+                        int32_t n_seg, int32_t rows, int32_t cols, int32_t dtype);
 
 /* ---- cosine k-NN   GraphONE.__compute_edges + cos_dissimilarity  graphONE.py:119-151 ----
  * inv_norm[r] = 1/||x[r,:]||  (rows of features or of the bank) */
-int egk_row_inv_norm(egk_stream_t s, const float* x, float* inv_norm, int32_t rows, int32_t cols);
+int egk_row_inv_norm(egk_stream_t s, const void* x, float* inv_norm, int32_t rows, int32_t cols, int32_t dtype);
 /* dist[n,j] = 1 - dot[n,j]*f_inv[n]*b_inv[j]  (cos_dissimilarity, graphONE.py:148-151) */
 int egk_cos_dist(egk_stream_t s, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv, float* dist,
                  int32_t rows, int32_t K);
@@ -167,8 +168,8 @@ int egk_topk_smallest(egk_stream_t s, const float* dot, int64_t ldd, const float
 /* ---- prototype bank accumulation  graphone.py:53,55 (scatter(..., reduce='sum') in float64
  * + bincount).  bank[label[n],:] += x[n,:] (fp64), count[label[n]] += 1.  Rows with label<0
  * are skipped. */
-int egk_scatter_add_rows_f64(egk_stream_t s, const float* x, const int64_t* label, double* bank, int64_t* count,
-                             int32_t rows, int32_t cols, int64_t n_labels);
+int egk_scatter_add_rows_f64(egk_stream_t s, const void* x, const int64_t* label, double* bank, int64_t* count,
+                             int32_t rows, int32_t cols, int64_t n_labels, int32_t dtype);
 
 /* ---- losses ---------------------------------------------------------------------------
  * nn.CrossEntropyLoss(reduction='none', ignore_index=-1[, label_smoothing]) criterion/wrapper.py:67-82,
@@ -177,18 +178,25 @@ int egk_scatter_add_rows_f64(egk_stream_t s, const float* x, const int64_t* labe
 int egk_ce_fwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, float* loss,
                float* lse, int32_t rows, int32_t C, float smoothing, int32_t accumulate);
 int egk_ce_bwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, const float* lse,
-               const float* gloss, float* dlogits, int64_t ldd, int32_t rows, int32_t C, float smoothing);
+               const float* gloss, void* dlogits, int64_t ldd, int32_t rows, int32_t C, float smoothing, int32_t dtype);
 /* nn.BCEWithLogitsLoss(reduction='none') on y.float()  main_temporal.py:123,298; pnr.py:82-83 */
 int egk_bce_fwd(egk_stream_t s, const float* logits, const int64_t* y, float* loss, int32_t n);
-int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const float* gloss, float* dlogits, int32_t n);
+int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const float* gloss, void* dlogits, int32_t n,
+                int32_t dtype);
+
+/* Activation element types.  Every entry point with a trailing ``dtype`` argument reads / writes its
+ * [rows, cols] activation (and activation-gradient) matrices as EGK_F32 or EGK_BF16; all arithmetic,
+ * statistics, parameters and parameter gradients stay f32.
+ * egk_cast converts n contiguous elements between the two types. */
+int egk_cast(egk_stream_t s, const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n);
 
 /* ---- small elementwise helpers ----------------------------------------------------------- */
 /* y = keep ? x/(1-p) : 0 with a fresh Philox mask (nn.Dropout: task.py:18, graph.py:30, heads) */
-int egk_dropout_fwd(egk_stream_t s, const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
-                    uint64_t offset, const uint64_t* dev_offset);
-int egk_dropout_bwd(egk_stream_t s, const float* dy, const uint8_t* mask, float* dx, int64_t n, float p);
+int egk_dropout_fwd(egk_stream_t s, const void* x, void* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                    uint64_t offset, const uint64_t* dev_offset, int32_t dtype);
+int egk_dropout_bwd(egk_stream_t s, const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, int32_t dtype);
 /* dx = y > 0 ? dy : 0  -- backward of a ReLU fused into a contraction epilogue (graph.py:42 project) */
-int egk_relu_gate(egk_stream_t s, const float* dy, const float* y, float* dx, int64_t n);
+int egk_relu_gate(egk_stream_t s, const void* dy, const void* y, void* dx, int64_t n, int32_t dtype);
 /* out = a*x + b*y (y may be NULL) */
 int egk_axpby(egk_stream_t s, const float* x, const float* y, float* out, int64_t n, float a, float b);
 /* out[i] = scalar[0] * coef  -- backward of the scaled mean below */
@@ -200,9 +208,11 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
  * One launch over the flat parameter / gradient / moment buffers.  hyper (device, float[4]) =
  * {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale}: rewritten by the host between graph replays.
  * g' = g*grad_scale + wd*p; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2;
- * p -= (lr/bc1) * m / (sqrt(v)/bc2_sqrt + eps) */
+ * p -= (lr/bc1) * m / (sqrt(v)/bc2_sqrt + eps)
+ * bf16_shadow (may be NULL): bf16 copy of the updated parameters, same flat layout, written by the same
+ * launch -- the operand the bf16 contractions read (no separate cast pass over the weights). */
 int egk_adam_step(egk_stream_t s, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                  float beta1, float beta2, float eps, float weight_decay);
+                  float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
 
 #ifdef __cplusplus
 }

@@ -481,3 +481,134 @@ def test_flat_adam_matches_torch_adam(ops):
 def test_ops_reject_cpu_tensors(ops):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.linear(torch.randn(4, 4), torch.randn(4, 4))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16 activations / operands in memory (mode 'bf16'): every kernel computes in f32 from bf16-rounded inputs,
+# so the reference is the f32/f64 op applied to the ROUNDED inputs; the only extra error is the final rounding
+# of a bf16 output (relative 2^-8) -> rtol 8e-3.
+# ---------------------------------------------------------------------------------------------------------
+BF = torch.bfloat16
+OUT16 = dict(rtol=8e-3, atol=8e-3)
+
+
+def r16(t):
+    return t.to(BF).float()
+
+
+@pytest.mark.parametrize("transA,transB", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(130, 70, 40), (257, 129, 144), (64, 7, 32), (300, 256, 200), (128, 128, 64)])
+@pytest.mark.parametrize("out16", [False, True])
+def test_gemm_bf16_memory_operands(ops, transA, transB, M, N, K, out16):
+    g = gen(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if transA else (M, K), generator=g)
+    B = torch.randn((K, N) if transB else (N, K), generator=g)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    opA = (A.t() if transA else A).to(BF).double()
+    opB = (B.t() if transB else B).to(BF).double()
+    ref = (opA @ opB.t() + bias.double()).float() + r16(res)
+    out = torch.empty(M, N, device=DEV, dtype=BF if out16 else torch.float32)
+    ops.gemm(M, N, A.to(DEV).to(BF), A.shape[1], B.to(DEV).to(BF), B.shape[1], K, out, N, transA=transA, transB=transB,
+             bias=bias.to(DEV), residual=res.to(DEV).to(BF), ldr=N)
+    torch.testing.assert_close(out.float().cpu(), ref, **(OUT16 if out16 else dict(rtol=1e-3, atol=1e-3)))
+
+
+def test_gemm_bf16_two_source_splitk_accumulate(ops):
+    g = gen(77)
+    M, N, K1, K2 = 128, 256, 2048, 2048  # dW shape: few tiles, deep K -> split-K slabs
+    A1, A2 = torch.randn(K1, M, generator=g), torch.randn(K2, M, generator=g)
+    B1, B2 = torch.randn(K1, N, generator=g), torch.randn(K2, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = (A1.to(BF).double().t() @ B1.to(BF).double() + A2.to(BF).double().t() @ B2.to(BF).double() + C0.double()).float()
+    out = C0.clone().to(DEV)
+    ops.gemm(M, N, A1.to(DEV).to(BF), M, B1.to(DEV).to(BF), N, K1, out, N, A2=A2.to(DEV).to(BF), lda2=M,
+             B2=B2.to(DEV).to(BF), ldb2=N, K2=K2, transA=True, transB=True, accumulate=True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=1e-2)
+
+
+def test_cast_roundtrip(ops):
+    x = torch.randn(1000, 37, device=DEV)
+    h = ops.cast_raw(x, BF)
+    assert h.dtype == BF and torch.equal(h, x.to(BF))
+    assert torch.equal(ops.cast_raw(h, torch.float32), h.float())
+
+
+def test_linear_autograd_full_bf16(ops):
+    g = gen(88)
+    M, K1, K2, N = 70, 40, 32, 24
+    x, x2 = r16(torch.randn(M, K1, generator=g)), r16(torch.randn(M, K2, generator=g))
+    W, W2, b = r16(torch.randn(N, K1, generator=g)), r16(torch.randn(N, K2, generator=g)), torch.randn(N, generator=g)
+    r, w = r16(torch.randn(M, N, generator=g)), r16(torch.randn(M, N, generator=g))
+    cpu = [t.clone().requires_grad_(True) for t in (x, W, b, x2, W2, r)]
+    ref = torch.nn.functional.linear(cpu[0], cpu[1], cpu[2]) + torch.nn.functional.linear(cpu[3], cpu[4]) + cpu[5]
+    (ref * w).sum().backward()
+    dx, dx2, dr = (t.clone().to(DEV).to(BF).requires_grad_(True) for t in (x, x2, r))
+    dW, db, dW2 = (t.clone().to(DEV).requires_grad_(True) for t in (W, b, W2))
+    with ops.compute_mode("bf16"):
+        out = ops.linear(dx, dW, db, x2=dx2, W2=dW2, residual=dr)
+        assert out.dtype == BF
+        (out.float() * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().float().cpu(), ref.detach(), rtol=1e-2, atol=3e-2)
+    for a, c in zip((dx, dW, db, dx2, dW2, dr), cpu):
+        torch.testing.assert_close(a.grad.float().cpu(), c.grad, rtol=2e-2, atol=6e-2)
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 40), (130, 1024), (9, 4096)])
+def test_rowln_bf16_activations(ops, rows, cols):
+    g = gen(rows + cols + 1)
+    x = r16(torch.randn(rows, cols, generator=g) * 2 + 0.3)
+    w, b = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    wt = r16(torch.randn(rows, cols, generator=g))
+    cx, cw, cb = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = torch.relu(F.layer_norm(cx, (cols,), cw, cb, 1e-5))
+    (ref * wt).sum().backward()
+    dx = x.clone().to(DEV).to(BF).requires_grad_(True)
+    dw, db = w.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    out = ops.row_layernorm(dx, dw, db, 1e-5, relu=True)
+    assert out.dtype == BF
+    (out.float() * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().float().cpu(), ref.detach(), **OUT16)
+    # the incoming gradient passes through the bf16 output of ``out.float()``'s backward: rounded once more
+    torch.testing.assert_close(dx.grad.float().cpu(), cx.grad, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dw.grad.cpu(), cw.grad, rtol=2e-2, atol=3e-2 * rows ** 0.5)
+    torch.testing.assert_close(db.grad.cpu(), cb.grad, rtol=2e-2, atol=3e-2 * rows ** 0.5)
+
+
+def test_graphln_csr_pe_bf16_activations(ops):
+    from egopack_amd.data import build_csr, radius_band_edges
+    g = gen(99)
+    rows, cols = 64, 1024
+    x = r16(torch.randn(rows, cols, generator=g) * 1.5 + 0.2)
+    w, b = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    seg = [0, 24, 64]
+    ref = torch.cat([F.leaky_relu(P.graph_layer_norm(x[s:e], w, b), 0.2) for s, e in zip(seg[:-1], seg[1:])])
+    xd = x.to(DEV).to(BF)
+    out = ops.graph_layernorm_lrelu(xd, w.to(DEV), b.to(DEV), torch.tensor(seg, dtype=torch.int32, device=DEV))
+    assert out.dtype == BF
+    torch.testing.assert_close(out.float().cpu(), ref, **OUT16)
+    ei = torch.cat([radius_band_edges(torch.arange(32), 1), radius_band_edges(torch.arange(32), 2) + 32], 1)
+    agg = ops.csr_mean_aggregate(xd, build_csr(ei, rows).to(DEV))
+    torch.testing.assert_close(agg.float().cpu(), P.scatter_mean(x[ei[0]], ei[1], rows), **OUT16)
+    pos = torch.randint(-64, 64, (rows,), generator=g)
+    freq = P.positional_encoding_frequency(cols)
+    pe = ops.pe_add(xd, pos.to(DEV), freq.to(DEV))
+    torch.testing.assert_close(pe.float().cpu(), x + P.positional_encoding(pos, freq), **OUT16)
+
+
+def test_gather_segmax_dropout_relu_bf16_activations(ops):
+    g = gen(111)
+    N, K, H, k = 40, 37, 256, 4
+    f, bank = r16(torch.randn(N, H, generator=g)), torch.randn(K, H, generator=g)
+    nn = torch.stack([torch.randperm(K, generator=g)[:k] for _ in range(N)])
+    fd = f.to(DEV).to(BF).requires_grad_(True)
+    m = ops.gather_max(fd, bank.to(DEV), nn.to(DEV))
+    ref = torch.cat([bank[nn], f.unsqueeze(1)], 1).max(1).values
+    torch.testing.assert_close(m.detach().float().cpu(), ref, **OUT16)  # bank values are rounded on output
+    m.float().sum().backward()
+    assert set(fd.grad.float().unique().tolist()) <= {0.0, 1.0}
+    ptr = torch.tensor([0, 10, 40], dtype=torch.int32)
+    sm = ops.segment_max(f.to(DEV).to(BF), ptr.to(DEV))
+    assert torch.equal(sm.float().cpu(), torch.stack([f[:10].max(0).values, f[10:].max(0).values]))
+    ops.manual_seed(3)
+    y = ops.dropout(torch.ones(4096, device=DEV, dtype=BF), 0.5, True)
+    assert y.dtype == BF and abs((y != 0).float().mean().item() - 0.5) < 0.05 and float(y.max()) == 2.0
