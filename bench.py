@@ -58,16 +58,22 @@ def build_workload(args, rank, device):
         host[t] = D.collate([ds[i] for i in range(args.batch)])
     gen = torch.Generator(device=device)
     gen.manual_seed(1 + rank)
+    order = ("ar", "lta", "pnr")
+    n = args.batch * args.T
+    # one resident feature buffer for the step (what data.pack_features builds from loader batches); the
+    # task batches are row ranges of it.  bf16 storage for the bf16 configs.
+    x_all = torch.randn(len(order) * n, S, F_IN, device=device, generator=gen)
+    if args.compute == "bf16":
+        x_all = x_all.to(torch.bfloat16)
     dev = {}
-    for t, b in host.items():
+    for i, t in enumerate(order):
+        b = host[t]
         b.x = torch.empty(0)
         d = b.to(device)
-        d.x = torch.randn(args.batch * args.T, S, F_IN, device=device, generator=gen)
-        if args.compute == "bf16":  # Omnivore features stored in bf16 for the bf16 configs
-            d.x = d.x.to(torch.bfloat16)
+        d.x = x_all[i * n:(i + 1) * n]
         dev[t] = d
-    merged = D.merge_batches([host[t] for t in ("ar", "lta", "pnr")]).to(device)
-    merged.x = [dev[t].x for t in ("ar", "lta", "pnr")]
+    merged = D.merge_batches([host[t] for t in order]).to(device)
+    merged.x = x_all
     return model, tasks, crit, weights, dev, merged
 
 

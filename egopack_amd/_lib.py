@@ -48,6 +48,7 @@ SIGNATURES = {
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
     "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),
+    "egk_gemm_set_pipeline": (C.c_int, [i32]),
     "egk_colsum_ws_len": (C.c_int, [i32, i32]),
     "egk_colsum": (C.c_int, [vp, vp, i64, i32, i32, vp, i32, vp, i32]),
     "egk_rowln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, f32, u64, u64, vp, i32]),

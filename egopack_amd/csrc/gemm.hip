@@ -213,6 +213,78 @@ __device__ __forceinline__ void load_operand(const void* base, long long ld, int
     else load_rowmajor<BF16C, T>((const T*)base, ld, rows_total, row0, k0, klim, vec, out);
 }
 
+// Epilogue shared by the contraction kernels.  D^T layout: lane holds C[m = .. + lr][n = .. + 4*lg + t], t = 0..3.
+template <int NI, int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[NI][NJ], int m0, int n0, int wm_off,
+                                              int wn_off, int lr, int lg, int z) {
+    const bool slab = g.splitk > 1;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int m = m0 + wm_off + i * 16 + lr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn_off + j * 16 + 4 * lg;
+            if (n >= g.N) continue;
+            f32x4 v = acc[i][j];
+            const bool full = n + 4 <= g.N;
+            if (slab) {
+                float* p = g.ws + ((long long)z * g.M + m) * g.N + n;
+                if (full && (g.N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) p[t] = v[t];
+                continue;
+            }
+            float o[4] = {v[0] * g.alpha, v[1] * g.alpha, v[2] * g.alpha, v[3] * g.alpha};
+            if (g.accumulate) {  // C is f32 when accumulating (checked on the host)
+                const float* cp = (const float*)g.C + (long long)m * g.ldc + n;
+                if (full && g.c_vec) {
+                    const float4 c = *reinterpret_cast<const float4*>(cp);
+                    o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
+                } else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += cp[t];
+            }
+            if (g.bias)
+                for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += g.bias[n + t];
+            if (g.act == EGK_ACT_RELU)
+                for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+            if (g.residual) {
+                if (g.r_bf16) {
+                    const bf16_t* rp = (const bf16_t*)g.residual + (long long)m * g.ldr + n;
+                    if (full && g.r_vec) {
+                        const uint2 r = *reinterpret_cast<const uint2*>(rp);
+                        o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xffff0000u);
+                        o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xffff0000u);
+                    } else
+                        for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += bf16_to_f32(rp[t]);
+                } else {
+                    const float* rp = (const float*)g.residual + (long long)m * g.ldr + n;
+                    if (full && g.r_vec) {
+                        const float4 r = *reinterpret_cast<const float4*>(rp);
+                        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                    } else
+                        for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += rp[t];
+                }
+            }
+            if (g.c_bf16) {
+                bf16_t* cp = (bf16_t*)g.C + (long long)m * g.ldc + n;
+                if (full && g.c_vec) {
+                    uint2 pk;
+                    pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+                    *reinterpret_cast<uint2*>(cp) = pk;
+                } else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = f32_to_bf16(o[t]);
+            } else {
+                float* cp = (float*)g.C + (long long)m * g.ldc + n;
+                if (full && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+                else
+                    for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = o[t];
+            }
+        }
+    }
+}
+
 // BF16C: bf16 MFMA (else exact f32).  TA/TB: operand transposed in memory.  AT/BT: element type in memory.
 template <bool BF16C, bool TA, bool TB, typename AT, typename BT>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
@@ -298,73 +370,200 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
         }
     }
 
-    // Epilogue.  D^T layout: lane holds C[m = .. + lr][n = .. + 4*lg + t], t = 0..3.
-    const bool slab = g.splitk > 1;
+    gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
+}
+
+// ---- pipelined contraction: bf16 operands in memory, K % 64 == 0 ---------------------------------------------
+// LDS-DMA staging (global_load_lds, 16 B per lane, 1 KiB per wave-instruction: no VGPR staging, no ds_write) into
+// an NSTAGE-deep ring; ONE raw s_barrier per K-tile and a COUNTED s_waitcnt vmcnt so that the loads of the next
+// tiles stay in flight across the barrier (cdna guide T3/T4).  Two LDS images, 16 KiB per 128-row operand tile:
+//   * row-major operand ([rows][K] in memory): image [128 rows][64 k] (128-B rows), fragments by ds_read_b128;
+//     16-byte chunk index XOR (row>>1)&7;
+//   * transposed operand ([K][rows] in memory: W for dX, dY / X for dW): image [64 k][128 rows] (256-B rows) kept
+//     in MEMORY order and read with ds_read_b64_tr_b16, the hardware transposing read: a 16-lane group fetches a
+//     4(k) x 16(rows) block and every lane receives the 4 k-values of ITS row -- two of them are the 8-element
+//     MFMA fragment.  16-byte chunk index XOR 2*(k&3) + 8*((k>>3)&1): the 8 k-rows one half-wave touches land on
+//     16 distinct slots of the bank row.
+// The images are lane-linear (DMA), so each swizzle is applied on the SOURCE address a lane fetches and again on
+// the read (guide rule 21).  Rows beyond M / N are clamped to valid memory: they only feed accumulators that are
+// never stored.  The MFMA chain per accumulator is the one of the generic kernel: results are bit-identical.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <bool TR>
+__device__ __forceinline__ void pipe_issue_operand(const bf16_t* __restrict__ base, long long ld, int rows_total, int row0,
+                                                   int k0, unsigned char* img, int w, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + lr;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * lg;
-            if (n >= g.N) continue;
-            f32x4 v = acc[i][j];
-            const bool full = n + 4 <= g.N;
-            if (slab) {
-                float* p = g.ws + ((long long)z * g.M + m) * g.N + n;
-                if (full && (g.N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int t = 0; t < 4 && n + t < g.N; ++t) p[t] = v[t];
-                continue;
-            }
-            float o[4] = {v[0] * g.alpha, v[1] * g.alpha, v[2] * g.alpha, v[3] * g.alpha};
-            if (g.accumulate) {  // C is f32 when accumulating (checked on the host)
-                const float* cp = (const float*)g.C + (long long)m * g.ldc + n;
-                if (full && g.c_vec) {
-                    const float4 c = *reinterpret_cast<const float4*>(cp);
-                    o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
-                } else
-                    for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += cp[t];
-            }
-            if (g.bias)
-                for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += g.bias[n + t];
-            if (g.act == EGK_ACT_RELU)
-                for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
-            if (g.residual) {
-                if (g.r_bf16) {
-                    const bf16_t* rp = (const bf16_t*)g.residual + (long long)m * g.ldr + n;
-                    if (full && g.r_vec) {
-                        const uint2 r = *reinterpret_cast<const uint2*>(rp);
-                        o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xffff0000u);
-                        o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xffff0000u);
-                    } else
-                        for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += bf16_to_f32(rp[t]);
-                } else {
-                    const float* rp = (const float*)g.residual + (long long)m * g.ldr + n;
-                    if (full && g.r_vec) {
-                        const float4 r = *reinterpret_cast<const float4*>(rp);
-                        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-                    } else
-                        for (int t = 0; t < 4 && n + t < g.N; ++t) o[t] += rp[t];
-                }
-            }
-            if (g.c_bf16) {
-                bf16_t* cp = (bf16_t*)g.C + (long long)m * g.ldc + n;
-                if (full && g.c_vec) {
-                    uint2 pk;
-                    pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-                    pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
-                    *reinterpret_cast<uint2*>(cp) = pk;
-                } else
-                    for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = f32_to_bf16(o[t]);
-            } else {
-                float* cp = (float*)g.C + (long long)m * g.ldc + n;
-                if (full && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
-                else
-                    for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = o[t];
-            }
+        const int piece = w * 4 + i;  // 16 pieces of 1 KiB per image, 4 per wave
+        const bf16_t* gp;
+        if constexpr (TR) {  // piece = 4 k-rows of 256 B; lane -> (k = 4*piece + lane/16, slot = lane%16)
+            const int k = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
+            int col = row0 + c * 8;
+            if (col + 8 > rows_total) col = row0;  // garbage for rows that are never stored, but in bounds
+            gp = base + (long long)(k0 + k) * ld + col;
+        } else {  // piece = 8 rows of 128 B; lane -> (row = 8*piece + lane/8, slot = lane%8)
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            gp = base + (long long)min(row0 + r, rows_total - 1) * ld + k0 + c * 8;
         }
+        __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(img + piece * 1024), 16, 0, 0);
     }
+}
+
+// 128 x 128 output tile, 4 waves as 2 x 2, NSTAGE-deep ring of (A image | B image) = 32 KiB per stage.
+template <int NSTAGE, bool TRA, bool TRB>
+__global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
+    constexpr int IMG = 16384, STAGE = 2 * IMG;
+    constexpr int LOADS = 8;  // wave-instructions per wave per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int KT = 64;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
+    const int z = blockIdx.y;
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    auto issue = [&](int t, int stage) {
+        const int src = t < nkt0 ? 0 : 1;
+        const int k0 = (src == 0 ? t : t - nkt0) * KT;
+        unsigned char* sbase = lds + stage * STAGE;
+        pipe_issue_operand<TRA>((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, sbase, w, lane);
+        pipe_issue_operand<TRB>((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, sbase + IMG, w, lane);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane LDS byte offsets of the fragment reads (relative to the image base) -------------------------------
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
+    // row-major image: (row, chunk) -> row*128 + ((chunk ^ ((row>>1)&7)) << 4); k-step toggles bit 6, fragment i adds i*2048
+    const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
+    const unsigned a_rm = (unsigned)((wm * 64 + lr) * ROWB) + rm_sw;
+    const unsigned b_rm = (unsigned)((wn * 64 + lr) * ROWB) + rm_sw;
+    // k-major image: lane 4q+p of a 16-lane group addresses (k-row 8*lg + q [+4 for the 2nd half] [+32 per k-step],
+    // 16-B chunk = (wave offset | fragment i | p>>1) ^ f, byte (p&1)*8), f = 2q + 8*(lg&1).  The fragment index enters
+    // through an XOR, so each fragment has its own lane offset (4 per operand), k-step / half are immediates.
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const unsigned tr_row = (unsigned)((8 * lg + tq) * 256 + (tp & 1) * 8);
+    const unsigned tr_f = (unsigned)(2 * tq + 8 * (lg & 1));
+    unsigned a_tr[4], b_tr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_tr[i] = tr_row + ((((unsigned)(wm * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
+        b_tr[i] = tr_row + ((((unsigned)(wn * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
+    }
+
+    const int nt = t_end - t_begin;
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p)
+        if (p < nt) issue(t_begin + p, p);
+    for (int it = 0; it < nt; ++it) {
+        // tile ``it`` has landed once this wave has at most the pieces of the LATER tiles already issued
+        // (min(NSTAGE-2, nt-1-it) tiles x LOADS pieces) outstanding
+        const int later = min(NSTAGE - 2, nt - 1 - it);
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of tile ``it`` landed; the stage read at it-1 is free
+        if (it + NSTAGE - 1 < nt) issue(t_begin + it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
+
+        // Fragment reads as inline asm: hipcc cannot prove that a plain ds_read does not alias the LDS-DMA writes
+        // in flight and would put s_waitcnt vmcnt(0) in front of it, draining the prefetched tiles.
+        const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG;
+        uint4 a0[4], a1[4], b0[4], b1[4];
+        if constexpr (TRA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ad = stA + a_tr[i];
+                uint2 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+                a0[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a0[i]) : "v"(stA + a_rm), "n"(i * 2048));
+        }
+        if constexpr (TRB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned ad = stB + b_tr[j];
+                uint2 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+                b0[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0[j]) : "v"(stB + b_rm), "n"(j * 2048));
+        }
+        if constexpr (TRA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ad = stA + a_tr[i];
+                uint2 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(hi) : "v"(ad));
+                a1[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a1[i]) : "v"((stA + a_rm) ^ 64u), "n"(i * 2048));
+        }
+        if constexpr (TRB) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned ad = stB + b_tr[j];
+                uint2 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(lo) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(hi) : "v"(ad));
+                b1[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1[j]) : "v"((stB + b_rm) ^ 64u), "n"(j * 2048));
+        }
+        // the reads return in issue order: k-step 0 is complete when only the k-step-1 reads are outstanding
+        // (lgkmcnt is a 4-bit counter: with 16 k-step-1 reads, "<= 15 outstanding" already implies the first 16 are back)
+        constexpr int R1 = ((TRA ? 8 : 4) + (TRB ? 8 : 4)) > 15 ? 15 : ((TRA ? 8 : 4) + (TRB ? 8 : 4));
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R1) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0[j]),
+                                                                    __builtin_bit_cast(bf16x8, a0[i]), acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1[j]),
+                                                                    __builtin_bit_cast(bf16x8, a1[i]), acc[i][j], 0, 0, 0);
+    }
+    gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
 }
 
 // Sum the split-K slabs in slab order (bitwise reproducible) and apply the epilogue.
@@ -401,6 +600,25 @@ static void launch_layout(const egk_gemm_desc* d, dim3 grid, hipStream_t s, cons
 }  // namespace egk
 
 using namespace egk;
+
+static int g_use_pipe = 1;
+static bool g_lds_attr_set = false;
+template <int NS, bool TA, bool TB>
+static void set_lds_attr() {
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<NS, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 32768);
+}
+static void ensure_lds_attr() {
+    if (g_lds_attr_set) return;
+    set_lds_attr<2, false, false>(); set_lds_attr<2, false, true>(); set_lds_attr<2, true, true>(); set_lds_attr<2, true, false>();
+    set_lds_attr<3, false, false>(); set_lds_attr<3, false, true>(); set_lds_attr<3, true, true>(); set_lds_attr<3, true, false>();
+    g_lds_attr_set = true;
+}
+// development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
+extern "C" int egk_gemm_set_pipeline(int32_t on) {
+    const int prev = g_use_pipe;
+    g_use_pipe = on;  // 0 generic kernel only, 1 pipelined 2-stage ring (default), 2 pipelined 3-stage ring
+    return prev;
+}
 
 // Split-K policy (host side, deterministic): slabs when the tile grid alone would leave most of
 // the 256 CUs idle and K is deep (the dW contractions: 64 tiles, K = nodes in the batch).
@@ -465,6 +683,31 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     const int kid = (bf ? KID_GEMM_BF16_NN : KID_GEMM_F32_NN) + (d->transA ? (d->transB ? 2 : 3) : (d->transB ? 1 : 0));
     ProfScope prof(kid, s, flops, bytes);
 
+    // LDS-DMA pipelined kernel: bf16 operands, 16-byte aligned rows, every K source a multiple of 64 (the rows of
+    // the contraction axis must not need zero fill); everything else runs on the generic register-staged kernel.
+    const bool pipe_ok = bf && a16 && g_use_pipe && d->K1 % 64 == 0 && d->K2 % 64 == 0 && d->K1 > 0 && g.a_vec[0] &&
+                         g.b_vec[0] && (d->K2 == 0 || (g.a_vec[1] && g.b_vec[1]));
+    if (pipe_ok) {
+        ensure_lds_attr();
+        dim3 pgrid(g.tiles_m * g.tiles_n, g.splitk), pblock(NTHREADS);
+        const int three = g_use_pipe == 2;  // development knob: 3-stage ring (96 KiB, one workgroup per CU)
+#define EGK_PIPE(TA, TB)                                                                                         \
+    do {                                                                                                         \
+        if (three) hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB>), pgrid, pblock, 3 * 32768, s, g);            \
+        else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB>), pgrid, pblock, 2 * 32768, s, g);                  \
+    } while (0)
+        if (!d->transA && !d->transB) EGK_PIPE(false, false);
+        else if (!d->transA && d->transB) EGK_PIPE(false, true);
+        else if (d->transA && d->transB) EGK_PIPE(true, true);
+        else EGK_PIPE(true, false);
+#undef EGK_PIPE
+        if (g.splitk > 1) {
+            const long long total = (long long)g.M * g.N;
+            hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
+                               dim3(256), 0, s, g);
+        }
+        return check_launch("egk_gemm");
+    }
     dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
     if (!bf) launch_layout<false, float, float>(d, grid, s, g);
     else if (a16) launch_layout<true, bf16_t, bf16_t>(d, grid, s, g);

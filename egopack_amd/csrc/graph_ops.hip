@@ -64,13 +64,20 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
         float4 acc[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = e0; e < e1; ++e) {
-            const T* src = x + (long long)col[e] * cols;
-            const float we = wgt ? wgt[e] : 1.f;
+        // neighbour indices / weights are fetched by the lanes in ONE load per 64 edges and broadcast with
+        // shuffles, so the row loads of consecutive edges do not wait on dependent index loads
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int cnt = min(64, e1 - eb);
+            const int my_c = lane < cnt ? col[eb + lane] : 0;
+            const float my_w = (wgt && lane < cnt) ? wgt[eb + lane] : 1.f;
+            for (int e = 0; e < cnt; ++e) {
+                const T* src = x + (long long)__shfl(my_c, e, 64) * cols;
+                const float we = __shfl(my_w, e, 64);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const float4 v = ld4(src, (i * 64 + lane) * 4, cols, vec);
-                acc[i].x += we * v.x; acc[i].y += we * v.y; acc[i].z += we * v.z; acc[i].w += we * v.w;
+                for (int i = 0; i < NV; ++i) {
+                    const float4 v = ld4(src, (i * 64 + lane) * 4, cols, vec);
+                    acc[i].x += we * v.x; acc[i].y += we * v.y; acc[i].z += we * v.z; acc[i].w += we * v.w;
+                }
             }
         }
 #pragma unroll

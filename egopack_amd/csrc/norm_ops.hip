@@ -180,15 +180,15 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy
 }
 
 // out_a[c] += sum_b ws[b][0][c]; out_b[c] += sum_b ws[b][1][c]   (fixed order)
-// workgroup = 64 columns x 4 row groups; the 4 partial sums of a column are combined in LDS in group order.
+// workgroup = 32 columns x 8 row groups; the 8 partial sums of a column are combined in LDS in group order.
 __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __restrict__ ws, float* __restrict__ oa,
                                                               float* __restrict__ ob, int nblk, int cols) {
-    __shared__ float red[2][4][64];
-    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cg;
+    __shared__ float red[2][8][32];
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cg;
     float a = 0.f, d = 0.f;
     if (c < cols)
-        for (int k = rg; k < nblk; k += 4) {
+        for (int k = rg; k < nblk; k += 8) {
             a += ws[((long long)k * 2 + 0) * cols + c];
             d += ws[((long long)k * 2 + 1) * cols + c];
         }
@@ -196,8 +196,12 @@ __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __res
     red[1][rg][cg] = d;
     __syncthreads();
     if (rg == 0 && c < cols) {
-        a = (red[0][0][cg] + red[0][1][cg]) + (red[0][2][cg] + red[0][3][cg]);
-        d = (red[1][0][cg] + red[1][1][cg]) + (red[1][2][cg] + red[1][3][cg]);
+        a = d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += red[0][k][cg];
+            d += red[1][k][cg];
+        }
         if (oa) oa[c] += a;
         if (ob) ob[c] += d;
     }
@@ -434,36 +438,50 @@ __global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ 
 // -------------------------------------------------------------------------------------------
 // column sum: stage 1 partials over row chunks, stage 2 fixed-order sum
 // -------------------------------------------------------------------------------------------
+// stage 1: each lane owns 4 consecutive columns (8 / 16 B loads), each workgroup a chunk of rows
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long long ldx, int M, int N,
-                                                             float* __restrict__ ws, int rows_per) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+                                                             float* __restrict__ ws, int rows_per, int vec) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= N) return;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     int r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        s0 += ld1t(x + (long long)(r + 0) * ldx + c);
-        s1 += ld1t(x + (long long)(r + 1) * ldx + c);
-        s2 += ld1t(x + (long long)(r + 2) * ldx + c);
-        s3 += ld1t(x + (long long)(r + 3) * ldx + c);
+    for (; r + 2 <= r1; r += 2) {
+        const float4 v0 = ld4t(x + (long long)r * ldx, c, N, vec);
+        const float4 v1 = ld4t(x + (long long)(r + 1) * ldx, c, N, vec);
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
     }
-    for (; r < r1; ++r) s0 += ld1t(x + (long long)r * ldx + c);
-    ws[(long long)blockIdx.y * N + c] = (s0 + s1) + (s2 + s3);
+    if (r < r1) {
+        const float4 v0 = ld4t(x + (long long)r * ldx, c, N, vec);
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    }
+    st4t(ws + (long long)blockIdx.y * N, c, N, (N & 3) == 0, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
 }
+// stage 2: 32 columns x 8 partial-row groups per workgroup, groups combined in LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int N,
                                                            int nchunk, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float red[8][32];
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cg;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += ws[(long long)k * N + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < N)
+        for (int k = rg; k < nchunk; k += 8) s += ws[(long long)k * N + c];
+    red[rg][cg] = s;
+    __syncthreads();
+    if (rg == 0 && c < N) {
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cg];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
 static inline int row_grid(int rows) {  // <= 2 workgroups per CU: keeps the partial buffers small
     int g = cdiv(rows, WPB);
-    return g < 1 ? 1 : (g > 512 ? 512 : g);
+    return g < 1 ? 1 : (g > 256 ? 256 : g);
 }
 
 }  // namespace egk
@@ -482,26 +500,29 @@ using namespace egk;
 
 extern "C" {
 
-int egk_colsum_ws_len(int32_t M, int32_t N) {
-    int chunks = cdiv(M, 64);
-    if (chunks > 128) chunks = 128;
-    if (chunks < 1) chunks = 1;
-    return chunks * N;
+static inline int colsum_chunks(int M, int N) {
+    // enough workgroups to stream at HBM rate (>= ~256 with the column blocks), <= 64 partial rows to re-read
+    const int col_blocks = cdiv(N, 1024);
+    int chunks = cdiv(512, col_blocks);  // ~2 workgroups per CU stream the rows
+    if (chunks > cdiv(M, 8)) chunks = cdiv(M, 8);
+    return chunks < 1 ? 1 : chunks;
 }
+
+int egk_colsum_ws_len(int32_t M, int32_t N) { return colsum_chunks(M, N) * N; }
 
 int egk_colsum(egk_stream_t stream, const void* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
                float* ws, int32_t dtype) {
     EGK_REQUIRE(x && out && ws, "egk_colsum: null pointer");
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    int chunks = cdiv(M, 64);
-    if (chunks > 128) chunks = 128;
-    if (chunks < 1) chunks = 1;
+    const int chunks = colsum_chunks(M, N);
     const int rows_per = cdiv(M, chunks);
+    const int ebytes = dtype == EGK_BF16 ? 2 : 4;
+    const int vec = (((uintptr_t)x) % (4 * ebytes) == 0) && ((ldx * ebytes) % (4 * ebytes) == 0);
     ProfScope prof(KID_COLSUM, s, 0, (dtype == EGK_BF16 ? 2.0 : 4.0) * M * N);
-    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(cdiv(N, 256), chunks), dim3(256), 0, s,
-                                             (const T*)x, (long long)ldx, M, N, ws, rows_per));
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, out, N, chunks, accumulate);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(cdiv(N, 1024), chunks), dim3(256), 0, s,
+                                             (const T*)x, (long long)ldx, M, N, ws, rows_per, vec));
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 32)), dim3(256), 0, s, ws, out, N, chunks, accumulate);
     return check_launch("egk_colsum");
 }
 
@@ -538,7 +559,7 @@ int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const floa
     }
     {
         ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, ws, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, s, ws, dw, db, grid, cols);
     }
     return check_launch("egk_rowln_bwd");
 }
@@ -595,7 +616,7 @@ int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const fl
     }
     if (dw || db) {
         ProfScope prof(KID_GRAPHLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
     }
     return check_launch("egk_graphln_bwd");
 }

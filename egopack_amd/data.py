@@ -195,11 +195,34 @@ def merge_batches(batches: Sequence[Data]) -> Data:
         off += b.pos.shape[0]
         seg.append(off)
     ei = torch.cat(eis, dim=1)
-    out = Data(x=[b.x for b in batches], pos=torch.cat(poss), edge_index=ei)
+    xs = [b.x for b in batches]
+    # if the task blocks already are consecutive row ranges of ONE buffer (see ``pack_features``) the merged
+    # batch exposes that buffer: the first contraction then runs once at M = all nodes
+    base = getattr(batches[0], "x_base", None)
+    x = base if (base is not None and all(getattr(b, "x_base", None) is base for b in batches)
+                 and base.shape[0] == off) else xs
+    out = Data(x=x, pos=torch.cat(poss), edge_index=ei)
     out.graph = build_csr(ei, off)
     out.seg_ptr = torch.tensor(seg, dtype=torch.int32)
     out.num_segments = len(batches)
     return out
+
+
+def pack_features(batches: Sequence[Data], dtype=None, device=None, pin: bool = False) -> torch.Tensor:
+    """Copy the feature blocks of several task batches into ONE [sum N, S, F] buffer (one host->device
+    transfer, one merged contraction) and re-point every ``batch.x`` at its row range of that buffer."""
+    n = sum(b.x.shape[0] for b in batches)
+    ref = batches[0].x
+    buf = torch.empty((n, *ref.shape[1:]), dtype=dtype or ref.dtype, device=device or ref.device,
+                      pin_memory=pin and (device is None or str(device) == "cpu"))
+    off = 0
+    for b in batches:
+        m = b.x.shape[0]
+        buf[off:off + m].copy_(b.x)
+        b.x = buf[off:off + m]
+        b.x_base = buf
+        off += m
+    return buf
 
 
 # --------------------------------------------------------------------------------------------

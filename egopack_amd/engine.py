@@ -23,6 +23,31 @@ from .dist import GradSync
 TASK_ORDER = ("ar", "lta", "oscc", "pnr")  # order of the loss terms in main_temporal.train
 
 
+def stage_batches(host, device, order=TASK_ORDER, pin: bool = True):
+    """Host -> device transfer of one step's task batches for the fused pass: the feature blocks are packed
+    into ONE (pinned) buffer and moved with ONE copy; the returned per-task batches view row ranges of the
+    device buffer and ``merged`` exposes the whole buffer (first contraction at M = all nodes)."""
+    from .data import pack_features
+    live = [t for t in order if host.get(t) is not None]
+    buf = pack_features([host[t] for t in live], pin=pin)
+    merged = merge_batches([host[t] for t in live])
+    dbuf = buf.to(device, non_blocking=True)
+    dev, off = {}, 0
+    for t in live:
+        b = host[t]
+        x, xb = b.x, b.x_base
+        b.x = b.x_base = None
+        d = b.to(device, non_blocking=True)
+        b.x, b.x_base = x, xb
+        d.x = dbuf[off:off + x.shape[0]]
+        off += x.shape[0]
+        dev[t] = d
+    merged.x = None
+    md = merged.to(device, non_blocking=True)
+    md.x = dbuf
+    return dev, md
+
+
 class MTLStep:
     """One multi-task pre-training step (BASELINE configs 2, 3, 5)."""
 

@@ -90,6 +90,18 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rm(t: torch.Tensor) -> torch.Tensor:
+    """row-major 2-D matrix with unit column stride (any row stride: padded logits are views)"""
+    _dt(t)
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32, got {t.dtype}")
@@ -235,7 +247,7 @@ def _grad_slot(param: Optional[torch.Tensor]):
 
 
 def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    g = _c(g)
+    g = _rm(g) if g.dim() == 2 else _c(g)
     return g if g.dtype == dtype else cast_raw(g, dtype)
 
 
@@ -255,8 +267,11 @@ class _Linear(torch.autograd.Function):
             K2 = x2.shape[1]
             W2op = weight_operand(W2, x.dtype)
         res = _c(residual) if residual is not None else None
-        y = torch.empty((M, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-        gemm(M, N, x, K1, Wop, K1, K1, y, N, A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2,
+        if out_f32 and N % 8:  # logits: pad the row stride so the loss gradient is a 16-byte aligned operand
+            y = torch.empty((M, _pad8(N)), dtype=torch.float32, device=x.device)[:, :N]
+        else:
+            y = torch.empty((M, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        gemm(M, N, x, K1, Wop, K1, K1, y, y.stride(0), A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2,
              bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
         ctx.relu, ctx.compute = relu, compute
         ctx.has = (b is not None, x2 is not None, residual is not None)
@@ -278,6 +293,7 @@ class _Linear(torch.autograd.Function):
         lib = _lib.load()
         if ctx.relu:
             assert not has_res
+            g = g.contiguous()
             gg = torch.empty_like(g)
             _ck(lib.egk_relu_gate(_stream(), _p(g), _p(_match(y, g.dtype)), _p(gg), g.numel(), _dt(g)), "egk_relu_gate")
             g = gg
@@ -285,11 +301,11 @@ class _Linear(torch.autograd.Function):
         dx = dW = db = dx2 = dW2 = None
         if needs[0]:
             dx = torch.empty_like(x)
-            gemm(M, K1, g, N, W, K1, N, dx, K1, transB=True, compute=ctx.compute)
+            gemm(M, K1, g, g.stride(0), W, K1, N, dx, K1, transB=True, compute=ctx.compute)
         if needs[1]:
             slot = _grad_slot(Wp)
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
-            gemm(N, K1, g, N, x, K1, M, out, K1, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+            gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True, compute=ctx.compute)
             dW = None if slot is not None else out
         if has_b and needs[2]:
             slot = _grad_slot(bp)
@@ -300,11 +316,11 @@ class _Linear(torch.autograd.Function):
             K2 = x2.shape[1]
             if needs[3]:
                 dx2 = torch.empty_like(x2)
-                gemm(M, K2, g, N, W2, K2, N, dx2, K2, transB=True, compute=ctx.compute)
+                gemm(M, K2, g, g.stride(0), W2, K2, N, dx2, K2, transB=True, compute=ctx.compute)
             if needs[4]:
                 slot = _grad_slot(W2p)
                 out = slot if slot is not None else torch.zeros(W2.shape, dtype=torch.float32, device=g.device)
-                gemm(N, K2, g, N, x2, K2, M, out, K2, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+                gemm(N, K2, g, g.stride(0), x2, K2, M, out, K2, transA=True, transB=True, accumulate=True, compute=ctx.compute)
                 dW2 = None if slot is not None else out
         dres = _match(dy, ctx.res_dtype) if (has_res and needs[5]) else None
         return dx, dW, db, dx2, dW2, dres, None, None, None
@@ -608,7 +624,9 @@ class _CE(torch.autograd.Function):
         ystride = 1 if y.dim() == 1 else y.shape[1]
         saved = []
         for h, l in enumerate(logits):
-            l = _f32c(l)
+            if l.dtype != torch.float32:
+                raise TypeError("cross_entropy expects f32 logits")
+            l = _rm(l)
             lse = torch.empty(rows, dtype=torch.float32, device=l.device)
             yh = y if y.dim() == 1 else y[:, h]
             _ck(lib.egk_ce_fwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ystride, _p(loss), _p(lse), rows,
@@ -627,7 +645,7 @@ class _CE(torch.autograd.Function):
         for h in range(ctx.nh):
             l, lse = saved[2 * h], saved[2 * h + 1]
             rows, Cn = l.shape
-            d = torch.empty((rows, Cn), dtype=ctx.gdt[h], device=l.device)
+            d = torch.empty((rows, _pad8(Cn)), dtype=ctx.gdt, device=l.device)[:, :Cn]
             yh = y if y.dim() == 1 else y[:, h]
             _ck(lib.egk_ce_bwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ctx.ystride, _p(lse), _p(gloss),
                                _p(d), d.stride(0), rows, Cn, ctx.smoothing, _dt(d)), "egk_ce_bwd")
@@ -641,7 +659,7 @@ def cross_entropy(logits, y, smoothing: float = 0.0):
     producing contraction wants (bf16 in 'bf16' mode)."""
     if torch.is_tensor(logits):
         logits = (logits,)
-    return _CE.apply(float(smoothing), y, tuple(_grad_dtype_of(l) for l in logits), *logits)
+    return _CE.apply(float(smoothing), y, _state["act"], *logits)
 
 
 class _BCE(torch.autograd.Function):
@@ -669,7 +687,7 @@ def bce_with_logits(logits, y):
     """BCEWithLogitsLoss(reduction='none') against y.float(); y int64 of the same shape."""
     if y.dtype != torch.int64:
         y = y.to(torch.int64)
-    return _BCE.apply(logits, y, _grad_dtype_of(logits))
+    return _BCE.apply(logits, y, _state["act"])
 
 
 # ---- dropout / reductions -----------------------------------------------------------------------------------

@@ -35,8 +35,12 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
     order = ("ar", "lta", "oscc", "pnr")
     it, sums, counts = 0, {t: 0.0 for t in order}, {t: 0 for t in order}
     for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]):
-        batches = {t: b.to(device, non_blocking=True) for t, b in zip(order, batch) if b is not None}
-        total, vectors = step.step(batches)
+        host = {t: b for t, b in zip(order, batch) if b is not None}
+        if step.fused and len(host) > 1:
+            batches, merged = engine.stage_batches(host, device, order)
+        else:
+            batches, merged = {t: b.to(device, non_blocking=True) for t, b in host.items()}, None
+        total, vectors = step.step(batches, merged)
         for t, v in vectors.items():
             sums[t] += float(v.sum())
             counts[t] += v.numel()

@@ -612,3 +612,68 @@ def test_gather_segmax_dropout_relu_bf16_activations(ops):
     ops.manual_seed(3)
     y = ops.dropout(torch.ones(4096, device=DEV, dtype=BF), 0.5, True)
     assert y.dtype == BF and abs((y != 0).float().mean().item() - 0.5) < 0.05 and float(y.max()) == 2.0
+
+
+@pytest.mark.parametrize("transA,transB", [(False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K1,K2", [(304, 200, 256, 0), (128, 128, 64, 0), (264, 136, 128, 192), (1024, 1024, 2048, 0),
+                                       (472, 1024, 1024, 0), (1024, 480, 512, 0)])
+def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, transB, M, N, K1, K2):
+    """dX / dW forms of the LDS-DMA kernel (k-major LDS images read with ds_read_b64_tr_b16) against the generic
+    register-transposing kernel: bit-identical, incl. two-source K, split-K and f32 accumulation into C."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + 3 * N + K1)
+
+    def operand(rows, K, tr):
+        return torch.randn((K, rows) if tr else (rows, K), device=DEV, generator=g).to(BF)
+    A1, B1 = operand(M, K1, transA), operand(N, K1, transB)
+    A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
+    C0 = torch.randn(M, N, device=DEV, generator=g)
+    outs = {}
+    for pipe in (1, 2, 0):
+        prev = lib.egk_gemm_set_pipeline(pipe)
+        try:
+            out = C0.clone()
+            ops.gemm(M, N, A1, A1.shape[1], B1, B1.shape[1], K1, out, N, A2=A2, lda2=A2.shape[1] if K2 else 0, B2=B2,
+                     ldb2=B2.shape[1] if K2 else 0, K2=K2, transA=transA, transB=transB, accumulate=True)
+            outs[pipe] = out
+        finally:
+            lib.egk_gemm_set_pipeline(prev)
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+    opA = lambda t, tr: (t.t() if tr else t).double()
+    ref = opA(A1, transA) @ opA(B1, transB).t() + (opA(A2, transA) @ opA(B2, transB).t() if K2 else 0) + C0.double()
+    torch.testing.assert_close(outs[1], ref.float(), rtol=2e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(300, 200, 256, 0), (128, 128, 64, 0), (257, 129, 128, 192), (2048, 1024, 1024, 0),
+                                       (6144, 1024, 1024, 1024), (130, 478, 1024, 0)])
+def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
+    """The LDS-DMA pipelined kernel (bf16 row-major operands, K % 64 == 0) issues the same MFMA chain per
+    accumulator as the generic kernel: results must be BIT-identical, for bf16 and f32 outputs, with the
+    fused epilogue; and both must match an fp64 reference on the bf16-rounded operands."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K1)
+    A1 = torch.randn(M, K1, device=DEV, generator=g).to(BF)
+    B1 = torch.randn(N, K1, device=DEV, generator=g).to(BF)
+    A2 = torch.randn(M, K2, device=DEV, generator=g).to(BF) if K2 else None
+    B2 = torch.randn(N, K2, device=DEV, generator=g).to(BF) if K2 else None
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(BF)
+    outs = {}
+    for pipe in (1, 0):
+        prev = lib.egk_gemm_set_pipeline(pipe)
+        try:
+            for dt in (BF, torch.float32):
+                out = torch.empty(M, N, device=DEV, dtype=dt)
+                ops.gemm(M, N, A1, K1, B1, K1, K1, out, N, A2=A2, lda2=K2, B2=B2, ldb2=K2, K2=K2, bias=bias, residual=res,
+                         ldr=N, act=1)
+                outs[(pipe, dt)] = out
+        finally:
+            lib.egk_gemm_set_pipeline(prev)
+    for dt in (BF, torch.float32):
+        assert torch.equal(outs[(1, dt)], outs[(0, dt)])
+    if M * N <= 1 << 21:
+        ref = A1.double() @ B1.double().t() + (A2.double() @ B2.double().t() if K2 else 0) + bias.double()
+        ref = torch.relu(ref).float() + res.float()
+        torch.testing.assert_close(outs[(1, torch.float32)], ref, rtol=1e-3, atol=2e-3)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the contractions of the bench workload (HIP events, back-to-back launches).
+Usage: python tools/gemm_bench.py [--iters 50] [--dtype bf16|f32act]"""
+import argparse
+import sys
+
+sys.path.insert(0, ".")
+import torch
+
+from egopack_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--variants", default="1", help="comma list of egk_gemm_set_pipeline values (0 generic, 1 auto, 2/3/4)")
+args = ap.parse_args()
+dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+dev = "cuda"
+
+# (name, M, N, K, transA, transB, out_f32/accumulate)
+N6, H = 6144, 1024
+SHAPES = [
+    ("fwd TRN1 (per task)", 2048, 1024, 4608, False, False, False),
+    ("fwd HxH merged", N6, H, H, False, False, False),
+    ("fwd SAGE combine K=2H", N6, H, 2 * H, False, False, False),
+    ("fwd head HxH", 2048, H, H, False, False, False),
+    ("fwd cls 478", 2048, 478, H, False, False, True),
+    ("dX HxH merged", N6, H, H, False, True, False),
+    ("dX head", 2048, H, H, False, True, False),
+    ("dX cls 478", 2048, H, 478, False, True, False),
+    ("dW HxH merged", H, H, N6, True, True, True),
+    ("dW TRN1 (per task)", H, 4608, 2048, True, True, True),
+    ("dW head", H, H, 2048, True, True, True),
+    ("dW cls 478", 478, H, 2048, True, True, True),
+]
+variants = [int(v) for v in args.variants.split(",")]
+from egopack_amd import _lib
+print(f"{'shape':28s} {'M':>5s} {'N':>5s} {'K':>5s} splitk " + " ".join(f"{'v' + str(v) + ' us':>9s} {'TF/s':>6s}" for v in variants))
+for name, M, N, K, tA, tB, f32out in SHAPES:
+    A = torch.randn((K, M) if tA else (M, K), device=dev).to(dt)
+    B = torch.randn((K, N) if tB else (N, K), device=dev).to(dt)
+    out = torch.zeros(M, N, device=dev, dtype=torch.float32 if (f32out or dt == torch.float32) else dt)
+    acc = tA and tB
+    sk = _lib.load().egk_gemm_splitk(M, N, K, ops.BF16)
+
+    def run():
+        ops.gemm(M, N, A, A.shape[1], B, B.shape[1], K, out, N, transA=tA, transB=tB, accumulate=acc, compute=ops.BF16)
+    cells = []
+    for v in variants:
+        _lib.load().egk_gemm_set_pipeline(v)
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        cells.append(f"{us:9.1f} {2.0 * M * N * K / us / 1e6:6.0f}")
+    _lib.load().egk_gemm_set_pipeline(1)
+    print(f"{name:28s} {M:5d} {N:5d} {K:5d} {sk:6d} " + " ".join(cells))
