@@ -275,6 +275,16 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D*
     }
 }
 
+// row-strided conversion: dst[r, c] = src[r, c] for c < cols (different leading dimensions: builds the 16-byte
+// aligned operand copy of a [rows, cols] gradient whose width is not a multiple of 8)
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const S* __restrict__ src, long long lds_, D* __restrict__ dst,
+                                                        long long ldd, int rows, int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB)
+        for (int c = lane; c < cols; c += 64) st1t(dst + (long long)row * ldd + c, ld1t(src + (long long)row * lds_ + c));
+}
+
 static inline int row_grid(int rows) {
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -304,6 +314,26 @@ int egk_cast(egk_stream_t stream, const void* src, int32_t src_dtype, void* dst,
         return EGK_EUNSUPPORTED;
     }
     return check_launch("egk_cast");
+}
+
+int egk_cast_rows(egk_stream_t stream, const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,
+                  int64_t ld_dst, int32_t rows, int32_t cols) {
+    EGK_REQUIRE(src && dst, "egk_cast_rows: null pointer");
+    if (rows == 0 || cols == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CAST, s, 0, 6.0 * rows * cols);
+    const dim3 grid(row_grid(rows)), block(256);
+#define EGK_CR(S, D) hipLaunchKernelGGL((cast_rows_kernel<S, D>), grid, block, 0, s, (const S*)src, (long long)ld_src, (D*)dst, (long long)ld_dst, rows, cols)
+    if (src_dtype == EGK_F32 && dst_dtype == EGK_BF16) EGK_CR(float, bf16_t);
+    else if (src_dtype == EGK_BF16 && dst_dtype == EGK_F32) EGK_CR(bf16_t, float);
+    else if (src_dtype == EGK_F32 && dst_dtype == EGK_F32) EGK_CR(float, float);
+    else if (src_dtype == EGK_BF16 && dst_dtype == EGK_BF16) EGK_CR(bf16_t, bf16_t);
+    else {
+        set_error("egk_cast_rows: unknown element type");
+        return EGK_EINVAL;
+    }
+#undef EGK_CR
+    return check_launch("egk_cast_rows");
 }
 
 int egk_pe_add(egk_stream_t stream, const void* x, const int64_t* pos, const float* freq, void* y, int32_t rows,

@@ -503,7 +503,7 @@ extern "C" {
 static inline int colsum_chunks(int M, int N) {
     // enough workgroups to stream at HBM rate (>= ~256 with the column blocks), <= 64 partial rows to re-read
     const int col_blocks = cdiv(N, 1024);
-    int chunks = cdiv(512, col_blocks);  // ~2 workgroups per CU stream the rows
+    int chunks = cdiv(128, col_blocks);  // 128 row chunks: enough workgroups to stream, few partials to re-read
     if (chunks > cdiv(M, 8)) chunks = cdiv(M, 8);
     return chunks < 1 ? 1 : chunks;
 }

@@ -246,6 +246,24 @@ def _grad_slot(param: Optional[torch.Tensor]):
     return None
 
 
+def _operand_rows(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[rows, cols] gradient as a contraction operand of element type ``dtype`` with a 16-byte aligned row stride.
+    (autograd hands the gradient of an f32 output back as contiguous f32 whatever the loss emitted, and a width
+    such as 478 or 115 is not a multiple of 8: one strided conversion instead of an unaligned, scalar-load GEMM)"""
+    esize = 2 if dtype == torch.bfloat16 else 4
+    ok = g.dim() == 2 and g.stride(1) == 1 and (g.stride(0) * esize) % 16 == 0 and g.data_ptr() % 16 == 0
+    if g.dtype == dtype and ok:
+        return g
+    if g.dim() != 2 or g.stride(1) != 1:
+        g = g.contiguous()
+    rows, cols = g.shape
+    per16 = 16 // esize
+    out = torch.empty((rows, (cols + per16 - 1) // per16 * per16), dtype=dtype, device=g.device)[:, :cols]
+    _ck(_lib.load().egk_cast_rows(_stream(), _p(g), _dt(g), g.stride(0), _p(out), _dt(out), out.stride(0), rows, cols),
+        "egk_cast_rows")
+    return out
+
+
 def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     g = _rm(g) if g.dim() == 2 else _c(g)
     return g if g.dtype == dtype else cast_raw(g, dtype)
@@ -287,7 +305,7 @@ class _Linear(torch.autograd.Function):
         x, W, x2, W2, y = ctx.saved_tensors
         Wp, bp, W2p = ctx.params
         has_b, has_x2, has_res = ctx.has
-        g = _match(dy, x.dtype)
+        g = _operand_rows(dy, x.dtype)
         M, N = g.shape
         K1 = x.shape[1]
         lib = _lib.load()
@@ -645,7 +663,7 @@ class _CE(torch.autograd.Function):
         for h in range(ctx.nh):
             l, lse = saved[2 * h], saved[2 * h + 1]
             rows, Cn = l.shape
-            d = torch.empty((rows, _pad8(Cn)), dtype=ctx.gdt, device=l.device)[:, :Cn]
+            d = torch.empty((rows, Cn), dtype=torch.float32, device=l.device)
             yh = y if y.dim() == 1 else y[:, h]
             _ck(lib.egk_ce_bwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ctx.ystride, _p(lse), _p(gloss),
                                _p(d), d.stride(0), rows, Cn, ctx.smoothing, _dt(d)), "egk_ce_bwd")
@@ -678,7 +696,7 @@ class _BCE(torch.autograd.Function):
     def backward(ctx, g):
         logits, y = ctx.saved_tensors
         g = _f32c(g)
-        d = torch.empty(logits.shape, dtype=ctx.gdt, device=logits.device)
+        d = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
         _ck(_lib.load().egk_bce_bwd(_stream(), _p(logits), _p(y), _p(g), _p(d), logits.numel(), _dt(d)), "egk_bce_bwd")
         return d, None, None
 

@@ -193,6 +193,11 @@ int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const flo
  * statistics, parameters and parameter gradients stay f32.
  * egk_cast converts n contiguous elements between the two types. */
 int egk_cast(egk_stream_t s, const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n);
+/* row-strided variant: dst[r, c] = src[r, c], c < cols, with independent leading dimensions (elements) and
+ * element types (equal types allowed: a re-striding copy).  Used to give a [rows, cols] gradient whose width is
+ * not a multiple of 8 a 16-byte aligned row stride before it becomes a contraction operand. */
+int egk_cast_rows(egk_stream_t s, const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,
+                  int64_t ld_dst, int32_t rows, int32_t cols);
 
 /* ---- small elementwise helpers ----------------------------------------------------------- */
 /* y = keep ? x/(1-p) : 0 with a fresh Philox mask (nn.Dropout: task.py:18, graph.py:30, heads) */
