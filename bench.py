@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--compute", choices=["bf16", "bf16_f32act", "f32"], default="bf16")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--no-fused-backbone", action="store_true")
+    ap.add_argument("--serial-heads", action="store_true", help="run the task heads on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
@@ -212,7 +213,8 @@ def main():
     params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
     opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
     sync = edist.GradSync(world) if world > 1 else None
-    step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync)
+    step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync,
+                          parallel_heads=not args.serial_heads)
     fused_merged = None if args.no_fused_backbone else merged
 
     def eager_step():

@@ -70,7 +70,32 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
             const int cnt = min(64, e1 - eb);
             const int my_c = lane < cnt ? col[eb + lane] : 0;
             const float my_w = (wgt && lane < cnt) ? wgt[eb + lane] : 1.f;
-            for (int e = 0; e < cnt; ++e) {
+            // 4 neighbour rows in flight per step (independent loads first, then the FMAs): rows with many
+            // neighbours -- the LTA fan-out node has out-degree 31 -- are not one serial latency chain
+            int e = 0;
+            for (; e + 4 <= cnt; e += 4) {
+                const T* s0 = x + (long long)__shfl(my_c, e + 0, 64) * cols;
+                const T* s1 = x + (long long)__shfl(my_c, e + 1, 64) * cols;
+                const T* s2 = x + (long long)__shfl(my_c, e + 2, 64) * cols;
+                const T* s3 = x + (long long)__shfl(my_c, e + 3, 64) * cols;
+                const float w0 = __shfl(my_w, e + 0, 64), w1 = __shfl(my_w, e + 1, 64);
+                const float w2 = __shfl(my_w, e + 2, 64), w3 = __shfl(my_w, e + 3, 64);
+                float4 v0[NV], v1[NV], v2[NV], v3[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    v0[i] = ld4(s0, c, cols, vec); v1[i] = ld4(s1, c, cols, vec);
+                    v2[i] = ld4(s2, c, cols, vec); v3[i] = ld4(s3, c, cols, vec);
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {  // same summation order as the one-by-one loop
+                    acc[i].x += w0 * v0[i].x; acc[i].y += w0 * v0[i].y; acc[i].z += w0 * v0[i].z; acc[i].w += w0 * v0[i].w;
+                    acc[i].x += w1 * v1[i].x; acc[i].y += w1 * v1[i].y; acc[i].z += w1 * v1[i].z; acc[i].w += w1 * v1[i].w;
+                    acc[i].x += w2 * v2[i].x; acc[i].y += w2 * v2[i].y; acc[i].z += w2 * v2[i].z; acc[i].w += w2 * v2[i].w;
+                    acc[i].x += w3 * v3[i].x; acc[i].y += w3 * v3[i].y; acc[i].z += w3 * v3[i].z; acc[i].w += w3 * v3[i].w;
+                }
+            }
+            for (; e < cnt; ++e) {
                 const T* src = x + (long long)__shfl(my_c, e, 64) * cols;
                 const float we = __shfl(my_w, e, 64);
 #pragma unroll

@@ -479,9 +479,13 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 
 static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
-static inline int row_grid(int rows) {  // <= 2 workgroups per CU: keeps the partial buffers small
+static inline int row_grid(int rows) {  // kernels that emit per-workgroup partial rows: one workgroup per CU
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > 256 ? 256 : g);
+}
+static inline int row_grid_wide(int rows) {  // pure streaming row kernels: one row per wave up to 8 workgroups per CU
+    int g = cdiv(rows, WPB);
+    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
 }
 
 }  // namespace egk
@@ -536,7 +540,7 @@ int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const floa
     hipStream_t s = (hipStream_t)stream;
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
-    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T>), dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, w, b,
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
                                                  (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset));
     return check_launch("egk_rowln_fwd");
 }
@@ -585,7 +589,7 @@ int egk_graphln_fwd(egk_stream_t stream, const void* x, const float* w, const fl
     }
     {
         ProfScope prof(KID_GRAPHLN_FWD, s, 0, 2 * eb * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T>), dim3(grid), dim3(256), 0, s, (const T*)x, w, b,
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
                                                      (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)ws, grid));
     }
     return check_launch("egk_graphln_fwd");
@@ -610,7 +614,7 @@ int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const fl
     }
     {
         ProfScope prof(KID_GRAPHLN_BWD, s, 0, 3 * eb * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_kernel<NV, T>), dim3(grid), dim3(256), 0, s, (const T*)dy,
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_kernel<NV, T>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)dy,
                                                      (const T*)x, w, b, stats, (T*)dx, seg_ptr, n_seg, rows, cols, eps, slope,
                                                      ws_seg, grid));
     }

@@ -52,11 +52,14 @@ class MTLStep:
     """One multi-task pre-training step (BASELINE configs 2, 3, 5)."""
 
     def __init__(self, model, tasks: Mapping[str, torch.nn.Module], criteria: Mapping[str, torch.nn.Module],
-                 weights: Mapping[str, float], optimizer, fused_backbone: bool = True, sync: Optional[GradSync] = None):
+                 weights: Mapping[str, float], optimizer, fused_backbone: bool = True, sync: Optional[GradSync] = None,
+                 parallel_heads: bool = True):
         self.model, self.tasks, self.criteria = model, dict(tasks), dict(criteria)
         self.weights = {t: float(w) for t, w in weights.items()}
         self.optimizer, self.fused, self.sync = optimizer, fused_backbone, sync
         self.enabled = [t for t in TASK_ORDER if self.weights.get(t, 0) > 0 and t in self.tasks]
+        self.parallel_heads = parallel_heads
+        self._head_streams = []
         self._graph = None
         self._static_out = None
 
@@ -73,22 +76,33 @@ class MTLStep:
             return dict(zip(live, parts))
         return {t: self.model(batches[t]) for t in live}
 
+    def _head(self, t: str, feat, d):
+        task = self.tasks[t]
+        f = task.forward_features(feat)
+        logits = task.forward_logits(f, d) if t == "oscc" else task.forward_logits(f)
+        return self.criteria[t](logits, d.y), logits
+
     def losses(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
         feats = self.features(batches, merged)
         vectors, logits_out = {}, {}
-        for t, feat in feats.items():
-            task, d = self.tasks[t], batches[t]
-            f = task.forward_features(feat)
-            if t == "oscc":
-                logits = task.forward_logits(f, d)
-                loss = self.criteria[t](logits, d.y)
-            elif t == "pnr":
-                logits = task.forward_logits(f)
-                loss = self.criteria[t](logits, d.y)
-            else:
-                logits = task.forward_logits(f)
-                loss = self.criteria[t](logits, d.y)
-            vectors[t], logits_out[t] = loss, logits
+        if self.parallel_heads and len(feats) > 1 and next(iter(feats.values())).is_cuda:
+            # the task heads are independent small contractions (M = one task batch: half a chip each): run them on
+            # side streams so they overlap; autograd replays each head's backward on the stream of its forward
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            while len(self._head_streams) < len(feats):
+                self._head_streams.append(torch.cuda.Stream())
+            for st, (t, feat) in zip(self._head_streams, feats.items()):
+                st.wait_event(fork)
+                feat.record_stream(st)
+                with torch.cuda.stream(st):
+                    vectors[t], logits_out[t] = self._head(t, feat, batches[t])
+            for st, _ in zip(self._head_streams, feats):
+                main.wait_stream(st)
+        else:
+            for t, feat in feats.items():
+                vectors[t], logits_out[t] = self._head(t, feat, batches[t])
         order = [t for t in self.enabled if t in vectors]
         total = ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
         return total, vectors, logits_out
