@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("C", vp), ("ldc", i64), ("c_dtype", i32),
         ("accumulate", i32), ("act", i32), ("alpha", f32),
         ("bias", vp), ("residual", vp), ("ldr", i64), ("r_dtype", i32),
-        ("splitk", i32), ("ws", vp), ("ws_bytes", i64),
+        ("splitk", i32), ("ws", vp), ("ws_bytes", i64), ("dbias", vp),
     ]
 
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "egk_prof_get": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(i64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
+    "egk_gemm_ws_bytes": (i64, [C.POINTER(GemmDesc)]),
     "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),
     "egk_gemm_set_pipeline": (C.c_int, [i32]),
     "egk_colsum_ws_len": (C.c_int, [i32, i32]),

@@ -48,6 +48,8 @@ struct GemmArgs {
     int splitk;
     float* ws;  // [splitk][M][N] partial slabs when splitk > 1
     int tiles_m, tiles_n;
+    float* dbias;     // fused bias gradient: dbias[m] += sum_k op(A)[m, k]  (transA pipelined kernel only)
+    float* ws_bias;   // [splitk][M] partial row sums when splitk > 1
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -400,8 +402,11 @@ __device__ __forceinline__ void pipe_issue_operand(const bf16_t* __restrict__ ba
         if constexpr (TR) {  // piece = 4 k-rows of 256 B; lane -> (k = 4*piece + lane/16, slot = lane%16)
             const int k = piece * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
+            // a chunk is fetched whenever it lies inside the ALLOCATED row (ld): with a padded row stride the last
+            // valid rows (e.g. 112..114 of 115) sit in a chunk that extends into the padding.  Chunks beyond the
+            // row are redirected to chunk 0: they only feed output rows that are never stored.
             int col = row0 + c * 8;
-            if (col + 8 > rows_total) col = row0;  // garbage for rows that are never stored, but in bounds
+            if (col + 8 > ld) col = row0;
             gp = base + (long long)(k0 + k) * ld + col;
         } else {  // piece = 8 rows of 128 B; lane -> (row = 8*piece + lane/8, slot = lane%8)
             const int r = piece * 8 + (lane >> 3);
@@ -471,6 +476,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
         b_tr[i] = tr_row + ((((unsigned)(wn * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
     }
 
+    // fused bias gradient (dW form: op(A) = dY^T, so sum_k op(A)[m, k] is the column sum of dY): the workgroups of
+    // the first column tile also sum their k-major A image over k.  Thread -> 16-byte chunk column cc (8 output rows)
+    // and a group of 4 k-rows; 8 f32 partial sums per thread across all K-tiles, combined through LDS at the end.
+    const bool do_bias = TRA && g.dbias != nullptr && tn == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int bcc = tid & 15, bkg = tid >> 4;
+
     const int nt = t_end - t_begin;
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
@@ -489,6 +501,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
         // in flight and would put s_waitcnt vmcnt(0) in front of it, draining the prefetched tiles.
         const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG;
         uint4 a0[4], a1[4], b0[4], b1[4];
+        uint4 bz[4];
+        if constexpr (TRA) {
+            if (do_bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = bkg * 4 + r;
+                    const unsigned ad = stA + (unsigned)(k * 256 + ((bcc ^ (2 * (k & 3) + 8 * ((k >> 3) & 1))) << 4));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(bz[r]) : "v"(ad));
+                }
+            }
+        }
         if constexpr (TRA) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -562,6 +585,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1[j]),
                                                                     __builtin_bit_cast(bf16x8, a1[i]), acc[i][j], 0, 0, 0);
+        if constexpr (TRA) {
+            if (do_bias) {  // (the reads above completed at the lgkmcnt(0))
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned wv[4] = {bz[r].x, bz[r].y, bz[r].z, bz[r].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bsum[2 * e] += __uint_as_float(wv[e] << 16);
+                        bsum[2 * e + 1] += __uint_as_float(wv[e] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (TRA) {
+        if (g.dbias != nullptr && tn == 0) {  // block-uniform
+            __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [16][128]
+            float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[bkg * 128 + bcc * 8 + e] = bsum[e];
+            __syncthreads();
+            if (tid < 128 && m0 + tid < g.M) {
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t += red[q * 128 + tid];
+                if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
+                else g.dbias[m0 + tid] += t;
+            }
+            __syncthreads();
+        }
     }
     gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
 }
@@ -584,6 +637,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs g) {
         if (g.c_bf16) ((bf16_t*)g.C)[(long long)m * g.ldc + n] = f32_to_bf16(o);
         else ((float*)g.C)[(long long)m * g.ldc + n] = o;
     }
+    if (g.dbias && g.ws_bias)
+        for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < g.M; m += (long long)gridDim.x * blockDim.x) {
+            float t = 0.f;
+            for (int z = 0; z < g.splitk; ++z) t += g.ws_bias[(long long)z * g.M + m];
+            g.dbias[m] += t;
+        }
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -633,6 +692,18 @@ extern "C" int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute)
     return s < 1 ? 1 : s;
 }
 
+extern "C" int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d) {
+    if (!d) return 0;
+    const int sk = d->splitk > 1 ? d->splitk : 1;
+    int64_t n = sk > 1 ? (int64_t)sk * d->M * d->N * 4 : 0;
+    if (d->dbias) {
+        const int64_t fused = sk > 1 ? (int64_t)sk * d->M * 4 : 0;
+        const int64_t plain = (int64_t)egk_colsum_ws_len(d->K1, d->M) * 4;
+        n += fused > plain ? fused : plain;
+    }
+    return n;
+}
+
 extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
     EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
@@ -675,6 +746,7 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     if (g.splitk > 1)
         EGK_REQUIRE(g.ws && d->ws_bytes >= (int64_t)g.splitk * d->M * d->N * 4, "egk_gemm: split-K workspace too small");
     g.tiles_m = cdiv(g.M, BM); g.tiles_n = cdiv(g.N, BN);
+    g.dbias = nullptr; g.ws_bias = nullptr;
 
     const int K = d->K1 + d->K2;
     const double flops = 2.0 * d->M * d->N * K;
@@ -687,6 +759,22 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     // the contraction axis must not need zero fill); everything else runs on the generic register-staged kernel.
     const bool pipe_ok = bf && a16 && g_use_pipe && d->K1 % 64 == 0 && d->K2 % 64 == 0 && d->K1 > 0 && g.a_vec[0] &&
                          g.b_vec[0] && (d->K2 == 0 || (g.a_vec[1] && g.b_vec[1]));
+    // fused bias gradient: only the pipelined dW form sums its A image; anything else gets explicit column sums below
+    const bool bias_fused = pipe_ok && d->dbias && d->transA && d->K2 == 0;
+    if (d->dbias) {
+        EGK_REQUIRE(d->transA && d->K2 == 0, "egk_gemm: dbias needs the dW form (transA, single K source)");
+        const int64_t slab = g.splitk > 1 ? (int64_t)g.splitk * d->M * d->N * 4 : 0;
+        const int64_t need = bias_fused ? slab + (g.splitk > 1 ? (int64_t)g.splitk * d->M * 4 : 0)
+                                        : slab + (int64_t)egk_colsum_ws_len(d->K1, d->M) * 4;
+        EGK_REQUIRE(d->ws && d->ws_bytes >= need, "egk_gemm: workspace too small for dbias (%lld bytes needed)", (long long)need);
+        if (bias_fused) {
+            g.dbias = d->dbias;
+            g.ws_bias = g.splitk > 1 ? (float*)((char*)d->ws + slab) : nullptr;
+        } else {  // explicit column sums of dY (= A1 as stored: [K1 rows, M columns])
+            const int rc = egk_colsum(stream, d->A1, d->lda1, d->K1, d->M, d->dbias, 1, (float*)((char*)d->ws + slab), d->a_dtype);
+            if (rc) return rc;
+        }
+    }
     if (pipe_ok) {
         ensure_lds_attr();
         dim3 pgrid(g.tiles_m * g.tiles_n, g.splitk), pblock(NTHREADS);

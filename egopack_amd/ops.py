@@ -201,7 +201,7 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
          transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-         allow_splitk=True):
+         allow_splitk=True, dbias=None):
     lib = _lib.load()
     op_dt = _dt(A1)
     if _dt(B1) != op_dt or (A2 is not None and (_dt(A2) != op_dt or _dt(B2) != op_dt)):
@@ -221,8 +221,10 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ld
     d.r_dtype = _dt(residual) if residual is not None else F32
     sk = lib.egk_gemm_splitk(M, N, K1 + K2, compute) if allow_splitk else 1
     d.splitk = sk
-    if sk > 1:
-        ws = workspace(sk * M * N * 4, out.device)
+    d.dbias = _p(dbias)
+    need = lib.egk_gemm_ws_bytes(C.byref(d))
+    if need:
+        ws = workspace(need, out.device)
         d.ws, d.ws_bytes = _p(ws), ws.numel()
     _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
 
@@ -320,16 +322,20 @@ class _Linear(torch.autograd.Function):
         if needs[0]:
             dx = torch.empty_like(x)
             gemm(M, K1, g, g.stride(0), W, K1, N, dx, K1, transB=True, compute=ctx.compute)
+        db_out = None
+        if has_b and needs[2]:
+            slot_b = _grad_slot(bp)
+            db_out = slot_b if slot_b is not None else torch.zeros(N, dtype=torch.float32, device=g.device)
+            db = None if slot_b is not None else db_out
         if needs[1]:
             slot = _grad_slot(Wp)
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
-            gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+            # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS)
+            gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True, compute=ctx.compute,
+                 dbias=db_out)
             dW = None if slot is not None else out
-        if has_b and needs[2]:
-            slot = _grad_slot(bp)
-            out = slot if slot is not None else torch.zeros(N, dtype=torch.float32, device=g.device)
-            _colsum_into(g, out, True)
-            db = None if slot is not None else out
+        elif db_out is not None:
+            _colsum_into(g, db_out, True)
         if has_x2:
             K2 = x2.shape[1]
             if needs[3]:

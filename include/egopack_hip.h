@@ -80,7 +80,14 @@ typedef struct egk_gemm_desc {
     int32_t splitk;
     void* ws;
     int64_t ws_bytes;
+    /* dW form only (transA = 1, K2 = 0): dbias[m] += sum_k op(A)[m, k], i.e. the bias gradient colsum(dY) of the
+     * Linear whose weight gradient this launch computes -- summed from the dY^T image the kernel already holds in
+     * LDS (or by explicit column-sum launches when the pipelined kernel is not eligible).  Needs
+     * ws_bytes >= egk_gemm_ws_bytes(desc). */
+    float* dbias;
 } egk_gemm_desc;
+/* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
+int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute);
 /* development knob for A/B measurements in one process: 0 routes every contraction through the generic

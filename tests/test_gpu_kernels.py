@@ -677,3 +677,31 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
         ref = A1.double() @ B1.double().t() + (A2.double() @ B2.double().t() if K2 else 0) + bias.double()
         ref = torch.relu(ref).float() + res.float()
         torch.testing.assert_close(outs[(1, torch.float32)], ref, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 2048), (472, 1024, 1024), (128, 256, 4096), (1024, 4608, 6144), (115, 1024, 2048)])
+def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
+    """dW launch with dbias: dbias[m] += sum_k dY[k, m], fused into the pipelined kernel (from the dY^T LDS image) or
+    computed by the library's column-sum launches when the pipelined kernel is off -- both against fp64."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    ldg = (M + 7) // 8 * 8
+    dY = torch.randn(K, ldg, device=DEV, generator=g).to(BF)[:, :M]  # padded row stride, as _operand_rows builds it
+    X = torch.randn(K, N, device=DEV, generator=g).to(BF)
+    W0, b0 = torch.randn(M, N, device=DEV, generator=g), torch.randn(M, device=DEV, generator=g)
+    ref_w = (dY.double().t() @ X.double() + W0.double()).float()
+    ref_b = (dY.double().sum(0) + b0.double()).float()
+    res = {}
+    for pipe in (1, 0):
+        prev = lib.egk_gemm_set_pipeline(pipe)
+        try:
+            w, b = W0.clone(), b0.clone()
+            ops.gemm(M, N, dY, dY.stride(0), X, N, K, w, N, transA=True, transB=True, accumulate=True, dbias=b)
+            res[pipe] = (w, b)
+        finally:
+            lib.egk_gemm_set_pipeline(prev)
+    assert torch.equal(res[1][0], res[0][0])
+    for pipe in (1, 0):
+        torch.testing.assert_close(res[pipe][0], ref_w, rtol=2e-3, atol=2e-2)
+        torch.testing.assert_close(res[pipe][1], ref_b, rtol=1e-3, atol=2e-2)

@@ -106,6 +106,39 @@ def test_bf16_backbone_vs_oracle_moderate_size(A):
         assert r < 8e-2, f"{k}: {r:.4f}"
 
 
+@pytest.mark.parametrize("mode,ftol,gtol", [("bf16", 2e-2, 5e-2), ("f32", 1e-4, 1e-3)])
+def test_recognition_head_real_class_counts(A, mode, ftol, gtol):
+    """AR head with the Ego4D class counts (115 verbs, 478 nouns: widths that are NOT multiples of 8) on 2048 nodes,
+    so that logits / loss gradients take the padded-stride operand path and the pipelined dX / dW kernels: logits,
+    loss and every parameter gradient against the fp32 oracle (relative Frobenius error)."""
+    torch.manual_seed(3)
+    H, N = 256, 2048
+    t = A.RecognitionTask(H, H, (115, 478))
+    sd = {k: v.clone() for k, v in t.state_dict().items()}
+    feat = torch.randn(N, H)
+    y = torch.stack([torch.randint(0, 115, (N,)), torch.randint(0, 478, (N,))], 1)
+    y[::5] = -1
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fo = O.projection_features(leaf, feat)
+    lo = O.multihead_logits(leaf, fo, 2)
+    loss_o = O.multihead_ce(lo, y)
+    loss_o.mean().backward()
+    t = t.to(DEV).train()
+    with A.ops.compute_mode(mode):
+        f = t.forward_features(feat.to(DEV))
+        logits = t.forward_logits(f)
+        loss = t.compute_loss(logits, y.to(DEV))
+        A.ops.weighted_mean_sum([loss], [1.0]).backward()
+
+    def rel(a, b):
+        return ((a.float().cpu() - b).norm() / b.norm().clamp(min=1e-12)).item()
+    for a, b in zip(logits, lo):
+        assert a.shape == b.shape and rel(a.detach(), b.detach()) < ftol
+    assert rel(loss.detach(), loss_o.detach()) < ftol
+    for k, p in t.named_parameters():
+        assert rel(p.grad, leaf[k].grad) < gtol, f"{k}: {rel(p.grad, leaf[k].grad):.4f}"
+
+
 def test_graph_accepts_plain_batch_without_csr(A, golden):
     """Drop-in contract: a batch that only carries x / pos / edge_index / batch (what PyG's loader gives)."""
     G = golden("graph_forward")
