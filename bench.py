@@ -139,6 +139,33 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=16, budget_s=20.0):
                       f"{b0.x.shape[0] // b0.num_graphs}), fp32 torch CPU oracle, {cores} threads, {dt * 1e3:.0f} ms/step"}
 
 
+# library profiler name -> kernel symbol (substring) in rocprofv3 output
+ROCPROF_NAME = {"gemm_bf16_nn": "gemm_pipe_kernel<2, false, false>", "gemm_bf16_nt": "gemm_pipe_kernel<2, false, true>",
+                "gemm_bf16_tt": "gemm_pipe_kernel<2, true, true>", "gemm_bf16_tn": "gemm_pipe_kernel<2, true, false>",
+                "adam": "adam_kernel", "csr_gather": "csr_gather_kernel"}
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
+    by tools/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, FETCH_SIZE doubled as the
+    MI355X guide prescribes for gfx950).  None when no profile is committed."""
+    f = REPO / "profiles" / "pmc_latest.json"
+    sym = ROCPROF_NAME.get(kernel)
+    if not f.exists() or sym is None:
+        return None
+    try:
+        pmc = json.loads(f.read_text())
+        tot = 0.0
+        hit = False
+        for name, ctrs in pmc.items():
+            if sym in name:
+                hit = True
+                tot += sum(c["bytes_per_launch"] for c in ctrs.values())
+        return tot if hit else None
+    except Exception:
+        return None
+
+
 def roofline(ops, step_fn, compute, n_steps=3):
     """Profile ``n_steps`` eager steps with the library's HIP-event timers; report the dominant kernel."""
     ops.prof_reset()
@@ -160,7 +187,8 @@ def roofline(ops, step_fn, compute, n_steps=3):
     else:
         achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
         out = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS}
-    out.update({"traffic": None, "kernel": name, "launches_per_step": r["launches"] / n_steps, "avg_launch_us": avg_ms * 1e3,
+    out.update({"traffic": pmc_traffic(name), "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc passes)",
+                "kernel": name, "rocprof_symbol": ROCPROF_NAME.get(name), "launches_per_step": r["launches"] / n_steps, "avg_launch_us": avg_ms * 1e3,
                 "alg_per_launch": (r["flops"] if name.startswith("gemm") else r["bytes"]) / r["launches"]})
     table = {k: {"launches_per_step": v["launches"] / n_steps, "ms_per_step": v["total_ms"] / n_steps,
                  "tflops": (v["flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["flops"] and v["total_ms"] else None,
@@ -183,6 +211,8 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--no-fused-backbone", action="store_true")
     ap.add_argument("--serial-heads", action="store_true", help="run the task heads on the main stream")
+    ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
+                    help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
@@ -212,7 +242,7 @@ def main():
         t.to(device).train()
     params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
     opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
-    sync = edist.GradSync(world) if world > 1 else None
+    sync = edist.GradSync(world, compress=args.grad_compress) if world > 1 else None
     step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync,
                           parallel_heads=not args.serial_heads)
     fused_merged = None if args.no_fused_backbone else merged
@@ -273,6 +303,7 @@ def main():
                                    f"{'fused' if not args.no_fused_backbone else 'per-task'} backbone pass",
                        "global_batch": seqs_per_step, "nodes_per_step": seqs_per_step * args.T,
                        "parallelism": f"dp{world}", "trainable_params": n_params,
+                       "grad_allreduce": (args.grad_compress if world > 1 else None),
                        "master_weights": "f32", "mode": args.compute,
                        "activations": "bf16" if args.compute == "bf16" else "f32"},
             "roofline": rl, "cpu_baseline": cb,

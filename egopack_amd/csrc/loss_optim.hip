@@ -166,7 +166,8 @@ __global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict
 }
 
 // ---- Adam (torch.optim.Adam single-tensor formulas, L2 weight decay) ----------------------------------------
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <typename GT>  // GT: element type of the gradient buffer (f32, or bf16 after a compressed all-reduce)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, const float* __restrict__ hyper,
                                                    float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow) {
     const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
          i += (long long)gridDim.x * blockDim.x * 4) {
         if (i + 4 <= n) {
             float4 pv = *reinterpret_cast<float4*>(p + i);
-            const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            const float4 gv = ld4t(g + i, 0, 4, true);
             float4 mv = *reinterpret_cast<float4*>(m + i);
             float4 vv = *reinterpret_cast<float4*>(v + i);
             float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             if (shadow) st4t(shadow + i, 0, 4, true, pv);
         } else {
             for (long long j = i; j < n; ++j) {
-                const float gg = g[j] * gs + wd * p[j];
+                const float gg = ld1t(g + j) * gs + wd * p[j];
                 m[j] = m[j] + (gg - m[j]) * (1.f - b1);
                 v[j] = v[j] * b2 + (1.f - b2) * gg * gg;
                 p[j] = p[j] - step * (m[j] / (sqrtf(v[j]) / bc2s + eps));
@@ -322,17 +323,17 @@ int egk_sum_scale(egk_stream_t stream, const float* x, float* out, int64_t n, fl
     return check_launch("egk_sum_scale");
 }
 
-int egk_adam_step(egk_stream_t stream, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                  float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow) {
+int egk_adam_step(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
+                  const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow) {
     EGK_REQUIRE(p && g && m && v && hyper, "egk_adam_step: null pointer");
     EGK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "egk_adam_step: buffers must be 16-byte aligned");
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     EGK_REQUIRE(!bf16_shadow || ((uintptr_t)bf16_shadow & 7) == 0, "egk_adam_step: shadow must be 8-byte aligned");
-    ProfScope prof(KID_ADAM, s, 0, (bf16_shadow ? 30.0 : 28.0) * n);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, s, p, g, m, v, (long long)n, hyper, beta1, beta2, eps,
-                       weight_decay, (bf16_t*)bf16_shadow);
+    ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * n);
+    EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(ew_grid(n, 4)), dim3(256), 0, s, p, (const T*)g, m, v,
+                                               (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow));
     return check_launch("egk_adam_step");
 }
 }

@@ -46,19 +46,37 @@ class GradSync:
     backward, so the first chunks overlap whatever the compute stream does next, and the optimiser
     waits for ``done`` before it reads the buffer."""
 
-    def __init__(self, world_size: int, chunk_mb: float = 32.0, group=None):
-        self.world, self.group = world_size, group
+    def __init__(self, world_size: int, chunk_mb: float = 32.0, group=None, compress: str = "none"):
+        """compress='bf16' (GPU only): the flat f32 gradient is converted to a bf16 copy by one kernel launch, the
+        bf16 copy is all-reduced (half the bytes on every xGMI link) and the Adam kernel reads it directly."""
+        if compress not in ("none", "bf16"):
+            raise ValueError(compress)
+        self.world, self.group, self.compress = world_size, group, compress
         self.chunk_elems = max(1, int(chunk_mb * (1 << 20) / 4))
         self._side = None
+        self._g16 = None
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         if self.world > 1:
             dist.broadcast(flat, src=src, group=self.group)
 
-    def all_reduce_(self, flat_g: torch.Tensor):
-        """In place sum over ranks; returns when the work is ENQUEUED (GPU) or done (CPU/gloo)."""
+    def all_reduce_(self, flat_g: torch.Tensor) -> torch.Tensor:
+        """Sum over ranks; returns the buffer that holds the summed gradient (``flat_g`` itself, or its bf16 copy
+        under compression) once the work is ENQUEUED (GPU) or done (CPU/gloo)."""
         if self.world <= 1:
-            return
+            return flat_g
+        if self.compress == "bf16" and flat_g.is_cuda:
+            from . import _lib
+            from .ops import _ck, _p, _stream
+            if self._g16 is None or self._g16.numel() != flat_g.numel():
+                self._g16 = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device)
+            _ck(_lib.load().egk_cast(_stream(), _p(flat_g), 0, _p(self._g16), 1, flat_g.numel()), "egk_cast")
+            self._reduce_chunks(self._g16)
+            return self._g16
+        self._reduce_chunks(flat_g)
+        return flat_g
+
+    def _reduce_chunks(self, flat_g: torch.Tensor):
         bounds = chunk_bounds(flat_g.numel(), self.chunk_elems)
         if flat_g.is_cuda:
             if self._side is None:

@@ -123,10 +123,11 @@ class MTLStep:
         opt = self.optimizer
         if hasattr(opt, "materialised") and not opt.materialised:
             opt._materialise()
+        grads = None
         if self.sync is not None and self.sync.world > 1:
-            self.sync.all_reduce_(opt.flat_g)
+            grads = self.sync.all_reduce_(opt.flat_g)
             opt.grad_scale = 1.0 / self.sync.world
-        opt.step()
+        opt.step(grads=grads)
 
     # ---- hipGraph capture ---------------------------------------------------------------------------------
     def capture(self, batches: Mapping[str, Data], merged: Optional[Data] = None, warmup: int = 2):
@@ -165,9 +166,9 @@ class MTLStep:
             opt.step_count += 1
         else:
             self._graph.replay()
-            self.sync.all_reduce_(opt.flat_g)
+            grads = self.sync.all_reduce_(opt.flat_g)
             opt.grad_scale = 1.0 / self.sync.world
-            opt.step()
+            opt.step(grads=grads)
         return self._static_out[0]
 
 
@@ -223,8 +224,9 @@ class EgoPackStep:
         opt = self.optimizer
         if hasattr(opt, "materialised") and not opt.materialised:
             opt._materialise()
+        grads = None
         if self.sync is not None and self.sync.world > 1:
-            self.sync.all_reduce_(opt.flat_g)
+            grads = self.sync.all_reduce_(opt.flat_g)
             opt.grad_scale = 1.0 / self.sync.world
-        opt.step()
+        opt.step(grads=grads)
         return total.detach(), {t: v.detach() for t, v in vectors.items()}

@@ -100,19 +100,21 @@ class FlatAdam(torch.optim.Optimizer):
         host[3] = self.grad_scale
         self._hyper.copy_(host, non_blocking=True)
 
-    def launch(self):
-        """The kernel launch alone (capturable)."""
+    def launch(self, grads=None):
+        """The kernel launch alone (capturable).  ``grads``: the buffer to read gradients from (default the f32
+        flat buffer; dist.GradSync hands in its bf16 copy after a compressed all-reduce)."""
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
-                                      self.flat_p.numel(), _p(self._hyper), b1, b2, g["eps"], g["weight_decay"],
-                                      _p(self.flat_w16)),
+        grads = self.flat_g if grads is None else grads
+        _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p), _p(grads), 1 if grads.dtype == torch.bfloat16 else 0,
+                                      _p(self.flat_m), _p(self.flat_v), self.flat_p.numel(), _p(self._hyper), b1, b2,
+                                      g["eps"], g["weight_decay"], _p(self.flat_w16)),
             "egk_adam_step")
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grads=None):
         if not self.materialised:
             self._materialise()
         self.prepare_hyper()
-        self.launch()
+        self.launch(grads)
         self.step_count += 1

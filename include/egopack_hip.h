@@ -225,10 +225,11 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
  * {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale}: rewritten by the host between graph replays.
  * g' = g*grad_scale + wd*p; m = b1*m+(1-b1)*g'; v = b2*v+(1-b2)*g'^2;
  * p -= (lr/bc1) * m / (sqrt(v)/bc2_sqrt + eps)
+ * g_dtype: EGK_F32, or EGK_BF16 when the gradient buffer handed in is the bf16 copy a compressed all-reduce summed.
  * bf16_shadow (may be NULL): bf16 copy of the updated parameters, same flat layout, written by the same
  * launch -- the operand the bf16 contractions read (no separate cast pass over the weights). */
-int egk_adam_step(egk_stream_t s, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                  float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
+int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
+                  const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
 
 #ifdef __cplusplus
 }

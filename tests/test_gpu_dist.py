@@ -1,0 +1,102 @@
+"""The data-parallel step path on ONE GPU: a 1-rank RCCL process group driven through dist.GradSync as if the world
+had 2 ranks (the all-reduce then sums a single contribution), with bf16 gradient compression, eager and hipGraph
+replay.  Checks the plumbing the 8-GPU run uses: cast -> all-reduce on the side stream -> Adam reading bf16 grads."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+def _setup(golden, sync):
+    import egopack_amd.data as D
+    from egopack_amd import engine
+    from egopack_amd.criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper
+    from egopack_amd.models import Graph
+    from egopack_amd.models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+    from egopack_amd.optim import FlatAdam
+    G = golden("mtl_train")
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": 40}
+    model = Graph(48, hidden_size=32, depth=3, temporal_pooling=trn, num_segments=3)
+    model.load_state_dict(G["before"]["temporal_graph"])
+    tasks = {"ar": RecognitionTask(32, 32, (7, 11)), "oscc": OSCCTask(32, 32), "lta": LTATask(32, 32, (7, 11)), "pnr": PNRTask(32, 32)}
+    for t, n in (("ar", "task/recognition"), ("oscc", "task/oscc"), ("lta", "task/lta"), ("pnr", "task/pnr")):
+        tasks[t].load_state_dict(G["before"][n])
+        tasks[t].cuda()
+    model.cuda()
+
+    class DS:
+        has_joint_label, num_labels = False, 2
+    crit = {"ar": MetricSelectorWrapper(CrossEntropyNone(), DS()), "lta": MetricSelectorWrapper(CrossEntropyNone(), DS()),
+            "oscc": CrossEntropyNone(), "pnr": BCEWithLogitsNone()}
+    live = [*model.parameters(), *(p for t in ("ar", "lta", "pnr") for p in tasks[t].parameters())]
+    opt = FlatAdam(live, lr=1e-3, weight_decay=1e-5)
+    step = engine.MTLStep(model, tasks, crit, G["weights"], opt, fused_backbone=True, sync=sync)
+    batches = {}
+    for t in ("ar", "lta", "pnr"):
+        b = D.Data(**G["batches"][t][0])
+        b.graph = D.build_csr(b.edge_index, b.x.shape[0])
+        b.ptr32 = b.ptr.to(torch.int32)
+        batches[t] = b.to("cuda")
+    return step, opt, batches
+
+
+def test_dp_step_with_bf16_compressed_allreduce(pg, golden):
+    from egopack_amd import ops
+    from egopack_amd.dist import GradSync
+    with ops.compute_mode("f32"):
+        # reference: no exchange, gradient scale 1/2 applied by Adam on the f32 gradients
+        step, opt, batches = _setup(golden, None)
+        opt.grad_scale = 0.5
+        for _ in range(3):
+            step.step(batches)
+        ref = opt.flat_p.clone()
+        # DP path, eager: "world of 2" whose all-reduce sums one contribution -> same gradients / 2, bf16-rounded
+        step, opt, batches = _setup(golden, GradSync(2, chunk_mb=0.01, compress="bf16"))
+        for _ in range(3):
+            step.step(batches)
+        torch.cuda.synchronize()
+        assert opt.grad_scale == 0.5 and step.sync._g16 is not None and step.sync._g16.dtype == torch.bfloat16
+        # Adam normalises the update; bf16 rounding of a gradient moves an update by << lr
+        torch.testing.assert_close(opt.flat_p, ref, rtol=0, atol=2e-4)
+        eager = opt.flat_p.clone()
+        # DP path, hipGraph: forward+backward captured, exchange + Adam outside the graph
+        step, opt, batches = _setup(golden, GradSync(2, chunk_mb=0.01, compress="bf16"))
+        step.capture(batches, warmup=1)
+        assert step._fuse_adam is False
+        for _ in range(2):
+            step.replay()
+        torch.cuda.synchronize()
+        assert opt.step_count == 3
+        torch.testing.assert_close(opt.flat_p, eager, rtol=0, atol=2e-6)
+
+
+def test_adam_reads_bf16_gradients(pg):
+    from egopack_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(5)
+    p0, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    cp = p0.clone().requires_grad_(True)
+    cp.grad = gr.to(torch.bfloat16).float()
+    ref = torch.optim.Adam([cp], lr=1e-2, weight_decay=1e-3)
+    ref.step()
+    dp = p0.clone().cuda().requires_grad_(True)
+    dp.grad = gr.clone().cuda()
+    opt = FlatAdam([dp], lr=1e-2, weight_decay=1e-3)
+    opt._materialise()
+    opt.step(grads=opt.flat_g.to(torch.bfloat16))
+    torch.testing.assert_close(dp.detach().cpu(), cp.detach(), rtol=1e-5, atol=1e-6)
+    # the bf16 shadow the contractions read tracks the updated parameters
+    torch.testing.assert_close(opt.flat_w16[:1000].float().cpu(), cp.detach().to(torch.bfloat16).float(), rtol=0, atol=0)

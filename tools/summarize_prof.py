@@ -32,6 +32,8 @@ if stats:
                   f"{float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
     print()
 
+import json
+pmc = {}
 for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
     f = find(sub, "*counter_collection.csv")
     if not f:
@@ -50,3 +52,6 @@ for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SI
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
         print(f"| {short(k)} | {n} | {v * 1024 * mult / n / 1e6:.2f} |")
     print()
+    for k, (n, v) in agg.items():
+        pmc.setdefault(short(k), {})[ctr] = {"launches": n, "bytes_per_launch": v * 1024 * mult / n}
+(root / "pmc.json").write_text(json.dumps(pmc, indent=1))
