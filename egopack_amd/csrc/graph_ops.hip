@@ -49,75 +49,136 @@ __global__ __launch_bounds__(256) void pe_add_kernel(const T* __restrict__ x, co
 }
 
 // ---- CSR gather ----------------------------------------------------------------------------------
-// The output row lives in NV float4 registers per lane; per edge the NV loads of the neighbour row are
-// independent (one index load, then NV wide loads in flight) instead of a chunk-outer / edge-inner walk.
+// One wave per output row, the row in NV float4 registers per lane.  Neighbour indices / weights are fetched by
+// the lanes in one load per 64 edges and broadcast with shuffles; 4 neighbour rows are in flight per step.
+// HEAVY rows (more than HEAVY edges: the LTA fan-out node has out-degree 31 in the backward orientation) are not
+// walked by their wave alone: after the light rows of a workgroup are done, its 4 waves share each heavy row's
+// edge list (edge e -> wave e % 4), combine their partial rows through LDS in wave order and wave 0 stores.
+constexpr int HEAVY = 12;
+
+template <int NV, typename T>
+__device__ __forceinline__ void csr_accumulate(const T* __restrict__ x, const int* __restrict__ col, const float* __restrict__ wgt,
+                                               int e0, int e1, int e_first, int e_stride, int cols, bool vec, int lane,
+                                               float4 (&acc)[NV]) {
+    // edges e0 + e_first, e0 + e_first + e_stride, ... < e1
+    const int n_mine = (e1 - e0 - e_first + e_stride - 1) / e_stride;
+    for (int base = 0; base < n_mine; base += 64) {
+        const int cnt = min(64, n_mine - base);
+        const int my_e = e0 + e_first + (base + lane) * e_stride;
+        const int my_c = lane < cnt ? col[my_e] : 0;
+        const float my_w = (wgt && lane < cnt) ? wgt[my_e] : 1.f;
+        int e = 0;
+        for (; e + 4 <= cnt; e += 4) {
+            const T* s0 = x + (long long)__shfl(my_c, e + 0, 64) * cols;
+            const T* s1 = x + (long long)__shfl(my_c, e + 1, 64) * cols;
+            const T* s2 = x + (long long)__shfl(my_c, e + 2, 64) * cols;
+            const T* s3 = x + (long long)__shfl(my_c, e + 3, 64) * cols;
+            const float w0 = __shfl(my_w, e + 0, 64), w1 = __shfl(my_w, e + 1, 64);
+            const float w2 = __shfl(my_w, e + 2, 64), w3 = __shfl(my_w, e + 3, 64);
+            float4 v0[NV], v1[NV], v2[NV], v3[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                v0[i] = ld4(s0, c, cols, vec); v1[i] = ld4(s1, c, cols, vec);
+                v2[i] = ld4(s2, c, cols, vec); v3[i] = ld4(s3, c, cols, vec);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                acc[i].x += w0 * v0[i].x; acc[i].y += w0 * v0[i].y; acc[i].z += w0 * v0[i].z; acc[i].w += w0 * v0[i].w;
+                acc[i].x += w1 * v1[i].x; acc[i].y += w1 * v1[i].y; acc[i].z += w1 * v1[i].z; acc[i].w += w1 * v1[i].w;
+                acc[i].x += w2 * v2[i].x; acc[i].y += w2 * v2[i].y; acc[i].z += w2 * v2[i].z; acc[i].w += w2 * v2[i].w;
+                acc[i].x += w3 * v3[i].x; acc[i].y += w3 * v3[i].y; acc[i].z += w3 * v3[i].z; acc[i].w += w3 * v3[i].w;
+            }
+        }
+        for (; e < cnt; ++e) {
+            const T* src = x + (long long)__shfl(my_c, e, 64) * cols;
+            const float we = __shfl(my_w, e, 64);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 v = ld4(src, (i * 64 + lane) * 4, cols, vec);
+                acc[i].x += we * v.x; acc[i].y += we * v.y; acc[i].z += we * v.z; acc[i].w += we * v.w;
+            }
+        }
+    }
+}
+
+template <int NV, typename T>
+__device__ __forceinline__ void csr_finish(float4 (&acc)[NV], const float* __restrict__ wgt, float mean_w, const T* __restrict__ gate,
+                                           T* __restrict__ out, int row, int cols, bool vec, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (!wgt) {  // mean = sum / count, as scatter_add / clamp(count, 1)
+            acc[i].x *= mean_w; acc[i].y *= mean_w; acc[i].z *= mean_w; acc[i].w *= mean_w;
+        }
+        if (gate) {
+            const float4 g = ld4(gate + (long long)row * cols, c, cols, vec);
+            acc[i].x = g.x > 0.f ? acc[i].x : 0.f; acc[i].y = g.y > 0.f ? acc[i].y : 0.f;
+            acc[i].z = g.z > 0.f ? acc[i].z : 0.f; acc[i].w = g.w > 0.f ? acc[i].w : 0.f;
+        }
+        st4(out + (long long)row * cols, c, cols, vec, acc[i]);
+    }
+}
+
 template <int NV, typename T>
 __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x, const int* __restrict__ rowptr,
                                                          const int* __restrict__ col, const float* __restrict__ wgt,
                                                          const T* __restrict__ gate, T* __restrict__ out, int rows,
                                                          int cols) {
+    extern __shared__ __attribute__((aligned(16))) float part[];  // [3][NV*256] partial rows of waves 1..3
+    __shared__ int heavy[64];
+    __shared__ int n_heavy;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
+    if (threadIdx.x == 0) n_heavy = 0;
+    __syncthreads();
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const int e0 = rowptr[row], e1 = rowptr[row + 1];
-        const float mean_w = e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f;
+        if (e1 - e0 > HEAVY) {  // deferred to the cooperative phase (wave-uniform branch) while the list has room
+            int slot = lane == 0 ? atomicAdd(&n_heavy, 1) : 0;
+            slot = __shfl(slot, 0, 64);
+            if (slot < 64) {
+                if (lane == 0) heavy[slot] = row;
+                continue;
+            }
+        }
         float4 acc[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // neighbour indices / weights are fetched by the lanes in ONE load per 64 edges and broadcast with
-        // shuffles, so the row loads of consecutive edges do not wait on dependent index loads
-        for (int eb = e0; eb < e1; eb += 64) {
-            const int cnt = min(64, e1 - eb);
-            const int my_c = lane < cnt ? col[eb + lane] : 0;
-            const float my_w = (wgt && lane < cnt) ? wgt[eb + lane] : 1.f;
-            // 4 neighbour rows in flight per step (independent loads first, then the FMAs): rows with many
-            // neighbours -- the LTA fan-out node has out-degree 31 -- are not one serial latency chain
-            int e = 0;
-            for (; e + 4 <= cnt; e += 4) {
-                const T* s0 = x + (long long)__shfl(my_c, e + 0, 64) * cols;
-                const T* s1 = x + (long long)__shfl(my_c, e + 1, 64) * cols;
-                const T* s2 = x + (long long)__shfl(my_c, e + 2, 64) * cols;
-                const T* s3 = x + (long long)__shfl(my_c, e + 3, 64) * cols;
-                const float w0 = __shfl(my_w, e + 0, 64), w1 = __shfl(my_w, e + 1, 64);
-                const float w2 = __shfl(my_w, e + 2, 64), w3 = __shfl(my_w, e + 3, 64);
-                float4 v0[NV], v1[NV], v2[NV], v3[NV];
+        csr_accumulate<NV, T>(x, col, wgt, e0, e1, 0, 1, cols, vec, lane, acc);
+        csr_finish<NV, T>(acc, wgt, e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f, gate, out, row, cols, vec, lane);
+    }
+    __syncthreads();
+    const int nh = min(n_heavy, 64);  // (a workgroup walks <= rows/grid rows: far fewer than 64 heavy ones)
+    for (int h = 0; h < nh; ++h) {
+        // slots are claimed in arrival order: process them in ROW order so results do not depend on timing
+        int row = 0x7fffffff;
+        for (int q = 0; q < nh; ++q) {  // h-th smallest row id (nh is tiny)
+            int below = 0;
+            for (int r = 0; r < nh; ++r) below += heavy[r] < heavy[q];
+            if (below == h) row = heavy[q];
+        }
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        float4 acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        csr_accumulate<NV, T>(x, col, wgt, e0, e1, wave, WPB, cols, vec, lane, acc);
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(part + (wave - 1) * NV * 256 + (i * 64 + lane) * 4) = acc[i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int wv = 0; wv < WPB - 1; ++wv)
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    const int c = (i * 64 + lane) * 4;
-                    v0[i] = ld4(s0, c, cols, vec); v1[i] = ld4(s1, c, cols, vec);
-                    v2[i] = ld4(s2, c, cols, vec); v3[i] = ld4(s3, c, cols, vec);
+                    const float4 p = *reinterpret_cast<const float4*>(part + wv * NV * 256 + (i * 64 + lane) * 4);
+                    acc[i].x += p.x; acc[i].y += p.y; acc[i].z += p.z; acc[i].w += p.w;
                 }
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {  // same summation order as the one-by-one loop
-                    acc[i].x += w0 * v0[i].x; acc[i].y += w0 * v0[i].y; acc[i].z += w0 * v0[i].z; acc[i].w += w0 * v0[i].w;
-                    acc[i].x += w1 * v1[i].x; acc[i].y += w1 * v1[i].y; acc[i].z += w1 * v1[i].z; acc[i].w += w1 * v1[i].w;
-                    acc[i].x += w2 * v2[i].x; acc[i].y += w2 * v2[i].y; acc[i].z += w2 * v2[i].z; acc[i].w += w2 * v2[i].w;
-                    acc[i].x += w3 * v3[i].x; acc[i].y += w3 * v3[i].y; acc[i].z += w3 * v3[i].z; acc[i].w += w3 * v3[i].w;
-                }
-            }
-            for (; e < cnt; ++e) {
-                const T* src = x + (long long)__shfl(my_c, e, 64) * cols;
-                const float we = __shfl(my_w, e, 64);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const float4 v = ld4(src, (i * 64 + lane) * 4, cols, vec);
-                    acc[i].x += we * v.x; acc[i].y += we * v.y; acc[i].z += we * v.z; acc[i].w += we * v.w;
-                }
-            }
+            csr_finish<NV, T>(acc, wgt, 1.f / (float)(e1 - e0), gate, out, row, cols, vec, lane);
         }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (!wgt) {  // mean = sum / count, as scatter_add / clamp(count, 1)
-                acc[i].x *= mean_w; acc[i].y *= mean_w; acc[i].z *= mean_w; acc[i].w *= mean_w;
-            }
-            if (gate) {
-                const float4 g = ld4(gate + (long long)row * cols, c, cols, vec);
-                acc[i].x = g.x > 0.f ? acc[i].x : 0.f; acc[i].y = g.y > 0.f ? acc[i].y : 0.f;
-                acc[i].z = g.z > 0.f ? acc[i].z : 0.f; acc[i].w = g.w > 0.f ? acc[i].w : 0.f;
-            }
-            st4(out + (long long)row * cols, c, cols, vec, acc[i]);
-        }
+        __syncthreads();
     }
 }
 
@@ -380,7 +441,7 @@ int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, co
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CSR_GATHER, s, 0, (dtype == EGK_BF16 ? 0.5 : 1.0) * (relu_gate ? 12.0 : 8.0) * rows * cols);
     EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
-#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols)
+#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows)), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols)
     EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
 #undef EGK_CSR
     return check_launch("egk_csr_gather");

@@ -154,6 +154,9 @@ class MTLStep:
             if fuse_adam:
                 opt.launch()
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
+        # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
+        # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
+        self._static_in = (batches, merged)
         return g
 
     def replay(self):

@@ -86,8 +86,6 @@ class Graph(torch.nn.Module):
             conv = getattr(self.net, f"module_{3 * d}")
             norm = getattr(self.net, f"module_{3 * d + 1}")
             slope = getattr(self.net, f"module_{3 * d + 2}").negative_slope
-            xp = conv.lin(h, relu=True)                       # relu(lin(x)): ReLU in the epilogue
-            agg = ops.csr_mean_aggregate(xp, graph)           # mean over in-neighbours
-            h = norm(conv.combine(agg, h), seg_ptr, slope)    # [agg|x].[Wl|Wr]^T + b -> graph-LN -> LeakyReLU
+            h = norm(ops.sage_mean_layer(h, conv, graph), seg_ptr, slope)  # SAGEConv -> graph-LN -> LeakyReLU
         last = getattr(self.net, f"module_{3 * self.depth}")
         return last(h, residual=x)                            # x + Linear(h): residual in the epilogue

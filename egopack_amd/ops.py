@@ -567,6 +567,73 @@ def csr_mean_aggregate(x, graph):
     return _CSRMean.apply(x, graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt)
 
 
+class _SageMean(torch.autograd.Function):
+    """One SAGEConv(project=True, aggr='mean') layer as ONE autograd node (reference models/graph.py:42):
+        xp  = relu(h @ Wp.T + bp);  agg = mean_{j->i} xp_j;  out = agg @ Wl.T + h @ Wr.T + bl
+    forward 3 launches; backward 6: the ReLU gate rides on the transposed gather, d_h = d_out @ Wr + d_pre @ Wp is one
+    two-source contraction (no gradient-accumulation add), the two bias gradients ride on their dW launches."""
+
+    @staticmethod
+    def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute):
+        _need_gpu(h, Wp, Wl, Wr)
+        lib = _lib.load()
+        h = _c(h)
+        N, H = h.shape
+        dt = h.dtype
+        Wp_o, Wl_o, Wr_o = weight_operand(Wp, dt), weight_operand(Wl, dt), weight_operand(Wr, dt)
+        xp = torch.empty_like(h)
+        gemm(N, H, h, H, Wp_o, H, H, xp, H, bias=_f32c(bp), act=1, compute=compute)
+        agg = torch.empty_like(h)
+        _ck(lib.egk_csr_gather(_stream(), _p(xp), _p(rowptr), _p(col), None, None, _p(agg), N, H, _dt(h)), "egk_csr_gather")
+        Ho = Wl.shape[0]
+        out = torch.empty((N, Ho), dtype=dt, device=h.device)
+        gemm(N, Ho, agg, H, Wl_o, H, H, out, Ho, A2=h, lda2=H, B2=Wr_o, ldb2=H, K2=H, bias=_f32c(bl), compute=compute)
+        ctx.compute, ctx.params = compute, (Wp, bp, Wl, bl, Wr)
+        ctx.save_for_backward(h, xp, agg, Wp_o, Wl_o, Wr_o, t_rowptr, t_col, t_wgt)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        h, xp, agg, Wp_o, Wl_o, Wr_o, t_rowptr, t_col, t_wgt = ctx.saved_tensors
+        Wp, bp, Wl, bl, Wr = ctx.params
+        g = _operand_rows(d_out, h.dtype)
+        N, H = h.shape
+        Ho = g.shape[1]
+        dev = g.device
+
+        def slot_or_zeros(p, shape):
+            s_ = _grad_slot(p)
+            return (s_, None) if s_ is not None else ((z := torch.zeros(shape, dtype=torch.float32, device=dev)), z)
+
+        dWl, rWl = slot_or_zeros(Wl, Wl_o.shape)
+        dbl, rbl = slot_or_zeros(bl, (Ho,))
+        dWr, rWr = slot_or_zeros(Wr, Wr_o.shape)
+        dWp, rWp = slot_or_zeros(Wp, Wp_o.shape)
+        dbp, rbp = slot_or_zeros(bp, (H,))
+        gemm(Ho, H, g, g.stride(0), agg, H, N, dWl, H, transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=dbl)
+        gemm(Ho, H, g, g.stride(0), h, H, N, dWr, H, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+        d_agg = torch.empty_like(h)
+        gemm(N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H, transB=True, compute=ctx.compute)
+        d_pre = torch.empty_like(h)  # gradient at the projection's pre-activation: transposed gather gated by xp > 0
+        _ck(lib.egk_csr_gather(_stream(), _p(d_agg), _p(t_rowptr), _p(t_col), _p(t_wgt), _p(xp), _p(d_pre), N, H, _dt(h)),
+            "egk_csr_gather")
+        gemm(H, H, d_pre, H, h, H, N, dWp, H, transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=dbp)
+        d_h = None
+        if ctx.needs_input_grad[0]:
+            d_h = torch.empty_like(h)
+            gemm(N, H, g, g.stride(0), Wr_o, H, Ho, d_h, H, A2=d_pre, lda2=H, B2=Wp_o, ldb2=H, K2=H, transB=True,
+                 compute=ctx.compute)
+        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None)
+
+
+def sage_mean_layer(h, conv, graph, compute=None):
+    """SAGEConv(project=True, mean) of ``conv`` (models.layers.SAGEConv parameters) on CSR ``graph``."""
+    return _SageMean.apply(h, conv.lin.weight, conv.lin.bias, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight,
+                           graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
+                           _compute_for(h) if compute is None else compute)
+
+
 # ---- GraphONE gather-max ------------------------------------------------------------------------------
 class _GatherMax(torch.autograd.Function):
     @staticmethod
