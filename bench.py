@@ -31,6 +31,16 @@ PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
+WORKLOADS = {
+    # name: (enabled tasks, note).  "mtl" is the headline (BASELINE.json metric / configs[2]); the others are the
+    # remaining BASELINE configs, selectable for evidence but never the default.
+    "mtl": (("ar", "lta", "pnr"), "MTL pre-train AR+LTA+PNR (BASELINE config 3)"),
+    "ar": (("ar",), "GraphONE-free temporal backbone, AR single task (BASELINE config 2)"),
+    "mtl4": (("ar", "lta", "oscc", "pnr"), "4-task MTL (BASELINE config 5: use --T 256 --batch 16)"),
+    "egopack_oscc": (("oscc",), "EgoPack novel task OSCC: frozen AR/LTA/PNR prototype banks + GraphONE (BASELINE config 4)"),
+}
+
+
 def build_workload(args, rank, device):
     from egopack_amd import data as D
     from egopack_amd.criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper
@@ -48,17 +58,17 @@ def build_workload(args, rank, device):
         has_joint_label, num_labels = False, 2
     crit = {"ar": MetricSelectorWrapper(CrossEntropyNone(), DS()), "lta": MetricSelectorWrapper(CrossEntropyNone(), DS()),
             "oscc": CrossEntropyNone(), "pnr": BCEWithLogitsNone()}
-    weights = {"ar": 1.0, "oscc": 0.0, "lta": 1.0, "pnr": 1.0}
+    order = WORKLOADS[args.workload][0]
+    weights = {t: (1.0 if t in order else 0.0) for t in ("ar", "oscc", "lta", "pnr")}
 
     # synthetic batches: labels / positions / edges from the host-side dataset logic, features N(0,1)
     # generated straight into HBM (seed 1 + rank: SURVEY 8d)
     host = {}
-    for t in ("ar", "lta", "pnr"):
+    for t in order:
         ds = D.SyntheticTaskDataset(t, args.batch, args.T, S, 8, heads, k=1, seed=1 + rank)  # tiny x, replaced below
         host[t] = D.collate([ds[i] for i in range(args.batch)])
     gen = torch.Generator(device=device)
     gen.manual_seed(1 + rank)
-    order = ("ar", "lta", "pnr")
     n = args.batch * args.T
     # one resident feature buffer for the step (what data.pack_features builds from loader batches); the
     # task batches are row ranges of it.  bf16 storage for the bf16 configs.
@@ -72,8 +82,14 @@ def build_workload(args, rank, device):
         d = b.to(device)
         d.x = x_all[i * n:(i + 1) * n]
         dev[t] = d
-    merged = D.merge_batches([host[t] for t in order]).to(device)
-    merged.x = x_all
+    merged = None
+    if len(order) > 1:
+        merged = D.merge_batches([host[t] for t in order]).to(device)
+        merged.x = x_all
+    if args.workload == "egopack_oscc":  # aux-classifier heads + frozen prototype banks
+        aux = {"ar": ("oscc", "lta", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"), "pnr": ("ar", "oscc", "lta")}
+        tasks = {"ar": RecognitionTask(H, H, heads, aux_tasks=aux["ar"]), "oscc": OSCCTask(H, H, aux_tasks=aux["oscc"], average_logits=True),
+                 "lta": LTATask(H, H, heads, aux_tasks=aux["lta"]), "pnr": PNRTask(H, H, aux_tasks=aux["pnr"])}
     return model, tasks, crit, weights, dev, merged
 
 
@@ -208,6 +224,10 @@ def main():
     ap.add_argument("--trn-hidden", type=int, default=1024)
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--compute", choices=["bf16", "bf16_f32act", "f32"], default="bf16")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mtl")
+    ap.add_argument("--bank", type=int, default=4096, help="prototypes per task bank (egopack_oscc)")
+    ap.add_argument("--graphone-k", type=int, default=4)
+    ap.add_argument("--graphone-depth", type=int, default=3)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--no-fused-backbone", action="store_true")
     ap.add_argument("--serial-heads", action="store_true", help="run the task heads on the main stream")
@@ -233,7 +253,7 @@ def main():
     model, tasks, crit, weights, dev, merged = build_workload(args, rank, device)
     names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
     sds = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("mtl", "ar", "mtl4"):
         sds = {"temporal_graph": {k: v.clone() for k, v in model.state_dict().items()}}
         for t, n in names.items():
             sds[n] = {k: v.clone() for k, v in tasks[t].state_dict().items()}
@@ -241,14 +261,30 @@ def main():
     for t in tasks.values():
         t.to(device).train()
     params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
-    opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
     sync = edist.GradSync(world, compress=args.grad_compress) if world > 1 else None
-    step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync,
-                          parallel_heads=not args.serial_heads)
     fused_merged = None if args.no_fused_backbone else merged
+    if args.workload == "egopack_oscc":
+        from egopack_amd.models.graphONE.graphONE import GraphONE
+        gen = torch.Generator(device=device)
+        gen.manual_seed(7)
+        banks = {t: torch.randn(args.bank, args.hidden, device=device, generator=gen) for t in ("ar", "lta", "pnr")}
+        graphone = GraphONE(banks, features_size=args.hidden, hidden_size=args.hidden, k=args.graphone_k,
+                            depth=args.graphone_depth, residual=True).to(device)
+        params += list(graphone.parameters())
+        opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)
+        step = engine.EgoPackStep(model, tasks, graphone, weights, opt, backprop_temporal_graph=True,
+                                  temporal_graph_train_mode=False, sync=sync)
+        args.mode = "eager"  # the EgoPack step is not captured (its k-NN search sizes are data dependent only in K)
 
-    def eager_step():
-        step.step(dev, fused_merged)
+        def eager_step():
+            step.step(dev)
+    else:
+        opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
+        step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync,
+                              parallel_heads=not args.serial_heads)
+
+        def eager_step():
+            step.step(dev, fused_merged)
 
     if args.mode == "graph":
         step.capture(dev, fused_merged, warmup=2)
@@ -276,7 +312,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = t.item()
 
-    seqs_per_step = world * 3 * args.batch
+    seqs_per_step = world * len(WORKLOADS[args.workload][0]) * args.batch
     rl, table = (None, {})
     if rank == 0 and not args.no_roofline:
         try:
@@ -293,11 +329,12 @@ def main():
     if rank == 0:
         n_params = opt.flat_p.numel()
         out = {
-            "metric": "clip-seqs/sec training, AR+LTA+PNR multi-task", "value": seqs_per_step / (ms * 1e-3),
+            "metric": ("clip-seqs/sec training, AR+LTA+PNR multi-task" if args.workload == "mtl"
+                       else f"clip-seqs/sec training, {args.workload}"), "value": seqs_per_step / (ms * 1e-3),
             "unit": "clip-seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.compute == "f32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"MTL pre-train AR+LTA+PNR, per GPU B={args.batch} seqs/task x T={args.T} nodes, "
+            "config": {"workload": f"{WORKLOADS[args.workload][1]}: per GPU B={args.batch} seqs/task x T={args.T} nodes, "
                                    f"3x1536-d Omnivore-shaped features, H={args.hidden}, TRN hidden {args.trn_hidden} "
                                    f"(dropout {args.dropout}), depth 3, k=1, Adam; {args.mode} mode, "
                                    f"{'fused' if not args.no_fused_backbone else 'per-task'} backbone pass",

@@ -682,12 +682,15 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
 // Split-K policy (host side, deterministic): slabs when the tile grid alone would leave most of
 // the 256 CUs idle and K is deep (the dW contractions: 64 tiles, K = nodes in the batch).
 extern "C" int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute) {
+    // Slabs pay off only when the tile grid leaves most CUs idle AND K is deep enough that the second launch
+    // (reads splitk slabs, ~7 us for a 1024 x 1024 output) is cheaper than the serial K walk it removes:
+    // measured on MI355X, K = 6144 (96 tiles of 64) gains with 4 slabs, K = 2048 (32 tiles) loses.
     const int KT = compute == EGK_COMPUTE_BF16 ? 64 : 32;
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     const int nkt = cdiv(K, KT);
-    if (tiles >= 128 || nkt < 16) return 1;
+    if (tiles >= 128 || nkt < 64) return 1;
     int s = 256 / tiles;
-    if (s > nkt / 8) s = nkt / 8;
+    if (s > nkt / 16) s = nkt / 16;
     if (s > 16) s = 16;
     return s < 1 ? 1 : s;
 }

@@ -180,15 +180,15 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy
 }
 
 // out_a[c] += sum_b ws[b][0][c]; out_b[c] += sum_b ws[b][1][c]   (fixed order)
-// workgroup = 32 columns x 8 row groups; the 8 partial sums of a column are combined in LDS in group order.
+// workgroup = 16 columns x 16 row groups; the 16 partial sums of a column are combined in LDS in group order.
 __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __restrict__ ws, float* __restrict__ oa,
                                                               float* __restrict__ ob, int nblk, int cols) {
-    __shared__ float red[2][8][32];
-    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cg;
+    __shared__ float red[2][16][16];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cg;
     float a = 0.f, d = 0.f;
     if (c < cols)
-        for (int k = rg; k < nblk; k += 8) {
+        for (int k = rg; k < nblk; k += 16) {
             a += ws[((long long)k * 2 + 0) * cols + c];
             d += ws[((long long)k * 2 + 1) * cols + c];
         }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __res
     if (rg == 0 && c < cols) {
         a = d = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             a += red[0][k][cg];
             d += red[1][k][cg];
         }
@@ -479,9 +479,9 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 
 static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
-static inline int row_grid(int rows) {  // kernels that emit per-workgroup partial rows: one workgroup per CU
+static inline int row_grid(int rows) {  // kernels that emit per-workgroup partial rows: two workgroups per CU
     int g = cdiv(rows, WPB);
-    return g < 1 ? 1 : (g > 256 ? 256 : g);
+    return g < 1 ? 1 : (g > 512 ? 512 : g);
 }
 static inline int row_grid_wide(int rows) {  // pure streaming row kernels: one row per wave up to 8 workgroups per CU
     int g = cdiv(rows, WPB);
@@ -563,7 +563,7 @@ int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const floa
     }
     {
         ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, s, ws, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws, dw, db, grid, cols);
     }
     return check_launch("egk_rowln_bwd");
 }
@@ -620,7 +620,7 @@ int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const fl
     }
     if (dw || db) {
         ProfScope prof(KID_GRAPHLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
     }
     return check_launch("egk_graphln_bwd");
 }

@@ -178,6 +178,7 @@ def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
                ptr=torch.tensor(ptr, dtype=torch.long), num_graphs=len(samples))
     out.graph = build_csr(ei, off) if with_csr else None
     out.ptr32 = out.ptr.to(torch.int32)
+    out.seg_ptr = torch.tensor([0, off], dtype=torch.int32)  # one graph-LayerNorm segment: the whole batch
     return out
 
 

@@ -79,8 +79,12 @@ class Graph(torch.nn.Module):
             return x
         graph = self._graph_of(data)
         seg_ptr = getattr(data, "seg_ptr", None)
-        if seg_ptr is None:
+        if seg_ptr is None:  # plain batch: one segment; cached on the batch (a host->device copy cannot be captured)
             seg_ptr = torch.tensor([0, x.shape[0]], dtype=torch.int32, device=x.device)
+            try:
+                data.seg_ptr = seg_ptr
+            except Exception:
+                pass
         h = self.positional_encoding.add_to(x, data.pos)
         for d in range(self.depth):
             conv = getattr(self.net, f"module_{3 * d}")

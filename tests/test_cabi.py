@@ -41,7 +41,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.egk_gemm(None, None) == -1  # EGK_EINVAL: null descriptor
     assert "null descriptor" in _lib.last_error()
     assert lib.egk_prof_count() > 30
-    assert lib.egk_gemm_splitk(128, 256, 4096, 1) > 1 and lib.egk_gemm_splitk(6144, 1024, 1024, 1) == 1
+    assert lib.egk_gemm_splitk(128, 256, 8192, 1) > 1 and lib.egk_gemm_splitk(6144, 1024, 1024, 1) == 1
     assert lib.egk_rowln_bwd_ws_rows(6144) >= 1 and lib.egk_graphln_ws_bytes(6144, 1024, 3) > 0
     name = ctypes.create_string_buffer(64)
     n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()

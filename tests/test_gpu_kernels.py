@@ -88,7 +88,7 @@ def test_gemm_splitk_matches_single_pass(ops, compute):
     """dW-shaped contraction (few tiles, deep K): the library picks split-K slabs; compare with fp64."""
     from egopack_amd import _lib
     g = gen(11)
-    M, N, K = 128, 256, 4096
+    M, N, K = 128, 256, 8192
     c = ops.BF16 if compute == "bf16" else ops.F32
     assert _lib.load().egk_gemm_splitk(M, N, K, c) > 1
     A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)  # both transposed (dW form)
@@ -515,7 +515,7 @@ def test_gemm_bf16_memory_operands(ops, transA, transB, M, N, K, out16):
 
 def test_gemm_bf16_two_source_splitk_accumulate(ops):
     g = gen(77)
-    M, N, K1, K2 = 128, 256, 2048, 2048  # dW shape: few tiles, deep K -> split-K slabs
+    M, N, K1, K2 = 128, 256, 4096, 4096  # dW shape: few tiles, deep K -> split-K slabs
     A1, A2 = torch.randn(K1, M, generator=g), torch.randn(K2, M, generator=g)
     B1, B2 = torch.randn(K1, N, generator=g), torch.randn(K2, N, generator=g)
     C0 = torch.randn(M, N, generator=g)
