@@ -274,10 +274,8 @@ def main():
         opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)
         step = engine.EgoPackStep(model, tasks, graphone, weights, opt, backprop_temporal_graph=True,
                                   temporal_graph_train_mode=False, sync=sync)
-        args.mode = "eager"  # the EgoPack step is not captured (its k-NN search sizes are data dependent only in K)
-
         def eager_step():
-            step.step(dev)
+            step.step(dev, fused_merged)
     else:
         opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
         step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync,

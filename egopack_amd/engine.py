@@ -48,46 +48,42 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True):
     return dev, md
 
 
-class MTLStep:
-    """One multi-task pre-training step (BASELINE configs 2, 3, 5)."""
+class StepBase:
+    """Shared machinery of the two training steps: fused multi-task backbone pass, eager step with gradient
+    exchange + flat Adam, hipGraph capture / replay.  Subclasses implement ``losses(batches, merged)`` returning
+    ``(total, vectors, extra)``."""
 
-    def __init__(self, model, tasks: Mapping[str, torch.nn.Module], criteria: Mapping[str, torch.nn.Module],
-                 weights: Mapping[str, float], optimizer, fused_backbone: bool = True, sync: Optional[GradSync] = None,
-                 parallel_heads: bool = True):
-        self.model, self.tasks, self.criteria = model, dict(tasks), dict(criteria)
+    order: Sequence[str] = TASK_ORDER
+
+    def _init_base(self, model, tasks, weights, optimizer, fused_backbone, sync, parallel_heads):
+        self.model, self.tasks = model, dict(tasks)
         self.weights = {t: float(w) for t, w in weights.items()}
         self.optimizer, self.fused, self.sync = optimizer, fused_backbone, sync
-        self.enabled = [t for t in TASK_ORDER if self.weights.get(t, 0) > 0 and t in self.tasks]
+        self.enabled = [t for t in self.order if self.weights.get(t, 0) > 0 and t in self.tasks]
         self.parallel_heads = parallel_heads
         self._head_streams = []
         self._graph = None
         self._static_out = None
+        self._static_in = None
+        self._fuse_adam = True
 
-    # ---- forward -------------------------------------------------------------------------------------
+    # ---- backbone ------------------------------------------------------------------------------------
     def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:
         live = [t for t in self.enabled if batches.get(t) is not None]
         if self.fused and len(live) > 1:
             if merged is None:
                 merged = merge_batches([batches[t] for t in live])
-                dev = batches[live[0]].pos.device
-                merged = merged.to(dev)
+                merged = merged.to(batches[live[0]].pos.device)
             feat = self.model(merged)
             parts = ops.split_rows(feat, [batches[t].pos.shape[0] for t in live])
             return dict(zip(live, parts))
         return {t: self.model(batches[t]) for t in live}
 
-    def _head(self, t: str, feat, d):
-        task = self.tasks[t]
-        f = task.forward_features(feat)
-        logits = task.forward_logits(f, d) if t == "oscc" else task.forward_logits(f)
-        return self.criteria[t](logits, d.y), logits
-
-    def losses(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
-        feats = self.features(batches, merged)
-        vectors, logits_out = {}, {}
+    def _run_heads(self, feats, head_fn):
+        """``head_fn(t, feat) -> (loss_vector, extra)`` for every task; on side streams when there are several
+        (independent half-chip contractions: they overlap; autograd replays each head's backward on its stream)."""
+        vectors, extras = {}, {}
         if self.parallel_heads and len(feats) > 1 and next(iter(feats.values())).is_cuda:
-            # the task heads are independent small contractions (M = one task batch: half a chip each): run them on
-            # side streams so they overlap; autograd replays each head's backward on the stream of its forward
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event()
             fork.record(main)
@@ -97,15 +93,17 @@ class MTLStep:
                 st.wait_event(fork)
                 feat.record_stream(st)
                 with torch.cuda.stream(st):
-                    vectors[t], logits_out[t] = self._head(t, feat, batches[t])
+                    vectors[t], extras[t] = head_fn(t, feat)
             for st, _ in zip(self._head_streams, feats):
                 main.wait_stream(st)
         else:
             for t, feat in feats.items():
-                vectors[t], logits_out[t] = self._head(t, feat, batches[t])
+                vectors[t], extras[t] = head_fn(t, feat)
+        return vectors, extras
+
+    def _objective(self, vectors):
         order = [t for t in self.enabled if t in vectors]
-        total = ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
-        return total, vectors, logits_out
+        return ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
 
     # ---- eager step -------------------------------------------------------------------------------------
     def forward_backward(self, batches, merged=None):
@@ -175,27 +173,46 @@ class MTLStep:
         return self._static_out[0]
 
 
-class EgoPackStep:
-    """One novel-task step of main_egopack.train with late fusion (BASELINE configs 4, 5): backbone
-    (train/eval mode and grad mode as configured) -> primary projection; aux projections DETACHED ->
-    GraphONE.interact -> fused logits -> primary.compute_loss."""
+class MTLStep(StepBase):
+    """One multi-task pre-training step (BASELINE configs 2, 3, 5; reference main_temporal.train :49-134)."""
+
+    def __init__(self, model, tasks: Mapping[str, torch.nn.Module], criteria: Mapping[str, torch.nn.Module],
+                 weights: Mapping[str, float], optimizer, fused_backbone: bool = True, sync: Optional[GradSync] = None,
+                 parallel_heads: bool = True):
+        self._init_base(model, tasks, weights, optimizer, fused_backbone, sync, parallel_heads)
+        self.criteria = dict(criteria)
+
+    def _head(self, t: str, feat, d):
+        task = self.tasks[t]
+        f = task.forward_features(feat)
+        logits = task.forward_logits(f, d) if t == "oscc" else task.forward_logits(f)
+        return self.criteria[t](logits, d.y), logits
+
+    def losses(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
+        feats = self.features(batches, merged)
+        vectors, logits_out = self._run_heads(feats, lambda t, feat: self._head(t, feat, batches[t]))
+        return self._objective(vectors), vectors, logits_out
+
+
+class EgoPackStep(StepBase):
+    """One novel-task step of main_egopack.train with late fusion (BASELINE configs 4, 5; reference
+    main_egopack.py:45-159): backbone (train/eval mode and grad mode as configured) -> primary projection; aux
+    projections DETACHED -> GraphONE.interact -> fused logits -> primary.compute_loss."""
+
+    order = ("ar", "oscc", "lta", "pnr")  # order of the loss terms in main_egopack.train
+    AUX_ORDER = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
+                 "pnr": ("ar", "oscc", "lta")}  # main_egopack.py:121-147
 
     def __init__(self, model, tasks: Mapping[str, torch.nn.Module], graphone, weights: Mapping[str, float], optimizer,
                  backprop_temporal_graph: bool = True, temporal_graph_train_mode: bool = False,
-                 sync: Optional[GradSync] = None):
-        self.model, self.tasks, self.graphone = model, dict(tasks), graphone
-        self.weights = {t: float(w) for t, w in weights.items()}
-        self.optimizer, self.sync = optimizer, sync
+                 sync: Optional[GradSync] = None, fused_backbone: bool = True, parallel_heads: bool = True):
+        self._init_base(model, tasks, weights, optimizer, fused_backbone, sync, parallel_heads)
+        self.graphone = graphone
         self.backprop, self.train_mode = backprop_temporal_graph, temporal_graph_train_mode
-        self.enabled = [t for t in ("ar", "oscc", "lta", "pnr") if self.weights.get(t, 0) > 0]  # egopack order
 
     def task_loss(self, primary: str, feat, data):
         task = self.tasks[primary]
-        others = [t for t in ("ar", "lta", "oscc", "pnr") if t != primary and t in self.graphone.task_labels]
-        # reference orders: ar:[lta,oscc,pnr] oscc:[ar,lta,pnr] lta:[ar,oscc,pnr] pnr:[ar,oscc,lta]
-        order = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
-                 "pnr": ("ar", "oscc", "lta")}[primary]
-        others = [t for t in order if t in others]
+        others = [t for t in self.AUX_ORDER[primary] if t in self.graphone.task_labels]
         f_primary = task.forward_features(feat)
         with torch.no_grad():
             aux_in = {t: self.tasks[t].forward_features(feat) for t in others}
@@ -206,30 +223,16 @@ class EgoPackStep:
             logits = task.forward_logits(features=f_primary, batch=getattr(data, "batch", None), aux_features=aux)
         return task.compute_loss(logits, data.y), logits, aux, closest
 
-    def losses(self, batches: Mapping[str, Data]):
+    def losses(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
         self.model.train(self.train_mode)
         for t in self.tasks.values():
             t.train(True)
         self.graphone.train()
-        vectors = {}
         with torch.set_grad_enabled(self.backprop):
-            feats = {t: self.model(batches[t]) for t in self.enabled if batches.get(t) is not None}
-        for t, feat in feats.items():
-            vectors[t], _, _, _ = self.task_loss(t, feat, batches[t])
-        order = [t for t in self.enabled if t in vectors]
-        total = ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
-        return total, vectors
+            feats = self.features(batches, merged)
 
-    def step(self, batches: Mapping[str, Data]):
-        self.optimizer.zero_grad()
-        total, vectors = self.losses(batches)
-        total.backward()
-        opt = self.optimizer
-        if hasattr(opt, "materialised") and not opt.materialised:
-            opt._materialise()
-        grads = None
-        if self.sync is not None and self.sync.world > 1:
-            grads = self.sync.all_reduce_(opt.flat_g)
-            opt.grad_scale = 1.0 / self.sync.world
-        opt.step(grads=grads)
-        return total.detach(), {t: v.detach() for t, v in vectors.items()}
+        def head(t, feat):
+            loss, logits, _, _ = self.task_loss(t, feat, batches[t])
+            return loss, logits
+        vectors, logits_out = self._run_heads(feats, head)
+        return self._objective(vectors), vectors, logits_out
