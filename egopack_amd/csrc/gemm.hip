@@ -392,34 +392,52 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+// Per-wave cursor over the 4 pieces (1 KiB each) a wave fetches of one operand image per K tile.  The per-lane
+// source addresses are computed ONCE; a K-tile step is a uniform pointer increment (the address arithmetic of 8
+// DMA instructions per tile would otherwise cost as many VALU cycles as the tile's MFMAs at one wave per SIMD).
 template <bool TR>
-__device__ __forceinline__ void pipe_issue_operand(const bf16_t* __restrict__ base, long long ld, int rows_total, int row0,
-                                                   int k0, unsigned char* img, int w, int lane) {
+struct OperandCursor {
+    const bf16_t* p[4];
+    long long step;  // elements per cursor advance
+    __device__ __forceinline__ void init(const bf16_t* __restrict__ base, long long ld, int rows_total, int row0, int k0,
+                                         int w, int lane, int tiles_per_step) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = w * 4 + i;  // 16 pieces of 1 KiB per image, 4 per wave
-        const bf16_t* gp;
-        if constexpr (TR) {  // piece = 4 k-rows of 256 B; lane -> (k = 4*piece + lane/16, slot = lane%16)
-            const int k = piece * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
-            // a chunk is fetched whenever it lies inside the ALLOCATED row (ld): with a padded row stride the last
-            // valid rows (e.g. 112..114 of 115) sit in a chunk that extends into the padding.  Chunks beyond the
-            // row are redirected to chunk 0: they only feed output rows that are never stored.
-            int col = row0 + c * 8;
-            if (col + 8 > ld) col = row0;
-            gp = base + (long long)(k0 + k) * ld + col;
-        } else {  // piece = 8 rows of 128 B; lane -> (row = 8*piece + lane/8, slot = lane%8)
-            const int r = piece * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            gp = base + (long long)min(row0 + r, rows_total - 1) * ld + k0 + c * 8;
+        for (int i = 0; i < 4; ++i) {
+            const int piece = w * 4 + i;  // 16 pieces of 1 KiB per image, 4 per wave
+            if constexpr (TR) {  // piece = 4 k-rows of 256 B; lane -> (k = 4*piece + lane/16, slot = lane%16)
+                const int k = piece * 4 + (lane >> 4);
+                const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
+                // a chunk is fetched whenever it lies inside the ALLOCATED row (ld): with a padded row stride the last
+                // valid rows (e.g. 112..114 of 115) sit in a chunk that extends into the padding.  Chunks beyond the
+                // row are redirected to chunk 0: they only feed output rows that are never stored.
+                int col = row0 + c * 8;
+                if (col + 8 > ld) col = row0;
+                p[i] = base + (long long)(k0 + k) * ld + col;
+            } else {  // piece = 8 rows of 128 B; lane -> (row = 8*piece + lane/8, slot = lane%8)
+                const int r = piece * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                p[i] = base + (long long)min(row0 + r, rows_total - 1) * ld + k0 + c * 8;
+            }
         }
-        __builtin_amdgcn_global_load_lds((glb_void_t*)gp, (lds_void_t*)(img + piece * 1024), 16, 0, 0);
+        step = (TR ? 64 * ld : 64) * tiles_per_step;
     }
-}
+    __device__ __forceinline__ void issue(unsigned char* img, int w) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(img + (w * 4 + i) * 1024), 16, 0, 0);
+            p[i] += step;
+        }
+    }
+};
 
-// 128 x 128 output tile, 4 waves as 2 x 2, NSTAGE-deep ring of (A image | B image) = 32 KiB per stage.
-template <int NSTAGE, bool TRA, bool TRB>
-__global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
+// 128 x 128 output tile, NSTAGE-deep ring of (A image | B image) = 32 KiB per stage.
+// KG = 1: 4 waves as 2 x 2 (two such workgroups share a CU and hide each other's latencies).
+// KG = 2: 8 waves = two wave groups, each 2 x 2 over the SAME output tile with its own ring, walking alternate K
+//         tiles; the partial accumulators meet through LDS at the end (each group finishes half of the rows).  For
+//         launches that cannot put two workgroups on a CU: the K walk per wave halves and the two groups overlap
+//         each other's DMA / LDS / MFMA phases, with no slab traffic and no second launch.
+template <int NSTAGE, bool TRA, bool TRB, int KG>
+__global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs g) {
     constexpr int IMG = 16384, STAGE = 2 * IMG;
     constexpr int LOADS = 8;  // wave-instructions per wave per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -439,16 +457,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KG == 1 ? 0 : (wall >> 2);  // wave group (K-tile parity)
+    const int w = wall & 3;
     const int wm = w >> 1, wn = w & 1;
     const int lr = lane & 15, lg = lane >> 4;
+    unsigned char* ring = lds + grp * (NSTAGE * STAGE);
 
-    auto issue = [&](int t, int stage) {
+    // this group's tiles: t_begin + grp + KG * i, i = 0 .. nt-1; every group runs ``rounds`` barrier rounds
+    const int nt_all = t_end - t_begin;
+    const int nt = nt_all > grp ? (nt_all - grp + KG - 1) / KG : 0;
+    const int rounds = (nt_all + KG - 1) / KG;
+
+    OperandCursor<TRA> ca;
+    OperandCursor<TRB> cb;
+    int cur_src = -1;
+    auto issue = [&](int i, int stage) {  // i-th tile of this group
+        const int t = t_begin + grp + KG * i;
         const int src = t < nkt0 ? 0 : 1;
-        const int k0 = (src == 0 ? t : t - nkt0) * KT;
-        unsigned char* sbase = lds + stage * STAGE;
-        pipe_issue_operand<TRA>((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, sbase, w, lane);
-        pipe_issue_operand<TRB>((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, sbase + IMG, w, lane);
+        if (src != cur_src) {  // (uniform) first tile, or the walk crossed from the first K source into the second
+            const int k0 = (src == 0 ? t : t - nkt0) * KT;
+            ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, w, lane, KG);
+            cb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, w, lane, KG);
+            cur_src = src;
+        }
+        unsigned char* sbase = ring + stage * STAGE;
+        ca.issue(sbase, w);
+        cb.issue(sbase + IMG, w);
     };
 
     f32x4 acc[4][4];
@@ -458,7 +493,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- per-lane LDS byte offsets of the fragment reads (relative to the image base) -------------------------------
-    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)ring;
     // row-major image: (row, chunk) -> row*128 + ((chunk ^ ((row>>1)&7)) << 4); k-step toggles bit 6, fragment i adds i*2048
     const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
     const unsigned a_rm = (unsigned)((wm * 64 + lr) * ROWB) + rm_sw;
@@ -481,21 +516,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
     // and a group of 4 k-rows; 8 f32 partial sums per thread across all K-tiles, combined through LDS at the end.
     const bool do_bias = TRA && g.dbias != nullptr && tn == 0;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int bcc = tid & 15, bkg = tid >> 4;
+    const int bcc = tid & 15, bkg = (tid & 255) >> 4;
 
-    const int nt = t_end - t_begin;
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
-        if (p < nt) issue(t_begin + p, p);
-    for (int it = 0; it < nt; ++it) {
+        if (p < nt) issue(p, p);
+    for (int it = 0; it < rounds; ++it) {
         // tile ``it`` has landed once this wave has at most the pieces of the LATER tiles already issued
         // (min(NSTAGE-2, nt-1-it) tiles x LOADS pieces) outstanding
         const int later = min(NSTAGE - 2, nt - 1 - it);
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+        if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory");
+        else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's pieces of tile ``it`` landed; the stage read at it-1 is free
-        if (it + NSTAGE - 1 < nt) issue(t_begin + it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
+        if (it + NSTAGE - 1 < nt) issue(it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
+        if (KG > 1 && it >= nt) continue;  // (wave-group uniform) odd tile count: the last round is group 0's only
 
         // Fragment reads as inline asm: hipcc cannot prove that a plain ds_read does not alias the LDS-DMA writes
         // in flight and would put s_waitcnt vmcnt(0) in front of it, draining the prefetched tiles.
@@ -601,22 +637,57 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const GemmArgs g) {
     }
     if constexpr (TRA) {
         if (g.dbias != nullptr && tn == 0) {  // block-uniform
-            __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [16][128]
+            __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [16 * KG][128]
             float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[bkg * 128 + bcc * 8 + e] = bsum[e];
+            for (int e = 0; e < 8; ++e) red[(grp * 16 + bkg) * 128 + bcc * 8 + e] = bsum[e];
             __syncthreads();
             if (tid < 128 && m0 + tid < g.M) {
                 float t = 0.f;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) t += red[q * 128 + tid];
+                for (int q = 0; q < 16 * KG; ++q) t += red[q * 128 + tid];
                 if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
                 else g.dbias[m0 + tid] += t;
             }
             __syncthreads();
         }
     }
-    gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
+    if constexpr (KG == 1) {
+        gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
+    } else {
+        // Exchange: group 0 finishes rows i = 0,1 of each wave tile, group 1 rows i = 2,3.  Each group parks the half
+        // it does not finish in LDS ([group][wave][i2][j][lane] f32x4, lane-contiguous 16-B stores), then adds the
+        // other group's half to its own (a + b in either order: the same bits in both groups).
+        __syncthreads();  // all rings are dead
+        f32x4* xch = reinterpret_cast<f32x4*>(lds);
+        f32x4* mine_out = xch + ((grp * 4 + w) * 8) * 64 + lane;
+        const f32x4* theirs = xch + (((1 - grp) * 4 + w) * 8) * 64 + lane;
+        f32x4 half[2][4];
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine_out[(i * 4 + j) * 64] = acc[2 + i][j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine_out[(i * 4 + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) half[i][j] = acc[i][j] + theirs[(i * 4 + j) * 64];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) half[i][j] = theirs[(i * 4 + j) * 64] + acc[2 + i][j];
+        }
+        gemm_epilogue<2, 4>(g, half, m0, n0, wm * 64 + grp * 32, wn * 64, lr, lg, z);
+    }
 }
 
 // Sum the split-K slabs in slab order (bitwise reproducible) and apply the epilogue.
@@ -662,37 +733,47 @@ using namespace egk;
 
 static int g_use_pipe = 1;
 static bool g_lds_attr_set = false;
-template <int NS, bool TA, bool TB>
+template <int NS, bool TA, bool TB, int KG>
 static void set_lds_attr() {
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<NS, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 32768);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<NS, TA, TB, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NS * KG * 32768);
 }
 static void ensure_lds_attr() {
     if (g_lds_attr_set) return;
-    set_lds_attr<2, false, false>(); set_lds_attr<2, false, true>(); set_lds_attr<2, true, true>(); set_lds_attr<2, true, false>();
-    set_lds_attr<3, false, false>(); set_lds_attr<3, false, true>(); set_lds_attr<3, true, true>(); set_lds_attr<3, true, false>();
+    set_lds_attr<2, false, false, 1>(); set_lds_attr<2, false, true, 1>(); set_lds_attr<2, true, true, 1>(); set_lds_attr<2, true, false, 1>();
+    set_lds_attr<3, false, false, 1>(); set_lds_attr<3, false, true, 1>(); set_lds_attr<3, true, true, 1>(); set_lds_attr<3, true, false, 1>();
+    set_lds_attr<4, false, false, 1>(); set_lds_attr<4, false, true, 1>(); set_lds_attr<4, true, true, 1>(); set_lds_attr<4, true, false, 1>();
+    set_lds_attr<2, false, false, 2>(); set_lds_attr<2, false, true, 2>(); set_lds_attr<2, true, true, 2>(); set_lds_attr<2, true, false, 2>();
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
-    g_use_pipe = on;  // 0 generic kernel only, 1 pipelined 2-stage ring (default), 2 pipelined 3-stage ring
+    // 0 generic kernel only; 1 default (2-stage ring; two wave groups per workgroup for launches of at most one
+    // workgroup per CU); 2 always 3-stage; 3 always 2-stage; 4 always 4-stage; 5 always two wave groups
+    g_use_pipe = on;
     return prev;
 }
 
-// Split-K policy (host side, deterministic): slabs when the tile grid alone would leave most of
-// the 256 CUs idle and K is deep (the dW contractions: 64 tiles, K = nodes in the batch).
+// Split-K policy (host side, deterministic).  A launch of at most 128 tiles leaves half of the 256 CUs idle and
+// walks K serially; slabs shorten the walk at the price of a second launch that sums them.  Cost model in
+// microseconds, fitted on MI355X to tools/gemm_bench.py (device time inside a hipGraph):
+//   walk(s)   = 6.5 + 0.45 * ceil(K tiles / s)                  launch + prologue + epilogue, then per 64-deep K tile
+//   reduce(s) = 3.5 + 1.5 * s * (M * N / 2^20)                  slabs written and read back at ~5.5 TB/s
+// s = the power of two <= 16 with tiles * s <= 256 and at least 2 K tiles per slab that minimises walk + reduce.
 extern "C" int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute) {
-    // Slabs pay off only when the tile grid leaves most CUs idle AND K is deep enough that the second launch
-    // (reads splitk slabs, ~7 us for a 1024 x 1024 output) is cheaper than the serial K walk it removes:
-    // measured on MI355X, K = 6144 (96 tiles of 64) gains with 4 slabs, K = 2048 (32 tiles) loses.
     const int KT = compute == EGK_COMPUTE_BF16 ? 64 : 32;
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     const int nkt = cdiv(K, KT);
-    if (tiles >= 128 || nkt < 64) return 1;
-    int s = 256 / tiles;
-    if (s > nkt / 16) s = nkt / 16;
-    if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
+    if (tiles > 128 || nkt < 4) return 1;
+    const double mn = (double)M * N / 1048576.0;
+    int best = 1;
+    double best_cost = 6.5 + 0.45 * nkt;
+    for (int s = 2; s <= 16 && tiles * s <= 256 && nkt / s >= 2; s *= 2) {
+        const double cost = 6.5 + 0.45 * cdiv(nkt, s) + 3.5 + 1.5 * s * mn;
+        if (cost < best_cost - 0.5) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 extern "C" int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d) {
@@ -781,11 +862,20 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     if (pipe_ok) {
         ensure_lds_attr();
         dim3 pgrid(g.tiles_m * g.tiles_n, g.splitk), pblock(NTHREADS);
-        const int three = g_use_pipe == 2;  // development knob: 3-stage ring (96 KiB, one workgroup per CU)
-#define EGK_PIPE(TA, TB)                                                                                         \
-    do {                                                                                                         \
-        if (three) hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB>), pgrid, pblock, 3 * 32768, s, g);            \
-        else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB>), pgrid, pblock, 2 * 32768, s, g);                  \
+        // Two 64 KiB workgroups share a CU and hide each other's latencies when the launch has more than 256
+        // workgroups; a smaller launch leaves one workgroup (one wave per SIMD) per CU and its K walk runs at a
+        // fifth of the MFMA rate (DMA issue, LDS reads and MFMAs of the lone wave serialise): such launches get the
+        // two-wave-group kernel instead (measured: a 4-deep ring alone does not help, the walk is not latency bound).
+        const int nwg_total = g.tiles_m * g.tiles_n * g.splitk;
+        const int nkt_slab = cdiv((d->K1 + d->K2) / 64, g.splitk);
+        const int variant = g_use_pipe == 1 ? ((nwg_total <= 256 && nkt_slab >= 4) ? 5 : 3) : g_use_pipe;
+#define EGK_PIPE(TA, TB)                                                                                              \
+    do {                                                                                                              \
+        if (variant == 5)                                                                                             \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 2>), pgrid, dim3(2 * NTHREADS), 4 * 32768, s, g);         \
+        else if (variant == 4) hipLaunchKernelGGL((gemm_pipe_kernel<4, TA, TB, 1>), pgrid, pblock, 4 * 32768, s, g);  \
+        else if (variant == 2) hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1>), pgrid, pblock, 3 * 32768, s, g);  \
+        else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1>), pgrid, pblock, 2 * 32768, s, g);                    \
     } while (0)
         if (!d->transA && !d->transB) EGK_PIPE(false, false);
         else if (!d->transA && d->transB) EGK_PIPE(false, true);

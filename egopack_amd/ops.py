@@ -201,7 +201,7 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
          transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-         allow_splitk=True, dbias=None):
+         allow_splitk=True, dbias=None, splitk=None):
     lib = _lib.load()
     op_dt = _dt(A1)
     if _dt(B1) != op_dt or (A2 is not None and (_dt(A2) != op_dt or _dt(B2) != op_dt)):
@@ -220,7 +220,7 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ld
     d.bias, d.residual, d.ldr = _p(bias), _p(residual), ldr
     d.r_dtype = _dt(residual) if residual is not None else F32
     sk = lib.egk_gemm_splitk(M, N, K1 + K2, compute) if allow_splitk else 1
-    d.splitk = sk
+    d.splitk = sk if splitk is None else int(splitk)
     d.dbias = _p(dbias)
     need = lib.egk_gemm_ws_bytes(C.byref(d))
     if need:

@@ -619,7 +619,9 @@ def test_gather_segmax_dropout_relu_bf16_activations(ops):
                                        (472, 1024, 1024, 0), (1024, 480, 512, 0)])
 def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, transB, M, N, K1, K2):
     """dX / dW forms of the LDS-DMA kernel (k-major LDS images read with ds_read_b64_tr_b16) against the generic
-    register-transposing kernel: bit-identical, incl. two-source K, split-K and f32 accumulation into C."""
+    register-transposing kernel: bit-identical for every ring depth, incl. two-source K, split-K and f32 accumulation
+    into C.  The two-wave-group variant (5; what the default policy 1 picks for small launches) sums even and odd K
+    tiles separately: equal to rounding, and bitwise reproducible."""
     from egopack_amd import _lib
     lib = _lib.load()
     g = torch.Generator(device=DEV).manual_seed(M + 3 * N + K1)
@@ -630,8 +632,8 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
     A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
     C0 = torch.randn(M, N, device=DEV, generator=g)
     outs = {}
-    for pipe in (1, 2, 0):
-        prev = lib.egk_gemm_set_pipeline(pipe)
+    for pipe in (3, 2, 4, 0, 5, 1, 55):
+        prev = lib.egk_gemm_set_pipeline(5 if pipe == 55 else pipe)
         try:
             out = C0.clone()
             ops.gemm(M, N, A1, A1.shape[1], B1, B1.shape[1], K1, out, N, A2=A2, lda2=A2.shape[1] if K2 else 0, B2=B2,
@@ -639,7 +641,10 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
             outs[pipe] = out
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+    assert torch.equal(outs[3], outs[0]) and torch.equal(outs[2], outs[0]) and torch.equal(outs[4], outs[0])
+    assert torch.equal(outs[5], outs[55])
+    assert torch.equal(outs[1], outs[5]) or torch.equal(outs[1], outs[3])
+    torch.testing.assert_close(outs[5], outs[0], rtol=1e-5, atol=2e-3)
     opA = lambda t, tr: (t.t() if tr else t).double()
     ref = opA(A1, transA) @ opA(B1, transB).t() + (opA(A2, transA) @ opA(B2, transB).t() if K2 else 0) + C0.double()
     torch.testing.assert_close(outs[1], ref.float(), rtol=2e-3, atol=5e-3)
@@ -661,7 +666,7 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     bias = torch.randn(N, device=DEV, generator=g)
     res = torch.randn(M, N, device=DEV, generator=g).to(BF)
     outs = {}
-    for pipe in (1, 0):
+    for pipe in (3, 0, 5, 1):
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             for dt in (BF, torch.float32):
@@ -672,11 +677,16 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
         finally:
             lib.egk_gemm_set_pipeline(prev)
     for dt in (BF, torch.float32):
-        assert torch.equal(outs[(1, dt)], outs[(0, dt)])
+        assert torch.equal(outs[(3, dt)], outs[(0, dt)])
+        assert torch.equal(outs[(1, dt)], outs[(5, dt)]) or torch.equal(outs[(1, dt)], outs[(3, dt)])
+    # two wave groups: even / odd K tiles summed separately
+    torch.testing.assert_close(outs[(5, torch.float32)], outs[(0, torch.float32)], rtol=1e-5, atol=2e-3)
+    torch.testing.assert_close(outs[(5, BF)].float(), outs[(0, BF)].float(), rtol=1e-2, atol=1e-2)
     if M * N <= 1 << 21:
         ref = A1.double() @ B1.double().t() + (A2.double() @ B2.double().t() if K2 else 0) + bias.double()
         ref = torch.relu(ref).float() + res.float()
         torch.testing.assert_close(outs[(1, torch.float32)], ref, rtol=1e-3, atol=2e-3)
+        torch.testing.assert_close(outs[(5, torch.float32)], ref, rtol=1e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 1024, 2048), (472, 1024, 1024), (128, 256, 4096), (1024, 4608, 6144), (115, 1024, 2048)])
@@ -693,7 +703,7 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
     ref_w = (dY.double().t() @ X.double() + W0.double()).float()
     ref_b = (dY.double().sum(0) + b0.double()).float()
     res = {}
-    for pipe in (1, 0):
+    for pipe in (3, 0, 5, 1):
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             w, b = W0.clone(), b0.clone()
@@ -701,7 +711,7 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
             res[pipe] = (w, b)
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    assert torch.equal(res[1][0], res[0][0])
-    for pipe in (1, 0):
+    assert torch.equal(res[3][0], res[0][0])
+    for pipe in (3, 0, 5, 1):
         torch.testing.assert_close(res[pipe][0], ref_w, rtol=2e-3, atol=2e-2)
         torch.testing.assert_close(res[pipe][1], ref_b, rtol=1e-3, atol=2e-2)

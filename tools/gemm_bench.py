@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variants", default="1", help="comma list of egk_gemm_set_pipeline values (0 generic, 1 auto, 2/3/4)")
+ap.add_argument("--splitk", default="", help="comma list of forced split-K factors (applied to the dW shapes)")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
@@ -32,13 +33,44 @@ SHAPES = [
     ("dW TRN1 (per task)", H, 4608, 2048, True, True, True),
     ("dW head", H, H, 2048, True, True, True),
     ("dW cls 478", 478, H, 2048, True, True, True),
+    ("fwd cls 115", 2048, 115, H, False, False, True),
+    ("dX cls 115 (K pad 128)", 2048, H, 128, False, True, False),
+    ("dX cls 478 (K pad 512)", 2048, H, 512, False, True, False),
+    ("dW cls 115", 115, H, 2048, True, True, True),
+    ("dW cls 2", 2, H, 2048, True, True, True),
 ]
+def time_us(fn, iters):
+    """Device time per launch: ``iters`` launches captured in one hipGraph (no host launch cost in the number)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(iters):
+            fn()
+    gr.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    gr.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
 variants = [int(v) for v in args.variants.split(",")]
 from egopack_amd import _lib
 print(f"{'shape':28s} {'M':>5s} {'N':>5s} {'K':>5s} splitk " + " ".join(f"{'v' + str(v) + ' us':>9s} {'TF/s':>6s}" for v in variants))
 for name, M, N, K, tA, tB, f32out in SHAPES:
-    A = torch.randn((K, M) if tA else (M, K), device=dev).to(dt)
-    B = torch.randn((K, N) if tB else (N, K), device=dev).to(dt)
+    pad8 = lambda n: (n + 7) // 8 * 8  # rows padded to 16 bytes, as ops._operand_rows builds them
+    A = torch.randn((K, pad8(M)) if tA else (M, pad8(K)), device=dev).to(dt)
+    B = torch.randn((K, pad8(N)) if tB else (N, pad8(K)), device=dev).to(dt)
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if (f32out or dt == torch.float32) else dt)
     acc = tA and tB
     sk = _lib.load().egk_gemm_splitk(M, N, K, ops.BF16)
@@ -48,16 +80,14 @@ for name, M, N, K, tA, tB, f32out in SHAPES:
     cells = []
     for v in variants:
         _lib.load().egk_gemm_set_pipeline(v)
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        us = time_us(run, args.iters)
         cells.append(f"{us:9.1f} {2.0 * M * N * K / us / 1e6:6.0f}")
     _lib.load().egk_gemm_set_pipeline(1)
     print(f"{name:28s} {M:5d} {N:5d} {K:5d} {sk:6d} " + " ".join(cells))
+    if args.splitk:
+        row = []
+        for fk in [int(v) for v in args.splitk.split(",")]:
+            def run_sk():
+                ops.gemm(M, N, A, A.shape[1], B, B.shape[1], K, out, N, transA=tA, transB=tB, accumulate=acc, compute=ops.BF16, splitk=fk)
+            row.append(f"sk{fk}: {time_us(run_sk, args.iters):.1f}us")
+        print("      forced split-K  " + "  ".join(row))
