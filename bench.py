@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--no-fused-backbone", action="store_true")
     ap.add_argument("--serial-heads", action="store_true", help="run the task heads on the main stream")
+    ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -274,12 +275,18 @@ def main():
         opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)
         step = engine.EgoPackStep(model, tasks, graphone, weights, opt, backprop_temporal_graph=True,
                                   temporal_graph_train_mode=False, sync=sync)
+        if args.no_wgrad_streams:
+            step.wgrad_side_streams = False
+
         def eager_step():
             step.step(dev, fused_merged)
     else:
         opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
         step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync,
                               parallel_heads=not args.serial_heads)
+
+        if args.no_wgrad_streams:
+            step.wgrad_side_streams = False
 
         def eager_step():
             step.step(dev, fused_merged)

@@ -48,9 +48,30 @@ struct GemmArgs {
     int splitk;
     float* ws;  // [splitk][M][N] partial slabs when splitk > 1
     int tiles_m, tiles_n;
+    int group_m;      // pipelined kernel: tile rows per group of the XCD-local tile order (see tile_of)
     float* dbias;     // fused bias gradient: dbias[m] += sum_k op(A)[m, k]  (transA pipelined kernel only)
     float* ws_bias;   // [splitk][M] partial row sums when splitk > 1
 };
+
+// Workgroup -> (slab z, tile row, tile column) for a 1-D launch of tiles_m * tiles_n * splitk workgroups.
+// The hardware deals consecutive workgroup ids round-robin over the 8 XCDs; each XCD has its own L2.  XCD x is
+// given a CONSECUTIVE run of the (z-major) virtual ids, and virtual ids walk the tile grid in groups of group_m tile
+// rows, column by column inside a group: the run of one XCD is a near-square patch of ONE slab, so the operand
+// strips its workgroups fetch (one A strip per tile row, one B strip per tile column) overlap as much as they can
+// in that XCD's L2.  (Row-by-row order gives an XCD 1 x 36 tiles of the 8 x 36 dW grid: 37 strips instead of 12.)
+__device__ __forceinline__ void tile_of(const GemmArgs& g, int bid, int& z, int& tm, int& tn) {
+    const int tiles = g.tiles_m * g.tiles_n, nwg = tiles * g.splitk;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    z = v / tiles;
+    const int t = v - z * tiles;
+    const int gsz = g.group_m * g.tiles_n;
+    const int grp = t / gsz, first = grp * g.group_m;
+    const int rows = min(g.group_m, g.tiles_m - first);
+    const int rr = t - grp * gsz;
+    tm = first + rr % rows;
+    tn = rr / rows;
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -443,16 +464,10 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KT = 64;
 
-    const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    int z, tm, tn;
+    tile_of(g, blockIdx.x, z, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
-    const int z = blockIdx.y;
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
 
@@ -732,6 +747,7 @@ static void launch_layout(const egk_gemm_desc* d, dim3 grid, hipStream_t s, cons
 using namespace egk;
 
 static int g_use_pipe = 1;
+static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static bool g_lds_attr_set = false;
 template <int NS, bool TA, bool TB, int KG>
 static void set_lds_attr() {
@@ -749,6 +765,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 100) { g_group_m_override = on - 100; return prev; }
     // 0 generic kernel only; 1 default (2-stage ring; two wave groups per workgroup for launches of at most one
     // workgroup per CU); 2 always 3-stage; 3 always 2-stage; 4 always 4-stage; 5 always two wave groups
     g_use_pipe = on;
@@ -831,6 +848,15 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         EGK_REQUIRE(g.ws && d->ws_bytes >= (int64_t)g.splitk * d->M * d->N * 4, "egk_gemm: split-K workspace too small");
     g.tiles_m = cdiv(g.M, BM); g.tiles_n = cdiv(g.N, BN);
     g.dbias = nullptr; g.ws_bias = nullptr;
+    {  // near-square XCD patches: group_m ~ sqrt(workgroups per XCD), inside one slab
+        const int tiles = g.tiles_m * g.tiles_n;
+        int per_xcd = cdiv(tiles * g.splitk, 8);
+        if (per_xcd > tiles) per_xcd = tiles;
+        int gm = 1;
+        while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
+        g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
+        if (g_group_m_override > 0) g.group_m = g_group_m_override < g.tiles_m ? g_group_m_override : g.tiles_m;
+    }
 
     const int K = d->K1 + d->K2;
     const double flops = 2.0 * d->M * d->N * K;
@@ -861,7 +887,7 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     }
     if (pipe_ok) {
         ensure_lds_attr();
-        dim3 pgrid(g.tiles_m * g.tiles_n, g.splitk), pblock(NTHREADS);
+        dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk), pblock(NTHREADS);
         // Two 64 KiB workgroups share a CU and hide each other's latencies when the launch has more than 256
         // workgroups; a smaller launch leaves one workgroup (one wave per SIMD) per CU and its K walk runs at a
         // fifth of the MFMA rate (DMA issue, LDS reads and MFMAs of the lone wave serialise): such launches get the

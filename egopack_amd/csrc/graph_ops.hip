@@ -365,10 +365,12 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D*
 // aligned operand copy of a [rows, cols] gradient whose width is not a multiple of 8)
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_rows_kernel(const S* __restrict__ src, long long lds_, D* __restrict__ dst,
-                                                        long long ldd, int rows, int cols) {
+                                                        long long ldd, int rows, int cols, int zero_cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB)
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         for (int c = lane; c < cols; c += 64) st1t(dst + (long long)row * ldd + c, ld1t(src + (long long)row * lds_ + c));
+        for (int c = cols + lane; c < zero_cols; c += 64) st1t(dst + (long long)row * ldd + c, 0.f);
+    }
 }
 
 static inline int row_grid(int rows) {
@@ -403,13 +405,14 @@ int egk_cast(egk_stream_t stream, const void* src, int32_t src_dtype, void* dst,
 }
 
 int egk_cast_rows(egk_stream_t stream, const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,
-                  int64_t ld_dst, int32_t rows, int32_t cols) {
+                  int64_t ld_dst, int32_t rows, int32_t cols, int32_t zero_cols) {
     EGK_REQUIRE(src && dst, "egk_cast_rows: null pointer");
+    EGK_REQUIRE(zero_cols <= ld_dst, "egk_cast_rows: zero_cols beyond the destination row");
     if (rows == 0 || cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CAST, s, 0, 6.0 * rows * cols);
     const dim3 grid(row_grid(rows)), block(256);
-#define EGK_CR(S, D) hipLaunchKernelGGL((cast_rows_kernel<S, D>), grid, block, 0, s, (const S*)src, (long long)ld_src, (D*)dst, (long long)ld_dst, rows, cols)
+#define EGK_CR(S, D) hipLaunchKernelGGL((cast_rows_kernel<S, D>), grid, block, 0, s, (const S*)src, (long long)ld_src, (D*)dst, (long long)ld_dst, rows, cols, zero_cols)
     if (src_dtype == EGK_F32 && dst_dtype == EGK_BF16) EGK_CR(float, bf16_t);
     else if (src_dtype == EGK_BF16 && dst_dtype == EGK_F32) EGK_CR(bf16_t, float);
     else if (src_dtype == EGK_F32 && dst_dtype == EGK_F32) EGK_CR(float, float);

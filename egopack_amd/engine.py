@@ -66,6 +66,8 @@ class StepBase:
         self._static_out = None
         self._static_in = None
         self._fuse_adam = True
+        # weight-gradient launches of the backbone on a side stream: pays off beside parallel task heads only
+        self.wgrad_side_streams = parallel_heads and len(self.enabled) > 1
 
     # ---- backbone ------------------------------------------------------------------------------------
     def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:
@@ -89,6 +91,7 @@ class StepBase:
             fork.record(main)
             while len(self._head_streams) < len(feats):
                 self._head_streams.append(torch.cuda.Stream())
+                ops.exclude_wgrad_streams(self._head_streams[-1:])
             for st, (t, feat) in zip(self._head_streams, feats.items()):
                 st.wait_event(fork)
                 feat.record_stream(st)
@@ -108,8 +111,13 @@ class StepBase:
     # ---- eager step -------------------------------------------------------------------------------------
     def forward_backward(self, batches, merged=None):
         self.optimizer.zero_grad()
-        total, vectors, _ = self.losses(batches, merged)
-        total.backward()
+        prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        try:
+            total, vectors, _ = self.losses(batches, merged)
+            total.backward()
+            ops.join_wgrad()
+        finally:
+            ops.set_wgrad_side_streams(prev)
         return total, vectors
 
     def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
@@ -145,12 +153,17 @@ class StepBase:
         fuse_adam = self.sync is None or self.sync.world <= 1
         g = torch.cuda.CUDAGraph()
         opt.prepare_hyper()
-        with torch.cuda.graph(g):
-            opt.flat_g.zero_()
-            total, vectors, _ = self.losses(batches, merged)
-            total.backward()
-            if fuse_adam:
-                opt.launch()
+        prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        try:
+            with torch.cuda.graph(g):
+                opt.flat_g.zero_()
+                total, vectors, _ = self.losses(batches, merged)
+                total.backward()
+                ops.join_wgrad()
+                if fuse_adam:
+                    opt.launch()
+        finally:
+            ops.set_wgrad_side_streams(prev)
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)

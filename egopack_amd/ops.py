@@ -248,22 +248,90 @@ def _grad_slot(param: Optional[torch.Tensor]):
     return None
 
 
-def _operand_rows(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+# ---- weight-gradient side streams --------------------------------------------------------------------------------
+# A dW contraction (64 tiles of 128 x 128, walked as <= 256 workgroups) feeds nothing but the optimizer, while the
+# dX chain it would sit in is a strict dependency chain of launches, many of them small.  When the gradient lands in
+# the flat buffer (no tensor goes back to autograd) the launch is put on a side stream that forks from the
+# backward stream at that point; ``join_wgrad()`` (queued as an end-of-backward callback of the autograd engine) joins
+# every side stream with the stream that called backward() before the gradients can be consumed.
+# Off by default: measured on MI355X it gains 3-4 % on the multi-task steps (M = 6144 backbone rows, heads on their
+# own streams) and loses 3-5 % on single-task steps (M = 2048: every launch is already a partial-chip launch);
+# egopack_amd.engine turns it on for steps with more than one enabled task.
+_wgrad = {"enabled": False, "streams": {}, "pending": [], "queued": False, "exclude": set()}
+
+
+def exclude_wgrad_streams(streams) -> None:
+    """Backward work running on these streams keeps its weight-gradient launches (the task-head streams of the
+    engine already overlap each other; forking each of them again oversubscribes the hardware queues)."""
+    for st in streams:
+        _wgrad["exclude"].add((st.device.index, st.cuda_stream))
+
+
+
+def set_wgrad_side_streams(on: bool) -> bool:
+    prev = _wgrad["enabled"]
+    _wgrad["enabled"] = bool(on)
+    return prev
+
+
+def _wgrad_launch(in_place: bool, tensors, launch):
+    """Run ``launch()`` (weight / bias gradient kernels that only write persistent gradient slots) on the side
+    stream of the current stream; ``tensors`` are the temporaries it reads (kept alive for that stream)."""
+    if not (_wgrad["enabled"] and in_place and tensors and tensors[0].is_cuda):
+        launch()
+        return
+    main = torch.cuda.current_stream()
+    key = (main.device.index, main.cuda_stream)
+    if key in _wgrad["exclude"]:
+        launch()
+        return
+    side = _wgrad["streams"].get(key)
+    if side is None:
+        side = _wgrad["streams"][key] = torch.cuda.Stream(device=main.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        launch()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    if side not in _wgrad["pending"]:
+        _wgrad["pending"].append(side)
+    if not _wgrad["queued"]:  # join at the end of THIS backward pass, on the stream of the thread that called it
+        _wgrad["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
+
+
+def join_wgrad():
+    """The current stream waits for every weight-gradient side stream with work in flight (call after backward,
+    before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture)."""
+    cur = torch.cuda.current_stream() if _wgrad["pending"] else None
+    for side in _wgrad["pending"]:
+        cur.wait_stream(side)
+    _wgrad["pending"].clear()
+    _wgrad["queued"] = False
+
+
+def _operand_rows(g: torch.Tensor, dtype: torch.dtype, pad_cols: int = 0) -> torch.Tensor:
     """[rows, cols] gradient as a contraction operand of element type ``dtype`` with a 16-byte aligned row stride.
     (autograd hands the gradient of an f32 output back as contiguous f32 whatever the loss emitted, and a width
-    such as 478 or 115 is not a multiple of 8: one strided conversion instead of an unaligned, scalar-load GEMM)"""
+    such as 478 or 115 is not a multiple of 8: one strided conversion instead of an unaligned, scalar-load GEMM)
+    ``pad_cols`` > cols: the copy gets a row stride of pad_cols with ZEROS in [cols, pad_cols) -- the dX contraction
+    of a classifier layer then runs over a K axis that is a multiple of 64 (``.base_cols`` of the result)."""
     esize = 2 if dtype == torch.bfloat16 else 4
+    rows, cols = g.shape if g.dim() == 2 else (0, 0)
+    want_pad = pad_cols > cols
     ok = g.dim() == 2 and g.stride(1) == 1 and (g.stride(0) * esize) % 16 == 0 and g.data_ptr() % 16 == 0
-    if g.dtype == dtype and ok:
+    if g.dtype == dtype and ok and not want_pad:
         return g
     if g.dim() != 2 or g.stride(1) != 1:
         g = g.contiguous()
     rows, cols = g.shape
     per16 = 16 // esize
-    out = torch.empty((rows, (cols + per16 - 1) // per16 * per16), dtype=dtype, device=g.device)[:, :cols]
-    _ck(_lib.load().egk_cast_rows(_stream(), _p(g), _dt(g), g.stride(0), _p(out), _dt(out), out.stride(0), rows, cols),
-        "egk_cast_rows")
-    return out
+    ld = pad_cols if want_pad else (cols + per16 - 1) // per16 * per16
+    out = torch.empty((rows, ld), dtype=dtype, device=g.device)
+    _ck(_lib.load().egk_cast_rows(_stream(), _p(g), _dt(g), g.stride(0), _p(out), _dt(out), ld, rows, cols,
+                                  ld if want_pad else 0), "egk_cast_rows")
+    return out[:, :cols]
 
 
 def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -297,6 +365,10 @@ class _Linear(torch.autograd.Function):
         ctx.has = (b is not None, x2 is not None, residual is not None)
         ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.params = (W, b, W2)
+        # classifier layers (N = 478, 115, 2 ...): the optimizer's flat layout keeps the bf16 copy of W with its rows
+        # zero-padded to a multiple of 64, so dX = dY @ W can contract over a padded K on the pipelined kernel
+        wpad = getattr(W, "_egk_shadow_rows64", None)
+        ctx.Wpad = wpad if (wpad is not None and wpad.dtype == x.dtype and x2 is None and not relu) else None
         ctx.save_for_backward(x, Wop, x2, W2op, y if relu else None)
         if out_f32:
             y._egk_grad_dtype = x.dtype  # lets the loss emit its gradient in the operand type
@@ -307,7 +379,8 @@ class _Linear(torch.autograd.Function):
         x, W, x2, W2, y = ctx.saved_tensors
         Wp, bp, W2p = ctx.params
         has_b, has_x2, has_res = ctx.has
-        g = _operand_rows(dy, x.dtype)
+        Wpad = ctx.Wpad if ctx.needs_input_grad[0] else None
+        g = _operand_rows(dy, x.dtype, pad_cols=Wpad.shape[0] if Wpad is not None else 0)
         M, N = g.shape
         K1 = x.shape[1]
         lib = _lib.load()
@@ -321,31 +394,37 @@ class _Linear(torch.autograd.Function):
         dx = dW = db = dx2 = dW2 = None
         if needs[0]:
             dx = torch.empty_like(x)
-            gemm(M, K1, g, g.stride(0), W, K1, N, dx, K1, transB=True, compute=ctx.compute)
+            if Wpad is not None and g.stride(0) == Wpad.shape[0]:  # zero columns of g x zero rows of the padded copy
+                gemm(M, K1, g, g.stride(0), Wpad, K1, Wpad.shape[0], dx, K1, transB=True, compute=ctx.compute)
+            else:
+                gemm(M, K1, g, g.stride(0), W, K1, N, dx, K1, transB=True, compute=ctx.compute)
         db_out = None
         if has_b and needs[2]:
             slot_b = _grad_slot(bp)
             db_out = slot_b if slot_b is not None else torch.zeros(N, dtype=torch.float32, device=g.device)
             db = None if slot_b is not None else db_out
+        if has_x2 and needs[3]:
+            K2 = x2.shape[1]
+            dx2 = torch.empty_like(x2)
+            gemm(M, K2, g, g.stride(0), W2, K2, N, dx2, K2, transB=True, compute=ctx.compute)
         if needs[1]:
             slot = _grad_slot(Wp)
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
             # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS)
-            gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True, compute=ctx.compute,
-                 dbias=db_out)
+            _wgrad_launch(slot is not None and (db_out is None or db is None), (g, x),
+                          lambda: gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True,
+                                       compute=ctx.compute, dbias=db_out))
             dW = None if slot is not None else out
         elif db_out is not None:
             _colsum_into(g, db_out, True)
-        if has_x2:
+        if has_x2 and needs[4]:
             K2 = x2.shape[1]
-            if needs[3]:
-                dx2 = torch.empty_like(x2)
-                gemm(M, K2, g, g.stride(0), W2, K2, N, dx2, K2, transB=True, compute=ctx.compute)
-            if needs[4]:
-                slot = _grad_slot(W2p)
-                out = slot if slot is not None else torch.zeros(W2.shape, dtype=torch.float32, device=g.device)
-                gemm(N, K2, g, g.stride(0), x2, K2, M, out, K2, transA=True, transB=True, accumulate=True, compute=ctx.compute)
-                dW2 = None if slot is not None else out
+            slot = _grad_slot(W2p)
+            out2 = slot if slot is not None else torch.zeros(W2.shape, dtype=torch.float32, device=g.device)
+            _wgrad_launch(slot is not None, (g, x2),
+                          lambda: gemm(N, K2, g, g.stride(0), x2, K2, M, out2, K2, transA=True, transB=True,
+                                       accumulate=True, compute=ctx.compute))
+            dW2 = None if slot is not None else out2
         dres = _match(dy, ctx.res_dtype) if (has_res and needs[5]) else None
         return dx, dW, db, dx2, dW2, dres, None, None, None
 
@@ -391,20 +470,6 @@ class _MultiLinear(torch.autograd.Function):
         N, K = Wop.shape
         needs = ctx.needs_input_grad
         dW = db = None
-        if needs[0]:
-            slot = _grad_slot(Wp)
-            out = slot if slot is not None else torch.zeros(Wop.shape, dtype=torch.float32, device=dy.device)
-            off = 0
-            for x, m in zip(xs, ctx.rows):
-                gemm(N, K, dy[off:off + m], N, x, K, m, out, K, transA=True, transB=True, accumulate=True,
-                     compute=ctx.compute)
-                off += m
-            dW = None if slot is not None else out
-        if bp is not None and needs[1]:
-            slot = _grad_slot(bp)
-            out = slot if slot is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
-            _colsum_into(dy, out, True)
-            db = None if slot is not None else out
         dxs = []
         off = 0
         for i, (x, m) in enumerate(zip(xs, ctx.rows)):
@@ -415,6 +480,23 @@ class _MultiLinear(torch.autograd.Function):
             else:
                 dxs.append(None)
             off += m
+        if needs[0]:
+            slot = _grad_slot(Wp)
+            out = slot if slot is not None else torch.zeros(Wop.shape, dtype=torch.float32, device=dy.device)
+
+            def launch_dw():
+                off = 0
+                for x, m in zip(xs, ctx.rows):
+                    gemm(N, K, dy[off:off + m], N, x, K, m, out, K, transA=True, transB=True, accumulate=True,
+                         compute=ctx.compute)
+                    off += m
+            _wgrad_launch(slot is not None, (dy, *xs), launch_dw)
+            dW = None if slot is not None else out
+        if bp is not None and needs[1]:
+            slot = _grad_slot(bp)
+            outb = slot if slot is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+            _wgrad_launch(slot is not None, (dy,), lambda: _colsum_into(dy, outb, True))
+            db = None if slot is not None else outb
         return (dW, db, None, *dxs)
 
 
@@ -611,19 +693,26 @@ class _SageMean(torch.autograd.Function):
         dWr, rWr = slot_or_zeros(Wr, Wr_o.shape)
         dWp, rWp = slot_or_zeros(Wp, Wp_o.shape)
         dbp, rbp = slot_or_zeros(bp, (H,))
-        gemm(Ho, H, g, g.stride(0), agg, H, N, dWl, H, transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=dbl)
-        gemm(Ho, H, g, g.stride(0), h, H, N, dWr, H, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+        in_place = rWl is None and rbl is None and rWr is None
+
+        def launch_out_grads():
+            gemm(Ho, H, g, g.stride(0), agg, H, N, dWl, H, transA=True, transB=True, accumulate=True, compute=ctx.compute,
+                 dbias=dbl)
+            gemm(Ho, H, g, g.stride(0), h, H, N, dWr, H, transA=True, transB=True, accumulate=True, compute=ctx.compute)
+        _wgrad_launch(in_place, (g, agg, h), launch_out_grads)
         d_agg = torch.empty_like(h)
         gemm(N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H, transB=True, compute=ctx.compute)
         d_pre = torch.empty_like(h)  # gradient at the projection's pre-activation: transposed gather gated by xp > 0
         _ck(lib.egk_csr_gather(_stream(), _p(d_agg), _p(t_rowptr), _p(t_col), _p(t_wgt), _p(xp), _p(d_pre), N, H, _dt(h)),
             "egk_csr_gather")
-        gemm(H, H, d_pre, H, h, H, N, dWp, H, transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=dbp)
         d_h = None
         if ctx.needs_input_grad[0]:
             d_h = torch.empty_like(h)
             gemm(N, H, g, g.stride(0), Wr_o, H, Ho, d_h, H, A2=d_pre, lda2=H, B2=Wp_o, ldb2=H, K2=H, transB=True,
                  compute=ctx.compute)
+        _wgrad_launch(rWp is None and rbp is None, (d_pre, h),
+                      lambda: gemm(H, H, d_pre, H, h, H, N, dWp, H, transA=True, transB=True, accumulate=True,
+                                   compute=ctx.compute, dbias=dbp))
         return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None)
 
 

@@ -48,7 +48,15 @@ class FlatAdam(torch.optim.Optimizer):
         dev = live[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam needs parameters on a ROCm device (no CPU fallback)")
-        sizes = [(p.numel() + 7) // 8 * 8 for p in live]  # slots aligned to 16 bytes in the bf16 shadow (32 B in f32)
+        # slots aligned to 16 bytes in the bf16 shadow (32 B in f32).  A matrix whose row count is not a multiple of
+        # 64 (the classifier layers: 478, 115, 2 ... rows) gets its slot padded to whole 64-row blocks: the padding
+        # stays zero under Adam (zero gradient, zero moments, zero weight), and the padded bf16 copy is the K-major
+        # operand of the layer's dX contraction on the pipelined kernel (ops._Linear.backward).
+        def slot(p):
+            if p.dim() == 2 and p.shape[0] % 64:
+                return (p.shape[0] + 63) // 64 * 64 * p.shape[1]
+            return p.numel()
+        sizes = [(slot(p) + 7) // 8 * 8 for p in live]
         total = sum(sizes)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -64,6 +72,9 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 p._egk_shadow = self.flat_w16[off:off + n].view(p.shape)
+                if p.dim() == 2 and p.shape[0] % 64 and p.shape[1] % 8 == 0:
+                    rows64 = (p.shape[0] + 63) // 64 * 64
+                    p._egk_shadow_rows64 = self.flat_w16[off:off + rows64 * p.shape[1]].view(rows64, p.shape[1])
                 off += sz
         self.active = live
         self.refresh_shadows()

@@ -202,9 +202,11 @@ int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const flo
 int egk_cast(egk_stream_t s, const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n);
 /* row-strided variant: dst[r, c] = src[r, c], c < cols, with independent leading dimensions (elements) and
  * element types (equal types allowed: a re-striding copy).  Used to give a [rows, cols] gradient whose width is
- * not a multiple of 8 a 16-byte aligned row stride before it becomes a contraction operand. */
+ * not a multiple of 8 a 16-byte aligned row stride before it becomes a contraction operand; columns
+ * [cols, zero_cols) of every destination row are set to zero (zero_cols <= ld_dst; 0 for none), which makes the
+ * copy a valid contraction operand over a K axis padded to the 64-deep tile of the pipelined kernel. */
 int egk_cast_rows(egk_stream_t s, const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,
-                  int64_t ld_dst, int32_t rows, int32_t cols);
+                  int64_t ld_dst, int32_t rows, int32_t cols, int32_t zero_cols);
 
 /* ---- small elementwise helpers ----------------------------------------------------------- */
 /* y = keep ? x/(1-p) : 0 with a fresh Philox mask (nn.Dropout: task.py:18, graph.py:30, heads) */

@@ -715,3 +715,38 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
     for pipe in (3, 0, 5, 1):
         torch.testing.assert_close(res[pipe][0], ref_w, rtol=2e-3, atol=2e-2)
         torch.testing.assert_close(res[pipe][1], ref_b, rtol=1e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("n_out", [478, 115, 2])
+def test_classifier_dx_on_zero_padded_k_axis(ops, n_out):
+    """A classifier layer (rows of W not a multiple of 64) whose parameters live in FlatAdam's flat buffers: the
+    bf16 copy of W is kept zero-padded to whole 64-row blocks and the loss gradient is converted with zero columns,
+    so dX = dY @ W contracts over a padded K on the pipelined kernel.  dX, dW, db against fp64 on the bf16-rounded
+    operands, before and after an optimizer step (the padding must stay zero under Adam)."""
+    from egopack_amd import _lib
+    from egopack_amd.optim import FlatAdam
+    g = torch.Generator(device=DEV).manual_seed(n_out)
+    M, K = 2048, 1024
+    W = (torch.randn(n_out, K, device=DEV, generator=g) / 32).requires_grad_(True)
+    b = torch.randn(n_out, device=DEV, generator=g).requires_grad_(True)
+    opt = FlatAdam([W, b], lr=1e-3, weight_decay=1e-5)
+    lib = _lib.load()
+    for it in range(3):
+        x = torch.randn(M, K, device=DEV, generator=g).to(BF).requires_grad_(True)
+        wt = torch.randn(M, n_out, device=DEV, generator=g)
+        opt.zero_grad()
+        with ops.compute_mode("bf16"):
+            y = ops.linear(x, W, b, out_f32=True)
+            lib.egk_prof_reset()
+            ops.prof_enable(True)
+            (y * wt).sum().backward()
+            ops.prof_enable(False)
+        if it > 0:  # flat buffers exist: the padded copy is in use and the dX launch is a pipelined NT contraction
+            assert W._egk_shadow_rows64.shape == ((n_out + 63) // 64 * 64, K)
+            assert torch.count_nonzero(W._egk_shadow_rows64[n_out:]) == 0
+        Wr, xr, gr = W.detach().to(BF).double(), x.detach().double(), wt.to(BF).double()
+        torch.testing.assert_close(x.grad.float(), (gr @ Wr).float(), rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(W.grad, (gr.t() @ xr).float(), rtol=2e-3, atol=5e-2)
+        torch.testing.assert_close(b.grad, gr.sum(0).float(), rtol=2e-3, atol=5e-2)
+        torch.testing.assert_close(y, (xr @ Wr.t() + b.detach().double()).float(), rtol=2e-3, atol=2e-2)
+        opt.step()

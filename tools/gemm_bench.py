@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variants", default="1", help="comma list of egk_gemm_set_pipeline values (0 generic, 1 auto, 2/3/4)")
+ap.add_argument("--layouts", action="store_true", help="same dims in the four operand layouts instead of the workload shapes")
 ap.add_argument("--splitk", default="", help="comma list of forced split-K factors (applied to the dW shapes)")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -64,6 +65,11 @@ def time_us(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+if args.layouts:
+    SHAPES = []
+    for (M, N, K) in [(2048, 2048, 2048), (4096, 2048, 2048), (4096, 4096, 4096), (8192, 8192, 8192)]:
+        for nm, tA, tB in [("NN", False, False), ("NT", False, True), ("TT", True, True), ("TN", True, False)]:
+            SHAPES.append((f"{nm} {M}x{N}x{K}", M, N, K, tA, tB, False))
 variants = [int(v) for v in args.variants.split(",")]
 from egopack_amd import _lib
 print(f"{'shape':28s} {'M':>5s} {'N':>5s} {'K':>5s} splitk " + " ".join(f"{'v' + str(v) + ' us':>9s} {'TF/s':>6s}" for v in variants))
@@ -72,7 +78,7 @@ for name, M, N, K, tA, tB, f32out in SHAPES:
     A = torch.randn((K, pad8(M)) if tA else (M, pad8(K)), device=dev).to(dt)
     B = torch.randn((K, pad8(N)) if tB else (N, pad8(K)), device=dev).to(dt)
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if (f32out or dt == torch.float32) else dt)
-    acc = tA and tB
+    acc = tA and tB and not args.layouts
     sk = _lib.load().egk_gemm_splitk(M, N, K, ops.BF16)
 
     def run():
