@@ -416,66 +416,74 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Per-wave cursor over the 4 pieces (1 KiB each) a wave fetches of one operand image per K tile.  The per-lane
 // source addresses are computed ONCE; a K-tile step is a uniform pointer increment (the address arithmetic of 8
 // DMA instructions per tile would otherwise cost as many VALU cycles as the tile's MFMAs at one wave per SIMD).
-template <bool TR>
+template <bool TR, int NP>
 struct OperandCursor {
-    const bf16_t* p[4];
+    const bf16_t* p[NP];
     long long step;  // elements per cursor advance
+    // pieces first .. first + NP - 1 of an operand image made of 16-KiB sub-images of 128 rows (16 pieces each)
     __device__ __forceinline__ void init(const bf16_t* __restrict__ base, long long ld, int rows_total, int row0, int k0,
-                                         int w, int lane, int tiles_per_step) {
+                                         int first, int lane, int tiles_per_step) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = w * 4 + i;  // 16 pieces of 1 KiB per image, 4 per wave
+        for (int i = 0; i < NP; ++i) {
+            const int piece = (first + i) & 15, sub_row0 = row0 + ((first + i) >> 4) * 128;
             if constexpr (TR) {  // piece = 4 k-rows of 256 B; lane -> (k = 4*piece + lane/16, slot = lane%16)
                 const int k = piece * 4 + (lane >> 4);
                 const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
                 // a chunk is fetched whenever it lies inside the ALLOCATED row (ld): with a padded row stride the last
                 // valid rows (e.g. 112..114 of 115) sit in a chunk that extends into the padding.  Chunks beyond the
-                // row are redirected to chunk 0: they only feed output rows that are never stored.
-                int col = row0 + c * 8;
-                if (col + 8 > ld) col = row0;
+                // row are redirected to the row's first chunk: they only feed output rows that are never stored.
+                int col = sub_row0 + c * 8;
+                if (col + 8 > ld) col = 0;
                 p[i] = base + (long long)(k0 + k) * ld + col;
             } else {  // piece = 8 rows of 128 B; lane -> (row = 8*piece + lane/8, slot = lane%8)
                 const int r = piece * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
-                p[i] = base + (long long)min(row0 + r, rows_total - 1) * ld + k0 + c * 8;
+                p[i] = base + (long long)min(sub_row0 + r, rows_total - 1) * ld + k0 + c * 8;
             }
         }
         step = (TR ? 64 * ld : 64) * tiles_per_step;
     }
-    __device__ __forceinline__ void issue(unsigned char* img, int w) {
+    __device__ __forceinline__ void issue(unsigned char* img, int first) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(img + (w * 4 + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < NP; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(img + (first + i) * 1024), 16, 0, 0);
             p[i] += step;
         }
     }
 };
 
-// 128 x 128 output tile, NSTAGE-deep ring of (A image | B image) = 32 KiB per stage.
-// KG = 1: 4 waves as 2 x 2 (two such workgroups share a CU and hide each other's latencies).
-// KG = 2: 8 waves = two wave groups, each 2 x 2 over the SAME output tile with its own ring, walking alternate K
+// (128 * MB) x 128 output tile, NSTAGE-deep ring of (A image | B image) = (16 * MB + 16) KiB per stage; every wave
+// owns a 64 x 64 patch of the tile (4 x 4 MFMA accumulators).
+// MB = 1, KG = 1: 4 waves as 2 x 2; two such workgroups share a CU and hide each other's latencies.
+// MB = 1, KG = 2: 8 waves = two wave groups, each 2 x 2 over the SAME output tile with its own ring, walking alternate K
 //         tiles; the partial accumulators meet through LDS at the end (each group finishes half of the rows).  For
 //         launches that cannot put two workgroups on a CU: the K walk per wave halves and the two groups overlap
 //         each other's DMA / LDS / MFMA phases, with no slab traffic and no second launch.
-template <int NSTAGE, bool TRA, bool TRB, int KG>
-__global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs g) {
-    constexpr int IMG = 16384, STAGE = 2 * IMG;
-    constexpr int LOADS = 8;  // wave-instructions per wave per tile
+// MB = 2, KG = 1: 8 waves as 4 x 2 over a 256 x 128 tile, one workgroup per CU.  A CU takes in ~70 GB/s from L2
+//         whatever the kernel does (MI355X_MICROARCH.md, gather-into-LDS table), so bytes fetched per flop bound the
+//         rate: 48 KiB per K tile for 2 x the flops of the 32 KiB of a 128 x 128 tile.  For large outputs.
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB>
+__global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
+    static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
+    constexpr int IMG = 16384, IMG_A = MB * IMG, STAGE = IMG_A + IMG;
+    constexpr int NPB = 4 / MB;        // B pieces per wave per tile
+    constexpr int LOADS = 4 + NPB;     // wave-instructions per wave per tile
+    constexpr int WG = 4 * MB;         // waves per wave group
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KT = 64;
 
     int z, tm, tn;
     tile_of(g, blockIdx.x, z, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * (BM * MB), n0 = tn * BN;
     const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = KG == 1 ? 0 : (wall >> 2);  // wave group (K-tile parity)
-    const int w = wall & 3;
-    const int wm = w >> 1, wn = w & 1;
+    const int grp = KG == 1 ? 0 : (wall / WG);  // wave group (K-tile parity)
+    const int w = wall % WG;
+    const int wm = w >> 1, wn = w & 1;  // wm: 64-row band of the tile, 0 .. 2 * MB - 1
     const int lr = lane & 15, lg = lane >> 4;
     unsigned char* ring = lds + grp * (NSTAGE * STAGE);
 
@@ -484,21 +492,21 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
     const int nt = nt_all > grp ? (nt_all - grp + KG - 1) / KG : 0;
     const int rounds = (nt_all + KG - 1) / KG;
 
-    OperandCursor<TRA> ca;
-    OperandCursor<TRB> cb;
+    OperandCursor<TRA, 4> ca;
+    OperandCursor<TRB, NPB> cb;
     int cur_src = -1;
     auto issue = [&](int i, int stage) {  // i-th tile of this group
         const int t = t_begin + grp + KG * i;
         const int src = t < nkt0 ? 0 : 1;
         if (src != cur_src) {  // (uniform) first tile, or the walk crossed from the first K source into the second
             const int k0 = (src == 0 ? t : t - nkt0) * KT;
-            ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, w, lane, KG);
-            cb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, w, lane, KG);
+            ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, w * 4, lane, KG);
+            cb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, w * NPB, lane, KG);
             cur_src = src;
         }
         unsigned char* sbase = ring + stage * STAGE;
-        ca.issue(sbase, w);
-        cb.issue(sbase + IMG, w);
+        ca.issue(sbase, w * 4);
+        cb.issue(sbase + IMG_A, w * NPB);
     };
 
     f32x4 acc[4][4];
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)ring;
     // row-major image: (row, chunk) -> row*128 + ((chunk ^ ((row>>1)&7)) << 4); k-step toggles bit 6, fragment i adds i*2048
     const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
-    const unsigned a_rm = (unsigned)((wm * 64 + lr) * ROWB) + rm_sw;
+    const unsigned a_rm = (unsigned)((wm * 64 + lr) * ROWB) + rm_sw;  // (sub-images are contiguous: row r at r * 128)
     const unsigned b_rm = (unsigned)((wn * 64 + lr) * ROWB) + rm_sw;
     // k-major image: lane 4q+p of a 16-lane group addresses (k-row 8*lg + q [+4 for the 2nd half] [+32 per k-step],
     // 16-B chunk = (wave offset | fragment i | p>>1) ^ f, byte (p&1)*8), f = 2q + 8*(lg&1).  The fragment index enters
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
     unsigned a_tr[4], b_tr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a_tr[i] = tr_row + ((((unsigned)(wm * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
+        a_tr[i] = (unsigned)((wm >> 1) * IMG) + tr_row + ((((unsigned)((wm & 1) * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
         b_tr[i] = tr_row + ((((unsigned)(wn * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
     }
 
@@ -532,6 +540,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
     const bool do_bias = TRA && g.dbias != nullptr && tn == 0;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int bcc = tid & 15, bkg = (tid & 255) >> 4;
+    const int bsub = MB == 2 ? (tid >> 8) : 0;  // tall tile: threads 256.. sum the second 128-row sub-image
 
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
 
         // Fragment reads as inline asm: hipcc cannot prove that a plain ds_read does not alias the LDS-DMA writes
         // in flight and would put s_waitcnt vmcnt(0) in front of it, draining the prefetched tiles.
-        const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG;
+        const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG_A;
         uint4 a0[4], a1[4], b0[4], b1[4];
         uint4 bz[4];
         if constexpr (TRA) {
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = bkg * 4 + r;
-                    const unsigned ad = stA + (unsigned)(k * 256 + ((bcc ^ (2 * (k & 3) + 8 * ((k >> 3) & 1))) << 4));
+                    const unsigned ad = stA + (unsigned)(bsub * IMG + k * 256 + ((bcc ^ (2 * (k & 3) + 8 * ((k >> 3) & 1))) << 4));
                     asm volatile("ds_read_b128 %0, %1" : "=v"(bz[r]) : "v"(ad));
                 }
             }
@@ -654,13 +663,15 @@ __global__ __launch_bounds__(NTHREADS * KG) void gemm_pipe_kernel(const GemmArgs
         if (g.dbias != nullptr && tn == 0) {  // block-uniform
             __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [16 * KG][128]
             float* red = reinterpret_cast<float*>(lds);
+            const int slot = MB == 2 ? bsub : grp;  // [KG * MB slots][16 k groups][128 rows]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[(grp * 16 + bkg) * 128 + bcc * 8 + e] = bsum[e];
+            for (int e = 0; e < 8; ++e) red[(slot * 16 + bkg) * 128 + bcc * 8 + e] = bsum[e];
             __syncthreads();
-            if (tid < 128 && m0 + tid < g.M) {
+            if (tid < 128 * MB && m0 + tid < g.M) {
+                // MB = 1: the KG groups' partials of row tid; MB = 2: the 16 partials of sub-image tid / 128
+                const int q0 = MB == 2 ? (tid >> 7) * 16 : 0, nq = MB == 2 ? 16 : 16 * KG;
                 float t = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16 * KG; ++q) t += red[q * 128 + tid];
+                for (int q = 0; q < nq; ++q) t += red[(q0 + q) * 128 + (tid & 127)];
                 if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
                 else g.dbias[m0 + tid] += t;
             }
@@ -749,10 +760,10 @@ using namespace egk;
 static int g_use_pipe = 1;
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static bool g_lds_attr_set = false;
-template <int NS, bool TA, bool TB, int KG>
+template <int NS, bool TA, bool TB, int KG, int MB = 1>
 static void set_lds_attr() {
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<NS, TA, TB, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NS * KG * 32768);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<NS, TA, TB, KG, MB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NS * KG * (MB + 1) * 16384);
 }
 static void ensure_lds_attr() {
     if (g_lds_attr_set) return;
@@ -760,14 +771,15 @@ static void ensure_lds_attr() {
     set_lds_attr<3, false, false, 1>(); set_lds_attr<3, false, true, 1>(); set_lds_attr<3, true, true, 1>(); set_lds_attr<3, true, false, 1>();
     set_lds_attr<4, false, false, 1>(); set_lds_attr<4, false, true, 1>(); set_lds_attr<4, true, true, 1>(); set_lds_attr<4, true, false, 1>();
     set_lds_attr<2, false, false, 2>(); set_lds_attr<2, false, true, 2>(); set_lds_attr<2, true, true, 2>(); set_lds_attr<2, true, false, 2>();
+    set_lds_attr<2, false, false, 1, 2>(); set_lds_attr<2, false, true, 1, 2>(); set_lds_attr<2, true, true, 1, 2>(); set_lds_attr<2, true, false, 1, 2>();
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
-    // 0 generic kernel only; 1 default (2-stage ring; two wave groups per workgroup for launches of at most one
-    // workgroup per CU); 2 always 3-stage; 3 always 2-stage; 4 always 4-stage; 5 always two wave groups
+    // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
+    // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage)
     g_use_pipe = on;
     return prev;
 }
@@ -848,16 +860,7 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         EGK_REQUIRE(g.ws && d->ws_bytes >= (int64_t)g.splitk * d->M * d->N * 4, "egk_gemm: split-K workspace too small");
     g.tiles_m = cdiv(g.M, BM); g.tiles_n = cdiv(g.N, BN);
     g.dbias = nullptr; g.ws_bias = nullptr;
-    {  // near-square XCD patches: group_m ~ sqrt(workgroups per XCD), inside one slab
-        const int tiles = g.tiles_m * g.tiles_n;
-        int per_xcd = cdiv(tiles * g.splitk, 8);
-        if (per_xcd > tiles) per_xcd = tiles;
-        int gm = 1;
-        while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
-        g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
-        if (g_group_m_override > 0) g.group_m = g_group_m_override < g.tiles_m ? g_group_m_override : g.tiles_m;
-    }
-
+    g.group_m = 1;
     const int K = d->K1 + d->K2;
     const double flops = 2.0 * d->M * d->N * K;
     const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
@@ -887,21 +890,40 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     }
     if (pipe_ok) {
         ensure_lds_attr();
-        dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk), pblock(NTHREADS);
-        // Two 64 KiB workgroups share a CU and hide each other's latencies when the launch has more than 256
-        // workgroups; a smaller launch leaves one workgroup (one wave per SIMD) per CU and its K walk runs at a
-        // fifth of the MFMA rate (DMA issue, LDS reads and MFMAs of the lone wave serialise): such launches get the
-        // two-wave-group kernel instead (measured: a 4-deep ring alone does not help, the walk is not latency bound).
-        const int nwg_total = g.tiles_m * g.tiles_n * g.splitk;
+        dim3 pblock(NTHREADS);
+        // Variant policy (g_use_pipe == 1), by the number of 128 x 128 workgroups the launch would have:
+        //   <= 256 : one workgroup (one wave per SIMD) per CU would walk K at a fifth of the MFMA rate (DMA issue, LDS
+        //            reads and MFMAs of the lone wave serialise): two wave groups per workgroup instead (5);
+        //   >  256 : 128 x 128 tiles, two 4-wave workgroups per CU (3).
+        // The 256 x 128 tile (6) is kept as a measured alternative: it fetches a third fewer bytes per flop, but the
+        // rate of this loop is set by LDS fragment reads + MFMA issue per 64 x 64 wave patch, not by the bytes a CU
+        // takes in -- it is 3-10 % slower than (3) up to 4096^3 and 5 % faster at 8192^3 (tools/gemm_bench.py --layouts).
+        const int nwg128 = g.tiles_m * g.tiles_n * g.splitk;
         const int nkt_slab = cdiv((d->K1 + d->K2) / 64, g.splitk);
-        const int variant = g_use_pipe == 1 ? ((nwg_total <= 256 && nkt_slab >= 4) ? 5 : 3) : g_use_pipe;
-#define EGK_PIPE(TA, TB)                                                                                              \
-    do {                                                                                                              \
-        if (variant == 5)                                                                                             \
-            hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 2>), pgrid, dim3(2 * NTHREADS), 4 * 32768, s, g);         \
-        else if (variant == 4) hipLaunchKernelGGL((gemm_pipe_kernel<4, TA, TB, 1>), pgrid, pblock, 4 * 32768, s, g);  \
-        else if (variant == 2) hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1>), pgrid, pblock, 3 * 32768, s, g);  \
-        else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1>), pgrid, pblock, 2 * 32768, s, g);                    \
+        int variant = g_use_pipe;
+        if (variant == 1) variant = nwg128 > 256 ? 3 : (nkt_slab >= 4 ? 5 : 3);
+        const int mb = variant == 6 ? 2 : 1;
+        g.tiles_m = cdiv(g.M, BM * mb);
+        {  // near-square XCD patches: group_m ~ sqrt(workgroups per XCD), inside one slab
+            const int tiles = g.tiles_m * g.tiles_n;
+            int per_xcd = cdiv(tiles * g.splitk, 8);
+            if (per_xcd > tiles) per_xcd = tiles;
+            int gm = 1;
+            while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
+            g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
+            if (g_group_m_override > 0) g.group_m = g_group_m_override < g.tiles_m ? g_group_m_override : g.tiles_m;
+        }
+
+        dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
+#define EGK_PIPE(TA, TB)                                                                                                  \
+    do {                                                                                                                  \
+        if (variant == 6)                                                                                                 \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
+        else if (variant == 5)                                                                                            \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 2, 1>), pgrid, dim3(2 * NTHREADS), 4 * 32768, s, g);          \
+        else if (variant == 4) hipLaunchKernelGGL((gemm_pipe_kernel<4, TA, TB, 1, 1>), pgrid, pblock, 4 * 32768, s, g);   \
+        else if (variant == 2) hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 1>), pgrid, pblock, 3 * 32768, s, g);   \
+        else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, g);                     \
     } while (0)
         if (!d->transA && !d->transB) EGK_PIPE(false, false);
         else if (!d->transA && d->transB) EGK_PIPE(false, true);

@@ -36,7 +36,7 @@ __device__ __forceinline__ float el(const float4& v, int t) { return t == 0 ? v.
 // -------------------------------------------------------------------------------------------
 // row LayerNorm (+ReLU, +dropout)
 // -------------------------------------------------------------------------------------------
-template <int NV, typename T>
+template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x,
                                                         const uint64_t* __restrict__ dev_offset) {
     if (dev_offset) offset += dev_offset[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool vec = (cols & 3) == 0;
+    if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
+    const bool vec = FULL || (cols & 3) == 0;
     Row<NV> wv, bv;
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x,
 }
 
 // dx for one row + per-wave column partials of dw/db, combined per workgroup through LDS.
-template <int NV, typename T>
+template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -109,17 +110,15 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy
                                                         float* __restrict__ ws, int rows, int cols, int relu, float p) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [WPB][2][NV*256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool vec = (cols & 3) == 0;
+    if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
+    const bool vec = FULL || (cols & 3) == 0;
     Row<NV> wv, bv, dwp, dbp;
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
 #pragma unroll
     for (int i = 0; i < NV; ++i) dwp.v[i] = dbp.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
-        Row<NV> g, xr;
-        load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
-        load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
+    auto process = [&](int row, Row<NV>& g, Row<NV>& xr) {
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -157,6 +156,26 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy
 #pragma unroll
             for (int t = 0; t < 4; ++t) el(g.v[i], t) = rs * (el(g.v[i], t) - s1 - el(xr.v[i], t) * s2);
         store_row<NV>(dx + (long long)row * cols, cols, vec, lane, g);
+    };
+    // TWO rows in flight per wave (a wave walks rows / (4 * grid) of them; with one row's loads outstanding at a
+    // time the walk is latency bound).  Wide rows (NV > 4) keep one row in flight: registers.
+    const int stride_rows = gridDim.x * WPB;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
+        Row<NV> g, xr;
+        load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
+        if constexpr (NV <= 4) {
+            const int row2 = row + stride_rows;
+            Row<NV> g2, xr2;
+            if (row2 < rows) {
+                load_row<NV>(dy + (long long)row2 * cols, cols, vec, lane, g2);
+                load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, xr2);
+            }
+            process(row, g, xr);
+            if (row2 < rows) process(row2, g2, xr2);
+        } else {
+            process(row, g, xr);
+        }
     }
     // combine the 4 waves' column partials in wave order, write this workgroup's partial row
     const int stride = NV * 256;
@@ -188,9 +207,19 @@ __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __res
     const int c = blockIdx.x * 16 + cg;
     float a = 0.f, d = 0.f;
     if (c < cols)
-        for (int k = rg; k < nblk; k += 16) {
-            a += ws[((long long)k * 2 + 0) * cols + c];
-            d += ws[((long long)k * 2 + 1) * cols + c];
+        for (int k = rg; k < nblk; k += 128) {  // 2 x 8 loads in flight, summed in k order
+            float va[8], vd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = k + 16 * u < nblk;
+                va[u] = in ? ws[((long long)(k + 16 * u) * 2 + 0) * cols + c] : 0.f;
+                vd[u] = in ? ws[((long long)(k + 16 * u) * 2 + 1) * cols + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += va[u];
+                d += vd[u];
+            }
         }
     red[0][rg][cg] = a;
     red[1][rg][cg] = d;
@@ -219,16 +248,15 @@ __device__ __forceinline__ int seg_of(const int* __restrict__ seg_ptr, int n_seg
 }
 
 // pass 1: per-workgroup per-segment (sum, sumsq) in double -> ws[blk][seg][2]
-template <int NV, typename T>
+template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict__ x, const int* __restrict__ seg_ptr,
                                                             int n_seg, int rows, int cols, double* __restrict__ ws) {
     __shared__ double acc[WPB][MAXSEG][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool vec = (cols & 3) == 0;
+    if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
+    const bool vec = FULL || (cols & 3) == 0;
     if (lane < n_seg) acc[wave][lane][0] = acc[wave][lane][1] = 0.0;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
-        Row<NV> r;
-        load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
+    auto process = [&](int row, const Row<NV>& r) {
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -244,6 +272,20 @@ __global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict_
             acc[wave][sg][0] += ds;
             acc[wave][sg][1] += dq;
         }
+    };
+    const int stride_rows = gridDim.x * WPB;  // two rows in flight per wave (see rowln_bwd_kernel)
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
+        Row<NV> r;
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
+        if constexpr (NV <= 4) {
+            const int row2 = row + stride_rows;
+            Row<NV> r2;
+            if (row2 < rows) load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, r2);
+            process(row, r);
+            if (row2 < rows) process(row2, r2);
+        } else {
+            process(row, r);
+        }
     }
     __syncthreads();
     if (threadIdx.x < n_seg * 2) {
@@ -254,39 +296,57 @@ __global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict_
     }
 }
 
-// block-wide sum of the per-workgroup double partials ws[k][sg][j], k < nblk, in a fixed order
-// (thread-strided partial sums, wave shuffle tree, 4 waves combined in wave order): bitwise reproducible.
-__device__ __forceinline__ double block_sum_partials(const double* __restrict__ ws, int nblk, int n_seg, int sg, int j,
-                                                     double* scratch /* [4] */) {
-    double v = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += 256) v += ws[((long long)k * n_seg + sg) * 2 + j];
-    v = wave_sum(v);
+// Block-wide sums of the per-workgroup double partials ws[k][sg][j], k < nblk, for EVERY (sg, j) at once, in a fixed
+// order (thread-strided partial sums, wave shuffle tree, 4 waves combined in wave order): bitwise reproducible.
+// All loads of a group of 8 values are issued before the first reduction and the group shares ONE barrier pair: this
+// prologue runs in every workgroup of the normalising kernels, and a chain of 2 * n_seg dependent
+// load -> reduce -> barrier rounds used to cost more than the row work behind it.
+__device__ __forceinline__ void block_sum_all(const double* __restrict__ ws, int nblk, int n_seg, double* out /* [n_seg*2] LDS */,
+                                              double (*scratch)[8] /* [4][8] LDS */) {
+    const int nv = n_seg * 2;
+    for (int v0 = 0; v0 < nv; v0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = 0.0;
+        for (int k = threadIdx.x; k < nblk; k += 256) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v0 + u < nv) v[u] += ws[(long long)k * nv + v0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = wave_sum(v[u]);
+        __syncthreads();  // scratch free (previous group consumed)
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) scratch[threadIdx.x >> 6][u] = v[u];
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && v0 + threadIdx.x < nv)
+            out[v0 + threadIdx.x] = (scratch[0][threadIdx.x] + scratch[1][threadIdx.x]) + (scratch[2][threadIdx.x] + scratch[3][threadIdx.x]);
+    }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
 // every workgroup re-derives (mean, 1/(std+eps)) of every segment from the partials
 __device__ __forceinline__ void graphln_finish_stats(const double* __restrict__ ws, int nblk, const int* __restrict__ seg_ptr,
                                                      int n_seg, int cols, float eps, float (*st)[2]) {
-    __shared__ double scratch[4];
-    for (int sg = 0; sg < n_seg; ++sg) {
-        const double s = block_sum_partials(ws, nblk, n_seg, sg, 0, scratch);
-        const double q = block_sum_partials(ws, nblk, n_seg, sg, 1, scratch);
-        if (threadIdx.x == 0) {
-            const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
-            const double mu = n > 0 ? s / n : 0.0;
-            double var = n > 0 ? q / n - mu * mu : 0.0;
-            if (var < 0) var = 0;
-            st[sg][0] = (float)mu;
-            st[sg][1] = (float)(1.0 / (sqrt(var) + (double)eps));
-        }
+    __shared__ double scratch[4][8];
+    __shared__ double sums[MAXSEG * 2];
+    block_sum_all(ws, nblk, n_seg, sums, scratch);
+    if (threadIdx.x < n_seg) {
+        const int sg = threadIdx.x;
+        const double s = sums[sg * 2 + 0], q = sums[sg * 2 + 1];
+        const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
+        const double mu = n > 0 ? s / n : 0.0;
+        double var = n > 0 ? q / n - mu * mu : 0.0;
+        if (var < 0) var = 0;
+        st[sg][0] = (float)mu;
+        st[sg][1] = (float)(1.0 / (sqrt(var) + (double)eps));
     }
     __syncthreads();
 }
 
-template <int NV, typename T>
+template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void graphln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ b, T* __restrict__ y,
                                                           float* __restrict__ stats, const int* __restrict__ seg_ptr,
@@ -296,7 +356,8 @@ __global__ __launch_bounds__(256) void graphln_fwd_kernel(const T* __restrict__ 
     graphln_finish_stats(ws, nblk_stats, seg_ptr, n_seg, cols, eps, st);
     if (blockIdx.x == 0 && threadIdx.x < n_seg * 2) stats[threadIdx.x] = st[threadIdx.x >> 1][threadIdx.x & 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool vec = (cols & 3) == 0;
+    if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
+    const bool vec = FULL || (cols & 3) == 0;
     Row<NV> wv, bv;
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
@@ -317,7 +378,7 @@ __global__ __launch_bounds__(256) void graphln_fwd_kernel(const T* __restrict__ 
 }
 
 // bwd pass 1: per-segment S1 = sum(dxhat), S2 = sum(dxhat*xhat) (double) + column partials of dw/db
-template <int NV, typename T>
+template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                 const float* __restrict__ w, const float* __restrict__ b,
                                                                 const float* __restrict__ stats,
@@ -327,19 +388,17 @@ __global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const T* __restr
     extern __shared__ __attribute__((aligned(16))) float red[];  // [WPB][2][NV*256]
     __shared__ double acc[WPB][MAXSEG][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool vec = (cols & 3) == 0;
+    if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
+    const bool vec = FULL || (cols & 3) == 0;
     if (lane < n_seg) acc[wave][lane][0] = acc[wave][lane][1] = 0.0;
     Row<NV> wv, bv, dwp, dbp;
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
 #pragma unroll
     for (int i = 0; i < NV; ++i) dwp.v[i] = dbp.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    auto process = [&](int row, const Row<NV>& g, const Row<NV>& xr) {
         const int sg = seg_of(seg_ptr, n_seg, row);
         const float mu = stats[sg * 2 + 0], ri = stats[sg * 2 + 1];
-        Row<NV> g, xr;
-        load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
-        load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -359,6 +418,25 @@ __global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const T* __restr
         if (lane == 0) {
             acc[wave][sg][0] += d1;
             acc[wave][sg][1] += d2;
+        }
+    };
+    // two rows in flight per wave (see rowln_bwd_kernel)
+    const int stride_rows = gridDim.x * WPB;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
+        Row<NV> g, xr;
+        load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
+        load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
+        if constexpr (NV <= 4) {
+            const int row2 = row + stride_rows;
+            Row<NV> g2, xr2;
+            if (row2 < rows) {
+                load_row<NV>(dy + (long long)row2 * cols, cols, vec, lane, g2);
+                load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, xr2);
+            }
+            process(row, g, xr);
+            if (row2 < rows) process(row2, g2, xr2);
+        } else {
+            process(row, g, xr);
         }
     }
     const int stride = NV * 256;
@@ -388,7 +466,7 @@ __global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const T* __restr
 }
 
 // bwd pass 2: dx = r*dxhat - r*S1/n - xhat*S2/(n*sigma),  sigma = 1/r - eps
-template <int NV, typename T>
+template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ b,
                                                           const float* __restrict__ stats, T* __restrict__ dx,
@@ -396,23 +474,24 @@ __global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ 
                                                           float eps, float slope, const double* __restrict__ ws_seg,
                                                           int nblk_stats) {
     __shared__ float sc[MAXSEG][4];  // mean, r, r*S1/n, S2/(n*sigma)
-    __shared__ double scratch[4];
-    for (int sg = 0; sg < n_seg; ++sg) {
-        const double s1 = block_sum_partials(ws_seg, nblk_stats, n_seg, sg, 0, scratch);
-        const double s2 = block_sum_partials(ws_seg, nblk_stats, n_seg, sg, 1, scratch);
-        if (threadIdx.x == 0) {
-            const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
-            const double r = stats[sg * 2 + 1];
-            const double sigma = 1.0 / r - (double)eps;
-            sc[sg][0] = stats[sg * 2 + 0];
-            sc[sg][1] = (float)r;
-            sc[sg][2] = n > 0 ? (float)(r * s1 / n) : 0.f;
-            sc[sg][3] = (n > 0 && sigma > 0) ? (float)(s2 / (n * sigma)) : 0.f;
-        }
+    __shared__ double scratch[4][8];
+    __shared__ double sums[MAXSEG * 2];
+    block_sum_all(ws_seg, nblk_stats, n_seg, sums, scratch);
+    if (threadIdx.x < n_seg) {
+        const int sg = threadIdx.x;
+        const double s1 = sums[sg * 2 + 0], s2 = sums[sg * 2 + 1];
+        const double n = (double)(seg_ptr[sg + 1] - seg_ptr[sg]) * cols;
+        const double r = stats[sg * 2 + 1];
+        const double sigma = 1.0 / r - (double)eps;
+        sc[sg][0] = stats[sg * 2 + 0];
+        sc[sg][1] = (float)r;
+        sc[sg][2] = n > 0 ? (float)(r * s1 / n) : 0.f;
+        sc[sg][3] = (n > 0 && sigma > 0) ? (float)(s2 / (n * sigma)) : 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool vec = (cols & 3) == 0;
+    if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
+    const bool vec = FULL || (cols & 3) == 0;
     Row<NV> wv, bv;
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
@@ -445,19 +524,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= N) return;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    int r = r0;
-    for (; r + 2 <= r1; r += 2) {
-        const float4 v0 = ld4t(x + (long long)r * ldx, c, N, vec);
-        const float4 v1 = ld4t(x + (long long)(r + 1) * ldx, c, N, vec);
-        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
-        b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+    // 8 row loads in flight per lane (a lone dependent load per iteration is latency bound: ~0.5 us per row)
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; r += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = r + u < r1 ? ld4t(x + (long long)(r + u) * ldx, c, N, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[u & 3].x += v[u].x; acc[u & 3].y += v[u].y; acc[u & 3].z += v[u].z; acc[u & 3].w += v[u].w;
+        }
     }
-    if (r < r1) {
-        const float4 v0 = ld4t(x + (long long)r * ldx, c, N, vec);
-        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
-    }
-    st4t(ws + (long long)blockIdx.y * N, c, N, (N & 3) == 0, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    st4t(ws + (long long)blockIdx.y * N, c, N, (N & 3) == 0,
+         make_float4((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                     (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)));
 }
 // stage 2: 32 columns x 8 partial-row groups per workgroup, groups combined in LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int N,
@@ -467,7 +550,13 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     const int c = blockIdx.x * 32 + cg;
     float s = 0.f;
     if (c < N)
-        for (int k = rg; k < nchunk; k += 8) s += ws[(long long)k * N + c];
+        for (int k = rg; k < nchunk; k += 64) {  // 8 loads in flight, summed in k order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k + 8 * u < nchunk ? ws[(long long)(k + 8 * u) * N + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
     red[rg][cg] = s;
     __syncthreads();
     if (rg == 0 && c < N) {
@@ -479,13 +568,14 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 
 static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
+static int g_cap_partial = 512, g_cap_wide = 2048;  // development knobs (egk_tune 1 / 2)
 static inline int row_grid(int rows) {  // kernels that emit per-workgroup partial rows: two workgroups per CU
     int g = cdiv(rows, WPB);
-    return g < 1 ? 1 : (g > 512 ? 512 : g);
+    return g < 1 ? 1 : (g > g_cap_partial ? g_cap_partial : g);
 }
-static inline int row_grid_wide(int rows) {  // pure streaming row kernels: one row per wave up to 8 workgroups per CU
+static inline int row_grid_wide(int rows) {  // pure streaming row kernels
     int g = cdiv(rows, WPB);
-    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    return g < 1 ? 1 : (g > g_cap_wide ? g_cap_wide : g);
 }
 
 }  // namespace egk
@@ -494,9 +584,12 @@ using namespace egk;
 
 #define DISPATCH_NV_(cols, ...)                                         \
     switch (nv_for(cols)) {                                             \
-        case 1: { constexpr int NV = 1; __VA_ARGS__; } break;           \
-        case 4: { constexpr int NV = 4; __VA_ARGS__; } break;           \
-        case 16: { constexpr int NV = 16; __VA_ARGS__; } break;         \
+        case 1: { constexpr int NV = 1; constexpr bool FULL = false; __VA_ARGS__; } break;           \
+        case 4:                                                                                    \
+            if ((cols) == 1024) { constexpr int NV = 4; constexpr bool FULL = true; __VA_ARGS__; }   \
+            else { constexpr int NV = 4; constexpr bool FULL = false; __VA_ARGS__; }                 \
+            break;                                                                                 \
+        case 16: { constexpr int NV = 16; constexpr bool FULL = false; __VA_ARGS__; } break;         \
         default: set_error("row width %d > 4096 unsupported", cols); return EGK_EUNSUPPORTED; \
     }
 // NV (registers per lane) x T (activation element type)
@@ -504,10 +597,17 @@ using namespace egk;
 
 extern "C" {
 
+// development knob: 1 = workgroup cap of the row kernels that emit per-workgroup partials, 2 = cap of the streaming ones
+int egk_tune(int32_t key, int32_t value) {
+    if (key == 1) { const int p = g_cap_partial; g_cap_partial = value; return p; }
+    if (key == 2) { const int p = g_cap_wide; g_cap_wide = value; return p; }
+    return -1;
+}
+
 static inline int colsum_chunks(int M, int N) {
     // enough workgroups to stream at HBM rate (>= ~256 with the column blocks), <= 64 partial rows to re-read
     const int col_blocks = cdiv(N, 1024);
-    int chunks = cdiv(128, col_blocks);  // 128 row chunks: enough workgroups to stream, few partials to re-read
+    int chunks = cdiv(256, col_blocks);  // one workgroup per CU, 8 rows in flight per lane; 256 partial rows to re-read
     if (chunks > cdiv(M, 8)) chunks = cdiv(M, 8);
     return chunks < 1 ? 1 : chunks;
 }
@@ -540,7 +640,7 @@ int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const floa
     hipStream_t s = (hipStream_t)stream;
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
-    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
                                                  (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset));
     return check_launch("egk_rowln_fwd");
 }
@@ -557,7 +657,7 @@ int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const floa
     const int grid = row_grid(rows);
     {
         ProfScope prof(KID_ROWLN_BWD, s, 0, (dtype == EGK_BF16 ? 6.0 : 12.0) * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_bwd_kernel<NV, T>), dim3(grid), dim3(256),
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_bwd_kernel<NV, T, FULL>), dim3(grid), dim3(256),
                                                      WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, mean,
                                                      rstd, mask, (T*)dx, ws, rows, cols, relu, p));
     }
@@ -584,12 +684,12 @@ int egk_graphln_fwd(egk_stream_t stream, const void* x, const float* w, const fl
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     {
         ProfScope prof(KID_GRAPHLN_STATS, s, 0, eb * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_stats_kernel<NV, T>), dim3(grid), dim3(256), 0, s, (const T*)x, seg_ptr,
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_stats_kernel<NV, T, FULL>), dim3(grid), dim3(256), 0, s, (const T*)x, seg_ptr,
                                                      n_seg, rows, cols, (double*)ws));
     }
     {
         ProfScope prof(KID_GRAPHLN_FWD, s, 0, 2 * eb * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
                                                      (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)ws, grid));
     }
     return check_launch("egk_graphln_fwd");
@@ -608,13 +708,13 @@ int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const fl
     float* ws_col = (float*)((char*)ws + (int64_t)grid * n_seg * 2 * 8);
     {
         ProfScope prof(KID_GRAPHLN_BWD_STATS, s, 0, 2 * eb * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_stats_kernel<NV, T>), dim3(grid), dim3(256),
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_stats_kernel<NV, T, FULL>), dim3(grid), dim3(256),
                                                      WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, stats,
                                                      seg_ptr, n_seg, rows, cols, slope, ws_seg, ws_col));
     }
     {
         ProfScope prof(KID_GRAPHLN_BWD, s, 0, 3 * eb * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_kernel<NV, T>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)dy,
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)dy,
                                                      (const T*)x, w, b, stats, (T*)dx, seg_ptr, n_seg, rows, cols, eps, slope,
                                                      ws_seg, grid));
     }

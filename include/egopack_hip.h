@@ -93,6 +93,8 @@ int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute);
 /* development knob for A/B measurements in one process: 0 routes every contraction through the generic
  * register-staged kernel, 1 (default) lets eligible ones (bf16 operands, 16-byte aligned rows, K % 64 == 0) use
  * the LDS-DMA pipelined kernel with a 2-stage ring, 2 the same with a 3-stage ring.  Returns the previous setting. */
+/* development knob of the row kernels (launch geometry only, results unchanged): returns the previous value */
+int egk_tune(int32_t key, int32_t value);
 int egk_gemm_set_pipeline(int32_t on);
 
 /* out[n] (+)= sum_m x[m, n] : bias gradients of every Linear above.  Two launches (row-chunk
