@@ -299,27 +299,62 @@ __global__ __launch_bounds__(256) void cos_dist_kernel(const float* __restrict__
     if (j < K) dist[(long long)r * K + j] = 1.f - dot[(long long)r * ldd + j] * f_inv[r] * b_inv[j];
 }
 
-// one wave per row: k rounds of a lexicographic (distance, index) arg-min over the row.
+// One wave per row, ONE pass over the row: every lane keeps the KM smallest (distance, index) pairs of the columns it
+// visits (16-byte loads, 4 consecutive columns per lane and step) in a sorted register list -- almost every element
+// fails the first comparison against the list's worst entry -- then k rounds of a wave-wide lexicographic arg-min
+// over the list heads pick the row's k nearest in order (the winning lane pops its head).  Ties go to the smaller
+// index, NaN distances are never selected, exactly as a full (distance, index) sort would order them.
+template <int KM>
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot, long long ldd,
                                                    const float* __restrict__ f_inv, const float* __restrict__ b_inv,
-                                                   long long* __restrict__ nn, int rows, int K, int k) {
+                                                   long long* __restrict__ nn, int rows, int K, int k, int vec) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const float* dr = dot + (long long)row * ldd;
         const float fi = f_inv[row];
-        float last_v = -INFINITY;
-        int last_i = -1;
-        for (int sel = 0; sel < k; ++sel) {
-            float bv = INFINITY;
-            int bi = 0x7fffffff;
-            for (int j = lane; j < K; j += 64) {
-                const float d = 1.f - dr[j] * fi * b_inv[j];
-                const bool eligible = d > last_v || (d == last_v && j > last_i);
-                if (eligible && (d < bv || (d == bv && j < bi))) {
-                    bv = d;
-                    bi = j;
+        float lv[KM];
+        int li[KM];
+#pragma unroll
+        for (int s = 0; s < KM; ++s) {
+            lv[s] = INFINITY;
+            li[s] = 0x7fffffff;
+        }
+        for (int base = lane * 4; base < K; base += 256) {
+            float dv[4], bv4[4];
+            if (vec && base + 4 <= K) {
+                const float4 a = *reinterpret_cast<const float4*>(dr + base);
+                const float4 b = *reinterpret_cast<const float4*>(b_inv + base);
+                dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w;
+                bv4[0] = b.x; bv4[1] = b.y; bv4[2] = b.z; bv4[3] = b.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dv[t] = base + t < K ? dr[base + t] : 0.f;
+                    bv4[t] = base + t < K ? b_inv[base + t] : 0.f;
                 }
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = base + t;
+                float d = 1.f - dv[t] * fi * bv4[t];
+                int dj = j;
+                if (j < K && (d < lv[KM - 1] || (d == lv[KM - 1] && dj < li[KM - 1]))) {
+#pragma unroll
+                    for (int s = 0; s < KM; ++s) {  // sorted insert: carry the larger pair down the list
+                        const bool before = d < lv[s] || (d == lv[s] && dj < li[s]);
+                        const float tv = lv[s];
+                        const int ti = li[s];
+                        lv[s] = before ? d : tv;
+                        li[s] = before ? dj : ti;
+                        d = before ? tv : d;
+                        dj = before ? ti : dj;
+                    }
+                }
+            }
+        }
+        for (int sel = 0; sel < k; ++sel) {
+            float bv = lv[0];
+            int bi = li[0];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const float ov = __shfl_xor(bv, o, 64);
@@ -330,8 +365,15 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
                 }
             }
             if (lane == 0) nn[(long long)row * k + sel] = bi == 0x7fffffff ? 0 : bi;
-            last_v = bv;
-            last_i = bi;
+            if (li[0] == bi && bi != 0x7fffffff) {  // column indices are unique: exactly one lane owns the winner
+#pragma unroll
+                for (int s = 0; s + 1 < KM; ++s) {
+                    lv[s] = lv[s + 1];
+                    li[s] = li[s + 1];
+                }
+                lv[KM - 1] = INFINITY;
+                li[KM - 1] = 0x7fffffff;
+            }
         }
     }
 }
@@ -525,8 +567,13 @@ int egk_topk_smallest(egk_stream_t stream, const float* dot, int64_t ldd, const 
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_TOPK, s, 0, 4.0 * rows * K);
-    hipLaunchKernelGGL(topk_kernel, dim3(row_grid(rows)), dim3(256), 0, s, dot, (long long)ldd, f_inv, b_inv, (long long*)nn,
-                       rows, K, k);
+    const int vec = (ldd % 4 == 0) && ((uintptr_t)dot % 16 == 0) && ((uintptr_t)b_inv % 16 == 0);
+    if (k <= 4)
+        hipLaunchKernelGGL(topk_kernel<4>, dim3(row_grid(rows)), dim3(256), 0, s, dot, (long long)ldd, f_inv, b_inv,
+                           (long long*)nn, rows, K, k, vec);
+    else
+        hipLaunchKernelGGL(topk_kernel<16>, dim3(row_grid(rows)), dim3(256), 0, s, dot, (long long)ldd, f_inv, b_inv,
+                           (long long*)nn, rows, K, k, vec);
     return check_launch("egk_topk_smallest");
 }
 

@@ -59,6 +59,10 @@ class GraphONE(nn.Module):
             stages[t] = nn.ModuleList(per_depth)
         self.conv_stages = nn.ModuleDict(stages)
         self._bank_inv_norm: Dict[str, torch.Tensor] = {}
+        # MI355X knob (not a reference key): the aux tasks' stages are independent chains of M = batch-nodes
+        # contractions that each fill half of the chip at best -- run them on one HIP stream per task
+        self.parallel_tasks = bool(kwargs.get("parallel_tasks", True))
+        self._task_streams: List[torch.cuda.Stream] = []
 
     def _inv_norm(self, task: str) -> torch.Tensor:
         bank = self.embeddings[task].weight
@@ -77,7 +81,26 @@ class GraphONE(nn.Module):
         if not self.freeze:
             raise NotImplementedError("trainable prototypes are outside the hot path (freeze=True in every experiment)")
         output, closest = {}, {}
-        for task, f in features.items():
+        items = list(features.items())
+        if self.parallel_tasks and len(items) > 1 and items[0][1].is_cuda:
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            while len(self._task_streams) < len(items):
+                self._task_streams.append(torch.cuda.Stream())
+                ops.exclude_wgrad_streams(self._task_streams[-1:])
+            for st, (task, f) in zip(self._task_streams, items):
+                st.wait_event(fork)
+                f.record_stream(st)
+                with torch.cuda.stream(st):  # autograd replays each chain's backward on its stream as well
+                    output[task], closest[task] = self._task_interaction(task, f)
+            for st, (task, _) in zip(self._task_streams, items):
+                main.wait_stream(st)
+                output[task].record_stream(main)
+                for a in closest[task][:1]:
+                    a.record_stream(main)
+            return output, closest
+        for task, f in items:
             output[task], closest[task] = self._task_interaction(task, f)
         return output, closest
 

@@ -752,3 +752,35 @@ def test_classifier_dx_on_zero_padded_k_axis(ops, n_out):
         torch.testing.assert_close(b.grad, gr.sum(0).float(), rtol=2e-3, atol=5e-2)
         torch.testing.assert_close(y, (xr @ Wr.t() + b.detach().double()).float(), rtol=2e-3, atol=2e-2)
         opt.step()
+
+
+@pytest.mark.parametrize("rows,K,k", [(7, 5, 3), (33, 257, 4), (64, 4096, 4), (17, 1000, 16), (5, 64, 1), (9, 130, 9)])
+def test_topk_selection_equals_full_lexicographic_sort(ops, rows, K, k):
+    """egk_topk_smallest on a given dot-product matrix: the k picks of every row must equal a full (distance, index)
+    sort of d = 1 - dot * f_inv * b_inv (same f32 expression) -- with many exact ties, +/-inf and NaN distances."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(rows * 1000 + K)
+    dot = (torch.randint(-3, 4, (rows, K), generator=g).float() / 4)  # few distinct values: ties everywhere
+    dot[0, :] = 0.5  # a row of identical distances -> indices 0..k-1
+    if K > 8:
+        dot[1, 3] = float("nan")
+        dot[1, 5] = float("inf")   # distance -inf: the nearest
+        dot[2, 1] = float("-inf")  # distance +inf: the farthest
+    # scales that are powers of two: every product and difference below is exact in f32, so the expected order does
+    # not depend on whether the device contracts 1 - a*b into an FMA
+    f_inv = 2.0 ** torch.randint(-1, 2, (rows,), generator=g).float()
+    b_inv = 2.0 ** torch.randint(-1, 2, (K,), generator=g).float()
+    d = 1.0 - dot * f_inv[:, None] * b_inv[None, :]
+    key = torch.where(torch.isnan(d), torch.full_like(d, float("inf")), d)
+    # NaN never wins against a number: order them after everything else; ties by index (stable sort)
+    order = torch.sort(key + torch.where(torch.isnan(d), torch.tensor(float("inf")), torch.tensor(0.0)), dim=1, stable=True).indices
+    nn = torch.empty((rows, k), dtype=torch.int64, device=DEV)
+    d_dot, d_f, d_b = dot.to(DEV), f_inv.to(DEV), b_inv.to(DEV)  # keep the device copies alive across the raw call
+    rc = lib.egk_topk_smallest(ops._stream(), ops._p(d_dot), K, ops._p(d_f), ops._p(d_b), ops._p(nn), rows, K, k)
+    assert rc == 0
+    nn = nn.cpu()
+    valid = (~torch.isnan(d)).sum(1)
+    for r in range(rows):
+        kk = min(k, int(valid[r]))
+        assert nn[r, :kk].tolist() == order[r, :kk].tolist(), r
