@@ -156,8 +156,15 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=16, budget_s=20.0):
 
 
 # library profiler name -> kernel symbol (substring) in rocprofv3 output
-ROCPROF_NAME = {"gemm_bf16_nn": "gemm_pipe_kernel<2, false, false>", "gemm_bf16_nt": "gemm_pipe_kernel<2, false, true>",
-                "gemm_bf16_tt": "gemm_pipe_kernel<2, true, true>", "gemm_bf16_tn": "gemm_pipe_kernel<2, true, false>",
+def _pipe(ta, tb, kg):
+    return f"gemm_pipe_kernel<2, {ta}, {tb}, {kg}, 1>"
+
+
+ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pipe("false", "true", 1),
+                "gemm_bf16_tt": _pipe("true", "true", 1), "gemm_bf16_tn": _pipe("true", "false", 1),
+                "gemm_bf16_nn_g2": _pipe("false", "false", 2), "gemm_bf16_nt_g2": _pipe("false", "true", 2),
+                "gemm_bf16_tt_g2": _pipe("true", "true", 2), "gemm_bf16_tn_g2": _pipe("true", "false", 2),
+                "gemm_bf16_generic": "gemm_kernel<true", "gemm_splitk_reduce": "gemm_splitk_reduce",
                 "adam": "adam_kernel", "csr_gather": "csr_gather_kernel"}
 
 
@@ -321,7 +328,19 @@ def main():
     rl, table = (None, {})
     if rank == 0 and not args.no_roofline:
         try:
-            rl, table = roofline(ops, eager_step, args.compute)
+            # per-kernel durations are taken with every launch on ONE stream (heads, aux tasks and weight gradients
+            # serialised), the way rocprofv3 --kernel-trace times them: the committed profile must agree with them
+            saved = (step.parallel_heads, step.wgrad_side_streams)
+            step.parallel_heads = step.wgrad_side_streams = False
+            g1 = getattr(step, "graphone", None)
+            if g1 is not None:
+                saved_g1, g1.parallel_tasks = g1.parallel_tasks, False
+            try:
+                rl, table = roofline(ops, eager_step, args.compute)
+            finally:
+                step.parallel_heads, step.wgrad_side_streams = saved
+                if g1 is not None:
+                    g1.parallel_tasks = saved_g1
         except Exception as e:  # the headline number must still be printed
             rl = {"error": repr(e)}
     cb = None

@@ -38,6 +38,12 @@ enum KernelId {
     KID_GEMM_F32_NT,
     KID_GEMM_F32_TT,
     KID_GEMM_F32_TN,
+    KID_GEMM_BF16_NN_G2,   // the same four layouts on the two-wave-group pipelined kernel (launches of <= 256 workgroups)
+    KID_GEMM_BF16_NT_G2,
+    KID_GEMM_BF16_TT_G2,
+    KID_GEMM_BF16_TN_G2,
+    KID_GEMM_BF16_GENERIC, // bf16 MFMA on the register-staged kernel (K not a multiple of 64, unaligned rows, f32 storage)
+    KID_GEMM_SPLITK_REDUCE,
     KID_COLSUM,
     KID_ROWLN_FWD,
     KID_ROWLN_BWD,

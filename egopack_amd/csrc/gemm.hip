@@ -865,8 +865,8 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     const double flops = 2.0 * d->M * d->N * K;
     const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
     const int bf = d->compute == EGK_COMPUTE_BF16;
-    const int kid = (bf ? KID_GEMM_BF16_NN : KID_GEMM_F32_NN) + (d->transA ? (d->transB ? 2 : 3) : (d->transB ? 1 : 0));
-    ProfScope prof(kid, s, flops, bytes);
+    const int layout = d->transA ? (d->transB ? 2 : 3) : (d->transB ? 1 : 0);  // nn, nt, tt, tn
+    const double slab_bytes = d->splitk > 1 ? ((double)d->splitk + 1.0) * d->M * d->N * 4.0 : 0.0;
 
     // LDS-DMA pipelined kernel: bf16 operands, 16-byte aligned rows, every K source a multiple of 64 (the rows of
     // the contraction axis must not need zero fill); everything else runs on the generic register-staged kernel.
@@ -925,12 +925,16 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         else if (variant == 2) hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 1>), pgrid, pblock, 3 * 32768, s, g);   \
         else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, g);                     \
     } while (0)
-        if (!d->transA && !d->transB) EGK_PIPE(false, false);
-        else if (!d->transA && d->transB) EGK_PIPE(false, true);
-        else if (d->transA && d->transB) EGK_PIPE(true, true);
-        else EGK_PIPE(true, false);
+        {
+            ProfScope prof((variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
+            if (!d->transA && !d->transB) EGK_PIPE(false, false);
+            else if (!d->transA && d->transB) EGK_PIPE(false, true);
+            else if (d->transA && d->transB) EGK_PIPE(true, true);
+            else EGK_PIPE(true, false);
+        }
 #undef EGK_PIPE
         if (g.splitk > 1) {
+            ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
             const long long total = (long long)g.M * g.N;
             hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
                                dim3(256), 0, s, g);
@@ -938,10 +942,14 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         return check_launch("egk_gemm");
     }
     dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
-    if (!bf) launch_layout<false, float, float>(d, grid, s, g);
-    else if (a16) launch_layout<true, bf16_t, bf16_t>(d, grid, s, g);
-    else launch_layout<true, float, float>(d, grid, s, g);
+    {
+        ProfScope prof(bf ? KID_GEMM_BF16_GENERIC : KID_GEMM_F32_NN + layout, s, flops, bytes);
+        if (!bf) launch_layout<false, float, float>(d, grid, s, g);
+        else if (a16) launch_layout<true, bf16_t, bf16_t>(d, grid, s, g);
+        else launch_layout<true, float, float>(d, grid, s, g);
+    }
     if (g.splitk > 1) {
+        ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
         const long long total = (long long)g.M * g.N;
         hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
                            dim3(256), 0, s, g);
