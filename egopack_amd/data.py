@@ -179,6 +179,15 @@ def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
     out.graph = build_csr(ei, off) if with_csr else None
     out.ptr32 = out.ptr.to(torch.int32)
     out.seg_ptr = torch.tensor([0, off], dtype=torch.int32)  # one graph-LayerNorm segment: the whole batch
+    # per-sample scalar attributes (pnr_frame, start_frame, end_frame, ...) become [B] tensors, as PyG's collation
+    # does for python numbers (utils/dataloading.py:56-70; read by the PNR meter)
+    known = {"x", "y", "pos", "edge_index", "batch", "ptr", "graph", "num_graphs", "ptr32", "seg_ptr"}
+    for key, v in vars(samples[0]).items():
+        if key in known or key.startswith("_"):
+            continue
+        if isinstance(v, (int, float)) or (torch.is_tensor(v) and v.dim() == 0):
+            setattr(out, key, torch.tensor([float(getattr(smp, key)) if isinstance(v, float) else int(getattr(smp, key))
+                                            for smp in samples]))
     return out
 
 
@@ -307,11 +316,15 @@ class SyntheticTaskDataset:
 
     has_joint_label = False
     num_labels = 2
+    label_names = ["verbs", "nouns"]
 
     def __init__(self, task: str, length: int, T: int, num_segments: int = 3, features_size: int = 1536,
                  num_class_labels=(115, 478), k: int = 1, seed: int = 1, transform=None):
         self.task, self.length, self.T, self.S, self.features_size = task, length, T, num_segments, features_size
         self.num_class_labels, self.seed = tuple(num_class_labels), seed
+        self.class_labels = [[f"verb_{i}" for i in range(self.num_class_labels[0])],
+                             [f"noun_{i}" for i in range(self.num_class_labels[1])]]
+        self.lta_nodes = T  # the LTA meter cuts the label vector into sequences of this many nodes (22 on Ego4D)
         if transform is None:
             transform = LTATemporalConnectivity(r=k + 0.5) if task == "lta" else RadiusGraph(r=k + 0.5)
         self.transform = transform
@@ -339,7 +352,14 @@ class SyntheticTaskDataset:
         elif self.task == "pnr":
             pos = torch.arange(T)
             y = torch.zeros(T, dtype=torch.long)
-            y[int(torch.randint(0, T, (1,), generator=g))] = 1
+            at = int(torch.randint(0, T, (1,), generator=g))
+            y[at] = 1
+            # clip of 8 s at 30 fps starting at a random frame; the PNR frame sits inside the positive node's span
+            start = int(torch.randint(0, 10000, (1,), generator=g))
+            d = self.transform(Data(x=x, pos=pos, y=y, batch=None))
+            d.start_frame, d.end_frame = start, start + 240
+            d.pnr_frame = start + int((at + 0.5) * 240 / T)
+            return d
         else:
             raise ValueError(self.task)
         return self.transform(Data(x=x, pos=pos, y=y, batch=None))

@@ -1,0 +1,76 @@
+"""Validation loops (reference validate.py:13-150): eval mode, no grad, one backbone pass per batch, primary head
+(optionally fused with the GraphONE aux features), per-batch mean loss, meter update.  Same signatures."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+
+def _eval_mode(model, primary_task, other_tasks, graphone):
+    model.eval()
+    for task in [primary_task, *other_tasks]:
+        task.eval()
+    if graphone is not None:
+        graphone.eval()
+
+
+def _logits(model, data, primary_task, other_tasks, graphone, late_fusion, needs_batch: bool):
+    """validate.py:34-53 / :85-100 / :130-145.  ``late_fusion=False`` with a GraphONE takes the elementwise max of the
+    primary and aux features before the classifier, as the reference does."""
+    feat = model(data)
+    feat_primary = primary_task.forward_features(feat)
+    batch = getattr(data, "batch", None)
+    if graphone is not None:
+        feat_secondary = {task.name: task.forward_features(feat) for task in other_tasks}
+        feat_secondary, *_ = graphone.interact(feat_secondary)
+        if late_fusion:
+            logits = primary_task.forward_logits(features=feat_primary, batch=data if needs_batch else batch,
+                                                 aux_features=feat_secondary)
+        else:
+            feat = torch.stack([feat_primary.float(), *[f.float() for f in feat_secondary.values()]], dim=1).max(1).values
+            logits = primary_task.forward_logits(feat, data) if needs_batch else primary_task.forward_logits(feat)
+    else:
+        feat = feat_primary
+        logits = primary_task.forward_logits(feat, data) if needs_batch else primary_task.forward_logits(feat)
+    return logits, feat
+
+
+@torch.no_grad()
+def validate(epoch, temporal_graph_model, dataloader, meter, primary_task, other_tasks: Optional[List] = None, graphone=None,
+             late_fusion: bool = True, device: str = "cuda"):
+    other_tasks = other_tasks or []
+    _eval_mode(temporal_graph_model, primary_task, other_tasks, graphone)
+    for data in dataloader:
+        data = data.to(device)
+        logits, feat = _logits(temporal_graph_model, data, primary_task, other_tasks, graphone, late_fusion, needs_batch=True)
+        pre = data.x.mean(1) if data.x.dim() == 3 else data.x
+        loss = primary_task.compute_loss(logits, data.y).mean()
+        meter.update(logits, data.y, loss, pre, feat)
+
+
+@torch.no_grad()
+def validate_lta(temporal_graph_model, dataloader, meter, primary_task, other_tasks: Optional[List] = None, graphone=None,
+                 late_fusion: bool = False, device: str = "cuda"):
+    other_tasks = other_tasks or []
+    _eval_mode(temporal_graph_model, primary_task, other_tasks, graphone)
+    for data in dataloader:
+        data = data.to(device)
+        logits, _ = _logits(temporal_graph_model, data, primary_task, other_tasks, graphone, late_fusion, needs_batch=True)
+        predictions, logits = primary_task.generate_from_logits(logits)
+        loss = primary_task.compute_loss(logits, data.y).mean()
+        meter.update(logits, data.y, predictions, loss)
+
+
+@torch.no_grad()
+def validate_pnr(temporal_graph_model, dataloader, meter, primary_task, other_tasks: Optional[List] = None, graphone=None,
+                 late_fusion: bool = False, device: str = "cuda"):
+    other_tasks = other_tasks or []
+    _eval_mode(temporal_graph_model, primary_task, other_tasks, graphone)
+    for data in dataloader:
+        data = data.to(device)
+        logits, _ = _logits(temporal_graph_model, data, primary_task, other_tasks, graphone, late_fusion, needs_batch=False)
+        loss = primary_task.compute_loss(logits, data.y)  # (the reference passes y.float(); the BCE kernel converts)
+        # (the batch object carries the int32 sequence pointer the collation built; a plain ``batch`` vector works too)
+        meter.update(logits, data.y, data if getattr(data, "ptr32", None) is not None else data.batch,
+                     data.start_frame, data.end_frame, data.pnr_frame, loss)

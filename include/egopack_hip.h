@@ -235,6 +235,16 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
 int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
 
+/* ---- validation metrics  utils/meters/ego4d.py, utils/meters/utils.py:6-28 ----
+ * rank[r] = #{j : s[r,j] > s[r,y]} + #{j < y : s[r,j] == s[r,y]} for y = labels[r*label_stride]; -1 when y < 0
+ * (ignore_index) or y >= C.  top-k accuracy = mean(rank < k) over rank >= 0; per-class recall likewise. */
+int egk_label_rank(egk_stream_t s, const float* logits, int64_t ld, const int64_t* labels, int64_t label_stride,
+                   int32_t* rank, int32_t rows, int32_t C);
+/* out[n*K + k] = Levenshtein distance between pred[n, :, k] and label[n, :] (element strides given), Z <= 64
+ * (Ego4dLTAMeter._edit_distance, ego4d.py:410-423: editdistance.eval(...)/Z, minimum over k taken by the caller) */
+int egk_edit_distance(egk_stream_t s, const int64_t* pred, int64_t p_sn, int64_t p_sz, int64_t p_sk, const int64_t* label,
+                      int64_t l_sn, int64_t l_sz, int32_t* out, int32_t N, int32_t Z, int32_t K);
+
 #ifdef __cplusplus
 }
 #endif

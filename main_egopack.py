@@ -23,8 +23,36 @@ from egopack_amd.data import build_dataloader, multiloader
 from graphone import build_graphone
 from models.graphONE.graphONE import GraphONE
 from models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+from utils.meters import build_meter_for_dataset
+from validate import validate, validate_lta, validate_pnr
 
 logger = logging.getLogger("main_egopack")
+
+AUX_ORDER = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
+             "pnr": ("ar", "lta", "oscc")}  # other_tasks lists of the reference's validation calls (main_egopack.py:377-448)
+
+
+def validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, loaders, late_fusion=True, validate_all=False,
+                     device="cuda"):
+    """Task metrics with the GraphONE interaction for the novel task(s) (reference main_egopack.py:374-448)."""
+    out = {}
+    for t in ("ar", "oscc", "lta", "pnr"):
+        if not (validate_all or weights.get(t, 0) > 0):
+            continue
+        is_egopack = weights.get(t, 0) > 0
+        others = [tasks[o] for o in AUX_ORDER[t] if o in graphone.task_labels] if is_egopack else []
+        g1 = graphone if is_egopack else None
+        meter = build_meter_for_dataset(dsets_val[t], device=device)
+        if t == "lta":
+            validate_lta(model, loaders[t], meter, tasks[t], others, g1, late_fusion=late_fusion, device=device)
+        elif t == "pnr":
+            validate_pnr(model, loaders[t], meter, tasks[t], others, g1, late_fusion=late_fusion, device=device)
+        else:
+            validate(epoch, model, loaders[t], meter, tasks[t], others, g1, late_fusion=late_fusion, device=device)
+        for line in meter.print_logs():
+            logger.info("[val %s] %s", t, line)
+        out[t] = {k: v for k, v in meter.get_logs().items() if isinstance(v, (int, float))}
+    return out
 
 
 def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda"):
@@ -52,8 +80,9 @@ def main(argv=None):
     ops.set_compute(cfg.compute)
     weights = T.task_weights(cfg)
 
-    dsets_train = T.build_datasets(cfg, "train")
+    dsets_train, dsets_val = T.build_datasets(cfg, "train"), T.build_datasets(cfg, cfg.validation_split)
     dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
+    dl_val = T.build_loaders(cfg, dsets_val, False, 0, 1)
     H = cfg.model.hidden_size
     model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,
                         num_segments=cfg.dataset_recognition.num_segments, _recursive_=False).to(device)
@@ -88,6 +117,9 @@ def main(argv=None):
     for epoch in range(1, cfg.num_epochs + 1):
         train(epoch, step, dl_train, weights, device)
         scheduler.step()
+        if rank == 0:
+            validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, dl_val, late_fusion=cfg.late_fusion,
+                             validate_all=cfg.validate_all_tasks, device=device)
     if cfg.save_model and rank == 0:
         name = f"{cfg.artifact_prefix}_egopack_" + "-".join(sorted(t for t, w in weights.items() if w > 0))
         T.save_checkpoint(Path(cfg.checkpoint_dir) / name / "checkpoint.pth", model, tasks, cfg.num_epochs,

@@ -7,10 +7,10 @@
 
 Same configuration keys and training semantics as the reference (zero_grad -> backbone forward for
 every enabled task batch -> head -> weight * loss.mean() summed -> backward -> Adam; cosine schedule
-stepped per epoch; ``multiloader`` restarts exhausted loaders).  W&B logging, torchmetrics meters and
-the task-metric validation of the last epochs are outside the hot path: per-task
-validation LOSSES are reported instead, and checkpoints are written locally with the reference's
-key layout."""
+stepped per epoch; ``multiloader`` restarts exhausted loaders).  In the last epochs every enabled task is
+validated with its meter (``validate`` / ``validate_lta`` / ``validate_pnr`` + ``utils.meters``, reference
+main_temporal.py:340-400); W&B logging is not reproduced, checkpoints are written locally with the reference's key
+layout."""
 from __future__ import annotations
 
 import logging
@@ -23,6 +23,8 @@ from egopack_amd import engine, ops, train as T
 from egopack_amd.config import instantiate
 from egopack_amd.data import multiloader
 from models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+from utils.meters import build_meter_for_dataset
+from validate import validate, validate_lta, validate_pnr
 
 logger = logging.getLogger("main_temporal")
 
@@ -63,6 +65,23 @@ def validate_losses(step: engine.MTLStep, loaders, device="cuda"):
             s += float(vectors[t].sum())
             n += vectors[t].numel()
         out[t] = s / max(n, 1)
+    return out
+
+
+def validate_metrics(epoch, model, tasks, enabled, dsets_val, loaders, device="cuda"):
+    """Task metrics of every enabled task (reference main_temporal.py:340-400)."""
+    out = {}
+    for t in enabled:
+        meter = build_meter_for_dataset(dsets_val[t], device=device)
+        if t == "lta":
+            validate_lta(model, loaders[t], meter, tasks[t], device=device)
+        elif t == "pnr":
+            validate_pnr(model, loaders[t], meter, tasks[t], device=device)
+        else:
+            validate(epoch, model, loaders[t], meter, tasks[t], device=device)
+        for line in meter.print_logs():
+            logger.info("[val %s] %s", t, line)
+        out[t] = {k: v for k, v in meter.get_logs().items() if isinstance(v, (int, float))}
     return out
 
 
@@ -111,6 +130,7 @@ def main(argv=None):
         logger.info("learning rate -> %.6g", scheduler.get_last_lr()[0])
         if epoch >= cfg.num_epochs - 5 and rank == 0:
             logger.info("validation losses: %s", validate_losses(step, dl_val, device))
+            validate_metrics(epoch, model, tasks, step.enabled, dsets_val, dl_val, device)
     if cfg.save_model and rank == 0:
         T.save_checkpoint(Path(cfg.checkpoint_dir) / artifact / "checkpoint.pth", model, tasks, cfg.num_epochs,
                           optimizer=optimizer)

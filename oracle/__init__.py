@@ -19,4 +19,9 @@ Pinning status (see DESIGN.md "Oracle"):
     that release's published semantics in ``oracle/pyg_ops.py``.  The reference holds no
     tests or vectors for them, so for those leaf ops: **parity unpinned** beyond the
     hand-derived known-answer tests in tests/test_oracle_known_answers.py.
+  * Validation meters (``oracle/meters.py``): the reference's own numpy top-k accuracy / recall,
+    its PNR localisation and LTA edit-distance bookkeeping and its validate.py loops are PINNED by
+    tests/golden/meters.pt and tests/golden/validate.pt (``oracle/make_golden_meters.py``); the absent packages
+    torchmetrics 0.11 / editdistance 0.6 are restated from their published definitions: **parity unpinned** for
+    those leaves beyond the known-answer tests in tests/test_meters_cpu.py.
 """

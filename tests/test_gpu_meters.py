@@ -1,0 +1,207 @@
+"""Validation meters and loops on the GPU: the two metric kernels against the CPU oracle, the
+meters against the reference-generated fixture (tests/golden/meters.pt) and the validation loops against what the
+reference's validate.py handed to ``meter.update`` on the same models and batches (tests/golden/validate.pt)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import meters as OM  # noqa: E402
+
+DEV = "cuda"
+TRN_CFG = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": 40}
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import egopack_amd.data as data
+    import egopack_amd.meters as meters
+    import egopack_amd.ops as ops
+    import egopack_amd.validate as validate
+    from egopack_amd.models import Graph
+    from egopack_amd.models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+
+    class NS:
+        pass
+    ns = NS()
+    ns.__dict__.update(locals())
+    return ns
+
+
+class _DS:
+    label_names = ["verbs", "nouns"]
+    class_labels = [[f"v{i}" for i in range(7)], [f"n{i}" for i in range(11)]]
+
+
+@pytest.mark.parametrize("rows,C", [(1, 2), (37, 7), (300, 478), (513, 115), (64, 1000)])
+def test_label_rank_kernel_equals_oracle(M, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    scores = (torch.randint(-4, 5, (rows, C), generator=g).float() / 2)  # few distinct values: ties
+    labels = torch.randint(-1, C, (rows,), generator=g)
+    scores[0, 0] = float("nan")
+    pad = torch.full((rows, C + 3), 99.0)  # a padded row stride (logits are stored with ld % 8 == 0)
+    pad[:, :C] = scores
+    rank = M.meters.label_rank(pad.to(DEV)[:, :C], labels.to(DEV)).cpu().numpy()
+    np.testing.assert_array_equal(rank, OM.label_rank(scores.numpy(), labels.numpy()))
+
+
+@pytest.mark.parametrize("N,Z,K", [(1, 1, 1), (5, 20, 5), (64, 20, 5), (3, 64, 2), (7, 0, 3)])
+def test_edit_distance_kernel_equals_oracle(M, N, Z, K):
+    g = torch.Generator().manual_seed(N * 100 + Z)
+    pred = torch.randint(0, 4, (N, Z, K), generator=g)
+    label = torch.randint(0, 4, (N, Z), generator=g)
+    if Z:
+        pred[0, :, 0] = label[0]
+    out = M.meters.edit_distances(pred.to(DEV), label.to(DEV)).cpu()
+    ref = torch.tensor([[OM.levenshtein(pred[n, :, k].tolist(), label[n].tolist()) for k in range(K)] for n in range(N)],
+                       dtype=torch.int32).reshape(N, K)
+    assert torch.equal(out, ref)
+
+
+def test_recognition_meter_matches_reference_topk_functions(M, golden):
+    g = golden("meters")["topk"]
+    scores, labels = g["scores"], g["labels"]
+    noun_scores = torch.randn(scores.shape[0], 11)
+    y = torch.stack([labels, torch.full_like(labels, -1)], 1)  # nouns all ignored
+    class DS11(_DS):  # the fixture's score matrix has 11 classes
+        class_labels = [[f"v{i}" for i in range(11)], [f"n{i}" for i in range(11)]]
+    m = M.meters.RecognitionMeter(DS11(), device=DEV)
+    half = scores.shape[0] // 2
+    for sl in (slice(0, half), slice(half, None)):  # two updates accumulate
+        m.update((scores[sl].to(DEV), noun_scores[sl].to(DEV)), y[sl].to(DEV), torch.tensor(0.25, device=DEV))
+    logs = m.get_logs()
+    for k, acc in zip(g["ks"], g["accuracy"]):
+        assert logs[f"verbs_top{k}"] == pytest.approx(acc, abs=1e-12)
+    assert logs["verbs_mc"] == pytest.approx(g["recall"][1], abs=1e-12)
+    assert m.verbs.mean_class(5) == pytest.approx(g["recall"][5], abs=1e-12)
+    assert float(logs["verbs_class_acc"]["top-1"][3]) == pytest.approx(g["class3"][0], abs=1e-12)
+    assert logs["nouns_top1"] == 0.0 and logs["loss"] == pytest.approx(0.25) and m.counter == scores.shape[0]
+
+
+def test_pnr_meter_matches_reference_meter_and_oracle(M, golden):
+    g = golden("meters")["pnr"]
+    gen = torch.Generator().manual_seed(5)
+    y = (torch.rand(g["logits"].shape[0], generator=gen) < 0.3).long()
+    m = M.meters.PNRMeter(device=DEV)
+    m.update(g["logits"].to(DEV), y.to(DEV), g["batch"].to(DEV), g["start_frame"], g["end_frame"], g["pnr_frame"],
+             torch.tensor([0.5, 1.5], device=DEV))
+    logs = m.get_logs()
+    assert logs["localization_error"] == pytest.approx(float(g["loc_errors"].mean()), abs=1e-9)
+    probs = torch.sigmoid(g["logits"]).numpy()
+    s = OM.binary_stats(probs, y.numpy())
+    assert logs["accuracy"] == pytest.approx(s["accuracy"]) and logs["recall"] == pytest.approx(s["recall"])
+    assert logs["auroc"] == pytest.approx(OM.binary_auroc(probs, y.numpy()), abs=1e-12)
+    assert logs["loss"] == pytest.approx(1.0)
+
+
+def test_lta_meter_matches_reference_meter(M, golden):
+    g = golden("meters")["lta"]
+    gen = torch.Generator().manual_seed(6)
+    logits = (torch.randn(g["labels"].shape[0], 7, generator=gen), torch.randn(g["labels"].shape[0], 11, generator=gen))
+    m = M.meters.LTAMeter(_DS(), device=DEV)
+    m.update(tuple(l.to(DEV) for l in logits), g["labels"].to(DEV), [p.to(DEV) for p in g["predictions"]], torch.tensor(0.1, device=DEV))
+    dv, dn = m.last_distances
+    np.testing.assert_allclose(dv.cpu().numpy(), g["verbs"].numpy(), atol=1e-12)
+    np.testing.assert_allclose(dn.cpu().numpy(), g["nouns"].numpy(), atol=1e-12)
+    logs = m.get_logs()
+    assert logs["verbs_ed"] == pytest.approx(float(g["verbs"].mean()), abs=1e-12)
+    assert logs["verbs_top1"] == pytest.approx(OM.multiclass_accuracy(logits[0].numpy(), g["labels"][:, 0].numpy(), 1))
+
+
+def _to_data(M, d):
+    b = M.data.Data(**{k: v for k, v in d.items()})
+    n = b.x.shape[0]
+    b.graph = M.data.build_csr(b.edge_index, n)
+    counts = torch.bincount(b.batch, minlength=b.num_graphs)
+    b.ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)])
+    b.ptr32 = b.ptr.to(torch.int32)
+    return b
+
+
+class _Recorder:
+    def __init__(self):
+        self.calls = []
+
+    def update(self, *args):
+        self.calls.append(args)
+
+
+@pytest.mark.parametrize("kind", ["ar", "oscc", "pnr", "lta"])
+def test_validate_loops_feed_the_meter_what_the_reference_does(M, golden, kind):
+    G = golden("validate")
+    F_IN, S, H, HP, HEADS = G["dims"]
+    model = M.Graph(F_IN, hidden_size=H, depth=2, temporal_pooling=TRN_CFG, num_segments=S)
+    model.load_state_dict(G["sd"]["model"])
+    task = {"ar": lambda: M.RecognitionTask(H, H, HEADS), "lta": lambda: M.LTATask(H, H, HEADS), "pnr": lambda: M.PNRTask(H, H),
+            "oscc": lambda: M.OSCCTask(H, H)}[kind]()
+    task.load_state_dict(G["sd"][kind])
+    model, task = model.to(DEV), task.to(DEV)
+    batches = [_to_data(M, d) for d in G[kind]["batches"]]
+    rec = _Recorder()
+    tol = dict(rtol=2e-4, atol=2e-4)
+    with M.ops.compute_mode("f32"):
+        if kind in ("ar", "oscc"):
+            M.validate.validate(0, model, batches, rec, task, device=DEV)
+        elif kind == "pnr":
+            M.validate.validate_pnr(model, batches, rec, task, device=DEV)
+        else:
+            M.validate.validate_lta(model, batches, rec, task, device=DEV)
+    assert len(rec.calls) == len(G[kind]["calls"])
+    assert not model.training and not task.training
+    for got, ref in zip(rec.calls, G[kind]["calls"]):
+        logits, ref_logits = got[0], ref[0]
+        if isinstance(ref_logits, (list, tuple)):
+            for a, b in zip(logits, ref_logits):
+                torch.testing.assert_close(a.float().cpu(), b, **tol)
+        else:
+            torch.testing.assert_close(logits.float().cpu().reshape(b_shape := ref_logits.shape), ref_logits, **tol)
+        assert torch.equal(got[1].cpu(), ref[1])  # labels
+        if kind in ("ar", "oscc"):
+            torch.testing.assert_close(got[2].float().cpu(), ref[2], **tol)  # mean loss
+            torch.testing.assert_close(got[3].float().cpu(), ref[3], **tol)  # pre-features (segment mean of x)
+            torch.testing.assert_close(got[4].float().cpu(), ref[4], **tol)  # post-features
+        elif kind == "pnr":
+            torch.testing.assert_close(got[6].float().cpu(), ref[6], **tol)  # per-node BCE loss vector
+            for i in (3, 4, 5):
+                assert torch.equal(got[i].cpu(), ref[i])
+        else:
+            preds = got[2]
+            assert len(preds) == 2 and all(p.shape == r.shape and p.dtype == torch.int64 for p, r in zip(preds, ref[2]))
+            assert all(int(p.min()) >= 0 and int(p.max()) < c for p, c in zip(preds, HEADS))  # samples are class ids
+            torch.testing.assert_close(got[3].float().cpu(), ref[3], **tol)
+
+
+def test_lta_sampling_follows_the_logits(M):
+    """generate_from_logits draws K categorical samples per node: with one dominant class they must all be it."""
+    task = M.LTATask(32, 32, (7, 11)).to(DEV)
+    lv = torch.full((44, 7), -30.0, device=DEV)
+    lv[:, 3] = 30.0
+    ln = torch.full((44, 11), -30.0, device=DEV)
+    ln[:, 9] = 30.0
+    preds, _ = task.generate_from_logits((lv, ln))
+    assert preds[0].shape == (44, 5) and bool((preds[0] == 3).all()) and bool((preds[1] == 9).all())
+
+
+def test_validate_metrics_on_synthetic_loaders(M):
+    """The per-task validation pass of main_temporal on small synthetic loaders: every meter reports finite values in
+    range, PNR frames ride through the collation, LTA sequences use the dataset's node count."""
+    import main_temporal
+    H = 64
+    ds = {t: M.data.SyntheticTaskDataset(t, 12, 8, 3, 48, (7, 11), k=1, seed=3) for t in ("ar", "lta", "oscc", "pnr")}
+    dl = {t: M.data.build_dataloader(d, 4, False, 0, False, 1) for t, d in ds.items()}
+    b = next(iter(dl["pnr"]))
+    assert b.start_frame.shape == (4,) and bool((b.pnr_frame >= b.start_frame).all()) and bool((b.pnr_frame <= b.end_frame).all())
+    torch.manual_seed(0)
+    model = M.Graph(48, hidden_size=H, depth=2, temporal_pooling={**TRN_CFG, "hidden_size": H}, num_segments=3).to(DEV)
+    tasks = {"ar": M.RecognitionTask(H, H, (7, 11)).to(DEV), "lta": M.LTATask(H, H, (7, 11)).to(DEV),
+             "oscc": M.OSCCTask(H, H).to(DEV), "pnr": M.PNRTask(H, H).to(DEV)}
+    out = main_temporal.validate_metrics(1, model, tasks, ["ar", "lta", "oscc", "pnr"], ds, dl, DEV)
+    assert set(out) == {"ar", "lta", "oscc", "pnr"}
+    for t, logs in out.items():
+        assert all(v == v and abs(v) < 1e6 for v in logs.values()), (t, logs)
+    assert 0 <= out["ar"]["verbs_top1"] <= out["ar"]["verbs_top5"] <= 1
+    assert 0 <= out["oscc"]["accuracy"] <= 1 and 0 <= out["pnr"]["auroc"] <= 1 and out["pnr"]["localization_error"] >= 0
+    assert 0 <= out["lta"]["verbs_ed"] <= 1 and 0 <= out["lta"]["nouns_ed"] <= 1
