@@ -291,6 +291,13 @@ class BatchLoader:
         n = len(self.dataset) // self.world_size if self.world_size > 1 else len(self.dataset)
         return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
 
+    def state_dict(self) -> dict:
+        """Shuffle generator state: a resumed run draws the permutations the uninterrupted run would have drawn."""
+        return {"generator": self.gen.get_state()}
+
+    def load_state_dict(self, state: dict) -> None:
+        self.gen.set_state(state["generator"].cpu())  # (a checkpoint loaded with map_location=device moved it)
+
     def __iter__(self):
         idx = self._indices()
         for i in range(0, len(idx), self.batch_size):

@@ -155,6 +155,18 @@ def advance_rng_device(device, stride: int = 1 << 40):
     rng_device_offset(device).add_(stride)
 
 
+def get_rng_state() -> dict:
+    """State of the dropout streams (host seed / offset and the per-device replay offsets) for checkpoints."""
+    return {"seed": _rng["seed"], "offset": _rng["offset"], "device": {k: int(v.item()) for k, v in _rng_dev.items()}}
+
+
+def set_rng_state(state: dict) -> None:
+    _rng["seed"], _rng["offset"] = int(state["seed"]), int(state["offset"])
+    for k, v in state.get("device", {}).items():
+        dev = torch.device("cuda", int(k)) if k is not None else torch.device("cuda")
+        rng_device_offset(dev).fill_(int(v))
+
+
 # ---- element-type conversion ---------------------------------------------------------------------------
 def cast_raw(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Plain (non-differentiable) f32 <-> bf16 conversion on the HIP path."""

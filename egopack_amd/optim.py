@@ -38,6 +38,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_scale = 1.0
         self._hyper = None
+        self._moment_views = {}     # id(param) -> (m view, v view) once materialised
+        self._pending_state = None  # a state dict loaded before the flat buffers exist
 
     # -- construction of the flat buffers (first step, once the set of live gradients is known) -------
     def _materialise(self):
@@ -72,6 +74,7 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 p._egk_shadow = self.flat_w16[off:off + n].view(p.shape)
+                self._moment_views[id(p)] = (self.flat_m[off:off + n].view(p.shape), self.flat_v[off:off + n].view(p.shape))
                 if p.dim() == 2 and p.shape[0] % 64 and p.shape[1] % 8 == 0:
                     rows64 = (p.shape[0] + 63) // 64 * 64
                     p._egk_shadow_rows64 = self.flat_w16[off:off + rows64 * p.shape[1]].view(rows64, p.shape[1])
@@ -79,6 +82,55 @@ class FlatAdam(torch.optim.Optimizer):
         self.active = live
         self.refresh_shadows()
         self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        if self._pending_state is not None:
+            self._apply_state(self._pending_state)
+            self._pending_state = None
+
+    # -- checkpointing: the layout of torch.optim.Adam's state dict (per-parameter exp_avg / exp_avg_sq / step) -----
+    def state_dict(self):
+        """``{"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}`` with parameter indices
+        in constructor order -- loadable by torch.optim.Adam over the same parameter list and vice versa."""
+        group = self.param_groups[0]
+        state = {}
+        for i, p in enumerate(group["params"]):
+            mv = self._moment_views.get(id(p))
+            if mv is not None:
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": mv[0].detach().clone(),
+                            "exp_avg_sq": mv[1].detach().clone()}
+        if self._pending_state is not None and not state:
+            return self._pending_state
+        pg = {k: v for k, v in group.items() if k != "params"}
+        pg["params"] = list(range(len(group["params"])))
+        return {"state": state, "param_groups": [pg]}
+
+    def load_state_dict(self, state_dict):
+        """Hyper-parameters now; moments now if the flat buffers exist, otherwise when the first step builds them."""
+        pg = state_dict["param_groups"][0]
+        for k, v in pg.items():
+            if k != "params" and k in self.param_groups[0]:
+                self.param_groups[0][k] = v
+        if self.materialised:
+            self._apply_state(state_dict)
+        else:  # snapshot: the caller may keep using (or another optimizer may step) the tensors it handed in
+            self._pending_state = {"state": {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                             for i, st in state_dict["state"].items()},
+                                   "param_groups": state_dict["param_groups"]}
+            steps = [float(s["step"]) for s in state_dict["state"].values() if "step" in s]
+            self.step_count = int(max(steps)) if steps else 0
+
+    def _apply_state(self, state_dict):
+        params = self.param_groups[0]["params"]
+        steps = []
+        with torch.no_grad():
+            for i, st in state_dict["state"].items():
+                mv = self._moment_views.get(id(params[int(i)]))
+                if mv is None:
+                    continue  # saved for a parameter that receives no gradient in this run
+                mv[0].copy_(st["exp_avg"])
+                mv[1].copy_(st["exp_avg_sq"])
+                steps.append(float(st["step"]))
+        if steps:
+            self.step_count = int(max(steps))
 
     def refresh_shadows(self):
         """Re-derive the bf16 operand copies from the f32 parameters (after load_state_dict or any other

@@ -87,27 +87,54 @@ def build_scheduler(cfg, optimizer):
     return sched
 
 
-def save_checkpoint(path: Path, model, tasks, epoch: int, graphone=None, optimizer=None):
-    """Reference key layout (main_temporal.py:410-417, main_egopack.py:453-460) + optional optimiser state."""
+def save_checkpoint(path: Path, model, tasks, epoch: int, graphone=None, optimizer=None, scheduler=None, loaders=None):
+    """Reference key layout (main_temporal.py:410-417, main_egopack.py:453-460) + what the reference does not keep and
+    a resumed run needs: the optimiser state (torch.optim.Adam's per-parameter layout) and the schedule state."""
     path.parent.mkdir(parents=True, exist_ok=True)
     ckpt = {"temporal_graph": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "epoch": epoch}
     for t, key in CKPT_KEYS.items():
         ckpt[key] = {k: v.detach().cpu().clone() for k, v in tasks[t].state_dict().items()}
     if graphone is not None:
         ckpt["graphone"] = {k: v.detach().cpu().clone() for k, v in graphone.state_dict().items()}
-    if optimizer is not None and getattr(optimizer, "materialised", False):
-        ckpt["optimizer"] = {"m": optimizer.flat_m.cpu(), "v": optimizer.flat_v.cpu(), "step": optimizer.step_count}
-    torch.save(ckpt, path)
+    if optimizer is not None:
+        sd = optimizer.state_dict()
+        sd["state"] = {i: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in sd["state"].items()}
+        ckpt["optimizer"] = sd
+    if scheduler is not None:
+        ckpt["scheduler"] = scheduler.state_dict()
+    if loaders is not None:  # shuffle generators of the training loaders + dropout streams: exact continuation
+        ckpt["rng"] = {"loaders": {t: dl.state_dict() for t, dl in loaders.items() if hasattr(dl, "state_dict")},
+                       "dropout": ops.get_rng_state(), "torch": torch.get_rng_state()}
+    tmp = path.with_suffix(path.suffix + ".tmp")
+    torch.save(ckpt, tmp)
+    tmp.replace(path)  # a killed run never leaves a half-written checkpoint behind
     logger.info("saved %s", path)
 
 
-def load_checkpoint(path, model, tasks, strict_tasks: bool = True, device="cpu"):
+def load_checkpoint(path, model, tasks, strict_tasks: bool = True, device="cpu", graphone=None, optimizer=None,
+                    scheduler=None, loaders=None):
+    """Weights (reference layout; a reference checkpoint loads as it is) and, when given and present, GraphONE,
+    optimiser and schedule state.  Returns the checkpoint dict (``["epoch"]`` = last finished epoch)."""
     ckpt = torch.load(path, map_location=device, weights_only=False)
     model.load_state_dict(ckpt["temporal_graph"])
     for t, key in CKPT_KEYS.items():
         if ckpt.get(key) is not None:
             tasks[t].load_state_dict(ckpt[key], strict=strict_tasks)
-    return ckpt  # NOTE: after FlatAdam has materialised, follow a load with optimizer.refresh_shadows()
+    if graphone is not None and ckpt.get("graphone") is not None:
+        graphone.load_state_dict(ckpt["graphone"])
+    if optimizer is not None and ckpt.get("optimizer") is not None:
+        optimizer.load_state_dict(ckpt["optimizer"])
+        if getattr(optimizer, "materialised", False):
+            optimizer.refresh_shadows()  # the bf16 operand copies follow the f32 parameters just loaded
+    if scheduler is not None and ckpt.get("scheduler") is not None:
+        scheduler.load_state_dict(ckpt["scheduler"])
+    if loaders is not None and ckpt.get("rng") is not None:
+        for t, st in ckpt["rng"]["loaders"].items():
+            if t in loaders and hasattr(loaders[t], "load_state_dict"):
+                loaders[t].load_state_dict(st)
+        ops.set_rng_state(ckpt["rng"]["dropout"])
+        torch.set_rng_state(ckpt["rng"]["torch"].cpu())
+    return ckpt
 
 
 def setup_logging(rank: int):

@@ -124,16 +124,24 @@ def main(argv=None):
     step = engine.MTLStep(model, tasks, T.build_criteria(dsets_train), weights, optimizer,
                           fused_backbone=cfg.fused_backbone, sync=sync)
 
-    for epoch in range(1, cfg.num_epochs + 1):
+    first_epoch = 1
+    ckpt_path = Path(cfg.checkpoint_dir) / artifact / "checkpoint.pth"
+    if cfg.resume_from:  # continue an interrupted run: weights, Adam moments, schedule, epoch counter
+        ck = T.load_checkpoint(cfg.resume_from, model, tasks, strict_tasks=True, device=device, optimizer=optimizer,
+                               scheduler=scheduler, loaders=dl_train)
+        first_epoch = int(ck.get("epoch", 0)) + 1
+        logger.info("resumed from %s at epoch %d", cfg.resume_from, first_epoch)
+    for epoch in range(first_epoch, cfg.num_epochs + 1):
         train(epoch, step, dl_train, weights, device)
         scheduler.step()
         logger.info("learning rate -> %.6g", scheduler.get_last_lr()[0])
+        if cfg.save_model and cfg.get("save_every", 0) and epoch % cfg.save_every == 0 and rank == 0:
+            T.save_checkpoint(ckpt_path, model, tasks, epoch, optimizer=optimizer, scheduler=scheduler, loaders=dl_train)
         if epoch >= cfg.num_epochs - 5 and rank == 0:
             logger.info("validation losses: %s", validate_losses(step, dl_val, device))
             validate_metrics(epoch, model, tasks, step.enabled, dsets_val, dl_val, device)
     if cfg.save_model and rank == 0:
-        T.save_checkpoint(Path(cfg.checkpoint_dir) / artifact / "checkpoint.pth", model, tasks, cfg.num_epochs,
-                          optimizer=optimizer)
+        T.save_checkpoint(ckpt_path, model, tasks, cfg.num_epochs, optimizer=optimizer, scheduler=scheduler, loaders=dl_train)
     if world > 1:
         torch.distributed.destroy_process_group()
 

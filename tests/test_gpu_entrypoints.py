@@ -32,3 +32,70 @@ def test_main_temporal_then_main_egopack(tmp_path):
     # the backbone moved (backprop_temporal_graph defaults to true), the frozen banks did not
     moved = sum((ego["temporal_graph"][k] - ckpt["temporal_graph"][k]).abs().sum() for k in ckpt["temporal_graph"])
     assert moved > 0
+
+
+def test_flat_adam_state_dict_round_trip_and_torch_interchange():
+    """FlatAdam.state_dict() has torch.optim.Adam's per-parameter layout: a torch Adam on copies of the parameters
+    loads it and both continue identically; a FlatAdam that loads a state BEFORE its flat buffers exist applies it
+    when the first step builds them."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(33, 16), (16,), (70, 8), (5,)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(5)]
+
+    def run(opt, params, its):
+        for it in its:
+            for p, gr in zip(params, grads[it]):
+                if p.grad is None:
+                    p.grad = gr.clone().to(p.device)
+                else:
+                    p.grad.copy_(gr)
+            opt.step()
+
+    a = [p.clone().cuda().requires_grad_(True) for p in ps]
+    opt_a = FlatAdam(a, lr=1e-2, weight_decay=1e-3)
+    run(opt_a, a, range(3))
+    sd = opt_a.state_dict()
+    assert set(sd["state"]) == {0, 1, 2, 3} and sd["state"][0]["exp_avg"].shape == (33, 16) and float(sd["state"][2]["step"]) == 3
+    # torch.optim.Adam continues from it
+    t = [p.detach().clone().cpu().requires_grad_(True) for p in a]
+    opt_t = torch.optim.Adam(t, lr=1e-2, weight_decay=1e-3)
+    opt_t.load_state_dict({"state": {i: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in sd["state"].items()},
+                           "param_groups": sd["param_groups"]})
+    # a fresh FlatAdam loads it before materialising
+    b = [p.detach().clone().requires_grad_(True) for p in a]
+    opt_b = FlatAdam(b, lr=1.0)  # wrong lr on purpose: the loaded param_groups must win
+    opt_b.load_state_dict(sd)
+    assert opt_b.step_count == 3 and opt_b.param_groups[0]["lr"] == 1e-2
+    run(opt_a, a, range(3, 5))
+    run(opt_t, t, range(3, 5))
+    run(opt_b, b, range(3, 5))
+    for pa, pt, pb in zip(a, t, b):
+        assert torch.equal(pa.detach(), pb.detach())  # resumed == uninterrupted, bitwise
+        torch.testing.assert_close(pa.detach().cpu(), pt.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.timeout(600)
+def test_main_temporal_resume_equals_uninterrupted_run(tmp_path):
+    """3 epochs in one go == 2 epochs, checkpoint (weights + Adam moments + schedule), resume, 1 more epoch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import main_temporal
+    base = ["k=1", "batch_size=4", "synthetic_samples=16", "model.hidden_size=64", "model.temporal_pooling.hidden_size=64",
+            "oscc_feat_size=64", "save_model=True", "compute=f32", "optimizer.lr=1e-3", "enabled_tasks=[ar,pnr]",
+            "lr_scheduler.T_max=3"]  # (dropout stays on: its streams are part of the checkpoint)
+    main_temporal.main(base + ["num_epochs=3", f"checkpoint_dir={tmp_path / 'full'}"])
+    main_temporal.main(base + ["num_epochs=2", f"checkpoint_dir={tmp_path / 'part'}"])
+    part = tmp_path / "part" / "MTL_ar-pnr" / "checkpoint.pth"
+    ck = torch.load(part, weights_only=False)
+    assert ck["epoch"] == 2 and "optimizer" in ck and "scheduler" in ck
+    main_temporal.main(base + ["num_epochs=3", f"checkpoint_dir={tmp_path / 'resumed'}", f"resume_from={part}"])
+    full = torch.load(tmp_path / "full" / "MTL_ar-pnr" / "checkpoint.pth", weights_only=False)
+    res = torch.load(tmp_path / "resumed" / "MTL_ar-pnr" / "checkpoint.pth", weights_only=False)
+    assert res["epoch"] == 3
+    for key in ("temporal_graph", "task/recognition", "task/pnr"):
+        for k, v in full[key].items():
+            torch.testing.assert_close(res[key][k], v, rtol=0, atol=0, msg=lambda s: f"{key}.{k}: {s}")
