@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--no-fused-backbone", action="store_true")
     ap.add_argument("--serial-heads", action="store_true", help="run the task heads on the main stream")
+    ap.add_argument("--feature-store", type=int, default=0, metavar="ROWS",
+                    help="assemble every step's input block inside the step from a device-resident feature store of ROWS rows "
+                         "(egk_gather_rows on a fixed index matrix, captured with the step): the input-pipeline-inclusive rate")
     ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
                     help="element type of the gradient all-reduce when --gpus > 1")
@@ -297,6 +300,16 @@ def main():
 
         def eager_step():
             step.step(dev, fused_merged)
+
+    if args.feature_store and fused_merged is not None and torch.is_tensor(fused_merged.x):
+        from egopack_amd import feature_store as FS
+        buf = fused_merged.x  # the packed [sum N, S, F] input block every task batch views
+        store = FS.FeatureStore.__new__(FS.FeatureStore)
+        store.table = torch.randn(args.feature_store, buf.shape[-1], device=device).to(buf.dtype)
+        store.rows, store.features_size, store.offsets = args.feature_store, buf.shape[-1], {}
+        gen = torch.Generator().manual_seed(3 + rank)
+        idx = torch.randint(0, args.feature_store, buf.shape[:-1], generator=gen).to(device)
+        step.input_hook = lambda: store.gather(idx, out=buf)
 
     if args.mode == "graph":
         step.capture(dev, fused_merged, warmup=2)
@@ -365,6 +378,8 @@ def main():
                        "global_batch": seqs_per_step, "nodes_per_step": seqs_per_step * args.T,
                        "parallelism": f"dp{world}", "trainable_params": n_params,
                        "grad_allreduce": (args.grad_compress if world > 1 else None),
+                       "input": (f"assembled in the step by egk_gather_rows from a resident {args.feature_store}-row feature store"
+                                 if args.feature_store else "resident in HBM before the timed region"),
                        "master_weights": "f32", "mode": args.compute,
                        "activations": "bf16" if args.compute == "bf16" else "f32"},
             "roofline": rl, "cpu_baseline": cb,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "egk_relu_gate": (C.c_int, [vp, vp, vp, vp, i64, i32]),
     "egk_cast": (C.c_int, [vp, vp, i32, vp, i32, i64]),
     "egk_tune": (C.c_int, [i32, i32]),
+    "egk_gather_rows": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, i32, i64, i32]),
     "egk_label_rank": (C.c_int, [vp, vp, i64, vp, i64, vp, i32, i32]),
     "egk_edit_distance": (C.c_int, [vp, vp, i64, i64, i64, vp, i64, i64, vp, i32, i32, i32]),
     "egk_cast_rows": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, i32, i32, i32]),

@@ -415,6 +415,49 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const S* __restrict__ sr
     }
 }
 
+// ---- resident feature store: out[i, :] = table[idx[i], :] (idx < 0 -> zeros), any f32 / bf16 pair ---------------------
+// one wave per output row, 16 bytes of the source row per lane and step; rows are 3-6 KB (1536 features), so every
+// access is a full-width coalesced instruction and the kernel streams at the rate the gathered rows arrive from HBM.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const S* __restrict__ table, long long ld,
+                                                          const long long* __restrict__ idx, D* __restrict__ out,
+                                                          long long n, int cols, long long table_rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int V = 16 / sizeof(S);  // source elements per 16 bytes
+    const bool vec = (cols % V == 0) && (ld % V == 0);
+    for (long long row = (long long)blockIdx.x * WPB + wave; row < n; row += (long long)gridDim.x * WPB) {
+        const long long src = idx[row];
+        D* o = out + row * cols;
+        if (src < 0 || src >= table_rows) {
+            for (int c = lane; c < cols; c += 64) st1t(o + c, 0.f);
+            continue;
+        }
+        const S* t = table + src * ld;
+        if (vec) {
+            for (int c = lane * V; c < cols; c += 64 * V) {
+                if constexpr (sizeof(S) == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(t + c);
+                    st4t(o, c, cols, true, v);
+                } else {
+                    const uint4 v = *reinterpret_cast<const uint4*>(t + c);
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    if constexpr (sizeof(D) == 2) {
+                        *reinterpret_cast<uint4*>(o + c) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            o[c + 2 * q] = __uint_as_float(w[q] << 16);
+                            o[c + 2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int c = lane; c < cols; c += 64) st1t(o + c, ld1t(t + c));
+        }
+    }
+}
+
 static inline int row_grid(int rows) {
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -465,6 +508,27 @@ int egk_cast_rows(egk_stream_t stream, const void* src, int32_t src_dtype, int64
     }
 #undef EGK_CR
     return check_launch("egk_cast_rows");
+}
+
+int egk_gather_rows(egk_stream_t stream, const void* table, int32_t table_dtype, int64_t ld, int64_t table_rows,
+                    const int64_t* idx, void* out, int32_t out_dtype, int64_t n, int32_t cols) {
+    EGK_REQUIRE(table && idx && out, "egk_gather_rows: null pointer");
+    EGK_REQUIRE(cols >= 1 && ld >= cols, "egk_gather_rows: bad row width / leading dimension");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long blocks = (n + WPB - 1) / WPB;
+    const dim3 grid((unsigned)(blocks > 4096 ? 4096 : blocks)), block(256);
+#define EGK_GR(S, D) hipLaunchKernelGGL((gather_rows_kernel<S, D>), grid, block, 0, s, (const S*)table, (long long)ld, (const long long*)idx, (D*)out, (long long)n, cols, (long long)table_rows)
+    if (table_dtype == EGK_F32 && out_dtype == EGK_F32) EGK_GR(float, float);
+    else if (table_dtype == EGK_F32 && out_dtype == EGK_BF16) EGK_GR(float, bf16_t);
+    else if (table_dtype == EGK_BF16 && out_dtype == EGK_BF16) EGK_GR(bf16_t, bf16_t);
+    else if (table_dtype == EGK_BF16 && out_dtype == EGK_F32) EGK_GR(bf16_t, float);
+    else {
+        set_error("egk_gather_rows: unknown element type");
+        return EGK_EINVAL;
+    }
+#undef EGK_GR
+    return check_launch("egk_gather_rows");
 }
 
 int egk_pe_add(egk_stream_t stream, const void* x, const int64_t* pos, const float* freq, void* y, int32_t rows,

@@ -164,9 +164,10 @@ class LTATemporalConnectivity:
 def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
     xs, ys, poss, eis, batch, ptr = [], [], [], [], [], [0]
     off = 0
+    resident = getattr(samples[0], "x", None) is None and getattr(samples[0], "x_idx", None) is not None
     for b, s in enumerate(samples):
-        n = s.x.shape[0]
-        xs.append(s.x)
+        n = s.pos.shape[0]
+        xs.append(s.x_idx if resident else s.x)
         poss.append(s.pos)
         ys.append(s.y if torch.is_tensor(s.y) else torch.tensor([s.y]))
         eis.append(s.edge_index + off)
@@ -174,14 +175,16 @@ def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
         off += n
         ptr.append(off)
     ei = torch.cat(eis, dim=1)
-    out = Data(x=torch.cat(xs), y=torch.cat(ys), pos=torch.cat(poss), edge_index=ei, batch=torch.cat(batch),
-               ptr=torch.tensor(ptr, dtype=torch.long), num_graphs=len(samples))
+    out = Data(x=None if resident else torch.cat(xs), y=torch.cat(ys), pos=torch.cat(poss), edge_index=ei,
+               batch=torch.cat(batch), ptr=torch.tensor(ptr, dtype=torch.long), num_graphs=len(samples))
+    if resident:  # rows of the device-resident feature store (feature_store.FeatureStore.gather builds x in HBM)
+        out.x_idx = torch.cat(xs)
     out.graph = build_csr(ei, off) if with_csr else None
     out.ptr32 = out.ptr.to(torch.int32)
     out.seg_ptr = torch.tensor([0, off], dtype=torch.int32)  # one graph-LayerNorm segment: the whole batch
     # per-sample scalar attributes (pnr_frame, start_frame, end_frame, ...) become [B] tensors, as PyG's collation
     # does for python numbers (utils/dataloading.py:56-70; read by the PNR meter)
-    known = {"x", "y", "pos", "edge_index", "batch", "ptr", "graph", "num_graphs", "ptr32", "seg_ptr"}
+    known = {"x", "x_idx", "y", "pos", "edge_index", "batch", "ptr", "graph", "num_graphs", "ptr32", "seg_ptr"}
     for key, v in vars(samples[0]).items():
         if key in known or key.startswith("_"):
             continue
@@ -370,3 +373,59 @@ class SyntheticTaskDataset:
         else:
             raise ValueError(self.task)
         return self.transform(Data(x=x, pos=pos, y=y, batch=None))
+
+
+class SyntheticResidentDataset(SyntheticTaskDataset):
+    """Synthetic counterpart of the reference's frame datasets on top of a device-resident feature store: a few
+    synthetic "videos" ([frames, F] arrays, as the reference's ``.npy`` per video) and, per sample, T action windows
+    over one of them; ``__getitem__`` does the reference's index arithmetic (feature_store.window_rows: random
+    segment sampling on ``train``, uniform otherwise) and returns ``x_idx [T, S]`` instead of ``x``.
+    ``host_item`` builds the same sample the reference's way (``np.take`` on the host) from the same random stream."""
+
+    def __init__(self, task: str, length: int, T: int, num_segments: int = 3, features_size: int = 1536,
+                 num_class_labels=(115, 478), k: int = 1, seed: int = 1, transform=None, split: str = "train",
+                 n_videos: int = 4, frames: int = 600):
+        super().__init__(task, length, T, num_segments, features_size, num_class_labels, k, seed, transform)
+        import numpy as np
+        self.split = split
+        rs = np.random.RandomState(seed)
+        self.videos = {f"video_{v}": rs.standard_normal((frames, features_size)).astype(np.float32) for v in range(n_videos)}
+        self.first_row, off = {}, 0
+        for uid, arr in self.videos.items():  # the row layout FeatureStore(self.videos) will use
+            self.first_row[uid] = off
+            off += arr.shape[0]
+        self.windows = []
+        for i in range(length):
+            uid = f"video_{int(rs.randint(n_videos))}"
+            starts = np.sort(rs.randint(0, frames - 8, size=T))
+            lens = rs.randint(0, 40, size=T)  # some windows are empty or shorter than S: the zero-clip / linspace paths
+            self.windows.append((uid, starts, starts + lens))
+        self.rng = np.random.RandomState(seed + 17)
+
+    def _labels(self, i: int):
+        d = SyntheticTaskDataset.__getitem__(self, i)  # labels / positions / edges of the parent; its x is dropped
+        d.x = None
+        return d
+
+    def _rows(self, i: int):
+        import numpy as np
+        from .feature_store import window_rows
+        uid, starts, ends = self.windows[i]
+        n = self.videos[uid].shape[0]
+        rows = [window_rows(self.first_row[uid], n, int(a), int(b), self.S, self.split == "train", self.rng)
+                for a, b in zip(starts, ends)]
+        return np.stack(rows)
+
+    def __getitem__(self, i: int) -> Data:
+        d = self._labels(i)
+        d.x_idx = torch.from_numpy(self._rows(i))
+        return d
+
+    def host_item(self, i: int) -> Data:
+        """The sample as the reference builds it: features taken on the host (consumes the same random numbers)."""
+        import numpy as np
+        d = self._labels(i)
+        rows = self._rows(i)
+        table = np.concatenate(list(self.videos.values()))
+        d.x = torch.from_numpy(np.where(rows[..., None] >= 0, table[np.maximum(rows, 0)], 0.0).astype(np.float32))
+        return d

@@ -23,25 +23,43 @@ from .dist import GradSync
 TASK_ORDER = ("ar", "lta", "oscc", "pnr")  # order of the loss terms in main_temporal.train
 
 
-def stage_batches(host, device, order=TASK_ORDER, pin: bool = True):
+def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, dtype=None):
     """Host -> device transfer of one step's task batches for the fused pass: the feature blocks are packed
     into ONE (pinned) buffer and moved with ONE copy; the returned per-task batches view row ranges of the
-    device buffer and ``merged`` exposes the whole buffer (first contraction at M = all nodes)."""
-    from .data import pack_features
+    device buffer and ``merged`` exposes the whole buffer (first contraction at M = all nodes).
+
+    With a ``feature_store.FeatureStore`` and batches that carry ``x_idx`` instead of ``x`` nothing but the index
+    matrices crosses PCIe: ONE gather launch builds the packed ``[sum N, S, F]`` buffer in HBM."""
     live = [t for t in order if host.get(t) is not None]
-    buf = pack_features([host[t] for t in live], pin=pin)
-    merged = merge_batches([host[t] for t in live])
-    dbuf = buf.to(device, non_blocking=True)
+    resident = store is not None and all(getattr(host[t], "x", None) is None and getattr(host[t], "x_idx", None) is not None
+                                         for t in live)
+    if resident:
+        idx = torch.cat([host[t].x_idx for t in live])
+        if pin and idx.device.type == "cpu":
+            idx = idx.pin_memory()
+        dbuf = store.gather(idx.to(device, non_blocking=True), dtype=dtype)
+        rows = [host[t].x_idx.shape[0] for t in live]
+    else:
+        from .data import pack_features
+        buf = pack_features([host[t] for t in live], pin=pin)
+        dbuf = buf.to(device, non_blocking=True)
+        rows = [host[t].x.shape[0] for t in live]
     dev, off = {}, 0
-    for t in live:
+    saved = {}
+    for t, n in zip(live, rows):  # move everything but the features (they are already on the device)
         b = host[t]
-        x, xb = b.x, b.x_base
-        b.x = b.x_base = None
+        saved[t] = (b.x, getattr(b, "x_base", None), getattr(b, "x_idx", None))
+        b.x = b.x_base = b.x_idx = None
         d = b.to(device, non_blocking=True)
-        b.x, b.x_base = x, xb
-        d.x = dbuf[off:off + x.shape[0]]
-        off += x.shape[0]
+        d.x = dbuf[off:off + n]
+        d.x_base = dbuf
+        off += n
         dev[t] = d
+    for t in live:  # merge on the host with the packed device buffer as the shared base
+        host[t].x, host[t].x_base = dev[t].x, dbuf
+    merged = merge_batches([host[t] for t in live])
+    for t in live:
+        host[t].x, host[t].x_base, host[t].x_idx = saved[t]
     merged.x = None
     md = merged.to(device, non_blocking=True)
     md.x = dbuf
@@ -66,6 +84,9 @@ class StepBase:
         self._static_out = None
         self._static_in = None
         self._fuse_adam = True
+        # optional launch(es) in front of every step, inside the captured graph too: e.g. the feature-store gather that
+        # materialises the step's input block from its index matrix (feature_store.FeatureStore.gather(idx, out=buffer))
+        self.input_hook = None
         # weight-gradient launches of the backbone on a side stream: pays off beside parallel task heads only
         self.wgrad_side_streams = parallel_heads and len(self.enabled) > 1
 
@@ -111,6 +132,8 @@ class StepBase:
     # ---- eager step -------------------------------------------------------------------------------------
     def forward_backward(self, batches, merged=None):
         self.optimizer.zero_grad()
+        if self.input_hook is not None:
+            self.input_hook()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         try:
             total, vectors, _ = self.losses(batches, merged)
@@ -157,6 +180,8 @@ class StepBase:
         try:
             with torch.cuda.graph(g):
                 opt.flat_g.zero_()
+                if self.input_hook is not None:
+                    self.input_hook()
                 total, vectors, _ = self.losses(batches, merged)
                 total.backward()
                 ops.join_wgrad()

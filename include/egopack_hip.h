@@ -235,6 +235,14 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
 int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
 
+/* ---- resident feature store  data/base_dataset.py:128-155, ego4d_fho.py:217-242 ----
+ * out[i, :] = table[idx[i], :] for i < n, zeros where idx[i] < 0 or >= table_rows (the reference's all-zero clip when
+ * a window cannot be sampled); table rows are ld elements apart; element types EGK_F32 / EGK_BF16 independently
+ * (bf16 -> bf16 and f32 -> f32 copy bits; f32 -> bf16 rounds to nearest even).  The device-side half of
+ * ``np.take(video_features[a:b], indices, axis=0)``: the index arithmetic stays on the host, bit-exact. */
+int egk_gather_rows(egk_stream_t s, const void* table, int32_t table_dtype, int64_t ld, int64_t table_rows,
+                    const int64_t* idx, void* out, int32_t out_dtype, int64_t n, int32_t cols);
+
 /* ---- validation metrics  utils/meters/ego4d.py, utils/meters/utils.py:6-28 ----
  * rank[r] = #{j : s[r,j] > s[r,y]} + #{j < y : s[r,j] == s[r,y]} for y = labels[r*label_stride]; -1 when y < 0
  * (ignore_index) or y >= C.  top-k accuracy = mean(rank < k) over rank >= 0; per-class recall likewise. */
