@@ -124,7 +124,7 @@ template <int NV, typename T>
 __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x, const int* __restrict__ rowptr,
                                                          const int* __restrict__ col, const float* __restrict__ wgt,
                                                          const T* __restrict__ gate, T* __restrict__ out, int rows,
-                                                         int cols) {
+                                                         int cols, int skip_above) {
     extern __shared__ __attribute__((aligned(16))) float part[];  // [3][NV*256] partial rows of waves 1..3
     __shared__ int heavy[64];
     __shared__ int n_heavy;
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
     __syncthreads();
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        if (e1 - e0 > skip_above) continue;  // listed by the host: the split launches below produce this row
         if (e1 - e0 > HEAVY) {  // deferred to the cooperative phase (wave-uniform branch) while the list has room
             int slot = lane == 0 ? atomicAdd(&n_heavy, 1) : 0;
             slot = __shfl(slot, 0, 64);
@@ -179,6 +180,72 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
             csr_finish<NV, T>(acc, wgt, 1.f / (float)(e1 - e0), gate, out, row, cols, vec, lane);
         }
         __syncthreads();
+    }
+}
+
+// ---- rows with hundreds of edges (the LTA fan-out node at T = 256 has out-degree 255) ------------------------------------
+// One such row per sequence would keep ONE workgroup busy for ~100 us of dependent index -> row round trips while
+// the rest of the chip idles.  The host lists them (data.build_csr: degree > VERY_HEAVY); each listed row is cut
+// into CSR_CHUNKS edge ranges summed by separate workgroups (thread = 4 columns, the chunk's indices fetched up
+// front, 8 neighbour rows in flight) into f32 partial rows, and a finish launch adds the partials in chunk order and
+// applies weights / mean / gate.  No atomics: bitwise reproducible.
+constexpr int VERY_HEAVY = 24, CSR_CHUNKS = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void csr_heavy_partial_kernel(const T* __restrict__ x, const int* __restrict__ rowptr,
+                                                                const int* __restrict__ col, const float* __restrict__ wgt,
+                                                                const int* __restrict__ heavy, float* __restrict__ ws,
+                                                                int cols) {
+    const int h = blockIdx.x, ch = blockIdx.y;
+    const int row = heavy[h];
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    const int per = (e1 - e0 + CSR_CHUNKS - 1) / CSR_CHUNKS;
+    const int c_begin = e0 + ch * per, c_end = min(e1, c_begin + per);
+    const bool vec = (cols & 3) == 0;
+    float* wrow = ws + ((long long)h * CSR_CHUNKS + ch) * cols;
+    for (int c0 = threadIdx.x * 4; c0 < cols; c0 += 1024) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = c_begin; e < c_end; e += 8) {
+            const int cnt = min(8, c_end - e);  // (workgroup-uniform)
+            int ci[8];
+            float w[8];
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = u < cnt ? e + u : e;
+                ci[u] = col[ee];
+                w[u] = wgt ? wgt[ee] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld4(x + (long long)ci[u] * cols, c0, cols, vec);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < cnt) {
+                    a.x += w[u] * v[u].x; a.y += w[u] * v[u].y; a.z += w[u] * v[u].z; a.w += w[u] * v[u].w;
+                }
+        }
+        if (c0 + 4 <= cols) *reinterpret_cast<float4*>(wrow + c0) = a;
+        else {
+            const float t[4] = {a.x, a.y, a.z, a.w};
+            for (int q = 0; q < 4 && c0 + q < cols; ++q) wrow[c0 + q] = t[q];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void csr_heavy_finish_kernel(const float* __restrict__ ws, const int* __restrict__ rowptr,
+                                                               const float* __restrict__ wgt, const T* __restrict__ gate,
+                                                               const int* __restrict__ heavy, T* __restrict__ out, int cols) {
+    const int h = blockIdx.x;
+    const int row = heavy[h];
+    const float mean_w = 1.f / (float)(rowptr[row + 1] - rowptr[row]);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CSR_CHUNKS; ++ch) a += ws[((long long)h * CSR_CHUNKS + ch) * cols + c];
+        if (!wgt) a *= mean_w;
+        if (gate && !(ld1t(gate + (long long)row * cols + c) > 0.f)) a = 0.f;
+        st1t(out + (long long)row * cols + c, a);
     }
 }
 
@@ -543,16 +610,31 @@ int egk_pe_add(egk_stream_t stream, const void* x, const int64_t* pos, const flo
     return check_launch("egk_pe_add");
 }
 
+int64_t egk_csr_heavy_ws_bytes(int32_t n_heavy, int32_t cols) { return (int64_t)n_heavy * CSR_CHUNKS * cols * 4; }
+
+int32_t egk_csr_heavy_threshold(void) { return VERY_HEAVY; }
+
 int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
-                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype) {
+                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
+                   int32_t n_heavy, float* ws) {
     EGK_REQUIRE(x && rowptr && out, "egk_csr_gather: null pointer");
+    EGK_REQUIRE(n_heavy == 0 || (heavy_rows && ws), "egk_csr_gather: heavy rows need their list and a workspace");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CSR_GATHER, s, 0, (dtype == EGK_BF16 ? 0.5 : 1.0) * (relu_gate ? 12.0 : 8.0) * rows * cols);
     EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
-#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows)), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols)
+    const int skip_above = n_heavy > 0 ? VERY_HEAVY : 0x7fffffff;
+#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows)), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above)
     EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
 #undef EGK_CSR
+    if (n_heavy > 0) {
+        EGK_DISPATCH_T(dtype, {
+            hipLaunchKernelGGL((csr_heavy_partial_kernel<T>), dim3(n_heavy, CSR_CHUNKS), dim3(256), 0, s, (const T*)x, rowptr, col,
+                               wgt, heavy_rows, ws, cols);
+            hipLaunchKernelGGL((csr_heavy_finish_kernel<T>), dim3(n_heavy), dim3(256), 0, s, (const float*)ws, rowptr, wgt,
+                               (const T*)relu_gate, heavy_rows, (T*)out, cols);
+        });
+    }
     return check_launch("egk_csr_gather");
 }
 

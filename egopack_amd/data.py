@@ -49,6 +49,9 @@ class Data:
         return self
 
 
+HEAVY_DEGREE = 24  # = egk_csr_heavy_threshold() (tests/test_cabi.py checks the two agree)
+
+
 @dataclass
 class CSRGraph:
     """Both orientations of an edge list as int32 CSR.
@@ -64,14 +67,20 @@ class CSRGraph:
     t_col: torch.Tensor
     t_wgt: torch.Tensor
     num_nodes: int
+    # ascending ids of the rows with more than HEAVY_DEGREE edges in each orientation (usually empty; the LTA fan-out
+    # node has out-degree T - 1): the gather kernel cuts those rows over several workgroups (egk_csr_gather)
+    heavy: Optional[torch.Tensor] = None
+    t_heavy: Optional[torch.Tensor] = None
+
+    def _map(self, f):
+        return CSRGraph(*(f(t) for t in (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)), self.num_nodes,
+                        *(f(t) if t is not None else None for t in (self.heavy, self.t_heavy)))
 
     def to(self, device, non_blocking: bool = False):
-        return CSRGraph(*(t.to(device, non_blocking=non_blocking) for t in
-                          (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)), self.num_nodes)
+        return self._map(lambda t: t.to(device, non_blocking=non_blocking))
 
     def pin_memory(self):
-        return CSRGraph(*(t.pin_memory() for t in (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)),
-                        self.num_nodes)
+        return self._map(lambda t: t.pin_memory())
 
 
 def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
@@ -89,7 +98,9 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
     t_rowptr[1:] = torch.cumsum(deg_out, 0)
     t_col = tgt[t_order]
     t_wgt = 1.0 / deg_in[t_col].clamp(min=1).to(torch.float32)
-    return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes))
+    heavy = torch.nonzero(deg_in > HEAVY_DEGREE).flatten().int()
+    t_heavy = torch.nonzero(deg_out > HEAVY_DEGREE).flatten().int()
+    return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes), heavy, t_heavy)
 
 
 # --------------------------------------------------------------------------------------------

@@ -148,9 +148,16 @@ int egk_pe_add(egk_stream_t s, const void* x, const int64_t* pos, const float* f
  * ReLU backward of SAGEConv's projection).  One launch = SAGEConv mean aggregation forward
  * (CSR by target, wgt NULL) or its backward (CSR by source, wgt = 1/deg(target)):
  * models/graph.py:42 (PyG SAGEConv.propagate + MeanAggregation).  No atomics:
- * bitwise reproducible. */
+ * bitwise reproducible.
+ * heavy_rows (may be NULL with n_heavy = 0): ascending ids of EXACTLY the rows with more than
+ * egk_csr_heavy_threshold() edges, listed by whoever built the CSR; those rows are summed by several workgroups
+ * each (edge ranges -> f32 partial rows in ws, egk_csr_heavy_ws_bytes(n_heavy, cols) bytes, -> ordered finish)
+ * instead of by one: the LTA fan-out node has out-degree T - 1. */
 int egk_csr_gather(egk_stream_t s, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
-                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype);
+                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
+                   int32_t n_heavy, float* ws);
+int64_t egk_csr_heavy_ws_bytes(int32_t n_heavy, int32_t cols);
+int32_t egk_csr_heavy_threshold(void);
 
 /* GraphONE SAGEConv(aggr='max') over cat([bank, f]) restricted to the N feature rows that are
  * kept (graphONE.py:104-115): m[n,:] = max(f[n,:], bank[nn[n,0..k),:]); arg[n,c] = winner

@@ -47,3 +47,15 @@ def test_argument_errors_are_reported_without_a_gpu():
     n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     assert lib.egk_prof_get(0, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)) == 0
     assert name.value.decode().startswith("gemm")
+
+
+def test_heavy_row_threshold_is_shared_by_the_csr_builder_and_the_kernel():
+    """data.build_csr lists EXACTLY the rows the gather kernel leaves to its split launches."""
+    from egopack_amd import _lib, data
+    assert _lib.load().egk_csr_heavy_threshold() == data.HEAVY_DEGREE
+    import torch
+    ei = torch.stack([torch.zeros(100, dtype=torch.long), torch.arange(1, 101)])  # node 0 -> 100 targets
+    g = data.build_csr(ei, 101)
+    assert g.t_heavy.tolist() == [0] and g.heavy.numel() == 0 and g.t_heavy.dtype == torch.int32
+    ei = torch.stack([torch.zeros(data.HEAVY_DEGREE, dtype=torch.long), torch.arange(1, data.HEAVY_DEGREE + 1)])
+    assert data.build_csr(ei, data.HEAVY_DEGREE + 1).t_heavy.numel() == 0  # exactly the threshold: not listed

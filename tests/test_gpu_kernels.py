@@ -784,3 +784,47 @@ def test_topk_selection_equals_full_lexicographic_sort(ops, rows, K, k):
     for r in range(rows):
         kk = min(k, int(valid[r]))
         assert nn[r, :kk].tolist() == order[r, :kk].tolist(), r
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+@pytest.mark.parametrize("T,B", [(256, 3), (70, 5), (20, 2)])
+def test_csr_gather_rows_with_hundreds_of_edges(ops, dtype, T, B):
+    """LTA connectivity at long T: the fan-out node has out-degree T - 1 (backward orientation) -- listed by
+    build_csr and cut over several workgroups by the kernel; both orientations and the gated transposed form against
+    fp64, incl. a fan-IN node (forward orientation) and rows just below / above the threshold."""
+    from egopack_amd import data as D
+    g = torch.Generator().manual_seed(T + B)
+    eis, off = [], 0
+    for b in range(B):
+        y = torch.ones(T, 2, dtype=torch.long)
+        y[:2] = -1
+        ei = D.lta_connectivity_edges(torch.arange(T), y, 1.5)
+        fan_in = torch.stack([torch.arange(3, T), torch.full((T - 3,), 2)])  # every later node -> node 2
+        eis.append(torch.cat([ei, fan_in], 1) + off)
+        off += T
+    N, H = off, 256
+    graph = D.build_csr(torch.cat(eis, 1), N)
+    if T - 4 > D.HEAVY_DEGREE:
+        assert graph.t_heavy.numel() >= B and graph.heavy.numel() >= B
+    else:
+        assert graph.t_heavy.numel() == 0 and graph.heavy.numel() == 0  # below the threshold: the in-workgroup path
+    gd = graph.to(DEV)
+    x = torch.randn(N, H, generator=g).to(dtype)
+    gate = torch.randn(N, H, generator=g).to(dtype)
+    xd, gated = x.to(DEV), gate.to(DEV)
+    A = torch.zeros(N, N, dtype=torch.float64)
+    src, tgt = torch.cat(eis, 1)
+    A.index_put_((tgt, src), torch.ones(src.numel(), dtype=torch.float64), accumulate=True)
+    deg = A.sum(1).clamp(min=1)
+    ref_f = (A / deg[:, None]) @ x.double()
+    ref_b = ((A / deg[:, None]).t() @ x.double()) * (gate.double() > 0)
+    out = torch.empty_like(xd)
+    ops._csr_gather(xd, gd.rowptr, gd.col, None, None, out, gd.heavy)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.float().cpu().double(), ref_f, **tol)
+    out2 = torch.empty_like(xd)
+    ops._csr_gather(xd, gd.t_rowptr, gd.t_col, gd.t_wgt, gated, out2, gd.t_heavy)
+    torch.testing.assert_close(out2.float().cpu().double(), ref_b, **tol)
+    out3 = torch.empty_like(xd)  # reproducible bit for bit
+    ops._csr_gather(xd, gd.t_rowptr, gd.t_col, gd.t_wgt, gated, out3, gd.t_heavy)
+    assert torch.equal(out2, out3)
