@@ -52,7 +52,7 @@ class GradSync:
         if compress not in ("none", "bf16"):
             raise ValueError(compress)
         self.world, self.group, self.compress = world_size, group, compress
-        self.chunk_elems = max(1, int(chunk_mb * (1 << 20) / 4))
+        self.chunk_elems = max(8, (int(chunk_mb * (1 << 20) / 4) + 7) // 8 * 8)  # chunk starts stay 32-byte aligned
         self._side = None
         self._g16 = None
 
@@ -90,6 +90,45 @@ class GradSync:
         else:
             for b, e in bounds:
                 dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+
+
+    def reduce_and_step(self, opt) -> None:
+        """Gradient exchange + optimizer step of a ``FlatAdam`` as a PIPELINE over chunks of the flat buffer: chunk i is
+        converted (bf16 compression) on the compute stream, all-reduced on the communication stream, and stepped by
+        its own Adam launch as soon as its collective is done -- the Adam launch of chunk i runs while chunks i+1..
+        are still on the xGMI links (the one-shot form waited for the last collective before the first Adam byte)."""
+        flat_g = opt.flat_g
+        n = flat_g.numel()
+        compress = self.compress == "bf16"
+        src = flat_g
+        if compress:
+            from . import _lib
+            from .ops import _ck, _p, _stream
+            if self._g16 is None or self._g16.numel() != n:
+                self._g16 = torch.empty(n, dtype=torch.bfloat16, device=flat_g.device)
+            src = self._g16
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=flat_g.device)
+        main = torch.cuda.current_stream(flat_g.device)
+        bounds = chunk_bounds(n, self.chunk_elems)
+        done = []
+        for b, e in bounds:
+            if compress:
+                _ck(_lib.load().egk_cast(_stream(), _p(flat_g[b:e]), 0, _p(src[b:e]), 1, e - b), "egk_cast")
+            ready = torch.cuda.Event()
+            ready.record(main)
+            self._side.wait_event(ready)
+            with torch.cuda.stream(self._side):
+                dist.all_reduce(src[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            done.append(ev)
+        opt.grad_scale = 1.0 / self.world
+        opt.prepare_hyper()
+        for (b, e), ev in zip(bounds, done):
+            main.wait_event(ev)
+            opt.launch(src, b, e)
+        opt.step_count += 1
 
 
 def sync_parameters(optimizer, sync: GradSync):

@@ -152,11 +152,10 @@ class StepBase:
         opt = self.optimizer
         if hasattr(opt, "materialised") and not opt.materialised:
             opt._materialise()
-        grads = None
         if self.sync is not None and self.sync.world > 1:
-            grads = self.sync.all_reduce_(opt.flat_g)
-            opt.grad_scale = 1.0 / self.sync.world
-        opt.step(grads=grads)
+            self.sync.reduce_and_step(opt)  # chunked: Adam of chunk i overlaps the collectives of the later chunks
+        else:
+            opt.step()
 
     # ---- hipGraph capture ---------------------------------------------------------------------------------
     def capture(self, batches: Mapping[str, Data], merged: Optional[Data] = None, warmup: int = 2):
@@ -205,9 +204,7 @@ class StepBase:
             opt.step_count += 1
         else:
             self._graph.replay()
-            grads = self.sync.all_reduce_(opt.flat_g)
-            opt.grad_scale = 1.0 / self.sync.world
-            opt.step(grads=grads)
+            self.sync.reduce_and_step(opt)
         return self._static_out[0]
 
 

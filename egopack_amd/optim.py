@@ -163,15 +163,20 @@ class FlatAdam(torch.optim.Optimizer):
         host[3] = self.grad_scale
         self._hyper.copy_(host, non_blocking=True)
 
-    def launch(self, grads=None):
+    def launch(self, grads=None, lo: int = 0, hi=None):
         """The kernel launch alone (capturable).  ``grads``: the buffer to read gradients from (default the f32
-        flat buffer; dist.GradSync hands in its bf16 copy after a compressed all-reduce)."""
+        flat buffer; dist.GradSync hands in its bf16 copy after a compressed all-reduce).  ``[lo, hi)``: element range
+        of the flat buffers to update (multiples of 8; the pipelined gradient exchange steps chunk by chunk)."""
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         grads = self.flat_g if grads is None else grads
-        _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p), _p(grads), 1 if grads.dtype == torch.bfloat16 else 0,
-                                      _p(self.flat_m), _p(self.flat_v), self.flat_p.numel(), _p(self._hyper), b1, b2,
-                                      g["eps"], g["weight_decay"], _p(self.flat_w16)),
+        hi = self.flat_p.numel() if hi is None else hi
+        if hi <= lo:
+            return
+        sl = slice(lo, hi)
+        _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p[sl]), _p(grads[sl]), 1 if grads.dtype == torch.bfloat16 else 0,
+                                      _p(self.flat_m[sl]), _p(self.flat_v[sl]), hi - lo, _p(self._hyper), b1, b2,
+                                      g["eps"], g["weight_decay"], _p(self.flat_w16[sl])),
             "egk_adam_step")
 
     @torch.no_grad()
