@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--feature-store", type=int, default=0, metavar="ROWS",
                     help="assemble every step's input block inside the step from a device-resident feature store of ROWS rows "
                          "(egk_gather_rows on a fixed index matrix, captured with the step): the input-pipeline-inclusive rate")
+    ap.add_argument("--staged", choices=["auto", "on", "off"], default="auto",
+                    help="three-stage backward with region-wise gradient exchange (auto: when there are several ranks)")
     ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
                     help="element type of the gradient all-reduce when --gpus > 1")
@@ -297,6 +299,7 @@ def main():
 
         if args.no_wgrad_streams:
             step.wgrad_side_streams = False
+        step.staged = {"auto": None, "on": True, "off": False}[args.staged]
 
         def eager_step():
             step.step(dev, fused_merged)

@@ -55,6 +55,7 @@ class GradSync:
         self.chunk_elems = max(8, (int(chunk_mb * (1 << 20) / 4) + 7) // 8 * 8)  # chunk starts stay 32-byte aligned
         self._side = None
         self._g16 = None
+        self._inflight = []
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         if self.world > 1:
@@ -91,6 +92,53 @@ class GradSync:
             for b, e in bounds:
                 dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
 
+
+    # ---- region-wise exchange for the staged backward (engine.StepBase): start() as soon as a region of the flat
+    # gradient is final, finish_and_step() after the last stage ---------------------------------------------------------
+    def start(self, opt, lo: int, hi: int) -> None:
+        """Enqueue conversion (compute stream) + all-reduce (communication stream) of flat_g[lo:hi] in chunks; the
+        compute stream goes on with the next backward stage while the collectives run."""
+        if hi <= lo:
+            return
+        flat_g = opt.flat_g
+        compress = self.compress == "bf16"
+        src = flat_g
+        if compress:
+            from . import _lib
+            from .ops import _ck, _p, _stream
+            if self._g16 is None or self._g16.numel() != flat_g.numel():
+                self._g16 = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device)
+            src = self._g16
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=flat_g.device)
+        main = torch.cuda.current_stream(flat_g.device)
+        for b in range(lo, hi, self.chunk_elems):
+            e = min(hi, b + self.chunk_elems)
+            if compress:
+                _ck(_lib.load().egk_cast(_stream(), _p(flat_g[b:e]), 0, _p(src[b:e]), 1, e - b), "egk_cast")
+            ready = torch.cuda.Event()
+            ready.record(main)
+            self._side.wait_event(ready)
+            with torch.cuda.stream(self._side):
+                dist.all_reduce(src[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            self._inflight.append((b, e, ev, src))
+
+    def finish_and_step(self, opt) -> None:
+        """Adam launch per exchanged chunk, in the order the chunks were started, each behind its collective."""
+        main = torch.cuda.current_stream(opt.flat_g.device)
+        opt.grad_scale = 1.0 / self.world
+        opt.prepare_hyper()
+        covered = 0
+        for b, e, ev, src in self._inflight:
+            main.wait_event(ev)
+            opt.launch(src, b, e)
+            covered += e - b
+        self._inflight.clear()
+        if covered != opt.flat_g.numel():
+            raise RuntimeError(f"staged gradient exchange covered {covered} of {opt.flat_g.numel()} elements")
+        opt.step_count += 1
 
     def reduce_and_step(self, opt) -> None:
         """Gradient exchange + optimizer step of a ``FlatAdam`` as a PIPELINE over chunks of the flat buffer: chunk i is

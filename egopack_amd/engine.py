@@ -84,6 +84,7 @@ class StepBase:
         self._static_out = None
         self._static_in = None
         self._fuse_adam = True
+        self._stage_state, self._cuts = None, []
         # optional launch(es) in front of every step, inside the captured graph too: e.g. the feature-store gather that
         # materialises the step's input block from its index matrix (feature_store.FeatureStore.gather(idx, out=buffer))
         self.input_hook = None
@@ -144,8 +145,56 @@ class StepBase:
         return total, vectors
 
     def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
+        if self._use_stages():
+            return self._staged_step(batches, merged)
         total, vectors = self.forward_backward(batches, merged)
         self._exchange_and_update()
+        return total.detach(), {t: v.detach() for t, v in vectors.items()}
+
+    # ---- staged backward: gradient exchange overlapped with the rest of backward --------------------------------------
+    # With several ranks the flat gradient is exchanged REGION BY REGION as backward finishes it: the task heads'
+    # region after stage A (forward + heads' backward), the SAGE stack's after stage B, the TRN's after stage C.  The
+    # stages are pieces of ONE backward pass, cut at detached leaves (the backbone output per task, the TRN output),
+    # so every gradient is what the single pass computes; each stage is its own hipGraph under capture and the
+    # collectives run between the graph launches, on the communication stream, while the next stage computes.
+    staged = None  # None: automatic (several ranks, flat buffers laid out [TRN | SAGE stack | heads]); True / False: forced
+
+    def _stage_regions(self):
+        return None  # steps that support stages return [(lo, hi) heads, (lo, hi) SAGE stack, (lo, hi) TRN]
+
+    def _use_stages(self) -> bool:
+        if self.staged is False or not getattr(self.optimizer, "materialised", False):
+            return False
+        if self.staged is None and (self.sync is None or self.sync.world <= 1):
+            return False
+        return self._stage_regions() is not None
+
+    def _exchange_region(self, region):
+        if self.sync is not None and self.sync.world > 1:
+            self.sync.start(self.optimizer, *region)
+
+    def _finish_staged(self):
+        if self.sync is not None and self.sync.world > 1:
+            self.sync.finish_and_step(self.optimizer)
+        else:
+            self.optimizer.step()
+
+    def _staged_step(self, batches, merged=None):
+        regions = self._stage_regions()
+        self.optimizer.zero_grad()
+        if self.input_hook is not None:
+            self.input_hook()
+        prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        try:
+            total, vectors = self._stage_a(batches, merged)
+            self._exchange_region(regions[0])
+            self._stage_b()
+            self._exchange_region(regions[1])
+            self._stage_c()
+            self._exchange_region(regions[2])
+        finally:
+            ops.set_wgrad_side_streams(prev)
+        self._finish_staged()
         return total.detach(), {t: v.detach() for t, v in vectors.items()}
 
     def _exchange_and_update(self):
@@ -172,6 +221,8 @@ class StepBase:
                 self.step(batches, merged)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self._use_stages():
+            return self._capture_staged(batches, merged)
         fuse_adam = self.sync is None or self.sync.world <= 1
         g = torch.cuda.CUDAGraph()
         opt.prepare_hyper()
@@ -194,10 +245,39 @@ class StepBase:
         self._static_in = (batches, merged)
         return g
 
+    def _capture_staged(self, batches, merged):
+        """Three graphs (one per backward stage) from one memory pool; the gradient exchange sits between them."""
+        opt = self.optimizer
+        gs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        try:
+            with torch.cuda.graph(gs[0]):
+                opt.flat_g.zero_()
+                if self.input_hook is not None:
+                    self.input_hook()
+                total, vectors = self._stage_a(batches, merged)
+            pool = gs[0].pool()
+            with torch.cuda.graph(gs[1], pool=pool):
+                self._stage_b()
+            with torch.cuda.graph(gs[2], pool=pool):
+                self._stage_c()
+        finally:
+            ops.set_wgrad_side_streams(prev)
+        self._graph, self._static_out, self._fuse_adam = gs, (total, vectors), False
+        self._static_in = (batches, merged, self._stage_state, self._cuts)  # everything the graphs read stays alive
+        return gs
+
     def replay(self):
-        """One training step from the captured graph."""
+        """One training step from the captured graph(s)."""
         opt = self.optimizer
         ops.advance_rng_device(opt.flat_p.device)
+        if isinstance(self._graph, list):
+            regions = self._stage_regions()
+            for g, region in zip(self._graph, regions):
+                g.replay()
+                self._exchange_region(region)
+            self._finish_staged()
+            return self._static_out[0]
         if self._fuse_adam:
             opt.prepare_hyper()
             self._graph.replay()
@@ -227,6 +307,55 @@ class MTLStep(StepBase):
         feats = self.features(batches, merged)
         vectors, logits_out = self._run_heads(feats, lambda t, feat: self._head(t, feat, batches[t]))
         return self._objective(vectors), vectors, logits_out
+
+    # ---- the three backward stages (StepBase._staged_step) ---------------------------------------------------------
+    def _stage_regions(self):
+        opt, model = self.optimizer, self.model
+        if not hasattr(opt, "region_of") or not hasattr(model, "net") or getattr(model, "temporal_pooling", None) is None:
+            return None
+        head_params = [p for t in self.enabled for p in self.tasks[t].parameters()]
+        mid_params = list(model.net.parameters())
+        mid_ids = {id(p) for p in mid_params}
+        trn_params = [p for p in model.parameters() if id(p) not in mid_ids]
+        heads, mid, trn = opt.region_of(head_params), opt.region_of(mid_params), opt.region_of(trn_params)
+        total = opt.flat_p.numel()
+        tiles = sorted(r for r in (trn, mid, heads) if r[1] > r[0])
+        ok = tiles and tiles[0][0] == 0 and tiles[-1][1] == total and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))
+        return [heads, mid, trn] if ok else None  # (any other layout: the one-piece backward + pipelined exchange)
+
+    def _stage_a(self, batches, merged):
+        """Forward, heads' forward / backward: final gradients of the head parameters + d(objective)/d(features)."""
+        self._cuts = []
+
+        def cut(x):
+            leaf = x.detach().requires_grad_(True)
+            self._cuts.append((x, leaf))
+            return leaf
+        self.model.stage_cut = cut
+        try:
+            feats = self.features(batches, merged)
+        finally:
+            self.model.stage_cut = None
+        leaves = {t: f.detach().requires_grad_(True) for t, f in feats.items()}
+        vectors, _ = self._run_heads(leaves, lambda t, feat: self._head(t, feat, batches[t]))
+        total = self._objective(vectors)
+        total.backward()
+        ops.join_wgrad()
+        self._stage_state = (feats, leaves)
+        return total, vectors
+
+    def _stage_b(self):
+        """Backbone output -> TRN output: final gradients of the SAGE stack."""
+        feats, leaves = self._stage_state
+        order = list(feats)
+        torch.autograd.backward([feats[t] for t in order], [leaves[t].grad for t in order])
+        ops.join_wgrad()
+
+    def _stage_c(self):
+        """TRN output -> inputs: final gradients of the temporal pooling."""
+        if self._cuts:
+            torch.autograd.backward([x for x, _ in self._cuts], [leaf.grad for _, leaf in self._cuts])
+            ops.join_wgrad()
 
 
 class EgoPackStep(StepBase):

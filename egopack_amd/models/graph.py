@@ -77,6 +77,11 @@ class Graph(torch.nn.Module):
             x = ops.to_act(x)
         if not hasattr(self, "net"):
             return x
+        cut = getattr(self, "stage_cut", None)
+        if cut is not None and torch.is_grad_enabled():
+            # engine-installed autograd cut at the TRN output (engine.StepBase staged backward): everything below runs
+            # on a detached leaf, so the backbone's backward can be issued in two pieces (SAGE stack, then TRN)
+            x = cut(x)
         graph = self._graph_of(data)
         seg_ptr = getattr(data, "seg_ptr", None)
         if seg_ptr is None:  # plain batch: one segment; cached on the batch (a host->device copy cannot be captured)

@@ -39,6 +39,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0
         self._hyper = None
         self._moment_views = {}     # id(param) -> (m view, v view) once materialised
+        self._slot_of = {}          # id(param) -> (first element, slot length) in the flat buffers
         self._pending_state = None  # a state dict loaded before the flat buffers exist
 
     # -- construction of the flat buffers (first step, once the set of live gradients is known) -------
@@ -75,6 +76,7 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 p._egk_shadow = self.flat_w16[off:off + n].view(p.shape)
                 self._moment_views[id(p)] = (self.flat_m[off:off + n].view(p.shape), self.flat_v[off:off + n].view(p.shape))
+                self._slot_of[id(p)] = (off, sz)
                 if p.dim() == 2 and p.shape[0] % 64 and p.shape[1] % 8 == 0:
                     rows64 = (p.shape[0] + 63) // 64 * 64
                     p._egk_shadow_rows64 = self.flat_w16[off:off + rows64 * p.shape[1]].view(rows64, p.shape[1])
@@ -85,6 +87,13 @@ class FlatAdam(torch.optim.Optimizer):
         if self._pending_state is not None:
             self._apply_state(self._pending_state)
             self._pending_state = None
+
+    def region_of(self, params) -> tuple:
+        """[lo, hi) of the flat buffers spanned by ``params`` (those that live there); (0, 0) if none does."""
+        slots = [self._slot_of[id(p)] for p in params if id(p) in self._slot_of]
+        if not slots:
+            return (0, 0)
+        return (min(o for o, _ in slots), max(o + n for o, n in slots))
 
     # -- checkpointing: the layout of torch.optim.Adam's state dict (per-parameter exp_avg / exp_avg_sq / step) -----
     def state_dict(self):

@@ -100,3 +100,37 @@ def test_adam_reads_bf16_gradients(pg):
     torch.testing.assert_close(dp.detach().cpu(), cp.detach(), rtol=1e-5, atol=1e-6)
     # the bf16 shadow the contractions read tracks the updated parameters
     torch.testing.assert_close(opt.flat_w16[:1000].float().cpu(), cp.detach().to(torch.bfloat16).float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("with_sync", [False, True])
+def test_staged_backward_equals_the_one_piece_backward(pg, golden, with_sync):
+    """The three-stage backward (heads | SAGE stack | TRN, cut at detached leaves, region-wise exchange between the
+    stages) produces the parameters of the one-piece backward BIT FOR BIT -- eager and as three captured graphs."""
+    from egopack_amd import ops
+    from egopack_amd.dist import GradSync
+
+    def run(staged, graph):
+        sync = GradSync(2, chunk_mb=0.01, compress="bf16") if with_sync else None
+        step, opt, batches = _setup(golden, sync)
+        step.staged = staged
+        if not with_sync:
+            opt.grad_scale = 0.5
+        if graph:
+            step.capture(batches, warmup=1)
+            assert isinstance(step._graph, list) == bool(staged)
+            for _ in range(2):
+                step.replay()
+        else:
+            for _ in range(3):
+                step.step(batches)
+        torch.cuda.synchronize()
+        assert opt.step_count == 3
+        if staged:
+            heads, mid, trn = step._stage_regions()
+            assert trn[0] == 0 and trn[1] == mid[0] and mid[1] == heads[0] and heads[1] == opt.flat_p.numel()
+        return opt.flat_p.clone()
+    with ops.compute_mode("f32"):
+        ref = run(False, False)
+        assert torch.equal(run(True, False), ref)
+        assert torch.equal(run(False, True), ref)
+        assert torch.equal(run(True, True), ref)
