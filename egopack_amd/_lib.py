@@ -79,6 +79,9 @@ SIGNATURES = {
     "egk_relu_gate": (C.c_int, [vp, vp, vp, vp, i64, i32]),
     "egk_cast": (C.c_int, [vp, vp, i32, vp, i32, i64]),
     "egk_tune": (C.c_int, [i32, i32]),
+    "egk_weighted_sums": (C.c_int, [vp, vp, vp, vp, i32, vp]),
+    "egk_fill_scaled_multi": (C.c_int, [vp, vp, vp, vp, vp, i32]),
+    "egk_copy_blocks": (C.c_int, [vp, vp, vp, vp, i32]),
     "egk_gather_rows": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, i32, i64, i32]),
     "egk_label_rank": (C.c_int, [vp, vp, i64, vp, i64, vp, i32, i32]),
     "egk_edit_distance": (C.c_int, [vp, vp, i64, i64, i64, vp, i64, i64, vp, i32, i32, i32]),

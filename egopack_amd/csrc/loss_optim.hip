@@ -165,6 +165,67 @@ __global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict
     }
 }
 
+// The objective of a multi-task step in ONE launch each way: out = sum_i coef_i * sum(x_i) (vectors reduced one after
+// the other by the same fixed-order tree, terms added in vector order: the values of the per-vector launches), and
+// its backward d x_i[:] = g * coef_i.  (Per task that was a chain of 1-workgroup launches separated by graph-node
+// latencies: 7 nodes for three tasks.)
+constexpr int MAXVEC = 8;
+struct VecList {
+    const float* x[MAXVEC];
+    float* out[MAXVEC];
+    long long n[MAXVEC];
+    float coef[MAXVEC];
+    int count;
+};
+
+__global__ __launch_bounds__(1024) void weighted_sums_kernel(const VecList v, float* __restrict__ out) {
+    __shared__ float part[16];
+    float total = 0.f;
+    for (int k = 0; k < v.count; ++k) {
+        float s = 0.f;
+        for (long long i = threadIdx.x; i < v.n[k]; i += 1024) s += v.x[k][i];
+        s = wave_sum(s);
+        __syncthreads();  // part[] free (previous vector consumed)
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < 16; ++i) t += part[i];
+            t *= v.coef[k];
+            total = k ? total + t : t;
+        }
+    }
+    if (threadIdx.x == 0) out[0] = total;
+}
+
+__global__ __launch_bounds__(256) void fill_scaled_multi_kernel(const float* __restrict__ scalar, const VecList v) {
+    const int k = blockIdx.y;
+    const float val = scalar[0] * v.coef[k];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < v.n[k]; i += (long long)gridDim.x * blockDim.x)
+        v.out[k][i] = val;
+}
+
+// dst = srcs[0] | srcs[1] | ... (contiguous blocks, byte sizes; a NULL source fills its block with zeros) in one launch:
+// the per-task feature gradients of the fused backbone pass go back into ONE buffer (ops._SplitRows.backward).
+struct BlockList {
+    const unsigned char* src[MAXVEC];
+    long long off[MAXVEC], bytes[MAXVEC];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void copy_blocks_kernel(const BlockList b, unsigned char* __restrict__ dst) {
+    const int k = blockIdx.y;
+    const unsigned char* s = b.src[k];
+    unsigned char* d = dst + b.off[k];
+    const long long n = b.bytes[k];
+    const bool vec = s == nullptr ? ((uintptr_t)d & 15) == 0 : (((uintptr_t)s | (uintptr_t)d) & 15) == 0;
+    const long long n16 = vec ? n / 16 : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x)
+        reinterpret_cast<uint4*>(d)[i] = s ? reinterpret_cast<const uint4*>(s)[i] : make_uint4(0, 0, 0, 0);
+    for (long long i = n16 * 16 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        d[i] = s ? s[i] : 0;
+}
+
 // ---- Adam (torch.optim.Adam single-tensor formulas, L2 weight decay) ----------------------------------------
 template <typename GT>  // GT: element type of the gradient buffer (f32, or bf16 after a compressed all-reduce)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
@@ -321,6 +382,61 @@ int egk_sum_scale(egk_stream_t stream, const float* x, float* out, int64_t n, fl
     ProfScope prof(KID_SUM_SCALE, s, 0, 4.0 * n);
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, s, x, out, (long long)n, scale, accumulate);
     return check_launch("egk_sum_scale");
+}
+
+int egk_weighted_sums(egk_stream_t stream, const float* const* xs, const int64_t* ns, const float* coefs, int32_t count,
+                      float* out) {
+    EGK_REQUIRE(xs && ns && coefs && out, "egk_weighted_sums: null pointer");
+    EGK_REQUIRE(count >= 1 && count <= MAXVEC, "egk_weighted_sums: 1..%d vectors", MAXVEC);
+    VecList v{};
+    double bytes = 0;
+    for (int k = 0; k < count; ++k) {
+        EGK_REQUIRE(xs[k] || ns[k] == 0, "egk_weighted_sums: null vector");
+        v.x[k] = xs[k]; v.n[k] = ns[k]; v.coef[k] = coefs[k];
+        bytes += 4.0 * ns[k];
+    }
+    v.count = count;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_SUM_SCALE, s, 0, bytes);
+    hipLaunchKernelGGL(weighted_sums_kernel, dim3(1), dim3(1024), 0, s, v, out);
+    return check_launch("egk_weighted_sums");
+}
+
+int egk_fill_scaled_multi(egk_stream_t stream, const float* scalar, const float* coefs, float* const* outs, const int64_t* ns,
+                          int32_t count) {
+    EGK_REQUIRE(scalar && coefs && outs && ns, "egk_fill_scaled_multi: null pointer");
+    EGK_REQUIRE(count >= 1 && count <= MAXVEC, "egk_fill_scaled_multi: 1..%d vectors", MAXVEC);
+    VecList v{};
+    long long nmax = 0;
+    for (int k = 0; k < count; ++k) {
+        EGK_REQUIRE(outs[k] || ns[k] == 0, "egk_fill_scaled_multi: null vector");
+        v.out[k] = outs[k]; v.n[k] = ns[k]; v.coef[k] = coefs[k];
+        nmax = ns[k] > nmax ? ns[k] : nmax;
+    }
+    v.count = count;
+    if (nmax == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long blocks = (nmax + 255) / 256;
+    hipLaunchKernelGGL(fill_scaled_multi_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks), count), dim3(256), 0, s, scalar, v);
+    return check_launch("egk_fill_scaled_multi");
+}
+
+int egk_copy_blocks(egk_stream_t stream, const void* const* srcs, const int64_t* nbytes, void* dst, int32_t count) {
+    EGK_REQUIRE(srcs && nbytes && dst, "egk_copy_blocks: null pointer");
+    EGK_REQUIRE(count >= 1 && count <= MAXVEC, "egk_copy_blocks: 1..%d blocks", MAXVEC);
+    BlockList b{};
+    long long off = 0, nmax = 0;
+    for (int k = 0; k < count; ++k) {
+        b.src[k] = (const unsigned char*)srcs[k]; b.off[k] = off; b.bytes[k] = nbytes[k];
+        off += nbytes[k];
+        nmax = nbytes[k] > nmax ? nbytes[k] : nmax;
+    }
+    b.count = count;
+    if (nmax == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long blocks = (nmax / 16 + 255) / 256 + 1;
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), count), dim3(256), 0, s, b, (unsigned char*)dst);
+    return check_launch("egk_copy_blocks");
 }
 
 int egk_adam_step(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,

@@ -924,26 +924,30 @@ class _WeightedMeanSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *vectors):
         _need_gpu(*vectors)
+        import ctypes as C_
         lib = _lib.load()
-        out = torch.empty(1, dtype=torch.float32, device=vectors[0].device)
-        coefs = []
-        for i, (w, v) in enumerate(zip(weights, vectors)):
-            v = _f32c(v)
-            n = v.numel()
-            coefs.append(w / max(n, 1))
-            _ck(lib.egk_sum_scale(_stream(), _p(v), _p(out), n, coefs[-1], int(i > 0)), "egk_sum_scale")
+        k = len(vectors)
+        vs = [_f32c(v) for v in vectors]
+        coefs = [w / max(v.numel(), 1) for w, v in zip(weights, vs)]
+        out = torch.empty(1, dtype=torch.float32, device=vs[0].device)
+        xs = (C_.c_void_p * k)(*[v.data_ptr() if v.numel() else None for v in vs])
+        ns = (C_.c_int64 * k)(*[v.numel() for v in vs])
+        cf = (C_.c_float * k)(*coefs)
+        _ck(lib.egk_weighted_sums(_stream(), xs, ns, cf, k, _p(out)), "egk_weighted_sums")
         ctx.coefs, ctx.shapes = coefs, [v.shape for v in vectors]
         return out.view(())
 
     @staticmethod
     def backward(ctx, g):
+        import ctypes as C_
         lib = _lib.load()
         g = _f32c(g.reshape(1))
-        grads = []
-        for coef, shape in zip(ctx.coefs, ctx.shapes):
-            d = torch.empty(shape, dtype=torch.float32, device=g.device)
-            _ck(lib.egk_fill_scaled(_stream(), _p(g), coef, _p(d), d.numel()), "egk_fill_scaled")
-            grads.append(d)
+        k = len(ctx.shapes)
+        grads = [torch.empty(shape, dtype=torch.float32, device=g.device) for shape in ctx.shapes]
+        outs = (C_.c_void_p * k)(*[d.data_ptr() if d.numel() else None for d in grads])
+        ns = (C_.c_int64 * k)(*[d.numel() for d in grads])
+        cf = (C_.c_float * k)(*ctx.coefs)
+        _ck(lib.egk_fill_scaled_multi(_stream(), _p(g), cf, outs, ns, k), "egk_fill_scaled_multi")
         return (None, *grads)
 
 
@@ -1004,20 +1008,22 @@ class _SplitRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        import ctypes as C_
         lib = _lib.load()
         dev = next(g.device for g in gs if g is not None)
         out = torch.empty(ctx.shape, dtype=ctx.dtype, device=dev)
+        row_bytes = out[0].numel() * out.element_size() if out.shape[0] else 0
+        srcs = [None if g is None else _c(_match(g, ctx.dtype)) for g in gs]
+        k = len(srcs)
+        if k <= 8:  # one launch for all slices (a copy per slice was a chain of memcpy nodes)
+            ptrs = (C_.c_void_p * k)(*[s_.data_ptr() if (s_ is not None and s_.numel()) else None for s_ in srcs])
+            nb = (C_.c_int64 * k)(*[s * row_bytes for s in ctx.sizes])
+            _ck(lib.egk_copy_blocks(_stream(), ptrs, nb, _p(out), k), "egk_copy_blocks")
+            return out, None
         off = 0
-        for s, g in zip(ctx.sizes, gs):
+        for s, g in zip(ctx.sizes, srcs):
             dst = out[off:off + s]
-            if g is None:
-                dst.zero_()
-            else:
-                g = _match(g, ctx.dtype)
-                if ctx.dtype == torch.float32:
-                    _ck(lib.egk_axpby(_stream(), _p(g), None, _p(dst), g.numel(), 1.0, 0.0), "egk_axpby")
-                else:
-                    dst.copy_(g)  # device-to-device memcpy of a contiguous block
+            dst.zero_() if g is None else dst.copy_(g)
             off += s
         return out, None
 

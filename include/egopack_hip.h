@@ -242,6 +242,16 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
 int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
 
+/* ---- the step objective in one launch each way  main_temporal.py:99-128 (torch.stack([w * l.mean() ...]).sum()) ----
+ * out[0] = sum_k coefs[k] * sum(xs[k][0..ns[k])), terms added in k order (count <= 8; xs / ns / coefs are HOST arrays);
+ * backward: outs[k][i] = scalar[0] * coefs[k]. */
+int egk_weighted_sums(egk_stream_t s, const float* const* xs, const int64_t* ns, const float* coefs, int32_t count, float* out);
+int egk_fill_scaled_multi(egk_stream_t s, const float* scalar, const float* coefs, float* const* outs, const int64_t* ns,
+                          int32_t count);
+/* dst = srcs[0] | srcs[1] | ... : count <= 8 contiguous blocks of nbytes[k] bytes each, a NULL source zero-fills its
+ * block (the per-task feature gradients back into the merged buffer of the fused backbone pass); host arrays. */
+int egk_copy_blocks(egk_stream_t s, const void* const* srcs, const int64_t* nbytes, void* dst, int32_t count);
+
 /* ---- resident feature store  data/base_dataset.py:128-155, ego4d_fho.py:217-242 ----
  * out[i, :] = table[idx[i], :] for i < n, zeros where idx[i] < 0 or >= table_rows (the reference's all-zero clip when
  * a window cannot be sampled); table rows are ld elements apart; element types EGK_F32 / EGK_BF16 independently
