@@ -128,6 +128,8 @@ _rng = {"seed": 0x5EED_E60, "offset": 0}
 def manual_seed(seed: int) -> None:
     """Seed of the Philox dropout streams (per process; ranks should use different seeds)."""
     _rng["seed"], _rng["offset"] = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+    for t in _rng_dev.values():  # the per-device replay offsets restart too: seeding twice gives the same masks twice
+        t.zero_()
 
 
 def _next_rng(n_elems: int):
