@@ -719,20 +719,68 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
 // Sum the split-K slabs in slab order (bitwise reproducible) and apply the epilogue.
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs g) {
     const long long total = (long long)g.M * g.N;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int m = (int)(idx / g.N), n = (int)(idx % g.N);
-        float s = 0.f;
-        for (int z = 0; z < g.splitk; ++z) s += g.ws[(long long)z * total + idx];
-        float o = s * g.alpha;
-        if (g.accumulate) o += ((const float*)g.C)[(long long)m * g.ldc + n];
-        if (g.bias) o += g.bias[n];
-        if (g.act == EGK_ACT_RELU) o = fmaxf(o, 0.f);
-        if (g.residual)
-            o += g.r_bf16 ? bf16_to_f32(((const bf16_t*)g.residual)[(long long)m * g.ldr + n])
-                          : ((const float*)g.residual)[(long long)m * g.ldr + n];
-        if (g.c_bf16) ((bf16_t*)g.C)[(long long)m * g.ldc + n] = f32_to_bf16(o);
-        else ((float*)g.C)[(long long)m * g.ldc + n] = o;
+    // four consecutive columns per thread, 16-byte slab loads (all slabs of an element group in flight together);
+    // rows are walked with N / 4 groups each, so no element group straddles a row
+    const bool vec4 = (g.N & 3) == 0 && g.c_vec && (!g.residual || g.r_vec);
+    if (vec4) {
+        const int gpr = g.N >> 2;  // groups per row
+        const long long groups = (long long)g.M * gpr;
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += (long long)gridDim.x * blockDim.x) {
+            const int m = (int)(q / gpr), n = (int)(q - (long long)m * gpr) * 4;
+            const long long idx = (long long)m * g.N + n;
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < g.splitk; ++z) {
+                const float4 v = *reinterpret_cast<const float4*>(g.ws + (long long)z * total + idx);
+                s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+            }
+            float o[4] = {s4.x * g.alpha, s4.y * g.alpha, s4.z * g.alpha, s4.w * g.alpha};
+            if (g.accumulate) {
+                const float4 c = *reinterpret_cast<const float4*>((const float*)g.C + (long long)m * g.ldc + n);
+                o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
+            }
+            if (g.bias) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] += g.bias[n + t];
+            }
+            if (g.act == EGK_ACT_RELU) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+            }
+            if (g.residual) {
+                if (g.r_bf16) {
+                    const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)g.residual + (long long)m * g.ldr + n);
+                    o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xffff0000u);
+                    o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xffff0000u);
+                } else {
+                    const float4 r = *reinterpret_cast<const float4*>((const float*)g.residual + (long long)m * g.ldr + n);
+                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                }
+            }
+            if (g.c_bf16) {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+                *reinterpret_cast<uint2*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
+            } else {
+                *reinterpret_cast<float4*>((float*)g.C + (long long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    } else {
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+             idx += (long long)gridDim.x * blockDim.x) {
+            const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+            float s = 0.f;
+            for (int z = 0; z < g.splitk; ++z) s += g.ws[(long long)z * total + idx];
+            float o = s * g.alpha;
+            if (g.accumulate) o += ((const float*)g.C)[(long long)m * g.ldc + n];
+            if (g.bias) o += g.bias[n];
+            if (g.act == EGK_ACT_RELU) o = fmaxf(o, 0.f);
+            if (g.residual)
+                o += g.r_bf16 ? bf16_to_f32(((const bf16_t*)g.residual)[(long long)m * g.ldr + n])
+                              : ((const float*)g.residual)[(long long)m * g.ldr + n];
+            if (g.c_bf16) ((bf16_t*)g.C)[(long long)m * g.ldc + n] = f32_to_bf16(o);
+            else ((float*)g.C)[(long long)m * g.ldc + n] = o;
+        }
     }
     if (g.dbias && g.ws_bias)
         for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < g.M; m += (long long)gridDim.x * blockDim.x) {
@@ -936,7 +984,8 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         if (g.splitk > 1) {
             ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
             const long long total = (long long)g.M * g.N;
-            hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)),
+            const long long work = (total + 3) / 4;  // element groups of 4 (the vector path; the scalar path strides)
+            hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)),
                                dim3(256), 0, s, g);
         }
         return check_launch("egk_gemm");
