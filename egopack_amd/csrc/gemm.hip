@@ -462,19 +462,22 @@ struct OperandCursor {
 // MB = 2, KG = 1: 8 waves as 4 x 2 over a 256 x 128 tile, one workgroup per CU.  A CU takes in ~70 GB/s from L2
 //         whatever the kernel does (MI355X_MICROARCH.md, gather-into-LDS table), so bytes fetched per flop bound the
 //         rate: 48 KiB per K tile for 2 x the flops of the 32 KiB of a 128 x 128 tile.  For large outputs.
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
 __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
+    // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
+    // 128-row tiling leaves the CUs unevenly loaded (6144 x 1024: 384 tiles = 1.5 per CU; 512 tiles of 96 x 128 = 2)
+    static_assert(NI == 4 || (NI == 3 && !TRA && KG == 1 && MB == 1), "96-row tiles: row-major A, plain variant");
     constexpr int IMG = 16384, IMG_A = MB * IMG, STAGE = IMG_A + IMG;
     constexpr int NPB = 4 / MB;        // B pieces per wave per tile
-    constexpr int LOADS = 4 + NPB;     // wave-instructions per wave per tile
+    constexpr int LOADS = NI + NPB;    // wave-instructions per wave per tile
     constexpr int WG = 4 * MB;         // waves per wave group
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KT = 64;
 
     int z, tm, tn;
     tile_of(g, blockIdx.x, z, tm, tn);
-    const int m0 = tm * (BM * MB), n0 = tn * BN;
+    const int m0 = tm * (32 * NI * MB), n0 = tn * BN;
     const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
     const int nt = nt_all > grp ? (nt_all - grp + KG - 1) / KG : 0;
     const int rounds = (nt_all + KG - 1) / KG;
 
-    OperandCursor<TRA, 4> ca;
+    OperandCursor<TRA, NI> ca;
     OperandCursor<TRB, NPB> cb;
     int cur_src = -1;
     auto issue = [&](int i, int stage) {  // i-th tile of this group
@@ -500,18 +503,18 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         const int src = t < nkt0 ? 0 : 1;
         if (src != cur_src) {  // (uniform) first tile, or the walk crossed from the first K source into the second
             const int k0 = (src == 0 ? t : t - nkt0) * KT;
-            ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, w * 4, lane, KG);
+            ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, w * NI, lane, KG);
             cb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, w * NPB, lane, KG);
             cur_src = src;
         }
         unsigned char* sbase = ring + stage * STAGE;
-        ca.issue(sbase, w * 4);
+        ca.issue(sbase, w * NI);
         cb.issue(sbase + IMG_A, w * NPB);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)ring;
     // row-major image: (row, chunk) -> row*128 + ((chunk ^ ((row>>1)&7)) << 4); k-step toggles bit 6, fragment i adds i*2048
     const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
-    const unsigned a_rm = (unsigned)((wm * 64 + lr) * ROWB) + rm_sw;  // (sub-images are contiguous: row r at r * 128)
+    const unsigned a_rm = (unsigned)((wm * 16 * NI + lr) * ROWB) + rm_sw;  // (sub-images are contiguous: row r at r * 128)
     const unsigned b_rm = (unsigned)((wn * 64 + lr) * ROWB) + rm_sw;
     // k-major image: lane 4q+p of a 16-lane group addresses (k-row 8*lg + q [+4 for the 2nd half] [+32 per k-step],
     // 16-B chunk = (wave offset | fragment i | p>>1) ^ f, byte (p&1)*8), f = 2q + 8*(lg&1).  The fragment index enters
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         // Fragment reads as inline asm: hipcc cannot prove that a plain ds_read does not alias the LDS-DMA writes
         // in flight and would put s_waitcnt vmcnt(0) in front of it, draining the prefetched tiles.
         const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG_A;
-        uint4 a0[4], a1[4], b0[4], b1[4];
+        uint4 a0[4], a1[4], b0[4], b1[4];  // (a*[NI..3] stay unused for 96-row tiles)
         uint4 bz[4];
         if constexpr (TRA) {
             if (do_bias) {
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a0[i]) : "v"(stA + a_rm), "n"(i * 2048));
+            for (int i = 0; i < NI; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a0[i]) : "v"(stA + a_rm), "n"(i * 2048));
         }
         if constexpr (TRB) {
 #pragma unroll
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a1[i]) : "v"((stA + a_rm) ^ 64u), "n"(i * 2048));
         }
         if constexpr (TRB) {
@@ -628,11 +631,11 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         }
         // the reads return in issue order: k-step 0 is complete when only the k-step-1 reads are outstanding
         // (lgkmcnt is a 4-bit counter: with 16 k-step-1 reads, "<= 15 outstanding" already implies the first 16 are back)
-        constexpr int R1 = ((TRA ? 8 : 4) + (TRB ? 8 : 4)) > 15 ? 15 : ((TRA ? 8 : 4) + (TRB ? 8 : 4));
+        constexpr int R1 = ((TRA ? 8 : NI) + (TRB ? 8 : 4)) > 15 ? 15 : ((TRA ? 8 : NI) + (TRB ? 8 : 4));
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R1) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0[j]),
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1[j]),
@@ -679,8 +682,8 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         }
     }
     if constexpr (KG == 1) {
-        gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
-    } else {
+        gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
+    } else if constexpr (NI == 4) {
         // Exchange: group 0 finishes rows i = 0,1 of each wave tile, group 1 rows i = 2,3.  Each group parks the half
         // it does not finish in LDS ([group][wave][i2][j][lane] f32x4, lane-contiguous 16-B stores), then adds the
         // other group's half to its own (a + b in either order: the same bits in both groups).
@@ -819,6 +822,8 @@ static void ensure_lds_attr() {
     set_lds_attr<3, false, false, 1>(); set_lds_attr<3, false, true, 1>(); set_lds_attr<3, true, true, 1>(); set_lds_attr<3, true, false, 1>();
     set_lds_attr<4, false, false, 1>(); set_lds_attr<4, false, true, 1>(); set_lds_attr<4, true, true, 1>(); set_lds_attr<4, true, false, 1>();
     set_lds_attr<2, false, false, 2>(); set_lds_attr<2, false, true, 2>(); set_lds_attr<2, true, true, 2>(); set_lds_attr<2, true, false, 2>();
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     set_lds_attr<2, false, false, 1, 2>(); set_lds_attr<2, false, true, 1, 2>(); set_lds_attr<2, true, true, 1, 2>(); set_lds_attr<2, true, false, 1, 2>();
     g_lds_attr_set = true;
 }
@@ -827,7 +832,7 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
     // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
-    // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage)
+    // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 8 the 96 x 128 tile where legal
     g_use_pipe = on;
     return prev;
 }
@@ -950,8 +955,16 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         const int nkt_slab = cdiv((d->K1 + d->K2) / 64, g.splitk);
         int variant = g_use_pipe;
         if (variant == 1) variant = nwg128 > 256 ? 3 : (nkt_slab >= 4 ? 5 : 3);
+        // 96-row tiles (8) for row-major A when they load the CUs more evenly: a CU runs its share of the tiles two at
+        // a time at a fixed intake, so the launch ends after ceil(tiles / 256) tiles' worth of bytes on the fullest CU
+        // (6144 x 1024: 2 x 32 KiB per K tile with 384 tiles of 128 rows, 2 x 28 KiB with 512 tiles of 96 rows)
+        if ((variant == 3 && g_use_pipe == 1 && !d->transA && g.splitk == 1) || g_use_pipe == 8) {
+            const long long t128 = (long long)cdiv(g.M, 128) * g.tiles_n, t96 = (long long)cdiv(g.M, 96) * g.tiles_n;
+            const long long c128 = ((t128 + 255) / 256) * 32, c96 = ((t96 + 255) / 256) * 28;
+            variant = (!d->transA && (g_use_pipe == 8 || c96 < c128)) ? 8 : (g_use_pipe == 8 ? 3 : variant);
+        }
         const int mb = variant == 6 ? 2 : 1;
-        g.tiles_m = cdiv(g.M, BM * mb);
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : cdiv(g.M, BM * mb);
         {  // near-square XCD patches: group_m ~ sqrt(workgroups per XCD), inside one slab
             const int tiles = g.tiles_m * g.tiles_n;
             int per_xcd = cdiv(tiles * g.splitk, 8);
@@ -965,7 +978,9 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
-        if (variant == 6)                                                                                                 \
+        if (variant == 8) {                                                                                               \
+            if constexpr (!TA) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 32768, s, g); \
+        } else if (variant == 6)                                                                                          \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
         else if (variant == 5)                                                                                            \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 2, 1>), pgrid, dim3(2 * NTHREADS), 4 * 32768, s, g);          \
