@@ -156,14 +156,15 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=16, budget_s=20.0):
 
 
 # library profiler name -> kernel symbol (substring) in rocprofv3 output
-def _pipe(ta, tb, kg):
-    return f"gemm_pipe_kernel<2, {ta}, {tb}, {kg}, 1>"
+def _pipe(ta, tb, kg, ni=4):
+    return f"gemm_pipe_kernel<2, {ta}, {tb}, {kg}, 1, {ni}>"
 
 
 ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pipe("false", "true", 1),
                 "gemm_bf16_tt": _pipe("true", "true", 1), "gemm_bf16_tn": _pipe("true", "false", 1),
                 "gemm_bf16_nn_g2": _pipe("false", "false", 2), "gemm_bf16_nt_g2": _pipe("false", "true", 2),
                 "gemm_bf16_tt_g2": _pipe("true", "true", 2), "gemm_bf16_tn_g2": _pipe("true", "false", 2),
+                "gemm_bf16_nn_r96": _pipe("false", "false", 1, 3), "gemm_bf16_nt_r96": _pipe("false", "true", 1, 3),
                 "gemm_bf16_generic": "gemm_kernel<true", "gemm_splitk_reduce": "gemm_splitk_reduce",
                 "adam": "adam_kernel", "csr_gather": "csr_gather_kernel"}
 

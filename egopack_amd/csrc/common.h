@@ -42,6 +42,8 @@ enum KernelId {
     KID_GEMM_BF16_NT_G2,
     KID_GEMM_BF16_TT_G2,
     KID_GEMM_BF16_TN_G2,
+    KID_GEMM_BF16_NN_R96,  // 96-row tiles (row-major A): forward Linear / dX of outputs that 128-row tiles load unevenly
+    KID_GEMM_BF16_NT_R96,
     KID_GEMM_BF16_GENERIC, // bf16 MFMA on the register-staged kernel (K not a multiple of 64, unaligned rows, f32 storage)
     KID_GEMM_SPLITK_REDUCE,
     KID_COLSUM,

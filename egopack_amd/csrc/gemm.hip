@@ -989,7 +989,8 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, g);                     \
     } while (0)
         {
-            ProfScope prof((variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
+            ProfScope prof(variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : (variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout,
+                           s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);
             else if (d->transA && d->transB) EGK_PIPE(true, true);
