@@ -165,6 +165,7 @@ ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pip
                 "gemm_bf16_nn_g2": _pipe("false", "false", 2), "gemm_bf16_nt_g2": _pipe("false", "true", 2),
                 "gemm_bf16_tt_g2": _pipe("true", "true", 2), "gemm_bf16_tn_g2": _pipe("true", "false", 2),
                 "gemm_bf16_nn_r96": _pipe("false", "false", 1, 3), "gemm_bf16_nt_r96": _pipe("false", "true", 1, 3),
+                "gemm_bf16_nn_r64": _pipe("false", "false", 1, 2), "gemm_bf16_nt_r64": _pipe("false", "true", 1, 2),
                 "gemm_bf16_generic": "gemm_kernel<true", "gemm_splitk_reduce": "gemm_splitk_reduce",
                 "adam": "adam_kernel", "csr_gather": "csr_gather_kernel"}
 

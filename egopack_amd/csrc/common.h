@@ -44,6 +44,8 @@ enum KernelId {
     KID_GEMM_BF16_TN_G2,
     KID_GEMM_BF16_NN_R96,  // 96-row tiles (row-major A): forward Linear / dX of outputs that 128-row tiles load unevenly
     KID_GEMM_BF16_NT_R96,
+    KID_GEMM_BF16_NN_R64,  // 64-row tiles: launches of at most 128 tiles of 128 rows, one 4-wave workgroup per CU
+    KID_GEMM_BF16_NT_R64,
     KID_GEMM_BF16_GENERIC, // bf16 MFMA on the register-staged kernel (K not a multiple of 64, unaligned rows, f32 storage)
     KID_GEMM_SPLITK_REDUCE,
     KID_COLSUM,

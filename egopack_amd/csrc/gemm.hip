@@ -467,8 +467,8 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
     // 128-row tiling leaves the CUs unevenly loaded (6144 x 1024: 384 tiles = 1.5 per CU; 512 tiles of 96 x 128 = 2)
-    static_assert(NI == 4 || (NI == 3 && !TRA && KG == 1 && MB == 1), "96-row tiles: row-major A, plain variant");
-    constexpr int IMG = 16384, IMG_A = MB * IMG, STAGE = IMG_A + IMG;
+    static_assert(NI == 4 || ((NI == 3 || NI == 2) && !TRA && KG == 1 && MB == 1), "96- / 64-row tiles: row-major A, plain variant");
+    constexpr int IMG = 16384, IMG_A = NI == 4 ? MB * IMG : NI * 4096, STAGE = IMG_A + IMG;
     constexpr int NPB = 4 / MB;        // B pieces per wave per tile
     constexpr int LOADS = NI + NPB;    // wave-instructions per wave per tile
     constexpr int WG = 4 * MB;         // waves per wave group
@@ -822,6 +822,8 @@ static void ensure_lds_attr() {
     set_lds_attr<3, false, false, 1>(); set_lds_attr<3, false, true, 1>(); set_lds_attr<3, true, true, 1>(); set_lds_attr<3, true, false, 1>();
     set_lds_attr<4, false, false, 1>(); set_lds_attr<4, false, true, 1>(); set_lds_attr<4, true, true, 1>(); set_lds_attr<4, true, false, 1>();
     set_lds_attr<2, false, false, 2>(); set_lds_attr<2, false, true, 2>(); set_lds_attr<2, true, true, 2>(); set_lds_attr<2, true, false, 2>();
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     set_lds_attr<2, false, false, 1, 2>(); set_lds_attr<2, false, true, 1, 2>(); set_lds_attr<2, true, true, 1, 2>(); set_lds_attr<2, true, false, 1, 2>();
@@ -832,7 +834,7 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
     // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
-    // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 8 the 96 x 128 tile where legal
+    // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 8 / 11 the 96 x 128 / 64 x 128 tile where legal (row-major A)
     g_use_pipe = on;
     return prev;
 }
@@ -954,17 +956,27 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         const int nwg128 = g.tiles_m * g.tiles_n * g.splitk;
         const int nkt_slab = cdiv((d->K1 + d->K2) / 64, g.splitk);
         int variant = g_use_pipe;
-        if (variant == 1) variant = nwg128 > 256 ? 3 : (nkt_slab >= 4 ? 5 : 3);
-        // 96-row tiles (8) for row-major A when they load the CUs more evenly: a CU runs its share of the tiles two at
-        // a time at a fixed intake, so the launch ends after ceil(tiles / 256) tiles' worth of bytes on the fullest CU
-        // (6144 x 1024: 2 x 32 KiB per K tile with 384 tiles of 128 rows, 2 x 28 KiB with 512 tiles of 96 rows)
-        if ((variant == 3 && g_use_pipe == 1 && !d->transA && g.splitk == 1) || g_use_pipe == 8) {
-            const long long t128 = (long long)cdiv(g.M, 128) * g.tiles_n, t96 = (long long)cdiv(g.M, 96) * g.tiles_n;
-            const long long c128 = ((t128 + 255) / 256) * 32, c96 = ((t96 + 255) / 256) * 28;
-            variant = (!d->transA && (g_use_pipe == 8 || c96 < c128)) ? 8 : (g_use_pipe == 8 ? 3 : variant);
+        if (variant == 1) {
+            variant = nwg128 > 256 ? 3 : (nkt_slab >= 4 ? 5 : 3);
+            if (!d->transA && g.splitk == 1) {  // row-major A: the tile height is free (MFMA row fragments per wave)
+                const long long t128 = (long long)cdiv(g.M, 128) * g.tiles_n, t96 = (long long)cdiv(g.M, 96) * g.tiles_n;
+                const long long t64 = (long long)cdiv(g.M, 64) * g.tiles_n;
+                if (nwg128 > 256) {
+                    // a CU runs its share of the tiles two at a time at a fixed intake: the launch ends after
+                    // ceil(tiles / 256) tiles' worth of bytes on the fullest CU (6144 x 1024: 2 x 32 KiB per K tile with
+                    // 384 tiles of 128 rows, 2 x 28 KiB with 512 tiles of 96 rows)
+                    if (((t96 + 255) / 256) * 28 < ((t128 + 255) / 256) * 32) variant = 8;
+                } else if (t64 <= 256 && t64 > t128) {
+                    // at most 128 tiles: 64-row tiles put one 4-wave workgroup on twice as many CUs instead of one
+                    // 8-wave (two wave groups) workgroup on half of them (2048 x 1024 x 1024: 10.6 vs 12.4 us)
+                    variant = 11;
+                }
+            }
+        } else if ((variant == 8 || variant == 11) && d->transA) {
+            variant = 3;  // the forced variants exist for row-major A only
         }
         const int mb = variant == 6 ? 2 : 1;
-        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : cdiv(g.M, BM * mb);
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : cdiv(g.M, BM * mb);
         {  // near-square XCD patches: group_m ~ sqrt(workgroups per XCD), inside one slab
             const int tiles = g.tiles_m * g.tiles_n;
             int per_xcd = cdiv(tiles * g.splitk, 8);
@@ -978,8 +990,10 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
-        if (variant == 8) {                                                                                               \
-            if constexpr (!TA) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 32768, s, g); \
+        if (variant == 11) {                                                                                              \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);                \
+        } else if (variant == 8) {                                                                                        \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);                \
         } else if (variant == 6)                                                                                          \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
         else if (variant == 5)                                                                                            \
@@ -989,8 +1003,8 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, g);                     \
     } while (0)
         {
-            ProfScope prof(variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : (variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout,
-                           s, flops, bytes);
+            ProfScope prof(variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
+                                       : (variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);
             else if (d->transA && d->transB) EGK_PIPE(true, true);

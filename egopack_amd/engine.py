@@ -66,6 +66,12 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, 
     return dev, md
 
 
+# hipGraph capture mode.  'thread_local': HIP calls of OTHER threads stay legal while this thread captures -- the
+# process-group watchdog of torch.distributed polls its events (hipEventQuery) from its own thread at any time, and
+# under the default 'global' mode that query is an error that aborts the process.
+CAPTURE_MODE = "thread_local"
+
+
 class StepBase:
     """Shared machinery of the two training steps: fused multi-task backbone pass, eager step with gradient
     exchange + flat Adam, hipGraph capture / replay.  Subclasses implement ``losses(batches, merged)`` returning
@@ -228,7 +234,7 @@ class StepBase:
         opt.prepare_hyper()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 opt.flat_g.zero_()
                 if self.input_hook is not None:
                     self.input_hook()
@@ -251,15 +257,15 @@ class StepBase:
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         try:
-            with torch.cuda.graph(gs[0]):
+            with torch.cuda.graph(gs[0], capture_error_mode=CAPTURE_MODE):
                 opt.flat_g.zero_()
                 if self.input_hook is not None:
                     self.input_hook()
                 total, vectors = self._stage_a(batches, merged)
             pool = gs[0].pool()
-            with torch.cuda.graph(gs[1], pool=pool):
+            with torch.cuda.graph(gs[1], pool=pool, capture_error_mode=CAPTURE_MODE):
                 self._stage_b()
-            with torch.cuda.graph(gs[2], pool=pool):
+            with torch.cuda.graph(gs[2], pool=pool, capture_error_mode=CAPTURE_MODE):
                 self._stage_c()
         finally:
             ops.set_wgrad_side_streams(prev)

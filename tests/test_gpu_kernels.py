@@ -632,7 +632,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
     A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
     C0 = torch.randn(M, N, device=DEV, generator=g)
     outs = {}
-    for pipe in (3, 2, 4, 6, 8, 0, 5, 1, 55):
+    for pipe in (3, 2, 4, 6, 8, 11, 0, 5, 1, 55):
         prev = lib.egk_gemm_set_pipeline(5 if pipe == 55 else pipe)
         try:
             out = C0.clone()
@@ -641,7 +641,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
             outs[pipe] = out
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    for v in (3, 2, 4, 6, 8):  # one wave group: the MFMA chain of the generic kernel, whatever the tile / ring depth
+    for v in (3, 2, 4, 6, 8, 11):  # one wave group: the MFMA chain of the generic kernel, whatever the tile / ring depth
         assert torch.equal(outs[v], outs[0]), v
     assert torch.equal(outs[5], outs[55])
     assert torch.equal(outs[1], outs[5]) or torch.equal(outs[1], outs[3])
@@ -667,7 +667,7 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     bias = torch.randn(N, device=DEV, generator=g)
     res = torch.randn(M, N, device=DEV, generator=g).to(BF)
     outs = {}
-    for pipe in (3, 6, 8, 0, 5, 1):
+    for pipe in (3, 6, 8, 11, 0, 5, 1):
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             for dt in (BF, torch.float32):
@@ -679,8 +679,8 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
             lib.egk_gemm_set_pipeline(prev)
     for dt in (BF, torch.float32):
         assert torch.equal(outs[(3, dt)], outs[(0, dt)])
-        assert torch.equal(outs[(6, dt)], outs[(0, dt)]) and torch.equal(outs[(8, dt)], outs[(0, dt)])  # 256- / 96-row tiles
-        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8))
+        assert torch.equal(outs[(6, dt)], outs[(0, dt)]) and torch.equal(outs[(8, dt)], outs[(0, dt)]) and torch.equal(outs[(11, dt)], outs[(0, dt)])  # 256- / 96- / 64-row tiles
+        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11))
     # two wave groups: even / odd K tiles summed separately
     torch.testing.assert_close(outs[(5, torch.float32)], outs[(0, torch.float32)], rtol=1e-5, atol=2e-3)
     torch.testing.assert_close(outs[(5, BF)].float(), outs[(0, BF)].float(), rtol=1e-2, atol=1e-2)

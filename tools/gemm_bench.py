@@ -52,7 +52,7 @@ def time_us(fn, iters):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
+    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
         for _ in range(iters):
             fn()
     gr.replay()

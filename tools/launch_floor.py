@@ -29,7 +29,7 @@ def time_graph(fn, n):
         fn(2)
     torch.cuda.current_stream().wait_stream(s)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         fn(n)
     g.replay()
     torch.cuda.synchronize()
