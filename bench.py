@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--feature-store", type=int, default=0, metavar="ROWS",
                     help="assemble every step's input block inside the step from a device-resident feature store of ROWS rows "
                          "(egk_gather_rows on a fixed index matrix, captured with the step): the input-pipeline-inclusive rate")
+    ap.add_argument("--exchange-dry-run", type=int, default=0, metavar="N",
+                    help="one GPU: run the N-rank gradient-exchange path (staged backward, conversion, RCCL all-reduce on a "
+                         "1-rank group, per-chunk Adam) -- everything of the N-GPU step except the time on the xGMI links")
     ap.add_argument("--staged", choices=["auto", "on", "off"], default="auto",
                     help="three-stage backward with region-wise gradient exchange (auto: when there are several ranks)")
     ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
@@ -277,6 +280,11 @@ def main():
         t.to(device).train()
     params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
     sync = edist.GradSync(world, compress=args.grad_compress) if world > 1 else None
+    if world == 1 and args.exchange_dry_run > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        sync = edist.GradSync(args.exchange_dry_run, compress=args.grad_compress)
     fused_merged = None if args.no_fused_backbone else merged
     if args.workload == "egopack_oscc":
         from egopack_amd.models.graphONE.graphONE import GraphONE
@@ -317,8 +325,26 @@ def main():
         step.input_hook = lambda: store.gather(idx, out=buf)
 
     if args.mode == "graph":
-        step.capture(dev, fused_merged, warmup=2)
-        run = step.replay
+        # capture, with fallbacks that keep the measurement alive if a capture path fails on a configuration that could
+        # not be tried on the one-GPU development box (several ranks): staged graphs -> one-piece graph -> eager
+        run = None
+        for attempt in ("as configured", "one-piece backward", "eager"):
+            try:
+                if attempt == "one-piece backward":
+                    step.staged = False
+                if attempt == "eager":
+                    args.mode = "eager"
+                    eager_step()
+                    run = eager_step
+                else:
+                    step.capture(dev, fused_merged, warmup=2)
+                    run = step.replay
+                break
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] capture ({attempt}) failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+        if run is None:
+            raise RuntimeError("bench.py: no execution mode worked")
     else:
         eager_step()  # materialise the flat buffers
         run = eager_step
@@ -391,9 +417,17 @@ def main():
         }
         if args.kernel_table and table:
             print(json.dumps(table, indent=1), file=sys.stderr)
-        print(json.dumps(out))
-    if world > 1:
+    else:
+        out = None
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if out is not None:
+        # RCCL writes a version banner to the C stdout stream (block-buffered when piped): push it out BEFORE the
+        # result so that the JSON line is the last line of rank 0's stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
