@@ -260,6 +260,9 @@ def main():
     rank, local_rank, world = edist.init_from_env()
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    if rank != 0:  # only rank 0 reports: nothing else (RCCL's C-level stdout banner included) may reach the shared stdout
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
