@@ -246,6 +246,7 @@ def main():
     ap.add_argument("--exchange-dry-run", type=int, default=0, metavar="N",
                     help="one GPU: run the N-rank gradient-exchange path (staged backward, conversion, RCCL all-reduce on a "
                          "1-rank group, per-chunk Adam) -- everything of the N-GPU step except the time on the xGMI links")
+    ap.add_argument("--head-streams", type=int, default=0, help="cap on the HIP streams the task heads are spread over (0 = one per task)")
     ap.add_argument("--staged", choices=["auto", "on", "off"], default="auto",
                     help="three-stage backward with region-wise gradient exchange (auto: when there are several ranks)")
     ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
@@ -313,6 +314,8 @@ def main():
         if args.no_wgrad_streams:
             step.wgrad_side_streams = False
         step.staged = {"auto": None, "on": True, "off": False}[args.staged]
+        if args.head_streams:
+            step.max_head_streams = args.head_streams
 
         def eager_step():
             step.step(dev, fused_merged)

@@ -117,15 +117,19 @@ class StepBase:
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event()
             fork.record(main)
-            while len(self._head_streams) < len(feats):
+            n_streams = min(len(feats), getattr(self, "max_head_streams", len(feats)))
+            while len(self._head_streams) < n_streams:
                 self._head_streams.append(torch.cuda.Stream())
                 ops.exclude_wgrad_streams(self._head_streams[-1:])
-            for st, (t, feat) in zip(self._head_streams, feats.items()):
+            used = self._head_streams[:n_streams]
+            for st in used:
                 st.wait_event(fork)
+            for i, (t, feat) in enumerate(feats.items()):
+                st = used[i % n_streams]
                 feat.record_stream(st)
                 with torch.cuda.stream(st):
                     vectors[t], extras[t] = head_fn(t, feat)
-            for st, _ in zip(self._head_streams, feats):
+            for st in used:
                 main.wait_stream(st)
         else:
             for t, feat in feats.items():
