@@ -83,6 +83,7 @@ SIGNATURES = {
     "egk_fill_scaled_multi": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     "egk_copy_blocks": (C.c_int, [vp, vp, vp, vp, i32]),
     "egk_gather_rows": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, i32, i64, i32]),
+    "egk_gather_lerp_rows": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, i32, i64, i32]),
     "egk_label_rank": (C.c_int, [vp, vp, i64, vp, i64, vp, i32, i32]),
     "egk_edit_distance": (C.c_int, [vp, vp, i64, i64, i64, vp, i64, i64, vp, i32, i32, i32]),
     "egk_cast_rows": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, i32, i32, i32]),

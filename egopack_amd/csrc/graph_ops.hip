@@ -525,6 +525,34 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const S* __restrict__ 
     }
 }
 
+// out[i, :] = table[lo[i], :] where lo[i] == hi[i] (a copy), else (float)((1 - w[i]) * table[lo[i], :] + w[i] * table[hi[i], :])
+// evaluated in double with separately rounded products and sum -- numpy's
+//     (1 - frac)[:, None] * low + frac[:, None] * high  ->  torch.from_numpy(...).float()
+// of the PNR sampling (data/ego4d_oscc.py:258-275) bit for bit; an index < 0 stands for an all-zero row.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void gather_lerp_rows_kernel(const S* __restrict__ table, long long ld,
+                                                               const long long* __restrict__ lo, const long long* __restrict__ hi,
+                                                               const double* __restrict__ w, D* __restrict__ out, long long n,
+                                                               int cols, long long table_rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long row = (long long)blockIdx.x * WPB + wave; row < n; row += (long long)gridDim.x * WPB) {
+        const long long a = lo[row], b = hi[row];
+        const bool va = a >= 0 && a < table_rows, vb = b >= 0 && b < table_rows;
+        const S* ta = table + (va ? a : 0) * ld;
+        const S* tb = table + (vb ? b : 0) * ld;
+        D* o = out + row * cols;
+        if (a == b) {
+            for (int c = lane; c < cols; c += 64) st1t(o + c, va ? ld1t(ta + c) : 0.f);
+        } else {
+            const double wb = w[row], wa = 1.0 - wb;
+            for (int c = lane; c < cols; c += 64) {
+                const double x = va ? (double)ld1t(ta + c) : 0.0, y = vb ? (double)ld1t(tb + c) : 0.0;
+                st1t(o + c, (float)__dadd_rn(__dmul_rn(wa, x), __dmul_rn(wb, y)));
+            }
+        }
+    }
+}
+
 static inline int row_grid(int rows) {
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -596,6 +624,28 @@ int egk_gather_rows(egk_stream_t stream, const void* table, int32_t table_dtype,
     }
 #undef EGK_GR
     return check_launch("egk_gather_rows");
+}
+
+int egk_gather_lerp_rows(egk_stream_t stream, const void* table, int32_t table_dtype, int64_t ld, int64_t table_rows,
+                         const int64_t* lo, const int64_t* hi, const double* w, void* out, int32_t out_dtype, int64_t n,
+                         int32_t cols) {
+    EGK_REQUIRE(table && lo && hi && w && out, "egk_gather_lerp_rows: null pointer");
+    EGK_REQUIRE(cols >= 1 && ld >= cols, "egk_gather_lerp_rows: bad row width / leading dimension");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long blocks = (n + WPB - 1) / WPB;
+    const dim3 grid((unsigned)(blocks > 4096 ? 4096 : blocks)), block(256);
+#define EGK_GL(S, D) hipLaunchKernelGGL((gather_lerp_rows_kernel<S, D>), grid, block, 0, s, (const S*)table, (long long)ld, (const long long*)lo, (const long long*)hi, w, (D*)out, (long long)n, cols, (long long)table_rows)
+    if (table_dtype == EGK_F32 && out_dtype == EGK_F32) EGK_GL(float, float);
+    else if (table_dtype == EGK_F32 && out_dtype == EGK_BF16) EGK_GL(float, bf16_t);
+    else if (table_dtype == EGK_BF16 && out_dtype == EGK_BF16) EGK_GL(bf16_t, bf16_t);
+    else if (table_dtype == EGK_BF16 && out_dtype == EGK_F32) EGK_GL(bf16_t, float);
+    else {
+        set_error("egk_gather_lerp_rows: unknown element type");
+        return EGK_EINVAL;
+    }
+#undef EGK_GL
+    return check_launch("egk_gather_lerp_rows");
 }
 
 int egk_pe_add(egk_stream_t stream, const void* x, const int64_t* pos, const float* freq, void* y, int32_t rows,

@@ -89,21 +89,42 @@ class FeatureStore:
         path = Path(path)
         return cls({uid: np.load(path / f"{uid}.npy", mmap_mode="r") for uid in video_uids}, **kw)
 
-    def gather(self, idx: torch.Tensor, out: Optional[torch.Tensor] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """x[..., :] = table[idx[...], :] (zeros where idx < 0): ``[N, S] -> [N, S, F]`` on the device."""
-        idx = idx.to(self.table.device, dtype=torch.int64, non_blocking=True).contiguous()
+    def gather(self, idx: torch.Tensor, out: Optional[torch.Tensor] = None, dtype: Optional[torch.dtype] = None,
+               hi: Optional[torch.Tensor] = None, w: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x[..., :] = table[idx[...], :] (zeros where idx < 0): ``[N, S] -> [N, S, F]`` on the device.  With ``hi`` / ``w``
+        (same shape; w float64): the interpolating form ``egk_gather_lerp_rows`` (PNR sampling, LTA 'avg' nodes)."""
+        dev = self.table.device
+        idx = idx.to(dev, dtype=torch.int64, non_blocking=True).contiguous()
         shape = (*idx.shape, self.features_size)
         if out is None:
-            out = torch.empty(shape, dtype=dtype or self.table.dtype, device=self.table.device)
+            out = torch.empty(shape, dtype=dtype or self.table.dtype, device=dev)
         elif tuple(out.shape) != shape or not out.is_contiguous():
             raise ValueError(f"FeatureStore.gather: out must be contiguous {shape}")
         ops._need_gpu(self.table, out)
         n = idx.numel()
-        if n:
-            ops._ck(_lib.load().egk_gather_rows(ops._stream(), ops._p(self.table), ops._dt(self.table), self.table.stride(0),
-                                                self.rows, ops._p(idx), ops._p(out), ops._dt(out), n, self.features_size),
-                    "egk_gather_rows")
+        if not n:
+            return out
+        lib = _lib.load()
+        if hi is None:
+            ops._ck(lib.egk_gather_rows(ops._stream(), ops._p(self.table), ops._dt(self.table), self.table.stride(0), self.rows,
+                                        ops._p(idx), ops._p(out), ops._dt(out), n, self.features_size), "egk_gather_rows")
+        else:
+            hi = hi.to(dev, dtype=torch.int64, non_blocking=True).contiguous()
+            w = w.to(dev, dtype=torch.float64, non_blocking=True).contiguous()
+            if hi.shape != idx.shape or w.shape != idx.shape:
+                raise ValueError("FeatureStore.gather: idx / hi / w shapes differ")
+            ops._ck(lib.egk_gather_lerp_rows(ops._stream(), ops._p(self.table), ops._dt(self.table), self.table.stride(0), self.rows,
+                                             ops._p(idx), ops._p(hi), ops._p(w), ops._p(out), ops._dt(out), n, self.features_size),
+                    "egk_gather_lerp_rows")
         return out
+
+    def gather_item(self, item, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """Feature block of one sample built by ``ar_item`` / ``lta_item`` / ``oscc_item`` / ``pnr_item``."""
+        lo = torch.from_numpy(np.ascontiguousarray(item["lo"]))
+        if "hi" in item:
+            return self.gather(lo, dtype=dtype, hi=torch.from_numpy(np.ascontiguousarray(item["hi"])),
+                               w=torch.from_numpy(np.ascontiguousarray(item["w"], dtype=np.float64)))
+        return self.gather(lo, dtype=dtype)
 
 
 def materialise_features(batch, store: FeatureStore, dtype: Optional[torch.dtype] = None):
@@ -111,3 +132,120 @@ def materialise_features(batch, store: FeatureStore, dtype: Optional[torch.dtype
     if getattr(batch, "x", None) is None and getattr(batch, "x_idx", None) is not None:
         batch.x = store.gather(batch.x_idx, dtype=dtype)
     return batch
+
+
+# ---- per-task sample builders: the index half of the reference datasets' ``get`` ------------------------------------
+# Each returns the sample as INDEX matrices over the resident store -- ``lo`` [T, S] (and, where the reference
+# interpolates or averages, ``hi`` [T, S] + ``w`` [T, S]: x = table[lo] if lo == hi else (1 - w) table[lo] + w table[hi]) --
+# plus labels / positions / scalar attributes exactly as the reference builds them.  -1 = the reference's all-zero clip.
+def ar_item(first_row: int, video_len: int, actions, window_size: int, stride: int, S: int, random: bool, rng=np.random):
+    """Ego4dRecognitionDataset.get (ego4d_fho.py:217-242).  ``actions``: the window's (start_frame, end_frame, verb, noun)."""
+    T = len(actions)
+    c = window_size // 2
+    y = np.full((T, 2), -1, dtype=np.int64)
+    y[c] = (actions[c][2], actions[c][3])
+    pos = np.arange(T, dtype=np.int64) - c
+    rows = np.stack([window_rows(first_row, video_len, a[0] // stride, min(video_len - 1, a[1] // stride), S, random, rng)
+                     for a in actions])
+    return {"lo": rows, "y": y, "pos": pos}
+
+
+def lta_item(first_row: int, video_len: int, input_clips, forecast_labels, n_forecast: int, stride: int, S: int, random: bool,
+             append_node: str = "avg", rng=np.random):
+    """Ego4dLTADataset.get (ego4d_fho.py:353-396): input clips sampled like AR windows (start shifted by one stride
+    unit), forecast nodes = mean of the input clips ('avg': two input clips -> a w = 1/2 interpolation), zeros
+    ('zero'), or uniform noise ('random': not index-expressible, unsupported)."""
+    n_in = len(input_clips)
+    rows = [window_rows(first_row, video_len, max(1, a[0] // stride) - 1, min(video_len - 1, a[1] // stride), S, random, rng)
+            for a in input_clips]
+    lo, hi, w = list(rows), list(rows), [np.zeros(S)] * n_in
+    if append_node == "avg":
+        if n_in != 2:
+            raise NotImplementedError("lta_item: the 'avg' forecast nodes are built for 2 input clips (the reference default)")
+        for _ in range(n_forecast):
+            lo.append(rows[0]); hi.append(rows[1]); w.append(np.full(S, 0.5))
+    elif append_node == "zero":
+        for _ in range(n_forecast):
+            lo.append(np.full(S, -1, dtype=np.int64)); hi.append(np.full(S, -1, dtype=np.int64)); w.append(np.zeros(S))
+    else:
+        raise NotImplementedError(f"lta_item: append_node={append_node!r}")
+    y = np.full((n_in + n_forecast, 2), -1, dtype=np.int64)
+    y[n_in:] = np.asarray(forecast_labels, dtype=np.int64).reshape(n_forecast, 2)
+    return {"lo": np.stack(lo), "hi": np.stack(hi), "w": np.stack(w), "y": y, "pos": np.arange(n_in + n_forecast, dtype=np.int64)}
+
+
+def oscc_item(first_row: int, video_len: int, start_frame: int, end_frame: int, pnr_frame, state_change: int, stride: int, S: int,
+              train: bool, aug_prob: float = 0.0, rng=np.random, py_random=None):
+    """Ego4dOSCCDataset.get (ego4d_oscc.py:191-223): 4 * S segments drawn from the clip (sorted random choice on
+    train, linspace otherwise), reshaped to 4 nodes; on train, with probability ``aug_prob``, a state-change clip is
+    the reference tries a frame-replacement augmentation that is not executable as written (see below; aug_prob is 0 in
+    the experiments)."""
+    import random as _random
+    py_random = py_random or _random
+    sf, ef = start_frame - (start_frame % stride), end_frame - (end_frame % stride)
+    n_segments = (ef - sf) // stride
+    n = 4 * S
+    if train:
+        sel = rng.choice(n_segments, size=n, replace=(n_segments < n))
+    else:
+        sel = np.linspace(0, n_segments, num=n, endpoint=False, dtype=int)
+    sel = np.sort(sel)
+    lo_, hi_ = min(max(sf // stride, 0), video_len), min(max(ef // stride, 0), video_len)
+    size = max(hi_ - lo_, 0)
+    if size == 0 or sel.max(initial=0) >= size:
+        rows = np.full(n, -1, dtype=np.int64)  # np.take raised -> zeros
+    else:
+        rows = (first_row + lo_ + sel).astype(np.int64)
+    rows = rows.reshape(4, S)
+    label = int(state_change)
+    if train and state_change and py_random.random() < aug_prob:  # (the reference draws the number in exactly this case)
+        # the reference's frame-replacement branch adds an ndarray and a list (``graph[:p] + [graph[p-1]] * k``) or hands
+        # torch.from_numpy a list: it cannot run as written, and configs/dataset_oscc/ego4d.yaml sets aug_prob: 0
+        raise NotImplementedError("oscc_item: the frame-replacement augmentation (aug_prob > 0) is not executable in the reference")
+    return {"lo": rows, "y": label, "pos": np.arange(rows.shape[0], dtype=np.int64)}
+
+
+def pnr_item(first_row: int, video_len: int, start_frame: int, end_frame: int, pnr_frame: int, start_sec: float, end_sec: float,
+             stride: int, T: int, train: bool, test: bool = False, rng=np.random):
+    """Ego4dPNRDataset.get (ego4d_oscc.py:238-302): T candidate frames over the (randomly cropped, on train) clip,
+    each feature interpolated between the two stored rows around it; label = one-hot of the candidate nearest to the
+    PNR frame; every node repeats its feature in the 3 segment slots."""
+    if train:
+        length = rng.uniform(5, 8)
+        start_s = start_sec + rng.uniform(8 - length)
+        start_frame_ = np.floor(start_s * 30).astype(np.int32)
+        end_s = start_s + length
+        if end_s > end_sec:
+            end_s = end_sec
+        end_frame_ = np.floor(end_s * 30).astype(np.int32)
+        if pnr_frame > end_frame_:
+            end_frame_ = end_frame
+        if pnr_frame < start_frame_:
+            start_frame_ = start_frame
+        start_frame, end_frame = start_frame_, end_frame_
+    cand = np.linspace(start_frame, end_frame, num=T, dtype=int, endpoint=False)
+    cand = np.clip(cand, start_frame, end_frame)
+    lo = np.clip(np.floor(cand / stride).astype(int), 0, video_len - 1)
+    hi = np.clip(np.ceil(cand / stride).astype(int), 0, video_len - 1)
+    w = (cand % stride) / stride
+    if test:
+        y = -np.ones(T, dtype=np.int64)
+    else:
+        y = np.zeros(T, dtype=np.int64)
+        y[int(np.abs(cand - pnr_frame).argmin())] = 1
+    rep = lambda v: np.repeat(v[:, None], 3, axis=1)
+    return {"lo": rep(first_row + lo).astype(np.int64), "hi": rep(first_row + hi).astype(np.int64), "w": rep(w), "y": y,
+            "pos": np.arange(T, dtype=np.int64), "start_frame": start_frame, "end_frame": end_frame, "pnr_frame": pnr_frame}
+
+
+def take_reference(table: np.ndarray, item) -> np.ndarray:
+    """numpy evaluation of an item's feature block (what ``FeatureStore.gather`` computes on the device)."""
+    lo = item["lo"]
+    get = lambda idx: np.where(idx[..., None] >= 0, table[np.maximum(idx, 0)], 0.0).astype(np.float32)
+    a = get(lo)
+    if "hi" not in item:
+        return a
+    hi, w = item["hi"], item["w"]
+    b = get(hi)
+    mix = ((1 - w)[..., None] * a + w[..., None] * b).astype(np.float32)  # double products and sum, rounded once
+    return np.where((lo == hi)[..., None], a, mix)

@@ -260,6 +260,14 @@ int egk_copy_blocks(egk_stream_t s, const void* const* srcs, const int64_t* nbyt
 int egk_gather_rows(egk_stream_t s, const void* table, int32_t table_dtype, int64_t ld, int64_t table_rows,
                     const int64_t* idx, void* out, int32_t out_dtype, int64_t n, int32_t cols);
 
+/* interpolating variant (PNR key-frame sampling data/ego4d_oscc.py:258-275, LTA 'avg' forecast nodes ego4d_fho.py:388-394):
+ * out[i, :] = table[lo[i], :] where lo[i] == hi[i], else (float)((1 - w[i]) * table[lo[i], :] + w[i] * table[hi[i], :]) in
+ * double with separately rounded products and sum (numpy's evaluation, then ``.float()``); an index < 0 or >= table_rows
+ * stands for an all-zero row. */
+int egk_gather_lerp_rows(egk_stream_t s, const void* table, int32_t table_dtype, int64_t ld, int64_t table_rows,
+                         const int64_t* lo, const int64_t* hi, const double* w, void* out, int32_t out_dtype, int64_t n,
+                         int32_t cols);
+
 /* ---- validation metrics  utils/meters/ego4d.py, utils/meters/utils.py:6-28 ----
  * rank[r] = #{j : s[r,j] > s[r,y]} + #{j < y : s[r,j] == s[r,y]} for y = labels[r*label_stride]; -1 when y < 0
  * (ignore_index) or y >= C.  top-k accuracy = mean(rank < k) over rank >= 0; per-class recall likewise. */

@@ -24,4 +24,7 @@ Pinning status (see DESIGN.md "Oracle"):
     tests/golden/meters.pt and tests/golden/validate.pt (``oracle/make_golden_meters.py``); the absent packages
     torchmetrics 0.11 / editdistance 0.6 are restated from their published definitions: **parity unpinned** for
     those leaves beyond the known-answer tests in tests/test_meters_cpu.py.
+  * Input pipeline: the reference's sampling functions and its four datasets' ``get`` methods are
+    PINNED by tests/golden/sampling.pt and tests/golden/pipeline.pt (``oracle/make_golden_sampling.py``,
+    ``oracle/make_golden_pipeline.py``).
 """

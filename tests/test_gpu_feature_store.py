@@ -91,3 +91,25 @@ def test_resident_batches_equal_host_built_batches_and_train_identically(X):
             total, _ = step.step(batches, merged)
         return float(total)
     assert one_step(dev_res, merged_res) == one_step(dev_host, merged_host)
+
+
+def test_store_builds_the_reference_datasets_samples(X, golden):
+    """The whole input pipeline against the reference datasets' ``get`` (tests/golden/pipeline.pt): index matrices from the
+    host builders, feature blocks from the resident store on the device (plain and interpolating gather) -- x bit for bit
+    for AR, LTA ('avg' / 'zero' forecast nodes), OSCC and PNR samples, incl. all-zero clips."""
+    import sys
+    sys.path.insert(0, "tests")
+    from test_feature_store_cpu import _build, _first_rows
+    G = golden("pipeline")
+    first, table = _first_rows(G)
+    lens = {k: v.shape[0] for k, v in G["videos"].items()}
+    store = X.fs.FeatureStore({k: v.numpy() for k, v in G["videos"].items()}, device=DEV, dtype=torch.float32)
+    assert {k: v[0] for k, v in store.offsets.items()} == first
+    for case in G["cases"]:
+        item = _build(case, first, lens, G["stride"])
+        x = store.gather_item(item, dtype=torch.float32)
+        assert torch.equal(x.cpu(), case["data"]["x"]), (case["kind"], case["split"])
+    # bf16 output of the interpolating form: the f32 result rounded once
+    case = next(c for c in G["cases"] if c["kind"] == "pnr")
+    item = _build(case, first, lens, G["stride"])
+    assert torch.equal(store.gather_item(item, dtype=BF).cpu(), case["data"]["x"].to(BF))
