@@ -257,6 +257,15 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
     args = ap.parse_args()
 
+    lib_path = REPO / "egopack_amd" / "libegopack_hip.so"
+    if not lib_path.exists():  # a checkout without the (git-ignored) library: compile it in-tree, once, rank 0 first
+        from egopack_amd import build as _build
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            _build.build_library(force=False, verbose=False)
+        else:
+            while not lib_path.exists():
+                time.sleep(1.0)
+            time.sleep(2.0)
     from egopack_amd import dist as edist
     rank, local_rank, world = edist.init_from_env()
     if not torch.cuda.is_available():
