@@ -283,25 +283,37 @@ class multiloader:
 
 class BatchLoader:
     """Minimal seeded loader: shuffles sample indices with a torch.Generator (re-drawn per epoch),
-    shards them by rank (rank-strided over the common permutation), collates ``batch_size`` samples.
-    Stands in for utils/dataloading.build_dataloader + PyG DataLoader (reference :56-70)."""
+    shards them by rank, collates ``batch_size`` samples.
+    Stands in for utils/dataloading.build_dataloader + PyG DataLoader (reference :56-70).
+
+    shard="samples" (training): rank-strided over the common permutation, equal share per rank.
+    shard="batches" (evaluation passes): every rank cuts the SAME batches the single-process loader would and takes
+    batches rank, rank+world, ... -- the graph-mode LayerNorm statistics span a whole batch, so only
+    identical batches give the single-process logits; ranks may get one batch more or less than each other, which is
+    fine for passes without a per-step collective."""
 
     def __init__(self, dataset, batch_size: int, shuffle: bool, drop_last: bool, seed: int = 0, rank: int = 0,
-                 world_size: int = 1, pin_memory: bool = False):
+                 world_size: int = 1, pin_memory: bool = False, shard: str = "samples"):
+        if shard not in ("samples", "batches"):
+            raise ValueError(f"shard={shard!r}: 'samples' or 'batches'")
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
-        self.rank, self.world_size, self.pin_memory = rank, world_size, pin_memory
+        self.rank, self.world_size, self.pin_memory, self.shard = rank, world_size, pin_memory, shard
         self.gen = torch.Generator()
         self.gen.manual_seed(seed)
 
     def _indices(self) -> List[int]:
         n = len(self.dataset)
         idx = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
-        if self.world_size > 1:  # equal share per rank so that every rank runs the same number of steps
+        if self.world_size > 1 and self.shard == "samples":  # equal share per rank: same number of steps everywhere
             per = n // self.world_size
             idx = idx[: per * self.world_size][self.rank:: self.world_size]
         return idx
 
     def __len__(self):
+        if self.world_size > 1 and self.shard == "batches":
+            n = len(self.dataset)
+            total = n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
+            return len(range(self.rank, total, self.world_size))
         n = len(self.dataset) // self.world_size if self.world_size > 1 else len(self.dataset)
         return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
 
@@ -314,17 +326,20 @@ class BatchLoader:
 
     def __iter__(self):
         idx = self._indices()
-        for i in range(0, len(idx), self.batch_size):
+        by_batch = self.world_size > 1 and self.shard == "batches"
+        for b, i in enumerate(range(0, len(idx), self.batch_size)):
             chunk = idx[i: i + self.batch_size]
             if len(chunk) < self.batch_size and self.drop_last:
                 return
+            if by_batch and b % self.world_size != self.rank:
+                continue
             b = collate([self.dataset[j] for j in chunk])
             yield b.pin_memory() if self.pin_memory else b
 
 
-def build_dataloader(dataset, batch_size, shuffle, num_workers, drop_last, seed=0, rank=0, world_size=1):
+def build_dataloader(dataset, batch_size, shuffle, num_workers, drop_last, seed=0, rank=0, world_size=1, shard="samples"):
     """Signature of the reference's build_dataloader (num_workers accepted, collation is in-process)."""
-    return BatchLoader(dataset, batch_size, shuffle, drop_last, seed, rank, world_size)
+    return BatchLoader(dataset, batch_size, shuffle, drop_last, seed, rank, world_size, shard=shard)
 
 
 # --------------------------------------------------------------------------------------------

@@ -12,12 +12,18 @@ it kept in small device tensors -- nothing is copied to the host before ``comput
     Ego4dPNRMeter :321-377            PNRMeter             accuracy, recall, auroc, localization_error, loss
     Ego4dLTAMeter :380-453            LTAMeter             verbs_ed, nouns_ed (+ verbs/nouns_top1), loss
 Dropped: confusion matrices, calibration / Brier scores, per-class loss tables, feature dumps (reporting only).
+
+Several ranks (SURVEY §8(e) caveat 5): every meter is a set of SUMS (integer counts, float64 loss / distance sums) plus,
+for the PNR AUROC, a list of scores.  ``merge`` adds another meter's state, ``all_reduce`` does the same across the
+process group (sum all-reduce of the packed counts, all-gather of the scores), so a validation split sharded batch by
+batch (data.BatchLoader ``shard="batches"``) reports exactly the numbers of the single-process pass.
 """
 from __future__ import annotations
 
 from typing import Dict, List, Sequence
 
 import torch
+import torch.distributed as dist
 
 from . import _lib, ops
 
@@ -75,6 +81,9 @@ class _HeadCounts:
             self.hits[i] += hit.sum()
             self.class_hits[i] += torch.bincount(lab, weights=hit.to(torch.float64), minlength=self.C).to(torch.int64)
 
+    def tensors(self) -> List[torch.Tensor]:
+        return [self.hits, self.valid, self.class_hits, self.support]
+
     def accuracy(self, k: int) -> float:  # MulticlassAccuracy(top_k=k, average="micro", ignore_index=-1)
         return float(self.hits[self.ks.index(k)]) / max(int(self.valid), 1)
 
@@ -107,6 +116,64 @@ class BaseMeter:
     def loss(self) -> float:
         return float(self.loss_sum) / max(self.loss_n, 1)
 
+    # ---- combining meters (other shards of the same split) ----------------------------------------------------
+    _INTS = ("loss_n", "counter")  # python-int counters
+    _LISTS = ()  # attributes holding lists of 1-D tensors that concatenate across shards
+
+    def _sums(self) -> List[torch.Tensor]:
+        """Device tensors that add across shards (updated in place)."""
+        return [self.loss_sum]
+
+    def merge(self, other: "BaseMeter") -> "BaseMeter":
+        """Add the state of a meter that saw another shard of the split."""
+        for a, b in zip(self._sums(), other._sums()):
+            a += b.to(a.device)
+        for n in self._INTS:
+            setattr(self, n, getattr(self, n) + getattr(other, n))
+        for n in self._LISTS:
+            getattr(self, n).extend(t.to(self.device) for t in getattr(other, n))
+        return self
+
+    def all_reduce(self, group=None) -> "BaseMeter":
+        """Combine the meters of all ranks (every rank ends with the totals).  Two collectives for the sums (one int64,
+        one float64 buffer) and, for list state, a size exchange plus one padded all-gather per list."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        world = dist.get_world_size(group)
+        sums = self._sums()
+        ints = torch.tensor([getattr(self, n) for n in self._INTS], dtype=torch.int64, device=self.device)
+        for dtype in (torch.int64, torch.float64):
+            parts = [t for t in sums if t.dtype == dtype] + ([ints] if dtype == torch.int64 else [])
+            if not parts:
+                continue
+            flat = torch.cat([t.reshape(-1) for t in parts])
+            dist.all_reduce(flat, group=group)
+            o = 0
+            for t in parts:
+                t.copy_(flat[o: o + t.numel()].view(t.shape))
+                o += t.numel()
+        for n, v in zip(self._INTS, ints.tolist()):
+            setattr(self, n, v)
+        for n in self._LISTS:
+            mine = torch.cat(getattr(self, n)) if getattr(self, n) else None
+            count = torch.tensor([0 if mine is None else mine.numel()], dtype=torch.int64, device=self.device)
+            counts = [torch.zeros_like(count) for _ in range(world)]
+            dist.all_gather(counts, count, group=group)
+            counts = [int(c) for c in counts]
+            if max(counts) == 0:
+                continue
+            dtype = self._list_dtype(n)
+            pad = torch.zeros(max(counts), dtype=dtype, device=self.device)
+            if mine is not None:
+                pad[: mine.numel()] = mine.to(dtype)
+            got = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(got, pad, group=group)
+            setattr(self, n, [torch.cat([g[:c] for g, c in zip(got, counts)])])
+        return self
+
+    def _list_dtype(self, name: str) -> torch.dtype:
+        return torch.float32
+
     def print_logs(self) -> List[str]:
         return [f"Loss: {self.loss():.4f}"]
 
@@ -122,6 +189,9 @@ class _VerbNounMeter(BaseMeter):
         self.verb_labels, self.noun_labels = dataset.class_labels[self.idx_verbs], dataset.class_labels[self.idx_nouns]
         self.verbs = _HeadCounts(len(self.verb_labels), self.device)
         self.nouns = _HeadCounts(len(self.noun_labels), self.device)
+
+    def _sums(self):
+        return [*super()._sums(), *self.verbs.tensors(), *self.nouns.tensors()]
 
     @torch.no_grad()
     def _count(self, logits, labels):
@@ -176,6 +246,9 @@ class OSCCMeter(BaseMeter):
         self.dataset = dataset
         self.counts = _HeadCounts(2, self.device, ks=(1,))
 
+    def _sums(self):
+        return [*super()._sums(), *self.counts.tensors()]
+
     @torch.no_grad()
     def update(self, logits, labels, *args, **kwargs) -> None:
         super().update(labels, *args, **kwargs)
@@ -199,6 +272,15 @@ class PNRMeter(BaseMeter):
         self.targets: List[torch.Tensor] = []
         self.loc_err_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         self.loc_n = 0
+
+    _INTS = (*BaseMeter._INTS, "loc_n")
+    _LISTS = ("probs", "targets")
+
+    def _sums(self):
+        return [*super()._sums(), self.stats, self.loc_err_sum]
+
+    def _list_dtype(self, name):
+        return torch.float32 if name == "probs" else torch.uint8
 
     @torch.no_grad()
     def update(self, logits, labels, batch, start_frame, end_frame, pnr_frame, *args, **kwargs) -> None:
@@ -228,7 +310,7 @@ class PNRMeter(BaseMeter):
         """Exact area under the ROC curve (Mann-Whitney U, ties count 1/2) over everything seen."""
         if not self.probs:
             return 0.0
-        p, t = torch.cat(self.probs).double(), torch.cat(self.targets)
+        p, t = torch.cat(self.probs).double(), torch.cat(self.targets).to(torch.bool)
         n_pos, n_neg = int(t.sum()), int((~t).sum())
         if n_pos == 0 or n_neg == 0:
             return 0.0
@@ -260,6 +342,11 @@ class LTAMeter(_VerbNounMeter):
         self.N_NODES = int(getattr(dataset, "lta_nodes", self.N_NODES))  # synthetic datasets use their own T
         self.ed_sum = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.ed_n = 0
+
+    _INTS = (*BaseMeter._INTS, "ed_n")
+
+    def _sums(self):
+        return [*super()._sums(), self.ed_sum]
 
     def _edit_distance(self, preds: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         p = preds.reshape(-1, self.N_NODES, self.N_SAMPLES)[:, self.SKIP:]

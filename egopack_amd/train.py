@@ -59,8 +59,11 @@ def build_datasets(cfg, split: str):
 
 
 def build_loaders(cfg, dsets, train: bool, rank: int, world: int, batch_size: Optional[int] = None):
+    """Training loaders shard by sample (equal steps per rank); evaluation loaders shard by batch, so that every batch
+    -- and with it every graph-LayerNorm statistic -- is the one the single-process pass sees."""
     bs = batch_size or cfg.batch_size
-    return {t: D.build_dataloader(ds, bs, train, cfg.num_workers, train, seed=cfg.seed, rank=rank, world_size=world)
+    return {t: D.build_dataloader(ds, bs, train, cfg.num_workers, train, seed=cfg.seed, rank=rank, world_size=world,
+                                  shard="samples" if train else "batches")
             for t, ds in dsets.items()}
 
 

@@ -49,6 +49,7 @@ def validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, loaders,
             validate_pnr(model, loaders[t], meter, tasks[t], others, g1, late_fusion=late_fusion, device=device)
         else:
             validate(epoch, model, loaders[t], meter, tasks[t], others, g1, late_fusion=late_fusion, device=device)
+        meter.all_reduce()  # ranks validated disjoint batches of the split: every rank ends with the totals
         for line in meter.print_logs():
             logger.info("[val %s] %s", t, line)
         out[t] = {k: v for k, v in meter.get_logs().items() if isinstance(v, (int, float))}
@@ -82,7 +83,7 @@ def main(argv=None):
 
     dsets_train, dsets_val = T.build_datasets(cfg, "train"), T.build_datasets(cfg, cfg.validation_split)
     dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
-    dl_val = T.build_loaders(cfg, dsets_val, False, 0, 1)
+    dl_val = T.build_loaders(cfg, dsets_val, False, rank, world)  # batch-sharded; meters are summed across ranks
     H = cfg.model.hidden_size
     model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,
                         num_segments=cfg.dataset_recognition.num_segments, _recursive_=False).to(device)
@@ -101,13 +102,17 @@ def main(argv=None):
 
     bank_tasks = [tasks[t] for t in ("ar", "oscc", "lta", "pnr") if tasks[t].name in str(cfg.resume_from)]
     banks = build_graphone(model, tasks["ar"], bank_tasks,
-                           dataloader=build_dataloader(dsets_train["ar"], 256, False, cfg.num_workers, True, cfg.seed),
-                           device=device)
+                           dataloader=build_dataloader(dsets_train["ar"], 256, False, cfg.num_workers, True, cfg.seed,
+                                                       rank=rank, world_size=world, shard="batches"),
+                           device=device)  # partial fp64 banks are summed across ranks inside
     graphone = GraphONE(banks, **cfg.graphone).to(device)
 
     wd = cfg.optimizer.weight_decay
     params = [*model.configure_optimizers(wd), *(p for t in ("ar", "oscc", "lta", "pnr") for p in tasks[t].configure_optimizers(wd)),
               *graphone.parameters()]
+    if world > 1:
+        for p in params:  # same start everywhere (seeded identically; broadcast makes it unconditional)
+            torch.distributed.broadcast(p.data, src=0)
     optimizer = T.build_optimizer(cfg, params)
     scheduler = T.build_scheduler(cfg, optimizer)
     sync = edist.GradSync(world) if world > 1 else None
@@ -117,9 +122,8 @@ def main(argv=None):
     for epoch in range(1, cfg.num_epochs + 1):
         train(epoch, step, dl_train, weights, device)
         scheduler.step()
-        if rank == 0:
-            validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, dl_val, late_fusion=cfg.late_fusion,
-                             validate_all=cfg.validate_all_tasks, device=device)
+        validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, dl_val, late_fusion=cfg.late_fusion,
+                         validate_all=cfg.validate_all_tasks, device=device)  # all ranks: the split is sharded by batch
     if cfg.save_model and rank == 0:
         name = f"{cfg.artifact_prefix}_egopack_" + "-".join(sorted(t for t, w in weights.items() if w > 0))
         T.save_checkpoint(Path(cfg.checkpoint_dir) / name / "checkpoint.pth", model, tasks, cfg.num_epochs,

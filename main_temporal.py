@@ -64,6 +64,10 @@ def validate_losses(step: engine.MTLStep, loaders, device="cuda"):
             _, vectors, _ = step.losses({t: b.to(device)})
             s += float(vectors[t].sum())
             n += vectors[t].numel()
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:  # batch-sharded split
+            tot = torch.tensor([s, n], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(tot)
+            s, n = float(tot[0]), int(tot[1])
         out[t] = s / max(n, 1)
     return out
 
@@ -79,6 +83,7 @@ def validate_metrics(epoch, model, tasks, enabled, dsets_val, loaders, device="c
             validate_pnr(model, loaders[t], meter, tasks[t], device=device)
         else:
             validate(epoch, model, loaders[t], meter, tasks[t], device=device)
+        meter.all_reduce()  # ranks validated disjoint batches of the split: every rank ends with the totals
         for line in meter.print_logs():
             logger.info("[val %s] %s", t, line)
         out[t] = {k: v for k, v in meter.get_logs().items() if isinstance(v, (int, float))}
@@ -100,7 +105,7 @@ def main(argv=None):
     dsets_train, dsets_val = T.build_datasets(cfg, "train"), T.build_datasets(cfg, cfg.validation_split)
     assert len({d.features_size for d in dsets_train.values()}) == 1, "all tasks must share the input feature size"
     dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
-    dl_val = T.build_loaders(cfg, dsets_val, False, 0, 1)
+    dl_val = T.build_loaders(cfg, dsets_val, False, rank, world)  # batch-sharded; meters are summed across ranks
 
     H = cfg.model.hidden_size
     model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,
@@ -137,7 +142,7 @@ def main(argv=None):
         logger.info("learning rate -> %.6g", scheduler.get_last_lr()[0])
         if cfg.save_model and cfg.get("save_every", 0) and epoch % cfg.save_every == 0 and rank == 0:
             T.save_checkpoint(ckpt_path, model, tasks, epoch, optimizer=optimizer, scheduler=scheduler, loaders=dl_train)
-        if epoch >= cfg.num_epochs - 5 and rank == 0:
+        if epoch >= cfg.num_epochs - 5:  # all ranks: the validation split is sharded by batch
             logger.info("validation losses: %s", validate_losses(step, dl_val, device))
             validate_metrics(epoch, model, tasks, step.enabled, dsets_val, dl_val, device)
     if cfg.save_model and rank == 0:

@@ -66,3 +66,90 @@ def test_gloo_world2_allreduce_broadcast_and_sharding():
         assert ok_sum and ok_bcast
         assert gathered[0] == gathered[1]  # identical step counts on both ranks
         assert gathered[0][0] == gathered[0][1] == 5
+
+
+# ---- evaluation passes over several ranks (SURVEY 8(e) caveats 3 and 5) -------------------------------------------
+class _DS:
+    """What the meters read from a dataset."""
+    label_names = ["verbs", "nouns"]
+    class_labels = [[f"v{i}" for i in range(5)], [f"n{i}" for i in range(7)]]
+    lta_nodes = 6
+    task = "ar"
+
+
+def _fake_meters(seed):
+    """One meter of every kind on the CPU with a seeded, plausible state (the kernels that fill them need a GPU; the
+    cross-rank combination is host logic over the state tensors)."""
+    from egopack_amd import meters as M
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda hi, *shape: torch.randint(0, hi, shape, generator=g)
+    out = []
+    for cls in (M.RecognitionMeter, M.AnticipationMeter, M.LTAMeter):
+        m = cls(_DS(), device="cpu")
+        for h in (m.verbs, m.nouns):
+            for t in h.tensors():
+                t.copy_(ri(50, *t.shape) if t.dim() else ri(50, 1)[0])
+        if isinstance(m, M.LTAMeter):
+            m.ed_sum += torch.rand(2, generator=g, dtype=torch.float64)
+            m.ed_n = int(ri(20, 1)) + 1
+        out.append(m)
+    o = M.OSCCMeter(device="cpu")
+    for t in o.counts.tensors():
+        t.copy_(ri(50, *t.shape) if t.dim() else ri(50, 1)[0])
+    out.append(o)
+    p = M.PNRMeter(device="cpu")
+    p.stats += ri(30, 4)
+    n = 5 + seed  # ranks hold different numbers of scores (padded all-gather)
+    p.probs, p.targets = [torch.rand(n, generator=g)], [ri(2, n).bool()]
+    p.targets[0][0], p.targets[0][1] = True, False
+    p.loc_err_sum += torch.rand((), generator=g, dtype=torch.float64)
+    p.loc_n = 3 + seed
+    out.append(p)
+    for m in out:
+        m.loss_sum += torch.rand((), generator=g, dtype=torch.float64)
+        m.loss_n, m.counter = 2 + seed, 10 + seed
+    return out
+
+
+def _scalars(m):
+    return {k: v for k, v in m.get_logs().items() if isinstance(v, (int, float))}
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    init_from_env(backend="gloo")
+    logs = [_scalars(m.all_reduce()) for m in _fake_meters(rank)]
+    ds = D.SyntheticTaskDataset("pnr", 23, 4, 3, 4)
+    dl = D.BatchLoader(ds, 4, shuffle=False, drop_last=False, rank=rank, world_size=world, shard="batches")
+    mine = [b.x.clone() for b in dl]
+    assert len(mine) == len(dl)
+    q.put((rank, logs, [m.tolist() for m in mine]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gloo_world2_meters_and_batch_sharded_eval_loader():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=100) for _ in range(2)), key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    # the in-process merge of the two ranks' meters is the expected total
+    want = [_scalars(a.merge(b)) for a, b in zip(_fake_meters(0), _fake_meters(1))]
+    for rank, logs, _ in out:
+        for got, exp in zip(logs, want):
+            assert got.keys() == exp.keys()
+            for k in exp:
+                assert got[k] == pytest.approx(exp[k], rel=1e-12, abs=1e-12), (rank, k)
+    # the two ranks' batches interleave into exactly the single-process batches (same rows, same batch boundaries)
+    ds = D.SyntheticTaskDataset("pnr", 23, 4, 3, 4)
+    single = [b.x.tolist() for b in D.BatchLoader(ds, 4, shuffle=False, drop_last=False)]
+    assert len(single) == 6 and len(out[0][2]) == 3 and len(out[1][2]) == 3
+    assert [out[i % 2][2][i // 2] for i in range(6)] == single

@@ -205,3 +205,65 @@ def test_validate_metrics_on_synthetic_loaders(M):
     assert 0 <= out["ar"]["verbs_top1"] <= out["ar"]["verbs_top5"] <= 1
     assert 0 <= out["oscc"]["accuracy"] <= 1 and 0 <= out["pnr"]["auroc"] <= 1 and out["pnr"]["localization_error"] >= 0
     assert 0 <= out["lta"]["verbs_ed"] <= 1 and 0 <= out["lta"]["nouns_ed"] <= 1
+
+
+def test_batch_sharded_validation_merges_to_the_single_pass_numbers(M):
+    """SURVEY 8(e) caveat 5: two ranks validating alternate batches of the split and adding their meters report what one
+    pass over the split reports -- counts exactly; the graph-LayerNorm statistics span a batch, which is why the shards
+    are whole batches."""
+    import main_temporal
+    H = 64
+    ds = {t: M.data.SyntheticTaskDataset(t, 22, 8, 3, 48, (7, 11), k=1, seed=5) for t in ("ar", "oscc", "pnr", "lta")}
+    torch.manual_seed(1)
+    model = M.Graph(48, hidden_size=H, depth=2, temporal_pooling={**TRN_CFG, "hidden_size": H}, num_segments=3).to(DEV)
+    tasks = {"ar": M.RecognitionTask(H, H, (7, 11)).to(DEV), "lta": M.LTATask(H, H, (7, 11)).to(DEV),
+             "oscc": M.OSCCTask(H, H).to(DEV), "pnr": M.PNRTask(H, H).to(DEV)}
+
+    def run(t, rank, world):
+        dl = M.data.build_dataloader(ds[t], 4, False, 0, False, 1, rank=rank, world_size=world, shard="batches")
+        meter = M.meters.build_meter_for_dataset(ds[t], device=DEV)
+        if t == "lta":
+            M.validate.validate_lta(model, dl, meter, tasks[t], device=DEV)
+        elif t == "pnr":
+            M.validate.validate_pnr(model, dl, meter, tasks[t], device=DEV)
+        else:
+            M.validate.validate(1, model, dl, meter, tasks[t], device=DEV)
+        return meter
+
+    for t in ("ar", "oscc", "pnr", "lta"):
+        whole = run(t, 0, 1)
+        merged = run(t, 0, 2).merge(run(t, 1, 2))
+        assert merged.counter == whole.counter and merged.loss_n == whole.loss_n
+        for a, b in zip(merged._sums(), whole._sums()):
+            if t == "lta" and a.dtype == torch.float64:
+                continue  # the K=5 futures are sampled (multinomial): distances and nothing else depend on the draw order
+            if a.dtype == torch.int64:
+                assert torch.equal(a, b), t
+            else:
+                torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+        if t != "lta":
+            got, want = merged.get_logs(), whole.get_logs()
+            for k, v in want.items():
+                if isinstance(v, (int, float)):
+                    assert got[k] == pytest.approx(v, rel=1e-12, abs=1e-12), (t, k)
+    assert run("ar", 0, 1).all_reduce().counter == 22 * 8  # no process group: a no-op (counter = label rows seen)
+
+
+def test_batch_sharded_bank_pass_sums_to_the_single_pass_banks(M):
+    """SURVEY 8(e) caveat 3: fp64 partial banks of alternate batches add up to the single-pass banks."""
+    from egopack_amd import graphone as G1
+    H = 64
+    ds = M.data.SyntheticTaskDataset("ar", 40, 8, 3, 48, (5, 6), k=1, seed=9)
+    torch.manual_seed(2)
+    model = M.Graph(48, hidden_size=H, depth=2, temporal_pooling={**TRN_CFG, "hidden_size": H}, num_segments=3).to(DEV)
+    ar, pnr = M.RecognitionTask(H, H, (5, 6)).to(DEV), M.PNRTask(H, H).to(DEV)
+    mk = lambda r, w: M.data.build_dataloader(ds, 8, False, 0, True, 1, rank=r, world_size=w, shard="batches")
+    whole = G1.build_graphone(model, ar, [ar, pnr], mk(0, 1), device=DEV)
+    b0, c0 = G1.accumulate_banks(model, ar, [ar, pnr], mk(0, 2), device=DEV)
+    b1, c1 = G1.accumulate_banks(model, ar, [ar, pnr], mk(1, 2), device=DEV)
+    assert int(c0.sum()) + int(c1.sum()) == 2 * 40 and int(c0.sum()) == 2 * 24  # 5 batches: 3 + 2; count once per task
+    merged = G1.finalise_banks({k: b0[k] + b1[k] for k in b0}, c0 + c1)
+    assert merged.keys() == whole.keys()
+    for k in whole:
+        assert merged[k].shape == whole[k].shape
+        torch.testing.assert_close(merged[k], whole[k], rtol=1e-6, atol=1e-7)
