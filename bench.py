@@ -215,6 +215,17 @@ def roofline(ops, step_fn, compute, n_steps=3):
     out.update({"traffic": pmc_traffic(name), "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc passes)",
                 "kernel": name, "rocprof_symbol": ROCPROF_NAME.get(name), "launches_per_step": r["launches"] / n_steps, "avg_launch_us": avg_ms * 1e3,
                 "alg_per_launch": (r["flops"] if name.startswith("gemm") else r["bytes"]) / r["launches"]})
+    # whole step against the same peaks: the sum over every launch of max(algorithmic flops / MFMA peak,
+    # algorithmic bytes / HBM peak) -- what the step would take if each kernel ran at its bounding roofline with no
+    # launch gaps; main() divides it by the measured step
+    lb = 0.0
+    for k, v in rep.items():
+        t = v["bytes"] / (PEAK_HBM_GBS * 1e9)
+        if k.startswith("gemm") and v["flops"]:
+            t = max(t, v["flops"] / (PEAK["bf16" if "bf16" in k else "f32"] * 1e12))
+        lb += t
+    out["step"] = {"lower_bound_ms": lb / n_steps * 1e3, "flops_per_step": sum(v["flops"] for v in rep.values()) / n_steps,
+                   "bytes_per_step": sum(v["bytes"] for v in rep.values()) / n_steps}
     table = {k: {"launches_per_step": v["launches"] / n_steps, "ms_per_step": v["total_ms"] / n_steps,
                  "tflops": (v["flops"] / (v["total_ms"] * 1e-3) / 1e12) if v["flops"] and v["total_ms"] else None,
                  "gbs": (v["bytes"] / (v["total_ms"] * 1e-3) / 1e9) if v["bytes"] and v["total_ms"] else None}
@@ -402,6 +413,8 @@ def main():
                     g1.parallel_tasks = saved_g1
         except Exception as e:  # the headline number must still be printed
             rl = {"error": repr(e)}
+    if rl and "step" in rl:
+        rl["step"]["frac"] = rl["step"]["lower_bound_ms"] / ms
     cb = None
     if sds is not None:
         try:

@@ -18,6 +18,8 @@
 //   * the MFMA is issued as D^T = B.A^T so each lane owns 4 CONSECUTIVE columns of one output row: bias /
 //     residual / C traffic is 16 B (f32) or 8 B (bf16) per lane;
 //   * blockIdx is remapped so that each XCD owns a contiguous range of M-tiles.
+#include <type_traits>
+
 #include "common.h"
 
 namespace egk {
@@ -416,40 +418,50 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Per-wave cursor over the 4 pieces (1 KiB each) a wave fetches of one operand image per K tile.  The per-lane
 // source addresses are computed ONCE; a K-tile step is a uniform pointer increment (the address arithmetic of 8
 // DMA instructions per tile would otherwise cost as many VALU cycles as the tile's MFMAs at one wave per SIMD).
+template <bool TR, int NP, int OFF = 0, int TOT = NP>
+__device__ __forceinline__ void cursor_init(const bf16_t* (&pp)[TOT], long long& step, const bf16_t* __restrict__ base, long long ld,
+                                            int rows_total, int row0, int k0, int first, int lane, int tiles_per_step) {
+    // pieces first .. first + NP - 1 of an operand image made of 16-KiB sub-images of 128 rows (16 pieces each), kept in
+    // slots OFF .. OFF + NP - 1 of the pointer array
+    const bf16_t** p = pp + OFF;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = (first + i) & 15, sub_row0 = row0 + ((first + i) >> 4) * 128;
+        if constexpr (TR) {  // piece = 4 k-rows of 256 B; lane -> (k = 4*piece + lane/16, slot = lane%16)
+            const int k = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
+            // a chunk is fetched whenever it lies inside the ALLOCATED row (ld): with a padded row stride the last
+            // valid rows (e.g. 112..114 of 115) sit in a chunk that extends into the padding.  Chunks beyond the
+            // row are redirected to the row's first chunk: they only feed output rows that are never stored.
+            int col = sub_row0 + c * 8;
+            if (col + 8 > ld) col = 0;
+            p[i] = base + (long long)(k0 + k) * ld + col;
+        } else {  // piece = 8 rows of 128 B; lane -> (row = 8*piece + lane/8, slot = lane%8)
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            p[i] = base + (long long)min(sub_row0 + r, rows_total - 1) * ld + k0 + c * 8;
+        }
+    }
+    step = (TR ? 64 * ld : 64) * tiles_per_step;
+}
+template <int NP, int OFF = 0, int TOT = NP>
+__device__ __forceinline__ void cursor_issue(const bf16_t* (&pp)[TOT], long long step, unsigned char* img, int first) {
+    const bf16_t** p = pp + OFF;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(img + (first + i) * 1024), 16, 0, 0);
+        p[i] += step;
+    }
+}
 template <bool TR, int NP>
 struct OperandCursor {
     const bf16_t* p[NP];
     long long step;  // elements per cursor advance
-    // pieces first .. first + NP - 1 of an operand image made of 16-KiB sub-images of 128 rows (16 pieces each)
     __device__ __forceinline__ void init(const bf16_t* __restrict__ base, long long ld, int rows_total, int row0, int k0,
                                          int first, int lane, int tiles_per_step) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int piece = (first + i) & 15, sub_row0 = row0 + ((first + i) >> 4) * 128;
-            if constexpr (TR) {  // piece = 4 k-rows of 256 B; lane -> (k = 4*piece + lane/16, slot = lane%16)
-                const int k = piece * 4 + (lane >> 4);
-                const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
-                // a chunk is fetched whenever it lies inside the ALLOCATED row (ld): with a padded row stride the last
-                // valid rows (e.g. 112..114 of 115) sit in a chunk that extends into the padding.  Chunks beyond the
-                // row are redirected to the row's first chunk: they only feed output rows that are never stored.
-                int col = sub_row0 + c * 8;
-                if (col + 8 > ld) col = 0;
-                p[i] = base + (long long)(k0 + k) * ld + col;
-            } else {  // piece = 8 rows of 128 B; lane -> (row = 8*piece + lane/8, slot = lane%8)
-                const int r = piece * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ ((r >> 1) & 7);
-                p[i] = base + (long long)min(sub_row0 + r, rows_total - 1) * ld + k0 + c * 8;
-            }
-        }
-        step = (TR ? 64 * ld : 64) * tiles_per_step;
+        cursor_init<TR, NP, 0, NP>(p, step, base, ld, rows_total, row0, k0, first, lane, tiles_per_step);
     }
-    __device__ __forceinline__ void issue(unsigned char* img, int first) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)p[i], (lds_void_t*)(img + (first + i) * 1024), 16, 0, 0);
-            p[i] += step;
-        }
-    }
+    __device__ __forceinline__ void issue(unsigned char* img, int first) { cursor_issue<NP, 0, NP>(p, step, img, first); }
 };
 
 // (128 * MB) x 128 output tile, NSTAGE-deep ring of (A image | B image) = (16 * MB + 16) KiB per stage; every wave
@@ -719,6 +731,224 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
     }
 }
 
+// Fragment reads of the 256 x 256 kernel: fragments FIRST .. FIRST + 3 of k-step S of one operand image (inline asm for
+// the reason given in gemm_pipe_kernel: a plain LDS load would drain the DMA queue first).
+template <bool TR, int FIRST, int S>
+__device__ __forceinline__ void read_frags4(uint4 (&dst)[4], unsigned st, unsigned rm, const unsigned* tr) {
+    if constexpr (TR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned ad = st + tr[FIRST + i];
+            uint2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ad), "n"(S * 8192));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ad), "n"(S * 8192 + 1024));
+            dst[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    } else {
+        const unsigned ad = S ? ((st + rm) ^ 64u) : (st + rm);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[i]) : "v"(ad), "n"((FIRST + i) * 2048));
+    }
+}
+__device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[8][4], int i0, const uint4 (&a)[4], const uint4 (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]),
+                                                                     acc[i0 + i][j], 0, 0, 0);
+}
+
+// ---- 256 x 256 output tile: large outputs -------------------------------------------------------------------------
+// 8 waves as 2 (rows) x 4 (columns), every wave a 128 x 64 patch (8 x 4 MFMA accumulators), ONE workgroup per CU (two
+// waves per SIMD), 2-stage ring of (A image | B image), each image two 16-KiB sub-images of 128 rows: 64 KiB per stage,
+// 128 KiB in all.  Same images, swizzles and MFMA chain per accumulator as gemm_pipe_kernel (results are bit-identical
+// to it and to the generic kernel); what changes is the bytes per flop:
+//   * through the CU's vector-memory path: 64 KiB per K tile for 8.4 MFLOP = 128 flop/B against 64 flop/B for a
+//     128 x 128 tile.  That path takes 64 B/clk -- one 1-KiB DMA piece per 16 cycles -- and a wave that issues a piece
+//     is held until it is accepted (~68 cycles per piece with four SIMDs feeding it): at 128 x 128 the pieces of a K
+//     tile take the path as long as its MFMAs take the matrix pipes (512 cycles each), which is the ~65 % pipe
+//     utilisation / ~70 GB/s per CU / ~1.1 PFLOP/s every 128-row variant ends at;
+//   * from LDS: 12 fragment reads per 32 MFMAs per k-step instead of 8 per 16.
+// In-kernel clock under this load: 1.5-1.7 GHz (tools/gemm_stamps.py), i.e. the matrix peak the loop can be held
+// against is ~1.7 PFLOP/s, not 2.5.
+// Only whole tiles (M, N multiples of 256) of outputs that fill the chip with them, and a long K walk (host policy); no
+// fused bias gradient (dW outputs are far too small to come here).
+template <bool TRA, bool TRB, int DMA_NBE = 8>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
+    constexpr int IMG = 16384, IMG_OP = 2 * IMG, STAGE = 2 * IMG_OP, KT = 64, NI = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    int z, tm, tn;
+    tile_of(g, blockIdx.x, z, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
+    const int nt = t_end - t_begin;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;  // wm: 128-row band (= A sub-image); wn: 64-column band (B sub-image wn >> 1)
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // DMA roles.  A wave is held ~60-125 cycles per 1-KiB piece it issues (the CU's address path takes the pieces of all
+    // four SIMDs): as long as the 64 MFMAs of its K tile take, when it issues an even share of 8.  Issued by everybody
+    // behind the barrier, the matrix pipes idle meanwhile (in-kernel stamps, tools/gemm_stamps.py).  So the two waves of
+    // a SIMD take turns: waves 0-3 ("early", one per SIMD) issue the A image and NBE of every 8 B pieces behind the
+    // barrier while their partners 4-7 ("late") run MFMA phases; the late waves issue the remaining B pieces after their
+    // second phase, under the early waves' MFMAs.
+    // Addresses: the tile is whole (M, N multiples of 256: host policy), so piece q of an operand is a UNIFORM base plus a
+    // per-lane offset that takes one of two values (the swizzle state alternates with q): 2 VGPRs per operand instead of a
+    // 64-bit pointer per piece, and the K walk is scalar arithmetic.
+    //   row-major [rows][K]: piece q = rows 8q .. 8q+7; lane -> row 8q + lane/8, chunk (lane%8) ^ (4*(q&1) | (lane/16)%4)
+    //   k-major   [K][rows]: piece q = k-rows 4(q%16) .. +3 of sub-image q/16; lane -> k-row + lane/16,
+    //                        chunk (lane%16) ^ (2*((lane/16)%4) + 8*x), x = ((q%16)/2)&1
+    constexpr int NBE = DMA_NBE;  // B pieces per early wave (4 or 8); late waves take 8 - NBE each
+    const bool early = w < 4;
+    unsigned voffA[2], voffB[2];
+    const char *baseA = nullptr, *baseB = nullptr;  // (uniform) tile origin of the current K tile
+    long long lda_b = 0, ldb_b = 0;                 // row strides in bytes
+    int cur_src = -1;
+    auto lane_off = [&](bool tr, long long ld_bytes, int state) -> unsigned {
+        if (tr) return (unsigned)((lane >> 4) * ld_bytes + ((((lane & 15) ^ (2 * ((lane >> 4) & 3) + 8 * state))) << 4));
+        return (unsigned)((lane >> 3) * ld_bytes + (((lane & 7) ^ ((state << 2) | ((lane >> 4) & 3))) << 4));
+    };
+    auto aim = [&](int i) {  // (uniform) first tile, or the walk crossed from the first K source into the second
+        const int t = t_begin + i;
+        const int src = t < nkt0 ? 0 : 1;
+        if (src != cur_src) {
+            const long long k0 = (long long)(src == 0 ? t : t - nkt0) * KT;
+            lda_b = g.lda[src] * 2; ldb_b = g.ldb[src] * 2;
+            baseA = (const char*)g.A[src] + (TRA ? k0 * lda_b + (long long)m0 * 2 : (long long)m0 * lda_b + k0 * 2);
+            baseB = (const char*)g.B[src] + (TRB ? k0 * ldb_b + (long long)n0 * 2 : (long long)n0 * ldb_b + k0 * 2);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                voffA[x] = lane_off(TRA, lda_b, x);
+                voffB[x] = lane_off(TRB, ldb_b, x);
+            }
+            cur_src = src;
+        }
+    };
+    // pieces first .. first + N - 1 of one operand (first a multiple of 4: the swizzle state of piece first + i depends
+    // on i alone), then nothing else: the K advance is applied once per tile by the caller
+    auto issue_pieces = [&](auto trc, auto nc, const char* base, long long ld_bytes, const unsigned (&voff)[2], int first,
+                            unsigned char* img) {
+        constexpr bool TR = decltype(trc)::value;
+        constexpr int N = decltype(nc)::value;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int q = first + i;
+            const long long off = TR ? (long long)(4 * (q & 15)) * ld_bytes + (q >> 4) * 256 : (long long)(8 * q) * ld_bytes;
+            const unsigned v = voff[TR ? ((i >> 1) & 1) : (i & 1)];
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off + v), (lds_void_t*)(img + q * 1024), 16, 0, 0);
+        }
+    };
+    using std::integral_constant;
+    auto advance = [&]() {
+        baseA += TRA ? KT * lda_b : KT * 2;
+        baseB += TRB ? KT * ldb_b : KT * 2;
+    };
+    auto issue_early = [&](unsigned char* stage) {
+        issue_pieces(integral_constant<bool, TRA>{}, integral_constant<int, 8>{}, baseA, lda_b, voffA, w * 8, stage);
+        issue_pieces(integral_constant<bool, TRB>{}, integral_constant<int, NBE>{}, baseB, ldb_b, voffB, w * NBE, stage + IMG_OP);
+    };
+    auto issue_late = [&](unsigned char* stage) {
+        if constexpr (NBE < 8)
+            issue_pieces(integral_constant<bool, TRB>{}, integral_constant<int, 8 - NBE>{}, baseB, ldb_b, voffB,
+                         4 * NBE + (w - 4) * (8 - NBE), stage + IMG_OP);
+    };
+
+    f32x4 acc[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
+    const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
+    const unsigned a_rm = (unsigned)(wm * IMG + lr * ROWB) + rm_sw;
+    const unsigned b_rm = (unsigned)((wn >> 1) * IMG + ((wn & 1) * 64 + lr) * ROWB) + rm_sw;
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const unsigned tr_row = (unsigned)((8 * lg + tq) * 256 + (tp & 1) * 8);
+    const unsigned tr_f = (unsigned)(2 * tq + 8 * (lg & 1));
+    unsigned a_tr[NI], b_tr[4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a_tr[i] = (unsigned)(wm * IMG) + tr_row + ((((unsigned)(2 * i + (tp >> 1))) ^ tr_f) << 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        b_tr[j] = (unsigned)((wn >> 1) * IMG) + tr_row + ((((unsigned)((wn & 1) * 8 + 2 * j + (tp >> 1))) ^ tr_f) << 4);
+
+#ifdef EGK_GEMM_STAMPS  // diagnostic build only (tools/gemm_stamps.py): where a wave's cycles go, per loop section
+    unsigned long long st_wait = 0, st_issue = 0, st_head = 0, st_body = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
+#define EGK_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define EGK_STAMP(var)
+#endif
+    if (nt > 0) {
+        aim(0);
+        if (early) issue_early(lds);
+        else issue_late(lds);
+        advance();
+    }
+    for (int it = 0; it < nt; ++it) {
+        EGK_STAMP(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // 2-stage ring: only tile ``it`` is in flight at this point
+        __builtin_amdgcn_s_barrier();
+        EGK_STAMP(s1);
+        const bool more = it + 1 < nt;
+        unsigned char* nxt = lds + ((it + 1) & 1) * STAGE;
+        if (more) aim(it + 1);
+        if (more && early) issue_early(nxt);
+        EGK_STAMP(s2);
+
+        // Four phases of 16 MFMAs per K tile: (k-step 0 | 1) x (A fragments 0-3 | 4-7).  The fragments of the NEXT phase
+        // are read while this one's MFMAs run, into the registers the previous phase released: 64 fragment registers live
+        // (two B sets, two A halves) beside the 128 accumulators, so two waves per SIMD fit in the register file.
+        const unsigned stA = lds_base + (it & 1) * STAGE, stB = stA + IMG_OP;
+        uint4 b0[4], b1[4], alo[4], ahi[4];
+        constexpr int NA = TRA ? 8 : 4, NB = TRB ? 8 : 4;  // read instructions per group of 4 fragments
+        read_frags4<TRB, 0, 0>(b0, stB, b_rm, b_tr);
+        read_frags4<TRA, 0, 0>(alo, stA, a_rm, a_tr);
+        read_frags4<TRA, 4, 0>(ahi, stA, a_rm, a_tr);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA) : "memory");  // reads return in issue order: b0, alo are back
+        __builtin_amdgcn_sched_barrier(0);
+        EGK_STAMP(s3);
+        mfma_4x4(acc, 0, alo, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags4<TRB, 0, 1>(b1, stB, b_rm, b_tr);
+        read_frags4<TRA, 0, 1>(alo, stA, a_rm, a_tr);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA + NB > 15 ? 15 : NA + NB) : "memory");  // ahi (k-step 0) is back
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_4x4(acc, 4, ahi, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !early) issue_late(nxt);
+        if (more) advance();
+        read_frags4<TRA, 4, 1>(ahi, stA, a_rm, a_tr);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA) : "memory");  // b1, alo (k-step 1) are back
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_4x4(acc, 0, alo, b1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_4x4(acc, 4, ahi, b1);
+#ifdef EGK_GEMM_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        EGK_STAMP(s4);
+        st_wait += s1 - s0; st_issue += s2 - s1; st_head += s3 - s2; st_body += s4 - s3;
+#endif
+    }
+#ifdef EGK_GEMM_STAMPS
+    if (g.ws_bias != nullptr && lane == 0) {  // (the host points ws_bias at the caller's workspace in this build)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws_bias) + ((long long)blockIdx.x * 8 + w) * 8;
+        o[0] = st_wait; o[1] = st_issue; o[2] = st_head; o[3] = st_body;
+        o[4] = __builtin_amdgcn_s_memtime() - st_begin; o[5] = __builtin_amdgcn_s_memrealtime() - st_rbegin; o[6] = nt;
+    }
+#endif
+#undef EGK_STAMP
+    gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 128, wn * 64, lr, lg, z);
+}
+
 // Sum the split-K slabs in slab order (bitwise reproducible) and apply the epilogue.
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs g) {
     const long long total = (long long)g.M * g.N;
@@ -827,6 +1057,11 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     set_lds_attr<2, false, false, 1, 2>(); set_lds_attr<2, false, true, 1, 2>(); set_lds_attr<2, true, true, 1, 2>(); set_lds_attr<2, true, false, 1, 2>();
+    set_lds_attr<3, false, false, 1, 2>(); set_lds_attr<3, false, true, 1, 2>(); set_lds_attr<3, true, true, 1, 2>(); set_lds_attr<3, true, false, 1, 2>();
+    (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
@@ -834,7 +1069,8 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
     // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
-    // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 8 / 11 the 96 x 128 / 64 x 128 tile where legal (row-major A)
+    // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 7 always the 256 x 256 tile (no fused
+    // bias gradient: falls back to 3 with one); 8 / 11 the 96 x 128 / 64 x 128 tile where legal (row-major A)
     g_use_pipe = on;
     return prev;
 }
@@ -972,11 +1208,27 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
                     variant = 11;
                 }
             }
+            // large outputs with a long K walk: 256 x 256 tiles, one 8-wave workgroup per CU, when whole tiles fill at least
+            // 90 % of the CU slots of the rounds they take.  Measured against the 128 x 128 kernel (tools/gemm_big.py):
+            // 16384 x 1024 x 4608: 126 vs 145 us; 4096^3: 113 vs 128; 8192^3: 836 vs 1178; but 16384 x 1024 x 2048: 76 vs 74
+            // and x 1024: 45 vs 45 (16 K tiles: prologue and epilogue of the big tile weigh as much as its loop saves),
+            // 24576 x 1024 (384 tiles, 1.5 rounds): 78 vs 65.  6144 x 1024 (96 tiles) never qualifies.
+            const long long t256 = (long long)cdiv(g.M, 256) * cdiv(g.N, 256);
+            if (g.splitk == 1 && !g.dbias && g.M % 256 == 0 && g.N % 256 == 0 && t256 >= 192 && d->K1 + d->K2 >= 3072 &&
+                10 * t256 >= 9 * 256 * ((t256 + 255) / 256))
+                variant = 7;
         } else if ((variant == 8 || variant == 11) && d->transA) {
             variant = 3;  // the forced variants exist for row-major A only
+        } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
+            variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
         }
-        const int mb = variant == 6 ? 2 : 1;
-        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : cdiv(g.M, BM * mb);
+        const int mb = (variant == 6 || variant == 9) ? 2 : 1;
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
+        if (variant == 7) g.tiles_n = cdiv(g.N, 256);
+#ifdef EGK_GEMM_STAMPS
+        if (variant == 7 && g.splitk == 1 && !g.dbias && d->ws && d->ws_bytes >= (int64_t)g.tiles_m * g.tiles_n * 8 * 64)
+            g.ws_bias = (float*)d->ws;  // per-wave cycle stamps land in the caller's workspace
+#endif
         {  // near-square XCD patches: group_m ~ sqrt(workgroups per XCD), inside one slab
             const int tiles = g.tiles_m * g.tiles_n;
             int per_xcd = cdiv(tiles * g.splitk, 8);
@@ -990,10 +1242,14 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
-        if (variant == 11) {                                                                                              \
+        if (variant == 7) {                                                                                               \
+            hipLaunchKernelGGL((gemm_big_kernel<TA, TB>), pgrid, dim3(512), 131072, s, g);                                \
+        } else if (variant == 11) {                                                                                       \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);                \
         } else if (variant == 8) {                                                                                        \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);                \
+        } else if (variant == 9) {                                                                                        \
+            hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, g);          \
         } else if (variant == 6)                                                                                          \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
         else if (variant == 5)                                                                                            \
@@ -1003,7 +1259,7 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, g);                     \
     } while (0)
         {
-            ProfScope prof(variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
+            ProfScope prof(variant == 7 ? KID_GEMM_BF16_NN_T256 + layout : variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
                                        : (variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);

@@ -632,7 +632,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
     A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
     C0 = torch.randn(M, N, device=DEV, generator=g)
     outs = {}
-    for pipe in (3, 2, 4, 6, 8, 11, 0, 5, 1, 55):
+    for pipe in (3, 2, 4, 6, 7, 8, 11, 0, 5, 1, 55):
         prev = lib.egk_gemm_set_pipeline(5 if pipe == 55 else pipe)
         try:
             out = C0.clone()
@@ -641,7 +641,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
             outs[pipe] = out
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    for v in (3, 2, 4, 6, 8, 11):  # one wave group: the MFMA chain of the generic kernel, whatever the tile / ring depth
+    for v in (3, 2, 4, 6, 7, 8, 11):  # one wave group: the MFMA chain of the generic kernel, whatever the tile / ring depth
         assert torch.equal(outs[v], outs[0]), v
     assert torch.equal(outs[5], outs[55])
     assert torch.equal(outs[1], outs[5]) or torch.equal(outs[1], outs[3])
@@ -652,7 +652,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(300, 200, 256, 0), (128, 128, 64, 0), (257, 129, 128, 192), (2048, 1024, 1024, 0),
-                                       (6144, 1024, 1024, 1024), (130, 478, 1024, 0)])
+                                       (6144, 1024, 1024, 1024), (130, 478, 1024, 0), (16384, 1024, 512, 0), (12200, 1100, 128, 64)])
 def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     """The LDS-DMA pipelined kernel (bf16 row-major operands, K % 64 == 0) issues the same MFMA chain per
     accumulator as the generic kernel: results must be BIT-identical, for bf16 and f32 outputs, with the
@@ -667,7 +667,7 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     bias = torch.randn(N, device=DEV, generator=g)
     res = torch.randn(M, N, device=DEV, generator=g).to(BF)
     outs = {}
-    for pipe in (3, 6, 8, 11, 0, 5, 1):
+    for pipe in (3, 6, 7, 8, 11, 0, 5, 1):
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             for dt in (BF, torch.float32):
@@ -680,7 +680,8 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     for dt in (BF, torch.float32):
         assert torch.equal(outs[(3, dt)], outs[(0, dt)])
         assert torch.equal(outs[(6, dt)], outs[(0, dt)]) and torch.equal(outs[(8, dt)], outs[(0, dt)]) and torch.equal(outs[(11, dt)], outs[(0, dt)])  # 256- / 96- / 64-row tiles
-        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11))
+        assert torch.equal(outs[(7, dt)], outs[(0, dt)])  # 256 x 256 tiles (the policy's choice for the two large outputs)
+        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11, 7))
     # two wave groups: even / odd K tiles summed separately
     torch.testing.assert_close(outs[(5, torch.float32)], outs[(0, torch.float32)], rtol=1e-5, atol=2e-3)
     torch.testing.assert_close(outs[(5, BF)].float(), outs[(0, BF)].float(), rtol=1e-2, atol=1e-2)
@@ -705,7 +706,7 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
     ref_w = (dY.double().t() @ X.double() + W0.double()).float()
     ref_b = (dY.double().sum(0) + b0.double()).float()
     res = {}
-    for pipe in (3, 6, 0, 5, 1):
+    for pipe in (3, 6, 7, 0, 5, 1):  # (7 has no fused bias gradient: it must hand the launch to 3)
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             w, b = W0.clone(), b0.clone()
@@ -713,8 +714,9 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
             res[pipe] = (w, b)
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    assert torch.equal(res[3][0], res[0][0]) and torch.equal(res[6][0], res[0][0])
-    for pipe in (3, 6, 0, 5, 1):
+    assert torch.equal(res[3][0], res[0][0]) and torch.equal(res[6][0], res[0][0]) and torch.equal(res[7][0], res[0][0])
+    assert torch.equal(res[7][1], res[3][1])
+    for pipe in (3, 6, 7, 0, 5, 1):
         torch.testing.assert_close(res[pipe][0], ref_w, rtol=2e-3, atol=2e-2)
         torch.testing.assert_close(res[pipe][1], ref_b, rtol=1e-3, atol=2e-2)
 
