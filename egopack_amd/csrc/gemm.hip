@@ -310,6 +310,102 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
     }
 }
 
+// Epilogue of the 4-wave pipelined variants through LDS.  The accumulator layout gives a lane 4 consecutive columns of
+// ONE row per MFMA tile: stored directly, a wave-instruction writes 16 rows x 32 bytes (bf16) -- 16 partial-line
+// requests for 512 bytes -- and a 96 x 128 tile took 3.7 us just to ISSUE its stores (in-kernel stamps,
+// tools/gemm_stamps.py --phases: 2 us to the first K tile, 9.4 us of K loop, 3.7 us of epilogue for 6144 x 1024 x
+// 1024).  Here the raw accumulators go to the (now idle) ring as f32 [rows][128], 16-byte slot index XOR (row & 15)
+// (conflict-free for the scattered writes and the row reads), and come back as 8 consecutive columns per lane: a
+// wave-instruction then covers 4 whole 256-byte (bf16) rows.  The arithmetic per element is gemm_epilogue's, in its
+// order: results are bit-identical.  Block-uniform precondition (epilogue_rows_ok): 16-byte aligned rows everywhere.
+__device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if ((g.N & 7) != 0) return false;
+    if (g.splitk > 1) return al16(g.ws);  // slabs: [z][M][N] f32, N % 8 == 0
+    if (!al16(g.C) || (g.ldc & (g.c_bf16 ? 7 : 3)) != 0) return false;
+    if (g.bias && !al16(g.bias)) return false;
+    if (g.residual && (!al16(g.residual) || (g.ldr & (g.r_bf16 ? 7 : 3)) != 0)) return false;
+    return true;
+}
+
+template <int NI>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[NI][4], unsigned char* lds, int m0, int n0,
+                                                   int wm, int wn, int lr, int lg, int z, int tid) {
+    __syncthreads();  // every wave is done with the ring (nothing is in flight: the last tiles were waited for)
+    float* stage = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = wm * 16 * NI + i * 16 + lr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int slot = (wn * 16 + j * 4 + lg) ^ (row & 15);
+            *reinterpret_cast<f32x4*>(stage + row * 128 + slot * 4) = acc[i][j];
+        }
+    }
+    __syncthreads();
+    const int c8 = tid & 15, n = n0 + c8 * 8;
+    if (n >= g.N) return;  // (N % 8 == 0: a group of 8 columns is all in or all out)
+    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.bias && g.splitk == 1) {
+        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
+#pragma unroll
+    for (int it = 0; it < 2 * NI; ++it) {
+        const int row = it * 16 + (tid >> 4), m = m0 + row;
+        if (m >= g.M) continue;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * 128 + (((2 * c8) ^ (row & 15)) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * 128 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+        float o[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (g.splitk > 1) {
+            float* p = g.ws + ((long long)z * g.M + m) * g.N + n;
+            *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            continue;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] *= g.alpha;
+        if (g.accumulate) {  // C is f32 when accumulating (checked on the host)
+            const float* cp = (const float*)g.C + (long long)m * g.ldc + n;
+            const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+            o[0] += c0.x; o[1] += c0.y; o[2] += c0.z; o[3] += c0.w; o[4] += c1.x; o[5] += c1.y; o[6] += c1.z; o[7] += c1.w;
+        }
+        if (g.bias)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] += bias[t];
+        if (g.act == EGK_ACT_RELU)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = fmaxf(o[t], 0.f);
+        if (g.residual) {
+            if (g.r_bf16) {
+                const uint4 r = *reinterpret_cast<const uint4*>((const bf16_t*)g.residual + (long long)m * g.ldr + n);
+                const unsigned rw[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    o[2 * t] += __uint_as_float(rw[t] << 16);
+                    o[2 * t + 1] += __uint_as_float(rw[t] & 0xffff0000u);
+                }
+            } else {
+                const float* rp = (const float*)g.residual + (long long)m * g.ldr + n;
+                const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+            }
+        }
+        if (g.c_bf16) {
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
+            *reinterpret_cast<uint4*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
+        } else {
+            float* cp = (float*)g.C + (long long)m * g.ldc + n;
+            *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(cp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
 // BF16C: bf16 MFMA (else exact f32).  TA/TB: operand transposed in memory.  AT/BT: element type in memory.
 template <bool BF16C, bool TA, bool TB, typename AT, typename BT>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
@@ -486,6 +582,10 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
     constexpr int WG = 4 * MB;         // waves per wave group
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KT = 64;
+#ifdef EGK_GEMM_STAMPS  // diagnostic build only (tools/gemm_stamps.py --phases): entry, first tile landed, loop end, exit
+    const unsigned long long ps_entry = __builtin_amdgcn_s_memtime(), ps_rentry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ps_first = 0;
+#endif
 
     int z, tm, tn;
     tile_of(g, blockIdx.x, z, tm, tn);
@@ -569,6 +669,9 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's pieces of tile ``it`` landed; the stage read at it-1 is free
+#ifdef EGK_GEMM_STAMPS
+        if (it == 0) ps_first = __builtin_amdgcn_s_memtime();
+#endif
         if (it + NSTAGE - 1 < nt) issue(it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
         if (KG > 1 && it >= nt) continue;  // (wave-group uniform) odd tile count: the last round is group 0's only
 
@@ -674,6 +777,9 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
             }
         }
     }
+#ifdef EGK_GEMM_STAMPS
+    const unsigned long long ps_loop = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (TRA) {
         if (g.dbias != nullptr && tn == 0) {  // block-uniform
             __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [16 * KG][128]
@@ -694,7 +800,12 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         }
     }
     if constexpr (KG == 1) {
-        gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
+        if constexpr (MB == 1) {
+            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid);
+            else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
+        } else {
+            gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
+        }
     } else if constexpr (NI == 4) {
         // Exchange: group 0 finishes rows i = 0,1 of each wave tile, group 1 rows i = 2,3.  Each group parks the half
         // it does not finish in LDS ([group][wave][i2][j][lane] f32x4, lane-contiguous 16-B stores), then adds the
@@ -729,6 +840,17 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
         }
         gemm_epilogue<2, 4>(g, half, m0, n0, wm * 64 + grp * 32, wn * 64, lr, lg, z);
     }
+#ifdef EGK_GEMM_STAMPS
+    if (g.ws_bias != nullptr && g.dbias == nullptr && tid == 0) {  // (the host points ws_bias behind the slabs in this build)
+        const unsigned long long ps_issued = __builtin_amdgcn_s_memtime();  // the output stores are issued ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // ... and acknowledged
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws_bias) + (long long)blockIdx.x * 8;
+        const unsigned long long ps_end = __builtin_amdgcn_s_memtime();
+        o[7] = ps_issued - ps_loop;
+        o[0] = ps_first - ps_entry; o[1] = ps_loop - ps_first; o[2] = ps_end - ps_loop; o[3] = ps_end - ps_entry;
+        o[4] = __builtin_amdgcn_s_memrealtime() - ps_rentry; o[5] = ps_rentry; o[6] = nt;
+    }
+#endif
 }
 
 // Fragment reads of the 256 x 256 kernel: fragments FIRST .. FIRST + 3 of k-step S of one operand image (inline asm for
@@ -1226,6 +1348,10 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
         if (variant == 7) g.tiles_n = cdiv(g.N, 256);
 #ifdef EGK_GEMM_STAMPS
+        if (variant != 7 && !g.dbias && d->ws) {
+            const int64_t slab = g.splitk > 1 ? (int64_t)g.splitk * d->M * d->N * 4 : 0;
+            if (d->ws_bytes >= slab + (int64_t)g.tiles_m * g.tiles_n * g.splitk * 64) g.ws_bias = (float*)((char*)d->ws + slab);
+        }
         if (variant == 7 && g.splitk == 1 && !g.dbias && d->ws && d->ws_bytes >= (int64_t)g.tiles_m * g.tiles_n * 8 * 64)
             g.ws_bias = (float*)d->ws;  // per-wave cycle stamps land in the caller's workspace
 #endif

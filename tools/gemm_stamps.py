@@ -32,6 +32,55 @@ from egopack_amd import _lib
 _lib.LIB_PATH = LIB
 from egopack_amd import ops
 
+if "--phases" in sys.argv:
+    # python tools/gemm_stamps.py --phases M N K tA tB splitk [variant]: entry -> first tile landed -> K loop -> epilogue,
+    # per workgroup, of the 128-row pipelined kernels (the launch the policy would make unless a variant is forced)
+    a = [v for v in sys.argv[1:] if not v.startswith("--")]
+    M, N, K, tA, tB, sk = (int(v) for v in a[:6])
+    lib = _lib.load()
+    lib.egk_gemm_set_pipeline(int(a[6]) if len(a) > 6 else 1)
+    bf = torch.bfloat16
+    A = torch.randn((K, M) if tA else (M, K), device="cuda").to(bf)
+    B = torch.randn((K, N) if tB else (N, K), device="cuda").to(bf)
+    acc = bool(tA and tB)
+    out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if acc else bf)
+    slab = sk * M * N * 4 if sk > 1 else 0
+    nwg_max = ((M + 63) // 64) * ((N + 127) // 128) * sk
+    ws = torch.zeros(slab + nwg_max * 64 + 64, dtype=torch.uint8, device="cuda")
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K1, d.K2 = M, N, K, 0
+    d.A1, d.B1 = A.data_ptr(), B.data_ptr()
+    d.lda1, d.ldb1 = A.shape[1], B.shape[1]
+    d.transA, d.transB = tA, tB
+    d.a_dtype = d.b_dtype = ops.BF16
+    d.c_dtype, d.compute = (ops.F32 if acc else ops.BF16), ops.BF16
+    d.C, d.ldc, d.alpha, d.splitk, d.accumulate = out.data_ptr(), N, 1.0, sk, int(acc)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        assert lib.egk_gemm(ops._stream(), C.byref(d)) == 0
+    torch.cuda.synchronize()
+    ws[slab:].zero_()
+    torch.cuda.synchronize()
+    e0.record()
+    assert lib.egk_gemm(ops._stream(), C.byref(d)) == 0
+    e1.record()
+    torch.cuda.synchronize()
+    st = ws[slab: slab + nwg_max * 64].view(torch.int64).view(-1, 8).cpu().double()
+    st = st[st[:, 3] > 0]
+    clk = (st[:, 3] / st[:, 4]).median().item() * 0.1
+    t0 = st[:, 5].min()
+    start_us, end_us = (st[:, 5] - t0) / 100, (st[:, 5] - t0 + st[:, 4]) / 100
+    med = st.median(0).values
+    print(f"{M}x{N}x{K} tA={tA} tB={tB} splitk={sk}: {st.shape[0]} workgroups x {int(med[6])} K tiles (per wave group); events around the "
+          f"launch (incl. the slab reduce if any): {e0.elapsed_time(e1) * 1e3:.1f} us; in-kernel clock {clk:.2f} GHz")
+    print(f"  first workgroup entry -> last workgroup exit: {end_us.max():.1f} us; workgroup entries spread over {start_us.max():.1f} us "
+          f"(median {start_us.median():.1f})")
+    for name, i in (("entry -> first K tile landed", 0), ("K loop", 1), ("epilogue: until the stores are issued", 7),
+                    ("epilogue: until they are acknowledged", 2), ("workgroup lifetime", 3)):
+        print(f"  {name:42s} median {med[i] / clk / 1e3:6.2f} us   max {st[:, i].max().item() / clk / 1e3:6.2f} us")
+    sys.exit(0)
+
 M, N, K = (int(v) for v in sys.argv[1:4])
 tA, tB = (int(v) for v in sys.argv[4:6]) if len(sys.argv) > 5 else (0, 0)
 lib = _lib.load()
