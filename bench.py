@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
                     help="element type of the gradient all-reduce when --gpus > 1")
+    ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
@@ -291,6 +292,9 @@ def main():
     from egopack_amd.optim import FlatAdam
     ops.set_compute(args.compute)
     ops.manual_seed(1000 + rank)  # dropout streams differ per rank
+    if args.gemm_knob is not None:
+        from egopack_amd import _lib
+        _lib.load().egk_gemm_set_pipeline(args.gemm_knob)
 
     model, tasks, crit, weights, dev, merged = build_workload(args, rank, device)
     names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}

@@ -53,6 +53,7 @@ struct GemmArgs {
     int group_m;      // pipelined kernel: tile rows per group of the XCD-local tile order (see tile_of)
     float* dbias;     // fused bias gradient: dbias[m] += sum_k op(A)[m, k]  (transA pipelined kernel only)
     float* ws_bias;   // [splitk][M] partial row sums when splitk > 1
+    int rows_epilogue;  // 4-wave pipelined variants: write the tile out through LDS in whole rows (development knob, default 1)
 };
 
 // Workgroup -> (slab z, tile row, tile column) for a 1-D launch of tiles_m * tiles_n * splitk workgroups.
@@ -319,6 +320,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
 // wave-instruction then covers 4 whole 256-byte (bf16) rows.  The arithmetic per element is gemm_epilogue's, in its
 // order: results are bit-identical.  Block-uniform precondition (epilogue_rows_ok): 16-byte aligned rows everywhere.
 __device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
+    if (!g.rows_epilogue) return false;
     const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if ((g.N & 7) != 0) return false;
     if (g.splitk > 1) return al16(g.ws);  // slabs: [z][M][N] f32, N % 8 == 0
@@ -1162,6 +1164,7 @@ using namespace egk;
 
 static int g_use_pipe = 1;
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
+static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static bool g_lds_attr_set = false;
 template <int NS, bool TA, bool TB, int KG, int MB = 1>
 static void set_lds_attr() {
@@ -1189,6 +1192,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 200) { g_rows_epilogue = on - 200; return prev; }
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
     // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
     // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 7 always the 256 x 256 tile (no fused
@@ -1274,6 +1278,7 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     g.tiles_m = cdiv(g.M, BM); g.tiles_n = cdiv(g.N, BN);
     g.dbias = nullptr; g.ws_bias = nullptr;
     g.group_m = 1;
+    g.rows_epilogue = g_rows_epilogue;
     const int K = d->K1 + d->K2;
     const double flops = 2.0 * d->M * d->N * K;
     const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
