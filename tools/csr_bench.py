@@ -33,5 +33,8 @@ for name, T, B, lta in [("band T=32 B=192", 32, 192, False), ("band T=256 B=48",
 
     def bwd():
         ops._csr_gather(x, g.t_rowptr, g.t_col, g.t_wgt, x, out, g.t_heavy)
+    def bwd_inkernel():  # no heavy-row list: rows above the in-kernel threshold are summed by their workgroup's four waves
+        ops._csr_gather(x, g.t_rowptr, g.t_col, g.t_wgt, x, out, None)
     deg = (g.t_rowptr[1:] - g.t_rowptr[:-1]).max().item()
-    print(f"{name:34s} N={N:6d} E={g.col.numel():7d} max out-degree {deg:4d}   fwd {time_us(fwd, 20):7.1f} us   bwd {time_us(bwd, 20):7.1f} us")
+    print(f"{name:34s} N={N:6d} E={g.col.numel():7d} max out-degree {deg:4d} ({g.t_heavy.numel()} listed)   fwd {time_us(fwd, 20):7.1f} us   "
+          f"bwd {time_us(bwd, 20):7.1f} us   bwd without the split launches {time_us(bwd_inkernel, 20):7.1f} us")
