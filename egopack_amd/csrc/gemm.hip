@@ -1182,7 +1182,6 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     set_lds_attr<2, false, false, 1, 2>(); set_lds_attr<2, false, true, 1, 2>(); set_lds_attr<2, true, true, 1, 2>(); set_lds_attr<2, true, false, 1, 2>();
-    set_lds_attr<3, false, false, 1, 2>(); set_lds_attr<3, false, true, 1, 2>(); set_lds_attr<3, true, true, 1, 2>(); set_lds_attr<3, true, false, 1, 2>();
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1349,7 +1348,7 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
         }
-        const int mb = (variant == 6 || variant == 9) ? 2 : 1;
+        const int mb = variant == 6 ? 2 : 1;
         g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
         if (variant == 7) g.tiles_n = cdiv(g.N, 256);
 #ifdef EGK_GEMM_STAMPS
@@ -1379,8 +1378,6 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
             hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);                \
         } else if (variant == 8) {                                                                                        \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);                \
-        } else if (variant == 9) {                                                                                        \
-            hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, g);          \
         } else if (variant == 6)                                                                                          \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
         else if (variant == 5)                                                                                            \

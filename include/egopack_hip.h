@@ -90,11 +90,15 @@ typedef struct egk_gemm_desc {
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute);
-/* development knob for A/B measurements in one process: 0 routes every contraction through the generic
- * register-staged kernel, 1 (default) lets eligible ones (bf16 operands, 16-byte aligned rows, K % 64 == 0) use
- * the LDS-DMA pipelined kernel with a 2-stage ring, 2 the same with a 3-stage ring.  Returns the previous setting. */
 /* development knob of the row kernels (launch geometry only, results unchanged): returns the previous value */
 int egk_tune(int32_t key, int32_t value);
+/* development knob for A/B measurements in one process (results unchanged up to the summation order of variant 5):
+ * 0 routes every contraction through the generic register-staged kernel; 1 (default) lets eligible ones (bf16
+ * operands, 16-byte aligned rows, K % 64 == 0) use the LDS-DMA pipelined kernels, variant chosen per launch; a value
+ * 2..11 forces one variant where it is legal (2 / 3 / 4: 3- / 2- / 4-stage ring on 128 x 128 tiles, 5: two wave groups,
+ * 6: 256 x 128 tile, 7: 256 x 256 tile, 8 / 11: 96- / 64-row tiles); 100 + g overrides the XCD tile-group height
+ * (100 = policy); 200 / 201 selects the direct / row-contiguous (default) epilogue of the 4-wave variants.  Returns the
+ * previous variant setting. */
 int egk_gemm_set_pipeline(int32_t on);
 
 /* out[n] (+)= sum_m x[m, n] : bias gradients of every Linear above.  Two launches (row-chunk
