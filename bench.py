@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--staged", choices=["auto", "on", "off"], default="auto",
                     help="three-stage backward with region-wise gradient exchange (auto: when there are several ranks)")
     ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
+    ap.add_argument("--one-call-backward", action="store_true",
+                    help="one backward() call over all head streams instead of one per head inside its stream context (A/B)")
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
@@ -342,6 +344,8 @@ def main():
         step.staged = {"auto": None, "on": True, "off": False}[args.staged]
         if args.head_streams:
             step.max_head_streams = args.head_streams
+        if args.one_call_backward:
+            step.headwise_backward = False
 
         def eager_step():
             step.step(dev, fused_merged)
