@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
+    ap.add_argument("--csr-split-heavy", action="store_true",
+                    help="A/B: sum the listed heavy CSR rows with the split launches even when they are short enough for the launch itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
@@ -300,6 +302,9 @@ def main():
         from egopack_amd import _lib
         _lib.load().egk_gemm_set_pipeline(args.gemm_knob)
 
+    if args.csr_split_heavy:
+        from egopack_amd import data as _D
+        _D.HEAVY_IN_LAUNCH_DEGREE = 0
     model, tasks, crit, weights, dev, merged = build_workload(args, rank, device)
     names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
     sds = None

@@ -59,7 +59,7 @@ SIGNATURES = {
     "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
     "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
     "egk_pe_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
-    "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]),
+    "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32]),
     "egk_csr_heavy_ws_bytes": (i64, [i32, i32]),
     "egk_csr_heavy_threshold": (i32, []),
     "egk_gather_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),

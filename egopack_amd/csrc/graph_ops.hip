@@ -59,7 +59,8 @@ constexpr int HEAVY = 12;
 template <int NV, typename T>
 __device__ __forceinline__ void csr_accumulate(const T* __restrict__ x, const int* __restrict__ col, const float* __restrict__ wgt,
                                                int e0, int e1, int e_first, int e_stride, int cols, bool vec, int lane,
-                                               float4 (&acc)[NV]) {
+                                               float4 (&acc)[NV], long long stride = -1) {
+    if (stride < 0) stride = cols;  // (a column slice of wider rows passes the row stride and its own width as cols)
     // edges e0 + e_first, e0 + e_first + e_stride, ... < e1
     const int n_mine = (e1 - e0 - e_first + e_stride - 1) / e_stride;
     for (int base = 0; base < n_mine; base += 64) {
@@ -69,10 +70,10 @@ __device__ __forceinline__ void csr_accumulate(const T* __restrict__ x, const in
         const float my_w = (wgt && lane < cnt) ? wgt[my_e] : 1.f;
         int e = 0;
         for (; e + 4 <= cnt; e += 4) {
-            const T* s0 = x + (long long)__shfl(my_c, e + 0, 64) * cols;
-            const T* s1 = x + (long long)__shfl(my_c, e + 1, 64) * cols;
-            const T* s2 = x + (long long)__shfl(my_c, e + 2, 64) * cols;
-            const T* s3 = x + (long long)__shfl(my_c, e + 3, 64) * cols;
+            const T* s0 = x + (long long)__shfl(my_c, e + 0, 64) * stride;
+            const T* s1 = x + (long long)__shfl(my_c, e + 1, 64) * stride;
+            const T* s2 = x + (long long)__shfl(my_c, e + 2, 64) * stride;
+            const T* s3 = x + (long long)__shfl(my_c, e + 3, 64) * stride;
             const float w0 = __shfl(my_w, e + 0, 64), w1 = __shfl(my_w, e + 1, 64);
             const float w2 = __shfl(my_w, e + 2, 64), w3 = __shfl(my_w, e + 3, 64);
             float4 v0[NV], v1[NV], v2[NV], v3[NV];
@@ -91,7 +92,7 @@ __device__ __forceinline__ void csr_accumulate(const T* __restrict__ x, const in
             }
         }
         for (; e < cnt; ++e) {
-            const T* src = x + (long long)__shfl(my_c, e, 64) * cols;
+            const T* src = x + (long long)__shfl(my_c, e, 64) * stride;
             const float we = __shfl(my_w, e, 64);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -104,7 +105,8 @@ __device__ __forceinline__ void csr_accumulate(const T* __restrict__ x, const in
 
 template <int NV, typename T>
 __device__ __forceinline__ void csr_finish(float4 (&acc)[NV], const float* __restrict__ wgt, float mean_w, const T* __restrict__ gate,
-                                           T* __restrict__ out, int row, int cols, bool vec, int lane) {
+                                           T* __restrict__ out, int row, int cols, bool vec, int lane, long long stride = -1) {
+    if (stride < 0) stride = cols;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -112,11 +114,11 @@ __device__ __forceinline__ void csr_finish(float4 (&acc)[NV], const float* __res
             acc[i].x *= mean_w; acc[i].y *= mean_w; acc[i].z *= mean_w; acc[i].w *= mean_w;
         }
         if (gate) {
-            const float4 g = ld4(gate + (long long)row * cols, c, cols, vec);
+            const float4 g = ld4(gate + (long long)row * stride, c, cols, vec);
             acc[i].x = g.x > 0.f ? acc[i].x : 0.f; acc[i].y = g.y > 0.f ? acc[i].y : 0.f;
             acc[i].z = g.z > 0.f ? acc[i].z : 0.f; acc[i].w = g.w > 0.f ? acc[i].w : 0.f;
         }
-        st4(out + (long long)row * cols, c, cols, vec, acc[i]);
+        st4(out + (long long)row * stride, c, cols, vec, acc[i]);
     }
 }
 
@@ -124,15 +126,33 @@ template <int NV, typename T>
 __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x, const int* __restrict__ rowptr,
                                                          const int* __restrict__ col, const float* __restrict__ wgt,
                                                          const T* __restrict__ gate, T* __restrict__ out, int rows,
-                                                         int cols, int skip_above) {
+                                                         int cols, int skip_above, const int* __restrict__ block_rows,
+                                                         int n_block_rows) {
     extern __shared__ __attribute__((aligned(16))) float part[];  // [3][NV*256] partial rows of waves 1..3
     __shared__ int heavy[64];
     __shared__ int n_heavy;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
+    if ((int)blockIdx.x < n_block_rows) {
+        // One of the listed rows (more than skip_above edges, at most a few dozen: the LTA fan-out node at T = 32), summed
+        // by THIS workgroup alone while the others do the light rows: every wave walks all the edges, in order, for its
+        // quarter of the columns -- the summation order of a light row, no partial rows, no second launch.
+        constexpr int NVW = NV >= 4 ? NV / 4 : 1;
+        const int row = block_rows[blockIdx.x], c0 = wave * NVW * 256;
+        if (c0 >= cols) return;
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        float4 acc[NVW];
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        csr_accumulate<NVW, T>(x + c0, col, wgt, e0, e1, 0, 1, cols - c0, vec, lane, acc, cols);
+        csr_finish<NVW, T>(acc, wgt, e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f, gate ? gate + c0 : gate, out + c0, row, cols - c0, vec,
+                           lane, cols);
+        return;
+    }
+    const int bid = blockIdx.x - n_block_rows, nblk = gridDim.x - n_block_rows;
     if (threadIdx.x == 0) n_heavy = 0;
     __syncthreads();
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    for (int row = bid * WPB + wave; row < rows; row += nblk * WPB) {
         const int e0 = rowptr[row], e1 = rowptr[row + 1];
         if (e1 - e0 > skip_above) continue;  // listed by the host: the split launches below produce this row
         if (e1 - e0 > HEAVY) {  // deferred to the cooperative phase (wave-uniform branch) while the list has room
@@ -666,18 +686,19 @@ int32_t egk_csr_heavy_threshold(void) { return VERY_HEAVY; }
 
 int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
                    const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
-                   int32_t n_heavy, float* ws) {
+                   int32_t n_heavy, float* ws, int32_t heavy_mode) {
     EGK_REQUIRE(x && rowptr && out, "egk_csr_gather: null pointer");
-    EGK_REQUIRE(n_heavy == 0 || (heavy_rows && ws), "egk_csr_gather: heavy rows need their list and a workspace");
+    EGK_REQUIRE(n_heavy == 0 || (heavy_rows && (ws || heavy_mode == 1)), "egk_csr_gather: heavy rows need their list and a workspace");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CSR_GATHER, s, 0, (dtype == EGK_BF16 ? 0.5 : 1.0) * (relu_gate ? 12.0 : 8.0) * rows * cols);
     EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
     const int skip_above = n_heavy > 0 ? VERY_HEAVY : 0x7fffffff;
-#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows)), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above)
+    const int in_launch = (n_heavy > 0 && heavy_mode == 1) ? n_heavy : 0;  // listed rows summed by one workgroup each, in the same launch
+#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows) + in_launch), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above, heavy_rows, in_launch)
     EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
 #undef EGK_CSR
-    if (n_heavy > 0) {
+    if (n_heavy > 0 && !in_launch) {
         EGK_DISPATCH_T(dtype, {
             hipLaunchKernelGGL((csr_heavy_partial_kernel<T>), dim3(n_heavy, CSR_CHUNKS), dim3(256), 0, s, (const T*)x, rowptr, col,
                                wgt, heavy_rows, ws, cols);

@@ -50,6 +50,7 @@ class Data:
 
 
 HEAVY_DEGREE = 24  # = egk_csr_heavy_threshold() (tests/test_cabi.py checks the two agree)
+HEAVY_IN_LAUNCH_DEGREE = 64  # listed rows up to this many edges: one workgroup each inside the gather launch (heavy_mode 1)
 
 
 @dataclass
@@ -71,10 +72,14 @@ class CSRGraph:
     # node has out-degree T - 1): the gather kernel cuts those rows over several workgroups (egk_csr_gather)
     heavy: Optional[torch.Tensor] = None
     t_heavy: Optional[torch.Tensor] = None
+    # egk_csr_gather's heavy_mode per orientation: 1 if every listed row has at most HEAVY_IN_LAUNCH_DEGREE edges (T = 32:
+    # the fan-out node's 31), 0 if some have hundreds (T = 256)
+    heavy_mode: int = 0
+    t_heavy_mode: int = 0
 
     def _map(self, f):
         return CSRGraph(*(f(t) for t in (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)), self.num_nodes,
-                        *(f(t) if t is not None else None for t in (self.heavy, self.t_heavy)))
+                        *(f(t) if t is not None else None for t in (self.heavy, self.t_heavy)), self.heavy_mode, self.t_heavy_mode)
 
     def to(self, device, non_blocking: bool = False):
         return self._map(lambda t: t.to(device, non_blocking=non_blocking))
@@ -100,7 +105,9 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
     t_wgt = 1.0 / deg_in[t_col].clamp(min=1).to(torch.float32)
     heavy = torch.nonzero(deg_in > HEAVY_DEGREE).flatten().int()
     t_heavy = torch.nonzero(deg_out > HEAVY_DEGREE).flatten().int()
-    return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes), heavy, t_heavy)
+    mode = lambda deg, listed: int(listed.numel() > 0 and int(deg.max()) <= HEAVY_IN_LAUNCH_DEGREE)
+    return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes), heavy, t_heavy,
+                    mode(deg_in, heavy), mode(deg_out, t_heavy))
 
 
 # --------------------------------------------------------------------------------------------

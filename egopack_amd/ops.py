@@ -635,25 +635,27 @@ def pe_add(x, pos, freq):
 
 
 # ---- CSR mean aggregation -------------------------------------------------------------------------------
-def _csr_gather(x, rowptr, col, wgt, gate, out, heavy=None):
+def _csr_gather(x, rowptr, col, wgt, gate, out, heavy=None, heavy_mode=0):
     """One ``egk_csr_gather`` call; ``heavy`` = ascending int32 ids of the rows with more than
-    ``egk_csr_heavy_threshold()`` edges (data.build_csr lists them), or None / empty."""
+    ``egk_csr_heavy_threshold()`` edges (data.build_csr lists them), or None / empty; ``heavy_mode`` 1 when none of them
+    has more than data.HEAVY_IN_LAUNCH_DEGREE edges (summed inside the launch), 0 for the split launches."""
     lib = _lib.load()
     rows, cols = x.shape
     nh = int(heavy.numel()) if heavy is not None else 0
-    ws = workspace(lib.egk_csr_heavy_ws_bytes(nh, cols), x.device) if nh else None
+    ws = workspace(lib.egk_csr_heavy_ws_bytes(nh, cols), x.device) if nh and not heavy_mode else None
     _ck(lib.egk_csr_gather(_stream(), _p(x), _p(rowptr), _p(col), _p(wgt), _p(gate), _p(out), rows, cols, _dt(x),
-                           _p(heavy) if nh else None, nh, _p(ws) if nh else None), "egk_csr_gather")
+                           _p(heavy) if nh else None, nh, _p(ws) if ws is not None else None, int(heavy_mode)), "egk_csr_gather")
 
 
 class _CSRMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rowptr, col, t_rowptr, t_col, t_wgt, heavy, t_heavy):
+    def forward(ctx, x, rowptr, col, t_rowptr, t_col, t_wgt, heavy, t_heavy, heavy_mode=0, t_heavy_mode=0):
         _need_gpu(x, rowptr, col)
         x = _c(x)
         out = torch.empty_like(x)
-        _csr_gather(x, rowptr, col, None, None, out, heavy)
+        _csr_gather(x, rowptr, col, None, None, out, heavy, heavy_mode)
         ctx.save_for_backward(t_rowptr, t_col, t_wgt, t_heavy)
+        ctx.t_heavy_mode = t_heavy_mode
         return out
 
     @staticmethod
@@ -661,14 +663,15 @@ class _CSRMean(torch.autograd.Function):
         t_rowptr, t_col, t_wgt, t_heavy = ctx.saved_tensors
         dout = _c(dout)
         dx = torch.empty_like(dout)
-        _csr_gather(dout, t_rowptr, t_col, t_wgt, None, dx, t_heavy)
-        return dx, None, None, None, None, None, None, None
+        _csr_gather(dout, t_rowptr, t_col, t_wgt, None, dx, t_heavy, ctx.t_heavy_mode)
+        return dx, None, None, None, None, None, None, None, None, None
 
 
 def csr_mean_aggregate(x, graph):
     """agg[i] = mean_{j->i} x[j] (0 without in-edges); ``graph`` = egopack_amd.data.CSRGraph."""
     return _CSRMean.apply(x, graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
-                          getattr(graph, "heavy", None), getattr(graph, "t_heavy", None))
+                          getattr(graph, "heavy", None), getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0),
+                          getattr(graph, "t_heavy_mode", 0))
 
 
 class _SageMean(torch.autograd.Function):
@@ -678,7 +681,8 @@ class _SageMean(torch.autograd.Function):
     two-source contraction (no gradient-accumulation add), the two bias gradients ride on their dW launches."""
 
     @staticmethod
-    def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute, heavy=None, t_heavy=None):
+    def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute, heavy=None, t_heavy=None,
+                heavy_mode=0, t_heavy_mode=0):
         _need_gpu(h, Wp, Wl, Wr)
         lib = _lib.load()
         h = _c(h)
@@ -688,7 +692,8 @@ class _SageMean(torch.autograd.Function):
         xp = torch.empty_like(h)
         gemm(N, H, h, H, Wp_o, H, H, xp, H, bias=_f32c(bp), act=1, compute=compute)
         agg = torch.empty_like(h)
-        _csr_gather(xp, rowptr, col, None, None, agg, heavy)
+        _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode)
+        ctx.t_heavy_mode = t_heavy_mode
         Ho = Wl.shape[0]
         out = torch.empty((N, Ho), dtype=dt, device=h.device)
         gemm(N, Ho, agg, H, Wl_o, H, H, out, Ho, A2=h, lda2=H, B2=Wr_o, ldb2=H, K2=H, bias=_f32c(bl), compute=compute)
@@ -725,7 +730,7 @@ class _SageMean(torch.autograd.Function):
         d_agg = torch.empty_like(h)
         gemm(N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H, transB=True, compute=ctx.compute)
         d_pre = torch.empty_like(h)  # gradient at the projection's pre-activation: transposed gather gated by xp > 0
-        _csr_gather(d_agg, t_rowptr, t_col, t_wgt, xp, d_pre, t_heavy)
+        _csr_gather(d_agg, t_rowptr, t_col, t_wgt, xp, d_pre, t_heavy, ctx.t_heavy_mode)
         d_h = None
         if ctx.needs_input_grad[0]:
             d_h = torch.empty_like(h)
@@ -734,7 +739,7 @@ class _SageMean(torch.autograd.Function):
         _wgrad_launch(rWp is None and rbp is None, (d_pre, h),
                       lambda: gemm(H, H, d_pre, H, h, H, N, dWp, H, transA=True, transB=True, accumulate=True,
                                    compute=ctx.compute, dbias=dbp))
-        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None)
+        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None)
 
 
 def sage_mean_layer(h, conv, graph, compute=None):
@@ -742,7 +747,7 @@ def sage_mean_layer(h, conv, graph, compute=None):
     return _SageMean.apply(h, conv.lin.weight, conv.lin.bias, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight,
                            graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
                            _compute_for(h) if compute is None else compute, getattr(graph, "heavy", None),
-                           getattr(graph, "t_heavy", None))
+                           getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0), getattr(graph, "t_heavy_mode", 0))
 
 
 # ---- GraphONE gather-max ------------------------------------------------------------------------------

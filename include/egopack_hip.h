@@ -156,10 +156,13 @@ int egk_pe_add(egk_stream_t s, const void* x, const int64_t* pos, const float* f
  * heavy_rows (may be NULL with n_heavy = 0): ascending ids of EXACTLY the rows with more than
  * egk_csr_heavy_threshold() edges, listed by whoever built the CSR; those rows are summed by several workgroups
  * each (edge ranges -> f32 partial rows in ws, egk_csr_heavy_ws_bytes(n_heavy, cols) bytes, -> ordered finish)
- * instead of by one: the LTA fan-out node has out-degree T - 1. */
+ * instead of by one: the LTA fan-out node has out-degree T - 1.
+ * heavy_mode: 0 = that (two extra launches; for rows of hundreds of edges); 1 = every listed row is summed by ONE
+ * workgroup of the same launch, edges in order, while the other workgroups do the light rows (for listed rows of a few
+ * dozen edges, e.g. T = 32: no extra launch, ws may be NULL; the caller knows the degrees it listed). */
 int egk_csr_gather(egk_stream_t s, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
                    const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
-                   int32_t n_heavy, float* ws);
+                   int32_t n_heavy, float* ws, int32_t heavy_mode);
 int64_t egk_csr_heavy_ws_bytes(int32_t n_heavy, int32_t cols);
 int32_t egk_csr_heavy_threshold(void);
 

@@ -789,7 +789,7 @@ def test_topk_selection_equals_full_lexicographic_sort(ops, rows, K, k):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
-@pytest.mark.parametrize("T,B", [(256, 3), (70, 5), (20, 2)])
+@pytest.mark.parametrize("T,B", [(256, 3), (70, 5), (20, 2), (32, 6), (66, 2), (67, 2)])
 def test_csr_gather_rows_with_hundreds_of_edges(ops, dtype, T, B):
     """LTA connectivity at long T: the fan-out node has out-degree T - 1 (backward orientation) -- listed by
     build_csr and cut over several workgroups by the kernel; both orientations and the gated transposed form against
@@ -830,3 +830,13 @@ def test_csr_gather_rows_with_hundreds_of_edges(ops, dtype, T, B):
     out3 = torch.empty_like(xd)  # reproducible bit for bit
     ops._csr_gather(xd, gd.t_rowptr, gd.t_col, gd.t_wgt, gated, out3, gd.t_heavy)
     assert torch.equal(out2, out3)
+    # heavy_mode 1 (listed rows of at most HEAVY_IN_LAUNCH_DEGREE edges: one workgroup each inside the launch) is what
+    # build_csr picks for them, and both modes are legal for any list: same sums (mode 1 in edge order, mode 0 in chunks)
+    max_out = int((graph.t_rowptr[1:] - graph.t_rowptr[:-1]).max())
+    assert graph.t_heavy_mode == int(graph.t_heavy.numel() > 0 and max_out <= D.HEAVY_IN_LAUNCH_DEGREE)
+    for mode in (0, 1):
+        o_f, o_b = torch.empty_like(xd), torch.empty_like(xd)
+        ops._csr_gather(xd, gd.rowptr, gd.col, None, None, o_f, gd.heavy, mode)
+        ops._csr_gather(xd, gd.t_rowptr, gd.t_col, gd.t_wgt, gated, o_b, gd.t_heavy, mode)
+        torch.testing.assert_close(o_f.float().cpu().double(), ref_f, **tol)
+        torch.testing.assert_close(o_b.float().cpu().double(), ref_b, **tol)

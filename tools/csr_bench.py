@@ -32,9 +32,12 @@ for name, T, B, lta in [("band T=32 B=192", 32, 192, False), ("band T=256 B=48",
         ops._csr_gather(x, g.rowptr, g.col, None, None, out, g.heavy)
 
     def bwd():
-        ops._csr_gather(x, g.t_rowptr, g.t_col, g.t_wgt, x, out, g.t_heavy)
-    def bwd_inkernel():  # no heavy-row list: rows above the in-kernel threshold are summed by their workgroup's four waves
-        ops._csr_gather(x, g.t_rowptr, g.t_col, g.t_wgt, x, out, None)
+        ops._csr_gather(x, g.t_rowptr, g.t_col, g.t_wgt, x, out, g.t_heavy, g.t_heavy_mode)
+    def bwd_inkernel():  # heavy_mode 1: every listed row summed by one workgroup of the same launch
+        ops._csr_gather(x, g.t_rowptr, g.t_col, g.t_wgt, x, out, g.t_heavy, 1)
+
+    def bwd_split():  # heavy_mode 0: two extra launches
+        ops._csr_gather(x, g.t_rowptr, g.t_col, g.t_wgt, x, out, g.t_heavy, 0)
     deg = (g.t_rowptr[1:] - g.t_rowptr[:-1]).max().item()
     print(f"{name:34s} N={N:6d} E={g.col.numel():7d} max out-degree {deg:4d} ({g.t_heavy.numel()} listed)   fwd {time_us(fwd, 20):7.1f} us   "
-          f"bwd {time_us(bwd, 20):7.1f} us   bwd without the split launches {time_us(bwd_inkernel, 20):7.1f} us")
+          f"bwd (mode {g.t_heavy_mode}) {time_us(bwd, 20):7.1f} us   split launches {time_us(bwd_split, 20):7.1f} us   in-launch blocks {time_us(bwd_inkernel, 20):7.1f} us")
