@@ -134,3 +134,29 @@ def test_staged_backward_equals_the_one_piece_backward(pg, golden, with_sync):
         assert torch.equal(run(True, False), ref)
         assert torch.equal(run(False, True), ref)
         assert torch.equal(run(True, True), ref)
+
+
+def test_headwise_backward_equals_the_one_call_backward(golden):
+    """Every head's backward as its own backward() call inside the head's stream context (so that the captured branches
+    overlap), then the backbone from the three feature gradients: the parameters of one backward() over the whole
+    objective, BIT FOR BIT -- eager and captured, with the heads on side streams and on the main stream."""
+    from egopack_amd import ops
+
+    def run(headwise, graph, parallel):
+        step, opt, batches = _setup(golden, None)
+        step.headwise_backward, step.parallel_heads = headwise, parallel
+        if graph:
+            step.capture(batches, warmup=1)
+            for _ in range(2):
+                step.replay()
+        else:
+            for _ in range(3):
+                step.step(batches)
+        torch.cuda.synchronize()
+        assert opt.step_count == 3
+        return opt.flat_p.clone()
+    for mode in ("f32", "bf16"):
+        with ops.compute_mode(mode):
+            ref = run(False, False, False)
+            for headwise, graph, parallel in [(True, False, False), (True, False, True), (True, True, True), (False, True, True)]:
+                assert torch.equal(run(headwise, graph, parallel), ref), (mode, headwise, graph, parallel)
