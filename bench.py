@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
+    ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
     ap.add_argument("--csr-split-heavy", action="store_true",
                     help="A/B: sum the listed heavy CSR rows with the split launches even when they are short enough for the launch itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -351,6 +352,8 @@ def main():
             step.max_head_streams = args.head_streams
         if args.one_call_backward:
             step.headwise_backward = False
+        if args.no_early_adam:
+            step.early_adam = False
 
         def eager_step():
             step.step(dev, fused_merged)

@@ -245,22 +245,69 @@ class StepBase:
         g = torch.cuda.CUDAGraph()
         opt.prepare_hyper()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        early = self._early_adam_plan(live) if fuse_adam else None
         try:
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 opt.flat_g.zero_()
                 if self.input_hook is not None:
                     self.input_hook()
+                if early is not None:
+                    ops.set_last_wgrad_hook(early["param"], early["hook"])
                 total, vectors = self._backward_pass(batches, merged)
+                ops.set_last_wgrad_hook(None, None)
                 ops.join_wgrad()
                 if fuse_adam:
-                    opt.launch()
+                    if early is not None and early["fired"]:
+                        torch.cuda.current_stream().wait_stream(early["stream"])
+                        opt.launch(None, early["lo"], early["hi"])
+                    else:
+                        opt.launch()
         finally:
+            ops.set_last_wgrad_hook(None, None)
             ops.set_wgrad_side_streams(prev)
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
         self._static_in = (batches, merged)
         return g
+
+    early_adam = True  # captured single-GPU step: start Adam on everything but the last weight gradient's slots beside it
+
+    def _early_adam_plan(self, live):
+        """The step ends with two launches that have the chip to themselves one after the other: the weight gradient of
+        the first TRN linear (the last node of backward, 58 GFLOP, compute-bound) and Adam (750 MB, HBM-bound).  When the
+        backbone runs once per step (fused pass or a single task) every other gradient is final when that weight gradient
+        is launched: Adam over the rest of the flat buffers starts beside it on its own stream, Adam over the slots of
+        that weight and bias follows it.  Elementwise: the same update, bit for bit."""
+        opt = self.optimizer
+        tp = getattr(self.model, "temporal_pooling", None)
+        first = getattr(tp, "proj", [None])[0] if tp is not None else None
+        if not (self.early_adam and first is not None and hasattr(opt, "region_of") and (self.fused or len(live) == 1)):
+            return None
+        params = [p for p in (getattr(first, "weight", None), getattr(first, "bias", None)) if p is not None]
+        lo, hi = opt.region_of(params)
+        total = opt.flat_p.numel()
+        slots = [opt._slot_of[id(p)] for p in params if id(p) in opt._slot_of]
+        if hi <= lo or lo % 8 or hi % 8 or sum(n for _, n in slots) != hi - lo:  # (their slots must be adjacent)
+            return None
+        if not hasattr(self, "_adam_stream"):
+            self._adam_stream = torch.cuda.Stream()
+        plan = {"param": first.weight, "lo": lo, "hi": hi, "stream": self._adam_stream, "fired": False}
+
+        def hook():
+            if plan["fired"]:
+                return
+            main = torch.cuda.current_stream()
+            side = ops.wgrad_side_stream(main)
+            plan["stream"].wait_stream(main)
+            if side is not None:
+                plan["stream"].wait_stream(side)
+            with torch.cuda.stream(plan["stream"]):
+                opt.launch(None, 0, lo)
+                opt.launch(None, hi, total)
+            plan["fired"] = True
+        plan["hook"] = hook
+        return plan
 
     def _capture_staged(self, batches, merged):
         """Three graphs (one per backward stage) from one memory pool; the gradient exchange sits between them."""

@@ -315,6 +315,20 @@ def _wgrad_launch(in_place: bool, tensors, launch):
         torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
 
 
+_last_wgrad = {"param": None, "hook": None}
+
+
+def set_last_wgrad_hook(param, hook) -> None:
+    """``hook()`` is called (on the backward stream) just before the weight-gradient launch of ``param`` -- the engine
+    marks the LAST weight gradient of the step with it to start the optimizer on everything else meanwhile."""
+    _last_wgrad["param"], _last_wgrad["hook"] = param, hook
+
+
+def wgrad_side_stream(main) -> Optional[torch.cuda.Stream]:
+    """The weight-gradient side stream of ``main`` if one has been created."""
+    return _wgrad["streams"].get((main.device.index, main.cuda_stream))
+
+
 def join_wgrad():
     """The current stream waits for every weight-gradient side stream with work in flight (call after backward,
     before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture)."""
@@ -424,6 +438,8 @@ class _Linear(torch.autograd.Function):
         if needs[1]:
             slot = _grad_slot(Wp)
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
+            if Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None:
+                _last_wgrad["hook"]()
             # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS)
             _wgrad_launch(slot is not None and (db_out is None or db is None), (g, x),
                           lambda: gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True,
