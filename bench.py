@@ -269,6 +269,7 @@ def main():
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
+    ap.add_argument("--no-classifier-bank", action="store_true", help="A/B: one contraction per classifier instead of one per head")
     ap.add_argument("--csr-split-heavy", action="store_true",
                     help="A/B: sum the listed heavy CSR rows with the split launches even when they are short enough for the launch itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -313,6 +314,11 @@ def main():
         sds = {"temporal_graph": {k: v.clone() for k, v in model.state_dict().items()}}
         for t, n in names.items():
             sds[n] = {k: v.clone() for k, v in tasks[t].state_dict().items()}
+    if args.no_classifier_bank:
+        for t in tasks.values():
+            for p in t.parameters():
+                if hasattr(p, "_egk_bank"):
+                    del p._egk_bank
     model.to(device).train()
     for t in tasks.values():
         t.to(device).train()

@@ -385,7 +385,8 @@ class MTLStep(StepBase):
             if v.numel():
                 v.backward(gradient=torch.full_like(v, self.weights[t] / v.numel(), dtype=v.dtype))
             return v.detach(), logits
-        vectors, _ = self._run_heads(leaves, head)
+        with ops.bank_grad_handoff():  # every head's logits feed exactly one loss node here
+            vectors, _ = self._run_heads(leaves, head)
         with torch.no_grad():
             total = self._objective(vectors)
         return total, vectors, leaves

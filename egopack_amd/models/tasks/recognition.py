@@ -22,6 +22,9 @@ class MultiHeadTask(ProjectionTask):
         super().__init__(name, input_size, features_size, dropout)
         self.heads = tuple(heads)
         self.classifiers = self._build_classifier(head_dropout, heads)
+        key = object()  # (identity of this bank; a deep copy of the task gets its own)
+        for h, c in enumerate(self.classifiers):  # one bank: optim.FlatAdam lays their padded slots out as one matrix
+            c[1].weight._egk_bank, c[1].bias._egk_bank = (key, "w", h), (key, "b", h)
         if aux_tasks:
             self.aux_classifiers = nn.ModuleDict({t: self._build_classifier(head_dropout, heads) for t in aux_tasks})
             self.average_logits = average_logits
@@ -31,7 +34,11 @@ class MultiHeadTask(ProjectionTask):
 
     def forward_logits(self, features: torch.Tensor, batch: Optional[torch.Tensor] = None,
                        aux_features: Optional[Dict[TaskLiteral, torch.Tensor]] = None, *args, **kwargs):
-        logits = tuple(apply_classifier(c, features) for c in self.classifiers)
+        bank = getattr(self.classifiers[0][1].weight, "_egk_bank_views", None)
+        if bank is not None and features.is_cuda and not (self.training and any(c[0].p > 0 for c in self.classifiers)):
+            logits = ops.classifier_bank(features, self.classifiers[0][1].weight, bank)  # one contraction for all heads
+        else:
+            logits = tuple(apply_classifier(c, features) for c in self.classifiers)
         if aux_features is not None:
             aux = [self.forward_aux_logits(f, t) for t, f in aux_features.items()]
             logits = tuple(fuse_logits(p, [a[h] for a in aux], self.average_logits) for h, p in enumerate(logits))

@@ -463,6 +463,74 @@ def _compute_for(x):
     return BF16 if x.dtype == torch.bfloat16 else _state["compute"]
 
 
+# ---- classifier bank: several Linear layers over the same input as one contraction ---------------------------------------
+_bank_handoff = {"on": False}
+
+
+class bank_grad_handoff:
+    """``with bank_grad_handoff():`` -- inside, a cross-entropy whose logits come straight from ``classifier_bank`` writes
+    its gradient into the bank's padded operand buffer (element type and row stride the dX / dW contractions want) and
+    hands autograd an uninitialised placeholder, which the bank's backward ignores.  Legal only where every such logits
+    tensor feeds exactly ONE loss node and nothing else that needs its gradient (the engine's training heads)."""
+
+    def __enter__(self):
+        self.prev, _bank_handoff["on"] = _bank_handoff["on"], True
+
+    def __exit__(self, *a):
+        _bank_handoff["on"] = self.prev
+
+
+class _ClassifierBank(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, views, gbuf, state, compute):
+        _need_gpu(x)
+        x = _c(x)
+        M, K = x.shape
+        Wop = views["w16"] if x.dtype == torch.bfloat16 else views["wp"]
+        out = torch.empty((M, views["n"]), dtype=torch.float32, device=x.device)
+        gemm(M, views["n"], x, K, Wop, K, K, out, views["n"], bias=views["b"], compute=compute)
+        ctx.views, ctx.gbuf, ctx.state, ctx.compute = views, gbuf, state, compute
+        ctx.save_for_backward(x, Wop)
+        return tuple(out[:, r0:r0 + n] for r0, n in views["rows"])
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, Wop = ctx.saved_tensors
+        views, gbuf, lib = ctx.views, ctx.gbuf, _lib.load()
+        M, K = x.shape
+        N = views["n"]
+        if gbuf is None:  # (forward ran without a gradient consumer in sight; cannot happen under autograd)
+            gbuf = torch.zeros((M, N), dtype=x.dtype, device=x.device)
+        for (r0, n), g in zip(views["rows"], gs):
+            if r0 in ctx.state["filled"] or g is None:
+                continue  # the loss wrote these columns itself (bank_grad_handoff); None: no gradient, columns stay zero
+            g = _rm(g)
+            dst = gbuf[:, r0:r0 + n]
+            _ck(lib.egk_cast_rows(_stream(), _p(g), _dt(g), g.stride(0), _p(dst), _dt(gbuf), gbuf.stride(0), M, n, 0),
+                "egk_cast_rows")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(M, K, gbuf, N, Wop, K, N, dx, K, transB=True, compute=ctx.compute)
+        _wgrad_launch(True, (gbuf, x),
+                      lambda: gemm(N, K, gbuf, N, x, K, M, views["wg"], K, transA=True, transB=True, accumulate=True,
+                                   compute=ctx.compute, dbias=views["bg"]))
+        return dx, None, None, None, None, None
+
+
+def classifier_bank(x, anchor, views, compute=None):
+    """Logits of every classifier of a bank (``views``: optim.FlatAdam._bank_views) as column ranges of ONE
+    [rows, sum rows64] f32 contraction output; backward is one dX and one dW contraction over the zero-padded bank."""
+    needs = torch.is_grad_enabled() and (x.requires_grad or anchor.requires_grad)
+    gbuf = torch.zeros((x.shape[0], views["n"]), dtype=x.dtype, device=x.device) if needs else None  # pad columns stay zero
+    state = {"filled": set()}
+    outs = _ClassifierBank.apply(x, anchor, views, gbuf, state, _compute_for(x) if compute is None else compute)
+    if _bank_handoff["on"] and gbuf is not None:
+        for o, (r0, _) in zip(outs, views["rows"]):
+            o._egk_grad_dst = (gbuf, r0, state)
+    return outs
+
+
 def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False):
     """y = relu?(x @ W.T (+ x2 @ W2.T) + b) (+ residual): one MFMA launch.  ``out_f32`` keeps the result
     in f32 whatever the activation type (logits)."""
@@ -846,6 +914,7 @@ class _CE(torch.autograd.Function):
         y = y.contiguous()
         ystride = 1 if y.dim() == 1 else y.shape[1]
         saved = []
+        ctx.dst = [getattr(l, "_egk_grad_dst", None) if _bank_handoff["on"] else None for l in logits]
         for h, l in enumerate(logits):
             if l.dtype != torch.float32:
                 raise TypeError("cross_entropy expects f32 logits")
@@ -870,8 +939,17 @@ class _CE(torch.autograd.Function):
             rows, Cn = l.shape
             d = torch.empty((rows, Cn), dtype=torch.float32, device=l.device)
             yh = y if y.dim() == 1 else y[:, h]
-            _ck(lib.egk_ce_bwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ctx.ystride, _p(lse), _p(gloss),
-                               _p(d), d.stride(0), rows, Cn, ctx.smoothing, _dt(d)), "egk_ce_bwd")
+            dst = ctx.dst[h]
+            if dst is not None and dst[1] not in dst[2]["filled"]:
+                # classifier_bank's operand buffer takes the gradient directly; ``d`` stays an uninitialised placeholder
+                gbuf, c0, state = dst
+                out = gbuf[:, c0:c0 + Cn]
+                _ck(lib.egk_ce_bwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ctx.ystride, _p(lse), _p(gloss),
+                                   _p(out), gbuf.stride(0), rows, Cn, ctx.smoothing, _dt(gbuf)), "egk_ce_bwd")
+                state["filled"].add(c0)
+            else:
+                _ck(lib.egk_ce_bwd(_stream(), _p(l), l.stride(0), C.c_void_p(yh.data_ptr()), ctx.ystride, _p(lse), _p(gloss),
+                                   _p(d), d.stride(0), rows, Cn, ctx.smoothing, _dt(d)), "egk_ce_bwd")
             grads.append(d)
         return (None, None, None, *grads)
 

@@ -58,7 +58,10 @@ class FlatAdam(torch.optim.Optimizer):
         def slot(p):
             if p.dim() == 2 and p.shape[0] % 64:
                 return (p.shape[0] + 63) // 64 * 64 * p.shape[1]
+            if p.dim() == 1 and getattr(p, "_egk_bank", None) is not None:
+                return (p.numel() + 63) // 64 * 64  # a bank's bias vector lines up with the padded rows of its weights
             return p.numel()
+        live = self._bank_order(live)
         sizes = [(slot(p) + 7) // 8 * 8 for p in live]
         total = sum(sizes)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -82,11 +85,60 @@ class FlatAdam(torch.optim.Optimizer):
                     p._egk_shadow_rows64 = self.flat_w16[off:off + rows64 * p.shape[1]].view(rows64, p.shape[1])
                 off += sz
         self.active = live
+        self._bank_views(live)
         self.refresh_shadows()
         self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
         if self._pending_state is not None:
             self._apply_state(self._pending_state)
             self._pending_state = None
+
+    # -- classifier banks: several Linear layers over the SAME input (verb / noun classifiers of a head) ---------------
+    # Their parameters carry ``_egk_bank = (owner, "w" | "b", index)`` (models/tasks/task.py).  The weights of a bank get
+    # adjacent slots, and so do its biases: the zero-padded 64-row blocks of the members then form ONE [sum rows64, K]
+    # matrix in the flat buffers (weights, bf16 copies, gradients), and the bank runs as one contraction forward, one for
+    # dX, one for dW (ops.classifier_bank) instead of one of each per member.
+    @staticmethod
+    def _bank_order(live):
+        groups, out, done = {}, [], set()
+        for p in live:
+            b = getattr(p, "_egk_bank", None)
+            if b is not None:
+                groups.setdefault((b[0], b[1]), []).append((b[2], p))
+        for p in live:
+            b = getattr(p, "_egk_bank", None)
+            if b is None:
+                out.append(p)
+            elif (b[0], b[1]) not in done:
+                done.add((b[0], b[1]))
+                out.extend(q for _, q in sorted(groups[(b[0], b[1])], key=lambda t: t[0]))
+        return out
+
+    def _bank_views(self, live):
+        banks = {}
+        for p in live:
+            b = getattr(p, "_egk_bank", None)
+            if b is not None:
+                banks.setdefault(b[0], {}).setdefault(b[1], []).append((b[2], p))
+                p._egk_bank_views = None
+        for kinds in banks.values():
+            ws = [q for _, q in sorted(kinds.get("w", []), key=lambda t: t[0])]
+            bs = [q for _, q in sorted(kinds.get("b", []), key=lambda t: t[0])]
+            if len(ws) < 2 or len(bs) != len(ws) or len({w.shape[1] for w in ws}) != 1 or ws[0].shape[1] % 64:
+                continue
+            cols = ws[0].shape[1]
+            rows64 = [(w.shape[0] + 63) // 64 * 64 for w in ws]
+            offs_w, offs_b = [self._slot_of[id(w)][0] for w in ws], [self._slot_of[id(b)][0] for b in bs]
+            ok = all(offs_w[i + 1] == offs_w[i] + rows64[i] * cols for i in range(len(ws) - 1))
+            ok = ok and all(offs_b[i + 1] == offs_b[i] + rows64[i] for i in range(len(bs) - 1))
+            ok = ok and all(b.numel() == w.shape[0] for w, b in zip(ws, bs))
+            if not ok:
+                continue
+            n, ow, ob = sum(rows64), offs_w[0], offs_b[0]
+            starts = [sum(rows64[:i]) for i in range(len(ws))]
+            ws[0]._egk_bank_views = {
+                "rows": [(st, w.shape[0]) for st, w in zip(starts, ws)], "n": n, "k": cols,
+                "w16": self.flat_w16[ow:ow + n * cols].view(n, cols), "wp": self.flat_p[ow:ow + n * cols].view(n, cols),
+                "wg": self.flat_g[ow:ow + n * cols].view(n, cols), "b": self.flat_p[ob:ob + n], "bg": self.flat_g[ob:ob + n]}
 
     def region_of(self, params) -> tuple:
         """[lo, hi) of the flat buffers spanned by ``params`` (those that live there); (0, 0) if none does."""
@@ -126,6 +178,16 @@ class FlatAdam(torch.optim.Optimizer):
                                    "param_groups": state_dict["param_groups"]}
             steps = [float(s["step"]) for s in state_dict["state"].values() if "step" in s]
             self.step_count = int(max(steps)) if steps else 0
+            # The parameters with saved moments ARE the live set of the run that wrote the state: build the flat buffers
+            # now, so that the first step after a resume runs on the layout (bf16 operand copies, classifier banks) every
+            # later step of the interrupted run ran on -- a resumed run continues it bit for bit.
+            params = self.param_groups[0]["params"]
+            live = [params[int(i)] for i in state_dict["state"] if int(i) < len(params)]
+            if live and all(p.is_cuda and p.requires_grad for p in live):
+                for p in live:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                self._materialise()
 
     def _apply_state(self, state_dict):
         params = self.param_groups[0]["params"]

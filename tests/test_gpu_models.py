@@ -8,6 +8,8 @@ Two compute modes are checked:
              within 6e-2 absolute at these O(1) magnitudes, loss vectors within 5e-2.
 Index outputs (k-NN assignments) are exact.
 """
+import contextlib
+
 import pytest
 import torch
 
@@ -407,3 +409,61 @@ def test_captured_step_equals_eager_step(A, golden):
     p_graph, n_graph = run(True)
     assert n_eager == n_graph == 5
     torch.testing.assert_close(p_graph, p_eager, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_classifier_bank_equals_the_separate_classifiers(mode):
+    """The verb / noun classifiers of a head as ONE contraction over the zero-padded bank the optimizer lays out
+    (forward, dX, dW, bias gradients; the loss writing its gradient straight into the bank's operand buffer or not)
+    against the per-classifier path on the same parameters; the padding stays zero under Adam."""
+    from egopack_amd import ops
+    from egopack_amd.models.tasks import RecognitionTask
+    from egopack_amd.optim import FlatAdam
+    heads, H, M = (115, 478), 128, 200
+    torch.manual_seed(5)
+    ref = RecognitionTask(H, H, heads).to(DEV)
+    tasks = {k: RecognitionTask(H, H, heads).to(DEV) for k in ("bank", "handoff")}
+    for t in tasks.values():
+        t.load_state_dict(ref.state_dict())
+    x = torch.randn(M, H, device=DEV)
+    y = torch.stack([torch.randint(-1, heads[0], (M,)), torch.randint(-1, heads[1], (M,))], 1).to(DEV)
+
+    def run(task, bank, handoff, steps=2):
+        opt = FlatAdam(task.parameters(), lr=1e-2, weight_decay=1e-3)
+        out = []
+        for _ in range(steps):
+            opt.zero_grad()
+            xin = x.clone().requires_grad_(True)
+            views = getattr(task.classifiers[0][1].weight, "_egk_bank_views", None)
+            assert (views is not None) == (bank and opt.materialised)
+            ctx = ops.bank_grad_handoff() if handoff else contextlib.nullcontext()
+            with ctx:
+                logits = task.forward_logits(task.forward_features(xin))
+                loss = task.compute_loss(logits, y)
+            loss.backward(torch.full_like(loss, 1.0 / M))
+            out.append((tuple(l.detach().float().clone() for l in logits), xin.grad.clone(),
+                        [p.grad.detach().clone() for p in task.parameters()]))
+            opt.step()
+        return out, opt
+    with ops.compute_mode(mode):
+        for p in ref.parameters():  # the reference task: no bank tags -> the per-classifier path on the same layout rules
+            if hasattr(p, "_egk_bank"):
+                del p._egk_bank
+        want, _ = run(ref, False, False)
+        tol = dict(rtol=1e-4, atol=1e-5) if mode == "f32" else dict(rtol=3e-2, atol=3e-3)
+        for name in ("bank", "handoff"):
+            got, opt = run(tasks[name], True, name == "handoff")
+            for (lg, dxg, pg), (lw, dxw, pw) in zip(got, want):
+                for a, b in zip(lg, lw):
+                    torch.testing.assert_close(a, b, **tol)
+                torch.testing.assert_close(dxg.float(), dxw.float(), **tol)
+                for a, b in zip(pg, pw):
+                    torch.testing.assert_close(a, b, **tol)
+            v = tasks[name].classifiers[0][1].weight._egk_bank_views
+            assert v["rows"] == [(0, 115), (128, 478)] and v["n"] == 640
+            pad = torch.ones(640, dtype=torch.bool, device=DEV)
+            for r0, n in v["rows"]:
+                pad[r0:r0 + n] = False
+            for buf in (v["wp"], v["w16"], v["wg"]):
+                assert float(buf[pad].float().abs().max()) == 0.0
+            assert float(v["b"][pad].abs().max()) == 0.0 and float(v["bg"][pad].abs().max()) == 0.0
