@@ -55,6 +55,7 @@ SIGNATURES = {
     "egk_rowln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, f32, u64, u64, vp, i32]),
     "egk_rowln_bwd_ws_rows": (C.c_int, [i32]),
     "egk_rowln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
+    "egk_ln_bwd_reduce": (C.c_int, [vp, vp, vp, vp, i32, i32, i32]),
     "egk_graphln_ws_bytes": (i64, [i32, i32, i32]),
     "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
     "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),

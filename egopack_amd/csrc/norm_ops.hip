@@ -650,7 +650,7 @@ int egk_rowln_bwd_ws_rows(int32_t rows) { return row_grid(rows); }
 int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b, const float* mean,
                   const float* rstd, const uint8_t* mask, void* dx, float* dw, float* db, float* ws, int32_t rows,
                   int32_t cols, int32_t relu, float p, int32_t dtype) {
-    EGK_REQUIRE(dy && x && w && b && mean && rstd && dx && ws, "egk_rowln_bwd: null pointer");
+    EGK_REQUIRE(dy && x && w && b && mean && rstd && dx && ws, "egk_rowln_bwd: null pointer");  // (dw = db = NULL: see egk_ln_bwd_reduce)
     EGK_REQUIRE(p == 0.f || mask, "egk_rowln_bwd: dropout needs the mask");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -661,11 +661,25 @@ int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const floa
                                                      WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, mean,
                                                      rstd, mask, (T*)dx, ws, rows, cols, relu, p));
     }
-    {
+    if (dw || db) {
         ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
         hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws, dw, db, grid, cols);
     }
     return check_launch("egk_rowln_bwd");
+}
+
+// The parameter-gradient half of the two backward entry points above, for callers that passed dw = db = NULL there and
+// want the reduction of the per-workgroup partial rows on another stream (it feeds nothing but the optimizer).
+int egk_ln_bwd_reduce(egk_stream_t stream, const void* ws, float* dw, float* db, int32_t rows, int32_t cols, int32_t n_seg) {
+    EGK_REQUIRE(ws && dw && db, "egk_ln_bwd_reduce: null pointer");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    // n_seg = 0: egk_rowln_bwd's workspace (partial rows first); n_seg >= 1: egk_graphln_bwd's (segment sums first)
+    const float* ws_col = n_seg > 0 ? (const float*)((const char*)ws + (int64_t)grid * n_seg * 2 * 8) : (const float*)ws;
+    ProfScope prof(n_seg > 0 ? KID_GRAPHLN_BWD_REDUCE : KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
+    hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
+    return check_launch("egk_ln_bwd_reduce");
 }
 
 int64_t egk_graphln_ws_bytes(int32_t rows, int32_t cols, int32_t n_seg) {

@@ -329,6 +329,18 @@ def wgrad_side_stream(main) -> Optional[torch.cuda.Stream]:
     return _wgrad["streams"].get((main.device.index, main.cuda_stream))
 
 
+def _ln_reduce_on_side(slot_w, slot_b, x) -> bool:
+    """The norm layers' dw / db reduction moves to the weight-gradient side stream when there is one for this stream
+    (side streams on, stream not one of the excluded head / task streams) and both gradients accumulate in place."""
+    if not (_wgrad["enabled"] and _wgrad_ln["side"] and slot_w is not None and slot_b is not None and x.is_cuda):
+        return False
+    main = torch.cuda.current_stream()
+    return (main.device.index, main.cuda_stream) not in _wgrad["exclude"]
+
+
+_wgrad_ln = {"side": True}  # development knob
+
+
 def join_wgrad():
     """The current stream waits for every weight-gradient side stream with work in flight (call after backward,
     before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture)."""
@@ -636,7 +648,17 @@ class _RowLN(torch.autograd.Function):
         slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
         dw = slot_w if slot_w is not None else torch.zeros_like(w)
         db = slot_b if slot_b is not None else torch.zeros_like(b)
-        ws = workspace(2 * lib.egk_rowln_bwd_ws_rows(rows) * cols * 4, x.device)
+        nbytes = 2 * lib.egk_rowln_bwd_ws_rows(rows) * cols * 4
+        if _ln_reduce_on_side(slot_w, slot_b, x):
+            # dw / db feed nothing but the optimizer: their reduction goes to the weight-gradient side stream, from a
+            # workspace of its own (the shared one may be rewritten by the next launch of this stream)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), None, None,
+                                  _p(ws), rows, cols, int(ctx.relu), ctx.p, _dt(x)), "egk_rowln_bwd")
+            _wgrad_launch(True, (ws,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, 0),
+                                                   "egk_ln_bwd_reduce"))
+            return dx, None, None, None, None, None, None
+        ws = workspace(nbytes, x.device)
         _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), _p(dw), _p(db),
                               _p(ws), rows, cols, int(ctx.relu), ctx.p, _dt(x)), "egk_rowln_bwd")
         return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None, None
@@ -684,7 +706,15 @@ class _GraphLN(torch.autograd.Function):
         slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
         dw = slot_w if slot_w is not None else torch.zeros_like(w)
         db = slot_b if slot_b is not None else torch.zeros_like(b)
-        ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
+        nbytes = lib.egk_graphln_ws_bytes(rows, cols, n_seg)
+        if _ln_reduce_on_side(slot_w, slot_b, x):  # (see _RowLN.backward)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), None, None, _p(seg_ptr),
+                                    n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws), _dt(x)), "egk_graphln_bwd")
+            _wgrad_launch(True, (ws,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, n_seg),
+                                                   "egk_ln_bwd_reduce"))
+            return dx, None, None, None, None, None
+        ws = workspace(nbytes, x.device)
         _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(seg_ptr),
                                 n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws), _dt(x)), "egk_graphln_bwd")
         return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None

@@ -139,6 +139,11 @@ int egk_graphln_fwd(egk_stream_t s, const void* x, const float* w, const float* 
 int egk_graphln_bwd(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b,
                     const float* stats, void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
                     int32_t rows, int32_t cols, float eps, float slope, void* ws, int32_t dtype);
+/* The parameter-gradient reduction of egk_rowln_bwd (n_seg = 0) / egk_graphln_bwd (n_seg >= 1) as its own launch: call
+ * those with dw = db = NULL (they then leave the per-workgroup partial rows in ws) and this one, with the same ws, rows,
+ * cols, on whatever stream should carry it -- dw / db feed nothing but the optimizer, the kernels that need dx need not
+ * wait for them.  dw[c] += sum of partials, db[c] += ... (accumulating, like the fused form). */
+int egk_ln_bwd_reduce(egk_stream_t s, const void* ws, float* dw, float* db, int32_t rows, int32_t cols, int32_t n_seg);
 
 /* ---- positional encoding  gnn.PositionalEncoding + add   models/graph.py:37,63 ----------
  * y[n, c] = x[n, c] + (c < C/2 ? sin(pos[n]*freq[c]) : cos(pos[n]*freq[c-C/2])) */
