@@ -271,7 +271,10 @@ class StepBase:
         self._static_in = (batches, merged)
         return g
 
-    early_adam = True  # captured single-GPU step: start Adam on everything but the last weight gradient's slots beside it
+    # captured single-GPU step: start Adam on everything but the last weight gradient's slots beside that launch.  Only
+    # for steps that have JOINED every other gradient producer into the backward stream by then (MTLStep with its
+    # head-wise backward does; a step whose branches are still running on their own streams at that point must not)
+    early_adam = False
 
     def _early_adam_plan(self, live):
         """The step ends with two launches that have the chip to themselves one after the other: the weight gradient of
@@ -282,7 +285,7 @@ class StepBase:
         opt = self.optimizer
         tp = getattr(self.model, "temporal_pooling", None)
         first = getattr(tp, "proj", [None])[0] if tp is not None else None
-        if not (self.early_adam and first is not None and hasattr(opt, "region_of") and (self.fused or len(live) == 1)):
+        if not (self._early_adam_ok() and first is not None and hasattr(opt, "region_of") and (self.fused or len(live) == 1)):
             return None
         params = [p for p in (getattr(first, "weight", None), getattr(first, "bias", None)) if p is not None]
         lo, hi = opt.region_of(params)
@@ -308,6 +311,9 @@ class StepBase:
             plan["fired"] = True
         plan["hook"] = hook
         return plan
+
+    def _early_adam_ok(self) -> bool:
+        return bool(self.early_adam)
 
     def _capture_staged(self, batches, merged):
         """Three graphs (one per backward stage) from one memory pool; the gradient exchange sits between them."""
@@ -392,6 +398,10 @@ class MTLStep(StepBase):
         return total, vectors, leaves
 
     headwise_backward = True  # False: one backward() call over all streams (kept for A/B measurements)
+    early_adam = True
+
+    def _early_adam_ok(self) -> bool:  # the heads are joined into the main stream before the backbone's backward starts
+        return bool(self.early_adam and self.headwise_backward)
 
     def _backward_pass(self, batches, merged=None):
         if not self.headwise_backward:

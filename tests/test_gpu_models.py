@@ -378,6 +378,41 @@ def test_egopack_train_two_iterations_vs_reference(A, golden):
             torch.testing.assert_close(cur[k].cpu(), v, rtol=0, atol=1.5e-4, msg=lambda s: f"{grp}/{k}: {s}")
 
 
+def test_captured_egopack_step_equals_eager_step(A, golden):
+    """hipGraph replay of the EgoPack novel-task step (GraphONE task chains on their own streams) leaves the parameters
+    of the eager step, bit for bit: nothing of the optimizer may start before every chain's gradients are final."""
+    G = golden("egopack_train")
+
+    def run(use_graph):
+        model, tasks, names = _load_all(A, G, aux=True)
+        sd = G["before"]["graphone"]
+        banks = {t: sd[f"embeddings.{t}.weight"].clone() for t in ("ar", "lta", "pnr")}
+        gone = A.GraphONE(banks, features_size=32, hidden_size=32, k=G["k"], depth=G["depth"], residual=G["residual"],
+                          dropout=0, output_dropout=0, output_projection=True)
+        gone.load_state_dict(sd)
+        gone = gone.to(DEV)
+        params = [*model.parameters(), *(p for t in ("ar", "oscc", "lta", "pnr") for p in tasks[t].parameters()), *gone.parameters()]
+        opt = A.FlatAdam(params, lr=G["lr"], weight_decay=G["weight_decay"])
+        step = A.engine.EgoPackStep(model, tasks, gone, {"oscc": 1.0}, opt, backprop_temporal_graph=True,
+                                    temporal_graph_train_mode=False)
+        batches = {"oscc": to_data(A, G["batches"]["oscc"][0])}
+        with A.ops.compute_mode("f32"):
+            if use_graph:
+                step.capture(batches, warmup=2)
+                for _ in range(3):
+                    step.replay()
+            else:
+                for _ in range(5):
+                    step.step(batches)
+        torch.cuda.synchronize()
+        return opt.flat_p.clone().cpu(), opt.step_count
+
+    p_eager, n_eager = run(False)
+    p_graph, n_graph = run(True)
+    assert n_eager == n_graph == 5
+    assert torch.equal(p_graph, p_eager)
+
+
 def test_captured_step_equals_eager_step(A, golden):
     """hipGraph replay of forward+backward+Adam gives the same parameters as the eager step."""
     G = golden("mtl_train")
