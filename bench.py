@@ -269,6 +269,7 @@ def main():
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
+    ap.add_argument("--last-wgrad-side", action="store_true", help="A/B: the last weight gradient goes to the side stream like the others")
     ap.add_argument("--ln-reduce-inline", action="store_true", help="A/B: the norm layers' dw / db reduction stays on the backward stream")
     ap.add_argument("--no-classifier-bank", action="store_true", help="A/B: one contraction per classifier instead of one per head")
     ap.add_argument("--csr-split-heavy", action="store_true",
@@ -307,6 +308,8 @@ def main():
 
     if args.ln_reduce_inline:
         ops._wgrad_ln["side"] = False
+    if args.last_wgrad_side:
+        ops._last_wgrad["inline"] = False
     if args.csr_split_heavy:
         from egopack_amd import data as _D
         _D.HEAVY_IN_LAUNCH_DEGREE = 0

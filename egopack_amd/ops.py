@@ -315,7 +315,7 @@ def _wgrad_launch(in_place: bool, tensors, launch):
         torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
 
 
-_last_wgrad = {"param": None, "hook": None}
+_last_wgrad = {"param": None, "hook": None, "inline": True}
 
 
 def set_last_wgrad_hook(param, hook) -> None:
@@ -450,10 +450,13 @@ class _Linear(torch.autograd.Function):
         if needs[1]:
             slot = _grad_slot(Wp)
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
-            if Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None:
+            last = Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None
+            if last:
                 _last_wgrad["hook"]()
-            # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS)
-            _wgrad_launch(slot is not None and (db_out is None or db is None), (g, x),
+            # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS).  The LAST
+            # weight gradient of the step stays on the backward stream: nothing is left to overlap it with there, and the
+            # hop to the side stream and back costs two cross-queue hand-offs (~10 us each) on the step's tail.
+            _wgrad_launch(slot is not None and (db_out is None or db is None) and not (last and _last_wgrad["inline"]), (g, x),
                           lambda: gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True,
                                        compute=ctx.compute, dbias=db_out))
             dW = None if slot is not None else out
