@@ -27,6 +27,11 @@ if str(REPO) not in sys.path:
 
 import torch  # noqa: E402
 
+import egopack_amd  # noqa: E402
+
+if "--exchange-dry-run" not in " ".join(sys.argv):  # (the dry run creates an RCCL group in this process)
+    egopack_amd.tune_single_process_runtime()  # before anything initialises the device; no-op under a multi-rank launch
+
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md: chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 

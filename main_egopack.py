@@ -133,4 +133,6 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    import egopack_amd
+    egopack_amd.tune_single_process_runtime()  # (no-op under a multi-rank launch; before the device is initialised)
     main()
