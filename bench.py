@@ -27,11 +27,6 @@ if str(REPO) not in sys.path:
 
 import torch  # noqa: E402
 
-import egopack_amd  # noqa: E402
-
-if "--exchange-dry-run" not in " ".join(sys.argv):  # (the dry run creates an RCCL group in this process)
-    egopack_amd.tune_single_process_runtime()  # before anything initialises the device; no-op under a multi-rank launch
-
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md: chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 
@@ -283,6 +278,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
     args = ap.parse_args()
+    if not args.exchange_dry_run:  # (the dry run creates an RCCL group in this process)
+        import egopack_amd
+        # before anything initialises the device; no-op under a multi-rank launch
+        egopack_amd.tune_single_process_runtime(parallel_heads=len(WORKLOADS[args.workload][0]))
 
     lib_path = REPO / "egopack_amd" / "libegopack_hip.so"
     if not lib_path.exists():  # a checkout without the (git-ignored) library: compile it in-tree, once, rank 0 first

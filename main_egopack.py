@@ -134,5 +134,7 @@ def main(argv=None):
 
 if __name__ == "__main__":
     import egopack_amd
-    egopack_amd.tune_single_process_runtime()  # (no-op under a multi-rank launch; before the device is initialised)
+    _cfg = T.load_config(None)  # (pure Python) how many task heads will run side by side
+    # no-op under a multi-rank launch; must come before the device is initialised
+    egopack_amd.tune_single_process_runtime(parallel_heads=len([t for t in T.TASKS if t in _cfg.enabled_tasks]))
     main()
