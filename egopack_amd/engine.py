@@ -385,11 +385,19 @@ class MTLStep(StepBase):
         constant w_t / numel(v_t) -- the value the one-call backward of the objective hands it, bit for bit."""
         leaves = {t: f.detach().requires_grad_(True) for t, f in feats.items()}
         batches = self._head_batches
+        if not hasattr(self, "_coef_grads"):
+            self._coef_grads = {}
 
         def head(t, leaf):
             v, logits = self._head(t, leaf, batches[t])
             if v.numel():
-                v.backward(gradient=torch.full_like(v, self.weights[t] / v.numel(), dtype=v.dtype))
+                # the constant the objective's backward hands this head (w_t / numel): one tensor per task, filled once
+                key = (t, v.numel(), v.dtype, v.device)
+                g = self._coef_grads.get(key)
+                if g is None or g._egk_coef != self.weights[t] / v.numel():
+                    g = self._coef_grads[key] = torch.full_like(v, self.weights[t] / v.numel(), dtype=v.dtype).detach()
+                    g._egk_coef = self.weights[t] / v.numel()
+                v.backward(gradient=g)
             return v.detach(), logits
         with ops.bank_grad_handoff():  # every head's logits feed exactly one loss node here
             vectors, _ = self._run_heads(leaves, head)
