@@ -197,6 +197,12 @@ def roofline(ops, step_fn, compute, n_steps=3):
     """Profile ``n_steps`` eager steps with the library's HIP-event timers; report the dominant kernel."""
     ops.prof_reset()
     ops.prof_enable(True)
+    # Keep the device queue FULL while the eager steps are issued: the start event of a launch is stamped when the
+    # command processor reaches it, so on an empty queue (the host-bound forward pass) the host's time between
+    # hipEventRecord and the kernel launch call (5-9 us) would be counted as kernel time -- the forward contraction read
+    # 42 us live against 33 us in the rocprofv3 trace of the same launches.  Behind a ~40 ms spin the three steps are
+    # enqueued ahead of the device and every launch is timed back to back, the way the captured graph runs them.
+    torch.cuda._sleep(int(8e7))
     for _ in range(n_steps):
         step_fn()
     torch.cuda.synchronize()
