@@ -32,6 +32,7 @@ SHAPES = [
     ("dX cls 478", 2048, H, 478, False, True, False),
     ("dW HxH merged", H, H, N6, True, True, True),
     ("dW TRN1 (per task)", H, 4608, 2048, True, True, True),
+    ("dW TRN1 merged", H, 4608, N6, True, True, True),
     ("dW head", H, H, 2048, True, True, True),
     ("dW cls 478", 478, H, 2048, True, True, True),
     ("fwd cls 115", 2048, 115, H, False, False, True),
