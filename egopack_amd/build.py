@@ -4,7 +4,6 @@ hipcc cross-compiles without a GPU.  The built library sits next to this file so
 with a repo snapshot; it is git-ignored (source-only history)."""
 from __future__ import annotations
 
-import os
 import shutil
 import subprocess
 import sys

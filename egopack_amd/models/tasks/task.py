@@ -4,7 +4,7 @@
 by the prototype builder) but the forward is 2 MFMA contractions + 1 fused LayerNorm+ReLU launch."""
 from __future__ import annotations
 
-from typing import Dict, List, Literal, Optional
+from typing import List, Literal
 
 import torch
 import torch.nn as nn

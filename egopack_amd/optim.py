@@ -10,14 +10,12 @@ Parameters whose gradient is None after the first backward (disabled tasks, deta
 frozen prototypes) are left alone, exactly as torch.optim.Adam skips ``grad is None``."""
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Iterable, List
 
 import torch
 
 from . import _lib
-from . import ops
 from .ops import _ck, _p, _stream
 
 

@@ -3,7 +3,6 @@ and loader construction, checkpoints with the reference's key layout, schedulers
 from __future__ import annotations
 
 import logging
-import os
 import sys
 from pathlib import Path
 from typing import Dict, Optional
@@ -11,7 +10,6 @@ from typing import Dict, Optional
 import torch
 
 from . import data as D
-from . import dist as edist
 from . import ops
 from .config import Cfg, compose, instantiate
 from .criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper

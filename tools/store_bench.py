@@ -5,7 +5,6 @@ import sys
 
 sys.path.insert(0, ".")
 sys.path.insert(0, "tools")
-import numpy as np
 import torch
 from _timing import time_us
 
