@@ -275,6 +275,9 @@ def main():
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
+    ap.add_argument("--hw-queues", type=int, default=0,
+                    help="GPU_MAX_HW_QUEUES for this process (0 = runtime default, 4).  3 measured 1.3 %% faster on the three-head "
+                         "step but crashed hipGraphLaunch in other stream configurations: opt-in only")
     ap.add_argument("--last-wgrad-side", action="store_true", help="A/B: the last weight gradient goes to the side stream like the others")
     ap.add_argument("--ln-reduce-inline", action="store_true", help="A/B: the norm layers' dw / db reduction stays on the backward stream")
     ap.add_argument("--no-classifier-bank", action="store_true", help="A/B: one contraction per classifier instead of one per head")
@@ -284,10 +287,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
     args = ap.parse_args()
-    if not args.exchange_dry_run:  # (the dry run creates an RCCL group in this process)
-        import egopack_amd
-        # before anything initialises the device; no-op under a multi-rank launch
-        egopack_amd.tune_single_process_runtime(parallel_heads=len(WORKLOADS[args.workload][0]))
+    if args.hw_queues:  # opt-in: must be set before anything initialises the device
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
 
     lib_path = REPO / "egopack_amd" / "libegopack_hip.so"
     if not lib_path.exists():  # a checkout without the (git-ignored) library: compile it in-tree, once, rank 0 first

@@ -66,6 +66,94 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, 
     return dev, md
 
 
+# ---- static-shape batches: what a captured step may be replayed on ----------------------------------------------------
+def _walk(obj, prefix=""):
+    """(path, value) for every tensor / plain scalar reachable from a Data / CSRGraph (lists of tensors included)."""
+    from dataclasses import fields, is_dataclass
+    if obj is None:
+        return
+    if torch.is_tensor(obj):
+        yield prefix, obj
+    elif is_dataclass(obj):
+        for f in fields(obj):
+            yield from _walk(getattr(obj, f.name), f"{prefix}.{f.name}")
+    elif isinstance(obj, Data):
+        for k in sorted(obj.__dict__):
+            yield from _walk(obj.__dict__[k], f"{prefix}.{k}")
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            yield from _walk(v, f"{prefix}[{i}]")
+    elif isinstance(obj, (int, float, bool, str)):
+        yield prefix, obj
+
+
+def batch_signature(batches: Mapping[str, Data], merged=None) -> tuple:
+    """Everything a capture bakes in: the shape / dtype of every tensor and every plain scalar (node counts, heavy-row
+    modes ...) of the step's batches.  Two steps with equal signatures differ in tensor VALUES only."""
+    sig = []
+    for name, obj in [*sorted(batches.items()), ("merged", merged)]:
+        for path, v in _walk(obj, name):
+            if not (torch.is_tensor(v) and v.dim() >= 1 and path.endswith(".x_base")):  # (x_base aliases x's storage)
+                sig.append((path, (tuple(v.shape), v.dtype)) if torch.is_tensor(v) else (path, v))
+    return tuple(sig)
+
+
+@torch.no_grad()
+def copy_batch_values(dst_batches, dst_merged, src_batches, src_merged) -> None:
+    """dst <- src for every tensor of two sets of batches with the same signature (device to device).  Per-task feature
+    blocks that are row ranges of a packed buffer (``x_base``) are written once, through the buffer."""
+    done = set()
+    pairs = [(dst_batches[t], src_batches[t]) for t in sorted(dst_batches) if dst_batches[t] is not None]
+    if dst_merged is not None:
+        pairs.append((dst_merged, src_merged))
+    for dst, src in pairs:
+        smap = dict(_walk(src))
+        base = getattr(dst, "x_base", None)
+        for path, d in _walk(dst):
+            if not torch.is_tensor(d) or path.endswith(".x_base"):
+                continue
+            s_ = smap.get(path)
+            if s_ is None or d.data_ptr() == s_.data_ptr():
+                continue
+            if (path == ".x" and torch.is_tensor(base) and base.untyped_storage().data_ptr() == d.untyped_storage().data_ptr()
+                    and d.numel() != base.numel()):
+                continue  # a row range of the packed buffer: the buffer itself is copied as the merged batch's x
+            key = (d.untyped_storage().data_ptr(), d.storage_offset(), tuple(d.shape))
+            if key not in done:
+                d.copy_(s_, non_blocking=True)
+                done.add(key)
+
+
+def _clone_batch(d: Data) -> Data:
+    """Deep copy of a device batch (own storage for every tensor; scalars shared)."""
+    from dataclasses import fields, is_dataclass, replace
+    out = Data()
+    for k, v in d.__dict__.items():
+        if torch.is_tensor(v):
+            v = v.clone()
+        elif is_dataclass(v):
+            v = replace(v, **{f.name: (getattr(v, f.name).clone() if torch.is_tensor(getattr(v, f.name)) else getattr(v, f.name))
+                              for f in fields(v)})
+        elif isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
+            v = [t.clone() for t in v]
+        setattr(out, k, v)
+    return out
+
+
+def _rewire_packed(static_b, static_m) -> None:
+    """After cloning: the per-task feature blocks become row ranges of the merged batch's packed buffer again."""
+    if static_m is None or not torch.is_tensor(getattr(static_m, "x", None)):
+        return
+    off = 0
+    for t in [t for t in TASK_ORDER if static_b.get(t) is not None]:
+        b = static_b[t]
+        n = b.x.shape[0]
+        b.x = static_m.x[off:off + n]
+        b.x_base = static_m.x
+        off += n
+    static_m.x_base = static_m.x
+
+
 # hipGraph capture mode.  'thread_local': HIP calls of OTHER threads stay legal while this thread captures -- the
 # process-group watchdog of torch.distributed polls its events (hipEventQuery) from its own thread at any time, and
 # under the default 'global' mode that query is an error that aborts the process.
@@ -224,6 +312,45 @@ class StepBase:
         else:
             opt.step()
 
+    # ---- training loop entry: eager for the first steps, then the captured step on static-shape batches -------------
+    use_graph = True
+    graph_after = 2  # eager steps before the capture (they build the flat optimizer buffers and warm the allocator)
+
+    def train_step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
+        """One optimizer step on device batches, for training loops (main_temporal / main_egopack).
+
+        The first ``graph_after`` steps run eagerly.  The next one is captured on private copies of its batches, and every
+        later step whose batches have the SAME signature (``batch_signature``: shapes, dtypes, node counts -- the loaders
+        deliver fixed-size batches of fixed-length sequences, so that is every step but a short last one) copies its
+        values into those buffers and replays the graph: the step the benchmark measures instead of ~150 launches issued
+        from Python.  Anything else (different shapes, several ranks with an eager exchange path, ``use_graph`` off) takes
+        the eager step.  Returns what ``step`` returns; after a replay the loss vectors are the graph's static outputs,
+        valid until the next call."""
+        self._steps_seen = getattr(self, "_steps_seen", 0) + 1
+        if not self.use_graph or self._steps_seen <= self.graph_after or not next(iter(batches.values())).x.is_cuda:
+            return self.step(batches, merged)
+        if self.fused and len([t for t in self.enabled if batches.get(t) is not None]) > 1 and merged is None:
+            return self.step(batches, merged)  # (the caller did not stage a merged batch: nothing static to replay on)
+        sig = batch_signature(batches, merged)
+        st = getattr(self, "_train_static", None)
+        if st is None:
+            clone = lambda d: None if d is None else _clone_batch(d)
+            static_b = {t: clone(b) for t, b in batches.items()}
+            static_m = clone(merged)
+            _rewire_packed(static_b, static_m)
+            copy_batch_values(static_b, static_m, batches, merged)
+            self.capture(static_b, static_m, warmup=0)
+            st = self._train_static = {"sig": batch_signature(static_b, static_m), "batches": static_b, "merged": static_m}
+            if st["sig"] != sig:  # (cannot happen: the clones mirror the originals)
+                self._train_static = None
+                return self.step(batches, merged)
+        elif st["sig"] != sig:
+            return self.step(batches, merged)
+        else:
+            copy_batch_values(st["batches"], st["merged"], batches, merged)
+        total = self.replay()
+        return total.detach(), {t: v.detach() for t, v in self._static_out[1].items()}
+
     # ---- hipGraph capture ---------------------------------------------------------------------------------
     def capture(self, batches: Mapping[str, Data], merged: Optional[Data] = None, warmup: int = 2):
         """Capture forward+backward(+Adam if no gradient exchange) for THESE device tensors (static
@@ -232,12 +359,13 @@ class StepBase:
         live = [t for t in self.enabled if batches.get(t) is not None]
         if self.fused and len(live) > 1 and merged is None:  # index work must stay outside the capture
             merged = merge_batches([batches[t] for t in live]).to(batches[live[0]].pos.device)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):  # also materialises the flat buffers
-                self.step(batches, merged)
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup > 0 or not getattr(opt, "materialised", True):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(warmup, 1)):  # also materialises the flat buffers
+                    self.step(batches, merged)
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self._use_stages():
             return self._capture_staged(batches, merged)

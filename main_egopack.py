@@ -62,7 +62,7 @@ def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda"):
     it = 0
     for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]):
         batches = {t: b.to(device) for t, b in zip(order, batch) if b is not None}
-        total, _ = step.step(batches)
+        total, _ = step.train_step(batches)  # eager for the first steps, then the captured step
         it += 1
     logger.info("epoch %d: %d iterations, last objective %.4f", epoch, it, float(total))
     return it
@@ -119,6 +119,7 @@ def main(argv=None):
     step = engine.EgoPackStep(model, tasks, graphone, weights, optimizer,
                               backprop_temporal_graph=cfg.backprop_temporal_graph,
                               temporal_graph_train_mode=cfg.temporal_graph_train_mode, sync=sync)
+    step.use_graph = bool(cfg.get("use_graph", True))
     for epoch in range(1, cfg.num_epochs + 1):
         train(epoch, step, dl_train, weights, device)
         scheduler.step()
@@ -133,8 +134,4 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    import egopack_amd
-    _cfg = T.load_config(None)  # (pure Python) how many task heads will run side by side
-    # no-op under a multi-rank launch; must come before the device is initialised
-    egopack_amd.tune_single_process_runtime(parallel_heads=len([t for t in T.TASKS if t in _cfg.enabled_tasks]))
     main()

@@ -42,7 +42,7 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
             batches, merged = engine.stage_batches(host, device, order)
         else:
             batches, merged = {t: b.to(device, non_blocking=True) for t, b in host.items()}, None
-        total, vectors = step.step(batches, merged)
+        total, vectors = step.train_step(batches, merged)  # eager for the first steps, then the captured step
         for t, v in vectors.items():
             sums[t] += float(v.sum())
             counts[t] += v.numel()
@@ -128,6 +128,7 @@ def main(argv=None):
     sync = edist.GradSync(world) if world > 1 else None
     step = engine.MTLStep(model, tasks, T.build_criteria(dsets_train), weights, optimizer,
                           fused_backbone=cfg.fused_backbone, sync=sync)
+    step.use_graph = bool(cfg.get("use_graph", True))
 
     first_epoch = 1
     ckpt_path = Path(cfg.checkpoint_dir) / artifact / "checkpoint.pth"
@@ -152,8 +153,4 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    import egopack_amd
-    _cfg = T.load_config(None)  # (pure Python) how many task heads will run side by side
-    # no-op under a multi-rank launch; must come before the device is initialised
-    egopack_amd.tune_single_process_runtime(parallel_heads=len([t for t in T.TASKS if t in _cfg.enabled_tasks]))
     main()

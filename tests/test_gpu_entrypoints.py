@@ -86,7 +86,8 @@ def test_main_temporal_resume_equals_uninterrupted_run(tmp_path):
     import main_temporal
     base = ["k=1", "batch_size=4", "synthetic_samples=16", "model.hidden_size=64", "model.temporal_pooling.hidden_size=64",
             "oscc_feat_size=64", "save_model=True", "compute=f32", "optimizer.lr=1e-3", "enabled_tasks=[ar,pnr]",
-            "lr_scheduler.T_max=3"]  # (dropout stays on: its streams are part of the checkpoint)
+            "lr_scheduler.T_max=3", "use_graph=false"]  # (dropout stays on: its streams are part of the checkpoint; eager: a resumed
+    # run would capture at another step than the uninterrupted one, and the replayed step draws its masks from other offsets)
     main_temporal.main(base + ["num_epochs=3", f"checkpoint_dir={tmp_path / 'full'}"])
     main_temporal.main(base + ["num_epochs=2", f"checkpoint_dir={tmp_path / 'part'}"])
     part = tmp_path / "part" / "MTL_ar-pnr" / "checkpoint.pth"
@@ -99,3 +100,56 @@ def test_main_temporal_resume_equals_uninterrupted_run(tmp_path):
     for key in ("temporal_graph", "task/recognition", "task/pnr"):
         for k, v in full[key].items():
             torch.testing.assert_close(res[key][k], v, rtol=0, atol=0, msg=lambda s: f"{key}.{k}: {s}")
+
+
+def test_train_step_replays_the_captured_step_on_static_shape_batches():
+    """StepBase.train_step (what the training loops call): eager for the first steps, then ONE capture, then value
+    copies + replays for every batch with the capture's signature and the eager step for any other (a short last
+    batch) -- the parameters of a plain eager loop over the same batches, bit for bit (no dropout: the eager and the
+    replayed step draw their masks from different Philox offsets)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import data as D
+    from egopack_amd import engine, ops
+    from egopack_amd.criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper
+    from egopack_amd.models import Graph
+    from egopack_amd.models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+    from egopack_amd.optim import FlatAdam
+    H, heads = 64, (7, 11)
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": H}
+
+    class DS:
+        has_joint_label, num_labels = False, 2
+
+    def run(use_graph):
+        torch.manual_seed(3)
+        model = Graph(48, hidden_size=H, depth=2, temporal_pooling=trn, num_segments=3).cuda()
+        tasks = {"ar": RecognitionTask(H, H, heads).cuda(), "oscc": OSCCTask(H, H).cuda(), "lta": LTATask(H, H, heads).cuda(),
+                 "pnr": PNRTask(H, H).cuda()}
+        crit = {"ar": MetricSelectorWrapper(CrossEntropyNone(), DS()), "lta": MetricSelectorWrapper(CrossEntropyNone(), DS()),
+                "oscc": CrossEntropyNone(), "pnr": BCEWithLogitsNone()}
+        live = [*model.parameters(), *(p for t in ("ar", "lta", "pnr") for p in tasks[t].parameters())]
+        opt = FlatAdam(live, lr=1e-3, weight_decay=1e-5)
+        weights = {"ar": 1.0, "lta": 0.5, "pnr": 2.0, "oscc": 0.0}
+        step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=True)
+        step.use_graph = use_graph
+        dsets = {t: D.SyntheticTaskDataset(t, 22, 8, 3, 48, heads, k=1, seed=11) for t in ("ar", "lta", "pnr")}
+        loaders = {t: D.build_dataloader(d, 4, False, 0, False, 1) for t, d in dsets.items()}  # 5 full batches + one of 2
+        losses = []
+        with ops.compute_mode("f32"):
+            for bs in zip(*(loaders[t] for t in ("ar", "lta", "pnr"))):
+                host = dict(zip(("ar", "lta", "pnr"), bs))
+                batches, merged = engine.stage_batches(host, "cuda", ("ar", "lta", "oscc", "pnr"))
+                total, vectors = step.train_step(batches, merged)
+                losses.append((float(total), {t: v.clone() for t, v in vectors.items()}))
+        torch.cuda.synchronize()
+        return opt.flat_p.clone(), losses, step
+
+    p_eager, l_eager, _ = run(False)
+    p_graph, l_graph, step = run(True)
+    assert getattr(step, "_train_static", None) is not None and step._steps_seen == 6  # captured at step 3, replayed, then eager
+    assert torch.equal(p_graph, p_eager)
+    for (ta, va), (tb, vb) in zip(l_eager, l_graph):
+        assert ta == tb
+        for t in va:
+            assert torch.equal(va[t], vb[t]), t
