@@ -35,7 +35,7 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
     for t in step.tasks.values():
         t.train()
     order = ("ar", "lta", "oscc", "pnr")
-    it, sums, counts = 0, {t: 0.0 for t in order}, {t: 0 for t in order}
+    it, sums, counts = 0, {t: None for t in order}, {t: 0 for t in order}  # loss sums stay on the device until the epoch ends
     for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]):
         host = {t: b for t, b in zip(order, batch) if b is not None}
         if step.fused and len(host) > 1:
@@ -43,12 +43,13 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
         else:
             batches, merged = {t: b.to(device, non_blocking=True) for t, b in host.items()}, None
         total, vectors = step.train_step(batches, merged)  # eager for the first steps, then the captured step
-        for t, v in vectors.items():
-            sums[t] += float(v.sum())
+        for t, v in vectors.items():  # (no host synchronisation per step: the next batch is staged while this one runs)
+            s_ = v.detach().double().sum()
+            sums[t] = s_ if sums[t] is None else sums[t] + s_
             counts[t] += v.numel()
         it += 1
     logger.info("epoch %d: %d iterations, train loss %s", epoch, it,
-                {t: round(sums[t] / max(counts[t], 1), 4) for t in order if counts[t]})
+                {t: round(float(sums[t]) / max(counts[t], 1), 4) for t in order if counts[t]})
     return it
 
 
