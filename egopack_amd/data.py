@@ -233,19 +233,129 @@ def merge_batches(batches: Sequence[Data]) -> Data:
     x = base if (base is not None and all(getattr(b, "x_base", None) is base for b in batches)
                  and base.shape[0] == off) else xs
     out = Data(x=x, pos=torch.cat(poss), edge_index=ei)
-    out.graph = build_csr(ei, off)
+    # The merged CSR depends on the tasks' edge lists only: with fixed-length sequences it is the same every step, and
+    # building it (two stable sorts over all edges) cost 9 ms of host time per step.  Callers that know the structure
+    # fingerprint of their batches (engine.stage_batches) pass it as ``structure_key`` on the batches: one build per key.
+    keys = tuple(getattr(b, "_struct_key", 0) for b in batches)
+    cached = _merged_graph_cache.get(keys) if all(keys) else None
+    if cached is not None and cached[0] == (tuple(ei.shape), off):
+        out.graph = cached[1]
+    else:
+        out.graph = build_csr(ei, off)
+        if all(keys):
+            if len(_merged_graph_cache) >= 8:
+                _merged_graph_cache.clear()
+            _merged_graph_cache[keys] = ((tuple(ei.shape), off), out.graph)
     out.seg_ptr = torch.tensor(seg, dtype=torch.int32)
     out.num_segments = len(batches)
     return out
 
 
-def pack_features(batches: Sequence[Data], dtype=None, device=None, pin: bool = False) -> torch.Tensor:
+_merged_graph_cache = {}
+
+
+class PinnedRing:
+    """A few persistent page-locked staging buffers per (shape, dtype), handed out in turn.  Allocating 57 MB of pinned
+    memory per training step cost ~70 ms per step in the loop (hipHostMalloc / hipHostFree synchronise with the device);
+    a buffer is handed out again only after the event recorded behind its last host-to-device copy has completed."""
+
+    def __init__(self, depth: int = 3):
+        self.depth, self.slots, self.next = depth, {}, {}
+
+    def get(self, shape, dtype) -> "tuple[torch.Tensor, list]":
+        key = (tuple(shape), dtype)
+        ring = self.slots.setdefault(key, [])
+        i = self.next.get(key, 0)
+        if len(ring) < self.depth:
+            ring.append([torch.empty(shape, dtype=dtype, pin_memory=True), None])
+            i = len(ring) - 1
+        self.next[key] = (i + 1) % self.depth
+        slot = ring[i]
+        if slot[1] is not None:
+            slot[1].synchronize()  # the copy that last read this buffer
+            slot[1] = None
+        return slot[0], slot
+
+
+_pinned_ring = PinnedRing()
+
+
+def to_device_packed(datas: Sequence["Data"], device, non_blocking: bool = True) -> List["Data"]:
+    """``[d.to(device) for d in datas]`` with ONE host-to-device copy: every tensor of the batches (labels, positions,
+    CSR arrays, per-sample attributes ...) is laid out in one page-locked byte buffer of ``_pinned_ring`` and the device
+    tensors are views of its device copy.  A step's ~55 small tensors cost ~0.16 ms EACH as separate pageable copies
+    (9 ms per step); packed, they are one 1-2 MB transfer."""
+    from dataclasses import fields, is_dataclass, replace
+    if torch.device(device).type != "cuda":
+        return [d.to(device, non_blocking=non_blocking) for d in datas]
+    items = []  # (tensor, byte offset)
+    total = 0
+
+    def plan(t):
+        nonlocal total
+        if t.device.type != "cpu":
+            return None
+        off = total
+        total += (t.numel() * t.element_size() + 255) // 256 * 256
+        items.append((t, off))
+        return off
+
+    def walk(v):
+        if torch.is_tensor(v):
+            return ("t", v, plan(v))
+        if is_dataclass(v):
+            return ("dc", v, {f.name: walk(getattr(v, f.name)) for f in fields(v)})
+        if isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
+            return ("l", v, [walk(t) for t in v])
+        return ("o", v, None)
+    plans = [{k: walk(v) for k, v in d.__dict__.items()} for d in datas]
+    if total == 0:
+        return [d.to(device, non_blocking=non_blocking) for d in datas]
+    host, slot = _pinned_ring.get((total,), torch.uint8)
+    for t, off in items:
+        n = t.numel() * t.element_size()
+        if n:
+            host[off:off + n].view(t.dtype).view(t.shape).copy_(t)
+    dev = host.to(device, non_blocking=non_blocking)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    slot[1] = ev
+
+    def build(p):
+        kind, v, extra = p
+        if kind == "t":
+            if extra is None:
+                return v.to(device, non_blocking=non_blocking)
+            n = v.numel() * v.element_size()
+            return dev[extra:extra + n].view(v.dtype).view(v.shape) if n else torch.empty(v.shape, dtype=v.dtype, device=device)
+        if kind == "dc":
+            return replace(v, **{name: build(q) for name, q in extra.items()})
+        if kind == "l":
+            return [build(q) for q in extra]
+        return v
+    outs = []
+    for pl in plans:
+        out = Data()
+        for k, q in pl.items():
+            setattr(out, k, build(q))
+        outs.append(out)
+    return outs
+
+
+def pack_features(batches: Sequence[Data], dtype=None, device=None, pin: bool = False, ring_slot: list = None) -> torch.Tensor:
     """Copy the feature blocks of several task batches into ONE [sum N, S, F] buffer (one host->device
-    transfer, one merged contraction) and re-point every ``batch.x`` at its row range of that buffer."""
+    transfer, one merged contraction) and re-point every ``batch.x`` at its row range of that buffer.
+    ``pin``: the buffer is one of the persistent page-locked buffers of ``_pinned_ring``; the caller that copies it to a
+    device records an event behind that copy in ``ring_slot[1]`` (pass a list to receive the slot)."""
     n = sum(b.x.shape[0] for b in batches)
     ref = batches[0].x
-    buf = torch.empty((n, *ref.shape[1:]), dtype=dtype or ref.dtype, device=device or ref.device,
-                      pin_memory=pin and (device is None or str(device) == "cpu"))
+    shape, dt = (n, *ref.shape[1:]), dtype or ref.dtype
+    if pin and (device is None or str(device) == "cpu") and torch.cuda.is_available():
+        buf, slot = _pinned_ring.get(shape, dt)
+        if ring_slot is not None:
+            ring_slot.append(slot)
+    else:
+        buf = torch.empty(shape, dtype=dt, device=device or ref.device)
     off = 0
     for b in batches:
         m = b.x.shape[0]

@@ -28,6 +28,17 @@ def load_config(argv=None, config_dir: Optional[Path] = None) -> Cfg:
     return compose(config_dir, "defaults", [a for a in argv if "=" in a])
 
 
+def cap_host_threads(n: int = 8) -> int:
+    """The training process does no arithmetic on the host: what its intra-op thread pool runs is the memcpy of the
+    step's feature block into the page-locked staging buffer.  With the default pool of one thread per core (128 on the
+    MI355X host) that copy stalls for ~90 ms every few steps (per-step host time: median 83 ms, mean 60 ms); with 4-16
+    threads it takes < 1 ms (3.0 ms per step for staging + replay bookkeeping, no stalls) -- tools/exp/loop_trace.py."""
+    prev = torch.get_num_threads()
+    if prev > n:
+        torch.set_num_threads(n)
+    return prev
+
+
 def seed_everything(cfg, rank: int):
     if cfg.seed > 0:
         import numpy as np

@@ -75,6 +75,7 @@ def main(argv=None):
         return
     rank, local_rank, world = edist.init_from_env()
     T.setup_logging(rank)
+    T.cap_host_threads(int(cfg.get("host_threads", 8)))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     T.seed_everything(cfg, rank)

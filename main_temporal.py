@@ -36,12 +36,9 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
         t.train()
     order = ("ar", "lta", "oscc", "pnr")
     it, sums, counts = 0, {t: None for t in order}, {t: 0 for t in order}  # loss sums stay on the device until the epoch ends
-    for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]):
-        host = {t: b for t, b in zip(order, batch) if b is not None}
-        if step.fused and len(host) > 1:
-            batches, merged = engine.stage_batches(host, device, order)
-        else:
-            batches, merged = {t: b.to(device, non_blocking=True) for t, b in host.items()}, None
+    hosts = (dict(zip(order, batch)) for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]))
+    # batch i + 1 is collated and copied to the device (copy stream) while step i runs
+    for batches, merged in engine.StagedBatches(hosts, device, order, fused=step.fused):
         total, vectors = step.train_step(batches, merged)  # eager for the first steps, then the captured step
         for t, v in vectors.items():  # (no host synchronisation per step: the next batch is staged while this one runs)
             s_ = v.detach().double().sum()
@@ -95,6 +92,7 @@ def main(argv=None):
     cfg = T.load_config(argv)
     rank, local_rank, world = edist.init_from_env()
     T.setup_logging(rank)
+    T.cap_host_threads(int(cfg.get("host_threads", 8)))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     T.seed_everything(cfg, rank)
