@@ -112,7 +112,11 @@ class StagedBatches:
         live = {t: b for t, b in host.items() if b is not None}
         if self.fused and len(live) > 1:
             return stage_batches(live, self.device, self.order, store=self.store, dtype=self.dtype)
-        return {t: b.to(self.device, non_blocking=True) for t, b in live.items()}, None
+        from .data import to_device_packed
+        moved = to_device_packed([live[t] for t in live], self.device)  # (one copy for all of a step's tensors)
+        for t, d in zip(live, moved):
+            d._struct_key = structure_key(live[t])
+        return dict(zip(live, moved)), None
 
     def _fetch(self):
         try:

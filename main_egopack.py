@@ -60,8 +60,9 @@ def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda"):
     """One epoch (reference main_egopack.train :64-159)."""
     order = ("ar", "lta", "oscc", "pnr")
     it = 0
-    for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]):
-        batches = {t: b.to(device) for t, b in zip(order, batch) if b is not None}
+    hosts = (dict(zip(order, batch)) for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]))
+    # batch i + 1 is collated and copied to the device (copy stream) while step i runs; per-task backbone passes here
+    for batches, _ in engine.StagedBatches(hosts, device, order, fused=False):
         total, _ = step.train_step(batches)  # eager for the first steps, then the captured step
         it += 1
     logger.info("epoch %d: %d iterations, last objective %.4f", epoch, it, float(total))
