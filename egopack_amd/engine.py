@@ -116,6 +116,8 @@ class StagedBatches:
         moved = to_device_packed([live[t] for t in live], self.device)  # (one copy for all of a step's tensors)
         for t, d in zip(live, moved):
             d._struct_key = structure_key(live[t])
+            if self.store is not None and getattr(d, "x", None) is None and getattr(d, "x_idx", None) is not None:
+                d.x = self.store.gather(d.x_idx, dtype=self.dtype)  # features from the device-resident table
         return dict(zip(live, moved)), None
 
     def _fetch(self):

@@ -58,13 +58,39 @@ def build_datasets(cfg, split: str):
     for t in TASKS:
         tf = D.LTATemporalConnectivity(r=cfg.k + 0.5, loop=False) if t == "lta" else D.RadiusGraph(r=cfg.k + 0.5, loop=False)
         dcfg = dict(cfg[DSET_GROUP[t]])
-        if dcfg["_target_"].endswith("SyntheticTaskDataset"):
+        if dcfg["_target_"].endswith(("SyntheticTaskDataset", "SyntheticResidentDataset")):
             dcfg.update(length=cfg.synthetic_samples if split == "train" else max(cfg.synthetic_samples // 4, 1),
                         seed=cfg.seed + (0 if split == "train" else 10_000), k=cfg.k)
+            if dcfg["_target_"].endswith("SyntheticResidentDataset"):
+                dcfg["split"] = split
             out[t] = instantiate(dcfg, transform=tf)
         else:
             out[t] = instantiate(dcfg, split=split, transform=tf)
     return out
+
+
+def build_feature_store(dsets, device):
+    """ONE device-resident feature table for the tasks' datasets when they index one (datasets that expose ``videos``:
+    uid -> [frames, F] and deliver ``x_idx``): the reference's four datasets read the same Omnivore file per video, so do
+    these.  None for datasets that deliver features themselves."""
+    from .feature_store import FeatureStore
+    have = [ds for ds in dsets.values() if getattr(ds, "videos", None) is not None]
+    if not have:
+        return None
+    if len(have) != len(dsets):
+        raise ValueError("either every task dataset indexes the resident feature table or none does")
+    ref = have[0].videos
+    for ds in have[1:]:
+        if ds.videos.keys() != ref.keys() or any(ds.videos[k].shape != ref[k].shape for k in ref):
+            raise ValueError("the task datasets must index ONE feature table (same videos)")
+    return FeatureStore(ref, device=device)
+
+
+def resident_batches(loader, store, device, dtype=None):
+    """Evaluation-side adapter: the loader's batches on the device with their features gathered from the store."""
+    from .feature_store import materialise_features
+    for b in loader:
+        yield materialise_features(b.to(device), store, dtype)
 
 
 def build_loaders(cfg, dsets, train: bool, rank: int, world: int, batch_size: Optional[int] = None):

@@ -29,7 +29,7 @@ from validate import validate, validate_lta, validate_pnr
 logger = logging.getLogger("main_temporal")
 
 
-def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
+def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda", store=None):
     """One epoch (reference main_temporal.train :49-134)."""
     step.model.train()
     for t in step.tasks.values():
@@ -38,7 +38,7 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda"):
     it, sums, counts = 0, {t: None for t in order}, {t: 0 for t in order}  # loss sums stay on the device until the epoch ends
     hosts = (dict(zip(order, batch)) for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]))
     # batch i + 1 is collated and copied to the device (copy stream) while step i runs
-    for batches, merged in engine.StagedBatches(hosts, device, order, fused=step.fused):
+    for batches, merged in engine.StagedBatches(hosts, device, order, fused=step.fused, store=store, dtype=ops.act_dtype()):
         total, vectors = step.train_step(batches, merged)  # eager for the first steps, then the captured step
         for t, v in vectors.items():  # (no host synchronisation per step: the next batch is staged while this one runs)
             s_ = v.detach().double().sum()
@@ -105,6 +105,20 @@ def main(argv=None):
     assert len({d.features_size for d in dsets_train.values()}) == 1, "all tasks must share the input feature size"
     dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
     dl_val = T.build_loaders(cfg, dsets_val, False, rank, world)  # batch-sharded; meters are summed across ranks
+    # datasets that index a device-resident feature table (dataset_*=synthetic_resident; the reference's .npy files
+    # loaded into HBM): one table per split, the training step gathers its rows on the device, evaluation batches get
+    # theirs through an adapter
+    store, store_val = T.build_feature_store(dsets_train, device), T.build_feature_store(dsets_val, device)
+    if store_val is not None:
+        _val = dl_val
+
+        class _Resident:
+            def __init__(self, loader):
+                self.loader = loader
+
+            def __iter__(self):
+                return T.resident_batches(self.loader, store_val, device, ops.act_dtype())
+        dl_val = {t: _Resident(l) for t, l in _val.items()}
 
     H = cfg.model.hidden_size
     model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,
@@ -137,7 +151,7 @@ def main(argv=None):
         first_epoch = int(ck.get("epoch", 0)) + 1
         logger.info("resumed from %s at epoch %d", cfg.resume_from, first_epoch)
     for epoch in range(first_epoch, cfg.num_epochs + 1):
-        train(epoch, step, dl_train, weights, device)
+        train(epoch, step, dl_train, weights, device, store=store)
         scheduler.step()
         logger.info("learning rate -> %.6g", scheduler.get_last_lr()[0])
         if cfg.save_model and cfg.get("save_every", 0) and epoch % cfg.save_every == 0 and rank == 0:

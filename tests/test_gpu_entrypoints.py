@@ -153,3 +153,32 @@ def test_train_step_replays_the_captured_step_on_static_shape_batches():
         assert ta == tb
         for t in va:
             assert torch.equal(va[t], vb[t]), t
+
+
+@pytest.mark.timeout(600)
+def test_main_temporal_on_the_device_resident_feature_store(tmp_path):
+    """dataset_*=synthetic_resident: the datasets deliver index matrices over ONE feature table in HBM; the training step
+    gathers its rows on the device (stage_batches with a store), the captured step is replayed on them, validation goes
+    through the resident adapter -- and the features are the reference's np.take of the same rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import main_temporal
+    from egopack_amd import data as D
+    from egopack_amd import train as T
+    from egopack_amd.feature_store import FeatureStore
+    groups = [f"{g}=synthetic_resident" for g in ("dataset_recognition", "dataset_lta", "dataset_oscc", "dataset_pnr")]
+    args = [*groups, "k=1", "batch_size=4", "synthetic_samples=24", "model.hidden_size=64", "model.temporal_pooling.hidden_size=64",
+            "oscc_feat_size=64", "num_epochs=2", "enabled_tasks=[ar,lta,pnr]", "save_model=True", f"checkpoint_dir={tmp_path}"]
+    main_temporal.main(args)
+    ck = torch.load(tmp_path / "MTL_ar-lta-pnr" / "checkpoint.pth", weights_only=False)
+    assert ck["epoch"] == 2 and all(torch.isfinite(v).all() for v in ck["temporal_graph"].values() if v.is_floating_point())
+    # what the step trains on = the reference's host-side np.take of the same rows
+    cfg = T.load_config(args)
+    ds = T.build_datasets(cfg, "train")
+    store = T.build_feature_store(ds, "cuda")
+    assert isinstance(store, FeatureStore)
+    b = D.collate([ds["ar"][i] for i in range(3)])
+    got = store.gather(b.x_idx.cuda(), dtype=torch.float32).cpu()
+    table = torch.cat([torch.from_numpy(v) for v in ds["ar"].videos.values()])
+    want = table[b.x_idx.clamp(min=0)] * (b.x_idx >= 0).unsqueeze(-1)
+    torch.testing.assert_close(got, want.to(torch.bfloat16).float(), rtol=0, atol=0)
