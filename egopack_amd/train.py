@@ -98,7 +98,8 @@ def build_loaders(cfg, dsets, train: bool, rank: int, world: int, batch_size: Op
     -- and with it every graph-LayerNorm statistic -- is the one the single-process pass sees."""
     bs = batch_size or cfg.batch_size
     return {t: D.build_dataloader(ds, bs, train, cfg.num_workers, train, seed=cfg.seed, rank=rank, world_size=world,
-                                  shard="samples" if train else "batches")
+                                  shard="samples" if train else "batches",
+                                  workers=int(cfg.get("loader_workers", 0)) if train else 0)
             for t, ds in dsets.items()}
 
 
