@@ -275,6 +275,7 @@ def main():
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
+    ap.add_argument("--egk-tune", default="", help="development: comma list key=value passed to egk_tune (row-kernel grid caps)")
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="GPU_MAX_HW_QUEUES for this process (0 = runtime default, 4).  3 measured 1.3 %% faster on the three-head "
                          "step but crashed hipGraphLaunch in other stream configurations: opt-in only")
@@ -316,6 +317,10 @@ def main():
     if args.gemm_knob is not None:
         from egopack_amd import _lib
         _lib.load().egk_gemm_set_pipeline(args.gemm_knob)
+    for kv in filter(None, args.egk_tune.split(",")):
+        from egopack_amd import _lib
+        k, v = kv.split("=")
+        _lib.load().egk_tune(int(k), int(v))
 
     if args.ln_reduce_inline:
         ops._wgrad_ln["side"] = False
