@@ -275,6 +275,7 @@ def main():
                     help="element type of the gradient all-reduce when --gpus > 1")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
+    ap.add_argument("--force-wgrad-streams", action="store_true", help="A/B: weight gradients on a side stream also for single-task steps")
     ap.add_argument("--egk-tune", default="", help="development: comma list key=value passed to egk_tune (row-kernel grid caps)")
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="GPU_MAX_HW_QUEUES for this process (0 = runtime default, 4).  3 measured 1.3 %% faster on the three-head "
@@ -365,6 +366,8 @@ def main():
                                   temporal_graph_train_mode=False, sync=sync)
         if args.no_wgrad_streams:
             step.wgrad_side_streams = False
+        if args.force_wgrad_streams:
+            step.wgrad_side_streams = True
 
         def eager_step():
             step.step(dev, fused_merged)
@@ -382,6 +385,8 @@ def main():
             step.headwise_backward = False
         if args.no_early_adam:
             step.early_adam = False
+        if args.force_wgrad_streams:
+            step.wgrad_side_streams = True
 
         def eager_step():
             step.step(dev, fused_merged)
