@@ -1,6 +1,6 @@
 // Message-passing and prototype kernels: positional encoding add, CSR row gather (SAGE mean
-// forward/backward), GraphONE gather-max, per-sequence max pool, cosine k-NN selection and the
-// float64 prototype-bank scatter-add.
+// forward/backward), GraphONE gather-max, per-sequence max pool, cosine / L2 k-NN selection and the
+// float64 prototype-bank accumulation (label-grouped, no atomics).
 //
 // All row kernels use the one-wave-per-row layout (16 B per lane, 1 KiB per wave-instruction):
 // a 1024-wide fp32 feature row is 4 wave-instructions.  Neighbour rows of the banded temporal
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ d
 // ---- cosine k-NN ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void row_inv_norm_kernel(const T* __restrict__ x, float* __restrict__ inv, int rows,
-                                                           int cols) {
+                                                           int cols, int squared) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const T* __restrict__
             s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
         s = wave_sum(s);
-        if (lane == 0) inv[row] = 1.f / sqrtf(s);
+        if (lane == 0) inv[row] = squared ? s : 1.f / sqrtf(s);
     }
 }
 
@@ -391,7 +391,10 @@ __global__ __launch_bounds__(256) void cos_dist_kernel(const float* __restrict__
 // fails the first comparison against the list's worst entry -- then k rounds of a wave-wide lexicographic arg-min
 // over the list heads pick the row's k nearest in order (the winning lane pops its head).  Ties go to the smaller
 // index, NaN distances are never selected, exactly as a full (distance, index) sort would order them.
-template <int KM>
+// L2 = false: d = 1 - dot * f_inv[n] * b_inv[j] (cos_dissimilarity, graphONE.py:148-151);
+// L2 = true : d = sqrt(max(|f_n|^2 + |p_j|^2 - 2 dot, 0)) / 4096 (cdist / 4096, graphONE.py:126-127,144-145) with the
+//             squared norms passed in f_inv / b_inv.
+template <int KM, bool L2>
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot, long long ldd,
                                                    const float* __restrict__ f_inv, const float* __restrict__ b_inv,
                                                    long long* __restrict__ nn, int rows, int K, int k, int vec) {
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = base + t;
-                float d = 1.f - dv[t] * fi * bv4[t];
+                float d = L2 ? sqrtf(fmaxf(fi + bv4[t] - 2.f * dv[t], 0.f)) * (1.f / 4096.f) : 1.f - dv[t] * fi * bv4[t];
                 int dj = j;
                 if (j < K && (d < lv[KM - 1] || (d == lv[KM - 1] && dj < li[KM - 1]))) {
 #pragma unroll
@@ -465,17 +468,82 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
     }
 }
 
-// ---- prototype bank scatter-add (fp64) --------------------------------------------------------------------
+// ---- prototype bank accumulation (fp64 bank, no atomics) -----------------------------------------------------------
+// reference graphone.py:53: bank += scatter(task_feat, labels, dim_size, reduce="sum") -- the per-batch scatter sums the
+// rows of one label in the feature type (fp32) in node order, then the [size, H] result is added to the fp64 bank.  Here
+// the labelled rows arrive grouped by label (``order`` = node ids stably sorted by label, ``seg_ptr`` the group
+// boundaries, ``seg_label`` the label of each group: integer work done by the caller) and ONE wave owns a group: it sums
+// the group's rows in fp32 in node order -- the summation order of the reference's CPU scatter_add_ -- and adds the sum
+// to its bank row in fp64.  Groups of one call have distinct labels, so no two waves touch the same bank row: no atomics,
+// bitwise reproducible.  count[label] += group size.
 template <typename T>
-__global__ __launch_bounds__(256) void scatter_add_f64_kernel(const T* __restrict__ x, const long long* __restrict__ label,
-                                                              double* __restrict__ bank, long long* __restrict__ count,
-                                                              int rows, int cols, long long n_labels) {
+__global__ __launch_bounds__(256) void segment_sum_f64_kernel(const T* __restrict__ x, const int* __restrict__ order,
+                                                              const int* __restrict__ seg_ptr,
+                                                              const long long* __restrict__ seg_label, double* __restrict__ bank,
+                                                              long long* __restrict__ count, int n_seg, int cols,
+                                                              long long n_labels) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
-        const long long lb = label[row];
+    const bool vec = (cols & 3) == 0;
+    for (int sg = blockIdx.x * WPB + wave; sg < n_seg; sg += gridDim.x * WPB) {
+        const long long lb = seg_label[sg];
         if (lb < 0 || lb >= n_labels) continue;
-        if (lane == 0 && count) atomicAdd(reinterpret_cast<unsigned long long*>(count + lb), 1ull);
-        for (int c = lane; c < cols; c += 64) atomicAdd(bank + lb * cols + c, (double)ld1t(x + (long long)row * cols + c));
+        const int r0 = seg_ptr[sg], r1 = seg_ptr[sg + 1];
+        if (lane == 0 && count) count[lb] += r1 - r0;
+        for (int c = lane * 4; c < cols; c += 256) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            int r = r0;
+            for (; r + 4 <= r1; r += 4) {  // 4 rows in flight, added in node order
+                const int i0 = order[r], i1 = order[r + 1], i2 = order[r + 2], i3 = order[r + 3];
+                const float4 v0 = ld4(x + (long long)i0 * cols, c, cols, vec), v1 = ld4(x + (long long)i1 * cols, c, cols, vec);
+                const float4 v2 = ld4(x + (long long)i2 * cols, c, cols, vec), v3 = ld4(x + (long long)i3 * cols, c, cols, vec);
+                a.x = ((a.x + v0.x) + v1.x) + v2.x + v3.x; a.y = ((a.y + v0.y) + v1.y) + v2.y + v3.y;
+                a.z = ((a.z + v0.z) + v1.z) + v2.z + v3.z; a.w = ((a.w + v0.w) + v1.w) + v2.w + v3.w;
+            }
+            for (; r < r1; ++r) {
+                const float4 v = ld4(x + (long long)order[r] * cols, c, cols, vec);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            double* b = bank + lb * cols + c;
+            if (c + 0 < cols) b[0] += (double)a.x;
+            if (c + 1 < cols) b[1] += (double)a.y;
+            if (c + 2 < cols) b[2] += (double)a.z;
+            if (c + 3 < cols) b[3] += (double)a.w;
+        }
+    }
+}
+
+// ---- GraphONE gather-max: gradient of the (trainable) prototype rows ---------------------------------------------------
+// dbank[p, c] += sum over the edges e = (n, j) with nn[n, j] == p of (arg[n, c] == j ? dm[n, c] : 0): a gather over the
+// edge list grouped by prototype (t_rowptr [K+1], t_edge = n*k + j ascending inside a group), one wave per prototype
+// row, fixed summation order -- no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_max_bank_grad_kernel(const T* __restrict__ dm, const uint8_t* __restrict__ arg,
+                                                                   const int* __restrict__ t_rowptr,
+                                                                   const int* __restrict__ t_edge, float* __restrict__ dbank,
+                                                                   int K, int cols, int k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    for (int p = blockIdx.x * WPB + wave; p < K; p += gridDim.x * WPB) {
+        const int e0 = t_rowptr[p], e1 = t_rowptr[p + 1];
+        if (e0 == e1) continue;
+        for (int c = lane * 4; c < cols; c += 256) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e0; e < e1; ++e) {
+                const int ed = t_edge[e], n = ed / k;
+                const uint32_t j = (uint32_t)(ed - n * k);
+                const float4 g = ld4(dm + (long long)n * cols, c, cols, vec);
+                const uint8_t* ap = arg + (long long)n * cols + c;
+                if (c + 0 < cols && ap[0] == j) a.x += g.x;
+                if (c + 1 < cols && ap[1] == j) a.y += g.y;
+                if (c + 2 < cols && ap[2] == j) a.z += g.z;
+                if (c + 3 < cols && ap[3] == j) a.w += g.w;
+            }
+            float* d = dbank + (long long)p * cols + c;
+            if (c + 0 < cols) d[0] += a.x;
+            if (c + 1 < cols) d[1] += a.y;
+            if (c + 2 < cols) d[2] += a.z;
+            if (c + 3 < cols) d[3] += a.w;
+        }
     }
 }
 
@@ -762,8 +830,18 @@ int egk_row_inv_norm(egk_stream_t stream, const void* x, float* inv_norm, int32_
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_ROW_INV_NORM, s, 0, 4.0 * rows * cols);
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(row_inv_norm_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, inv_norm,
-                                             rows, cols));
+                                             rows, cols, 0));
     return check_launch("egk_row_inv_norm");
+}
+
+int egk_row_sq_norm(egk_stream_t stream, const void* x, float* sq_norm, int32_t rows, int32_t cols, int32_t dtype) {
+    EGK_REQUIRE(x && sq_norm, "egk_row_sq_norm: null pointer");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_ROW_INV_NORM, s, 0, 4.0 * rows * cols);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(row_inv_norm_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, sq_norm,
+                                             rows, cols, 1));
+    return check_launch("egk_row_sq_norm");
 }
 
 int egk_cos_dist(egk_stream_t stream, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv, float* dist,
@@ -777,31 +855,58 @@ int egk_cos_dist(egk_stream_t stream, const float* dot, int64_t ldd, const float
     return check_launch("egk_cos_dist");
 }
 
-int egk_topk_smallest(egk_stream_t stream, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv,
-                      int64_t* nn, int32_t rows, int32_t K, int32_t k) {
-    EGK_REQUIRE(dot && f_inv && b_inv && nn, "egk_topk_smallest: null pointer");
-    EGK_REQUIRE(k >= 1 && k <= 16 && k <= K, "egk_topk_smallest: k must be in [1, min(16, K)]");
+static int topk_launch(const char* what, bool l2, egk_stream_t stream, const float* dot, int64_t ldd, const float* fa,
+                       const float* ba, int64_t* nn, int32_t rows, int32_t K, int32_t k) {
+    EGK_REQUIRE(dot && fa && ba && nn, "%s: null pointer", what);
+    EGK_REQUIRE(k >= 1 && k <= 16 && k <= K, "%s: k must be in [1, min(16, K)]", what);
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_TOPK, s, 0, 4.0 * rows * K);
-    const int vec = (ldd % 4 == 0) && ((uintptr_t)dot % 16 == 0) && ((uintptr_t)b_inv % 16 == 0);
-    if (k <= 4)
-        hipLaunchKernelGGL(topk_kernel<4>, dim3(row_grid(rows)), dim3(256), 0, s, dot, (long long)ldd, f_inv, b_inv,
-                           (long long*)nn, rows, K, k, vec);
-    else
-        hipLaunchKernelGGL(topk_kernel<16>, dim3(row_grid(rows)), dim3(256), 0, s, dot, (long long)ldd, f_inv, b_inv,
-                           (long long*)nn, rows, K, k, vec);
-    return check_launch("egk_topk_smallest");
+    const int vec = (ldd % 4 == 0) && ((uintptr_t)dot % 16 == 0) && ((uintptr_t)ba % 16 == 0);
+    const dim3 grid(row_grid(rows)), block(256);
+#define EGK_TOPK(KM, L2) \
+    hipLaunchKernelGGL((topk_kernel<KM, L2>), grid, block, 0, s, dot, (long long)ldd, fa, ba, (long long*)nn, rows, K, k, vec)
+    if (k <= 4) {
+        if (l2) EGK_TOPK(4, true); else EGK_TOPK(4, false);
+    } else {
+        if (l2) EGK_TOPK(16, true); else EGK_TOPK(16, false);
+    }
+#undef EGK_TOPK
+    return check_launch(what);
 }
 
-int egk_scatter_add_rows_f64(egk_stream_t stream, const void* x, const int64_t* label, double* bank, int64_t* count,
-                             int32_t rows, int32_t cols, int64_t n_labels, int32_t dtype) {
-    EGK_REQUIRE(x && label && bank, "egk_scatter_add_rows_f64: null pointer");
-    if (rows == 0) return 0;
+int egk_topk_smallest(egk_stream_t stream, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv,
+                      int64_t* nn, int32_t rows, int32_t K, int32_t k) {
+    return topk_launch("egk_topk_smallest", false, stream, dot, ldd, f_inv, b_inv, nn, rows, K, k);
+}
+
+int egk_topk_smallest_l2(egk_stream_t stream, const float* dot, int64_t ldd, const float* f_sq, const float* b_sq,
+                         int64_t* nn, int32_t rows, int32_t K, int32_t k) {
+    return topk_launch("egk_topk_smallest_l2", true, stream, dot, ldd, f_sq, b_sq, nn, rows, K, k);
+}
+
+int egk_segment_sum_rows_f64(egk_stream_t stream, const void* x, const int32_t* order, const int32_t* seg_ptr,
+                             const int64_t* seg_label, double* bank, int64_t* count, int32_t n_seg, int32_t cols,
+                             int64_t n_labels, int32_t dtype) {
+    EGK_REQUIRE(x && order && seg_ptr && seg_label && bank, "egk_segment_sum_rows_f64: null pointer");
+    if (n_seg == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(KID_SCATTER_ADD_F64, s, 0, 4.0 * rows * cols + 16.0 * rows * cols);
-    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(scatter_add_f64_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
-                                             (const long long*)label, bank, (long long*)count, rows, cols, (long long)n_labels));
-    return check_launch("egk_scatter_add_rows_f64");
+    ProfScope prof(KID_SCATTER_ADD_F64, s, 0, 4.0 * n_seg * cols + 16.0 * n_seg * cols);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segment_sum_f64_kernel<T>, dim3(row_grid(n_seg)), dim3(256), 0, s, (const T*)x, order,
+                                             seg_ptr, (const long long*)seg_label, bank, (long long*)count, n_seg, cols,
+                                             (long long)n_labels));
+    return check_launch("egk_segment_sum_rows_f64");
+}
+
+int egk_gather_max_bank_grad(egk_stream_t stream, const void* dm, const uint8_t* arg, const int32_t* t_rowptr,
+                             const int32_t* t_edge, float* dbank, int32_t K, int32_t cols, int32_t k, int32_t dtype) {
+    EGK_REQUIRE(dm && arg && t_rowptr && t_edge && dbank, "egk_gather_max_bank_grad: null pointer");
+    EGK_REQUIRE(k >= 1 && k < 255, "egk_gather_max_bank_grad: k out of range");
+    if (K == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_GATHER_MAX_BWD, s, 0, 8.0 * K * cols);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(gather_max_bank_grad_kernel<T>, dim3(row_grid(K)), dim3(256), 0, s, (const T*)dm, arg,
+                                             t_rowptr, t_edge, dbank, K, cols, k));
+    return check_launch("egk_gather_max_bank_grad");
 }
 }

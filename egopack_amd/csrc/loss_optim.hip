@@ -81,6 +81,51 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
     st1t(dx + i, (1.f / (1.f + expf(-v)) - (float)y[i]) * gloss[i]);
 }
 
+// ---- sigmoid losses against one-hot class targets (OSCCTask.compute_loss 'bce' / 'focal', reference oscc.py:91-96) ---
+// element i = (row, c) of [rows, C] logits; target t = (y[row] == c).  kind 0: BCE-with-logits; kind 1: torchvision
+// sigmoid_focal_loss(alpha, gamma):  p_t = sigmoid(z), z = (2t-1) x;  L = a_t (1-p_t)^gamma (-log p_t),
+// a_t = alpha t + (1-alpha)(1-t) (alpha < 0: no weighting);  dL/dx = (2t-1) a_t (1-p_t)^gamma (gamma p_t log p_t - (1-p_t)).
+__device__ __forceinline__ float log_sigmoid(float z) { return -(fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)))); }
+
+__global__ __launch_bounds__(256) void onehot_sigmoid_fwd_kernel(const float* __restrict__ x, const long long* __restrict__ y,
+                                                                 float* __restrict__ loss, int n, int C, int kind, float alpha,
+                                                                 float gamma) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float t = y[i / C] == (long long)(i % C) ? 1.f : 0.f;
+    const float ce = (1.f - t) * v + fmaxf(-v, 0.f) + log1pf(expf(-fabsf(v)));
+    if (kind == 0) {
+        loss[i] = ce;
+        return;
+    }
+    const float p = 1.f / (1.f + expf(-v));
+    const float pt = p * t + (1.f - p) * (1.f - t);
+    float l = ce * (gamma == 2.f ? (1.f - pt) * (1.f - pt) : powf(1.f - pt, gamma));
+    if (alpha >= 0.f) l *= alpha * t + (1.f - alpha) * (1.f - t);
+    loss[i] = l;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void onehot_sigmoid_bwd_kernel(const float* __restrict__ x, const long long* __restrict__ y,
+                                                                 const float* __restrict__ gloss, T* __restrict__ dx, int n,
+                                                                 int C, int kind, float alpha, float gamma) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float t = y[i / C] == (long long)(i % C) ? 1.f : 0.f;
+    float d;
+    if (kind == 0) {
+        d = 1.f / (1.f + expf(-v)) - t;
+    } else {
+        const float sg = 2.f * t - 1.f, z = sg * v;
+        const float pt = 1.f / (1.f + expf(-z)), q = 1.f - pt;
+        const float mod = gamma == 2.f ? q * q : powf(q, gamma);
+        const float a = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+        d = sg * a * mod * (gamma * pt * log_sigmoid(z) - q);
+    }
+    st1t(dx + i, d * gloss[i]);
+}
+
 // ---- dropout ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
@@ -322,6 +367,32 @@ int egk_bce_bwd(egk_stream_t stream, const float* logits, const int64_t* y, cons
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(bce_bwd_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, (const long long*)y,
                                              gloss, (T*)dlogits, n));
     return check_launch("egk_bce_bwd");
+}
+
+int egk_onehot_sigmoid_loss_fwd(egk_stream_t stream, const float* logits, const int64_t* y, float* loss, int32_t rows, int32_t C,
+                                int32_t kind, float alpha, float gamma) {
+    EGK_REQUIRE(logits && y && loss, "egk_onehot_sigmoid_loss_fwd: null pointer");
+    EGK_REQUIRE(C >= 1 && (kind == 0 || kind == 1), "egk_onehot_sigmoid_loss_fwd: bad C / kind");
+    const int n = rows * C;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_BCE_FWD, s, 0, 8.0 * n + 8.0 * rows);
+    hipLaunchKernelGGL(onehot_sigmoid_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, (const long long*)y, loss, n, C,
+                       kind, alpha, gamma);
+    return check_launch("egk_onehot_sigmoid_loss_fwd");
+}
+
+int egk_onehot_sigmoid_loss_bwd(egk_stream_t stream, const float* logits, const int64_t* y, const float* gloss, void* dlogits,
+                                int32_t rows, int32_t C, int32_t kind, float alpha, float gamma, int32_t dtype) {
+    EGK_REQUIRE(logits && y && gloss && dlogits, "egk_onehot_sigmoid_loss_bwd: null pointer");
+    EGK_REQUIRE(C >= 1 && (kind == 0 || kind == 1), "egk_onehot_sigmoid_loss_bwd: bad C / kind");
+    const int n = rows * C;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_BCE_BWD, s, 0, 12.0 * n + 8.0 * rows);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(onehot_sigmoid_bwd_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, logits,
+                                             (const long long*)y, gloss, (T*)dlogits, n, C, kind, alpha, gamma));
+    return check_launch("egk_onehot_sigmoid_loss_bwd");
 }
 
 int egk_dropout_fwd(egk_stream_t stream, const void* x, void* y, uint8_t* mask, int64_t n, float p, uint64_t seed,

@@ -233,25 +233,43 @@ def merge_batches(batches: Sequence[Data]) -> Data:
     x = base if (base is not None and all(getattr(b, "x_base", None) is base for b in batches)
                  and base.shape[0] == off) else xs
     out = Data(x=x, pos=torch.cat(poss), edge_index=ei)
-    # The merged CSR depends on the tasks' edge lists only: with fixed-length sequences it is the same every step, and
-    # building it (two stable sorts over all edges) cost 9 ms of host time per step.  Callers that know the structure
-    # fingerprint of their batches (engine.stage_batches) pass it as ``structure_key`` on the batches: one build per key.
-    keys = tuple(getattr(b, "_struct_key", 0) for b in batches)
-    cached = _merged_graph_cache.get(keys) if all(keys) else None
-    if cached is not None and cached[0] == (tuple(ei.shape), off):
-        out.graph = cached[1]
-    else:
-        out.graph = build_csr(ei, off)
-        if all(keys):
-            if len(_merged_graph_cache) >= 8:
-                _merged_graph_cache.clear()
-            _merged_graph_cache[keys] = ((tuple(ei.shape), off), out.graph)
+    # The task batches occupy disjoint, ascending node ranges, so the merged CSR is the CONCATENATION of the tasks' CSR
+    # arrays with node / edge offsets (what the stable sorts of build_csr over the merged edge list would give, entry for
+    # entry) -- O(E) copies instead of two sorts over all edges (9 ms of host time per step), whatever the edge lists are
+    # (the LTA edge set changes with the labels of every batch).
+    graphs = [getattr(b, "graph", None) for b in batches]
+    out.graph = concat_csr(graphs) if all(g is not None for g in graphs) else build_csr(ei, off)
     out.seg_ptr = torch.tensor(seg, dtype=torch.int32)
     out.num_segments = len(batches)
     return out
 
 
-_merged_graph_cache = {}
+def concat_csr(graphs: Sequence[CSRGraph]) -> CSRGraph:
+    """CSR of the disjoint union of graphs whose node ranges follow each other (== build_csr of the offset edge lists)."""
+    def ptr(name):
+        parts, eoff = [], 0
+        for g in graphs:
+            rp = getattr(g, name)
+            parts.append(rp[:-1] + eoff)
+            eoff += int(rp[-1])
+        parts.append(torch.tensor([eoff], dtype=torch.int32, device=parts[0].device))
+        return torch.cat(parts).to(torch.int32)
+
+    def ids(name):
+        parts, noff = [], 0
+        for g in graphs:
+            v = getattr(g, name)
+            parts.append((v if v is not None else torch.zeros(0, dtype=torch.int32)) + noff)
+            noff += g.num_nodes
+        return torch.cat(parts).to(torch.int32)
+
+    def mode(listed, name):
+        with_rows = [getattr(g, name) for g, l in zip(graphs, listed) if l is not None and l.numel()]
+        return int(bool(with_rows) and all(m == 1 for m in with_rows))
+    heavy, t_heavy = ids("heavy"), ids("t_heavy")
+    return CSRGraph(ptr("rowptr"), ids("col"), ptr("t_rowptr"), ids("t_col"), torch.cat([g.t_wgt for g in graphs]),
+                    sum(g.num_nodes for g in graphs), heavy, t_heavy, mode([g.heavy for g in graphs], "heavy_mode"),
+                    mode([g.t_heavy for g in graphs], "t_heavy_mode"))
 
 
 class PinnedRing:
@@ -311,7 +329,9 @@ def to_device_packed(datas: Sequence["Data"], device, non_blocking: bool = True)
     plans = [{k: walk(v) for k, v in d.__dict__.items()} for d in datas]
     if total == 0:
         return [d.to(device, non_blocking=non_blocking) for d in datas]
-    host, slot = _pinned_ring.get((total,), torch.uint8)
+    # (staging size rounded up to 64 KiB: batches whose edge counts differ by a few entries reuse one ring of buffers
+    #  instead of allocating a new page-locked ring per distinct byte total)
+    host, slot = _pinned_ring.get(((total + 65535) // 65536 * 65536,), torch.uint8)
     for t, off in items:
         n = t.numel() * t.element_size()
         if n:
@@ -415,6 +435,7 @@ class BatchLoader:
             raise ValueError(f"shard={shard!r}: 'samples' or 'batches'")
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
         self.rank, self.world_size, self.pin_memory, self.shard = rank, world_size, pin_memory, shard
+        self.seed = int(seed)
         self.gen = torch.Generator()
         self.gen.manual_seed(seed)
 
@@ -463,23 +484,33 @@ class BatchLoader:
     # -- worker processes (opt-in: ``workers`` > 0) ------------------------------------------------------------------
     # Building a sample is per-sample Python (the reference's segment-sampling index arithmetic, edge builders): ~1 ms per
     # sample, 100-200 ms per step of 192 samples in the training process against a 1.8 ms device step.  ``workers``
-    # forked processes (they never touch the device) collate whole batches ahead, at most 2 per worker in flight, and hand
+    # processes (they never touch the device) collate whole batches ahead, at most 2 per worker in flight, and hand
     # them back in order.  Datasets whose samples depend on a sequential random stream (segment sampling with a shared
-    # RandomState) draw from per-worker copies of it: still the reference's sampling, not the single-process sequence.
+    # RandomState) draw every chunk from a stream seeded by (loader seed, epoch, chunk index): still the reference's
+    # sampling, reproducible from the seed, not the single-process sequence.
     workers = 0
     _pool = None
 
+    def start_workers(self):
+        """Create the collation processes.  Entry points call this BEFORE the process touches the GPU (plain ``fork`` of a
+        process without HIP state); if the device is already initialised the pool comes from a ``forkserver`` (a clean
+        helper process forks the workers: no HIP runtime locks, threads or pinned mappings are inherited)."""
+        import torch.multiprocessing as mp
+        if self._pool is None and self.workers > 0:
+            ctx = mp.get_context("forkserver" if torch.cuda.is_initialized() else "fork")
+            self._pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self.dataset,))
+        return self
+
     def _iter_workers(self):
         import collections
-        import torch.multiprocessing as mp
-        if self._pool is None:
-            ctx = mp.get_context("fork")
-            self._pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self.dataset,))
+        self.start_workers()
+        self._epoch = getattr(self, "_epoch", -1) + 1
         pending = collections.deque()
-        chunks = self._chunks()
         try:
-            for chunk in chunks:
-                pending.append(self._pool.apply_async(_worker_collate, (chunk,)))
+            for n, chunk in enumerate(self._chunks()):
+                # the sampling stream of a chunk is a function of (loader seed, epoch, chunk index): the batches do not
+                # depend on which worker builds them
+                pending.append(self._pool.apply_async(_worker_collate, (chunk, (self.seed, self._epoch, n))))
                 if len(pending) >= 2 * self.workers:
                     b = pending.popleft().get(timeout=300)
                     yield b.pin_memory() if self.pin_memory else b
@@ -487,11 +518,8 @@ class BatchLoader:
                 b = pending.popleft().get(timeout=300)
                 yield b.pin_memory() if self.pin_memory else b
         finally:
-            for r in pending:  # (consumer stopped early: let the in-flight batches finish, drop them)
-                try:
-                    r.get(timeout=60)
-                except Exception:  # noqa: BLE001
-                    pass
+            if pending:  # the consumer stopped early: drop the in-flight work with its processes (a new pool next time)
+                self.close()
 
     def close(self):
         if self._pool is not None:
@@ -513,13 +541,13 @@ def _worker_init(dataset):
     global _worker_dataset
     _worker_dataset = dataset
     torch.set_num_threads(1)
-    rng = getattr(dataset, "rng", None)  # a per-worker stream for datasets that sample with a shared RandomState
-    if rng is not None and hasattr(rng, "seed"):
-        import os
-        rng.seed((int(getattr(dataset, "seed", 0)) * 7919 + os.getpid()) % (2 ** 32))
 
 
-def _worker_collate(chunk):
+def _worker_collate(chunk, stream=None):
+    rng = getattr(_worker_dataset, "rng", None)  # datasets that sample with a shared RandomState: one stream per chunk
+    if stream is not None and rng is not None and hasattr(rng, "seed"):
+        seed, epoch, n = stream
+        rng.seed((int(seed) * 1000003 + int(epoch) * 7919 + int(n) * 104729 + int(getattr(_worker_dataset, "seed", 0))) % (2 ** 32))
     return collate([_worker_dataset[j] for j in chunk])
 
 

@@ -170,21 +170,47 @@ def _walk(obj, prefix=""):
         yield prefix, obj
 
 
+# Arrays whose length is the EDGE count of a batch.  The LTA edge set depends on the labels (n_forecast counts ``y[:, 0] >
+# 0``, reference lta_temp_connectivity.py:47), so E differs by a few entries from batch to batch.  No kernel takes E: the
+# gathers walk ``rowptr[i] .. rowptr[i + 1]``.  The static buffers of a captured step therefore hold these arrays at a
+# CAPACITY (E rounded up to EDGE_BUCKET), a replay writes the first E entries, and the signature compares capacities.
+EDGE_FIELDS = (".edge_index", ".graph.col", ".graph.t_col", ".graph.t_wgt")
+EDGE_BUCKET = 1024
+
+
+def _edge_capacity(e: int) -> int:
+    return (int(e) + EDGE_BUCKET - 1) // EDGE_BUCKET * EDGE_BUCKET
+
+
+def _is_edge_field(path: str) -> bool:
+    return path.endswith(EDGE_FIELDS)
+
+
 def batch_signature(batches: Mapping[str, Data], merged=None) -> tuple:
-    """Everything a capture bakes in: the shape / dtype of every tensor and every plain scalar (node counts, heavy-row
-    modes ...) of the step's batches.  Two steps with equal signatures differ in tensor VALUES only."""
+    """Everything a capture bakes in: the shape / dtype of every tensor (edge-sized arrays: their capacity) and every plain
+    scalar (node counts, heavy-row modes ...) of the step's batches.  Two steps with equal signatures differ in tensor
+    VALUES only.  Private attributes (``_struct_key`` ...) describe values, not shapes: they are not part of it."""
     sig = []
     for name, obj in [*sorted(batches.items()), ("merged", merged)]:
         for path, v in _walk(obj, name):
-            if not (torch.is_tensor(v) and v.dim() >= 1 and path.endswith(".x_base")):  # (x_base aliases x's storage)
-                sig.append((path, (tuple(v.shape), v.dtype)) if torch.is_tensor(v) else (path, v))
+            if "._" in path or (torch.is_tensor(v) and v.dim() >= 1 and path.endswith(".x_base")):  # (x_base aliases x)
+                continue
+            if torch.is_tensor(v):
+                shape = tuple(v.shape)
+                if _is_edge_field(path) and v.dim() >= 1:
+                    shape = shape[:-1] + (_edge_capacity(shape[-1]),)
+                sig.append((path, (shape, v.dtype)))
+            else:
+                sig.append((path, v))
     return tuple(sig)
 
 
 @torch.no_grad()
 def copy_batch_values(dst_batches, dst_merged, src_batches, src_merged) -> None:
     """dst <- src for every tensor of two sets of batches with the same signature (device to device).  Per-task feature
-    blocks that are row ranges of a packed buffer (``x_base``) are written once, through the buffer."""
+    blocks that are row ranges of a packed buffer (``x_base``) are written once, through the buffer; edge-sized arrays are
+    written into the first E entries of their capacity.  Graph-structure arrays are skipped when both sides carry the same
+    non-zero structure fingerprint; after a full copy the destination takes over the source's fingerprint."""
     done = set()
     pairs = [(dst_batches[t], src_batches[t]) for t in sorted(dst_batches) if dst_batches[t] is not None]
     if dst_merged is not None:
@@ -207,20 +233,33 @@ def copy_batch_values(dst_batches, dst_merged, src_batches, src_merged) -> None:
                 continue  # a row range of the packed buffer: the buffer itself is copied as the merged batch's x
             key = (d.untyped_storage().data_ptr(), d.storage_offset(), tuple(d.shape))
             if key not in done:
-                d.copy_(s_, non_blocking=True)
+                if d.shape != s_.shape and _is_edge_field(path):
+                    d[..., :s_.shape[-1]].copy_(s_, non_blocking=True)  # (the tail keeps stale entries no row range reaches)
+                else:
+                    d.copy_(s_, non_blocking=True)
                 done.add(key)
+        if not same_structure:
+            dst._struct_key = k_src  # (0 when the source's structure is unknown: the next copy is a full one again)
 
 
-def _clone_batch(d: Data) -> Data:
-    """Deep copy of a device batch (own storage for every tensor; scalars shared)."""
+def _clone_batch(d: Data, pad_edges: bool = False) -> Data:
+    """Deep copy of a device batch (own storage for every tensor; scalars shared).  ``pad_edges``: edge-sized arrays are
+    allocated at their capacity (zeros behind the copied entries) -- the static buffers of a captured training step."""
     from dataclasses import fields, is_dataclass, replace
+
+    def dup(path, t):
+        if pad_edges and _is_edge_field(path) and t.dim() >= 1 and _edge_capacity(t.shape[-1]) != t.shape[-1]:
+            out = torch.zeros(t.shape[:-1] + (_edge_capacity(t.shape[-1]),), dtype=t.dtype, device=t.device)
+            out[..., :t.shape[-1]].copy_(t)
+            return out
+        return t.clone()
     out = Data()
     for k, v in d.__dict__.items():
         if torch.is_tensor(v):
-            v = v.clone()
+            v = dup(f".{k}", v)
         elif is_dataclass(v):
-            v = replace(v, **{f.name: (getattr(v, f.name).clone() if torch.is_tensor(getattr(v, f.name)) else getattr(v, f.name))
-                              for f in fields(v)})
+            v = replace(v, **{f.name: (dup(f".{k}.{f.name}", getattr(v, f.name)) if torch.is_tensor(getattr(v, f.name))
+                                       else getattr(v, f.name)) for f in fields(v)})
         elif isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
             v = [t.clone() for t in v]
         setattr(out, k, v)
@@ -408,21 +447,26 @@ class StepBase:
         """One optimizer step on device batches, for training loops (main_temporal / main_egopack).
 
         The first ``graph_after`` steps run eagerly.  The next one is captured on private copies of its batches, and every
-        later step whose batches have the SAME signature (``batch_signature``: shapes, dtypes, node counts -- the loaders
-        deliver fixed-size batches of fixed-length sequences, so that is every step but a short last one) copies its
+        later step whose batches have the SAME signature (``batch_signature``: shapes, dtypes, node counts, edge CAPACITIES
+        -- the loaders deliver fixed-size batches of fixed-length sequences, so that is every step but a short last one,
+        also for LTA batches whose edge count moves with the labels) copies its
         values into those buffers and replays the graph: the step the benchmark measures instead of ~150 launches issued
         from Python.  Anything else (different shapes, several ranks with an eager exchange path, ``use_graph`` off) takes
         the eager step.  Returns what ``step`` returns; after a replay the loss vectors are the graph's static outputs,
-        valid until the next call."""
+        valid until the next call.  ``loop_counts`` tallies replayed vs eager steps."""
         self._steps_seen = getattr(self, "_steps_seen", 0) + 1
+        if not hasattr(self, "loop_counts"):
+            self.loop_counts = {"replayed": 0, "eager": 0}  # per training loop; the entry points log and reset it per epoch
         if not self.use_graph or self._steps_seen <= self.graph_after or not next(iter(batches.values())).x.is_cuda:
+            self.loop_counts["eager"] += 1
             return self.step(batches, merged)
         if self.fused and len([t for t in self.enabled if batches.get(t) is not None]) > 1 and merged is None:
+            self.loop_counts["eager"] += 1
             return self.step(batches, merged)  # (the caller did not stage a merged batch: nothing static to replay on)
         sig = batch_signature(batches, merged)
         st = getattr(self, "_train_static", None)
         if st is None:
-            clone = lambda d: None if d is None else _clone_batch(d)
+            clone = lambda d: None if d is None else _clone_batch(d, pad_edges=True)
             static_b = {t: clone(b) for t, b in batches.items()}
             static_m = clone(merged)
             _rewire_packed(static_b, static_m)
@@ -431,11 +475,14 @@ class StepBase:
             st = self._train_static = {"sig": batch_signature(static_b, static_m), "batches": static_b, "merged": static_m}
             if st["sig"] != sig:  # (cannot happen: the clones mirror the originals)
                 self._train_static = None
+                self.loop_counts["eager"] += 1
                 return self.step(batches, merged)
         elif st["sig"] != sig:
+            self.loop_counts["eager"] += 1
             return self.step(batches, merged)
         else:
             copy_batch_values(st["batches"], st["merged"], batches, merged)
+        self.loop_counts["replayed"] += 1
         total = self.replay()
         return total.detach(), {t: v.detach() for t, v in self._static_out[1].items()}
 
@@ -706,7 +753,9 @@ class EgoPackStep(StepBase):
         others = [t for t in self.AUX_ORDER[primary] if t in self.graphone.task_labels]
         f_primary = task.forward_features(feat)
         with torch.no_grad():
-            aux_in = {t: self.tasks[t].forward_features(feat) for t in others}
+            # f32 out of the projections' last contraction: the nearest-prototype search (an index op) ranks the f32
+            # accumulators in every compute mode; GraphONE brings them to the activation type for its stages
+            aux_in = {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others}
         aux, closest = self.graphone.interact(aux_in)
         if primary == "oscc":
             logits = task.forward_logits(features=f_primary, batch=data, aux_features=aux)

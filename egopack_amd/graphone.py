@@ -4,7 +4,9 @@ Eval-mode, no-grad pass over the AR loader: per batch keep the labelled nodes, p
 every task head, and accumulate ``bank_t[verb*|nouns|+noun] += feature`` in float64 plus a label
 count; the banks are the per-label means over the seen labels.  The fp64 [|V|*|N|, H] banks live on
 the device for the whole pass (one allocation per task instead of one 450 MB temporary per
-``scatter`` call) and rows are added by the scatter kernel.
+``scatter`` call).  Rows are added by a label-grouped segmented reduction (one wave per label of the
+batch, rows of a label summed in fp32 in node order like the reference's per-batch scatter, then added
+to the fp64 row): no atomics, the banks are bitwise reproducible.
 
 Several ranks (SURVEY §8(e) caveat 3): give every rank a loader sharded batch by batch
 (data.BatchLoader ``shard="batches"``: same batches as the single-process pass, split round-robin);
@@ -35,16 +37,18 @@ def accumulate_banks(model, ar_task, tasks: List, dataloader, device="cuda"):
     banks = {t.name: torch.zeros((size, feat_size), dtype=torch.float64, device=device) for t in tasks}
     count = torch.zeros(size, dtype=torch.int64, device=device)
     for data in dataloader:
-        data = data.to(device)
-        feat = model(data)
-        # label = verb * |nouns| + noun for labelled nodes, -1 (skipped by the kernel) otherwise
+        # label = verb * |nouns| + noun for labelled nodes, -1 (skipped) otherwise; the nodes are grouped by label where
+        # the labels already are (on the host for loader batches: integer work, bit-exact), once per batch
         y = data.y
         labels = torch.where(y[:, 0] != -1, y[:, 0] * n_classes[1] + y[:, 1], torch.full_like(y[:, 0], -1))
+        groups = tuple(g.to(device) for g in ops.label_groups(labels))
+        data = data.to(device)
+        feat = model(data)
         for t in tasks:
             # the label count is incremented once PER TASK, as in the reference where
             # ``all_labels.append(labels)`` sits inside the task loop (graphone.py:50-52): every bank is the
             # per-label mean divided by len(tasks).  Kept for parity (prototypes are L2-normalised downstream).
-            ops.scatter_add_rows_f64(t.forward_features(feat), labels, banks[t.name], count)
+            ops.scatter_add_rows_f64(t.forward_features(feat), None, banks[t.name], count, groups=groups)
     return banks, count
 
 

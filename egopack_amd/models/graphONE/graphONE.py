@@ -10,10 +10,12 @@ What the reference computes per aux task and depth d (graphONE.py:94-115):
     f      = graph[-N:] (+ f if residual)
 Only the last N rows are kept and the bank is frozen, so the K prototype rows of the stage are
 dead work, and the edges are identical at every depth.  Here, per aux task:
-    nn = cosine_topk(f0, bank)              ONCE  (exact-f32 MFMA similarity + wave top-k)
+    nn = nearest_prototypes(f0, bank)       ONCE  (exact-f32 MFMA product + wave top-k; cosine or cdist/4096)
     per depth:  m = gather_max(f, bank, nn) (max over the k prototype rows and the self row)
                 h = [m | f].[Wl | Wr]^T -> LayerNorm+ReLU -> Linear (+ f residual in the epilogue)
-which gives the same N output rows.
+which gives the same N output rows.  With ``freeze=False`` the prototypes are parameters: their gradient comes
+through the max aggregation only (the bank rows' own stage outputs are discarded by the reference, the search runs
+under no_grad) and is a deterministic gather over the edge list grouped by prototype (ops._GatherMax.backward).
 """
 from __future__ import annotations
 
@@ -64,22 +66,21 @@ class GraphONE(nn.Module):
         self.parallel_tasks = bool(kwargs.get("parallel_tasks", True))
         self._task_streams: List[torch.cuda.Stream] = []
 
-    def _inv_norm(self, task: str) -> torch.Tensor:
+    def _bank_norm(self, task: str) -> torch.Tensor:
+        """Per-prototype 1/||p|| (cosine) or ||p||^2 (l2): cached while the bank is frozen, recomputed per call otherwise
+        (trainable prototypes move with every optimizer step)."""
         bank = self.embeddings[task].weight
         cached = self._bank_inv_norm.get(task)
         if (cached is None or cached.device != bank.device or cached.shape[0] != bank.shape[0]
-                or not self.freeze or cached._version_of != bank._version):
-            cached = ops.row_inv_norm(bank.detach())
-            cached._version_of = bank._version
+                or not self.freeze or cached._version_of != bank._version or cached._kind != self.distance_func):
+            cached = (ops.row_sq_norm if self.distance_func == "l2" else ops.row_inv_norm)(bank.detach())
+            cached._version_of, cached._kind = bank._version, self.distance_func
             self._bank_inv_norm[task] = cached
         return cached
 
     def interact(self, features: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], Dict[str, List[torch.Tensor]]]:
-        if self.distance_func != "cosine":
-            raise ValueError(f"Unknown distance function: {self.distance_func}" if self.distance_func != "l2"
-                             else "distance_func='l2' is outside the hot path (experiments use cosine)")
-        if not self.freeze:
-            raise NotImplementedError("trainable prototypes are outside the hot path (freeze=True in every experiment)")
+        if self.distance_func not in ("cosine", "l2"):
+            raise ValueError(f"Unknown distance function: {self.distance_func}")  # reference graphONE.py:131
         output, closest = {}, {}
         items = list(features.items())
         if self.parallel_tasks and len(items) > 1 and items[0][1].is_cuda:
@@ -106,7 +107,9 @@ class GraphONE(nn.Module):
 
     def _task_interaction(self, task: str, features: torch.Tensor):
         bank = self.embeddings[task].weight
-        nn_idx = ops.cosine_topk(features.detach(), bank.detach(), self.k, self._inv_norm(task))
+        # the search reads the features as they are handed in: callers that want index selection independent of the
+        # activation storage type pass the f32 output of the producing contraction (engine.EgoPackStep does)
+        nn_idx = ops.nearest_prototypes(features.detach(), bank.detach(), self.k, self.distance_func, self._bank_norm(task))
         assignments = [nn_idx[:, 0]] * self.depth  # the reference recomputes identical edges per depth
         f = ops.to_act(features)
         for stage in self.conv_stages[task]:

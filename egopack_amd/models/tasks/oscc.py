@@ -56,4 +56,8 @@ class OSCCTask(ProjectionTask):
     def compute_loss(self, logits, targets):
         if self.loss_func == "ce":
             return ops.cross_entropy(logits, targets, smoothing=0.1)
-        raise NotImplementedError(f"oscc loss '{self.loss_func}' is outside the hot path (experiments use 'ce')")
+        if self.loss_func == "bce":  # one_hot(targets, 2).float() targets, reduction 'none' -> [B, 2]
+            return ops.onehot_bce_with_logits(logits, targets)
+        if self.loss_func == "focal":  # torchvision sigmoid_focal_loss(alpha=0.5, gamma=2.0, reduction='none')
+            return ops.onehot_sigmoid_focal_loss(logits, targets, alpha=0.5, gamma=2.0)
+        return None  # (the reference falls through and returns None for an unknown loss_func, oscc.py:88-96)

@@ -21,10 +21,12 @@ class ProjectionTask(torch.nn.Module):
         self.net = nn.Sequential(Dropout(dropout), Linear(input_size, features_size), LayerNorm(features_size),
                                  nn.ReLU(), Linear(features_size, features_size))
 
-    def forward_features(self, x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+    def forward_features(self, x: torch.Tensor, *args, out_f32: bool = False, **kwargs) -> torch.Tensor:
+        """``out_f32`` (not a reference argument): keep the last contraction's f32 accumulators as the output whatever the
+        activation storage type -- the GraphONE prototype search then ranks f32 values, not their bf16 roundings."""
         from ... import ops
         n = self.net
-        return n[4](n[2](n[1](n[0](ops.to_act(x))), relu=True))
+        return n[4](n[2](n[1](n[0](ops.to_act(x))), relu=True), out_f32=out_f32)
 
     def configure_optimizers(self, _):
         return self.parameters()

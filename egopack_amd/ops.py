@@ -868,6 +868,17 @@ def sage_mean_layer(h, conv, graph, compute=None):
 
 
 # ---- GraphONE gather-max ------------------------------------------------------------------------------
+@torch.no_grad()
+def _edges_by_prototype(nn: torch.Tensor, K: int):
+    """Edge list of ``nn`` [N, k] grouped by prototype: (t_rowptr int32 [K+1], t_edge int32 [N*k]) with
+    t_edge = n*k + j ascending inside a group.  Integer index work (a stable device sort): bit-exact."""
+    flat = nn.reshape(-1)
+    srt, perm = torch.sort(flat, stable=True)
+    rowptr = torch.zeros(K + 1, dtype=torch.int32, device=nn.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(srt, minlength=K), 0).to(torch.int32)
+    return rowptr, perm.to(torch.int32)
+
+
 class _GatherMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f, bank, nn):
@@ -877,25 +888,35 @@ class _GatherMax(torch.autograd.Function):
         k = nn.shape[1]
         m = torch.empty_like(f)
         arg = torch.empty((rows, cols), dtype=torch.uint8, device=f.device)
-        _ck(_lib.load().egk_gather_max_fwd(_stream(), _p(f), _p(bank), _p(nn.contiguous()), _p(m), _p(arg), rows, cols, k,
+        nn = nn.contiguous()
+        _ck(_lib.load().egk_gather_max_fwd(_stream(), _p(f), _p(bank), _p(nn), _p(m), _p(arg), rows, cols, k,
                                            _dt(f)), "egk_gather_max_fwd")
         ctx.k = k
-        ctx.save_for_backward(arg)
+        ctx.K = bank.shape[0]
+        ctx.save_for_backward(arg, nn if ctx.needs_input_grad[1] else None)
         return m
 
     @staticmethod
     def backward(ctx, dm):
-        (arg,) = ctx.saved_tensors
+        arg, nn = ctx.saved_tensors
+        lib = _lib.load()
         dm = _c(dm)
         rows, cols = dm.shape
-        df = torch.empty_like(dm)
-        _ck(_lib.load().egk_gather_max_bwd(_stream(), _p(dm), _p(arg), _p(df), rows, cols, ctx.k, 0, _dt(dm)),
-            "egk_gather_max_bwd")
-        return df, None, None
+        df = None
+        if ctx.needs_input_grad[0]:
+            df = torch.empty_like(dm)
+            _ck(lib.egk_gather_max_bwd(_stream(), _p(dm), _p(arg), _p(df), rows, cols, ctx.k, 0, _dt(dm)), "egk_gather_max_bwd")
+        dbank = None
+        if ctx.needs_input_grad[1]:  # trainable prototypes (GraphONE(freeze=False)): rows gather the gradients they won
+            t_rowptr, t_edge = _edges_by_prototype(nn, ctx.K)
+            dbank = torch.zeros((ctx.K, cols), dtype=torch.float32, device=dm.device)
+            _ck(lib.egk_gather_max_bank_grad(_stream(), _p(dm), _p(arg), _p(t_rowptr), _p(t_edge), _p(dbank), ctx.K, cols, ctx.k,
+                                             _dt(dm)), "egk_gather_max_bank_grad")
+        return df, dbank, None
 
 
 def gather_max(f, bank, nn):
-    """m[n] = max(f[n], bank[nn[n, :]]) elementwise (frozen f32 bank: no gradient to it)."""
+    """m[n] = max(f[n], bank[nn[n, :]]) elementwise (f32 bank; its rows receive a gradient when the bank is trainable)."""
     return _GatherMax.apply(f, bank, nn)
 
 
@@ -1022,6 +1043,47 @@ def bce_with_logits(logits, y):
     if y.dtype != torch.int64:
         y = y.to(torch.int64)
     return _BCE.apply(logits, y, _state["act"])
+
+
+class _OneHotSigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y, kind, alpha, gamma):
+        _need_gpu(logits, y)
+        logits = _f32c(logits)
+        y = y.contiguous()
+        rows, Cn = logits.shape
+        loss = torch.empty_like(logits)
+        _ck(_lib.load().egk_onehot_sigmoid_loss_fwd(_stream(), _p(logits), _p(y), _p(loss), rows, Cn, kind, alpha, gamma),
+            "egk_onehot_sigmoid_loss_fwd")
+        ctx.cfg = (kind, alpha, gamma)
+        ctx.save_for_backward(logits, y)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, y = ctx.saved_tensors
+        g = _f32c(g)
+        rows, Cn = logits.shape
+        d = torch.empty_like(logits)
+        kind, alpha, gamma = ctx.cfg
+        _ck(_lib.load().egk_onehot_sigmoid_loss_bwd(_stream(), _p(logits), _p(y), _p(g), _p(d), rows, Cn, kind, alpha, gamma,
+                                                    _dt(d)), "egk_onehot_sigmoid_loss_bwd")
+        return d, None, None, None, None
+
+
+def onehot_bce_with_logits(logits, y):
+    """F.binary_cross_entropy_with_logits(logits, one_hot(y, C).float(), reduction='none') (reference oscc.py:91-93)."""
+    if y.dtype != torch.int64:
+        y = y.to(torch.int64)
+    return _OneHotSigmoid.apply(logits, y, 0, -1.0, 0.0)
+
+
+def onehot_sigmoid_focal_loss(logits, y, alpha: float = 0.5, gamma: float = 2.0):
+    """torchvision.ops.sigmoid_focal_loss(logits, one_hot(y, C).float(), alpha, gamma, reduction='none')
+    (reference oscc.py:94-96)."""
+    if y.dtype != torch.int64:
+        y = y.to(torch.int64)
+    return _OneHotSigmoid.apply(logits, y, 1, float(alpha), float(gamma))
 
 
 # ---- dropout / reductions -----------------------------------------------------------------------------------
@@ -1186,33 +1248,84 @@ def scaled_one_minus(dot, f_inv, b_inv):
 
 
 @torch.no_grad()
-def cosine_topk(f, bank, k, bank_inv_norm=None):
-    """Indices [N, k] (int64, ascending cosine distance) of the k nearest bank rows of every row of f.
-    The similarity product always runs on the exact-f32 MFMA path (bf16 features are widened first) so
-    that index selection depends on the stored feature values only, not on the MFMA type."""
+def row_sq_norm(x):
+    _need_gpu(x)
+    x = _c(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _ck(_lib.load().egk_row_sq_norm(_stream(), _p(x), _p(out), x.shape[0], x.shape[1], _dt(x)), "egk_row_sq_norm")
+    return out
+
+
+@torch.no_grad()
+def nearest_prototypes(f, bank, k, distance_func: str = "cosine", bank_norm=None):
+    """Indices [N, k] (int64, ascending distance, ties to the lower index) of the k nearest bank rows of every row of
+    f (GraphONE.__compute_edges, reference graphONE.py:119-141).  'cosine': 1 - cos similarity; 'l2': cdist / 4096.
+    The f . bank^T product always runs on the exact-f32 MFMA path (bf16 features are widened first) so that index
+    selection depends on the stored feature values only, not on the MFMA type.  ``bank_norm``: cached per-row
+    1/||p|| (cosine) or ||p||^2 (l2) of the bank."""
     _need_gpu(f, bank)
+    if distance_func not in ("cosine", "l2"):
+        raise ValueError(f"Unknown distance function: {distance_func}")
     lib = _lib.load()
     f, bank = _c(f), _f32c(bank)
     if f.dtype != torch.float32:
         f = cast_raw(f, torch.float32)
     N, H = f.shape
     K = bank.shape[0]
-    if bank_inv_norm is None:
-        bank_inv_norm = row_inv_norm(bank)
-    f_inv = row_inv_norm(f)
+    l2 = distance_func == "l2"
+    norm = row_sq_norm if l2 else row_inv_norm
+    if bank_norm is None:
+        bank_norm = norm(bank)
+    f_norm = norm(f)
     dot = torch.empty((N, K), dtype=torch.float32, device=f.device)
     gemm(N, K, f, H, bank, H, H, dot, K, compute=F32)
     nn = torch.empty((N, k), dtype=torch.int64, device=f.device)
-    _ck(lib.egk_topk_smallest(_stream(), _p(dot), K, _p(f_inv), _p(bank_inv_norm), _p(nn), N, K, k), "egk_topk_smallest")
+    fn = lib.egk_topk_smallest_l2 if l2 else lib.egk_topk_smallest
+    _ck(fn(_stream(), _p(dot), K, _p(f_norm), _p(bank_norm), _p(nn), N, K, k), "egk_topk_smallest")
     return nn
 
 
+def cosine_topk(f, bank, k, bank_inv_norm=None):
+    return nearest_prototypes(f, bank, k, "cosine", bank_inv_norm)
+
+
 @torch.no_grad()
-def scatter_add_rows_f64(x, label, bank, count):
-    _need_gpu(x, label, bank)
+def label_groups(label: torch.Tensor):
+    """Group the rows with label >= 0 by label: (order int32 [n], seg_ptr int32 [G+1], seg_label int64 [G]) with the node
+    ids of a group in ascending order (stable sort).  Host labels are grouped with numpy, device labels with a stable
+    device sort -- integer work either way."""
+    if label.device.type == "cpu":
+        import numpy as np
+        lb = label.numpy()
+        keep = np.nonzero(lb >= 0)[0]
+        order = keep[np.argsort(lb[keep], kind="stable")]
+        srt = lb[order]
+        starts = np.nonzero(np.concatenate([[True], srt[1:] != srt[:-1]]))[0] if srt.size else np.zeros(0, dtype=np.int64)
+        seg_ptr = np.concatenate([starts, [srt.size]]).astype(np.int32)
+        return (torch.from_numpy(order.astype(np.int32)), torch.from_numpy(seg_ptr),
+                torch.from_numpy(srt[starts].astype(np.int64)))
+    keep = torch.nonzero(label >= 0).reshape(-1)
+    srt, perm = torch.sort(label[keep], stable=True)
+    order = keep[perm]
+    seg_label, counts = torch.unique_consecutive(srt, return_counts=True)
+    seg_ptr = torch.zeros(seg_label.numel() + 1, dtype=torch.int32, device=label.device)
+    seg_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order.to(torch.int32), seg_ptr, seg_label
+
+
+@torch.no_grad()
+def scatter_add_rows_f64(x, label, bank, count, groups=None):
+    """bank[label[n]] += x[n] (fp64 bank, rows of one label summed in fp32 in node order first: what the reference's
+    per-batch ``scatter(..., reduce='sum')`` does, graphone.py:53), count[label[n]] += 1; rows with label < 0 are skipped.
+    Label-grouped segmented reduction, one wave per label: no atomics, bitwise reproducible.  ``groups`` =
+    ``label_groups(label)`` when the caller already has it (one grouping per batch, several task banks)."""
+    _need_gpu(x, bank)
     x = _c(x)
-    _ck(_lib.load().egk_scatter_add_rows_f64(_stream(), _p(x), _p(label.contiguous()), _p(bank), _p(count), x.shape[0],
-                                            x.shape[1], bank.shape[0], _dt(x)), "egk_scatter_add_rows_f64")
+    order, seg_ptr, seg_label = groups if groups is not None else label_groups(label)
+    dev = x.device
+    order, seg_ptr, seg_label = order.to(dev), seg_ptr.to(dev), seg_label.to(dev)
+    _ck(_lib.load().egk_segment_sum_rows_f64(_stream(), _p(x), _p(order), _p(seg_ptr), _p(seg_label), _p(bank), _p(count),
+                                            seg_label.numel(), x.shape[1], bank.shape[0], _dt(x)), "egk_segment_sum_rows_f64")
 
 
 # ---- profiling --------------------------------------------------------------------------------------------------

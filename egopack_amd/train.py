@@ -83,7 +83,10 @@ def build_feature_store(dsets, device):
     for ds in have[1:]:
         if ds.videos.keys() != ref.keys() or any(ds.videos[k].shape != ref[k].shape for k in ref):
             raise ValueError("the task datasets must index ONE feature table (same videos)")
-    return FeatureStore(ref, device=device)
+    from . import ops
+    # the table is stored in the activation type of the compute mode: f32 under compute=f32 (the reference-precision mode
+    # must not round its inputs to bf16 before the first contraction), bf16 otherwise
+    return FeatureStore(ref, device=device, dtype=ops.act_dtype())
 
 
 def resident_batches(loader, store, device, dtype=None):

@@ -22,13 +22,15 @@ def _logits(model, data, primary_task, other_tasks, graphone, late_fusion, needs
     feat_primary = primary_task.forward_features(feat)
     batch = getattr(data, "batch", None)
     if graphone is not None:
-        feat_secondary = {task.name: task.forward_features(feat) for task in other_tasks}
+        feat_secondary = {task.name: task.forward_features(feat, out_f32=True) for task in other_tasks}  # (f32 for the search)
         feat_secondary, *_ = graphone.interact(feat_secondary)
+        # post_features as the reference hands them to the meter (validate.py:43): [N, 1 + aux, H]
+        feat = torch.stack([feat_primary.float(), *[f.float() for f in feat_secondary.values()]], dim=1)
         if late_fusion:
             logits = primary_task.forward_logits(features=feat_primary, batch=data if needs_batch else batch,
                                                  aux_features=feat_secondary)
         else:
-            feat = torch.stack([feat_primary.float(), *[f.float() for f in feat_secondary.values()]], dim=1).max(1).values
+            feat = feat.max(1).values
             logits = primary_task.forward_logits(feat, data) if needs_batch else primary_task.forward_logits(feat)
     else:
         feat = feat_primary

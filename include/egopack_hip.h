@@ -197,11 +197,26 @@ int egk_cos_dist(egk_stream_t s, const float* dot, int64_t ldd, const float* f_i
 int egk_topk_smallest(egk_stream_t s, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv,
                       int64_t* nn, int32_t rows, int32_t K, int32_t k);
 
-/* ---- prototype bank accumulation  graphone.py:53,55 (scatter(..., reduce='sum') in float64
- * + bincount).  bank[label[n],:] += x[n,:] (fp64), count[label[n]] += 1.  Rows with label<0
- * are skipped. */
-int egk_scatter_add_rows_f64(egk_stream_t s, const void* x, const int64_t* label, double* bank, int64_t* count,
-                             int32_t rows, int32_t cols, int64_t n_labels, int32_t dtype);
+/* distance_func='l2' (graphONE.py:126-127,144-145: cdist / 4096): sq_norm[r] = ||x[r,:]||^2 and
+ * dist[n,j] = sqrt(max(f_sq[n] + b_sq[j] - 2 dot[n,j], 0)) / 4096; selection exactly as egk_topk_smallest. */
+int egk_row_sq_norm(egk_stream_t s, const void* x, float* sq_norm, int32_t rows, int32_t cols, int32_t dtype);
+int egk_topk_smallest_l2(egk_stream_t s, const float* dot, int64_t ldd, const float* f_sq, const float* b_sq,
+                         int64_t* nn, int32_t rows, int32_t K, int32_t k);
+
+/* Trainable prototypes (GraphONE(freeze=False), graphONE.py:47-49): gradient of the bank rows through the max
+ * aggregation.  dbank[p,:] += sum over edges e of prototype p (t_rowptr [K+1]; t_edge[e] = n*k + j with nn[n,j] == p,
+ * ascending inside a prototype) of (arg[n,:] == j ? dm[n,:] : 0).  One wave per prototype, fixed order, no atomics. */
+int egk_gather_max_bank_grad(egk_stream_t s, const void* dm, const uint8_t* arg, const int32_t* t_rowptr,
+                             const int32_t* t_edge, float* dbank, int32_t K, int32_t cols, int32_t k, int32_t dtype);
+
+/* ---- prototype bank accumulation  graphone.py:53,55 (scatter(..., reduce='sum') added to a float64 bank
+ * + bincount).  The labelled rows come grouped by label: order[seg_ptr[g] .. seg_ptr[g+1]) are the node ids of
+ * group g in ascending node order, seg_label[g] its label (distinct per call; groups with a label outside
+ * [0, n_labels) are skipped).  bank[seg_label[g],:] += (double)(fp32 sum of x[order[..],:] in node order),
+ * count[seg_label[g]] += group size.  No atomics: bitwise reproducible. */
+int egk_segment_sum_rows_f64(egk_stream_t s, const void* x, const int32_t* order, const int32_t* seg_ptr,
+                             const int64_t* seg_label, double* bank, int64_t* count, int32_t n_seg, int32_t cols,
+                             int64_t n_labels, int32_t dtype);
 
 /* ---- losses ---------------------------------------------------------------------------
  * nn.CrossEntropyLoss(reduction='none', ignore_index=-1[, label_smoothing]) criterion/wrapper.py:67-82,
@@ -215,6 +230,14 @@ int egk_ce_bwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y
 int egk_bce_fwd(egk_stream_t s, const float* logits, const int64_t* y, float* loss, int32_t n);
 int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const float* gloss, void* dlogits, int32_t n,
                 int32_t dtype);
+
+/* OSCCTask.compute_loss 'bce' / 'focal' (models/tasks/oscc.py:91-96): elementwise sigmoid losses of [rows, C] logits against
+ * one_hot(y, C).float(), reduction 'none'.  kind 0 = F.binary_cross_entropy_with_logits; kind 1 =
+ * torchvision.ops.sigmoid_focal_loss(alpha, gamma) (alpha < 0: unweighted).  y must hold class ids in [0, C). */
+int egk_onehot_sigmoid_loss_fwd(egk_stream_t s, const float* logits, const int64_t* y, float* loss, int32_t rows, int32_t C,
+                                int32_t kind, float alpha, float gamma);
+int egk_onehot_sigmoid_loss_bwd(egk_stream_t s, const float* logits, const int64_t* y, const float* gloss, void* dlogits,
+                                int32_t rows, int32_t C, int32_t kind, float alpha, float gamma, int32_t dtype);
 
 /* Activation element types.  Every entry point with a trailing ``dtype`` argument reads / writes its
  * [rows, cols] activation (and activation-gradient) matrices as EGK_F32 or EGK_BF16; all arithmetic,

@@ -66,6 +66,10 @@ def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda"):
         total, _ = step.train_step(batches)  # eager for the first steps, then the captured step
         it += 1
     logger.info("epoch %d: %d iterations, last objective %.4f", epoch, it, float(total))
+    lc = getattr(step, "loop_counts", None)
+    if lc is not None:  # how many steps replayed the captured graph and how many ran eagerly (shape changes, warm-up)
+        logger.info("epoch %d: %d steps replayed the captured step, %d ran eagerly", epoch, lc["replayed"], lc["eager"])
+        step.loop_counts = {"replayed": 0, "eager": 0}
     return it
 
 

@@ -47,6 +47,10 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda", store=No
         it += 1
     logger.info("epoch %d: %d iterations, train loss %s", epoch, it,
                 {t: round(float(sums[t]) / max(counts[t], 1), 4) for t in order if counts[t]})
+    lc = getattr(step, "loop_counts", None)
+    if lc is not None:  # how many steps replayed the captured graph and how many ran eagerly (shape changes, warm-up)
+        logger.info("epoch %d: %d steps replayed the captured step, %d ran eagerly", epoch, lc["replayed"], lc["eager"])
+        step.loop_counts = {"replayed": 0, "eager": 0}
     return it
 
 

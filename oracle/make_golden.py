@@ -383,6 +383,43 @@ def golden_egopack_train():
                            "loss_vectors": {"oscc": meters[1].values}})
 
 
+def golden_variants():
+    """Variants of the cited functions beside the configured ones: GraphONE distance_func='l2' (graphONE.py:126-127,
+    144-145) and trainable prototypes freeze=False (:47-49), OSCC loss_func='bce' with its gradients (oscc.py:91-93).
+    ('focal' needs torchvision.ops.sigmoid_focal_loss: absent package, restated in oracle/path.py, parity unpinned.)"""
+    g = torch.Generator().manual_seed(909)
+    torch.manual_seed(909)
+    banks = {t: torch.randn(K_PROTO, H, generator=g) for t in ("ar", "lta", "pnr")}
+    N = 14
+    out = {"banks": banks, "k": KG, "depth": 2}
+    for name, kw in (("l2", dict(distance_func="l2", freeze=True)), ("trainable", dict(distance_func="cosine", freeze=False)),
+                     ("l2_trainable", dict(distance_func="l2", freeze=False))):
+        m = GraphONE({k: v.clone() for k, v in banks.items()}, features_size=H, hidden_size=H, k=KG, depth=2,
+                     residual=True, dropout=0, output_dropout=0, output_projection=True, **kw)
+        randomize_norm_affine(m, g)
+        feats = {t: torch.randn(N, H, generator=g, requires_grad=True) for t in ("ar", "lta", "pnr")}
+        res, closest = m.interact(feats)
+        w = {t: torch.randn(N, H, generator=g) for t in feats}
+        sum((res[t] * w[t]).sum() for t in feats).backward()
+        out[name] = {"kw": kw, "sd": sd_of(m), "features": {t: f.detach() for t, f in feats.items()}, "w": w,
+                     "out": {t: r.detach() for t, r in res.items()},
+                     "closest": {t: [c.clone() for c in cs] for t, cs in closest.items()},
+                     "grad_features": {t: f.grad.clone() for t, f in feats.items()}, "grads": grads_of(m)}
+    Nn, B = 12, 3
+    feat = torch.randn(Nn, H, generator=g)
+    batch = torch.arange(B).repeat_interleave(Nn // B)
+    yb = torch.randint(0, 2, (B,), generator=g)
+    t = OSCCTask(H, H, 0, 0, loss_func="bce")
+    randomize_norm_affine(t, g)
+    logits = t.forward_logits(t.forward_features(feat), batch)
+    loss = t.compute_loss(logits, yb)
+    wl = torch.randn(loss.shape, generator=g)
+    (loss * wl).sum().backward()
+    out["oscc_bce"] = {"sd": sd_of(t), "feat": feat, "batch": batch, "y": yb, "logits": logits.detach(), "loss": loss.detach(),
+                       "w": wl, "grads": grads_of(t)}
+    save("variants", out)
+
+
 if __name__ == "__main__":
     golden_trn()
     golden_graph()
@@ -392,3 +429,4 @@ if __name__ == "__main__":
     golden_edges_and_loader()
     golden_mtl_train()
     golden_egopack_train()
+    golden_variants()

@@ -353,18 +353,87 @@ def test_topk_tie_breaks_to_lower_index(ops):
     assert nn.tolist() == [[0, 1, 3]]
 
 
-def test_scatter_add_rows_f64(ops):
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("cols", [1024, 37])
+def test_scatter_add_rows_f64(ops, where, cols):
+    """Prototype accumulation (reference graphone.py:53): rows of one label summed in fp32 in node order (what the
+    reference's per-batch fp32 scatter does on the CPU), the sum added to the fp64 bank row -- BIT-EXACT against that
+    restatement, twice in a row (a second batch accumulates), with labels grouped on the host or on the device."""
     g = gen(41)
-    rows, cols, L = 200, 1024, 35
-    x = torch.randn(rows, cols, generator=g)
-    label = torch.randint(-1, L, (rows,), generator=g)
+    rows, L = 300, 35
     bank = torch.zeros(L, cols, dtype=torch.float64, device=DEV)
     count = torch.zeros(L, dtype=torch.int64, device=DEV)
-    ops.scatter_add_rows_f64(x.to(DEV), label.to(DEV), bank, count)
-    keep = label >= 0
-    ref = P.scatter_sum(x[keep].double(), label[keep], L)
-    torch.testing.assert_close(bank.cpu(), ref, rtol=1e-12, atol=1e-12)
-    assert torch.equal(count.cpu(), torch.bincount(label[keep], minlength=L))
+    ref = torch.zeros(L, cols, dtype=torch.float64)
+    ref_count = torch.zeros(L, dtype=torch.int64)
+    for it in range(2):
+        x = torch.randn(rows, cols, generator=g)
+        label = torch.randint(-1, L, (rows,), generator=g)
+        label[:40] = 7  # a heavy label: 40+ rows in one group
+        ops.scatter_add_rows_f64(x.to(DEV), label if where == "host" else label.to(DEV), bank, count)
+        keep = label >= 0
+        ref = ref + P.scatter_sum(x[keep], label[keep], L)  # fp64 + fp32, as graphone.py:53
+        ref_count += torch.bincount(label[keep], minlength=L)
+    assert torch.equal(bank.cpu(), ref)
+    assert torch.equal(count.cpu(), ref_count)
+
+
+def test_scatter_add_rows_f64_is_reproducible_and_handles_empty(ops):
+    g = gen(43)
+    x = torch.randn(500, 256, generator=g).to(DEV)
+    label = torch.randint(0, 9, (500,), generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        bank = torch.zeros(9, 256, dtype=torch.float64, device=DEV)
+        ops.scatter_add_rows_f64(x, label, bank, None)
+        outs.append(bank.clone())
+    assert torch.equal(outs[0], outs[1])
+    bank = torch.zeros(9, 256, dtype=torch.float64, device=DEV)
+    count = torch.zeros(9, dtype=torch.int64, device=DEV)
+    ops.scatter_add_rows_f64(x, torch.full((500,), -1, dtype=torch.int64), bank, count)  # nothing labelled
+    assert float(bank.abs().max()) == 0.0 and int(count.sum()) == 0
+
+
+@pytest.mark.parametrize("K,H,k", [(37, 32, 4), (600, 1024, 8)])
+def test_l2_topk_matches_cdist(ops, K, H, k):
+    """distance_func='l2' (reference graphONE.py:126-127: cdist / 4096, argsort): indices exact wherever the ranking gap
+    exceeds fp32 noise, and the selected distances are the k smallest everywhere."""
+    g = gen(K + k)
+    f, bank = torch.randn(50, H, generator=g), torch.randn(K, H, generator=g)
+    nn = ops.nearest_prototypes(f.to(DEV), bank.to(DEV), k, "l2").cpu()
+    _, closest = O.compute_edges(f, bank, k, "l2")
+    dist = torch.cdist(f.double(), bank.double()) / 4096
+    srt = dist.sort(dim=-1).values
+    gap = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values
+    safe = gap > 1e-8 * 4  # (distances are O(sqrt(2H)/4096) ~ 1e-2; fp32 noise on them ~1e-9)
+    assert safe.float().mean() > 0.9
+    assert torch.equal(nn[safe], closest[safe])
+    torch.testing.assert_close(torch.gather(dist, 1, nn), srt[:, :k], rtol=0, atol=1e-8)
+    with pytest.raises(ValueError):
+        ops.nearest_prototypes(f.to(DEV), bank.to(DEV), k, "manhattan")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gather_max_trainable_bank_gradient(ops, dt):
+    """GraphONE(freeze=False): the prototype rows receive, through the max aggregation, the gradient of every element
+    they won -- against torch autograd on the same values (fp64), exact selection."""
+    g = gen(77)
+    N, K, H, k = 70, 19, 260, 4
+    f = torch.randn(N, H, generator=g).to(dt)
+    bank = torch.randn(K, H, generator=g)
+    nn = torch.stack([torch.randperm(K, generator=g)[:k] for _ in range(N)])
+    dm = torch.randn(N, H, generator=g).to(dt)
+    fd, bd = f.to(DEV).requires_grad_(True), bank.to(DEV).requires_grad_(True)
+    m = ops.gather_max(fd, bd, nn.to(DEV))
+    m.backward(dm.to(DEV))
+    f64, b64 = f.double().requires_grad_(True), bank.double().requires_grad_(True)
+    cand = torch.cat([b64[nn], f64[:, None]], 1)  # prototype messages first, the self loop last; first maximum wins
+    ref, _ = cand.max(dim=1)
+    ref.backward(dm.double())
+    tol = dict(rtol=1e-6, atol=1e-6) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(m.detach().double().cpu(), ref.detach(), **(tol if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)))
+    torch.testing.assert_close(fd.grad.double().cpu(), f64.grad, **tol)
+    assert bd.grad.dtype == torch.float32
+    torch.testing.assert_close(bd.grad.double().cpu(), b64.grad, rtol=1e-5, atol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------------

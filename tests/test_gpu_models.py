@@ -502,3 +502,106 @@ def test_classifier_bank_equals_the_separate_classifiers(mode):
             for buf in (v["wp"], v["w16"], v["wg"]):
                 assert float(buf[pad].float().abs().max()) == 0.0
             assert float(v["b"][pad].abs().max()) == 0.0 and float(v["bg"][pad].abs().max()) == 0.0
+
+
+# ---- variants of the cited functions beside the configured ones (tests/golden/variants.pt, reference-generated) -------
+@pytest.mark.parametrize("name", ["l2", "trainable", "l2_trainable"])
+def test_graphone_variants_vs_reference(A, golden, name):
+    """GraphONE(distance_func='l2') (reference graphONE.py:126-127,144-145) and GraphONE(freeze=False) (:47-49) in exact-f32
+    mode: outputs, nearest-prototype indices (exact), feature / stage gradients and the prototype gradients."""
+    G = golden("variants")
+    c = G[name]
+    m = A.GraphONE({k: v.clone() for k, v in G["banks"].items()}, features_size=32, hidden_size=32, k=G["k"], depth=G["depth"],
+                   residual=True, dropout=0, output_dropout=0, output_projection=True, **c["kw"])
+    m.load_state_dict(c["sd"])
+    m = m.to(DEV)
+    feats = {t: f.clone().to(DEV).requires_grad_(True) for t, f in c["features"].items()}
+    with A.ops.compute_mode("f32"):
+        out, closest = m.interact(feats)
+        sum((out[t] * c["w"][t].to(DEV)).sum() for t in feats).backward()
+    for t in feats:
+        for a, b in zip(closest[t], c["closest"][t]):
+            assert torch.equal(a.cpu(), b)
+        torch.testing.assert_close(out[t].detach().float().cpu(), c["out"][t], **F32_TOL)
+        torch.testing.assert_close(feats[t].grad.float().cpu(), c["grad_features"][t], rtol=2e-3, atol=2e-3)
+    named = dict(m.named_parameters())
+    for k, g in c["grads"].items():
+        assert named[k].grad is not None, k
+        torch.testing.assert_close(named[k].grad.float().cpu(), g, rtol=2e-3, atol=2e-3, msg=lambda s: f"{k}: {s}")
+    trainable_banks = not c["kw"]["freeze"]
+    assert all(p.requires_grad == trainable_banks for n, p in m.named_parameters() if n.startswith("embeddings."))
+
+
+def test_trainable_prototypes_move_under_flat_adam(A, golden):
+    """freeze=False end to end: the prototypes are optimizer parameters (main_egopack.py:323 passes graphone.parameters());
+    one FlatAdam step equals torch.optim.Adam on the reference-generated gradients."""
+    G = golden("variants")
+    c = G["trainable"]
+    m = A.GraphONE({k: v.clone() for k, v in G["banks"].items()}, features_size=32, hidden_size=32, k=G["k"], depth=G["depth"],
+                   residual=True, **c["kw"])
+    m.load_state_dict(c["sd"])
+    m = m.to(DEV)
+    opt = A.FlatAdam(m.parameters(), lr=1e-2, weight_decay=1e-3)
+    feats = {t: f.clone().to(DEV) for t, f in c["features"].items()}
+    with A.ops.compute_mode("f32"):
+        out, _ = m.interact(feats)
+        sum((out[t] * c["w"][t].to(DEV)).sum() for t in feats).backward()
+        opt.step()
+    ref = {k: v.clone().requires_grad_(True) for k, v in c["sd"].items()}
+    for k, g in c["grads"].items():
+        ref[k].grad = g.clone()
+    topt = torch.optim.Adam([ref[k] for k in c["grads"]], lr=1e-2, weight_decay=1e-3)
+    topt.step()
+    cur = m.state_dict()
+    for k in c["grads"]:
+        torch.testing.assert_close(cur[k].cpu(), ref[k].detach(), rtol=0, atol=2e-4, msg=lambda s: f"{k}: {s}")
+    assert not torch.equal(cur["embeddings.ar.weight"].cpu(), c["sd"]["embeddings.ar.weight"])
+
+
+def test_oscc_bce_vs_reference_and_focal_vs_oracle(A, golden):
+    """OSCCTask.compute_loss 'bce' against the reference's own outputs and gradients (oscc.py:91-93) and 'focal'
+    (oscc.py:94-96: torchvision.ops.sigmoid_focal_loss, absent package -> restated in the oracle) against the oracle."""
+    c = golden("variants")["oscc_bce"]
+    for kind in ("bce", "focal"):
+        t = A.OSCCTask(32, 32, 0, 0, loss_func=kind)
+        t.load_state_dict(c["sd"])
+        t = t.to(DEV).eval()
+        with A.ops.compute_mode("f32"):
+            logits = t.forward_logits(t.forward_features(c["feat"].to(DEV)), c["batch"].to(DEV))
+            loss = t.compute_loss(logits, c["y"].to(DEV))
+            (loss * c["w"].to(DEV)).sum().backward()
+        if kind == "bce":
+            want_loss, want_grads = c["loss"], c["grads"]
+        else:
+            sd = {k: v.clone().requires_grad_(True) for k, v in c["sd"].items()}
+            lo = O.oscc_loss(O.oscc_logits(sd, O.projection_features(sd, c["feat"]), c["batch"]), c["y"], "focal")
+            (lo * c["w"]).sum().backward()
+            want_loss, want_grads = lo.detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}
+        assert loss.shape == want_loss.shape == (3, 2)
+        torch.testing.assert_close(loss.detach().cpu(), want_loss, **F32_TOL)
+        named = dict(t.named_parameters())
+        for k, g in want_grads.items():
+            torch.testing.assert_close(named[k].grad.float().cpu(), g, rtol=2e-3, atol=2e-4, msg=lambda s: f"{kind} {k}: {s}")
+
+
+@pytest.mark.parametrize("gamma,alpha", [(2.0, 0.5), (1.5, 0.25), (2.0, -1.0)])
+def test_onehot_sigmoid_focal_kernel_vs_autograd(A, gamma, alpha):
+    """The focal kernel pair over a range of logits (saturated ones included) against torch autograd of the published
+    formula in fp64."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(40, 2, generator=g) * 3, torch.tensor([[30., -30.], [-30., 30.], [0., 0.]])])
+    y = torch.randint(0, 2, (x.shape[0],), generator=g)
+    w = torch.randn(x.shape, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    loss = A.ops.onehot_sigmoid_focal_loss(xd, y.to(DEV), alpha, gamma)
+    (loss * w.to(DEV)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    t = torch.nn.functional.one_hot(y, 2).double()
+    p = torch.sigmoid(x64)
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(x64, t, reduction="none")
+    ref = ce * (1 - (p * t + (1 - p) * (1 - t))) ** gamma
+    if alpha >= 0:
+        ref = (alpha * t + (1 - alpha) * (1 - t)) * ref
+    (ref * w.double()).sum().backward()
+    torch.testing.assert_close(loss.detach().double().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xd.grad.double().cpu(), x64.grad, rtol=1e-4, atol=1e-6)

@@ -206,3 +206,65 @@ def test_batch_loader_worker_processes_deliver_the_in_process_batches_in_order()
         del it
     finally:
         par.close()
+
+
+# ---- static-shape batches of the captured training step (engine.train_step) -------------------------------------------
+def _lta_batch(seed, B=6, T=12):
+    ds = D.SyntheticTaskDataset("lta", B, T, 3, 8, (7, 11), k=1, seed=seed)
+    return D.collate([ds[i] for i in range(B)])
+
+
+def test_merged_csr_is_the_concatenation_of_the_task_csrs():
+    """merge_batches builds the merged CSR from the tasks' CSR arrays with offsets: identical, entry for entry, to
+    build_csr over the merged edge list (stable sorts), heavy rows and modes included."""
+    batches = []
+    for t, T, seed in (("ar", 9, 1), ("lta", 40, 2), ("pnr", 16, 3), ("lta", 12, 4)):
+        ds = D.SyntheticTaskDataset(t, 4, T, 3, 8, (7, 11), k=1, seed=seed)
+        batches.append(D.collate([ds[i] for i in range(4)]))
+    m = D.merge_batches(batches)
+    ref = D.build_csr(m.edge_index, m.pos.shape[0])
+    for f in ("rowptr", "col", "t_rowptr", "t_col", "t_wgt", "heavy", "t_heavy"):
+        a, b = getattr(m.graph, f), getattr(ref, f)
+        assert a.dtype == b.dtype and torch.equal(a, b), f
+    assert (m.graph.num_nodes, m.graph.heavy_mode, m.graph.t_heavy_mode) == (ref.num_nodes, ref.heavy_mode, ref.t_heavy_mode)
+    assert m.graph.t_heavy.numel() > 0  # the T = 40 LTA fan-out rows are listed
+
+
+def test_signature_is_stable_across_lta_batches_with_different_edge_counts():
+    """the LTA edge count moves with the labels; the replay signature compares edge CAPACITIES and ignores the
+    structure fingerprints, so fresh LTA batches keep replaying the captured step."""
+    from egopack_amd import engine as E
+    a, b = _lta_batch(11), _lta_batch(12)
+    for x, k in ((a, 101), (b, 202)):
+        x._struct_key = k
+    # force different edge counts (drop one band edge of b) while staying in one capacity bucket
+    b.edge_index = b.edge_index[:, 1:]
+    b.graph = D.build_csr(b.edge_index, b.pos.shape[0])
+    assert a.edge_index.shape != b.edge_index.shape
+    assert E.batch_signature({"lta": a}) == E.batch_signature({"lta": b})
+    c = _lta_batch(13, B=5)
+    assert E.batch_signature({"lta": a}) != E.batch_signature({"lta": c})  # another node count is another signature
+
+
+def test_copy_batch_values_tracks_the_structure_fingerprint_A_B_A():
+    """sequence A, B, A through one set of static buffers -- the third copy must restore A's structure (the
+    destination's fingerprint follows every full copy), and the padded edge arrays receive the first E entries."""
+    from egopack_amd import engine as E
+    A_, B_ = _lta_batch(21), _lta_batch(22)
+    B_.edge_index = B_.edge_index[:, 2:]
+    B_.graph = D.build_csr(B_.edge_index, B_.pos.shape[0])
+    A_._struct_key, B_._struct_key = 7, 9
+    static = E._clone_batch(A_, pad_edges=True)
+    cap = E._edge_capacity(A_.edge_index.shape[1])
+    assert static.edge_index.shape == (2, cap) and static.graph.col.shape == (cap,)
+    static._struct_key = A_._struct_key
+    for src in (B_, A_, A_, B_):
+        E.copy_batch_values({"lta": static}, None, {"lta": src}, None)
+        e = src.edge_index.shape[1]
+        assert static._struct_key == src._struct_key
+        assert torch.equal(static.edge_index[:, :e], src.edge_index)
+        assert torch.equal(static.graph.rowptr, src.graph.rowptr) and torch.equal(static.graph.col[:e], src.graph.col)
+        assert torch.equal(static.graph.t_wgt[:e], src.graph.t_wgt) and torch.equal(static.y, src.y)
+    unknown = _lta_batch(23)  # no fingerprint: everything is copied and the destination forgets its own
+    E.copy_batch_values({"lta": static}, None, {"lta": unknown}, None)
+    assert static._struct_key == 0 and torch.equal(static.graph.rowptr, unknown.graph.rowptr)

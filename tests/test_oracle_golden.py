@@ -196,3 +196,49 @@ def test_egopack_train_two_iterations(golden):
     # frozen banks unchanged
     for t in ("ar", "lta", "pnr"):
         assert torch.equal(G["after"]["graphone"][f"embeddings.{t}.weight"], G["before"]["graphone"][f"embeddings.{t}.weight"])
+
+
+# ---- variants of the cited functions beside the configured ones (tests/golden/variants.pt) ---------------------------
+@pytest.mark.parametrize("name", ["l2", "trainable", "l2_trainable"])
+def test_graphone_variants(golden, name):
+    """distance_func='l2' (graphONE.py:126-127) and trainable prototypes (freeze=False, :47-49): outputs, exact
+    nearest-prototype indices, feature / stage gradients and -- when trainable -- the prototype gradients."""
+    G = golden("variants")
+    c = G[name]
+    free = not c["kw"]["freeze"]
+    sd = {k: (v.clone().requires_grad_(True) if (not k.startswith("embeddings.") or free) else v.clone()) for k, v in c["sd"].items()}
+    feats = {t: f.clone().requires_grad_(True) for t, f in c["features"].items()}
+    out, closest = O.graphone_interact(sd, feats, G["k"], G["depth"], True, c["kw"]["distance_func"])
+    for t in feats:
+        torch.testing.assert_close(out[t], c["out"][t], **TOL)
+        for a, b in zip(closest[t], c["closest"][t]):
+            assert torch.equal(a, b)
+    sum((out[t] * c["w"][t]).sum() for t in feats).backward()
+    for t in feats:
+        torch.testing.assert_close(feats[t].grad, c["grad_features"][t], **TOL)
+    assert any(k.startswith("embeddings.") for k in c["grads"]) == free
+    for k, g in c["grads"].items():
+        torch.testing.assert_close(sd[k].grad, g, rtol=1e-4, atol=1e-5)
+
+
+def test_oscc_bce_gradients(golden):
+    c = golden("variants")["oscc_bce"]
+    sd = leafify(c["sd"])
+    logits = O.oscc_logits(sd, O.projection_features(sd, c["feat"]), c["batch"])
+    loss = O.oscc_loss(logits, c["y"], "bce")
+    torch.testing.assert_close(loss, c["loss"], **TOL)
+    (loss * c["w"]).sum().backward()
+    for k, g in c["grads"].items():
+        torch.testing.assert_close(sd[k].grad, g, rtol=1e-4, atol=1e-5)
+
+
+def test_focal_loss_known_answers():
+    """torchvision.ops.sigmoid_focal_loss(alpha=0.5, gamma=2) (absent package: restated, parity unpinned) on hand-
+    computable points: x = 0 -> p = 1/2: 0.5 * (1/2)^2 * ln 2 for either class; a confident correct logit gives ~0, a
+    confident wrong one ~alpha * |x|."""
+    import math
+    y = torch.tensor([1, 0])
+    l = O.oscc_loss(torch.zeros(2, 2), y, "focal")
+    assert torch.allclose(l, torch.full((2, 2), 0.5 * 0.25 * math.log(2.0)), atol=1e-7)
+    l = O.oscc_loss(torch.tensor([[-20.0, 20.0], [-20.0, 20.0]]), y, "focal")  # row 0 right on both columns, row 1 wrong
+    assert l[0].abs().max() < 1e-12 and torch.allclose(l[1], torch.full((2,), 0.5 * 20.0), rtol=1e-6)
