@@ -105,11 +105,12 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(sds, names, dev, weights, sample_batch=16, budget_s=20.0):
+def cpu_baseline(sds, names, dev, weights, sample_batch=None, budget_s=20.0):
     """The CPU oracle (oracle/path.py, checker code) timed on the host cores on a BOUNDED sample of the
-    same workload: the same step (fp32, forward + backward + torch.optim.Adam, 3 tasks, same T and
-    model) with ``sample_batch`` of the B sequences per task, as many steps as fit the budget (>= 1).
-    Throughput is sequences of the sample per second."""
+    same workload: the same step (fp32, forward + backward + torch.optim.Adam, same tasks, same T and
+    model) on the FULL batch of B sequences per task (graph-LayerNorm couples the samples of a batch:
+    a step on fewer sequences is a different computation), as many steps as fit the budget (>= 1, at
+    most 20).  ``sample_batch`` < B restricts it to the first sequences (development only)."""
     from oracle import path as O
     from oracle import pyg_ops as P
     cores = min(usable_cores(), 64)
@@ -120,7 +121,7 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=16, budget_s=20.0):
     for t, d in dev.items():
         B, n = d.num_graphs, d.pos.shape[0]
         T = n // B
-        b = min(sample_batch, B)
+        b = B if sample_batch is None else min(sample_batch, B)
         rows = b * T  # the first b sequences (collation keeps sequences contiguous)
         ei = d.edge_index.cpu()
         ei = ei[:, (ei[0] < rows) & (ei[1] < rows)]
@@ -148,10 +149,11 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=16, budget_s=20.0):
         dt = (time.perf_counter() - t0) / n
     else:
         dt = first
-    b0 = batches["ar"]
+    t0_ = next(iter(batches))
+    b0 = batches[t0_]
     return {"value": seqs / dt, "unit": "clip-seqs/s", "cores": cores, "kind": "port",
             "sample": f"{n or 1} step(s){' after 1 warm-up' if n else ' (the first one)'} of the same step on "
-                      f"{b0.num_graphs} of the {dev['ar'].num_graphs} sequences per task (3 tasks x T="
+                      f"{b0.num_graphs} of the {dev[t0_].num_graphs} sequences per task ({len(batches)} task(s) x T="
                       f"{b0.x.shape[0] // b0.num_graphs}), fp32 torch CPU oracle, {cores} threads, {dt * 1e3:.0f} ms/step"}
 
 
@@ -241,7 +243,7 @@ def roofline(ops, step_fn, compute, n_steps=3):
     return out, table
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -271,8 +273,11 @@ def main():
     ap.add_argument("--no-wgrad-streams", action="store_true", help="keep the weight-gradient launches on the backward stream")
     ap.add_argument("--one-call-backward", action="store_true",
                     help="one backward() call over all head streams instead of one per head inside its stream context (A/B)")
-    ap.add_argument("--grad-compress", choices=["bf16", "none"], default="bf16",
-                    help="element type of the gradient all-reduce when --gpus > 1")
+    ap.add_argument("--grad-compress", choices=["bf16", "none"], default="none",
+                    help="element type of the gradient all-reduce when --gpus > 1: 'none' = the f32 exchange the entry "
+                         "points train with (main_temporal.py grad_compress default); 'bf16' = the half-size variant")
+    ap.add_argument("--strict-capture", action="store_true",
+                    help="fail instead of falling back (staged graphs -> one-piece graph -> eager) when a capture fails")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
     ap.add_argument("--force-wgrad-streams", action="store_true", help="A/B: weight gradients on a side stream also for single-task steps")
@@ -287,53 +292,60 @@ def main():
                     help="A/B: sum the listed heavy CSR rows with the split launches even when they are short enough for the launch itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32-leg", action="store_true",
+                    help="skip the short reference-precision (--compute f32) measurement added to the JSON line at N = 1")
+    ap.add_argument("--f32-steps", type=int, default=10, help="timed steps of the reference-precision leg")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
-    args = ap.parse_args()
-    if args.hw_queues:  # opt-in (DESIGN.md section 5): must be set before anything initialises the device
-        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+    return ap.parse_args(argv)
 
-    lib_path = REPO / "egopack_amd" / "libegopack_hip.so"
-    if not lib_path.exists():  # a checkout without the (git-ignored) library: compile it in-tree, once, rank 0 first
-        from egopack_amd import build as _build
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            _build.build_library(force=False, verbose=False)
-        else:
-            while not lib_path.exists():
-                time.sleep(1.0)
-            time.sleep(2.0)
+
+def spawn_plan(n: int, argv, port: int = None):
+    """Command that starts ``n`` ranks of this script on this node -- exactly what the driver runs for N > 1:
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>``."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """``python bench.py --gpus N`` without a torchrun environment: start N ranks as CHILD processes (this parent has not
+    touched the GPU and never does; nothing is exec'ed), relay their output, keep rank 0's JSON line as the last line of
+    stdout, and return non-zero if any rank failed."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC only on this pool: RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(n, 1))))
+    proc = subprocess.run(spawn_plan(n, argv), env=env, stdout=subprocess.PIPE, text=True)
+    lines = proc.stdout.splitlines()
+    result = next((ln for ln in reversed(lines) if ln.startswith("{") and '"metric"' in ln), None)
+    for ln in lines:
+        if ln is not result:
+            print(ln)
+    if result is not None:
+        print(result, flush=True)
+    if proc.returncode != 0 or result is None:
+        print(f"[bench] {n}-rank run failed (exit code {proc.returncode}, result line {'present' if result else 'missing'})",
+              file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    return 0
+
+
+def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_cpu=True):
+    """Build the workload in ``args.compute`` mode, capture / warm up, time ``steps`` steps (barrier + synchronize on both
+    sides, MAX over ranks) and take the roofline / CPU-baseline legs.  Returns a dict of results."""
     from egopack_amd import dist as edist
-    rank, local_rank, world = edist.init_from_env()
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a ROCm GPU: the product path has no CPU fallback")
-    if rank != 0:  # only rank 0 reports: nothing else (RCCL's C-level stdout banner included) may reach the shared stdout
-        sys.stdout.flush()
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-
     from egopack_amd import engine, ops
     from egopack_amd.optim import FlatAdam
     ops.set_compute(args.compute)
     ops.manual_seed(1000 + rank)  # dropout streams differ per rank
-    if args.gemm_knob is not None:
-        from egopack_amd import _lib
-        _lib.load().egk_gemm_set_pipeline(args.gemm_knob)
-    for kv in filter(None, args.egk_tune.split(",")):
-        from egopack_amd import _lib
-        k, v = kv.split("=")
-        _lib.load().egk_tune(int(k), int(v))
-
-    if args.ln_reduce_inline:
-        ops._wgrad_ln["side"] = False
-    if args.last_wgrad_side:
-        ops._last_wgrad["inline"] = False
-    if args.csr_split_heavy:
-        from egopack_amd import data as _D
-        _D.HEAVY_IN_LAUNCH_DEGREE = 0
     model, tasks, crit, weights, dev, merged = build_workload(args, rank, device)
     names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
     sds = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("mtl", "ar", "mtl4"):
+    if rank == 0 and world == 1 and want_cpu and not args.no_cpu_baseline and args.workload in ("mtl", "ar", "mtl4"):
         sds = {"temporal_graph": {k: v.clone() for k, v in model.state_dict().items()}}
         for t, n in names.items():
             sds[n] = {k: v.clone() for k, v in tasks[t].state_dict().items()}
@@ -348,9 +360,10 @@ def main():
     params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
     sync = edist.GradSync(world, compress=args.grad_compress) if world > 1 else None
     if world == 1 and args.exchange_dry_run > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        if not torch.distributed.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         sync = edist.GradSync(args.exchange_dry_run, compress=args.grad_compress)
     fused_merged = None if args.no_fused_backbone else merged
     if args.workload == "egopack_oscc":
@@ -368,14 +381,10 @@ def main():
             step.wgrad_side_streams = False
         if args.force_wgrad_streams:
             step.wgrad_side_streams = True
-
-        def eager_step():
-            step.step(dev, fused_merged)
     else:
         opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)  # defaults.yaml:17-20
         step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=not args.no_fused_backbone, sync=sync,
                               parallel_heads=not args.serial_heads)
-
         if args.no_wgrad_streams:
             step.wgrad_side_streams = False
         step.staged = {"auto": None, "on": True, "off": False}[args.staged]
@@ -388,8 +397,8 @@ def main():
         if args.force_wgrad_streams:
             step.wgrad_side_streams = True
 
-        def eager_step():
-            step.step(dev, fused_merged)
+    def eager_step():
+        step.step(dev, fused_merged)
 
     if args.feature_store and fused_merged is not None and torch.is_tensor(fused_merged.x):
         from egopack_amd import feature_store as FS
@@ -401,25 +410,44 @@ def main():
         idx = torch.randint(0, args.feature_store, buf.shape[:-1], generator=gen).to(device)
         step.input_hook = lambda: store.gather(idx, out=buf)
 
+    # which execution mode actually ran is part of the result (config.capture): 'staged graphs' (three hipGraphs with the
+    # gradient exchange between them), 'one graph', or 'eager'; a failed capture is reported, never silent
+    capture, fallbacks = "eager", []
+
+    def all_ranks_ok(ok: bool) -> bool:
+        """A capture that fails on ONE rank must send EVERY rank to the next mode: the modes issue different collectives."""
+        if world <= 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], device=device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item())
+
     if args.mode == "graph":
-        # capture, with fallbacks that keep the measurement alive if a capture path fails on a configuration that could
-        # not be tried on the one-GPU development box (several ranks): staged graphs -> one-piece graph -> eager
         run = None
         for attempt in ("as configured", "one-piece backward", "eager"):
+            err = None
             try:
                 if attempt == "one-piece backward":
                     step.staged = False
                 if attempt == "eager":
-                    args.mode = "eager"
                     eager_step()
-                    run = eager_step
+                    run, capture = eager_step, "eager"
                 else:
                     step.capture(dev, fused_merged, warmup=2)
                     run = step.replay
-                break
+                    capture = "staged graphs" if isinstance(step._graph, list) else "one graph"
             except Exception as e:  # noqa: BLE001
+                err = e
+                fallbacks.append(f"{attempt}: {e!r}")
                 print(f"[bench] capture ({attempt}) failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
                 torch.cuda.synchronize()
+                if args.strict_capture or attempt == "eager":
+                    raise
+            if all_ranks_ok(err is None):
+                break
+            if err is None:
+                fallbacks.append(f"{attempt}: failed on another rank")
+            run = None
         if run is None:
             raise RuntimeError("bench.py: no execution mode worked")
     else:
@@ -430,24 +458,23 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         run()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         run()
     torch.cuda.synchronize()
     barrier()
-    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    ms = (time.perf_counter() - t0) * 1e3 / steps
     if world > 1:
         t = torch.tensor([ms], device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = t.item()
 
-    seqs_per_step = world * len(WORKLOADS[args.workload][0]) * args.batch
     rl, table = (None, {})
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and want_roofline and not args.no_roofline:
         try:
             # per-kernel durations are taken with every launch on ONE stream (heads, aux tasks and weight gradients
             # serialised), the way rocprofv3 --kernel-trace times them: the committed profile must agree with them
@@ -472,9 +499,81 @@ def main():
             cb = cpu_baseline(sds, names, dev, weights)
         except Exception as e:
             cb = {"error": repr(e)}
+    return {"ms": ms, "roofline": rl, "table": table, "cpu_baseline": cb, "n_params": opt.flat_p.numel(), "capture": capture,
+            "fallbacks": fallbacks, "mode": "eager" if capture == "eager" else "graph"}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # asked for N GPUs without a launcher: start the N ranks ourselves, before anything initialises the device here
+        sys.exit(spawn_ranks(args.gpus, argv))
+    if args.hw_queues:  # opt-in (DESIGN.md section 5): must be set before anything initialises the device
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+
+    lib_path = REPO / "egopack_amd" / "libegopack_hip.so"
+    if not lib_path.exists():  # a checkout without the (git-ignored) library: compile it in-tree, once, rank 0 first
+        from egopack_amd import build as _build
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            _build.build_library(force=False, verbose=False)
+        else:
+            while not lib_path.exists():
+                time.sleep(1.0)
+            time.sleep(2.0)
+    from egopack_amd import dist as edist
+    rank, local_rank, world = edist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    if rank != 0:  # only rank 0 reports: nothing else (RCCL's C-level stdout banner included) may reach the shared stdout
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    if args.gemm_knob is not None:
+        from egopack_amd import _lib
+        _lib.load().egk_gemm_set_pipeline(args.gemm_knob)
+    for kv in filter(None, args.egk_tune.split(",")):
+        from egopack_amd import _lib
+        k, v = kv.split("=")
+        _lib.load().egk_tune(int(k), int(v))
+    from egopack_amd import ops
+    if args.ln_reduce_inline:
+        ops._wgrad_ln["side"] = False
+    if args.last_wgrad_side:
+        ops._last_wgrad["inline"] = False
+    if args.csr_split_heavy:
+        from egopack_amd import data as _D
+        _D.HEAVY_IN_LAUNCH_DEGREE = 0
+
+    res = measure(args, rank, world, device, args.steps, args.warmup)
+    ms = res["ms"]
+    seqs_per_step = world * len(WORKLOADS[args.workload][0]) * args.batch
+
+    # reference-precision leg (N = 1, rank 0): the same step in --compute f32 (exact-f32 MFMA, f32 activations / weights --
+    # what the reference computes in), a short run, so the record carries a figure at the reference's own precision
+    f32_leg = None
+    if rank == 0 and world == 1 and args.compute != "f32" and not args.no_f32_leg and args.mode == "graph":
+        try:
+            import copy
+            a32 = copy.copy(args)
+            a32.compute = "f32"
+            r32 = measure(a32, rank, world, device, args.f32_steps, 3, want_roofline=not args.no_roofline, want_cpu=False)
+            f32_leg = {"ms_per_step": r32["ms"], "value": seqs_per_step / (r32["ms"] * 1e-3), "unit": "clip-seqs/s",
+                       "steps": args.f32_steps, "capture": r32["capture"],
+                       "roofline": None if not r32["roofline"] or "error" in r32["roofline"] else
+                       {k: r32["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us",
+                                                         "launches_per_step", "step") if k in r32["roofline"]}}
+        except Exception as e:  # noqa: BLE001
+            f32_leg = {"error": repr(e)}
+        finally:
+            ops.set_compute(args.compute)
 
     if rank == 0:
-        n_params = opt.flat_p.numel()
+        rl, cb = res["roofline"], res["cpu_baseline"]
         out = {
             "metric": ("clip-seqs/sec training, AR+LTA+PNR multi-task" if args.workload == "mtl"
                        else f"clip-seqs/sec training, {args.workload}"), "value": seqs_per_step / (ms * 1e-3),
@@ -483,19 +582,20 @@ def main():
             "dtype": "f32" if args.compute == "f32" else "bf16", "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.workload][1]}: per GPU B={args.batch} seqs/task x T={args.T} nodes, "
                                    f"3x1536-d Omnivore-shaped features, H={args.hidden}, TRN hidden {args.trn_hidden} "
-                                   f"(dropout {args.dropout}), depth 3, k=1, Adam; {args.mode} mode, "
+                                   f"(dropout {args.dropout}), depth 3, k=1, Adam; {res['mode']} mode, "
                                    f"{'fused' if not args.no_fused_backbone else 'per-task'} backbone pass",
                        "global_batch": seqs_per_step, "nodes_per_step": seqs_per_step * args.T,
-                       "parallelism": f"dp{world}", "trainable_params": n_params,
-                       "grad_allreduce": (args.grad_compress if world > 1 else None),
+                       "parallelism": f"dp{world}", "trainable_params": res["n_params"],
+                       "grad_allreduce": (("bf16" if args.grad_compress == "bf16" else "f32") if world > 1 else None),
+                       "capture": res["capture"], "capture_fallbacks": res["fallbacks"],
                        "input": (f"assembled in the step by egk_gather_rows from a resident {args.feature_store}-row feature store"
                                  if args.feature_store else "resident in HBM before the timed region"),
                        "master_weights": "f32", "mode": args.compute,
                        "activations": "bf16" if args.compute == "bf16" else "f32"},
-            "roofline": rl, "cpu_baseline": cb,
+            "roofline": rl, "cpu_baseline": cb, "f32": f32_leg,
         }
-        if args.kernel_table and table:
-            print(json.dumps(table, indent=1), file=sys.stderr)
+        if args.kernel_table and res["table"]:
+            print(json.dumps(res["table"], indent=1), file=sys.stderr)
     else:
         out = None
     if torch.distributed.is_initialized():

@@ -210,16 +210,23 @@ def compute_edges(features: torch.Tensor, bank: torch.Tensor, k: int,
 
 def graphone_task_interaction(sd: SD, task: str, features: torch.Tensor, k: int, depth: int,
                               residual: bool = False, distance_func: str = "cosine",
+                              closest_override: Optional[torch.Tensor] = None,
                               ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """GraphONE.__task_interaction (reference graphONE.py:87-117).  Edges are always computed
     from the ORIGINAL features and bank (features_match is never reassigned), the SAGE stage runs
-    over cat([bank, features]) with remaining self loops and only the last N rows are kept."""
+    over cat([bank, features]) with remaining self loops and only the last N rows are kept.
+    ``closest_override`` [N, k] (tests only): use these prototype indices instead of the searched ones,
+    to measure what a different neighbour selection does to the outputs."""
     bank = sd[f"embeddings.{task}.weight"]
     f0 = features
     n = features.shape[0]
     assignments: List[torch.Tensor] = []
     for d in range(depth):
         edges, closest = compute_edges(f0, bank, k, distance_func)
+        if closest_override is not None:
+            closest = closest_override
+            tgt = torch.arange(bank.shape[0], bank.shape[0] + n).repeat_interleave(k)
+            edges = torch.stack([closest.flatten(), tgt])
         assignments.append(closest[:, 0])
         graph = torch.cat([bank, features], dim=0)
         edges = P.add_remaining_self_loops(edges, graph.shape[0])
@@ -232,11 +239,14 @@ def graphone_task_interaction(sd: SD, task: str, features: torch.Tensor, k: int,
 
 
 def graphone_interact(sd: SD, features: Mapping[str, torch.Tensor], k: int, depth: int,
-                      residual: bool = False, distance_func: str = "cosine"):
+                      residual: bool = False, distance_func: str = "cosine",
+                      closest_override: Optional[Mapping[str, torch.Tensor]] = None):
     """GraphONE.interact (reference graphONE.py:76-85)."""
     out, closest = {}, {}
     for task, f in features.items():
-        out[task], closest[task] = graphone_task_interaction(sd, task, f, k, depth, residual, distance_func)
+        out[task], closest[task] = graphone_task_interaction(
+            sd, task, f, k, depth, residual, distance_func,
+            None if closest_override is None else closest_override[task])
     return out, closest
 
 
@@ -324,13 +334,14 @@ def mtl_objective(backbone_sd: SD, task_sds: Mapping[str, SD], batches: Mapping[
 def egopack_task_loss(primary: str, task_sds: Mapping[str, SD], graphone_sd: SD, feat: torch.Tensor,
                       batch: torch.Tensor, y: torch.Tensor, others: Sequence[str],
                       k: int, depth: int, residual: bool, average_logits: bool,
-                      oscc_kind: str = "ce", n_heads: int = 2, num_graphs: Optional[int] = None):
+                      oscc_kind: str = "ce", n_heads: int = 2, num_graphs: Optional[int] = None,
+                      closest_override: Optional[Mapping[str, torch.Tensor]] = None):
     """main_egopack.train_step_task (reference main_egopack.py:45-61) with late_fusion=True:
     primary features; aux features = GraphONE.interact on the DETACHED projections of the other
     tasks; fused logits; primary.compute_loss."""
     f_primary = projection_features(task_sds[primary], feat)
     aux_in = {t: projection_features(task_sds[t], feat).detach() for t in others}
-    aux, closest = graphone_interact(graphone_sd, aux_in, k, depth, residual)
+    aux, closest = graphone_interact(graphone_sd, aux_in, k, depth, residual, closest_override=closest_override)
     sd = task_sds[primary]
     if primary in ("ar", "lta"):
         logits = multihead_logits(sd, f_primary, n_heads, aux, average_logits)

@@ -1,0 +1,322 @@
+"""Every BASELINE.json configuration AT ITS STATED SIZE, one training step through the HIP path against the CPU oracle
+(oracle/path.py: the reference's control flow, pinned by the reference-generated fixtures; its torch_geometric leaf ops are
+a restatement of the absent package -- see oracle/pyg_ops.py -- which no reference-held vector pins).
+
+  #1  AR single task, B = 2, T = 32            (the reference's CPU plumbing case, here on the HIP path)
+  #2  AR single task, B = 64, T = 32
+  #3  AR + LTA + PNR, B = 64 per task, T = 32  (the headline workload of bench.py)
+  #4  EgoPack novel task OSCC: 3 frozen banks of K = 4096 prototypes, GraphONE k = 4, depth 3, residual
+  #5  4 tasks, T = 256, B = 16 per task
+All at F = 3 x 1536, H = Hp = 1024, 115 / 478 classes, temporal radius 1, dropout 0 (the oracle has no RNG stream in common
+with the Philox masks; dropout-mask semantics are pinned in test_gpu_kernels.py), built by bench.build_workload itself.
+The synthetic features are bf16-representable so that both compute modes and the oracle read identical input values.
+
+Stated tolerances
+  f32 mode  (exact-f32 MFMA, everything f32: the reference's precision)
+      loss vectors      |d| <= 1e-3 absolute (values are O(1..10))
+      objective         relative 1e-4
+      gradients         relative Frobenius error <= 2e-3 per parameter tensor
+      parameters after one Adam step (lr 1e-3): at least 99.9 % of the elements within 2e-4 of torch.optim.Adam on the
+      oracle's gradients -- Adam's first step moves every element by lr * g / (|g| + eps) = +-lr, so an element whose
+      gradient is within rounding noise of zero may legitimately move the other way (2e-3 apart); the bound on the count
+      of such elements is the test
+      nearest-prototype indices (#4): identical wherever the fp32 ranking gap exceeds 1e-5, and >= 99.5 % identical overall
+  bf16 mode (bf16 MFMA, bf16 activations / gradients / weight operands: the benchmark mode)
+      loss vectors      relative Frobenius error <= BF16_LOSS
+      objective         relative BF16_OBJ
+      gradients         relative Frobenius error <= BF16_GRAD per parameter tensor (tensors with a non-negligible norm)
+      nearest-prototype indices (#4): exact given the same f32 projection outputs; against the f32 oracle end to end the
+      agreement rate is asserted >= BF16_KNN (the upstream activations differ by bf16 rounding, so near-ties flip) and the
+      logit change those flips cause is bounded separately
+"""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import path as O  # noqa: E402
+from oracle import pyg_ops as P  # noqa: E402
+
+DEV = "cuda"
+NAMES = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
+CONFIGS = {
+    "c1_ar_B2_T32": dict(workload="ar", batch=2, T=32),
+    "c2_ar_B64_T32": dict(workload="ar", batch=64, T=32),
+    "c3_mtl_B64_T32": dict(workload="mtl", batch=64, T=32),
+    "c4_egopack_oscc_K4096_d3": dict(workload="egopack_oscc", batch=64, T=32),
+    "c5_mtl4_B16_T256": dict(workload="mtl4", batch=16, T=256),
+}
+LR, WD = 1e-3, 1e-5
+BF16_LOSS, BF16_OBJ, BF16_GRAD, BF16_KNN = 3e-2, 1e-2, 0.12, 0.90
+
+
+def _args(name, mode):
+    a = argparse.Namespace(hidden=1024, trn_hidden=1024, dropout=0.0, compute="bf16", bank=4096, graphone_k=4,
+                           graphone_depth=3)
+    a.__dict__.update(CONFIGS[name])
+    return a
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+
+
+def _odata(d):
+    """Host copy of a device batch in the oracle's batch type (features widened to f32: identical values)."""
+    return P.OData(x=d.x.float().cpu(), pos=d.pos.cpu(), edge_index=d.edge_index.cpu(), batch=d.batch.cpu(), y=d.y.cpu(),
+                   num_graphs=d.num_graphs)
+
+
+def _build(name, mode):
+    """(step, optimizer, device batches, merged, modules, oracle inputs) for one configuration and compute mode."""
+    import bench
+    from egopack_amd import engine, ops
+    from egopack_amd.optim import FlatAdam
+    args = _args(name, mode)
+    ops.set_compute(mode)
+    ops.manual_seed(5)
+    model, tasks, crit, weights, dev, merged = bench.build_workload(args, 0, torch.device(DEV))  # bf16-representable features
+    if mode != "bf16":  # same values, f32 storage
+        if merged is not None:
+            merged.x = merged.x.float()
+            off = 0
+            for t in [t for t in ("ar", "lta", "oscc", "pnr") if t in dev]:
+                n = dev[t].x.shape[0]
+                dev[t].x = merged.x[off:off + n]
+                off += n
+        else:
+            for d in dev.values():
+                d.x = d.x.float()
+    sds = {"temporal_graph": {k: v.clone() for k, v in model.state_dict().items()}}
+    for t, n in NAMES.items():
+        sds[n] = {k: v.clone() for k, v in tasks[t].state_dict().items()}
+    model.to(DEV)
+    for t in tasks.values():
+        t.to(DEV)
+    params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
+    graphone = None
+    if args.workload == "egopack_oscc":
+        from egopack_amd.models.graphONE.graphONE import GraphONE
+        gen = torch.Generator(device=DEV)
+        gen.manual_seed(7)
+        banks = {t: torch.randn(args.bank, args.hidden, device=DEV, generator=gen) for t in ("ar", "lta", "pnr")}
+        graphone = GraphONE(banks, features_size=args.hidden, hidden_size=args.hidden, k=args.graphone_k,
+                            depth=args.graphone_depth, residual=True).to(DEV)
+        sds["graphone"] = {k: v.detach().cpu().clone() for k, v in graphone.state_dict().items()}
+        params += list(graphone.parameters())
+        opt = FlatAdam(params, lr=LR, weight_decay=WD)
+        step = engine.EgoPackStep(model, tasks, graphone, weights, opt, backprop_temporal_graph=True, temporal_graph_train_mode=False)
+    else:
+        opt = FlatAdam(params, lr=LR, weight_decay=WD)
+        step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=True)
+        model.train()
+        for t in tasks.values():
+            t.train()
+    modules = {"temporal_graph": model, **{NAMES[t]: tasks[t] for t in tasks}}
+    if graphone is not None:
+        modules["graphone"] = graphone
+    return args, step, opt, dev, merged, modules, sds, weights
+
+
+_oracle_cache = {}
+
+
+def _oracle(name, args, sds, dev, weights):
+    """One oracle step per configuration (cached across the compute modes: same parameters, same input values):
+    loss vectors, objective, gradients, parameters after torch.optim.Adam."""
+    if name in _oracle_cache:
+        return _oracle_cache[name]
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    leaf = {g: {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith("frequency")
+                                                      and not k.startswith("embeddings.")) else v.clone())
+                for k, v in sd.items()} for g, sd in sds.items()}
+    batches = {t: _odata(d) for t, d in dev.items()}
+    extra = {}
+    if args.workload == "egopack_oscc":
+        d = batches["oscc"]
+        feat = O.graph_forward(leaf["temporal_graph"], d.x, d.pos, d.edge_index, 3)
+        tsd = {t: leaf[n] for t, n in NAMES.items()}
+        loss, logits, aux, closest = O.egopack_task_loss("oscc", tsd, leaf["graphone"], feat, d.batch, d.y, ("ar", "lta", "pnr"),
+                                                         args.graphone_k, args.graphone_depth, True, True, num_graphs=d.num_graphs)
+        total = loss.mean()
+        vectors = {"oscc": loss.detach()}
+        with torch.no_grad():
+            aux_in = {t: O.projection_features(tsd[t], feat) for t in ("ar", "lta", "pnr")}
+            full = {t: O.compute_edges(aux_in[t], leaf["graphone"][f"embeddings.{t}.weight"], args.graphone_k)[1] for t in aux_in}
+        extra = {"logits": logits.detach(), "aux_in": aux_in, "closest": full, "feat": feat.detach(),
+                 "aux": {t: a.detach() for t, a in aux.items()}}
+    else:
+        total, detail = O.mtl_objective(leaf["temporal_graph"], {t: leaf[n] for t, n in NAMES.items()}, batches, weights)
+        vectors = {t: l.detach() for t, (_, l) in detail.items()}
+        extra = {"logits": {t: lg for t, (lg, _) in detail.items()}}
+    total.backward()
+    grads = {g: {k: v.grad.clone() for k, v in sd.items() if v.requires_grad and v.grad is not None} for g, sd in leaf.items()}
+    flat = [v for sd in leaf.values() for v in sd.values() if v.requires_grad and v.grad is not None]
+    torch.optim.Adam(flat, lr=LR, weight_decay=WD).step()
+    after = {g: {k: v.detach().clone() for k, v in sd.items() if k in grads[g]} for g, sd in leaf.items()}
+    res = {"total": float(total), "vectors": vectors, "grads": grads, "after": after, **extra}
+    _oracle_cache[name] = res
+    return res
+
+
+def _report(name, mode, rows):
+    """Measured error figures of this run (gpurun_out/config_parity.jsonl): what the stated bounds are set against."""
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/config_parity.jsonl", "a") as f:
+        f.write(json.dumps({"config": name, "mode": mode, **rows}) + "\n")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_step_vs_oracle(name, mode):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops
+    prev = ops.get_compute()
+    try:
+        args, step, opt, dev, merged, modules, sds, weights = _build(name, mode)
+        ref = _oracle(name, args, sds, dev, weights)
+        total, vectors = step.forward_backward(dev, merged)
+        torch.cuda.synchronize()
+        grads = {g: {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+                 for g, m in modules.items()}
+        step._exchange_and_update()
+        torch.cuda.synchronize()
+        after = {g: {k: v.detach().float().cpu() for k, v in m.state_dict().items()} for g, m in modules.items()}
+    finally:
+        ops.set_compute(prev)
+
+    # which parameters carry a gradient must agree exactly (disabled tasks, frozen banks, detached aux projections)
+    for g in ref["grads"]:
+        assert set(grads.get(g, {})) == set(ref["grads"][g]), g
+    rows = {"objective_rel": abs(total.item() - ref["total"]) / abs(ref["total"])}
+    worst_loss, worst_grad, worst_name, frac_far = 0.0, 0.0, "", 0.0
+    for t, v in ref["vectors"].items():
+        got = vectors[t].detach().float().cpu()
+        assert got.shape == v.shape
+        if mode == "f32":
+            torch.testing.assert_close(got, v, rtol=0, atol=1e-3, msg=lambda s: f"{name} loss[{t}]: {s}")
+        worst_loss = max(worst_loss, _rel(got, v))
+    gmax = max(float(x.norm()) for g in ref["grads"].values() for x in g.values())
+    for g, gd in ref["grads"].items():
+        for k, want in gd.items():
+            if float(want.norm()) < 1e-6 * gmax:
+                continue  # (a numerically dead tensor has no meaningful relative error)
+            r = _rel(grads[g][k], want)
+            if r > worst_grad:
+                worst_grad, worst_name = r, f"{g}/{k}"
+    n_far = n_all = 0
+    for g, ad in ref["after"].items():
+        for k, want in ad.items():
+            d = (after[g][k] - want).abs()
+            n_far += int((d > 2e-4).sum())
+            n_all += d.numel()
+    frac_far = n_far / max(n_all, 1)
+    rows.update(loss_rel=worst_loss, grad_rel=worst_grad, grad_worst=worst_name, adam_frac_beyond_2e4=frac_far)
+    _report(name, mode, rows)
+    if mode == "f32":
+        assert rows["objective_rel"] < 1e-4, rows
+        assert worst_grad < 2e-3, rows
+        assert frac_far < 1e-3, rows
+    else:
+        assert rows["objective_rel"] < BF16_OBJ, rows
+        assert worst_loss < BF16_LOSS, rows
+        assert worst_grad < BF16_GRAD, rows
+
+
+def test_config4_prototype_indices_f32_vs_oracle():
+    """BASELINE #4 at size, exact-f32 mode: the nearest-prototype index op (reference graphONE.py:119-141) against the
+    oracle's full argsort -- identical wherever the fp32 ranking gap exceeds 1e-5; logits and GraphONE outputs within the
+    f32 tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops
+    name = "c4_egopack_oscc_K4096_d3"
+    prev = ops.get_compute()
+    try:
+        args, step, opt, dev, merged, modules, sds, weights = _build(name, "f32")
+        ref = _oracle(name, args, sds, dev, weights)
+        step.losses(dev)  # sets the train / eval modes of the step
+        with torch.no_grad():
+            feat = step.features(dev)["oscc"]
+            aux_in = {t: step.tasks[t].forward_features(feat, out_f32=True) for t in ("ar", "lta", "pnr")}
+            nn = {t: ops.nearest_prototypes(aux_in[t], step.graphone.embeddings[t].weight, args.graphone_k).cpu() for t in aux_in}
+            loss, logits, aux, closest = step.task_loss("oscc", feat, dev["oscc"])
+    finally:
+        ops.set_compute(prev)
+    agree = []
+    for t in nn:
+        f, bank = ref["aux_in"][t], sds["graphone"][f"embeddings.{t}.weight"]
+        dist = O.cos_dissimilarity(f.double(), bank.double())
+        srt = dist.sort(dim=-1).values
+        k = args.graphone_k
+        gap = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values
+        safe = gap > 1e-5
+        assert safe.float().mean() > 0.97, t
+        assert torch.equal(nn[t][safe], ref["closest"][t][safe]), t
+        agree.append(float((nn[t] == ref["closest"][t]).float().mean()))
+        assert torch.equal(closest[t][0].cpu(), nn[t][:, 0])  # what interact() reports = column 0 of the same search
+    assert min(agree) > 0.995, agree
+    torch.testing.assert_close(logits.float().cpu(), ref["logits"], rtol=1e-3, atol=1e-3)
+    for t in aux:
+        assert _rel(aux[t].float().cpu(), ref["aux"][t]) < 2e-3, t
+    _report(name, "f32-indices", {"agreement": agree})
+
+
+def test_config4_prototype_indices_in_bf16_mode():
+    """The index op in the BENCHMARK dtype at K = 4096 / H = 1024.
+      (a) exact given the same activations: the search ranks the f32 accumulators of the aux projections' last contraction
+          (not their bf16 roundings) on the exact-f32 path; fed those very values, the oracle's argsort picks the same
+          prototypes wherever the ranking gap exceeds 1e-5;
+      (b) end to end against the f32 oracle the upstream activations carry bf16 rounding, so near-ties flip: the agreement
+          rate is measured and asserted >= BF16_KNN, and what the flips do to the logits is bounded by running the oracle
+          with the HIP path's neighbour lists in place of its own (the only difference between the two oracle runs)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops
+    name = "c4_egopack_oscc_K4096_d3"
+    prev = ops.get_compute()
+    try:
+        args, step, opt, dev, merged, modules, sds, weights = _build(name, "bf16")
+        ref = _oracle(name, args, sds, dev, weights)
+        step.losses(dev)
+        with torch.no_grad():
+            feat = step.features(dev)["oscc"]
+            aux_in = {t: step.tasks[t].forward_features(feat, out_f32=True) for t in ("ar", "lta", "pnr")}
+            assert all(a.dtype == torch.float32 for a in aux_in.values())
+            nn = {t: ops.nearest_prototypes(aux_in[t], step.graphone.embeddings[t].weight, args.graphone_k).cpu() for t in aux_in}
+            loss, logits, aux, closest = step.task_loss("oscc", feat, dev["oscc"])
+    finally:
+        ops.set_compute(prev)
+    k = args.graphone_k
+    rates = {}
+    for t in nn:
+        bank = sds["graphone"][f"embeddings.{t}.weight"]
+        f_gpu = aux_in[t].cpu()
+        _, same_act = O.compute_edges(f_gpu, bank, k)  # (a): the oracle on the SAME activations
+        dist = O.cos_dissimilarity(f_gpu.double(), bank.double())
+        srt = dist.sort(dim=-1).values
+        safe = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values > 1e-5
+        assert safe.float().mean() > 0.97, t
+        assert torch.equal(nn[t][safe], same_act[safe]), t
+        assert float((nn[t] == same_act).float().mean()) > 0.995, t
+        rates[t] = {"ordered": float((nn[t] == ref["closest"][t]).float().mean()),  # (b): against the f32 oracle
+                    "as_sets": float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(nn[t], ref["closest"][t]))
+                                     / nn[t].numel())}
+        assert rates[t]["ordered"] >= BF16_KNN, (t, rates[t])
+    # effect of the flipped neighbours alone: oracle with the HIP path's neighbour lists vs the oracle with its own
+    d = _odata(dev["oscc"])
+    tsd = {t: sds[n] for t, n in NAMES.items()}
+    with torch.no_grad():
+        _, logits_swapped, _, _ = O.egopack_task_loss("oscc", tsd, sds["graphone"], ref["feat"], d.batch, d.y, ("ar", "lta", "pnr"),
+                                                      k, args.graphone_depth, True, True, num_graphs=d.num_graphs,
+                                                      closest_override=nn)
+    flip_effect = _rel(logits_swapped, ref["logits"])
+    end_to_end = _rel(logits.float().cpu(), ref["logits"])
+    _report(name, "bf16-indices", {"agreement": rates, "logit_rel_from_flips": flip_effect, "logit_rel_end_to_end": end_to_end})
+    assert flip_effect < 2e-2, flip_effect
+    assert end_to_end < 5e-2, end_to_end

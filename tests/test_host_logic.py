@@ -268,3 +268,23 @@ def test_copy_batch_values_tracks_the_structure_fingerprint_A_B_A():
     unknown = _lta_batch(23)  # no fingerprint: everything is copied and the destination forgets its own
     E.copy_batch_values({"lta": static}, None, {"lta": unknown}, None)
     assert static._struct_key == 0 and torch.equal(static.graph.rowptr, unknown.graph.rowptr)
+
+
+def test_bench_gpus_n_spawns_n_ranks_and_propagates_failure():
+    """``python bench.py --gpus N`` without a launcher environment starts N ranks itself (the driver's own command line),
+    as child processes of a parent that never touches the GPU.  Without GPUs (this container) every rank must fail loudly
+    and the parent must exit non-zero with no result line."""
+    import subprocess
+    import bench
+    plan = bench.spawn_plan(2, ["--gpus", "2", "--steps", "3"], port=29431)
+    assert plan[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in plan
+    assert plan[plan.index("--master-addr") + 1] == "127.0.0.1" and plan[plan.index("--master-port") + 1] == "29431"
+    assert plan[-5].endswith("bench.py") and plan[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert bench.parse_args([]).grad_compress == "none" and bench.parse_args([]).gpus == 1  # the entry points' exchange type
+    if torch.cuda.is_available():
+        pytest.skip("the failure leg needs a box without GPUs")
+    r = subprocess.run([sys.executable, str(Path(bench.__file__)), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a ROCm GPU") >= 2  # both ranks were started and both raised
+    assert '"metric"' not in r.stdout

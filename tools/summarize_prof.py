@@ -63,4 +63,32 @@ for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SI
     print()
     for k, (n, v) in agg.items():
         pmc.setdefault(short(k), {})[ctr] = {"launches": n, "bytes_per_launch": v * 1024 * mult / n}
+# matrix-pipe counters (pmc_mfma pass): per kernel, summed over its launches
+f = find("pmc_mfma", "*counter_collection.csv")
+if f:
+    agg = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(int)
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_WAVE_CYCLES":
+                calls[r["Kernel_Name"]] += 1
+    print("## matrix-pipe utilisation (SQ counters, own pass)\n")
+    print("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (both summed over SEs/XCDs as rocprofv3 reports them; the ratio is "
+          "the fraction of the busy time in which a matrix instruction was executing); wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES "
+          "(waves parked on s_waitcnt / barriers), issue-stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.\n")
+    print("| kernel | launches | MFMA busy / busy | wait / wave cycles | issue stall / wave cycles | bf16 MOPS per launch |")
+    print("|---|---:|---:|---:|---:|---:|")
+    mfma = {}
+    for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))[:25]:
+        busy, wave = c.get("SQ_BUSY_CYCLES", 0.0) or 1.0, c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        n = max(calls[k], 1)
+        row = {"launches": n, "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy,
+               "wait_frac": c.get("SQ_WAIT_ANY", 0.0) / wave, "issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0.0) / wave,
+               "mops_bf16_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / n}
+        mfma[short(k)] = row
+        print(f"| {short(k)} | {n} | {row['mfma_busy_frac']:.3f} | {row['wait_frac']:.3f} | {row['issue_stall_frac']:.3f} | "
+              f"{row['mops_bf16_per_launch']:.3g} |")
+    print()
+    (root / "mfma.json").write_text(json.dumps(mfma, indent=1))
 (root / "pmc.json").write_text(json.dumps(pmc, indent=1))
