@@ -1323,6 +1323,8 @@ def scatter_add_rows_f64(x, label, bank, count, groups=None):
     x = _c(x)
     order, seg_ptr, seg_label = groups if groups is not None else label_groups(label)
     dev = x.device
+    if seg_label.numel() == 0:
+        return  # no labelled row in this batch
     order, seg_ptr, seg_label = order.to(dev), seg_ptr.to(dev), seg_label.to(dev)
     _ck(_lib.load().egk_segment_sum_rows_f64(_stream(), _p(x), _p(order), _p(seg_ptr), _p(seg_label), _p(bank), _p(count),
                                             seg_label.numel(), x.shape[1], bank.shape[0], _dt(x)), "egk_segment_sum_rows_f64")
