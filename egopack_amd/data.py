@@ -621,6 +621,53 @@ class SyntheticTaskDataset:
         return self.transform(Data(x=x, pos=pos, y=y, batch=None))
 
 
+class LearnableSyntheticDataset(SyntheticTaskDataset):
+    """Synthetic samples whose labels can be LEARNED from the features (the plain synthetic datasets carry random labels:
+    fine for throughput, useless for a metric).  A fixed code book (one F-vector per verb / noun / event, the same for
+    every split) is added to the N(0,1) features with amplitude ``signal``:
+      AR   the centre node's (verb, noun) codes on the centre node and its two neighbours;
+      LTA  one (verb, noun) per sequence, every forecast node is labelled with it: its codes at full amplitude on the 2
+           observed nodes and at half amplitude on the forecast nodes;
+      OSCC label 1 = one random node carries the state-change code;
+      PNR  the positive node carries the point-of-no-return code.
+    Used by the fixed-seed metric-agreement test (f32 vs bf16 training) and as a sanity workload."""
+
+    def __init__(self, task: str, length: int, T: int, num_segments: int = 3, features_size: int = 1536,
+                 num_class_labels=(115, 478), k: int = 1, seed: int = 1, transform=None, signal: float = 1.0,
+                 code_seed: int = 4242):
+        super().__init__(task, length, T, num_segments, features_size, num_class_labels, k, seed, transform)
+        g = torch.Generator().manual_seed(code_seed)  # the code book does not depend on the split's sample seed
+        V, Nn = self.num_class_labels
+        self.codes_v = torch.randn(V, features_size, generator=g)
+        self.codes_n = torch.randn(Nn, features_size, generator=g)
+        self.code_event = torch.randn(2, features_size, generator=g)  # [0]: OSCC state change, [1]: PNR
+        self.signal = float(signal)
+
+    def __getitem__(self, i: int, with_x: bool = True) -> Data:
+        d = SyntheticTaskDataset.__getitem__(self, i)
+        g = torch.Generator().manual_seed(self.seed * 7_000_003 + i)
+        T, s = self.T, self.signal
+        x = d.x
+        if self.task == "ar":
+            c = T // 2
+            v, n = int(d.y[c, 0]), int(d.y[c, 1])
+            x[max(c - 1, 0): c + 2] += s * (self.codes_v[v] + self.codes_n[n])
+        elif self.task == "lta":
+            V, Nn = self.num_class_labels
+            v, n = int(torch.randint(1, V, (1,), generator=g)), int(torch.randint(0, Nn, (1,), generator=g))
+            d.y[2:, 0], d.y[2:, 1] = v, n
+            x[:2] += s * (self.codes_v[v] + self.codes_n[n])
+            x[2:] += 0.5 * s * (self.codes_v[v] + self.codes_n[n])
+            d = self.transform(Data(x=x, pos=d.pos, y=d.y, batch=None))  # (the LTA edges count the forecast labels)
+        elif self.task == "oscc":
+            if int(d.y) == 1:
+                x[int(torch.randint(0, T, (1,), generator=g))] += s * self.code_event[0]
+        elif self.task == "pnr":
+            x[int(torch.argmax(d.y))] += s * self.code_event[1]
+        d.x = x
+        return d
+
+
 class SyntheticResidentDataset(SyntheticTaskDataset):
     """Synthetic counterpart of the reference's frame datasets on top of a device-resident feature store: a few
     synthetic "videos" ([frames, F] arrays, as the reference's ``.npy`` per video) and, per sample, T action windows

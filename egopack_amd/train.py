@@ -58,8 +58,9 @@ def build_datasets(cfg, split: str):
     for t in TASKS:
         tf = D.LTATemporalConnectivity(r=cfg.k + 0.5, loop=False) if t == "lta" else D.RadiusGraph(r=cfg.k + 0.5, loop=False)
         dcfg = dict(cfg[DSET_GROUP[t]])
-        if dcfg["_target_"].endswith(("SyntheticTaskDataset", "SyntheticResidentDataset")):
-            dcfg.update(length=cfg.synthetic_samples if split == "train" else max(cfg.synthetic_samples // 4, 1),
+        if dcfg["_target_"].endswith(("SyntheticTaskDataset", "SyntheticResidentDataset", "LearnableSyntheticDataset")):
+            n_val = int(cfg.get("synthetic_val_samples", 0)) or max(cfg.synthetic_samples // 4, 1)
+            dcfg.update(length=cfg.synthetic_samples if split == "train" else n_val,
                         seed=cfg.seed + (0 if split == "train" else 10_000), k=cfg.k)
             if dcfg["_target_"].endswith("SyntheticResidentDataset"):
                 dcfg["split"] = split

@@ -142,7 +142,18 @@ def main(argv=None):
             torch.distributed.broadcast(p.data, src=0)
     optimizer = T.build_optimizer(cfg, params)
     scheduler = T.build_scheduler(cfg, optimizer)
-    sync = edist.GradSync(world) if world > 1 else None
+    compress = str(cfg.get("grad_compress", "none"))  # element type of the gradient all-reduce: none (f32) | bf16
+    sync = edist.GradSync(world, compress=compress) if world > 1 else None
+    dry = int(cfg.get("exchange_dry_run", 0))
+    if world == 1 and dry > 1:
+        # development / test knob: run the N-rank exchange path (conversion, RCCL all-reduce on a 1-rank group, 1/N gradient
+        # scale, staged backward) on ONE GPU -- everything of the N-GPU step except the peers' contributions
+        if not torch.distributed.is_initialized():
+            import os
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29571")
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        sync = edist.GradSync(dry, compress=compress)
     step = engine.MTLStep(model, tasks, T.build_criteria(dsets_train), weights, optimizer,
                           fused_backbone=cfg.fused_backbone, sync=sync)
     step.use_graph = bool(cfg.get("use_graph", True))
@@ -154,6 +165,7 @@ def main(argv=None):
                                scheduler=scheduler, loaders=dl_train)
         first_epoch = int(ck.get("epoch", 0)) + 1
         logger.info("resumed from %s at epoch %d", cfg.resume_from, first_epoch)
+    metrics = None
     for epoch in range(first_epoch, cfg.num_epochs + 1):
         train(epoch, step, dl_train, weights, device, store=store)
         scheduler.step()
@@ -162,11 +174,15 @@ def main(argv=None):
             T.save_checkpoint(ckpt_path, model, tasks, epoch, optimizer=optimizer, scheduler=scheduler, loaders=dl_train)
         if epoch >= cfg.num_epochs - 5:  # all ranks: the validation split is sharded by batch
             logger.info("validation losses: %s", validate_losses(step, dl_val, device))
-            validate_metrics(epoch, model, tasks, step.enabled, dsets_val, dl_val, device)
+            metrics = validate_metrics(epoch, model, tasks, step.enabled, dsets_val, dl_val, device)
+    if cfg.num_epochs < first_epoch and cfg.get("validate_untrained", False):  # (num_epochs=0: metrics of the initial state)
+        metrics = validate_metrics(0, model, tasks, step.enabled, dsets_val, dl_val, device)
     if cfg.save_model and rank == 0:
         T.save_checkpoint(ckpt_path, model, tasks, cfg.num_epochs, optimizer=optimizer, scheduler=scheduler, loaders=dl_train)
     if world > 1:
         torch.distributed.destroy_process_group()
+    # (callers that drive main() from Python -- the tests -- get the last validation metrics and the trained modules)
+    return {"metrics": metrics, "model": model, "tasks": tasks, "step": step, "loaders": dl_train, "val_datasets": dsets_val}
 
 
 if __name__ == "__main__":
