@@ -296,6 +296,11 @@ def parse_args(argv=None):
                     help="skip the short reference-precision (--compute f32) measurement added to the JSON line at N = 1")
     ap.add_argument("--f32-steps", type=int, default=10, help="timed steps of the reference-precision leg")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
+    ap.add_argument("--stamps", action="store_true",
+                    help="development: capture one-lane wall-clock stamps at the phase boundaries of the step and print the "
+                         "phase table of the last replay (stderr); each stamp costs ~2 us of the step")
+    ap.add_argument("--no-grouped-heads", action="store_true", help="A/B: one projection chain per task instead of grouped launches")
+    ap.add_argument("--no-wgrad-grouping", action="store_true", help="A/B: every weight gradient as its own (split-K) launch")
     return ap.parse_args(argv)
 
 
@@ -342,6 +347,8 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
     from egopack_amd.optim import FlatAdam
     ops.set_compute(args.compute)
     ops.manual_seed(1000 + rank)  # dropout streams differ per rank
+    if getattr(args, "stamps", False):
+        ops.stamps_enable(device)
     model, tasks, crit, weights, dev, merged = build_workload(args, rank, device)
     names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
     sds = None
@@ -396,6 +403,10 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             step.early_adam = False
         if args.force_wgrad_streams:
             step.wgrad_side_streams = True
+        if getattr(args, "no_grouped_heads", False):
+            step.grouped_heads = False
+    if getattr(args, "no_wgrad_grouping", False):
+        step.wgrad_grouping = False
 
     def eager_step():
         step.step(dev, fused_merged)
@@ -468,6 +479,11 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
     torch.cuda.synchronize()
     barrier()
     ms = (time.perf_counter() - t0) * 1e3 / steps
+    if getattr(args, "stamps", False) and rank == 0:
+        prev = 0.0
+        for name, us in sorted(ops.stamps_read(), key=lambda kv: kv[1]):
+            print(f"[stamp] {us:9.1f} us  (+{us - prev:7.1f})  {name}", file=sys.stderr)
+            prev = us
     if world > 1:
         t = torch.tensor([ms], device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -46,7 +46,9 @@ SIGNATURES = {
     "egk_prof_count": (C.c_int, []),
     "egk_prof_get": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(i64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egk_stamp": (C.c_int, [vp, vp, i32]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
+    "egk_gemm_grouped": (C.c_int, [vp, C.POINTER(GemmDesc), i32]),
     "egk_gemm_ws_bytes": (i64, [C.POINTER(GemmDesc)]),
     "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),
     "egk_gemm_set_pipeline": (C.c_int, [i32]),
@@ -56,6 +58,8 @@ SIGNATURES = {
     "egk_rowln_bwd_ws_rows": (C.c_int, [i32]),
     "egk_rowln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
     "egk_ln_bwd_reduce": (C.c_int, [vp, vp, vp, vp, i32, i32, i32]),
+    "egk_rowln_group_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, i32]),
+    "egk_rowln_group_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32]),
     "egk_graphln_ws_bytes": (i64, [i32, i32, i32]),
     "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
     "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),

@@ -573,7 +573,7 @@ struct OperandCursor {
 //         whatever the kernel does (MI355X_MICROARCH.md, gather-into-LDS table), so bytes fetched per flop bound the
 //         rate: 48 KiB per K tile for 2 x the flops of the 32 KiB of a 128 x 128 tile.  For large outputs.
 template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
-__global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid) {
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
     // 128-row tiling leaves the CUs unevenly loaded (6144 x 1024: 384 tiles = 1.5 per CU; 512 tiles of 96 x 128 = 2)
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
 #endif
 
     int z, tm, tn;
-    tile_of(g, blockIdx.x, z, tm, tn);
+    tile_of(g, bid, z, tm, tn);
     const int m0 = tm * (32 * NI * MB), n0 = tn * BN;
     const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
     const int per = (nkt + g.splitk - 1) / g.splitk;
@@ -846,13 +846,34 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
     if (g.ws_bias != nullptr && g.dbias == nullptr && tid == 0) {  // (the host points ws_bias behind the slabs in this build)
         const unsigned long long ps_issued = __builtin_amdgcn_s_memtime();  // the output stores are issued ...
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // ... and acknowledged
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws_bias) + (long long)blockIdx.x * 8;
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws_bias) + (long long)bid * 8;
         const unsigned long long ps_end = __builtin_amdgcn_s_memtime();
         o[7] = ps_issued - ps_loop;
         o[0] = ps_first - ps_entry; o[1] = ps_loop - ps_first; o[2] = ps_end - ps_loop; o[3] = ps_end - ps_entry;
         o[4] = __builtin_amdgcn_s_memrealtime() - ps_rentry; o[5] = ps_rentry; o[6] = nt;
     }
 #endif
+}
+
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
+__global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI>(g, blockIdx.x);
+}
+
+// Grouped launch: up to MAX_GROUPS independent contractions of the SAME layout / element types / tile variant in one
+// launch (the projection heads of the task batches: same shapes, different rows of the backbone output, different
+// weights).  blockIdx.y = problem, blockIdx.x = its tile id; gridDim.x is the largest tile count rounded up to a
+// multiple of 8, so that blockIdx.x & 7 is still the XCD the hardware deals the workgroup to (linear id = y * gridDim.x
+// + x) and every problem keeps its XCD-local tile order.  Workgroups beyond a problem's tile count leave at once.
+constexpr int MAX_GROUPS = 4;
+struct GemmGroup {
+    GemmArgs p[MAX_GROUPS];
+};
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
+__global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(const GemmGroup gg) {
+    const GemmArgs& g = gg.p[blockIdx.y];
+    if ((int)blockIdx.x >= g.tiles_m * g.tiles_n * g.splitk) return;
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI>(g, blockIdx.x);
 }
 
 // Fragment reads of the 256 x 256 kernel: fragments FIRST .. FIRST + 3 of k-step S of one operand image (inline asm for
@@ -1186,6 +1207,16 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
@@ -1418,4 +1449,111 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
                            dim3(256), 0, s, g);
     }
     return check_launch("egk_gemm");
+}
+
+// ---- grouped contractions ---------------------------------------------------------------------------------------------
+// Fill the device-side argument block of one problem of a grouped launch (bf16 operands on the pipelined kernel only).
+static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
+    EGK_REQUIRE(d->M > 0 && d->N > 0 && d->K1 > 0 && d->K2 >= 0, "egk_gemm_grouped: empty problem");
+    EGK_REQUIRE(d->a_dtype == EGK_BF16 && d->b_dtype == EGK_BF16 && d->compute == EGK_COMPUTE_BF16,
+                "egk_gemm_grouped: bf16 operands on the bf16 MFMA path only");
+    EGK_REQUIRE(d->K1 % 64 == 0 && d->K2 % 64 == 0, "egk_gemm_grouped: K sources must be multiples of 64");
+    EGK_REQUIRE(d->splitk <= 1, "egk_gemm_grouped: no split-K in a grouped launch");
+    EGK_REQUIRE(!(d->accumulate && d->c_dtype != EGK_F32), "egk_gemm_grouped: accumulate needs an f32 C");
+    EGK_REQUIRE(d->A1 && d->B1 && d->C && (d->K2 == 0 || (d->A2 && d->B2)), "egk_gemm_grouped: null pointer");
+    EGK_REQUIRE(!d->dbias || (d->transA && d->K2 == 0), "egk_gemm_grouped: dbias needs the dW form (transA, single K source)");
+    g.M = d->M; g.N = d->N;
+    g.K[0] = d->K1; g.K[1] = d->K2;
+    g.A[0] = d->A1; g.A[1] = d->A2;
+    g.B[0] = d->B1; g.B[1] = d->B2;
+    g.lda[0] = d->lda1; g.lda[1] = d->lda2; g.ldb[0] = d->ldb1; g.ldb[1] = d->ldb2;
+    for (int i = 0; i < 2; ++i) {
+        g.a_vec[i] = g.A[i] && aligned16(g.A[i]) && (g.lda[i] % 8 == 0);
+        g.b_vec[i] = g.B[i] && aligned16(g.B[i]) && (g.ldb[i] % 8 == 0);
+    }
+    EGK_REQUIRE(g.a_vec[0] && g.b_vec[0] && (d->K2 == 0 || (g.a_vec[1] && g.b_vec[1])),
+                "egk_gemm_grouped: operand rows must be 16-byte aligned");
+    g.C = d->C; g.ldc = d->ldc;
+    g.c_bf16 = d->c_dtype == EGK_BF16;
+    g.c_vec = g.c_bf16 ? ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0 && g.ldc % 4 == 0) : (aligned16(g.C) && g.ldc % 4 == 0);
+    g.accumulate = d->accumulate; g.act = d->act; g.alpha = d->alpha;
+    g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
+    g.r_bf16 = d->r_dtype == EGK_BF16;
+    g.r_vec = g.residual && (g.r_bf16 ? ((reinterpret_cast<uintptr_t>(g.residual) & 7) == 0 && g.ldr % 4 == 0)
+                                      : (aligned16(g.residual) && g.ldr % 4 == 0));
+    g.splitk = 1;
+    g.ws = nullptr;
+    g.dbias = d->dbias; g.ws_bias = nullptr;
+    g.rows_epilogue = g_rows_epilogue;
+    return 0;
+}
+
+extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs, int32_t count) {
+    EGK_REQUIRE(descs != nullptr && count >= 1 && count <= MAX_GROUPS, "egk_gemm_grouped: 1 .. %d problems", MAX_GROUPS);
+    if (count == 1) return egk_gemm(stream, descs);
+    hipStream_t s = (hipStream_t)stream;
+    GemmGroup gg;
+    const bool ta = descs[0].transA != 0, tb = descs[0].transB != 0;
+    double flops = 0, bytes = 0;
+    long long t128 = 0, t96 = 0, t64 = 0;
+    int min_nkt = 1 << 30;
+    for (int i = 0; i < count; ++i) {
+        const egk_gemm_desc* d = descs + i;
+        EGK_REQUIRE((d->transA != 0) == ta && (d->transB != 0) == tb, "egk_gemm_grouped: the problems must share one layout");
+        const int rc = fill_group_args(d, gg.p[i]);
+        if (rc) return rc;
+        const int K = d->K1 + d->K2;
+        flops += 2.0 * d->M * d->N * K;
+        bytes += 2.0 * ((double)d->M * K + (double)d->N * K) + (gg.p[i].c_bf16 ? 2.0 : 4.0) * d->M * d->N;
+        const int tn = cdiv(d->N, BN);
+        t128 += (long long)cdiv(d->M, 128) * tn; t96 += (long long)cdiv(d->M, 96) * tn; t64 += (long long)cdiv(d->M, 64) * tn;
+        min_nkt = K / 64 < min_nkt ? K / 64 : min_nkt;
+    }
+    ensure_lds_attr();
+    // one tile variant for the whole launch, by the policy of egk_gemm applied to the TOTAL tile count
+    int variant = t128 > 256 ? 3 : (min_nkt >= 4 ? 5 : 3);
+    if (!ta) {
+        if (t128 > 256) {
+            if (((t96 + 255) / 256) * 28 < ((t128 + 255) / 256) * 32) variant = 8;
+        } else if (t64 <= 256 && t64 > t128) {
+            variant = 11;
+        }
+    }
+    if (g_use_pipe == 3 || g_use_pipe == 5) variant = g_use_pipe;
+    if ((g_use_pipe == 8 || g_use_pipe == 11) && !ta) variant = g_use_pipe;
+    int max_wg = 0;
+    for (int i = 0; i < count; ++i) {
+        GemmArgs& g = gg.p[i];
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : cdiv(g.M, BM);
+        g.tiles_n = cdiv(g.N, BN);
+        const int tiles = g.tiles_m * g.tiles_n;
+        int per_xcd = cdiv(tiles, 8), gm = 1;
+        while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
+        g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
+        max_wg = tiles > max_wg ? tiles : max_wg;
+    }
+    for (int i = count; i < MAX_GROUPS; ++i) gg.p[i] = gg.p[0];
+    const dim3 pgrid((max_wg + 7) / 8 * 8, count), pblock(NTHREADS);
+    const int layout = ta ? (tb ? 2 : 3) : (tb ? 1 : 0);
+    EGK_REQUIRE(!(ta && !tb), "egk_gemm_grouped: the tn layout is not instantiated");
+#define EGK_PIPE_G(TA, TB)                                                                                                  \
+    do {                                                                                                                    \
+        if (variant == 5) hipLaunchKernelGGL((gemm_pipe_group_kernel<2, TA, TB, 2, 1>), pgrid, dim3(2 * NTHREADS), 4 * 32768, s, gg); \
+        else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, gg);                \
+    } while (0)
+    {
+        ProfScope prof(variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
+                                   : (variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
+        if (!ta && variant == 11) {
+            if (!tb) hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);
+            else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);
+        } else if (!ta && variant == 8) {
+            if (!tb) hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, gg);
+            else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, gg);
+        } else if (!ta && !tb) EGK_PIPE_G(false, false);
+        else if (!ta && tb) EGK_PIPE_G(false, true);
+        else EGK_PIPE_G(true, true);
+    }
+#undef EGK_PIPE_G
+    return check_launch("egk_gemm_grouped");
 }

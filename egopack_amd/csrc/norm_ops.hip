@@ -36,13 +36,15 @@ __device__ __forceinline__ float el(const float4& v, int t) { return t == 0 ? v.
 // -------------------------------------------------------------------------------------------
 // row LayerNorm (+ReLU, +dropout)
 // -------------------------------------------------------------------------------------------
+// rows [row_begin, rows) are walked by ``nblk`` workgroups, this one being number ``blk`` (the plain launch: 0, all rows,
+// gridDim.x, blockIdx.x; the grouped launch: one row range and one (w, b) pair per blockIdx.y)
 template <int NV, typename T, bool FULL>
-__global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, T* __restrict__ y,
-                                                        float* __restrict__ mean, float* __restrict__ rstd,
-                                                        uint8_t* __restrict__ mask, int rows, int cols, float eps, int relu,
-                                                        float p, uint64_t seed, uint64_t offset,
-                                                        const uint64_t* __restrict__ dev_offset) {
+__device__ __forceinline__ void rowln_fwd_body(const T* __restrict__ x, const float* __restrict__ w,
+                                               const float* __restrict__ b, T* __restrict__ y,
+                                               float* __restrict__ mean, float* __restrict__ rstd,
+                                               uint8_t* __restrict__ mask, int row_begin, int rows, int cols, float eps, int relu,
+                                               float p, uint64_t seed, uint64_t offset,
+                                               const uint64_t* __restrict__ dev_offset, int blk, int nblk) {
     if (dev_offset) offset += dev_offset[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x,
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    for (int row = row_begin + blk * WPB + wave; row < rows; row += nblk * WPB) {
         Row<NV> r;
         load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
         float s = 0.f;
@@ -101,13 +103,42 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x,
     }
 }
 
+template <int NV, typename T, bool FULL>
+__global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, T* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        uint8_t* __restrict__ mask, int rows, int cols, float eps, int relu,
+                                                        float p, uint64_t seed, uint64_t offset,
+                                                        const uint64_t* __restrict__ dev_offset) {
+    rowln_fwd_body<NV, T, FULL>(x, w, b, y, mean, rstd, mask, 0, rows, cols, eps, relu, p, seed, offset, dev_offset, blockIdx.x,
+                                gridDim.x);
+}
+
+// Grouped row LayerNorm: up to LN_MAX_GROUPS consecutive row ranges of ONE [rows, cols] matrix, each with its own affine
+// parameters (the projection heads of the task batches), in one launch: blockIdx.y = range.  No dropout.
+constexpr int LN_MAX_GROUPS = 4;
+struct RowLNGroups {
+    int row0[LN_MAX_GROUPS + 1];
+    const float* w[LN_MAX_GROUPS];
+    const float* b[LN_MAX_GROUPS];
+};
+template <int NV, typename T, bool FULL>
+__global__ __launch_bounds__(256) void rowln_fwd_group_kernel(const T* __restrict__ x, const RowLNGroups G, T* __restrict__ y,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, int cols,
+                                                              float eps, int relu) {
+    const int g = blockIdx.y;
+    rowln_fwd_body<NV, T, FULL>(x, G.w[g], G.b[g], y, mean, rstd, nullptr, G.row0[g], G.row0[g + 1], cols, eps, relu, 0.f, 0, 0,
+                                nullptr, blockIdx.x, gridDim.x);
+}
+
 // dx for one row + per-wave column partials of dw/db, combined per workgroup through LDS.
 template <int NV, typename T, bool FULL>
-__global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        const uint8_t* __restrict__ mask, T* __restrict__ dx,
-                                                        float* __restrict__ ws, int rows, int cols, int relu, float p) {
+__device__ __forceinline__ void rowln_bwd_body(const T* __restrict__ dy, const T* __restrict__ x,
+                                               const float* __restrict__ w, const float* __restrict__ b,
+                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                               const uint8_t* __restrict__ mask, T* __restrict__ dx,
+                                               float* __restrict__ ws, int row_begin, int rows, int cols, int relu, float p,
+                                               int blk, int nblk, long long ws_blk) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [WPB][2][NV*256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
@@ -159,8 +190,8 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy
     };
     // TWO rows in flight per wave (a wave walks rows / (4 * grid) of them; with one row's loads outstanding at a
     // time the walk is latency bound).  Wide rows (NV > 4) keep one row in flight: registers.
-    const int stride_rows = gridDim.x * WPB;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
+    const int stride_rows = nblk * WPB;
+    for (int row = row_begin + blk * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
         Row<NV> g, xr;
         load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
         load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
@@ -193,9 +224,29 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy
             a += red[(wv_ * 2 + 0) * stride + c];
             d += red[(wv_ * 2 + 1) * stride + c];
         }
-        ws[((long long)blockIdx.x * 2 + 0) * cols + c] = a;
-        ws[((long long)blockIdx.x * 2 + 1) * cols + c] = d;
+        ws[(ws_blk * 2 + 0) * cols + c] = a;
+        ws[(ws_blk * 2 + 1) * cols + c] = d;
     }
+}
+
+template <int NV, typename T, bool FULL>
+__global__ __launch_bounds__(256) void rowln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const uint8_t* __restrict__ mask, T* __restrict__ dx,
+                                                        float* __restrict__ ws, int rows, int cols, int relu, float p) {
+    rowln_bwd_body<NV, T, FULL>(dy, x, w, b, mean, rstd, mask, dx, ws, 0, rows, cols, relu, p, blockIdx.x, gridDim.x, blockIdx.x);
+}
+
+// grouped backward: partial rows of range g land in ws[(g * gridDim.x + blockIdx.x)][2][cols]
+template <int NV, typename T, bool FULL>
+__global__ __launch_bounds__(256) void rowln_bwd_group_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const RowLNGroups G, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, T* __restrict__ dx,
+                                                              float* __restrict__ ws, int cols, int relu) {
+    const int g = blockIdx.y;
+    rowln_bwd_body<NV, T, FULL>(dy, x, G.w[g], G.b[g], mean, rstd, nullptr, dx, ws, G.row0[g], G.row0[g + 1], cols, relu, 0.f,
+                                blockIdx.x, gridDim.x, (long long)g * gridDim.x + blockIdx.x);
 }
 
 // out_a[c] += sum_b ws[b][0][c]; out_b[c] += sum_b ws[b][1][c]   (fixed order)
@@ -646,6 +697,61 @@ int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const floa
 }
 
 int egk_rowln_bwd_ws_rows(int32_t rows) { return row_grid(rows); }
+
+static int fill_ln_groups(const char* what, RowLNGroups& G, const float* const* w, const float* const* b, const int32_t* row_ptr,
+                          int32_t n_groups, int& max_rows) {
+    EGK_REQUIRE(w && b && row_ptr && n_groups >= 1 && n_groups <= LN_MAX_GROUPS, "%s: 1 .. %d row ranges", what, LN_MAX_GROUPS);
+    max_rows = 0;
+    for (int g = 0; g < LN_MAX_GROUPS; ++g) {
+        const int k = g < n_groups ? g : n_groups - 1;
+        EGK_REQUIRE(w[k] && b[k], "%s: null parameter pointer", what);
+        G.w[g] = w[k]; G.b[g] = b[k];
+    }
+    for (int g = 0; g <= LN_MAX_GROUPS; ++g) G.row0[g] = row_ptr[g <= n_groups ? g : n_groups];
+    for (int g = 0; g < n_groups; ++g) {
+        EGK_REQUIRE(row_ptr[g + 1] >= row_ptr[g], "%s: row_ptr must be non-decreasing", what);
+        max_rows = row_ptr[g + 1] - row_ptr[g] > max_rows ? row_ptr[g + 1] - row_ptr[g] : max_rows;
+    }
+    return 0;
+}
+
+int egk_rowln_group_fwd(egk_stream_t stream, const void* x, const float* const* w, const float* const* b, const int32_t* row_ptr,
+                        int32_t n_groups, void* y, float* mean, float* rstd, int32_t cols, float eps, int32_t relu,
+                        int32_t dtype) {
+    EGK_REQUIRE(x && y && mean && rstd, "egk_rowln_group_fwd: null pointer");
+    RowLNGroups G;
+    int max_rows;
+    const int rc = fill_ln_groups("egk_rowln_group_fwd", G, w, b, row_ptr, n_groups, max_rows);
+    if (rc) return rc;
+    if (max_rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * (row_ptr[n_groups] - row_ptr[0]) * cols);
+    const int per = cdiv(row_grid_wide(row_ptr[n_groups] - row_ptr[0]), n_groups);
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_group_kernel<NV, T, FULL>), dim3(per < 1 ? 1 : per, n_groups), dim3(256), 0,
+                                                 s, (const T*)x, G, (T*)y, mean, rstd, cols, eps, relu));
+    return check_launch("egk_rowln_group_fwd");
+}
+
+/* partial rows of range g: ws[(g * egk_rowln_bwd_ws_rows(max range rows) + block)][2][cols]; reduce each range with
+ * egk_ln_bwd_reduce(ws + g * blocks * 2 * cols, dw_g, db_g, max range rows, cols, 0) */
+int egk_rowln_group_bwd(egk_stream_t stream, const void* dy, const void* x, const float* const* w, const float* const* b,
+                        const int32_t* row_ptr, int32_t n_groups, const float* mean, const float* rstd, void* dx, float* ws,
+                        int32_t cols, int32_t relu, int32_t dtype) {
+    EGK_REQUIRE(dy && x && mean && rstd && dx && ws, "egk_rowln_group_bwd: null pointer");
+    RowLNGroups G;
+    int max_rows;
+    const int rc = fill_ln_groups("egk_rowln_group_bwd", G, w, b, row_ptr, n_groups, max_rows);
+    if (rc) return rc;
+    if (max_rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(max_rows);
+    ProfScope prof(KID_ROWLN_BWD, s, 0, (dtype == EGK_BF16 ? 6.0 : 12.0) * (row_ptr[n_groups] - row_ptr[0]) * cols);
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_bwd_group_kernel<NV, T, FULL>), dim3(grid, n_groups), dim3(256),
+                                                 WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, G, mean, rstd,
+                                                 (T*)dx, ws, cols, relu));
+    return check_launch("egk_rowln_group_bwd");
+}
 
 int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b, const float* mean,
                   const float* rstd, const uint8_t* mask, void* dx, float* dw, float* db, float* ws, int32_t rows,

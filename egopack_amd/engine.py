@@ -311,6 +311,8 @@ class StepBase:
         # weight-gradient launches of the backbone on a side stream (they feed nothing but the optimizer): 2-4 % on the
         # multi-task steps, 1.8 % on the single-task step (1.236 -> 1.214 ms), neutral on the EgoPack step
         self.wgrad_side_streams = bool(parallel_heads)
+        # H x H weight gradients parked and issued four at a time as ONE grouped launch of 256 workgroups (ops._wgrad_defer)
+        self.wgrad_grouping = True
 
     # ---- backbone ------------------------------------------------------------------------------------
     def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:
@@ -364,11 +366,13 @@ class StepBase:
         if self.input_hook is not None:
             self.input_hook()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         try:
             total, vectors = self._backward_pass(batches, merged)
             ops.join_wgrad()
         finally:
             ops.set_wgrad_side_streams(prev)
+            ops.set_wgrad_grouping(prev_g)
         return total, vectors
 
     def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
@@ -418,6 +422,7 @@ class StepBase:
         if self.input_hook is not None:
             self.input_hook()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         try:
             total, vectors = self._stage_a(batches, merged)
             self._exchange_region(regions[0])
@@ -427,6 +432,7 @@ class StepBase:
             self._exchange_region(regions[2])
         finally:
             ops.set_wgrad_side_streams(prev)
+            ops.set_wgrad_grouping(prev_g)
         self._finish_staged()
         return total.detach(), {t: v.detach() for t, v in vectors.items()}
 
@@ -508,9 +514,11 @@ class StepBase:
         g = torch.cuda.CUDAGraph()
         opt.prepare_hyper()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         early = self._early_adam_plan(live) if fuse_adam else None
         try:
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                ops.stamp("step_start")
                 opt.flat_g.zero_()
                 if self.input_hook is not None:
                     self.input_hook()
@@ -519,15 +527,18 @@ class StepBase:
                 total, vectors = self._backward_pass(batches, merged)
                 ops.set_last_wgrad_hook(None, None)
                 ops.join_wgrad()
+                ops.stamp("backward_done")
                 if fuse_adam:
                     if early is not None and early["fired"]:
                         torch.cuda.current_stream().wait_stream(early["stream"])
                         opt.launch(None, early["lo"], early["hi"])
                     else:
                         opt.launch()
+                    ops.stamp("adam_done")
         finally:
             ops.set_last_wgrad_hook(None, None)
             ops.set_wgrad_side_streams(prev)
+            ops.set_wgrad_grouping(prev_g)
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
@@ -583,6 +594,7 @@ class StepBase:
         opt = self.optimizer
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         try:
             with torch.cuda.graph(gs[0], capture_error_mode=CAPTURE_MODE):
                 opt.flat_g.zero_()
@@ -596,6 +608,7 @@ class StepBase:
                 self._stage_c()
         finally:
             ops.set_wgrad_side_streams(prev)
+            ops.set_wgrad_grouping(prev_g)
         self._graph, self._static_out, self._fuse_adam = gs, (total, vectors), False
         self._static_in = (batches, merged, self._stage_state, self._cuts)  # everything the graphs read stays alive
         return gs
@@ -641,6 +654,11 @@ class MTLStep(StepBase):
         vectors, logits_out = self._run_heads(feats, lambda t, feat: self._head(t, feat, batches[t]))
         return self._objective(vectors), vectors, logits_out
 
+    # the projection heads of the task batches as ONE chain of grouped launches (ops.grouped_projection) instead of one
+    # chain per task on its own stream: same shapes, different rows, different weights -- 3 x 2048-row launches that each
+    # fill half of the chip become one 6144-row launch per stage (bf16 mode, once the optimizer's flat buffers exist)
+    grouped_heads = True
+
     def _heads_forward_backward(self, feats):
         """Heads' forward AND backward, every head inside its own stream context, on detached copies of the backbone
         features: returns (objective, loss vectors, {task: leaf}) with d(objective)/d(features) in ``leaf.grad``.
@@ -650,9 +668,22 @@ class MTLStep(StepBase):
         batches = self._head_batches
         if not hasattr(self, "_coef_grads"):
             self._coef_grads = {}
+        order = list(leaves)
+        nets = [self.tasks[t].net for t in order]
+        grouped = self.grouped_heads and len(order) > 1 and ops.grouped_projection_ok([leaves[t] for t in order], nets)
+        proj = proj_leaves = None
+        if grouped:
+            proj = ops.grouped_projection([leaves[t] for t in order], nets)
+            proj_leaves = {t: f.detach().requires_grad_(True) for t, f in zip(order, proj)}
+            ops.stamp("heads_proj_fwd_done")
 
         def head(t, leaf):
-            v, logits = self._head(t, leaf, batches[t])
+            if grouped:  # ``leaf`` is the task's projected feature block: classifier + loss (+ their backward) only
+                task, d = self.tasks[t], batches[t]
+                logits = task.forward_logits(leaf, d) if t == "oscc" else task.forward_logits(leaf)
+                v = self.criteria[t](logits, d.y)
+            else:
+                v, logits = self._head(t, leaf, batches[t])
             if v.numel():
                 # the constant the objective's backward hands this head (w_t / numel): one tensor per task, filled once
                 key = (t, v.numel(), v.dtype, v.device)
@@ -663,7 +694,13 @@ class MTLStep(StepBase):
                 v.backward(gradient=g)
             return v.detach(), logits
         with ops.bank_grad_handoff():  # every head's logits feed exactly one loss node here
-            vectors, _ = self._run_heads(leaves, head)
+            vectors, _ = self._run_heads(proj_leaves if grouped else leaves, head)
+        if grouped:  # back on the main stream: the grouped projection's backward down to the backbone features
+            ops.stamp("heads_classifiers_done")
+            live = [t for t in order if proj_leaves[t].grad is not None]
+            if live:
+                outs = dict(zip(order, proj))
+                torch.autograd.backward([outs[t] for t in live], [proj_leaves[t].grad for t in live])
         with torch.no_grad():
             total = self._objective(vectors)
         return total, vectors, leaves
@@ -679,7 +716,9 @@ class MTLStep(StepBase):
             return super()._backward_pass(batches, merged)
         self._head_batches = batches
         feats = self.features(batches, merged)
+        ops.stamp("fwd_backbone_done")
         total, vectors, leaves = self._heads_forward_backward(feats)
+        ops.stamp("heads_done")
         order = [t for t in feats if leaves[t].grad is not None]
         torch.autograd.backward([feats[t] for t in order], [leaves[t].grad for t in order])
         return total, vectors

@@ -82,6 +82,7 @@ class Graph(torch.nn.Module):
             # engine-installed autograd cut at the TRN output (engine.StepBase staged backward): everything below runs
             # on a detached leaf, so the backbone's backward can be issued in two pieces (SAGE stack, then TRN)
             x = cut(x)
+        ops.stamp("fwd_trn_done")
         graph = self._graph_of(data)
         seg_ptr = getattr(data, "seg_ptr", None)
         if seg_ptr is None:  # plain batch: one segment; cached on the batch (a host->device copy cannot be captured)

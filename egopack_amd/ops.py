@@ -213,15 +213,15 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 # ---- raw GEMM ------------------------------------------------------------------------------------
-def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
-         transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-         allow_splitk=True, dbias=None, splitk=None):
-    lib = _lib.load()
+def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
+               transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
+               dbias=None, into=None):
+    """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array)."""
     op_dt = _dt(A1)
     if _dt(B1) != op_dt or (A2 is not None and (_dt(A2) != op_dt or _dt(B2) != op_dt)):
         raise TypeError("gemm: all A / B operands must share one element type")
     compute = (BF16 if op_dt == BF16 else _state["compute"]) if compute is None else compute
-    d = _lib.GemmDesc()
+    d = _lib.GemmDesc() if into is None else into
     d.M, d.N, d.K1, d.K2 = M, N, K1, K2
     d.A1, d.A2, d.B1, d.B2 = _p(A1), _p(A2), _p(B1), _p(B2)
     d.lda1, d.lda2, d.ldb1, d.ldb2 = lda1, lda2, ldb1, ldb2
@@ -233,14 +233,32 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ld
     d.accumulate, d.act, d.alpha = int(accumulate), act, alpha
     d.bias, d.residual, d.ldr = _p(bias), _p(residual), ldr
     d.r_dtype = _dt(residual) if residual is not None else F32
-    sk = lib.egk_gemm_splitk(M, N, K1 + K2, compute) if allow_splitk else 1
-    d.splitk = sk if splitk is None else int(splitk)
+    d.splitk = 1
     d.dbias = _p(dbias)
+    d.ws, d.ws_bytes = None, 0
+    return d
+
+
+def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, **kw):
+    lib = _lib.load()
+    d = _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, **kw)
+    sk = lib.egk_gemm_splitk(M, N, K1 + d.K2, d.compute) if allow_splitk else 1
+    d.splitk = sk if splitk is None else int(splitk)
     need = lib.egk_gemm_ws_bytes(C.byref(d))
     if need:
         ws = workspace(need, out.device)
         d.ws, d.ws_bytes = _p(ws), ws.numel()
     _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
+
+
+def gemm_grouped(problems):
+    """ONE launch for up to 4 independent contractions of the same layout (``problems``: a list of (args, kwargs) of
+    ``gemm`` without the split-K options; bf16 operands, K sources multiples of 64)."""
+    lib = _lib.load()
+    arr = (_lib.GemmDesc * len(problems))()
+    for i, (a, kw) in enumerate(problems):
+        _gemm_desc(*a, into=arr[i], **kw)
+    _ck(lib.egk_gemm_grouped(_stream(), arr, len(problems)), "egk_gemm_grouped")
 
 
 def _colsum_into(x2d: torch.Tensor, out: torch.Tensor, accumulate: bool):
@@ -315,6 +333,69 @@ def _wgrad_launch(in_place: bool, tensors, launch):
         torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
 
 
+# ---- deferred, grouped weight gradients ------------------------------------------------------------------------------------
+# A weight gradient of an H x H layer is a 64-tile contraction over K = all nodes: alone it fills a quarter of the chip,
+# and split-K to fill it costs slabs plus a second launch (measured: 23 us + 8.7 us per launch, 12 of them in the headline
+# step, all competing with the dX chain for the CUs).  With the queue on, such launches are PARKED (operands kept alive)
+# and issued FOUR AT A TIME as one grouped launch on the side stream: 256 workgroups, one per CU, no slabs, no reduce
+# launch, a quarter of the forks.  ``flush_wgrad`` issues what is parked (fewer than four at the end of backward).
+_wq = {"on": False, "items": [], "tiles": 0, "hold": [], "extra": []}
+WGRAD_GROUP_TILES = 256
+
+
+def set_wgrad_grouping(on: bool) -> bool:
+    prev = _wq["on"]
+    _wq["on"] = bool(on)
+    return prev
+
+
+def _wgrad_groupable(M, N, A, lda, B, ldb, K) -> bool:
+    return (_wq["on"] and _wgrad["enabled"] and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and K % 64 == 0
+            and lda % 8 == 0 and ldb % 8 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+            and ((M + 127) // 128) * ((N + 127) // 128) <= 128)
+
+
+def _wgrad_defer(args, kw, tensors) -> bool:
+    """Park the dW contraction ``gemm(*args, **kw)`` (transA, transB, accumulate into a gradient slot) for the next grouped
+    launch.  False: not eligible (the caller launches it itself)."""
+    M, N, A, lda, B, ldb, K = args[:7]
+    main = torch.cuda.current_stream()
+    if not _wgrad_groupable(M, N, A, lda, B, ldb, K) or (main.device.index, main.cuda_stream) in _wgrad["exclude"]:
+        return False
+    _wq["items"].append((args, kw))
+    _wq["hold"].extend(t for t in tensors if t is not None)
+    _wq["tiles"] += ((M + 127) // 128) * ((N + 127) // 128)
+    if len(_wq["items"]) == 4 or _wq["tiles"] >= WGRAD_GROUP_TILES:
+        flush_wgrad()
+    elif not _wgrad["queued"]:  # make sure the end-of-backward join (which flushes) is scheduled
+        _wgrad["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
+    return True
+
+
+def _wgrad_defer_call(fn, tensors):
+    """Park a small side-stream launch (the norm layers' dw / db reductions) with the next grouped launch."""
+    _wq["extra"].append(fn)
+    _wq["hold"].extend(t for t in tensors if t is not None)
+
+
+def flush_wgrad():
+    items, hold, extra = _wq["items"], _wq["hold"], _wq["extra"]
+    if not items and not extra:
+        return
+    _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
+
+    def launch():
+        if len(items) == 1:
+            a, kw = items[0]
+            gemm(*a, **kw)
+        elif items:
+            gemm_grouped(items)
+        for fn in extra:
+            fn()
+    _wgrad_launch(True, hold, launch)
+
+
 _last_wgrad = {"param": None, "hook": None, "inline": True}
 
 
@@ -344,6 +425,7 @@ _wgrad_ln = {"side": True}  # development knob
 def join_wgrad():
     """The current stream waits for every weight-gradient side stream with work in flight (call after backward,
     before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture)."""
+    flush_wgrad()
     cur = torch.cuda.current_stream() if _wgrad["pending"] else None
     for side in _wgrad["pending"]:
         cur.wait_stream(side)
@@ -452,13 +534,16 @@ class _Linear(torch.autograd.Function):
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
             last = Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None
             if last:
+                flush_wgrad()  # (the hook starts the optimizer on every other slot: their gradients must be issued)
                 _last_wgrad["hook"]()
             # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS).  The LAST
             # weight gradient of the step stays on the backward stream: nothing is left to overlap it with there, and the
             # hop to the side stream and back costs two cross-queue hand-offs (~10 us each) on the step's tail.
-            _wgrad_launch(slot is not None and (db_out is None or db is None) and not (last and _last_wgrad["inline"]), (g, x),
-                          lambda: gemm(N, K1, g, g.stride(0), x, K1, M, out, K1, transA=True, transB=True, accumulate=True,
-                                       compute=ctx.compute, dbias=db_out))
+            in_place = slot is not None and (db_out is None or db is None)
+            dw_args = (N, K1, g, g.stride(0), x, K1, M, out, K1)
+            dw_kw = dict(transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=db_out)
+            if not (in_place and not last and ctx.compute == BF16 and _wgrad_defer(dw_args, dw_kw, (g, x))):
+                _wgrad_launch(in_place and not (last and _last_wgrad["inline"]), (g, x), lambda: gemm(*dw_args, **dw_kw))
             dW = None if slot is not None else out
         elif db_out is not None:
             _colsum_into(g, db_out, True)
@@ -617,6 +702,130 @@ def multi_linear(xs, W, b=None, compute=None):
     return _MultiLinear.apply(W, b, _compute_for(xs[0]) if compute is None else compute, *xs)
 
 
+# ---- grouped projection heads: Linear -> LayerNorm -> ReLU -> Linear of several tasks as ONE chain of grouped launches ----
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _GroupedProjection(torch.autograd.Function):
+    """``ProjectionTask.net`` (reference models/tasks/task.py:17-26 with dropout 0) of G task batches: every stage is one
+    launch over all groups -- grouped contraction, grouped row LayerNorm + ReLU, grouped contraction forward; the two
+    grouped dX contractions, the grouped LayerNorm backward and the two grouped dW (+ fused bias gradient) launches
+    backward -- instead of G chains on G streams.  Inputs: G row blocks x_g [M_g, H]; per group (W1, b1, lnw, lnb, W2, b2).
+    Parameter gradients accumulate in place (the optimizer's flat gradient slots must exist)."""
+
+    @staticmethod
+    def forward(ctx, G, compute, eps, *args):
+        lib = _lib.load()
+        xs = [_c(x) for x in args[:G]]
+        params = [args[G + 6 * g: G + 6 * g + 6] for g in range(G)]
+        dt, dev = xs[0].dtype, xs[0].device
+        rows = [x.shape[0] for x in xs]
+        H = xs[0].shape[1]
+        H1, H2 = params[0][0].shape[0], params[0][4].shape[0]
+        ptr = [0]
+        for m in rows:
+            ptr.append(ptr[-1] + m)
+        n = ptr[-1]
+        W1o = [weight_operand(p[0], dt) for p in params]
+        W2o = [weight_operand(p[4], dt) for p in params]
+        h1 = torch.empty((n, H1), dtype=dt, device=dev)
+        a = torch.empty_like(h1)
+        f = torch.empty((n, H2), dtype=dt, device=dev)
+        mean = torch.empty(n, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        gemm_grouped([((rows[g], H1, xs[g], H, W1o[g], H, H, h1[ptr[g]:ptr[g + 1]], H1),
+                       dict(bias=_f32c(params[g][1]), compute=compute)) for g in range(G)])
+        lw, lb = [_f32c(p[2]) for p in params], [_f32c(p[3]) for p in params]
+        row_ptr = (C.c_int32 * (G + 1))(*ptr)
+        _ck(lib.egk_rowln_group_fwd(_stream(), _p(h1), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(a), _p(mean), _p(rstd), H1,
+                                    eps, 1, _dt(h1)), "egk_rowln_group_fwd")
+        gemm_grouped([((rows[g], H2, a[ptr[g]:ptr[g + 1]], H1, W2o[g], H1, H1, f[ptr[g]:ptr[g + 1]], H2),
+                       dict(bias=_f32c(params[g][5]), compute=compute)) for g in range(G)])
+        ctx.G, ctx.compute, ctx.ptr, ctx.dims, ctx.params = G, compute, ptr, (H, H1, H2), params
+        ctx.save_for_backward(h1, a, mean, rstd, *xs, *W1o, *W2o, *lw, *lb)
+        return tuple(f[ptr[g]:ptr[g + 1]] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *dfs):
+        lib = _lib.load()
+        G, ptr, (H, H1, H2), params = ctx.G, ctx.ptr, ctx.dims, ctx.params
+        h1, a, mean, rstd, *rest = ctx.saved_tensors
+        xs, W1o, W2o, lw, lb = (rest[i * G:(i + 1) * G] for i in range(5))
+        dt, dev = h1.dtype, h1.device
+        rows = [ptr[g + 1] - ptr[g] for g in range(G)]
+        dfs = [_operand_rows(d if d is not None else torch.zeros((rows[g], H2), dtype=dt, device=dev), dt) for g, d in enumerate(dfs)]
+        slots = [[_grad_slot(p) for p in pg] for pg in params]
+        if any(s_ is None for sg in slots for s_ in sg):
+            raise RuntimeError("grouped_projection: the parameters need in-place gradient slots (optim.FlatAdam materialised)")
+        cmp = ctx.compute
+        da = torch.empty_like(a)
+        gemm_grouped([((rows[g], H1, dfs[g], dfs[g].stride(0), W2o[g], H1, H2, da[ptr[g]:ptr[g + 1]], H1),
+                       dict(transB=True, compute=cmp)) for g in range(G)])
+        _wgrad_launch(True, (a, *dfs), lambda: gemm_grouped(
+            [((H2, H1, dfs[g], dfs[g].stride(0), a[ptr[g]:ptr[g + 1]], H1, rows[g], slots[g][4], H1),
+              dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][5])) for g in range(G)]))
+        dh1 = torch.empty_like(h1)
+        grid = lib.egk_rowln_bwd_ws_rows(max(rows))
+        ws = torch.empty(G * grid * 2 * H1 * 4, dtype=torch.uint8, device=dev)  # (own buffer: reduced on the side stream)
+        row_ptr = (C.c_int32 * (G + 1))(*ptr)
+        _ck(lib.egk_rowln_group_bwd(_stream(), _p(da), _p(h1), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(mean), _p(rstd),
+                                    _p(dh1), _p(ws), H1, 1, _dt(h1)), "egk_rowln_group_bwd")
+
+        def reduce_ln():
+            for g in range(G):
+                part = ws[g * grid * 2 * H1 * 4:]
+                _ck(lib.egk_ln_bwd_reduce(_stream(), _p(part), _p(slots[g][2]), _p(slots[g][3]), max(rows), H1, 0), "egk_ln_bwd_reduce")
+        _wgrad_launch(True, (ws,), reduce_ln)
+        dxs = [None] * G
+        if any(ctx.needs_input_grad[3:3 + G]):
+            dx = torch.empty((ptr[-1], H), dtype=dt, device=dev)
+            gemm_grouped([((rows[g], H, dh1[ptr[g]:ptr[g + 1]], H1, W1o[g], H, H1, dx[ptr[g]:ptr[g + 1]], H),
+                           dict(transB=True, compute=cmp)) for g in range(G)])
+            dxs = [dx[ptr[g]:ptr[g + 1]] for g in range(G)]
+        _wgrad_launch(True, (dh1, *xs), lambda: gemm_grouped(
+            [((H1, H, dh1[ptr[g]:ptr[g + 1]], H1, xs[g], H, rows[g], slots[g][0], H),
+              dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][1])) for g in range(G)]))
+        return (None, None, None, *dxs, *([None] * (6 * G)))
+
+
+def grouped_projection_ok(xs, nets) -> bool:
+    """Whether ``grouped_projection`` can serve these task batches: bf16 activations, 2 .. 4 standard projection heads
+    (Dropout(0 / eval) -> Linear -> LayerNorm -> ReLU -> Linear) of equal widths, every width a multiple of 64 (whole K
+    tiles of the pipelined contraction), every batch a multiple of 64 rows (the K axis of its weight gradient), and the
+    parameters already living in the optimizer's flat buffers (in-place gradient slots, bf16 weight shadows)."""
+    if not (2 <= len(xs) <= 4) or any(x.dtype != torch.bfloat16 or not x.is_cuda or x.dim() != 2 for x in xs):
+        return False
+    dims = None
+    for x, net in zip(xs, nets):
+        if len(net) != 5 or (net[0].p > 0 and net[0].training):
+            return False
+        l1, ln, l2 = net[1], net[2], net[4]
+        d = (l1.in_features, l1.out_features, l2.out_features)
+        if dims is None:
+            dims = d
+        if d != dims or l2.in_features != d[1] or x.shape[1] != d[0] or any(v % 64 for v in d) or x.shape[0] % 64 or x.shape[0] == 0:
+            return False
+        if d[1] > 4096 or l1.bias is None or l2.bias is None:
+            return False
+        for p in (l1.weight, l1.bias, ln.weight, ln.bias, l2.weight, l2.bias):
+            if _grad_slot(p) is None:
+                return False
+        if getattr(l1.weight, "_egk_shadow", None) is None or getattr(l2.weight, "_egk_shadow", None) is None:
+            return False
+    return True
+
+
+def grouped_projection(xs, nets, compute=None):
+    """f_g = net_g(x_g) for the projection heads ``nets`` (ProjectionTask.net) of several task batches: see
+    ``_GroupedProjection``.  Call ``grouped_projection_ok`` first."""
+    args = []
+    for net in nets:
+        l1, ln, l2 = net[1], net[2], net[4]
+        args += [l1.weight, l1.bias, ln.weight, ln.bias, l2.weight, l2.bias]
+    return _GroupedProjection.apply(len(xs), _compute_for(xs[0]) if compute is None else compute, float(nets[0][2].eps), *xs, *args)
+
+
 # ---- row LayerNorm (+ReLU, +dropout) ------------------------------------------------------------------
 class _RowLN(torch.autograd.Function):
     @staticmethod
@@ -643,6 +852,7 @@ class _RowLN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
+        stamp("bwd_rowln", seq=True)
         x, w, b, mean, rstd, mask = ctx.saved_tensors
         wp, bp = ctx.params
         rows, cols = x.shape
@@ -658,8 +868,11 @@ class _RowLN(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), None, None,
                                   _p(ws), rows, cols, int(ctx.relu), ctx.p, _dt(x)), "egk_rowln_bwd")
-            _wgrad_launch(True, (ws,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, 0),
-                                                   "egk_ln_bwd_reduce"))
+            red = lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, 0), "egk_ln_bwd_reduce")
+            if _wq["on"] and _wgrad["enabled"]:
+                _wgrad_defer_call(red, (ws,))
+            else:
+                _wgrad_launch(True, (ws,), red)
             return dx, None, None, None, None, None, None
         ws = workspace(nbytes, x.device)
         _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), _p(dw), _p(db),
@@ -700,6 +913,7 @@ class _GraphLN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
+        stamp("bwd_graphln", seq=True)
         x, w, b, stats, seg_ptr = ctx.saved_tensors
         wp, bp = ctx.params
         rows, cols = x.shape
@@ -714,8 +928,11 @@ class _GraphLN(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), None, None, _p(seg_ptr),
                                     n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws), _dt(x)), "egk_graphln_bwd")
-            _wgrad_launch(True, (ws,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, n_seg),
-                                                   "egk_ln_bwd_reduce"))
+            red = lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, n_seg), "egk_ln_bwd_reduce")
+            if _wq["on"] and _wgrad["enabled"]:
+                _wgrad_defer_call(red, (ws,))
+            else:
+                _wgrad_launch(True, (ws,), red)
             return dx, None, None, None, None, None
         ws = workspace(nbytes, x.device)
         _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(seg_ptr),
@@ -821,6 +1038,7 @@ class _SageMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
+        stamp("bwd_sage", seq=True)
         h, xp, agg, Wp_o, Wl_o, Wr_o, t_rowptr, t_col, t_wgt, t_heavy = ctx.saved_tensors
         Wp, bp, Wl, bl, Wr = ctx.params
         g = _operand_rows(d_out, h.dtype)
@@ -839,11 +1057,16 @@ class _SageMean(torch.autograd.Function):
         dbp, rbp = slot_or_zeros(bp, (H,))
         in_place = rWl is None and rbl is None and rWr is None
 
+        l_args, l_kw = (Ho, H, g, g.stride(0), agg, H, N, dWl, H), dict(transA=True, transB=True, accumulate=True,
+                                                                        compute=ctx.compute, dbias=dbl)
+        r_args, r_kw = (Ho, H, g, g.stride(0), h, H, N, dWr, H), dict(transA=True, transB=True, accumulate=True, compute=ctx.compute)
+
         def launch_out_grads():
-            gemm(Ho, H, g, g.stride(0), agg, H, N, dWl, H, transA=True, transB=True, accumulate=True, compute=ctx.compute,
-                 dbias=dbl)
-            gemm(Ho, H, g, g.stride(0), h, H, N, dWr, H, transA=True, transB=True, accumulate=True, compute=ctx.compute)
-        _wgrad_launch(in_place, (g, agg, h), launch_out_grads)
+            gemm(*l_args, **l_kw)
+            gemm(*r_args, **r_kw)
+        if not (in_place and ctx.compute == BF16 and _wgrad_groupable(Ho, H, g, g.stride(0), agg, H, N)
+                and _wgrad_defer(l_args, l_kw, (g, agg)) and _wgrad_defer(r_args, r_kw, (g, h))):
+            _wgrad_launch(in_place, (g, agg, h), launch_out_grads)
         d_agg = torch.empty_like(h)
         gemm(N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H, transB=True, compute=ctx.compute)
         d_pre = torch.empty_like(h)  # gradient at the projection's pre-activation: transposed gather gated by xp > 0
@@ -853,9 +1076,10 @@ class _SageMean(torch.autograd.Function):
             d_h = torch.empty_like(h)
             gemm(N, H, g, g.stride(0), Wr_o, H, Ho, d_h, H, A2=d_pre, lda2=H, B2=Wp_o, ldb2=H, K2=H, transB=True,
                  compute=ctx.compute)
-        _wgrad_launch(rWp is None and rbp is None, (d_pre, h),
-                      lambda: gemm(H, H, d_pre, H, h, H, N, dWp, H, transA=True, transB=True, accumulate=True,
-                                   compute=ctx.compute, dbias=dbp))
+        p_args, p_kw = (H, H, d_pre, H, h, H, N, dWp, H), dict(transA=True, transB=True, accumulate=True, compute=ctx.compute,
+                                                               dbias=dbp)
+        if not (rWp is None and rbp is None and ctx.compute == BF16 and _wgrad_defer(p_args, p_kw, (d_pre, h))):
+            _wgrad_launch(rWp is None and rbp is None, (d_pre, h), lambda: gemm(*p_args, **p_kw))
         return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None)
 
 
@@ -1328,6 +1552,48 @@ def scatter_add_rows_f64(x, label, bank, count, groups=None):
     order, seg_ptr, seg_label = order.to(dev), seg_ptr.to(dev), seg_label.to(dev)
     _ck(_lib.load().egk_segment_sum_rows_f64(_stream(), _p(x), _p(order), _p(seg_ptr), _p(seg_label), _p(bank), _p(count),
                                             seg_label.numel(), x.shape[1], bank.shape[0], _dt(x)), "egk_segment_sum_rows_f64")
+
+
+# ---- phase stamps (development) ---------------------------------------------------------------------------------
+_stamps = {"buf": None, "names": []}
+
+
+def stamps_enable(device="cuda", slots: int = 256):
+    """Turn ``stamp(name)`` calls into one-lane launches that record the device wall clock (captured with the step:
+    every replay rewrites the slots).  tools/phase_stamps.py reads them back."""
+    _stamps["buf"] = torch.zeros(slots, dtype=torch.int64, device=device)
+    _stamps["names"] = []
+
+
+def stamp(name: str, seq: bool = False):
+    """``seq``: the name gets a running index per step (reset by stamp("step_start")): stamps inside autograd nodes that
+    run once per layer."""
+    buf = _stamps["buf"]
+    if buf is None:
+        return
+    if name == "step_start":
+        _stamps["seq"] = {}
+    if seq:
+        k = _stamps.setdefault("seq", {}).get(name, 0)
+        _stamps["seq"][name] = k + 1
+        name = f"{name}[{k}]"
+    names = _stamps["names"]
+    if name in names:
+        idx = names.index(name)
+    else:
+        names.append(name)
+        idx = len(names) - 1
+    _ck(_lib.load().egk_stamp(_stream(), _p(buf), idx), "egk_stamp")
+
+
+def stamps_read():
+    """[(name, microseconds since the first stamp)] of the last recorded step (100 MHz counter)."""
+    buf = _stamps["buf"]
+    if buf is None:
+        return []
+    v = buf.cpu().tolist()
+    t0 = min(v[i] for i in range(len(_stamps["names"])))
+    return [(n, (v[i] - t0) / 100.0) for i, n in enumerate(_stamps["names"])]
 
 
 # ---- profiling --------------------------------------------------------------------------------------------------

@@ -44,6 +44,10 @@ int egk_prof_count(void);
 int egk_prof_get(int id, char* name, int name_len, int64_t* launches, double* total_ms,
                  double* alg_flops, double* alg_bytes);
 
+/* Development aid: a one-lane launch that writes the device wall clock (100 MHz constant-rate counter) to buf[idx] when
+ * the stream reaches it -- phase boundaries of a captured step timed in place (tools/phase_stamps.py). */
+int egk_stamp(egk_stream_t s, uint64_t* buf, int32_t idx);
+
 /* ---- dense contractions (MFMA) ---------------------------------------------------------
  * C[M,N] = act(alpha * (op(A) . op(B)^T) + (accumulate ? C : 0) + bias[n]) + residual[m,n]
  * where the contraction runs over K = K1 + K2 with a two-source split:
@@ -89,6 +93,13 @@ typedef struct egk_gemm_desc {
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
+/* Grouped launch: ``count`` (<= 4) independent contractions of the SAME layout (transA / transB), bf16 operands with
+ * 16-byte aligned rows, every K source a multiple of 64, no split-K, in ONE launch (blockIdx.y = problem).  Replaces the
+ * per-task projection heads of the multi-task step -- ProjectionTask.forward_features of every enabled task
+ * (models/tasks/task.py:17-26, called per task at main_temporal.py:93-126) -- whose contractions have the same shapes but
+ * read different rows of the backbone output and different weights.  Results are bit-identical to ``count`` egk_gemm
+ * calls that pick the same tile variant.  dbias (fused bias gradient of the dW form) is allowed. */
+int egk_gemm_grouped(egk_stream_t s, const egk_gemm_desc* descs, int32_t count);
 int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute);
 /* development knob of the row kernels (launch geometry only, results unchanged): returns the previous value */
 int egk_tune(int32_t key, int32_t value);
@@ -144,6 +155,17 @@ int egk_graphln_bwd(egk_stream_t s, const void* dy, const void* x, const float* 
  * cols, on whatever stream should carry it -- dw / db feed nothing but the optimizer, the kernels that need dx need not
  * wait for them.  dw[c] += sum of partials, db[c] += ... (accumulating, like the fused form). */
 int egk_ln_bwd_reduce(egk_stream_t s, const void* ws, float* dw, float* db, int32_t rows, int32_t cols, int32_t n_seg);
+/* Grouped row LayerNorm(+ReLU): n_groups (<= 4) consecutive row ranges [row_ptr[g], row_ptr[g+1]) of ONE [rows, cols]
+ * matrix, each with its own (w, b) -- the LayerNorms of the per-task projection heads (models/tasks/task.py:20-21) in one
+ * launch.  No dropout.  bwd writes dx and per-workgroup partial rows of dw / db:
+ *   ws[(g * egk_rowln_bwd_ws_rows(max range rows) + block)][2][cols]   (f32)
+ * reduce range g with egk_ln_bwd_reduce(ws + g * blocks * 2 * cols, dw_g, db_g, max range rows, cols, 0). */
+int egk_rowln_group_fwd(egk_stream_t s, const void* x, const float* const* w, const float* const* b, const int32_t* row_ptr,
+                        int32_t n_groups, void* y, float* mean, float* rstd, int32_t cols, float eps, int32_t relu,
+                        int32_t dtype);
+int egk_rowln_group_bwd(egk_stream_t s, const void* dy, const void* x, const float* const* w, const float* const* b,
+                        const int32_t* row_ptr, int32_t n_groups, const float* mean, const float* rstd, void* dx, float* ws,
+                        int32_t cols, int32_t relu, int32_t dtype);
 
 /* ---- positional encoding  gnn.PositionalEncoding + add   models/graph.py:37,63 ----------
  * y[n, c] = x[n, c] + (c < C/2 ? sin(pos[n]*freq[c]) : cos(pos[n]*freq[c-C/2])) */

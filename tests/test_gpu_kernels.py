@@ -909,3 +909,96 @@ def test_csr_gather_rows_with_hundreds_of_edges(ops, dtype, T, B):
         ops._csr_gather(xd, gd.t_rowptr, gd.t_col, gd.t_wgt, gated, o_b, gd.t_heavy, mode)
         torch.testing.assert_close(o_f.float().cpu().double(), ref_f, **tol)
         torch.testing.assert_close(o_b.float().cpu().double(), ref_b, **tol)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# grouped launches (the projection heads of several task batches as one chain)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["nn", "nt", "tt"])
+@pytest.mark.parametrize("sizes", [[(2048, 1024, 1024)] * 3, [(256, 128, 64), (192, 256, 64), (64, 128, 128), (448, 128, 64)],
+                                   [(6144, 1024, 1024), (2048, 1024, 1024)]])
+def test_gemm_grouped_equals_separate_contractions(ops, layout, sizes):
+    """egk_gemm_grouped (one launch, blockIdx.y = problem) against the fp64 product of the bf16-rounded operands, and
+    against egk_gemm problem by problem (same kernel body; the tile variant may differ: fp32 accumulation-order noise only)."""
+    g = gen(len(sizes) * 7 + len(layout))
+    ta, tb = layout[0] == "t", layout[1] == "t"
+    probs, refs, outs, singles = [], [], [], []
+    for (M, N, K) in sizes:
+        if layout == "tt":
+            K = (K + 63) // 64 * 64
+        A = torch.randn((K, M) if ta else (M, K), generator=g).to(torch.bfloat16)
+        B = torch.randn((K, N) if tb else (N, K), generator=g).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g)
+        opA = (A.t() if ta else A).double()
+        opB = (B.t() if tb else B).double()
+        acc = layout == "tt"
+        c0 = torch.randn(M, N, generator=g) if acc else torch.zeros(M, N)
+        refs.append(opA @ opB.t() + (c0.double() if acc else bias.double()))
+        Ad, Bd = A.to(DEV), B.to(DEV)
+        out = c0.clone().to(DEV) if acc else torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        one = out.clone()
+        kw = dict(transA=ta, transB=tb, compute=ops.BF16)
+        kw.update(dict(accumulate=True) if acc else dict(bias=bias.to(DEV)))
+        args = (M, N, Ad, Ad.stride(0), Bd, Bd.stride(0), K, out, N)
+        probs.append((args, kw))
+        outs.append(out)
+        ops.gemm(M, N, Ad, Ad.stride(0), Bd, Bd.stride(0), K, one, N, allow_splitk=False, **kw)
+        singles.append(one)
+    ops.gemm_grouped(probs)
+    for out, one, ref in zip(outs, singles, refs):
+        tol = dict(rtol=1e-3, atol=1e-3) if out.dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(out.double().cpu(), ref, **tol)
+        torch.testing.assert_close(out.float(), one.float(), rtol=1e-5, atol=1e-4 if out.dtype == torch.float32 else 2e-2)
+
+
+def test_gemm_grouped_rejects_what_it_cannot_run(ops):
+    A = torch.randn(64, 96, device=DEV).to(torch.bfloat16)  # K = 96 is not a multiple of 64
+    B = torch.randn(64, 96, device=DEV).to(torch.bfloat16)
+    out = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of 64"):
+        ops.gemm_grouped([((64, 64, A, 96, B, 96, 96, out, 64), {}), ((64, 64, A, 96, B, 96, 96, out, 64), {})])
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cols,rows", [(1024, [2048, 2048, 2048]), (256, [64, 192, 5]), (640, [100, 0, 37, 64])])
+def test_rowln_grouped_equals_per_range_launches(ops, dt, cols, rows):
+    """The grouped row LayerNorm + ReLU (one launch, one parameter pair per row range) forward and backward against the
+    single-range kernel run range by range: y / dx to last-bit noise (a few % of the elements differ in the last bit), dw / db to summation-order noise."""
+    import ctypes as C
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(cols + len(rows))
+    G, n = len(rows), sum(rows)
+    ptr = [0]
+    for r in rows:
+        ptr.append(ptr[-1] + r)
+    x = torch.randn(n, cols, generator=g).to(dt).to(DEV)
+    dy = torch.randn(n, cols, generator=g).to(dt).to(DEV)
+    ws_, bs_ = [torch.randn(cols, generator=g).to(DEV) for _ in rows], [torch.randn(cols, generator=g).to(DEV) for _ in rows]
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    row_ptr = (C.c_int32 * (G + 1))(*ptr)
+    s = ops._stream()
+    assert lib.egk_rowln_group_fwd(s, ops._p(x), ops._ptr_array(ws_), ops._ptr_array(bs_), row_ptr, G, ops._p(y), ops._p(mean),
+                                   ops._p(rstd), cols, 1e-5, 1, ops._dt(x)) == 0
+    grid = lib.egk_rowln_bwd_ws_rows(max(rows))
+    ws = torch.zeros(G * grid * 2 * cols, device=DEV)
+    assert lib.egk_rowln_group_bwd(s, ops._p(dy), ops._p(x), ops._ptr_array(ws_), ops._ptr_array(bs_), row_ptr, G, ops._p(mean),
+                                   ops._p(rstd), ops._p(dx), ops._p(ws), cols, 1, ops._dt(x)) == 0
+    for k in range(G):
+        if rows[k] == 0:
+            continue
+        xs = x[ptr[k]:ptr[k + 1]].clone().requires_grad_(True)
+        w1, b1 = ws_[k].clone().requires_grad_(True), bs_[k].clone().requires_grad_(True)
+        y1 = ops.row_layernorm(xs, w1, b1, 1e-5, relu=True)
+        y1.backward(dy[ptr[k]:ptr[k + 1]])
+        # (same source, two kernel instantiations: the compiler may contract a multiply-add differently -> last-bit noise)
+        ulp = dict(rtol=2e-6, atol=2e-6) if dt == torch.float32 else dict(rtol=8e-3, atol=8e-3)
+        torch.testing.assert_close(y[ptr[k]:ptr[k + 1]].float(), y1.detach().float(), **ulp)
+        torch.testing.assert_close(dx[ptr[k]:ptr[k + 1]].float(), xs.grad.float(), **ulp)
+        dw, db = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+        part = ws[k * grid * 2 * cols:]
+        assert lib.egk_ln_bwd_reduce(s, ops._p(part), ops._p(dw), ops._p(db), max(rows), cols, 0) == 0
+        tol = dict(rtol=1e-4, atol=1e-4 * max(1.0, rows[k] ** 0.5))
+        torch.testing.assert_close(dw, w1.grad, **tol)
+        torch.testing.assert_close(db, b1.grad, **tol)

@@ -605,3 +605,54 @@ def test_onehot_sigmoid_focal_kernel_vs_autograd(A, gamma, alpha):
     (ref * w.double()).sum().backward()
     torch.testing.assert_close(loss.detach().double().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(xd.grad.double().cpu(), x64.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("what", ["grouped_heads", "wgrad_grouping"])
+def test_grouped_launches_equal_the_per_problem_launches(A, what):
+    """engine.MTLStep with (a) the task heads' projections as ONE chain of grouped launches (ops.grouped_projection) and (b) the
+    H x H weight gradients parked and issued four at a time as one grouped launch (ops._wgrad_defer), each against the same
+    step without it: objective, loss vectors and every parameter after 3 Adam steps (bf16 mode: the paths run the same
+    kernel bodies with other tile variants / no split-K -> fp32 accumulation-order noise, then bf16 rounding)."""
+    import argparse
+    import bench
+
+    def run(on):
+        args = argparse.Namespace(hidden=256, trn_hidden=256, dropout=0.0, compute="bf16", workload="mtl4", batch=8, T=16)
+        A.ops.set_compute("bf16")
+        A.ops.manual_seed(11)
+        model, tasks, crit, weights, dev, merged = bench.build_workload(args, 0, torch.device(DEV))
+        model.to(DEV).train()
+        for t in tasks.values():
+            t.to(DEV).train()
+        params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
+        opt = A.FlatAdam(params, lr=1e-3, weight_decay=1e-5)
+        step = A.engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=True)
+        step.grouped_heads = on if what == "grouped_heads" else False
+        step.wgrad_grouping = on if what == "wgrad_grouping" else False
+        used = []
+        name = "grouped_projection" if what == "grouped_heads" else "gemm_grouped"
+        orig = getattr(A.ops, name)
+
+        def spy(*a, **k):
+            used.append(1)
+            return orig(*a, **k)
+        setattr(A.ops, name, spy)
+        try:
+            outs = [step.step(dev, merged) for _ in range(3)]
+        finally:
+            setattr(A.ops, name, orig)
+        torch.cuda.synchronize()
+        return outs, opt.flat_p.clone(), len(used)
+
+    try:
+        (o1, p1, n1), (o0, p0, n0) = run(True), run(False)
+    finally:
+        A.ops.set_compute("bf16")
+    # the first step builds the optimizer's flat buffers on the per-problem paths; the grouped ones run from the second on
+    assert n0 == 0 and (n1 == 2 if what == "grouped_heads" else n1 >= 4), (n0, n1)
+    for (t1, v1), (t0, v0) in zip(o1, o0):
+        torch.testing.assert_close(t1, t0, rtol=2e-3, atol=2e-3)
+        for k in v0:
+            torch.testing.assert_close(v1[k], v0[k], rtol=2e-2, atol=2e-2)
+    rel = float((p1 - p0).norm() / p0.norm())
+    assert rel < 2e-3, rel

@@ -10,7 +10,10 @@ rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]) for r in rows]
 ev.sort()
 # replays are delimited by the Adam kernel (one per step, the last kernel of a replay)
-ends = [i for i, e in enumerate(ev) if e[3].startswith("void egk::adam_kernel") or "adam_kernel" in e[3]]
+# (a captured step may issue Adam in several launches: early slices beside the last weight gradient, then the rest --
+#  the step ends with the last Adam launch of such a group)
+adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[3]]
+ends = [i for i in adam if not any("adam_kernel" in ev[j][3] for j in range(i + 1, min(i + 4, len(ev))))]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 hi = ends[-back]
 lo = ends[-back - 1] + 1
@@ -45,3 +48,9 @@ for t, d in pts:
     level += d
     last = t
 print("time with k kernels in flight: " + ", ".join(f"{k}: {v / 1e3:.0f} us" for k, v in sorted(hist.items())))
+if len(sys.argv) > 3:  # full listing of the replay: start (us from the replay's first start), duration, queue, kernel
+    import re
+    with open(sys.argv[3], "w") as f:
+        for s, e, q, k in step:
+            k = re.sub(r"^void ", "", k).replace("egk::", "")
+            f.write(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:7.1f} q{q} {k[:100]}\n")
