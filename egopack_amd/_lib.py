@@ -58,6 +58,7 @@ SIGNATURES = {
     "egk_rowln_bwd_ws_rows": (C.c_int, [i32]),
     "egk_rowln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
     "egk_ln_bwd_reduce": (C.c_int, [vp, vp, vp, vp, i32, i32, i32]),
+    "egk_ln_bwd_reduce_multi": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),
     "egk_rowln_group_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, f32, i32, i32]),
     "egk_rowln_group_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32]),
     "egk_graphln_ws_bytes": (i64, [i32, i32, i32]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "egk_onehot_sigmoid_loss_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, i32]),
     "egk_ce_fwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, i32, i32, f32, i32]),
     "egk_ce_bwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, f32, i32]),
+    "egk_ce_fused": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i64, vp, vp, i64, i32, f32, f32, i32]),
     "egk_bce_fwd": (C.c_int, [vp, vp, vp, vp, i32]),
     "egk_bce_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
     "egk_dropout_fwd": (C.c_int, [vp, vp, vp, vp, i64, f32, u64, u64, vp, i32]),

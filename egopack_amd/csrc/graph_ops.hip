@@ -69,6 +69,25 @@ __device__ __forceinline__ void csr_accumulate(const T* __restrict__ x, const in
         const int my_c = lane < cnt ? col[my_e] : 0;
         const float my_w = (wgt && lane < cnt) ? wgt[my_e] : 1.f;
         int e = 0;
+        if constexpr (NV == 1) {
+            // a column slice of a listed heavy row (one float4 per lane per neighbour row): 16 neighbour rows in flight --
+            // with 4 the walk over the fan-out node's 31 edges is 8 dependent round trips, with 16 it is 2.  The rows are
+            // still ADDED in edge order.
+            for (; e + 16 <= cnt; e += 16) {
+                float4 v[16];
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const T* su = x + (long long)__shfl(my_c, e + u, 64) * stride;
+                    w[u] = __shfl(my_w, e + u, 64);
+                    v[u] = ld4(su, lane * 4, cols, vec);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    acc[0].x += w[u] * v[u].x; acc[0].y += w[u] * v[u].y; acc[0].z += w[u] * v[u].z; acc[0].w += w[u] * v[u].w;
+                }
+            }
+        }
         for (; e + 4 <= cnt; e += 4) {
             const T* s0 = x + (long long)__shfl(my_c, e + 0, 64) * stride;
             const T* s1 = x + (long long)__shfl(my_c, e + 1, 64) * stride;

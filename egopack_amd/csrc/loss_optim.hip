@@ -63,6 +63,58 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
+// ---- fused multi-head cross entropy: loss AND its gradient in one launch -----------------------------------------------------
+// The training heads of the engine know the gradient of the objective with respect to every loss-vector element when the
+// loss is computed: objective = sum_t w_t * mean(loss_t)  =>  d objective / d loss_t[n] = w_t / N_t, a constant.  One wave
+// per row then does, for every head h of the task (verb, noun): loss[n] += CE_h(n) and
+//   dlogits_h[n, c] = gscale * (softmax_h(n)[c] - target_h(n)[c])      (0 for ignored rows)
+// written straight into the classifier bank's operand buffer, zero-filling the bank's pad columns [C_h, pad_h) on the way
+// (the buffer needs no memset).  Replaces 2 forward + 2 backward launches per two-head task.
+constexpr int CE_MAX_HEADS = 4;
+struct CEHeads {
+    const float* logits[CE_MAX_HEADS];
+    long long ld[CE_MAX_HEADS];
+    int C[CE_MAX_HEADS];
+    int pad[CE_MAX_HEADS];     // columns [C, pad) of the gradient block are set to zero
+    long long dcol[CE_MAX_HEADS];  // first column of the head's block in the gradient buffer
+};
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fused_kernel(const CEHeads H, int n_heads, const long long* __restrict__ y, long long ys,
+                                                       float* __restrict__ loss, T* __restrict__ dlogits, long long ldd, int rows,
+                                                       float smoothing, float gscale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        float total = 0.f;
+        for (int h = 0; h < n_heads; ++h) {
+            const float* lr = H.logits[h] + (long long)row * H.ld[h];
+            const int C = H.C[h];
+            T* dr = dlogits + (long long)row * ldd + H.dcol[h];
+            const long long t = y[(long long)row * ys + h];
+            const bool live = t >= 0 && t < C;
+            float mx = -INFINITY;
+            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+            mx = wave_max(mx);
+            float se = 0.f, sx = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float v = lr[c];
+                se += expf(v - mx);
+                sx += v;
+            }
+            se = wave_sum(se);
+            sx = wave_sum(sx);
+            const float l = mx + logf(se);
+            if (live) total += l - (1.f - smoothing) * lr[t] - (smoothing > 0.f ? smoothing / C * sx : 0.f);
+            const float sm = smoothing > 0.f ? smoothing / C : 0.f;
+            for (int c = lane; c < H.pad[h]; c += 64) {
+                float d = 0.f;
+                if (live && c < C) d = gscale * (expf(lr[c] - l) - (c == t ? 1.f - smoothing : 0.f) - sm);
+                st1t(dr + c, d);
+            }
+        }
+        if (lane == 0) loss[row] = total;
+    }
+}
+
 // ---- BCE with logits ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const long long* __restrict__ y,
                                                       float* __restrict__ loss, int n) {
@@ -347,6 +399,27 @@ int egk_ce_bwd(egk_stream_t stream, const float* logits, int64_t ld, const int64
                                              (const long long*)y, (long long)y_stride, lse, gloss, (T*)dlogits, (long long)ldd, rows,
                                              C, smoothing));
     return check_launch("egk_ce_bwd");
+}
+
+int egk_ce_fused(egk_stream_t stream, const float* const* logits, const int64_t* ld, const int32_t* C, const int32_t* pad,
+                 const int64_t* dcol, int32_t n_heads, const int64_t* y, int64_t y_stride, float* loss, void* dlogits, int64_t ldd,
+                 int32_t rows, float smoothing, float gscale, int32_t dtype) {
+    EGK_REQUIRE(logits && ld && C && pad && dcol && y && loss && dlogits, "egk_ce_fused: null pointer");
+    EGK_REQUIRE(n_heads >= 1 && n_heads <= CE_MAX_HEADS, "egk_ce_fused: 1 .. %d heads", CE_MAX_HEADS);
+    if (rows == 0) return 0;
+    CEHeads H;
+    double bytes = 0;
+    for (int h = 0; h < CE_MAX_HEADS; ++h) {
+        const int k = h < n_heads ? h : n_heads - 1;
+        EGK_REQUIRE(logits[k] && C[k] >= 1 && pad[k] >= C[k], "egk_ce_fused: bad head %d", k);
+        H.logits[h] = logits[k]; H.ld[h] = ld[k]; H.C[h] = C[k]; H.pad[h] = pad[k]; H.dcol[h] = dcol[k];
+        if (h < n_heads) bytes += 6.0 * rows * C[k];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CE_FWD, s, 0, bytes);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(ce_fused_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, H, n_heads, (const long long*)y,
+                                             (long long)y_stride, loss, (T*)dlogits, (long long)ldd, rows, smoothing, gscale));
+    return check_launch("egk_ce_fused");
 }
 
 int egk_bce_fwd(egk_stream_t stream, const float* logits, const int64_t* y, float* loss, int32_t n) {

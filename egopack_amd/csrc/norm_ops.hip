@@ -287,6 +287,55 @@ __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __res
     }
 }
 
+// several reductions of that kind in ONE launch (blockIdx.y = problem): the dw / db reductions of the norm layers whose
+// backward has run since the last weight-gradient flush (each is ~4 MB of partial rows: launch latency, not bytes)
+constexpr int REDUCE_MAX = 8;
+struct ReduceBatch {
+    const float* ws[REDUCE_MAX];
+    float* oa[REDUCE_MAX];
+    float* ob[REDUCE_MAX];
+    int nblk[REDUCE_MAX];
+    int cols[REDUCE_MAX];
+};
+__global__ __launch_bounds__(256) void partial_reduce2_multi_kernel(const ReduceBatch B) {
+    __shared__ float red[2][16][16];
+    const int p = blockIdx.y;
+    const float* __restrict__ ws = B.ws[p];
+    const int nblk = B.nblk[p], cols = B.cols[p];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cg;
+    if (blockIdx.x * 16 >= cols) return;  // (block-uniform: the grid is sized for the widest problem)
+    float a = 0.f, d = 0.f;
+    if (c < cols)
+        for (int k = rg; k < nblk; k += 128) {  // the summation order of partial_reduce2_kernel: same bits
+            float va[8], vd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = k + 16 * u < nblk;
+                va[u] = in ? ws[((long long)(k + 16 * u) * 2 + 0) * cols + c] : 0.f;
+                vd[u] = in ? ws[((long long)(k + 16 * u) * 2 + 1) * cols + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += va[u];
+                d += vd[u];
+            }
+        }
+    red[0][rg][cg] = a;
+    red[1][rg][cg] = d;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        a = d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            a += red[0][k][cg];
+            d += red[1][k][cg];
+        }
+        if (B.oa[p]) B.oa[p][c] += a;
+        if (B.ob[p]) B.ob[p][c] += d;
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // graph-mode LayerNorm + LeakyReLU (statistics over all elements of a row segment)
 // -------------------------------------------------------------------------------------------
@@ -786,6 +835,32 @@ int egk_ln_bwd_reduce(egk_stream_t stream, const void* ws, float* dw, float* db,
     ProfScope prof(n_seg > 0 ? KID_GRAPHLN_BWD_REDUCE : KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
     hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
     return check_launch("egk_ln_bwd_reduce");
+}
+
+/* ``count`` (<= 8) reductions egk_ln_bwd_reduce(ws[i], dw[i], db[i], rows[i], cols[i], n_seg[i]) in one launch. */
+int egk_ln_bwd_reduce_multi(egk_stream_t stream, const void* const* ws, float* const* dw, float* const* db, const int32_t* rows,
+                            const int32_t* cols, const int32_t* n_seg, int32_t count) {
+    EGK_REQUIRE(ws && dw && db && rows && cols && n_seg && count >= 1 && count <= REDUCE_MAX, "egk_ln_bwd_reduce_multi: 1 .. %d reductions",
+                REDUCE_MAX);
+    ReduceBatch B;
+    int max_cols = 0;
+    double bytes = 0;
+    for (int i = 0; i < REDUCE_MAX; ++i) {
+        const int k = i < count ? i : count - 1;
+        EGK_REQUIRE(ws[k] && dw[k] && db[k], "egk_ln_bwd_reduce_multi: null pointer");
+        const int grid = row_grid(rows[k]);
+        B.ws[i] = n_seg[k] > 0 ? (const float*)((const char*)ws[k] + (int64_t)grid * n_seg[k] * 2 * 8) : (const float*)ws[k];
+        B.oa[i] = dw[k]; B.ob[i] = db[k]; B.nblk[i] = rows[k] > 0 ? grid : 0; B.cols[i] = cols[k];
+        if (i < count) {
+            max_cols = cols[k] > max_cols ? cols[k] : max_cols;
+            bytes += 8.0 * grid * cols[k];
+        }
+    }
+    if (max_cols == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, bytes);
+    hipLaunchKernelGGL(partial_reduce2_multi_kernel, dim3(cdiv(max_cols, 16), count), dim3(256), 0, s, B);
+    return check_launch("egk_ln_bwd_reduce_multi");
 }
 
 int64_t egk_graphln_ws_bytes(int32_t rows, int32_t cols, int32_t n_seg) {

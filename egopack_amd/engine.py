@@ -570,7 +570,6 @@ class StepBase:
         if not hasattr(self, "_adam_stream"):
             self._adam_stream = torch.cuda.Stream()
         plan = {"param": first.weight, "lo": lo, "hi": hi, "stream": self._adam_stream, "fired": False}
-
         def hook():
             if plan["fired"]:
                 return
@@ -585,6 +584,9 @@ class StepBase:
             plan["fired"] = True
         plan["hook"] = hook
         return plan
+
+    # (measured and not kept: Adam over the SAGE + head slots started when backward enters the temporal pooling, beside the
+    #  TRN backward chain: 1.85 vs 1.75 ms -- the HBM-bound launch slows the chain more than the shorter tail saves)
 
     def _early_adam_ok(self) -> bool:
         return bool(self.early_adam)
@@ -678,12 +680,18 @@ class MTLStep(StepBase):
             ops.stamp("heads_proj_fwd_done")
 
         def head(t, leaf):
-            if grouped:  # ``leaf`` is the task's projected feature block: classifier + loss (+ their backward) only
-                task, d = self.tasks[t], batches[t]
-                logits = task.forward_logits(leaf, d) if t == "oscc" else task.forward_logits(leaf)
-                v = self.criteria[t](logits, d.y)
-            else:
-                v, logits = self._head(t, leaf, batches[t])
+            # AR / LTA: one loss element per node, back-propagated below with the constant w_t / numel -- known before the
+            # loss is computed, so the cross entropy emits its gradient in the same launch (ops.loss_seed)
+            n_loss = leaf.shape[0] if t in ("ar", "lta") else 0
+            with ops.loss_seed(self.weights[t] / n_loss if n_loss else None):
+                if grouped:  # ``leaf`` is the task's projected feature block: classifier + loss (+ their backward) only
+                    task, d = self.tasks[t], batches[t]
+                    logits = task.forward_logits(leaf, d) if t == "oscc" else task.forward_logits(leaf)
+                    v = self.criteria[t](logits, d.y)
+                else:
+                    v, logits = self._head(t, leaf, batches[t])
+            if n_loss and v.numel() != n_loss:
+                raise RuntimeError(f"head {t}: {v.numel()} loss elements where {n_loss} were announced to the fused loss")
             if v.numel():
                 # the constant the objective's backward hands this head (w_t / numel): one tensor per task, filled once
                 key = (t, v.numel(), v.dtype, v.device)

@@ -355,17 +355,27 @@ def _wgrad_groupable(M, N, A, lda, B, ldb, K) -> bool:
             and ((M + 127) // 128) * ((N + 127) // 128) <= 128)
 
 
-def _wgrad_defer(args, kw, tensors) -> bool:
+def _on_excluded_stream() -> bool:
+    cur = torch.cuda.current_stream()
+    return (cur.device.index, cur.cuda_stream) in _wgrad["exclude"]
+
+
+def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False) -> bool:
     """Park the dW contraction ``gemm(*args, **kw)`` (transA, transB, accumulate into a gradient slot) for the next grouped
-    launch.  False: not eligible (the caller launches it itself)."""
+    launch.  False: not eligible (the caller launches it itself).  On an excluded stream (the task-head streams of the
+    engine) nothing is parked unless ``park_on_excluded``: such a problem is only PARKED there -- it is issued by a later
+    flush from the backward stream, which by then has joined the head streams (engine._run_heads), never from the head
+    stream itself, where the operands parked by the OTHER head streams would be raced."""
     M, N, A, lda, B, ldb, K = args[:7]
-    main = torch.cuda.current_stream()
-    if not _wgrad_groupable(M, N, A, lda, B, ldb, K) or (main.device.index, main.cuda_stream) in _wgrad["exclude"]:
+    excluded = _on_excluded_stream()
+    if not _wgrad_groupable(M, N, A, lda, B, ldb, K) or (excluded and not park_on_excluded):
         return False
     _wq["items"].append((args, kw))
     _wq["hold"].extend(t for t in tensors if t is not None)
     _wq["tiles"] += ((M + 127) // 128) * ((N + 127) // 128)
-    if len(_wq["items"]) == 4 or _wq["tiles"] >= WGRAD_GROUP_TILES:
+    if excluded:
+        return True
+    if len(_wq["items"]) >= 4 or _wq["tiles"] >= WGRAD_GROUP_TILES:
         flush_wgrad()
     elif not _wgrad["queued"]:  # make sure the end-of-backward join (which flushes) is scheduled
         _wgrad["queued"] = True
@@ -373,26 +383,43 @@ def _wgrad_defer(args, kw, tensors) -> bool:
     return True
 
 
-def _wgrad_defer_call(fn, tensors):
-    """Park a small side-stream launch (the norm layers' dw / db reductions) with the next grouped launch."""
-    _wq["extra"].append(fn)
-    _wq["hold"].extend(t for t in tensors if t is not None)
+def _wgrad_defer_reduce(ws, dw, db, rows, cols, n_seg):
+    """Park a norm layer's dw / db reduction (egk_ln_bwd_reduce arguments) with the next grouped launch: the parked
+    reductions are issued as ONE launch (egk_ln_bwd_reduce_multi)."""
+    _wq["extra"].append((ws, dw, db, rows, cols, n_seg))
+    _wq["hold"].append(ws)
+
+
+def _launch_reductions(reds):
+    lib = _lib.load()
+    for i in range(0, len(reds), 8):
+        chunk = reds[i:i + 8]
+        n = len(chunk)
+        if n == 1:
+            ws, dw, db, rows, cols, n_seg = chunk[0]
+            _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, n_seg), "egk_ln_bwd_reduce")
+            continue
+        _ck(lib.egk_ln_bwd_reduce_multi(_stream(), _ptr_array([c[0] for c in chunk]), _ptr_array([c[1] for c in chunk]),
+                                        _ptr_array([c[2] for c in chunk]), (C.c_int32 * n)(*[c[3] for c in chunk]),
+                                        (C.c_int32 * n)(*[c[4] for c in chunk]), (C.c_int32 * n)(*[c[5] for c in chunk]), n),
+            "egk_ln_bwd_reduce_multi")
 
 
 def flush_wgrad():
     items, hold, extra = _wq["items"], _wq["hold"], _wq["extra"]
-    if not items and not extra:
+    if (not items and not extra) or _on_excluded_stream():  # (a head stream never issues what other streams parked)
         return
     _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
 
     def launch():
-        if len(items) == 1:
-            a, kw = items[0]
-            gemm(*a, **kw)
-        elif items:
-            gemm_grouped(items)
-        for fn in extra:
-            fn()
+        for i in range(0, len(items), 4):
+            chunk = items[i:i + 4]
+            if len(chunk) == 1:
+                gemm(*chunk[0][0], **chunk[0][1])
+            else:
+                gemm_grouped(chunk)
+        if extra:
+            _launch_reductions(extra)
     _wgrad_launch(True, hold, launch)
 
 
@@ -601,6 +628,13 @@ class _ClassifierBank(torch.autograd.Function):
         N = views["n"]
         if gbuf is None:  # (forward ran without a gradient consumer in sight; cannot happen under autograd)
             gbuf = torch.zeros((M, N), dtype=x.dtype, device=x.device)
+        if not ctx.state["pads"]:  # allocated uncleared for the fused loss, which then did not run: clear the pads now
+            ends = [r for r, _ in views["rows"][1:]] + [N]
+            for (r0, n), e in zip(views["rows"], ends):
+                if e > r0 + n:
+                    gbuf[:, r0 + n:e].zero_()
+                if r0 not in ctx.state["filled"]:
+                    gbuf[:, r0:r0 + n].zero_()
         for (r0, n), g in zip(views["rows"], gs):
             if r0 in ctx.state["filled"] or g is None:
                 continue  # the loss wrote these columns itself (bank_grad_handoff); None: no gradient, columns stay zero
@@ -612,9 +646,10 @@ class _ClassifierBank(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(M, K, gbuf, N, Wop, K, N, dx, K, transB=True, compute=ctx.compute)
-        _wgrad_launch(True, (gbuf, x),
-                      lambda: gemm(N, K, gbuf, N, x, K, M, views["wg"], K, transA=True, transB=True, accumulate=True,
-                                   compute=ctx.compute, dbias=views["bg"]))
+        w_args = (N, K, gbuf, N, x, K, M, views["wg"], K)
+        w_kw = dict(transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=views["bg"])
+        if not (ctx.compute == BF16 and _wgrad_defer(w_args, w_kw, (gbuf, x), park_on_excluded=True)):
+            _wgrad_launch(True, (gbuf, x), lambda: gemm(*w_args, **w_kw))
         return dx, None, None, None, None, None
 
 
@@ -622,8 +657,13 @@ def classifier_bank(x, anchor, views, compute=None):
     """Logits of every classifier of a bank (``views``: optim.FlatAdam._bank_views) as column ranges of ONE
     [rows, sum rows64] f32 contraction output; backward is one dX and one dW contraction over the zero-padded bank."""
     needs = torch.is_grad_enabled() and (x.requires_grad or anchor.requires_grad)
-    gbuf = torch.zeros((x.shape[0], views["n"]), dtype=x.dtype, device=x.device) if needs else None  # pad columns stay zero
-    state = {"filled": set()}
+    # the gradient operand: zero pad columns.  Under a known loss seed (loss_seed) the fused cross entropy writes every
+    # column of every block itself, pads included, so the buffer is not cleared first (state["pads"] records that it did)
+    lazy = _bank_handoff["on"] and _loss_seed["coef"] is not None
+    gbuf = None
+    if needs:
+        gbuf = (torch.empty if lazy else torch.zeros)((x.shape[0], views["n"]), dtype=x.dtype, device=x.device)
+    state = {"filled": set(), "pads": not lazy}
     outs = _ClassifierBank.apply(x, anchor, views, gbuf, state, _compute_for(x) if compute is None else compute)
     if _bank_handoff["on"] and gbuf is not None:
         for o, (r0, _) in zip(outs, views["rows"]):
@@ -772,11 +812,8 @@ class _GroupedProjection(torch.autograd.Function):
         _ck(lib.egk_rowln_group_bwd(_stream(), _p(da), _p(h1), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(mean), _p(rstd),
                                     _p(dh1), _p(ws), H1, 1, _dt(h1)), "egk_rowln_group_bwd")
 
-        def reduce_ln():
-            for g in range(G):
-                part = ws[g * grid * 2 * H1 * 4:]
-                _ck(lib.egk_ln_bwd_reduce(_stream(), _p(part), _p(slots[g][2]), _p(slots[g][3]), max(rows), H1, 0), "egk_ln_bwd_reduce")
-        _wgrad_launch(True, (ws,), reduce_ln)
+        reds = [(ws[g * grid * 2 * H1 * 4:], slots[g][2], slots[g][3], max(rows), H1, 0) for g in range(G)]
+        _wgrad_launch(True, (ws,), lambda: _launch_reductions(reds))
         dxs = [None] * G
         if any(ctx.needs_input_grad[3:3 + G]):
             dx = torch.empty((ptr[-1], H), dtype=dt, device=dev)
@@ -868,11 +905,11 @@ class _RowLN(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), None, None,
                                   _p(ws), rows, cols, int(ctx.relu), ctx.p, _dt(x)), "egk_rowln_bwd")
-            red = lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, 0), "egk_ln_bwd_reduce")
             if _wq["on"] and _wgrad["enabled"]:
-                _wgrad_defer_call(red, (ws,))
+                _wgrad_defer_reduce(ws, dw, db, rows, cols, 0)
             else:
-                _wgrad_launch(True, (ws,), red)
+                _wgrad_launch(True, (ws,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, 0),
+                                                       "egk_ln_bwd_reduce"))
             return dx, None, None, None, None, None, None
         ws = workspace(nbytes, x.device)
         _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), _p(dw), _p(db),
@@ -928,11 +965,11 @@ class _GraphLN(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), None, None, _p(seg_ptr),
                                     n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws), _dt(x)), "egk_graphln_bwd")
-            red = lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, n_seg), "egk_ln_bwd_reduce")
             if _wq["on"] and _wgrad["enabled"]:
-                _wgrad_defer_call(red, (ws,))
+                _wgrad_defer_reduce(ws, dw, db, rows, cols, n_seg)
             else:
-                _wgrad_launch(True, (ws,), red)
+                _wgrad_launch(True, (ws,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, n_seg),
+                                                       "egk_ln_bwd_reduce"))
             return dx, None, None, None, None, None
         ws = workspace(nbytes, x.device)
         _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(seg_ptr),
@@ -1181,15 +1218,70 @@ def _grad_dtype_of(t: torch.Tensor) -> torch.dtype:
     return getattr(t, "_egk_grad_dtype", torch.float32)
 
 
+_loss_seed = {"coef": None}
+
+
+class loss_seed:
+    """``with loss_seed(c):`` -- inside, the caller guarantees that the loss vector computed next is back-propagated with the
+    constant gradient ``c`` for every element (the engine's training heads: objective = sum_t w_t * mean(loss_t), so
+    c = w_t / numel).  A multi-head cross entropy whose logits come from ``classifier_bank`` then computes loss AND gradient
+    in one launch (egk_ce_fused) and its backward is a no-op."""
+
+    def __init__(self, coef):
+        self.coef = coef
+
+    def __enter__(self):
+        self.prev, _loss_seed["coef"] = _loss_seed["coef"], self.coef
+
+    def __exit__(self, *a):
+        _loss_seed["coef"] = self.prev
+
+
 class _CE(torch.autograd.Function):
+    @staticmethod
+    def _fused(ctx, smoothing, y, logits):
+        """One launch for loss and gradient when the seed is known and every head's logits are blocks of ONE bank buffer."""
+        if _loss_seed["coef"] is None or not _bank_handoff["on"] or y.dim() != 2 or y.shape[1] != len(logits) or len(logits) > 4:
+            return None
+        dsts = [getattr(l, "_egk_grad_dst", None) for l in logits]
+        if any(d is None for d in dsts) or any(d[0] is not dsts[0][0] or d[2] is not dsts[0][2] for d in dsts):
+            return None
+        gbuf, state = dsts[0][0], dsts[0][2]
+        if any(d[1] in state["filled"] for d in dsts) or any(l.dtype != torch.float32 or l.stride(1) != 1 for l in logits):
+            return None
+        lib = _lib.load()
+        rows, n = logits[0].shape[0], len(logits)
+        starts = sorted(d[1] for d in dsts)
+        if [d[1] for d in dsts] != starts:
+            return None
+        ends = starts[1:] + [gbuf.shape[1]]
+        loss = torch.empty(rows, dtype=torch.float32, device=gbuf.device)
+        lp = (C.c_void_p * n)(*[l.data_ptr() for l in logits])
+        ld = (C.c_int64 * n)(*[l.stride(0) for l in logits])
+        Cs = (C.c_int32 * n)(*[l.shape[1] for l in logits])
+        pad = (C.c_int32 * n)(*[e - s0 for s0, e in zip(starts, ends)])
+        dcol = (C.c_int64 * n)(*starts)
+        _ck(lib.egk_ce_fused(_stream(), lp, ld, Cs, pad, dcol, n, _p(y), y.shape[1], _p(loss), _p(gbuf), gbuf.stride(0), rows,
+                             smoothing, float(_loss_seed["coef"]), _dt(gbuf)), "egk_ce_fused")
+        if starts[0] > 0:
+            gbuf[:, :starts[0]].zero_()
+        state["filled"].update(starts)
+        state["pads"] = True
+        ctx.fused, ctx.shapes, ctx.seed = True, [tuple(l.shape) for l in logits], float(_loss_seed["coef"])
+        return loss
+
     @staticmethod
     def forward(ctx, smoothing, y, gdt, *logits):
         # loss[n] = sum_h CE(logits[h][n], y[n, h]) with ignore_index -1 (y: [N] or [N, heads] int64)
         _need_gpu(y, *logits)
         lib = _lib.load()
         rows = logits[0].shape[0]
-        loss = torch.empty(rows, dtype=torch.float32, device=logits[0].device)
         y = y.contiguous()
+        ctx.fused = False
+        fused = _CE._fused(ctx, smoothing, y, logits)
+        if fused is not None:
+            return fused
+        loss = torch.empty(rows, dtype=torch.float32, device=logits[0].device)
         ystride = 1 if y.dim() == 1 else y.shape[1]
         saved = []
         ctx.dst = [getattr(l, "_egk_grad_dst", None) if _bank_handoff["on"] else None for l in logits]
@@ -1209,6 +1301,8 @@ class _CE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         lib = _lib.load()
+        if ctx.fused:  # the gradient is already in the bank's operand buffer: placeholders for autograd
+            return (None, None, None, *[torch.empty(s_, dtype=torch.float32, device=gloss.device) for s_ in ctx.shapes])
         y, *saved = ctx.saved_tensors
         gloss = _f32c(gloss)
         grads = []

@@ -155,6 +155,10 @@ int egk_graphln_bwd(egk_stream_t s, const void* dy, const void* x, const float* 
  * cols, on whatever stream should carry it -- dw / db feed nothing but the optimizer, the kernels that need dx need not
  * wait for them.  dw[c] += sum of partials, db[c] += ... (accumulating, like the fused form). */
 int egk_ln_bwd_reduce(egk_stream_t s, const void* ws, float* dw, float* db, int32_t rows, int32_t cols, int32_t n_seg);
+/* ``count`` (<= 8) of those reductions in one launch (the norm layers whose backward ran since the last weight-gradient
+ * flush); same summation order as egk_ln_bwd_reduce: same bits. */
+int egk_ln_bwd_reduce_multi(egk_stream_t s, const void* const* ws, float* const* dw, float* const* db, const int32_t* rows,
+                            const int32_t* cols, const int32_t* n_seg, int32_t count);
 /* Grouped row LayerNorm(+ReLU): n_groups (<= 4) consecutive row ranges [row_ptr[g], row_ptr[g+1]) of ONE [rows, cols]
  * matrix, each with its own (w, b) -- the LayerNorms of the per-task projection heads (models/tasks/task.py:20-21) in one
  * launch.  No dropout.  bwd writes dx and per-workgroup partial rows of dw / db:
@@ -248,6 +252,13 @@ int egk_ce_fwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y
                float* lse, int32_t rows, int32_t C, float smoothing, int32_t accumulate);
 int egk_ce_bwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, const float* lse,
                const float* gloss, void* dlogits, int64_t ldd, int32_t rows, int32_t C, float smoothing, int32_t dtype);
+/* Fused multi-head form for training steps that know d objective / d loss[n] = gscale when the loss is computed (the step
+ * objective is sum_t w_t * mean(loss_t), main_temporal.py:99-128): loss[n] = sum_h CE_h(n) and
+ * dlogits[n, dcol[h] + c] = gscale * (softmax_h - target_h) for c < C[h], 0 for C[h] <= c < pad[h] (the zero-padded column
+ * blocks of the classifier bank's gradient operand), in ONE launch.  y: [rows, y_stride] int64, head h reads column h. */
+int egk_ce_fused(egk_stream_t s, const float* const* logits, const int64_t* ld, const int32_t* C, const int32_t* pad,
+                 const int64_t* dcol, int32_t n_heads, const int64_t* y, int64_t y_stride, float* loss, void* dlogits, int64_t ldd,
+                 int32_t rows, float smoothing, float gscale, int32_t dtype);
 /* nn.BCEWithLogitsLoss(reduction='none') on y.float()  main_temporal.py:123,298; pnr.py:82-83 */
 int egk_bce_fwd(egk_stream_t s, const float* logits, const int64_t* y, float* loss, int32_t n);
 int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const float* gloss, void* dlogits, int32_t n,

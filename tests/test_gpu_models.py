@@ -457,7 +457,7 @@ def test_classifier_bank_equals_the_separate_classifiers(mode):
     heads, H, M = (115, 478), 128, 200
     torch.manual_seed(5)
     ref = RecognitionTask(H, H, heads).to(DEV)
-    tasks = {k: RecognitionTask(H, H, heads).to(DEV) for k in ("bank", "handoff")}
+    tasks = {k: RecognitionTask(H, H, heads).to(DEV) for k in ("bank", "handoff", "seeded")}
     for t in tasks.values():
         t.load_state_dict(ref.state_dict())
     x = torch.randn(M, H, device=DEV)
@@ -472,7 +472,10 @@ def test_classifier_bank_equals_the_separate_classifiers(mode):
             views = getattr(task.classifiers[0][1].weight, "_egk_bank_views", None)
             assert (views is not None) == (bank and opt.materialised)
             ctx = ops.bank_grad_handoff() if handoff else contextlib.nullcontext()
-            with ctx:
+            # "seeded": the constant gradient of the loss vector is announced up front -> ONE fused launch computes the loss
+            # and writes its gradient (and the zero pad columns) into the bank's operand buffer (egk_ce_fused)
+            seed = ops.loss_seed(1.0 / M) if handoff == "seeded" else contextlib.nullcontext()
+            with ctx, seed:
                 logits = task.forward_logits(task.forward_features(xin))
                 loss = task.compute_loss(logits, y)
             loss.backward(torch.full_like(loss, 1.0 / M))
@@ -486,8 +489,8 @@ def test_classifier_bank_equals_the_separate_classifiers(mode):
                 del p._egk_bank
         want, _ = run(ref, False, False)
         tol = dict(rtol=1e-4, atol=1e-5) if mode == "f32" else dict(rtol=3e-2, atol=3e-3)
-        for name in ("bank", "handoff"):
-            got, opt = run(tasks[name], True, name == "handoff")
+        for name in ("bank", "handoff", "seeded"):
+            got, opt = run(tasks[name], True, {"bank": False, "handoff": True, "seeded": "seeded"}[name])
             for (lg, dxg, pg), (lw, dxw, pw) in zip(got, want):
                 for a, b in zip(lg, lw):
                     torch.testing.assert_close(a, b, **tol)
