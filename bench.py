@@ -170,6 +170,8 @@ ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pip
                 "gemm_bf16_nn_r64": _pipe("false", "false", 1, 2), "gemm_bf16_nt_r64": _pipe("false", "true", 1, 2),
                 "gemm_bf16_nn_t256": "gemm_big_kernel<false, false", "gemm_bf16_nt_t256": "gemm_big_kernel<false, true",
                 "gemm_bf16_tt_t256": "gemm_big_kernel<true, true", "gemm_bf16_tn_t256": "gemm_big_kernel<true, false",
+                "gemm_bf16_group_nn": "gemm_pipe_group_kernel<2, false, false", "gemm_bf16_group_nt": "gemm_pipe_group_kernel<2, false, true",
+                "gemm_bf16_group_tt": "gemm_pipe_group_kernel<2, true, true",
                 "gemm_bf16_generic": "gemm_kernel<true", "gemm_splitk_reduce": "gemm_splitk_reduce",
                 "adam": "adam_kernel", "csr_gather": "csr_gather_kernel"}
 

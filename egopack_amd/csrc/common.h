@@ -50,6 +50,9 @@ enum KernelId {
     KID_GEMM_BF16_NT_T256,
     KID_GEMM_BF16_TT_T256,
     KID_GEMM_BF16_TN_T256,
+    KID_GEMM_BF16_GROUP_NN,  // grouped launches (egk_gemm_grouped): several problems of one layout in one launch
+    KID_GEMM_BF16_GROUP_NT,
+    KID_GEMM_BF16_GROUP_TT,
     KID_GEMM_BF16_GENERIC, // bf16 MFMA on the register-staged kernel (K not a multiple of 64, unaligned rows, f32 storage)
     KID_GEMM_SPLITK_REDUCE,
     KID_COLSUM,

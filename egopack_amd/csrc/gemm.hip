@@ -1542,8 +1542,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, gg);                \
     } while (0)
     {
-        ProfScope prof(variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
-                                   : (variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
+        ProfScope prof(KID_GEMM_BF16_GROUP_NN + layout, s, flops, bytes);  // (layout 0 nn, 1 nt, 2 tt)
         if (!ta && variant == 11) {
             if (!tb) hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);
             else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);

@@ -23,6 +23,7 @@ static const char* const kNames[KID_COUNT] = {
     "gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tt", "gemm_f32_tn",
     "gemm_bf16_nn_g2", "gemm_bf16_nt_g2", "gemm_bf16_tt_g2", "gemm_bf16_tn_g2", "gemm_bf16_nn_r96", "gemm_bf16_nt_r96", "gemm_bf16_nn_r64", "gemm_bf16_nt_r64",
     "gemm_bf16_nn_t256", "gemm_bf16_nt_t256", "gemm_bf16_tt_t256", "gemm_bf16_tn_t256",
+    "gemm_bf16_group_nn", "gemm_bf16_group_nt", "gemm_bf16_group_tt",
     "gemm_bf16_generic", "gemm_splitk_reduce",
     "colsum", "rowln_fwd", "rowln_bwd", "rowln_bwd_reduce",
     "graphln_stats", "graphln_fwd", "graphln_bwd_stats", "graphln_bwd", "graphln_bwd_reduce",

@@ -292,6 +292,7 @@ class StepBase:
     ``(total, vectors, extra)``."""
 
     order: Sequence[str] = TASK_ORDER
+    wgrad_grouping_default = True
 
     def _init_base(self, model, tasks, weights, optimizer, fused_backbone, sync, parallel_heads):
         self.model, self.tasks = model, dict(tasks)
@@ -311,8 +312,17 @@ class StepBase:
         # weight-gradient launches of the backbone on a side stream (they feed nothing but the optimizer): 2-4 % on the
         # multi-task steps, 1.8 % on the single-task step (1.236 -> 1.214 ms), neutral on the EgoPack step
         self.wgrad_side_streams = bool(parallel_heads)
-        # H x H weight gradients parked and issued four at a time as ONE grouped launch of 256 workgroups (ops._wgrad_defer)
-        self.wgrad_grouping = True
+        # H x H weight gradients parked and issued four at a time as ONE grouped launch of 256 workgroups (ops._wgrad_defer):
+        # -4 % on the 3-task step, -12 % on the single-task step; the EgoPack step, whose GraphONE chains already keep three
+        # streams busy, measured 3.59 vs 3.46-3.52 ms with it and leaves it off
+        self.wgrad_grouping = type(self).wgrad_grouping_default
+        import os
+        off = set(filter(None, os.environ.get("EGK_DISABLE", "").split(",")))  # development: A/B of the grouped paths
+        if "wgrad_grouping" in off:
+            self.wgrad_grouping = False
+        if "grouped_heads" in off:
+            self.grouped_heads = False
+        self._fused_loss = "fused_loss" not in off
 
     # ---- backbone ------------------------------------------------------------------------------------
     def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:
@@ -369,7 +379,7 @@ class StepBase:
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         try:
             total, vectors = self._backward_pass(batches, merged)
-            ops.join_wgrad()
+            ops.join_wgrad(force=True)
         finally:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
@@ -517,7 +527,7 @@ class StepBase:
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         early = self._early_adam_plan(live) if fuse_adam else None
         try:
-            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+            with torch.cuda.graph(g, stream=ops.unexcluded_stream(), capture_error_mode=CAPTURE_MODE):
                 ops.stamp("step_start")
                 opt.flat_g.zero_()
                 if self.input_hook is not None:
@@ -526,7 +536,7 @@ class StepBase:
                     ops.set_last_wgrad_hook(early["param"], early["hook"])
                 total, vectors = self._backward_pass(batches, merged)
                 ops.set_last_wgrad_hook(None, None)
-                ops.join_wgrad()
+                ops.join_wgrad(force=True)
                 ops.stamp("backward_done")
                 if fuse_adam:
                     if early is not None and early["fired"]:
@@ -682,7 +692,7 @@ class MTLStep(StepBase):
         def head(t, leaf):
             # AR / LTA: one loss element per node, back-propagated below with the constant w_t / numel -- known before the
             # loss is computed, so the cross entropy emits its gradient in the same launch (ops.loss_seed)
-            n_loss = leaf.shape[0] if t in ("ar", "lta") else 0
+            n_loss = leaf.shape[0] if (t in ("ar", "lta") and getattr(self, "_fused_loss", True)) else 0
             with ops.loss_seed(self.weights[t] / n_loss if n_loss else None):
                 if grouped:  # ``leaf`` is the task's projected feature block: classifier + loss (+ their backward) only
                     task, d = self.tasks[t], batches[t]
@@ -761,7 +771,7 @@ class MTLStep(StepBase):
             self.model.stage_cut = None
         self._head_batches = batches
         total, vectors, leaves = self._heads_forward_backward(feats)
-        ops.join_wgrad()
+        ops.join_wgrad(force=True)
         self._stage_state = (feats, leaves)
         return total, vectors
 
@@ -770,13 +780,13 @@ class MTLStep(StepBase):
         feats, leaves = self._stage_state
         order = list(feats)
         torch.autograd.backward([feats[t] for t in order], [leaves[t].grad for t in order])
-        ops.join_wgrad()
+        ops.join_wgrad(force=True)
 
     def _stage_c(self):
         """TRN output -> inputs: final gradients of the temporal pooling."""
         if self._cuts:
             torch.autograd.backward([x for x, _ in self._cuts], [leaf.grad for _, leaf in self._cuts])
-            ops.join_wgrad()
+            ops.join_wgrad(force=True)
 
 
 class EgoPackStep(StepBase):
@@ -785,6 +795,7 @@ class EgoPackStep(StepBase):
     projections DETACHED -> GraphONE.interact -> fused logits -> primary.compute_loss."""
 
     order = ("ar", "oscc", "lta", "pnr")  # order of the loss terms in main_egopack.train
+    wgrad_grouping_default = False
     AUX_ORDER = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
                  "pnr": ("ar", "oscc", "lta")}  # main_egopack.py:121-147
 

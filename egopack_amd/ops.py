@@ -300,15 +300,29 @@ def exclude_wgrad_streams(streams) -> None:
 
 
 
+def unexcluded_stream() -> torch.cuda.Stream:
+    """A stream from the pool whose handle is not registered as a head / task stream (torch hands pooled handles out
+    round-robin: a fresh ``torch.cuda.Stream()`` may alias one an earlier step excluded) -- for graph captures."""
+    keep = []
+    for _ in range(64):
+        st = torch.cuda.Stream()
+        if (st.device.index, st.cuda_stream) not in _wgrad["exclude"]:
+            return st
+        keep.append(st)
+    return keep[-1]
+
+
 def set_wgrad_side_streams(on: bool) -> bool:
     prev = _wgrad["enabled"]
     _wgrad["enabled"] = bool(on)
     return prev
 
 
-def _wgrad_launch(in_place: bool, tensors, launch):
+def _wgrad_launch(in_place: bool, tensors, launch, in_backward: bool = True):
     """Run ``launch()`` (weight / bias gradient kernels that only write persistent gradient slots) on the side
-    stream of the current stream; ``tensors`` are the temporaries it reads (kept alive for that stream)."""
+    stream of the current stream; ``tensors`` are the temporaries it reads (kept alive for that stream).
+    ``in_backward`` False: called from ``join_wgrad`` itself (possibly after backward has returned): no end-of-backward
+    callback is installed, the caller joins right away."""
     if not (_wgrad["enabled"] and in_place and tensors and tensors[0].is_cuda):
         launch()
         return
@@ -328,7 +342,7 @@ def _wgrad_launch(in_place: bool, tensors, launch):
             t.record_stream(side)
     if side not in _wgrad["pending"]:
         _wgrad["pending"].append(side)
-    if not _wgrad["queued"]:  # join at the end of THIS backward pass, on the stream of the thread that called it
+    if in_backward and not _wgrad["queued"]:  # join at the end of THIS backward pass, on the stream of the thread that called it
         _wgrad["queued"] = True
         torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
 
@@ -392,8 +406,19 @@ def _wgrad_defer_reduce(ws, dw, db, rows, cols, n_seg):
 
 def _launch_reductions(reds):
     lib = _lib.load()
-    for i in range(0, len(reds), 8):
-        chunk = reds[i:i + 8]
+    # batches of at most 8 reductions with DISTINCT targets: a parameter used several times in one step (per-task backbone
+    # passes) has several reductions accumulating into the same dw / db -- those stay in separate, ordered launches
+    chunks, cur, seen = [], [], set()
+    for r in reds:
+        key = (r[1].data_ptr(), r[2].data_ptr())
+        if len(cur) == 8 or key[0] in seen or key[1] in seen:
+            chunks.append(cur)
+            cur, seen = [], set()
+        cur.append(r)
+        seen.update(key)
+    if cur:
+        chunks.append(cur)
+    for chunk in chunks:
         n = len(chunk)
         if n == 1:
             ws, dw, db, rows, cols, n_seg = chunk[0]
@@ -405,9 +430,13 @@ def _launch_reductions(reds):
             "egk_ln_bwd_reduce_multi")
 
 
-def flush_wgrad():
+def flush_wgrad(in_backward: bool = True, force: bool = False):
+    """Issue what is parked.  On an excluded (task-head) stream nothing is issued -- unless ``force``: the engine's own
+    calls from the backward stream (end of a step's backward, the last-weight-gradient hook) must never leave parked work
+    behind, whatever stream handle the backward stream happens to have (a capture stream may alias a pooled handle that an
+    earlier step registered as excluded)."""
     items, hold, extra = _wq["items"], _wq["hold"], _wq["extra"]
-    if (not items and not extra) or _on_excluded_stream():  # (a head stream never issues what other streams parked)
+    if (not items and not extra) or (_on_excluded_stream() and not force):  # (a head stream never issues what others parked)
         return
     _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
 
@@ -420,7 +449,7 @@ def flush_wgrad():
                 gemm_grouped(chunk)
         if extra:
             _launch_reductions(extra)
-    _wgrad_launch(True, hold, launch)
+    _wgrad_launch(True, hold, launch, in_backward)
 
 
 _last_wgrad = {"param": None, "hook": None, "inline": True}
@@ -449,10 +478,11 @@ def _ln_reduce_on_side(slot_w, slot_b, x) -> bool:
 _wgrad_ln = {"side": True}  # development knob
 
 
-def join_wgrad():
+def join_wgrad(force: bool = False):
     """The current stream waits for every weight-gradient side stream with work in flight (call after backward,
-    before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture)."""
-    flush_wgrad()
+    before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture).  ``force``: the
+    caller IS the step's backward stream (see flush_wgrad)."""
+    flush_wgrad(in_backward=False, force=force)
     cur = torch.cuda.current_stream() if _wgrad["pending"] else None
     for side in _wgrad["pending"]:
         cur.wait_stream(side)
@@ -561,7 +591,7 @@ class _Linear(torch.autograd.Function):
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
             last = Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None
             if last:
-                flush_wgrad()  # (the hook starts the optimizer on every other slot: their gradients must be issued)
+                flush_wgrad(force=True)  # (the hook starts the optimizer on every other slot: their gradients must be issued)
                 _last_wgrad["hook"]()
             # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS).  The LAST
             # weight gradient of the step stays on the backward stream: nothing is left to overlap it with there, and the
