@@ -34,6 +34,8 @@ class GemmDesc(C.Structure):
         ("accumulate", i32), ("act", i32), ("alpha", f32),
         ("bias", vp), ("residual", vp), ("ldr", i64), ("r_dtype", i32),
         ("splitk", i32), ("ws", vp), ("ws_bytes", i64), ("dbias", vp),
+        ("st_mode", i32), ("st_nseg", i32), ("st_min_seg_rows", i32), ("st_seg_ptr", vp), ("st_ws", vp), ("st_x", vp),
+        ("st_ldx", i64), ("st_stats", vp), ("st_w", vp), ("st_b", vp), ("st_slope", f32),
     ]
 
 
@@ -48,6 +50,7 @@ SIGNATURES = {
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egk_stamp": (C.c_int, [vp, vp, i32]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
+    "egk_gemm_stats_blocks": (C.c_int, [C.POINTER(GemmDesc)]),
     "egk_gemm_grouped": (C.c_int, [vp, C.POINTER(GemmDesc), i32]),
     "egk_gemm_ws_bytes": (i64, [C.POINTER(GemmDesc)]),
     "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),
@@ -64,6 +67,8 @@ SIGNATURES = {
     "egk_graphln_ws_bytes": (i64, [i32, i32, i32]),
     "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
     "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
+    "egk_graphln_fwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32]),
+    "egk_graphln_bwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, vp, i32]),
     "egk_pe_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
     "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32]),
     "egk_csr_heavy_ws_bytes": (i64, [i32, i32]),

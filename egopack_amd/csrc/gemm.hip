@@ -54,6 +54,16 @@ struct GemmArgs {
     float* dbias;     // fused bias gradient: dbias[m] += sum_k op(A)[m, k]  (transA pipelined kernel only)
     float* ws_bias;   // [splitk][M] partial row sums when splitk > 1
     int rows_epilogue;  // 4-wave pipelined variants: write the tile out through LDS in whole rows (development knob, default 1)
+    // per-segment sums of the RESULT for the graph-mode LayerNorm that consumes it (egk_gemm_desc.st_*), rows epilogue only
+    int st_mode, st_nseg;
+    const int* st_seg_ptr;
+    double* st_ws;             // [tiles_m * tiles_n][st_nseg][2]
+    const void* st_x;          // mode 2: the LayerNorm's input (same shape / element type as C), leading dimension st_ldx
+    long long st_ldx;
+    const float* st_stats;     // mode 2: [st_nseg][2] (mean, 1 / (std + eps)) of the forward pass
+    const float* st_w;
+    const float* st_b;
+    float st_slope;
 };
 
 // Workgroup -> (slab z, tile row, tile column) for a 1-D launch of tiles_m * tiles_n * splitk workgroups.
@@ -319,7 +329,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
 // (conflict-free for the scattered writes and the row reads), and come back as 8 consecutive columns per lane: a
 // wave-instruction then covers 4 whole 256-byte (bf16) rows.  The arithmetic per element is gemm_epilogue's, in its
 // order: results are bit-identical.  Block-uniform precondition (epilogue_rows_ok): 16-byte aligned rows everywhere.
-__device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
+__host__ __device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
     if (!g.rows_epilogue) return false;
     const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if ((g.N & 7) != 0) return false;
@@ -332,7 +342,7 @@ __device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
 
 template <int NI>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[NI][4], unsigned char* lds, int m0, int n0,
-                                                   int wm, int wn, int lr, int lg, int z, int tid) {
+                                                   int wm, int wn, int lr, int lg, int z, int tid, int st_tile = 0) {
     __syncthreads();  // every wave is done with the ring (nothing is in flight: the last tiles were waited for)
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -346,7 +356,24 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     }
     __syncthreads();
     const int c8 = tid & 15, n = n0 + c8 * 8;
-    if (n >= g.N) return;  // (N % 8 == 0: a group of 8 columns is all in or all out)
+    // per-segment sums of the stored result for the graph LayerNorm that consumes it.  A tile spans at most two row segments
+    // (checked on the host): s0 = segment of the tile's first row, rel = 0 / 1.
+    const int st_mode = g.splitk == 1 ? g.st_mode : 0;
+    float sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    int s0 = 0, s_split = 0x7fffffff;
+    float st_mu[2] = {0.f, 0.f}, st_ri[2] = {0.f, 0.f}, lw[8], lb[8];
+    if (st_mode) {
+        while (s0 + 1 < g.st_nseg && m0 >= g.st_seg_ptr[s0 + 1]) ++s0;
+        if (s0 + 1 < g.st_nseg) s_split = g.st_seg_ptr[s0 + 1];
+        if (st_mode == 2 && n < g.N) {
+            st_mu[0] = g.st_stats[s0 * 2]; st_ri[0] = g.st_stats[s0 * 2 + 1];
+            if (s0 + 1 < g.st_nseg) { st_mu[1] = g.st_stats[s0 * 2 + 2]; st_ri[1] = g.st_stats[s0 * 2 + 3]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { lw[t] = g.st_w[n + t]; lb[t] = g.st_b[n + t]; }
+        }
+    }
+    const bool st_cols = n < g.N;
+    if (n >= g.N && !st_mode) return;  // (N % 8 == 0: a group of 8 columns is all in or all out)
     float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (g.bias && g.splitk == 1) {
         const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
@@ -355,7 +382,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
 #pragma unroll
     for (int it = 0; it < 2 * NI; ++it) {
         const int row = it * 16 + (tid >> 4), m = m0 + row;
-        if (m >= g.M) continue;
+        if (m >= g.M || !st_cols) continue;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * 128 + (((2 * c8) ^ (row & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * 128 + (((2 * c8 + 1) ^ (row & 15)) << 2));
         float o[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -400,10 +427,76 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
             pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
             *reinterpret_cast<uint4*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
+            if (st_mode) {  // the sums are those of the values the LayerNorm will READ: the rounded ones
+                const unsigned pw[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    o[2 * t] = __uint_as_float(pw[t] << 16);
+                    o[2 * t + 1] = __uint_as_float(pw[t] & 0xffff0000u);
+                }
+            }
         } else {
             float* cp = (float*)g.C + (long long)m * g.ldc + n;
             *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
             *reinterpret_cast<float4*>(cp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (st_mode == 1) {
+            const int rel = m >= s_split ? 1 : 0;
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                a1 += o[t];
+                a2 += o[t] * o[t];
+            }
+            sa[rel][0] += a1;
+            sa[rel][1] += a2;
+        } else if (st_mode == 2) {
+            const int rel = m >= s_split ? 1 : 0;
+            const float mu = st_mu[rel], ri = st_ri[rel];
+            float xv[8];
+            if (g.c_bf16) {
+                const uint4 r = *reinterpret_cast<const uint4*>((const bf16_t*)g.st_x + (long long)m * g.st_ldx + n);
+                const unsigned rw[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    xv[2 * t] = __uint_as_float(rw[t] << 16);
+                    xv[2 * t + 1] = __uint_as_float(rw[t] & 0xffff0000u);
+                }
+            } else {
+                const float* xp = (const float*)g.st_x + (long long)m * g.st_ldx + n;
+                const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
+                xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+            }
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {  // graphln_bwd_stats_kernel's arithmetic: dxhat = dy * lrelu'(pre) * w
+                const float xh = (xv[t] - mu) * ri;
+                const float pre = xh * lw[t] + lb[t];
+                const float dxh = o[t] * (pre > 0.f ? 1.f : g.st_slope) * lw[t];
+                a1 += dxh;
+                a2 += dxh * xh;
+            }
+            sa[rel][0] += a1;
+            sa[rel][1] += a2;
+        }
+    }
+    if (st_mode) {  // block sums in a fixed order: lanes (shuffle tree), then the 4 waves in wave order
+        __shared__ double st_red[4][4];
+        double v4[4] = {(double)sa[0][0], (double)sa[0][1], (double)sa[1][0], (double)sa[1][1]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1) v4[q] += __shfl_xor(v4[q], o_, 64);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st_red[tid >> 6][q] = v4[q];
+        }
+        __syncthreads();
+        if (tid < g.st_nseg * 2) {
+            const int sg = tid >> 1, k = tid & 1, rel = sg - s0;
+            double t_ = 0.0;
+            if (rel == 0 || rel == 1) t_ = (st_red[0][rel * 2 + k] + st_red[1][rel * 2 + k]) + (st_red[2][rel * 2 + k] + st_red[3][rel * 2 + k]);
+            g.st_ws[((long long)st_tile * g.st_nseg + sg) * 2 + k] = t_;
         }
     }
 }
@@ -803,7 +896,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     }
     if constexpr (KG == 1) {
         if constexpr (MB == 1) {
-            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid);
+            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
             else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         } else {
             gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
@@ -1264,7 +1357,20 @@ extern "C" int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d) {
     return n;
 }
 
-extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks);
+
+extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) { return gemm_core(stream, d, nullptr); }
+
+// Number of per-tile partial blocks [blocks][st_nseg][2] a launch of ``d`` with st_mode != 0 writes to st_ws -- 0 when the
+// tile variant the policy picks for ``d`` cannot (the caller then runs the LayerNorm's own statistics pass).  Nothing is
+// launched.
+extern "C" int egk_gemm_stats_blocks(const egk_gemm_desc* d) {
+    int blocks = 0;
+    const int rc = gemm_core(nullptr, d, &blocks);
+    return rc == 0 ? blocks : 0;
+}
+
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks) {
     EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
     EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
     EGK_REQUIRE(d->compute == EGK_COMPUTE_F32 || d->compute == EGK_COMPUTE_BF16, "egk_gemm: bad compute type");
@@ -1309,6 +1415,14 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
     g.dbias = nullptr; g.ws_bias = nullptr;
     g.group_m = 1;
     g.rows_epilogue = g_rows_epilogue;
+    g.st_mode = d->st_mode; g.st_nseg = d->st_nseg; g.st_seg_ptr = d->st_seg_ptr; g.st_ws = (double*)d->st_ws;
+    g.st_x = d->st_x; g.st_ldx = d->st_ldx; g.st_stats = d->st_stats; g.st_w = d->st_w; g.st_b = d->st_b; g.st_slope = d->st_slope;
+    if (d->st_mode) {
+        EGK_REQUIRE(d->st_mode == 1 || d->st_mode == 2, "egk_gemm: st_mode must be 0, 1 or 2");
+        EGK_REQUIRE(d->st_nseg >= 1 && d->st_nseg <= 16 && d->st_seg_ptr && (query_blocks || d->st_ws), "egk_gemm: st_* segments / workspace");
+        EGK_REQUIRE(d->st_mode == 1 || (d->st_x && d->st_stats && d->st_w && d->st_b), "egk_gemm: st_mode 2 needs x, stats, w, b");
+    }
+    if (query_blocks) *query_blocks = 0;
     const int K = d->K1 + d->K2;
     const double flops = 2.0 * d->M * d->N * K;
     const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
@@ -1331,7 +1445,7 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
         if (bias_fused) {
             g.dbias = d->dbias;
             g.ws_bias = g.splitk > 1 ? (float*)((char*)d->ws + slab) : nullptr;
-        } else {  // explicit column sums of dY (= A1 as stored: [K1 rows, M columns])
+        } else if (!query_blocks) {  // explicit column sums of dY (= A1 as stored: [K1 rows, M columns])
             const int rc = egk_colsum(stream, d->A1, d->lda1, d->K1, d->M, d->dbias, 1, (float*)((char*)d->ws + slab), d->a_dtype);
             if (rc) return rc;
         }
@@ -1400,6 +1514,20 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
             if (g_group_m_override > 0) g.group_m = g_group_m_override < g.tiles_m ? g_group_m_override : g.tiles_m;
         }
 
+        // segment statistics in the epilogue: the 4-wave variants that write their tile out through LDS in whole rows, unsplit,
+        // and tiles that span at most two row segments
+        const int tile_rows = variant == 8 ? 96 : variant == 11 ? 64 : 128;
+        const bool st_ok = (variant == 2 || variant == 3 || variant == 4 || variant == 8 || variant == 11) && g.splitk == 1 &&
+                           epilogue_rows_ok(g) && d->st_min_seg_rows >= tile_rows &&
+                           (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % (g.c_bf16 ? 8 : 4) == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
+        if (query_blocks) {
+            *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
+            return 0;
+        }
+        if (d->st_mode && !st_ok) {
+            set_error("egk_gemm: st_mode %d is not available for this launch (ask egk_gemm_stats_blocks first)", d->st_mode);
+            return EGK_EUNSUPPORTED;
+        }
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
@@ -1434,6 +1562,11 @@ extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) {
                                dim3(256), 0, s, g);
         }
         return check_launch("egk_gemm");
+    }
+    if (query_blocks) return 0;  // (the generic kernel has no statistics epilogue: 0 blocks)
+    if (d->st_mode) {
+        set_error("egk_gemm: st_mode %d is not available on the generic kernel (ask egk_gemm_stats_blocks first)", d->st_mode);
+        return EGK_EUNSUPPORTED;
     }
     dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
     {
@@ -1485,6 +1618,9 @@ static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     g.ws = nullptr;
     g.dbias = d->dbias; g.ws_bias = nullptr;
     g.rows_epilogue = g_rows_epilogue;
+    g.st_mode = 0; g.st_nseg = 0; g.st_seg_ptr = nullptr; g.st_ws = nullptr; g.st_x = nullptr; g.st_ldx = 0;
+    g.st_stats = nullptr; g.st_w = nullptr; g.st_b = nullptr; g.st_slope = 0.f;
+    EGK_REQUIRE(d->st_mode == 0, "egk_gemm_grouped: no segment statistics in a grouped launch");
     return 0;
 }
 

@@ -566,13 +566,16 @@ __global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const T* __restr
 }
 
 // bwd pass 2: dx = r*dxhat - r*S1/n - xhat*S2/(n*sigma),  sigma = 1/r - eps
-template <int NV, typename T, bool FULL>
+// COLS: also the per-workgroup column partials of dw / db (ws_col[blk][2][cols]) -- when the segment sums came from the
+// epilogue of the contraction that produced dy (egk_gemm_desc.st_mode 2) there is no statistics pass to carry them
+template <int NV, typename T, bool FULL, bool COLS = false>
 __global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ b,
                                                           const float* __restrict__ stats, T* __restrict__ dx,
                                                           const int* __restrict__ seg_ptr, int n_seg, int rows, int cols,
                                                           float eps, float slope, const double* __restrict__ ws_seg,
-                                                          int nblk_stats) {
+                                                          int nblk_stats, float* __restrict__ ws_col = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // COLS: [WPB][2][NV*256]
     __shared__ float sc[MAXSEG][4];  // mean, r, r*S1/n, S2/(n*sigma)
     __shared__ double scratch[4][8];
     __shared__ double sums[MAXSEG * 2];
@@ -592,9 +595,13 @@ __global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
     const bool vec = FULL || (cols & 3) == 0;
-    Row<NV> wv, bv;
+    Row<NV> wv, bv, dwp, dbp;
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
+    if constexpr (COLS) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dwp.v[i] = dbp.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const int sg = seg_of(seg_ptr, n_seg, row);
         const float mu = sc[sg][0], ri = sc[sg][1], c1 = sc[sg][2], c2 = sc[sg][3];
@@ -605,12 +612,38 @@ __global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ 
         for (int i = 0; i < NV; ++i)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float xh = (el(xr.v[i], t) - mu) * ri;
+                const bool in = FULL || (i * 64 + lane) * 4 + t < cols;
+                const float xh = in ? (el(xr.v[i], t) - mu) * ri : 0.f;
                 const float pre = xh * el(wv.v[i], t) + el(bv.v[i], t);
-                const float dxh = el(g.v[i], t) * (pre > 0.f ? 1.f : slope) * el(wv.v[i], t);
+                const float gg = in ? el(g.v[i], t) * (pre > 0.f ? 1.f : slope) : 0.f;
+                if constexpr (COLS) {
+                    el(dwp.v[i], t) += gg * xh;
+                    el(dbp.v[i], t) += gg;
+                }
+                const float dxh = gg * el(wv.v[i], t);
                 el(g.v[i], t) = ri * dxh - c1 - xh * c2;
             }
         store_row<NV>(dx + (long long)row * cols, cols, vec, lane, g);
+    }
+    if constexpr (COLS) {  // the 4 waves' column partials in wave order -> this workgroup's partial row (as in the stats pass)
+        const int stride = NV * 256;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            *reinterpret_cast<float4*>(red + (wave * 2 + 0) * stride + c) = dwp.v[i];
+            *reinterpret_cast<float4*>(red + (wave * 2 + 1) * stride + c) = dbp.v[i];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            float a = 0.f, d = 0.f;
+#pragma unroll
+            for (int wv_ = 0; wv_ < WPB; ++wv_) {
+                a += red[(wv_ * 2 + 0) * stride + c];
+                d += red[(wv_ * 2 + 1) * stride + c];
+            }
+            ws_col[((long long)blockIdx.x * 2 + 0) * cols + c] = a;
+            ws_col[((long long)blockIdx.x * 2 + 1) * cols + c] = d;
+        }
     }
 }
 
@@ -888,6 +921,42 @@ int egk_graphln_fwd(egk_stream_t stream, const void* x, const float* w, const fl
                                                      (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)ws, grid));
     }
     return check_launch("egk_graphln_fwd");
+}
+
+/* The normalising pass alone, from per-block segment sums computed elsewhere: ``partials`` = double [n_partials][n_seg][2]
+ * (sum, sum of squares of x per segment), e.g. written by the epilogue of the contraction that produced x
+ * (egk_gemm_desc.st_mode 1).  Same arithmetic as egk_graphln_fwd's second launch. */
+int egk_graphln_fwd_apply(egk_stream_t stream, const void* x, const float* w, const float* b, void* y, float* stats,
+                          const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope,
+                          const void* partials, int32_t n_partials, int32_t dtype) {
+    EGK_REQUIRE(x && w && b && y && stats && seg_ptr && partials, "egk_graphln_fwd_apply: null pointer");
+    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG && n_partials >= 1, "egk_graphln_fwd_apply: bad segment / partial count");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    ProfScope prof(KID_GRAPHLN_FWD, s, 0, 2 * eb * rows * cols);
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
+                                                 (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)partials, n_partials));
+    return check_launch("egk_graphln_fwd_apply");
+}
+
+/* Backward from per-block segment sums computed elsewhere: ``partials`` = double [n_partials][n_seg][2] holding
+ * (sum dxhat, sum dxhat * xhat) per segment (egk_gemm_desc.st_mode 2: the epilogue of the contraction that produced dy).
+ * Writes dx and the per-workgroup partial rows of dw / db to ws_col (f32 [egk_rowln_bwd_ws_rows(rows)][2][cols]; reduce
+ * with egk_ln_bwd_reduce(ws_col, dw, db, rows, cols, 0)). */
+int egk_graphln_bwd_apply(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b, const float* stats,
+                          void* dx, const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope,
+                          const void* partials, int32_t n_partials, float* ws_col, int32_t dtype) {
+    EGK_REQUIRE(dy && x && w && b && stats && dx && seg_ptr && partials && ws_col, "egk_graphln_bwd_apply: null pointer");
+    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG && n_partials >= 1, "egk_graphln_bwd_apply: bad segment / partial count");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    ProfScope prof(KID_GRAPHLN_BWD, s, 0, 3 * eb * rows * cols);
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_kernel<NV, T, FULL, true>), dim3(row_grid(rows)), dim3(256),
+                                                 WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, stats, (T*)dx,
+                                                 seg_ptr, n_seg, rows, cols, eps, slope, (const double*)partials, n_partials, ws_col));
+    return check_launch("egk_graphln_bwd_apply");
 }
 
 int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b,

@@ -241,6 +241,7 @@ def merge_batches(batches: Sequence[Data]) -> Data:
     out.graph = concat_csr(graphs) if all(g is not None for g in graphs) else build_csr(ei, off)
     out.seg_ptr = torch.tensor(seg, dtype=torch.int32)
     out.num_segments = len(batches)
+    out.min_seg_rows = min(b - a for a, b in zip(seg, seg[1:]))  # (host integer: the shortest task batch, in rows)
     return out
 
 

@@ -323,6 +323,8 @@ class StepBase:
         if "grouped_heads" in off:
             self.grouped_heads = False
         self._fused_loss = "fused_loss" not in off
+        if "ln_fusion" in off:
+            ops._ln_fusion["on"] = False
 
     # ---- backbone ------------------------------------------------------------------------------------
     def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:

@@ -92,10 +92,19 @@ class Graph(torch.nn.Module):
             except Exception:
                 pass
         h = self.positional_encoding.add_to(x, data.pos)
+        # the graph LayerNorm's per-segment sums ride on the epilogue of the contraction that produces its input (forward:
+        # the SAGE layer's last contraction; backward: the dX contraction of whatever consumes its output) when the shortest
+        # row segment is known on the host (merged / collated batches carry it) -- no statistics pass over the tensor
+        min_rows = int(getattr(data, "min_seg_rows", 0) or (x.shape[0] if seg_ptr.numel() == 2 else 0))
+        n_seg = seg_ptr.numel() - 1
+        ln_prev = None
         for d in range(self.depth):
             conv = getattr(self.net, f"module_{3 * d}")
             norm = getattr(self.net, f"module_{3 * d + 1}")
             slope = getattr(self.net, f"module_{3 * d + 2}").negative_slope
-            h = norm(ops.sage_mean_layer(h, conv, graph), seg_ptr, slope)  # SAGEConv -> graph-LN -> LeakyReLU
+            req = {"seg_ptr": seg_ptr, "n_seg": n_seg, "min_rows": min_rows} if min_rows > 0 else None
+            c = ops.sage_mean_layer(h, conv, graph, ln_out=req, ln_in=ln_prev)
+            h, ln_prev = norm(c, seg_ptr, slope, partials=req.get("partials") if req else None, min_seg_rows=min_rows,
+                              return_ctx=True)                # SAGEConv -> graph-LN -> LeakyReLU
         last = getattr(self.net, f"module_{3 * self.depth}")
-        return last(h, residual=x)                            # x + Linear(h): residual in the epilogue
+        return last(h, residual=x, ln_in=ln_prev)             # x + Linear(h): residual in the epilogue

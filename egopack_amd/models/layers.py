@@ -11,8 +11,8 @@ class Linear(nn.Linear):
     """nn.Linear / gnn.Linear parameters (kaiming-uniform(a=sqrt 5), bias U(+-1/sqrt(fan_in)));
     forward = one MFMA launch with the bias (and optional ReLU / residual) in the epilogue."""
 
-    def forward(self, x, residual=None, relu=False, out_f32=False):
-        return ops.linear(x, self.weight, self.bias, residual=residual, relu=relu, out_f32=out_f32)
+    def forward(self, x, residual=None, relu=False, out_f32=False, ln_in=None):
+        return ops.linear(x, self.weight, self.bias, residual=residual, relu=relu, out_f32=out_f32, ln_in=ln_in)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -36,8 +36,8 @@ class GraphLayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(in_channels))
         self.bias = nn.Parameter(torch.zeros(in_channels))
 
-    def forward(self, x, seg_ptr, slope=0.2):
-        return ops.graph_layernorm_lrelu(x, self.weight, self.bias, seg_ptr, self.eps, slope)
+    def forward(self, x, seg_ptr, slope=0.2, **kw):
+        return ops.graph_layernorm_lrelu(x, self.weight, self.bias, seg_ptr, self.eps, slope, **kw)
 
 
 class PositionalEncoding(nn.Module):

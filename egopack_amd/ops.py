@@ -215,8 +215,9 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
                transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-               dbias=None, into=None):
-    """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array)."""
+               dbias=None, into=None, stats=None):
+    """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array).  ``stats``: per-segment sums of
+    the result for the graph LayerNorm that consumes it, taken in the epilogue (``_ln_stats_request``)."""
     op_dt = _dt(A1)
     if _dt(B1) != op_dt or (A2 is not None and (_dt(A2) != op_dt or _dt(B2) != op_dt)):
         raise TypeError("gemm: all A / B operands must share one element type")
@@ -236,7 +237,30 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
     d.splitk = 1
     d.dbias = _p(dbias)
     d.ws, d.ws_bytes = None, 0
+    d.st_mode = 0
+    if stats is not None:
+        d.st_mode, d.st_nseg, d.st_min_seg_rows = stats["mode"], stats["n_seg"], stats["min_rows"]
+        d.st_seg_ptr, d.st_ws = _p(stats["seg_ptr"]), _p(stats.get("ws"))
+        if stats["mode"] == 2:
+            x = stats["x"]
+            d.st_x, d.st_ldx, d.st_stats = _p(x), x.stride(0), _p(stats["stats"])
+            d.st_w, d.st_b, d.st_slope = _p(stats["w"]), _p(stats["b"]), stats["slope"]
     return d
+
+
+def _gemm_with_stats(args, kw, stats):
+    """``gemm(*args, **kw)`` with the epilogue statistics ``stats`` if the tile variant of this launch can take them:
+    returns (partials, blocks) or None (plain launch done instead).  No split-K (the statistics need the finished tile)."""
+    lib = _lib.load()
+    d = _gemm_desc(*args, stats=stats, **kw)
+    blocks = lib.egk_gemm_stats_blocks(C.byref(d))
+    if blocks <= 0:
+        gemm(*args, **kw)
+        return None
+    ws = torch.empty(blocks * stats["n_seg"] * 2, dtype=torch.float64, device=args[7].device)
+    d.st_ws = _p(ws)
+    _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
+    return ws, blocks
 
 
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, **kw):
@@ -521,7 +545,7 @@ def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- Linear (two-source, fused bias / ReLU / residual) ----------------------------------------------
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32):
+    def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32, ln_in=None):
         _need_gpu(x, W)
         x = _c(x)
         M, K1 = x.shape
@@ -541,6 +565,7 @@ class _Linear(torch.autograd.Function):
         gemm(M, N, x, K1, Wop, K1, K1, y, y.stride(0), A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2,
              bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
         ctx.relu, ctx.compute = relu, compute
+        ctx.ln_in = ln_in if (x2 is None and not relu) else None
         ctx.has = (b is not None, x2 is not None, residual is not None)
         ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.params = (W, b, W2)
@@ -575,6 +600,8 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             if Wpad is not None and g.stride(0) == Wpad.shape[0]:  # zero columns of g x zero rows of the padded copy
                 gemm(M, K1, g, g.stride(0), Wpad, K1, Wpad.shape[0], dx, K1, transB=True, compute=ctx.compute)
+            elif ctx.ln_in is not None:  # dx is dy of the graph LayerNorm that produced x: its segment sums ride on this launch
+                _ln_bwd_stats_launch(ctx.ln_in, (M, K1, g, g.stride(0), W, K1, N, dx, K1), dict(transB=True, compute=ctx.compute), dx)
             else:
                 gemm(M, K1, g, g.stride(0), W, K1, N, dx, K1, transB=True, compute=ctx.compute)
         db_out = None
@@ -613,7 +640,7 @@ class _Linear(torch.autograd.Function):
                                        accumulate=True, compute=ctx.compute))
             dW2 = None if slot is not None else out2
         dres = _match(dy, ctx.res_dtype) if (has_res and needs[5]) else None
-        return dx, dW, db, dx2, dW2, dres, None, None, None
+        return dx, dW, db, dx2, dW2, dres, None, None, None, None
 
 
 def _compute_for(x):
@@ -701,10 +728,11 @@ def classifier_bank(x, anchor, views, compute=None):
     return outs
 
 
-def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False):
+def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False, ln_in=None):
     """y = relu?(x @ W.T (+ x2 @ W2.T) + b) (+ residual): one MFMA launch.  ``out_f32`` keeps the result
-    in f32 whatever the activation type (logits)."""
-    return _Linear.apply(x, W, b, x2, W2, residual, relu, _compute_for(x) if compute is None else compute, out_f32)
+    in f32 whatever the activation type (logits).  ``ln_in``: the context of the graph LayerNorm that produced x
+    (``graph_layernorm_lrelu(..., return_ctx=True)``): its backward sums are then taken in this layer's dX epilogue."""
+    return _Linear.apply(x, W, b, x2, W2, residual, relu, _compute_for(x) if compute is None else compute, out_f32, ln_in)
 
 
 class _MultiLinear(torch.autograd.Function):
@@ -958,9 +986,23 @@ def last_rowln_mask(y: torch.Tensor):
 
 
 # ---- graph-mode LayerNorm + LeakyReLU -------------------------------------------------------------------
+def _ln_bwd_stats_launch(lnctx, args, kw, dy_out):
+    """Launch the dX contraction ``gemm(*args, **kw)`` whose result ``dy_out`` is the gradient at the output of the graph
+    LayerNorm + LeakyReLU described by ``lnctx``; if the launch can, its epilogue also takes that LayerNorm's backward sums
+    (egk_gemm st_mode 2) and leaves them in ``lnctx['bwd']`` for ``_GraphLN.backward``."""
+    req = dict(mode=2, seg_ptr=lnctx["seg_ptr"], n_seg=lnctx["n_seg"], min_rows=lnctx["min_rows"], x=lnctx["x"],
+               stats=lnctx["stats"], w=lnctx["w"], b=lnctx["b"], slope=lnctx["slope"])
+    ok = (_ln_fusion["on"] and lnctx["x"].dtype == dy_out.dtype and lnctx["x"].shape == dy_out.shape)
+    got = _gemm_with_stats(args, kw, req) if ok else (gemm(*args, **kw) and None)
+    lnctx["bwd"] = (got[0], got[1], dy_out.data_ptr()) if got else None
+
+
+_ln_fusion = {"on": True}  # development knob: False = every graph LayerNorm runs its own statistics passes
+
+
 class _GraphLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, seg_ptr, eps, slope):
+    def forward(ctx, x, w, b, seg_ptr, eps, slope, partials=None, lnctx=None):
         _need_gpu(x, w, seg_ptr)
         lib = _lib.load()
         x = _c(x)
@@ -968,12 +1010,19 @@ class _GraphLN(torch.autograd.Function):
         n_seg = seg_ptr.numel() - 1
         y = torch.empty_like(x)
         stats = torch.empty(n_seg * 2, dtype=torch.float32, device=x.device)
-        ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
         wc, bc = _f32c(w), _f32c(b)
-        _ck(lib.egk_graphln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
-                                slope, _p(ws), _dt(x)), "egk_graphln_fwd")
+        if partials is not None:  # the segment sums came with the contraction that produced x
+            _ck(lib.egk_graphln_fwd_apply(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
+                                          slope, _p(partials[0]), partials[1], _dt(x)), "egk_graphln_fwd_apply")
+        else:
+            ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
+            _ck(lib.egk_graphln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
+                                    slope, _p(ws), _dt(x)), "egk_graphln_fwd")
         ctx.eps, ctx.slope = eps, slope
         ctx.params = (w, b)
+        ctx.lnctx = lnctx
+        if lnctx is not None:  # what the consumer's dX epilogue needs to take this layer's backward sums
+            lnctx.update(x=x, stats=stats, w=wc, b=bc, slope=slope, seg_ptr=seg_ptr, n_seg=n_seg, bwd=None)
         ctx.save_for_backward(x, wc, bc, stats, seg_ptr)
         return y
 
@@ -990,6 +1039,23 @@ class _GraphLN(torch.autograd.Function):
         slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
         dw = slot_w if slot_w is not None else torch.zeros_like(w)
         db = slot_b if slot_b is not None else torch.zeros_like(b)
+        pre = ctx.lnctx.get("bwd") if ctx.lnctx is not None else None
+        if ctx.lnctx is not None:
+            ctx.lnctx["bwd"] = None
+        if pre is not None and pre[2] == dy.data_ptr():
+            # the segment sums came with the contraction that produced dy: ONE pass (dx + the dw / db partial rows)
+            ws_col = torch.empty(lib.egk_rowln_bwd_ws_rows(rows) * 2 * cols, dtype=torch.float32, device=x.device)
+            _ck(lib.egk_graphln_bwd_apply(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(seg_ptr), n_seg, rows,
+                                          cols, ctx.eps, ctx.slope, _p(pre[0]), pre[1], _p(ws_col), _dt(x)), "egk_graphln_bwd_apply")
+            if _ln_reduce_on_side(slot_w, slot_b, x):
+                if _wq["on"] and _wgrad["enabled"]:
+                    _wgrad_defer_reduce(ws_col, dw, db, rows, cols, 0)
+                else:
+                    _wgrad_launch(True, (ws_col,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws_col), _p(dw), _p(db), rows, cols, 0),
+                                                               "egk_ln_bwd_reduce"))
+                return dx, None, None, None, None, None, None, None
+            _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws_col), _p(dw), _p(db), rows, cols, 0), "egk_ln_bwd_reduce")
+            return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None, None, None
         nbytes = lib.egk_graphln_ws_bytes(rows, cols, n_seg)
         if _ln_reduce_on_side(slot_w, slot_b, x):  # (see _RowLN.backward)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -1000,16 +1066,22 @@ class _GraphLN(torch.autograd.Function):
             else:
                 _wgrad_launch(True, (ws,), lambda: _ck(lib.egk_ln_bwd_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols, n_seg),
                                                        "egk_ln_bwd_reduce"))
-            return dx, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         ws = workspace(nbytes, x.device)
         _ck(lib.egk_graphln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(seg_ptr),
                                 n_seg, rows, cols, ctx.eps, ctx.slope, _p(ws), _dt(x)), "egk_graphln_bwd")
-        return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None
+        return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None, None, None
 
 
-def graph_layernorm_lrelu(x, w, b, seg_ptr, eps=1e-5, slope=0.2):
-    """LeakyReLU(gnn.LayerNorm(mode='graph')(x)) with statistics per row segment (int32 seg_ptr)."""
-    return _GraphLN.apply(x, w, b, seg_ptr, float(eps), float(slope))
+def graph_layernorm_lrelu(x, w, b, seg_ptr, eps=1e-5, slope=0.2, partials=None, min_seg_rows=0, return_ctx=False):
+    """LeakyReLU(gnn.LayerNorm(mode='graph')(x)) with statistics per row segment (int32 seg_ptr).
+    ``partials``: (double [blocks][n_seg][2], blocks) per-block (sum, sum of squares) per segment when the contraction that
+    produced x took them in its epilogue.  ``return_ctx``: also return the context a consumer (``sage_mean_layer`` /
+    ``linear`` with ``ln_in=``) needs to take this layer's BACKWARD sums in its dX epilogue (``min_seg_rows``: the
+    shortest segment, a host integer)."""
+    lnctx = {"min_rows": int(min_seg_rows)} if (return_ctx and min_seg_rows > 0) else None
+    y = _GraphLN.apply(x, w, b, seg_ptr, float(eps), float(slope), partials, lnctx)
+    return (y, lnctx) if return_ctx else y
 
 
 # ---- positional encoding add --------------------------------------------------------------------------
@@ -1083,7 +1155,7 @@ class _SageMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute, heavy=None, t_heavy=None,
-                heavy_mode=0, t_heavy_mode=0):
+                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None):
         _need_gpu(h, Wp, Wl, Wr)
         lib = _lib.load()
         h = _c(h)
@@ -1097,7 +1169,15 @@ class _SageMean(torch.autograd.Function):
         ctx.t_heavy_mode = t_heavy_mode
         Ho = Wl.shape[0]
         out = torch.empty((N, Ho), dtype=dt, device=h.device)
-        gemm(N, Ho, agg, H, Wl_o, H, H, out, Ho, A2=h, lda2=H, B2=Wr_o, ldb2=H, K2=H, bias=_f32c(bl), compute=compute)
+        c_args = (N, Ho, agg, H, Wl_o, H, H, out, Ho)
+        c_kw = dict(A2=h, lda2=H, B2=Wr_o, ldb2=H, K2=H, bias=_f32c(bl), compute=compute)
+        if ln_out is not None and _ln_fusion["on"]:
+            # the graph LayerNorm that follows needs (sum, sum of squares) per row segment of ``out``: taken in this epilogue
+            ln_out["partials"] = _gemm_with_stats(c_args, c_kw, dict(mode=1, seg_ptr=ln_out["seg_ptr"], n_seg=ln_out["n_seg"],
+                                                                     min_rows=ln_out["min_rows"]))
+        else:
+            gemm(*c_args, **c_kw)
+        ctx.ln_in = ln_in
         ctx.compute, ctx.params = compute, (Wp, bp, Wl, bl, Wr)
         ctx.save_for_backward(h, xp, agg, Wp_o, Wl_o, Wr_o, t_rowptr, t_col, t_wgt, t_heavy)
         return out
@@ -1141,21 +1221,29 @@ class _SageMean(torch.autograd.Function):
         d_h = None
         if ctx.needs_input_grad[0]:
             d_h = torch.empty_like(h)
-            gemm(N, H, g, g.stride(0), Wr_o, H, Ho, d_h, H, A2=d_pre, lda2=H, B2=Wp_o, ldb2=H, K2=H, transB=True,
-                 compute=ctx.compute)
+            h_args = (N, H, g, g.stride(0), Wr_o, H, Ho, d_h, H)
+            h_kw = dict(A2=d_pre, lda2=H, B2=Wp_o, ldb2=H, K2=H, transB=True, compute=ctx.compute)
+            if ctx.ln_in is not None:  # d_h is dy of the graph LayerNorm that produced h: its segment sums ride on this launch
+                _ln_bwd_stats_launch(ctx.ln_in, h_args, h_kw, d_h)
+            else:
+                gemm(*h_args, **h_kw)
         p_args, p_kw = (H, H, d_pre, H, h, H, N, dWp, H), dict(transA=True, transB=True, accumulate=True, compute=ctx.compute,
                                                                dbias=dbp)
         if not (rWp is None and rbp is None and ctx.compute == BF16 and _wgrad_defer(p_args, p_kw, (d_pre, h))):
             _wgrad_launch(rWp is None and rbp is None, (d_pre, h), lambda: gemm(*p_args, **p_kw))
-        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None)
+        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
-def sage_mean_layer(h, conv, graph, compute=None):
-    """SAGEConv(project=True, mean) of ``conv`` (models.layers.SAGEConv parameters) on CSR ``graph``."""
+def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None):
+    """SAGEConv(project=True, mean) of ``conv`` (models.layers.SAGEConv parameters) on CSR ``graph``.
+    ``ln_out`` = dict(seg_ptr, n_seg, min_rows): a graph LayerNorm over those row segments follows -- its forward sums are
+    taken in the last contraction's epilogue and left in ``ln_out['partials']`` (None if that launch could not).
+    ``ln_in``: context of the graph LayerNorm that produced ``h`` (see ``graph_layernorm_lrelu``)."""
     return _SageMean.apply(h, conv.lin.weight, conv.lin.bias, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight,
                            graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
                            _compute_for(h) if compute is None else compute, getattr(graph, "heavy", None),
-                           getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0), getattr(graph, "t_heavy_mode", 0))
+                           getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0), getattr(graph, "t_heavy_mode", 0),
+                           ln_out, ln_in)
 
 
 # ---- GraphONE gather-max ------------------------------------------------------------------------------

@@ -89,10 +89,30 @@ typedef struct egk_gemm_desc {
      * LDS (or by explicit column-sum launches when the pipelined kernel is not eligible).  Needs
      * ws_bytes >= egk_gemm_ws_bytes(desc). */
     float* dbias;
+    /* Per-segment sums of the RESULT for the graph-mode LayerNorm that consumes it (gnn.LayerNorm(mode='graph') at
+     * models/graph.py:43 -- statistics over all elements of a task batch = a row segment), taken in the epilogue so that the
+     * LayerNorm's own statistics pass over the tensor disappears:
+     *   st_mode 1  (sum c, sum c^2) of the stored result c                      -> egk_graphln_fwd_apply
+     *   st_mode 2  the result is dy of that LayerNorm + LeakyReLU: (sum dxhat, sum dxhat * xhat), dxhat = dy * lrelu'(pre) * w,
+     *              xhat = (x - mean) * rinv, pre = xhat * w + b                  -> egk_graphln_bwd_apply
+     * per row segment [st_seg_ptr[s], st_seg_ptr[s+1]) (device int32 [st_nseg + 1]; st_min_seg_rows = the shortest segment,
+     * for the host-side check that a tile spans at most two), one partial per output tile:
+     *   st_ws = double [egk_gemm_stats_blocks(desc)][st_nseg][2].
+     * Only some tile variants can do it: ask egk_gemm_stats_blocks() first (0 = run the LayerNorm's statistics pass). */
+    int32_t st_mode, st_nseg, st_min_seg_rows;
+    const int32_t* st_seg_ptr;
+    void* st_ws;
+    const void* st_x;      /* st_mode 2: the LayerNorm's input, laid out like C (leading dimension st_ldx, element type c_dtype) */
+    int64_t st_ldx;
+    const float* st_stats; /* st_mode 2: [st_nseg][2] (mean, 1 / (std + eps)) from the forward pass */
+    const float* st_w;
+    const float* st_b;
+    float st_slope;
 } egk_gemm_desc;
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
+int egk_gemm_stats_blocks(const egk_gemm_desc* d);
 /* Grouped launch: ``count`` (<= 4) independent contractions of the SAME layout (transA / transB), bf16 operands with
  * 16-byte aligned rows, every K source a multiple of 64, no split-K, in ONE launch (blockIdx.y = problem).  Replaces the
  * per-task projection heads of the multi-task step -- ProjectionTask.forward_features of every enabled task
@@ -150,6 +170,17 @@ int egk_graphln_fwd(egk_stream_t s, const void* x, const float* w, const float* 
 int egk_graphln_bwd(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b,
                     const float* stats, void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
                     int32_t rows, int32_t cols, float eps, float slope, void* ws, int32_t dtype);
+/* The second launches alone, with the per-segment sums taken from per-block partials computed ELSEWHERE -- by the
+ * epilogue of the contraction that produced x (forward, egk_gemm_desc.st_mode 1) or dy (backward, st_mode 2):
+ *   partials = double [n_partials][n_seg][2]  ((sum x, sum x^2)  /  (sum dxhat, sum dxhat * xhat) per segment).
+ * bwd_apply also writes the partial rows of dw / db (the statistics pass used to): ws_col f32
+ * [egk_rowln_bwd_ws_rows(rows)][2][cols], reduced by egk_ln_bwd_reduce(ws_col, dw, db, rows, cols, 0). */
+int egk_graphln_fwd_apply(egk_stream_t s, const void* x, const float* w, const float* b, void* y, float* stats,
+                          const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope,
+                          const void* partials, int32_t n_partials, int32_t dtype);
+int egk_graphln_bwd_apply(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b, const float* stats,
+                          void* dx, const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope,
+                          const void* partials, int32_t n_partials, float* ws_col, int32_t dtype);
 /* The parameter-gradient reduction of egk_rowln_bwd (n_seg = 0) / egk_graphln_bwd (n_seg >= 1) as its own launch: call
  * those with dw = db = NULL (they then leave the per-workgroup partial rows in ws) and this one, with the same ws, rows,
  * cols, on whatever stream should carry it -- dw / db feed nothing but the optimizer, the kernels that need dx need not

@@ -1002,3 +1002,77 @@ def test_rowln_grouped_equals_per_range_launches(ops, dt, cols, rows):
         tol = dict(rtol=1e-4, atol=1e-4 * max(1.0, rows[k] ** 0.5))
         torch.testing.assert_close(dw, w1.grad, **tol)
         torch.testing.assert_close(db, b1.grad, **tol)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# graph-LayerNorm statistics taken in the epilogue of the contraction that produces its input / its output gradient
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,segs", [(6144, [0, 2048, 4096, 6144]), (2048, [0, 2048]), (1000, [0, 300, 1000]), (4500, [0, 1000, 2500, 4500])])
+def test_gemm_epilogue_segment_statistics_feed_graph_layernorm(ops, M, segs):
+    """egk_gemm st_mode 1 / 2: the per-tile partials of (sum, sum^2) of the result, resp. of the LayerNorm-backward sums,
+    summed over tiles equal the direct fp64 sums of the STORED (bf16-rounded) result; the apply-only LayerNorm entry points
+    fed with them reproduce the two-pass kernels (y, dx, dw, db), tiles straddling segment boundaries included."""
+    import ctypes as C
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(M)
+    H = 1024 if M > 1500 else 256
+    K = 512
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(H, K, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(H, generator=g).to(DEV)
+    seg = torch.tensor(segs, dtype=torch.int32, device=DEV)
+    n_seg, min_rows = len(segs) - 1, min(b - a for a, b in zip(segs, segs[1:]))
+    lw, lb = (torch.randn(H, generator=g) * 0.5 + 1).to(DEV), (torch.randn(H, generator=g) * 0.2).to(DEV)
+    out = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    args, kw = (M, H, A, K, W, K, K, out, H), dict(bias=bias, compute=ops.BF16)
+    got = ops._gemm_with_stats(args, kw, dict(mode=1, seg_ptr=seg, n_seg=n_seg, min_rows=min_rows))
+    if min_rows < 64:
+        assert got is None
+        return
+    assert got is not None, "the rows-epilogue variants must take the statistics at these shapes"
+    ws, blocks = got
+    part = ws.view(blocks, n_seg, 2).sum(0).cpu()
+    ref_out = torch.empty_like(out)
+    ops.gemm(*args[:7], ref_out, H, **kw)
+    assert torch.equal(out, ref_out)  # the statistics do not touch the result
+    o64 = out.double().cpu()
+    for s_ in range(n_seg):
+        blk = o64[segs[s_]:segs[s_ + 1]]
+        torch.testing.assert_close(part[s_, 0], blk.sum(), rtol=1e-6, atol=1e-3)
+        torch.testing.assert_close(part[s_, 1], (blk * blk).sum(), rtol=1e-6, atol=1e-3)
+    # forward: apply-only entry point == the two-pass kernel
+    y_ref = ops.graph_layernorm_lrelu(out, lw, lb, seg)
+    y, lnctx = ops.graph_layernorm_lrelu(out, lw, lb, seg, partials=(ws, blocks), min_seg_rows=min_rows, return_ctx=True)
+    torch.testing.assert_close(y.float(), y_ref.float(), rtol=1e-2, atol=1e-2)
+    assert (y != y_ref).float().mean() < 0.02  # (last-bit differences of the segment mean / std only)
+    # backward: dy produced by a dX-shaped contraction with st_mode 2
+    G = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    W2 = (torch.randn(K, H, generator=g) * 0.1).to(torch.bfloat16).to(DEV)  # [K, H]: transB layout, dy = G @ W2
+    dy = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    ops._ln_bwd_stats_launch(lnctx, (M, H, G, K, W2, H, K, dy, H), dict(transB=True, compute=ops.BF16), dy)
+    assert lnctx["bwd"] is not None and lnctx["bwd"][2] == dy.data_ptr()
+    ws2, blocks2, _ = lnctx["bwd"]
+    x64, dy64 = out.double().cpu(), dy.double().cpu()
+    stats = lnctx["stats"].double().cpu().view(n_seg, 2)
+    part2 = ws2.view(blocks2, n_seg, 2).sum(0).cpu()
+    for s_ in range(n_seg):
+        xs, ds = x64[segs[s_]:segs[s_ + 1]], dy64[segs[s_]:segs[s_ + 1]]
+        xh = (xs - stats[s_, 0]) * stats[s_, 1]
+        pre = xh * lw.double().cpu() + lb.double().cpu()
+        dxh = ds * torch.where(pre > 0, 1.0, 0.2) * lw.double().cpu()
+        torch.testing.assert_close(part2[s_, 0], dxh.sum(), rtol=2e-4, atol=5e-2)
+        torch.testing.assert_close(part2[s_, 1], (dxh * xh).sum(), rtol=2e-4, atol=5e-2)
+    # autograd through both paths
+    def grads(use_pre):
+        xin = out.clone().requires_grad_(True)
+        w1, b1 = lw.clone().requires_grad_(True), lb.clone().requires_grad_(True)
+        yy, ctx2 = ops.graph_layernorm_lrelu(xin, w1, b1, seg, min_seg_rows=min_rows, return_ctx=True)
+        if use_pre:
+            ops._ln_bwd_stats_launch(ctx2, (M, H, G, K, W2, H, K, dy, H), dict(transB=True, compute=ops.BF16), dy)
+        yy.backward(dy)
+        return xin.grad, w1.grad, b1.grad
+    (dx1, dw1, db1), (dx0, dw0, db0) = grads(True), grads(False)
+    torch.testing.assert_close(dx1.float(), dx0.float(), rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(dw1, dw0, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(db1, db0, rtol=1e-3, atol=1e-2)
