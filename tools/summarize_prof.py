@@ -74,16 +74,19 @@ if f:
             if r["Counter_Name"] == "SQ_WAVE_CYCLES":
                 calls[r["Kernel_Name"]] += 1
     print("## matrix-pipe utilisation (SQ counters, own pass)\n")
-    print("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (both summed over SEs/XCDs as rocprofv3 reports them; the ratio is "
-          "the fraction of the busy time in which a matrix instruction was executing); wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES "
-          "(waves parked on s_waitcnt / barriers), issue-stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.\n")
-    print("| kernel | launches | MFMA busy / busy | wait / wave cycles | issue stall / wave cycles | bf16 MOPS per launch |")
+    print("MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32).  Calibration on this chip: "
+          "SQ_VALU_MFMA_BUSY_CYCLES is the matrix-pipe cycles summed over all 1024 SIMDs (6144 x 1024 x 1024 bf16 = 786 432 "
+          "v_mfma_f32_16x16x32_bf16 x 16 cycles = 12 582 912, the value reported), SQ_BUSY_CYCLES is summed over the 32 shader "
+          "engines (32 SIMDs each), so the quotient is the fraction of the kernel's busy SIMD-cycles in which the matrix pipe "
+          "was executing.  wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked on s_waitcnt / barriers), issue-stall = "
+          "SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.\n")
+    print("| kernel | launches | MFMA pipe utilisation | wait / wave cycles | issue stall / wave cycles | bf16 MOPS per launch |")
     print("|---|---:|---:|---:|---:|---:|")
     mfma = {}
     for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))[:25]:
         busy, wave = c.get("SQ_BUSY_CYCLES", 0.0) or 1.0, c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
         n = max(calls[k], 1)
-        row = {"launches": n, "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy,
+        row = {"launches": n, "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (busy * 32.0),
                "wait_frac": c.get("SQ_WAIT_ANY", 0.0) / wave, "issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0.0) / wave,
                "mops_bf16_per_launch": c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / n}
         mfma[short(k)] = row
