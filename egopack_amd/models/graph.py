@@ -98,13 +98,17 @@ class Graph(torch.nn.Module):
         min_rows = int(getattr(data, "min_seg_rows", 0) or (x.shape[0] if seg_ptr.numel() == 2 else 0))
         n_seg = seg_ptr.numel() - 1
         ln_prev = None
+        # x feeds the stack (through x + PE(pos), gradient = identity) and the final residual: instead of autograd adding
+        # the two gradients of x in a pass of its own, the final Linear hands the residual's gradient to the FIRST SAGE layer,
+        # which adds it in the epilogue of its dX contraction (both are gradients of the same [N, H] tensor)
+        res = {} if (self.depth > 0 and x.requires_grad and h.dtype == x.dtype) else None
         for d in range(self.depth):
             conv = getattr(self.net, f"module_{3 * d}")
             norm = getattr(self.net, f"module_{3 * d + 1}")
             slope = getattr(self.net, f"module_{3 * d + 2}").negative_slope
             req = {"seg_ptr": seg_ptr, "n_seg": n_seg, "min_rows": min_rows} if min_rows > 0 else None
-            c = ops.sage_mean_layer(h, conv, graph, ln_out=req, ln_in=ln_prev)
+            c = ops.sage_mean_layer(h, conv, graph, ln_out=req, ln_in=ln_prev, res_src=res if d == 0 else None)
             h, ln_prev = norm(c, seg_ptr, slope, partials=req.get("partials") if req else None, min_seg_rows=min_rows,
                               return_ctx=True)                # SAGEConv -> graph-LN -> LeakyReLU
         last = getattr(self.net, f"module_{3 * self.depth}")
-        return last(h, residual=x, ln_in=ln_prev)             # x + Linear(h): residual in the epilogue
+        return last(h, residual=x, ln_in=ln_prev, res_sink=res)  # x + Linear(h): residual in the epilogue

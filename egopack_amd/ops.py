@@ -545,7 +545,7 @@ def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- Linear (two-source, fused bias / ReLU / residual) ----------------------------------------------
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32, ln_in=None):
+    def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32, ln_in=None, res_sink=None):
         _need_gpu(x, W)
         x = _c(x)
         M, K1 = x.shape
@@ -566,6 +566,7 @@ class _Linear(torch.autograd.Function):
              bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
         ctx.relu, ctx.compute = relu, compute
         ctx.ln_in = ln_in if (x2 is None and not relu) else None
+        ctx.res_sink = res_sink if residual is not None else None
         ctx.has = (b is not None, x2 is not None, residual is not None)
         ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.params = (W, b, W2)
@@ -640,7 +641,12 @@ class _Linear(torch.autograd.Function):
                                        accumulate=True, compute=ctx.compute))
             dW2 = None if slot is not None else out2
         dres = _match(dy, ctx.res_dtype) if (has_res and needs[5]) else None
-        return dx, dW, db, dx2, dW2, dres, None, None, None, None
+        if dres is not None and ctx.res_sink is not None:
+            # the residual operand's gradient is handed to the node named by the caller (models.Graph: the first SAGE layer,
+            # which adds it in its dX epilogue) instead of to autograd, which would add the two gradients of x in a pass
+            ctx.res_sink["dy"] = dres
+            dres = None
+        return dx, dW, db, dx2, dW2, dres, None, None, None, None, None
 
 
 def _compute_for(x):
@@ -728,11 +734,13 @@ def classifier_bank(x, anchor, views, compute=None):
     return outs
 
 
-def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False, ln_in=None):
+def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False, ln_in=None, res_sink=None):
     """y = relu?(x @ W.T (+ x2 @ W2.T) + b) (+ residual): one MFMA launch.  ``out_f32`` keeps the result
     in f32 whatever the activation type (logits).  ``ln_in``: the context of the graph LayerNorm that produced x
-    (``graph_layernorm_lrelu(..., return_ctx=True)``): its backward sums are then taken in this layer's dX epilogue."""
-    return _Linear.apply(x, W, b, x2, W2, residual, relu, _compute_for(x) if compute is None else compute, out_f32, ln_in)
+    (``graph_layernorm_lrelu(..., return_ctx=True)``): its backward sums are then taken in this layer's dX epilogue.
+    ``res_sink``: a dict -- in backward the gradient of ``residual`` is put there (key 'dy') instead of being returned to
+    autograd; the caller guarantees that a node earlier in the graph (``sage_mean_layer(..., res_src=)``) adds it."""
+    return _Linear.apply(x, W, b, x2, W2, residual, relu, _compute_for(x) if compute is None else compute, out_f32, ln_in, res_sink)
 
 
 class _MultiLinear(torch.autograd.Function):
@@ -1155,7 +1163,7 @@ class _SageMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute, heavy=None, t_heavy=None,
-                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None):
+                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None, res_src=None):
         _need_gpu(h, Wp, Wl, Wr)
         lib = _lib.load()
         h = _c(h)
@@ -1177,7 +1185,7 @@ class _SageMean(torch.autograd.Function):
                                                                      min_rows=ln_out["min_rows"]))
         else:
             gemm(*c_args, **c_kw)
-        ctx.ln_in = ln_in
+        ctx.ln_in, ctx.res_src = ln_in, res_src
         ctx.compute, ctx.params = compute, (Wp, bp, Wl, bl, Wr)
         ctx.save_for_backward(h, xp, agg, Wp_o, Wl_o, Wr_o, t_rowptr, t_col, t_wgt, t_heavy)
         return out
@@ -1223,6 +1231,11 @@ class _SageMean(torch.autograd.Function):
             d_h = torch.empty_like(h)
             h_args = (N, H, g, g.stride(0), Wr_o, H, Ho, d_h, H)
             h_kw = dict(A2=d_pre, lda2=H, B2=Wp_o, ldb2=H, K2=H, transB=True, compute=ctx.compute)
+            extra = ctx.res_src.pop("dy", None) if ctx.res_src is not None else None
+            if extra is not None:  # a gradient of h that another node handed over (the backbone's residual): added here
+                if tuple(extra.shape) != tuple(d_h.shape):
+                    raise RuntimeError("sage_mean_layer: the handed-over gradient does not have the layer input's shape")
+                h_kw.update(residual=_c(extra), ldr=H)
             if ctx.ln_in is not None:  # d_h is dy of the graph LayerNorm that produced h: its segment sums ride on this launch
                 _ln_bwd_stats_launch(ctx.ln_in, h_args, h_kw, d_h)
             else:
@@ -1231,19 +1244,21 @@ class _SageMean(torch.autograd.Function):
                                                                dbias=dbp)
         if not (rWp is None and rbp is None and ctx.compute == BF16 and _wgrad_defer(p_args, p_kw, (d_pre, h))):
             _wgrad_launch(rWp is None and rbp is None, (d_pre, h), lambda: gemm(*p_args, **p_kw))
-        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None)
+        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
-def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None):
+def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_src=None):
     """SAGEConv(project=True, mean) of ``conv`` (models.layers.SAGEConv parameters) on CSR ``graph``.
     ``ln_out`` = dict(seg_ptr, n_seg, min_rows): a graph LayerNorm over those row segments follows -- its forward sums are
     taken in the last contraction's epilogue and left in ``ln_out['partials']`` (None if that launch could not).
-    ``ln_in``: context of the graph LayerNorm that produced ``h`` (see ``graph_layernorm_lrelu``)."""
+    ``ln_in``: context of the graph LayerNorm that produced ``h`` (see ``graph_layernorm_lrelu``).
+    ``res_src``: a dict in which a later node of the forward graph leaves, in backward, a gradient that belongs to ``h``
+    as well (``linear(..., res_sink=)``): it is added in this layer's dX epilogue."""
     return _SageMean.apply(h, conv.lin.weight, conv.lin.bias, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight,
                            graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
                            _compute_for(h) if compute is None else compute, getattr(graph, "heavy", None),
                            getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0), getattr(graph, "t_heavy_mode", 0),
-                           ln_out, ln_in)
+                           ln_out, ln_in, res_src)
 
 
 # ---- GraphONE gather-max ------------------------------------------------------------------------------
@@ -1643,6 +1658,21 @@ class _SplitRows(torch.autograd.Function):
         import ctypes as C_
         lib = _lib.load()
         dev = next(g.device for g in gs if g is not None)
+        # the slice gradients already are consecutive row ranges of ONE buffer (the grouped projection heads write their
+        # dx that way): hand that buffer back, no copy
+        if all(g is not None and g.dtype == ctx.dtype and g.is_contiguous() for g in gs):
+            st = gs[0].untyped_storage()
+            row_elems = 1
+            for d_ in ctx.shape[1:]:
+                row_elems *= d_
+            off, ok = gs[0].storage_offset(), True
+            for g, sz in zip(gs, ctx.sizes):
+                ok = (ok and g.untyped_storage().data_ptr() == st.data_ptr() and g.storage_offset() == off
+                      and tuple(g.shape) == (sz, *ctx.shape[1:]))
+                off += sz * row_elems
+            if ok and (off - gs[0].storage_offset()) == ctx.shape[0] * row_elems:
+                whole = torch.empty(0, dtype=ctx.dtype, device=dev).set_(st, gs[0].storage_offset(), tuple(ctx.shape))
+                return whole, None
         out = torch.empty(ctx.shape, dtype=ctx.dtype, device=dev)
         row_bytes = out[0].numel() * out.element_size() if out.shape[0] else 0
         srcs = [None if g is None else _c(_match(g, ctx.dtype)) for g in gs]
