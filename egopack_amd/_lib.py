@@ -69,6 +69,8 @@ SIGNATURES = {
     "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
     "egk_graphln_fwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32]),
     "egk_graphln_bwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, vp, i32]),
+    "egk_pe_table": (C.c_int, [vp, vp, i64, i32, i32, vp]),
+    "egk_pe_add_table": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, vp, i32, i32, i32]),
     "egk_pe_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
     "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32]),
     "egk_csr_heavy_ws_bytes": (i64, [i32, i32]),

@@ -195,6 +195,8 @@ def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
     ei = torch.cat(eis, dim=1)
     out = Data(x=None if resident else torch.cat(xs), y=torch.cat(ys), pos=torch.cat(poss), edge_index=ei,
                batch=torch.cat(batch), ptr=torch.tensor(ptr, dtype=torch.long), num_graphs=len(samples))
+    if out.pos.numel() and not out.pos.is_floating_point():  # host integers: the positional-encoding table's range
+        out.pos_range = (int(out.pos.min()), int(out.pos.max()))
     if resident:  # rows of the device-resident feature store (feature_store.FeatureStore.gather builds x in HBM)
         out.x_idx = torch.cat(xs)
     out.graph = build_csr(ei, off) if with_csr else None
@@ -242,6 +244,8 @@ def merge_batches(batches: Sequence[Data]) -> Data:
     out.seg_ptr = torch.tensor(seg, dtype=torch.int32)
     out.num_segments = len(batches)
     out.min_seg_rows = min(b - a for a, b in zip(seg, seg[1:]))  # (host integer: the shortest task batch, in rows)
+    if all(getattr(b, "pos_range", None) is not None for b in batches):
+        out.pos_range = (min(b.pos_range[0] for b in batches), max(b.pos_range[1] for b in batches))
     return out
 
 

@@ -325,6 +325,7 @@ class StepBase:
         self._fused_loss = "fused_loss" not in off
         if "ln_fusion" in off:
             ops._ln_fusion["on"] = False
+        self._dev_off = off
 
     # ---- backbone ------------------------------------------------------------------------------------
     def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:
@@ -541,12 +542,16 @@ class StepBase:
                 ops.stamp("step_start")
                 # the gradient buffer is cleared BESIDE the forward pass (nothing writes a gradient before the first backward
                 # launch): 100 MB of memset off the chain's head; joined in _join_zero() before backward starts
-                if not hasattr(self, "_zero_stream"):
-                    self._zero_stream = torch.cuda.Stream()
-                self._zero_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._zero_stream):
+                if "zero_stream" in getattr(self, "_dev_off", ()):
                     opt.flat_g.zero_()
-                self._zero_pending = True
+                else:
+                    if not hasattr(self, "_zero_stream"):
+                        self._zero_stream = torch.cuda.Stream()
+                    self._zero_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._zero_stream):
+                        opt.flat_g.zero_()
+                    self._zero_pending = True
+                self._rng_in_graph = False
                 if self.input_hook is not None:
                     self.input_hook()
                 if early is not None:
@@ -563,6 +568,11 @@ class StepBase:
                     else:
                         opt.launch()
                     ops.stamp("adam_done")
+                # the Philox offset word of the dropout launches moves on INSIDE the graph (last node, beside nothing that reads
+                # it): replay k draws the masks of offset base + k * stride without a separate launch in front of every replay
+                if "rng_in_graph" not in getattr(self, "_dev_off", ()):
+                    ops.advance_rng_device(opt.flat_p.device)
+                    self._rng_in_graph = True
         finally:
             ops.set_last_wgrad_hook(None, None)
             ops.set_wgrad_side_streams(prev)
@@ -646,7 +656,8 @@ class StepBase:
     def replay(self):
         """One training step from the captured graph(s)."""
         opt = self.optimizer
-        ops.advance_rng_device(opt.flat_p.device)
+        if not getattr(self, "_rng_in_graph", False):
+            ops.advance_rng_device(opt.flat_p.device)
         if isinstance(self._graph, list):
             regions = self._stage_regions()
             for g, region in zip(self._graph, regions):

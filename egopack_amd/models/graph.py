@@ -91,7 +91,11 @@ class Graph(torch.nn.Module):
                 data.seg_ptr = seg_ptr
             except Exception:
                 pass
-        h = self.positional_encoding.add_to(x, data.pos)
+        pr = getattr(data, "pos_range", None)  # (min, max) of the positions, known on the host for collated batches
+        import os
+        if "pe_table" in os.environ.get("EGK_DISABLE", ""):
+            pr = None
+        h = self.positional_encoding.add_to(x, data.pos, tuple(pr) if pr is not None else None)
         # the graph LayerNorm's per-segment sums ride on the epilogue of the contraction that produces its input (forward:
         # the SAGE layer's last contraction; backward: the dX contraction of whatever consumes its output) when the shortest
         # row segment is known on the host (merged / collated batches carry it) -- no statistics pass over the tensor

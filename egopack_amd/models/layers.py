@@ -50,8 +50,8 @@ class PositionalEncoding(nn.Module):
         self.out_channels = out_channels
         self.register_buffer("frequency", torch.logspace(0, 1, out_channels // 2, base_freq))
 
-    def add_to(self, x, pos):
-        return ops.pe_add(x, pos, self.frequency)
+    def add_to(self, x, pos, pos_range=None):
+        return ops.pe_add(x, pos, self.frequency, pos_range)
 
 
 class SAGEConv(nn.Module):

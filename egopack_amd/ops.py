@@ -1093,26 +1093,74 @@ def graph_layernorm_lrelu(x, w, b, seg_ptr, eps=1e-5, slope=0.2, partials=None, 
 
 
 # ---- positional encoding add --------------------------------------------------------------------------
+_pe_tables = {}
+_pe_freq_ids = {}
+
+
+def _pe_freq_id(freq):
+    """Identity of a frequency buffer by CONTENT (models built alike share their tables; a table is never freed, so a
+    captured graph that reads one stays valid): a host hash taken the first time a buffer is seen -- outside graph captures
+    only (it synchronises); None while capturing an unseen buffer."""
+    k = (freq.data_ptr(), freq._version, freq.numel(), freq.device.index)
+    fid = _pe_freq_ids.get(k)
+    if fid is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        fid = hash(freq.detach().float().cpu().numpy().tobytes())
+        if len(_pe_freq_ids) > 256:
+            _pe_freq_ids.clear()
+        _pe_freq_ids[k] = fid
+    return fid
+
+
+def _pe_table(freq, fid, pos_min: int, n_pos: int, cols: int):
+    """[n_pos, cols] f32 table of PE(p), p in [pos_min, pos_min + n_pos), cached per (frequency content, range, device) for
+    the life of the process (128 KB for 32 positions x 1024 channels).  Built outside graph captures; None if it would have
+    to be built inside one."""
+    key = (fid, int(pos_min), int(n_pos), int(cols), freq.device.index)
+    t = _pe_tables.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = torch.empty((n_pos, cols), dtype=torch.float32, device=freq.device)
+        _ck(_lib.load().egk_pe_table(_stream(), _p(_f32c(freq)), int(pos_min), int(n_pos), int(cols), _p(t)), "egk_pe_table")
+        torch.cuda.current_stream().synchronize()  # (built once; later readers may sit on any stream)
+        _pe_tables[key] = t
+    return t
+
+
 class _PEAdd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pos, freq):
+    def forward(ctx, x, pos, freq, pos_range):
         _need_gpu(x, pos, freq)
         x = _c(x)
         rows, cols = x.shape
         y = torch.empty_like(x)
-        _ck(_lib.load().egk_pe_add(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(y), rows, cols, _dt(x)),
-            "egk_pe_add")
+        lib = _lib.load()
+        n_pos = (pos_range[1] - pos_range[0] + 1) if pos_range is not None else 0
+        table = None
+        if 0 < n_pos <= 4096:
+            fid = _pe_freq_id(freq)
+            table = _pe_table(freq, fid, pos_range[0], n_pos, cols) if fid is not None else None
+        if table is not None:
+            _ck(lib.egk_pe_add_table(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(table), int(pos_range[0]), int(n_pos),
+                                     _p(y), rows, cols, _dt(x)), "egk_pe_add_table")
+        else:
+            _ck(lib.egk_pe_add(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(y), rows, cols, _dt(x)), "egk_pe_add")
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        return dy, None, None
+        return dy, None, None, None
 
 
-def pe_add(x, pos, freq):
+def pe_add(x, pos, freq, pos_range=None):
+    """x + PositionalEncoding(pos).  ``pos_range`` = (min, max) of the integer positions when the host knows it (collated
+    batches carry it): PE is then evaluated once per distinct position (a cached [max - min + 1, C] table) instead of once
+    per node -- same bits."""
     if pos.dtype != torch.int64:
         pos = pos.to(torch.int64)
-    return _PEAdd.apply(x, pos, freq)
+    return _PEAdd.apply(x, pos, freq, pos_range)
 
 
 # ---- CSR mean aggregation -------------------------------------------------------------------------------

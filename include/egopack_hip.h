@@ -206,6 +206,13 @@ int egk_rowln_group_bwd(egk_stream_t s, const void* dy, const void* x, const flo
  * y[n, c] = x[n, c] + (c < C/2 ? sin(pos[n]*freq[c]) : cos(pos[n]*freq[c-C/2])) */
 int egk_pe_add(egk_stream_t s, const void* x, const int64_t* pos, const float* freq, void* y, int32_t rows,
                int32_t cols, int32_t dtype);
+/* The same with PE evaluated once per DISTINCT position instead of once per node (a batch of B sequences of T clips has T
+ * positions): table[p - pos_min, :] = PE(p) for p in [pos_min, pos_min + n_pos) (egk_pe_table: the sinf / cosf evaluations
+ * of egk_pe_add, so the sums are bit-identical), then y = x + table[pos - pos_min] (positions outside the table are
+ * evaluated directly). */
+int egk_pe_table(egk_stream_t s, const float* freq, int64_t pos_min, int32_t n_pos, int32_t cols, float* table);
+int egk_pe_add_table(egk_stream_t s, const void* x, const int64_t* pos, const float* freq, const float* table, int64_t pos_min,
+                     int32_t n_pos, void* y, int32_t rows, int32_t cols, int32_t dtype);
 
 /* ---- CSR row gathers (message passing) ------------------------------------------------
  * out[i,:] = sum_{e in [rowptr[i], rowptr[i+1])} w_e * x[col[e], :]

@@ -1076,3 +1076,20 @@ def test_gemm_epilogue_segment_statistics_feed_graph_layernorm(ops, M, segs):
     torch.testing.assert_close(dx1.float(), dx0.float(), rtol=2e-2, atol=2e-3)
     torch.testing.assert_close(dw1, dw0, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(db1, db0, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pe_add_table_is_bit_identical_to_the_direct_evaluation(ops, dt):
+    """x + PE(pos) from the cached per-position table (egk_pe_table + egk_pe_add_table) against the per-node evaluation
+    (egk_pe_add): the same sinf / cosf values, so the same bits; positions outside the announced range fall back to the
+    direct evaluation inside the kernel."""
+    g = gen(17)
+    rows, cols = 300, 1024
+    x = torch.randn(rows, cols, generator=g).to(dt).to(DEV)
+    pos = torch.randint(-16, 16, (rows,), generator=g).to(DEV)
+    freq = torch.logspace(0, 1, cols // 2, 1e-4).to(DEV)
+    ref = ops.pe_add(x, pos, freq)
+    assert torch.equal(ops.pe_add(x, pos, freq, (-16, 15)), ref)
+    assert torch.equal(ops.pe_add(x, pos, freq, (-4, 3)), ref)  # most positions outside the table
+    torch.testing.assert_close(ref.float().cpu(), (x.float().cpu() + P.positional_encoding(pos.cpu(), freq.cpu())).to(dt).float(),
+                               rtol=1e-2 if dt == torch.bfloat16 else 1e-5, atol=1e-2 if dt == torch.bfloat16 else 1e-5)
