@@ -958,7 +958,7 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
 // weights).  blockIdx.y = problem, blockIdx.x = its tile id; gridDim.x is the largest tile count rounded up to a
 // multiple of 8, so that blockIdx.x & 7 is still the XCD the hardware deals the workgroup to (linear id = y * gridDim.x
 // + x) and every problem keeps its XCD-local tile order.  Workgroups beyond a problem's tile count leave at once.
-constexpr int MAX_GROUPS = 4;
+constexpr int MAX_GROUPS = 8;
 struct GemmGroup {
     GemmArgs p[MAX_GROUPS];
 };

@@ -15,6 +15,7 @@ Every op is polymorphic in the activation element type: it follows the dtype of 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -276,7 +277,7 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=No
 
 
 def gemm_grouped(problems):
-    """ONE launch for up to 4 independent contractions of the same layout (``problems``: a list of (args, kwargs) of
+    """ONE launch for up to 8 independent contractions of the same layout (``problems``: a list of (args, kwargs) of
     ``gemm`` without the split-K options; bf16 operands, K sources multiples of 64)."""
     lib = _lib.load()
     arr = (_lib.GemmDesc * len(problems))()
@@ -378,7 +379,12 @@ def _wgrad_launch(in_place: bool, tensors, launch, in_backward: bool = True):
 # and issued FOUR AT A TIME as one grouped launch on the side stream: 256 workgroups, one per CU, no slabs, no reduce
 # launch, a quarter of the forks.  ``flush_wgrad`` issues what is parked (fewer than four at the end of backward).
 _wq = {"on": False, "items": [], "tiles": 0, "hold": [], "extra": []}
-WGRAD_GROUP_TILES = 256
+# Four per launch is the measured optimum INSIDE the step.  Alone, six H x H problems in one launch of two 4-wave
+# workgroups per CU run at 900 TF/s against 740 for four (tools/gemm_group_bench.py: x4 70 us, x6 85 us, x8 133 us at
+# K = 6144), but beside the dX chain the larger launches cost more than they save: 1.68 / 1.75 / 1.68 ms per step for
+# 4 / 6 / 8 on one box, 200 steps each, four rounds.  EGK_WGRAD_COUNT is a development knob (the library takes up to 8).
+WGRAD_GROUP_COUNT = int(os.environ.get("EGK_WGRAD_COUNT", "4"))
+WGRAD_GROUP_TILES = 64 * WGRAD_GROUP_COUNT
 
 
 def set_wgrad_grouping(on: bool) -> bool:
@@ -413,7 +419,7 @@ def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False) -> bool:
     _wq["tiles"] += ((M + 127) // 128) * ((N + 127) // 128)
     if excluded:
         return True
-    if len(_wq["items"]) >= 4 or _wq["tiles"] >= WGRAD_GROUP_TILES:
+    if len(_wq["items"]) >= WGRAD_GROUP_COUNT or _wq["tiles"] >= WGRAD_GROUP_TILES:
         flush_wgrad()
     elif not _wgrad["queued"]:  # make sure the end-of-backward join (which flushes) is scheduled
         _wgrad["queued"] = True
@@ -465,8 +471,8 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
     _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
 
     def launch():
-        for i in range(0, len(items), 4):
-            chunk = items[i:i + 4]
+        for i in range(0, len(items), 8):
+            chunk = items[i:i + 8]
             if len(chunk) == 1:
                 gemm(*chunk[0][0], **chunk[0][1])
             else:

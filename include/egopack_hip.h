@@ -113,7 +113,7 @@ typedef struct egk_gemm_desc {
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_stats_blocks(const egk_gemm_desc* d);
-/* Grouped launch: ``count`` (<= 4) independent contractions of the SAME layout (transA / transB), bf16 operands with
+/* Grouped launch: ``count`` (<= 8) independent contractions of the SAME layout (transA / transB), bf16 operands with
  * 16-byte aligned rows, every K source a multiple of 64, no split-K, in ONE launch (blockIdx.y = problem).  Replaces the
  * per-task projection heads of the multi-task step -- ProjectionTask.forward_features of every enabled task
  * (models/tasks/task.py:17-26, called per task at main_temporal.py:93-126) -- whose contractions have the same shapes but

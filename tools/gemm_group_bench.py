@@ -33,3 +33,14 @@ for M in (2048, 6144, 16384):
     for n in (2, 3):
         us = time_us(lambda: ops.gemm_grouped(probs[:n]), 20)
         print(f"M={M:6d} grouped x{n}                     {us:7.1f} us  {n / 4 * fl / us / 1e6:7.0f} TF/s")
+    gs8 = gs + [torch.randn(M, H, device="cuda").to(torch.bfloat16) for _ in range(4)]
+    xs8 = xs + [torch.randn(M, H, device="cuda").to(torch.bfloat16) for _ in range(4)]
+    outs8 = outs + [torch.zeros(H, H, device="cuda") for _ in range(4)]
+    probs8 = [((H, H, gs8[i], H, xs8[i], H, M, outs8[i], H), dict(transA=True, transB=True, accumulate=True, compute=ops.BF16))
+              for i in range(8)]
+    for knob, name in ((1, "policy"), (3, "4-wave 128x128"), (5, "two wave groups")):
+        lib.egk_gemm_set_pipeline(knob)
+        for n in (6, 8):
+            us = time_us(lambda: ops.gemm_grouped(probs8[:n]), 10)
+            print(f"M={M:6d} grouped x{n} [{name:16s}] {us:7.1f} us  {n / 4 * fl / us / 1e6:7.0f} TF/s")
+    lib.egk_gemm_set_pipeline(1)
