@@ -67,6 +67,10 @@ SIGNATURES = {
     "egk_graphln_ws_bytes": (i64, [i32, i32, i32]),
     "egk_graphln_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
     "egk_graphln_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32]),
+    "egk_graphln_stats_blocks": (i32, [i32]),
+    "egk_graphln_stats": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32]),
+    "egk_graphln_bwd_stats": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, i32]),
+    "egk_graphln_bwd_finish": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, vp, i32]),
     "egk_graphln_fwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, i32]),
     "egk_graphln_bwd_apply": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, i32, vp, i32]),
     "egk_pe_table": (C.c_int, [vp, vp, i64, i32, i32, vp]),

@@ -959,33 +959,74 @@ int egk_graphln_bwd_apply(egk_stream_t stream, const void* dy, const void* x, co
     return check_launch("egk_graphln_bwd_apply");
 }
 
-int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b,
-                    const float* stats, void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
-                    int32_t rows, int32_t cols, float eps, float slope, void* ws, int32_t dtype) {
-    EGK_REQUIRE(dy && x && w && b && stats && dx && seg_ptr && ws, "egk_graphln_bwd: null pointer");
-    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG, "egk_graphln_bwd: n_seg must be in [1,%d]", MAXSEG);
+/* The three launches of egk_graphln_bwd as two calls, so that the segment sums can be combined with those of other
+ * ranks in between (exact cross-rank statistics, egopack_amd/ops.py graph_ln_exchange): egk_graphln_bwd_stats writes the
+ * per-block (sum dxhat, sum dxhat * xhat) per segment to the head of ws (double [egk_graphln_stats_blocks(rows)][n_seg][2])
+ * and the dw / db partial rows behind them; egk_graphln_bwd_finish normalises with the sums in ``partials`` (the head of
+ * ws itself, or any double [n_partials][n_seg][2]) and reduces the dw / db rows of ws. */
+int32_t egk_graphln_stats_blocks(int32_t rows) { return row_grid(rows); }
+
+int egk_graphln_stats(egk_stream_t stream, const void* x, const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols,
+                      void* partials, int32_t dtype) {
+    EGK_REQUIRE(x && seg_ptr && partials, "egk_graphln_stats: null pointer");
+    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG, "egk_graphln_stats: n_seg must be in [1,%d]", MAXSEG);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    ProfScope prof(KID_GRAPHLN_STATS, s, 0, eb * rows * cols);
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_stats_kernel<NV, T, FULL>), dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
+                                                 seg_ptr, n_seg, rows, cols, (double*)partials));
+    return check_launch("egk_graphln_stats");
+}
+
+int egk_graphln_bwd_stats(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b, const float* stats,
+                          const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float slope, void* ws, int32_t dtype) {
+    EGK_REQUIRE(dy && x && w && b && stats && seg_ptr && ws, "egk_graphln_bwd_stats: null pointer");
+    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG, "egk_graphln_bwd_stats: n_seg must be in [1,%d]", MAXSEG);
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows);
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     double* ws_seg = (double*)ws;
     float* ws_col = (float*)((char*)ws + (int64_t)grid * n_seg * 2 * 8);
-    {
-        ProfScope prof(KID_GRAPHLN_BWD_STATS, s, 0, 2 * eb * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_stats_kernel<NV, T, FULL>), dim3(grid), dim3(256),
-                                                     WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, stats,
-                                                     seg_ptr, n_seg, rows, cols, slope, ws_seg, ws_col));
-    }
+    ProfScope prof(KID_GRAPHLN_BWD_STATS, s, 0, 2 * eb * rows * cols);
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_stats_kernel<NV, T, FULL>), dim3(grid), dim3(256),
+                                                 WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, stats,
+                                                 seg_ptr, n_seg, rows, cols, slope, ws_seg, ws_col));
+    return check_launch("egk_graphln_bwd_stats");
+}
+
+int egk_graphln_bwd_finish(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b, const float* stats,
+                           void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols,
+                           float eps, float slope, const void* partials, int32_t n_partials, const void* ws, int32_t dtype) {
+    EGK_REQUIRE(dy && x && w && b && stats && dx && seg_ptr && partials && ws, "egk_graphln_bwd_finish: null pointer");
+    EGK_REQUIRE(n_seg >= 1 && n_seg <= MAXSEG && n_partials >= 1, "egk_graphln_bwd_finish: bad segment / partial count");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    const float* ws_col = (const float*)((const char*)ws + (int64_t)grid * n_seg * 2 * 8);
     {
         ProfScope prof(KID_GRAPHLN_BWD, s, 0, 3 * eb * rows * cols);
         DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_bwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)dy,
                                                      (const T*)x, w, b, stats, (T*)dx, seg_ptr, n_seg, rows, cols, eps, slope,
-                                                     ws_seg, grid));
+                                                     (const double*)partials, n_partials));
     }
     if (dw || db) {
         ProfScope prof(KID_GRAPHLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
         hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
     }
-    return check_launch("egk_graphln_bwd");
+    return check_launch("egk_graphln_bwd_finish");
+}
+
+int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const float* w, const float* b,
+                    const float* stats, void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg,
+                    int32_t rows, int32_t cols, float eps, float slope, void* ws, int32_t dtype) {
+    EGK_REQUIRE(dy && x && w && b && stats && dx && seg_ptr && ws, "egk_graphln_bwd: null pointer");
+    if (rows == 0) return 0;
+    const int rc = egk_graphln_bwd_stats(stream, dy, x, w, b, stats, seg_ptr, n_seg, rows, cols, slope, ws, dtype);
+    if (rc) return rc;
+    return egk_graphln_bwd_finish(stream, dy, x, w, b, stats, dx, dw, db, seg_ptr, n_seg, rows, cols, eps, slope, ws, row_grid(rows),
+                                  ws, dtype);
 }
 }

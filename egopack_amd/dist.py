@@ -33,6 +33,22 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, local_rank, world
 
 
+def _via_host(t: torch.Tensor, group) -> bool:
+    """A device tensor on a gloo group: ranks that share one GPU (the two-process test topology of
+    tools/two_rank_check.py; RCCL refuses two ranks on one device) exchange through host memory."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> None:
+    """Sum over the ranks in place, ordered on the current stream (RCCL), or synchronously through the host (gloo)."""
+    if _via_host(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 def chunk_bounds(n: int, chunk_elems: int) -> List[tuple]:
     """[(begin, end)] covering [0, n) in chunks of ``chunk_elems`` (last one shorter), reverse order."""
     out = [(b, min(n, b + chunk_elems)) for b in range(0, n, chunk_elems)]
@@ -59,7 +75,18 @@ class GradSync:
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         if self.world > 1:
-            dist.broadcast(flat, src=src, group=self.group)
+            if _via_host(flat, self.group):
+                h = flat.cpu()
+                dist.broadcast(h, src=src, group=self.group)
+                flat.copy_(h)
+            else:
+                dist.broadcast(flat, src=src, group=self.group)
+
+    def sum_small(self, buf: torch.Tensor) -> None:
+        """In-place sum over the ranks of a small tensor ON THE CURRENT STREAM (the statistics of a graph LayerNorm in the
+        exact cross-rank mode, ops.set_graph_ln_exchange): the launches that follow on this stream read the result."""
+        if self.world > 1:
+            all_reduce_sum_(buf, self.group)
 
     def all_reduce_(self, flat_g: torch.Tensor) -> torch.Tensor:
         """Sum over ranks; returns the buffer that holds the summed gradient (``flat_g`` itself, or its bf16 copy
@@ -86,11 +113,11 @@ class GradSync:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 for b, e in bounds:
-                    dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                    all_reduce_sum_(flat_g[b:e], self.group)
             main.wait_stream(self._side)
         else:
             for b, e in bounds:
-                dist.all_reduce(flat_g[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                all_reduce_sum_(flat_g[b:e], self.group)
 
 
     # ---- region-wise exchange for the staged backward (engine.StepBase): start() as soon as a region of the flat
@@ -120,7 +147,7 @@ class GradSync:
             ready.record(main)
             self._side.wait_event(ready)
             with torch.cuda.stream(self._side):
-                dist.all_reduce(src[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                all_reduce_sum_(src[b:e], self.group)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             self._inflight.append((b, e, ev, src))
@@ -167,7 +194,7 @@ class GradSync:
             ready.record(main)
             self._side.wait_event(ready)
             with torch.cuda.stream(self._side):
-                dist.all_reduce(src[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                all_reduce_sum_(src[b:e], self.group)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             done.append(ev)

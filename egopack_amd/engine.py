@@ -374,6 +374,28 @@ class StepBase:
         return ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
 
     # ---- eager step -------------------------------------------------------------------------------------
+    # Exact cross-rank graph-LayerNorm statistics (SURVEY 8e caveat 1, optional): with several ranks every graph LayerNorm
+    # sums its segment statistics over the ranks (forward and backward, ops.set_graph_ln_exchange), so the step computes
+    # what ONE process computes on the global batch -- the reference's semantics at that batch size -- instead of the
+    # default per-rank statistics (each replica = the reference at its local batch size).  Six small collectives per step
+    # on the compute stream; collectives cannot be captured, so the mode steps eagerly.
+    exact_graph_ln = False
+
+    def _exact_ln_on(self) -> bool:
+        return bool(self.exact_graph_ln and self.sync is not None and self.sync.world > 1)
+
+    def _ln_exchange_scope(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev = ops.set_graph_ln_exchange(self.sync.sum_small) if self._exact_ln_on() else ops.set_graph_ln_exchange(None)
+            try:
+                yield
+            finally:
+                ops.set_graph_ln_exchange(prev)
+        return scope()
+
     def forward_backward(self, batches, merged=None):
         self.optimizer.zero_grad()
         if self.input_hook is not None:
@@ -381,7 +403,8 @@ class StepBase:
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         try:
-            total, vectors = self._backward_pass(batches, merged)
+            with self._ln_exchange_scope():
+                total, vectors = self._backward_pass(batches, merged)
             ops.join_wgrad(force=True)
         finally:
             ops.set_wgrad_side_streams(prev)
@@ -445,12 +468,13 @@ class StepBase:
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         try:
-            total, vectors = self._stage_a(batches, merged)
-            self._exchange_region(regions[0])
-            self._stage_b()
-            self._exchange_region(regions[1])
-            self._stage_c()
-            self._exchange_region(regions[2])
+            with self._ln_exchange_scope():
+                total, vectors = self._stage_a(batches, merged)
+                self._exchange_region(regions[0])
+                self._stage_b()
+                self._exchange_region(regions[1])
+                self._stage_c()
+                self._exchange_region(regions[2])
         finally:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
@@ -484,7 +508,8 @@ class StepBase:
         self._steps_seen = getattr(self, "_steps_seen", 0) + 1
         if not hasattr(self, "loop_counts"):
             self.loop_counts = {"replayed": 0, "eager": 0}  # per training loop; the entry points log and reset it per epoch
-        if not self.use_graph or self._steps_seen <= self.graph_after or not next(iter(batches.values())).x.is_cuda:
+        if (not self.use_graph or self._steps_seen <= self.graph_after or not next(iter(batches.values())).x.is_cuda
+                or self._exact_ln_on()):
             self.loop_counts["eager"] += 1
             return self.step(batches, merged)
         if self.fused and len([t for t in self.enabled if batches.get(t) is not None]) > 1 and merged is None:
@@ -518,6 +543,9 @@ class StepBase:
         """Capture forward+backward(+Adam if no gradient exchange) for THESE device tensors (static
         shapes and addresses: refill them in place between replays)."""
         opt = self.optimizer
+        if self._exact_ln_on():
+            raise RuntimeError("exact_graph_ln sums the graph-LayerNorm statistics over the ranks inside the step: collectives "
+                               "cannot be captured in a hipGraph here -- use step() / train_step() (eager) in this mode")
         live = [t for t in self.enabled if batches.get(t) is not None]
         if self.fused and len(live) > 1 and merged is None:  # index work must stay outside the capture
             merged = merge_batches([batches[t] for t in live]).to(batches[live[0]].pos.device)

@@ -110,7 +110,8 @@ class Graph(torch.nn.Module):
             conv = getattr(self.net, f"module_{3 * d}")
             norm = getattr(self.net, f"module_{3 * d + 1}")
             slope = getattr(self.net, f"module_{3 * d + 2}").negative_slope
-            req = {"seg_ptr": seg_ptr, "n_seg": n_seg, "min_rows": min_rows} if min_rows > 0 else None
+            req = ({"seg_ptr": seg_ptr, "n_seg": n_seg, "min_rows": min_rows}
+                   if min_rows > 0 and not ops.graph_ln_exchange_on() else None)
             c = ops.sage_mean_layer(h, conv, graph, ln_out=req, ln_in=ln_prev, res_src=res if d == 0 else None)
             h, ln_prev = norm(c, seg_ptr, slope, partials=req.get("partials") if req else None, min_seg_rows=min_rows,
                               return_ctx=True)                # SAGEConv -> graph-LN -> LeakyReLU

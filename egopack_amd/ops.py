@@ -1013,6 +1013,37 @@ def _ln_bwd_stats_launch(lnctx, args, kw, dy_out):
 
 _ln_fusion = {"on": True}  # development knob: False = every graph LayerNorm runs its own statistics passes
 
+# Exact cross-rank statistics (data parallelism): the reference is one process, its graph-mode LayerNorm sees the whole
+# batch (models/graph.py:43); with the batch sharded over ranks the default is per-rank statistics (every replica is the
+# reference at its local batch size).  With an exchange function installed, every graph LayerNorm sums its segment
+# statistics over the ranks between its statistics pass and its normalising pass, forward and backward -- the result is
+# the single-process result at the GLOBAL batch (up to summation order).  ``fn(buf)`` must sum the f64 tensor ``buf``
+# [n_seg, 3] over the ranks in place, ordered on the current stream (dist.GradSync.sum_small).  Collectives cannot be
+# captured: the engine steps eagerly in this mode.
+_ln_exchange = {"fn": None}
+
+
+def set_graph_ln_exchange(fn):
+    """Install (or with None remove) the cross-rank sum of the graph LayerNorm statistics; returns the previous one."""
+    prev = _ln_exchange["fn"]
+    _ln_exchange["fn"] = fn
+    return prev
+
+
+def graph_ln_exchange_on() -> bool:
+    return _ln_exchange["fn"] is not None
+
+
+def _exchange_segment_sums(partials, n_blocks, seg_ptr, n_seg, cols):
+    """Per-block (a, b) sums per segment of THIS rank -> [1, n_seg, 2] f64 sums over all ranks, scaled by local / global
+    element count (the normalising kernels divide by the local count of a segment)."""
+    loc = partials.view(torch.float64)[: n_blocks * n_seg * 2].view(n_blocks, n_seg, 2).sum(0)
+    cnt = (seg_ptr[1:] - seg_ptr[:-1]).to(torch.float64) * cols
+    buf = torch.cat([loc, cnt[:, None]], 1).contiguous()
+    _ln_exchange["fn"](buf)
+    scale = torch.where(buf[:, 2] > 0, cnt / buf[:, 2].clamp_min(1.0), torch.zeros_like(cnt))
+    return (buf[:, :2] * scale[:, None]).contiguous().view(1, n_seg, 2)
+
 
 class _GraphLN(torch.autograd.Function):
     @staticmethod
@@ -1025,7 +1056,15 @@ class _GraphLN(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty(n_seg * 2, dtype=torch.float32, device=x.device)
         wc, bc = _f32c(w), _f32c(b)
-        if partials is not None:  # the segment sums came with the contraction that produced x
+        if _ln_exchange["fn"] is not None:  # exact cross-rank statistics: local sums -> sum over ranks -> normalise
+            nb = lib.egk_graphln_stats_blocks(rows)
+            loc = torch.empty(nb * n_seg * 2, dtype=torch.float64, device=x.device)
+            _ck(lib.egk_graphln_stats(_stream(), _p(x), _p(seg_ptr), n_seg, rows, cols, _p(loc), _dt(x)), "egk_graphln_stats")
+            glob = _exchange_segment_sums(loc, nb, seg_ptr, n_seg, cols)
+            _ck(lib.egk_graphln_fwd_apply(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
+                                          slope, _p(glob), 1, _dt(x)), "egk_graphln_fwd_apply")
+            lnctx = None
+        elif partials is not None:  # the segment sums came with the contraction that produced x
             _ck(lib.egk_graphln_fwd_apply(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
                                           slope, _p(partials[0]), partials[1], _dt(x)), "egk_graphln_fwd_apply")
         else:
@@ -1035,6 +1074,7 @@ class _GraphLN(torch.autograd.Function):
         ctx.eps, ctx.slope = eps, slope
         ctx.params = (w, b)
         ctx.lnctx = lnctx
+        ctx.exchange = _ln_exchange["fn"] is not None
         if lnctx is not None:  # what the consumer's dX epilogue needs to take this layer's backward sums
             lnctx.update(x=x, stats=stats, w=wc, b=bc, slope=slope, seg_ptr=seg_ptr, n_seg=n_seg, bwd=None)
         ctx.save_for_backward(x, wc, bc, stats, seg_ptr)
@@ -1053,6 +1093,17 @@ class _GraphLN(torch.autograd.Function):
         slot_w, slot_b = _grad_slot(wp), _grad_slot(bp)
         dw = slot_w if slot_w is not None else torch.zeros_like(w)
         db = slot_b if slot_b is not None else torch.zeros_like(b)
+        if ctx.exchange:  # exact cross-rank statistics (forward ran with an exchange function)
+            if _ln_exchange["fn"] is None:
+                raise RuntimeError("graph LayerNorm: forward summed its statistics over the ranks, backward has no exchange function")
+            ws = torch.empty(lib.egk_graphln_ws_bytes(rows, cols, n_seg), dtype=torch.uint8, device=x.device)
+            _ck(lib.egk_graphln_bwd_stats(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(seg_ptr), n_seg, rows, cols, ctx.slope,
+                                          _p(ws), _dt(x)), "egk_graphln_bwd_stats")
+            nb = lib.egk_graphln_stats_blocks(rows)
+            glob = _exchange_segment_sums(ws[: nb * n_seg * 16], nb, seg_ptr, n_seg, cols)
+            _ck(lib.egk_graphln_bwd_finish(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(dw), _p(db), _p(seg_ptr),
+                                           n_seg, rows, cols, ctx.eps, ctx.slope, _p(glob), 1, _p(ws), _dt(x)), "egk_graphln_bwd_finish")
+            return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None, None, None
         pre = ctx.lnctx.get("bwd") if ctx.lnctx is not None else None
         if ctx.lnctx is not None:
             ctx.lnctx["bwd"] = None
@@ -1094,6 +1145,8 @@ def graph_layernorm_lrelu(x, w, b, seg_ptr, eps=1e-5, slope=0.2, partials=None, 
     ``linear`` with ``ln_in=``) needs to take this layer's BACKWARD sums in its dX epilogue (``min_seg_rows``: the
     shortest segment, a host integer)."""
     lnctx = {"min_rows": int(min_seg_rows)} if (return_ctx and min_seg_rows > 0) else None
+    if _ln_exchange["fn"] is not None:  # statistics summed over the ranks: nothing rides on a neighbouring contraction
+        lnctx = partials = None
     y = _GraphLN.apply(x, w, b, seg_ptr, float(eps), float(slope), partials, lnctx)
     return (y, lnctx) if return_ctx else y
 

@@ -181,6 +181,25 @@ int egk_graphln_fwd_apply(egk_stream_t s, const void* x, const float* w, const f
 int egk_graphln_bwd_apply(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b, const float* stats,
                           void* dx, const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float eps, float slope,
                           const void* partials, int32_t n_partials, float* ws_col, int32_t dtype);
+/* The passes of egk_graphln_fwd / egk_graphln_bwd as separate calls, so that a data-parallel run can combine the segment
+ * sums of all ranks between the statistics pass and the normalising pass (exact global-batch statistics; the reference
+ * has one process, so its gnn.LayerNorm(mode='graph') at models/graph.py:43 sees the whole batch):
+ *   egk_graphln_stats       partials = double [egk_graphln_stats_blocks(rows)][n_seg][2]: per-block (sum x, sum x^2);
+ *                           follow with egk_graphln_fwd_apply(partials, n_partials)
+ *   egk_graphln_bwd_stats   head of ws = double [egk_graphln_stats_blocks(rows)][n_seg][2]: per-block
+ *                           (sum dxhat, sum dxhat * xhat); the dw / db partial rows follow in ws (layout of egk_graphln_bwd)
+ *   egk_graphln_bwd_finish  dx from the sums in ``partials`` (the head of ws, or combined sums) + the dw / db reduction of ws
+ * The kernels divide the sums they are given by the LOCAL element count of a segment: sums combined over ranks are passed
+ * scaled by local count / global count.  egk_graphln_bwd == bwd_stats + bwd_finish(partials = ws). */
+int32_t egk_graphln_stats_blocks(int32_t rows);
+int egk_graphln_stats(egk_stream_t s, const void* x, const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols,
+                      void* partials, int32_t dtype);
+int egk_graphln_bwd_stats(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b, const float* stats,
+                          const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols, float slope, void* ws,
+                          int32_t dtype);
+int egk_graphln_bwd_finish(egk_stream_t s, const void* dy, const void* x, const float* w, const float* b, const float* stats,
+                           void* dx, float* dw, float* db, const int32_t* seg_ptr, int32_t n_seg, int32_t rows, int32_t cols,
+                           float eps, float slope, const void* partials, int32_t n_partials, const void* ws, int32_t dtype);
 /* The parameter-gradient reduction of egk_rowln_bwd (n_seg = 0) / egk_graphln_bwd (n_seg >= 1) as its own launch: call
  * those with dw = db = NULL (they then leave the per-workgroup partial rows in ws) and this one, with the same ws, rows,
  * cols, on whatever stream should carry it -- dw / db feed nothing but the optimizer, the kernels that need dx need not

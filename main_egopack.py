@@ -126,6 +126,7 @@ def main(argv=None):
                               backprop_temporal_graph=cfg.backprop_temporal_graph,
                               temporal_graph_train_mode=cfg.temporal_graph_train_mode, sync=sync)
     step.use_graph = bool(cfg.get("use_graph", True))
+    step.exact_graph_ln = bool(cfg.get("exact_graph_ln", False))
     for epoch in range(1, cfg.num_epochs + 1):
         train(epoch, step, dl_train, weights, device)
         scheduler.step()

@@ -157,6 +157,7 @@ def main(argv=None):
     step = engine.MTLStep(model, tasks, T.build_criteria(dsets_train), weights, optimizer,
                           fused_backbone=cfg.fused_backbone, sync=sync)
     step.use_graph = bool(cfg.get("use_graph", True))
+    step.exact_graph_ln = bool(cfg.get("exact_graph_ln", False))  # several ranks: graph-LN statistics over the GLOBAL batch
 
     first_epoch = 1
     ckpt_path = Path(cfg.checkpoint_dir) / artifact / "checkpoint.pth"

@@ -32,6 +32,9 @@ def _worker(rank, world, port, q):
     p = torch.full((37,), float(rank + 5))
     sync.broadcast_(p)
     ok_bcast = bool((p == 5.0).all())
+    st = torch.tensor([[1.0, 2.0, 10.0], [3.0, 4.0, 20.0]], dtype=torch.float64) * (rank + 1)  # graph-LN sums + counts
+    sync.sum_small(st)
+    ok_sum = ok_sum and torch.equal(st, torch.tensor([[3.0, 6.0, 30.0], [9.0, 12.0, 60.0]], dtype=torch.float64))
     # sharded loaders: disjoint samples, same number of steps
     ds = D.SyntheticTaskDataset("pnr", 21, 4, 3, 4)
     dl = D.BatchLoader(ds, 2, shuffle=True, drop_last=True, seed=7, rank=rank, world_size=world)

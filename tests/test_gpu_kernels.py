@@ -247,6 +247,57 @@ def test_graphln_lrelu_fwd_bwd(ops, rows, cols, segs):
     torch.testing.assert_close(db.grad.cpu(), cb.grad, rtol=1e-3, atol=2e-3)
 
 
+def test_graphln_statistics_summed_with_a_second_rank(ops):
+    """Exact cross-rank statistics (ops.set_graph_ln_exchange): this process plays rank A of two; the exchange function
+    adds what rank B would contribute (computed here in f64 from B's rows).  Rank A's outputs and input gradients must be
+    those of the oracle's graph LayerNorm over the UNION of the rows -- the single-process result on the global batch."""
+    g = gen(77)
+    cols, na, nb = 256, [40, 60], [24, 36]
+    w, b = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    xa = [torch.randn(n, cols, generator=g) * 1.5 + 0.3 for n in na]
+    xb = [torch.randn(n, cols, generator=g) * 0.7 - 0.2 for n in nb]
+    wa = [torch.randn(n, cols, generator=g) for n in na]
+    wb = [torch.randn(n, cols, generator=g) for n in nb]
+    # oracle on the union, segment by segment
+    leaves = [torch.cat([a, bb]).clone().requires_grad_(True) for a, bb in zip(xa, xb)]
+    cw, cb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    outs = [F.leaky_relu(P.graph_layer_norm(l, cw, cb), 0.2) for l in leaves]
+    sum((o * torch.cat([u, v])).sum() for o, u, v in zip(outs, wa, wb)).backward()
+    # rank B's contributions, f64
+    fwd_b = torch.tensor([[x.double().sum(), (x.double() ** 2).sum(), x.numel()] for x in xb], dtype=torch.float64)
+    bwd_b = []
+    for s in range(2):
+        u = torch.cat([xa[s], xb[s]]).double()
+        mean, std = u.mean(), u.std(unbiased=False)
+        xhat = ((xb[s].double() - mean) / (std + 1e-5)).requires_grad_(True)
+        (F.leaky_relu(xhat * w.double() + b.double(), 0.2) * wb[s].double()).sum().backward()
+        bwd_b.append([xhat.grad.sum(), (xhat.grad * xhat.detach()).sum(), xb[s].numel()])
+    bwd_b = torch.tensor(bwd_b, dtype=torch.float64)
+    calls = []
+
+    def exchange(buf):
+        assert buf.dtype == torch.float64 and tuple(buf.shape) == (2, 3)
+        buf += (fwd_b if not calls else bwd_b).to(buf.device)
+        calls.append(1)
+    prev = ops.set_graph_ln_exchange(exchange)
+    try:
+        x = torch.cat(xa).to(DEV).requires_grad_(True)
+        dw, db = w.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+        seg = torch.tensor([0, na[0], na[0] + na[1]], dtype=torch.int32, device=DEV)
+        out = ops.graph_layernorm_lrelu(x, dw, db, seg, 1e-5, 0.2)
+        (out * torch.cat(wa).to(DEV)).sum().backward()
+    finally:
+        ops.set_graph_ln_exchange(prev)
+    assert len(calls) == 2
+    ref_out = torch.cat([o[:n] for o, n in zip(outs, na)]).detach()
+    ref_dx = torch.cat([l.grad[:n] for l, n in zip(leaves, na)])
+    torch.testing.assert_close(out.detach().cpu(), ref_out, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(x.grad.cpu(), ref_dx, rtol=1e-3, atol=1e-4)
+    # and without the exchange the same call is a different (per-rank) normalisation
+    plain = ops.graph_layernorm_lrelu(torch.cat(xa).to(DEV), w.to(DEV), b.to(DEV), seg, 1e-5, 0.2)
+    assert (plain.cpu() - ref_out).abs().max() > 1e-2
+
+
 def test_graphln_full_size_properties(ops):
     """[6144, 1024], 3 segments: each output segment (before the affine/LeakyReLU, w=1,b=0,slope=1) has
     mean 0 and population std 1/(1+eps/std) -- the defining property, checked on the GPU in fp64."""
