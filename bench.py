@@ -278,6 +278,10 @@ def parse_args(argv=None):
     ap.add_argument("--grad-compress", choices=["bf16", "none"], default="none",
                     help="element type of the gradient all-reduce when --gpus > 1: 'none' = the f32 exchange the entry "
                          "points train with (main_temporal.py grad_compress default); 'bf16' = the half-size variant")
+    ap.add_argument("--one-gpu-gloo", action="store_true",
+                    help="development: run the N ranks on ONE GPU (every rank on cuda:0) over a gloo group -- the N-rank step, "
+                         "capture mode and timing protocol on a one-GPU box (RCCL refuses two ranks on one device); the "
+                         "throughput it prints is NOT a multi-GPU figure and says so in config.transport")
     ap.add_argument("--strict-capture", action="store_true",
                     help="fail instead of falling back (staged graphs -> one-piece graph -> eager) when a capture fails")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
@@ -431,7 +435,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
         """A capture that fails on ONE rank must send EVERY rank to the next mode: the modes issue different collectives."""
         if world <= 1:
             return ok
-        flag = torch.tensor([1 if ok else 0], device=device)
+        flag = torch.tensor([1 if ok else 0], device="cpu" if args.one_gpu_gloo else device)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         return bool(flag.item())
 
@@ -487,12 +491,14 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             print(f"[stamp] {us:9.1f} us  (+{us - prev:7.1f})  {name}", file=sys.stderr)
             prev = us
     if world > 1:
-        t = torch.tensor([ms], device=device)
+        t = torch.tensor([ms], device="cpu" if args.one_gpu_gloo else device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = t.item()
 
     rl, table = (None, {})
-    if rank == 0 and want_roofline and not args.no_roofline:
+    # (with several ranks EVERY rank takes these eager steps: they issue the gradient collectives, and a rank 0 stepping
+    #  alone would wait for its peers for ever -- found by running two real ranks, --one-gpu-gloo; rank 0 reports)
+    if (rank == 0 or world > 1) and want_roofline and not args.no_roofline:
         try:
             # per-kernel durations are taken with every launch on ONE stream (heads, aux tasks and weight gradients
             # serialised), the way rocprofv3 --kernel-trace times them: the committed profile must agree with them
@@ -540,7 +546,9 @@ def main(argv=None):
                 time.sleep(1.0)
             time.sleep(2.0)
     from egopack_amd import dist as edist
-    rank, local_rank, world = edist.init_from_env()
+    rank, local_rank, world = edist.init_from_env("gloo" if args.one_gpu_gloo else None)
+    if args.one_gpu_gloo:
+        local_rank = 0  # every rank on the box's one GPU
     if world != args.gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -606,6 +614,8 @@ def main(argv=None):
                        "parallelism": f"dp{world}", "trainable_params": res["n_params"],
                        "grad_allreduce": (("bf16" if args.grad_compress == "bf16" else "f32") if world > 1 else None),
                        "capture": res["capture"], "capture_fallbacks": res["fallbacks"],
+                       "transport": ("gloo, all ranks on ONE GPU (development run of the N-rank path: not a multi-GPU figure)"
+                                     if args.one_gpu_gloo else ("RCCL" if world > 1 else None)),
                        "input": (f"assembled in the step by egk_gather_rows from a resident {args.feature_store}-row feature store"
                                  if args.feature_store else "resident in HBM before the timed region"),
                        "master_weights": "f32", "mode": args.compute,

@@ -26,3 +26,20 @@ def test_two_ranks_with_exact_graph_ln_equal_one_process_on_the_global_batch():
     assert l["grad_rel"] >= 20 * e["grad_rel"] and l["objective_rel"] >= 20 * e["objective_rel"], out
     assert e["ranks_bit_identical"] and l["ranks_bit_identical"], out
     assert r.returncode == 0, out
+
+
+def test_bench_runs_two_ranks_through_the_staged_graphs():
+    """``bench.py --gpus 2`` end to end with two REAL ranks (both on the box's one GPU, gloo transport, --one-gpu-gloo):
+    the ranks are spawned by bench.py itself, the step is captured as staged graphs on both (no silent fallback), the
+    timing protocol and the per-kernel leg complete on every rank (a rank 0 taking its eager profiling steps alone used to
+    wait for its peers for ever), and rank 0's JSON line is the last line of stdout."""
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--one-gpu-gloo", "--steps", "4", "--warmup", "2",
+                        "--strict-capture"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    last = r.stdout.strip().splitlines()[-1]
+    out = json.loads(last)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["capture"] == "staged graphs" and out["config"]["capture_fallbacks"] == []
+    assert out["config"]["grad_allreduce"] == "f32" and "ONE GPU" in out["config"]["transport"]
+    assert out["roofline"] and "error" not in out["roofline"], out["roofline"]
+    assert out["config"]["global_batch"] == 2 * 3 * 64
