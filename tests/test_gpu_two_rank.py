@@ -25,6 +25,9 @@ def test_two_ranks_with_exact_graph_ln_equal_one_process_on_the_global_batch():
     # default mode (per-rank statistics) is a different computation: the mode, not luck, makes the runs agree
     assert l["grad_rel"] >= 20 * e["grad_rel"] and l["objective_rel"] >= 20 * e["objective_rel"], out
     assert e["ranks_bit_identical"] and l["ranks_bit_identical"], out
+    # benchmark mode: both ranks capture the step as staged hipGraphs; replayed steps = eagerly issued steps, bit for bit
+    rp = out["bf16_replay"]
+    assert rp["capture"] == "staged graphs" and rp["ranks_bit_identical"] and rp["replayed_vs_eager_max_abs"] == 0.0, out
     assert r.returncode == 0, out
 
 

@@ -13,7 +13,9 @@ Checks (f32 mode, dropout 0, 3-task MTL step, global batch = 2 x B sequences per
     LayerNorm spans the whole batch, models/graph.py:43) up to f32 summation order;
   * exact_graph_ln = False (default, per-rank statistics): the same comparison differs by orders of magnitude more -- the
     mode is what makes the two agree, and the default is each replica = the reference at its LOCAL batch size;
-  * both ranks end with bit-identical parameters in both modes.
+  * both ranks end with bit-identical parameters in both modes;
+  * bf16 mode (the benchmark's): the step captured on both ranks as STAGED hipGraphs (gradient exchange between the graph
+    launches) and replayed gives the parameters of the eagerly issued steps, and both ranks stay bit-identical.
 The parent process never touches the GPU: it starts the two rank processes and relays rank 0's verdict (last stdout line,
 JSON) and exit code.  Usage: python tools/two_rank_check.py [--hidden 512] [--batch 8] [--T 16] [--steps 2]"""
 import argparse
@@ -72,7 +74,8 @@ def build(args, device, seq_lo, seq_hi, sync):
         gen.manual_seed(100 + i)
         x = torch.randn(G * args.T, S, F_IN, generator=gen)  # the global feature block of the task; this rank's rows
         xs.append(x[seq_lo * args.T: seq_hi * args.T])
-    x_all = torch.cat(xs).to(device)
+    from egopack_amd import ops
+    x_all = torch.cat(xs).to(device).to(ops.act_dtype())
     n = (seq_hi - seq_lo) * args.T
     dev = {}
     for i, t in enumerate(ORDER):
@@ -118,6 +121,25 @@ def run(args, device, seq_lo, seq_hi, sync, exact):
     return float(obj.item()), grad.cpu(), opt.flat_p.detach().cpu().clone(), opt
 
 
+def run_replayed(args, device, seq_lo, seq_hi, sync, graph: bool):
+    """Parameters after 4 optimizer steps: eagerly, or 2 eager warm-up steps + the captured step replayed twice."""
+    import torch
+    from egopack_amd import ops
+    ops.manual_seed(5)
+    step, opt, dev, merged = build(args, device, seq_lo, seq_hi, sync)
+    if graph:
+        step.capture(dev, merged, warmup=2)
+        kind = "staged graphs" if isinstance(step._graph, list) else "one graph"
+        for _ in range(2):
+            step.replay()
+    else:
+        kind = "eager"
+        for _ in range(4):
+            step.step(dev, merged)
+    torch.cuda.synchronize()
+    return opt.flat_p.detach().cpu().clone(), kind
+
+
 def worker(args):
     import torch
     import torch.distributed as dist
@@ -137,6 +159,15 @@ def worker(args):
         other = [torch.empty_like(par) for _ in range(2)]
         dist.all_gather(other, par)
         res[exact] = (obj, grad, par, bool(torch.equal(other[0], other[1])), opt)
+    # the benchmark's mode: bf16, the step captured as staged hipGraphs with the exchange between them, two ranks
+    ops.set_compute("bf16")
+    rep = {}
+    for graph in (False, True):
+        par, kind = run_replayed(args, device, rank * B, (rank + 1) * B, edist.GradSync(2), graph)
+        other = [torch.empty_like(par) for _ in range(2)]
+        dist.all_gather(other, par)
+        rep[graph] = (par, kind, bool(torch.equal(other[0], other[1])))
+    ops.set_compute("f32")
     dist.barrier()
     if rank == 0:
         obj1, grad1, par1, opt1 = run(args, device, 0, 2 * B, None, False)  # ONE process on the global batch
@@ -150,11 +181,17 @@ def worker(args):
                       "param_frac_within_2e-4": float(((par - par1).abs() <= 2e-4).double().mean()),
                       "param_max_abs": float((par - par1).abs().max()), "ranks_bit_identical": same}
         out["objective_one_process"] = obj1
+        pe, pg = rep[False][0], rep[True][0]
+        out["bf16_replay"] = {"capture": rep[True][1], "ranks_bit_identical": rep[True][2] and rep[False][2],
+                              "replayed_vs_eager_rel": float((pg.double() - pe.double()).norm() / pe.double().norm()),
+                              "replayed_vs_eager_max_abs": float((pg - pe).abs().max())}
         out["config"] = dict(hidden=args.hidden, batch_per_rank=B, T=args.T, steps=args.steps, mode="f32", tasks=list(ORDER))
         e, l = out["exact"], out["local"]
         ok = (e["objective_rel"] <= 1e-5 and e["grad_rel"] <= 2e-3 and e["param_frac_within_2e-4"] >= 0.999
               and e["ranks_bit_identical"] and l["ranks_bit_identical"]
-              and l["grad_rel"] >= 20 * e["grad_rel"] and l["objective_rel"] >= 20 * e["objective_rel"])
+              and l["grad_rel"] >= 20 * e["grad_rel"] and l["objective_rel"] >= 20 * e["objective_rel"]
+              and out["bf16_replay"]["capture"] == "staged graphs" and out["bf16_replay"]["ranks_bit_identical"]
+              and out["bf16_replay"]["replayed_vs_eager_rel"] <= 1e-6)
         out["ok"] = bool(ok)
         print(json.dumps(out), flush=True)
         dist.barrier()
