@@ -700,6 +700,105 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// One-logit classifier + BCE-with-logits, forward AND backward in one pass over the rows (the PNR head: reference
+// models/tasks/pnr.py:20,37-52 -- Linear(features, 1) -> squeeze -> BCEWithLogitsLoss(reduction='none') at
+// main_temporal.py:117-121).  A [rows, cols] x [cols, 1] contraction is a row reduction, not matrix work:
+//   z_n = <f_n, w> + b;   loss_n = (1 - y_n) z_n + max(-z_n, 0) + log1p(exp(-|z_n|))      (egk_bce_fwd's formula)
+//   g_n = (sigmoid(z_n) - y_n) * seed   (egk_bce_bwd's; rounded to T, as the contraction path rounds its operand)
+//   df_n = g_n * w;   dw = sum_n g_n f_n;   db = sum_n g_n
+// dw / db leave as per-workgroup partial rows ws[blk][cols + 4] (column ``cols`` = db), summed in block order by
+// rowdot_reduce_kernel: fixed order, no atomics.
+template <int NV, typename T, bool FULL>
+__global__ __launch_bounds__(256) void rowdot_bce_kernel(const T* __restrict__ f, const T* __restrict__ w, const float* __restrict__ bias,
+                                                         const long long* __restrict__ y, float* __restrict__ logits,
+                                                         float* __restrict__ loss, T* __restrict__ df, float* __restrict__ ws,
+                                                         int rows, int cols, float seed) {
+    extern __shared__ __attribute__((aligned(16))) float red_[];  // [WPB][NV * 256 + 4]
+    float (*red)[NV * 256 + 4] = reinterpret_cast<float (*)[NV * 256 + 4]>(red_);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (FULL) cols = NV * 256;
+    const bool vec = FULL || (cols & 3) == 0;
+    Row<NV> wv, acc;
+    load_row<NV>(w, cols, vec, lane, wv);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gsum = 0.f;
+    const float b0 = bias ? bias[0] : 0.f;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        Row<NV> r;
+        load_row<NV>(f + (long long)row * cols, cols, vec, lane, r);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d = fmaf(el(r.v[i], t), el(wv.v[i], t), d);  // out-of-range columns load as 0
+        const float z = wave_sum(d) + b0;
+        const float t = (float)y[row];
+        if (lane == 0) {
+            logits[row] = z;
+            loss[row] = (1.f - t) * z + fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)));
+        }
+        if (df) {
+            T gr;
+            st1t(&gr, (1.f / (1.f + expf(-z)) - t) * seed);  // the gradient in the operand element type
+            const float g = ld1t(&gr);
+            gsum += g;  // (identical in every lane)
+            Row<NV> o;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    el(o.v[i], t4) = g * el(wv.v[i], t4);
+                    el(acc.v[i], t4) = fmaf(g, el(r.v[i], t4), el(acc.v[i], t4));
+                }
+            store_row<NV>(df + (long long)row * cols, cols, vec, lane, o);
+        }
+    }
+    if (!df) return;
+    // per-workgroup partial row: the four waves' accumulators summed in wave order
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[wave][(i * 64 + lane) * 4 + t] = el(acc.v[i], t);
+    if (lane == 0) red[wave][NV * 256] = gsum;
+    __syncthreads();
+    float* out = ws + (long long)blockIdx.x * (cols + 4);
+    for (int c = threadIdx.x; c <= cols; c += 256) {
+        const int cc = c < cols ? c : NV * 256;
+        out[c] = (red[0][cc] + red[1][cc]) + (red[2][cc] + red[3][cc]);
+    }
+}
+
+// dw[c] += sum over blocks of ws[blk][c] (c < cols);  db[0] += sum of ws[blk][cols]
+// workgroup = 16 columns x 16 block groups, 8 loads in flight per thread, the 16 partial sums of a column combined in LDS
+// in group order (the shape of partial_reduce2_kernel: a single thread walking 512 blocks is a 125-us chain of loads)
+__global__ __launch_bounds__(256) void rowdot_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
+                                                            int nblk, int cols) {
+    __shared__ float red[16][16];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cg;
+    const long long ld = cols + 4;
+    float a = 0.f;
+    if (c <= cols)
+        for (int k = rg; k < nblk; k += 128) {
+            float va[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) va[u] = k + 16 * u < nblk ? ws[(long long)(k + 16 * u) * ld + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += va[u];
+        }
+    red[rg][cg] = a;
+    __syncthreads();
+    if (rg == 0 && c <= cols) {
+        a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][cg];
+        if (c < cols) dw[c] += a;
+        else if (db) db[0] += a;
+    }
+}
+
 static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
 static int g_cap_partial = 512, g_cap_wide = 2048;  // development knobs (egk_tune 1 / 2)
 static inline int row_grid(int rows) {  // kernels that emit per-workgroup partial rows: two workgroups per CU
@@ -1028,5 +1127,34 @@ int egk_graphln_bwd(egk_stream_t stream, const void* dy, const void* x, const fl
     if (rc) return rc;
     return egk_graphln_bwd_finish(stream, dy, x, w, b, stats, dx, dw, db, seg_ptr, n_seg, rows, cols, eps, slope, ws, row_grid(rows),
                                   ws, dtype);
+}
+/* One-logit classifier + BCE-with-logits over the rows of f, loss AND gradients in one pass (see rowdot_bce_kernel).
+ * w: the classifier's weight row in the element type of f (the operand copy the contraction path would read).
+ * df == NULL: forward only (logits, loss).  Otherwise df = g w per row and ws = float [egk_rowdot_ws_rows(rows)][cols + 4]
+ * receives the partial rows of dw / db; egk_rowdot_reduce ACCUMULATES them into dw [cols] and db [1]. */
+int32_t egk_rowdot_ws_rows(int32_t rows) { return row_grid(rows); }
+
+int egk_rowdot_bce(egk_stream_t stream, const void* f, const void* w, const float* bias, const int64_t* y, float* logits,
+                   float* loss, void* df, float* ws, int32_t rows, int32_t cols, float seed, int32_t dtype) {
+    EGK_REQUIRE(f && w && y && logits && loss, "egk_rowdot_bce: null pointer");
+    EGK_REQUIRE(!df || ws, "egk_rowdot_bce: gradients need the partial-row workspace");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    ProfScope prof(KID_BCE_FWD, s, 2.0 * rows * cols * (df ? 3 : 1), eb * rows * cols * (df ? 2 : 1) + 16.0 * rows);
+    DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowdot_bce_kernel<NV, T, FULL>), dim3(row_grid(rows)), dim3(256),
+                                                 WPB * (NV * 256 + 4) * sizeof(float), s, (const T*)f,
+                                                 (const T*)w, bias, (const long long*)y, logits, loss, (T*)df, ws, rows, cols, seed));
+    return check_launch("egk_rowdot_bce");
+}
+
+int egk_rowdot_reduce(egk_stream_t stream, const float* ws, float* dw, float* db, int32_t rows, int32_t cols) {
+    EGK_REQUIRE(ws && dw, "egk_rowdot_reduce: null pointer");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 4.0 * grid * (cols + 4));
+    hipLaunchKernelGGL(rowdot_reduce_kernel, dim3(cdiv(cols + 1, 16)), dim3(256), 0, s, ws, dw, db, grid, cols);
+    return check_launch("egk_rowdot_reduce");
 }
 }

@@ -728,6 +728,17 @@ class MTLStep(StepBase):
     # fill half of the chip become one 6144-row launch per stage (bf16 mode, once the optimizer's flat buffers exist)
     grouped_heads = True
 
+    # a head whose classifier has ONE logit under BCE-with-logits (PNR) runs classifier + loss + their gradients as one row
+    # pass (ops.linear1_bce) instead of ten launches of [N, H] x [H, 1] matrix work: same-box A/B of the headline step
+    # 1.650 -> 1.624 ms.  Same values up to summation order (a row reduction instead of an MFMA K walk), so the bitwise
+    # equalities between execution structures (tests/test_gpu_dist.py) are stated with it off
+    one_pass_heads = True
+
+    def _one_pass_head_ok(self, t: str) -> bool:
+        from .criterion import BCEWithLogitsNone
+        return (self.one_pass_heads and hasattr(self.tasks[t], "fused_head_loss") and type(self.criteria[t]) is BCEWithLogitsNone
+                and "rowdot_head" not in getattr(self, "_dev_off", ()))
+
     def _heads_forward_backward(self, feats):
         """Heads' forward AND backward, every head inside its own stream context, on detached copies of the backbone
         features: returns (objective, loss vectors, {task: leaf}) with d(objective)/d(features) in ``leaf.grad``.
@@ -749,14 +760,18 @@ class MTLStep(StepBase):
         def head(t, leaf):
             # AR / LTA: one loss element per node, back-propagated below with the constant w_t / numel -- known before the
             # loss is computed, so the cross entropy emits its gradient in the same launch (ops.loss_seed)
-            n_loss = leaf.shape[0] if (t in ("ar", "lta") and getattr(self, "_fused_loss", True)) else 0
+            n_loss = leaf.shape[0] if (t in ("ar", "lta", "pnr") and getattr(self, "_fused_loss", True)) else 0
             with ops.loss_seed(self.weights[t] / n_loss if n_loss else None):
-                if grouped:  # ``leaf`` is the task's projected feature block: classifier + loss (+ their backward) only
-                    task, d = self.tasks[t], batches[t]
-                    logits = task.forward_logits(leaf, d) if t == "oscc" else task.forward_logits(leaf)
-                    v = self.criteria[t](logits, d.y)
+                task, d = self.tasks[t], batches[t]
+                f = leaf if grouped else task.forward_features(leaf)  # grouped: ``leaf`` is the projected feature block
+                one_pass = None
+                if n_loss and self._one_pass_head_ok(t):
+                    one_pass = task.fused_head_loss(f, d.y)  # one-logit classifier + BCE + their gradients: one row pass
+                if one_pass is not None:
+                    v, logits = one_pass
                 else:
-                    v, logits = self._head(t, leaf, batches[t])
+                    logits = task.forward_logits(f, d) if t == "oscc" else task.forward_logits(f)
+                    v = self.criteria[t](logits, d.y)
             if n_loss and v.numel() != n_loss:
                 raise RuntimeError(f"head {t}: {v.numel()} loss elements where {n_loss} were announced to the fused loss")
             if v.numel():

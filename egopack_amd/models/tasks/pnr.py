@@ -40,5 +40,14 @@ class PNRTask(ProjectionTask):
             raise ValueError("PNR task has no auxiliary classifiers.")
         return apply_classifier(self.aux_classifiers[t], features)
 
+    def fused_head_loss(self, features: torch.Tensor, targets: torch.Tensor):
+        """(loss vector, logits) of ``BCEWithLogits(forward_logits(features), targets)`` in ONE row pass that also emits the
+        gradients (ops.linear1_bce), or None when it does not apply (classifier dropout active, no announced loss seed):
+        a one-logit classifier is a row reduction, not matrix work."""
+        drop, lin = self.classifier[0], self.classifier[1]
+        if (self.training and getattr(drop, "p", 0) > 0) or not ops.linear1_bce_ok(features, lin.weight):
+            return None
+        return ops.linear1_bce(features, lin.weight, lin.bias, targets)
+
     def compute_loss(self, logits: torch.Tensor, targets: torch.Tensor):
         return ops.bce_with_logits(logits, targets)

@@ -1603,6 +1603,58 @@ def bce_with_logits(logits, y):
     return _BCE.apply(logits, y, _state["act"])
 
 
+class _RowDotBCE(torch.autograd.Function):
+    """Linear(features, 1) + squeeze + BCE-with-logits(reduction='none') as ONE row pass that also emits the gradients
+    (egk_rowdot_bce): used when the seed of the loss vector's backward is known (``loss_seed``)."""
+
+    @staticmethod
+    def forward(ctx, f, W, b, y, seed):
+        _need_gpu(f, W, y)
+        lib = _lib.load()
+        f = _c(f)
+        rows, cols = f.shape
+        w_op = weight_operand(W, f.dtype).reshape(-1)
+        bias = _f32c(b) if b is not None else None
+        y = y.contiguous()
+        logits = torch.empty(rows, dtype=torch.float32, device=f.device)
+        loss = torch.empty(rows, dtype=torch.float32, device=f.device)
+        df = torch.empty_like(f)
+        ws = torch.empty(lib.egk_rowdot_ws_rows(rows) * (cols + 4), dtype=torch.float32, device=f.device)
+        _ck(lib.egk_rowdot_bce(_stream(), _p(f), _p(w_op), _p(bias), _p(y), _p(logits), _p(loss), _p(df), _p(ws), rows, cols,
+                               float(seed), _dt(f)), "egk_rowdot_bce")
+        slot_w, slot_b = _grad_slot(W), _grad_slot(b)
+        dw = slot_w if slot_w is not None else torch.zeros(W.shape, dtype=torch.float32, device=f.device)
+        db = (slot_b if slot_b is not None else torch.zeros(b.shape, dtype=torch.float32, device=f.device)) if b is not None else None
+        _ck(lib.egk_rowdot_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols), "egk_rowdot_reduce")
+        ctx.ret = (df, None if slot_w is not None else dw, None if (slot_b is not None or b is None) else db)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        df, dw, db = ctx.ret  # computed in forward from the announced seed (the constant weight / numel of the objective)
+        return df, dw, db, None, None
+
+
+def linear1_bce_ok(f, W) -> bool:
+    """The one-pass head applies: the backward seed is announced (``loss_seed``), gradients are wanted, ``f`` is a device
+    matrix of at most 4096 columns in an element type the row kernels compute in (bf16 activations, or exact-f32 mode)."""
+    return bool(_loss_seed["coef"] is not None and torch.is_grad_enabled() and f.is_cuda and f.dim() == 2 and W.dim() == 2
+                and W.shape[0] == 1 and W.shape[1] == f.shape[1] and f.shape[1] <= 4096 and f.shape[1] % 8 == 0
+                and (f.dtype == torch.bfloat16 or (f.dtype == torch.float32 and _state["compute"] == F32)))
+
+
+def linear1_bce(f, W, b, y):
+    """(loss [N], logits [N]) of BCEWithLogits(reduction='none')(Linear(H, 1)(f).squeeze(), y.float()) -- reference
+    models/tasks/pnr.py:37-52 + main_temporal.py:117-121 -- in one row pass that also writes d f, d W, d b.  Requires
+    ``linear1_bce_ok``."""
+    if not linear1_bce_ok(f, W):
+        raise RuntimeError("linear1_bce: needs an announced loss seed (ops.loss_seed) and a device feature matrix")
+    if y.dtype != torch.int64:
+        y = y.to(torch.int64)
+    return _RowDotBCE.apply(f, W, b, y, float(_loss_seed["coef"]))
+
+
 class _OneHotSigmoid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, y, kind, alpha, gamma):

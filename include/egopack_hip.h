@@ -209,6 +209,19 @@ int egk_ln_bwd_reduce(egk_stream_t s, const void* ws, float* dw, float* db, int3
  * flush); same summation order as egk_ln_bwd_reduce: same bits. */
 int egk_ln_bwd_reduce_multi(egk_stream_t s, const void* const* ws, float* const* dw, float* const* db, const int32_t* rows,
                             const int32_t* cols, const int32_t* n_seg, int32_t count);
+/* ---- one-logit classifier + BCE-with-logits in one pass over the rows: the PNR head
+ * models/tasks/pnr.py:20,37-52 (Linear(features, 1) -> squeeze) + nn.BCEWithLogitsLoss(reduction='none')
+ * (main_temporal.py:117-121).  A [rows, cols] x [cols, 1] contraction is a row reduction: per row n
+ *   z = <f_n, w> + bias[0];  logits[n] = z;  loss[n] = BCE(z, y[n])  (the formula of egk_bce_fwd)
+ * and, when df != NULL (the seed of the loss vector's backward is known: it is the constant weight / numel),
+ *   g = (sigmoid(z) - y[n]) * seed rounded to the element type;  df_n = g w;  dw += sum_n g f_n;  db += sum_n g
+ * f, w, df: element type ``dtype`` (w = the operand copy of the weight row the contraction path reads).
+ * ws: float [egk_rowdot_ws_rows(rows)][cols + 4] partial rows of dw / db; egk_rowdot_reduce ACCUMULATES them into
+ * dw [cols] / db [1] in block order (fixed order: bitwise reproducible). */
+int32_t egk_rowdot_ws_rows(int32_t rows);
+int egk_rowdot_bce(egk_stream_t s, const void* f, const void* w, const float* bias, const int64_t* y, float* logits,
+                   float* loss, void* df, float* ws, int32_t rows, int32_t cols, float seed, int32_t dtype);
+int egk_rowdot_reduce(egk_stream_t s, const float* ws, float* dw, float* db, int32_t rows, int32_t cols);
 /* Grouped row LayerNorm(+ReLU): n_groups (<= 4) consecutive row ranges [row_ptr[g], row_ptr[g+1]) of ONE [rows, cols]
  * matrix, each with its own (w, b) -- the LayerNorms of the per-task projection heads (models/tasks/task.py:20-21) in one
  * launch.  No dropout.  bwd writes dx and per-workgroup partial rows of dw / db:

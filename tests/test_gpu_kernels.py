@@ -535,6 +535,53 @@ def test_bce_with_logits(ops):
     torch.testing.assert_close(dx.grad.cpu(), cx.grad, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("rows,cols,mode", [(333, 256, "f32"), (2048, 1024, "f32"), (2048, 1024, "bf16"), (77, 1000, "bf16")])
+def test_one_logit_head_with_bce_in_one_row_pass(ops, rows, cols, mode):
+    """ops.linear1_bce = BCEWithLogits(reduction='none')(Linear(H, 1)(f).squeeze(), y.float()) -- models/tasks/pnr.py:37-52,
+    main_temporal.py:117-121 -- plus d f, d W, d b for the announced backward seed, against torch on the same (rounded)
+    operands, and against the contraction path of this library (the path it replaces)."""
+    g = gen(rows + cols)
+    f = torch.randn(rows, cols, generator=g)
+    W, b = torch.randn(1, cols, generator=g) * 0.05, torch.randn(1, generator=g)
+    y = torch.randint(0, 2, (rows,), generator=g)
+    seed = 0.7 / rows
+    ops.set_compute(mode)
+    try:
+        if mode == "bf16":
+            f, Wr = r16(f), r16(W)
+        else:
+            Wr = W
+        cf, cW, cb = f.clone().requires_grad_(True), Wr.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        z = (cf @ cW.t()).squeeze(1) + cb
+        ref = F.binary_cross_entropy_with_logits(z, y.float(), reduction="none")
+        ref.backward(torch.full_like(ref, seed))
+        df = f.to(DEV).to(ops.act_dtype()).requires_grad_(True)
+        dW, db = W.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+        with ops.loss_seed(seed):
+            assert ops.linear1_bce_ok(df, dW)
+            loss, logits = ops.linear1_bce(df, dW, db, y.to(DEV))
+        loss.backward(torch.full_like(loss, seed))
+        tol = dict(rtol=2e-5, atol=2e-6) if mode == "f32" else dict(rtol=2e-2, atol=2e-3)
+        torch.testing.assert_close(logits.cpu(), z.detach(), rtol=1e-4 if mode == "f32" else 1e-2, atol=1e-4 if mode == "f32" else 2e-2)
+        torch.testing.assert_close(loss.detach().cpu(), ref.detach(), rtol=1e-4 if mode == "f32" else 1e-2, atol=1e-4 if mode == "f32" else 2e-2)
+        gscale = float(cf.grad.abs().max())
+        assert (df.grad.float().cpu() - cf.grad).abs().max() <= (1e-5 if mode == "f32" else 1.5e-2) * gscale
+        wscale = float(cW.grad.abs().max())
+        assert (dW.grad.cpu() - cW.grad).abs().max() <= (2e-5 if mode == "f32" else 1.5e-2) * wscale
+        assert abs(float(db.grad.cpu()) - float(cb.grad)) <= (2e-5 if mode == "f32" else 1e-2) * max(1.0, abs(float(cb.grad)) * 100)
+        # the path it replaces: classifier contraction + egk_bce_* -- same values up to summation order
+        df2 = f.to(DEV).to(ops.act_dtype()).requires_grad_(True)
+        dW2, db2 = W.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+        z2 = ops.linear(df2, dW2, db2, out_f32=True).squeeze(1)
+        l2 = ops.bce_with_logits(z2, y.to(DEV))
+        l2.backward(torch.full_like(l2, seed))
+        torch.testing.assert_close(loss.detach(), l2.detach(), **(dict(rtol=1e-4, atol=1e-5) if mode == "f32" else dict(rtol=5e-3, atol=5e-3)))
+        assert (df.grad.float() - df2.grad.float()).abs().max().item() <= (1e-5 if mode == "f32" else 1e-2) * gscale
+        assert (dW.grad - dW2.grad).abs().max().item() <= (2e-5 if mode == "f32" else 1e-2) * wscale
+    finally:
+        ops.set_compute("f32")
+
+
 def test_weighted_mean_sum_and_sum_tensors(ops):
     g = gen(54)
     a, b = torch.randn(100, generator=g), torch.randn(37, generator=g)

@@ -19,11 +19,11 @@ def test_two_ranks_with_exact_graph_ln_equal_one_process_on_the_global_batch():
     out = json.loads(lines[-1])
     e, l = out["exact"], out["local"]
     # exact mode: the two-rank run IS the one-process run on the global batch, up to f32 summation order
-    assert e["objective_rel"] <= 1e-5, out
+    assert e["objective_rel"] <= 1e-6, out
     assert e["grad_rel"] <= 2e-3, out  # (a few ReLU / LeakyReLU gates at rounding distance from zero: see test_gpu_configs.py)
     assert e["param_frac_within_2e-4"] >= 0.999, out
     # default mode (per-rank statistics) is a different computation: the mode, not luck, makes the runs agree
-    assert l["grad_rel"] >= 20 * e["grad_rel"] and l["objective_rel"] >= 20 * e["objective_rel"], out
+    assert l["grad_rel"] >= 100 * e["grad_rel"] and l["param_frac_within_2e-4"] < 0.99, out
     assert e["ranks_bit_identical"] and l["ranks_bit_identical"], out
     # benchmark mode: both ranks capture the step as staged hipGraphs; replayed steps = eagerly issued steps, bit for bit
     rp = out["bf16_replay"]

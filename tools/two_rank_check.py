@@ -187,9 +187,9 @@ def worker(args):
                               "replayed_vs_eager_max_abs": float((pg - pe).abs().max())}
         out["config"] = dict(hidden=args.hidden, batch_per_rank=B, T=args.T, steps=args.steps, mode="f32", tasks=list(ORDER))
         e, l = out["exact"], out["local"]
-        ok = (e["objective_rel"] <= 1e-5 and e["grad_rel"] <= 2e-3 and e["param_frac_within_2e-4"] >= 0.999
+        ok = (e["objective_rel"] <= 1e-6 and e["grad_rel"] <= 2e-3 and e["param_frac_within_2e-4"] >= 0.999
               and e["ranks_bit_identical"] and l["ranks_bit_identical"]
-              and l["grad_rel"] >= 20 * e["grad_rel"] and l["objective_rel"] >= 20 * e["objective_rel"]
+              and l["grad_rel"] >= 100 * e["grad_rel"] and l["param_frac_within_2e-4"] < 0.99
               and out["bf16_replay"]["capture"] == "staged graphs" and out["bf16_replay"]["ranks_bit_identical"]
               and out["bf16_replay"]["replayed_vs_eager_rel"] <= 1e-6)
         out["ok"] = bool(ok)
