@@ -18,6 +18,7 @@ import torch
 
 from . import ops
 from .data import Data, merge_batches
+from .criterion import MetricSelectorWrapper
 from .dist import GradSync
 
 TASK_ORDER = ("ar", "lta", "oscc", "pnr")  # order of the loss terms in main_temporal.train
@@ -339,14 +340,17 @@ class StepBase:
             return dict(zip(live, parts))
         return {t: self.model(batches[t]) for t in live}
 
-    def _run_heads(self, feats, head_fn):
+    def _run_heads(self, feats, head_fn, main_job=None):
         """``head_fn(t, feat) -> (loss_vector, extra)`` for every task; on side streams when there are several
         (independent half-chip contractions: they overlap).  A head_fn that also runs the head's BACKWARD (see
         ``_backward_pass``) must do so here, inside the head's stream context: one ``backward()`` over several streams
         replays the branches one after the other (tools/exp/branch_overlap.py: 676 us against 441 us for three chains of
         20 contractions), one call per branch inside its stream context lets them overlap."""
         vectors, extras = {}, {}
-        if self.parallel_heads and len(feats) > 1 and next(iter(feats.values())).is_cuda:
+        if main_job is not None and not feats:
+            main_job()
+            return vectors, extras
+        if self.parallel_heads and (len(feats) > 1 or main_job is not None) and next(iter(feats.values())).is_cuda:
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event()
             fork.record(main)
@@ -362,11 +366,15 @@ class StepBase:
                 feat.record_stream(st)
                 with torch.cuda.stream(st):
                     vectors[t], extras[t] = head_fn(t, feat)
+            if main_job is not None:  # (a chain that stays on the main stream, beside the forked ones)
+                main_job()
             for st in used:
                 main.wait_stream(st)
         else:
             for t, feat in feats.items():
                 vectors[t], extras[t] = head_fn(t, feat)
+            if main_job is not None:
+                main_job()
         return vectors, extras
 
     def _objective(self, vectors):
@@ -739,6 +747,26 @@ class MTLStep(StepBase):
         return (self.one_pass_heads and hasattr(self.tasks[t], "fused_head_loss") and type(self.criteria[t]) is BCEWithLogitsNone
                 and "rowdot_head" not in getattr(self, "_dev_off", ()))
 
+    grouped_classifiers = True
+
+    def _banked_tasks(self, order, proj_leaves):
+        """Tasks whose multi-head classifier banks can share grouped launches (ops.grouped_classifier_banks): at least two."""
+        if not self.grouped_classifiers or "grouped_classifiers" in getattr(self, "_dev_off", ()):
+            return []
+        cand = []
+        for t in order:
+            task = self.tasks[t]
+            cls = getattr(task, "classifiers", None)
+            if cls is None or (task.training and any(c[0].p > 0 for c in cls)):
+                continue  # (no multi-head bank, or classifier dropout active: the per-task path)
+            if getattr(cls[0][1].weight, "_egk_bank_views", None) is None or not isinstance(self.criteria[t], MetricSelectorWrapper):
+                continue
+            cand.append(t)
+        if len(cand) < 2:
+            return []
+        views = [self.tasks[t].classifiers[0][1].weight._egk_bank_views for t in cand]
+        return cand if ops.grouped_classifier_banks_ok([proj_leaves[t] for t in cand], views) else []
+
     def _heads_forward_backward(self, feats):
         """Heads' forward AND backward, every head inside its own stream context, on detached copies of the backbone
         features: returns (objective, loss vectors, {task: leaf}) with d(objective)/d(features) in ``leaf.grad``.
@@ -783,8 +811,38 @@ class MTLStep(StepBase):
                     g._egk_coef = self.weights[t] / v.numel()
                 v.backward(gradient=g)
             return v.detach(), logits
+        # the multi-head classifier banks of several tasks (AR and LTA: same widths, own rows and weights) as ONE chain of
+        # grouped launches on the main stream -- grouped classifier contraction, one fused cross entropy per task, grouped dX --
+        # instead of one chain per task on its own stream (each fork / join of a stream costs more than these launches)
+        banked = self._banked_tasks(order, proj_leaves) if grouped else []
+        banked_vectors = {}
+
+        def banked_chain():
+            views = [self.tasks[t].classifiers[0][1].weight._egk_bank_views for t in banked]
+            n_loss = {t: proj_leaves[t].shape[0] for t in banked}
+            all_logits = ops.grouped_classifier_banks([proj_leaves[t] for t in banked], views,
+                                                      fused_loss=getattr(self, "_fused_loss", True))
+            vs, gs = [], []
+            for t, logits in zip(banked, all_logits):
+                with ops.loss_seed(self.weights[t] / n_loss[t] if getattr(self, "_fused_loss", True) else None):
+                    v = self.criteria[t](logits, batches[t].y)
+                if v.numel() != n_loss[t]:
+                    raise RuntimeError(f"head {t}: {v.numel()} loss elements where {n_loss[t]} were announced to the fused loss")
+                key = (t, v.numel(), v.dtype, v.device)
+                g = self._coef_grads.get(key)
+                if g is None or g._egk_coef != self.weights[t] / v.numel():
+                    g = self._coef_grads[key] = torch.full_like(v, self.weights[t] / v.numel(), dtype=v.dtype).detach()
+                    g._egk_coef = self.weights[t] / v.numel()
+                vs.append(v)
+                gs.append(g)
+                banked_vectors[t] = v.detach()
+            torch.autograd.backward(vs, gs)  # ONE pass: both cross entropies, then the grouped banks' backward once
         with ops.bank_grad_handoff():  # every head's logits feed exactly one loss node here
-            vectors, _ = self._run_heads(proj_leaves if grouped else leaves, head)
+            src = proj_leaves if grouped else leaves
+            rest = {t: f for t, f in src.items() if t not in banked}
+            vectors, _ = self._run_heads(rest, head, main_job=banked_chain if banked else None)
+            vectors.update(banked_vectors)
+            vectors = {t: vectors[t] for t in order if t in vectors}
         if grouped:  # back on the main stream: the grouped projection's backward down to the backbone features
             ops.stamp("heads_classifiers_done")
             live = [t for t in order if proj_leaves[t].grad is not None]

@@ -676,6 +676,30 @@ class bank_grad_handoff:
         _bank_handoff["on"] = self.prev
 
 
+def _bank_gradient_operand(views, gbuf, state, gs, x):
+    """The [M, sum rows64] gradient operand of a classifier bank's backward contractions: the columns the loss wrote itself
+    (bank_grad_handoff) stay, the others are converted from the incoming gradients ``gs``, pad columns are zero."""
+    lib = _lib.load()
+    M, N = x.shape[0], views["n"]
+    if gbuf is None:  # (forward ran without a gradient consumer in sight; cannot happen under autograd)
+        gbuf = torch.zeros((M, N), dtype=x.dtype, device=x.device)
+    if not state["pads"]:  # allocated uncleared for the fused loss, which then did not run: clear the pads now
+        ends = [r for r, _ in views["rows"][1:]] + [N]
+        for (r0, n), e in zip(views["rows"], ends):
+            if e > r0 + n:
+                gbuf[:, r0 + n:e].zero_()
+            if r0 not in state["filled"]:
+                gbuf[:, r0:r0 + n].zero_()
+    for (r0, n), g in zip(views["rows"], gs):
+        if r0 in state["filled"] or g is None:
+            continue  # the loss wrote these columns itself (bank_grad_handoff); None: no gradient, columns stay zero
+        g = _rm(g)
+        dst = gbuf[:, r0:r0 + n]
+        _ck(lib.egk_cast_rows(_stream(), _p(g), _dt(g), g.stride(0), _p(dst), _dt(gbuf), gbuf.stride(0), M, n, 0),
+            "egk_cast_rows")
+    return gbuf
+
+
 class _ClassifierBank(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, views, gbuf, state, compute):
@@ -695,22 +719,7 @@ class _ClassifierBank(torch.autograd.Function):
         views, gbuf, lib = ctx.views, ctx.gbuf, _lib.load()
         M, K = x.shape
         N = views["n"]
-        if gbuf is None:  # (forward ran without a gradient consumer in sight; cannot happen under autograd)
-            gbuf = torch.zeros((M, N), dtype=x.dtype, device=x.device)
-        if not ctx.state["pads"]:  # allocated uncleared for the fused loss, which then did not run: clear the pads now
-            ends = [r for r, _ in views["rows"][1:]] + [N]
-            for (r0, n), e in zip(views["rows"], ends):
-                if e > r0 + n:
-                    gbuf[:, r0 + n:e].zero_()
-                if r0 not in ctx.state["filled"]:
-                    gbuf[:, r0:r0 + n].zero_()
-        for (r0, n), g in zip(views["rows"], gs):
-            if r0 in ctx.state["filled"] or g is None:
-                continue  # the loss wrote these columns itself (bank_grad_handoff); None: no gradient, columns stay zero
-            g = _rm(g)
-            dst = gbuf[:, r0:r0 + n]
-            _ck(lib.egk_cast_rows(_stream(), _p(g), _dt(g), g.stride(0), _p(dst), _dt(gbuf), gbuf.stride(0), M, n, 0),
-                "egk_cast_rows")
+        gbuf = _bank_gradient_operand(views, gbuf, ctx.state, gs, x)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -737,6 +746,88 @@ def classifier_bank(x, anchor, views, compute=None):
     if _bank_handoff["on"] and gbuf is not None:
         for o, (r0, _) in zip(outs, views["rows"]):
             o._egk_grad_dst = (gbuf, r0, state)
+    return outs
+
+
+class _GroupedBanks(torch.autograd.Function):
+    """The classifier banks of several task heads (same feature width, own rows, own weights) as ONE grouped contraction
+    forward and ONE grouped dX contraction backward -- the multi-head classifiers of the AR and LTA tasks
+    (models/tasks/recognition.py:37-45, called per task at main_temporal.py:93-126) -- instead of one chain per task on
+    its own stream.  The weight gradients are parked like those of ``_ClassifierBank``."""
+
+    @staticmethod
+    def forward(ctx, views_list, gbufs, states, compute, *xs):
+        xs = [_c(x) for x in xs]
+        outs, probs = [], []
+        for x, views in zip(xs, views_list):
+            M, K = x.shape
+            out = torch.empty((M, views["n"]), dtype=torch.float32, device=x.device)
+            probs.append(((M, views["n"], x, K, views["w16"], K, K, out, views["n"]), dict(bias=views["b"], compute=compute)))
+            outs.append(out)
+        gemm_grouped(probs)
+        ctx.views_list, ctx.gbufs, ctx.states, ctx.compute = views_list, gbufs, states, compute
+        ctx.save_for_backward(*xs)
+        return tuple(out[:, r0:r0 + n] for out, views in zip(outs, views_list) for r0, n in views["rows"])
+
+    @staticmethod
+    def backward(ctx, *gs):
+        xs = ctx.saved_tensors
+        cmp, k, probs, dxs, parked = ctx.compute, 0, [], [], []
+        for i, (x, views) in enumerate(zip(xs, ctx.views_list)):
+            nb = len(views["rows"])
+            gbuf = _bank_gradient_operand(views, ctx.gbufs[i], ctx.states[i], gs[k:k + nb], x)
+            k += nb
+            M, K = x.shape
+            N = views["n"]
+            if ctx.needs_input_grad[4 + i]:
+                dx = torch.empty_like(x)
+                probs.append(((M, K, gbuf, N, views["w16"], K, N, dx, K), dict(transB=True, compute=cmp)))
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+            parked.append(((N, K, gbuf, N, x, K, M, views["wg"], K),
+                           dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=views["bg"]), (gbuf, x)))
+        if len(probs) > 1:
+            gemm_grouped(probs)
+        elif probs:
+            gemm(*probs[0][0], **probs[0][1])
+        for w_args, w_kw, hold in parked:
+            if not _wgrad_defer(w_args, w_kw, hold, park_on_excluded=True):
+                _wgrad_launch(True, hold, lambda a=w_args, kw=w_kw: gemm(*a, **kw))
+        return (None, None, None, None, *dxs)
+
+
+def grouped_classifier_banks_ok(xs, views_list) -> bool:
+    """bf16 activations, 2 .. 8 banks over features of one width (a multiple of 64), row counts multiples of 64."""
+    if not (2 <= len(xs) <= 8) or any(v is None for v in views_list):
+        return False
+    K = xs[0].shape[1] if xs[0].dim() == 2 else 0
+    for x, v in zip(xs, views_list):
+        if (x.dim() != 2 or not x.is_cuda or x.dtype != torch.bfloat16 or x.shape[1] != K or K % 64 or x.shape[0] % 64
+                or x.shape[0] == 0 or v["n"] % 64 or v.get("w16") is None):
+            return False
+    return True
+
+
+def grouped_classifier_banks(xs, views_list, fused_loss: bool = False, compute=None):
+    """Per bank, the tuple of logits ``classifier_bank`` returns -- all banks in one launch (see ``_GroupedBanks``).
+    ``fused_loss``: a cross entropy with an announced seed follows for every bank (it then writes the whole gradient
+    operand itself, so the operand is not cleared first)."""
+    needs = torch.is_grad_enabled()
+    lazy = _bank_handoff["on"] and fused_loss
+    gbufs, states = [], []
+    for x, views in zip(xs, views_list):
+        gbufs.append((torch.empty if lazy else torch.zeros)((x.shape[0], views["n"]), dtype=x.dtype, device=x.device) if needs else None)
+        states.append({"filled": set(), "pads": not lazy})
+    flat = _GroupedBanks.apply(list(views_list), gbufs, states, _compute_for(xs[0]) if compute is None else compute, *xs)
+    outs, k = [], 0
+    for views, gbuf, state in zip(views_list, gbufs, states):
+        blk = flat[k:k + len(views["rows"])]
+        k += len(views["rows"])
+        if _bank_handoff["on"] and gbuf is not None:
+            for o, (r0, _) in zip(blk, views["rows"]):
+                o._egk_grad_dst = (gbuf, r0, state)
+        outs.append(tuple(blk))
     return outs
 
 
