@@ -800,7 +800,10 @@ __global__ __launch_bounds__(256) void rowdot_reduce_kernel(const float* __restr
 }
 
 static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 : cols <= 4096 ? 16 : 0; }
-static int g_cap_partial = 512, g_cap_wide = 2048;  // development knobs (egk_tune 1 / 2)
+// development knobs (egk_tune 1 / 2).  Streaming kernels: three workgroups per CU -- every wave re-reads the f32 affine rows
+// (8 KB against a 2 KB bf16 row) and, in the graph LayerNorm, re-reduces the statistics partials, so a wave should walk
+// >= 2 rows; in-step A/B of the headline workload, 200 steps x 3 rounds: 2048 -> 1.637, 512 -> 1.626, 768 -> 1.612 ms
+static int g_cap_partial = 512, g_cap_wide = 768;
 static inline int row_grid(int rows) {  // kernels that emit per-workgroup partial rows: two workgroups per CU
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > g_cap_partial ? g_cap_partial : g);
