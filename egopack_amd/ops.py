@@ -1719,11 +1719,13 @@ class _RowDotBCE(torch.autograd.Function):
         _ck(lib.egk_rowdot_reduce(_stream(), _p(ws), _p(dw), _p(db), rows, cols), "egk_rowdot_reduce")
         ctx.ret = (df, None if slot_w is not None else dw, None if (slot_b is not None or b is None) else db)
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the logits' absent gradient: a launch of its own)
         return loss, logits
 
     @staticmethod
     def backward(ctx, gloss, _glogits):
         df, dw, db = ctx.ret  # computed in forward from the announced seed (the constant weight / numel of the objective)
+        ctx.ret = None        # (sole owner of df from here: autograd keeps it as the leaf's gradient instead of cloning it)
         return df, dw, db, None, None
 
 
