@@ -591,6 +591,7 @@ class StepBase:
                 if self.input_hook is not None:
                     self.input_hook()
                 if early is not None:
+                    early["rng"] = "rng_in_graph" not in getattr(self, "_dev_off", ()) and "rng_early" not in getattr(self, "_dev_off", ())
                     ops.set_last_wgrad_hook(early["param"], early["hook"])
                 total, vectors = self._backward_pass(batches, merged)
                 self._join_zero()  # (a backward path that did not: the memset must at least precede the optimizer)
@@ -607,7 +608,8 @@ class StepBase:
                 # the Philox offset word of the dropout launches moves on INSIDE the graph (last node, beside nothing that reads
                 # it): replay k draws the masks of offset base + k * stride without a separate launch in front of every replay
                 if "rng_in_graph" not in getattr(self, "_dev_off", ()):
-                    ops.advance_rng_device(opt.flat_p.device)
+                    if not (early is not None and early.get("rng_done")):
+                        ops.advance_rng_device(opt.flat_p.device)
                     self._rng_in_graph = True
         finally:
             ops.set_last_wgrad_hook(None, None)
@@ -653,6 +655,9 @@ class StepBase:
             if side is not None:
                 plan["stream"].wait_stream(side)
             with torch.cuda.stream(plan["stream"]):
+                if plan.get("rng"):  # the dropout offset word moves on here, beside the last weight gradient, instead of as
+                    ops.advance_rng_device(opt.flat_p.device)  # a launch of its own behind Adam at the tail of the step
+                    plan["rng_done"] = True  # (every dropout launch of the step has been issued: this is backward's end)
                 opt.launch(None, 0, lo)
                 opt.launch(None, hi, total)
             plan["fired"] = True
