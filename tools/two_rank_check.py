@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="sequences per task PER RANK")
     ap.add_argument("--T", type=int, default=16)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--port", type=int, default=29617)
+    ap.add_argument("--port", type=int, default=0, help="rendezvous port (0: a free one picked by the parent)")
     ap.add_argument("--worker", type=int, default=-1)
     return ap.parse_args()
 
@@ -207,6 +207,11 @@ def main():
     if args.worker >= 0:
         sys.exit(worker(args))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not args.port:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            args.port = sk.getsockname()[1]
     procs = [subprocess.Popen([sys.executable, str(Path(__file__).resolve()), "--worker", str(r), "--hidden", str(args.hidden),
                                "--batch", str(args.batch), "--T", str(args.T), "--steps", str(args.steps), "--port", str(args.port)],
                               env=env, stdout=subprocess.PIPE if r == 0 else None, text=True) for r in range(2)]
