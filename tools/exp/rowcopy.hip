@@ -77,6 +77,57 @@ __global__ __launch_bounds__(256) void k_row8_red(const bf16_t* x, bf16_t* y, in
         }
     }
 }
+// (5) the library's shape: wave per row, 8-byte loads, f32 affine rows (w, b) in registers, mean / variance reductions
+__global__ __launch_bounds__(256) void k_rowln(const bf16_t* x, const float* w, const float* b, bf16_t* y, int rows, int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 wv[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wv[i] = *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4);
+        bv[i] = *reinterpret_cast<const float4*>(b + (i * 64 + lane) * 4);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        uint2 v[4];
+        float f[16], s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint2*>(x + (long long)row * cols + (i * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[4 * i] = __uint_as_float(v[i].x << 16); f[4 * i + 1] = __uint_as_float(v[i].x & 0xffff0000u);
+            f[4 * i + 2] = __uint_as_float(v[i].y << 16); f[4 * i + 3] = __uint_as_float(v[i].y & 0xffff0000u);
+            s += (f[4 * i] + f[4 * i + 1]) + (f[4 * i + 2] + f[4 * i + 3]);
+        }
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        const float mu = s / cols;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) q += (f[k] - mu) * (f[k] - mu);
+        for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+        const float rs = rsqrtf(q / cols + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = fmaxf((f[4 * i] - mu) * rs * wv[i].x + bv[i].x, 0.f), bb = fmaxf((f[4 * i + 1] - mu) * rs * wv[i].y + bv[i].y, 0.f);
+            const float c = fmaxf((f[4 * i + 2] - mu) * rs * wv[i].z + bv[i].z, 0.f), d = fmaxf((f[4 * i + 3] - mu) * rs * wv[i].w + bv[i].w, 0.f);
+            uint2 o; o.x = f2bf(a) | ((unsigned)f2bf(bb) << 16); o.y = f2bf(c) | ((unsigned)f2bf(d) << 16);
+            *reinterpret_cast<uint2*>(y + (long long)row * cols + (i * 64 + lane) * 4) = o;
+        }
+    }
+}
+// device time per launch of 20 DEPENDENT launches replayed from a hipGraph (how the library's kernels are timed)
+template <typename F> float timegraph(F f) {
+    hipStream_t st; hipStreamCreate(&st);
+    hipGraph_t g; hipGraphExec_t ge;
+    f(st); hipStreamSynchronize(st);
+    hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < 20; ++i) f(st);
+    hipStreamEndCapture(st, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphLaunch(ge, st); hipStreamSynchronize(st);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, st);
+    for (int i = 0; i < 10; ++i) hipGraphLaunch(ge, st);
+    hipEventRecord(b, st); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms * 1000.f / 200;
+}
 template <typename F> float timeit(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 5; ++i) f();
@@ -95,6 +146,16 @@ int main() {
                timeit([&] { hipLaunchKernelGGL(k_row16, dim3(grid), dim3(256), 0, 0, x, y, rows, cols); }),
                timeit([&] { hipLaunchKernelGGL(k_row8_red, dim3(grid), dim3(256), 0, 0, x, y, rows, cols); }));
     }
+    float *w, *b; hipMalloc(&w, cols * 4); hipMalloc(&b, cols * 4); hipMemset(w, 0, cols * 4); hipMemset(b, 0, cols * 4);
+    printf("in a hipGraph, 20 dependent launches:\n");
+    for (int grid : {256, 512, 768, 1024, 1536}) {
+        printf("grid %4d  row8 %.2f us  row16 %.2f us  row8+reduce %.2f us  rowln %.2f us\n", grid,
+               timegraph([&](hipStream_t s) { hipLaunchKernelGGL(k_row8, dim3(grid), dim3(256), 0, s, x, y, rows, cols); }),
+               timegraph([&](hipStream_t s) { hipLaunchKernelGGL(k_row16, dim3(grid), dim3(256), 0, s, x, y, rows, cols); }),
+               timegraph([&](hipStream_t s) { hipLaunchKernelGGL(k_row8_red, dim3(grid), dim3(256), 0, s, x, y, rows, cols); }),
+               timegraph([&](hipStream_t s) { hipLaunchKernelGGL(k_rowln, dim3(grid), dim3(256), 0, s, x, w, b, y, rows, cols); }));
+    }
+    printf("flat16 in graph %.2f us\n", timegraph([&](hipStream_t s) { hipLaunchKernelGGL(k_flat16, dim3((n / 8 + 255) / 256), dim3(256), 0, s, x, y, n / 8); }));
     printf("flat16 %.2f us\n", timeit([&] { hipLaunchKernelGGL(k_flat16, dim3((n / 8 + 255) / 256), dim3(256), 0, 0, x, y, n / 8); }));
     printf("memcpy d2d %.2f us\n", timeit([&] { hipMemcpyAsync(y, x, n * 2, hipMemcpyDeviceToDevice, 0); }));
     return 0;
