@@ -361,13 +361,13 @@ class StepBase:
             used = self._head_streams[:n_streams]
             for st in used:
                 st.wait_event(fork)
+            if main_job is not None:  # a chain that stays on the main stream, beside the forked ones; issued FIRST: under
+                main_job()            # capture the child of a fork that is created first keeps the parent's hardware queue
             for i, (t, feat) in enumerate(feats.items()):
                 st = used[i % n_streams]
                 feat.record_stream(st)
                 with torch.cuda.stream(st):
                     vectors[t], extras[t] = head_fn(t, feat)
-            if main_job is not None:  # (a chain that stays on the main stream, beside the forked ones)
-                main_job()
             for st in used:
                 main.wait_stream(st)
         else:
@@ -650,16 +650,22 @@ class StepBase:
             if plan["fired"]:
                 return
             main = torch.cuda.current_stream()
-            side = ops.wgrad_side_stream(main)
-            plan["stream"].wait_stream(main)
-            if side is not None:
-                plan["stream"].wait_stream(side)
-            with torch.cuda.stream(plan["stream"]):
-                if plan.get("rng"):  # the dropout offset word moves on here, beside the last weight gradient, instead of as
-                    ops.advance_rng_device(opt.flat_p.device)  # a launch of its own behind Adam at the tail of the step
-                    plan["rng_done"] = True  # (every dropout launch of the step has been issued: this is backward's end)
-                opt.launch(None, 0, lo)
-                opt.launch(None, hi, total)
+
+            def issue(ev):
+                # (issued AFTER the last weight gradient's own launch, behind an event recorded here: see
+                #  ops.defer_after_next_launch -- the launch created first keeps the backward stream's hardware queue)
+                side = ops.wgrad_side_stream(main)
+                plan["stream"].wait_event(ev)
+                if side is not None:
+                    plan["stream"].wait_stream(side)
+                with torch.cuda.stream(plan["stream"]):
+                    if plan.get("rng"):  # the dropout offset word moves on here, beside the last weight gradient, instead of
+                        ops.advance_rng_device(opt.flat_p.device)  # as a launch of its own behind Adam at the tail of the step
+                    opt.launch(None, 0, lo)
+                    opt.launch(None, hi, total)
+            if plan.get("rng"):
+                plan["rng_done"] = True  # (every dropout launch of the step has been issued: this is backward's end)
+            ops.defer_after_next_launch(issue)
             plan["fired"] = True
         plan["hook"] = hook
         return plan

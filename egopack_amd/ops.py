@@ -72,9 +72,50 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Launches forked to another stream are ISSUED one launch late: after the forking stream's NEXT library launch, behind an
+# event recorded at the fork point.  Same dependencies, same work -- but under hipGraph capture the order in which the two
+# children of a fork are created decides which of them stays on the parent's hardware queue (the first one), and the
+# other pays a cross-queue hand-off.  A backward pass naturally issues the forked weight gradient first, so the dX CHAIN
+# was the child that hopped, at every fork (tools/exp/fork_order.py: 12 links with a forked weight-gradient launch each,
+# 601 us per replay side-launch-first, 500 us chain-first).
+_deferred = {"items": [], "busy": False, "on": "fork_order" not in os.environ.get("EGK_DISABLE", "")}
+
+
+def defer_after_next_launch(fn) -> None:
+    """Run ``fn(event)`` right after the current stream's next library launch (``event``: recorded on the current stream now);
+    immediately if the mechanism is off.  ``fn`` issues work on OTHER streams behind ``event``."""
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    if not _deferred["on"]:
+        fn(ev)
+        return
+    _deferred["items"].append(((cur.device.index, cur.cuda_stream), ev, fn))
+
+
+def drain_deferred(all_streams: bool = True) -> None:
+    """Issue the deferred side launches now (every join point calls this first)."""
+    if _deferred["busy"] or not _deferred["items"]:
+        return
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    take = [it for it in _deferred["items"] if all_streams or it[0] == key]
+    if not take:
+        return
+    _deferred["items"] = [it for it in _deferred["items"] if not (all_streams or it[0] == key)]
+    _deferred["busy"] = True
+    try:
+        for _, ev, fn in take:
+            fn(ev)
+    finally:
+        _deferred["busy"] = False
+
+
 def _ck(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"{what} failed (code {rc}): {_lib.last_error()}")
+    if _deferred["items"] and not _deferred["busy"]:
+        drain_deferred(all_streams=False)
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -359,12 +400,15 @@ def _wgrad_launch(in_place: bool, tensors, launch, in_backward: bool = True):
     side = _wgrad["streams"].get(key)
     if side is None:
         side = _wgrad["streams"][key] = torch.cuda.Stream(device=main.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        launch()
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)
+
+    def issue(ev):
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            launch()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+    defer_after_next_launch(issue)  # (the closure keeps the operands alive until then)
     if side not in _wgrad["pending"]:
         _wgrad["pending"].append(side)
     if in_backward and not _wgrad["queued"]:  # join at the end of THIS backward pass, on the stream of the thread that called it
@@ -513,6 +557,7 @@ def join_wgrad(force: bool = False):
     before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture).  ``force``: the
     caller IS the step's backward stream (see flush_wgrad)."""
     flush_wgrad(in_backward=False, force=force)
+    drain_deferred()
     cur = torch.cuda.current_stream() if _wgrad["pending"] else None
     for side in _wgrad["pending"]:
         cur.wait_stream(side)
