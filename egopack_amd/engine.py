@@ -294,6 +294,10 @@ class StepBase:
 
     order: Sequence[str] = TASK_ORDER
     wgrad_grouping_default = True
+    # forked launches (weight gradients, early Adam) issued one launch late so that the dX chain keeps its hardware queue under
+    # capture (ops.defer_after_next_launch): -4 % on the multi-task steps, -1.6 % on the single-task step; the EgoPack step,
+    # whose GraphONE chains already occupy three queues, measured 4.04 vs 3.51 ms with it and leaves it off
+    deferred_forks_default = True
 
     def _init_base(self, model, tasks, weights, optimizer, fused_backbone, sync, parallel_heads):
         self.model, self.tasks = model, dict(tasks)
@@ -317,6 +321,7 @@ class StepBase:
         # -4 % on the 3-task step, -12 % on the single-task step; the EgoPack step, whose GraphONE chains already keep three
         # streams busy, measured 3.59 vs 3.46-3.52 ms with it and leaves it off
         self.wgrad_grouping = type(self).wgrad_grouping_default
+        self.deferred_forks = type(self).deferred_forks_default
         import os
         off = set(filter(None, os.environ.get("EGK_DISABLE", "").split(",")))  # development: A/B of the grouped paths
         if "wgrad_grouping" in off:
@@ -410,6 +415,7 @@ class StepBase:
             self.input_hook()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             with self._ln_exchange_scope():
                 total, vectors = self._backward_pass(batches, merged)
@@ -417,6 +423,7 @@ class StepBase:
         finally:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
+            ops.set_deferred_forks(prev_d)
         return total, vectors
 
     def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
@@ -475,6 +482,7 @@ class StepBase:
             self.input_hook()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             with self._ln_exchange_scope():
                 total, vectors = self._stage_a(batches, merged)
@@ -486,6 +494,7 @@ class StepBase:
         finally:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
+            ops.set_deferred_forks(prev_d)
         self._finish_staged()
         return total.detach(), {t: v.detach() for t, v in vectors.items()}
 
@@ -572,6 +581,7 @@ class StepBase:
         opt.prepare_hyper()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_d = ops.set_deferred_forks(self.deferred_forks)
         early = self._early_adam_plan(live) if fuse_adam else None
         try:
             with torch.cuda.graph(g, stream=ops.unexcluded_stream(), capture_error_mode=CAPTURE_MODE):
@@ -615,6 +625,7 @@ class StepBase:
             ops.set_last_wgrad_hook(None, None)
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
+            ops.set_deferred_forks(prev_d)
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
@@ -682,6 +693,7 @@ class StepBase:
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             with torch.cuda.graph(gs[0], capture_error_mode=CAPTURE_MODE):
                 opt.flat_g.zero_()
@@ -696,6 +708,7 @@ class StepBase:
         finally:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
+            ops.set_deferred_forks(prev_d)
         self._graph, self._static_out, self._fuse_adam = gs, (total, vectors), False
         self._static_in = (batches, merged, self._stage_state, self._cuts)  # everything the graphs read stays alive
         return gs
@@ -938,6 +951,7 @@ class EgoPackStep(StepBase):
 
     order = ("ar", "oscc", "lta", "pnr")  # order of the loss terms in main_egopack.train
     wgrad_grouping_default = False
+    deferred_forks_default = False
     AUX_ORDER = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
                  "pnr": ("ar", "oscc", "lta")}  # main_egopack.py:121-147
 

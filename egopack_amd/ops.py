@@ -81,6 +81,13 @@ def _stream():
 _deferred = {"items": [], "busy": False, "on": "fork_order" not in os.environ.get("EGK_DISABLE", "")}
 
 
+def set_deferred_forks(on: bool) -> bool:
+    """Switch the late issue of forked launches (engine: per step class); returns the previous setting."""
+    prev = _deferred["on"]
+    _deferred["on"] = bool(on) and "fork_order" not in os.environ.get("EGK_DISABLE", "")
+    return prev
+
+
 def defer_after_next_launch(fn) -> None:
     """Run ``fn(event)`` right after the current stream's next library launch (``event``: recorded on the current stream now);
     immediately if the mechanism is off.  ``fn`` issues work on OTHER streams behind ``event``."""
@@ -420,14 +427,16 @@ def _wgrad_launch(in_place: bool, tensors, launch, in_backward: bool = True):
 # A weight gradient of an H x H layer is a 64-tile contraction over K = all nodes: alone it fills a quarter of the chip,
 # and split-K to fill it costs slabs plus a second launch (measured: 23 us + 8.7 us per launch, 12 of them in the headline
 # step, all competing with the dX chain for the CUs).  With the queue on, such launches are PARKED (operands kept alive)
-# and issued FOUR AT A TIME as one grouped launch on the side stream: 256 workgroups, one per CU, no slabs, no reduce
-# launch, a quarter of the forks.  ``flush_wgrad`` issues what is parked (fewer than four at the end of backward).
+# and issued SIX AT A TIME as one grouped launch on the side stream: 384 workgroups, no slabs, no reduce launch, a sixth
+# of the forks.  ``flush_wgrad`` issues what is parked (fewer than four at the end of backward).
 _wq = {"on": False, "items": [], "tiles": 0, "hold": [], "extra": []}
-# Four per launch is the measured optimum INSIDE the step.  Alone, six H x H problems in one launch of two 4-wave
-# workgroups per CU run at 900 TF/s against 740 for four (tools/gemm_group_bench.py: x4 70 us, x6 85 us, x8 133 us at
-# K = 6144), but beside the dX chain the larger launches cost more than they save: 1.68 / 1.75 / 1.68 ms per step for
-# 4 / 6 / 8 on one box, 200 steps each, four rounds.  EGK_WGRAD_COUNT is a development knob (the library takes up to 8).
-WGRAD_GROUP_COUNT = int(os.environ.get("EGK_WGRAD_COUNT", "4"))
+# Six per launch: alone, six H x H problems in one launch of two 4-wave workgroups per CU run at 900 TF/s against 740 for
+# four on one 8-wave workgroup per CU (tools/gemm_group_bench.py: x4 70 us, x6 85 us, x8 133 us at K = 6144).  Inside the
+# step: 4 / 5 / 6 / 7 / 8 -> 1.558 / 1.60 / 1.538 / 1.60 / 1.595 ms (three alternating rounds of 200 steps; 12 H x H weight
+# gradients = two full launches of six).  Before the dX chain kept its hardware queue at the forks (defer_after_next_launch)
+# six measured WORSE than four (1.75 vs 1.68): the chain was the child that paid the queue hand-off behind every larger
+# launch.  EGK_WGRAD_COUNT is a development knob (the library takes up to 8 per launch).
+WGRAD_GROUP_COUNT = int(os.environ.get("EGK_WGRAD_COUNT", "6"))
 WGRAD_GROUP_TILES = 64 * WGRAD_GROUP_COUNT
 
 
