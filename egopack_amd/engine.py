@@ -437,6 +437,7 @@ class StepBase:
         """Captured steps clear the gradient buffer on a side stream beside the forward pass: wait for it before the first
         launch that writes a gradient."""
         if getattr(self, "_zero_pending", False):
+            ops.drain_deferred()
             torch.cuda.current_stream().wait_stream(self._zero_stream)
             self._zero_pending = False
 
@@ -593,9 +594,15 @@ class StepBase:
                 else:
                     if not hasattr(self, "_zero_stream"):
                         self._zero_stream = torch.cuda.Stream()
-                    self._zero_stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(self._zero_stream):
-                        opt.flat_g.zero_()
+
+                    def issue_zero(ev):  # (behind the forward pass's first launch: see ops.defer_after_next_launch)
+                        self._zero_stream.wait_event(ev)
+                        with torch.cuda.stream(self._zero_stream):
+                            opt.flat_g.zero_()
+                    if "zero_deferred" in getattr(self, "_dev_off", ()):
+                        issue_zero(torch.cuda.current_stream().record_event())
+                    else:
+                        ops.defer_after_next_launch(issue_zero)
                     self._zero_pending = True
                 self._rng_in_graph = False
                 if self.input_hook is not None:
