@@ -324,6 +324,11 @@ class StepBase:
         self.deferred_forks = type(self).deferred_forks_default
         import os
         off = set(filter(None, os.environ.get("EGK_DISABLE", "").split(",")))  # development: A/B of the grouped paths
+        on = set(filter(None, os.environ.get("EGK_ENABLE", "").split(",")))  # development: force a path a step class leaves off
+        if "wgrad_grouping" in on:
+            self.wgrad_grouping = True
+        if "deferred_forks" in on:
+            self.deferred_forks = True
         if "wgrad_grouping" in off:
             self.wgrad_grouping = False
         if "grouped_heads" in off:
