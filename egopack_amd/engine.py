@@ -615,6 +615,9 @@ class StepBase:
                 if early is not None:
                     early["rng"] = "rng_in_graph" not in getattr(self, "_dev_off", ()) and "rng_early" not in getattr(self, "_dev_off", ())
                     ops.set_last_wgrad_hook(early["param"], early["hook"])
+                    if early["tail"]:
+                        g0 = opt.flat_g.data_ptr()
+                        ops.set_last_wgrad_tail(g0 + 4 * early["lo"], g0 + 4 * early["hi"])
                 total, vectors = self._backward_pass(batches, merged)
                 self._join_zero()  # (a backward path that did not: the memset must at least precede the optimizer)
                 ops.set_last_wgrad_hook(None, None)
@@ -660,15 +663,25 @@ class StepBase:
         first = getattr(tp, "proj", [None])[0] if tp is not None else None
         if not (self._early_adam_ok() and first is not None and hasattr(opt, "region_of") and (self.fused or len(live) == 1)):
             return None
-        params = [p for p in (getattr(first, "weight", None), getattr(first, "bias", None)) if p is not None]
-        lo, hi = opt.region_of(params)
         total = opt.flat_p.numel()
-        slots = [opt._slot_of[id(p)] for p in params if id(p) in opt._slot_of]
-        if hi <= lo or lo % 8 or hi % 8 or sum(n for _, n in slots) != hi - lo:  # (their slots must be adjacent)
+
+        def region(params):
+            lo, hi = opt.region_of(params)
+            slots = [opt._slot_of[id(p)] for p in params if id(p) in opt._slot_of]
+            ok = hi > lo and lo % 8 == 0 and hi % 8 == 0 and sum(n for _, n in slots) == hi - lo  # (adjacent slots)
+            return (lo, hi) if ok else None
+        # the late Adam slice: the whole temporal pooling when its slots are one block (then the step's tail is ONE grouped
+        # launch of its weight gradients, ops.set_last_wgrad_tail), else the first linear alone
+        tail = None
+        if "tail_group" not in getattr(self, "_dev_off", ()):
+            tail = region([p for p in tp.parameters() if p.requires_grad])
+        reg = tail or region([p for p in (getattr(first, "weight", None), getattr(first, "bias", None)) if p is not None])
+        if reg is None:
             return None
+        lo, hi = reg
         if not hasattr(self, "_adam_stream"):
             self._adam_stream = torch.cuda.Stream()
-        plan = {"param": first.weight, "lo": lo, "hi": hi, "stream": self._adam_stream, "fired": False}
+        plan = {"param": first.weight, "lo": lo, "hi": hi, "stream": self._adam_stream, "fired": False, "tail": tail is not None}
         def hook():
             if plan["fired"]:
                 return

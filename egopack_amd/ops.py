@@ -535,13 +535,40 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
     _wgrad_launch(True, hold, launch, in_backward)
 
 
-_last_wgrad = {"param": None, "hook": None, "inline": True}
+_last_wgrad = {"param": None, "hook": None, "inline": True, "tail": None}
+
+
+def set_last_wgrad_tail(lo_ptr: int, hi_ptr: int) -> None:
+    """With a last-weight-gradient hook installed: parked weight gradients and norm reductions whose gradient slots lie in
+    the address range [lo_ptr, hi_ptr) are issued TOGETHER WITH the last weight gradient as one grouped launch on the
+    backward stream (the caller's hook starts the optimizer on everything OUTSIDE that range meanwhile and steps the range
+    after the launch).  Stand-alone, the first TRN linear's weight gradient alone takes 120 us and the two other TRN weight
+    gradients as a group of their own 66 us; the three in one launch 123 us (tools/exp/tail_group_bench.py).
+    (0, 0): only the last weight gradient itself (the default)."""
+    _last_wgrad["tail"] = (int(lo_ptr), int(hi_ptr)) if hi_ptr > lo_ptr else None
+
+
+def _take_tail_items():
+    """Split what is parked by gradient-slot address: (contractions, reductions) inside the tail range are returned and
+    removed from the queue; the rest stays parked."""
+    rng = _last_wgrad["tail"]
+    if rng is None:
+        return [], []
+    inside = lambda t: rng[0] <= t.data_ptr() < rng[1]
+    items = [it for it in _wq["items"] if inside(it[0][7])]
+    _wq["items"] = [it for it in _wq["items"] if not inside(it[0][7])]
+    extra = [e for e in _wq["extra"] if inside(e[1]) and inside(e[2])]
+    _wq["extra"] = [e for e in _wq["extra"] if not (inside(e[1]) and inside(e[2]))]
+    _wq["tiles"] = sum(((it[0][0] + 127) // 128) * ((it[0][1] + 127) // 128) for it in _wq["items"])
+    return items, extra
 
 
 def set_last_wgrad_hook(param, hook) -> None:
     """``hook()`` is called (on the backward stream) just before the weight-gradient launch of ``param`` -- the engine
     marks the LAST weight gradient of the step with it to start the optimizer on everything else meanwhile."""
     _last_wgrad["param"], _last_wgrad["hook"] = param, hook
+    if hook is None:
+        _last_wgrad["tail"] = None
 
 
 def wgrad_side_stream(main) -> Optional[torch.cuda.Stream]:
@@ -678,7 +705,10 @@ class _Linear(torch.autograd.Function):
             slot = _grad_slot(Wp)
             out = slot if slot is not None else torch.zeros(W.shape, dtype=torch.float32, device=g.device)
             last = Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None
+            tail_items, tail_extra = [], []
             if last:
+                tail_items, tail_extra = _take_tail_items()  # (kept for the launch below; their operands stay alive in _wq["hold"])
+                hold = list(_wq["hold"]) if (tail_items or tail_extra) else []
                 flush_wgrad(force=True)  # (the hook starts the optimizer on every other slot: their gradients must be issued)
                 _last_wgrad["hook"]()
             # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS).  The LAST
@@ -687,7 +717,21 @@ class _Linear(torch.autograd.Function):
             in_place = slot is not None and (db_out is None or db is None)
             dw_args = (N, K1, g, g.stride(0), x, K1, M, out, K1)
             dw_kw = dict(transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=db_out)
-            if not (in_place and not last and ctx.compute == BF16 and _wgrad_defer(dw_args, dw_kw, (g, x))):
+            if last and (tail_items or tail_extra) and in_place and ctx.compute == BF16:
+                # the step's tail as ONE grouped launch on the backward stream: the parked weight gradients of the tail range
+                # + this one (the largest last), then the norm reductions of the range
+                if tail_items:
+                    gemm_grouped(tail_items + [(dw_args, dw_kw)])
+                else:
+                    gemm(*dw_args, **dw_kw)
+                if tail_extra:
+                    _launch_reductions(tail_extra)
+                del hold
+            elif not (in_place and not last and ctx.compute == BF16 and _wgrad_defer(dw_args, dw_kw, (g, x))):
+                for it in tail_items:  # (not eligible after all: issue what was taken, in order)
+                    gemm(*it[0], **it[1])
+                if tail_extra:
+                    _launch_reductions(tail_extra)
                 _wgrad_launch(in_place and not (last and _last_wgrad["inline"]), (g, x), lambda: gemm(*dw_args, **dw_kw))
             dW = None if slot is not None else out
         elif db_out is not None:
@@ -1496,6 +1540,10 @@ class _SageMean(torch.autograd.Function):
                                                                dbias=dbp)
         if not (rWp is None and rbp is None and ctx.compute == BF16 and _wgrad_defer(p_args, p_kw, (d_pre, h))):
             _wgrad_launch(rWp is None and rbp is None, (d_pre, h), lambda: gemm(*p_args, **p_kw))
+        if ctx.res_src is not None and _last_wgrad["tail"] is not None:
+            # the FIRST layer of the stack (its backward is the stack's last): what is parked goes out now, beside the temporal
+            # pooling's backward chain -- the step's tail launch then holds the temporal pooling's weight gradients only
+            flush_wgrad()
         return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
