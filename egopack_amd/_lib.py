@@ -6,6 +6,7 @@ kind (the CPU oracle under oracle/ is test infrastructure and is never imported 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import re
 from pathlib import Path
 
@@ -16,7 +17,7 @@ from pathlib import Path
 import torch  # noqa: F401
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libegopack_hip.so"
+LIB_PATH = Path(os.environ["EGK_LIB_PATH"]) if os.environ.get("EGK_LIB_PATH") else HERE / "libegopack_hip.so"  # (env: development A/B of two builds)
 HEADER = HERE.parent / "include" / "egopack_hip.h"
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
