@@ -324,14 +324,24 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=No
     _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
 
 
-def gemm_grouped(problems):
+def gemm_grouped(problems, four_wave: bool = False):
     """ONE launch for up to 8 independent contractions of the same layout (``problems``: a list of (args, kwargs) of
     ``gemm`` without the split-K options; bf16 operands, K sources multiples of 64)."""
     lib = _lib.load()
     arr = (_lib.GemmDesc * len(problems))()
     for i, (a, kw) in enumerate(problems):
         _gemm_desc(*a, into=arr[i], **kw)
-    _ck(lib.egk_gemm_grouped(_stream(), arr, len(problems)), "egk_gemm_grouped")
+    prev = None
+    if four_wave:  # launch-shape hint: the 4-wave 128 x 128 variant whatever the tile count (the two-wave-group variant it
+        prev = lib.egk_gemm_set_pipeline(3)  # replaces splits K over its two groups: same sums in another order)
+        if prev != 1:  # (a development setting is in force: leave it)
+            lib.egk_gemm_set_pipeline(prev)
+            prev = None
+    try:
+        _ck(lib.egk_gemm_grouped(_stream(), arr, len(problems)), "egk_gemm_grouped")
+    finally:
+        if prev is not None:
+            lib.egk_gemm_set_pipeline(prev)
 
 
 def _colsum_into(x2d: torch.Tensor, out: torch.Tensor, accumulate: bool):
@@ -529,7 +539,12 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
             if len(chunk) == 1:
                 gemm(*chunk[0][0], **chunk[0][1])
             else:
-                gemm_grouped(chunk)
+                # beside the dX chain a group runs on 4-WAVE workgroups also when it has <= 256 tiles (alone the 8-wave
+                # two-wave-group variant is faster there: 70 vs 85 us for four H x H problems): an 8-wave workgroup takes
+                # 2 x 208 VGPRs of every SIMD of its CU and the chain's row kernels (96-193 VGPRs) wait for it to leave --
+                # a 13 us row-LayerNorm backward took 82 us behind such a launch; 4 waves leave 304.  Step 1.511 -> 1.498 ms
+                # (six alternating runs of 300 steps, every pair)
+                gemm_grouped(chunk, four_wave=len(chunk) <= 4 and "wg4" not in os.environ.get("EGK_DISABLE", ""))
         if extra:
             _launch_reductions(extra)
     _wgrad_launch(True, hold, launch, in_backward)
