@@ -82,9 +82,12 @@ _deferred = {"items": [], "busy": False, "on": "fork_order" not in os.environ.ge
 
 
 def set_deferred_forks(on: bool) -> bool:
-    """Switch the late issue of forked launches (engine: per step class); returns the previous setting."""
+    """Switch the late issue of forked launches (engine: per step class); returns the previous setting.  Anything still
+    queued is dropped: a step ends with ``join_wgrad`` (which drains the queue), so something is left only when the step
+    was abandoned by an exception -- its launches must not surface in the next step."""
     prev = _deferred["on"]
     _deferred["on"] = bool(on) and "fork_order" not in os.environ.get("EGK_DISABLE", "")
+    _deferred["items"] = []
     return prev
 
 
