@@ -81,6 +81,7 @@ SIGNATURES = {
     "egk_pe_add_table": (C.c_int, [vp, vp, vp, vp, vp, i64, i32, vp, i32, i32, i32]),
     "egk_pe_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
     "egk_csr_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32]),
+    "egk_csr_gather_banded": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, i32]),
     "egk_csr_heavy_ws_bytes": (i64, [i32, i32]),
     "egk_csr_heavy_threshold": (i32, []),
     "egk_gather_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
                                                          const int* __restrict__ col, const float* __restrict__ wgt,
                                                          const T* __restrict__ gate, T* __restrict__ out, int rows,
                                                          int cols, int skip_above, const int* __restrict__ block_rows,
-                                                         int n_block_rows) {
+                                                         int n_block_rows, const unsigned char* __restrict__ band = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float part[];  // [3][NV*256] partial rows of waves 1..3
     __shared__ int heavy[64];
     __shared__ int n_heavy;
@@ -226,6 +226,33 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
     if (threadIdx.x == 0) n_heavy = 0;
     __syncthreads();
     for (int row = bid * WPB + wave; row < rows; row += nblk * WPB) {
+        if (band) {
+            // BANDED row (data.build_csr): its neighbours are a subset of {row - 1, row, row + 1}, named by three bits -- no
+            // rowptr / col fetches, the neighbour rows are requested at once.  Added in ascending order, which is the order
+            // of such a row's CSR entries (the builder checks): the same sums, bit for bit.  0xFF: a general row, below.
+            const unsigned code = band[row];
+            if (code != 0xFFu) {
+                float4 acc[NV], va[NV], vb[NV], vc[NV];
+                const long long r0 = (long long)row * cols;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    va[i] = (code & 1u) ? ld4(x + r0 - cols, c, cols, vec) : acc[i];
+                    vb[i] = (code & 2u) ? ld4(x + r0, c, cols, vec) : acc[i];
+                    vc[i] = (code & 4u) ? ld4(x + r0 + cols, c, cols, vec) : acc[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    if (code & 1u) { acc[i].x += 1.f * va[i].x; acc[i].y += 1.f * va[i].y; acc[i].z += 1.f * va[i].z; acc[i].w += 1.f * va[i].w; }
+                    if (code & 2u) { acc[i].x += 1.f * vb[i].x; acc[i].y += 1.f * vb[i].y; acc[i].z += 1.f * vb[i].z; acc[i].w += 1.f * vb[i].w; }
+                    if (code & 4u) { acc[i].x += 1.f * vc[i].x; acc[i].y += 1.f * vc[i].y; acc[i].z += 1.f * vc[i].z; acc[i].w += 1.f * vc[i].w; }
+                }
+                const int cnt = __popc(code & 7u);
+                csr_finish<NV, T>(acc, nullptr, cnt ? 1.f / (float)cnt : 0.f, gate, out, row, cols, vec, lane);
+                continue;
+            }
+        }
         const int e0 = rowptr[row], e1 = rowptr[row + 1];
         if (e1 - e0 > skip_above) continue;  // listed by the host: the split launches below produce this row
         if (e1 - e0 > HEAVY) {  // deferred to the cooperative phase (wave-uniform branch) while the list has room
@@ -847,10 +874,11 @@ int64_t egk_csr_heavy_ws_bytes(int32_t n_heavy, int32_t cols) { return (int64_t)
 
 int32_t egk_csr_heavy_threshold(void) { return VERY_HEAVY; }
 
-int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
-                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
-                   int32_t n_heavy, float* ws, int32_t heavy_mode) {
+static int csr_gather_impl(egk_stream_t stream, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
+                           const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
+                           int32_t n_heavy, float* ws, int32_t heavy_mode, const unsigned char* band) {
     EGK_REQUIRE(x && rowptr && out, "egk_csr_gather: null pointer");
+    EGK_REQUIRE(!band || !wgt, "egk_csr_gather_banded: the neighbour codes describe the unweighted (mean) orientation only");
     EGK_REQUIRE(n_heavy == 0 || (heavy_rows && (ws || heavy_mode == 1)), "egk_csr_gather: heavy rows need their list and a workspace");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -858,7 +886,7 @@ int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, co
     EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
     const int skip_above = n_heavy > 0 ? VERY_HEAVY : 0x7fffffff;
     const int in_launch = (n_heavy > 0 && heavy_mode == 1) ? n_heavy : 0;  // listed rows summed by one workgroup each, in the same launch
-#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows) + in_launch), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above, heavy_rows, in_launch)
+#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows) + in_launch), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above, heavy_rows, in_launch, band)
     EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
 #undef EGK_CSR
     if (n_heavy > 0 && !in_launch) {
@@ -870,6 +898,19 @@ int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, co
         });
     }
     return check_launch("egk_csr_gather");
+}
+
+int egk_csr_gather(egk_stream_t stream, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
+                   const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
+                   int32_t n_heavy, float* ws, int32_t heavy_mode) {
+    return csr_gather_impl(stream, x, rowptr, col, wgt, relu_gate, out, rows, cols, dtype, heavy_rows, n_heavy, ws, heavy_mode, nullptr);
+}
+
+int egk_csr_gather_banded(egk_stream_t stream, const void* x, const int32_t* rowptr, const int32_t* col, const uint8_t* band,
+                          void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows, int32_t n_heavy,
+                          float* ws, int32_t heavy_mode) {
+    EGK_REQUIRE(band, "egk_csr_gather_banded: null neighbour codes");
+    return csr_gather_impl(stream, x, rowptr, col, nullptr, nullptr, out, rows, cols, dtype, heavy_rows, n_heavy, ws, heavy_mode, band);
 }
 
 int egk_gather_max_fwd(egk_stream_t stream, const void* f, const float* bank, const int64_t* nn, void* m, uint8_t* arg,

@@ -76,10 +76,15 @@ class CSRGraph:
     # the fan-out node's 31), 0 if some have hundreds (T = 256)
     heavy_mode: int = 0
     t_heavy_mode: int = 0
+    # uint8 [num_nodes]: the in-neighbours of row i when they are a subset of {i - 1, i, i + 1} in ascending order (bit 0:
+    # i - 1, bit 1: i, bit 2: i + 1), 0xFF for any other row -- egk_csr_gather_banded reads the neighbours of a coded row
+    # without fetching rowptr / col (a radius-1 temporal graph is banded everywhere but at the LTA forecast nodes)
+    band: Optional[torch.Tensor] = None
 
     def _map(self, f):
         return CSRGraph(*(f(t) for t in (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)), self.num_nodes,
-                        *(f(t) if t is not None else None for t in (self.heavy, self.t_heavy)), self.heavy_mode, self.t_heavy_mode)
+                        *(f(t) if t is not None else None for t in (self.heavy, self.t_heavy)), self.heavy_mode, self.t_heavy_mode,
+                        f(self.band) if self.band is not None else None)
 
     def to(self, device, non_blocking: bool = False):
         return self._map(lambda t: t.to(device, non_blocking=non_blocking))
@@ -107,7 +112,31 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
     t_heavy = torch.nonzero(deg_out > HEAVY_DEGREE).flatten().int()
     mode = lambda deg, listed: int(listed.numel() > 0 and int(deg.max()) <= HEAVY_IN_LAUNCH_DEGREE)
     return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes), heavy, t_heavy,
-                    mode(deg_in, heavy), mode(deg_out, t_heavy))
+                    mode(deg_in, heavy), mode(deg_out, t_heavy), band_codes(rowptr, col, num_nodes))
+
+
+def band_codes(rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """uint8 [num_nodes] neighbour codes of a by-target CSR (CSRGraph.band): for a row whose entries are, in this order, a
+    subset of (i - 1, i, i + 1) the OR of bit 0 / 1 / 2; 0xFF for every other row (more than three entries, an entry farther
+    away, or entries out of ascending order)."""
+    n = int(num_nodes)
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    row_of = torch.repeat_interleave(torch.arange(n, device=col.device), deg)
+    off = col.long() - row_of  # -1, 0, +1 for band entries
+    near = off.abs() <= 1
+    bad = torch.zeros(n, dtype=torch.bool, device=col.device)
+    bad |= deg > 3
+    if col.numel():
+        bad.index_put_((row_of[~near],), torch.ones(int((~near).sum()), dtype=torch.bool, device=col.device), accumulate=False)
+        same_row = row_of[1:] == row_of[:-1]
+        unordered = same_row & (off[1:] <= off[:-1])  # (also catches duplicates)
+        bad.index_put_((row_of[1:][unordered],), torch.ones(int(unordered.sum()), dtype=torch.bool, device=col.device), accumulate=False)
+    bits = torch.zeros(n, dtype=torch.int64, device=col.device)
+    if col.numel():
+        ok = near
+        bits.index_add_(0, row_of[ok], (1 << (off[ok] + 1)).long())
+    code = torch.where(bad, torch.full_like(bits, 0xFF), bits.clamp(max=7))
+    return code.to(torch.uint8)
 
 
 # --------------------------------------------------------------------------------------------
@@ -272,9 +301,10 @@ def concat_csr(graphs: Sequence[CSRGraph]) -> CSRGraph:
         with_rows = [getattr(g, name) for g, l in zip(graphs, listed) if l is not None and l.numel()]
         return int(bool(with_rows) and all(m == 1 for m in with_rows))
     heavy, t_heavy = ids("heavy"), ids("t_heavy")
+    band = torch.cat([g.band for g in graphs]) if all(g.band is not None for g in graphs) else None  # (codes are relative)
     return CSRGraph(ptr("rowptr"), ids("col"), ptr("t_rowptr"), ids("t_col"), torch.cat([g.t_wgt for g in graphs]),
                     sum(g.num_nodes for g in graphs), heavy, t_heavy, mode([g.heavy for g in graphs], "heavy_mode"),
-                    mode([g.t_heavy for g in graphs], "t_heavy_mode"))
+                    mode([g.t_heavy for g in graphs], "t_heavy_mode"), band)
 
 
 class PinnedRing:

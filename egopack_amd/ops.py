@@ -1430,7 +1430,7 @@ def pe_add(x, pos, freq, pos_range=None):
 
 
 # ---- CSR mean aggregation -------------------------------------------------------------------------------
-def _csr_gather(x, rowptr, col, wgt, gate, out, heavy=None, heavy_mode=0):
+def _csr_gather(x, rowptr, col, wgt, gate, out, heavy=None, heavy_mode=0, band=None):
     """One ``egk_csr_gather`` call; ``heavy`` = ascending int32 ids of the rows with more than
     ``egk_csr_heavy_threshold()`` edges (data.build_csr lists them), or None / empty; ``heavy_mode`` 1 when none of them
     has more than data.HEAVY_IN_LAUNCH_DEGREE edges (summed inside the launch), 0 for the split launches."""
@@ -1438,17 +1438,26 @@ def _csr_gather(x, rowptr, col, wgt, gate, out, heavy=None, heavy_mode=0):
     rows, cols = x.shape
     nh = int(heavy.numel()) if heavy is not None else 0
     ws = workspace(lib.egk_csr_heavy_ws_bytes(nh, cols), x.device) if nh and not heavy_mode else None
+    if band is not None and wgt is None and gate is None and _banded["on"]:
+        # forward mean aggregation: rows whose neighbours are {i - 1, i, i + 1} need no index fetch (data.band_codes)
+        _ck(lib.egk_csr_gather_banded(_stream(), _p(x), _p(rowptr), _p(col), _p(band), _p(out), rows, cols, _dt(x),
+                                      _p(heavy) if nh else None, nh, _p(ws) if ws is not None else None, int(heavy_mode)),
+            "egk_csr_gather_banded")
+        return
     _ck(lib.egk_csr_gather(_stream(), _p(x), _p(rowptr), _p(col), _p(wgt), _p(gate), _p(out), rows, cols, _dt(x),
                            _p(heavy) if nh else None, nh, _p(ws) if ws is not None else None, int(heavy_mode)), "egk_csr_gather")
 
 
+_banded = {"on": "banded_gather" not in os.environ.get("EGK_DISABLE", "")}  # development knob
+
+
 class _CSRMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rowptr, col, t_rowptr, t_col, t_wgt, heavy, t_heavy, heavy_mode=0, t_heavy_mode=0):
+    def forward(ctx, x, rowptr, col, t_rowptr, t_col, t_wgt, heavy, t_heavy, heavy_mode=0, t_heavy_mode=0, band=None):
         _need_gpu(x, rowptr, col)
         x = _c(x)
         out = torch.empty_like(x)
-        _csr_gather(x, rowptr, col, None, None, out, heavy, heavy_mode)
+        _csr_gather(x, rowptr, col, None, None, out, heavy, heavy_mode, band)
         ctx.save_for_backward(t_rowptr, t_col, t_wgt, t_heavy)
         ctx.t_heavy_mode = t_heavy_mode
         return out
@@ -1459,14 +1468,14 @@ class _CSRMean(torch.autograd.Function):
         dout = _c(dout)
         dx = torch.empty_like(dout)
         _csr_gather(dout, t_rowptr, t_col, t_wgt, None, dx, t_heavy, ctx.t_heavy_mode)
-        return dx, None, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None, None
 
 
 def csr_mean_aggregate(x, graph):
     """agg[i] = mean_{j->i} x[j] (0 without in-edges); ``graph`` = egopack_amd.data.CSRGraph."""
     return _CSRMean.apply(x, graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
                           getattr(graph, "heavy", None), getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0),
-                          getattr(graph, "t_heavy_mode", 0))
+                          getattr(graph, "t_heavy_mode", 0), getattr(graph, "band", None))
 
 
 class _SageMean(torch.autograd.Function):
@@ -1477,7 +1486,7 @@ class _SageMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute, heavy=None, t_heavy=None,
-                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None, res_src=None):
+                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None, res_src=None, band=None):
         _need_gpu(h, Wp, Wl, Wr)
         lib = _lib.load()
         h = _c(h)
@@ -1487,7 +1496,7 @@ class _SageMean(torch.autograd.Function):
         xp = torch.empty_like(h)
         gemm(N, H, h, H, Wp_o, H, H, xp, H, bias=_f32c(bp), act=1, compute=compute)
         agg = torch.empty_like(h)
-        _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode)
+        _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode, band)
         ctx.t_heavy_mode = t_heavy_mode
         Ho = Wl.shape[0]
         out = torch.empty((N, Ho), dtype=dt, device=h.device)
@@ -1562,7 +1571,7 @@ class _SageMean(torch.autograd.Function):
             # the FIRST layer of the stack (its backward is the stack's last): what is parked goes out now, beside the temporal
             # pooling's backward chain -- the step's tail launch then holds the temporal pooling's weight gradients only
             flush_wgrad()
-        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None)
+        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_src=None):
@@ -1576,7 +1585,7 @@ def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_s
                            graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
                            _compute_for(h) if compute is None else compute, getattr(graph, "heavy", None),
                            getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0), getattr(graph, "t_heavy_mode", 0),
-                           ln_out, ln_in, res_src)
+                           ln_out, ln_in, res_src, getattr(graph, "band", None))
 
 
 # ---- GraphONE gather-max ------------------------------------------------------------------------------

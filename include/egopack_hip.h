@@ -264,6 +264,14 @@ int egk_pe_add_table(egk_stream_t s, const void* x, const int64_t* pos, const fl
 int egk_csr_gather(egk_stream_t s, const void* x, const int32_t* rowptr, const int32_t* col, const float* wgt,
                    const void* relu_gate, void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows,
                    int32_t n_heavy, float* ws, int32_t heavy_mode);
+/* The forward (unweighted mean) orientation with the BANDED fast path: band[i] names row i's in-neighbours when they are a
+ * subset of {i - 1, i, i + 1} -- bit 0: i - 1, bit 1: i, bit 2: i + 1, CSR entries of the row in ascending order -- and is
+ * 0xFF for any other row (the LTA forecast nodes), which goes through rowptr / col as in egk_csr_gather.  A radius-1
+ * temporal graph (RadiusGraph(r = 1.5) per sequence, reference main_temporal.py:168) is banded everywhere: its rows need no
+ * index fetch at all.  Same sums in the same order as egk_csr_gather on the same CSR: bit-identical. */
+int egk_csr_gather_banded(egk_stream_t s, const void* x, const int32_t* rowptr, const int32_t* col, const uint8_t* band,
+                          void* out, int32_t rows, int32_t cols, int32_t dtype, const int32_t* heavy_rows, int32_t n_heavy,
+                          float* ws, int32_t heavy_mode);
 int64_t egk_csr_heavy_ws_bytes(int32_t n_heavy, int32_t cols);
 int32_t egk_csr_heavy_threshold(void);
 

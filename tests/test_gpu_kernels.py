@@ -313,6 +313,38 @@ def test_graphln_full_size_properties(ops):
 # ---------------------------------------------------------------------------------------------------------
 # graph ops
 # ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cols,dt", [(1024, torch.bfloat16), (250, torch.float32), (64, torch.float32), (2048, torch.bfloat16)])
+def test_banded_gather_is_the_csr_gather_bit_for_bit(ops, cols, dt):
+    """egk_csr_gather_banded (rows coded {i - 1, i, i + 1}: no index fetch) against egk_csr_gather on the same CSR: band
+    sequences, LTA sequences (forecast nodes = general rows), isolated rows, self loops; the same sums in the same order."""
+    from egopack_amd import data as D
+    g = gen(cols)
+    parts, n = [], 0
+    for s_, T in enumerate((9, 32, 5, 1, 12)):
+        parts.append(D.radius_band_edges(torch.arange(T), 1) + n)
+        n += T
+    y = torch.stack([torch.randint(1, 5, (14,), generator=g), torch.randint(0, 5, (14,), generator=g)], 1)
+    y[:3] = -1
+    parts.append(D.lta_connectivity_edges(torch.arange(14), y, 1.5) + n)
+    n += 14 + 3  # + isolated rows
+    parts.append(torch.tensor([[2, 40, 20], [2, 40, 20]]))  # three self loops
+    ei = torch.cat(parts, 1)
+    keep = torch.ones(ei.shape[1], dtype=torch.bool)
+    keep[-1] = False
+    order = torch.argsort(ei[1, keep] * n + ei[0, keep])  # rows in ascending-source order (a row of 3 adjacent entries: code 7) ...
+    ei = torch.cat([ei[:, keep][:, order], ei[:, ~keep]], 1)  # ... but one self loop behind its row's other entries: a general row
+    graph = D.build_csr(ei, n).to(DEV)
+    assert int(graph.band[20]) == 0xFF
+    assert (graph.band == 0xFF).any() and (graph.band == 5).any() and (graph.band == 0).any() and (graph.band == 7).any()
+    x = torch.randn(n, cols, generator=g).to(DEV).to(dt)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    ops._csr_gather(x, graph.rowptr, graph.col, None, None, a, graph.heavy, graph.heavy_mode)
+    ops._csr_gather(x, graph.rowptr, graph.col, None, None, b, graph.heavy, graph.heavy_mode, band=graph.band)
+    assert torch.equal(a, b)
+    ref = P.scatter_mean(x.float().cpu()[ei[0]], ei[1], n)
+    torch.testing.assert_close(b.float().cpu(), ref, **(OUT16 if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-6)))
+
+
 def test_pe_add(ops):
     g = gen(9)
     x = torch.randn(50, 64, generator=g)

@@ -223,11 +223,32 @@ def test_merged_csr_is_the_concatenation_of_the_task_csrs():
         batches.append(D.collate([ds[i] for i in range(4)]))
     m = D.merge_batches(batches)
     ref = D.build_csr(m.edge_index, m.pos.shape[0])
-    for f in ("rowptr", "col", "t_rowptr", "t_col", "t_wgt", "heavy", "t_heavy"):
+    for f in ("rowptr", "col", "t_rowptr", "t_col", "t_wgt", "heavy", "t_heavy", "band"):
         a, b = getattr(m.graph, f), getattr(ref, f)
         assert a.dtype == b.dtype and torch.equal(a, b), f
     assert (m.graph.num_nodes, m.graph.heavy_mode, m.graph.t_heavy_mode) == (ref.num_nodes, ref.heavy_mode, ref.t_heavy_mode)
     assert m.graph.t_heavy.numel() > 0  # the T = 40 LTA fan-out rows are listed
+
+
+def test_band_codes_name_exactly_the_rows_whose_neighbours_are_adjacent():
+    """CSRGraph.band (egk_csr_gather_banded): bit 0 / 1 / 2 = neighbour i - 1 / i / i + 1 for rows whose CSR entries are an
+    ascending subset of those, 0xFF for every other row; checked entry by entry against the CSR itself."""
+    ds = D.SyntheticTaskDataset("lta", 3, 12, 3, 8, (7, 11), k=1, seed=5)
+    b = D.collate([ds[i] for i in range(3)])
+    loops = torch.arange(b.pos.shape[0]).repeat(2, 1)[:, ::5]  # a few self loops as well
+    far = torch.tensor([[0, 7], [9, 2]])
+    for ei in (b.edge_index, torch.cat([b.edge_index, loops], 1), torch.cat([b.edge_index, far], 1), torch.tensor([[1, 0, 2], [1, 1, 1]])):
+        n = int(ei.max()) + 1
+        g = D.build_csr(ei, n)
+        for i in range(n):
+            cols = g.col[g.rowptr[i]:g.rowptr[i + 1]].tolist()
+            offs = [c - i for c in cols]
+            banded = all(abs(o) <= 1 for o in offs) and offs == sorted(set(offs))
+            code = int(g.band[i])
+            assert (code != 0xFF) == banded, (i, cols, code)
+            if banded:
+                assert code == sum(1 << (o + 1) for o in offs), (i, cols, code)
+    assert (D.build_csr(b.edge_index, b.pos.shape[0]).band == 0xFF).any()  # the LTA forecast nodes are general rows
 
 
 def test_signature_is_stable_across_lta_batches_with_different_edge_counts():
