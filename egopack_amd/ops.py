@@ -725,8 +725,7 @@ class _Linear(torch.autograd.Function):
             last = Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None
             tail_items, tail_extra = [], []
             if last:
-                tail_items, tail_extra = _take_tail_items()  # (kept for the launch below; their operands stay alive in _wq["hold"])
-                hold = list(_wq["hold"]) if (tail_items or tail_extra) else []
+                tail_items, tail_extra = _take_tail_items()  # (issued below; the argument tuples keep their operands alive)
                 flush_wgrad(force=True)  # (the hook starts the optimizer on every other slot: their gradients must be issued)
                 _last_wgrad["hook"]()
             # the bias gradient colsum(dY) rides on the dW launch (summed from the dY^T tile already in LDS).  The LAST
@@ -744,7 +743,6 @@ class _Linear(torch.autograd.Function):
                     gemm(*dw_args, **dw_kw)
                 if tail_extra:
                     _launch_reductions(tail_extra)
-                del hold
             elif not (in_place and not last and ctx.compute == BF16 and _wgrad_defer(dw_args, dw_kw, (g, x))):
                 for it in tail_items:  # (not eligible after all: issue what was taken, in order)
                     gemm(*it[0], **it[1])
