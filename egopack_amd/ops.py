@@ -470,7 +470,7 @@ def _on_excluded_stream() -> bool:
     return (cur.device.index, cur.cuda_stream) in _wgrad["exclude"]
 
 
-def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False) -> bool:
+def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False, park_only: bool = False) -> bool:
     """Park the dW contraction ``gemm(*args, **kw)`` (transA, transB, accumulate into a gradient slot) for the next grouped
     launch.  False: not eligible (the caller launches it itself).  On an excluded stream (the task-head streams of the
     engine) nothing is parked unless ``park_on_excluded``: such a problem is only PARKED there -- it is issued by a later
@@ -483,7 +483,7 @@ def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False) -> bool:
     _wq["items"].append((args, kw))
     _wq["hold"].extend(t for t in tensors if t is not None)
     _wq["tiles"] += ((M + 127) // 128) * ((N + 127) // 128)
-    if excluded:
+    if excluded or park_only:  # (park_only: a later weight-gradient launch of the same step takes it along, see _take_parked)
         return True
     if len(_wq["items"]) >= WGRAD_GROUP_COUNT or _wq["tiles"] >= WGRAD_GROUP_TILES:
         flush_wgrad()
@@ -491,6 +491,16 @@ def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False) -> bool:
         _wgrad["queued"] = True
         torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
     return True
+
+
+def _take_parked(max_items: int):
+    """Remove and return up to ``max_items`` parked weight-gradient problems (all of them or none: a partial take would
+    reorder accumulations into one slot) for a caller that is about to issue a grouped launch of the same layout."""
+    items = _wq["items"]
+    if not items or len(items) > max_items:
+        return []
+    _wq["items"], _wq["tiles"] = [], 0
+    return items
 
 
 def _wgrad_defer_reduce(ws, dw, db, rows, cols, n_seg):
@@ -863,6 +873,9 @@ def classifier_bank(x, anchor, views, compute=None):
     return outs
 
 
+_banks_ride = {"on": "banks_ride" not in os.environ.get("EGK_DISABLE", "")}  # development knob
+
+
 class _GroupedBanks(torch.autograd.Function):
     """The classifier banks of several task heads (same feature width, own rows, own weights) as ONE grouped contraction
     forward and ONE grouped dX contraction backward -- the multi-head classifiers of the AR and LTA tasks
@@ -906,7 +919,9 @@ class _GroupedBanks(torch.autograd.Function):
         elif probs:
             gemm(*probs[0][0], **probs[0][1])
         for w_args, w_kw, hold in parked:
-            if not _wgrad_defer(w_args, w_kw, hold, park_on_excluded=True):
+            # parked WITHOUT a join of their own: the projection heads' backward, which follows in the same step, takes them
+            # along in its first grouped weight-gradient launch (one launch and one end-of-backward join fewer in the chain)
+            if not _wgrad_defer(w_args, w_kw, hold, park_on_excluded=True, park_only=_banks_ride["on"]):
                 _wgrad_launch(True, hold, lambda a=w_args, kw=w_kw: gemm(*a, **kw))
         return (None, None, None, None, *dxs)
 
@@ -1079,9 +1094,10 @@ class _GroupedProjection(torch.autograd.Function):
         da = torch.empty_like(a)
         gemm_grouped([((rows[g], H1, dfs[g], dfs[g].stride(0), W2o[g], H1, H2, da[ptr[g]:ptr[g + 1]], H1),
                        dict(transB=True, compute=cmp)) for g in range(G)])
-        _wgrad_launch(True, (a, *dfs), lambda: gemm_grouped(
-            [((H2, H1, dfs[g], dfs[g].stride(0), a[ptr[g]:ptr[g + 1]], H1, rows[g], slots[g][4], H1),
-              dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][5])) for g in range(G)]))
+        riders = _take_parked(8 - G) if _banks_ride["on"] else []  # (the classifier banks' weight gradients, parked by their backward)
+        _wgrad_launch(True, (a, *dfs), lambda: gemm_grouped(riders + [
+            ((H2, H1, dfs[g], dfs[g].stride(0), a[ptr[g]:ptr[g + 1]], H1, rows[g], slots[g][4], H1),
+             dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][5])) for g in range(G)]))
         dh1 = torch.empty_like(h1)
         grid = lib.egk_rowln_bwd_ws_rows(max(rows))
         ws = torch.empty(G * grid * 2 * H1 * 4, dtype=torch.uint8, device=dev)  # (own buffer: reduced on the side stream)
