@@ -1094,10 +1094,17 @@ class _GroupedProjection(torch.autograd.Function):
         da = torch.empty_like(a)
         gemm_grouped([((rows[g], H1, dfs[g], dfs[g].stride(0), W2o[g], H1, H2, da[ptr[g]:ptr[g + 1]], H1),
                        dict(transB=True, compute=cmp)) for g in range(G)])
-        riders = _take_parked(8 - G) if _banks_ride["on"] else []  # (the classifier banks' weight gradients, parked by their backward)
-        _wgrad_launch(True, (a, *dfs), lambda: gemm_grouped(riders + [
-            ((H2, H1, dfs[g], dfs[g].stride(0), a[ptr[g]:ptr[g + 1]], H1, rows[g], slots[g][4], H1),
-             dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][5])) for g in range(G)]))
+        proj_park = "proj_park" not in os.environ.get("EGK_DISABLE", "")
+        dw2 = [((H2, H1, dfs[g], dfs[g].stride(0), a[ptr[g]:ptr[g + 1]], H1, rows[g], slots[g][4], H1),
+                dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][5])) for g in range(G)]
+        proj_park = proj_park and all(_wgrad_groupable(*pa[:7]) for pa, _ in dw2)  # (the parking queue must be on and take them)
+        if proj_park:
+            for g, (pa, pk) in enumerate(dw2):
+                if not _wgrad_defer(pa, pk, (dfs[g], a), park_on_excluded=True, park_only=True):
+                    raise RuntimeError("grouped_projection: a weight gradient announced as parkable was refused")
+        else:
+            riders = _take_parked(8 - G) if _banks_ride["on"] else []  # (the classifier banks' weight gradients, parked by their backward)
+            _wgrad_launch(True, (a, *dfs), lambda: gemm_grouped(riders + dw2))
         dh1 = torch.empty_like(h1)
         grid = lib.egk_rowln_bwd_ws_rows(max(rows))
         ws = torch.empty(G * grid * 2 * H1 * 4, dtype=torch.uint8, device=dev)  # (own buffer: reduced on the side stream)
@@ -1106,16 +1113,25 @@ class _GroupedProjection(torch.autograd.Function):
                                     _p(dh1), _p(ws), H1, 1, _dt(h1)), "egk_rowln_group_bwd")
 
         reds = [(ws[g * grid * 2 * H1 * 4:], slots[g][2], slots[g][3], max(rows), H1, 0) for g in range(G)]
-        _wgrad_launch(True, (ws,), lambda: _launch_reductions(reds))
+        if proj_park:
+            for r in reds:
+                _wgrad_defer_reduce(*r)
+        else:
+            _wgrad_launch(True, (ws,), lambda: _launch_reductions(reds))
         dxs = [None] * G
         if any(ctx.needs_input_grad[3:3 + G]):
             dx = torch.empty((ptr[-1], H), dtype=dt, device=dev)
             gemm_grouped([((rows[g], H, dh1[ptr[g]:ptr[g + 1]], H1, W1o[g], H, H1, dx[ptr[g]:ptr[g + 1]], H),
                            dict(transB=True, compute=cmp)) for g in range(G)])
             dxs = [dx[ptr[g]:ptr[g + 1]] for g in range(G)]
-        _wgrad_launch(True, (dh1, *xs), lambda: gemm_grouped(
-            [((H1, H, dh1[ptr[g]:ptr[g + 1]], H1, xs[g], H, rows[g], slots[g][0], H),
-              dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][1])) for g in range(G)]))
+        dw1 = [((H1, H, dh1[ptr[g]:ptr[g + 1]], H1, xs[g], H, rows[g], slots[g][0], H),
+                dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][1])) for g in range(G)]
+        if proj_park and all(_wgrad_groupable(*pa[:7]) for pa, _ in dw1):
+            for g, (pa, pk) in enumerate(dw1):
+                if not _wgrad_defer(pa, pk, (dh1, xs[g]), park_on_excluded=True, park_only=True):
+                    raise RuntimeError("grouped_projection: a weight gradient announced as parkable was refused")
+        else:
+            _wgrad_launch(True, (dh1, *xs), lambda: gemm_grouped(dw1))
         return (None, None, None, *dxs, *([None] * (6 * G)))
 
 
