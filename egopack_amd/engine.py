@@ -917,6 +917,11 @@ class MTLStep(StepBase):
         self._join_zero()
         total, vectors, leaves = self._heads_forward_backward(feats)
         ops.stamp("heads_done")
+        if "heads_flush" not in getattr(self, "_dev_off", ()):
+            # the heads' parked weight gradients (classifier banks, projections) go out as one launch NOW, beside the first
+            # links of the backbone's dX chain; left parked, the backbone's first weight gradient would flush nine problems
+            # as 8 + 1
+            ops.flush_wgrad(in_backward=False, force=True)
         order = [t for t in feats if leaves[t].grad is not None]
         torch.autograd.backward([feats[t] for t in order], [leaves[t].grad for t in order])
         return total, vectors
