@@ -454,8 +454,12 @@ WGRAD_GROUP_TILES = 64 * WGRAD_GROUP_COUNT
 
 
 def set_wgrad_grouping(on: bool) -> bool:
+    """Switch the parking queue (engine: at the start and the end of every step); returns the previous setting.  Whatever is
+    still parked is dropped: a step ends with ``join_wgrad`` (which issues it), so something is left only when the step was
+    abandoned by an exception -- its weight gradients must not be accumulated by the next step."""
     prev = _wq["on"]
     _wq["on"] = bool(on)
+    _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
     return prev
 
 
