@@ -999,7 +999,11 @@ class EgoPackStep(StepBase):
         with torch.no_grad():
             # f32 out of the projections' last contraction: the nearest-prototype search (an index op) ranks the f32
             # accumulators in every compute mode; GraphONE brings them to the activation type for its stages
-            aux_in = {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others}
+            grouped = None
+            if "grouped_aux" not in getattr(self, "_dev_off", ()):
+                grouped = ops.grouped_projection_infer(ops.to_act(feat), [self.tasks[t].net for t in others], out_f32=True)
+            aux_in = (dict(zip(others, grouped)) if grouped is not None
+                      else {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others})
         aux, closest = self.graphone.interact(aux_in)
         if primary == "oscc":
             logits = task.forward_logits(features=f_primary, batch=data, aux_features=aux)

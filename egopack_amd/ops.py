@@ -261,6 +261,20 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     sh = getattr(W, "_egk_shadow", None)
     if sh is not None and sh.shape == W.shape:
         return sh
+    if not W.requires_grad:
+        # a FROZEN weight (the auxiliary tasks' heads of the EgoPack step are not in the optimizer): its bf16 copy is made once
+        # and kept while the parameter is not written (tensor version counter) -- it used to be converted at every use, six
+        # launches per EgoPack step
+        c = getattr(W, "_egk_frozen_copy", None)
+        if c is not None and c[0] == W._version and c[1] == W.data_ptr() and c[2].shape == W.shape:
+            return c[2]
+        if not torch.cuda.is_current_stream_capturing():
+            copy = cast_raw(W.detach(), torch.bfloat16)
+            try:
+                W._egk_frozen_copy = (W._version, W.data_ptr(), copy)
+            except Exception:  # noqa: BLE001  (a tensor type that takes no attributes)
+                pass
+            return copy
     return cast_raw(W.detach(), torch.bfloat16)
 
 
@@ -1138,6 +1152,47 @@ class _GroupedProjection(torch.autograd.Function):
         else:
             _wgrad_launch(True, (dh1, *xs), lambda: gemm_grouped(dw1))
         return (None, None, None, *dxs, *([None] * (6 * G)))
+
+
+@torch.no_grad()
+def grouped_projection_infer(x, nets, out_f32: bool = False):
+    """f_g = net_g(x) for several projection heads over the SAME input rows, without autograd: three grouped launches
+    (contraction, row LayerNorm + ReLU, contraction) instead of three per head -- the DETACHED auxiliary-task projections of
+    the EgoPack step (reference main_egopack.py:121-147: ``tasks[t].forward_features(feat)`` under no_grad for every
+    auxiliary task).  ``out_f32``: the last contraction keeps its f32 accumulators (the prototype search ranks those).
+    None when the heads do not qualify (bf16 activations, equal widths in multiples of 64, 2 .. 8 heads, no active dropout)."""
+    G = len(nets)
+    if not (2 <= G <= 8) or x.dim() != 2 or not x.is_cuda or x.dtype != torch.bfloat16 or x.shape[0] == 0:
+        return None
+    dims = None
+    for net in nets:
+        if len(net) != 5 or (net[0].p > 0 and net[0].training):
+            return None
+        l1, l2 = net[1], net[4]
+        d = (l1.in_features, l1.out_features, l2.out_features)
+        dims = dims or d
+        if d != dims or l2.in_features != d[1] or x.shape[1] != d[0] or any(v % 64 for v in d) or d[1] > 4096:
+            return None
+        if l1.bias is None or l2.bias is None:
+            return None
+    lib = _lib.load()
+    x = _c(x)
+    M, (H, H1, H2) = x.shape[0], dims
+    cmp = _compute_for(x)
+    h1 = torch.empty((G * M, H1), dtype=x.dtype, device=x.device)
+    a = torch.empty_like(h1)
+    f = torch.empty((G * M, H2), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    mean = torch.empty(G * M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    gemm_grouped([((M, H1, x, H, weight_operand(net[1].weight, x.dtype), H, H, h1[g * M:(g + 1) * M], H1),
+                   dict(bias=_f32c(net[1].bias), compute=cmp)) for g, net in enumerate(nets)])
+    lw, lb = [_f32c(net[2].weight) for net in nets], [_f32c(net[2].bias) for net in nets]
+    row_ptr = (C.c_int32 * (G + 1))(*[g * M for g in range(G + 1)])
+    _ck(lib.egk_rowln_group_fwd(_stream(), _p(h1), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(a), _p(mean), _p(rstd), H1,
+                                float(nets[0][2].eps), 1, _dt(h1)), "egk_rowln_group_fwd")
+    gemm_grouped([((M, H2, a[g * M:(g + 1) * M], H1, weight_operand(net[4].weight, x.dtype), H1, H1, f[g * M:(g + 1) * M], H2),
+                   dict(bias=_f32c(net[4].bias), compute=cmp)) for g, net in enumerate(nets)])
+    return [f[g * M:(g + 1) * M] for g in range(G)]
 
 
 def grouped_projection_ok(xs, nets) -> bool:
