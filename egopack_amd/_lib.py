@@ -40,6 +40,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class CETask(C.Structure):
+    """struct egk_ce_task (include/egopack_hip.h)."""
+    _fields_ = [("logits", vp * 4), ("ld", i64 * 4), ("C", i32 * 4), ("pad", i32 * 4), ("dcol", i64 * 4), ("n_heads", i32),
+                ("y", vp), ("y_stride", i64), ("loss", vp), ("dlogits", vp), ("ldd", i64), ("rows", i32), ("gscale", f32)]
+
+
 # name -> (restype, argtypes); mirrors include/egopack_hip.h one to one
 SIGNATURES = {
     "egk_version": (C.c_int, []),
@@ -99,6 +105,7 @@ SIGNATURES = {
     "egk_onehot_sigmoid_loss_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, i32]),
     "egk_ce_fwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, i32, i32, f32, i32]),
     "egk_ce_bwd": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, f32, i32]),
+    "egk_ce_fused_multi": (C.c_int, [vp, vp, i32, f32, i32]),
     "egk_ce_fused": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i64, vp, vp, i64, i32, f32, f32, i32]),
     "egk_bce_fwd": (C.c_int, [vp, vp, vp, vp, i32]),
     "egk_bce_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),

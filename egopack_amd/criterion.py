@@ -42,7 +42,9 @@ class MetricSelectorWrapper(torch.nn.Module):
             joint_label_training = False
         self.criterion, self.dataset, self.joint_label = criterion, dataset, joint_label_training
 
-    def forward(self, logits: Tuple[torch.Tensor, ...], ground_truths: torch.Tensor) -> torch.Tensor:
+    def select(self, logits: Tuple[torch.Tensor, ...], ground_truths: torch.Tensor):
+        """(logits of the heads that count, their label columns, label smoothing): what ``forward`` hands to the cross
+        entropy (the engine batches the cross entropies of several tasks into one launch from these)."""
         if len(logits) != ground_truths.shape[1]:
             raise ValueError("The number of predictions must match the number of ground truth labels")
         if self.dataset.has_joint_label:
@@ -51,7 +53,9 @@ class MetricSelectorWrapper(torch.nn.Module):
             heads = list(range(self.dataset.num_labels))
         smoothing = getattr(self.criterion, "label_smoothing", 0.0)
         if heads == list(range(ground_truths.shape[1])):
-            # all heads: one fused per-row sum over heads (the common case on the path)
-            return ops.cross_entropy(tuple(logits), ground_truths, smoothing)
-        sel = ground_truths[:, heads].contiguous()
-        return ops.cross_entropy(tuple(logits[h] for h in heads), sel, smoothing)
+            return tuple(logits), ground_truths, smoothing  # all heads: the common case on the path
+        return tuple(logits[h] for h in heads), ground_truths[:, heads].contiguous(), smoothing
+
+    def forward(self, logits: Tuple[torch.Tensor, ...], ground_truths: torch.Tensor) -> torch.Tensor:
+        sel, gt, smoothing = self.select(logits, ground_truths)
+        return ops.cross_entropy(sel, gt, smoothing)  # one fused per-row sum over the heads

@@ -115,6 +115,62 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CEHeads H, int n_he
     }
 }
 
+// the same for several TASKS in one launch (blockIdx.y = task): the AR and LTA heads of a multi-task step
+constexpr int CE_MAX_TASKS = 4;
+struct CETasks {
+    CEHeads H[CE_MAX_TASKS];
+    int n_heads[CE_MAX_TASKS];
+    const long long* y[CE_MAX_TASKS];
+    long long ys[CE_MAX_TASKS];
+    float* loss[CE_MAX_TASKS];
+    void* dlogits[CE_MAX_TASKS];
+    long long ldd[CE_MAX_TASKS];
+    int rows[CE_MAX_TASKS];
+    float gscale[CE_MAX_TASKS];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fused_multi_kernel(const CETasks P, float smoothing) {
+    const int k = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const CEHeads& H = P.H[k];
+    const int n_heads = P.n_heads[k], rows = P.rows[k];
+    const long long* __restrict__ y = P.y[k];
+    const long long ys = P.ys[k], ldd = P.ldd[k];
+    float* __restrict__ loss = P.loss[k];
+    T* __restrict__ dlogits = (T*)P.dlogits[k];
+    const float gscale = P.gscale[k];
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        float total = 0.f;
+        for (int h = 0; h < n_heads; ++h) {  // (the arithmetic of ce_fused_kernel, statement for statement)
+            const float* lr = H.logits[h] + (long long)row * H.ld[h];
+            const int C = H.C[h];
+            T* dr = dlogits + (long long)row * ldd + H.dcol[h];
+            const long long t = y[(long long)row * ys + h];
+            const bool live = t >= 0 && t < C;
+            float mx = -INFINITY;
+            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+            mx = wave_max(mx);
+            float se = 0.f, sx = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float v = lr[c];
+                se += expf(v - mx);
+                sx += v;
+            }
+            se = wave_sum(se);
+            sx = wave_sum(sx);
+            const float l = mx + logf(se);
+            if (live) total += l - (1.f - smoothing) * lr[t] - (smoothing > 0.f ? smoothing / C * sx : 0.f);
+            const float sm = smoothing > 0.f ? smoothing / C : 0.f;
+            for (int c = lane; c < H.pad[h]; c += 64) {
+                float d = 0.f;
+                if (live && c < C) d = gscale * (expf(lr[c] - l) - (c == t ? 1.f - smoothing : 0.f) - sm);
+                st1t(dr + c, d);
+            }
+        }
+        if (lane == 0) loss[row] = total;
+    }
+}
+
 // ---- BCE with logits ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const long long* __restrict__ y,
                                                       float* __restrict__ loss, int n) {
@@ -420,6 +476,33 @@ int egk_ce_fused(egk_stream_t stream, const float* const* logits, const int64_t*
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(ce_fused_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, H, n_heads, (const long long*)y,
                                              (long long)y_stride, loss, (T*)dlogits, (long long)ldd, rows, smoothing, gscale));
     return check_launch("egk_ce_fused");
+}
+
+int egk_ce_fused_multi(egk_stream_t stream, const egk_ce_task* tasks, int32_t count, float smoothing, int32_t dtype) {
+    EGK_REQUIRE(tasks && count >= 1 && count <= CE_MAX_TASKS, "egk_ce_fused_multi: 1 .. %d tasks", CE_MAX_TASKS);
+    CETasks P;
+    double bytes = 0;
+    int max_rows = 0;
+    for (int i = 0; i < CE_MAX_TASKS; ++i) {
+        const egk_ce_task& t = tasks[i < count ? i : count - 1];
+        EGK_REQUIRE(t.y && t.loss && t.dlogits && t.n_heads >= 1 && t.n_heads <= CE_MAX_HEADS && t.rows >= 0,
+                    "egk_ce_fused_multi: bad task %d", i);
+        for (int h = 0; h < CE_MAX_HEADS; ++h) {
+            const int k = h < t.n_heads ? h : t.n_heads - 1;
+            EGK_REQUIRE(t.logits[k] && t.C[k] >= 1 && t.pad[k] >= t.C[k], "egk_ce_fused_multi: bad head %d of task %d", k, i);
+            P.H[i].logits[h] = t.logits[k]; P.H[i].ld[h] = t.ld[k]; P.H[i].C[h] = t.C[k]; P.H[i].pad[h] = t.pad[k];
+            P.H[i].dcol[h] = t.dcol[k];
+            if (i < count && h < t.n_heads) bytes += 6.0 * t.rows * t.C[k];
+        }
+        P.n_heads[i] = t.n_heads; P.y[i] = (const long long*)t.y; P.ys[i] = t.y_stride; P.loss[i] = t.loss;
+        P.dlogits[i] = t.dlogits; P.ldd[i] = t.ldd; P.rows[i] = i < count ? t.rows : 0; P.gscale[i] = t.gscale;
+        if (i < count && t.rows > max_rows) max_rows = t.rows;
+    }
+    if (max_rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CE_FWD, s, 0, bytes);
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(ce_fused_multi_kernel<T>, dim3(row_grid(max_rows), count), dim3(256), 0, s, P, smoothing));
+    return check_launch("egk_ce_fused_multi");
 }
 
 int egk_bce_fwd(egk_stream_t stream, const float* logits, const int64_t* y, float* loss, int32_t n) {

@@ -872,9 +872,19 @@ class MTLStep(StepBase):
             all_logits = ops.grouped_classifier_banks([proj_leaves[t] for t in banked], views,
                                                       fused_loss=getattr(self, "_fused_loss", True))
             vs, gs = [], []
-            for t, logits in zip(banked, all_logits):
-                with ops.loss_seed(self.weights[t] / n_loss[t] if getattr(self, "_fused_loss", True) else None):
-                    v = self.criteria[t](logits, batches[t].y)
+            multi = None
+            if getattr(self, "_fused_loss", True) and "ce_multi" not in getattr(self, "_dev_off", ()):
+                # the cross entropies of the banked tasks as ONE launch (each writes its own loss vector and gradient operand)
+                sel = [self.criteria[t].select(logits, batches[t].y) for t, logits in zip(banked, all_logits)]
+                if len({s_[2] for s_ in sel}) == 1:
+                    multi = ops.cross_entropy_multi([(s_[0], s_[1]) for s_ in sel], [self.weights[t] / n_loss[t] for t in banked],
+                                                    sel[0][2])
+            for i, (t, logits) in enumerate(zip(banked, all_logits)):
+                if multi is not None:
+                    v = multi[i]
+                else:
+                    with ops.loss_seed(self.weights[t] / n_loss[t] if getattr(self, "_fused_loss", True) else None):
+                        v = self.criteria[t](logits, batches[t].y)
                 if v.numel() != n_loss[t]:
                     raise RuntimeError(f"head {t}: {v.numel()} loss elements where {n_loss[t]} were announced to the fused loss")
                 key = (t, v.numel(), v.dtype, v.device)

@@ -1876,6 +1876,89 @@ class _CE(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+def _ce_fused_plan(y, logits):
+    """What the fused cross entropy needs of one task -- (gradient operand, its state, column starts, block widths) -- or None
+    when it does not apply (see ``_CE._fused``)."""
+    if _loss_seed["coef"] is None and not _bank_handoff["on"]:
+        return None
+    if not _bank_handoff["on"] or y.dim() != 2 or y.shape[1] != len(logits) or len(logits) > 4:
+        return None
+    dsts = [getattr(l, "_egk_grad_dst", None) for l in logits]
+    if any(d is None for d in dsts) or any(d[0] is not dsts[0][0] or d[2] is not dsts[0][2] for d in dsts):
+        return None
+    gbuf, state = dsts[0][0], dsts[0][2]
+    if any(d[1] in state["filled"] for d in dsts) or any(l.dtype != torch.float32 or l.stride(1) != 1 for l in logits):
+        return None
+    starts = sorted(d[1] for d in dsts)
+    if [d[1] for d in dsts] != starts or starts[0] != 0:
+        return None
+    ends = starts[1:] + [gbuf.shape[1]]
+    return gbuf, state, starts, [e - s0 for s0, e in zip(starts, ends)]
+
+
+class _CEMulti(torch.autograd.Function):
+    """The fused cross entropies of several tasks (each: loss + gradient written into its bank's operand buffer, ``_CE._fused``)
+    as ONE launch, ``egk_ce_fused_multi``."""
+
+    @staticmethod
+    def forward(ctx, smoothing, coefs, heads_per_task, plans, *tensors):
+        lib = _lib.load()
+        n = len(coefs)
+        arr = (_lib.CETask * n)()
+        losses, shapes, k = [], [], 0
+        for i in range(n):
+            y = tensors[k]
+            logits = tensors[k + 1:k + 1 + heads_per_task[i]]
+            k += 1 + heads_per_task[i]
+            gbuf, state, starts, pads = plans[i]
+            rows = logits[0].shape[0]
+            loss = torch.empty(rows, dtype=torch.float32, device=gbuf.device)
+            t = arr[i]
+            for h, l in enumerate(logits):
+                t.logits[h], t.ld[h], t.C[h], t.pad[h], t.dcol[h] = l.data_ptr(), l.stride(0), l.shape[1], pads[h], starts[h]
+            t.n_heads, t.y, t.y_stride, t.loss = len(logits), y.data_ptr(), y.shape[1], loss.data_ptr()
+            t.dlogits, t.ldd, t.rows, t.gscale = gbuf.data_ptr(), gbuf.stride(0), rows, float(coefs[i])
+            losses.append(loss)
+            shapes.append([tuple(l.shape) for l in logits])
+            state["filled"].update(starts)
+            state["pads"] = True
+        _ck(lib.egk_ce_fused_multi(_stream(), arr, n, float(smoothing), _dt(plans[0][0])), "egk_ce_fused_multi")
+        ctx.shapes, ctx.heads = shapes, heads_per_task
+        ctx.set_materialize_grads(False)
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *glosses):
+        out = [None, None, None, None]
+        dev = next(g.device for g in glosses if g is not None)
+        for shp in ctx.shapes:  # placeholders: the gradients are already in the banks' operand buffers
+            out.append(None)  # y
+            out.extend(torch.empty(s_, dtype=torch.float32, device=dev) for s_ in shp)
+        return tuple(out)
+
+
+def cross_entropy_multi(tasks, coefs, smoothing: float = 0.0):
+    """[loss_t] of ``cross_entropy(logits_t, y_t, smoothing)`` for several tasks whose backward seeds ``coefs`` are known, in ONE
+    launch that also writes every task's gradient operand -- or None when some task does not qualify for the fused form
+    (the caller then takes them one by one).  ``tasks``: [(logits tuple, y [N, heads] int64)]."""
+    if not (2 <= len(tasks) <= 4) or not torch.is_grad_enabled():
+        return None
+    plans, flat, heads = [], [], []
+    dt = None
+    for logits, y in tasks:
+        if torch.is_tensor(logits):
+            logits = (logits,)
+        y = y.contiguous()
+        plan = _ce_fused_plan(y, logits)
+        if plan is None or (dt is not None and plan[0].dtype != dt):
+            return None
+        dt = plan[0].dtype
+        plans.append(plan)
+        heads.append(len(logits))
+        flat += [y, *logits]
+    return list(_CEMulti.apply(float(smoothing), [float(c) for c in coefs], heads, plans, *flat))
+
+
 def cross_entropy(logits, y, smoothing: float = 0.0):
     """Per-row CrossEntropy(reduction='none', ignore_index=-1), summed over heads when ``logits`` is
     a tuple and y is [N, heads].  Logits are f32; their gradient is emitted in the element type the

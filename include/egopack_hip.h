@@ -337,6 +337,25 @@ int egk_ce_bwd(egk_stream_t s, const float* logits, int64_t ld, const int64_t* y
 int egk_ce_fused(egk_stream_t s, const float* const* logits, const int64_t* ld, const int32_t* C, const int32_t* pad,
                  const int64_t* dcol, int32_t n_heads, const int64_t* y, int64_t y_stride, float* loss, void* dlogits, int64_t ldd,
                  int32_t rows, float smoothing, float gscale, int32_t dtype);
+/* The same for up to 4 TASKS in one launch (the AR and LTA heads of a multi-task step, main_temporal.py:93-126: one cross
+ * entropy per task over its own logits, labels, loss vector and gradient operand).  Per task the arithmetic of
+ * egk_ce_fused: bit-identical results. */
+typedef struct {
+    const float* logits[4];
+    int64_t ld[4];
+    int32_t C[4];
+    int32_t pad[4];
+    int64_t dcol[4];
+    int32_t n_heads;
+    const int64_t* y;
+    int64_t y_stride;
+    float* loss;
+    void* dlogits;
+    int64_t ldd;
+    int32_t rows;
+    float gscale;
+} egk_ce_task;
+int egk_ce_fused_multi(egk_stream_t s, const egk_ce_task* tasks, int32_t count, float smoothing, int32_t dtype);
 /* nn.BCEWithLogitsLoss(reduction='none') on y.float()  main_temporal.py:123,298; pnr.py:82-83 */
 int egk_bce_fwd(egk_stream_t s, const float* logits, const int64_t* y, float* loss, int32_t n);
 int egk_bce_bwd(egk_stream_t s, const float* logits, const int64_t* y, const float* gloss, void* dlogits, int32_t n,
