@@ -345,6 +345,45 @@ def test_banded_gather_is_the_csr_gather_bit_for_bit(ops, cols, dt):
     torch.testing.assert_close(b.float().cpu(), ref, **(OUT16 if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-6)))
 
 
+def test_frozen_weight_copies_follow_the_parameter(ops):
+    """ops.weight_operand keeps ONE bf16 copy of a frozen (requires_grad = False) weight while the parameter is not
+    written; an in-place write or a new storage makes the next call convert again."""
+    W = torch.nn.Parameter(torch.randn(64, 128, device=DEV), requires_grad=False)
+    a = ops.weight_operand(W, torch.bfloat16)
+    assert ops.weight_operand(W, torch.bfloat16) is a and torch.equal(a.float(), W.detach().to(torch.bfloat16).float())
+    with torch.no_grad():
+        W.mul_(2.0)
+    b = ops.weight_operand(W, torch.bfloat16)
+    assert b is not a and torch.equal(b.float(), W.detach().to(torch.bfloat16).float())
+    W.data = torch.randn(64, 128, device=DEV)
+    c = ops.weight_operand(W, torch.bfloat16)
+    assert c is not b and torch.equal(c.float(), W.detach().to(torch.bfloat16).float())
+    T_ = torch.nn.Parameter(torch.randn(64, 128, device=DEV))  # trainable without an optimizer shadow: converted per call
+    assert ops.weight_operand(T_, torch.bfloat16) is not ops.weight_operand(T_, torch.bfloat16)
+
+
+def test_grouped_projection_infer_equals_the_heads_one_by_one(ops):
+    """The detached auxiliary projections of the EgoPack step as three grouped launches (ops.grouped_projection_infer)
+    against ProjectionTask.forward_features per head: identical bits (same kernels on the same operands)."""
+    from egopack_amd.models.tasks import LTATask, PNRTask, RecognitionTask
+    ops.set_compute("bf16")
+    try:
+        torch.manual_seed(3)
+        tasks = [RecognitionTask(256, 256, (7, 11)), LTATask(256, 256, (7, 11)), PNRTask(256, 256)]
+        for t in tasks:
+            t.to(DEV).eval()
+            for p in t.parameters():
+                p.requires_grad_(False)
+        x = torch.randn(192, 256, device=DEV).to(torch.bfloat16)
+        got = ops.grouped_projection_infer(x, [t.net for t in tasks], out_f32=True)
+        assert got is not None and all(g.dtype == torch.float32 for g in got)
+        for t, g in zip(tasks, got):
+            ref = t.forward_features(x, out_f32=True)
+            torch.testing.assert_close(g, ref, rtol=1e-5, atol=1e-5)
+    finally:
+        ops.set_compute("f32")
+
+
 def test_pe_add(ops):
     g = gen(9)
     x = torch.randn(50, 64, generator=g)
