@@ -206,8 +206,25 @@ def batch_signature(batches: Mapping[str, Data], merged=None) -> tuple:
     return tuple(sig)
 
 
+def _fast_key(batches, merged):
+    """A cheap stand-in for ``batch_signature`` when every batch carries a structure fingerprint: the fingerprints and the
+    feature blocks' shapes / types (None: some batch has no fingerprint -- take the full signature)."""
+    parts = []
+    for name, b in [*sorted(batches.items()), ("merged", merged)]:
+        if b is None:
+            parts.append((name, None))
+            continue
+        k = getattr(b, "_struct_key", 0)
+        x = getattr(b, "x", None)
+        if not k or not torch.is_tensor(x):
+            return None
+        y = getattr(b, "y", None)
+        parts.append((name, k, tuple(x.shape), x.dtype, tuple(y.shape) if torch.is_tensor(y) else None))
+    return tuple(parts)
+
+
 @torch.no_grad()
-def copy_batch_values(dst_batches, dst_merged, src_batches, src_merged) -> None:
+def copy_batch_values(dst_batches, dst_merged, src_batches, src_merged, dst_walks=None) -> None:
     """dst <- src for every tensor of two sets of batches with the same signature (device to device).  Per-task feature
     blocks that are row ranges of a packed buffer (``x_base``) are written once, through the buffer; edge-sized arrays are
     written into the first E entries of their capacity.  Graph-structure arrays are skipped when both sides carry the same
@@ -221,7 +238,13 @@ def copy_batch_values(dst_batches, dst_merged, src_batches, src_merged) -> None:
         base = getattr(dst, "x_base", None)
         k_dst, k_src = getattr(dst, "_struct_key", 0), getattr(src, "_struct_key", 0)
         same_structure = bool(k_dst) and k_dst == k_src
-        for path, d in _walk(dst):
+        if dst_walks is not None:  # (the destination's tensors never change: walked once per static batch)
+            walk = dst_walks.get(id(dst))
+            if walk is None:
+                walk = dst_walks[id(dst)] = [(p_, d_) for p_, d_ in _walk(dst) if torch.is_tensor(d_) and not p_.endswith(".x_base")]
+        else:
+            walk = _walk(dst)
+        for path, d in walk:
             if not torch.is_tensor(d) or path.endswith(".x_base"):
                 continue
             if same_structure and path.split(".")[1].split("[")[0] in STRUCTURE_FIELDS:
@@ -538,8 +561,11 @@ class StepBase:
         if self.fused and len([t for t in self.enabled if batches.get(t) is not None]) > 1 and merged is None:
             self.loop_counts["eager"] += 1
             return self.step(batches, merged)  # (the caller did not stage a merged batch: nothing static to replay on)
-        sig = batch_signature(batches, merged)
         st = getattr(self, "_train_static", None)
+        # equal structure fingerprints (stage_batches attaches them) + equal feature shapes = equal signature: the walk over
+        # every tensor of the step's batches (0.2-0.3 ms of host time per step) is skipped for such a step
+        fast = _fast_key(batches, merged)
+        sig = st["sig"] if (st is not None and fast is not None and fast == st.get("fast")) else batch_signature(batches, merged)
         if st is None:
             clone = lambda d: None if d is None else _clone_batch(d, pad_edges=True)
             static_b = {t: clone(b) for t, b in batches.items()}
@@ -547,7 +573,8 @@ class StepBase:
             _rewire_packed(static_b, static_m)
             copy_batch_values(static_b, static_m, batches, merged)
             self.capture(static_b, static_m, warmup=0)
-            st = self._train_static = {"sig": batch_signature(static_b, static_m), "batches": static_b, "merged": static_m}
+            st = self._train_static = {"sig": batch_signature(static_b, static_m), "batches": static_b, "merged": static_m,
+                                       "fast": fast}
             if st["sig"] != sig:  # (cannot happen: the clones mirror the originals)
                 self._train_static = None
                 self.loop_counts["eager"] += 1
@@ -556,7 +583,9 @@ class StepBase:
             self.loop_counts["eager"] += 1
             return self.step(batches, merged)
         else:
-            copy_batch_values(st["batches"], st["merged"], batches, merged)
+            copy_batch_values(st["batches"], st["merged"], batches, merged, dst_walks=st.setdefault("walks", {}))
+            if fast is not None and st.get("fast") != fast:
+                st["fast"] = fast  # (the static buffers now hold this structure)
         self.loop_counts["replayed"] += 1
         total = self.replay()
         return total.detach(), {t: v.detach() for t, v in self._static_out[1].items()}
