@@ -445,10 +445,13 @@ class StepBase:
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
+            # (eagerly issued steps end with the same grouped tail launch as captured ones: same tile variants, same bits)
+            self._install_tail(self._tail_only_plan([t for t in self.enabled if batches.get(t) is not None]))
             with self._ln_exchange_scope():
                 total, vectors = self._backward_pass(batches, merged)
             ops.join_wgrad(force=True)
         finally:
+            ops.set_last_wgrad_hook(None, None)
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
@@ -513,6 +516,7 @@ class StepBase:
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
+            self._install_tail(self._tail_only_plan([t for t in self.enabled if batches.get(t) is not None]))
             with self._ln_exchange_scope():
                 total, vectors = self._stage_a(batches, merged)
                 self._exchange_region(regions[0])
@@ -521,6 +525,7 @@ class StepBase:
                 self._stage_c()
                 self._exchange_region(regions[2])
         finally:
+            ops.set_last_wgrad_hook(None, None)
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
@@ -641,6 +646,8 @@ class StepBase:
                 self._rng_in_graph = False
                 if self.input_hook is not None:
                     self.input_hook()
+                if early is None and not fuse_adam:
+                    self._install_tail(self._tail_only_plan(live))
                 if early is not None:
                     early["rng"] = "rng_in_graph" not in getattr(self, "_dev_off", ()) and "rng_early" not in getattr(self, "_dev_off", ())
                     ops.set_last_wgrad_hook(early["param"], early["hook"])
@@ -680,6 +687,33 @@ class StepBase:
     # for steps that have JOINED every other gradient producer into the backward stream by then (MTLStep with its
     # head-wise backward does; a step whose branches are still running on their own streams at that point must not)
     early_adam = False
+
+    def _tail_only_plan(self, live):
+        """(first TRN weight, flat range of the temporal pooling's slots) when the step can end with ONE grouped launch of the
+        pooling's weight gradients (ops.set_last_wgrad_tail) although no optimizer slice runs beside it -- the steps whose
+        Adam follows a gradient exchange.  None when the layout does not allow it."""
+        opt = self.optimizer
+        tp = getattr(self.model, "temporal_pooling", None)
+        first = getattr(tp, "proj", [None])[0] if tp is not None else None
+        if (first is None or not hasattr(opt, "region_of") or not getattr(opt, "materialised", False) or not (self.fused or len(live) == 1)
+                or "tail_group" in getattr(self, "_dev_off", ()) or not self.headwise_backward_ok()):
+            return None
+        params = [p for p in tp.parameters() if p.requires_grad]
+        lo, hi = opt.region_of(params)
+        slots = [opt._slot_of[id(p)] for p in params if id(p) in opt._slot_of]
+        if not (hi > lo and lo % 8 == 0 and hi % 8 == 0 and sum(n for _, n in slots) == hi - lo):
+            return None
+        return first.weight, lo, hi
+
+    def headwise_backward_ok(self) -> bool:
+        return bool(getattr(self, "headwise_backward", False))
+
+    def _install_tail(self, plan) -> None:
+        if plan is None:
+            return
+        g0 = self.optimizer.flat_g.data_ptr()
+        ops.set_last_wgrad_hook(plan[0], lambda: None)
+        ops.set_last_wgrad_tail(g0 + 4 * plan[1], g0 + 4 * plan[2])
 
     def _early_adam_plan(self, live):
         """The step ends with two launches that have the chip to themselves one after the other: the weight gradient of
@@ -749,6 +783,7 @@ class StepBase:
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
+            live = [t for t in self.enabled if batches.get(t) is not None]
             with torch.cuda.graph(gs[0], capture_error_mode=CAPTURE_MODE):
                 opt.flat_g.zero_()
                 if self.input_hook is not None:
@@ -756,10 +791,12 @@ class StepBase:
                 total, vectors = self._stage_a(batches, merged)
             pool = gs[0].pool()
             with torch.cuda.graph(gs[1], pool=pool, capture_error_mode=CAPTURE_MODE):
+                self._install_tail(self._tail_only_plan(live))  # (stage B ends with the stack's flush, stage C is the tail launch)
                 self._stage_b()
             with torch.cuda.graph(gs[2], pool=pool, capture_error_mode=CAPTURE_MODE):
                 self._stage_c()
         finally:
+            ops.set_last_wgrad_hook(None, None)
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
