@@ -72,6 +72,9 @@ class GradSync:
         self._side = None
         self._g16 = None
         self._inflight = []
+        # region-wise exchange (start / finish_and_step): every chunk's Adam slice is issued behind its collective on the
+        # communication stream (False: all of them after the last stage -- development A/B)
+        self.adam_behind_collective = "adam_behind_collective" not in os.environ.get("EGK_DISABLE", "")
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         if self.world > 1:
@@ -139,6 +142,9 @@ class GradSync:
         if self._side is None:
             self._side = torch.cuda.Stream(device=flat_g.device)
         main = torch.cuda.current_stream(flat_g.device)
+        if not self._inflight:  # first region of this step: the step's Adam constants, ordered before every slice below
+            opt.grad_scale = 1.0 / self.world
+            opt.prepare_hyper()
         for b in range(lo, hi, self.chunk_elems):
             e = min(hi, b + self.chunk_elems)
             if compress:
@@ -148,6 +154,11 @@ class GradSync:
             self._side.wait_event(ready)
             with torch.cuda.stream(self._side):
                 all_reduce_sum_(src[b:e], self.group)
+                # the Adam slice of the chunk right behind its collective, on the communication stream: the parameters of a
+                # region are not read again by the backward stages that follow it (heads: used in stage A only; SAGE stack:
+                # not by the temporal pooling's backward), so the update runs beside those stages instead of after them
+                if self.adam_behind_collective:
+                    opt.launch(src, b, e)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             self._inflight.append((b, e, ev, src))
@@ -155,12 +166,11 @@ class GradSync:
     def finish_and_step(self, opt) -> None:
         """Adam launch per exchanged chunk, in the order the chunks were started, each behind its collective."""
         main = torch.cuda.current_stream(opt.flat_g.device)
-        opt.grad_scale = 1.0 / self.world
-        opt.prepare_hyper()
         covered = 0
         for b, e, ev, src in self._inflight:
             main.wait_event(ev)
-            opt.launch(src, b, e)
+            if not self.adam_behind_collective:
+                opt.launch(src, b, e)
             covered += e - b
         self._inflight.clear()
         if covered != opt.flat_g.numel():
