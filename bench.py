@@ -189,12 +189,27 @@ def pmc_traffic(kernel: str):
         tot = 0.0
         hit = False
         for name, ctrs in pmc.items():
+            if name.startswith("_"):
+                continue
             if sym in name:
                 hit = True
                 tot += sum(c["bytes_per_launch"] for c in ctrs.values())
         return tot if hit else None
     except Exception:
         return None
+
+
+def pmc_provenance() -> str:
+    """Where ``roofline.traffic`` comes from: the committed PMC summary and the source commit it was measured at
+    (profiles/pmc_latest.json ``_meta``, written by tools/stamp_profile.py when the summary is copied into profiles/)."""
+    f = REPO / "profiles" / "pmc_latest.json"
+    try:
+        meta = json.loads(f.read_text()).get("_meta", {})
+    except Exception:  # noqa: BLE001
+        return "profiles/pmc_latest.json (absent)"
+    return (f"profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (tools/profile.sh), "
+            f"FETCH x2 per the gfx950 correction; measured at source commit {meta.get('commit', 'unknown')} "
+            f"({meta.get('tag', '?')}, {meta.get('date', '?')}); NOT re-measured in this run")
 
 
 def roofline(ops, step_fn, compute, n_steps=3):
@@ -224,7 +239,7 @@ def roofline(ops, step_fn, compute, n_steps=3):
     else:
         achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
         out = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS}
-    out.update({"traffic": pmc_traffic(name), "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc passes)",
+    out.update({"traffic": pmc_traffic(name), "traffic_source": pmc_provenance(),
                 "kernel": name, "rocprof_symbol": ROCPROF_NAME.get(name), "launches_per_step": r["launches"] / n_steps, "avg_launch_us": avg_ms * 1e3,
                 "alg_per_launch": (r["flops"] if name.startswith("gemm") else r["bytes"]) / r["launches"]})
     # whole step against the same peaks: the sum over every launch of max(algorithmic flops / MFMA peak,
@@ -300,7 +315,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true",
                     help="skip the short reference-precision (--compute f32) measurement added to the JSON line at N = 1")
-    ap.add_argument("--f32-steps", type=int, default=10, help="timed steps of the reference-precision leg")
+    ap.add_argument("--f32-steps", type=int, default=50, help="timed steps of the reference-precision leg")
+    ap.add_argument("--min-timed-s", type=float, default=0.5,
+                    help="repeat the timed K-step block until at least this much stepping has been timed; the median block is reported")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table (stderr)")
     ap.add_argument("--stamps", action="store_true",
                     help="development: capture one-lane wall-clock stamps at the phase boundaries of the step and print the "
@@ -345,7 +362,7 @@ def spawn_ranks(n: int, argv) -> int:
     return 0
 
 
-def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_cpu=True):
+def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_cpu=True, min_timed_s=0.0):
     """Build the workload in ``args.compute`` mode, capture / warm up, time ``steps`` steps (barrier + synchronize on both
     sides, MAX over ranks) and take the roofline / CPU-baseline legs.  Returns a dict of results."""
     from egopack_amd import dist as edist
@@ -477,23 +494,62 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
 
     for _ in range(warmup):
         run()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run()
-    torch.cuda.synchronize()
-    barrier()
-    ms = (time.perf_counter() - t0) * 1e3 / steps
+
+    def timed_block():
+        """EXACTLY ``steps`` steps between barrier + synchronize on both sides: milliseconds per step of this rank."""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+        barrier()
+        return (time.perf_counter() - t0) * 1e3 / steps
+
+    def over_ranks(v, op):
+        if world <= 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if args.one_gpu_gloo else device)
+        torch.distributed.all_reduce(t, op=op)
+        return float(t.item())
+
+    # The driver's K = 20 steps of the headline workload are a 30 ms window on boxes that differ by +-4 % and processes that
+    # land in one of two modes a few percent apart: the K-step block is REPEATED until at least ``min_timed_s`` of stepping
+    # has been timed (every block bracketed as above, MAX over ranks per block) and the MEDIAN block is reported; ``timed_s``
+    # / ``timed_blocks`` / ``block_ms`` say what was timed.
+    blocks = [over_ranks(timed_block(), torch.distributed.ReduceOp.MAX)]
+    want = 1
+    if min_timed_s > 0 and blocks[0] * steps * 1e-3 < min_timed_s:
+        want = min(200, int(min_timed_s / max(blocks[0] * steps * 1e-3, 1e-6)) + 1)
+    want = int(over_ranks(float(want), torch.distributed.ReduceOp.MAX))  # (every rank runs the same number of blocks)
+    while len(blocks) < want:
+        blocks.append(over_ranks(timed_block(), torch.distributed.ReduceOp.MAX))
+    srt = sorted(blocks)
+    ms = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    timing = {"timed_s": sum(blocks) * steps * 1e-3, "timed_blocks": len(blocks), "block_ms_min": srt[0], "block_ms_max": srt[-1]}
+
+    # N ranks: what the gradient exchange costs the step BEYOND what backward hides -- the same steps with the collectives
+    # left out of the exchange path (conversion, stream hand-offs, per-chunk Adam all still run: GradSync.skip_collectives)
+    exchange = None
+    if sync is not None and world > 1:
+        sync.skip_collectives = True
+        try:
+            for _ in range(max(2, warmup // 2)):
+                run()
+            dry = over_ranks(timed_block(), torch.distributed.ReduceOp.MAX)
+        finally:
+            sync.skip_collectives = False
+        sync.broadcast_(opt.flat_p)  # (the replicas stepped on local gradients meanwhile: same parameters again)
+        opt.refresh_shadows()
+        torch.cuda.synchronize()
+        exchange = {"ms_per_step_without_collectives": dry, "exposed_ms_per_step": ms - dry,
+                    "bytes_per_step": opt.flat_g.numel() * (2 if args.grad_compress == "bf16" else 4),
+                    "rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend()}
     if getattr(args, "stamps", False) and rank == 0:
         prev = 0.0
         for name, us in sorted(ops.stamps_read(), key=lambda kv: kv[1]):
             print(f"[stamp] {us:9.1f} us  (+{us - prev:7.1f})  {name}", file=sys.stderr)
             prev = us
-    if world > 1:
-        t = torch.tensor([ms], device="cpu" if args.one_gpu_gloo else device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        ms = t.item()
 
     rl, table = (None, {})
     # (with several ranks EVERY rank takes these eager steps: they issue the gradient collectives, and a rank 0 stepping
@@ -513,6 +569,20 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
                 step.parallel_heads, step.wgrad_side_streams = saved
                 if g1 is not None:
                     g1.parallel_tasks = saved_g1
+            # ... and once more with the step's OWN stream structure (heads, weight gradients and Adam beside the dX chain, as the
+            # captured graph replays them): the kernel with the largest summed time THERE -- co-running launches slow each
+            # other down, so this is the figure a trace of the replayed graph shows (round-2 verdict: the grouped
+            # weight-gradient launch, invisible in the serialised table)
+            try:
+                rl2, _ = roofline(ops, eager_step, args.compute)
+                if rl and rl2:
+                    rl["replay_dominant"] = {k: rl2[k] for k in ("kernel", "rocprof_symbol", "bound", "achieved", "peak", "unit", "frac",
+                                                                 "avg_launch_us", "launches_per_step", "alg_per_launch", "traffic")
+                                             if k in rl2}
+                    rl["replay_dominant"]["timing"] = ("HIP events on each launch's own stream, eager steps issued with the "
+                                                       "production stream structure (kernels co-run)")
+            except Exception as e:  # noqa: BLE001
+                rl["replay_dominant"] = {"error": repr(e)}
         except Exception as e:  # the headline number must still be printed
             rl = {"error": repr(e)}
     if rl and "step" in rl:
@@ -524,7 +594,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
         except Exception as e:
             cb = {"error": repr(e)}
     return {"ms": ms, "roofline": rl, "table": table, "cpu_baseline": cb, "n_params": opt.flat_p.numel(), "capture": capture,
-            "fallbacks": fallbacks, "mode": "eager" if capture == "eager" else "graph"}
+            "fallbacks": fallbacks, "mode": "eager" if capture == "eager" else "graph", "timing": timing, "exchange": exchange}
 
 
 def main(argv=None):
@@ -575,7 +645,7 @@ def main(argv=None):
         from egopack_amd import data as _D
         _D.HEAVY_IN_LAUNCH_DEGREE = 0
 
-    res = measure(args, rank, world, device, args.steps, args.warmup)
+    res = measure(args, rank, world, device, args.steps, args.warmup, min_timed_s=args.min_timed_s)
     ms = res["ms"]
     seqs_per_step = world * len(WORKLOADS[args.workload][0]) * args.batch
 
@@ -589,7 +659,7 @@ def main(argv=None):
             a32.compute = "f32"
             r32 = measure(a32, rank, world, device, args.f32_steps, 3, want_roofline=not args.no_roofline, want_cpu=False)
             f32_leg = {"ms_per_step": r32["ms"], "value": seqs_per_step / (r32["ms"] * 1e-3), "unit": "clip-seqs/s",
-                       "steps": args.f32_steps, "capture": r32["capture"],
+                       "steps": args.f32_steps, "capture": r32["capture"], **r32["timing"],
                        "roofline": None if not r32["roofline"] or "error" in r32["roofline"] else
                        {k: r32["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us",
                                                          "launches_per_step", "step") if k in r32["roofline"]}}
@@ -621,7 +691,10 @@ def main(argv=None):
                        "master_weights": "f32", "mode": args.compute,
                        "activations": "bf16" if args.compute == "bf16" else "f32"},
             "roofline": rl, "cpu_baseline": cb, "f32": f32_leg,
+            **res["timing"],
         }
+        if res["exchange"] is not None:  # N ranks: what the driver's SCALE line needs to be read (round-2 verdict #5c)
+            out["exchange"] = res["exchange"]
         if args.kernel_table and res["table"]:
             print(json.dumps(res["table"], indent=1), file=sys.stderr)
     else:

@@ -41,12 +41,17 @@ def _via_host(t: torch.Tensor, group) -> bool:
 
 def all_reduce_sum_(t: torch.Tensor, group=None) -> None:
     """Sum over the ranks in place, ordered on the current stream (RCCL), or synchronously through the host (gloo)."""
+    if _skip["collectives"]:
+        return
     if _via_host(t, group):
         h = t.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+_skip = {"collectives": False}  # measurement only (GradSync.skip_collectives): the exchange path without its collectives
 
 
 def chunk_bounds(n: int, chunk_elems: int) -> List[tuple]:
@@ -72,9 +77,23 @@ class GradSync:
         self._side = None
         self._g16 = None
         self._inflight = []
-        # region-wise exchange (start / finish_and_step): every chunk's Adam slice is issued behind its collective on the
-        # communication stream (False: all of them after the last stage -- development A/B)
-        self.adam_behind_collective = "adam_behind_collective" not in os.environ.get("EGK_DISABLE", "")
+        # region-wise exchange (start / finish_and_step): every chunk's Adam slice may be issued behind its collective on the
+        # communication stream, beside the backward stages that follow (a region's parameters are not read again by them).
+        # OPT-IN (EGK_ENABLE=adam_behind_collective or the attribute): the Adam writes (f32 parameters, bf16 shadows) then run
+        # concurrently with the remaining backward graphs, and that ordering has never executed against real RCCL peers --
+        # the default issues every slice after the last stage, behind its collective's event
+        self.adam_behind_collective = "adam_behind_collective" in os.environ.get("EGK_ENABLE", "")
+
+    @property
+    def skip_collectives(self) -> bool:
+        """Measurement only (bench.py): with this on, the gradient all-reduces are left out of the exchange path -- every rank
+        steps on its LOCAL gradient, everything else of the path (conversion, stream hand-offs, per-chunk Adam) runs.  The
+        step time with it minus the step time without is what the collectives cost beyond what backward hides."""
+        return _skip["collectives"]
+
+    @skip_collectives.setter
+    def skip_collectives(self, on: bool) -> None:
+        _skip["collectives"] = bool(on)
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         if self.world > 1:
@@ -125,6 +144,11 @@ class GradSync:
 
     # ---- region-wise exchange for the staged backward (engine.StepBase): start() as soon as a region of the flat
     # gradient is final, finish_and_step() after the last stage ---------------------------------------------------------
+    def begin_step(self) -> None:
+        """Start of a staged step: forget whatever an ABANDONED step (an exception between two stages) left in flight, so that
+        the first ``start`` of this step prepares the Adam constants and the coverage check counts this step's chunks only."""
+        self._inflight.clear()
+
     def start(self, opt, lo: int, hi: int) -> None:
         """Enqueue conversion (compute stream) + all-reduce (communication stream) of flat_g[lo:hi] in chunks; the
         compute stream goes on with the next backward stage while the collectives run."""

@@ -509,6 +509,8 @@ class StepBase:
 
     def _staged_step(self, batches, merged=None):
         regions = self._stage_regions()
+        if self.sync is not None:
+            self.sync.begin_step()
         self.optimizer.zero_grad()
         if self.input_hook is not None:
             self.input_hook()
@@ -779,6 +781,7 @@ class StepBase:
         """Three graphs (one per backward stage) from one memory pool; the gradient exchange sits between them."""
         opt = self.optimizer
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        self._rng_in_graph = False  # (no staged graph advances the Philox offset word: replay() does, also after a one-piece capture)
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
@@ -811,6 +814,8 @@ class StepBase:
             ops.advance_rng_device(opt.flat_p.device)
         if isinstance(self._graph, list):
             regions = self._stage_regions()
+            if self.sync is not None:
+                self.sync.begin_step()
             for g, region in zip(self._graph, regions):
                 g.replay()
                 self._exchange_region(region)

@@ -1450,22 +1450,23 @@ def graph_layernorm_lrelu(x, w, b, seg_ptr, eps=1e-5, slope=0.2, partials=None, 
 
 # ---- positional encoding add --------------------------------------------------------------------------
 _pe_tables = {}
-_pe_freq_ids = {}
 
 
 def _pe_freq_id(freq):
     """Identity of a frequency buffer by CONTENT (models built alike share their tables; a table is never freed, so a
     captured graph that reads one stays valid): a host hash taken the first time a buffer is seen -- outside graph captures
-    only (it synchronises); None while capturing an unseen buffer."""
-    k = (freq.data_ptr(), freq._version, freq.numel(), freq.device.index)
-    fid = _pe_freq_ids.get(k)
-    if fid is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        fid = hash(freq.detach().float().cpu().numpy().tobytes())
-        if len(_pe_freq_ids) > 256:
-            _pe_freq_ids.clear()
-        _pe_freq_ids[k] = fid
+    only (it synchronises); None while capturing an unseen buffer.  The id is kept ON the tensor, with the version counter it
+    was taken at (a raw address may be handed to another buffer once this one is freed)."""
+    c = getattr(freq, "_egk_pe_id", None)
+    if c is not None and c[0] == freq._version and c[1] == freq.data_ptr() and c[2] == freq.numel():
+        return c[3]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    fid = hash(freq.detach().float().cpu().numpy().tobytes())
+    try:
+        freq._egk_pe_id = (freq._version, freq.data_ptr(), freq.numel(), fid)
+    except Exception:  # noqa: BLE001  (a tensor type that takes no attributes: hashed again next time)
+        pass
     return fid
 
 
@@ -1632,8 +1633,17 @@ class _SageMean(torch.autograd.Function):
         def launch_out_grads():
             gemm(*l_args, **l_kw)
             gemm(*r_args, **r_kw)
-        if not (in_place and ctx.compute == BF16 and _wgrad_groupable(Ho, H, g, g.stride(0), agg, H, N)
-                and _wgrad_defer(l_args, l_kw, (g, agg)) and _wgrad_defer(r_args, r_kw, (g, h))):
+        # eligibility is decided ONCE for both problems (same shapes; both operand pairs checked, and the stream): a pair of which
+        # only the first was parked would be accumulated twice by the fallback below
+        park = (in_place and ctx.compute == BF16 and not _on_excluded_stream()
+                and _wgrad_groupable(Ho, H, g, g.stride(0), agg, H, N) and _wgrad_groupable(Ho, H, g, g.stride(0), h, H, N))
+        if park:
+            # one at a time: the first may flush a full group
+            if not _wgrad_defer(l_args, l_kw, (g, agg)):
+                raise RuntimeError("sage_mean_layer: a weight gradient announced as parkable was refused")
+            if not _wgrad_defer(r_args, r_kw, (g, h)):
+                raise RuntimeError("sage_mean_layer: a weight gradient announced as parkable was refused")
+        else:
             _wgrad_launch(in_place, (g, agg, h), launch_out_grads)
         d_agg = torch.empty_like(h)
         gemm(N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H, transB=True, compute=ctx.compute)

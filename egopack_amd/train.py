@@ -107,6 +107,21 @@ def build_loaders(cfg, dsets, train: bool, rank: int, world: int, batch_size: Op
             for t, ds in dsets.items()}
 
 
+def env_ranks() -> tuple:
+    """(rank, local_rank, world) of the launcher environment, without initialising anything."""
+    import os
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def start_loader_workers(loaders) -> None:
+    """Create the collation processes of every loader that asks for some (``loader_workers`` > 0).  The entry points call
+    this BEFORE anything touches the GPU: the pool is then a plain fork of a process without HIP state (no runtime locks,
+    threads or pinned mappings inherited, the dataset shared copy-on-write instead of pickled to every worker)."""
+    for dl in loaders.values():
+        if getattr(dl, "workers", 0) > 0:
+            dl.start_workers()
+
+
 def build_criteria(dsets):
     return {"ar": MetricSelectorWrapper(CrossEntropyNone(), dsets["ar"]),
             "lta": MetricSelectorWrapper(CrossEntropyNone(), dsets["lta"]),

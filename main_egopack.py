@@ -78,18 +78,21 @@ def main(argv=None):
     if not cfg.enable_graphone:
         logging.warning("Invalid configuration. Aborting!")
         return
-    rank, local_rank, world = edist.init_from_env()
+    rank, local_rank, world = T.env_ranks()
     T.setup_logging(rank)
     T.cap_host_threads(int(cfg.get("host_threads", 8)))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
     T.seed_everything(cfg, rank)
     ops.set_compute(cfg.compute)
     weights = T.task_weights(cfg)
 
+    # (before anything touches the GPU: collation workers are then a plain fork, data.BatchLoader.start_workers)
     dsets_train, dsets_val = T.build_datasets(cfg, "train"), T.build_datasets(cfg, cfg.validation_split)
     dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
     dl_val = T.build_loaders(cfg, dsets_val, False, rank, world)  # batch-sharded; meters are summed across ranks
+    T.start_loader_workers(dl_train)
+    rank, local_rank, world = edist.init_from_env()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
     H = cfg.model.hidden_size
     model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,
                         num_segments=cfg.dataset_recognition.num_segments, _recursive_=False).to(device)

@@ -94,21 +94,25 @@ def validate_metrics(epoch, model, tasks, enabled, dsets_val, loaders, device="c
 
 def main(argv=None):
     cfg = T.load_config(argv)
-    rank, local_rank, world = edist.init_from_env()
+    rank, local_rank, world = T.env_ranks()
     T.setup_logging(rank)
     T.cap_host_threads(int(cfg.get("host_threads", 8)))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
     T.seed_everything(cfg, rank)
     ops.set_compute(cfg.compute)
     weights = T.task_weights(cfg)
     logger.info("task weights: %s", weights)
     artifact = f"{cfg.artifact_prefix}_" + "-".join(sorted(t for t, w in weights.items() if w > 0))
 
+    # datasets, loaders and their collation processes come first: nothing has touched the GPU yet, so the workers are a
+    # plain fork of a process without HIP state (data.BatchLoader.start_workers)
     dsets_train, dsets_val = T.build_datasets(cfg, "train"), T.build_datasets(cfg, cfg.validation_split)
     assert len({d.features_size for d in dsets_train.values()}) == 1, "all tasks must share the input feature size"
     dl_train = T.build_loaders(cfg, dsets_train, True, rank, world)
     dl_val = T.build_loaders(cfg, dsets_val, False, rank, world)  # batch-sharded; meters are summed across ranks
+    T.start_loader_workers(dl_train)
+    rank, local_rank, world = edist.init_from_env()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
     # datasets that index a device-resident feature table (dataset_*=synthetic_resident; the reference's .npy files
     # loaded into HBM): one table per split, the training step gathers its rows on the device, evaluation batches get
     # theirs through an adapter
