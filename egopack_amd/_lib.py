@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("splitk", i32), ("ws", vp), ("ws_bytes", i64), ("dbias", vp),
         ("st_mode", i32), ("st_nseg", i32), ("st_min_seg_rows", i32), ("st_seg_ptr", vp), ("st_ws", vp), ("st_x", vp),
         ("st_ldx", i64), ("st_stats", vp), ("st_w", vp), ("st_b", vp), ("st_slope", f32),
+        ("n_extra", i32), ("xK", i32 * 4), ("xA", vp * 4), ("xB", vp * 4), ("xlda", i64 * 4), ("xldb", i64 * 4),
     ]
 
 
@@ -113,6 +114,7 @@ SIGNATURES = {
     "egk_dropout_bwd": (C.c_int, [vp, vp, vp, vp, i64, f32, i32]),
     "egk_relu_gate": (C.c_int, [vp, vp, vp, vp, i64, i32]),
     "egk_cast": (C.c_int, [vp, vp, i32, vp, i32, i64]),
+    "egk_split_bf16": (C.c_int, [vp, vp, i64, vp, vp, i64, i64, i64]),
     "egk_tune": (C.c_int, [i32, i32]),
     "egk_weighted_sums": (C.c_int, [vp, vp, vp, vp, i32, vp]),
     "egk_fill_scaled_multi": (C.c_int, [vp, vp, vp, vp, vp, i32]),

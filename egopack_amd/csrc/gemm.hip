@@ -31,13 +31,15 @@ typedef unsigned short bf16_t;  // storage type of a bf16 element in memory
 constexpr int BM = 128, BN = 128, ROWB = 128;  // LDS row = 128 bytes = 8 chunks of 16 B
 constexpr int NTHREADS = 256;
 
+constexpr int MAXSRC = 6;  // K sources of one contraction: C = sum_s op(A_s) . op(B_s)^T (same layout / element type)
 struct GemmArgs {
     int M, N;
-    int K[2];
-    const void* A[2];
-    const void* B[2];
-    long long lda[2], ldb[2];
-    int a_vec[2], b_vec[2];  // 16-byte vector loads legal for this source
+    int nsrc;
+    int K[MAXSRC];
+    const void* A[MAXSRC];
+    const void* B[MAXSRC];
+    long long lda[MAXSRC], ldb[MAXSRC];
+    int a_vec, b_vec;  // bit s: 16-byte vector loads legal for source s
     void* C;
     long long ldc;
     int c_vec, c_bf16;
@@ -84,6 +86,24 @@ __device__ __forceinline__ void tile_of(const GemmArgs& g, int bid, int& z, int&
     const int rr = t - grp * gsz;
     tm = first + rr % rows;
     tn = rr / rows;
+}
+
+// K tile t of the concatenated walk over the sources (tiles of KT elements) -> (source, tile inside it); uniform scalar work
+template <int KT>
+__device__ __forceinline__ void source_of(const GemmArgs& g, int t, int& src, int& tt) {
+    src = 0;
+    tt = t;
+    while (src + 1 < g.nsrc) {
+        const int n = (g.K[src] + KT - 1) / KT;
+        if (tt < n) break;
+        tt -= n;
+        ++src;
+    }
+}
+__device__ __forceinline__ int total_tiles(const GemmArgs& g, int KT) {
+    int n = 0;
+    for (int s = 0; s < g.nsrc; ++s) n += (g.K[s] + KT - 1) / KT;
+    return n;
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -520,8 +540,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
     const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int nkt0 = (g.K[0] + KT - 1) / KT, nkt1 = (g.K[1] + KT - 1) / KT;
-    const int nkt = nkt0 + nkt1;
+    const int nkt = total_tiles(g, KT);
     const int z = blockIdx.y;  // split-K: this block handles K-tiles [t_begin, t_end)
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
@@ -538,10 +557,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs g) {
 
     uint4 ra[8], rb[8];
     auto load_tile = [&](int t) {
-        const int src = t < nkt0 ? 0 : 1;
-        const int k0 = (src == 0 ? t : t - nkt0) * KT;
-        load_operand<BF16C, TA, AT>(g.A[src], g.lda[src], g.M, m0, k0, g.K[src], g.a_vec[src], 0, ra);
-        load_operand<BF16C, TB, BT>(g.B[src], g.ldb[src], g.N, n0, k0, g.K[src], g.b_vec[src], 1, rb);
+        int src, tt;
+        source_of<KT>(g, t, src, tt);
+        const int k0 = tt * KT;
+        load_operand<BF16C, TA, AT>(g.A[src], g.lda[src], g.M, m0, k0, g.K[src], (g.a_vec >> src) & 1, 0, ra);
+        load_operand<BF16C, TB, BT>(g.B[src], g.ldb[src], g.N, n0, k0, g.K[src], (g.b_vec >> src) & 1, 1, rb);
     };
 
     if (t_begin < t_end) load_tile(t_begin);
@@ -685,7 +705,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     int z, tm, tn;
     tile_of(g, bid, z, tm, tn);
     const int m0 = tm * (32 * NI * MB), n0 = tn * BN;
-    const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
+    const int nkt = total_tiles(g, KT);
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
 
@@ -707,9 +727,10 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     int cur_src = -1;
     auto issue = [&](int i, int stage) {  // i-th tile of this group
         const int t = t_begin + grp + KG * i;
-        const int src = t < nkt0 ? 0 : 1;
-        if (src != cur_src) {  // (uniform) first tile, or the walk crossed from the first K source into the second
-            const int k0 = (src == 0 ? t : t - nkt0) * KT;
+        int src, tt;
+        source_of<KT>(g, t, src, tt);
+        if (src != cur_src) {  // (uniform) first tile, or the walk crossed from one K source into the next
+            const int k0 = tt * KT;
             ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, w * NI, lane, KG);
             cb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, w * NPB, lane, KG);
             cur_src = src;
@@ -1020,7 +1041,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
     int z, tm, tn;
     tile_of(g, blockIdx.x, z, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
-    const int nkt0 = g.K[0] / KT, nkt = nkt0 + g.K[1] / KT;
+    const int nkt = total_tiles(g, KT);
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
     const int nt = t_end - t_begin;
@@ -1054,9 +1075,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
     };
     auto aim = [&](int i) {  // (uniform) first tile, or the walk crossed from the first K source into the second
         const int t = t_begin + i;
-        const int src = t < nkt0 ? 0 : 1;
+        int src, tt;
+        source_of<KT>(g, t, src, tt);
         if (src != cur_src) {
-            const long long k0 = (long long)(src == 0 ? t : t - nkt0) * KT;
+            const long long k0 = (long long)tt * KT;
             lda_b = g.lda[src] * 2; ldb_b = g.ldb[src] * 2;
             baseA = (const char*)g.A[src] + (TRA ? k0 * lda_b + (long long)m0 * 2 : (long long)m0 * lda_b + k0 * 2);
             baseB = (const char*)g.B[src] + (TRB ? k0 * ldb_b + (long long)n0 * 2 : (long long)n0 * ldb_b + k0 * 2);
@@ -1357,6 +1379,43 @@ extern "C" int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d) {
     return n;
 }
 
+// The K sources of a descriptor -- (A1, B1, K1), (A2, B2, K2), then the n_extra extra ones, empty ones skipped -- into g.
+// ea / eb: elements per 16 bytes of the operand element types.  Returns 0 or an error code (message set).
+struct SourceInfo {
+    long long k_total = 0;
+    bool all_k64 = true, all_vec = true;
+};
+static int fill_sources(const egk_gemm_desc* d, GemmArgs& g, int ea, int eb, SourceInfo& info, const char* who) {
+    EGK_REQUIRE(d->n_extra >= 0 && d->n_extra <= MAXSRC - 2, "%s: n_extra must be 0 .. %d", who, MAXSRC - 2);
+    g.nsrc = 0;
+    g.a_vec = g.b_vec = 0;
+    for (int i = 0; i < MAXSRC; ++i) { g.K[i] = 0; g.A[i] = g.B[i] = nullptr; g.lda[i] = g.ldb[i] = 0; }
+    auto add = [&](const void* A, const void* B, long long lda, long long ldb, int K) -> int {
+        EGK_REQUIRE(K >= 0, "%s: negative K", who);
+        if (K == 0) return 0;
+        EGK_REQUIRE(A && B, "%s: null operand of a non-empty K source", who);
+        const int i = g.nsrc++;
+        g.K[i] = K; g.A[i] = A; g.B[i] = B; g.lda[i] = lda; g.ldb[i] = ldb;
+        const bool av = aligned16(A) && (lda % ea == 0), bv = aligned16(B) && (ldb % eb == 0);
+        g.a_vec |= (av ? 1 : 0) << i;
+        g.b_vec |= (bv ? 1 : 0) << i;
+        info.k_total += K;
+        info.all_k64 = info.all_k64 && (K % 64 == 0);
+        info.all_vec = info.all_vec && av && bv;
+        return 0;
+    };
+    int rc = add(d->A1, d->B1, d->lda1, d->ldb1, d->K1);
+    if (rc) return rc;
+    rc = add(d->A2, d->B2, d->lda2, d->ldb2, d->K2);
+    if (rc) return rc;
+    for (int i = 0; i < d->n_extra; ++i) {
+        rc = add(d->xA[i], d->xB[i], d->xlda[i], d->xldb[i], d->xK[i]);
+        if (rc) return rc;
+    }
+    if (g.nsrc == 0) g.nsrc = 1;  // (K = 0: one empty source, the kernels store epilogue(0))
+    return 0;
+}
+
 static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks);
 
 extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) { return gemm_core(stream, d, nullptr); }
@@ -1383,21 +1442,16 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
     EGK_REQUIRE(!(a16 && d->compute == EGK_COMPUTE_F32), "egk_gemm: bf16 operands need EGK_COMPUTE_BF16");
     EGK_REQUIRE(!(d->accumulate && d->c_dtype != EGK_F32), "egk_gemm: accumulate needs an f32 C");
     EGK_REQUIRE(d->C != nullptr || d->M == 0 || d->N == 0, "egk_gemm: null C");
-    EGK_REQUIRE(d->K1 == 0 || (d->A1 && d->B1), "egk_gemm: null A1/B1");
-    EGK_REQUIRE(d->K2 == 0 || (d->A2 && d->B2), "egk_gemm: null A2/B2");
     if (d->M == 0 || d->N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
 
     GemmArgs g;
     g.M = d->M; g.N = d->N;
-    g.K[0] = d->K1; g.K[1] = d->K2;
-    g.A[0] = d->A1; g.A[1] = d->A2;
-    g.B[0] = d->B1; g.B[1] = d->B2;
-    g.lda[0] = d->lda1; g.lda[1] = d->lda2; g.ldb[0] = d->ldb1; g.ldb[1] = d->ldb2;
     const int ea = a16 ? 8 : 4, eb = b16 ? 8 : 4;  // elements per 16 bytes
-    for (int i = 0; i < 2; ++i) {
-        g.a_vec[i] = g.A[i] && aligned16(g.A[i]) && (g.lda[i] % ea == 0);
-        g.b_vec[i] = g.B[i] && aligned16(g.B[i]) && (g.ldb[i] % eb == 0);
+    SourceInfo src;
+    {
+        const int rc = fill_sources(d, g, ea, eb, src, "egk_gemm");
+        if (rc) return rc;
     }
     g.C = d->C; g.ldc = d->ldc;
     g.c_bf16 = d->c_dtype == EGK_BF16;
@@ -1423,7 +1477,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         EGK_REQUIRE(d->st_mode == 1 || (d->st_x && d->st_stats && d->st_w && d->st_b), "egk_gemm: st_mode 2 needs x, stats, w, b");
     }
     if (query_blocks) *query_blocks = 0;
-    const int K = d->K1 + d->K2;
+    const long long K = src.k_total;
     const double flops = 2.0 * d->M * d->N * K;
     const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
     const int bf = d->compute == EGK_COMPUTE_BF16;
@@ -1432,12 +1486,12 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
 
     // LDS-DMA pipelined kernel: bf16 operands, 16-byte aligned rows, every K source a multiple of 64 (the rows of
     // the contraction axis must not need zero fill); everything else runs on the generic register-staged kernel.
-    const bool pipe_ok = bf && a16 && g_use_pipe && d->K1 % 64 == 0 && d->K2 % 64 == 0 && d->K1 > 0 && g.a_vec[0] &&
-                         g.b_vec[0] && (d->K2 == 0 || (g.a_vec[1] && g.b_vec[1]));
+    const bool pipe_ok = bf && a16 && g_use_pipe && src.all_k64 && K > 0 && src.all_vec;
+    const bool single = d->K2 == 0 && d->n_extra == 0;
     // fused bias gradient: only the pipelined dW form sums its A image; anything else gets explicit column sums below
-    const bool bias_fused = pipe_ok && d->dbias && d->transA && d->K2 == 0;
+    const bool bias_fused = pipe_ok && d->dbias && d->transA && single;
     if (d->dbias) {
-        EGK_REQUIRE(d->transA && d->K2 == 0, "egk_gemm: dbias needs the dW form (transA, single K source)");
+        EGK_REQUIRE(d->transA && single, "egk_gemm: dbias needs the dW form (transA, single K source)");
         const int64_t slab = g.splitk > 1 ? (int64_t)g.splitk * d->M * d->N * 4 : 0;
         const int64_t need = bias_fused ? slab + (g.splitk > 1 ? (int64_t)g.splitk * d->M * 4 : 0)
                                         : slab + (int64_t)egk_colsum_ws_len(d->K1, d->M) * 4;
@@ -1461,7 +1515,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         // rate of this loop is set by LDS fragment reads + MFMA issue per 64 x 64 wave patch, not by the bytes a CU
         // takes in -- it is 3-10 % slower than (3) up to 4096^3 and 5 % faster at 8192^3 (tools/gemm_bench.py --layouts).
         const int nwg128 = g.tiles_m * g.tiles_n * g.splitk;
-        const int nkt_slab = cdiv((d->K1 + d->K2) / 64, g.splitk);
+        const int nkt_slab = cdiv(K / 64, g.splitk);
         int variant = g_use_pipe;
         if (variant == 1) {
             variant = nwg128 > 256 ? 3 : (nkt_slab >= 4 ? 5 : 3);
@@ -1485,7 +1539,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             // and x 1024: 45 vs 45 (16 K tiles: prologue and epilogue of the big tile weigh as much as its loop saves),
             // 24576 x 1024 (384 tiles, 1.5 rounds): 78 vs 65.  6144 x 1024 (96 tiles) never qualifies.
             const long long t256 = (long long)cdiv(g.M, 256) * cdiv(g.N, 256);
-            if (g.splitk == 1 && !g.dbias && g.M % 256 == 0 && g.N % 256 == 0 && t256 >= 192 && d->K1 + d->K2 >= 3072 &&
+            if (g.splitk == 1 && !g.dbias && g.M % 256 == 0 && g.N % 256 == 0 && t256 >= 192 && K >= 3072 &&
                 10 * t256 >= 9 * 256 * ((t256 + 255) / 256))
                 variant = 7;
         } else if ((variant == 8 || variant == 11) && d->transA) {
@@ -1590,22 +1644,18 @@ static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     EGK_REQUIRE(d->M > 0 && d->N > 0 && d->K1 > 0 && d->K2 >= 0, "egk_gemm_grouped: empty problem");
     EGK_REQUIRE(d->a_dtype == EGK_BF16 && d->b_dtype == EGK_BF16 && d->compute == EGK_COMPUTE_BF16,
                 "egk_gemm_grouped: bf16 operands on the bf16 MFMA path only");
-    EGK_REQUIRE(d->K1 % 64 == 0 && d->K2 % 64 == 0, "egk_gemm_grouped: K sources must be multiples of 64");
     EGK_REQUIRE(d->splitk <= 1, "egk_gemm_grouped: no split-K in a grouped launch");
     EGK_REQUIRE(!(d->accumulate && d->c_dtype != EGK_F32), "egk_gemm_grouped: accumulate needs an f32 C");
-    EGK_REQUIRE(d->A1 && d->B1 && d->C && (d->K2 == 0 || (d->A2 && d->B2)), "egk_gemm_grouped: null pointer");
-    EGK_REQUIRE(!d->dbias || (d->transA && d->K2 == 0), "egk_gemm_grouped: dbias needs the dW form (transA, single K source)");
+    EGK_REQUIRE(d->C, "egk_gemm_grouped: null pointer");
+    EGK_REQUIRE(!d->dbias || (d->transA && d->K2 == 0 && d->n_extra == 0), "egk_gemm_grouped: dbias needs the dW form (transA, single K source)");
     g.M = d->M; g.N = d->N;
-    g.K[0] = d->K1; g.K[1] = d->K2;
-    g.A[0] = d->A1; g.A[1] = d->A2;
-    g.B[0] = d->B1; g.B[1] = d->B2;
-    g.lda[0] = d->lda1; g.lda[1] = d->lda2; g.ldb[0] = d->ldb1; g.ldb[1] = d->ldb2;
-    for (int i = 0; i < 2; ++i) {
-        g.a_vec[i] = g.A[i] && aligned16(g.A[i]) && (g.lda[i] % 8 == 0);
-        g.b_vec[i] = g.B[i] && aligned16(g.B[i]) && (g.ldb[i] % 8 == 0);
+    SourceInfo src;
+    {
+        const int rc = fill_sources(d, g, 8, 8, src, "egk_gemm_grouped");
+        if (rc) return rc;
     }
-    EGK_REQUIRE(g.a_vec[0] && g.b_vec[0] && (d->K2 == 0 || (g.a_vec[1] && g.b_vec[1])),
-                "egk_gemm_grouped: operand rows must be 16-byte aligned");
+    EGK_REQUIRE(src.all_k64, "egk_gemm_grouped: K sources must be multiples of 64");
+    EGK_REQUIRE(src.all_vec, "egk_gemm_grouped: operand rows must be 16-byte aligned");
     g.C = d->C; g.ldc = d->ldc;
     g.c_bf16 = d->c_dtype == EGK_BF16;
     g.c_vec = g.c_bf16 ? ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0 && g.ldc % 4 == 0) : (aligned16(g.C) && g.ldc % 4 == 0);
@@ -1638,7 +1688,8 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         EGK_REQUIRE((d->transA != 0) == ta && (d->transB != 0) == tb, "egk_gemm_grouped: the problems must share one layout");
         const int rc = fill_group_args(d, gg.p[i]);
         if (rc) return rc;
-        const int K = d->K1 + d->K2;
+        int K = d->K1 + d->K2;
+        for (int x = 0; x < d->n_extra; ++x) K += d->xK[x];
         flops += 2.0 * d->M * d->N * K;
         bytes += 2.0 * ((double)d->M * K + (double)d->N * K) + (gg.p[i].c_bf16 ? 2.0 : 4.0) * d->M * d->N;
         const int tn = cdiv(d->N, BN);

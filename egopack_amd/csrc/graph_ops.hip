@@ -658,6 +658,41 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D*
     }
 }
 
+// x = hi + lo, hi = bf16(x), lo = bf16(x - hi): the bf16 operand pair of a three-product (f32-grade) contraction.
+// 4 consecutive elements per thread (16-byte load, 8-byte stores) when rows and pointers allow, else element by element.
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, long long lds_, bf16_t* __restrict__ hi,
+                                                         bf16_t* __restrict__ lo, long long ldo, long long rows, long long cols, int vec) {
+    const long long per_row = (cols + 3) / 4, total = rows * per_row;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const long long r = q / per_row, c = (q - r * per_row) * 4;
+        const float* p = src + r * lds_ + c;
+        float x[4];
+        const bool full = c + 4 <= cols;
+        if (vec && full) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = c + t < cols ? p[t] : 0.f;
+        }
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            h[t] = f2bf(x[t]);
+            l[t] = f2bf(x[t] - bf2f(h[t]));
+        }
+        if (vec && full) {
+            if (hi) *reinterpret_cast<uint2*>(hi + r * ldo + c) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+            *reinterpret_cast<uint2*>(lo + r * ldo + c) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+        } else {
+            for (int t = 0; t < 4 && c + t < cols; ++t) {
+                if (hi) hi[r * ldo + c + t] = h[t];
+                lo[r * ldo + c + t] = l[t];
+            }
+        }
+    }
+}
+
 // row-strided conversion: dst[r, c] = src[r, c] for c < cols (different leading dimensions: builds the 16-byte
 // aligned operand copy of a [rows, cols] gradient whose width is not a multiple of 8)
 template <typename S, typename D>
@@ -770,6 +805,21 @@ int egk_cast(egk_stream_t stream, const void* src, int32_t src_dtype, void* dst,
         return EGK_EUNSUPPORTED;
     }
     return check_launch("egk_cast");
+}
+
+int egk_split_bf16(egk_stream_t stream, const float* src, int64_t ld_src, void* hi, void* lo, int64_t ld_out, int64_t rows,
+                   int64_t cols) {
+    EGK_REQUIRE(src && lo, "egk_split_bf16: null pointer");
+    EGK_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols && ld_out >= cols, "egk_split_bf16: bad shape / leading dimension");
+    if (rows == 0 || cols == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_CAST, s, 0, (hi ? 8.0 : 6.0) * rows * cols);
+    const int vec = (((uintptr_t)src & 15) == 0) && (ld_src % 4 == 0) && ((((uintptr_t)lo | (uintptr_t)hi) & 7) == 0) && (ld_out % 4 == 0);
+    long long blocks = (rows * ((cols + 3) / 4) + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, (long long)ld_src, (bf16_t*)hi, (bf16_t*)lo,
+                       (long long)ld_out, (long long)rows, (long long)cols, vec);
+    return check_launch("egk_split_bf16");
 }
 
 int egk_cast_rows(egk_stream_t stream, const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype,

@@ -616,6 +616,8 @@ class StepBase:
                     self.step(batches, merged)
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if hasattr(opt, "invalidate_lo_shadows"):
+            opt.invalidate_lo_shadows()  # (a captured step must contain every refresh of the low halves it relies on)
         if self._use_stages():
             return self._capture_staged(batches, merged)
         fuse_adam = self.sync is None or self.sync.world <= 1
@@ -1072,19 +1074,59 @@ class EgoPackStep(StepBase):
         self._init_base(model, tasks, weights, optimizer, fused_backbone, sync, parallel_heads)
         self.graphone = graphone
         self.backprop, self.train_mode = backprop_temporal_graph, temporal_graph_train_mode
+        # Tasks that are not trained here only lend their projection heads to the detached auxiliary features (reference
+        # main_egopack.py:53: ``.detach()``): their parameters never receive a gradient and the reference's Adam skips them
+        # (grad is None).  They are marked frozen, which changes no result and lets the operand copies of their weights (bf16
+        # copies, bf16 halves of the three-product path) be made once instead of at every use.
+        for t, task in self.tasks.items():
+            if t not in self.enabled:
+                for p in task.parameters():
+                    p.requires_grad_(False)
 
-    def task_loss(self, primary: str, feat, data):
+    # The nearest-prototype search is an INDEX op (reference graphONE.py:119-141: argsort of the cosine distances): its lists must
+    # be the reference's, whatever the storage type of the training pass.  With bf16 activations the detached auxiliary features
+    # carry the rounding of a dozen bf16 layers (~1 % relative), enough to flip ~5 % of the neighbour positions at K = 4096.  In
+    # the bf16 modes they therefore come from a second, forward-only pass over the same batch in 'bf16x3' mode (f32 activations,
+    # every contraction as three bf16 products of split operands: f32-grade at ~3x the bf16 cost, ops.precise_scope): backbone
+    # + auxiliary projections, no gradient -- the reference detaches these features (main_egopack.py:53).  The GraphONE stages
+    # consume the same values (rounded to the activation type).
+    precise_search = True
+    precise_stream = True  # the precise pass on its own stream beside the training pass's forward (False: in line, A/B)
+
+    def _precise_on(self) -> bool:
+        return bool(self.precise_search and ops.get_compute() in ("bf16", "bf16_f32act") and "precise_search" not in getattr(self, "_dev_off", ()))
+
+    def _aux_names(self, primary: str):
+        return [t for t in self.AUX_ORDER[primary] if t in self.graphone.task_labels]
+
+    @torch.no_grad()
+    def precise_aux_features(self, batches, merged=None, rng_snap=None):
+        """{primary: {aux task: f32 [N, H]}}: the auxiliary projections of every enabled task batch from the 'bf16x3' pass."""
+        opt = self.optimizer
+        live = [t for t in self.enabled if batches.get(t) is not None]
+        with ops.precise_scope(), ops.rng_replay(ops.rng_snapshot() if rng_snap is None else rng_snap):
+            if getattr(opt, "materialised", False):
+                opt.refresh_lo_shadows(list(self.model.parameters()))  # the backbone's low halves: one launch
+            feats = self.features(batches, merged)
+            out = {}
+            for t in live:
+                others = self._aux_names(t)
+                out[t] = {o: self.tasks[o].forward_features(feats[t], out_f32=True) for o in others}
+        return out
+
+    def task_loss(self, primary: str, feat, data, aux_in=None):
         task = self.tasks[primary]
-        others = [t for t in self.AUX_ORDER[primary] if t in self.graphone.task_labels]
+        others = self._aux_names(primary)
         f_primary = task.forward_features(feat)
-        with torch.no_grad():
-            # f32 out of the projections' last contraction: the nearest-prototype search (an index op) ranks the f32
-            # accumulators in every compute mode; GraphONE brings them to the activation type for its stages
-            grouped = None
-            if "grouped_aux" not in getattr(self, "_dev_off", ()):
-                grouped = ops.grouped_projection_infer(ops.to_act(feat), [self.tasks[t].net for t in others], out_f32=True)
-            aux_in = (dict(zip(others, grouped)) if grouped is not None
-                      else {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others})
+        if aux_in is None:
+            with torch.no_grad():
+                # f32 out of the projections' last contraction: the nearest-prototype search (an index op) ranks the f32
+                # accumulators in every compute mode; GraphONE brings them to the activation type for its stages
+                grouped = None
+                if "grouped_aux" not in getattr(self, "_dev_off", ()):
+                    grouped = ops.grouped_projection_infer(ops.to_act(feat), [self.tasks[t].net for t in others], out_f32=True)
+                aux_in = (dict(zip(others, grouped)) if grouped is not None
+                          else {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others})
         aux, closest = self.graphone.interact(aux_in)
         if primary == "oscc":
             logits = task.forward_logits(features=f_primary, batch=data, aux_features=aux)
@@ -1097,11 +1139,35 @@ class EgoPackStep(StepBase):
         for t in self.tasks.values():
             t.train(True)
         self.graphone.train()
-        with torch.set_grad_enabled(self.backprop):
+        snap = ops.rng_snapshot()
+        precise, side = {}, None
+        first = next((b for b in batches.values() if b is not None), None)
+        if self._precise_on():
+            if self.precise_stream and first is not None and first.pos.is_cuda and "precise_stream" not in getattr(self, "_dev_off", ()):
+                # the precise pass is a chain of ~50 launches over the same few thousand rows as the training pass's forward:
+                # forked onto its own stream FIRST, the two chains run side by side (each alone leaves most of the chip idle)
+                main = torch.cuda.current_stream()
+                if getattr(self, "_precise_side", None) is None:
+                    self._precise_side = torch.cuda.Stream()
+                    ops.exclude_wgrad_streams([self._precise_side])
+                side = self._precise_side
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    precise = self.precise_aux_features(batches, merged)
+            else:
+                precise = self.precise_aux_features(batches, merged)
+        import contextlib
+        # (the training pass draws the dropout offsets the precise pass drew: same keep masks when the backbone is in train mode)
+        with (ops.rng_replay(snap) if precise else contextlib.nullcontext()), torch.set_grad_enabled(self.backprop):
             feats = self.features(batches, merged)
+        if side is not None:
+            main.wait_stream(side)
+            for d in precise.values():
+                for a in d.values():
+                    a.record_stream(main)
 
         def head(t, feat):
-            loss, logits, _, _ = self.task_loss(t, feat, batches[t])
+            loss, logits, _, _ = self.task_loss(t, feat, batches[t], aux_in=precise.get(t))
             return loss, logits
         vectors, logits_out = self._run_heads(feats, head)
         return self._objective(vectors), vectors, logits_out

@@ -109,7 +109,8 @@ class GraphONE(nn.Module):
         bank = self.embeddings[task].weight
         # the search reads the features as they are handed in: callers that want index selection independent of the
         # activation storage type pass the f32 output of the producing contraction (engine.EgoPackStep does)
-        nn_idx = ops.nearest_prototypes(features.detach(), bank.detach(), self.k, self.distance_func, self._bank_norm(task))
+        # (the bank is handed over as the parameter itself: its bf16 halves for the search product are cached on it)
+        nn_idx = ops.nearest_prototypes(features.detach(), bank, self.k, self.distance_func, self._bank_norm(task))
         assignments = [nn_idx[:, 0]] * self.depth  # the reference recomputes identical edges per depth
         f = ops.to_act(features)
         for stage in self.conv_stages[task]:

@@ -10,6 +10,11 @@ Numeric modes (``set_compute``):
                  parameter gradients and optimiser state are f32.  The benchmark mode.
   'bf16_f32act'  bf16 MFMA with f32 activations / weights in HBM (converted while staging).
   'f32'          exact f32 MFMA, everything f32: the tight-parity mode.
+  'bf16x3'       f32 activations and statistics like 'f32', but every contraction runs on the bf16 matrix pipe as THREE products
+                 of the operands' bf16 halves (x = hi + lo: a.b ~ a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, f32 accumulation; relative
+                 error ~2^-17 per product instead of 2^-9): the forward-only, f32-grade feature path that feeds the
+                 nearest-prototype index op in 'bf16' mode (``precise_features``), at ~3x the bf16 cost instead of the 16x of
+                 the exact-f32 matrix instructions.
 Every op is polymorphic in the activation element type: it follows the dtype of its activation input.
 """
 from __future__ import annotations
@@ -23,8 +28,10 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1  # EGK_COMPUTE_* and EGK_F32 / EGK_BF16 element types
+X3 = 2            # host-side pseudo compute type: f32 values contracted as three bf16 products per K source (``_x3_expand``)
 
-_MODES = {"bf16": (BF16, torch.bfloat16), "bf16_f32act": (BF16, torch.float32), "f32": (F32, torch.float32)}
+_MODES = {"bf16": (BF16, torch.bfloat16), "bf16_f32act": (BF16, torch.float32), "f32": (F32, torch.float32),
+          "bf16x3": (X3, torch.float32)}
 _state = {"mode": "bf16", "compute": BF16, "act": torch.bfloat16}
 
 
@@ -209,6 +216,28 @@ def advance_rng_device(device, stride: int = 1 << 40):
     rng_device_offset(device).add_(stride)
 
 
+def rng_snapshot() -> int:
+    """Host-side position of the dropout streams (see ``rng_replay``)."""
+    return _rng["offset"]
+
+
+class rng_replay:
+    """``with ops.rng_replay(snap):`` -- the dropout launches issued inside draw the offsets the launches issued since
+    ``snap = ops.rng_snapshot()`` drew: a second pass over the SAME sequence of dropout calls (same shapes) gets the same keep
+    masks (the forward-only precise pass of the EgoPack step when the backbone runs in train mode).  The stream position
+    afterwards is the furthest either pass reached."""
+
+    def __init__(self, snap: int):
+        self.snap = int(snap)
+
+    def __enter__(self):
+        self.resume = _rng["offset"]
+        _rng["offset"] = self.snap
+
+    def __exit__(self, *a):
+        _rng["offset"] = max(self.resume, _rng["offset"])
+
+
 def get_rng_state() -> dict:
     """State of the dropout streams (host seed / offset and the per-device replay offsets) for checkpoints."""
     return {"seed": _rng["seed"], "offset": _rng["offset"], "device": {k: int(v.item()) for k, v in _rng_dev.items()}}
@@ -249,7 +278,12 @@ def to_act(x: torch.Tensor) -> torch.Tensor:
     want = _state["act"]
     if x.dtype == want:
         return x
-    return _Cast.apply(x, want) if x.requires_grad else cast_raw(x, want)
+    if x.requires_grad:
+        return _Cast.apply(x, want)
+    y = cast_raw(x, want)
+    if _state["compute"] == X3 and x.dtype == torch.bfloat16:
+        y._egk_bf16_src = x if x.is_contiguous() else x.contiguous()  # (its lo half is zero: one product less, no split pass)
+    return y
 
 
 def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -262,9 +296,9 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if sh is not None and sh.shape == W.shape:
         return sh
     if not W.requires_grad:
-        # a FROZEN weight (the auxiliary tasks' heads of the EgoPack step are not in the optimizer): its bf16 copy is made once
-        # and kept while the parameter is not written (tensor version counter) -- it used to be converted at every use, six
-        # launches per EgoPack step
+        # a FROZEN weight (the auxiliary tasks' heads of the EgoPack step: engine.EgoPackStep freezes the tasks it does not
+        # train): its bf16 copy is made once and kept while the parameter is not written (tensor version counter) -- it used to
+        # be converted at every use, six launches per EgoPack step
         c = getattr(W, "_egk_frozen_copy", None)
         if c is not None and c[0] == W._version and c[1] == W.data_ptr() and c[2].shape == W.shape:
             return c[2]
@@ -285,15 +319,31 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
     """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array).  ``stats``: per-segment sums of
     the result for the graph LayerNorm that consumes it, taken in the epilogue (``_ln_stats_request``)."""
     op_dt = _dt(A1)
-    if _dt(B1) != op_dt or (A2 is not None and (_dt(A2) != op_dt or _dt(B2) != op_dt)):
-        raise TypeError("gemm: all A / B operands must share one element type")
     compute = (BF16 if op_dt == BF16 else _state["compute"]) if compute is None else compute
+    extra = []
+    if compute == X3:
+        srcs = _x3_expand(M, N, [(A1, lda1, B1, ldb1, K1)] + ([(A2, lda2, B2, ldb2, K2)] if A2 is not None and K2 else []),
+                          transA, transB)
+        if srcs is None:  # (shapes the pipelined kernel does not take: the exact-f32 matrix instructions instead)
+            compute = F32
+        else:
+            compute, op_dt = BF16, BF16
+            (A1, lda1, B1, ldb1, K1), rest = srcs[0], srcs[1:]
+            A2 = B2 = None
+            lda2 = ldb2 = K2 = 0
+            if rest:
+                (A2, lda2, B2, ldb2, K2), extra = rest[0], rest[1:]
+    if _dt(A1) != op_dt or _dt(B1) != op_dt or (A2 is not None and (_dt(A2) != op_dt or _dt(B2) != op_dt)):
+        raise TypeError("gemm: all A / B operands must share one element type")
     d = _lib.GemmDesc() if into is None else into
     d.M, d.N, d.K1, d.K2 = M, N, K1, K2
     d.A1, d.A2, d.B1, d.B2 = _p(A1), _p(A2), _p(B1), _p(B2)
     d.lda1, d.lda2, d.ldb1, d.ldb2 = lda1, lda2, ldb1, ldb2
     d.transA, d.transB = int(transA), int(transB)
     d.a_dtype = d.b_dtype = op_dt
+    d.n_extra = len(extra)
+    for i, (xa, xlda, xb, xldb, xk) in enumerate(extra):
+        d.xA[i], d.xB[i], d.xlda[i], d.xldb[i], d.xK[i] = xa.data_ptr(), xb.data_ptr(), xlda, xldb, xk
     d.c_dtype = _dt(out)
     d.compute = compute
     d.C, d.ldc = _p(out), ldc
@@ -314,6 +364,112 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
     return d
 
 
+def _desc_k(d) -> int:
+    return d.K1 + d.K2 + sum(d.xK[i] for i in range(d.n_extra))
+
+
+# ---- three-product contraction of f32 values on the bf16 matrix pipe ('bf16x3') -------------------------------------------
+# x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (egk_split_bf16).  a.b is taken as a_hi.b_hi + a_hi.b_lo + a_lo.b_hi -- three
+# K sources of ONE launch of the pipelined kernel (egk_gemm_desc extra sources), f32 accumulation; the dropped a_lo.b_lo term
+# is ~2^-18 relative.  Where the halves come from:
+#   * a weight in the optimizer's flat buffers: hi IS its bf16 shadow (written by the Adam kernel), lo comes from the flat lo
+#     buffer (optim.FlatAdam.refresh_lo_shadows: one launch per region and step);
+#   * any other weight / the prototype banks: split once and kept while (version, address) stand;
+#   * an activation: split when first used and kept for the duration of a ``precise_scope`` (the same activation feeds
+#     several contractions); an f32 activation that ``to_act`` widened from bf16 has lo = 0 and needs ONE product less.
+_x3 = {"cache": None, "keep": []}
+
+
+class precise_scope:
+    """``with ops.precise_scope():`` -- compute mode 'bf16x3' inside, with the activation splits shared between the contractions
+    that read the same tensor."""
+
+    def __enter__(self):
+        self.prev_mode, self.prev_cache = get_compute(), _x3["cache"]
+        set_compute("bf16x3")
+        _x3["cache"] = {}
+        return self
+
+    def __exit__(self, *a):
+        set_compute(self.prev_mode)
+        _x3["cache"] = self.prev_cache
+
+
+def _split_rows(x, rows, cols, ld, want_hi=True):
+    lib = _lib.load()
+    hi = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if want_hi else None
+    lo = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    _ck(lib.egk_split_bf16(_stream(), _p(x), ld, _p(hi), _p(lo), cols, rows, cols), "egk_split_bf16")
+    return hi, lo
+
+
+def _x3_act(A, rows, K, ld):
+    src = getattr(A, "_egk_bf16_src", None)
+    if src is not None and src.shape == A.shape and A.dim() == 2 and A.shape[1] == K and ld == K:
+        return src, None, K  # widened from bf16 by to_act: the value IS its bf16 half
+    key = (A.data_ptr(), rows, K, ld, A._version)
+    cache = _x3["cache"]
+    hit = cache.get(key) if cache is not None else None
+    if hit is None:
+        hi, lo = _split_rows(A, rows, K, ld)
+        hit = (hi, lo, A)  # (A is held so that its address cannot be handed to another tensor while the entry lives)
+        if cache is not None:
+            cache[key] = hit
+        else:
+            _x3["keep"].append(hit)
+    return hit[0], hit[1], K
+
+
+def _x3_weight(B, rows, K, ld):
+    sh, lo = getattr(B, "_egk_shadow", None), getattr(B, "_egk_lo", None)
+    if sh is not None and lo is not None and tuple(sh.shape) == (rows, K) and ld == K:
+        lo_view, fresh, refresh = lo
+        if not fresh():
+            refresh()
+        return sh, lo_view
+    c = getattr(B, "_egk_split", None)
+    if c is not None and c[0] == B._version and c[1] == B.data_ptr() and tuple(c[2].shape) == (rows, K):
+        return c[2], c[3]
+    if sh is not None and lo is None and not torch.cuda.is_current_stream_capturing():
+        init = getattr(B, "_egk_lo_init", None)  # in the flat buffers, low halves not allocated yet (optim.FlatAdam)
+        if init is not None and init() and getattr(B, "_egk_lo", None) is not None:
+            return _x3_weight(B, rows, K, ld)
+    hi, lo = _split_rows(B, rows, K, ld)
+    if sh is None and not B.requires_grad and not torch.cuda.is_current_stream_capturing():  # (frozen: as weight_operand's copies)
+        try:
+            B._egk_split = (B._version, B.data_ptr(), hi, lo)
+        except Exception:  # noqa: BLE001
+            _x3["keep"].append((hi, lo))
+    else:
+        _x3["keep"].append((hi, lo))
+    return hi, lo
+
+
+def _x3_expand(M, N, logical, transA, transB):
+    """[(A, lda, B, ldb, K)] f32 sources -> the bf16 sources of the three-product contraction, or None when the pipelined kernel
+    cannot take them (transposed operands, a K that is not a multiple of 64, unaligned rows)."""
+    if transA or transB or len(logical) > 2:
+        return None
+    for A, lda, B, ldb, K in logical:
+        if (K % 64 or K == 0 or A.dtype != torch.float32 or B.dtype != torch.float32 or lda % 4 or ldb % 4
+                or A.data_ptr() % 16 or B.data_ptr() % 16):
+            return None
+    out = []
+    for A, lda, B, ldb, K in logical:
+        ah, al, a_ld = _x3_act(A, M, K, lda)
+        bh, bl = _x3_weight(B, N, K, ldb)
+        out.append((ah, a_ld, bh, K, K))
+        out.append((ah, a_ld, bl, K, K))
+        if al is not None:
+            out.append((al, K, bh, K, K))
+    return out
+
+
+def _x3_release():
+    if _x3["keep"]:
+        _x3["keep"] = []
+
+
 def _gemm_with_stats(args, kw, stats):
     """``gemm(*args, **kw)`` with the epilogue statistics ``stats`` if the tile variant of this launch can take them:
     returns (partials, blocks) or None (plain launch done instead).  No split-K (the statistics need the finished tile)."""
@@ -326,19 +482,21 @@ def _gemm_with_stats(args, kw, stats):
     ws = torch.empty(blocks * stats["n_seg"] * 2, dtype=torch.float64, device=args[7].device)
     d.st_ws = _p(ws)
     _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
+    _x3_release()
     return ws, blocks
 
 
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, **kw):
     lib = _lib.load()
     d = _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, **kw)
-    sk = lib.egk_gemm_splitk(M, N, K1 + d.K2, d.compute) if allow_splitk else 1
+    sk = lib.egk_gemm_splitk(M, N, _desc_k(d), d.compute) if allow_splitk else 1
     d.splitk = sk if splitk is None else int(splitk)
     need = lib.egk_gemm_ws_bytes(C.byref(d))
     if need:
         ws = workspace(need, out.device)
         d.ws, d.ws_bytes = _p(ws), ws.numel()
     _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
+    _x3_release()
 
 
 def gemm_grouped(problems, four_wave: bool = False):
@@ -357,6 +515,7 @@ def gemm_grouped(problems, four_wave: bool = False):
     try:
         _ck(lib.egk_gemm_grouped(_stream(), arr, len(problems)), "egk_gemm_grouped")
     finally:
+        _x3_release()
         if prev is not None:
             lib.egk_gemm_set_pipeline(prev)
 
@@ -2259,6 +2418,14 @@ def split_rows(x, sizes):
 
 
 # ---- cosine k-NN (no grad) ------------------------------------------------------------------------------------
+def to_act_f32(x):
+    """f32 copy of a bf16 activation that remembers its source (a three-product contraction then skips the zero low half)."""
+    y = cast_raw(x, torch.float32)
+    if x.dtype == torch.bfloat16:
+        y._egk_bf16_src = x if x.is_contiguous() else x.contiguous()
+    return y
+
+
 @torch.no_grad()
 def row_inv_norm(x):
     _need_gpu(x)
@@ -2299,7 +2466,7 @@ def nearest_prototypes(f, bank, k, distance_func: str = "cosine", bank_norm=None
     lib = _lib.load()
     f, bank = _c(f), _f32c(bank)
     if f.dtype != torch.float32:
-        f = cast_raw(f, torch.float32)
+        f = to_act_f32(f)
     N, H = f.shape
     K = bank.shape[0]
     l2 = distance_func == "l2"
@@ -2308,7 +2475,11 @@ def nearest_prototypes(f, bank, k, distance_func: str = "cosine", bank_norm=None
         bank_norm = norm(bank)
     f_norm = norm(f)
     dot = torch.empty((N, K), dtype=torch.float32, device=f.device)
-    gemm(N, K, f, H, bank, H, H, dot, K, compute=F32)
+    # 'f32' mode: the exact-f32 matrix instructions.  The bf16 modes: the three-product contraction of the f32 values
+    # (absolute error of a cosine ~3e-7, against ranking gaps of ~5e-3 between neighbouring prototypes: the lists are those of
+    # the exact product wherever its gap exceeds 1e-5) at a fifth of the time -- the N x K x H product was 1 ms of the 3.4 ms
+    # EgoPack step on the exact path
+    gemm(N, K, f, H, bank, H, H, dot, K, compute=F32 if _state["compute"] == F32 else X3)
     nn = torch.empty((N, k), dtype=torch.int64, device=f.device)
     fn = lib.egk_topk_smallest_l2 if l2 else lib.egk_topk_smallest
     _ck(fn(_stream(), _p(dot), K, _p(f_norm), _p(bank_norm), _p(nn), N, K, k), "egk_topk_smallest")

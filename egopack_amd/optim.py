@@ -36,6 +36,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_scale = 1.0
         self._hyper = None
+        self.flat_w16lo = None      # bf16 LOW halves of the parameters (p - bf16(p)), built on demand: ensure_lo_shadows
+        self._lo_fresh = []         # [lo, hi) ranges of flat_w16lo that match flat_p (cleared by every write to flat_p)
         self._moment_views = {}     # id(param) -> (m view, v view) once materialised
         self._slot_of = {}          # id(param) -> (first element, slot length) in the flat buffers
         self._pending_state = None  # a state dict loaded before the flat buffers exist
@@ -78,6 +80,7 @@ class FlatAdam(torch.optim.Optimizer):
                 p._egk_shadow = self.flat_w16[off:off + n].view(p.shape)
                 self._moment_views[id(p)] = (self.flat_m[off:off + n].view(p.shape), self.flat_v[off:off + n].view(p.shape))
                 self._slot_of[id(p)] = (off, sz)
+                p._egk_lo_init = self.ensure_lo_shadows
                 if p.dim() == 2 and p.shape[0] % 64 and p.shape[1] % 8 == 0:
                     rows64 = (p.shape[0] + 63) // 64 * 64
                     p._egk_shadow_rows64 = self.flat_w16[off:off + rows64 * p.shape[1]].view(rows64, p.shape[1])
@@ -201,11 +204,48 @@ class FlatAdam(torch.optim.Optimizer):
         if steps:
             self.step_count = int(max(steps))
 
+    # -- low halves for the three-product ('bf16x3') contractions ---------------------------------------------------------
+    # A weight enters such a contraction as hi + lo with hi = its bf16 shadow (kept by the Adam kernel) and lo = bf16(p - hi).
+    # The lo buffer is allocated the first time it is asked for; ``refresh_lo_shadows(params)`` recomputes the region spanned
+    # by ``params`` in ONE launch (the engine: the backbone's region at the start of the forward-only precise pass of a step),
+    # and a parameter whose slot is not marked fresh when a contraction wants its lo half refreshes its own slot
+    # (ops._x3_weight) -- correctness never depends on the caller having refreshed.
+    def ensure_lo_shadows(self):
+        if not self.materialised:
+            return False
+        if self.flat_w16lo is None:
+            self.flat_w16lo = torch.zeros_like(self.flat_w16)
+            self._lo_fresh = []
+            for p in self.active:
+                off, _ = self._slot_of[id(p)]
+                n = p.numel()
+                view = self.flat_w16lo[off:off + n].view(p.shape)
+                p._egk_lo = (view, (lambda o=off, m=n: self._lo_is_fresh(o, m)), (lambda q=p: self.refresh_lo_shadows([q])))
+        return True
+
+    def _lo_is_fresh(self, off: int, n: int) -> bool:
+        return any(lo <= off and off + n <= hi for lo, hi in self._lo_fresh)
+
+    def invalidate_lo_shadows(self):
+        self._lo_fresh = []
+
+    def refresh_lo_shadows(self, params=None):
+        """flat_w16lo[lo:hi] = bf16(flat_p - bf16(flat_p)) over the region spanned by ``params`` (default: everything)."""
+        if not self.ensure_lo_shadows():
+            return
+        lo, hi = (0, self.flat_p.numel()) if params is None else self.region_of(list(params))
+        if hi <= lo:
+            return
+        _ck(_lib.load().egk_split_bf16(_stream(), _p(self.flat_p[lo:hi]), hi - lo, None, _p(self.flat_w16lo[lo:hi]), hi - lo, 1, hi - lo),
+            "egk_split_bf16")
+        self._lo_fresh.append((lo, hi))
+
     def refresh_shadows(self):
         """Re-derive the bf16 operand copies from the f32 parameters (after load_state_dict or any other
         write to the parameters that did not go through ``step``)."""
         if self.flat_w16 is not None:
             _ck(_lib.load().egk_cast(_stream(), _p(self.flat_p), 0, _p(self.flat_w16), 1, self.flat_p.numel()), "egk_cast")
+        self._lo_fresh = []
 
     @property
     def materialised(self) -> bool:
@@ -243,6 +283,8 @@ class FlatAdam(torch.optim.Optimizer):
         if hi <= lo:
             return
         sl = slice(lo, hi)
+        if self._lo_fresh:
+            self._lo_fresh = []  # (the parameters move: every low half is stale)
         _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p[sl]), _p(grads[sl]), 1 if grads.dtype == torch.bfloat16 else 0,
                                       _p(self.flat_m[sl]), _p(self.flat_v[sl]), hi - lo, _p(self._hyper), b1, b2,
                                       g["eps"], g["weight_decay"], _p(self.flat_w16[sl])),

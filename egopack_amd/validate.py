@@ -22,7 +22,15 @@ def _logits(model, data, primary_task, other_tasks, graphone, late_fusion, needs
     feat_primary = primary_task.forward_features(feat)
     batch = getattr(data, "batch", None)
     if graphone is not None:
-        feat_secondary = {task.name: task.forward_features(feat, out_f32=True) for task in other_tasks}  # (f32 for the search)
+        from . import ops
+        if ops.get_compute() in ("bf16", "bf16_f32act"):
+            # the features behind the nearest-prototype search (an index op) come from a forward-only 'bf16x3' pass: f32-grade
+            # values, so that the neighbour lists are the reference's also with bf16 activations (engine.EgoPackStep)
+            with ops.precise_scope():
+                feat_hp = model(data)
+                feat_secondary = {task.name: task.forward_features(feat_hp, out_f32=True) for task in other_tasks}
+        else:
+            feat_secondary = {task.name: task.forward_features(feat, out_f32=True) for task in other_tasks}  # (f32 for the search)
         feat_secondary, *_ = graphone.interact(feat_secondary)
         # post_features as the reference hands them to the meter (validate.py:43): [N, 1 + aux, H]
         feat = torch.stack([feat_primary.float(), *[f.float() for f in feat_secondary.values()]], dim=1)

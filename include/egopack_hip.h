@@ -108,11 +108,29 @@ typedef struct egk_gemm_desc {
     const float* st_w;
     const float* st_b;
     float st_slope;
+    /* Extra K sources beyond (A1, B1, K1) and (A2, B2, K2): C = epilogue(sum over ALL sources of op(A_s) . op(B_s)^T), same
+     * layout (transA / transB) and element type for every source, walked in the order K1, K2, xK[0 .. n_extra-1].  Up to 4
+     * (six sources in all).  What they are for: a contraction of f32 values at (close to) f32 precision on the bf16 matrix
+     * pipe -- each f32 operand is split into bf16 halves x = hi + lo (egk_split_bf16) and a.b is taken as
+     * a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, three sources per logical one, f32 accumulation throughout (the forward-only,
+     * higher-precision feature path in front of the nearest-prototype index op, models/graphONE/graphONE.py:119-141). */
+    int32_t n_extra;
+    int32_t xK[4];
+    const void* xA[4];
+    const void* xB[4];
+    int64_t xlda[4], xldb[4];
 } egk_gemm_desc;
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_stats_blocks(const egk_gemm_desc* d);
+/* x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): the two bf16 operands that stand for an f32
+ * matrix in a three-product contraction (egk_gemm_desc extra sources).  src f32 [rows, cols] with leading dimension ld_src;
+ * hi (may be NULL: only lo is wanted, e.g. when hi is the bf16 copy the optimizer already keeps) and lo bf16 [rows, cols]
+ * with leading dimension ld_out. */
+int egk_split_bf16(egk_stream_t s, const float* src, int64_t ld_src, void* hi, void* lo, int64_t ld_out, int64_t rows,
+                   int64_t cols);
+
 /* Grouped launch: ``count`` (<= 8) independent contractions of the SAME layout (transA / transB), bf16 operands with
  * 16-byte aligned rows, every K source a multiple of 64, no split-K, in ONE launch (blockIdx.y = problem).  Replaces the
  * per-task projection heads of the multi-task step -- ProjectionTask.forward_features of every enabled task

@@ -29,12 +29,12 @@ Stated tolerances
       loss vectors      relative Frobenius error <= BF16_LOSS
       objective         relative BF16_OBJ
       gradients         relative Frobenius error <= BF16_GRAD[config] per parameter tensor (tensors with a non-negligible norm)
-      nearest-prototype indices (#4): exact given the same f32 projection outputs; against the f32 oracle end to end the
-      agreement rate is asserted >= BF16_KNN_ORDERED position by position and >= BF16_KNN_SETS as neighbour sets (the
-      upstream activations differ by bf16 rounding, so near-ties flip).  With the synthetic N(0,1) banks of SURVEY 8d the
-      max aggregation is dominated by the prototype rows, so a changed neighbour moves the logits visibly: the arithmetic
-      tolerances of #4 in bf16 mode are therefore taken against the oracle run on the SAME neighbour lists, and the logit
-      change caused by the differing lists is measured and reported on its own
+      nearest-prototype indices (#4): the features behind the search come from the forward-only 'bf16x3' pass (f32-grade
+      values, engine.EgoPackStep.precise_aux_features), the search product is a three-product contraction: given the same
+      features the lists are the oracle's wherever the fp64 ranking gap exceeds 1e-5, and END TO END against the f32 oracle
+      (its own features, its own lists) the agreement is asserted >= BF16_KNN_ORDERED position by position (identical
+      wherever the gap exceeds 1e-5) -- round 2 measured 95 % here, with the search fed by the bf16 pass.  The logits of #4
+      in bf16 mode are compared with the oracle on ITS OWN lists (<= BF16_C4_LOGITS relative Frobenius).
 """
 import argparse
 
@@ -59,7 +59,7 @@ CONFIGS = {
     "x5_mtl3_B16_T256": dict(workload="mtl", batch=16, T=256),
 }
 LR, WD = 1e-3, 1e-5
-BF16_LOSS, BF16_OBJ, BF16_KNN_ORDERED, BF16_KNN_SETS = 1.5e-2, 5e-3, 0.93, 0.98
+BF16_LOSS, BF16_OBJ, BF16_KNN_ORDERED, BF16_KNN_SETS, BF16_C4_LOGITS = 1.5e-2, 5e-3, 0.999, 0.9995, 3e-2
 # bf16-mode gradient bound per configuration (relative Frobenius error of the worst parameter tensor; measured values in
 # profiles/r02_config_parity.md).  The OSCC head pools every sequence with a max over its T nodes: under bf16 rounding a
 # near-tie between two nodes resolves the other way for a few (sequence, channel) pairs and their gradient rows move to
@@ -198,15 +198,8 @@ def test_config_step_vs_oracle(name, mode):
     prev = ops.get_compute()
     try:
         args, step, opt, dev, merged, modules, sds, weights = _build(name, mode)
-        override = None
-        if mode == "bf16" and args.workload == "egopack_oscc":  # the step's own neighbour lists (deterministic search)
-            step.losses(dev)
-            with torch.no_grad():
-                feat = step.features(dev)["oscc"]
-                override = {t: ops.nearest_prototypes(step.tasks[t].forward_features(feat, out_f32=True),
-                                                      step.graphone.embeddings[t].weight, args.graphone_k).cpu()
-                            for t in ("ar", "lta", "pnr")}
-        ref = _oracle(name, args, sds, dev, weights, closest_override=override)
+        # (#4 in bf16 mode: against the oracle on ITS OWN neighbour lists -- the search is fed by the f32-grade pass)
+        ref = _oracle(name, args, sds, dev, weights)
         total, vectors = step.forward_backward(dev, merged)
         torch.cuda.synchronize()
         grads = {g: {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
@@ -295,14 +288,13 @@ def test_config4_prototype_indices_f32_vs_oracle():
 
 
 def test_config4_prototype_indices_in_bf16_mode():
-    """The index op in the BENCHMARK dtype at K = 4096 / H = 1024.
-      (a) exact given the same activations: the search ranks the f32 accumulators of the aux projections' last contraction
-          (not their bf16 roundings) on the exact-f32 path; fed those very values, the oracle's argsort picks the same
-          prototypes wherever the ranking gap exceeds 1e-5;
-      (b) end to end against the f32 oracle the upstream activations carry bf16 rounding, so near-ties flip: the agreement
-          rate is measured and asserted (>= BF16_KNN_ORDERED position by position, >= BF16_KNN_SETS as sets); what the
-          differing lists do to the logits is measured by running the oracle with the HIP path's neighbour lists in place of
-          its own (reported), and given the SAME lists the bf16-mode logits are within 3e-2 of the oracle's."""
+    """The index op in the BENCHMARK dtype at K = 4096 / H = 1024 (round-2 verdict, item 1).
+      (a) given the same features: fed the very f32 values the HIP path ranks, the oracle's argsort picks the same prototypes
+          wherever the fp64 ranking gap exceeds 1e-5 (the search product is a three-product contraction in this mode);
+      (b) END TO END against the f32 oracle (its own backbone, projections and lists): >= BF16_KNN_ORDERED position by position
+          and identical wherever the oracle's gap exceeds 1e-5 -- the features behind the search come from the forward-only
+          'bf16x3' pass, not from the bf16 activations of the training pass;
+      (c) the bf16-mode logits against the oracle on ITS OWN lists: <= BF16_C4_LOGITS relative Frobenius."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from egopack_amd import ops
@@ -311,13 +303,14 @@ def test_config4_prototype_indices_in_bf16_mode():
     try:
         args, step, opt, dev, merged, modules, sds, weights = _build(name, "bf16")
         ref = _oracle(name, args, sds, dev, weights)
-        step.losses(dev)
+        step.losses(dev)  # (sets the train / eval modes of the step)
+        assert step._precise_on()
         with torch.no_grad():
-            feat = step.features(dev)["oscc"]
-            aux_in = {t: step.tasks[t].forward_features(feat, out_f32=True) for t in ("ar", "lta", "pnr")}
+            aux_in = step.precise_aux_features(dev)["oscc"]
             assert all(a.dtype == torch.float32 for a in aux_in.values())
             nn = {t: ops.nearest_prototypes(aux_in[t], step.graphone.embeddings[t].weight, args.graphone_k).cpu() for t in aux_in}
-            loss, logits, aux, closest = step.task_loss("oscc", feat, dev["oscc"])
+            feat = step.features(dev)["oscc"]
+            loss, logits, aux, closest = step.task_loss("oscc", feat, dev["oscc"], aux_in=aux_in)
     finally:
         ops.set_compute(prev)
     k = args.graphone_k
@@ -325,28 +318,23 @@ def test_config4_prototype_indices_in_bf16_mode():
     for t in nn:
         bank = sds["graphone"][f"embeddings.{t}.weight"]
         f_gpu = aux_in[t].cpu()
-        _, same_act = O.compute_edges(f_gpu, bank, k)  # (a): the oracle on the SAME activations
-        dist = O.cos_dissimilarity(f_gpu.double(), bank.double())
-        srt = dist.sort(dim=-1).values
+        feat_err = _rel(f_gpu, ref["aux_in"][t])
+        _, same_act = O.compute_edges(f_gpu, bank, k)  # (a): the oracle on the SAME features
+        srt = O.cos_dissimilarity(f_gpu.double(), bank.double()).sort(dim=-1).values
         safe = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values > 1e-5
         assert safe.float().mean() > 0.97, t
         assert torch.equal(nn[t][safe], same_act[safe]), t
-        assert float((nn[t] == same_act).float().mean()) > 0.995, t
-        rates[t] = {"ordered": float((nn[t] == ref["closest"][t]).float().mean()),  # (b): against the f32 oracle
+        assert torch.equal(closest[t][0].cpu(), nn[t][:, 0])  # what interact() reports = column 0 of the same search
+        # (b): end to end
+        srt_o = O.cos_dissimilarity(ref["aux_in"][t].double(), bank.double()).sort(dim=-1).values
+        safe_o = (srt_o[:, 1:k + 1] - srt_o[:, :k]).min(dim=1).values > 1e-5
+        rates[t] = {"ordered": float((nn[t] == ref["closest"][t]).float().mean()),
                     "as_sets": float(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(nn[t], ref["closest"][t]))
-                                     / nn[t].numel())}
+                                     / nn[t].numel()),
+                    "ordered_where_gap_gt_1e-5": float((nn[t][safe_o] == ref["closest"][t][safe_o]).float().mean()),
+                    "feature_rel_err": feat_err}
         assert rates[t]["ordered"] >= BF16_KNN_ORDERED and rates[t]["as_sets"] >= BF16_KNN_SETS, (t, rates[t])
-    # what the differing neighbour lists do to the logits: the oracle on the HIP path's lists against the oracle on its own
-    # (nothing else differs between those two runs), and the HIP path against the oracle on the SAME lists (bf16 arithmetic)
-    d = _odata(dev["oscc"])
-    tsd = {t: sds[n] for t, n in NAMES.items()}
-    with torch.no_grad():
-        _, logits_swapped, _, _ = O.egopack_task_loss("oscc", tsd, sds["graphone"], ref["feat"], d.batch, d.y, ("ar", "lta", "pnr"),
-                                                      k, args.graphone_depth, True, True, num_graphs=d.num_graphs,
-                                                      closest_override=nn)
-    flip_effect = _rel(logits_swapped, ref["logits"])
-    same_lists = _rel(logits.float().cpu(), logits_swapped)
+        assert feat_err < 5e-4, (t, feat_err)
     end_to_end = _rel(logits.float().cpu(), ref["logits"])
-    _report(name, "bf16-indices", {"agreement": rates, "logit_rel_from_differing_lists": flip_effect,
-                                   "logit_rel_given_same_lists": same_lists, "logit_rel_end_to_end": end_to_end})
-    assert same_lists < 3e-2, same_lists
+    _report(name, "bf16-indices", {"agreement": rates, "logit_rel_end_to_end": end_to_end})
+    assert end_to_end < BF16_C4_LOGITS, end_to_end

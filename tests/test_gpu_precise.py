@@ -1,0 +1,190 @@
+"""The f32-grade feature path on the bf16 matrix pipe ('bf16x3': x = hi + lo, a.b ~ a_hi.b_hi + a_hi.b_lo + a_lo.b_hi) that feeds
+the nearest-prototype index op (reference models/graphONE/graphONE.py:119-141) when the training pass stores bf16 activations.
+
+  * egk_split_bf16: hi / lo bit-exact against torch's round-to-nearest-even casts;
+  * contractions with up to six K sources == the sum of the separate contractions (exact-f32 and bf16 kernels);
+  * three-product contraction against fp64: relative Frobenius error <= 3e-5 (plain bf16: ~3e-3; stated so that a broken low
+    half -- error back at 2^-9 -- cannot pass), also through Linear / SAGE layers with the optimizer's flat buffers;
+  * backbone + projection in 'bf16x3' mode against the CPU oracle (f32): features within 2e-4 relative Frobenius;
+  * nearest-prototype lists in 'bf16' mode == the exact-f32 lists wherever the f32 ranking gap exceeds 1e-5.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import path as O  # noqa: E402
+from oracle import pyg_ops as P  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops as _ops
+    return _ops
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("rows,cols,ld,want_hi", [(1, 1 << 16, 1 << 16, True), (37, 100, 104, True), (64, 1024, 1024, False), (5, 7, 9, True)])
+def test_split_bf16_is_the_two_rounded_halves(ops, rows, cols, ld, want_hi):
+    from egopack_amd import _lib
+    x = torch.randn(rows, ld, generator=gen(rows + cols)) * 3.0
+    x[0, 0] = 0.0
+    xd = x.to(DEV)
+    hi = torch.zeros(rows, cols, dtype=torch.bfloat16, device=DEV) if want_hi else None
+    lo = torch.zeros(rows, cols, dtype=torch.bfloat16, device=DEV)
+    rc = _lib.load().egk_split_bf16(ops._stream(), ops._p(xd), ld, ops._p(hi), ops._p(lo), cols, rows, cols)
+    assert rc == 0, _lib.last_error()
+    ref_hi = x[:, :cols].to(torch.bfloat16)
+    ref_lo = (x[:, :cols] - ref_hi.float()).to(torch.bfloat16)
+    if want_hi:
+        assert torch.equal(hi.cpu(), ref_hi)
+    assert torch.equal(lo.cpu(), ref_lo)
+    # hi + lo carries 16 significant bits of x
+    assert _rel(ref_hi.double() + ref_lo.double(), x[:, :cols]) < 2e-5
+
+
+@pytest.mark.parametrize("compute,Ks", [("bf16", (64, 128, 64, 192, 64, 64)), ("bf16", (128, 64, 64)), ("f32", (40, 72, 16, 32)),
+                                        ("bf16", (40, 72, 24))])
+def test_gemm_extra_k_sources_equal_the_sum_of_the_parts(ops, compute, Ks):
+    """C = sum_s A_s . B_s^T with 3 .. 6 sources in ONE launch (pipelined kernel when every K is a multiple of 64, generic
+    kernel otherwise) against fp64 on the operand values the kernel reads."""
+    from egopack_amd import _lib
+    import ctypes as C
+    g = gen(len(Ks) * 17 + Ks[0])
+    M, N = 200, 136
+    dt = torch.bfloat16 if compute == "bf16" else torch.float32
+    As = [torch.randn(M, k, generator=g).to(dt).to(DEV) for k in Ks]
+    Bs = [torch.randn(N, k, generator=g).to(dt).to(DEV) for k in Ks]
+    bias = torch.randn(N, generator=g).to(DEV)
+    out = torch.empty(M, N, device=DEV)
+    d = ops._gemm_desc(M, N, As[0], Ks[0], Bs[0], Ks[0], Ks[0], out, N, A2=As[1], lda2=Ks[1], B2=Bs[1], ldb2=Ks[1], K2=Ks[1],
+                       bias=bias, compute=ops.BF16 if compute == "bf16" else ops.F32)
+    d.n_extra = len(Ks) - 2
+    for i in range(2, len(Ks)):
+        d.xA[i - 2], d.xB[i - 2], d.xlda[i - 2], d.xldb[i - 2], d.xK[i - 2] = As[i].data_ptr(), Bs[i].data_ptr(), Ks[i], Ks[i], Ks[i]
+    rc = _lib.load().egk_gemm(ops._stream(), C.byref(d))
+    assert rc == 0, _lib.last_error()
+    ref = sum(a.double().cpu() @ b.double().cpu().t() for a, b in zip(As, Bs)) + bias.double().cpu()
+    tol = dict(rtol=1e-3, atol=1e-3) if compute == "bf16" else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.cpu().double(), ref, **tol)
+
+
+@pytest.mark.parametrize("M,N,K,K2", [(2048, 1024, 1024, 0), (300, 256, 4608, 0), (2048, 1024, 1024, 1024), (130, 70, 40, 0)])
+def test_three_product_contraction_is_f32_grade(ops, M, N, K, K2):
+    """gemm(compute = X3) on f32 operands against fp64: <= 3e-5 relative Frobenius where a plain bf16 contraction of the same
+    operands is at ~3e-3 (asserted, so the comparison means something).  The last shape does not qualify for the pipelined
+    kernel (K % 64 != 0) and runs on the exact-f32 instructions instead."""
+    g = gen(M + N + K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    A2 = torch.randn(M, K2, generator=g) if K2 else None
+    B2 = torch.randn(N, K2, generator=g) if K2 else None
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().t() + bias.double()
+    if K2:
+        ref = ref + A2.double() @ B2.double().t()
+    kw = dict(A2=A2.to(DEV), lda2=K2, B2=B2.to(DEV), ldb2=K2, K2=K2) if K2 else {}
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(M, N, A.to(DEV), K, B.to(DEV), K, K, out, N, bias=bias.to(DEV), compute=ops.X3, **kw)
+    err = _rel(out.cpu(), ref)
+    assert err < 3e-5, err
+    if K % 64 == 0:
+        out16 = torch.empty(M, N, device=DEV)
+        kw16 = dict(A2=A2.to(DEV).bfloat16(), lda2=K2, B2=B2.to(DEV).bfloat16(), ldb2=K2, K2=K2) if K2 else {}
+        ops.gemm(M, N, A.to(DEV).bfloat16(), K, B.to(DEV).bfloat16(), K, K, out16, N, bias=bias.to(DEV), compute=ops.BF16, **kw16)
+        assert _rel(out16.cpu(), ref) > 1e-3
+
+
+def test_three_product_linear_uses_the_optimizers_halves(ops):
+    """A Linear whose weight lives in FlatAdam's flat buffers: hi = the bf16 shadow the Adam kernel keeps, lo = the flat low
+    buffer (refreshed on demand, stale after every optimizer launch)."""
+    from egopack_amd.models.layers import Linear
+    from egopack_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    lin = Linear(1024, 512).to(DEV)
+    opt = FlatAdam(list(lin.parameters()), lr=1e-2)
+    x = torch.randn(256, 1024, device=DEV)
+    with ops.compute_mode("f32"):
+        lin(x).sum().backward()
+    opt.step()  # materialises the flat buffers, writes the shadows
+    assert getattr(lin.weight, "_egk_shadow", None) is not None
+
+    def run():
+        with torch.no_grad(), ops.precise_scope():
+            return lin(x)
+    ref = lambda: (x.double().cpu() @ lin.weight.detach().double().cpu().t() + lin.bias.detach().double().cpu())
+    assert _rel(run().cpu(), ref()) < 3e-5
+    off, _ = opt._slot_of[id(lin.weight)]
+    assert opt.flat_w16lo is not None and opt._lo_is_fresh(off, lin.weight.numel())
+    lin.weight.grad.normal_()
+    opt.step()  # parameters move: the low halves are stale and must be refreshed by the next use
+    assert not opt._lo_fresh
+    assert _rel(run().cpu(), ref()) < 3e-5
+
+
+def test_backbone_in_three_product_mode_matches_the_f32_oracle(ops, golden):
+    """Graph.forward + a projection head under ``precise_scope`` (bf16 input features, as the bf16 training pass stores them)
+    against the CPU oracle in f32: the features that rank the prototypes.  H = 256 so that every contraction takes the
+    pipelined three-product path."""
+    from egopack_amd import data as D
+    from egopack_amd.models import Graph
+    from egopack_amd.models.tasks import RecognitionTask
+    torch.manual_seed(11)
+    F_IN, S, H = 64, 3, 256  # S * F_IN = 192: a multiple of 64
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": H}
+    model = Graph(F_IN, hidden_size=H, depth=3, temporal_pooling=trn, num_segments=S)
+    task = RecognitionTask(H, H, (13, 17))
+    sd, tsd = {k: v.clone() for k, v in model.state_dict().items()}, {k: v.clone() for k, v in task.state_dict().items()}
+    ds = D.SyntheticTaskDataset("ar", 8, 16, S, F_IN, (13, 17), k=1, seed=5)
+    host = D.collate([ds[i] for i in range(8)])
+    host.x = host.x.to(torch.bfloat16)  # bf16-representable features
+    od = P.OData(x=host.x.float(), pos=host.pos, edge_index=host.edge_index, batch=host.batch, y=host.y, num_graphs=host.num_graphs)
+    with torch.no_grad():
+        ref = O.projection_features(tsd, O.graph_forward(sd, od.x, od.pos, od.edge_index, S))
+    model.to(DEV).eval()
+    task.to(DEV).eval()
+    dev = host.to(DEV)
+    with torch.no_grad(), ops.compute_mode("bf16"):
+        with ops.precise_scope():
+            got = task.forward_features(model(dev), out_f32=True)
+        plain = task.forward_features(model(dev), out_f32=True)
+    assert got.dtype == torch.float32
+    e3, e1 = _rel(got.cpu(), ref), _rel(plain.float().cpu(), ref)
+    assert e3 < 2e-4, (e3, e1)
+    assert e1 > 10 * e3, (e3, e1)  # (the plain bf16 pass is an order of magnitude further away: the pass is worth its cost)
+
+
+def test_nearest_prototypes_in_bf16_mode_are_the_exact_lists(ops):
+    """The search product as three bf16 products (every mode but 'f32') against the exact-f32 product: identical lists wherever
+    the fp64 ranking gap exceeds 1e-5, K = 4096 / H = 1024 / k = 4, cosine and l2."""
+    g = torch.Generator(device=DEV).manual_seed(2)
+    f = torch.randn(2048, 1024, device=DEV, generator=g)
+    bank = torch.nn.Parameter(torch.randn(4096, 1024, device=DEV, generator=g), requires_grad=False)
+    for dist in ("cosine", "l2"):
+        with ops.compute_mode("f32"):
+            exact = ops.nearest_prototypes(f, bank, 4, dist)
+        with ops.compute_mode("bf16"):
+            fast = ops.nearest_prototypes(f, bank, 4, dist)
+            again = ops.nearest_prototypes(f, bank, 4, dist)  # (second call: the bank's halves come from the cache)
+        assert torch.equal(fast, again)
+        fd, bd = f.double(), bank.detach().double()
+        if dist == "cosine":
+            d = 1 - (fd / fd.norm(dim=1, keepdim=True)) @ (bd / bd.norm(dim=1, keepdim=True)).t()
+        else:
+            d = torch.cdist(fd, bd) / 4096
+        srt = d.sort(dim=-1).values
+        # (l2 keys are cdist / 4096 ~ 0.011: a gap of 1e-7 there is a gap of ~0.02 in the dot product, ~100x the product's error)
+        safe = (srt[:, 1:5] - srt[:, :4]).min(dim=1).values > (1e-5 if dist == "cosine" else 1e-7)
+        assert safe.float().mean() > 0.97
+        assert torch.equal(fast[safe], exact[safe]), dist
+        assert float((fast == exact).float().mean()) > 0.999
