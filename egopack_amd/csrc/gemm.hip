@@ -1209,6 +1209,155 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
     gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 128, wn * 64, lr, lg, z);
 }
 
+// ---- exact-f32 pipelined contraction: f32 operands in memory, every K source a multiple of 32 -----------------------------
+// The reference computes in f32; this is the kernel of the 'f32' compute mode (v_mfma_f32_16x16x4_f32: an exact, k-ordered fmaf
+// chain at 1/16 of the bf16 matrix rate).  Same structure as gemm_pipe_kernel -- LDS-DMA staging (no VGPR staging, no
+// ds_write), a 2-stage ring of (A image | B image), ONE raw s_barrier per K tile, XCD-local tile order, row-contiguous
+// epilogue -- with a 32-deep K tile, so that an image is again 128 rows x 128 B (row-major operand) or 32 k-rows x 512 B
+// (operand transposed in memory):
+//   * row-major operand: image [128 rows][32 k] f32, 16-byte chunk index XOR (row >> 1) & 7, fragments by ds_read_b128: the
+//     four floats of a lane's chunk feed four consecutive MFMAs (k = 16 s + 4 lg + q);
+//   * transposed operand ([K][rows] in memory): the image keeps the memory order [32 k][128 rows]; a lane reads ITS (row, k)
+//     element with ds_read_b32; 16-byte chunk index XOR ((k >> 2) & 3) << 2 puts the two k-rows a 32-lane half touches on
+//     disjoint bank halves.
+// The matrix pipe needs 128 MFMAs x 32 cycles = 4096 cycles per wave and K tile against 8 DMA pieces and 16-64 LDS reads: the
+// loop is MFMA-issue bound, the next step's fragments are read while this step's MFMAs run.  Every accumulator sees the
+// k-ordered chain of the register-staged generic kernel: results are bit-identical to it.
+template <bool TR, int NP>
+__device__ __forceinline__ void cursor32_init(const float* (&p)[NP], long long& step, const float* __restrict__ base, long long ld,
+                                              int rows_total, int row0, int k0, int first, int lane) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = first + i;  // 0 .. 15 of the 16-KiB image
+        if constexpr (TR) {           // piece = 2 k-rows of 512 B; lane -> (k = 2 piece + lane / 32, chunk slot = lane % 32)
+            const int k = piece * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ (((k >> 2) & 3) << 2);
+            int col = row0 + c * 4;
+            if (col + 4 > ld) col = 0;  // (beyond the allocated row: feeds output rows that are never stored)
+            p[i] = base + (long long)(k0 + k) * ld + col;
+        } else {                      // piece = 8 rows of 128 B; lane -> (row = 8 piece + lane / 8, chunk slot = lane % 8)
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            p[i] = base + (long long)min(row0 + r, rows_total - 1) * ld + k0 + c * 4;
+        }
+    }
+    step = TR ? 32 * ld : 32;
+}
+
+// fragments of one k-step S (16 k values = four MFMA rounds q) of one operand image: f[i][q]
+template <bool TR, int S_, int NF>
+__device__ __forceinline__ void read_step32(float (&f)[NF][4], unsigned st, unsigned rm, const unsigned (&tr)[4]) {
+    if constexpr (TR) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[i][q]) : "v"(st + tr[i]), "n"((16 * S_ + q) * 512));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            f32x4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(S_ ? ((st + rm) ^ 64u) : (st + rm)), "n"(i * 2048));
+            f[i][0] = v[0]; f[i][1] = v[1]; f[i][2] = v[2]; f[i][3] = v[3];
+        }
+    }
+}
+
+// NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only) for outputs whose 128-row tiling
+// loads the CUs unevenly -- two co-resident workgroups share a CU's matrix pipes, so a launch takes as long as the rows on its
+// fullest CU: 6144 x 1024 is 384 tiles of 128 rows (2 x 128 rows on half of the CUs) but 512 tiles of 96 rows (2 x 96 everywhere).
+template <bool TRA, bool TRB, int NI = 4>
+__global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs g) {
+    static_assert(NI == 4 || (NI == 3 && !TRA), "96-row tiles: row-major A");
+    constexpr int IMG = 16384, IMG_A = NI * 4096, STAGE = IMG_A + IMG, KT = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int z, tm, tn;
+    tile_of(g, blockIdx.x, z, tm, tn);
+    const int m0 = tm * (32 * NI), n0 = tn * BN;
+    const int nkt = total_tiles(g, KT);
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
+    const int nt = t_end - t_begin;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const float* pa[NI];
+    const float* pb[4];
+    long long sa = 0, sb = 0;
+    int cur_src = -1;
+    auto issue = [&](int i, int stage) {
+        int src, tt;
+        source_of<KT>(g, t_begin + i, src, tt);
+        if (src != cur_src) {  // (uniform) first tile, or the walk crossed into the next K source
+            cursor32_init<TRA, NI>(pa, sa, (const float*)g.A[src], g.lda[src], g.M, m0, tt * KT, w * NI, lane);
+            cursor32_init<TRB, 4>(pb, sb, (const float*)g.B[src], g.ldb[src], g.N, n0, tt * KT, w * 4, lane);
+            cur_src = src;
+        }
+        unsigned char* sbase = lds + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)pa[q], (lds_void_t*)(sbase + (w * NI + q) * 1024), 16, 0, 0);
+            pa[q] += sa;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)pb[q], (lds_void_t*)(sbase + IMG_A + (w * 4 + q) * 1024), 16, 0, 0);
+            pb[q] += sb;
+        }
+    };
+
+    f32x4 acc[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
+    // row-major image: (row, chunk) -> row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); k-step s toggles bit 6, fragment i adds i * 2048
+    const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
+    const unsigned a_rm = (unsigned)((wm * 16 * NI + lr) * ROWB) + rm_sw, b_rm = (unsigned)((wn * 64 + lr) * ROWB) + rm_sw;
+    // k-major image: element (k, row) at k * 512 + (((row >> 2) ^ (((k >> 2) & 3) << 2)) << 4) + (row & 3) * 4 with
+    // k = 16 s + 4 lg + q: the swizzle term is lg << 2 for every (s, q), which become an immediate (16 s + q) * 512
+    unsigned a_tr[4], b_tr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_tr[i] = (unsigned)(4 * lg * 512 + ((((wm * 16 + i * 4 + (lr >> 2)) ^ (lg << 2))) << 4) + (lr & 3) * 4);
+        b_tr[i] = (unsigned)(4 * lg * 512 + ((((wn * 16 + i * 4 + (lr >> 2)) ^ (lg << 2))) << 4) + (lr & 3) * 4);
+    }
+
+    auto mfma_step = [&](const float (&fa)[NI][4], const float (&fb)[4][4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
+    };
+    if (nt > 0) issue(0, 0);
+    for (int it = 0; it < nt; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // 2-stage ring: only tile ``it`` is in flight here
+        __builtin_amdgcn_s_barrier();                    // every wave's pieces landed; the stage read at it - 1 is free
+        if (it + 1 < nt) issue(it + 1, (it + 1) & 1);    // in flight under this tile's 4096 MFMA cycles
+        const unsigned stA = lds_base + (it & 1) * STAGE, stB = stA + IMG_A;
+        float a0[NI][4], b0[4][4], a1[NI][4], b1[4][4];
+        read_step32<TRA, 0, NI>(a0, stA, a_rm, a_tr);
+        read_step32<TRB, 0, 4>(b0, stB, b_rm, b_tr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        read_step32<TRA, 1, NI>(a1, stA, a_rm, a_tr);  // (in flight while the first step's MFMAs run)
+        read_step32<TRB, 1, 4>(b1, stB, b_rm, b_tr);
+        mfma_step(a0, b0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(a1, b1);
+    }
+    if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
+    else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
+}
+
 // Sum the split-K slabs in slab order (bitwise reproducible) and apply the epilogue.
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs g) {
     const long long total = (long long)g.M * g.N;
@@ -1332,6 +1481,12 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
@@ -1356,6 +1511,28 @@ extern "C" int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute)
     const int KT = compute == EGK_COMPUTE_BF16 ? 64 : 32;
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     const int nkt = cdiv(K, KT);
+    if (compute != EGK_COMPUTE_BF16) {
+        // exact-f32 contractions are bound by the matrix pipes (1/16 of the bf16 rate), which the co-resident workgroups of a CU
+        // share: a launch lasts (workgroups on the fullest CU) x (one workgroup's K walk), so what slabs buy is an even load --
+        // 288 tiles keep 32 CUs busy twice as long as the rest, 288 x 4 slabs load every CU within 10 %.  Cost in microseconds:
+        //   walk(s)   = ceil(tiles * s / 256) * ceil(nkt / s) * 1.9        (4096 MFMA cycles per 32-deep K tile at ~2.2 GHz)
+        //   reduce(s) = 3.5 + 1.5 * s * (M * N / 2^20)                      (slabs written and read back)
+        // (rows on the fullest CU in units of a 128-row tile: 96-row tiles are the kernel's alternative for row-major A)
+        if (nkt < 8) return 1;
+        const double mn = (double)M * N / 1048576.0;
+        const long long t96 = (long long)cdiv(M, 96) * cdiv(N, BN);
+        auto rounds = [&](int s_) {
+            const double r128 = (double)cdiv((long long)tiles * s_, 256), r96 = 0.75 * cdiv(t96 * s_, 256);
+            return r128 < r96 ? r128 : r96;
+        };
+        int best = 1;
+        double best_cost = rounds(1) * nkt * 1.9;
+        for (int s = 2; s <= 16 && nkt / s >= 4; ++s) {
+            const double cost = rounds(s) * cdiv(nkt, s) * 1.9 + 3.5 + 1.5 * s * mn;
+            if (cost < 0.93 * best_cost) { best_cost = cost; best = s; }
+        }
+        return best;
+    }
     if (tiles > 128 || nkt < 4) return 1;
     const double mn = (double)M * N / 1048576.0;
     int best = 1;
@@ -1612,6 +1789,56 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
             const long long total = (long long)g.M * g.N;
             const long long work = (total + 3) / 4;  // element groups of 4 (the vector path; the scalar path strides)
+            hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)),
+                               dim3(256), 0, s, g);
+        }
+        return check_launch("egk_gemm");
+    }
+    // exact-f32 pipelined kernel: f32 operands, 16-byte aligned rows, every K source a multiple of 32
+    bool all_k32 = K > 0;
+    for (int i = 0; i < g.nsrc; ++i) all_k32 = all_k32 && (g.K[i] % 32 == 0);
+    if (!bf && !a16 && g_use_pipe && all_k32 && src.all_vec) {
+        ensure_lds_attr();
+        // 96-row tiles (row-major A) when they load the CUs more evenly: the matrix pipes of a CU are shared by its co-resident
+        // workgroups, so a launch lasts as long as the ROWS on its fullest CU
+        bool r96 = false;
+        if (!d->transA && g_use_pipe != 3) {
+            const long long t128 = (long long)cdiv(g.M, 128) * g.tiles_n * g.splitk, t96 = (long long)cdiv(g.M, 96) * g.tiles_n * g.splitk;
+            r96 = g_use_pipe == 8 || ((t96 + 255) / 256) * 96 < ((t128 + 255) / 256) * 128;
+        }
+        if (r96) g.tiles_m = cdiv(g.M, 96);
+        {  // near-square XCD patches, as for the bf16 kernel
+            const int tiles = g.tiles_m * g.tiles_n;
+            int per_xcd = cdiv(tiles * g.splitk, 8);
+            if (per_xcd > tiles) per_xcd = tiles;
+            int gm = 1;
+            while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
+            g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
+        }
+        const bool st_ok = g.splitk == 1 && epilogue_rows_ok(g) && d->st_min_seg_rows >= (r96 ? 96 : 128) &&
+                           (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % 4 == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
+        if (query_blocks) {
+            *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
+            return 0;
+        }
+        if (d->st_mode && !st_ok) {
+            set_error("egk_gemm: st_mode %d is not available for this launch (ask egk_gemm_stats_blocks first)", d->st_mode);
+            return EGK_EUNSUPPORTED;
+        }
+        const dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk), pblock(NTHREADS);
+        {
+            ProfScope prof(KID_GEMM_F32_NN + layout, s, flops, bytes);
+            if (r96 && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false, 3>), pgrid, pblock, 2 * 28672, s, g);
+            else if (r96) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true, 3>), pgrid, pblock, 2 * 28672, s, g);
+            else if (!d->transA && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false>), pgrid, pblock, 65536, s, g);
+            else if (!d->transA && d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true>), pgrid, pblock, 65536, s, g);
+            else if (d->transA && d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<true, true>), pgrid, pblock, 65536, s, g);
+            else hipLaunchKernelGGL((gemm_pipe_f32_kernel<true, false>), pgrid, pblock, 65536, s, g);
+        }
+        if (g.splitk > 1) {
+            ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
+            const long long total = (long long)g.M * g.N;
+            const long long work = (total + 3) / 4;
             hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)),
                                dim3(256), 0, s, g);
         }

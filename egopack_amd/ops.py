@@ -1412,6 +1412,8 @@ class _RowLN(torch.autograd.Function):
         ctx.relu, ctx.p = relu, p_eff
         ctx.params = (w, b)
         ctx.save_for_backward(x, wc, bc, mean, rstd, mask)
+        if _mask_tap["on"] and mask is not None:
+            _mask_tap["masks"].append(mask)
         return y
 
     @staticmethod
@@ -1443,6 +1445,23 @@ class _RowLN(torch.autograd.Function):
         _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), _p(dw), _p(db),
                               _p(ws), rows, cols, int(ctx.relu), ctx.p, _dt(x)), "egk_rowln_bwd")
         return dx, (None if slot_w is not None else dw), (None if slot_b is not None else db), None, None, None, None
+
+
+_mask_tap = {"on": False, "masks": []}
+
+
+class tap_dropout_masks:
+    """``with ops.tap_dropout_masks() as masks:`` -- the keep masks (uint8, 1 = keep) of every fused LayerNorm + dropout launch
+    issued inside, in issue order: tests hand them to the oracle (``oracle.path.trn_pooling(masks=...)``) so that a step with
+    active dropout can be compared element by element."""
+
+    def __enter__(self):
+        self.prev = (_mask_tap["on"], _mask_tap["masks"])
+        _mask_tap["on"], _mask_tap["masks"] = True, []
+        return _mask_tap["masks"]
+
+    def __exit__(self, *a):
+        _mask_tap["on"], _mask_tap["masks"] = self.prev
 
 
 def row_layernorm(x, w, b, eps=1e-5, relu=False, p=0.0, training=False):

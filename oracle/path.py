@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from . import pyg_ops as P
+from . import storage as S  # (identity hooks unless the bf16 storage model is switched on: oracle/storage.py)
 
 SD = Mapping[str, torch.Tensor]
 
@@ -45,13 +46,13 @@ def trn_pooling(sd: SD, x: torch.Tensor, dropout: float = 0.0,
     (training mode) or None (eval)."""
     m0, m1 = (masks if masks is not None else (None, None))
     h = x.reshape(x.shape[0], -1)
-    h = F.linear(h, sd["proj.0.weight"], sd["proj.0.bias"])
+    h = S.act(F.linear(h, S.weight(sd["proj.0.weight"]), sd["proj.0.bias"]))
     h = F.layer_norm(h, h.shape[-1:], sd["proj.1.weight"], sd["proj.1.bias"], 1e-5)
-    h = _dropout(F.relu(h), dropout, m0)
-    h = F.linear(h, sd["proj.4.weight"], sd["proj.4.bias"])
+    h = S.act(_dropout(F.relu(h), dropout, m0))
+    h = S.act(F.linear(h, S.weight(sd["proj.4.weight"]), sd["proj.4.bias"]))
     h = F.layer_norm(h, h.shape[-1:], sd["proj.5.weight"], sd["proj.5.bias"], 1e-5)
-    h = _dropout(F.relu(h), dropout, m1)
-    return F.linear(h, sd["proj.8.weight"], sd["proj.8.bias"])
+    h = S.act(_dropout(F.relu(h), dropout, m1))
+    return S.act(F.linear(h, S.weight(sd["proj.8.weight"]), sd["proj.8.bias"]))
 
 
 # --------------------------------------------------------------------------------------
@@ -67,17 +68,17 @@ def graph_forward(sd: SD, x: torch.Tensor, pos: torch.Tensor, edge_index: torch.
     x = _dropout(x, pre_dropout, pre_mask)
     x = trn_pooling(_sub(sd, "temporal_pooling."), x, trn_dropout, trn_masks)
     freq = sd["positional_encoding.frequency"]
-    h = x + P.positional_encoding(pos, freq)
+    h = S.act(x + P.positional_encoding(pos, freq))
     for d in range(depth):
         c, n = f"net.module_{3 * d}.", f"net.module_{3 * d + 1}."
-        h = P.sage_conv(h, edge_index,
-                        sd[c + "lin_l.weight"], sd[c + "lin_l.bias"], sd[c + "lin_r.weight"],
-                        sd[c + "lin.weight"], sd[c + "lin.bias"], aggr="mean")
+        h = S.act(P.sage_conv(h, edge_index,
+                              sd[c + "lin_l.weight"], sd[c + "lin_l.bias"], sd[c + "lin_r.weight"],
+                              sd[c + "lin.weight"], sd[c + "lin.bias"], aggr="mean"))
         h = P.graph_layer_norm(h, sd[n + "weight"], sd[n + "bias"])
-        h = F.leaky_relu(h, 0.2)
+        h = S.act(F.leaky_relu(h, 0.2))
     last = f"net.module_{3 * depth}."
-    h = F.linear(h, sd[last + "weight"], sd[last + "bias"])
-    return x + h
+    h = F.linear(h, S.weight(sd[last + "weight"]), sd[last + "bias"])
+    return S.act(x + h)
 
 
 # --------------------------------------------------------------------------------------
@@ -88,9 +89,11 @@ def projection_features(sd: SD, x: torch.Tensor, dropout: float = 0.0,
     """ProjectionTask.net: Dropout -> Linear -> LayerNorm -> ReLU -> Linear
     (reference models/tasks/task.py:17-26).  Keys net.{1,2,4}.{weight,bias}."""
     h = _dropout(x, dropout, mask)
-    h = F.linear(h, sd["net.1.weight"], sd["net.1.bias"])
-    h = F.relu(F.layer_norm(h, h.shape[-1:], sd["net.2.weight"], sd["net.2.bias"], 1e-5))
-    return F.linear(h, sd["net.4.weight"], sd["net.4.bias"])
+    if mask is not None and dropout > 0:
+        h = S.act(h)
+    h = S.act(F.linear(h, S.weight(sd["net.1.weight"]), sd["net.1.bias"]))
+    h = S.act(F.relu(F.layer_norm(h, h.shape[-1:], sd["net.2.weight"], sd["net.2.bias"], 1e-5)))
+    return S.act(F.linear(h, S.weight(sd["net.4.weight"]), sd["net.4.bias"]))
 
 
 def _fuse(primary: torch.Tensor, aux: List[torch.Tensor], average: bool) -> torch.Tensor:
@@ -105,12 +108,12 @@ def multihead_logits(sd: SD, features: torch.Tensor, n_heads: int,
     per head Linear(H,C); with aux features each aux task's own classifier bank is applied to
     that task's GraphONE feature and the per-head logits are summed (or averaged).
     (head dropout is identity in eval / p=0, which is what the oracle is used with.)"""
-    logits = [F.linear(features, sd[f"classifiers.{h}.1.weight"], sd[f"classifiers.{h}.1.bias"])
+    logits = [S.grad(F.linear(features, S.weight(sd[f"classifiers.{h}.1.weight"]), sd[f"classifiers.{h}.1.bias"]))
               for h in range(n_heads)]
     if aux_features is not None:
         fused = []
         for h in range(n_heads):
-            aux = [F.linear(f, sd[f"aux_classifiers.{t}.{h}.1.weight"], sd[f"aux_classifiers.{t}.{h}.1.bias"])
+            aux = [S.grad(F.linear(f, S.weight(sd[f"aux_classifiers.{t}.{h}.1.weight"]), sd[f"aux_classifiers.{t}.{h}.1.bias"]))
                    for t, f in aux_features.items()]
             fused.append(_fuse(logits[h], aux, average_logits))
         logits = fused
@@ -121,11 +124,11 @@ def oscc_logits(sd: SD, features: torch.Tensor, batch: torch.Tensor,
                 aux_features: Optional[Mapping[str, torch.Tensor]] = None,
                 average_logits: bool = False, num_graphs: Optional[int] = None) -> torch.Tensor:
     """OSCCTask.forward_logits (reference oscc.py:65-86): global_max_pool then Linear(H,2)."""
-    pooled = P.global_max_pool(features, batch, num_graphs)
-    logits = F.linear(pooled, sd["classifier.1.weight"], sd["classifier.1.bias"])
+    pooled = S.act(P.global_max_pool(features, batch, num_graphs))
+    logits = S.grad(F.linear(pooled, S.weight(sd["classifier.1.weight"]), sd["classifier.1.bias"]))
     if aux_features is not None:
-        aux = [F.linear(P.global_max_pool(f, batch, num_graphs),
-                        sd[f"aux_classifiers.{t}.1.weight"], sd[f"aux_classifiers.{t}.1.bias"])
+        aux = [S.grad(F.linear(S.act(P.global_max_pool(f, batch, num_graphs)),
+                               S.weight(sd[f"aux_classifiers.{t}.1.weight"]), sd[f"aux_classifiers.{t}.1.bias"]))
                for t, f in aux_features.items()]
         logits = _fuse(logits, aux, average_logits)
     return logits
@@ -136,9 +139,9 @@ def pnr_logits(sd: SD, features: torch.Tensor,
                average_logits: bool = False) -> torch.Tensor:
     """PNRTask.forward_logits (reference pnr.py:62-80): Linear(H,1).squeeze(); aux logits are
     stacked with logits.unsqueeze(1) and summed / averaged, then squeezed again."""
-    logits = F.linear(features, sd["classifier.1.weight"], sd["classifier.1.bias"]).squeeze()
+    logits = S.grad(F.linear(features, S.weight(sd["classifier.1.weight"]), sd["classifier.1.bias"])).squeeze()
     if aux_features is not None:
-        aux = [F.linear(f, sd[f"aux_classifiers.{t}.1.weight"], sd[f"aux_classifiers.{t}.1.bias"])
+        aux = [S.grad(F.linear(f, S.weight(sd[f"aux_classifiers.{t}.1.weight"]), sd[f"aux_classifiers.{t}.1.bias"]))
                for t, f in aux_features.items()]
         logits = _fuse(logits.unsqueeze(1), aux, average_logits)
     return logits.squeeze()
@@ -231,10 +234,10 @@ def graphone_task_interaction(sd: SD, task: str, features: torch.Tensor, k: int,
         graph = torch.cat([bank, features], dim=0)
         edges = P.add_remaining_self_loops(edges, graph.shape[0])
         s = f"conv_stages.{task}.{d}."
-        h = P.sage_conv(graph, edges, sd[s + "module_0.lin_l.weight"], None, sd[s + "module_0.lin_r.weight"], aggr="max")
-        h = F.relu(F.layer_norm(h, h.shape[-1:], sd[s + "module_1.weight"], sd[s + "module_1.bias"], 1e-5))
-        h = F.linear(h, sd[s + "module_3.weight"], sd[s + "module_3.bias"])
-        features = h[-n:] + features if residual else h[-n:]
+        h = S.act(P.sage_conv(graph, edges, sd[s + "module_0.lin_l.weight"], None, sd[s + "module_0.lin_r.weight"], aggr="max"))
+        h = S.act(F.relu(F.layer_norm(h, h.shape[-1:], sd[s + "module_1.weight"], sd[s + "module_1.bias"], 1e-5)))
+        h = F.linear(h, S.weight(sd[s + "module_3.weight"]), sd[s + "module_3.bias"])
+        features = S.act(h[-n:] + features if residual else h[-n:])
     return features, assignments
 
 
@@ -305,17 +308,20 @@ def lta_temporal_connectivity(pos: torch.Tensor, y: torch.Tensor, r: float) -> t
 # a16  step objectives
 # --------------------------------------------------------------------------------------
 def mtl_objective(backbone_sd: SD, task_sds: Mapping[str, SD], batches: Mapping[str, P.OData],
-                  weights: Mapping[str, float], depth: int = 3, n_heads: int = 2):
+                  weights: Mapping[str, float], depth: int = 3, n_heads: int = 2, trn_dropout: float = 0.0,
+                  trn_masks: Optional[Mapping[str, Sequence[torch.Tensor]]] = None):
     """main_temporal.train body (reference main_temporal.py:87-128): one backbone forward per
     enabled task batch, its head, its loss vector, ``weight * loss.mean()`` summed.
     Task order ar, lta, oscc, pnr as in the reference.  Returns (total, per-task dict of
-    (logits, loss_vector))."""
+    (logits, loss_vector)).  ``trn_masks`` {task: (mask0, mask1)}: keep masks of the temporal pooling's two dropouts
+    (training mode with ``trn_dropout``), None = eval."""
     total, detail = [], {}
     for t in ("ar", "lta", "oscc", "pnr"):
         if t not in batches or weights.get(t, 0) <= 0:
             continue
         d = batches[t]
-        feat = graph_forward(backbone_sd, d.x, d.pos, d.edge_index, depth)
+        feat = graph_forward(backbone_sd, d.x, d.pos, d.edge_index, depth, trn_dropout=trn_dropout,
+                             trn_masks=None if trn_masks is None else trn_masks[t])
         f = projection_features(task_sds[t], feat)
         if t in ("ar", "lta"):
             logits = multihead_logits(task_sds[t], f, n_heads)
@@ -335,12 +341,23 @@ def egopack_task_loss(primary: str, task_sds: Mapping[str, SD], graphone_sd: SD,
                       batch: torch.Tensor, y: torch.Tensor, others: Sequence[str],
                       k: int, depth: int, residual: bool, average_logits: bool,
                       oscc_kind: str = "ce", n_heads: int = 2, num_graphs: Optional[int] = None,
-                      closest_override: Optional[Mapping[str, torch.Tensor]] = None):
+                      closest_override: Optional[Mapping[str, torch.Tensor]] = None,
+                      aux_source: Optional[torch.Tensor] = None):
     """main_egopack.train_step_task (reference main_egopack.py:45-61) with late_fusion=True:
     primary features; aux features = GraphONE.interact on the DETACHED projections of the other
-    tasks; fused logits; primary.compute_loss."""
+    tasks; fused logits; primary.compute_loss.
+    ``aux_source`` (bf16 storage model only): the backbone features the detached auxiliary projections are taken from -- the
+    product computes them in a separate f32-grade pass (they feed an index op), so under the storage model they come from
+    f32 features through f32 projections and are rounded once, when they enter the GraphONE stages."""
     f_primary = projection_features(task_sds[primary], feat)
-    aux_in = {t: projection_features(task_sds[t], feat).detach() for t in others}
+    if aux_source is not None:
+        with S.bf16_storage(False), torch.no_grad():
+            aux_in = {t: projection_features(task_sds[t], aux_source) for t in others}
+            if closest_override is None:  # the search ranks the f32-grade values, not their bf16 roundings
+                closest_override = {t: compute_edges(aux_in[t], graphone_sd[f"embeddings.{t}.weight"], k)[1] for t in others}
+        aux_in = {t: S.act(a) for t, a in aux_in.items()}
+    else:
+        aux_in = {t: projection_features(task_sds[t], feat).detach() for t in others}
     aux, closest = graphone_interact(graphone_sd, aux_in, k, depth, residual, closest_override=closest_override)
     sd = task_sds[primary]
     if primary in ("ar", "lta"):

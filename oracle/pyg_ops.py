@@ -18,6 +18,8 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F
 
+from . import storage as S
+
 
 # --------------------------------------------------------------------------------------
 # scatter / aggregation primitives
@@ -39,12 +41,38 @@ def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch
     return s / cnt.clamp(min=1).view(-1, *([1] * (src.dim() - 1)))
 
 
+class _ScatterMaxFirst(torch.autograd.Function):
+    """amax per index group whose backward sends the whole gradient to ONE winner, the first source row (in source order) that
+    attains the maximum -- the rule of the product's max kernels and of torch_scatter's arg-max on CUDA.  Used only
+    under the bf16 storage model (oracle/storage.py): among bf16 values exact ties are common (8 significant bits), and
+    ``scatter_reduce('amax')`` would split a tied gradient evenly where the product routes it to one row."""
+
+    @staticmethod
+    def forward(ctx, src, index, dim_size):
+        out = src.new_zeros((dim_size,) + tuple(src.shape[1:]))
+        idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+        out.scatter_reduce_(0, idx, src, reduce="amax", include_self=False)
+        pos = torch.arange(src.shape[0], device=src.device).view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+        big = src.shape[0]
+        cand = torch.where(src == out.gather(0, idx), pos, torch.full_like(pos, big))
+        first = torch.full(out.shape, big, dtype=pos.dtype, device=src.device).scatter_reduce_(0, idx, cand, reduce="amin", include_self=True)
+        ctx.save_for_backward(idx, pos == first.gather(0, idx))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, win = ctx.saved_tensors
+        return g.gather(0, idx) * win.to(g.dtype), None, None
+
+
 def scatter_max(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
     """MaxAggregation on the CPU / no-torch_scatter branch of PyG 2.3.0:
     ``new_zeros(size).scatter_reduce_(0, index, src, 'amax', include_self=False)``;
     rows without entries stay 0.  Call sites: SAGEConv(aggr='max') reference
     models/graphONE/graphONE.py:60 and global_max_pool reference models/tasks/oscc.py:68,85.
     Backward on exact ties splits evenly here (torch_scatter picks one winner): SURVEY A.1."""
+    if S.is_on():  # (the product's single-winner tie rule: see _ScatterMaxFirst)
+        return _ScatterMaxFirst.apply(src, index, dim_size)
     out = src.new_zeros((dim_size,) + tuple(src.shape[1:]))
     idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
     return out.scatter_reduce_(0, idx, src, reduce="amax", include_self=False)
@@ -82,7 +110,9 @@ def sage_conv(
     Call sites: reference models/graph.py:42 (mean, project=True, bias=True) and
     models/graphONE/graphONE.py:60 (max, project=False, bias=False)."""
     n = x.shape[0]
-    x_src = F.relu(F.linear(x, lin_weight, lin_bias)) if lin_weight is not None else x
+    # (S.act / S.weight: identity unless the bf16 storage model of oracle/storage.py is on -- the projected features, the
+    #  aggregate and the layer's output are the three tensors the product stores)
+    x_src = S.act(F.relu(F.linear(x, S.weight(lin_weight), lin_bias))) if lin_weight is not None else x
     msg = x_src.index_select(0, edge_index[0])
     if aggr == "mean":
         agg = scatter_mean(msg, edge_index[1], n)
@@ -90,7 +120,8 @@ def sage_conv(
         agg = scatter_max(msg, edge_index[1], n)
     else:
         raise ValueError(aggr)
-    return F.linear(agg, lin_l_weight, lin_l_bias) + F.linear(x, lin_r_weight)
+    agg = S.act(agg)
+    return F.linear(agg, S.weight(lin_l_weight), lin_l_bias) + F.linear(x, S.weight(lin_r_weight))
 
 
 def graph_layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

@@ -1,0 +1,309 @@
+"""bf16-mode BACKWARD parity, block by block, at the full size of BASELINE configs 3 and 4.
+
+End to end, the bf16-mode gradients of a step sit 8-22 % (relative Frobenius, worst parameter tensor) from the f32 oracle and
+4-16 % from the oracle WITH the product's storage model (oracle/storage.py) -- and they cannot do better: two evaluations of a
+40-deep chain that round to bf16 at every stage decorrelate their rounding errors within a few stages (a 1e-5 perturbation
+flips the rounding of ~0.3 % of a tensor's elements, each flip is a 0.4 % error, the next stage turns that into more flips),
+so even an exact model ends at the rounding-noise level (tools/exp/storage_model_bisect.py: the 6-op temporal pooling alone
+agrees to 1e-4, the whole backbone to 1-2 %, backbone + head to 4 %; per op the model is exact, tools/exp/storage_model_ops.py).
+
+What CAN be shown -- and is what catches a wrong term -- is each block's backward against the storage model with the chain
+cut at the block: the HIP path's own input activations (the ones the production forward produced), a random bf16 cotangent at
+the block's output, and every parameter gradient plus the input gradient compared with the oracle block evaluated on the same
+values.  A block is 3-6 storage points deep, so the agreement is at accumulation-order level: asserted <= BLOCK_TOL.
+
+Blocks: temporal pooling with ACTIVE dropout (keep masks tapped and handed to the oracle); each SAGE layer + graph LayerNorm +
+LeakyReLU + a consuming Linear (both epilogue-fused statistics paths, forward and backward, ride on these launches); the task
+heads as the engine runs them (grouped projections, classifier banks, fused cross entropy, one-pass PNR head); GraphONE
+stages (gather-max + combine + LayerNorm + Linear + residual) and the OSCC head with fused auxiliary logits (config 4).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import path as O  # noqa: E402
+from oracle import pyg_ops as P  # noqa: E402
+from oracle import storage as S  # noqa: E402
+
+DEV = "cuda"
+BLOCK_TOL = 5e-3
+NAMES = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+
+
+def _leaf(sd):
+    return {k: (v.detach().float().cpu().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("frequency")
+                else v.detach().cpu().clone()) for k, v in sd.items()}
+
+
+def _report(block, rows):
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/blockwise_parity.jsonl", "a") as f:
+        f.write(json.dumps({"block": block, **rows}) + "\n")
+
+
+def _check(block, got, want):
+    """{name: tensor} of the HIP path against the oracle block: every entry within BLOCK_TOL."""
+    rows = {}
+    for k, w in want.items():
+        assert k in got and got[k] is not None, (block, k)
+        rows[k] = _rel(got[k].float().cpu(), w)
+    _report(block, rows)
+    worst = max(rows.items(), key=lambda kv: kv[1])
+    assert worst[1] < BLOCK_TOL, (block, worst, rows)
+
+
+def _grads(module, prefix=""):
+    return {prefix + k: p.grad.detach().clone() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def _zero(*modules):
+    for m in modules:
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+
+
+@pytest.fixture(scope="module")
+def c3():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops
+    from test_gpu_configs import _build
+    prev = ops.get_compute()
+    built = _build("c3_mtl_B64_T32", "bf16", dropout=0.5)
+    args, step, opt, dev, merged, modules, sds, weights = built
+    step.step(dev, merged)  # materialises the optimizer's flat buffers: the production (grouped / banked) paths are live
+    torch.cuda.synchronize()
+    yield built
+    ops.set_compute(prev)
+
+
+def _segments(dev, order=("ar", "lta", "oscc", "pnr")):
+    out, off = [], 0
+    for t in [t for t in order if t in dev]:
+        n = dev[t].pos.shape[0]
+        out.append((t, off, off + n))
+        off += n
+    return out
+
+
+def test_temporal_pooling_block_with_active_dropout(c3):
+    from egopack_amd import ops
+    args, step, opt, dev, merged, modules, sds, weights = c3
+    model = modules["temporal_graph"].train()
+    _zero(model)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    with ops.compute_mode("bf16"), ops.tap_dropout_masks() as masks:
+        out = model.temporal_pooling(merged.x, None, merged.pos)
+        R = torch.randn(out.shape, device=DEV, generator=g).to(out.dtype)
+        out.backward(R)
+        ops.join_wgrad()
+        torch.cuda.synchronize()
+        m0, m1 = (m.cpu() for m in masks)
+    got = _grads(model.temporal_pooling)
+    got["out"] = out.detach()
+    leaf = _leaf(model.temporal_pooling.state_dict())
+    with S.bf16_storage():
+        o = O.trn_pooling(leaf, merged.x.float().cpu(), 0.5, (m0, m1))
+        (o * R.float().cpu()).sum().backward()
+    want = {k: v.grad for k, v in leaf.items() if v.requires_grad}
+    want["out"] = o.detach()
+    _check("temporal pooling (dropout 0.5)", got, want)
+
+
+def _production_layer_inputs(model, merged):
+    """Inputs of the three SAGE layers as the production forward produces them (eval-mode temporal pooling: no masks to carry)."""
+    from egopack_amd import ops
+    with torch.no_grad():
+        was = model.training
+        model.eval()
+        x = model.temporal_pooling(merged.x, None, merged.pos)
+        model.train(was)
+        graph = model._graph_of(merged)
+        pr = getattr(merged, "pos_range", None)
+        h = model.positional_encoding.add_to(x, merged.pos, tuple(pr) if pr is not None else None)
+        hs = []
+        for d in range(model.depth):
+            hs.append(h)
+            c = ops.sage_mean_layer(h, getattr(model.net, f"module_{3 * d}"), graph)
+            h = getattr(model.net, f"module_{3 * d + 1}")(c, merged.seg_ptr, 0.2)
+    return x, hs, h, graph
+
+
+@pytest.mark.parametrize("d", [0, 1, 2])
+def test_sage_layer_graph_layernorm_block(c3, d):
+    """SAGEConv(mean) -> graph LayerNorm (per task batch) -> LeakyReLU -> Linear, with the LayerNorm's forward sums taken in the
+    SAGE layer's last contraction and its backward sums in the Linear's dX contraction (the production wiring of
+    egopack_amd/models/graph.py), on the layer's production input."""
+    from egopack_amd import ops
+    args, step, opt, dev, merged, modules, sds, weights = c3
+    model = modules["temporal_graph"]
+    with ops.compute_mode("bf16"):
+        _, hs, _, graph = _production_layer_inputs(model, merged)
+        conv, norm, last = getattr(model.net, f"module_{3 * d}"), getattr(model.net, f"module_{3 * d + 1}"), model.net.module_9
+        _zero(model)
+        h = hs[d].detach().clone().requires_grad_(True)
+        seg_ptr = merged.seg_ptr
+        min_rows = int(getattr(merged, "min_seg_rows", 0))
+        assert min_rows > 0
+        req = {"seg_ptr": seg_ptr, "n_seg": seg_ptr.numel() - 1, "min_rows": min_rows}
+        c = ops.sage_mean_layer(h, conv, graph, ln_out=req)
+        assert req.get("partials") is not None  # the forward sums did ride on the contraction
+        y, ctx = norm(c, seg_ptr, 0.2, partials=req["partials"], min_seg_rows=min_rows, return_ctx=True)
+        out = last(y, ln_in=ctx)
+        g = torch.Generator(device=DEV).manual_seed(2 + d)
+        R = torch.randn(out.shape, device=DEV, generator=g).to(out.dtype)
+        out.backward(R)
+        ops.join_wgrad()
+        torch.cuda.synchronize()
+    got = {**_grads(conv, "conv."), **_grads(norm, "norm."), **_grads(last, "last."), "h": h.grad, "out": out.detach()}
+    lc, ln, ll = _leaf(conv.state_dict()), _leaf(norm.state_dict()), _leaf(last.state_dict())
+    hc = h.detach().float().cpu().requires_grad_(True)
+    ei = merged.edge_index.cpu()
+    with S.bf16_storage():
+        cc = S.act(P.sage_conv(hc, ei, lc["lin_l.weight"], lc["lin_l.bias"], lc["lin_r.weight"], lc["lin.weight"], lc["lin.bias"]))
+        parts = [S.act(F.leaky_relu(P.graph_layer_norm(cc[a:b], ln["weight"], ln["bias"]), 0.2)) for _, a, b in _segments(dev)]
+        o = S.act(F.linear(torch.cat(parts), S.weight(ll["weight"]), ll["bias"]))
+        (o * R.float().cpu()).sum().backward()
+    want = {**{"conv." + k: v.grad for k, v in lc.items()}, **{"norm." + k: v.grad for k, v in ln.items()},
+            **{"last." + k: v.grad for k, v in ll.items()}, "h": hc.grad, "out": o.detach()}
+    _check(f"SAGE layer {d} + graph LayerNorm + Linear", got, want)
+
+
+def test_task_heads_block(c3):
+    """The heads as the engine runs them (grouped projections, classifier banks of AR + LTA as one chain, fused cross entropies,
+    one-pass PNR head) on the production backbone features: every head parameter's gradient and d objective / d features."""
+    from egopack_amd import ops
+    args, step, opt, dev, merged, modules, sds, weights = c3
+    model = modules["temporal_graph"]
+    with ops.compute_mode("bf16"):
+        with torch.no_grad():
+            was = model.training
+            model.eval()
+            feats = step.features(dev, merged)
+            model.train(was)
+        feats = {t: f.detach().clone() for t, f in feats.items()}
+        _zero(*[modules[NAMES[t]] for t in feats])
+        step._head_batches = dev
+        total, vectors, leaves = step._heads_forward_backward(feats)
+        ops.join_wgrad(force=True)
+        torch.cuda.synchronize()
+    got, want = {"objective": total.detach().reshape(1)}, {}
+    tot = []
+    with S.bf16_storage():
+        for t in feats:
+            tsd = _leaf(modules[NAMES[t]].state_dict())
+            fc = feats[t].float().cpu().requires_grad_(True)
+            f = O.projection_features(tsd, fc)
+            y = dev[t].y.cpu()
+            if t in ("ar", "lta"):
+                loss = O.multihead_ce(O.multihead_logits(tsd, f, 2), y)
+            else:
+                loss = O.pnr_loss(O.pnr_logits(tsd, f), y)
+            tot.append((weights[t] * loss.mean(), tsd, fc, t, loss.detach()))
+        torch.stack([x[0] for x in tot]).sum().backward()
+    want["objective"] = torch.stack([x[0] for x in tot]).sum().detach().reshape(1)
+    for _, tsd, fc, t, loss in tot:
+        for k, v in tsd.items():
+            if v.requires_grad and v.grad is not None:
+                want[f"{t}.{k}"] = v.grad
+        want[f"{t}.d_features"] = fc.grad
+        want[f"{t}.loss"] = loss
+        got[f"{t}.d_features"] = leaves[t].grad
+        got[f"{t}.loss"] = vectors[t]
+        got.update(_grads(modules[NAMES[t]], f"{t}."))
+    _check("task heads (AR + LTA + PNR)", got, want)
+
+
+@pytest.fixture(scope="module")
+def c4():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops
+    from test_gpu_configs import _build
+    prev = ops.get_compute()
+    built = _build("c4_egopack_oscc_K4096_d3", "bf16")
+    args, step, opt, dev, merged, modules, sds, weights = built
+    step.step(dev)
+    torch.cuda.synchronize()
+    yield built
+    ops.set_compute(prev)
+
+
+@pytest.mark.parametrize("task,d", [("ar", 0), ("lta", 1), ("pnr", 2)])
+def test_graphone_stage_block(c4, task, d):
+    """One GraphONE stage (reference graphONE.py:94-115 for one depth): max over the k nearest prototype rows and the node's own
+    row, lin_l(max) + lin_r(f), LayerNorm + ReLU, Linear, residual -- on production features, with the production lists."""
+    from egopack_amd import ops
+    args, step, opt, dev, merged, modules, sds, weights = c4
+    g1 = modules["graphone"]
+    with ops.compute_mode("bf16"):
+        with torch.no_grad():
+            aux_in = step.precise_aux_features(dev)["oscc"][task]
+            bank = g1.embeddings[task].weight
+            nn_idx = ops.nearest_prototypes(aux_in, bank, g1.k, g1.distance_func)
+            f = ops.to_act(aux_in)
+            for s_ in list(g1.conv_stages[task])[:d]:  # the production input of stage d
+                m = ops.gather_max(f, bank, nn_idx)
+                f = s_.module_3(s_.module_1(s_.module_0.combine(m, f), relu=True), residual=f)
+        stage = g1.conv_stages[task][d]
+        _zero(stage)
+        fin = f.detach().clone().requires_grad_(True)
+        m = ops.gather_max(fin, bank, nn_idx)
+        out = stage.module_3(stage.module_1(stage.module_0.combine(m, fin), relu=True), residual=fin)
+        gen = torch.Generator(device=DEV).manual_seed(9 + d)
+        R = torch.randn(out.shape, device=DEV, generator=gen).to(out.dtype)
+        out.backward(R)
+        ops.join_wgrad()
+        torch.cuda.synchronize()
+    got = {**_grads(stage), "f": fin.grad, "out": out.detach()}
+    sd = {f"conv_stages.{task}.0." + k: v for k, v in _leaf(stage.state_dict()).items()}
+    sd[f"embeddings.{task}.weight"] = bank.detach().float().cpu()
+    fc = fin.detach().float().cpu().requires_grad_(True)
+    with S.bf16_storage():
+        o, _ = O.graphone_task_interaction(sd, task, fc, g1.k, 1, residual=True, closest_override=nn_idx.cpu())
+        (o * R.float().cpu()).sum().backward()
+    want = {k[len(f"conv_stages.{task}.0."):]: v.grad for k, v in sd.items() if k.startswith("conv_stages") and v.requires_grad}
+    want.update(f=fc.grad, out=o.detach())
+    _check(f"GraphONE stage {task}/{d}", got, want)
+
+
+def test_oscc_head_with_fused_auxiliary_logits_block(c4):
+    """OSCC head of the EgoPack step: projection, per-sequence max pool, classifier, the three auxiliary classifiers on the
+    GraphONE features, mean fusion, label-smoothed cross entropy (reference oscc.py:65-96) on production features."""
+    from egopack_amd import ops
+    args, step, opt, dev, merged, modules, sds, weights = c4
+    task = modules[NAMES["oscc"]]
+    d = dev["oscc"]
+    with ops.compute_mode("bf16"):
+        with torch.no_grad():
+            feat = step.features(dev)["oscc"].detach().clone()
+            aux_in = step.precise_aux_features(dev)["oscc"]
+            aux, _ = step.graphone.interact(aux_in)
+            aux = {t: a.detach().clone() for t, a in aux.items()}
+        _zero(task)
+        fin = feat.clone().requires_grad_(True)
+        logits = task.forward_logits(features=task.forward_features(fin), batch=d, aux_features=aux)
+        loss = task.compute_loss(logits, d.y)
+        loss.mean().backward()
+        ops.join_wgrad()
+        torch.cuda.synchronize()
+    got = {**_grads(task), "d_features": fin.grad, "loss": loss.detach(), "logits": logits.detach()}
+    tsd = _leaf(task.state_dict())
+    fc = feat.float().cpu().requires_grad_(True)
+    with S.bf16_storage():
+        lg = O.oscc_logits(tsd, O.projection_features(tsd, fc), d.batch.cpu(), {t: a.float().cpu() for t, a in aux.items()}, True,
+                           num_graphs=d.num_graphs)
+        ls = O.oscc_loss(lg, d.y.cpu(), "ce")
+        ls.mean().backward()
+    want = {k: v.grad for k, v in tsd.items() if v.requires_grad and v.grad is not None}
+    want.update(d_features=fc.grad, loss=ls.detach(), logits=lg.detach())
+    _check("OSCC head + fused auxiliary logits", got, want)

@@ -930,6 +930,46 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
         torch.testing.assert_close(outs[(5, torch.float32)], ref, rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("transA,transB", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K1,K2,splitk", [(300, 200, 256, 0, 1), (128, 128, 32, 0, 1), (264, 136, 128, 96, 1), (1024, 1024, 2048, 0, 4),
+                                              (6144, 1024, 1024, 0, 1), (2048, 1024, 1024, 1024, 1), (472, 1024, 1024, 0, 2)])
+def test_gemm_f32_pipelined_kernel_bit_equal_to_generic(ops, transA, transB, M, N, K1, K2, splitk):
+    """The exact-f32 LDS-DMA kernel (f32 operands, K % 32 == 0: the kernel of the reference-precision mode) issues the k-ordered
+    v_mfma_f32_16x16x4_f32 chain of the register-staged generic kernel per accumulator: BIT-identical results in all four
+    operand layouts, with two K sources, split-K slabs, the fused epilogue (bias / ReLU / residual) and accumulation into C;
+    and both match fp64 to f32 accumulation error."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + 3 * N + K1 + 7 * K2)
+
+    def operand(rows, K, tr):
+        return torch.randn((K, rows) if tr else (rows, K), device=DEV, generator=g)
+    A1, B1 = operand(M, K1, transA), operand(N, K1, transB)
+    A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
+    bias, res, C0 = torch.randn(N, device=DEV, generator=g), torch.randn(M, N, device=DEV, generator=g), torch.randn(M, N, device=DEV, generator=g)
+    outs = {}
+    for pipe in (1, 0):
+        prev = lib.egk_gemm_set_pipeline(pipe)
+        try:
+            a = torch.empty(M, N, device=DEV)
+            ops.gemm(M, N, A1, A1.shape[1], B1, B1.shape[1], K1, a, N, A2=A2, lda2=A2.shape[1] if K2 else 0, B2=B2,
+                     ldb2=B2.shape[1] if K2 else 0, K2=K2, transA=transA, transB=transB, bias=bias, residual=res, ldr=N, act=1,
+                     compute=ops.F32, splitk=splitk)
+            b = C0.clone()
+            ops.gemm(M, N, A1, A1.shape[1], B1, B1.shape[1], K1, b, N, A2=A2, lda2=A2.shape[1] if K2 else 0, B2=B2,
+                     ldb2=B2.shape[1] if K2 else 0, K2=K2, transA=transA, transB=transB, accumulate=True, alpha=0.5,
+                     compute=ops.F32, splitk=splitk)
+            outs[pipe] = (a, b)
+        finally:
+            lib.egk_gemm_set_pipeline(prev)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    if M * N <= 1 << 21:
+        opA = lambda t, tr: (t.t() if tr else t).double()
+        dot = opA(A1, transA) @ opA(B1, transB).t() + (opA(A2, transA) @ opA(B2, transB).t() if K2 else 0)
+        torch.testing.assert_close(outs[1][0], (torch.relu(dot + bias.double()) + res.double()).float(), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(outs[1][1], (0.5 * dot + C0.double()).float(), rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 1024, 2048), (472, 1024, 1024), (128, 256, 4096), (1024, 4608, 6144), (115, 1024, 2048)])
 def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
     """dW launch with dbias: dbias[m] += sum_k dY[k, m], fused into the pipelined kernel (from the dY^T LDS image) or

@@ -1,0 +1,6 @@
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_kernels.py -x -q -k "gemm" 2>&1 | tail -4 > gpurun_out/t_f32.log; tail -n 3 gpurun_out/t_f32.log
+python tools/gemm_f32_bench.py > gpurun_out/gemm_f32_bench.log 2>&1; cat gpurun_out/gemm_f32_bench.log
+python -m pytest tests/test_gpu_configs.py tests/test_gpu_models.py -q 2>&1 | tail -4
+python bench.py --steps 50 --warmup 10 --no-cpu-baseline --kernel-table > gpurun_out/b_mtl.json 2> gpurun_out/b_mtl.err
+python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4), d['f32']['ms_per_step'], d['f32']['roofline']['frac'], d['f32']['roofline']['kernel'], d['f32']['roofline']['step'])" gpurun_out/b_mtl.json
