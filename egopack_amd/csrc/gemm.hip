@@ -74,6 +74,18 @@ struct GemmArgs {
 // rows, column by column inside a group: the run of one XCD is a near-square patch of ONE slab, so the operand
 // strips its workgroups fetch (one A strip per tile row, one B strip per tile column) overlap as much as they can
 // in that XCD's L2.  (Row-by-row order gives an XCD 1 x 36 tiles of the 8 x 36 dW grid: 37 strips instead of 12.)
+// (virtual id -> tile: the slab-major walk in groups of group_m tile rows)
+__device__ __forceinline__ void tile_of_virtual(const GemmArgs& g, int v, int& z, int& tm, int& tn) {
+    const int tiles = g.tiles_m * g.tiles_n;
+    z = v / tiles;
+    const int t = v - z * tiles;
+    const int gsz = g.group_m * g.tiles_n;
+    const int grp = t / gsz, first = grp * g.group_m;
+    const int rows = min(g.group_m, g.tiles_m - first);
+    const int rr = t - grp * gsz;
+    tm = first + rr % rows;
+    tn = rr / rows;
+}
 __device__ __forceinline__ void tile_of(const GemmArgs& g, int bid, int& z, int& tm, int& tn) {
     const int tiles = g.tiles_m * g.tiles_n, nwg = tiles * g.splitk;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -685,7 +697,7 @@ struct OperandCursor {
 // MB = 2, KG = 1: 8 waves as 4 x 2 over a 256 x 128 tile, one workgroup per CU.  A CU takes in ~70 GB/s from L2
 //         whatever the kernel does (MI355X_MICROARCH.md, gather-into-LDS table), so bytes fetched per flop bound the
 //         rate: 48 KiB per K tile for 2 x the flops of the 32 KiB of a 128 x 128 tile.  For large outputs.
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false>
 __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid) {
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
@@ -703,7 +715,8 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
 #endif
 
     int z, tm, tn;
-    tile_of(g, bid, z, tm, tn);
+    if constexpr (VIRT) tile_of_virtual(g, bid, z, tm, tn);  // (the caller did the XCD placement: grouped launches)
+    else tile_of(g, bid, z, tm, tn);
     const int m0 = tm * (32 * NI * MB), n0 = tn * BN;
     const int nkt = total_tiles(g, KT);
     const int per = (nkt + g.splitk - 1) / g.splitk;
@@ -979,12 +992,31 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const Gem
 // weights).  blockIdx.y = problem, blockIdx.x = its tile id; gridDim.x is the largest tile count rounded up to a
 // multiple of 8, so that blockIdx.x & 7 is still the XCD the hardware deals the workgroup to (linear id = y * gridDim.x
 // + x) and every problem keeps its XCD-local tile order.  Workgroups beyond a problem's tile count leave at once.
+// XCD-packed placement (``packed``, 1-D grid): the tiles of ALL problems form one list, problem after problem, and XCD x (linear
+// workgroup id mod 8) takes a CONSECUTIVE run of it -- so an XCD works on one problem (at most two) at a time and its L2 sees
+// that problem's operand strips once, instead of every XCD pulling the strips of every problem: six H x H weight gradients
+// fetched 450 MB (8 XCDs x 6 problems x ~6 strips of 1.5 MB) for 151 MB of operands; packed, 8 x ~14 strips = ~170 MB.
 constexpr int MAX_GROUPS = 8;
 struct GemmGroup {
     GemmArgs p[MAX_GROUPS];
+    int packed, count, total;  // packed placement: number of problems, total tile count
 };
 template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
 __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(const GemmGroup gg) {
+    if (gg.packed) {
+        const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        const int q = gg.total >> 3, r = gg.total & 7;
+        if (slot >= q + (xcd < r ? 1 : 0)) return;
+        int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        int pi = 0;
+        for (; pi + 1 < gg.count; ++pi) {  // (uniform scalar walk over <= 8 problems)
+            const int t = gg.p[pi].tiles_m * gg.p[pi].tiles_n;
+            if (v < t) break;
+            v -= t;
+        }
+        gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, true>(gg.p[pi], v);
+        return;
+    }
     const GemmArgs& g = gg.p[blockIdx.y];
     if ((int)blockIdx.x >= g.tiles_m * g.tiles_n * g.splitk) return;
     gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI>(g, blockIdx.x);
@@ -1450,6 +1482,7 @@ using namespace egk;
 static int g_use_pipe = 1;
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
+static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
 static bool g_lds_attr_set = false;
 template <int NS, bool TA, bool TB, int KG, int MB = 1>
 static void set_lds_attr() {
@@ -1492,6 +1525,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 300) { g_group_packed = on - 300; return prev; }
     if (on >= 200) { g_rows_epilogue = on - 200; return prev; }
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
     // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
@@ -1935,19 +1969,28 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     }
     if (g_use_pipe == 3 || g_use_pipe == 5) variant = g_use_pipe;
     if ((g_use_pipe == 8 || g_use_pipe == 11) && !ta) variant = g_use_pipe;
-    int max_wg = 0;
+    int max_wg = 0, total = 0;
     for (int i = 0; i < count; ++i) {
         GemmArgs& g = gg.p[i];
         g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : cdiv(g.M, BM);
         g.tiles_n = cdiv(g.N, BN);
+        total += g.tiles_m * g.tiles_n;
+    }
+    const bool packed = g_group_packed != 0;
+    for (int i = 0; i < count; ++i) {
+        GemmArgs& g = gg.p[i];
         const int tiles = g.tiles_m * g.tiles_n;
-        int per_xcd = cdiv(tiles, 8), gm = 1;
+        // near-square patches of what ONE XCD works on: its share of this problem (spread placement) or of the whole launch
+        int per_xcd = packed ? cdiv(total, 8) : cdiv(tiles, 8), gm = 1;
+        if (per_xcd > tiles) per_xcd = tiles;
         while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
         g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
         max_wg = tiles > max_wg ? tiles : max_wg;
     }
     for (int i = count; i < MAX_GROUPS; ++i) gg.p[i] = gg.p[0];
-    const dim3 pgrid((max_wg + 7) / 8 * 8, count), pblock(NTHREADS);
+    gg.packed = packed ? 1 : 0; gg.count = count; gg.total = total;
+    const dim3 pgrid = packed ? dim3((total + 7) / 8 * 8) : dim3((max_wg + 7) / 8 * 8, count);
+    const dim3 pblock(NTHREADS);
     const int layout = ta ? (tb ? 2 : 3) : (tb ? 1 : 0);
     EGK_REQUIRE(!(ta && !tb), "egk_gemm_grouped: the tn layout is not instantiated");
 #define EGK_PIPE_G(TA, TB)                                                                                                  \

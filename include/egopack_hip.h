@@ -146,8 +146,8 @@ int egk_tune(int32_t key, int32_t value);
  * operands, 16-byte aligned rows, K % 64 == 0) use the LDS-DMA pipelined kernels, variant chosen per launch; a value
  * 2..11 forces one variant where it is legal (2 / 3 / 4: 3- / 2- / 4-stage ring on 128 x 128 tiles, 5: two wave groups,
  * 6: 256 x 128 tile, 7: 256 x 256 tile, 8 / 11: 96- / 64-row tiles); 100 + g overrides the XCD tile-group height
- * (100 = policy); 200 / 201 selects the direct / row-contiguous (default) epilogue of the 4-wave variants.  Returns the
- * previous variant setting. */
+ * (100 = policy); 200 / 201 selects the direct / row-contiguous (default) epilogue of the 4-wave variants; 300 / 301 the
+ * spread / XCD-packed (default) workgroup placement of grouped launches.  Returns the previous variant setting. */
 int egk_gemm_set_pipeline(int32_t on);
 
 /* out[n] (+)= sum_m x[m, n] : bias gradients of every Linear above.  Two launches (row-chunk
