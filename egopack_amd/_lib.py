@@ -115,6 +115,8 @@ SIGNATURES = {
     "egk_relu_gate": (C.c_int, [vp, vp, vp, vp, i64, i32]),
     "egk_cast": (C.c_int, [vp, vp, i32, vp, i32, i64]),
     "egk_split_bf16": (C.c_int, [vp, vp, i64, vp, vp, i64, i64, i64]),
+    "egk_host_bounded_draws": (i64, [vp, vp, vp, i64, i32, vp]),
+    "egk_host_window_rows": (i64, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "egk_tune": (C.c_int, [i32, i32]),
     "egk_weighted_sums": (C.c_int, [vp, vp, vp, vp, i32, vp]),
     "egk_fill_scaled_multi": (C.c_int, [vp, vp, vp, vp, vp, i32]),

@@ -1,4 +1,5 @@
 // Library runtime: error strings and the built-in per-kernel HIP-event profiler.
+#include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -104,6 +105,123 @@ int egk_stamp(egk_stream_t stream, uint64_t* buf, int32_t idx) {
     EGK_REQUIRE(buf && idx >= 0, "egk_stamp: bad arguments");
     hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)buf, idx);
     return check_launch("egk_stamp");
+}
+
+/* Host-side helpers of the batch builders (no device work).  The reference draws its segment-sampling offsets window by
+ * window with numpy's legacy ``RandomState.randint(high, size=n)`` (data/base_dataset.py:128-139).  Reproducing that stream
+ * exactly lets a whole batch of windows be sampled in one call: the generator is the published MT19937 (state = 624 words +
+ * position, as ``RandomState.get_state()`` hands it out; a draw regenerates the block at position 624 and tempers the next
+ * word), and a bounded value is ``do v = next_uint32 & mask; while (v > high - 1)`` with mask = the smallest 2^k - 1 >= high - 1
+ * (numpy/random/src/distributions: buffered_bounded_masked_uint32; a bound of 1 consumes nothing).  The callers write the
+ * advanced state back with ``set_state``, so the stream continues where the per-window calls would have left it. */
+namespace {
+struct MT {
+    uint32_t* key;
+    int pos;
+    inline void regenerate() {
+        const uint32_t UP = 0x80000000u, LOW = 0x7fffffffu, A = 0x9908b0dfu;
+        int k = 0;
+        for (; k < 624 - 397; ++k) {
+            const uint32_t y = (key[k] & UP) | (key[k + 1] & LOW);
+            key[k] = key[k + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        for (; k < 623; ++k) {
+            const uint32_t y = (key[k] & UP) | (key[k + 1] & LOW);
+            key[k] = key[k + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        const uint32_t y = (key[623] & UP) | (key[0] & LOW);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        pos = 0;
+    }
+    inline uint32_t next() {
+        if (pos >= 624) regenerate();
+        uint32_t y = key[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    inline uint32_t bounded(uint32_t rng, uint32_t mask) {
+        uint32_t v;
+        do v = next() & mask; while (v > rng);
+        return v;
+    }
+};
+inline uint32_t mask_of(uint32_t rng) {
+    uint32_t m = rng;
+    m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16;
+    return m;
+}
+}  // namespace
+
+/* ``np.stack([rng.randint(h, size=n) for h in high])`` (h <= 1: a row of zeros, nothing drawn) on the MT19937 state
+ * (mt_key[624], *mt_pos), both advanced in place.  out int64 [W][n].  0, or -2 for a bound beyond 32 bits, -3 bad arguments. */
+int64_t egk_host_bounded_draws(uint32_t* mt_key, int32_t* mt_pos, const int64_t* high, int64_t W, int32_t n, int64_t* out) {
+    if (!mt_key || !mt_pos || !high || !out || n < 0 || W < 0 || *mt_pos < 0 || *mt_pos > 624) return -3;
+    MT mt{mt_key, *mt_pos};
+    for (int64_t w = 0; w < W; ++w) {
+        const int64_t h = high[w];
+        int64_t* o = out + w * n;
+        if (h <= 1) {
+            for (int32_t i = 0; i < n; ++i) o[i] = 0;
+            continue;
+        }
+        if (h - 1 > 0xFFFFFFFFLL) return -2;
+        const uint32_t rng = (uint32_t)(h - 1), mask = mask_of(rng);
+        for (int32_t i = 0; i < n; ++i) o[i] = (int64_t)mt.bounded(rng, mask);
+    }
+    *mt_pos = mt.pos;
+    return 0;
+}
+
+/* The store rows of W action windows -- feature_store.window_rows for every window in ONE call: numpy's arithmetic operation by
+ * operation (double(size) / n, i * step, + draw, clip, round-half-even, integer cast; linspace = floor(i * step); uniform
+ * sampling = linspace + size / n / 2), numpy's slice clipping of [start, end) to the video, and -1 rows where the reference's
+ * np.take raises (empty window, an index == size).  ``random``: draws from the MT19937 state (advanced in place; NULL allowed
+ * otherwise).  out int64 [W][n].  0, or -2 for a bound beyond 32 bits, -3 bad arguments. */
+int64_t egk_host_window_rows(uint32_t* mt_key, int32_t* mt_pos, const int64_t* first_row, const int64_t* video_len,
+                             const int64_t* start, const int64_t* end, int64_t W, int32_t n, int32_t random, int64_t* out) {
+    if (!first_row || !video_len || !start || !end || !out || n <= 0 || W < 0) return -3;
+    if (random && (!mt_key || !mt_pos || *mt_pos < 0 || *mt_pos > 624)) return -3;
+    MT mt{mt_key, random ? *mt_pos : 0};
+    for (int64_t w = 0; w < W; ++w) {
+        const int64_t vl = video_len[w];
+        int64_t lo = start[w] < 0 ? 0 : start[w], hi = end[w] < 0 ? 0 : end[w];
+        lo = lo > vl ? vl : lo;
+        hi = hi > vl ? vl : hi;
+        const int64_t size = hi > lo ? hi - lo : 0;
+        int64_t* o = out + w * n;
+        bool bad = size == 0;
+        if (!bad) {
+            const double step = (double)size / (double)n;
+            const int64_t avg = size / n;
+            uint32_t rng = 0, mask = 0;
+            if (random && avg > 1) {
+                if (avg - 1 > 0xFFFFFFFFLL) return -2;
+                rng = (uint32_t)(avg - 1);
+                mask = mask_of(rng);
+            }
+            for (int32_t i = 0; i < n; ++i) {
+                int64_t idx;
+                if (random && avg > 0) {
+                    const uint32_t v = avg > 1 ? mt.bounded(rng, mask) : 0u;
+                    double x = (double)i * step + (double)v;
+                    x = x < 0.0 ? 0.0 : (x > (double)size ? (double)size : x);
+                    idx = (int64_t)nearbyint(x);
+                } else {
+                    idx = (int64_t)floor((double)i * step);
+                    if (!random) idx += size / n / 2;
+                }
+                if (idx >= size) bad = true;
+                o[i] = first_row[w] + lo + idx;
+            }
+        }
+        if (bad)
+            for (int32_t i = 0; i < n; ++i) o[i] = -1;
+    }
+    if (random) *mt_pos = mt.pos;
+    return 0;
 }
 
 int egk_version(void) { return 100; }

@@ -89,7 +89,9 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, 
     for t in live:
         host[t].x, host[t].x_base, host[t].x_idx = saved[t]
     md = moved[-1]
-    md.x = dbuf
+    md.x = md.x_base = dbuf
+    if getattr(md, "_blob", None) is not None:
+        md._blob.names = [*live, "merged"]
     # fingerprint of everything that describes the graphs (not the features / labels): equal keys = equal structure, so a
     # replay on static buffers (StepBase.train_step) need not rewrite the CSR arrays, edge lists and batch vectors
     for t in live:
@@ -115,6 +117,8 @@ class StagedBatches:
             return stage_batches(live, self.device, self.order, store=self.store, dtype=self.dtype)
         from .data import to_device_packed
         moved = to_device_packed([live[t] for t in live], self.device)  # (one copy for all of a step's tensors)
+        if moved and getattr(moved[0], "_blob", None) is not None:
+            moved[0]._blob.names = list(live)
         for t, d in zip(live, moved):
             d._struct_key = structure_key(live[t])
             if self.store is not None and getattr(d, "x", None) is None and getattr(d, "x_idx", None) is not None:
@@ -143,7 +147,13 @@ class StagedBatches:
             if done is not None:
                 cur = torch.cuda.current_stream()
                 cur.wait_event(done)
-                for _, v in [*(kv for b in batches.values() for kv in _walk(b)), *_walk(merged)]:
+                ref = _shared_blob(batches, merged)
+                if ref is not None:  # every tensor but the features is a view of the transfer's one buffer
+                    used = [ref.dev, *(getattr(b, k, None) for b in [*batches.values(), merged] if b is not None
+                                       for k in ("x", "x_base"))]
+                else:
+                    used = [v for _, v in [*(kv for b in batches.values() for kv in _walk(b)), *_walk(merged)]]
+                for v in used:
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(cur)  # allocated on the copy stream, consumed here
             yield batches, merged
@@ -162,6 +172,7 @@ def _walk(obj, prefix=""):
         for f in fields(obj):
             yield from _walk(getattr(obj, f.name), f"{prefix}.{f.name}")
     elif isinstance(obj, Data):
+        obj.materialise()
         for k in sorted(obj.__dict__):
             yield from _walk(obj.__dict__[k], f"{prefix}.{k}")
     elif isinstance(obj, (list, tuple)):
@@ -171,16 +182,9 @@ def _walk(obj, prefix=""):
         yield prefix, obj
 
 
-# Arrays whose length is the EDGE count of a batch.  The LTA edge set depends on the labels (n_forecast counts ``y[:, 0] >
-# 0``, reference lta_temp_connectivity.py:47), so E differs by a few entries from batch to batch.  No kernel takes E: the
-# gathers walk ``rowptr[i] .. rowptr[i + 1]``.  The static buffers of a captured step therefore hold these arrays at a
-# CAPACITY (E rounded up to EDGE_BUCKET), a replay writes the first E entries, and the signature compares capacities.
-EDGE_FIELDS = (".edge_index", ".graph.col", ".graph.t_col", ".graph.t_wgt")
-EDGE_BUCKET = 1024
-
-
-def _edge_capacity(e: int) -> int:
-    return (int(e) + EDGE_BUCKET - 1) // EDGE_BUCKET * EDGE_BUCKET
+# Edge-sized arrays live in the static buffers of a captured step at a CAPACITY (data.EDGE_FIELDS / EDGE_BUCKET): the LTA edge
+# count moves by a few entries from batch to batch, no kernel takes E, and the signature compares capacities.
+from .data import EDGE_BUCKET, EDGE_FIELDS, edge_capacity as _edge_capacity  # noqa: E402
 
 
 def _is_edge_field(path: str) -> bool:
@@ -221,6 +225,46 @@ def _fast_key(batches, merged):
         y = getattr(b, "y", None)
         parts.append((name, k, tuple(x.shape), x.dtype, tuple(y.shape) if torch.is_tensor(y) else None))
     return tuple(parts)
+
+
+def _shared_blob(batches, merged):
+    """The ``data.BlobRef`` of a step whose batches all came out of ONE packed transfer with a layout signature, else None."""
+    objs = [b for b in [*batches.values(), merged] if b is not None]
+    ref = getattr(objs[0], "_blob", None) if objs else None
+    if ref is None or ref.gsig is None or ref.names is None or any(getattr(b, "_blob", None) is not ref for b in objs):
+        return None
+    return ref
+
+
+def _feature_key(batches, merged):
+    return tuple((name, tuple(b.x.shape), b.x.dtype) for name, b in [*sorted(batches.items()), ("merged", merged)]
+                 if b is not None and torch.is_tensor(getattr(b, "x", None)))
+
+
+def _static_from_blob(ref, batches, merged):
+    """Private buffers for a capture out of a packed transfer: ONE byte buffer of the transfer's layout (edge-sized arrays at
+    capacity) + clones of the feature blocks.  -> (buffer, static batches, static merged)."""
+    blob = torch.empty_like(ref.dev)
+    blob.copy_(ref.dev)
+    outs = dict(zip(ref.names, ref.rebuild(blob, True)))
+    static_m = outs.pop("merged", None) if merged is not None else None
+    static_b = {t: outs.get(t) for t in batches}
+    for dst, src in [*((static_b[t], batches[t]) for t in batches if batches[t] is not None), (static_m, merged)]:
+        if dst is None:
+            continue
+        for k, v in src.__dict__.items():  # what was attached after the transfer (features, fingerprints)
+            if k in ("_blob", "_fill") or k in dst.__dict__ and dst.__dict__[k] is not None:
+                continue
+            setattr(dst, k, v)
+    if static_m is not None and torch.is_tensor(merged.x):
+        static_m.x = merged.x.clone()
+        _rewire_packed(static_b, static_m)
+    else:
+        for t, b in static_b.items():
+            if b is not None and torch.is_tensor(b.x):
+                b.x = batches[t].x.clone()
+                b.x_base = None
+    return blob, static_b, static_m
 
 
 @torch.no_grad()
@@ -278,7 +322,7 @@ def _clone_batch(d: Data, pad_edges: bool = False) -> Data:
             return out
         return t.clone()
     out = Data()
-    for k, v in d.__dict__.items():
+    for k, v in d.materialise().__dict__.items():
         if torch.is_tensor(v):
             v = dup(f".{k}", v)
         elif is_dataclass(v):
@@ -569,19 +613,43 @@ class StepBase:
             self.loop_counts["eager"] += 1
             return self.step(batches, merged)  # (the caller did not stage a merged batch: nothing static to replay on)
         st = getattr(self, "_train_static", None)
+        # batches out of ONE packed transfer (data.to_device_packed) with the layout the static buffers were built from: one
+        # device-to-device copy of the byte buffer + one of the feature block instead of a copy per tensor, no signature walk
+        ref = _shared_blob(batches, merged)
+        if ref is not None and st is not None and st.get("gsig") == ref.gsig and st["xkey"] == _feature_key(batches, merged):
+            with torch.no_grad():
+                st["blob"].copy_(ref.dev, non_blocking=True)
+                if merged is not None:
+                    st["merged"].x.copy_(merged.x, non_blocking=True)
+                    st["merged"]._struct_key = getattr(merged, "_struct_key", 0)
+                for t, b in batches.items():
+                    if b is not None:
+                        if merged is None:
+                            st["batches"][t].x.copy_(b.x, non_blocking=True)
+                        st["batches"][t]._struct_key = getattr(b, "_struct_key", 0)
+            st["fast"] = None
+            self.loop_counts["replayed"] += 1
+            total = self.replay()
+            return total.detach(), {t: v.detach() for t, v in self._static_out[1].items()}
         # equal structure fingerprints (stage_batches attaches them) + equal feature shapes = equal signature: the walk over
         # every tensor of the step's batches (0.2-0.3 ms of host time per step) is skipped for such a step
         fast = _fast_key(batches, merged)
         sig = st["sig"] if (st is not None and fast is not None and fast == st.get("fast")) else batch_signature(batches, merged)
         if st is None:
-            clone = lambda d: None if d is None else _clone_batch(d, pad_edges=True)
-            static_b = {t: clone(b) for t, b in batches.items()}
-            static_m = clone(merged)
-            _rewire_packed(static_b, static_m)
-            copy_batch_values(static_b, static_m, batches, merged)
+            blob = None
+            if ref is not None:
+                blob, static_b, static_m = _static_from_blob(ref, batches, merged)
+            else:
+                clone = lambda d: None if d is None else _clone_batch(d, pad_edges=True)
+                static_b = {t: clone(b) for t, b in batches.items()}
+                static_m = clone(merged)
+                _rewire_packed(static_b, static_m)
+                copy_batch_values(static_b, static_m, batches, merged)
             self.capture(static_b, static_m, warmup=0)
             st = self._train_static = {"sig": batch_signature(static_b, static_m), "batches": static_b, "merged": static_m,
                                        "fast": fast}
+            if blob is not None:
+                st.update(blob=blob, gsig=ref.gsig, xkey=_feature_key(batches, merged))
             if st["sig"] != sig:  # (cannot happen: the clones mirror the originals)
                 self._train_static = None
                 self.loop_counts["eager"] += 1

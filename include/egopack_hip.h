@@ -124,6 +124,22 @@ typedef struct egk_gemm_desc {
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_stats_blocks(const egk_gemm_desc* d);
+/* HOST helper of the batch builders (runs on the CPU, touches no device): ``np.stack([rng.randint(h, size = n) for h in
+ * high])`` of numpy's legacy RandomState on the generator's own state -- MT19937, mt_key[624] + *mt_pos as
+ * ``RandomState.get_state()`` returns them, both advanced in place (per value: v = next_uint32 & mask until v <= high - 1; a
+ * bound <= 1 consumes nothing) -- the consumption pattern of the reference's per-window segment sampling
+ * (data/base_dataset.py:128-139), so that a whole batch of windows is sampled in one call on the SAME random stream.
+ * out int64 [W][n].  Returns 0, -2 for a bound beyond 32 bits, -3 for bad arguments. */
+int64_t egk_host_bounded_draws(uint32_t* mt_key, int32_t* mt_pos, const int64_t* high, int64_t W, int32_t n, int64_t* out);
+
+/* HOST helper: the feature-store rows of W action windows in one call -- the reference's per-window segment sampling
+ * (BaseFrameDataset.random_sampling_indices / uniform_sampling_indices, data/base_dataset.py:128-155, applied to
+ * video_features[start:end] and np.take'n as in data/ego4d_fho.py:228-236), numpy's arithmetic operation by operation, random
+ * offsets drawn from the MT19937 state as egk_host_bounded_draws does (mt_key / mt_pos may be NULL when ``random`` is 0); a
+ * window the reference replaces by an all-zero clip gives n times -1.  out int64 [W][n].  Returns 0, -2, -3 as above. */
+int64_t egk_host_window_rows(uint32_t* mt_key, int32_t* mt_pos, const int64_t* first_row, const int64_t* video_len,
+                             const int64_t* start, const int64_t* end, int64_t W, int32_t n, int32_t random, int64_t* out);
+
 /* x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): the two bf16 operands that stand for an f32
  * matrix in a three-product contraction (egk_gemm_desc extra sources).  src f32 [rows, cols] with leading dimension ld_src;
  * hi (may be NULL: only lo is wanted, e.g. when hi is the bf16 copy the optimizer already keeps) and lo bf16 [rows, cols]

@@ -1,6 +1,7 @@
 """Host half of the resident input pipeline: the segment-sampling index arithmetic against the
 reference's own functions run on seeded numpy state (tests/golden/sampling.pt, oracle/make_golden_sampling.py)."""
 import numpy as np
+import pytest
 import torch
 
 from egopack_amd import feature_store as FS
@@ -86,3 +87,65 @@ def test_sample_builders_reproduce_the_reference_datasets_get(golden):
         if (item["lo"] < 0).any():
             seen.add("zero-clip")
     assert {("ar", "train"), ("ar", "val"), ("lta", "train"), ("oscc", "validation"), ("pnr", "train"), "zero-clip"} <= seen
+
+
+# ---- whole-batch sampling on the same random stream (the live loaders' builders) ----------------------------------------
+def _windows(W=700, seed=5):
+    rs = np.random.RandomState(seed)
+    vl = rs.randint(100, 4000, W)
+    st = rs.randint(-5, 3900, W)
+    en = st + rs.randint(0, 400, W)
+    en[::53] = st[::53]  # empty windows
+    st[::71] = vl[::71] + 3  # windows past the end of the video
+    return rs.randint(0, 10 ** 6, W), vl, st, en
+
+
+@pytest.mark.parametrize("random", [True, False])
+@pytest.mark.parametrize("n", [1, 3, 8])
+def test_window_rows_batch_equals_the_per_window_calls_and_leaves_the_stream_where_they_do(random, n):
+    fr, vl, st, en = _windows()
+    W = len(fr)
+    a, b, c = (np.random.RandomState(7) for _ in range(3))
+    for _ in range(2):  # (twice: the second call starts from the advanced generator state)
+        ref = np.stack([FS.window_rows(fr[w], vl[w], st[w], en[w], n, random, a) for w in range(W)])
+        np.testing.assert_array_equal(FS.window_rows_batch(fr, vl, st, en, n, random, b), ref)
+        np.testing.assert_array_equal(FS.window_rows_batch(fr, vl, st, en, n, random, c, native=False), ref)
+    assert (ref < 0).any() and (ref >= 0).any()
+    assert a.randint(1 << 30) == b.randint(1 << 30) == c.randint(1 << 30)
+    np.testing.assert_array_equal(a.standard_normal(4), b.standard_normal(4))  # (the cached-gaussian half of the state too)
+
+
+def test_window_rows_batch_on_the_module_level_stream():
+    fr, vl, st, en = _windows(300)
+    for seed in (3, 4):
+        np.random.seed(seed)
+        ref = np.stack([FS.window_rows(fr[w], vl[w], st[w], en[w], 3, True) for w in range(len(fr))])
+        x = np.random.rand()
+        np.random.seed(seed)
+        got = FS.window_rows_batch(fr, vl, st, en, 3, True)
+        assert np.array_equal(ref, got) and x == np.random.rand()
+
+
+def test_randint_sequence_replays_numpys_masked_rejection_sampling():
+    highs = np.array([0, 1, 2, 3, 5, 17, 64, 65, 1000, 1 << 20, (1 << 32), 1, 7], dtype=np.int64)
+    for n in (1, 3, 16):
+        a, b = np.random.RandomState(11), np.random.RandomState(11)
+        ref = np.stack([a.randint(h, size=n) if h > 0 else np.zeros(n, dtype=np.int64) for h in highs])
+        np.testing.assert_array_equal(FS.randint_sequence(b, highs, n), ref)
+        assert a.randint(1 << 30) == b.randint(1 << 30)
+    with pytest.raises(ValueError):
+        FS.randint_sequence(np.random.RandomState(1), np.array([(1 << 32) + 2]), 2)  # a bound numpy draws 64-bit words for
+
+
+def test_generator_state_route_without_direct_access(monkeypatch):
+    """A generator whose state block cannot be viewed in place goes through get_state / set_state with the same results."""
+    fr, vl, st, en = _windows(200)
+
+    class Wrapped:  # no ``_bit_generator``: only the public state interface
+        def __init__(self, seed):
+            self.rs = np.random.RandomState(seed)
+        get_state = lambda self: self.rs.get_state()
+        set_state = lambda self, s: self.rs.set_state(s)
+    a, b = np.random.RandomState(9), Wrapped(9)
+    np.testing.assert_array_equal(FS.window_rows_batch(fr, vl, st, en, 3, True, a), FS.window_rows_batch(fr, vl, st, en, 3, True, b))
+    assert a.randint(1 << 30) == b.rs.randint(1 << 30)

@@ -309,3 +309,76 @@ def test_bench_gpus_n_spawns_n_ranks_and_propagates_failure():
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs a ROCm GPU") >= 2  # both ranks were started and both raised
     assert '"metric"' not in r.stdout
+
+
+# ---- whole-batch builders of the live loaders --------------------------------------------------------------
+def _same_fields(a, b, skip=()):
+    from egopack_amd import engine as E
+    A, B = dict(E._walk(a)), dict(E._walk(b))
+    keys = lambda m: {k for k in m if "._" not in k and k not in skip}
+    assert keys(A) == keys(B), keys(A) ^ keys(B)
+    for k in keys(A):
+        if torch.is_tensor(A[k]):
+            assert A[k].dtype == B[k].dtype and torch.equal(A[k], B[k]), k
+        else:
+            assert A[k] == B[k], k
+
+
+@pytest.mark.parametrize("task", ["ar", "lta", "pnr", "oscc"])
+@pytest.mark.parametrize("T,split", [(4, "train"), (9, "train"), (22, "val"), (32, "train")])
+def test_resident_dataset_batch_builder_equals_collating_its_items(task, T, split):
+    """``SyntheticResidentDataset.batch(chunk)`` (index matrices, labels, graph templates and CSR assembled for the whole batch
+    with array arithmetic) is field for field ``collate([ds[i] for i in chunk])``, and consumes the sampling stream the same way."""
+    import numpy as np
+    mk = lambda: D.SyntheticResidentDataset(task, 40, T, seed=4, split=split, n_videos=3, frames=900)
+    a, b = mk(), mk()
+    for chunk in ([0, 1, 2, 3, 4, 5, 6, 7], [39, 3, 17], [12]):
+        np.random.seed(21)
+        ref = D.collate([a[i] for i in chunk])
+        after_ref = np.random.rand()
+        np.random.seed(21)
+        got = D.collate_chunk(b, chunk)
+        assert after_ref == np.random.rand()
+        _same_fields(ref, got)
+
+
+def test_pack_data_round_trip_is_one_buffer_per_batch():
+    b = _lta_batch(31)
+    buf, spec = D.pack_data(b)
+    assert buf.dtype == torch.uint8 and buf.dim() == 1
+    _same_fields(b, D.unpack_data(buf, spec))
+
+
+def test_packed_transfer_layout_lazy_views_and_static_rebuild():
+    """``to_device_packed`` on its CPU stand-in: the returned (lazy) batches equal the originals, edge-sized arrays occupy their
+    CAPACITY in the buffer so that LTA batches with different edge counts share ONE layout signature, attributes assigned before
+    the first use survive it, and ``rebuild(buffer, static=True)`` gives capacity-shaped views that take the next batch with one
+    buffer copy (what engine.StepBase.train_step does per replayed step)."""
+    from egopack_amd import engine as E
+    a, b = _lta_batch(41), _lta_batch(42)
+    b.edge_index = b.edge_index[:, 3:]
+    b.graph = D.build_csr(b.edge_index, b.pos.shape[0])
+    oa, ob = (D.to_device_packed([x, _lta_batch(43)], "cpu", pack_on_cpu=True) for x in (a, b))
+    ra, rb = oa[0]._blob, ob[0]._blob
+    assert ra is oa[1]._blob and ra.gsig is not None and ra.gsig == rb.gsig and ra.dev.shape == rb.dev.shape
+    assert "_fill" in oa[0].__dict__  # nothing built yet
+    oa[0].marker = torch.arange(3)
+    _same_fields(a, oa[0], skip=(".marker",))
+    assert "_fill" not in oa[0].__dict__ and torch.equal(oa[0].marker, torch.arange(3))
+    with pytest.raises(AttributeError):
+        oa[1].no_such_field
+    _same_fields(b, ob[0])
+    # static buffers: capacity shapes, filled by ONE copy of the next transfer's buffer
+    blob = torch.zeros_like(ra.dev)
+    static = ra.rebuild(blob, True)[0]
+    cap = E._edge_capacity(a.edge_index.shape[1])
+    assert static.edge_index.shape == (2, cap) and static.graph.col.shape == (cap,) and static.graph.t_wgt.shape == (cap,)
+    for src, ref in ((b, rb), (a, ra)):
+        blob.copy_(ref.dev)
+        e = src.edge_index.shape[1]
+        assert torch.equal(static.edge_index[:, :e], src.edge_index) and not static.edge_index[:, e:].any()
+        assert torch.equal(static.graph.rowptr, src.graph.rowptr) and torch.equal(static.graph.col[:e], src.graph.col)
+        assert torch.equal(static.y, src.y) and torch.equal(static.pos, src.pos)
+    # another node count is another layout
+    c = D.to_device_packed([_lta_batch(44, B=5), _lta_batch(43)], "cpu", pack_on_cpu=True)
+    assert c[0]._blob.gsig != ra.gsig
