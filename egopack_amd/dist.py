@@ -83,6 +83,12 @@ class GradSync:
         # concurrently with the remaining backward graphs, and that ordering has never executed against real RCCL peers --
         # the default issues every slice after the last stage, behind its collective's event
         self.adam_behind_collective = "adam_behind_collective" in os.environ.get("EGK_ENABLE", "")
+        self.hyper_ready = False  # set by a caller that has prepared the step's Adam constants itself (a captured exchange)
+
+    def capturable(self) -> bool:
+        """Whether the exchange can be recorded into a hipGraph: RCCL collectives enqueue device work only (a gloo group moves
+        the data through host memory, synchronously)."""
+        return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
     @property
     def skip_collectives(self) -> bool:
@@ -149,10 +155,14 @@ class GradSync:
         the first ``start`` of this step prepares the Adam constants and the coverage check counts this step's chunks only."""
         self._inflight.clear()
 
-    def start(self, opt, lo: int, hi: int) -> None:
+    def start(self, opt, lo: int, hi: int, after=()) -> None:
         """Enqueue conversion (compute stream) + all-reduce (communication stream) of flat_g[lo:hi] in chunks; the
-        compute stream goes on with the next backward stage while the collectives run."""
+        compute stream goes on with the next backward stage while the collectives run.  ``after``: streams whose work the
+        region's gradients also come from (weight-gradient side streams the compute stream has NOT waited for)."""
         if hi <= lo:
+            main = torch.cuda.current_stream(opt.flat_g.device)
+            for s_ in after:
+                main.wait_stream(s_)
             return
         flat_g = opt.flat_g
         compress = self.compress == "bf16"
@@ -166,9 +176,15 @@ class GradSync:
         if self._side is None:
             self._side = torch.cuda.Stream(device=flat_g.device)
         main = torch.cuda.current_stream(flat_g.device)
-        if not self._inflight:  # first region of this step: the step's Adam constants, ordered before every slice below
+        if not self._inflight and not self.hyper_ready:  # first region of this step: the step's Adam constants, ordered before every slice below
             opt.grad_scale = 1.0 / self.world
             opt.prepare_hyper()
+        if compress:
+            for s_ in after:  # (the conversion reads the gradients on the compute stream)
+                main.wait_stream(s_)
+        else:
+            for s_ in after:
+                self._side.wait_stream(s_)
         for b in range(lo, hi, self.chunk_elems):
             e = min(hi, b + self.chunk_elems)
             if compress:
@@ -185,17 +201,30 @@ class GradSync:
                     opt.launch(src, b, e)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
-            self._inflight.append((b, e, ev, src))
+            self._inflight.append({"b": b, "e": e, "ev": ev, "src": src, "stepped": self.adam_behind_collective})
+
+    def step_started_chunks(self, opt, stream) -> None:
+        """The Adam slice of every chunk started so far and not stepped yet, on ``stream``, each behind its collective: the
+        engine calls this beside the LAST weight-gradient launch of backward (the parameters of the regions exchanged by then
+        -- heads, SAGE stack -- are not read again), so that only the last region's slices are left for the end of the step."""
+        for c in self._inflight:
+            if not c["stepped"]:
+                stream.wait_event(c["ev"])
+                with torch.cuda.stream(stream):
+                    opt.launch(c["src"], c["b"], c["e"])
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                c["ev"], c["stepped"] = ev, True
 
     def finish_and_step(self, opt) -> None:
         """Adam launch per exchanged chunk, in the order the chunks were started, each behind its collective."""
         main = torch.cuda.current_stream(opt.flat_g.device)
         covered = 0
-        for b, e, ev, src in self._inflight:
-            main.wait_event(ev)
-            if not self.adam_behind_collective:
-                opt.launch(src, b, e)
-            covered += e - b
+        for c in self._inflight:
+            main.wait_event(c["ev"])
+            if not c["stepped"]:
+                opt.launch(c["src"], c["b"], c["e"])
+            covered += c["e"] - c["b"]
         self._inflight.clear()
         if covered != opt.flat_g.numel():
             raise RuntimeError(f"staged gradient exchange covered {covered} of {opt.flat_g.numel()} elements")

@@ -543,7 +543,15 @@ class StepBase:
 
     def _exchange_region(self, region):
         if self.sync is not None and self.sync.world > 1:
-            self.sync.start(self.optimizer, *region)
+            # (handoff: the region's weight gradients may still be running on their side streams -- the communication stream
+            #  waits for them, the backward stream goes straight on with the next stage)
+            after = ops.take_wgrad_streams() if getattr(self, "_handoff", False) else ()
+            self.sync.start(self.optimizer, *region, after=after)
+
+    def _stage_join(self):
+        """End of a backward stage: the stage's gradients are complete once the weight-gradient side streams are joined."""
+        if not getattr(self, "_handoff", False):
+            ops.join_wgrad(force=True)
 
     def _finish_staged(self):
         if self.sync is not None and self.sync.world > 1:
@@ -686,6 +694,7 @@ class StepBase:
         torch.cuda.synchronize()
         if hasattr(opt, "invalidate_lo_shadows"):
             opt.invalidate_lo_shadows()  # (a captured step must contain every refresh of the low halves it relies on)
+        self._graph_has_exchange = False
         if self._use_stages():
             return self._capture_staged(batches, merged)
         fuse_adam = self.sync is None or self.sync.world <= 1
@@ -780,11 +789,11 @@ class StepBase:
     def headwise_backward_ok(self) -> bool:
         return bool(getattr(self, "headwise_backward", False))
 
-    def _install_tail(self, plan) -> None:
+    def _install_tail(self, plan, hook=None) -> None:
         if plan is None:
             return
         g0 = self.optimizer.flat_g.data_ptr()
-        ops.set_last_wgrad_hook(plan[0], lambda: None)
+        ops.set_last_wgrad_hook(plan[0], hook or (lambda: None))
         ops.set_last_wgrad_tail(g0 + 4 * plan[1], g0 + 4 * plan[2])
 
     def _early_adam_plan(self, live):
@@ -847,8 +856,108 @@ class StepBase:
     def _early_adam_ok(self) -> bool:
         return bool(self.early_adam)
 
+    # The N-rank step as ONE hipGraph: the three stages, the region-wise collectives between them (communication stream, forked
+    # and joined inside the capture) and the per-chunk Adam launches.  Three graph launches + ~13 collectives + ~13 Adam
+    # launches issued from Python per step become one graph launch (--exchange-dry-run 8 on one GPU: 1.70 -> see DESIGN.md).
+    # RCCL collectives enqueue device work only and are capturable; the process group's watchdog keeps polling its events from
+    # its own thread, legal under CAPTURE_MODE 'thread_local'.  A capture that raises falls back to the three staged graphs
+    # (same collectives in the same order, so ranks that end up in different modes still match); EGK_DISABLE=one_graph_exchange
+    # turns it off.  A gloo group (host round trip) is never captured.
+    one_graph_exchange = True
+
+    def _one_graph_exchange_ok(self) -> bool:
+        import os
+        return bool(self.one_graph_exchange and "one_graph_exchange" not in os.environ.get("EGK_DISABLE", "")
+                    and self.sync is not None and self.sync.world > 1 and self.sync.capturable())
+
+    def _capture_exchange_graph(self, batches, merged):
+        opt, sync = self.optimizer, self.sync
+        regions = self._stage_regions()
+        live = [t for t in self.enabled if batches.get(t) is not None]
+        g = torch.cuda.CUDAGraph()
+        opt.grad_scale = 1.0 / sync.world
+        opt.prepare_hyper()
+        count = opt.step_count
+        prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_d = ops.set_deferred_forks(self.deferred_forks)
+        sync.begin_step()
+        sync.hyper_ready = True
+        self._handoff = "wgrad_handoff" not in getattr(self, "_dev_off", ())
+        prev_h = ops.set_wgrad_handoff(self._handoff)
+        try:
+            with torch.cuda.graph(g, stream=ops.unexcluded_stream(), capture_error_mode=CAPTURE_MODE):
+                # (the gradient buffer is cleared beside the forward pass, as in the one-rank capture: joined by _join_zero()
+                #  before the heads' backward writes the first gradient)
+                if not hasattr(self, "_zero_stream"):
+                    self._zero_stream = torch.cuda.Stream()
+
+                def issue_zero(ev):
+                    self._zero_stream.wait_event(ev)
+                    with torch.cuda.stream(self._zero_stream):
+                        opt.flat_g.zero_()
+                ops.stamp("step_start")
+                ops.defer_after_next_launch(issue_zero)
+                self._zero_pending = True
+                self._rng_in_graph = False
+                if self.input_hook is not None:
+                    self.input_hook()
+                total, vectors = self._stage_a(batches, merged)
+                self._join_zero()
+                ops.stamp("heads_done")
+                self._exchange_region(regions[0])
+                # beside the step's LAST weight-gradient launch (the grouped tail of the temporal pooling): the Adam slices of
+                # the regions exchanged by then, each behind its collective -- what the one-rank capture does with its early
+                # Adam launch; only the pooling's own slices are left for the end of the step
+                fired = []
+
+                def early_adam_hook():
+                    if fired or "exchange_early_adam" in getattr(self, "_dev_off", ()):
+                        return
+                    fired.append(True)
+                    if not hasattr(self, "_adam_stream"):
+                        self._adam_stream = torch.cuda.Stream()
+
+                    def issue(ev):
+                        self._adam_stream.wait_event(ev)
+                        sync.step_started_chunks(opt, self._adam_stream)
+                    ops.defer_after_next_launch(issue)
+                self._install_tail(self._tail_only_plan(live), early_adam_hook if self._early_adam_ok() else None)
+                self._stage_b()
+                ops.stamp("stack_done")
+                self._exchange_region(regions[1])
+                self._stage_c()
+                ops.stamp("backward_done")
+                self._exchange_region(regions[2])
+                sync.finish_and_step(opt)
+                ops.stamp("adam_done")
+                if "rng_in_graph" not in getattr(self, "_dev_off", ()):
+                    ops.advance_rng_device(opt.flat_p.device)
+                    self._rng_in_graph = True
+        finally:
+            self._handoff = False
+            ops.set_wgrad_handoff(prev_h)
+            sync.hyper_ready = False
+            sync.begin_step()
+            opt.step_count = count  # (finish_and_step counted the capture; replay() counts the steps that run)
+            ops.set_last_wgrad_hook(None, None)
+            ops.set_wgrad_side_streams(prev)
+            ops.set_wgrad_grouping(prev_g)
+            ops.set_deferred_forks(prev_d)
+        self._graph, self._static_out, self._fuse_adam = g, (total, vectors), True
+        self._graph_has_exchange = True
+        self._static_in = (batches, merged, self._stage_state, self._cuts)
+        return g
+
     def _capture_staged(self, batches, merged):
         """Three graphs (one per backward stage) from one memory pool; the gradient exchange sits between them."""
+        self._graph_has_exchange = False
+        if self._one_graph_exchange_ok():
+            try:
+                return self._capture_exchange_graph(batches, merged)
+            except Exception as e:  # noqa: BLE001
+                self.capture_notes = [*getattr(self, "capture_notes", []), f"one graph with the exchange: {e!r}"]
+                torch.cuda.synchronize()
         opt = self.optimizer
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         self._rng_in_graph = False  # (no staged graph advances the Philox offset word: replay() does, also after a one-piece capture)
@@ -1106,8 +1215,9 @@ class MTLStep(StepBase):
         finally:
             self.model.stage_cut = None
         self._head_batches = batches
+        self._join_zero()  # (a capture that clears the gradient buffer beside the forward pass: before the first gradient)
         total, vectors, leaves = self._heads_forward_backward(feats)
-        ops.join_wgrad(force=True)
+        self._stage_join()
         self._stage_state = (feats, leaves)
         return total, vectors
 
@@ -1116,13 +1226,13 @@ class MTLStep(StepBase):
         feats, leaves = self._stage_state
         order = list(feats)
         torch.autograd.backward([feats[t] for t in order], [leaves[t].grad for t in order])
-        ops.join_wgrad(force=True)
+        self._stage_join()
 
     def _stage_c(self):
         """TRN output -> inputs: final gradients of the temporal pooling."""
         if self._cuts:
             torch.autograd.backward([x for x, _ in self._cuts], [leaf.grad for _, leaf in self._cuts])
-            ops.join_wgrad(force=True)
+            self._stage_join()
 
 
 class EgoPackStep(StepBase):

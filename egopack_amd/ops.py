@@ -798,6 +798,8 @@ def join_wgrad(force: bool = False):
     """The current stream waits for every weight-gradient side stream with work in flight (call after backward,
     before the gradients are read: optimizer step, gradient exchange, or the end of a hipGraph capture).  ``force``: the
     caller IS the step's backward stream (see flush_wgrad)."""
+    if _wgrad.get("handoff") and not force:
+        return  # (end-of-backward callback while the engine hands the side streams to its exchange: take_wgrad_streams)
     flush_wgrad(in_backward=False, force=force)
     drain_deferred()
     cur = torch.cuda.current_stream() if _wgrad["pending"] else None
@@ -805,6 +807,26 @@ def join_wgrad(force: bool = False):
         cur.wait_stream(side)
     _wgrad["pending"].clear()
     _wgrad["queued"] = False
+
+
+def set_wgrad_handoff(on: bool) -> bool:
+    """While on, the end of a backward() call does NOT make the backward stream wait for the weight-gradient side streams:
+    the engine takes them over with ``take_wgrad_streams`` and orders its gradient exchange behind them instead, so the next
+    backward stage's dX chain starts beside the weight gradients of the stage before.  Returns the previous setting."""
+    prev = bool(_wgrad.get("handoff"))
+    _wgrad["handoff"] = bool(on)
+    return prev
+
+
+def take_wgrad_streams() -> list:
+    """Issue whatever is parked, then hand over the side streams with weight-gradient work in flight: the CALLER orders its
+    consumer of the gradients behind them (and eventually joins that consumer into the backward stream)."""
+    flush_wgrad(in_backward=False, force=True)
+    drain_deferred()
+    streams = list(_wgrad["pending"])
+    _wgrad["pending"].clear()
+    _wgrad["queued"] = False
+    return streams
 
 
 def _operand_rows(g: torch.Tensor, dtype: torch.dtype, pad_cols: int = 0) -> torch.Tensor:

@@ -73,15 +73,19 @@ def test_dp_step_with_bf16_compressed_allreduce(pg, golden):
         # Adam normalises the update; bf16 rounding of a gradient moves an update by << lr
         torch.testing.assert_close(opt.flat_p, ref, rtol=0, atol=2e-4)
         eager = opt.flat_p.clone()
-        # DP path, hipGraph: forward+backward captured, exchange + Adam outside the graph
-        step, opt, batches = _setup(golden, GradSync(2, chunk_mb=0.01, compress="bf16"))
-        step.capture(batches, warmup=1)
-        assert step._fuse_adam is False
-        for _ in range(2):
-            step.replay()
-        torch.cuda.synchronize()
-        assert opt.step_count == 3
-        torch.testing.assert_close(opt.flat_p, eager, rtol=0, atol=2e-6)
+        # DP path, hipGraph: the whole step incl. the RCCL collectives and the per-chunk Adam launches in ONE graph (default on
+        # an RCCL group), or the backward stages captured with exchange + Adam issued between / after the graphs
+        for one_graph in (True, False):
+            step, opt, batches = _setup(golden, GradSync(2, chunk_mb=0.01, compress="bf16"))
+            step.one_graph_exchange = one_graph
+            step.capture(batches, warmup=1)
+            assert step._graph_has_exchange is one_graph and bool(step._fuse_adam) is one_graph
+            assert isinstance(step._graph, list) is (not one_graph) and not getattr(step, "capture_notes", [])
+            for _ in range(2):
+                step.replay()
+            torch.cuda.synchronize()
+            assert opt.step_count == 3
+            torch.testing.assert_close(opt.flat_p, eager, rtol=0, atol=2e-6)
 
 
 def test_adam_reads_bf16_gradients(pg):
@@ -109,15 +113,17 @@ def test_staged_backward_equals_the_one_piece_backward(pg, golden, with_sync):
     from egopack_amd import ops
     from egopack_amd.dist import GradSync
 
-    def run(staged, graph):
+    def run(staged, graph, one_graph=False):
         sync = GradSync(2, chunk_mb=0.01, compress="bf16") if with_sync else None
         step, opt, batches = _setup(golden, sync)
         step.staged = staged
+        step.one_graph_exchange = one_graph
         if not with_sync:
             opt.grad_scale = 0.5
         if graph:
             step.capture(batches, warmup=1)
-            assert isinstance(step._graph, list) == bool(staged)
+            assert isinstance(step._graph, list) == (bool(staged) and not (one_graph and with_sync))
+            assert step._graph_has_exchange is bool(staged and one_graph and with_sync)
             for _ in range(2):
                 step.replay()
         else:
@@ -134,6 +140,7 @@ def test_staged_backward_equals_the_one_piece_backward(pg, golden, with_sync):
         assert torch.equal(run(True, False), ref)
         assert torch.equal(run(False, True), ref)
         assert torch.equal(run(True, True), ref)
+        assert torch.equal(run(True, True, one_graph=True), ref)  # (stages + collectives + Adam slices in ONE captured graph)
 
 
 def test_headwise_backward_equals_the_one_call_backward(golden):

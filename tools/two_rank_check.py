@@ -129,7 +129,8 @@ def run_replayed(args, device, seq_lo, seq_hi, sync, graph: bool):
     step, opt, dev, merged = build(args, device, seq_lo, seq_hi, sync)
     if graph:
         step.capture(dev, merged, warmup=2)
-        kind = "staged graphs" if isinstance(step._graph, list) else "one graph"
+        kind = ("staged graphs" if isinstance(step._graph, list) else
+                "one graph incl. the gradient exchange" if getattr(step, "_graph_has_exchange", False) else "one graph")
         for _ in range(2):
             step.replay()
     else:
