@@ -67,12 +67,16 @@ class GradSync:
     backward, so the first chunks overlap whatever the compute stream does next, and the optimiser
     waits for ``done`` before it reads the buffer."""
 
-    def __init__(self, world_size: int, chunk_mb: float = 32.0, group=None, compress: str = "none"):
+    def __init__(self, world_size: int, chunk_mb: float = 32.0, group=None, compress: str = "none",
+                 shard_update: Optional[bool] = None):
         """compress='bf16' (GPU only): the flat f32 gradient is converted to a bf16 copy by one kernel launch, the
-        bf16 copy is all-reduced (half the bytes on every xGMI link) and the Adam kernel reads it directly."""
+        bf16 copy is all-reduced (half the bytes on every xGMI link) and the Adam kernel reads it directly.
+        shard_update (default: EGK_ENABLE=sharded_update): reduce-scatter -> Adam on this rank's 1 / world slice ->
+        all-gather of the parameters (``_sharded_step``) instead of all-reduce -> the whole Adam pass on every rank."""
         if compress not in ("none", "bf16"):
             raise ValueError(compress)
         self.world, self.group, self.compress = world_size, group, compress
+        self.shard_update = ("sharded_update" in os.environ.get("EGK_ENABLE", "")) if shard_update is None else bool(shard_update)
         self.chunk_elems = max(8, (int(chunk_mb * (1 << 20) / 4) + 7) // 8 * 8)  # chunk starts stay 32-byte aligned
         self._side = None
         self._g16 = None
@@ -230,11 +234,93 @@ class GradSync:
             raise RuntimeError(f"staged gradient exchange covered {covered} of {opt.flat_g.numel()} elements")
         opt.step_count += 1
 
+    # ---- sharded update: reduce-scatter -> Adam on 1 / world of the buffers -> all-gather ---------------------------------
+    # An all-reduce IS a reduce-scatter followed by an all-gather; doing the optimizer step between the two halves moves the
+    # same bytes over the links (the gradient sum in, the updated f32 parameters out) while every rank runs Adam over its own
+    # 1 / world slice only: 0.75 GB of HBM traffic per step becomes 0.75 / world GB + one conversion pass that rebuilds the
+    # bf16 operand copies from the gathered parameters (0.15 GB).  The moments of the other slices are never touched on
+    # this rank (they stay zero: a checkpoint of a sharded run holds each rank's own moment slice -- gather before saving).
+    def shard_bounds(self, n: int) -> tuple:
+        """(slice length, begin, end of THIS rank's slice, end of the evenly sharded body).  Slices are multiples of 8
+        elements; [body, n) -- fewer than 8 * world elements -- is all-reduced and stepped on every rank."""
+        per = (n // self.world) // 8 * 8
+        real = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        r = dist.get_rank(self.group) if real == self.world else 0  # (a dry run on fewer processes: the first slice)
+        return per, r * per, (r + 1) * per, per * self.world
+
+    def _sharded_step(self, opt) -> None:
+        flat_g, n = opt.flat_g, opt.flat_g.numel()
+        per, lo, hi, body = self.shard_bounds(n)
+        real = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        on_gpu = flat_g.is_cuda
+        compress = self.compress == "bf16" and on_gpu
+        src = flat_g
+        if compress:
+            from . import _lib
+            from .ops import _ck, _p, _stream
+            if self._g16 is None or self._g16.numel() != n:
+                self._g16 = torch.empty(n, dtype=torch.bfloat16, device=flat_g.device)
+            src = self._g16
+            _ck(_lib.load().egk_cast(_stream(), _p(flat_g), 0, _p(src), 1, n), "egk_cast")
+        native = on_gpu and real == self.world and dist.get_backend(self.group) == "nccl" and not _skip["collectives"]
+
+        def scatter_sum():
+            if per:
+                if native:  # in place: this rank's slice of the buffer receives the sum
+                    dist.reduce_scatter_tensor(src[lo:hi], src[:body], op=dist.ReduceOp.SUM, group=self.group)
+                elif real == self.world:  # (gloo has no reduce-scatter: the sum of the whole body, of which one slice is used)
+                    all_reduce_sum_(src[:body], self.group)
+                else:
+                    all_reduce_sum_(src[lo:hi], self.group)  # dry run: a collective of one slice on the group there is
+            if body < n:
+                all_reduce_sum_(src[body:n], self.group)
+
+        def gather_params():
+            if not per or _skip["collectives"]:
+                return
+            flat_p = opt.flat_p
+            if native:
+                dist.all_gather_into_tensor(flat_p[:body], flat_p[lo:hi], group=self.group)
+            elif real == self.world:
+                mine = flat_p[lo:hi].cpu() if on_gpu else flat_p[lo:hi].clone()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                for r, part in enumerate(parts):
+                    flat_p[r * per:(r + 1) * per].copy_(part)
+            # (a dry run on fewer processes has nothing to gather from)
+
+        if on_gpu:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=flat_g.device)
+            main = torch.cuda.current_stream(flat_g.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                scatter_sum()
+            main.wait_stream(self._side)
+        else:
+            scatter_sum()
+        opt.grad_scale = 1.0 / self.world
+        opt.prepare_hyper()
+        opt.launch(src, lo, hi)
+        if body < n:
+            opt.launch(src, body, n)
+        if on_gpu:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                gather_params()
+            main.wait_stream(self._side)
+        else:
+            gather_params()
+        opt.refresh_shadows()  # the bf16 operand copies of the slices other ranks stepped
+        opt.step_count += 1
+
     def reduce_and_step(self, opt) -> None:
         """Gradient exchange + optimizer step of a ``FlatAdam`` as a PIPELINE over chunks of the flat buffer: chunk i is
         converted (bf16 compression) on the compute stream, all-reduced on the communication stream, and stepped by
         its own Adam launch as soon as its collective is done -- the Adam launch of chunk i runs while chunks i+1..
         are still on the xGMI links (the one-shot form waited for the last collective before the first Adam byte)."""
+        if self.shard_update:
+            return self._sharded_step(opt)
         flat_g = opt.flat_g
         n = flat_g.numel()
         compress = self.compress == "bf16"

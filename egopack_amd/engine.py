@@ -539,6 +539,8 @@ class StepBase:
             return False
         if self.staged is None and (self.sync is None or self.sync.world <= 1):
             return False
+        if self.sync is not None and getattr(self.sync, "shard_update", False):
+            return False  # (the sharded update exchanges the whole buffer once: one-piece backward)
         return self._stage_regions() is not None
 
     def _exchange_region(self, region):

@@ -156,3 +156,74 @@ def test_gloo_world2_meters_and_batch_sharded_eval_loader():
     single = [b.x.tolist() for b in D.BatchLoader(ds, 4, shuffle=False, drop_last=False)]
     assert len(single) == 6 and len(out[0][2]) == 3 and len(out[1][2]) == 3
     assert [out[i % 2][2][i // 2] for i in range(6)] == single
+
+
+# ---- sharded update: reduce-scatter -> Adam on this rank's slice -> all-gather (VERDICT r2 #5b) -----------------------------
+class _CpuAdam:
+    """The slice-wise interface of optim.FlatAdam (flat buffers, prepare_hyper, launch(grads, lo, hi), refresh_shadows) in
+    plain torch on the CPU: what dist.GradSync drives.  Test infrastructure (the product optimizer needs a ROCm device)."""
+
+    def __init__(self, n):
+        g = torch.Generator().manual_seed(3)
+        self.flat_p = torch.randn(n, generator=g)
+        self.flat_g, self.flat_m, self.flat_v = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+        self.step_count, self.grad_scale, self.refreshed = 0, 1.0, 0
+
+    def prepare_hyper(self):
+        t = self.step_count + 1
+        self._c = (1.0 - 0.9 ** t, (1.0 - 0.999 ** t) ** 0.5, self.grad_scale)
+
+    def launch(self, grads=None, lo=0, hi=None):
+        sl = slice(lo, self.flat_p.numel() if hi is None else hi)
+        g = (self.flat_g if grads is None else grads)[sl] * self._c[2]
+        self.flat_m[sl] = 0.9 * self.flat_m[sl] + 0.1 * g
+        self.flat_v[sl] = 0.999 * self.flat_v[sl] + 0.001 * g * g
+        self.flat_p[sl] -= 1e-2 * (self.flat_m[sl] / self._c[0]) / (self.flat_v[sl].sqrt() / self._c[1] + 1e-8)
+
+    def refresh_shadows(self):
+        self.refreshed += 1
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    init_from_env(backend="gloo")
+    n = 1000  # slices of 496 elements, an 8-element remainder stepped on both ranks
+    ref, shd = _CpuAdam(n), _CpuAdam(n)
+    sync = GradSync(world, shard_update=True)
+    per, lo, hi, body = sync.shard_bounds(n)
+    ok = (per, lo, hi, body) == (496, rank * 496, (rank + 1) * 496, 992)
+    for step in range(3):
+        g = torch.randn(n, generator=torch.Generator().manual_seed(100 * step + rank))
+        # all-reduce, then the whole Adam pass on every rank
+        ref.flat_g.copy_(g)
+        dist.all_reduce(ref.flat_g)
+        ref.grad_scale = 1.0 / world
+        ref.prepare_hyper()
+        ref.launch()
+        ref.step_count += 1
+        # reduce-scatter (all-reduce on gloo), Adam on the own slice + the remainder, all-gather of the parameters
+        shd.flat_g.copy_(g)
+        sync.reduce_and_step(shd)
+    ok = ok and torch.equal(ref.flat_p, shd.flat_p) and shd.step_count == 3 and shd.refreshed == 3
+    other = torch.ones(n, dtype=torch.bool)
+    other[lo:hi] = False
+    other[body:] = False
+    ok = ok and not shd.flat_m[other].any() and bool(shd.flat_m[lo:hi].any()) and torch.equal(shd.flat_m[lo:hi], ref.flat_m[lo:hi])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gloo_world2_sharded_update_equals_allreduce_then_full_adam():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert res == [(0, True), (1, True)]

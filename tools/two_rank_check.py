@@ -15,7 +15,9 @@ Checks (f32 mode, dropout 0, 3-task MTL step, global batch = 2 x B sequences per
     mode is what makes the two agree, and the default is each replica = the reference at its LOCAL batch size;
   * both ranks end with bit-identical parameters in both modes;
   * bf16 mode (the benchmark's): the step captured on both ranks as STAGED hipGraphs (gradient exchange between the graph
-    launches) and replayed gives the parameters of the eagerly issued steps, and both ranks stay bit-identical.
+    launches) and replayed gives the parameters of the eagerly issued steps, and both ranks stay bit-identical;
+  * the sharded update (GradSync(shard_update=True): reduce-scatter -> Adam on the own half -> all-gather of the parameters)
+    gives the parameters of the all-reduce path, and both ranks stay bit-identical.
 The parent process never touches the GPU: it starts the two rank processes and relays rank 0's verdict (last stdout line,
 JSON) and exit code.  Usage: python tools/two_rank_check.py [--hidden 512] [--batch 8] [--T 16] [--steps 2]"""
 import argparse
@@ -168,6 +170,11 @@ def worker(args):
         other = [torch.empty_like(par) for _ in range(2)]
         dist.all_gather(other, par)
         rep[graph] = (par, kind, bool(torch.equal(other[0], other[1])))
+    # sharded update (reduce-scatter -> Adam on the own half -> all-gather of the parameters), captured step replayed
+    par_s, kind_s = run_replayed(args, device, rank * B, (rank + 1) * B, edist.GradSync(2, shard_update=True), True)
+    other = [torch.empty_like(par_s) for _ in range(2)]
+    dist.all_gather(other, par_s)
+    shard = (par_s, kind_s, bool(torch.equal(other[0], other[1])))
     ops.set_compute("f32")
     dist.barrier()
     if rank == 0:
@@ -186,13 +193,16 @@ def worker(args):
         out["bf16_replay"] = {"capture": rep[True][1], "ranks_bit_identical": rep[True][2] and rep[False][2],
                               "replayed_vs_eager_rel": float((pg.double() - pe.double()).norm() / pe.double().norm()),
                               "replayed_vs_eager_max_abs": float((pg - pe).abs().max())}
+        out["sharded_update"] = {"capture": shard[1], "ranks_bit_identical": shard[2],
+                                 "vs_allreduce_replay_max_abs": float((shard[0] - pg).abs().max())}
         out["config"] = dict(hidden=args.hidden, batch_per_rank=B, T=args.T, steps=args.steps, mode="f32", tasks=list(ORDER))
         e, l = out["exact"], out["local"]
         ok = (e["objective_rel"] <= 1e-6 and e["grad_rel"] <= 2e-3 and e["param_frac_within_2e-4"] >= 0.999
               and e["ranks_bit_identical"] and l["ranks_bit_identical"]
               and l["grad_rel"] >= 100 * e["grad_rel"] and l["param_frac_within_2e-4"] < 0.99
               and out["bf16_replay"]["capture"] == "staged graphs" and out["bf16_replay"]["ranks_bit_identical"]
-              and out["bf16_replay"]["replayed_vs_eager_rel"] <= 1e-6)
+              and out["bf16_replay"]["replayed_vs_eager_rel"] <= 1e-6
+              and out["sharded_update"]["ranks_bit_identical"] and out["sharded_update"]["vs_allreduce_replay_max_abs"] <= 1e-6)
         out["ok"] = bool(ok)
         print(json.dumps(out), flush=True)
         dist.barrier()
