@@ -2331,6 +2331,32 @@ def dropout(x, p: float, training: bool):
     return _Dropout.apply(x, float(p))
 
 
+class _Relu(torch.autograd.Function):
+    """max(x, 0) as a launch of its own (where no contraction epilogue can take it: the input ReLU of the multi-scale relation
+    module, reference models/TRN.py:32-36).  Forward and backward are the same gate kernel: y = x > 0 ? x : 0, dx = y > 0 ? dy : 0."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        _ck(_lib.load().egk_relu_gate(_stream(), _p(x), _p(x), _p(y), x.numel(), _dt(x)), "egk_relu_gate")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _match(_c(dy), y.dtype)
+        dx = torch.empty_like(y)
+        _ck(_lib.load().egk_relu_gate(_stream(), _p(dy), _p(y), _p(dx), y.numel(), _dt(y)), "egk_relu_gate")
+        return dx
+
+
+def relu(x):
+    return _Relu.apply(x)
+
+
 class _WeightedMeanSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *vectors):

@@ -382,3 +382,22 @@ def test_packed_transfer_layout_lazy_views_and_static_rebuild():
     # another node count is another layout
     c = D.to_device_packed([_lta_batch(44, B=5), _lta_batch(43)], "cpu", pack_on_cpu=True)
     assert c[0]._blob.gsig != ra.gsig
+
+
+def test_relation_module_multiscale_structure_and_init_equal_the_reference_class(golden):
+    """``RelationModuleMultiScale`` (reference models/TRN.py:9-74): scales, relation sets, sub-sampling, the relations a forward
+    pass selects, state-dict keys and -- under the same seed -- the initial parameters bit for bit, against the reference class
+    itself (tests/golden/trn_multiscale.pt); reachable under the reference's import path."""
+    from models.TRN import RelationModuleMultiScale
+    for c in golden("trn_multiscale")["cases"]:
+        torch.manual_seed(c["seed"])
+        m = RelationModuleMultiScale(c["img_feature_dim"], c["num_bottleneck"], c["num_frames"])
+        assert m.scales == c["scales"] and m.subsample_scales == c["subsample_scales"] and m.subsample_num == 3
+        assert [[list(r) for r in rs] for rs in m.relations_scales] == c["relations_scales"]
+        assert [[list(r) for r in m.selected_relations(i)] for i in range(len(m.scales))] == c["selected"]
+        sd = m.state_dict()
+        assert list(sd) == list(c["state_dict"])
+        for k, v in c["state_dict"].items():
+            assert torch.equal(sd[k], v), k
+        with pytest.raises(ValueError):
+            m(torch.zeros(2, c["num_frames"] + 1, c["img_feature_dim"]))
