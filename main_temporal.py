@@ -14,6 +14,7 @@ layout."""
 from __future__ import annotations
 
 import logging
+import time
 from pathlib import Path
 
 import torch
@@ -27,6 +28,7 @@ from utils.meters import build_meter_for_dataset
 from validate import validate, validate_lta, validate_pnr
 
 logger = logging.getLogger("main_temporal")
+RATE_WARMUP_STEPS = 30  # steps of an epoch left out of its logged steady-state rate (eager steps, the capture, first replays)
 
 
 def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda", store=None):
@@ -38,13 +40,27 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda", store=No
     it, sums, counts = 0, {t: None for t in order}, {t: 0 for t in order}  # loss sums stay on the device until the epoch ends
     hosts = (dict(zip(order, batch)) for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]))
     # batch i + 1 is collated and copied to the device (copy stream) while step i runs
+    mark = None  # (iteration, wall clock, sequences so far) once the eager steps and the capture are behind: steady-state rate
+    seqs = 0
     for batches, merged in engine.StagedBatches(hosts, device, order, fused=step.fused, store=store, dtype=ops.act_dtype()):
         total, vectors = step.train_step(batches, merged)  # eager for the first steps, then the captured step
         for t, v in vectors.items():  # (no host synchronisation per step: the next batch is staged while this one runs)
-            s_ = v.detach().double().sum()
-            sums[t] = s_ if sums[t] is None else sums[t] + s_
+            s_ = v.detach().sum(dtype=torch.float64)
+            if sums[t] is None:
+                sums[t] = s_
+            else:
+                sums[t].add_(s_)
             counts[t] += v.numel()
+        seqs += sum(int(b.num_graphs) for b in batches.values() if b is not None)
         it += 1
+        if it == RATE_WARMUP_STEPS and torch.cuda.is_available():
+            torch.cuda.synchronize()
+            mark = (it, time.perf_counter(), seqs)
+    if mark is not None and it > mark[0]:
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - mark[1]
+        logger.info("epoch %d: steady state %.3f ms/step, %.0f clip-seqs/s on this rank (%d steps after the first %d)", epoch,
+                    dt * 1e3 / (it - mark[0]), (seqs - mark[2]) / dt, it - mark[0], mark[0])
     logger.info("epoch %d: %d iterations, train loss %s", epoch, it,
                 {t: round(float(sums[t]) / max(counts[t], 1), 4) for t in order if counts[t]})
     lc = getattr(step, "loop_counts", None)
