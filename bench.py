@@ -270,7 +270,7 @@ def parse_args(argv=None):
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--trn-hidden", type=int, default=1024)
     ap.add_argument("--dropout", type=float, default=0.5)
-    ap.add_argument("--compute", choices=["bf16", "bf16_f32act", "f32"], default="bf16")
+    ap.add_argument("--compute", choices=["bf16", "bf16_f32act", "bf16x3", "f32"], default="bf16")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mtl")
     ap.add_argument("--bank", type=int, default=4096, help="prototypes per task bank (egopack_oscc)")
     ap.add_argument("--graphone-k", type=int, default=4)

@@ -15,6 +15,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variants", default="1", help="comma list of egk_gemm_set_pipeline values (0 generic, 1 auto, 2/3/4)")
 ap.add_argument("--layouts", action="store_true", help="same dims in the four operand layouts instead of the workload shapes")
 ap.add_argument("--splitk", default="", help="comma list of forced split-K factors (applied to the dW shapes)")
+ap.add_argument("--hp", type=int, default=0, help="the temporal pooling's contractions at this hidden size (e.g. 4096: BASELINE configs[1..2] as published) instead of the workload list")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
@@ -66,6 +67,13 @@ def time_us(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+if args.hp:
+    HP = args.hp
+    SHAPES = [("fwd TRN1 merged", N6, HP, 4608, False, False, False), ("fwd TRN2 merged", N6, HP, HP, False, False, False),
+              ("fwd TRN3 merged", N6, H, HP, False, False, False),
+              ("dX TRN3", N6, HP, H, False, True, False), ("dX TRN2", N6, HP, HP, False, True, False),
+              ("dW TRN1 merged", HP, 4608, N6, True, True, True), ("dW TRN2 merged", HP, HP, N6, True, True, True),
+              ("dW TRN3 merged", H, HP, N6, True, True, True)]
 if args.layouts:
     SHAPES = []
     for (M, N, K) in [(2048, 2048, 2048), (4096, 2048, 2048), (4096, 4096, 4096), (8192, 8192, 8192)]:
