@@ -327,6 +327,11 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
         if srcs is None:  # (shapes the pipelined kernel does not take: the exact-f32 matrix instructions instead)
             compute = F32
         else:
+            if dbias is not None:
+                # the kernel's fused bias gradient sums the A image of a SINGLE K source: with three products in the launch
+                # the column sum of dY (A as stored: [K rows, M columns]) is a launch of its own, in f32
+                _colsum_into(A1.as_strided((K1, M), (lda1, 1)), dbias, True)
+                dbias = None
             compute, op_dt = BF16, BF16
             (A1, lda1, B1, ldb1, K1), rest = srcs[0], srcs[1:]
             A2 = B2 = None
@@ -403,40 +408,56 @@ def _split_rows(x, rows, cols, ld, want_hi=True):
     return hi, lo
 
 
-def _x3_act(A, rows, K, ld):
+def _x3_act(A, rows, cols, ld):
+    """(hi, lo or None, ld of the halves) of an f32 operand stored as [rows, cols] with row stride ``ld`` (row-major A: [M, K];
+    a k-major one: [K, M])."""
     src = getattr(A, "_egk_bf16_src", None)
-    if src is not None and src.shape == A.shape and A.dim() == 2 and A.shape[1] == K and ld == K:
-        return src, None, K  # widened from bf16 by to_act: the value IS its bf16 half
-    key = (A.data_ptr(), rows, K, ld, A._version)
+    if src is not None and src.shape == A.shape and A.dim() == 2 and tuple(A.shape) == (rows, cols) and ld == cols:
+        return src, None, cols  # widened from bf16 by to_act: the value IS its bf16 half
+    key = (A.data_ptr(), rows, cols, ld, A._version)
     cache = _x3["cache"]
-    hit = cache.get(key) if cache is not None else None
+    if cache is None:
+        # outside a precise_scope (the mode as a TRAINING mode): the halves ride on the tensor itself, so the activation a
+        # layer split in forward is not split again for its weight gradient, and a gradient is split once for dX and dW
+        own = getattr(A, "_egk_x3", None)
+        if own is not None and own[0] == key:
+            return own[1], own[2], cols
+        hi, lo = _split_rows(A, rows, cols, ld)
+        try:
+            A._egk_x3 = (key, hi, lo)
+        except Exception:  # noqa: BLE001
+            _x3["keep"].append((hi, lo, A))
+        return hi, lo, cols
+    hit = cache.get(key)
     if hit is None:
-        hi, lo = _split_rows(A, rows, K, ld)
-        hit = (hi, lo, A)  # (A is held so that its address cannot be handed to another tensor while the entry lives)
-        if cache is not None:
-            cache[key] = hit
-        else:
-            _x3["keep"].append(hit)
-    return hit[0], hit[1], K
+        hi, lo = _split_rows(A, rows, cols, ld)
+        hit = cache[key] = (hi, lo, A)  # (A is held so that its address cannot be handed to another tensor while the entry lives)
+    return hit[0], hit[1], cols
 
 
-def _x3_weight(B, rows, K, ld):
+def _x3_weight(B, rows, cols, ld):
+    """(hi, lo) of the B operand stored as [rows, cols] ([N, K], or [K, N] for a k-major one): a weight in the optimizer's flat
+    buffers brings its halves along, a frozen one is split once, anything else (an activation standing as B in a weight
+    gradient) is split here."""
     sh, lo = getattr(B, "_egk_shadow", None), getattr(B, "_egk_lo", None)
-    if sh is not None and lo is not None and tuple(sh.shape) == (rows, K) and ld == K:
+    if sh is not None and lo is not None and tuple(sh.shape) == (rows, cols) and ld == cols:
         lo_view, fresh, refresh = lo
         if not fresh():
             refresh()
         return sh, lo_view
     c = getattr(B, "_egk_split", None)
-    if c is not None and c[0] == B._version and c[1] == B.data_ptr() and tuple(c[2].shape) == (rows, K):
+    if c is not None and c[0] == B._version and c[1] == B.data_ptr() and tuple(c[2].shape) == (rows, cols):
         return c[2], c[3]
     if sh is not None and lo is None and not torch.cuda.is_current_stream_capturing():
         init = getattr(B, "_egk_lo_init", None)  # in the flat buffers, low halves not allocated yet (optim.FlatAdam)
         if init is not None and init() and getattr(B, "_egk_lo", None) is not None:
-            return _x3_weight(B, rows, K, ld)
-    hi, lo = _split_rows(B, rows, K, ld)
-    if sh is None and not B.requires_grad and not torch.cuda.is_current_stream_capturing():  # (frozen: as weight_operand's copies)
-        try:
+            return _x3_weight(B, rows, cols, ld)
+    if sh is None and getattr(B, "_egk_bf16_src", None) is not None:
+        hi, lo_, _ = _x3_act(B, rows, cols, ld)  # an activation as B: the activation rules (a widened one has no low half)
+        return hi, lo_
+    hi, lo = _split_rows(B, rows, cols, ld)
+    if sh is None and not B.requires_grad and not torch.cuda.is_current_stream_capturing():
+        try:  # (frozen weights and banks: as weight_operand's copies; an in-place update moves ``_version``)
             B._egk_split = (B._version, B.data_ptr(), hi, lo)
         except Exception:  # noqa: BLE001
             _x3["keep"].append((hi, lo))
@@ -447,21 +468,27 @@ def _x3_weight(B, rows, K, ld):
 
 def _x3_expand(M, N, logical, transA, transB):
     """[(A, lda, B, ldb, K)] f32 sources -> the bf16 sources of the three-product contraction, or None when the pipelined kernel
-    cannot take them (transposed operands, a K that is not a multiple of 64, unaligned rows)."""
-    if transA or transB or len(logical) > 2:
+    cannot take them (a K that is not a multiple of 64, rows that are not 16-byte aligned as bf16, more than two sources).
+    Operands keep their layout: a k-major (transposed) operand is split as the [K, rows] array it is stored as."""
+    if len(logical) > 2:
         return None
+    shapes = []
     for A, lda, B, ldb, K in logical:
-        if (K % 64 or K == 0 or A.dtype != torch.float32 or B.dtype != torch.float32 or lda % 4 or ldb % 4
+        ar, ac = (K, M) if transA else (M, K)
+        br, bc = (K, N) if transB else (N, K)
+        if (K % 64 or K == 0 or A.dtype != torch.float32 or B.dtype != torch.float32 or lda % 4 or ldb % 4 or ac % 8 or bc % 8
                 or A.data_ptr() % 16 or B.data_ptr() % 16):
             return None
+        shapes.append((ar, ac, br, bc))
     out = []
-    for A, lda, B, ldb, K in logical:
-        ah, al, a_ld = _x3_act(A, M, K, lda)
-        bh, bl = _x3_weight(B, N, K, ldb)
-        out.append((ah, a_ld, bh, K, K))
-        out.append((ah, a_ld, bl, K, K))
+    for (A, lda, B, ldb, K), (ar, ac, br, bc) in zip(logical, shapes):
+        ah, al, a_ld = _x3_act(A, ar, ac, lda)
+        bh, bl = _x3_weight(B, br, bc, ldb)
+        out.append((ah, a_ld, bh, bc, K))
+        if bl is not None:
+            out.append((ah, a_ld, bl, bc, K))
         if al is not None:
-            out.append((al, K, bh, K, K))
+            out.append((al, ac, bh, bc, K))
     return out
 
 

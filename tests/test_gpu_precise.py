@@ -105,6 +105,51 @@ def test_three_product_contraction_is_f32_grade(ops, M, N, K, K2):
         assert _rel(out16.cpu(), ref) > 1e-3
 
 
+@pytest.mark.parametrize("tA,tB", [(False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 2048), (640, 1024, 6144)])
+def test_three_product_contraction_with_k_major_operands(ops, M, N, K, tA, tB):
+    """The dX (B stored [K, N]) and dW (A stored [K, M], B stored [K, N], accumulating, with the bias gradient) forms of a
+    Linear's backward in three-product mode: operands are split in the layout they are stored in; the bias gradient, which
+    the kernel can only fuse for a single K source, becomes a column-sum launch of its own.  <= 3e-5 against fp64."""
+    g = gen(M + 3 * N + K + tA + 2 * tB)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((K, N) if tB else (N, K), generator=g)
+    ref = (A.double().t() if tA else A.double()) @ (B.double() if tB else B.double().t())
+    out = torch.randn(M, N, generator=g)
+    ref = ref + out.double()
+    out = out.to(DEV)
+    kw = {}
+    if tA and tB:
+        db = torch.randn(M, generator=g)
+        ref_db = db.double() + A.double().sum(0)
+        kw["dbias"] = db = db.to(DEV)
+    ops.gemm(M, N, A.to(DEV), A.shape[1], B.to(DEV), B.shape[1], K, out, N, transA=tA, transB=tB, accumulate=True, compute=ops.X3, **kw)
+    assert _rel(out.cpu(), ref) < 3e-5, _rel(out.cpu(), ref)
+    if kw:
+        assert _rel(db.cpu(), ref_db) < 1e-6
+
+
+def test_linear_backward_in_three_product_mode_is_f32_grade(ops):
+    """A Linear's forward + backward under compute mode 'bf16x3' (f32 activations, every contraction three bf16 products):
+    output, input gradient, weight and bias gradient against fp64 <= 3e-5 -- the mode as a TRAINING mode, not only the
+    forward-only feature pass."""
+    from egopack_amd.models.layers import Linear
+    torch.manual_seed(5)
+    lin = Linear(1024, 512).to(DEV)
+    x = torch.randn(2048, 1024, device=DEV, requires_grad=True)
+    cot = torch.randn(2048, 512, device=DEV)
+    with ops.compute_mode("bf16x3"):
+        y = lin(x)
+        (y * cot).sum().backward()
+        ops.join_wgrad(force=True)
+    torch.cuda.synchronize()
+    xd, wd, bd, cd = x.detach().double().cpu(), lin.weight.detach().double().cpu(), lin.bias.detach().double().cpu(), cot.double().cpu()
+    assert _rel(y.detach().cpu(), xd @ wd.t() + bd) < 3e-5
+    assert _rel(x.grad.cpu(), cd @ wd) < 3e-5
+    assert _rel(lin.weight.grad.cpu(), cd.t() @ xd) < 3e-5
+    assert _rel(lin.bias.grad.cpu(), cd.sum(0)) < 1e-6
+
+
 def test_three_product_linear_uses_the_optimizers_halves(ops):
     """A Linear whose weight lives in FlatAdam's flat buffers: hi = the bf16 shadow the Adam kernel keeps, lo = the flat low
     buffer (refreshed on demand, stale after every optimizer launch)."""
