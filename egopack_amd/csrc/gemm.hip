@@ -1298,13 +1298,14 @@ __device__ __forceinline__ void read_step32(float (&f)[NF][4], unsigned st, unsi
 // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only) for outputs whose 128-row tiling
 // loads the CUs unevenly -- two co-resident workgroups share a CU's matrix pipes, so a launch takes as long as the rows on its
 // fullest CU: 6144 x 1024 is 384 tiles of 128 rows (2 x 128 rows on half of the CUs) but 512 tiles of 96 rows (2 x 96 everywhere).
-template <bool TRA, bool TRB, int NI = 4>
-__global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs g) {
+template <bool TRA, bool TRB, int NI = 4, bool VIRT = false>
+__device__ __forceinline__ void gemm_pipe_f32_body(const GemmArgs& g, const int bid) {
     static_assert(NI == 4 || (NI == 3 && !TRA), "96-row tiles: row-major A");
     constexpr int IMG = 16384, IMG_A = NI * 4096, STAGE = IMG_A + IMG, KT = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int z, tm, tn;
-    tile_of(g, blockIdx.x, z, tm, tn);
+    if constexpr (VIRT) tile_of_virtual(g, bid, z, tm, tn);  // (the caller did the XCD placement: grouped launches)
+    else tile_of(g, bid, z, tm, tn);
     const int m0 = tm * (32 * NI), n0 = tn * BN;
     const int nkt = total_tiles(g, KT);
     const int per = (nkt + g.splitk - 1) / g.splitk;
@@ -1368,6 +1369,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
     };
+    // fused bias gradient (dW form: op(A) = dY^T, so sum_k op(A)[m, k] is the column sum of dY), as in the bf16 kernel: the
+    // workgroups of the first column tile also sum their k-major A image over k.  Thread -> 16-byte chunk column bcc (4
+    // output rows) and a group of 4 of the tile's 32 k-rows; combined through LDS at the end.
+    const bool do_bias = TRA && g.dbias != nullptr && tn == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int bcc = tid & 31, bkg = tid >> 5;
     if (nt > 0) issue(0, 0);
     for (int it = 0; it < nt; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // 2-stage ring: only tile ``it`` is in flight here
@@ -1375,6 +1382,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs 
         if (it + 1 < nt) issue(it + 1, (it + 1) & 1);    // in flight under this tile's 4096 MFMA cycles
         const unsigned stA = lds_base + (it & 1) * STAGE, stB = stA + IMG_A;
         float a0[NI][4], b0[4][4], a1[NI][4], b1[4][4];
+        f32x4 bz[4];
+        if constexpr (TRA) {
+            if (do_bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = bkg * 4 + r;
+                    const unsigned ad = stA + (unsigned)(k * 512 + ((bcc ^ (((k >> 2) & 3) << 2)) << 4));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(bz[r]) : "v"(ad));
+                }
+            }
+        }
         read_step32<TRA, 0, NI>(a0, stA, a_rm, a_tr);
         read_step32<TRB, 0, 4>(b0, stB, b_rm, b_tr);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1385,9 +1403,55 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(a1, b1);
+        if constexpr (TRA) {
+            if (do_bias) {  // (the reads completed at the first lgkmcnt(0) of this tile)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsum[e] += bz[r][e];
+            }
+        }
+    }
+    if constexpr (TRA) {
+        if (g.dbias != nullptr && tn == 0) {  // block-uniform
+            __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [8 k groups][128 rows]
+            float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[bkg * 128 + bcc * 4 + e] = bsum[e];
+            __syncthreads();
+            if (tid < 128 && m0 + tid < g.M) {
+                float t = 0.f;
+                for (int q = 0; q < 8; ++q) t += red[q * 128 + tid];
+                if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
+                else g.dbias[m0 + tid] += t;
+            }
+            __syncthreads();
+        }
     }
     if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
     else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
+}
+
+template <bool TRA, bool TRB, int NI = 4>
+__global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs g) {
+    gemm_pipe_f32_body<TRA, TRB, NI>(g, blockIdx.x);
+}
+
+// grouped launch of exact-f32 contractions (the weight gradients of the reference-precision step): XCD-packed placement
+// as gemm_pipe_group_kernel -- the tiles of all problems form one list, XCD x takes a consecutive run of it
+template <bool TRA, bool TRB>
+__global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_group_kernel(const GemmGroup gg) {
+    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+    const int q = gg.total >> 3, r = gg.total & 7;
+    if (slot >= q + (xcd < r ? 1 : 0)) return;
+    int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    int pi = 0;
+    for (; pi + 1 < gg.count; ++pi) {  // (uniform scalar walk over <= 8 problems)
+        const int t = gg.p[pi].tiles_m * gg.p[pi].tiles_n;
+        if (v < t) break;
+        v -= t;
+    }
+    gemm_pipe_f32_body<TRA, TRB, 4, true>(gg.p[pi], v);
 }
 
 // Sum the split-K slabs in slab order (bitwise reproducible) and apply the epilogue.
@@ -1518,6 +1582,9 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_group_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_group_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_group_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     g_lds_attr_set = true;
@@ -1700,7 +1767,10 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
     const bool pipe_ok = bf && a16 && g_use_pipe && src.all_k64 && K > 0 && src.all_vec;
     const bool single = d->K2 == 0 && d->n_extra == 0;
     // fused bias gradient: only the pipelined dW form sums its A image; anything else gets explicit column sums below
-    const bool bias_fused = pipe_ok && d->dbias && d->transA && single;
+    bool all_k32 = K > 0;  // (the exact-f32 pipelined kernel: f32 operands, every K source a multiple of 32)
+    for (int i = 0; i < g.nsrc; ++i) all_k32 = all_k32 && (g.K[i] % 32 == 0);
+    const bool pipe32_ok = !bf && !a16 && g_use_pipe && all_k32 && src.all_vec;
+    const bool bias_fused = (pipe_ok || pipe32_ok) && d->dbias && d->transA && single;
     if (d->dbias) {
         EGK_REQUIRE(d->transA && single, "egk_gemm: dbias needs the dW form (transA, single K source)");
         const int64_t slab = g.splitk > 1 ? (int64_t)g.splitk * d->M * d->N * 4 : 0;
@@ -1829,9 +1899,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         return check_launch("egk_gemm");
     }
     // exact-f32 pipelined kernel: f32 operands, 16-byte aligned rows, every K source a multiple of 32
-    bool all_k32 = K > 0;
-    for (int i = 0; i < g.nsrc; ++i) all_k32 = all_k32 && (g.K[i] % 32 == 0);
-    if (!bf && !a16 && g_use_pipe && all_k32 && src.all_vec) {
+    if (pipe32_ok) {
         ensure_lds_attr();
         // 96-row tiles (row-major A) when they load the CUs more evenly: the matrix pipes of a CU are shared by its co-resident
         // workgroups, so a launch lasts as long as the ROWS on its fullest CU
@@ -1903,8 +1971,9 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
 // Fill the device-side argument block of one problem of a grouped launch (bf16 operands on the pipelined kernel only).
 static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     EGK_REQUIRE(d->M > 0 && d->N > 0 && d->K1 > 0 && d->K2 >= 0, "egk_gemm_grouped: empty problem");
-    EGK_REQUIRE(d->a_dtype == EGK_BF16 && d->b_dtype == EGK_BF16 && d->compute == EGK_COMPUTE_BF16,
-                "egk_gemm_grouped: bf16 operands on the bf16 MFMA path only");
+    const bool f32p = d->a_dtype == EGK_F32 && d->b_dtype == EGK_F32 && d->compute == EGK_COMPUTE_F32;
+    EGK_REQUIRE(f32p || (d->a_dtype == EGK_BF16 && d->b_dtype == EGK_BF16 && d->compute == EGK_COMPUTE_BF16),
+                "egk_gemm_grouped: bf16 operands on the bf16 MFMA path, or f32 operands on the exact-f32 path");
     EGK_REQUIRE(d->splitk <= 1, "egk_gemm_grouped: no split-K in a grouped launch");
     EGK_REQUIRE(!(d->accumulate && d->c_dtype != EGK_F32), "egk_gemm_grouped: accumulate needs an f32 C");
     EGK_REQUIRE(d->C, "egk_gemm_grouped: null pointer");
@@ -1912,10 +1981,14 @@ static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     g.M = d->M; g.N = d->N;
     SourceInfo src;
     {
-        const int rc = fill_sources(d, g, 8, 8, src, "egk_gemm_grouped");
+        const int rc = fill_sources(d, g, f32p ? 4 : 8, f32p ? 4 : 8, src, "egk_gemm_grouped");
         if (rc) return rc;
     }
-    EGK_REQUIRE(src.all_k64, "egk_gemm_grouped: K sources must be multiples of 64");
+    if (f32p) {
+        for (int i = 0; i < g.nsrc; ++i) EGK_REQUIRE(g.K[i] % 32 == 0, "egk_gemm_grouped: f32 K sources must be multiples of 32");
+    } else {
+        EGK_REQUIRE(src.all_k64, "egk_gemm_grouped: K sources must be multiples of 64");
+    }
     EGK_REQUIRE(src.all_vec, "egk_gemm_grouped: operand rows must be 16-byte aligned");
     g.C = d->C; g.ldc = d->ldc;
     g.c_bf16 = d->c_dtype == EGK_BF16;
@@ -1941,12 +2014,14 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     hipStream_t s = (hipStream_t)stream;
     GemmGroup gg;
     const bool ta = descs[0].transA != 0, tb = descs[0].transB != 0;
+    const bool f32g = descs[0].compute == EGK_COMPUTE_F32;
     double flops = 0, bytes = 0;
     long long t128 = 0, t96 = 0, t64 = 0;
     int min_nkt = 1 << 30;
     for (int i = 0; i < count; ++i) {
         const egk_gemm_desc* d = descs + i;
         EGK_REQUIRE((d->transA != 0) == ta && (d->transB != 0) == tb, "egk_gemm_grouped: the problems must share one layout");
+        EGK_REQUIRE((d->compute == EGK_COMPUTE_F32) == f32g, "egk_gemm_grouped: the problems must share one compute type");
         const int rc = fill_group_args(d, gg.p[i]);
         if (rc) return rc;
         int K = d->K1 + d->K2;
@@ -1958,6 +2033,33 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         min_nkt = K / 64 < min_nkt ? K / 64 : min_nkt;
     }
     ensure_lds_attr();
+    if (f32g) {  // exact-f32 problems: 128 x 128 tiles, XCD-packed placement
+        int total = 0;
+        for (int i = 0; i < count; ++i) {
+            GemmArgs& g = gg.p[i];
+            g.tiles_m = cdiv(g.M, BM);
+            g.tiles_n = cdiv(g.N, BN);
+            total += g.tiles_m * g.tiles_n;
+        }
+        for (int i = 0; i < count; ++i) {
+            GemmArgs& g = gg.p[i];
+            const int tiles = g.tiles_m * g.tiles_n;
+            int per_xcd = cdiv(total, 8), gm = 1;
+            if (per_xcd > tiles) per_xcd = tiles;
+            while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
+            g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
+        }
+        for (int i = count; i < MAX_GROUPS; ++i) gg.p[i] = gg.p[0];
+        gg.packed = 1; gg.count = count; gg.total = total;
+        const dim3 pgrid((total + 7) / 8 * 8), pblock(NTHREADS);
+        const int layout = ta ? (tb ? 2 : 3) : (tb ? 1 : 0);
+        EGK_REQUIRE(!(ta && !tb), "egk_gemm_grouped: the tn layout is not instantiated");
+        ProfScope prof(KID_GEMM_F32_NN + layout, s, flops, 2.0 * bytes);  // (bytes above count 2 per operand element)
+        if (!ta && !tb) hipLaunchKernelGGL((gemm_pipe_f32_group_kernel<false, false>), pgrid, pblock, 65536, s, gg);
+        else if (!ta) hipLaunchKernelGGL((gemm_pipe_f32_group_kernel<false, true>), pgrid, pblock, 65536, s, gg);
+        else hipLaunchKernelGGL((gemm_pipe_f32_group_kernel<true, true>), pgrid, pblock, 65536, s, gg);
+        return check_launch("egk_gemm_grouped");
+    }
     // one tile variant for the whole launch, by the policy of egk_gemm applied to the TOTAL tile count
     int variant = t128 > 256 ? 3 : (min_nkt >= 4 ? 5 : 3);
     if (!ta) {

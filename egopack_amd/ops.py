@@ -663,10 +663,16 @@ def set_wgrad_grouping(on: bool) -> bool:
     return prev
 
 
-def _wgrad_groupable(M, N, A, lda, B, ldb, K) -> bool:
-    return (_wq["on"] and _wgrad["enabled"] and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and K % 64 == 0
-            and lda % 8 == 0 and ldb % 8 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
-            and ((M + 127) // 128) * ((N + 127) // 128) <= 128)
+def _wgrad_groupable(M, N, A, lda, B, ldb, K, compute=None) -> bool:
+    if not (_wq["on"] and _wgrad["enabled"]) or A.dtype != B.dtype:
+        return False
+    if A.dtype == torch.bfloat16:
+        ok = K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0
+    elif A.dtype == torch.float32 and compute == F32 and "f32_wgrad_groups" not in os.environ.get("EGK_DISABLE", ""):
+        ok = K % 32 == 0 and lda % 4 == 0 and ldb % 4 == 0  # exact-f32 problems: the grouped f32 kernel (egk_gemm_grouped)
+    else:
+        return False
+    return (ok and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and ((M + 127) // 128) * ((N + 127) // 128) <= 128)
 
 
 def _on_excluded_stream() -> bool:
@@ -682,14 +688,17 @@ def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False, park_only: b
     stream itself, where the operands parked by the OTHER head streams would be raced."""
     M, N, A, lda, B, ldb, K = args[:7]
     excluded = _on_excluded_stream()
-    if not _wgrad_groupable(M, N, A, lda, B, ldb, K) or (excluded and not park_on_excluded):
+    if not _wgrad_groupable(M, N, A, lda, B, ldb, K, kw.get("compute")) or (excluded and not park_on_excluded):
         return False
     _wq["items"].append((args, kw))
     _wq["hold"].extend(t for t in tensors if t is not None)
     _wq["tiles"] += ((M + 127) // 128) * ((N + 127) // 128)
     if excluded or park_only:  # (park_only: a later weight-gradient launch of the same step takes it along, see _take_parked)
         return True
-    if len(_wq["items"]) >= WGRAD_GROUP_COUNT or _wq["tiles"] >= WGRAD_GROUP_TILES:
+    # exact-f32 problems are matrix-pipe bound: a launch lasts as long as the workgroups on its fullest CU, so EIGHT H x H
+    # problems (512 tiles = two per CU everywhere) where the bf16 launches take six
+    count = 8 if A.dtype == torch.float32 else WGRAD_GROUP_COUNT
+    if len(_wq["items"]) >= count or _wq["tiles"] >= 64 * count:
         flush_wgrad()
     # (no end-of-backward join is scheduled for a parked problem: whoever switched the queue on -- engine.StepBase -- ends the
     #  step's LAST backward() call with ``join_wgrad(force=True)``, which issues what is parked.  A join after every
@@ -971,7 +980,7 @@ class _Linear(torch.autograd.Function):
             in_place = slot is not None and (db_out is None or db is None)
             dw_args = (N, K1, g, g.stride(0), x, K1, M, out, K1)
             dw_kw = dict(transA=True, transB=True, accumulate=True, compute=ctx.compute, dbias=db_out)
-            if last and (tail_items or tail_extra) and in_place and ctx.compute == BF16:
+            if last and (tail_items or tail_extra) and in_place and ctx.compute in (BF16, F32):
                 # the step's tail as ONE grouped launch on the backward stream: the parked weight gradients of the tail range
                 # + this one (the largest last), then the norm reductions of the range
                 if tail_items:
@@ -980,7 +989,7 @@ class _Linear(torch.autograd.Function):
                     gemm(*dw_args, **dw_kw)
                 if tail_extra:
                     _launch_reductions(tail_extra)
-            elif not (in_place and not last and ctx.compute == BF16 and _wgrad_defer(dw_args, dw_kw, (g, x))):
+            elif not (in_place and not last and ctx.compute in (BF16, F32) and _wgrad_defer(dw_args, dw_kw, (g, x))):
                 for it in tail_items:  # (not eligible after all: issue what was taken, in order)
                     gemm(*it[0], **it[1])
                 if tail_extra:
@@ -1862,8 +1871,9 @@ class _SageMean(torch.autograd.Function):
             gemm(*r_args, **r_kw)
         # eligibility is decided ONCE for both problems (same shapes; both operand pairs checked, and the stream): a pair of which
         # only the first was parked would be accumulated twice by the fallback below
-        park = (in_place and ctx.compute == BF16 and not _on_excluded_stream()
-                and _wgrad_groupable(Ho, H, g, g.stride(0), agg, H, N) and _wgrad_groupable(Ho, H, g, g.stride(0), h, H, N))
+        park = (in_place and ctx.compute in (BF16, F32) and not _on_excluded_stream()
+                and _wgrad_groupable(Ho, H, g, g.stride(0), agg, H, N, ctx.compute)
+                and _wgrad_groupable(Ho, H, g, g.stride(0), h, H, N, ctx.compute))
         if park:
             # one at a time: the first may flush a full group
             if not _wgrad_defer(l_args, l_kw, (g, agg)):
@@ -1892,7 +1902,7 @@ class _SageMean(torch.autograd.Function):
                 gemm(*h_args, **h_kw)
         p_args, p_kw = (H, H, d_pre, H, h, H, N, dWp, H), dict(transA=True, transB=True, accumulate=True, compute=ctx.compute,
                                                                dbias=dbp)
-        if not (rWp is None and rbp is None and ctx.compute == BF16 and _wgrad_defer(p_args, p_kw, (d_pre, h))):
+        if not (rWp is None and rbp is None and ctx.compute in (BF16, F32) and _wgrad_defer(p_args, p_kw, (d_pre, h))):
             _wgrad_launch(rWp is None and rbp is None, (d_pre, h), lambda: gemm(*p_args, **p_kw))
         if ctx.res_src is not None and _last_wgrad["tail"] is not None:
             # the FIRST layer of the stack (its backward is the stack's last): what is parked goes out now, beside the temporal

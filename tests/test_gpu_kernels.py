@@ -999,6 +999,62 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
         torch.testing.assert_close(res[pipe][1], ref_b, rtol=1e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(1024, 1024, 2048, 1), (472, 1024, 1024, 2), (1024, 4608, 6144, 1), (116, 1024, 2048, 4)])
+def test_gemm_f32_dw_with_fused_bias_gradient(ops, M, N, K, splitk):
+    """The exact-f32 dW launch with dbias: the pipelined f32 kernel sums its k-major dY image over k (as the bf16 kernel does)
+    instead of a column-sum launch of its own; the weight gradient stays bit-identical to the generic kernel's, the bias
+    gradient agrees with fp64 to f32 summation error; split-K slabs included."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dY = torch.randn(K, M, device=DEV, generator=g)
+    X = torch.randn(K, N, device=DEV, generator=g)
+    W0, b0 = torch.randn(M, N, device=DEV, generator=g), torch.randn(M, device=DEV, generator=g)
+    res = {}
+    for pipe in (1, 0):
+        prev = lib.egk_gemm_set_pipeline(pipe)
+        try:
+            w, b = W0.clone(), b0.clone()
+            ops.gemm(M, N, dY, M, X, N, K, w, N, transA=True, transB=True, accumulate=True, dbias=b, compute=ops.F32, splitk=splitk)
+            res[pipe] = (w, b)
+        finally:
+            lib.egk_gemm_set_pipeline(prev)
+    assert torch.equal(res[1][0], res[0][0])
+    ref_b = (dY.double().sum(0) + b0.double()).float()
+    for pipe in (1, 0):
+        torch.testing.assert_close(res[pipe][1], ref_b, rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(res[1][0], (dY.double().t() @ X.double() + W0.double()).float(), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("layout", ["tt", "nn", "nt"])
+def test_gemm_f32_grouped_launch_equals_the_single_launches(ops, layout):
+    """Up to eight exact-f32 contractions of one layout in ONE launch (the weight gradients of the reference-precision step:
+    no split-K slabs, no reduce launches): every output BIT-identical to the problem's own launch, the fused bias gradients
+    of the dW form to f32 summation error."""
+    g = torch.Generator(device=DEV).manual_seed(len(layout) + 11)
+    tA, tB = layout[0] == "t", layout[1] == "t"
+    shapes = [(1024, 1024, 2048), (1024, 1024, 2048), (472, 1024, 1024), (1024, 4608, 2048), (128, 256, 4096), (115 if not tA else 116, 1024, 2048)]
+    probs, singles = [], []
+    for M, N, K in shapes:
+        A = torch.randn((K, M) if tA else (M, K), device=DEV, generator=g)
+        B = torch.randn((K, N) if tB else (N, K), device=DEV, generator=g)
+        C0 = torch.randn(M, N, device=DEV, generator=g)
+        b0 = torch.randn(M, device=DEV, generator=g) if layout == "tt" else None
+        cg, cs = C0.clone(), C0.clone()
+        bg, bs = (b0.clone(), b0.clone()) if b0 is not None else (None, None)
+        kw = dict(transA=tA, transB=tB, accumulate=True, compute=ops.F32)
+        probs.append(((M, N, A, A.shape[1], B, B.shape[1], K, cg, N), dict(kw, dbias=bg) if bg is not None else kw))
+        ops.gemm(M, N, A, A.shape[1], B, B.shape[1], K, cs, N, allow_splitk=False, **(dict(kw, dbias=bs) if bs is not None else kw))
+        singles.append((cs, bs, cg, bg, A, b0))
+    ops.gemm_grouped(probs)
+    torch.cuda.synchronize()
+    for cs, bs, cg, bg, A, b0 in singles:
+        assert torch.equal(cs, cg)
+        if bs is not None:
+            torch.testing.assert_close(bg, (A.double().sum(0) + b0.double()).float(), rtol=1e-5, atol=1e-3)
+            torch.testing.assert_close(bg, bs, rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("n_out", [478, 115, 2])
 def test_classifier_dx_on_zero_padded_k_axis(ops, n_out):
     """A classifier layer (rows of W not a multiple of 64) whose parameters live in FlatAdam's flat buffers: the
