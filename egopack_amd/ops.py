@@ -651,6 +651,7 @@ _wq = {"on": False, "items": [], "tiles": 0, "hold": [], "extra": []}
 # launch.  EGK_WGRAD_COUNT is a development knob (the library takes up to 8 per launch).
 WGRAD_GROUP_COUNT = int(os.environ.get("EGK_WGRAD_COUNT", "6"))
 WGRAD_GROUP_TILES = 64 * WGRAD_GROUP_COUNT
+F32_WGRAD_GROUP_COUNT = int(os.environ.get("EGK_F32_WGRAD_COUNT", "8"))  # (development knob, as EGK_WGRAD_COUNT)
 
 
 def set_wgrad_grouping(on: bool) -> bool:
@@ -697,7 +698,7 @@ def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False, park_only: b
         return True
     # exact-f32 problems are matrix-pipe bound: a launch lasts as long as the workgroups on its fullest CU, so EIGHT H x H
     # problems (512 tiles = two per CU everywhere) where the bf16 launches take six
-    count = 8 if A.dtype == torch.float32 else WGRAD_GROUP_COUNT
+    count = F32_WGRAD_GROUP_COUNT if A.dtype == torch.float32 else WGRAD_GROUP_COUNT
     if len(_wq["items"]) >= count or _wq["tiles"] >= 64 * count:
         flush_wgrad()
     # (no end-of-backward join is scheduled for a parked problem: whoever switched the queue on -- engine.StepBase -- ends the
