@@ -463,7 +463,8 @@ class StepBase:
     # sums its segment statistics over the ranks (forward and backward, ops.set_graph_ln_exchange), so the step computes
     # what ONE process computes on the global batch -- the reference's semantics at that batch size -- instead of the
     # default per-rank statistics (each replica = the reference at its local batch size).  Six small collectives per step
-    # on the compute stream; collectives cannot be captured, so the mode steps eagerly.
+    # on the compute stream.  On an RCCL group they are captured with the rest of the N-rank step (one graph incl. the
+    # exchange, _capture_exchange_graph); on a group whose collectives cannot be captured (gloo) the mode steps eagerly.
     exact_graph_ln = False
 
     def _exact_ln_on(self) -> bool:
@@ -616,7 +617,7 @@ class StepBase:
         if not hasattr(self, "loop_counts"):
             self.loop_counts = {"replayed": 0, "eager": 0}  # per training loop; the entry points log and reset it per epoch
         if (not self.use_graph or self._steps_seen <= self.graph_after or not next(iter(batches.values())).x.is_cuda
-                or self._exact_ln_on()):
+                or (self._exact_ln_on() and not self._one_graph_exchange_ok())):
             self.loop_counts["eager"] += 1
             return self.step(batches, merged)
         if self.fused and len([t for t in self.enabled if batches.get(t) is not None]) > 1 and merged is None:
@@ -680,9 +681,9 @@ class StepBase:
         """Capture forward+backward(+Adam if no gradient exchange) for THESE device tensors (static
         shapes and addresses: refill them in place between replays)."""
         opt = self.optimizer
-        if self._exact_ln_on():
-            raise RuntimeError("exact_graph_ln sums the graph-LayerNorm statistics over the ranks inside the step: collectives "
-                               "cannot be captured in a hipGraph here -- use step() / train_step() (eager) in this mode")
+        if self._exact_ln_on() and not self._one_graph_exchange_ok():
+            raise RuntimeError("exact_graph_ln sums the graph-LayerNorm statistics over the ranks inside the step: this process "
+                               "group's collectives cannot be captured in a hipGraph -- use step() / train_step() (eager) in this mode")
         live = [t for t in self.enabled if batches.get(t) is not None]
         if self.fused and len(live) > 1 and merged is None:  # index work must stay outside the capture
             merged = merge_batches([batches[t] for t in live]).to(batches[live[0]].pos.device)
@@ -904,6 +905,8 @@ class StepBase:
                 self._rng_in_graph = False
                 if self.input_hook is not None:
                     self.input_hook()
+                ln_scope = self._ln_exchange_scope()  # (exact cross-rank graph-LN statistics: their collectives are captured too)
+                ln_scope.__enter__()
                 total, vectors = self._stage_a(batches, merged)
                 self._join_zero()
                 ops.stamp("heads_done")
@@ -929,6 +932,7 @@ class StepBase:
                 ops.stamp("stack_done")
                 self._exchange_region(regions[1])
                 self._stage_c()
+                ln_scope.__exit__(None, None, None)
                 ops.stamp("backward_done")
                 self._exchange_region(regions[2])
                 sync.finish_and_step(opt)
@@ -959,7 +963,10 @@ class StepBase:
                 return self._capture_exchange_graph(batches, merged)
             except Exception as e:  # noqa: BLE001
                 self.capture_notes = [*getattr(self, "capture_notes", []), f"one graph with the exchange: {e!r}"]
+                ops.set_graph_ln_exchange(None)
                 torch.cuda.synchronize()
+                if self._exact_ln_on():
+                    raise
         opt = self.optimizer
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         self._rng_in_graph = False  # (no staged graph advances the Philox offset word: replay() does, also after a one-piece capture)

@@ -143,6 +143,31 @@ def test_staged_backward_equals_the_one_piece_backward(pg, golden, with_sync):
         assert torch.equal(run(True, True, one_graph=True), ref)  # (stages + collectives + Adam slices in ONE captured graph)
 
 
+def test_exact_graph_ln_mode_is_captured_with_the_exchange(pg, golden):
+    """exact_graph_ln (graph-LayerNorm statistics summed over the ranks, forward and backward): on an RCCL group its six small
+    collectives per step are captured with the rest of the N-rank step -- the replayed graph gives the parameters of the
+    eagerly issued steps bit for bit (1-rank group driven as a world of 2: the sums hold one contribution)."""
+    from egopack_amd import ops
+    from egopack_amd.dist import GradSync
+
+    def run(graph):
+        step, opt, batches = _setup(golden, GradSync(2, chunk_mb=0.01))
+        step.exact_graph_ln = True
+        if graph:
+            step.capture(batches, warmup=1)
+            assert step._graph_has_exchange and not getattr(step, "capture_notes", [])
+            for _ in range(2):
+                step.replay()
+        else:
+            for _ in range(3):
+                step.step(batches)
+        torch.cuda.synchronize()
+        assert opt.step_count == 3 and not ops.graph_ln_exchange_on()
+        return opt.flat_p.clone()
+    with ops.compute_mode("f32"):
+        assert torch.equal(run(True), run(False))
+
+
 def test_headwise_backward_equals_the_one_call_backward(golden):
     """Every head's backward as its own backward() call inside the head's stream context (so that the captured branches
     overlap), then the backbone from the three feature gradients: the parameters of one backward() over the whole
