@@ -97,6 +97,20 @@ def resident_batches(loader, store, device, dtype=None):
         yield materialise_features(b.to(device), store, dtype)
 
 
+class ResidentLoader:
+    """A loader of index-only batches (``x_idx``) seen as a loader of device batches with features: every batch is moved to
+    the device and its rows are gathered from the resident table (evaluation passes, the prototype-bank pass)."""
+
+    def __init__(self, loader, store, device, dtype=None):
+        self.loader, self.store, self.device, self.dtype = loader, store, device, dtype
+
+    def __iter__(self):
+        return resident_batches(self.loader, self.store, self.device, self.dtype)
+
+    def __len__(self):
+        return len(self.loader)
+
+
 def build_loaders(cfg, dsets, train: bool, rank: int, world: int, batch_size: Optional[int] = None):
     """Training loaders shard by sample (equal steps per rank); evaluation loaders shard by batch, so that every batch
     -- and with it every graph-LayerNorm statistic -- is the one the single-process pass sees."""

@@ -12,6 +12,7 @@ which tasks feed the prototype banks (substring match on the task names, main_eg
 from __future__ import annotations
 
 import logging
+import time
 from pathlib import Path
 
 import torch
@@ -27,6 +28,7 @@ from utils.meters import build_meter_for_dataset
 from validate import validate, validate_lta, validate_pnr
 
 logger = logging.getLogger("main_egopack")
+RATE_WARMUP_STEPS = 30  # steps of an epoch left out of its logged steady-state rate (eager steps, the capture, first replays)
 
 AUX_ORDER = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
              "pnr": ("ar", "lta", "oscc")}  # other_tasks lists of the reference's validation calls (main_egopack.py:377-448)
@@ -56,15 +58,24 @@ def validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, loaders,
     return out
 
 
-def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda"):
+def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda", store=None):
     """One epoch (reference main_egopack.train :64-159)."""
     order = ("ar", "lta", "oscc", "pnr")
-    it = 0
+    it, seqs, mark = 0, 0, None
     hosts = (dict(zip(order, batch)) for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]))
     # batch i + 1 is collated and copied to the device (copy stream) while step i runs; per-task backbone passes here
-    for batches, _ in engine.StagedBatches(hosts, device, order, fused=False):
+    for batches, _ in engine.StagedBatches(hosts, device, order, fused=False, store=store, dtype=ops.act_dtype()):
         total, _ = step.train_step(batches)  # eager for the first steps, then the captured step
+        seqs += sum(int(b.num_graphs) for b in batches.values() if b is not None)
         it += 1
+        if it == RATE_WARMUP_STEPS and torch.cuda.is_available():
+            torch.cuda.synchronize()
+            mark = (it, time.perf_counter(), seqs)
+    if mark is not None and it > mark[0]:
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - mark[1]
+        logger.info("epoch %d: steady state %.3f ms/step, %.0f clip-seqs/s on this rank (%d steps after the first %d)", epoch,
+                    dt * 1e3 / (it - mark[0]), (seqs - mark[2]) / dt, it - mark[0], mark[0])
     logger.info("epoch %d: %d iterations, last objective %.4f", epoch, it, float(total))
     lc = getattr(step, "loop_counts", None)
     if lc is not None:  # how many steps replayed the captured graph and how many ran eagerly (shape changes, warm-up)
@@ -109,10 +120,17 @@ def main(argv=None):
         logger.info("resuming from %s", cfg.resume_from)
         T.load_checkpoint(cfg.resume_from, model, tasks, strict_tasks=False, device=device)
 
+    # datasets that index a device-resident feature table (dataset_*=synthetic_resident; the reference's .npy files loaded
+    # into HBM): the training step gathers its rows on the device, the evaluation and prototype-bank passes through an adapter
+    store, store_val = T.build_feature_store(dsets_train, device), T.build_feature_store(dsets_val, device)
+    if store_val is not None:
+        dl_val = {t: T.ResidentLoader(l, store_val, device, ops.act_dtype()) for t, l in dl_val.items()}
     bank_tasks = [tasks[t] for t in ("ar", "oscc", "lta", "pnr") if tasks[t].name in str(cfg.resume_from)]
-    banks = build_graphone(model, tasks["ar"], bank_tasks,
-                           dataloader=build_dataloader(dsets_train["ar"], 256, False, cfg.num_workers, True, cfg.seed,
-                                                       rank=rank, world_size=world, shard="batches"),
+    bank_loader = build_dataloader(dsets_train["ar"], 256, False, cfg.num_workers, True, cfg.seed, rank=rank, world_size=world,
+                                   shard="batches")
+    if store is not None:
+        bank_loader = T.ResidentLoader(bank_loader, store, device, ops.act_dtype())
+    banks = build_graphone(model, tasks["ar"], bank_tasks, dataloader=bank_loader,
                            device=device)  # partial fp64 banks are summed across ranks inside
     graphone = GraphONE(banks, **cfg.graphone).to(device)
 
@@ -131,7 +149,7 @@ def main(argv=None):
     step.use_graph = bool(cfg.get("use_graph", True))
     step.exact_graph_ln = bool(cfg.get("exact_graph_ln", False))
     for epoch in range(1, cfg.num_epochs + 1):
-        train(epoch, step, dl_train, weights, device)
+        train(epoch, step, dl_train, weights, device, store=store)
         scheduler.step()
         validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, dl_val, late_fusion=cfg.late_fusion,
                          validate_all=cfg.validate_all_tasks, device=device)  # all ranks: the split is sharded by batch

@@ -134,15 +134,7 @@ def main(argv=None):
     # theirs through an adapter
     store, store_val = T.build_feature_store(dsets_train, device), T.build_feature_store(dsets_val, device)
     if store_val is not None:
-        _val = dl_val
-
-        class _Resident:
-            def __init__(self, loader):
-                self.loader = loader
-
-            def __iter__(self):
-                return T.resident_batches(self.loader, store_val, device, ops.act_dtype())
-        dl_val = {t: _Resident(l) for t, l in _val.items()}
+        dl_val = {t: T.ResidentLoader(l, store_val, device, ops.act_dtype()) for t, l in dl_val.items()}
 
     H = cfg.model.hidden_size
     model = instantiate(cfg.model, input_size=dsets_train["ar"].features_size,

@@ -182,3 +182,26 @@ def test_main_temporal_on_the_device_resident_feature_store(tmp_path):
     table = torch.cat([torch.from_numpy(v) for v in ds["ar"].videos.values()])
     want = table[b.x_idx.clamp(min=0)] * (b.x_idx >= 0).unsqueeze(-1)
     torch.testing.assert_close(got, want.to(torch.bfloat16).float(), rtol=0, atol=0)
+
+
+@pytest.mark.timeout(600)
+def test_main_egopack_on_the_device_resident_feature_store(tmp_path):
+    """Both phases over ONE feature table in HBM: main_temporal (dataset_*=synthetic_resident) writes the MTL checkpoint,
+    main_egopack resumes from it -- its prototype-bank pass and its validation go through the resident adapter
+    (train.ResidentLoader), its training step gathers the rows on the device (StagedBatches with a store) and replays the
+    captured step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import main_egopack
+    import main_temporal
+    groups = [f"{g}=synthetic_resident" for g in ("dataset_recognition", "dataset_lta", "dataset_oscc", "dataset_pnr")]
+    common = [*groups, "k=1", "batch_size=4", "synthetic_samples=256", "model.hidden_size=64", "model.temporal_pooling.hidden_size=64",
+              "oscc_feat_size=64", f"checkpoint_dir={tmp_path}", "save_model=True", "optimizer.lr=1e-3"]
+    main_temporal.main(common + ["num_epochs=1", "enabled_tasks=[ar,lta,pnr]"])
+    ckpt = tmp_path / "MTL_ar-lta-pnr" / "checkpoint.pth"
+    main_egopack.main(common + ["num_epochs=2", "enabled_tasks=[oscc]", "enable_graphone=True", f"resume_from={ckpt}", "graphone.k=4",
+                                "graphone.depth=2", "graphone.residual=True", "graphone.hidden_size=64", "+graphone.features_size=64",
+                                "artifact_prefix=EGO"])
+    ego = torch.load(tmp_path / "EGO_egopack_oscc" / "checkpoint.pth", weights_only=False)
+    assert "graphone" in ego and all(torch.isfinite(v).all() for v in ego["graphone"].values() if v.is_floating_point())
+    assert all(torch.isfinite(v).all() for v in ego["temporal_graph"].values() if v.is_floating_point())
