@@ -379,6 +379,21 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(const BlockList b, uns
         d[i] = s ? s[i] : 0;
 }
 
+// The step's constants ON THE DEVICE: t = ++(*t_dev); hyper = {lr, 1 - b1^t, sqrt(1 - b2^t), grad_scale} in the host's
+// arithmetic (double pow / sqrt, one rounding to f32).  A node of the captured step: a replay needs no host -> device copy
+// in front of it (4 us of copy + the gap behind it, per step) and the step count advances with the replays.
+__global__ void adam_hyper_kernel(const float* __restrict__ src, long long* __restrict__ t_dev, double b1, double b2,
+                                  float* __restrict__ hyper) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const long long t = *t_dev + 1;
+        *t_dev = t;
+        hyper[0] = src[0];
+        hyper[1] = (float)(1.0 - pow(b1, (double)t));
+        hyper[2] = (float)sqrt(1.0 - pow(b2, (double)t));
+        hyper[3] = src[1];
+    }
+}
+
 // ---- Adam (torch.optim.Adam single-tensor formulas, L2 weight decay) ----------------------------------------
 template <typename GT>  // GT: element type of the gradient buffer (f32, or bf16 after a compressed all-reduce)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
@@ -664,6 +679,12 @@ int egk_copy_blocks(egk_stream_t stream, const void* const* srcs, const int64_t*
     const long long blocks = (nmax / 16 + 255) / 256 + 1;
     hipLaunchKernelGGL(copy_blocks_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks), count), dim3(256), 0, s, b, (unsigned char*)dst);
     return check_launch("egk_copy_blocks");
+}
+
+int egk_adam_hyper(egk_stream_t stream, const float* src, int64_t* t_dev, double beta1, double beta2, float* hyper) {
+    EGK_REQUIRE(src && t_dev && hyper, "egk_adam_hyper: null pointer");
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, (long long*)t_dev, beta1, beta2, hyper);
+    return check_launch("egk_adam_hyper");
 }
 
 int egk_adam_step(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,

@@ -713,7 +713,8 @@ class StepBase:
             return self._capture_staged(batches, merged)
         fuse_adam = self.sync is None or self.sync.world <= 1
         g = torch.cuda.CUDAGraph()
-        opt.prepare_hyper()
+        opt.sync_hyper_source()  # (the step constants are computed inside the graph from a device-side step counter)
+        self._hyper_in_graph = False
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
@@ -723,8 +724,12 @@ class StepBase:
                 ops.stamp("step_start")
                 # the gradient buffer is cleared BESIDE the forward pass (nothing writes a gradient before the first backward
                 # launch): 100 MB of memset off the chain's head; joined in _join_zero() before backward starts
+                hyper_here = fuse_adam and "hyper_in_graph" not in getattr(self, "_dev_off", ())
+                self._hyper_in_graph = hyper_here
                 if "zero_stream" in getattr(self, "_dev_off", ()):
                     opt.flat_g.zero_()
+                    if hyper_here:
+                        opt.prepare_hyper(in_capture=True)
                 else:
                     if not hasattr(self, "_zero_stream"):
                         self._zero_stream = torch.cuda.Stream()
@@ -733,6 +738,8 @@ class StepBase:
                         self._zero_stream.wait_event(ev)
                         with torch.cuda.stream(self._zero_stream):
                             opt.flat_g.zero_()
+                            if hyper_here:  # the step's Adam constants: one thread, beside the forward pass
+                                opt.prepare_hyper(in_capture=True)
                     if "zero_deferred" in getattr(self, "_dev_off", ()):
                         issue_zero(torch.cuda.current_stream().record_event())
                     else:
@@ -890,7 +897,8 @@ class StepBase:
         live = [t for t in self.enabled if batches.get(t) is not None]
         g = torch.cuda.CUDAGraph()
         opt.grad_scale = 1.0 / sync.world
-        opt.prepare_hyper()
+        opt.sync_hyper_source()
+        self._hyper_in_graph = True
         count = opt.step_count
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
@@ -910,6 +918,7 @@ class StepBase:
                     self._zero_stream.wait_event(ev)
                     with torch.cuda.stream(self._zero_stream):
                         opt.flat_g.zero_()
+                        opt.prepare_hyper(in_capture=True)  # (the step's Adam constants, from the device-side step counter)
                 ops.stamp("step_start")
                 ops.defer_after_next_launch(issue_zero)
                 self._zero_pending = True
@@ -1021,8 +1030,13 @@ class StepBase:
             self._finish_staged()
             return self._static_out[0]
         if self._fuse_adam:
-            opt.prepare_hyper()
-            self._graph.replay()
+            if getattr(self, "_hyper_in_graph", False):
+                opt.sync_hyper_source()  # (host -> device only when lr / grad_scale changed or the step count was set)
+                self._graph.replay()
+                opt.note_captured_step()
+            else:
+                opt.prepare_hyper()
+                self._graph.replay()
             opt.step_count += 1
         else:
             self._graph.replay()

@@ -89,6 +89,9 @@ class FlatAdam(torch.optim.Optimizer):
         self._bank_views(live)
         self.refresh_shadows()
         self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_src = torch.zeros(2, dtype=torch.float32, device=dev)  # {lr, grad_scale}: uploaded when they change
+        self._t_dev = torch.zeros(1, dtype=torch.int64, device=dev)        # optimizer steps taken (device-side counter)
+        self._src_host, self._t_mirror = None, 0
         if self._pending_state is not None:
             self._apply_state(self._pending_state)
             self._pending_state = None
@@ -256,21 +259,42 @@ class FlatAdam(torch.optim.Optimizer):
             return super().zero_grad(set_to_none=True)
         self.flat_g.zero_()
 
-    def prepare_hyper(self):
-        """Host -> device copy of {lr, 1-b1^t, sqrt(1-b2^t), grad_scale} for the NEXT step; kept outside
-        any captured graph so that lr schedules and step counts keep advancing under replay."""
-        g = self.param_groups[0]
-        t = self.step_count + 1
-        b1, b2 = g["betas"]
-        # a FRESH pinned staging buffer per step: torch's caching host allocator does not hand a pinned
-        # block out again before the async copy that read it has completed, so a later step can never
-        # overwrite values an earlier, still queued, copy is about to read.
-        host = torch.empty(4, dtype=torch.float32, pin_memory=True)
-        host[0] = g["lr"]
-        host[1] = 1.0 - b1 ** t
-        host[2] = math.sqrt(1.0 - b2 ** t)
-        host[3] = self.grad_scale
-        self._hyper.copy_(host, non_blocking=True)
+    # The step constants {lr, 1-b1^t, sqrt(1-b2^t), grad_scale} are computed ON THE DEVICE (egk_adam_hyper) from a device-side
+    # step counter and a two-float source {lr, grad_scale}: the launch is a node of a captured step, so a replay needs no
+    # host -> device copy in front of it (4 us of copy + the gap behind it, 14 us per step of the headline workload) while lr
+    # schedules and step counts keep advancing.  The host uploads the source only when lr / grad_scale change (per epoch) and
+    # the counter only when ``step_count`` was set from outside (load_state_dict); ``_t_mirror`` is the value the device
+    # counter will hold once everything enqueued so far has run.
+    def sync_hyper_source(self) -> None:
+        src = (float(self.param_groups[0]["lr"]), float(self.grad_scale))
+        if src != self._src_host:
+            # (a FRESH pinned staging buffer per upload: torch's caching host allocator does not hand a pinned block out again
+            #  before the async copy that read it has completed)
+            host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+            host[0], host[1] = src
+            self._hyper_src.copy_(host, non_blocking=True)
+            self._src_host = src
+        if self._t_mirror != self.step_count:
+            host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            host[0] = self.step_count
+            self._t_dev.copy_(host, non_blocking=True)
+            self._t_mirror = self.step_count
+
+    def prepare_hyper(self, in_capture: bool = False):
+        """The constants of the NEXT step (t = step_count + 1), on the current stream.  ``in_capture``: the launch is being
+        recorded into a graph -- the caller has called ``sync_hyper_source`` before the capture and calls
+        ``note_captured_step`` after every replay."""
+        b1, b2 = self.param_groups[0]["betas"]
+        if not in_capture:
+            self.sync_hyper_source()
+        _ck(_lib.load().egk_adam_hyper(_stream(), _p(self._hyper_src), _p(self._t_dev), float(b1), float(b2), _p(self._hyper)),
+            "egk_adam_hyper")
+        if not in_capture:
+            self._t_mirror += 1
+
+    def note_captured_step(self) -> None:
+        """A replayed graph that contains the constants launch has been enqueued: the device counter moves on with it."""
+        self._t_mirror += 1
 
     def launch(self, grads=None, lo: int = 0, hi=None):
         """The kernel launch alone (capturable).  ``grads``: the buffer to read gradients from (default the f32

@@ -440,6 +440,11 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
  * launch -- the operand the bf16 contractions read (no separate cast pass over the weights). */
 int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
+/* The constants of the NEXT step computed on the device: t = ++(*t_dev) (device int64: optimizer steps taken so far);
+ * hyper[4] = {src[0] = lr, 1 - beta1^t, sqrt(1 - beta2^t), src[1] = grad_scale} (double pow / sqrt, rounded to f32 once, as
+ * torch.optim.Adam's bias corrections are).  One thread; a node of the captured step, so that a graph replay needs no
+ * host -> device copy in front of it and the step count advances with the replays.  src: device float[2]. */
+int egk_adam_hyper(egk_stream_t s, const float* src, int64_t* t_dev, double beta1, double beta2, float* hyper);
 
 /* ---- the step objective in one launch each way  main_temporal.py:99-128 (torch.stack([w * l.mean() ...]).sum()) ----
  * out[0] = sum_k coefs[k] * sum(xs[k][0..ns[k])), terms added in k order (count <= 8; xs / ns / coefs are HOST arrays);

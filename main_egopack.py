@@ -74,8 +74,9 @@ def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda", stor
     if mark is not None and it > mark[0]:
         torch.cuda.synchronize()
         dt = time.perf_counter() - mark[1]
-        logger.info("epoch %d: steady state %.3f ms/step, %.0f clip-seqs/s on this rank (%d steps after the first %d)", epoch,
-                    dt * 1e3 / (it - mark[0]), (seqs - mark[2]) / dt, it - mark[0], mark[0])
+        logger.info("epoch %d: steady state %.3f ms/step, %.0f clip-seqs/s on this rank (%d steps after the first %d); "
+                    "device memory %.0f MB allocated, %.0f MB reserved", epoch, dt * 1e3 / (it - mark[0]), (seqs - mark[2]) / dt,
+                    it - mark[0], mark[0], torch.cuda.memory_allocated() / 2 ** 20, torch.cuda.memory_reserved() / 2 ** 20)
     logger.info("epoch %d: %d iterations, last objective %.4f", epoch, it, float(total))
     lc = getattr(step, "loop_counts", None)
     if lc is not None:  # how many steps replayed the captured graph and how many ran eagerly (shape changes, warm-up)

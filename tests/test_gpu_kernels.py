@@ -1358,3 +1358,45 @@ def test_pe_add_table_is_bit_identical_to_the_direct_evaluation(ops, dt):
     assert torch.equal(ops.pe_add(x, pos, freq, (-4, 3)), ref)  # most positions outside the table
     torch.testing.assert_close(ref.float().cpu(), (x.float().cpu() + P.positional_encoding(pos.cpu(), freq.cpu())).to(dt).float(),
                                rtol=1e-2 if dt == torch.bfloat16 else 1e-5, atol=1e-2 if dt == torch.bfloat16 else 1e-5)
+
+
+def test_adam_step_constants_are_computed_on_the_device_and_follow_lr_and_the_step_count(ops):
+    """egk_adam_hyper: hyper = {lr, 1 - b1^t, sqrt(1 - b2^t), grad_scale} from a device-side step counter -- the host's
+    double arithmetic rounded to f32 once -- so that a captured step carries the launch and a replay needs no host -> device
+    copy.  The source is uploaded only when lr / grad_scale change, the counter only when ``step_count`` is set from outside."""
+    import math
+    from egopack_amd.optim import FlatAdam
+    p = torch.nn.Parameter(torch.randn(1000, device=DEV))
+    p.grad = torch.randn(1000, device=DEV)
+    opt = FlatAdam([p], lr=3e-4, betas=(0.9, 0.999))
+
+    def want(t, lr, gs):
+        return torch.tensor([lr, 1.0 - 0.9 ** t, math.sqrt(1.0 - 0.999 ** t), gs], dtype=torch.float32)
+    for t in range(1, 6):
+        opt.step()
+        assert torch.equal(opt._hyper.cpu(), want(t, 3e-4, 1.0)), t
+    assert opt.step_count == 5 and int(opt._t_dev.item()) == 5 and opt._t_mirror == 5
+    opt.param_groups[0]["lr"] = 1e-5  # an lr schedule stepping
+    opt.grad_scale = 0.125            # a gradient exchange over 8 ranks
+    opt.step()
+    assert torch.equal(opt._hyper.cpu(), want(6, 1e-5, 0.125))
+    opt.step_count = 123456           # a checkpoint being resumed
+    opt.step()
+    assert torch.equal(opt._hyper.cpu(), want(123457, 1e-5, 0.125)) and int(opt._t_dev.item()) == 123457
+    # captured: the launch inside a graph advances the counter with every replay
+    g = torch.cuda.CUDAGraph()
+    opt.sync_hyper_source()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            opt.prepare_hyper(in_capture=True)
+            opt.launch()
+    torch.cuda.current_stream().wait_stream(side)
+    for k in range(3):
+        opt.sync_hyper_source()
+        g.replay()
+        opt.note_captured_step()
+        opt.step_count += 1
+        assert torch.equal(opt._hyper.cpu(), want(123458 + k, 1e-5, 0.125))
+    assert int(opt._t_dev.item()) == opt.step_count == opt._t_mirror == 123460
