@@ -784,3 +784,46 @@ def test_relation_module_multiscale_vs_reference(A, golden, mode, otol, gtol):
     g0 = c["grads"]["fc_fusion_scales.0.1.weight"]
     moved = (c["state_dict"]["fc_fusion_scales.0.1.weight"] - w.detach().cpu())
     assert (torch.sign(moved[g0.abs() > 1e-6]) == torch.sign(g0[g0.abs() > 1e-6])).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("encoding", ["positional", "temporal", "learnt"])
+@pytest.mark.parametrize("level", ["frame", "action"])
+def test_temporal_pooling_encodings_follow_the_reference_base_class(A, encoding, level):
+    """``TemporalPooling.apply_positional_embedding`` (reference models/temporal_pooling/pooling.py:64-83; not reached by
+    TRNPooling, which passes no encoding): the reference's control flow restated on the CPU in f32 -- PyG's two encodings from
+    their published definitions, the per-batch-id loop of the 'action' level as written -- against the HIP path."""
+    from egopack_amd.models.temporal_pooling.pooling import TemporalPooling
+    torch.manual_seed(7)
+    S, F, N = 3, 64, 40
+    m = TemporalPooling(F, F, S, encoding, level)
+    if encoding == "learnt" and level == "action":
+        assert m.encoding is None and m.encoding_mlp is None  # (the reference warns and uses no encoding)
+        x = torch.randn(N, S, F)
+        assert m.apply_positional_embedding(x, None, None) is x
+        return
+    x = torch.randn(N, S, F)
+    batch = torch.arange(0, N // 4).repeat_interleave(4)
+    pos = torch.arange(0, 4).repeat(N // 4) - 1
+    W, b = m.encoding_mlp.weight.detach().clone(), m.encoding_mlp.bias.detach().clone()
+
+    def enc_rows(p):
+        p = p.float().view(-1, 1)
+        if encoding == "positional":
+            f = torch.logspace(0, 1, F // 2, 1e-4).view(1, -1)
+            return torch.cat([torch.sin(p * f), torch.cos(p * f)], -1)
+        if encoding == "temporal":
+            w = (1.0 / 10 ** torch.linspace(0, 9, F)).view(1, -1)
+            return (1.0 / F) ** 0.5 * torch.cos(p * w)
+        raise AssertionError
+    if level == "frame":
+        rows = m.encoding.detach().clone() if encoding == "learnt" else enc_rows(torch.arange(0, S))
+        ref = x + (rows @ W.t() + b).unsqueeze(0)
+    else:
+        ref = torch.zeros_like(x)
+        for bid in batch.unique():  # (as the reference writes it)
+            sel = batch == bid
+            ref[sel] = x[sel] + (enc_rows(pos[sel]) @ W.t() + b).unsqueeze(1)
+    m.to(DEV)
+    with A.ops.compute_mode("f32"):
+        got = m.apply_positional_embedding(x.to(DEV), batch.to(DEV), pos.to(DEV))
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-4, atol=1e-4)
