@@ -1354,10 +1354,13 @@ class EgoPackStep(StepBase):
         snap = ops.rng_snapshot()
         precise, side = {}, None
         first = next((b for b in batches.values() if b is not None), None)
-        if self._precise_on():
-            if self.precise_stream and first is not None and first.pos.is_cuda and "precise_stream" not in getattr(self, "_dev_off", ()):
+        on_side = (self._precise_on() and self.precise_stream and first is not None and first.pos.is_cuda
+                   and "precise_stream" not in getattr(self, "_dev_off", ()))
+        late = on_side and "precise_late_fork" not in getattr(self, "_dev_off", ())
+        if self._precise_on() and not late:
+            if on_side:
                 # the precise pass is a chain of ~50 launches over the same few thousand rows as the training pass's forward:
-                # forked onto its own stream FIRST, the two chains run side by side (each alone leaves most of the chip idle)
+                # forked onto its own stream, the two chains run side by side (each alone leaves most of the chip idle)
                 main = torch.cuda.current_stream()
                 if getattr(self, "_precise_side", None) is None:
                     self._precise_side = torch.cuda.Stream()
@@ -1365,13 +1368,28 @@ class EgoPackStep(StepBase):
                 side = self._precise_side
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    precise = self.precise_aux_features(batches, merged)
+                    precise = self.precise_aux_features(batches, merged, rng_snap=snap)
             else:
-                precise = self.precise_aux_features(batches, merged)
+                precise = self.precise_aux_features(batches, merged, rng_snap=snap)
         import contextlib
-        # (the training pass draws the dropout offsets the precise pass drew: same keep masks when the backbone is in train mode)
-        with (ops.rng_replay(snap) if precise else contextlib.nullcontext()), torch.set_grad_enabled(self.backprop):
+        fork_ev = None
+        if late:  # (the fork point: before the training pass's first launch)
+            main = torch.cuda.current_stream()
+            fork_ev = main.record_event()
+        # (the two passes draw the same dropout offsets: same keep masks when the backbone is in train mode)
+        with (ops.rng_replay(snap) if self._precise_on() else contextlib.nullcontext()), torch.set_grad_enabled(self.backprop):
             feats = self.features(batches, merged)
+        if late:
+            # the precise pass is CREATED after the training pass's forward chain although it forks from before it: under
+            # capture the branch created first keeps the launch queue, and created first the precise pass (700 us of launches)
+            # kept it -- the training pass's first contraction started when the precise backbone pass had finished
+            if getattr(self, "_precise_side", None) is None:
+                self._precise_side = torch.cuda.Stream()
+                ops.exclude_wgrad_streams([self._precise_side])
+            side = self._precise_side
+            side.wait_event(fork_ev)
+            with torch.cuda.stream(side):
+                precise = self.precise_aux_features(batches, merged, rng_snap=snap)
         if side is not None:
             main.wait_stream(side)
             for d in precise.values():
