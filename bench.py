@@ -176,11 +176,27 @@ ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pip
                 "adam": "adam_kernel", "csr_gather": "csr_gather_kernel"}
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
-    by tools/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, FETCH_SIZE doubled as the
-    MI355X guide prescribes for gfx950).  None when no profile is committed."""
-    f = REPO / "profiles" / "pmc_latest.json"
+def pmc_key(args) -> str:
+    """Name of the configuration a PMC summary belongs to (profiles/pmc_<key>.json, written by tools/stamp_profile.py <tag> <key>):
+    the same kernel name at other sizes moves other bytes, so every benchmarked configuration has a file of its own."""
+    return f"{args.workload}_B{args.batch}_T{args.T}_H{args.hidden}_Hp{args.trn_hidden}_{args.compute}"
+
+
+def pmc_file(args=None) -> Path:
+    if args is not None:
+        f = REPO / "profiles" / f"pmc_{pmc_key(args)}.json"
+        if f.exists():
+            return f
+        if pmc_key(args) != "mtl_B64_T32_H1024_Hp1024_bf16":
+            return f  # (absent: traffic stays null for this configuration)
+    return REPO / "profiles" / "pmc_latest.json"  # the default workload's passes (rounds 1-3 wrote this name)
+
+
+def pmc_traffic(kernel: str, args=None):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of THIS configuration (profiles/pmc_<key>.json,
+    written by tools/profile.sh + tools/stamp_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench,
+    FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).  None when no profile of the configuration is committed."""
+    f = pmc_file(args)
     sym = ROCPROF_NAME.get(kernel)
     if not f.exists() or sym is None:
         return None
@@ -199,20 +215,21 @@ def pmc_traffic(kernel: str):
         return None
 
 
-def pmc_provenance() -> str:
+def pmc_provenance(args=None) -> str:
     """Where ``roofline.traffic`` comes from: the committed PMC summary and the source commit it was measured at
-    (profiles/pmc_latest.json ``_meta``, written by tools/stamp_profile.py when the summary is copied into profiles/)."""
-    f = REPO / "profiles" / "pmc_latest.json"
+    (``_meta`` of the file, written by tools/stamp_profile.py when the summary is copied into profiles/)."""
+    f = pmc_file(args)
+    rel = f"profiles/{f.name}"
     try:
         meta = json.loads(f.read_text()).get("_meta", {})
     except Exception:  # noqa: BLE001
-        return "profiles/pmc_latest.json (absent)"
-    return (f"profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (tools/profile.sh), "
+        return f"{rel} (absent)"
+    return (f"{rel}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (tools/profile.sh), "
             f"FETCH x2 per the gfx950 correction; measured at source commit {meta.get('commit', 'unknown')} "
             f"({meta.get('tag', '?')}, {meta.get('date', '?')}); NOT re-measured in this run")
 
 
-def roofline(ops, step_fn, compute, n_steps=3):
+def roofline(ops, step_fn, compute, n_steps=3, args=None):
     """Profile ``n_steps`` eager steps with the library's HIP-event timers; report the dominant kernel."""
     ops.prof_reset()
     ops.prof_enable(True)
@@ -239,7 +256,7 @@ def roofline(ops, step_fn, compute, n_steps=3):
     else:
         achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
         out = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS}
-    out.update({"traffic": pmc_traffic(name), "traffic_source": pmc_provenance(),
+    out.update({"traffic": pmc_traffic(name, args), "traffic_source": pmc_provenance(args),
                 "kernel": name, "rocprof_symbol": ROCPROF_NAME.get(name), "launches_per_step": r["launches"] / n_steps, "avg_launch_us": avg_ms * 1e3,
                 "alg_per_launch": (r["flops"] if name.startswith("gemm") else r["bytes"]) / r["launches"]})
     # whole step against the same peaks: the sum over every launch of max(algorithmic flops / MFMA peak,
@@ -297,6 +314,13 @@ def parse_args(argv=None):
                     help="development: run the N ranks on ONE GPU (every rank on cuda:0) over a gloo group -- the N-rank step, "
                          "capture mode and timing protocol on a one-GPU box (RCCL refuses two ranks on one device); the "
                          "throughput it prints is NOT a multi-GPU figure and says so in config.transport")
+    ap.add_argument("--exchange-graph", choices=["auto", "one", "staged"], default="auto",
+                    help="N ranks on an RCCL group: 'staged' = three hipGraphs with the collectives issued eagerly between the graph "
+                         "launches (the default path: two real rank processes have run it); 'one' = ONE hipGraph that also holds the "
+                         "collectives and the per-chunk Adam launches (faster, has only met a 1-rank group); 'auto' = 'one' if a "
+                         "pre-flight CHILD process per rank captured and replayed it with exit code 0, else 'staged'")
+    ap.add_argument("--probe-timeout", type=float, default=300.0, help="seconds the pre-flight children of --exchange-graph auto may take")
+    ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)  # (this process IS a pre-flight child)
     ap.add_argument("--strict-capture", action="store_true",
                     help="fail instead of falling back (staged graphs -> one-piece graph -> eager) when a capture fails")
     ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
@@ -362,7 +386,61 @@ def spawn_ranks(n: int, argv) -> int:
     return 0
 
 
-def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_cpu=True, min_timed_s=0.0):
+def one_graph_probe(args, argv, rank: int, world: int):
+    """Pre-flight for ``--exchange-graph auto``: every rank starts a CHILD process (this rank process has not touched the GPU
+    yet) that runs the N-rank step as ONE hipGraph incl. the RCCL collectives -- capture, replays, the exchange-cost leg's
+    re-captures -- over its own rendezvous (a free port rank 0 picked), and exits 0 only if all of it worked and the ranks
+    ended bit-identical.  The ranks poll their children in lock step over the gloo coordination group: one failed / timed-out
+    child anywhere sends EVERY rank to the staged graphs (the modes issue different collectives), the remaining children are
+    killed, and the run goes on.  -> (ok, note)."""
+    import subprocess
+    import tempfile
+    import torch.distributed as dist
+    from egopack_amd.dist import free_port
+    port = [free_port() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # (the child ranks rendezvous among themselves: rank 0's child hosts the store)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, str(Path(__file__).resolve()), *argv, "--probe-child", "--exchange-graph", "one", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-roofline", "--no-f32-leg", "--strict-capture", "--min-timed-s", "0"]
+    log = tempfile.NamedTemporaryFile("w+", prefix=f"egk_probe_r{rank}_", suffix=".log", delete=False)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=log)
+    deadline = time.monotonic() + args.probe_timeout
+    inject = os.environ.get("EGK_TEST_KILL_PROBE") == str(rank)  # (tests: the probe child of this rank is killed mid-way)
+    t_inject = time.monotonic() + 2.0
+    note = ""
+    while True:
+        rc = proc.poll()
+        if rc is None and inject and time.monotonic() > t_inject:
+            proc.kill()
+            rc = proc.wait()
+        if rc is None and time.monotonic() > deadline:
+            proc.kill()
+            rc = proc.wait()
+            note = f"timed out after {args.probe_timeout:.0f} s"
+        state = [0, 1] if rc is None else ([1, 0] if rc != 0 else [0, 0])  # [failed, running]
+        flags = torch.tensor(state, dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(flags)
+        if int(flags[0]):  # a child failed somewhere: nobody waits for the others
+            if proc.poll() is None:
+                proc.kill()
+                proc.wait()
+            if rc is not None and rc != 0:
+                log.flush()
+                tail = Path(log.name).read_text()[-1500:]
+                note = note or f"child exit code {rc}"
+                print(f"[bench] rank {rank}: one-graph probe child failed ({note}); its stderr ends:\n{tail}", file=sys.stderr, flush=True)
+            return False, (note or "failed on another rank")
+        if not int(flags[1]):
+            return True, "passed"
+        time.sleep(0.25)
+
+
+def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_cpu=True, min_timed_s=0.0, group=None):
     """Build the workload in ``args.compute`` mode, capture / warm up, time ``steps`` steps (barrier + synchronize on both
     sides, MAX over ranks) and take the roofline / CPU-baseline legs.  Returns a dict of results."""
     from egopack_amd import dist as edist
@@ -388,13 +466,13 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
     for t in tasks.values():
         t.to(device).train()
     params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
-    sync = edist.GradSync(world, compress=args.grad_compress) if world > 1 else None
+    sync = edist.GradSync(world, compress=args.grad_compress, group=group) if world > 1 else None
     if world == 1 and args.exchange_dry_run > 1:
-        if not torch.distributed.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29577")
-            torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        edist.init_single_rank_group()  # (free rendezvous port)
         sync = edist.GradSync(args.exchange_dry_run, compress=args.grad_compress)
+    # coordination (flags, timings, barriers) goes over the DEFAULT group: gloo when this process was set up by main()
+    # (CPU tensors), RCCL otherwise (device tensors)
+    coord_cpu = world > 1 and torch.distributed.get_backend() == "gloo"
     fused_merged = None if args.no_fused_backbone else merged
     if args.workload == "egopack_oscc":
         from egopack_amd.models.graphONE.graphONE import GraphONE
@@ -430,6 +508,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             step.grouped_heads = False
     if getattr(args, "no_wgrad_grouping", False):
         step.wgrad_grouping = False
+    step.one_graph_exchange = getattr(args, "exchange_graph", "staged") == "one"  # ('auto' was resolved by main(): probe)
 
     def eager_step():
         step.step(dev, fused_merged)
@@ -452,7 +531,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
         """A capture that fails on ONE rank must send EVERY rank to the next mode: the modes issue different collectives."""
         if world <= 1:
             return ok
-        flag = torch.tensor([1 if ok else 0], device="cpu" if args.one_gpu_gloo else device)
+        flag = torch.tensor([1 if ok else 0], device="cpu" if coord_cpu else device)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         return bool(flag.item())
 
@@ -476,6 +555,11 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
                 err = e
                 fallbacks.append(f"{attempt}: {e!r}")
                 print(f"[bench] capture ({attempt}) failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+                if attempt == "as configured" and step._one_graph_exchange_ok():
+                    # a failed capture that HOLDS COLLECTIVES ends the attempt in this process: nothing guarantees that the
+                    # stream / communicator is reusable (round 3: carrying on aborted the process) -- a pre-flight child exits
+                    # non-zero here and its parent takes the staged graphs
+                    raise
                 torch.cuda.synchronize()
                 if args.strict_capture or attempt == "eager":
                     raise
@@ -511,7 +595,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
     def over_ranks(v, op):
         if world <= 1:
             return v
-        t = torch.tensor([v], dtype=torch.float64, device="cpu" if args.one_gpu_gloo else device)
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if coord_cpu else device)
         torch.distributed.all_reduce(t, op=op)
         return float(t.item())
 
@@ -535,6 +619,9 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
     exchange = None
     if sync is not None and world > 1:
         recapture = getattr(step, "_graph_has_exchange", False)  # (a graph that holds the collectives is captured again without them)
+        # the leg steps every rank on its LOCAL gradients: parameters, moments and the step counter are put back afterwards, so
+        # that whatever follows in this process is the replicated run again
+        snap = (opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_v.clone(), opt.step_count)
         sync.skip_collectives = True
         try:
             if recapture:
@@ -546,12 +633,17 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             sync.skip_collectives = False
             if recapture:
                 step.capture(dev, fused_merged, warmup=0)
-        sync.broadcast_(opt.flat_p)  # (the replicas stepped on local gradients meanwhile: same parameters again)
+        with torch.no_grad():
+            opt.flat_p.copy_(snap[0])
+            opt.flat_m.copy_(snap[1])
+            opt.flat_v.copy_(snap[2])
+        opt.step_count = snap[3]  # (the device-side counter follows at the next step: FlatAdam.sync_hyper_source)
         opt.refresh_shadows()
+        del snap
         torch.cuda.synchronize()
         exchange = {"ms_per_step_without_collectives": dry, "exposed_ms_per_step": ms - dry,
                     "bytes_per_step": opt.flat_g.numel() * (2 if args.grad_compress == "bf16" else 4),
-                    "rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend()}
+                    "rccl_ranks": torch.distributed.get_world_size(group), "backend": torch.distributed.get_backend(group)}
     if getattr(args, "stamps", False) and rank == 0:
         prev = 0.0
         for name, us in sorted(ops.stamps_read(), key=lambda kv: kv[1]):
@@ -571,7 +663,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             if g1 is not None:
                 saved_g1, g1.parallel_tasks = g1.parallel_tasks, False
             try:
-                rl, table = roofline(ops, eager_step, args.compute)
+                rl, table = roofline(ops, eager_step, args.compute, args=args)
             finally:
                 step.parallel_heads, step.wgrad_side_streams = saved
                 if g1 is not None:
@@ -581,7 +673,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             # other down, so this is the figure a trace of the replayed graph shows (round-2 verdict: the grouped
             # weight-gradient launch, invisible in the serialised table)
             try:
-                rl2, _ = roofline(ops, eager_step, args.compute)
+                rl2, _ = roofline(ops, eager_step, args.compute, args=args)
                 if rl and rl2:
                     rl["replay_dominant"] = {k: rl2[k] for k in ("kernel", "rocprof_symbol", "bound", "achieved", "peak", "unit", "frac",
                                                                  "avg_launch_us", "launches_per_step", "alg_per_launch", "traffic")
@@ -594,11 +686,10 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             rl = {"error": repr(e)}
     if rl and "step" in rl:
         rl["step"]["frac"] = rl["step"]["lower_bound_ms"] / ms
-    # the committed PMC passes are of the DEFAULT workload on one GPU: the same kernel name at other sizes moves other bytes
-    pmc_config = (args.workload == "mtl" and (args.batch, args.T, args.hidden, args.trn_hidden) == (64, 32, 1024, 1024)
-                  and args.compute == "bf16" and world == 1 and not args.exchange_dry_run)
+    # PMC passes are per configuration on ONE GPU (profiles/pmc_<key>.json): none for N ranks or the exchange dry run
+    pmc_config = world == 1 and not args.exchange_dry_run and pmc_file(args).exists()
     if rl and "traffic" in rl and not pmc_config:
-        rl["traffic"], rl["traffic_source"] = None, "not measured for this configuration (profiles/pmc_latest.json holds the default workload)"
+        rl["traffic"], rl["traffic_source"] = None, f"not measured for this configuration (no profiles/pmc_{pmc_key(args)}.json)"
         if isinstance(rl.get("replay_dominant"), dict) and "traffic" in rl["replay_dominant"]:
             rl["replay_dominant"]["traffic"] = None
     cb = None
@@ -607,7 +698,13 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             cb = cpu_baseline(sds, names, dev, weights)
         except Exception as e:
             cb = {"error": repr(e)}
-    return {"ms": ms, "roofline": rl, "table": table, "cpu_baseline": cb, "n_params": opt.flat_p.numel(), "capture": capture,
+    # replicated run: finite parameters, the same on every rank (checked over the coordination group)
+    params_ok = bool(torch.isfinite(opt.flat_p).all().item())
+    if world > 1:
+        h = opt.flat_p.double().sum().item()
+        params_ok = params_ok and over_ranks(h, torch.distributed.ReduceOp.MAX) == over_ranks(h, torch.distributed.ReduceOp.MIN)
+    return {"params_ok": params_ok,
+            "ms": ms, "roofline": rl, "table": table, "cpu_baseline": cb, "n_params": opt.flat_p.numel(), "capture": capture,
             "fallbacks": fallbacks, "mode": "eager" if capture == "eager" else "graph", "timing": timing, "exchange": exchange}
 
 
@@ -630,18 +727,34 @@ def main(argv=None):
                 time.sleep(1.0)
             time.sleep(2.0)
     from egopack_amd import dist as edist
-    rank, local_rank, world = edist.init_from_env("gloo" if args.one_gpu_gloo else None)
+    # Two groups for N ranks: the DEFAULT group is gloo -- coordination only (mode flags, barriers, max-over-ranks timings;
+    # creating it touches no GPU) -- and the gradient exchange runs over an RCCL group created below (``data_group``).
+    rank, local_rank, world = edist.init_from_env("gloo")
     if args.one_gpu_gloo:
         local_rank = 0  # every rank on the box's one GPU
     if world != args.gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     if rank != 0:  # only rank 0 reports: nothing else (RCCL's C-level stdout banner included) may reach the shared stdout
         sys.stdout.flush()
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    # which capture the N-rank step takes: resolved BEFORE this process touches the GPU (the pre-flight children are started
+    # by a process without a device context)
+    rccl_exchange = (world > 1 and not args.one_gpu_gloo) or (world == 1 and args.exchange_dry_run > 1)
+    probe = "not run"
+    if args.probe_child or not rccl_exchange or args.mode != "graph" or args.staged == "off":
+        if args.exchange_graph == "auto":
+            args.exchange_graph = "staged"
+    elif args.exchange_graph == "auto":
+        ok, probe = one_graph_probe(args, argv, rank, world)
+        args.exchange_graph = "one" if ok else "staged"
+    args.probe_note = probe
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    data_group = None
+    if world > 1 and not args.one_gpu_gloo:
+        data_group = torch.distributed.new_group(backend="nccl")  # RCCL over xGMI: the gradient exchange
 
     if args.gemm_knob is not None:
         from egopack_amd import _lib
@@ -659,8 +772,15 @@ def main(argv=None):
         from egopack_amd import data as _D
         _D.HEAVY_IN_LAUNCH_DEGREE = 0
 
-    res = measure(args, rank, world, device, args.steps, args.warmup, min_timed_s=args.min_timed_s)
+    res = measure(args, rank, world, device, args.steps, args.warmup, min_timed_s=args.min_timed_s, group=data_group)
     ms = res["ms"]
+    if args.probe_child:
+        # a pre-flight child of --exchange-graph auto: the one-graph step captured, replayed and (N > 1) re-captured for the
+        # exchange-cost leg; exit 0 only if it really ran in that mode and the ranks hold the same finite parameters
+        ok = res["capture"] == "one graph incl. the gradient exchange" and bool(res["params_ok"])
+        print(f"[bench probe] rank {rank}: capture '{res['capture']}', parameters ok {res['params_ok']}", file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(0 if ok else 3)  # (no teardown of the communicator in a process whose only job was to survive)
     seqs_per_step = world * len(WORKLOADS[args.workload][0]) * args.batch
 
     # reference-precision leg (N = 1, rank 0): the same step in --compute f32 (exact-f32 MFMA, f32 activations / weights --
@@ -698,6 +818,8 @@ def main(argv=None):
                        "parallelism": f"dp{world}", "trainable_params": res["n_params"],
                        "grad_allreduce": (("bf16" if args.grad_compress == "bf16" else "f32") if world > 1 else None),
                        "capture": res["capture"], "capture_fallbacks": res["fallbacks"],
+                       "exchange_graph": ({"mode": args.exchange_graph, "probe": args.probe_note, "ranks_identical": res["params_ok"]}
+                                          if (world > 1 or args.exchange_dry_run > 1) else None),
                        "transport": ("gloo, all ranks on ONE GPU (development run of the N-rank path: not a multi-GPU figure)"
                                      if args.one_gpu_gloo else ("RCCL" if world > 1 else None)),
                        "input": (f"assembled in the step by egk_gather_rows from a resident {args.feature_store}-row feature store"

@@ -429,6 +429,11 @@ def to_device_packed(datas: Sequence["Data"], device, non_blocking: bool = True,
             return ("l", v, [walk(t, f"{path}[{i}]") for i, t in enumerate(v)])
         if isinstance(v, (int, float, bool, str)) and "._" not in path:
             sig.append((path, v))
+        elif (isinstance(v, (list, tuple)) and "._" not in path
+              and all(isinstance(e, (int, float, bool, str)) for e in v)):
+            # tuples of plain scalars (pos_range = (min, max) ...) are baked into a captured step's kernel arguments like
+            # the scalars themselves (engine.batch_signature descends into them): part of the layout signature too
+            sig.append((path, tuple(v)))
         return ("o", v, None)
     plans = [{k: walk(v, f"{i}.{k}") for k, v in d.materialise().__dict__.items()} for i, d in enumerate(datas)]
     if total == 0:
@@ -488,7 +493,16 @@ def to_device_packed(datas: Sequence["Data"], device, non_blocking: bool = True,
 
     def rebuild(buf, static: bool = False, lazy: bool = False):
         if lazy:
-            return [LazyData(lambda pl=pl: {k: build(q, buf, static) for k, q in pl.items()}) for pl in plans]
+            lazies = []
+            for pl in plans:
+                ld = LazyData(lambda pl=pl: {k: build(q, buf, static) for k, q in pl.items()})
+                # plain host attributes (num_graphs, pos_range, heavy-row modes ...) are there at once: a training loop that
+                # only counts sequences (main_temporal / main_egopack: ``int(b.num_graphs)``) must not trigger the ~20 views
+                for k, (kind, v, _) in pl.items():
+                    if kind == "o":
+                        ld.__dict__[k] = v
+                lazies.append(ld)
+            return lazies
         outs = []
         for pl in plans:
             out = Data()

@@ -33,6 +33,48 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, local_rank, world
 
 
+def free_port() -> int:
+    """A TCP port nobody listens on right now (bound to port 0 and released)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def init_single_rank_group(backend: str = "nccl") -> None:
+    """A 1-rank process group for the exchange DRY RUN (``exchange_dry_run`` / ``--exchange-dry-run``: the N-rank code path
+    on one GPU): its own rendezvous on a free port -- a fixed one collides with whatever else runs on the box."""
+    if dist.is_initialized():
+        return
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(free_port())
+    dist.init_process_group(backend, rank=0, world_size=1)
+
+
+def quiesce_before_capture(group=None, settle_s: float = 0.35) -> None:
+    """Let the RCCL process group's WATCHDOG retire every collective issued so far before a hipGraph capture starts.
+
+    Root cause of the round-3 driver abort (reproduced 3 times in 9 on fresh boxes, tools/round4/repro_abort.sh; the C++ trace is
+    in profiles/r04_abort_root_cause.txt): ProcessGroupNCCL's watchdog thread keeps a copy of every EAGERLY issued collective
+    and polls its end event (hipEventQuery) every ~100 ms until it has completed.  ``capture(warmup=...)`` issues eager steps
+    -- with their collectives -- and starts capturing right behind them; when a capture that contains collectives then takes
+    the communicator's stream into capture mode while the watchdog still holds one of those eager works, its next poll fails
+    with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing stream"), the watchdog
+    rethrows on its own thread and std::terminate aborts the process -- hundreds of milliseconds later, wherever the main
+    thread happens to be.  A device synchronisation makes every pending work complete; one watchdog sweep later they are gone.
+    No-op without an RCCL group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        if dist.get_backend(group) != "nccl":
+            return
+    except Exception:  # noqa: BLE001  (not a member of the group)
+        return
+    import time
+    torch.cuda.synchronize()
+    time.sleep(settle_s)
+
+
 def _via_host(t: torch.Tensor, group) -> bool:
     """A device tensor on a gloo group: ranks that share one GPU (the two-process test topology of
     tools/two_rank_check.py; RCCL refuses two ranks on one device) exchange through host memory."""
@@ -88,6 +130,10 @@ class GradSync:
         # the default issues every slice after the last stage, behind its collective's event
         self.adam_behind_collective = "adam_behind_collective" in os.environ.get("EGK_ENABLE", "")
         self.hyper_ready = False  # set by a caller that has prepared the step's Adam constants itself (a captured exchange)
+
+    def quiesce(self) -> None:
+        """Before a hipGraph capture: see ``quiesce_before_capture``."""
+        quiesce_before_capture(self.group)
 
     def capturable(self) -> bool:
         """Whether the exchange can be recorded into a hipGraph: RCCL collectives enqueue device work only (a gloo group moves
@@ -239,7 +285,8 @@ class GradSync:
     # same bytes over the links (the gradient sum in, the updated f32 parameters out) while every rank runs Adam over its own
     # 1 / world slice only: 0.75 GB of HBM traffic per step becomes 0.75 / world GB + one conversion pass that rebuilds the
     # bf16 operand copies from the gathered parameters (0.15 GB).  The moments of the other slices are never touched on
-    # this rank (they stay zero: a checkpoint of a sharded run holds each rank's own moment slice -- gather before saving).
+    # this rank (they stay zero): ``gather_moments`` -- a collective, called by the entry points on every rank before rank 0
+    # saves -- rebuilds the full moment buffers for a checkpoint, and FlatAdam.state_dict() refuses to run without it.
     def shard_bounds(self, n: int) -> tuple:
         """(slice length, begin, end of THIS rank's slice, end of the evenly sharded body).  Slices are multiples of 8
         elements; [body, n) -- fewer than 8 * world elements -- is all-reduced and stepped on every rank."""
@@ -313,6 +360,34 @@ class GradSync:
             gather_params()
         opt.refresh_shadows()  # the bf16 operand copies of the slices other ranks stepped
         opt.step_count += 1
+        opt._moments_sharded = self.world > 1  # (FlatAdam.state_dict refuses until gather_moments has run)
+
+    def gather_moments(self, opt) -> None:
+        """Sharded update: all-gather every rank's slice of the Adam moments so that each rank holds the full flat_m / flat_v
+        -- what a checkpoint must contain (a resumed run may use another world size or the all-reduce path).  A COLLECTIVE:
+        every rank calls it (the entry points do, before rank 0 saves).  The slices of the other ranks are overwritten by the
+        next sharded step's bookkeeping only in the sense that this rank never reads them: the gathered values stay valid
+        until the next step."""
+        if not getattr(opt, "_moments_sharded", False):
+            return
+        if getattr(opt, "flat_m", None) is None:
+            opt._moments_sharded = False
+            return
+        n = opt.flat_m.numel()
+        per, lo, hi, body = self.shard_bounds(n)
+        real = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if per and real == self.world:
+            native = opt.flat_m.is_cuda and dist.get_backend(self.group) == "nccl"
+            for buf in (opt.flat_m, opt.flat_v):
+                if native:
+                    dist.all_gather_into_tensor(buf[:body], buf[lo:hi].clone(), group=self.group)
+                else:
+                    mine = buf[lo:hi].cpu() if buf.is_cuda else buf[lo:hi].clone()
+                    parts = [torch.empty_like(mine) for _ in range(self.world)]
+                    dist.all_gather(parts, mine, group=self.group)
+                    for r, part in enumerate(parts):
+                        buf[r * per:(r + 1) * per].copy_(part)
+        opt._moments_sharded = False
 
     def reduce_and_step(self, opt) -> None:
         """Gradient exchange + optimizer step of a ``FlatAdam`` as a PIPELINE over chunks of the flat buffer: chunk i is

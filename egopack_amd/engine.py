@@ -706,6 +706,10 @@ class StepBase:
                     self.step(batches, merged)
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.sync is not None and self.sync.world > 1:
+            # the eager steps above issued collectives: the process group's watchdog must have retired them before a capture
+            # may take the communicator's stream into capture mode (dist.quiesce_before_capture: the round-3 abort)
+            self.sync.quiesce()
         if hasattr(opt, "invalidate_lo_shadows"):
             opt.invalidate_lo_shadows()  # (a captured step must contain every refresh of the low halves it relies on)
         self._graph_has_exchange = False
@@ -879,16 +883,23 @@ class StepBase:
 
     # The N-rank step as ONE hipGraph: the three stages, the region-wise collectives between them (communication stream, forked
     # and joined inside the capture) and the per-chunk Adam launches.  Three graph launches + ~13 collectives + ~13 Adam
-    # launches issued from Python per step become one graph launch (--exchange-dry-run 8 on one GPU: 1.70 -> see DESIGN.md).
+    # launches issued from Python per step become one graph launch (--exchange-dry-run 8 on one GPU: 1.69 -> 1.53 ms).
     # RCCL collectives enqueue device work only and are capturable; the process group's watchdog keeps polling its events from
-    # its own thread, legal under CAPTURE_MODE 'thread_local'.  A capture that raises falls back to the three staged graphs
-    # (same collectives in the same order, so ranks that end up in different modes still match); EGK_DISABLE=one_graph_exchange
-    # turns it off.  A gloo group (host round trip) is never captured.
-    one_graph_exchange = True
+    # its own thread, legal under CAPTURE_MODE 'thread_local'.
+    #
+    # OPT-IN.  The default for several ranks is the path with the most evidence: three staged graphs with the collectives
+    # issued eagerly between the graph launches (two real rank processes run it, tools/two_rank_check.py).  This mode has only
+    # ever met a 1-rank RCCL group, so it is taken when the caller asks for it -- the attribute, or EGK_ENABLE=one_graph_exchange
+    # -- typically after a pre-flight child process per rank has captured and replayed it with exit code 0 (bench.py
+    # ``one_graph_probe``).  A capture that holds collectives and FAILS is not retried in this process: the exception reaches
+    # the caller (after a failed capture nothing guarantees that the stream / communicator is reusable; the round-3 catch-and-
+    # continue onto the staged graphs is gone), who ends the attempt -- the parent picks the next mode for ALL ranks.
+    one_graph_exchange = False
 
     def _one_graph_exchange_ok(self) -> bool:
         import os
-        return bool(self.one_graph_exchange and "one_graph_exchange" not in os.environ.get("EGK_DISABLE", "")
+        want = self.one_graph_exchange or "one_graph_exchange" in os.environ.get("EGK_ENABLE", "")
+        return bool(want and "one_graph_exchange" not in os.environ.get("EGK_DISABLE", "")
                     and self.sync is not None and self.sync.world > 1 and self.sync.capturable())
 
     def _capture_exchange_graph(self, batches, merged):
@@ -979,14 +990,7 @@ class StepBase:
         """Three graphs (one per backward stage) from one memory pool; the gradient exchange sits between them."""
         self._graph_has_exchange = False
         if self._one_graph_exchange_ok():
-            try:
-                return self._capture_exchange_graph(batches, merged)
-            except Exception as e:  # noqa: BLE001
-                self.capture_notes = [*getattr(self, "capture_notes", []), f"one graph with the exchange: {e!r}"]
-                ops.set_graph_ln_exchange(None)
-                torch.cuda.synchronize()
-                if self._exact_ln_on():
-                    raise
+            return self._capture_exchange_graph(batches, merged)  # (an exception ends the attempt: see one_graph_exchange)
         opt = self.optimizer
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         self._rng_in_graph = False  # (no staged graph advances the Philox offset word: replay() does, also after a one-piece capture)
@@ -995,16 +999,17 @@ class StepBase:
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             live = [t for t in self.enabled if batches.get(t) is not None]
-            with torch.cuda.graph(gs[0], capture_error_mode=CAPTURE_MODE):
+            cap = ops.unexcluded_stream()  # (one capture stream for the three graphs, never a registered head / task stream)
+            with torch.cuda.graph(gs[0], stream=cap, capture_error_mode=CAPTURE_MODE):
                 opt.flat_g.zero_()
                 if self.input_hook is not None:
                     self.input_hook()
                 total, vectors = self._stage_a(batches, merged)
             pool = gs[0].pool()
-            with torch.cuda.graph(gs[1], pool=pool, capture_error_mode=CAPTURE_MODE):
+            with torch.cuda.graph(gs[1], pool=pool, stream=cap, capture_error_mode=CAPTURE_MODE):
                 self._install_tail(self._tail_only_plan(live))  # (stage B ends with the stack's flush, stage C is the tail launch)
                 self._stage_b()
-            with torch.cuda.graph(gs[2], pool=pool, capture_error_mode=CAPTURE_MODE):
+            with torch.cuda.graph(gs[2], pool=pool, stream=cap, capture_error_mode=CAPTURE_MODE):
                 self._stage_c()
         finally:
             ops.set_last_wgrad_hook(None, None)
@@ -1038,6 +1043,9 @@ class StepBase:
                 opt.prepare_hyper()
                 self._graph.replay()
             opt.step_count += 1
+            # the graph's Adam launch moved flat_p on the DEVICE without opt.launch() running on the host: every low half a
+            # 'bf16x3' contraction marked fresh before this replay (validation's precise pass between two epochs) is stale now
+            opt.invalidate_lo_shadows()
         else:
             self._graph.replay()
             self.sync.reduce_and_step(opt)

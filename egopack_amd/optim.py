@@ -155,6 +155,10 @@ class FlatAdam(torch.optim.Optimizer):
     def state_dict(self):
         """``{"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}`` with parameter indices
         in constructor order -- loadable by torch.optim.Adam over the same parameter list and vice versa."""
+        if getattr(self, "_moments_sharded", False):
+            raise RuntimeError("FlatAdam.state_dict(): the moments are sharded over the ranks (dist.GradSync shard_update: every rank "
+                               "holds its own 1 / world slice, zeros elsewhere) -- call GradSync.gather_moments(optimizer) on "
+                               "EVERY rank before saving")
         group = self.param_groups[0]
         state = {}
         for i, p in enumerate(group["params"]):

@@ -154,6 +154,8 @@ def main(argv=None):
         scheduler.step()
         validate_metrics(epoch, model, tasks, graphone, weights, dsets_val, dl_val, late_fusion=cfg.late_fusion,
                          validate_all=cfg.validate_all_tasks, device=device)  # all ranks: the split is sharded by batch
+    if cfg.save_model and step.sync is not None:
+        step.sync.gather_moments(optimizer)  # (sharded update: a collective, every rank; a no-op otherwise)
     if cfg.save_model and rank == 0:
         name = f"{cfg.artifact_prefix}_egopack_" + "-".join(sorted(t for t, w in weights.items() if w > 0))
         T.save_checkpoint(Path(cfg.checkpoint_dir) / name / "checkpoint.pth", model, tasks, cfg.num_epochs,

@@ -161,11 +161,7 @@ def main(argv=None):
     if world == 1 and dry > 1:
         # development / test knob: run the N-rank exchange path (conversion, RCCL all-reduce on a 1-rank group, 1/N gradient
         # scale, staged backward) on ONE GPU -- everything of the N-GPU step except the peers' contributions
-        if not torch.distributed.is_initialized():
-            import os
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29571")
-            torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        edist.init_single_rank_group()  # (no-op when the caller already owns a group; free rendezvous port otherwise)
         sync = edist.GradSync(dry, compress=compress)
     step = engine.MTLStep(model, tasks, T.build_criteria(dsets_train), weights, optimizer,
                           fused_backbone=cfg.fused_backbone, sync=sync)
@@ -184,6 +180,8 @@ def main(argv=None):
         train(epoch, step, dl_train, weights, device, store=store)
         scheduler.step()
         logger.info("learning rate -> %.6g", scheduler.get_last_lr()[0])
+        if cfg.save_model and cfg.get("save_every", 0) and epoch % cfg.save_every == 0 and sync is not None:
+            sync.gather_moments(optimizer)  # (sharded update: a collective, every rank; a no-op otherwise)
         if cfg.save_model and cfg.get("save_every", 0) and epoch % cfg.save_every == 0 and rank == 0:
             T.save_checkpoint(ckpt_path, model, tasks, epoch, optimizer=optimizer, scheduler=scheduler, loaders=dl_train)
         if epoch >= cfg.num_epochs - 5:  # all ranks: the validation split is sharded by batch
@@ -191,6 +189,8 @@ def main(argv=None):
             metrics = validate_metrics(epoch, model, tasks, step.enabled, dsets_val, dl_val, device)
     if cfg.num_epochs < first_epoch and cfg.get("validate_untrained", False):  # (num_epochs=0: metrics of the initial state)
         metrics = validate_metrics(0, model, tasks, step.enabled, dsets_val, dl_val, device)
+    if cfg.save_model and sync is not None:
+        sync.gather_moments(optimizer)
     if cfg.save_model and rank == 0:
         T.save_checkpoint(ckpt_path, model, tasks, cfg.num_epochs, optimizer=optimizer, scheduler=scheduler, loaders=dl_train)
     if world > 1:

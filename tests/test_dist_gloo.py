@@ -210,6 +210,10 @@ def _sharded_worker(rank, world, port, q):
     other[lo:hi] = False
     other[body:] = False
     ok = ok and not shd.flat_m[other].any() and bool(shd.flat_m[lo:hi].any()) and torch.equal(shd.flat_m[lo:hi], ref.flat_m[lo:hi])
+    # a checkpoint needs the FULL moments: the sharded step flags the optimizer, gather_moments (a collective) rebuilds them
+    ok = ok and getattr(shd, "_moments_sharded", False) is True
+    sync.gather_moments(shd)
+    ok = ok and shd._moments_sharded is False and torch.equal(shd.flat_m, ref.flat_m) and torch.equal(shd.flat_v, ref.flat_v)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

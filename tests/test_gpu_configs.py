@@ -24,7 +24,7 @@ Stated tolerances
       oracle's gradients -- Adam's first step moves every element by lr * g / (|g| + eps) = +-lr, so an element whose
       gradient is within rounding noise of zero may legitimately move the other way (2e-3 apart); the bound on the count
       of such elements is the test
-      nearest-prototype indices (#4): identical wherever the fp32 ranking gap exceeds 1e-5, and >= 99.5 % identical overall
+      nearest-prototype indices (#4): identical wherever the fp32 ranking gap exceeds 1e-5, and >= 99.95 % identical overall
   bf16 mode (bf16 MFMA, bf16 activations / gradients / weight operands: the benchmark mode)
       loss vectors      relative Frobenius error <= BF16_LOSS
       objective         relative BF16_OBJ
@@ -64,7 +64,10 @@ CONFIGS = {
     "c3_mtl_B64_T32_Hp4096": dict(workload="mtl", batch=64, T=32, trn_hidden=4096),
 }
 LR, WD = 1e-3, 1e-5
-BF16_LOSS, BF16_OBJ, BF16_KNN_ORDERED, BF16_KNN_SETS, BF16_C4_LOGITS = 1.5e-2, 5e-3, 0.999, 0.9995, 3e-2
+# k-NN lists (an INDEX op: north_star's 'bit-exact for index/label ops'): identical wherever the oracle's fp ranking gap exceeds
+# 1e-5 -- asserted exactly -- and >= 0.9995 of the positions overall in BOTH modes (measured 100 / 100 / 99.98 %): exact up to
+# ties below 1e-5, which f32 summation order decides (reference models/graphONE/graphONE.py:133-136 argsorts f32 distances)
+BF16_LOSS, BF16_OBJ, BF16_KNN_ORDERED, BF16_KNN_SETS, BF16_C4_LOGITS = 1.5e-2, 5e-3, 0.9995, 0.9995, 2.6e-2
 # bf16-mode gradient bound per configuration (relative Frobenius error of the worst parameter tensor; measured values in
 # profiles/r02_config_parity.md).  The OSCC head pools every sequence with a max over its T nodes: under bf16 rounding a
 # near-tie between two nodes resolves the other way for a few (sequence, channel) pairs and their gradient rows move to
@@ -78,8 +81,10 @@ BF16_LOSS, BF16_OBJ, BF16_KNN_ORDERED, BF16_KNN_SETS, BF16_C4_LOGITS = 1.5e-2, 5
 # model at BF16_LOSS_VS_MODEL, HIP is CLOSER to the model than to the f32 oracle, and it is no further from the f32 oracle
 # than BF16_NOISE_FACTOR times what the model's own rounding puts between itself and the f32 oracle.
 BF16_LOSS_VS_MODEL, BF16_NOISE_FACTOR = 1e-2, 2.0
-BF16_GRAD = {"c1_ar_B2_T32": 0.15, "c2_ar_B64_T32": 0.15, "c3_mtl_B64_T32": 0.15, "c4_egopack_oscc_K4096_d3": 0.30,
-             "c5_mtl4_B16_T256": 0.30, "x5_mtl3_B16_T256": 0.15, "c2_ar_B64_T32_Hp4096": 0.15, "c3_mtl_B64_T32_Hp4096": 0.15}
+# bounds = measured x 1.25 (profiles/r03_config_parity.md: 0.085-0.106 without the OSCC head, 0.200 / 0.220 with it), so that
+# they can fail: a wrong term moves these figures by far more than a quarter
+BF16_GRAD = {"c1_ar_B2_T32": 0.13, "c2_ar_B64_T32": 0.13, "c3_mtl_B64_T32": 0.13, "c4_egopack_oscc_K4096_d3": 0.27,
+             "c5_mtl4_B16_T256": 0.27, "x5_mtl3_B16_T256": 0.13, "c2_ar_B64_T32_Hp4096": 0.13, "c3_mtl_B64_T32_Hp4096": 0.13}
 
 
 def _args(name, mode, dropout=0.0, trn_hidden=1024):
@@ -383,7 +388,7 @@ def test_config4_prototype_indices_f32_vs_oracle():
         assert torch.equal(nn[t][safe], ref["closest"][t][safe]), t
         agree.append(float((nn[t] == ref["closest"][t]).float().mean()))
         assert torch.equal(closest[t][0].cpu(), nn[t][:, 0])  # what interact() reports = column 0 of the same search
-    assert min(agree) > 0.995, agree
+    assert min(agree) >= BF16_KNN_ORDERED, agree  # (0.9995 in f32 mode too: exact up to ties below 1e-5)
     torch.testing.assert_close(logits.float().cpu(), ref["logits"], rtol=1e-3, atol=1e-3)
     for t in aux:
         assert _rel(aux[t].float().cpu(), ref["aux"][t]) < 2e-3, t

@@ -3,6 +3,8 @@
 its provenance: the source commit the numbers were measured at (this script runs in the build container, where .git is).
 
     python tools/stamp_profile.py r03a            # gpurun_out/prof_r03a -> profiles/r03a_*, profiles/pmc_latest.json
+    python tools/stamp_profile.py r04_c4 egopack_oscc_B64_T32_H1024_Hp1024_bf16
+                                                  # ... -> profiles/r04_c4_*, profiles/pmc_<key>.json (bench.pmc_key of that run)
 """
 import datetime
 import json
@@ -13,6 +15,7 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
 tag = sys.argv[1]
+key = sys.argv[2] if len(sys.argv) > 2 else None
 src = REPO / "gpurun_out" / f"prof_{tag}"
 dst = REPO / "profiles"
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
@@ -29,7 +32,8 @@ for name, out in (("summary.md", f"{tag}_rocprofv3_summary.md"), ("pmc.json", f"
             d["_meta"] = meta
             (dst / out).write_text(json.dumps(d, indent=1))
             if name == "pmc.json":
-                (dst / "pmc_latest.json").write_text(json.dumps(d, indent=1))
+                d["_meta"]["config"] = key or "mtl_B64_T32_H1024_Hp1024_bf16"
+                (dst / (f"pmc_{key}.json" if key else "pmc_latest.json")).write_text(json.dumps(d, indent=1))
         else:
             text = f.read_text()
             (dst / out).write_text(text + f"\n\n(measured at source commit {meta['commit']}, {meta['date']})\n")
