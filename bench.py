@@ -173,7 +173,7 @@ ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pip
                 "gemm_bf16_group_nn": "gemm_pipe_group_kernel<2, false, false", "gemm_bf16_group_nt": "gemm_pipe_group_kernel<2, false, true",
                 "gemm_bf16_group_tt": "gemm_pipe_group_kernel<2, true, true",
                 "gemm_bf16_generic": "gemm_kernel<true", "gemm_splitk_reduce": "gemm_splitk_reduce",
-                "adam": "adam_kernel", "csr_gather": "csr_gather_kernel"}
+                "adam": "adam_kernel<", "csr_gather": "csr_gather_"}
 
 
 def pmc_key(args) -> str:

@@ -38,6 +38,8 @@ class GemmDesc(C.Structure):
         ("st_mode", i32), ("st_nseg", i32), ("st_min_seg_rows", i32), ("st_seg_ptr", vp), ("st_ws", vp), ("st_x", vp),
         ("st_ldx", i64), ("st_stats", vp), ("st_w", vp), ("st_b", vp), ("st_slope", f32),
         ("n_extra", i32), ("xK", i32 * 4), ("xA", vp * 4), ("xB", vp * 4), ("xlda", i64 * 4), ("xldb", i64 * 4),
+        ("ga_mode", i32), ("ga_tile_mask", i32), ("ga_skip_c", i32), ("ga_rowptr", vp), ("ga_col", vp), ("ga_wgt", vp),
+        ("ga_band", vp), ("ga_gate", vp), ("ga_out", vp), ("ga_ld", i64),
     ]
 
 
@@ -59,6 +61,7 @@ SIGNATURES = {
     "egk_stamp": (C.c_int, [vp, vp, i32]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
     "egk_gemm_stats_blocks": (C.c_int, [C.POINTER(GemmDesc)]),
+    "egk_gemm_gather_ok": (C.c_int, [C.POINTER(GemmDesc)]),
     "egk_gemm_grouped": (C.c_int, [vp, C.POINTER(GemmDesc), i32]),
     "egk_gemm_ws_bytes": (i64, [C.POINTER(GemmDesc)]),
     "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),

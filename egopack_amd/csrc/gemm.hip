@@ -66,6 +66,15 @@ struct GemmArgs {
     const float* st_w;
     const float* st_b;
     float st_slope;
+    // row gather of the result inside the rows epilogue (egk_gemm_desc.ga_*)
+    int ga_mode, ga_skip_c;
+    const int* ga_rowptr;
+    const int* ga_col;
+    const float* ga_wgt;
+    const unsigned char* ga_band;
+    const void* ga_gate;
+    void* ga_out;
+    long long ga_ld;
 };
 
 // Workgroup -> (slab z, tile row, tile column) for a 1-D launch of tiles_m * tiles_n * splitk workgroups.
@@ -372,7 +381,7 @@ __host__ __device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
     return true;
 }
 
-template <int NI>
+template <int NI, bool GA = false>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[NI][4], unsigned char* lds, int m0, int n0,
                                                    int wm, int wn, int lr, int lg, int z, int tid, int st_tile = 0) {
     __syncthreads();  // every wave is done with the ring (nothing is in flight: the last tiles were waited for)
@@ -405,7 +414,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
         }
     }
     const bool st_cols = n < g.N;
-    if (n >= g.N && !st_mode) return;  // (N % 8 == 0: a group of 8 columns is all in or all out)
+    // (GA: the instantiations launched with a row gather in the epilogue -- its index batch costs ~30 registers that the
+    //  other launches, two workgroups per CU at <= 256 registers per lane, must not pay)
+    const int ga_mode = (GA && g.splitk == 1) ? g.ga_mode : 0;
+    if (n >= g.N && !st_mode && !ga_mode) return;  // (N % 8 == 0: a group of 8 columns is all in or all out)
     float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (g.bias && g.splitk == 1) {
         const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
@@ -458,8 +470,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
             pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
             pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
-            *reinterpret_cast<uint4*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
-            if (st_mode) {  // the sums are those of the values the LayerNorm will READ: the rounded ones
+            if (!g.ga_skip_c) *reinterpret_cast<uint4*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
+            if (st_mode || ga_mode) {  // the sums / the gather are those of the values a reader of C would READ: the rounded ones
                 const unsigned pw[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -467,10 +479,14 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
                     o[2 * t + 1] = __uint_as_float(pw[t] & 0xffff0000u);
                 }
             }
-        } else {
+        } else if (!g.ga_skip_c) {
             float* cp = (float*)g.C + (long long)m * g.ldc + n;
             *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
             *reinterpret_cast<float4*>(cp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (ga_mode) {  // park the stored values where the raw accumulators were (this thread's own two slots)
+            *reinterpret_cast<f32x4*>(stage + row * 128 + (((2 * c8) ^ (row & 15)) << 2)) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(stage + row * 128 + (((2 * c8 + 1) ^ (row & 15)) << 2)) = f32x4{o[4], o[5], o[6], o[7]};
         }
         if (st_mode == 1) {
             const int rel = m >= s_split ? 1 : 0;
@@ -529,6 +545,105 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             double t_ = 0.0;
             if (rel == 0 || rel == 1) t_ = (st_red[0][rel * 2 + k] + st_red[1][rel * 2 + k]) + (st_red[2][rel * 2 + k] + st_red[3][rel * 2 + k]);
             g.st_ws[((long long)st_tile * g.st_nseg + sg) * 2 + k] = t_;
+        }
+    }
+    if constexpr (GA) if (ga_mode) {
+        // The neighbour aggregation of the stored tile (egk_gemm_desc.ga_*): every edge of a row of this tile ends inside the
+        // tile (host-checked), so the rows come from LDS.  Added in edge order with the arithmetic of csr_gather_kernel.
+        // Every index this thread needs -- codes / row pointers of its 2 * NI rows, then the first four (column, weight)
+        // pairs of each row and the gate rows -- is requested in ONE batch per level (a dependent chain per row cost more
+        // than the separate gather launch: 43 against 19 + 16 us for the gated transposed gather).
+        constexpr int NR = 2 * NI;
+        unsigned code[NR];
+        int re0[NR], re1[NR];
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int m = m0 + it * 16 + (tid >> 4);
+            const bool live = m < g.M && st_cols;
+            code[it] = (ga_mode == 1 && g.ga_band && live) ? g.ga_band[m] : 0xFFu;
+            re0[it] = re1[it] = 0;
+            if (live && code[it] == 0xFFu) {
+                re0[it] = g.ga_rowptr[m];
+                re1[it] = g.ga_rowptr[m + 1];
+            }
+        }
+        // (two pairs per row in the batch: a band row has at most three neighbours, the third and later ones are fetched in the
+        //  loop below; the batch must fit in the registers the accumulators left behind -- two workgroups share a CU)
+        constexpr int NE = 2;
+        int ec[NR][NE];
+        float ew[NR][NE];
+        uint4 gq[NR];
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int m = m0 + it * 16 + (tid >> 4);
+            const bool live = m < g.M && st_cols;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const bool has = re0[it] + u < re1[it];
+                ec[it][u] = has ? g.ga_col[re0[it] + u] : 0;
+                ew[it][u] = (has && ga_mode == 2) ? g.ga_wgt[re0[it] + u] : 1.f;
+            }
+            if (ga_mode == 2 && live && g.c_bf16)
+                gq[it] = *reinterpret_cast<const uint4*>((const bf16_t*)g.ga_gate + (long long)m * g.ga_ld + n);
+        }
+        __syncthreads();  // (the parked values of every thread are in place)
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int row = it * 16 + (tid >> 4), m = m0 + row;
+            if (m >= g.M || !st_cols) continue;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            auto add_row = [&](int lrow, float w) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lrow * 128 + (((2 * c8) ^ (lrow & 15)) << 2));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lrow * 128 + (((2 * c8 + 1) ^ (lrow & 15)) << 2));
+                acc[0] += w * lo[0]; acc[1] += w * lo[1]; acc[2] += w * lo[2]; acc[3] += w * lo[3];
+                acc[4] += w * hi[0]; acc[5] += w * hi[1]; acc[6] += w * hi[2]; acc[7] += w * hi[3];
+            };
+            int cnt;
+            if (code[it] != 0xFFu) {  // (mode 1 only)
+                if (code[it] & 1u) add_row(row - 1, 1.f);
+                if (code[it] & 2u) add_row(row, 1.f);
+                if (code[it] & 4u) add_row(row + 1, 1.f);
+                cnt = __popc(code[it] & 7u);
+            } else {
+                cnt = re1[it] - re0[it];
+#pragma unroll
+                for (int u = 0; u < NE; ++u)
+                    if (u < cnt) add_row(ec[it][u] - m0, ew[it][u]);
+                for (int e = re0[it] + NE; e < re1[it]; ++e) add_row(g.ga_col[e] - m0, ga_mode == 2 ? g.ga_wgt[e] : 1.f);
+            }
+            if (ga_mode == 1) {
+                const float mean_w = cnt ? 1.f / (float)cnt : 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] *= mean_w;
+            } else {
+                float gv[8];
+                if (g.c_bf16) {
+                    const unsigned rw[4] = {gq[it].x, gq[it].y, gq[it].z, gq[it].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        gv[2 * t] = __uint_as_float(rw[t] << 16);
+                        gv[2 * t + 1] = __uint_as_float(rw[t] & 0xffff0000u);
+                    }
+                } else {  // (exact-f32 mode: fetched here)
+                    const float* gp = (const float*)g.ga_gate + (long long)m * g.ga_ld + n;
+                    const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+                    gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = gv[t] > 0.f ? acc[t] : 0.f;
+            }
+            if (g.c_bf16) {
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
+                *reinterpret_cast<uint4*>((bf16_t*)g.ga_out + (long long)m * g.ga_ld + n) = pk;
+            } else {
+                float* op = (float*)g.ga_out + (long long)m * g.ga_ld + n;
+                *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
         }
     }
 }
@@ -697,7 +812,7 @@ struct OperandCursor {
 // MB = 2, KG = 1: 8 waves as 4 x 2 over a 256 x 128 tile, one workgroup per CU.  A CU takes in ~70 GB/s from L2
 //         whatever the kernel does (MI355X_MICROARCH.md, gather-into-LDS table), so bytes fetched per flop bound the
 //         rate: 48 KiB per K tile for 2 x the flops of the 32 KiB of a 128 x 128 tile.  For large outputs.
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false, bool GA = false>
 __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid) {
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
@@ -930,7 +1045,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     }
     if constexpr (KG == 1) {
         if constexpr (MB == 1) {
-            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
+            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, GA>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
             else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         } else {
             gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
@@ -982,9 +1097,9 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
 #endif
 }
 
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool GA = false>
 __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
-    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI>(g, blockIdx.x);
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, GA>(g, blockIdx.x);
 }
 
 // Grouped launch: up to MAX_GROUPS independent contractions of the SAME layout / element types / tile variant in one
@@ -1298,7 +1413,7 @@ __device__ __forceinline__ void read_step32(float (&f)[NF][4], unsigned st, unsi
 // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only) for outputs whose 128-row tiling
 // loads the CUs unevenly -- two co-resident workgroups share a CU's matrix pipes, so a launch takes as long as the rows on its
 // fullest CU: 6144 x 1024 is 384 tiles of 128 rows (2 x 128 rows on half of the CUs) but 512 tiles of 96 rows (2 x 96 everywhere).
-template <bool TRA, bool TRB, int NI = 4, bool VIRT = false>
+template <bool TRA, bool TRB, int NI = 4, bool VIRT = false, bool GA = false>
 __device__ __forceinline__ void gemm_pipe_f32_body(const GemmArgs& g, const int bid) {
     static_assert(NI == 4 || (NI == 3 && !TRA), "96-row tiles: row-major A");
     constexpr int IMG = 16384, IMG_A = NI * 4096, STAGE = IMG_A + IMG, KT = 32;
@@ -1428,13 +1543,13 @@ __device__ __forceinline__ void gemm_pipe_f32_body(const GemmArgs& g, const int 
             __syncthreads();
         }
     }
-    if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
+    if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, GA>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
     else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
 }
 
-template <bool TRA, bool TRB, int NI = 4>
+template <bool TRA, bool TRB, int NI = 4, bool GA = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs g) {
-    gemm_pipe_f32_body<TRA, TRB, NI>(g, blockIdx.x);
+    gemm_pipe_f32_body<TRA, TRB, NI, false, GA>(g, blockIdx.x);
 }
 
 // grouped launch of exact-f32 contractions (the weight gradients of the reference-precision step): XCD-packed placement
@@ -1544,6 +1659,10 @@ static void launch_layout(const egk_gemm_desc* d, dim3 grid, hipStream_t s, cons
 using namespace egk;
 
 static int g_use_pipe = 1;
+// fixed cost of the reduce launch behind a split-K contraction in the bf16 cost model below, in microseconds.  3.5 is the
+// stand-alone fit; inside a captured step every extra launch also pays a boundary on its queue (a one-lane kernel lasts ~4.7 us
+// in a replay) -- development knob egk_gemm_set_pipeline(400 + tenths of a microsecond).
+static double g_reduce_fixed_us = 3.5;
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
@@ -1587,11 +1706,19 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_group_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    // the instantiations with the row gather in the epilogue (96- and 64-row tiles, row-major A)
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 400) { g_reduce_fixed_us = (on - 400) * 0.1; return prev; }
     if (on >= 300) { g_group_packed = on - 300; return prev; }
     if (on >= 200) { g_rows_epilogue = on - 200; return prev; }
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
@@ -1639,7 +1766,7 @@ extern "C" int egk_gemm_splitk(int32_t M, int32_t N, int32_t K, int32_t compute)
     int best = 1;
     double best_cost = 6.5 + 0.45 * nkt;
     for (int s = 2; s <= 16 && tiles * s <= 256 && nkt / s >= 2; s *= 2) {
-        const double cost = 6.5 + 0.45 * cdiv(nkt, s) + 3.5 + 1.5 * s * mn;
+        const double cost = 6.5 + 0.45 * cdiv(nkt, s) + g_reduce_fixed_us + 1.5 * s * mn;
         if (cost < best_cost - 0.5) { best_cost = cost; best = s; }
     }
     return best;
@@ -1694,9 +1821,17 @@ static int fill_sources(const egk_gemm_desc* d, GemmArgs& g, int ea, int eb, Sou
     return 0;
 }
 
-static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks);
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather = nullptr);
 
 extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) { return gemm_core(stream, d, nullptr); }
+
+// 1 when the launch of ``d`` would run its ga_mode row gather in the epilogue (the 4-wave tile variants that write their tile out
+// through LDS, unsplit, every edge inside one tile: ga_tile_mask).  Nothing is launched.
+extern "C" int egk_gemm_gather_ok(const egk_gemm_desc* d) {
+    int blocks = 0, ok = 0;
+    const int rc = gemm_core(nullptr, d, &blocks, &ok);
+    return rc == 0 ? ok : 0;
+}
 
 // Number of per-tile partial blocks [blocks][st_nseg][2] a launch of ``d`` with st_mode != 0 writes to st_ws -- 0 when the
 // tile variant the policy picks for ``d`` cannot (the caller then runs the LayerNorm's own statistics pass).  Nothing is
@@ -1707,7 +1842,7 @@ extern "C" int egk_gemm_stats_blocks(const egk_gemm_desc* d) {
     return rc == 0 ? blocks : 0;
 }
 
-static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks) {
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather) {
     EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
     EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
     EGK_REQUIRE(d->compute == EGK_COMPUTE_F32 || d->compute == EGK_COMPUTE_BF16, "egk_gemm: bad compute type");
@@ -1754,7 +1889,16 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         EGK_REQUIRE(d->st_nseg >= 1 && d->st_nseg <= 16 && d->st_seg_ptr && (query_blocks || d->st_ws), "egk_gemm: st_* segments / workspace");
         EGK_REQUIRE(d->st_mode == 1 || (d->st_x && d->st_stats && d->st_w && d->st_b), "egk_gemm: st_mode 2 needs x, stats, w, b");
     }
+    g.ga_mode = d->ga_mode; g.ga_skip_c = d->ga_mode ? d->ga_skip_c : 0;
+    g.ga_rowptr = d->ga_rowptr; g.ga_col = d->ga_col; g.ga_wgt = d->ga_wgt; g.ga_band = d->ga_band;
+    g.ga_gate = d->ga_gate; g.ga_out = d->ga_out; g.ga_ld = d->ga_ld;
+    if (d->ga_mode) {
+        EGK_REQUIRE(d->ga_mode == 1 || d->ga_mode == 2, "egk_gemm: ga_mode must be 0, 1 or 2");
+        EGK_REQUIRE(d->ga_rowptr && d->ga_col && d->ga_out, "egk_gemm: ga_mode needs rowptr, col and an output");
+        EGK_REQUIRE(d->ga_mode == 1 || (d->ga_wgt && d->ga_gate), "egk_gemm: ga_mode 2 needs the edge weights and the gate tensor");
+    }
     if (query_blocks) *query_blocks = 0;
+    if (query_gather) *query_gather = 0;
     const long long K = src.k_total;
     const double flops = 2.0 * d->M * d->N * K;
     const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
@@ -1855,12 +1999,23 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         const bool st_ok = (variant == 2 || variant == 3 || variant == 4 || variant == 8 || variant == 11) && g.splitk == 1 &&
                            epilogue_rows_ok(g) && d->st_min_seg_rows >= tile_rows &&
                            (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % (g.c_bf16 ? 8 : 4) == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
+        // row gather in the epilogue: the same variants; every edge inside one tile of this height (ga_tile_mask bit 0 / 1 / 2 =
+        // 64 / 96 / 128 rows); whole 8-column groups of 16-byte aligned rows for the output and the gate
+        const int ga_bit = tile_rows == 64 ? 1 : 2;
+        const bool ga_ok = (variant == 8 || variant == 11) && g.splitk == 1 &&  // (96- / 64-row tiles: the 128-row ones have no registers to spare)
+                           epilogue_rows_ok(g) && (d->ga_tile_mask & ga_bit) && aligned16(d->ga_out) && d->ga_ld % (g.c_bf16 ? 8 : 4) == 0 &&
+                           (d->ga_mode != 2 || aligned16(d->ga_gate));
         if (query_blocks) {
             *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
+            if (query_gather) *query_gather = (d->ga_mode && ga_ok) ? 1 : 0;
             return 0;
         }
         if (d->st_mode && !st_ok) {
             set_error("egk_gemm: st_mode %d is not available for this launch (ask egk_gemm_stats_blocks first)", d->st_mode);
+            return EGK_EUNSUPPORTED;
+        }
+        if (d->ga_mode && !ga_ok) {
+            set_error("egk_gemm: ga_mode %d is not available for this launch (ask egk_gemm_gather_ok first)", d->ga_mode);
             return EGK_EUNSUPPORTED;
         }
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
@@ -1869,9 +2024,11 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         if (variant == 7) {                                                                                               \
             hipLaunchKernelGGL((gemm_big_kernel<TA, TB>), pgrid, dim3(512), 131072, s, g);                                \
         } else if (variant == 11) {                                                                                       \
-            hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);                \
+            if (d->ga_mode) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2, true>), pgrid, pblock, 2 * 24576, s, g); \
+            else hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);           \
         } else if (variant == 8) {                                                                                        \
-            hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);                \
+            if (d->ga_mode) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3, true>), pgrid, pblock, 2 * 28672, s, g); \
+            else hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);           \
         } else if (variant == 6)                                                                                          \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
         else if (variant == 5)                                                                                            \
@@ -1919,18 +2076,27 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         }
         const bool st_ok = g.splitk == 1 && epilogue_rows_ok(g) && d->st_min_seg_rows >= (r96 ? 96 : 128) &&
                            (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % 4 == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
+        const bool ga_ok = r96 && g.splitk == 1 && epilogue_rows_ok(g) && (d->ga_tile_mask & 2) && aligned16(d->ga_out) &&
+                           d->ga_ld % (g.c_bf16 ? 8 : 4) == 0 && (d->ga_mode != 2 || aligned16(d->ga_gate));
         if (query_blocks) {
             *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
+            if (query_gather) *query_gather = (d->ga_mode && ga_ok) ? 1 : 0;
             return 0;
         }
         if (d->st_mode && !st_ok) {
             set_error("egk_gemm: st_mode %d is not available for this launch (ask egk_gemm_stats_blocks first)", d->st_mode);
             return EGK_EUNSUPPORTED;
         }
+        if (d->ga_mode && !ga_ok) {
+            set_error("egk_gemm: ga_mode %d is not available for this launch (ask egk_gemm_gather_ok first)", d->ga_mode);
+            return EGK_EUNSUPPORTED;
+        }
         const dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk), pblock(NTHREADS);
         {
             ProfScope prof(KID_GEMM_F32_NN + layout, s, flops, bytes);
-            if (r96 && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false, 3>), pgrid, pblock, 2 * 28672, s, g);
+            if (r96 && d->ga_mode && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false, 3, true>), pgrid, pblock, 2 * 28672, s, g);
+            else if (r96 && d->ga_mode) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true, 3, true>), pgrid, pblock, 2 * 28672, s, g);
+            else if (r96 && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false, 3>), pgrid, pblock, 2 * 28672, s, g);
             else if (r96) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true, 3>), pgrid, pblock, 2 * 28672, s, g);
             else if (!d->transA && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false>), pgrid, pblock, 65536, s, g);
             else if (!d->transA && d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true>), pgrid, pblock, 65536, s, g);
@@ -1946,7 +2112,11 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         }
         return check_launch("egk_gemm");
     }
-    if (query_blocks) return 0;  // (the generic kernel has no statistics epilogue: 0 blocks)
+    if (query_blocks) return 0;  // (the generic kernel has no statistics / gather epilogue: 0 blocks, not ok)
+    if (d->ga_mode) {
+        set_error("egk_gemm: ga_mode %d is not available on the generic kernel (ask egk_gemm_gather_ok first)", d->ga_mode);
+        return EGK_EUNSUPPORTED;
+    }
     if (d->st_mode) {
         set_error("egk_gemm: st_mode %d is not available on the generic kernel (ask egk_gemm_stats_blocks first)", d->st_mode);
         return EGK_EUNSUPPORTED;
@@ -2002,6 +2172,8 @@ static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     g.ws = nullptr;
     g.dbias = d->dbias; g.ws_bias = nullptr;
     g.rows_epilogue = g_rows_epilogue;
+    g.ga_mode = 0; g.ga_skip_c = 0; g.ga_rowptr = nullptr; g.ga_col = nullptr; g.ga_wgt = nullptr; g.ga_band = nullptr;
+    g.ga_gate = nullptr; g.ga_out = nullptr; g.ga_ld = 0;
     g.st_mode = 0; g.st_nseg = 0; g.st_seg_ptr = nullptr; g.st_ws = nullptr; g.st_x = nullptr; g.st_ldx = 0;
     g.st_stats = nullptr; g.st_w = nullptr; g.st_b = nullptr; g.st_slope = 0.f;
     EGK_REQUIRE(d->st_mode == 0, "egk_gemm_grouped: no segment statistics in a grouped launch");

@@ -9,6 +9,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "rows1024.h"
 
 namespace egk {
 
@@ -300,6 +301,119 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
             csr_finish<NV, T>(acc, wgt, 1.f / (float)(e1 - e0), gate, out, row, cols, vec, lane);
         }
         __syncthreads();
+    }
+}
+
+// ---- bf16 rows of 1024 columns (rows1024.h): the banded MEAN gather of the forward pass ---------------------------------------
+// RB rows per wave per sweep: their neighbour codes first (one byte each), then EVERY neighbour row of the sweep is requested
+// before the first is used.  Coded rows add {i - 1, i, i + 1} in ascending order, general rows (0xFF: the LTA forecast nodes)
+// walk their CSR entries in order -- the sums of csr_gather_kernel, bit for bit.  No listed heavy rows (host-checked).
+template <int RB>
+__global__ __launch_bounds__(256) void csr_gather_band_1k_kernel(const bf16_t* __restrict__ x, const int* __restrict__ rowptr,
+                                                                 const int* __restrict__ col, const unsigned char* __restrict__ band,
+                                                                 bf16_t* __restrict__ out, int rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + wave, W = gridDim.x * WPB;
+    for (int base = gw; base < rows; base += RB * W) {
+        unsigned code[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) code[k] = base + k * W < rows ? band[base + k * W] : 0u;
+        r1k::Raw nb[RB][3];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int row = base + k * W;
+            if (row < rows && code[k] != 0xFFu) {
+                const bf16_t* r0 = x + (long long)row * r1k::COLS;
+                if (code[k] & 1u) nb[k][0] = r1k::ld_raw(r0 - r1k::COLS, lane);
+                if (code[k] & 2u) nb[k][1] = r1k::ld_raw(r0, lane);
+                if (code[k] & 4u) nb[k][2] = r1k::ld_raw(r0 + r1k::COLS, lane);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int row = base + k * W;
+            if (row >= rows) break;
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            int cnt;
+            if (code[k] != 0xFFu) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (code[k] & (1u << q)) {
+                        float v[16];
+                        r1k::unpack(nb[k][q], v);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc[j] += 1.f * v[j];
+                    }
+                cnt = __popc(code[k] & 7u);
+            } else {
+                const int e0 = rowptr[row], e1 = rowptr[row + 1];
+                cnt = e1 - e0;
+                for (int e = e0; e < e1; e += 4) {  // 4 neighbour rows in flight, added in edge order
+                    r1k::Raw t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (e + u < e1) t[u] = r1k::ld_raw(x + (long long)col[e + u] * r1k::COLS, lane);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (e + u < e1) {
+                            float v[16];
+                            r1k::unpack(t[u], v);
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) acc[j] += 1.f * v[j];
+                        }
+                }
+            }
+            const float mean_w = cnt ? 1.f / (float)cnt : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] *= mean_w;
+            r1k::st_raw(out + (long long)row * r1k::COLS, lane, r1k::pack(acc));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// y = x + table[pos - pos_min] for bf16 rows of 1024 columns; positions outside the table are evaluated directly
+template <int RB>
+__global__ __launch_bounds__(256) void pe_add_table_1k_kernel(const bf16_t* __restrict__ x, const long long* __restrict__ pos,
+                                                              const float* __restrict__ freq, const float* __restrict__ table,
+                                                              long long pos_min, int n_pos, bf16_t* __restrict__ y, int rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + wave, W = gridDim.x * WPB;
+    for (int base = gw; base < rows; base += RB * W) {
+        r1k::Raw raw[RB];
+        long long pr[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k)
+            if (base + k * W < rows) {
+                raw[k] = r1k::ld_raw(x + (long long)(base + k * W) * r1k::COLS, lane);
+                pr[k] = pos[base + k * W];
+            }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int row = base + k * W;
+            if (row >= rows) break;
+            const long long ti = pr[k] - pos_min;
+            const bool hit = ti >= 0 && ti < n_pos;  // (wave-uniform)
+            float v[16], e[16];
+            r1k::unpack(raw[k], v);
+            if (hit) {
+                r1k::ld_vec16(table + ti * r1k::COLS, lane, e);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int cc = r1k::col_of(lane, j);
+                    const bool is_sin = cc < 512;
+                    const float a = (float)pr[k] * freq[is_sin ? cc : cc - 512];
+                    e[j] = is_sin ? sinf(a) : cosf(a);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] += e[j];
+            r1k::st_raw(y + (long long)row * r1k::COLS, lane, r1k::pack(v));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -780,6 +894,8 @@ static inline int row_grid(int rows) {
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
 }
+int g_graph_rows_v2 = 1;  // development knob (egk_tune 3, set from norm_ops.hip): the rows1024.h kernels of this file
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace egk
 
@@ -915,6 +1031,12 @@ int egk_pe_add_table(egk_stream_t stream, const void* x, const int64_t* pos, con
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_PE_ADD, s, 0, (dtype == EGK_BF16 ? 4.0 : 8.0) * rows * cols);
+    if (g_graph_rows_v2 && dtype == EGK_BF16 && cols == 1024 && al16(x) && al16(y) && al16(table)) {
+        const int g2 = cdiv(rows, 2 * WPB) > 1024 ? 1024 : cdiv(rows, 2 * WPB);
+        hipLaunchKernelGGL(pe_add_table_1k_kernel<2>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const long long*)pos, freq, table,
+                           (long long)pos_min, n_pos, (bf16_t*)y, rows);
+        return check_launch("egk_pe_add_table");
+    }
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(pe_add_table_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
                                              (const long long*)pos, freq, table, (long long)pos_min, n_pos, (T*)y, rows, cols));
     return check_launch("egk_pe_add_table");
@@ -934,6 +1056,12 @@ static int csr_gather_impl(egk_stream_t stream, const void* x, const int32_t* ro
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CSR_GATHER, s, 0, (dtype == EGK_BF16 ? 0.5 : 1.0) * (relu_gate ? 12.0 : 8.0) * rows * cols);
     EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
+    if (g_graph_rows_v2 && band && !wgt && !relu_gate && n_heavy == 0 && dtype == EGK_BF16 && cols == 1024 && al16(x) && al16(out)) {
+        EGK_REQUIRE(col, "egk_csr_gather_banded: null column indices");
+        const int g2 = cdiv(rows, 2 * WPB) > 1024 ? 1024 : cdiv(rows, 2 * WPB);
+        hipLaunchKernelGGL(csr_gather_band_1k_kernel<2>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, rowptr, col, band, (bf16_t*)out, rows);
+        return check_launch("egk_csr_gather");
+    }
     const int skip_above = n_heavy > 0 ? VERY_HEAVY : 0x7fffffff;
     const int in_launch = (n_heavy > 0 && heavy_mode == 1) ? n_heavy : 0;  // listed rows summed by one workgroup each, in the same launch
 #define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows) + in_launch), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above, heavy_rows, in_launch, band)

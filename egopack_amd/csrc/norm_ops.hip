@@ -804,6 +804,7 @@ static inline int nv_for(int cols) { return cols <= 256 ? 1 : cols <= 1024 ? 4 :
 // (8 KB against a 2 KB bf16 row) and, in the graph LayerNorm, re-reduces the statistics partials, so a wave should walk
 // >= 2 rows; in-step A/B of the headline workload, 200 steps x 3 rounds: 2048 -> 1.637, 512 -> 1.626, 768 -> 1.612 ms
 static int g_cap_partial = 512, g_cap_wide = 768;
+extern int g_graph_rows_v2;  // (graph_ops.hip)
 static inline int row_grid(int rows) {  // kernels that emit per-workgroup partial rows: two workgroups per CU
     int g = cdiv(rows, WPB);
     return g < 1 ? 1 : (g > g_cap_partial ? g_cap_partial : g);
@@ -836,6 +837,7 @@ extern "C" {
 int egk_tune(int32_t key, int32_t value) {
     if (key == 1) { const int p = g_cap_partial; g_cap_partial = value; return p; }
     if (key == 2) { const int p = g_cap_wide; g_cap_wide = value; return p; }
+    if (key == 3) { const int p = g_graph_rows_v2; g_graph_rows_v2 = value; return p; }  // graph_ops.hip: the rows1024.h kernels
     return -1;
 }
 

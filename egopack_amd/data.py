@@ -111,17 +111,42 @@ class CSRGraph:
     # i - 1, bit 1: i, bit 2: i + 1), 0xFF for any other row -- egk_csr_gather_banded reads the neighbours of a coded row
     # without fetching rowptr / col (a radius-1 temporal graph is banded everywhere but at the LTA forecast nodes)
     band: Optional[torch.Tensor] = None
+    # bit 0 / 1 / 2: no edge crosses a multiple of 64 / 96 / 128 rows (``tile_locality_mask``) -- a contraction whose output
+    # tiles are that high can then aggregate the neighbours of its own result inside its epilogue (egk_gemm_desc.ga_*).
+    # Sequences of 32 nodes collated back to back never cross any of them.
+    tile_mask: int = 0
 
     def _map(self, f):
         return CSRGraph(*(f(t) for t in (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)), self.num_nodes,
                         *(f(t) if t is not None else None for t in (self.heavy, self.t_heavy)), self.heavy_mode, self.t_heavy_mode,
-                        f(self.band) if self.band is not None else None)
+                        f(self.band) if self.band is not None else None, self.tile_mask)
 
     def to(self, device, non_blocking: bool = False):
         return self._map(lambda t: t.to(device, non_blocking=non_blocking))
 
     def pin_memory(self):
         return self._map(lambda t: t.pin_memory())
+
+
+TILE_HEIGHTS = (64, 96, 128)  # output-tile heights of the pipelined contraction (csrc/gemm.hip): bits of CSRGraph.tile_mask
+
+
+def tile_locality_mask(rowptr, col) -> int:
+    """Bit b is set when no edge of the by-target CSR (rowptr, col) joins two nodes on different sides of a multiple of
+    TILE_HEIGHTS[b] rows.  Host arrays only (a device-side CSR reports 0: nothing is fused)."""
+    if torch.is_tensor(rowptr):
+        if rowptr.device.type != "cpu":
+            return 0
+        rowptr, col = rowptr.numpy(), col.numpy()
+    rowptr, col = np.asarray(rowptr, dtype=np.int64), np.asarray(col, dtype=np.int64)
+    if col.size == 0:
+        return (1 << len(TILE_HEIGHTS)) - 1
+    row = np.repeat(np.arange(rowptr.size - 1, dtype=np.int64), np.diff(rowptr))
+    mask = 0
+    for b, h in enumerate(TILE_HEIGHTS):
+        if bool((row // h == col // h).all()):
+            mask |= 1 << b
+    return mask
 
 
 def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
@@ -143,7 +168,8 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
     t_heavy = torch.nonzero(deg_out > HEAVY_DEGREE).flatten().int()
     mode = lambda deg, listed: int(listed.numel() > 0 and int(deg.max()) <= HEAVY_IN_LAUNCH_DEGREE)
     return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes), heavy, t_heavy,
-                    mode(deg_in, heavy), mode(deg_out, t_heavy), band_codes(rowptr, col, num_nodes))
+                    mode(deg_in, heavy), mode(deg_out, t_heavy), band_codes(rowptr, col, num_nodes),
+                    tile_locality_mask(rowptr, col))
 
 
 def band_codes(rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int) -> torch.Tensor:
@@ -333,9 +359,10 @@ def concat_csr(graphs: Sequence[CSRGraph]) -> CSRGraph:
         return int(bool(with_rows) and all(m == 1 for m in with_rows))
     heavy, t_heavy = ids("heavy"), ids("t_heavy")
     band = torch.cat([g.band for g in graphs]) if all(g.band is not None for g in graphs) else None  # (codes are relative)
-    return CSRGraph(ptr("rowptr"), ids("col"), ptr("t_rowptr"), ids("t_col"), torch.cat([g.t_wgt for g in graphs]),
+    rowptr_all, col_all = ptr("rowptr"), ids("col")
+    return CSRGraph(rowptr_all, col_all, ptr("t_rowptr"), ids("t_col"), torch.cat([g.t_wgt for g in graphs]),
                     sum(g.num_nodes for g in graphs), heavy, t_heavy, mode([g.heavy for g in graphs], "heavy_mode"),
-                    mode([g.t_heavy for g in graphs], "t_heavy_mode"), band)
+                    mode([g.t_heavy for g in graphs], "t_heavy_mode"), band, tile_locality_mask(rowptr_all, col_all))
 
 
 class PinnedRing:
@@ -987,7 +1014,7 @@ class GraphTemplates:
         t_heavy, t_mode = listed(t["THV"], t["nth"], t["tdmax"])
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32))
         graph = CSRGraph(i32(rowptr), i32(col), i32(t_rowptr), i32(t_col), torch.from_numpy(np.ascontiguousarray(t_wgt)), B * T,
-                         heavy, t_heavy, mode, t_mode, torch.from_numpy(np.ascontiguousarray(band)))
+                         heavy, t_heavy, mode, t_mode, torch.from_numpy(np.ascontiguousarray(band)), tile_locality_mask(rowptr, col))
         out = (torch.from_numpy(np.ascontiguousarray(ei)), graph)
         if len(self._assembled) < 64:
             self._assembled[key] = out

@@ -315,7 +315,7 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
                transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-               dbias=None, into=None, stats=None):
+               dbias=None, into=None, stats=None, gather=None):
     """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array).  ``stats``: per-segment sums of
     the result for the graph LayerNorm that consumes it, taken in the epilogue (``_ln_stats_request``)."""
     op_dt = _dt(A1)
@@ -366,6 +366,12 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
             x = stats["x"]
             d.st_x, d.st_ldx, d.st_stats = _p(x), x.stride(0), _p(stats["stats"])
             d.st_w, d.st_b, d.st_slope = _p(stats["w"]), _p(stats["b"]), stats["slope"]
+    d.ga_mode = 0
+    if gather is not None:  # the neighbour aggregation of the result inside the epilogue (egk_gemm_desc.ga_*)
+        go = gather["out"]
+        d.ga_mode, d.ga_tile_mask, d.ga_skip_c = gather["mode"], gather["tile_mask"], int(gather.get("skip_c", False))
+        d.ga_rowptr, d.ga_col, d.ga_wgt = _p(gather["rowptr"]), _p(gather["col"]), _p(gather.get("wgt"))
+        d.ga_band, d.ga_gate, d.ga_out, d.ga_ld = _p(gather.get("band")), _p(gather.get("gate")), _p(go), go.stride(0)
     return d
 
 
@@ -513,6 +519,38 @@ def _gemm_with_stats(args, kw, stats):
     return ws, blocks
 
 
+# OPT-IN (EGK_ENABLE=gather_fusion).  Measured in round 4 on the headline step, same box, alternating: 1.474-1.477 ms with the
+# separate gather launches, 1.486-1.500 with the gathers in the epilogues -- the projection + gather pair took 33-35 us fused
+# against 25 + 12 separate, but the gated transposed gather 43-48 against 19 + 16: the epilogue's gather phase keeps a
+# workgroup's LDS and registers while its matrix pipes idle, and in backward the separate launch runs BESIDE weight-gradient
+# contractions that fill those pipes.  Kept behind the switch (and tested) as the measured alternative.
+_gather_fusion = {"on": "gather_fusion" in os.environ.get("EGK_ENABLE", "")}
+
+
+def gemm_with_gather(args, kw, gather, stats=None) -> bool:
+    """``gemm(*args, **kw)`` with the row gather ``gather`` of its result taken in the epilogue (egk_gemm_desc.ga_*) when the
+    tile variant of this launch can: True if it did (the gather's output is written; with ``skip_c`` the result itself is
+    not), False if nothing was launched (the caller runs the contraction and the gather launch).  No split-K."""
+    if not _gather_fusion["on"] or not gather.get("tile_mask"):
+        return False
+    lib = _lib.load()
+    d = _gemm_desc(*args, gather=gather, stats=stats, **kw)
+    if lib.egk_gemm_splitk(d.M, d.N, _desc_k(d), d.compute) > 1:
+        return False  # (a launch the policy would cut along K: its tiles are finished by the reduce launch)
+    if not lib.egk_gemm_gather_ok(C.byref(d)):
+        return False
+    if stats is not None:
+        blocks = lib.egk_gemm_stats_blocks(C.byref(d))
+        if blocks <= 0:
+            return False
+        ws = torch.empty(blocks * stats["n_seg"] * 2, dtype=torch.float64, device=args[7].device)
+        d.st_ws = _p(ws)
+        stats["result"] = (ws, blocks)
+    _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
+    _x3_release()
+    return True
+
+
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, **kw):
     lib = _lib.load()
     d = _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, **kw)
@@ -609,7 +647,7 @@ def _wgrad_launch(in_place: bool, tensors, launch, in_backward: bool = True):
     stream of the current stream; ``tensors`` are the temporaries it reads (kept alive for that stream).
     ``in_backward`` False: called from ``join_wgrad`` itself (possibly after backward has returned): no end-of-backward
     callback is installed, the caller joins right away."""
-    if not (_wgrad["enabled"] and in_place and tensors and tensors[0].is_cuda):
+    if not (_wgrad["enabled"] and in_place and tensors and tensors[0].is_cuda) or _wq_sched["mode"] == "inline":
         launch()
         return
     main = torch.cuda.current_stream()
@@ -652,6 +690,37 @@ _wq = {"on": False, "items": [], "tiles": 0, "hold": [], "extra": []}
 WGRAD_GROUP_COUNT = int(os.environ.get("EGK_WGRAD_COUNT", "6"))
 WGRAD_GROUP_TILES = 64 * WGRAD_GROUP_COUNT
 F32_WGRAD_GROUP_COUNT = int(os.environ.get("EGK_F32_WGRAD_COUNT", "8"))  # (development knob, as EGK_WGRAD_COUNT)
+
+
+# WHEN parked weight gradients are issued (development knob EGK_WGRAD_SCHED, A/B of the backward schedule):
+#   free   (default) a full group goes to the side stream as soon as it is full and runs beside whatever the dX chain does next
+#   rows   what is parked is issued right before a backward ROW kernel (graph / row LayerNorm backward) and JOINED behind it:
+#          the matrix-bound weight gradients then overlap the memory-bound row kernels only, never the chain's contractions
+#          (two matrix-bound launches side by side each slow down by more than they overlap: VERDICT r3 timeline, a 38 us dX
+#          contraction took 132 us beside a 184 us grouped weight-gradient launch)
+#   inline every group is issued on the backward stream itself (no side stream at all)
+# Measured (round 4, headline step, same box, three alternating rounds): free 1.474-1.477 ms, inline 1.598-1.604, rows
+# 1.774-1.782 -- letting the weight gradients run beside WHATEVER the chain does is worth 125 us against serialising them, and
+# a join behind every row kernel stalls the chain for the length of each group.
+_wq_sched = {"mode": os.environ.get("EGK_WGRAD_SCHED", "free")}
+
+
+def _rows_fork() -> bool:
+    """'rows' schedule: called right before a backward row kernel is launched on the backward stream."""
+    if _wq_sched["mode"] != "rows" or not (_wq["on"] and _wgrad["enabled"]) or not (_wq["items"] or _wq["extra"]) or _on_excluded_stream():
+        return False
+    flush_wgrad()  # (issued behind the row kernel's own launch: defer_after_next_launch)
+    return True
+
+
+def _rows_join(forked: bool) -> None:
+    if not forked:
+        return
+    drain_deferred(all_streams=False)
+    main = torch.cuda.current_stream()
+    side = wgrad_side_stream(main)
+    if side is not None:
+        main.wait_stream(side)
 
 
 def set_wgrad_grouping(on: bool) -> bool:
@@ -1492,8 +1561,10 @@ class _RowLN(torch.autograd.Function):
             # dw / db feed nothing but the optimizer: their reduction goes to the weight-gradient side stream, from a
             # workspace of its own (the shared one may be rewritten by the next launch of this stream)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            forked = _rows_fork()
             _ck(lib.egk_rowln_bwd(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(mean), _p(rstd), _p(mask), _p(dx), None, None,
                                   _p(ws), rows, cols, int(ctx.relu), ctx.p, _dt(x)), "egk_rowln_bwd")
+            _rows_join(forked)
             if _wq["on"] and _wgrad["enabled"]:
                 _wgrad_defer_reduce(ws, dw, db, rows, cols, 0)
             else:
@@ -1644,8 +1715,10 @@ class _GraphLN(torch.autograd.Function):
         if pre is not None and pre[2] == dy.data_ptr():
             # the segment sums came with the contraction that produced dy: ONE pass (dx + the dw / db partial rows)
             ws_col = torch.empty(lib.egk_rowln_bwd_ws_rows(rows) * 2 * cols, dtype=torch.float32, device=x.device)
+            forked = _rows_fork()
             _ck(lib.egk_graphln_bwd_apply(_stream(), _p(dy), _p(x), _p(w), _p(b), _p(stats), _p(dx), _p(seg_ptr), n_seg, rows,
                                           cols, ctx.eps, ctx.slope, _p(pre[0]), pre[1], _p(ws_col), _dt(x)), "egk_graphln_bwd_apply")
+            _rows_join(forked)
             if _ln_reduce_on_side(slot_w, slot_b, x):
                 if _wq["on"] and _wgrad["enabled"]:
                     _wgrad_defer_reduce(ws_col, dw, db, rows, cols, 0)
@@ -1814,7 +1887,7 @@ class _SageMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute, heavy=None, t_heavy=None,
-                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None, res_src=None, band=None):
+                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None, res_src=None, band=None, tile_mask=0):
         _need_gpu(h, Wp, Wl, Wr)
         lib = _lib.load()
         h = _c(h)
@@ -1822,10 +1895,15 @@ class _SageMean(torch.autograd.Function):
         dt = h.dtype
         Wp_o, Wl_o, Wr_o = weight_operand(Wp, dt), weight_operand(Wl, dt), weight_operand(Wr, dt)
         xp = torch.empty_like(h)
-        gemm(N, H, h, H, Wp_o, H, H, xp, H, bias=_f32c(bp), act=1, compute=compute)
         agg = torch.empty_like(h)
-        _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode, band)
-        ctx.t_heavy_mode = t_heavy_mode
+        # the mean over the in-neighbours of xp inside the projection's epilogue when no edge leaves an output tile (32-node
+        # sequences never do): the gather launch and its re-read of xp disappear
+        p_args, p_kw = (N, H, h, H, Wp_o, H, H, xp, H), dict(bias=_f32c(bp), act=1, compute=compute)
+        if not (tile_mask and gemm_with_gather(p_args, p_kw, dict(mode=1, tile_mask=tile_mask, rowptr=rowptr, col=col, band=band,
+                                                                    out=agg))):
+            gemm(*p_args, **p_kw)
+            _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode, band)
+        ctx.t_heavy_mode, ctx.tile_mask = t_heavy_mode, tile_mask
         Ho = Wl.shape[0]
         out = torch.empty((N, Ho), dtype=dt, device=h.device)
         c_args = (N, Ho, agg, H, Wl_o, H, H, out, Ho)
@@ -1884,9 +1962,14 @@ class _SageMean(torch.autograd.Function):
         else:
             _wgrad_launch(in_place, (g, agg, h), launch_out_grads)
         d_agg = torch.empty_like(h)
-        gemm(N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H, transB=True, compute=ctx.compute)
         d_pre = torch.empty_like(h)  # gradient at the projection's pre-activation: transposed gather gated by xp > 0
-        _csr_gather(d_agg, t_rowptr, t_col, t_wgt, xp, d_pre, t_heavy, ctx.t_heavy_mode)
+        a_args, a_kw = (N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H), dict(transB=True, compute=ctx.compute)
+        # ... inside the epilogue of the contraction that produces d_agg when no edge leaves an output tile (d_agg itself is
+        # then never stored: nothing else reads it)
+        if not (ctx.tile_mask and gemm_with_gather(a_args, a_kw, dict(mode=2, tile_mask=ctx.tile_mask, rowptr=t_rowptr, col=t_col,
+                                                                        wgt=t_wgt, gate=xp, out=d_pre, skip_c=True))):
+            gemm(*a_args, **a_kw)
+            _csr_gather(d_agg, t_rowptr, t_col, t_wgt, xp, d_pre, t_heavy, ctx.t_heavy_mode)
         d_h = None
         if ctx.needs_input_grad[0]:
             d_h = torch.empty_like(h)
@@ -1909,7 +1992,7 @@ class _SageMean(torch.autograd.Function):
             # the FIRST layer of the stack (its backward is the stack's last): what is parked goes out now, beside the temporal
             # pooling's backward chain -- the step's tail launch then holds the temporal pooling's weight gradients only
             flush_wgrad()
-        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
+        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_src=None):
@@ -1923,7 +2006,7 @@ def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_s
                            graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
                            _compute_for(h) if compute is None else compute, getattr(graph, "heavy", None),
                            getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0), getattr(graph, "t_heavy_mode", 0),
-                           ln_out, ln_in, res_src, getattr(graph, "band", None))
+                           ln_out, ln_in, res_src, getattr(graph, "band", None), int(getattr(graph, "tile_mask", 0) or 0))
 
 
 # ---- GraphONE gather-max ------------------------------------------------------------------------------

@@ -119,11 +119,31 @@ typedef struct egk_gemm_desc {
     const void* xA[4];
     const void* xB[4];
     int64_t xlda[4], xldb[4];
+    /* Row gather of the RESULT inside the epilogue (SAGEConv's neighbour aggregation, models/graph.py:42 via PyG
+     * SAGEConv.propagate: the launch that follows the projection forward, and the one that follows dX of lin_l backward):
+     *   ga_mode 1  ga_out[m] = mean over the CSR row m of C[ga_col[e]]   (C = relu(h Wp^T + bp); egk_csr_gather / _banded)
+     *   ga_mode 2  ga_out[m] = (ga_gate[m] > 0) ? sum over row m of ga_wgt[e] * C[ga_col[e]] : 0   (its backward: the transposed
+     *              gather with weights 1 / deg(target), gated by the projection's ReLU)
+     * in C's element type and leading dimension ga_ld, added in edge order -- the sums of the separate gather launch bit for
+     * bit -- from the tile the epilogue already holds in LDS, so the gather launch and its re-read of C disappear.  Only when
+     * every edge stays inside ONE output tile: the caller passes ga_tile_mask (bit 0 / 1 / 2: no edge crosses a multiple of
+     * 64 / 96 / 128 rows; 32-node sequences never do) and asks egk_gemm_gather_ok() first.  ga_band (uint8 [M], optional,
+     * mode 1): egk_csr_gather_banded's neighbour codes.  ga_skip_c: do not store C itself (mode 2: nothing else reads it). */
+    int32_t ga_mode, ga_tile_mask, ga_skip_c;
+    const int32_t* ga_rowptr;
+    const int32_t* ga_col;
+    const float* ga_wgt;
+    const uint8_t* ga_band;
+    const void* ga_gate;
+    void* ga_out;
+    int64_t ga_ld;
 } egk_gemm_desc;
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_stats_blocks(const egk_gemm_desc* d);
+/* 1 when the tile variant the policy picks for ``d`` can run its ga_mode gather in the epilogue (nothing is launched) */
+int egk_gemm_gather_ok(const egk_gemm_desc* d);
 /* HOST helper of the batch builders (runs on the CPU, touches no device): ``np.stack([rng.randint(h, size = n) for h in
  * high])`` of numpy's legacy RandomState on the generator's own state -- MT19937, mt_key[624] + *mt_pos as
  * ``RandomState.get_state()`` returns them, both advanced in place (per value: v = next_uint32 & mask until v <= high - 1; a

@@ -1400,3 +1400,125 @@ def test_adam_step_constants_are_computed_on_the_device_and_follow_lr_and_the_st
         opt.step_count += 1
         assert torch.equal(opt._hyper.cpu(), want(123458 + k, 1e-5, 0.125))
     assert int(opt._t_dev.item()) == opt.step_count == opt._t_mirror == 123460
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 4: the bf16 x 1024-column row kernels (csrc/rows1024.h) against the generic ones and against fp64
+# ---------------------------------------------------------------------------------------------------------
+class _rows_v2:
+    """``with _rows_v2(False):`` -- the generic row kernels (egk_tune 3)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        from egopack_amd import _lib
+        self.prev = _lib.load().egk_tune(3, 1 if self.on else 0)
+
+    def __exit__(self, *a):
+        from egopack_amd import _lib
+        _lib.load().egk_tune(3, self.prev)
+
+
+def test_rows1024_gather_and_positional_encoding_are_bit_identical_to_the_generic_kernels(ops):
+    """Banded mean gather (coded rows and general rows: LTA forecast nodes, isolated rows) and x + PE(pos) from the table on bf16
+    [N, 1024]: the same sums in the same order -- bit for bit."""
+    from egopack_amd import data as D
+    g = gen(4242)
+    parts, n = [], 0
+    for T in (32, 9, 1, 32, 5):
+        parts.append(D.radius_band_edges(torch.arange(T), 1) + n)
+        n += T
+    y = torch.stack([torch.randint(1, 5, (14,), generator=g), torch.randint(0, 5, (14,), generator=g)], 1)
+    y[:3] = -1
+    parts.append(D.lta_connectivity_edges(torch.arange(14), y, 1.5) + n)
+    n += 14 + 2  # + isolated rows
+    for rep in range(40):  # enough rows for several sweeps per wave
+        parts.append(D.radius_band_edges(torch.arange(32), 1) + n)
+        n += 32
+    ei = torch.cat(parts, 1)
+    graph = D.build_csr(ei, n).to(DEV)
+    assert (graph.band == 0xFF).any() and (graph.band == 5).any() and (graph.band == 0).any()
+    x = torch.randn(n, 1024, generator=g).to(DEV).to(BF)
+    outs = []
+    for v2 in (True, False):
+        with _rows_v2(v2):
+            o = torch.empty_like(x)
+            ops._csr_gather(x, graph.rowptr, graph.col, None, None, o, graph.heavy, graph.heavy_mode, band=graph.band)
+            outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    ref = P.scatter_mean(x.float().cpu()[ei[0]], ei[1], n)
+    torch.testing.assert_close(outs[0].float().cpu(), ref, **OUT16)
+    pos = (torch.arange(n) % 32 - 16).to(DEV)
+    freq = torch.logspace(0, 1, 512, 1e-4).to(DEV)
+    pes = []
+    for v2 in (True, False):
+        with _rows_v2(v2):
+            pes.append(ops.pe_add(x, pos, freq, (-16, 15)))
+            pes.append(ops.pe_add(x, pos, freq, (-4, 3)))  # most positions outside the table: evaluated directly
+    assert torch.equal(pes[0], pes[2]) and torch.equal(pes[1], pes[3]) and torch.equal(pes[0], pes[1])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("n_seq,T,lta", [(192, 32, False), (192, 32, True), (256, 32, True), (128, 48, False), (128, 32, False), (24, 256, False)])
+def test_sage_layer_with_the_gather_in_the_contraction_epilogue_is_bit_identical(ops, mode, n_seq, T, lta):
+    """SAGEConv(project=True, mean) forward and backward with the neighbour aggregation taken INSIDE the epilogue of the
+    contraction that produces its input (egk_gemm_desc.ga_mode 1: mean over in-neighbours of relu(h Wp^T + bp); ga_mode 2: the
+    gated transposed gather of d_agg, which is then never stored) against the separate gather launches: the same sums in the
+    same order -- every output and gradient bit for bit.  Band sequences and LTA sequences (general rows, the fan-out node's
+    31 out-edges), 96- and 128-row tiles, 48-node sequences (local to 96-row tiles only), and shapes where the fusion does not
+    apply (two-wave-group variant at 4096 rows; 256-node sequences cross every tile) and the call falls back by itself."""
+    from egopack_amd import data as D
+    from egopack_amd.models.layers import SAGEConv
+    g = gen(n_seq * T + lta)
+    H = 1024 if mode == "bf16" else 256
+    parts, n = [], 0
+    for i in range(n_seq):
+        if lta and i % 3 == 0:
+            y = torch.stack([torch.randint(1, 5, (T,), generator=g), torch.randint(0, 5, (T,), generator=g)], 1)
+            y[:T - 12] = -1
+            parts.append(D.lta_connectivity_edges(torch.arange(T), y, 1.5 if i % 2 else float(T)) + n)
+        else:
+            parts.append(D.radius_band_edges(torch.arange(T), 1) + n)
+        n += T
+    graph = D.build_csr(torch.cat(parts, 1), n)
+    expect_mask = {32: 7, 48: 2, 256: 0}[T]
+    assert graph.tile_mask == expect_mask
+    graph = graph.to(DEV)
+    torch.manual_seed(7)
+    conv = SAGEConv(H, H, project=True).to(DEV)
+    dt = BF if mode == "bf16" else torch.float32
+    h0 = torch.randn(n, H, generator=g).to(DEV).to(dt)
+    gy = torch.randn(n, H, generator=g).to(DEV).to(dt)
+    outs = {}
+    with ops.compute_mode(mode):
+        for fused in (True, False):
+            prev = ops._gather_fusion["on"]
+            ops._gather_fusion["on"] = fused
+            try:
+                h = h0.clone().requires_grad_(True)
+                for p in conv.parameters():
+                    p.grad = None
+                out = ops.sage_mean_layer(h, conv, graph)
+                out.backward(gy)
+                torch.cuda.synchronize()
+                outs[fused] = [out.detach().clone(), h.grad.clone(), *(p.grad.clone() for p in conv.parameters())]
+            finally:
+                ops._gather_fusion["on"] = prev
+    # Band-only batches: every row is summed in edge order by both paths -- bit for bit.  LTA batches have rows of 13 .. 24
+    # edges, which the separate gather launch sums cooperatively (edge e -> wave e % 4, partials combined in wave order:
+    # csr_gather_kernel's HEAVY rows) while the epilogue adds them in edge order, the order of the reference's scatter: those
+    # rows may differ by one rounding of the stored type, and so may what is downstream of them.
+    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
+        if not lta:
+            assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+        else:
+            scale = float(b.float().abs().max())
+            tol = (2.0 ** -6 if mode == "bf16" else 2.0 ** -18) * scale
+            assert float((a.float() - b.float()).abs().max()) <= tol, (i, float((a.float() - b.float()).abs().max()), scale)
+    # ... and the layer itself against the oracle's SAGEConv on the same (rounded) inputs
+    ei = torch.cat(parts, 1)
+    sd = {k: v.detach().float().cpu() for k, v in conv.state_dict().items()}
+    ref = P.sage_conv(h0.float().cpu(), ei, sd["lin_l.weight"], sd["lin_l.bias"], sd["lin_r.weight"], sd["lin.weight"], sd["lin.bias"],
+                      aggr="mean")
+    torch.testing.assert_close(outs[True][0].float().cpu(), ref, **(dict(rtol=3e-2, atol=3e-2) if mode == "bf16" else dict(rtol=2e-4, atol=2e-4)))

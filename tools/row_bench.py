@@ -16,6 +16,11 @@ if len(sys.argv) > 3:  # row_bench.py bf16 <cap_partial> <cap_wide>
     _lib.load().egk_tune(1, int(sys.argv[2]))
     _lib.load().egk_tune(2, int(sys.argv[3]))
     print("caps", sys.argv[2], sys.argv[3])
+import os
+if os.environ.get("EGK_ROWS_V2") is not None:  # EGK_ROWS_V2=0: the generic row kernels (egk_tune 3)
+    from egopack_amd import _lib
+    _lib.load().egk_tune(3, int(os.environ["EGK_ROWS_V2"]))
+    print("rows v2", os.environ["EGK_ROWS_V2"])
 x = torch.randn(N, H, device=dev).to(dt)
 g = torch.randn(N, H, device=dev).to(dt)
 w, b = torch.randn(H, device=dev), torch.randn(H, device=dev)
