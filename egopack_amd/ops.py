@@ -509,6 +509,13 @@ def _gemm_with_stats(args, kw, stats):
     lib = _lib.load()
     d = _gemm_desc(*args, stats=stats, **kw)
     blocks = lib.egk_gemm_stats_blocks(C.byref(d))
+    if blocks > 0 and d.n_extra and "x3_stats_split" not in os.environ.get("EGK_DISABLE", ""):
+        # a three-product contraction (six K sources for a SAGE layer's two-source launch: K = 6144 at H = 1024) of a batch
+        # that fills half the chip: the statistics epilogue needs the finished tile, i.e. NO split-K -- 87 us for 2048 x 1024
+        # on one workgroup per CU.  When the policy would cut the walk, the cut launch + its reduce + the LayerNorm's own
+        # statistics pass are the cheaper chain (the precise pass of the EgoPack step sits on the step's critical path).
+        if lib.egk_gemm_splitk(d.M, d.N, _desc_k(d), d.compute) > 1:
+            blocks = 0
     if blocks <= 0:
         gemm(*args, **kw)
         return None
