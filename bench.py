@@ -319,7 +319,7 @@ def parse_args(argv=None):
                          "launches (the default path: two real rank processes have run it); 'one' = ONE hipGraph that also holds the "
                          "collectives and the per-chunk Adam launches (faster, has only met a 1-rank group); 'auto' = 'one' if a "
                          "pre-flight CHILD process per rank captured and replayed it with exit code 0, else 'staged'")
-    ap.add_argument("--probe-timeout", type=float, default=300.0, help="seconds the pre-flight children of --exchange-graph auto may take")
+    ap.add_argument("--probe-timeout", type=float, default=240.0, help="seconds the pre-flight children of --exchange-graph auto may take")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)  # (this process IS a pre-flight child)
     ap.add_argument("--strict-capture", action="store_true",
                     help="fail instead of falling back (staged graphs -> one-piece graph -> eager) when a capture fails")
@@ -406,6 +406,9 @@ def one_graph_probe(args, argv, rank: int, world: int):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, str(Path(__file__).resolve()), *argv, "--probe-child", "--exchange-graph", "one", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline", "--no-roofline", "--no-f32-leg", "--strict-capture", "--min-timed-s", "0"]
+    if os.environ.get("EGK_TEST_PROBE_CMD"):  # (tests of the lock-step polling itself: a stand-in child, no GPU involved)
+        import shlex
+        cmd = shlex.split(os.environ["EGK_TEST_PROBE_CMD"])
     log = tempfile.NamedTemporaryFile("w+", prefix=f"egk_probe_r{rank}_", suffix=".log", delete=False)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=log)
     deadline = time.monotonic() + args.probe_timeout

@@ -59,6 +59,7 @@ SIGNATURES = {
     "egk_prof_get": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(i64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egk_stamp": (C.c_int, [vp, vp, i32]),
+    "egk_tee_split_next": (C.c_int, [vp, vp, i64]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
     "egk_gemm_stats_blocks": (C.c_int, [C.POINTER(GemmDesc)]),
     "egk_gemm_gather_ok": (C.c_int, [C.POINTER(GemmDesc)]),

@@ -198,6 +198,39 @@ __device__ __forceinline__ float ld1t(const bf16_t* p) { return bf2f(*p); }
 __device__ __forceinline__ void st1t(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1t(bf16_t* p, float v) { *p = f2bf(v); }
 
+// ---- split tee: the bf16 halves (hi = bf16(x), lo = bf16(x - hi): egk_split_bf16's arithmetic) of an f32 result, stored by
+// the kernel that produces it (egk_tee_split_next).  Row r of the result goes to hi / lo + r * ld.
+struct SplitTee {
+    bf16_t* hi;
+    bf16_t* lo;
+    long long ld;
+};
+__device__ __forceinline__ void tee4(const SplitTee& t, long long row, int c, int cols, bool vec, const float4& v) {
+    if (!t.lo) return;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h[k] = f2bf(x[k]);
+        l[k] = f2bf(x[k] - bf2f(h[k]));
+    }
+    bf16_t* hp = t.hi + row * t.ld + c;
+    bf16_t* lp = t.lo + row * t.ld + c;
+    if (vec && c + 4 <= cols && (t.ld & 3) == 0) {
+        *reinterpret_cast<uint2*>(hp) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2*>(lp) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    } else {
+        for (int k = 0; k < 4 && c + k < cols; ++k) {
+            hp[k] = h[k];
+            lp[k] = l[k];
+        }
+    }
+}
+// the tee armed by egk_tee_split_next, handed to (and cleared by) the next row-kernel launcher; null pointers when none is armed
+SplitTee take_split_tee();
+bool split_tee_armed();
+void arm_split_tee(bf16_t* hi, bf16_t* lo, long long ld);
+
 // host-side dispatch on an EGK_F32 / EGK_BF16 activation type: ``using T = ...`` inside CALL
 #define EGK_DISPATCH_T(dtype, ...)                                               \
     do {                                                                         \

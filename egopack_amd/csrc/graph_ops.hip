@@ -22,7 +22,7 @@ constexpr int WPB = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void pe_add_kernel(const T* __restrict__ x, const long long* __restrict__ pos,
                                                      const float* __restrict__ freq, T* __restrict__ y, int rows,
-                                                     int cols) {
+                                                     int cols, const SplitTee tee) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
     const int half = cols >> 1;
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void pe_add_kernel(const T* __restrict__ x, co
             }
             v.x += e[0]; v.y += e[1]; v.z += e[2]; v.w += e[3];
             st4(yr, c, cols, vec, v);
+            tee4(tee, row, c, cols, vec, v);
         }
     }
 }
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) void pe_table_kernel(const float* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void pe_add_table_kernel(const T* __restrict__ x, const long long* __restrict__ pos,
                                                            const float* __restrict__ freq, const float* __restrict__ table,
-                                                           long long pos_min, int n_pos, T* __restrict__ y, int rows, int cols) {
+                                                           long long pos_min, int n_pos, T* __restrict__ y, int rows, int cols,
+                                                           const SplitTee tee) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
     const int half = cols >> 1;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256) void pe_add_table_kernel(const T* __restrict__
             }
             v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
             st4(yr, c, cols, vec, v);
+            tee4(tee, row, c, cols, vec, v);
         }
     }
 }
@@ -179,7 +182,8 @@ __device__ __forceinline__ void csr_accumulate(const T* __restrict__ x, const in
 
 template <int NV, typename T>
 __device__ __forceinline__ void csr_finish(float4 (&acc)[NV], const float* __restrict__ wgt, float mean_w, const T* __restrict__ gate,
-                                           T* __restrict__ out, int row, int cols, bool vec, int lane, long long stride = -1) {
+                                           T* __restrict__ out, int row, int cols, bool vec, int lane, long long stride = -1,
+                                           const SplitTee tee = SplitTee{nullptr, nullptr, 0}) {
     if (stride < 0) stride = cols;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -193,6 +197,7 @@ __device__ __forceinline__ void csr_finish(float4 (&acc)[NV], const float* __res
             acc[i].z = g.z > 0.f ? acc[i].z : 0.f; acc[i].w = g.w > 0.f ? acc[i].w : 0.f;
         }
         st4(out + (long long)row * stride, c, cols, vec, acc[i]);
+        tee4(tee, row, c, cols, vec, acc[i]);  // (a column slice hands in halves advanced by its first column)
     }
 }
 
@@ -201,7 +206,8 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
                                                          const int* __restrict__ col, const float* __restrict__ wgt,
                                                          const T* __restrict__ gate, T* __restrict__ out, int rows,
                                                          int cols, int skip_above, const int* __restrict__ block_rows,
-                                                         int n_block_rows, const unsigned char* __restrict__ band = nullptr) {
+                                                         int n_block_rows, const unsigned char* __restrict__ band = nullptr,
+                                                         const SplitTee tee = SplitTee{nullptr, nullptr, 0}) {
     extern __shared__ __attribute__((aligned(16))) float part[];  // [3][NV*256] partial rows of waves 1..3
     __shared__ int heavy[64];
     __shared__ int n_heavy;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
         for (int i = 0; i < NVW; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         csr_accumulate<NVW, T>(x + c0, col, wgt, e0, e1, 0, 1, cols - c0, vec, lane, acc, cols);
         csr_finish<NVW, T>(acc, wgt, e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f, gate ? gate + c0 : gate, out + c0, row, cols - c0, vec,
-                           lane, cols);
+                           lane, cols, SplitTee{tee.lo ? tee.hi + c0 : nullptr, tee.lo ? tee.lo + c0 : nullptr, tee.ld});
         return;
     }
     const int bid = blockIdx.x - n_block_rows, nblk = gridDim.x - n_block_rows;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
                     if (code & 4u) { acc[i].x += 1.f * vc[i].x; acc[i].y += 1.f * vc[i].y; acc[i].z += 1.f * vc[i].z; acc[i].w += 1.f * vc[i].w; }
                 }
                 const int cnt = __popc(code & 7u);
-                csr_finish<NV, T>(acc, nullptr, cnt ? 1.f / (float)cnt : 0.f, gate, out, row, cols, vec, lane);
+                csr_finish<NV, T>(acc, nullptr, cnt ? 1.f / (float)cnt : 0.f, gate, out, row, cols, vec, lane, -1, tee);
                 continue;
             }
         }
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         csr_accumulate<NV, T>(x, col, wgt, e0, e1, 0, 1, cols, vec, lane, acc);
-        csr_finish<NV, T>(acc, wgt, e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f, gate, out, row, cols, vec, lane);
+        csr_finish<NV, T>(acc, wgt, e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f, gate, out, row, cols, vec, lane, -1, tee);
     }
     __syncthreads();
     const int nh = min(n_heavy, 64);  // (a workgroup walks <= rows/grid rows: far fewer than 64 heavy ones)
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
                     const float4 p = *reinterpret_cast<const float4*>(part + wv * NV * 256 + (i * 64 + lane) * 4);
                     acc[i].x += p.x; acc[i].y += p.y; acc[i].z += p.z; acc[i].w += p.w;
                 }
-            csr_finish<NV, T>(acc, wgt, 1.f / (float)(e1 - e0), gate, out, row, cols, vec, lane);
+            csr_finish<NV, T>(acc, wgt, 1.f / (float)(e1 - e0), gate, out, row, cols, vec, lane, -1, tee);
         }
         __syncthreads();
     }
@@ -1009,8 +1015,10 @@ int egk_pe_add(egk_stream_t stream, const void* x, const int64_t* pos, const flo
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_PE_ADD, s, 0, (dtype == EGK_BF16 ? 4.0 : 8.0) * rows * cols);
+    const SplitTee tee = take_split_tee();
+    EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_pe_add: a split tee needs an f32 result");
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(pe_add_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
-                                             (const long long*)pos, freq, (T*)y, rows, cols));
+                                             (const long long*)pos, freq, (T*)y, rows, cols, tee));
     return check_launch("egk_pe_add");
 }
 
@@ -1031,6 +1039,8 @@ int egk_pe_add_table(egk_stream_t stream, const void* x, const int64_t* pos, con
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_PE_ADD, s, 0, (dtype == EGK_BF16 ? 4.0 : 8.0) * rows * cols);
+    const SplitTee tee = take_split_tee();
+    EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_pe_add_table: a split tee needs an f32 result");
     if (g_graph_rows_v2 && dtype == EGK_BF16 && cols == 1024 && al16(x) && al16(y) && al16(table)) {
         const int g2 = cdiv(rows, 2 * WPB) > 1024 ? 1024 : cdiv(rows, 2 * WPB);
         hipLaunchKernelGGL(pe_add_table_1k_kernel<2>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const long long*)pos, freq, table,
@@ -1038,7 +1048,7 @@ int egk_pe_add_table(egk_stream_t stream, const void* x, const int64_t* pos, con
         return check_launch("egk_pe_add_table");
     }
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(pe_add_table_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
-                                             (const long long*)pos, freq, table, (long long)pos_min, n_pos, (T*)y, rows, cols));
+                                             (const long long*)pos, freq, table, (long long)pos_min, n_pos, (T*)y, rows, cols, tee));
     return check_launch("egk_pe_add_table");
 }
 
@@ -1064,7 +1074,10 @@ static int csr_gather_impl(egk_stream_t stream, const void* x, const int32_t* ro
     }
     const int skip_above = n_heavy > 0 ? VERY_HEAVY : 0x7fffffff;
     const int in_launch = (n_heavy > 0 && heavy_mode == 1) ? n_heavy : 0;  // listed rows summed by one workgroup each, in the same launch
-#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows) + in_launch), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above, heavy_rows, in_launch, band)
+    const SplitTee tee = take_split_tee();
+    EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_csr_gather: a split tee needs an f32 result");
+    EGK_REQUIRE(!tee.lo || n_heavy == 0 || in_launch, "egk_csr_gather: no split tee with rows finished by the split launches");
+#define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows) + in_launch), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above, heavy_rows, in_launch, band, tee)
     EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
 #undef EGK_CSR
     if (n_heavy > 0 && !in_launch) {

@@ -44,7 +44,8 @@ __device__ __forceinline__ void rowln_fwd_body(const T* __restrict__ x, const fl
                                                float* __restrict__ mean, float* __restrict__ rstd,
                                                uint8_t* __restrict__ mask, int row_begin, int rows, int cols, float eps, int relu,
                                                float p, uint64_t seed, uint64_t offset,
-                                               const uint64_t* __restrict__ dev_offset, int blk, int nblk) {
+                                               const uint64_t* __restrict__ dev_offset, int blk, int nblk,
+                                               const SplitTee tee = SplitTee{nullptr, nullptr, 0}) {
     if (dev_offset) offset += dev_offset[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
@@ -100,6 +101,10 @@ __device__ __forceinline__ void rowln_fwd_body(const T* __restrict__ x, const fl
             }
         }
         store_row<NV>(y + (long long)row * cols, cols, vec, lane, r);
+        if (tee.lo) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) tee4(tee, row, (i * 64 + lane) * 4, cols, vec, r.v[i]);
+        }
     }
 }
 
@@ -109,9 +114,9 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         uint8_t* __restrict__ mask, int rows, int cols, float eps, int relu,
                                                         float p, uint64_t seed, uint64_t offset,
-                                                        const uint64_t* __restrict__ dev_offset) {
+                                                        const uint64_t* __restrict__ dev_offset, const SplitTee tee) {
     rowln_fwd_body<NV, T, FULL>(x, w, b, y, mean, rstd, mask, 0, rows, cols, eps, relu, p, seed, offset, dev_offset, blockIdx.x,
-                                gridDim.x);
+                                gridDim.x, tee);
 }
 
 // Grouped row LayerNorm: up to LN_MAX_GROUPS consecutive row ranges of ONE [rows, cols] matrix, each with its own affine
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(256) void graphln_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ b, T* __restrict__ y,
                                                           float* __restrict__ stats, const int* __restrict__ seg_ptr,
                                                           int n_seg, int rows, int cols, float eps, float slope,
-                                                          const double* __restrict__ ws, int nblk_stats) {
+                                                          const double* __restrict__ ws, int nblk_stats, const SplitTee tee) {
     __shared__ float st[MAXSEG][2];
     graphln_finish_stats(ws, nblk_stats, seg_ptr, n_seg, cols, eps, st);
     if (blockIdx.x == 0 && threadIdx.x < n_seg * 2) stats[threadIdx.x] = st[threadIdx.x >> 1][threadIdx.x & 1];
@@ -474,6 +479,10 @@ __global__ __launch_bounds__(256) void graphln_fwd_kernel(const T* __restrict__ 
                 el(r.v[i], t) = o > 0.f ? o : o * slope;
             }
         store_row<NV>(y + (long long)row * cols, cols, vec, lane, r);
+        if (tee.lo) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) tee4(tee, row, (i * 64 + lane) * 4, cols, vec, r.v[i]);
+        }
     }
 }
 
@@ -877,8 +886,10 @@ int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const floa
     hipStream_t s = (hipStream_t)stream;
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
+    const SplitTee tee = take_split_tee();
+    EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_rowln_fwd: a split tee needs an f32 result");
     DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
-                                                 (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset));
+                                                 (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset, tee));
     return check_launch("egk_rowln_fwd");
 }
 
@@ -1021,8 +1032,10 @@ int egk_graphln_fwd(egk_stream_t stream, const void* x, const float* w, const fl
     }
     {
         ProfScope prof(KID_GRAPHLN_FWD, s, 0, 2 * eb * rows * cols);
+        const SplitTee tee = take_split_tee();
+        EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_graphln_fwd: a split tee needs an f32 result");
         DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
-                                                     (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)ws, grid));
+                                                     (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)ws, grid, tee));
     }
     return check_launch("egk_graphln_fwd");
 }
@@ -1039,8 +1052,10 @@ int egk_graphln_fwd_apply(egk_stream_t stream, const void* x, const float* w, co
     hipStream_t s = (hipStream_t)stream;
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     ProfScope prof(KID_GRAPHLN_FWD, s, 0, 2 * eb * rows * cols);
+    const SplitTee tee = take_split_tee();
+    EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_graphln_fwd_apply: a split tee needs an f32 result");
     DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
-                                                 (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)partials, n_partials));
+                                                 (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)partials, n_partials, tee));
     return check_launch("egk_graphln_fwd_apply");
 }
 

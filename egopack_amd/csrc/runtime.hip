@@ -10,6 +10,16 @@
 
 namespace egk {
 
+// one-shot split tee (egk_tee_split_next): per host thread, consumed by the next row-kernel launcher
+static thread_local SplitTee g_tee = {nullptr, nullptr, 0};
+void arm_split_tee(bf16_t* hi, bf16_t* lo, long long ld) { g_tee = SplitTee{hi, lo, ld}; }
+SplitTee take_split_tee() {
+    const SplitTee t = g_tee;
+    g_tee = SplitTee{nullptr, nullptr, 0};
+    return t;
+}
+bool split_tee_armed() { return g_tee.lo != nullptr; }
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {
@@ -226,6 +236,13 @@ int64_t egk_host_window_rows(uint32_t* mt_key, int32_t* mt_pos, const int64_t* f
 
 int egk_version(void) { return 100; }
 const char* egk_last_error(void) { return g_err; }
+
+int egk_tee_split_next(void* hi, void* lo, int64_t ld) {
+    EGK_REQUIRE((hi && lo && ld > 0) || (!hi && !lo), "egk_tee_split_next: both halves (8-byte aligned) and a row stride, or NULL, NULL to disarm");
+    EGK_REQUIRE(((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0, "egk_tee_split_next: halves must be 8-byte aligned");
+    egk::arm_split_tee((egk::bf16_t*)hi, (egk::bf16_t*)lo, (long long)ld);
+    return 0;
+}
 
 int egk_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);

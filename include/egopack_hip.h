@@ -48,6 +48,14 @@ int egk_prof_get(int id, char* name, int name_len, int64_t* launches, double* to
  * the stream reaches it -- phase boundaries of a captured step timed in place (tools/phase_stamps.py). */
 int egk_stamp(egk_stream_t s, uint64_t* buf, int32_t idx);
 
+/* One-shot "split tee" for the three-product contractions (egk_split_bf16's halves without its launch): the NEXT call, on this
+ * host thread, of egk_rowln_fwd, egk_graphln_fwd, egk_graphln_fwd_apply, egk_pe_add, egk_pe_add_table, egk_csr_gather or
+ * egk_csr_gather_banded -- with an f32 result [rows, cols] -- also stores hi = bf16(result) and lo = bf16(result - hi) to
+ * hi / lo + row * ld (8-byte aligned, ld >= cols), then the tee is disarmed.  The producers of every contraction operand of the
+ * forward-only precise pass (egopack_amd.engine.EgoPackStep.precise_aux_features; reference: the f32 activations of
+ * models/graph.py:53-63 feeding models/graphONE/graphONE.py:119-141) are exactly these row kernels.  NULL, NULL disarms. */
+int egk_tee_split_next(void* hi, void* lo, int64_t ld);
+
 /* ---- dense contractions (MFMA) ---------------------------------------------------------
  * C[M,N] = act(alpha * (op(A) . op(B)^T) + (accumulate ? C : 0) + bias[n]) + residual[m,n]
  * where the contraction runs over K = K1 + K2 with a two-source split:

@@ -231,3 +231,50 @@ def test_gloo_world2_sharded_update_equals_allreduce_then_full_adam():
     for p in procs:
         p.join(30)
     assert res == [(0, True), (1, True)]
+
+
+# ---- bench.py's pre-flight probe (--exchange-graph auto): the lock-step polling of the rank processes, with stand-in children ----
+def _probe_worker(rank, world, port, q, cmds, timeout):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import argparse
+    import time as _t
+    import bench
+    init_from_env(backend="gloo")
+    out = []
+    for cmd in cmds:
+        os.environ["EGK_TEST_PROBE_CMD"] = cmd[rank]
+        t0 = _t.monotonic()
+        ok, note = bench.one_graph_probe(argparse.Namespace(probe_timeout=timeout), [], rank, world)
+        out.append((bool(ok), note, round(_t.monotonic() - t0, 1)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gloo_world2_probe_verdict_is_the_same_on_every_rank():
+    """``bench.one_graph_probe``: every rank starts a child and the ranks poll in lock step over the gloo group.  Both children
+    exit 0 -> every rank takes the one-graph mode; ONE child fails (exit code 3 on rank 1) -> every rank takes the staged
+    graphs, at once; a child that hangs is killed at the timeout and counts as failed -- on both ranks, with the other rank's
+    (still running) child killed too."""
+    import sys
+    py = sys.executable
+    ok = f'{py} -c "import sys; sys.exit(0)"'
+    bad = f'{py} -c "import sys; sys.exit(3)"'
+    slow_ok = f'{py} -c "import time; time.sleep(1.5)"'
+    hang = f'{py} -c "import time; time.sleep(600)"'
+    cmds = [(ok, slow_ok), (slow_ok, bad), (hang, ok)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, 2, port, q, cmds, 4.0)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(30)
+    for r in (0, 1):
+        (ok1, note1, _), (ok2, note2, t2), (ok3, note3, t3) = res[r]
+        assert ok1 and note1 == "passed", res
+        assert not ok2 and ("exit code 3" in note2 or "another rank" in note2) and t2 < 3.5, res
+        assert not ok3 and ("timed out" in note3 or "another rank" in note3) and t3 < 8.0, res

@@ -21,6 +21,8 @@ dst = REPO / "profiles"
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
 dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "egopack_amd", "bench.py"], cwd=REPO, capture_output=True,
                             text=True).stdout.strip())
+if len(sys.argv) > 3:  # the commit the GPU run was taken at, when the tree has moved on since
+    commit, dirty = sys.argv[3], False
 meta = {"commit": commit + ("+uncommitted" if dirty else ""), "tag": tag,
         "date": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M UTC")}
 copied = []
