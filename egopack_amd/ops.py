@@ -503,6 +503,29 @@ def _x3_release():
         _x3["keep"] = []
 
 
+def _tee_arm(y: torch.Tensor):
+    """Inside a ``precise_scope``: arm the library's one-shot split tee (egk_tee_split_next) so that the row kernel launched
+    NEXT -- the producer of the f32 [rows, cols] activation ``y`` -- also stores y's bf16 halves: the contraction that reads y
+    then needs no egk_split_bf16 launch of its own (12 such launches sat on the precise pass's chain in BASELINE config 4).
+    -> the halves, for ``_tee_done`` right after the launch, or None (not in a scope, not an f32 matrix, switched off)."""
+    if (_x3["cache"] is None or _state["compute"] != X3 or y.dtype != torch.float32 or y.dim() != 2 or not y.is_contiguous()
+            or y.numel() == 0 or "x3_tee" in os.environ.get("EGK_DISABLE", "")):
+        return None
+    rows, cols = y.shape
+    hi = torch.empty((rows, cols), dtype=torch.bfloat16, device=y.device)
+    lo = torch.empty((rows, cols), dtype=torch.bfloat16, device=y.device)
+    rc = _lib.load().egk_tee_split_next(_p(hi), _p(lo), cols)  # (not through _ck: nothing may be launched in between)
+    if rc != 0:
+        raise RuntimeError(f"egk_tee_split_next failed (code {rc}): {_lib.last_error()}")
+    return hi, lo
+
+
+def _tee_done(y: torch.Tensor, halves) -> None:
+    if halves is not None:
+        rows, cols = y.shape
+        _x3["cache"][(y.data_ptr(), rows, cols, cols, y._version)] = (halves[0], halves[1], y)
+
+
 def _gemm_with_stats(args, kw, stats):
     """``gemm(*args, **kw)`` with the epilogue statistics ``stats`` if the tile variant of this launch can take them:
     returns (partials, blocks) or None (plain launch done instead).  No split-K (the statistics need the finished tile)."""
@@ -1541,9 +1564,12 @@ class _RowLN(torch.autograd.Function):
         mask = torch.empty((rows, cols), dtype=torch.uint8, device=x.device) if p_eff > 0 else None
         seed, off = _next_rng(rows * max(cols, 4096)) if p_eff > 0 else (0, 0)
         wc, bc = _f32c(w), _f32c(b)
+        dev_off = _p(rng_device_offset(x.device)) if p_eff > 0 else None
+        tee = _tee_arm(y)
         _ck(lib.egk_rowln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(mean), _p(rstd), _p(mask), rows, cols, eps,
-                              int(relu), p_eff, seed, off, _p(rng_device_offset(x.device)) if p_eff > 0 else None, _dt(x)),
+                              int(relu), p_eff, seed, off, dev_off, _dt(x)),
             "egk_rowln_fwd")
+        _tee_done(y, tee)
         ctx.relu, ctx.p = relu, p_eff
         ctx.params = (w, b)
         ctx.save_for_backward(x, wc, bc, mean, rstd, mask)
@@ -1677,12 +1703,16 @@ class _GraphLN(torch.autograd.Function):
                                           slope, _p(glob), 1, _dt(x)), "egk_graphln_fwd_apply")
             lnctx = None
         elif partials is not None:  # the segment sums came with the contraction that produced x
+            tee = _tee_arm(y)
             _ck(lib.egk_graphln_fwd_apply(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
                                           slope, _p(partials[0]), partials[1], _dt(x)), "egk_graphln_fwd_apply")
+            _tee_done(y, tee)
         else:
             ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
+            tee = _tee_arm(y)
             _ck(lib.egk_graphln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
                                     slope, _p(ws), _dt(x)), "egk_graphln_fwd")
+            _tee_done(y, tee)
         ctx.eps, ctx.slope = eps, slope
         ctx.params = (w, b)
         ctx.lnctx = lnctx
@@ -1816,11 +1846,14 @@ class _PEAdd(torch.autograd.Function):
         if 0 < n_pos <= 4096:
             fid = _pe_freq_id(freq)
             table = _pe_table(freq, fid, pos_range[0], n_pos, cols) if fid is not None else None
+        posc, fr = pos.contiguous(), _f32c(freq)
+        tee = _tee_arm(y)
         if table is not None:
-            _ck(lib.egk_pe_add_table(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(table), int(pos_range[0]), int(n_pos),
+            _ck(lib.egk_pe_add_table(_stream(), _p(x), _p(posc), _p(fr), _p(table), int(pos_range[0]), int(n_pos),
                                      _p(y), rows, cols, _dt(x)), "egk_pe_add_table")
         else:
-            _ck(lib.egk_pe_add(_stream(), _p(x), _p(pos.contiguous()), _p(_f32c(freq)), _p(y), rows, cols, _dt(x)), "egk_pe_add")
+            _ck(lib.egk_pe_add(_stream(), _p(x), _p(posc), _p(fr), _p(y), rows, cols, _dt(x)), "egk_pe_add")
+        _tee_done(y, tee)
         return y
 
     @staticmethod
@@ -1846,14 +1879,18 @@ def _csr_gather(x, rowptr, col, wgt, gate, out, heavy=None, heavy_mode=0, band=N
     rows, cols = x.shape
     nh = int(heavy.numel()) if heavy is not None else 0
     ws = workspace(lib.egk_csr_heavy_ws_bytes(nh, cols), x.device) if nh and not heavy_mode else None
+    # (the split tee: only when every row is finished inside the gather launch itself)
+    tee = _tee_arm(out) if (wgt is None and gate is None and (nh == 0 or heavy_mode)) else None
     if band is not None and wgt is None and gate is None and _banded["on"]:
         # forward mean aggregation: rows whose neighbours are {i - 1, i, i + 1} need no index fetch (data.band_codes)
         _ck(lib.egk_csr_gather_banded(_stream(), _p(x), _p(rowptr), _p(col), _p(band), _p(out), rows, cols, _dt(x),
                                       _p(heavy) if nh else None, nh, _p(ws) if ws is not None else None, int(heavy_mode)),
             "egk_csr_gather_banded")
+        _tee_done(out, tee)
         return
     _ck(lib.egk_csr_gather(_stream(), _p(x), _p(rowptr), _p(col), _p(wgt), _p(gate), _p(out), rows, cols, _dt(x),
                            _p(heavy) if nh else None, nh, _p(ws) if ws is not None else None, int(heavy_mode)), "egk_csr_gather")
+    _tee_done(out, tee)
 
 
 _banded = {"on": "banded_gather" not in os.environ.get("EGK_DISABLE", "")}  # development knob

@@ -233,3 +233,57 @@ def test_nearest_prototypes_in_bf16_mode_are_the_exact_lists(ops):
         assert safe.float().mean() > 0.97
         assert torch.equal(fast[safe], exact[safe]), dist
         assert float((fast == exact).float().mean()) > 0.999
+
+
+@pytest.mark.parametrize("cols", [1024, 250])
+def test_split_tee_stores_the_halves_of_the_split_launch(ops, cols, monkeypatch):
+    """egk_tee_split_next: inside a precise scope the row kernels that PRODUCE a contraction operand (row LayerNorm, graph
+    LayerNorm, positional-encoding add, mean gather) also store its bf16 halves -- bit for bit what egk_split_bf16 makes of
+    their f32 result -- so that the contraction needs no split launch; with EGK_DISABLE=x3_tee the same calls leave no halves
+    behind and the results are the same bits."""
+    from egopack_amd import data as D
+    g = gen(cols)
+    rows = 96
+    x = (torch.randn(rows, cols, generator=g) * 2).to(DEV)
+    w, b = torch.randn(cols, generator=g).to(DEV), torch.randn(cols, generator=g).to(DEV)
+    seg = torch.tensor([0, 40, rows], dtype=torch.int32, device=DEV)
+    ei = torch.cat([D.radius_band_edges(torch.arange(32), 1) + 32 * i for i in range(3)], 1)
+    graph = D.build_csr(ei, rows).to(DEV)
+    pos = (torch.arange(rows) % 32 - 16).to(DEV)
+    freq = P.positional_encoding_frequency(cols).to(DEV)
+    calls = {
+        "rowln": lambda: ops.row_layernorm(x, w, b, 1e-5, relu=True),
+        "graphln": lambda: ops.graph_layernorm_lrelu(x, w, b, seg, 1e-5, 0.2),
+        "pe": lambda: ops.pe_add(x, pos, freq, (-16, 15)),
+        "pe_direct": lambda: ops.pe_add(x, pos, freq),
+        "gather": lambda: ops.csr_mean_aggregate(x, graph),
+    }
+    for name, fn in calls.items():
+        outs = {}
+        for tee in (True, False):
+            if tee:
+                monkeypatch.delenv("EGK_DISABLE", raising=False)
+            else:
+                monkeypatch.setenv("EGK_DISABLE", "x3_tee")
+            with torch.no_grad(), ops.precise_scope():
+                y = fn()
+                key = (y.data_ptr(), rows, cols, cols, y._version)
+                hit = ops._x3["cache"].get(key)
+                assert (hit is not None) is tee, (name, tee)
+                hi, lo, ld = ops._x3_act(y, rows, cols, cols)  # (tee off: this is where the split launch happens)
+                outs[tee] = (y.clone(), hi.clone(), lo.clone())
+        torch.cuda.synchronize()
+        for a, b_ in zip(outs[True], outs[False]):
+            assert torch.equal(a, b_), name
+        y, hi, lo = outs[True]
+        assert torch.equal(hi, y.to(torch.bfloat16)) and torch.equal(lo, (y - hi.float()).to(torch.bfloat16)), name
+    monkeypatch.delenv("EGK_DISABLE", raising=False)
+    # outside a scope nothing is armed, and an armed tee refuses a bf16 result
+    y = ops.row_layernorm(x, w, b, 1e-5, relu=True)
+    assert ops._x3["cache"] is None
+    from egopack_amd import _lib
+    hi, lo = (torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    assert _lib.load().egk_tee_split_next(ops._p(hi), ops._p(lo), cols) == 0
+    with pytest.raises(RuntimeError, match="split tee"):
+        ops.row_layernorm(x.to(torch.bfloat16), w, b, 1e-5, relu=True)
+    assert _lib.load().egk_tee_split_next(None, None, 0) == 0
