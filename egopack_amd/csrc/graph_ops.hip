@@ -568,6 +568,66 @@ __global__ __launch_bounds__(256) void segmax_fwd_kernel(const T* __restrict__ x
     arg[(long long)sg * cols + c] = a;
 }
 
+// The same pool with the rows of a segment shared by four row lanes and four columns per thread: the thread-per-column walk
+// above is one dependent 2-byte load per row -- 94 us for the 256-node sequences of BASELINE config 5 ([16 x 256, 1024] in,
+// 16 rows out).  Workgroup = (segment, block of 256 columns); thread (cg = tid & 63, rl = tid >> 6) walks rows r0 + rl, r0 + rl
+// + 4, ... eight at a time for columns 4 cg .. 4 cg + 3; the four lanes meet through LDS: the larger value wins, on equal
+// values the SMALLER row -- the first occurrence, which is what the serial walk (strict >) keeps.  cols % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void segmax_fwd_v4_kernel(const T* __restrict__ x, const int* __restrict__ ptr,
+                                                            T* __restrict__ out, int* __restrict__ arg, int n_seg, int cols) {
+    __shared__ float sv[3][64][4];
+    __shared__ int sa[3][64][4];
+    const int sg = blockIdx.y, cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + cg * 4;
+    const bool live = c < cols;
+    const int r0 = ptr[sg], r1 = ptr[sg + 1];
+    float best[4] = {0.f, 0.f, 0.f, 0.f};  // empty segment -> 0 (scatter 'amax' into zeros, include_self=False)
+    int a[4] = {-1, -1, -1, -1};
+    if (live) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r + 4 * u < r1) v[u] = ld4t(x + (long long)(r + 4 * u) * cols, c, cols, true);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r + 4 * u < r1) {
+                    const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (a[t] < 0 || e[t] > best[t]) {
+                            best[t] = e[t];
+                            a[t] = r + 4 * u;
+                        }
+                }
+        }
+    }
+    if (rl > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sv[rl - 1][cg][t] = best[t];
+            sa[rl - 1][cg][t] = a[t];
+        }
+    }
+    __syncthreads();
+    if (rl == 0 && live) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = sv[q][cg][t];
+                const int av = sa[q][cg][t];
+                if (av >= 0 && (a[t] < 0 || v > best[t] || (v == best[t] && av < a[t]))) {
+                    best[t] = v;
+                    a[t] = av;
+                }
+            }
+        st4t(out + (long long)sg * cols, c, cols, true, make_float4(best[0], best[1], best[2], best[3]));
+        *reinterpret_cast<int4*>(arg + (long long)sg * cols + c) = make_int4(a[0], a[1], a[2], a[3]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ dout, const int* __restrict__ arg,
                                                          const int* __restrict__ ptr, T* __restrict__ dx, int n_seg,
@@ -1135,6 +1195,13 @@ int egk_segment_max_fwd(egk_stream_t stream, const void* x, const int32_t* ptr, 
     if (n_seg == 0 || cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_SEGMAX_FWD, s, 0, 0);
+    const int ebytes = dtype == EGK_BF16 ? 2 : 4;
+    if (cols % 4 == 0 && (reinterpret_cast<uintptr_t>(x) % (4 * ebytes)) == 0 && (reinterpret_cast<uintptr_t>(out) % (4 * ebytes)) == 0 &&
+        (reinterpret_cast<uintptr_t>(arg) & 15) == 0) {
+        EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_fwd_v4_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)x, ptr,
+                                                 (T*)out, arg, n_seg, cols));
+        return check_launch("egk_segment_max_fwd");
+    }
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_fwd_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)x, ptr,
                                              (T*)out, arg, n_seg, cols));
     return check_launch("egk_segment_max_fwd");

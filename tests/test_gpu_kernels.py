@@ -1522,3 +1522,34 @@ def test_sage_layer_with_the_gather_in_the_contraction_epilogue_is_bit_identical
     ref = P.sage_conv(h0.float().cpu(), ei, sd["lin_l.weight"], sd["lin_l.bias"], sd["lin_r.weight"], sd["lin.weight"], sd["lin.bias"],
                       aggr="mean")
     torch.testing.assert_close(outs[True][0].float().cpu(), ref, **(dict(rtol=3e-2, atol=3e-2) if mode == "bf16" else dict(rtol=2e-4, atol=2e-4)))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("lens,cols", [((256,) * 16, 1024), ((32,) * 64, 1024), ((1, 0, 7, 300, 33), 260), ((5, 9), 250)])
+def test_segment_max_rows_shared_by_four_lanes(ops, lens, cols, dt):
+    """The per-sequence max pool with a segment's rows shared by four row lanes (egk_segment_max_fwd; BASELINE config 5 pools
+    256-node sequences): values AND arg-max rows equal the serial first-occurrence rule -- ties (bf16 values repeat a lot at
+    T = 256) go to the smallest row -- empty segments give zeros / -1, widths that are not a multiple of 4 take the
+    thread-per-column kernel."""
+    g = gen(sum(lens) + cols)
+    n = sum(lens)
+    x = (torch.randn(n, cols, generator=g) * 0.5).to(dt)
+    x[torch.rand(n, cols, generator=g) < 0.3] = 0.25  # plenty of exact ties
+    ptr = torch.tensor([0, *torch.tensor(lens).cumsum(0).tolist()], dtype=torch.int32)
+    from egopack_amd import _lib
+    xd = x.to(DEV)
+    out = torch.empty(len(lens), cols, dtype=dt, device=DEV)
+    arg = torch.empty(len(lens), cols, dtype=torch.int32, device=DEV)
+    rc = _lib.load().egk_segment_max_fwd(ops._stream(), ops._p(xd), ops._p(ptr.to(DEV)), ops._p(out), ops._p(arg), len(lens), cols,
+                                         ops._dt(xd))
+    assert rc == 0, _lib.last_error()
+    ref_v = torch.zeros(len(lens), cols)
+    ref_a = torch.full((len(lens), cols), -1, dtype=torch.int32)
+    xf = x.float()
+    for s_, (a, b) in enumerate(zip(ptr[:-1].tolist(), ptr[1:].tolist())):
+        if b > a:
+            v, i = xf[a:b].max(dim=0)
+            first = (xf[a:b] == v).int().argmax(dim=0)  # first occurrence of the maximum
+            ref_v[s_], ref_a[s_] = v, (first + a).int()
+    assert torch.equal(out.float().cpu(), ref_v)
+    assert torch.equal(arg.cpu(), ref_a)
