@@ -159,7 +159,7 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=None, budget_s=20.0):
 
 # library profiler name -> kernel symbol (substring) in rocprofv3 output
 def _pipe(ta, tb, kg, ni=4):
-    return f"gemm_pipe_kernel<2, {ta}, {tb}, {kg}, 1, {ni}>"
+    return f"gemm_pipe_kernel<2, {ta}, {tb}, {kg}, 1, {ni}"  # (a prefix: later template arguments vary)
 
 
 ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pipe("false", "true", 1),

@@ -532,11 +532,14 @@ def _gemm_with_stats(args, kw, stats):
     lib = _lib.load()
     d = _gemm_desc(*args, stats=stats, **kw)
     blocks = lib.egk_gemm_stats_blocks(C.byref(d))
-    if blocks > 0 and d.n_extra and "x3_stats_split" not in os.environ.get("EGK_DISABLE", ""):
+    if blocks > 0 and d.n_extra and "x3_stats_split" in os.environ.get("EGK_ENABLE", ""):
         # a three-product contraction (six K sources for a SAGE layer's two-source launch: K = 6144 at H = 1024) of a batch
         # that fills half the chip: the statistics epilogue needs the finished tile, i.e. NO split-K -- 87 us for 2048 x 1024
         # on one workgroup per CU.  When the policy would cut the walk, the cut launch + its reduce + the LayerNorm's own
-        # statistics pass are the cheaper chain (the precise pass of the EgoPack step sits on the step's critical path).
+        # statistics pass are the cheaper chain (the precise pass of the EgoPack step sits on the step's critical path):
+        # config 4 3.70 -> 3.65 ms.  OPT-IN: the other summation order moves the auxiliary features by 1e-6, and with them
+        # WHICH near-ties of the OSCC head's max pool the block-wise parity test lands on (its d_features figure went from
+        # 1.7e-3 to 5.3e-3 against a bound of 5e-3: the same arithmetic, another draw) -- the bound stays, so the default does.
         if lib.egk_gemm_splitk(d.M, d.N, _desc_k(d), d.compute) > 1:
             blocks = 0
     if blocks <= 0:
