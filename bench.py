@@ -775,8 +775,6 @@ def main(argv=None):
         from egopack_amd import data as _D
         _D.HEAVY_IN_LAUNCH_DEGREE = 0
 
-    if os.environ.get("EGK_MAIN_PRIO"):  # (development: the whole step under a stream of this HIP priority; -1 = high)
-        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ["EGK_MAIN_PRIO"])))
     res = measure(args, rank, world, device, args.steps, args.warmup, min_timed_s=args.min_timed_s, group=data_group)
     ms = res["ms"]
     if args.probe_child:

@@ -690,8 +690,7 @@ def _wgrad_launch(in_place: bool, tensors, launch, in_backward: bool = True):
         return
     side = _wgrad["streams"].get(key)
     if side is None:
-        prio = int(os.environ.get("EGK_SIDE_PRIO", "0"))  # (development: HIP stream priority of the weight-gradient streams)
-        side = _wgrad["streams"][key] = torch.cuda.Stream(device=main.device, priority=prio)
+        side = _wgrad["streams"][key] = torch.cuda.Stream(device=main.device)
 
     def issue(ev):
         side.wait_event(ev)
