@@ -60,6 +60,11 @@ SIGNATURES = {
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egk_stamp": (C.c_int, [vp, vp, i32]),
     "egk_tee_split_next": (C.c_int, [vp, vp, i64]),
+    "egk_graph_plan_create": (C.c_int, [vp, i32, i32, vp]),
+    "egk_graph_plan_info": (C.c_int, [vp, vp, vp, vp, vp]),
+    "egk_graph_plan_segment": (C.c_int, [vp, i32, vp]),
+    "egk_graph_plan_launch": (C.c_int, [vp, vp]),
+    "egk_graph_plan_destroy": (None, [vp]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
     "egk_gemm_stats_blocks": (C.c_int, [C.POINTER(GemmDesc)]),
     "egk_gemm_gather_ok": (C.c_int, [C.POINTER(GemmDesc)]),

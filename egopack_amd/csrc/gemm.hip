@@ -817,7 +817,8 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
     // 128-row tiling leaves the CUs unevenly loaded (6144 x 1024: 384 tiles = 1.5 per CU; 512 tiles of 96 x 128 = 2)
-    static_assert(NI == 4 || ((NI == 3 || NI == 2) && !TRA && KG == 1 && MB == 1), "96- / 64-row tiles: row-major A, plain variant");
+    static_assert(NI == 4 || ((NI == 3 || NI == 2) && !TRA && MB == 1 && (KG == 1 || NI == 2)),
+                  "96- / 64-row tiles: row-major A; two wave groups with 64-row tiles only");
     constexpr int IMG = 16384, IMG_A = NI == 4 ? MB * IMG : NI * 4096, STAGE = IMG_A + IMG;
     constexpr int NPB = 4 / MB;        // B pieces per wave per tile
     constexpr int LOADS = NI + NPB;    // wave-instructions per wave per tile
@@ -1050,39 +1051,40 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
         } else {
             gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         }
-    } else if constexpr (NI == 4) {
-        // Exchange: group 0 finishes rows i = 0,1 of each wave tile, group 1 rows i = 2,3.  Each group parks the half
-        // it does not finish in LDS ([group][wave][i2][j][lane] f32x4, lane-contiguous 16-B stores), then adds the
+    } else if constexpr (NI == 4 || NI == 2) {
+        // Exchange: group 0 finishes the first NI / 2 row fragments of each wave tile, group 1 the others.  Each group parks
+        // the half it does not finish in LDS ([group][wave][i2][j][lane] f32x4, lane-contiguous 16-B stores), then adds the
         // other group's half to its own (a + b in either order: the same bits in both groups).
+        constexpr int HF = NI / 2;
         __syncthreads();  // all rings are dead
         f32x4* xch = reinterpret_cast<f32x4*>(lds);
-        f32x4* mine_out = xch + ((grp * 4 + w) * 8) * 64 + lane;
-        const f32x4* theirs = xch + (((1 - grp) * 4 + w) * 8) * 64 + lane;
-        f32x4 half[2][4];
+        f32x4* mine_out = xch + ((grp * 4 + w) * (HF * 4)) * 64 + lane;
+        const f32x4* theirs = xch + (((1 - grp) * 4 + w) * (HF * 4)) * 64 + lane;
+        f32x4 half[HF][4];
         if (grp == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < HF; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mine_out[(i * 4 + j) * 64] = acc[2 + i][j];
+                for (int j = 0; j < 4; ++j) mine_out[(i * 4 + j) * 64] = acc[HF + i][j];
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < HF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mine_out[(i * 4 + j) * 64] = acc[i][j];
         }
         __syncthreads();
         if (grp == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < HF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) half[i][j] = acc[i][j] + theirs[(i * 4 + j) * 64];
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < HF; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) half[i][j] = theirs[(i * 4 + j) * 64] + acc[2 + i][j];
+                for (int j = 0; j < 4; ++j) half[i][j] = theirs[(i * 4 + j) * 64] + acc[HF + i][j];
         }
-        gemm_epilogue<2, 4>(g, half, m0, n0, wm * 64 + grp * 32, wn * 64, lr, lg, z);
+        gemm_epilogue<HF, 4>(g, half, m0, n0, wm * 16 * NI + grp * 16 * HF, wn * 64, lr, lg, z);
     }
 #ifdef EGK_GEMM_STAMPS
     if (g.ws_bias != nullptr && g.dbias == nullptr && tid == 0) {  // (the host points ws_bias behind the slabs in this build)
@@ -1663,6 +1665,7 @@ static int g_use_pipe = 1;
 // stand-alone fit; inside a captured step every extra launch also pays a boundary on its queue (a one-lane kernel lasts ~4.7 us
 // in a replay) -- development knob egk_gemm_set_pipeline(400 + tenths of a microsecond).
 static double g_reduce_fixed_us = 3.5;
+static int g_wg2_rows64 = 0;        // development knob (egk_gemm_set_pipeline(500 / 501)): variant 12 inside the policy off / on
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
@@ -1706,6 +1709,8 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_group_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
     // the instantiations with the row gather in the epilogue (96- and 64-row tiles, row-major A)
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1718,6 +1723,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 500) { g_wg2_rows64 = on - 500; return prev; }
     if (on >= 400) { g_reduce_fixed_us = (on - 400) * 0.1; return prev; }
     if (on >= 300) { g_group_packed = on - 300; return prev; }
     if (on >= 200) { g_rows_epilogue = on - 200; return prev; }
@@ -1956,6 +1962,10 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                     // at most 128 tiles: 64-row tiles put one 4-wave workgroup on twice as many CUs instead of one
                     // 8-wave (two wave groups) workgroup on half of them (2048 x 1024 x 1024: 10.6 vs 12.4 us)
                     variant = 11;
+                    // ... and BOTH where the epilogue needs no finished tile in one wave group (no LayerNorm statistics, no row
+                    // gather): 64-row tiles on every CU, two wave groups per workgroup walking alternate K tiles -- the lone
+                    // 4-wave workgroup of (11) leaves its CU's DMA / LDS / matrix phases unoverlapped
+                    if (g_wg2_rows64 && !d->st_mode && !d->ga_mode && nkt_slab >= 8) variant = 12;
                 }
             }
             // large outputs with a long K walk: 256 x 256 tiles, one 8-wave workgroup per CU, when whole tiles fill at least
@@ -1967,13 +1977,14 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             if (g.splitk == 1 && !g.dbias && g.M % 256 == 0 && g.N % 256 == 0 && t256 >= 192 && K >= 3072 &&
                 10 * t256 >= 9 * 256 * ((t256 + 255) / 256))
                 variant = 7;
-        } else if ((variant == 8 || variant == 11) && d->transA) {
+        } else if ((variant == 8 || variant == 11 || variant == 12) && d->transA) {
             variant = 3;  // the forced variants exist for row-major A only
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
         }
         const int mb = variant == 6 ? 2 : 1;
-        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
+        if (variant == 12 && (d->st_mode || d->ga_mode)) variant = 11;  // (forced by the knob: the epilogue features win)
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : (variant == 11 || variant == 12) ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
         if (variant == 7) g.tiles_n = cdiv(g.N, 256);
 #ifdef EGK_GEMM_STAMPS
         if (variant != 7 && !g.dbias && d->ws) {
@@ -1995,7 +2006,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
 
         // segment statistics in the epilogue: the 4-wave variants that write their tile out through LDS in whole rows, unsplit,
         // and tiles that span at most two row segments
-        const int tile_rows = variant == 8 ? 96 : variant == 11 ? 64 : 128;
+        const int tile_rows = variant == 8 ? 96 : (variant == 11 || variant == 12) ? 64 : 128;
         const bool st_ok = (variant == 2 || variant == 3 || variant == 4 || variant == 8 || variant == 11) && g.splitk == 1 &&
                            epilogue_rows_ok(g) && d->st_min_seg_rows >= tile_rows &&
                            (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % (g.c_bf16 ? 8 : 4) == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
@@ -2023,6 +2034,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
     do {                                                                                                                  \
         if (variant == 7) {                                                                                               \
             hipLaunchKernelGGL((gemm_big_kernel<TA, TB>), pgrid, dim3(512), 131072, s, g);                                \
+        } else if (variant == 12) {                                                                                       \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 2, 1, 2>), pgrid, dim3(2 * NTHREADS), 4 * 24576, s, g);    \
         } else if (variant == 11) {                                                                                       \
             if (d->ga_mode) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2, true>), pgrid, pblock, 2 * 24576, s, g); \
             else hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);           \
@@ -2039,7 +2052,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
     } while (0)
         {
             ProfScope prof(variant == 7 ? KID_GEMM_BF16_NN_T256 + layout : variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
-                                       : (variant == 5 ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
+                                       : ((variant == 5 || variant == 12) ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);
             else if (d->transA && d->transB) EGK_PIPE(true, true);

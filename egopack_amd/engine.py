@@ -716,7 +716,8 @@ class StepBase:
         if self._use_stages():
             return self._capture_staged(batches, merged)
         fuse_adam = self.sync is None or self.sync.world <= 1
-        g = torch.cuda.CUDAGraph()
+        segmented = self._segmented_replay()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if segmented else torch.cuda.CUDAGraph()
         opt.sync_hyper_source()  # (the step constants are computed inside the graph from a device-side step counter)
         self._hyper_in_graph = False
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
@@ -783,6 +784,10 @@ class StepBase:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
+        if segmented:
+            from .graphexec import SegmentedGraph
+            import os
+            g = SegmentedGraph(g, max_streams=segmented, event_nodes="plan_event_nodes" in os.environ.get("EGK_ENABLE", ""))
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
@@ -1019,6 +1024,20 @@ class StepBase:
         self._graph, self._static_out, self._fuse_adam = gs, (total, vectors), False
         self._static_in = (batches, merged, self._stage_state, self._cuts)  # everything the graphs read stays alive
         return gs
+
+    # Replay through a plan of single-stream graphs (graphexec.SegmentedGraph) instead of the runtime's own replay of the
+    # captured graph: the number of streams of the plan, 0 = the runtime's replay.  EGK_ENABLE=segmented_replay[=N] /
+    # EGK_DISABLE=segmented_replay override the attribute.
+    segmented_replay = 0
+
+    def _segmented_replay(self) -> int:
+        import os
+        if "segmented_replay" in os.environ.get("EGK_DISABLE", ""):
+            return 0
+        for item in os.environ.get("EGK_ENABLE", "").split(","):
+            if item.startswith("segmented_replay"):
+                return int(item.split("=")[1]) if "=" in item else 4
+        return int(self.segmented_replay)
 
     def replay(self):
         """One training step from the captured graph(s)."""

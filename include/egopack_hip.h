@@ -48,6 +48,24 @@ int egk_prof_get(int id, char* name, int name_len, int64_t* launches, double* to
  * the stream reaches it -- phase boundaries of a captured step timed in place (tools/phase_stamps.py). */
 int egk_stamp(egk_stream_t s, uint64_t* buf, int32_t idx);
 
+/* ---- segmented replay of a captured step ---------------------------------------------------------------------------
+ * The reference steps eagerly (main_temporal.py:78-104, main_egopack.py:72-99: one Python call per op); this library's step is
+ * captured once and replayed.  The HIP runtime replays a captured graph that sits on ONE stream through a batch path (0.6 us of
+ * host time per node) but enqueues the nodes of any graph with a fork one by one, chain after chain in creation order (2.8-4.2
+ * us per node: a step of 330 short launches on four streams is bound by that for its first 1.4 ms).  A plan cuts the captured
+ * graph (hipGraph_t; kernel, memset, memcpy and empty nodes) into its maximal fork-free paths, builds one single-stream graph
+ * per path and replays them on up to max_streams streams with one event per edge that crosses streams: same nodes, same
+ * arguments, same edges -- bit-identical results.  The plan holds copies of the nodes' parameters, not the graph: the memory the
+ * nodes address (the capture's pool) must outlive it.  egk_graph_plan_launch enqueues on ``stream`` (+ the plan's own side
+ * streams, which start behind ``stream`` and are joined into it) and returns; not thread-safe per plan. */
+typedef struct egk_graph_plan egk_graph_plan;
+int egk_graph_plan_create(void* hip_graph, int32_t max_streams, int32_t event_nodes, egk_graph_plan** out);
+int egk_graph_plan_info(const egk_graph_plan* plan, int32_t* nodes, int32_t* segments, int32_t* streams, int32_t* cross_edges);
+/* desc[0..3] = number of nodes, stream index (0 = the launch stream), number of event waits, 1 if an event is recorded behind it */
+int egk_graph_plan_segment(const egk_graph_plan* plan, int32_t segment, int32_t* desc);
+int egk_graph_plan_launch(egk_graph_plan* plan, egk_stream_t stream);
+void egk_graph_plan_destroy(egk_graph_plan* plan);
+
 /* One-shot "split tee" for the three-product contractions (egk_split_bf16's halves without its launch): the NEXT call, on this
  * host thread, of egk_rowln_fwd, egk_graphln_fwd, egk_graphln_fwd_apply, egk_pe_add, egk_pe_add_table, egk_csr_gather or
  * egk_csr_gather_banded -- with an f32 result [rows, cols] -- also stores hi = bf16(result) and lo = bf16(result - hi) to

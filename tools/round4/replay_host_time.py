@@ -48,6 +48,11 @@ def main():
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    g = getattr(step, "_graph", None)
+    if hasattr(g, "segments"):
+        segs = g.segments()
+        print("plan:", g.info())
+        print("segments (nodes, stream, waits, records):", " ".join(f"{a}/{b}/{c}/{d}" for a, b, c, d in segs))
     print(f"workload {args.workload}: bench {res['ms']:.3f} ms/step; {n} replays back to back: host {t_host * 1e3:.3f} ms per call, "
           f"{t_all * 1e3:.3f} ms per step incl. the final wait; one replay alone: host call {1e3 * (t1 - t0):.3f} ms, done after {1e3 * (t2 - t0):.3f} ms")
 
