@@ -1665,6 +1665,7 @@ static int g_use_pipe = 1;
 // stand-alone fit; inside a captured step every extra launch also pays a boundary on its queue (a one-lane kernel lasts ~4.7 us
 // in a replay) -- development knob egk_gemm_set_pipeline(400 + tenths of a microsecond).
 static double g_reduce_fixed_us = 3.5;
+static int g_group_tt_pad_kb = 0;   // development knob (egk_gemm_set_pipeline(600 + KiB)): extra dynamic LDS of queued weight-gradient groups
 static int g_wg2_rows64 = 0;        // development knob (egk_gemm_set_pipeline(500 / 501)): variant 12 inside the policy off / on
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
@@ -1696,7 +1697,7 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1723,6 +1724,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
     if (on >= 500) { g_wg2_rows64 = on - 500; return prev; }
     if (on >= 400) { g_reduce_fixed_us = (on - 400) * 0.1; return prev; }
     if (on >= 300) { g_group_packed = on - 300; return prev; }
@@ -2283,8 +2285,16 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
 #define EGK_PIPE_G(TA, TB)                                                                                                  \
     do {                                                                                                                    \
         if (variant == 5) hipLaunchKernelGGL((gemm_pipe_group_kernel<2, TA, TB, 2, 1>), pgrid, dim3(2 * NTHREADS), 4 * 32768, s, gg); \
-        else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, gg);                \
+        else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768 + pad, s, gg);          \
     } while (0)
+    // (experiment) a weight-gradient group that runs BESIDE the backward chain may be held to one workgroup per CU by asking for
+    // more LDS than half a CU has: the chain's launches then always find registers and LDS on every CU
+    int pad = 0;
+    if (ta && tb && g_group_tt_pad_kb > 0) {
+        bool side = true;
+        for (int i = 0; i < count; ++i) side = side && gg.p[i].N <= 1024;
+        if (side) pad = g_group_tt_pad_kb * 1024;
+    }
     {
         ProfScope prof(KID_GEMM_BF16_GROUP_NN + layout, s, flops, bytes);  // (layout 0 nn, 1 nt, 2 tt)
         if (!ta && variant == 11) {

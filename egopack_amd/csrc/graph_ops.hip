@@ -380,6 +380,100 @@ __global__ __launch_bounds__(256) void csr_gather_band_1k_kernel(const bf16_t* _
     }
 }
 
+// ---- bf16 rows of 1024 columns: the general (weighted / gated) gather at <= 96 registers -------------------------------------
+// The backward pass's transposed gather (per-edge weights 1 / in-degree of the target, ReLU gate of the projection output) runs
+// BESIDE grouped weight-gradient launches whose two workgroups per CU leave 96 registers per SIMD lane: a row kernel that needs
+// more waits for a weight-gradient workgroup to retire (59.6 us instead of 16 for csr_gather_kernel<4> at 127 registers,
+// profiles/r04_c3_replay_timeline.txt).  This kernel stays under that line without spilling: a row is held as packed bf16
+// (rows1024.h) until it is added, at most four neighbour rows + the gate row are in flight per wave, the row's CSR bounds and
+// entries are wave-uniform (scalar) fetches, and every wave owns whole rows (one row per wave per sweep, grid = rows / 4).
+// Sums: edge order for every row that one wave sums (csr_gather_kernel's order for rows of <= HEAVY edges; rows of HEAVY + 1 ..
+// skip_above edges are summed in edge order here and by four cooperating waves there: equal to rounding); the listed rows
+// (> skip_above edges) are summed by one workgroup each, a quarter of the columns per wave, in edge order -- as there.
+template <bool WGT, bool GATE>
+__global__ __launch_bounds__(256, 5) void csr_gather_1k_kernel(const bf16_t* __restrict__ x, const int* __restrict__ rowptr,
+                                                               const int* __restrict__ col, const float* __restrict__ wgt,
+                                                               const bf16_t* __restrict__ gate, bf16_t* __restrict__ out, int rows,
+                                                               int skip_above, const int* __restrict__ block_rows, int n_block_rows) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.x < n_block_rows) {  // a listed row: wave w sums columns [256 w, 256 w + 256), 4 per lane, 8 rows in flight
+        const int row = block_rows[blockIdx.x];
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        const long long c = (long long)wave * 256 + lane * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int e = e0; e < e1; e += 8) {
+            uint2 v[8];
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e + u < e1) {
+                    v[u] = *reinterpret_cast<const uint2*>(x + (long long)col[e + u] * r1k::COLS + c);
+                    w[u] = WGT ? wgt[e + u] : 1.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e + u < e1) {
+                    a0 += w[u] * __uint_as_float(v[u].x << 16); a1 += w[u] * __uint_as_float(v[u].x & 0xffff0000u);
+                    a2 += w[u] * __uint_as_float(v[u].y << 16); a3 += w[u] * __uint_as_float(v[u].y & 0xffff0000u);
+                }
+        }
+        if (!WGT) {
+            const float mw = e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f;
+            a0 *= mw; a1 *= mw; a2 *= mw; a3 *= mw;
+        }
+        if (GATE) {
+            const uint2 gq = *reinterpret_cast<const uint2*>(gate + (long long)row * r1k::COLS + c);
+            a0 = __uint_as_float(gq.x << 16) > 0.f ? a0 : 0.f; a1 = __uint_as_float(gq.x & 0xffff0000u) > 0.f ? a1 : 0.f;
+            a2 = __uint_as_float(gq.y << 16) > 0.f ? a2 : 0.f; a3 = __uint_as_float(gq.y & 0xffff0000u) > 0.f ? a3 : 0.f;
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+        o.y = (unsigned)f2bf(a2) | ((unsigned)f2bf(a3) << 16);
+        *reinterpret_cast<uint2*>(out + (long long)row * r1k::COLS + c) = o;
+        return;
+    }
+    const int bid = blockIdx.x - n_block_rows, nblk = gridDim.x - n_block_rows;
+    for (int row = bid * WPB + wave; row < rows; row += nblk * WPB) {  // (row is wave-uniform: scalar fetches below)
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        if (e1 - e0 > skip_above) continue;  // listed by the host
+        r1k::Raw gt;
+        if (GATE) gt = r1k::ld_raw(gate + (long long)row * r1k::COLS, lane);
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int e = e0; e < e1; e += 4) {
+            r1k::Raw t[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < e1) {
+                    t[u] = r1k::ld_raw(x + (long long)col[e + u] * r1k::COLS, lane);
+                    w[u] = WGT ? wgt[e + u] : 1.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < e1) {
+                    float v[16];
+                    r1k::unpack(t[u], v);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[j] += w[u] * v[j];
+                }
+        }
+        if (!WGT) {
+            const float mw = e1 > e0 ? 1.f / (float)(e1 - e0) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] *= mw;
+        }
+        if (GATE) {
+            float gv[16];
+            r1k::unpack(gt, gv);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = gv[j] > 0.f ? acc[j] : 0.f;
+        }
+        r1k::st_raw(out + (long long)row * r1k::COLS, lane, r1k::pack(acc));
+    }
+}
+
 // y = x + table[pos - pos_min] for bf16 rows of 1024 columns; positions outside the table are evaluated directly
 template <int RB>
 __global__ __launch_bounds__(256) void pe_add_table_1k_kernel(const bf16_t* __restrict__ x, const long long* __restrict__ pos,
@@ -1134,6 +1228,15 @@ static int csr_gather_impl(egk_stream_t stream, const void* x, const int32_t* ro
     }
     const int skip_above = n_heavy > 0 ? VERY_HEAVY : 0x7fffffff;
     const int in_launch = (n_heavy > 0 && heavy_mode == 1) ? n_heavy : 0;  // listed rows summed by one workgroup each, in the same launch
+    if (g_graph_rows_v2 && !band && (n_heavy == 0 || in_launch) && !split_tee_armed() && dtype == EGK_BF16 && cols == 1024 && col &&
+        al16(x) && al16(out) && (!relu_gate || al16(relu_gate))) {
+        const int g1 = (cdiv(rows, WPB) > 2048 ? 2048 : cdiv(rows, WPB)) + in_launch;
+#define EGK_CSR1K(W, G) hipLaunchKernelGGL((csr_gather_1k_kernel<W, G>), dim3(g1), dim3(256), 0, s, (const bf16_t*)x, rowptr, col, wgt, (const bf16_t*)relu_gate, (bf16_t*)out, rows, skip_above, heavy_rows, in_launch)
+        if (wgt) { if (relu_gate) EGK_CSR1K(true, true); else EGK_CSR1K(true, false); }
+        else { if (relu_gate) EGK_CSR1K(false, true); else EGK_CSR1K(false, false); }
+#undef EGK_CSR1K
+        return check_launch("egk_csr_gather");
+    }
     const SplitTee tee = take_split_tee();
     EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_csr_gather: a split tee needs an f32 result");
     EGK_REQUIRE(!tee.lo || n_heavy == 0 || in_launch, "egk_csr_gather: no split tee with rows finished by the split launches");

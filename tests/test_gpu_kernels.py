@@ -1462,6 +1462,53 @@ def test_rows1024_gather_and_positional_encoding_are_bit_identical_to_the_generi
     assert torch.equal(pes[0], pes[2]) and torch.equal(pes[1], pes[3]) and torch.equal(pes[0], pes[1])
 
 
+@pytest.mark.parametrize("weighted,gated", [(True, True), (True, False), (False, True), (False, False)])
+def test_rows1024_general_gather_at_96_registers_against_the_generic_kernel(ops, weighted, gated):
+    """csr_gather_1k_kernel (bf16 [N, 1024], per-edge weights and / or a ReLU gate, no neighbour codes: the backward pass's
+    transposed gather) against csr_gather_kernel: rows that ONE wave sums in edge order there (<= 12 edges) and the listed rows
+    (> 24 edges, one workgroup each, in the launch) are equal bit for bit; rows of 13 .. 24 edges are summed by four cooperating
+    waves there and in edge order here -- equal to rounding, and both within bf16 output rounding of fp64."""
+    from egopack_amd import data as D
+    g = gen(77 + 2 * weighted + gated)
+    parts, n = [], 0
+    for rep in range(60):
+        T = 32
+        if rep % 4 == 0:  # an LTA sequence: forecast nodes fed by the last input nodes (fan-out rows in the transposed graph)
+            y = torch.stack([torch.randint(1, 5, (T,), generator=g), torch.randint(0, 5, (T,), generator=g)], 1)
+            y[:T - (20 if rep % 8 else 30)] = -1  # 20 forecast nodes behind a radius of 1.5, or 30 behind the whole sequence
+            parts.append(D.lta_connectivity_edges(torch.arange(T), y, 1.5 if rep % 8 else float(T)) + n)
+        else:
+            parts.append(D.radius_band_edges(torch.arange(T), 1) + n)
+        n += T
+    n += 3  # isolated rows
+    graph = D.build_csr(torch.cat(parts, 1), n).to(DEV)
+    deg = (graph.t_rowptr[1:] - graph.t_rowptr[:-1]).cpu()
+    assert (deg > 24).any() and ((deg > 12) & (deg <= 24)).any() and (deg == 0).any() and graph.t_heavy is not None
+    x = torch.randn(n, 1024, generator=g).to(DEV).to(BF)
+    gate = torch.randn(n, 1024, generator=g).to(DEV).to(BF) if gated else None
+    wgt = graph.t_wgt if weighted else None
+    outs = []
+    for v2 in (True, False):
+        with _rows_v2(v2):
+            o = torch.full_like(x, 7.0)
+            ops._csr_gather(x, graph.t_rowptr, graph.t_col, wgt, gate, o, graph.t_heavy, graph.t_heavy_mode)
+            outs.append(o)
+    one_wave = ((deg <= 12) | (deg > 24)).to(DEV)
+    assert torch.equal(outs[0][one_wave], outs[1][one_wave])
+    torch.testing.assert_close(outs[0].float(), outs[1].float(), rtol=1e-2, atol=1e-2)
+    xs, rp, cl = x.double().cpu(), graph.t_rowptr.cpu(), graph.t_col.cpu().long()
+    w = graph.t_wgt.double().cpu() if weighted else None
+    ref = torch.zeros(n, 1024, dtype=torch.float64)
+    for r in range(n):
+        e0, e1 = int(rp[r]), int(rp[r + 1])
+        if e1 > e0:
+            rows_ = xs[cl[e0:e1]]
+            ref[r] = (rows_ * w[e0:e1, None]).sum(0) if weighted else rows_.mean(0)
+    if gated:
+        ref = torch.where(gate.double().cpu() > 0, ref, torch.zeros_like(ref))
+    torch.testing.assert_close(outs[0].float().cpu(), ref.float(), **OUT16)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 @pytest.mark.parametrize("n_seq,T,lta", [(192, 32, False), (192, 32, True), (256, 32, True), (128, 48, False), (128, 32, False), (24, 256, False)])
 def test_sage_layer_with_the_gather_in_the_contraction_epilogue_is_bit_identical(ops, mode, n_seq, T, lta):
