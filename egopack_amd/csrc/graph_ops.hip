@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
 template <int RB>
 __global__ __launch_bounds__(256) void csr_gather_band_1k_kernel(const bf16_t* __restrict__ x, const int* __restrict__ rowptr,
                                                                  const int* __restrict__ col, const unsigned char* __restrict__ band,
-                                                                 bf16_t* __restrict__ out, int rows) {
+                                                                 bf16_t* __restrict__ out, int rows, int skip_above) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * WPB + wave, W = gridDim.x * WPB;
     for (int base = gw; base < rows; base += RB * W) {
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void csr_gather_band_1k_kernel(const bf16_t* _
             } else {
                 const int e0 = rowptr[row], e1 = rowptr[row + 1];
                 cnt = e1 - e0;
+                if (cnt > skip_above) continue;  // listed by the host: the split launches produce this row
                 for (int e = e0; e < e1; e += 4) {  // 4 neighbour rows in flight, added in edge order
                     r1k::Raw t[4];
 #pragma unroll
@@ -1220,28 +1221,32 @@ static int csr_gather_impl(egk_stream_t stream, const void* x, const int32_t* ro
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_CSR_GATHER, s, 0, (dtype == EGK_BF16 ? 0.5 : 1.0) * (relu_gate ? 12.0 : 8.0) * rows * cols);
     EGK_REQUIRE(cols <= 4096, "egk_csr_gather: rows wider than 4096 are unsupported");
-    if (g_graph_rows_v2 && band && !wgt && !relu_gate && n_heavy == 0 && dtype == EGK_BF16 && cols == 1024 && al16(x) && al16(out)) {
-        EGK_REQUIRE(col, "egk_csr_gather_banded: null column indices");
-        const int g2 = cdiv(rows, 2 * WPB) > 1024 ? 1024 : cdiv(rows, 2 * WPB);
-        hipLaunchKernelGGL(csr_gather_band_1k_kernel<2>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, rowptr, col, band, (bf16_t*)out, rows);
-        return check_launch("egk_csr_gather");
-    }
     const int skip_above = n_heavy > 0 ? VERY_HEAVY : 0x7fffffff;
     const int in_launch = (n_heavy > 0 && heavy_mode == 1) ? n_heavy : 0;  // listed rows summed by one workgroup each, in the same launch
-    if (g_graph_rows_v2 && !band && (n_heavy == 0 || in_launch) && !split_tee_armed() && dtype == EGK_BF16 && cols == 1024 && col &&
-        al16(x) && al16(out) && (!relu_gate || al16(relu_gate))) {
+    const bool lean_band = g_graph_rows_v2 && band && !wgt && !relu_gate && !in_launch && !split_tee_armed() && dtype == EGK_BF16 &&
+                           cols == 1024 && al16(x) && al16(out);
+    if (lean_band) {  // (listed rows are skipped and produced by the split launches below)
+        EGK_REQUIRE(col, "egk_csr_gather_banded: null column indices");
+        const int g2 = cdiv(rows, 2 * WPB) > 1024 ? 1024 : cdiv(rows, 2 * WPB);
+        hipLaunchKernelGGL(csr_gather_band_1k_kernel<2>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, rowptr, col, band, (bf16_t*)out, rows,
+                           skip_above);
+        if (n_heavy == 0) return check_launch("egk_csr_gather");
+    }
+    const bool lean = !lean_band && g_graph_rows_v2 && !band && !split_tee_armed() && dtype == EGK_BF16 && cols == 1024 && col && al16(x) &&
+                      al16(out) && (!relu_gate || al16(relu_gate));
+    if (lean) {  // (listed rows that are not summed in this launch are skipped by it and produced by the split launches below)
         const int g1 = (cdiv(rows, WPB) > 2048 ? 2048 : cdiv(rows, WPB)) + in_launch;
 #define EGK_CSR1K(W, G) hipLaunchKernelGGL((csr_gather_1k_kernel<W, G>), dim3(g1), dim3(256), 0, s, (const bf16_t*)x, rowptr, col, wgt, (const bf16_t*)relu_gate, (bf16_t*)out, rows, skip_above, heavy_rows, in_launch)
         if (wgt) { if (relu_gate) EGK_CSR1K(true, true); else EGK_CSR1K(true, false); }
         else { if (relu_gate) EGK_CSR1K(false, true); else EGK_CSR1K(false, false); }
 #undef EGK_CSR1K
-        return check_launch("egk_csr_gather");
+        if (n_heavy == 0 || in_launch) return check_launch("egk_csr_gather");
     }
-    const SplitTee tee = take_split_tee();
+    const SplitTee tee = (lean || lean_band) ? SplitTee{nullptr, nullptr, 0} : take_split_tee();
     EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_csr_gather: a split tee needs an f32 result");
     EGK_REQUIRE(!tee.lo || n_heavy == 0 || in_launch, "egk_csr_gather: no split tee with rows finished by the split launches");
 #define EGK_CSR(NVV) hipLaunchKernelGGL((csr_gather_kernel<NVV, T>), dim3(row_grid(rows) + in_launch), dim3(256), 3 * NVV * 256 * sizeof(float), s, (const T*)x, rowptr, col, wgt, (const T*)relu_gate, (T*)out, rows, cols, skip_above, heavy_rows, in_launch, band, tee)
-    EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
+    if (!lean && !lean_band) EGK_DISPATCH_T(dtype, { if (cols <= 256) EGK_CSR(1); else if (cols <= 1024) EGK_CSR(4); else EGK_CSR(16); });
 #undef EGK_CSR
     if (n_heavy > 0 && !in_launch) {
         EGK_DISPATCH_T(dtype, {

@@ -1452,6 +1452,24 @@ def test_rows1024_gather_and_positional_encoding_are_bit_identical_to_the_generi
     assert torch.equal(outs[0], outs[1])
     ref = P.scatter_mean(x.float().cpu()[ei[0]], ei[1], n)
     torch.testing.assert_close(outs[0].float().cpu(), ref, **OUT16)
+    # listed rows beyond the in-launch limit (a 256-node LTA sequence whose forecast nodes see every input node): the banded
+    # kernel skips them, the split launches produce them -- again the generic kernel's result, bit for bit
+    T2 = 256
+    y2 = torch.stack([torch.randint(1, 5, (T2,), generator=g), torch.randint(0, 5, (T2,), generator=g)], 1)
+    y2[:T2 - 100] = -1
+    ei2 = torch.cat([D.radius_band_edges(torch.arange(T2), 1), D.lta_connectivity_edges(torch.arange(T2), y2, float(T2)) + T2,
+                     D.radius_band_edges(torch.arange(T2), 1) + 2 * T2], 1)
+    g2 = D.build_csr(ei2, 3 * T2).to(DEV)
+    assert g2.heavy is not None and g2.heavy.numel() > 0 and g2.heavy_mode == 0
+    x2 = torch.randn(3 * T2, 1024, generator=g).to(DEV).to(BF)
+    o2 = []
+    for v2 in (True, False):
+        with _rows_v2(v2):
+            o = torch.full_like(x2, 3.0)
+            ops._csr_gather(x2, g2.rowptr, g2.col, None, None, o, g2.heavy, g2.heavy_mode, band=g2.band)
+            o2.append(o)
+    assert torch.equal(o2[0], o2[1])
+    torch.testing.assert_close(o2[0].float().cpu(), P.scatter_mean(x2.float().cpu()[ei2[0]], ei2[1], 3 * T2), **OUT16)
     pos = (torch.arange(n) % 32 - 16).to(DEV)
     freq = torch.logspace(0, 1, 512, 1e-4).to(DEV)
     pes = []
@@ -1462,8 +1480,9 @@ def test_rows1024_gather_and_positional_encoding_are_bit_identical_to_the_generi
     assert torch.equal(pes[0], pes[2]) and torch.equal(pes[1], pes[3]) and torch.equal(pes[0], pes[1])
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("weighted,gated", [(True, True), (True, False), (False, True), (False, False)])
-def test_rows1024_general_gather_at_96_registers_against_the_generic_kernel(ops, weighted, gated):
+def test_rows1024_general_gather_at_96_registers_against_the_generic_kernel(ops, weighted, gated, split):
     """csr_gather_1k_kernel (bf16 [N, 1024], per-edge weights and / or a ReLU gate, no neighbour codes: the backward pass's
     transposed gather) against csr_gather_kernel: rows that ONE wave sums in edge order there (<= 12 edges) and the listed rows
     (> 24 edges, one workgroup each, in the launch) are equal bit for bit; rows of 13 .. 24 edges are summed by four cooperating
@@ -1480,10 +1499,17 @@ def test_rows1024_general_gather_at_96_registers_against_the_generic_kernel(ops,
         else:
             parts.append(D.radius_band_edges(torch.arange(T), 1) + n)
         n += T
+    if split:  # listed rows beyond the in-launch limit (100 forecast nodes behind every input node): produced by the split launches
+        T2 = 256
+        y2 = torch.stack([torch.randint(1, 5, (T2,), generator=g), torch.randint(0, 5, (T2,), generator=g)], 1)
+        y2[:T2 - 100] = -1
+        parts.append(D.lta_connectivity_edges(torch.arange(T2), y2, float(T2)) + n)
+        n += T2
     n += 3  # isolated rows
     graph = D.build_csr(torch.cat(parts, 1), n).to(DEV)
     deg = (graph.t_rowptr[1:] - graph.t_rowptr[:-1]).cpu()
     assert (deg > 24).any() and ((deg > 12) & (deg <= 24)).any() and (deg == 0).any() and graph.t_heavy is not None
+    assert graph.t_heavy_mode == (0 if split else 1)
     x = torch.randn(n, 1024, generator=g).to(DEV).to(BF)
     gate = torch.randn(n, 1024, generator=g).to(DEV).to(BF) if gated else None
     wgt = graph.t_wgt if weighted else None
