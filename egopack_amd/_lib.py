@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("n_extra", i32), ("xK", i32 * 4), ("xA", vp * 4), ("xB", vp * 4), ("xlda", i64 * 4), ("xldb", i64 * 4),
         ("ga_mode", i32), ("ga_tile_mask", i32), ("ga_skip_c", i32), ("ga_rowptr", vp), ("ga_col", vp), ("ga_wgt", vp),
         ("ga_band", vp), ("ga_gate", vp), ("ga_out", vp), ("ga_ld", i64),
+        ("sk_tickets", vp),
     ]
 
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     "egk_graph_plan_destroy": (None, [vp]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
     "egk_gemm_stats_blocks": (C.c_int, [C.POINTER(GemmDesc)]),
+    "egk_gemm_splitk_in_launch": (C.c_int, [C.POINTER(GemmDesc)]),
     "egk_gemm_gather_ok": (C.c_int, [C.POINTER(GemmDesc)]),
     "egk_gemm_grouped": (C.c_int, [vp, C.POINTER(GemmDesc), i32]),
     "egk_gemm_ws_bytes": (i64, [C.POINTER(GemmDesc)]),

@@ -75,6 +75,8 @@ struct GemmArgs {
     const void* ga_gate;
     void* ga_out;
     long long ga_ld;
+    // split-K finished inside the launch (egk_gemm_desc.sk_tickets): one arrival counter per output tile, zero on entry and exit
+    int* sk_tickets;
 };
 
 // Workgroup -> (slab z, tile row, tile column) for a 1-D launch of tiles_m * tiles_n * splitk workgroups.
@@ -1099,9 +1101,99 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
 #endif
 }
 
+// The slab sum of four consecutive columns (slab order: bitwise reproducible) + the epilogue: gemm_splitk_reduce's vector path, and
+// the in-launch finish below.
+__device__ __forceinline__ void splitk_finish_group(const GemmArgs& g, int m, int n, long long total) {
+    const long long idx = (long long)m * g.N + n;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < g.splitk; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(g.ws + (long long)z * total + idx);
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    float o[4] = {s4.x * g.alpha, s4.y * g.alpha, s4.z * g.alpha, s4.w * g.alpha};
+    if (g.accumulate) {
+        const float4 c = *reinterpret_cast<const float4*>((const float*)g.C + (long long)m * g.ldc + n);
+        o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
+    }
+    if (g.bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] += g.bias[n + t];
+    }
+    if (g.act == EGK_ACT_RELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+    }
+    if (g.residual) {
+        if (g.r_bf16) {
+            const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)g.residual + (long long)m * g.ldr + n);
+            o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xffff0000u);
+            o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xffff0000u);
+        } else {
+            const float4 r = *reinterpret_cast<const float4*>((const float*)g.residual + (long long)m * g.ldr + n);
+            o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+        }
+    }
+    if (g.c_bf16) {
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+        *reinterpret_cast<uint2*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
+    } else {
+        *reinterpret_cast<float4*>((float*)g.C + (long long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Split-K finished INSIDE the launch: every workgroup has stored its slab tile; it takes a ticket of its output tile, and the
+// workgroup that takes the LAST one (all splitk slabs of the tile are in memory: release fence before the ticket, acquire fence
+// behind it) sums the slabs in slab order and applies the epilogue -- gemm_splitk_reduce's arithmetic, so the same bits whichever
+// workgroup arrives last -- and hands the ticket counter back at zero.  One launch and one launch boundary less per
+// contraction (a step of 2048-row sequences has ~60 of them on its chains: BASELINE config 4) -- and MEASURED SLOWER there
+// (4.50 ms against 3.62; 3.89 with the fences compiled out): the last workgroup of a tile sums S x 32-64 KiB alone, behind a
+// device-scope atomic and an L2 write-back, where the reduce launch uses the whole chip.  Opt-in (EGK_ENABLE=splitk_in_launch).
+template <int ROWS>
+__device__ __forceinline__ void splitk_finish_in_launch(const GemmArgs& g, int bid) {
+    // (no static LDS here: the contraction's fragment addressing XORs absolute LDS addresses and relies on the dynamic
+    //  array starting at LDS address 0; the ring is dead by now, its first word takes the flag)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    volatile int& is_last = *reinterpret_cast<volatile int*>(lds);
+    int z, tm, tn;
+    tile_of(g, bid, z, tm, tn);
+    __syncthreads();  // every thread's slab stores have left the CU (workgroup-scope release: the vector L1 writes through)
+    if (threadIdx.x == 0) {
+        __threadfence();  // device-scope release, ONCE per workgroup: the XCD's L2 writes its dirty lines back
+        int* t = g.sk_tickets + tm * g.tiles_n + tn;
+        const int prev = atomicAdd(t, 1);
+        is_last = prev == g.splitk - 1;
+        if (is_last) {
+            *t = 0;           // (nobody else touches this counter any more in this launch)
+            __threadfence();  // device-scope acquire: this CU's L1 and the XCD's L2 drop what they hold of the other slabs
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const int m0 = tm * ROWS, n0 = tn * BN;
+    const long long total = (long long)g.M * g.N;
+    for (int q = threadIdx.x; q < ROWS * (BN / 4); q += blockDim.x) {
+        const int m = m0 + (q >> 5), n = n0 + ((q & 31) << 2);
+        if (m < g.M && n < g.N) splitk_finish_group(g, m, n, total);
+    }
+    if (g.dbias && g.ws_bias && tn == 0) {
+        for (int r = threadIdx.x; r < ROWS; r += blockDim.x) {
+            const int m = m0 + r;
+            if (m >= g.M) continue;
+            float t = 0.f;
+            for (int zz = 0; zz < g.splitk; ++zz) t += g.ws_bias[(long long)zz * g.M + m];
+            g.dbias[m] += t;
+        }
+    }
+}
+
 template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool GA = false>
 __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
     gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, GA>(g, blockIdx.x);
+    if constexpr (!GA) {
+        if (g.sk_tickets != nullptr) splitk_finish_in_launch<32 * NI * MB>(g, blockIdx.x);  // (uniform; only with splitk > 1)
+    }
 }
 
 // Grouped launch: up to MAX_GROUPS independent contractions of the SAME layout / element types / tile variant in one
@@ -1582,43 +1674,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs g) {
         const long long groups = (long long)g.M * gpr;
         for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += (long long)gridDim.x * blockDim.x) {
             const int m = (int)(q / gpr), n = (int)(q - (long long)m * gpr) * 4;
-            const long long idx = (long long)m * g.N + n;
-            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int z = 0; z < g.splitk; ++z) {
-                const float4 v = *reinterpret_cast<const float4*>(g.ws + (long long)z * total + idx);
-                s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-            }
-            float o[4] = {s4.x * g.alpha, s4.y * g.alpha, s4.z * g.alpha, s4.w * g.alpha};
-            if (g.accumulate) {
-                const float4 c = *reinterpret_cast<const float4*>((const float*)g.C + (long long)m * g.ldc + n);
-                o[0] += c.x; o[1] += c.y; o[2] += c.z; o[3] += c.w;
-            }
-            if (g.bias) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] += g.bias[n + t];
-            }
-            if (g.act == EGK_ACT_RELU) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
-            }
-            if (g.residual) {
-                if (g.r_bf16) {
-                    const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)g.residual + (long long)m * g.ldr + n);
-                    o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xffff0000u);
-                    o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xffff0000u);
-                } else {
-                    const float4 r = *reinterpret_cast<const float4*>((const float*)g.residual + (long long)m * g.ldr + n);
-                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-                }
-            }
-            if (g.c_bf16) {
-                uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
-                *reinterpret_cast<uint2*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
-            } else {
-                *reinterpret_cast<float4*>((float*)g.C + (long long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-            }
+            splitk_finish_group(g, m, n, total);
         }
     } else {
         for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1666,6 +1722,7 @@ static int g_use_pipe = 1;
 // in a replay) -- development knob egk_gemm_set_pipeline(400 + tenths of a microsecond).
 static double g_reduce_fixed_us = 3.5;
 static int g_group_tt_pad_kb = 0;   // development knob (egk_gemm_set_pipeline(600 + KiB)): extra dynamic LDS of queued weight-gradient groups
+static int g_sk_in_launch = 1;      // development knob (egk_gemm_set_pipeline(700 / 701)): split-K finished inside the launch off / on
 static int g_wg2_rows64 = 0;        // development knob (egk_gemm_set_pipeline(500 / 501)): variant 12 inside the policy off / on
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
@@ -1724,6 +1781,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 700) { g_sk_in_launch = on - 700; return prev; }
     if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
     if (on >= 500) { g_wg2_rows64 = on - 500; return prev; }
     if (on >= 400) { g_reduce_fixed_us = (on - 400) * 0.1; return prev; }
@@ -1829,7 +1887,7 @@ static int fill_sources(const egk_gemm_desc* d, GemmArgs& g, int ea, int eb, Sou
     return 0;
 }
 
-static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather = nullptr);
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather = nullptr, int* query_sk = nullptr);
 
 extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) { return gemm_core(stream, d, nullptr); }
 
@@ -1844,13 +1902,19 @@ extern "C" int egk_gemm_gather_ok(const egk_gemm_desc* d) {
 // Number of per-tile partial blocks [blocks][st_nseg][2] a launch of ``d`` with st_mode != 0 writes to st_ws -- 0 when the
 // tile variant the policy picks for ``d`` cannot (the caller then runs the LayerNorm's own statistics pass).  Nothing is
 // launched.
+extern "C" int egk_gemm_splitk_in_launch(const egk_gemm_desc* d) {
+    int blocks = 0, ga = 0, sk = 0;
+    const int rc = gemm_core(nullptr, d, &blocks, &ga, &sk);
+    return rc == 0 ? sk : 0;
+}
+
 extern "C" int egk_gemm_stats_blocks(const egk_gemm_desc* d) {
     int blocks = 0;
     const int rc = gemm_core(nullptr, d, &blocks);
     return rc == 0 ? blocks : 0;
 }
 
-static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather) {
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather, int* query_sk) {
     EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
     EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
     EGK_REQUIRE(d->compute == EGK_COMPUTE_F32 || d->compute == EGK_COMPUTE_BF16, "egk_gemm: bad compute type");
@@ -1897,6 +1961,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         EGK_REQUIRE(d->st_nseg >= 1 && d->st_nseg <= 16 && d->st_seg_ptr && (query_blocks || d->st_ws), "egk_gemm: st_* segments / workspace");
         EGK_REQUIRE(d->st_mode == 1 || (d->st_x && d->st_stats && d->st_w && d->st_b), "egk_gemm: st_mode 2 needs x, stats, w, b");
     }
+    g.sk_tickets = nullptr;
     g.ga_mode = d->ga_mode; g.ga_skip_c = d->ga_mode ? d->ga_skip_c : 0;
     g.ga_rowptr = d->ga_rowptr; g.ga_col = d->ga_col; g.ga_wgt = d->ga_wgt; g.ga_band = d->ga_band;
     g.ga_gate = d->ga_gate; g.ga_out = d->ga_out; g.ga_ld = d->ga_ld;
@@ -2018,9 +2083,13 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         const bool ga_ok = (variant == 8 || variant == 11) && g.splitk == 1 &&  // (96- / 64-row tiles: the 128-row ones have no registers to spare)
                            epilogue_rows_ok(g) && (d->ga_tile_mask & ga_bit) && aligned16(d->ga_out) && d->ga_ld % (g.c_bf16 ? 8 : 4) == 0 &&
                            (d->ga_mode != 2 || aligned16(d->ga_gate));
+        // split-K finished in the launch (sk_tickets): the reduce kernel's vector path, every tile variant but the 256 x 256 one
+        const bool sk_in_launch = g.splitk > 1 && d->sk_tickets != nullptr && variant != 7 && (g.N & 3) == 0 && g.c_vec &&
+                                  (!g.residual || g.r_vec) && g_sk_in_launch;
         if (query_blocks) {
             *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
             if (query_gather) *query_gather = (d->ga_mode && ga_ok) ? 1 : 0;
+            if (query_sk) *query_sk = sk_in_launch ? 1 : 0;
             return 0;
         }
         if (d->st_mode && !st_ok) {
@@ -2031,6 +2100,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             set_error("egk_gemm: ga_mode %d is not available for this launch (ask egk_gemm_gather_ok first)", d->ga_mode);
             return EGK_EUNSUPPORTED;
         }
+        g.sk_tickets = sk_in_launch ? d->sk_tickets : nullptr;
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
@@ -2061,7 +2131,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             else EGK_PIPE(true, false);
         }
 #undef EGK_PIPE
-        if (g.splitk > 1) {
+        if (g.splitk > 1 && !g.sk_tickets) {
             ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
             const long long total = (long long)g.M * g.N;
             const long long work = (total + 3) / 4;  // element groups of 4 (the vector path; the scalar path strides)
@@ -2188,7 +2258,7 @@ static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     g.dbias = d->dbias; g.ws_bias = nullptr;
     g.rows_epilogue = g_rows_epilogue;
     g.ga_mode = 0; g.ga_skip_c = 0; g.ga_rowptr = nullptr; g.ga_col = nullptr; g.ga_wgt = nullptr; g.ga_band = nullptr;
-    g.ga_gate = nullptr; g.ga_out = nullptr; g.ga_ld = 0;
+    g.ga_gate = nullptr; g.ga_out = nullptr; g.ga_ld = 0; g.sk_tickets = nullptr;
     g.st_mode = 0; g.st_nseg = 0; g.st_seg_ptr = nullptr; g.st_ws = nullptr; g.st_x = nullptr; g.st_ldx = 0;
     g.st_stats = nullptr; g.st_w = nullptr; g.st_b = nullptr; g.st_slope = 0.f;
     EGK_REQUIRE(d->st_mode == 0, "egk_gemm_grouped: no segment statistics in a grouped launch");

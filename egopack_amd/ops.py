@@ -584,6 +584,30 @@ def gemm_with_gather(args, kw, gather, stats=None) -> bool:
     return True
 
 
+_SK_TICKETS = 1 << 16
+_sk_cache = {}
+# OPT-IN (EGK_ENABLE=splitk_in_launch): bit-identical to the reduce launch and measured SLOWER -- the workgroup that arrives last
+# sums its tile's slabs alone while the reduce launch spreads that over the chip (BASELINE config 4: 4.50 ms against 3.62; 3.89
+# even with the device-scope fences compiled out), DESIGN 10.9
+_sk_in_launch = {"on": "splitk_in_launch" in os.environ.get("EGK_ENABLE", "")}
+
+
+def _sk_tickets(M: int, N: int, device):
+    """The arrival counters of a split contraction that is finished inside its launch (egk_gemm_desc.sk_tickets): one zeroed
+    int32 buffer per (device, stream) -- launches on one stream run one after the other and each hands its counters back at
+    zero.  None when the buffer would have to be created inside a capture (the reduce launch is used)."""
+    if not _sk_in_launch["on"] or ((M + 63) // 64) * ((N + 127) // 128) > _SK_TICKETS:
+        return None
+    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    buf = _sk_cache.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        buf = torch.zeros(_SK_TICKETS, dtype=torch.int32, device=device)
+        _sk_cache[key] = buf
+    return buf
+
+
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, **kw):
     lib = _lib.load()
     d = _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, **kw)
@@ -593,6 +617,8 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=No
     if need:
         ws = workspace(need, out.device)
         d.ws, d.ws_bytes = _p(ws), ws.numel()
+    if d.splitk > 1:
+        d.sk_tickets = _p(_sk_tickets(M, N, out.device))
     _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
     _x3_release()
 

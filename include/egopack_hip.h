@@ -163,11 +163,20 @@ typedef struct egk_gemm_desc {
     const void* ga_gate;
     void* ga_out;
     int64_t ga_ld;
+    /* Split-K finished inside the launch: sk_tickets = int32 [ceil(M / 64) * ceil(N / 128)] (enough for every tile height),
+     * caller-owned, ZERO on entry and left zero on exit, not shared with a launch that may run at the same time (another stream).
+     * The workgroup that stores the last slab of an output tile sums the tile's slabs in slab order and applies the epilogue
+     * (the separate reduce launch's arithmetic: the same bits) -- one launch less per split contraction.  NULL, or a shape the
+     * in-launch path does not take (N not a multiple of 4, unaligned C / residual, the 256 x 256 tile, f32 operands): the reduce
+     * launch as before.  egk_gemm_splitk_in_launch() says which. */
+    int32_t* sk_tickets;
 } egk_gemm_desc;
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_stats_blocks(const egk_gemm_desc* d);
+/* 1 when egk_gemm(d) would finish its split-K inside the launch (d->sk_tickets set, splitk > 1, eligible shape) */
+int egk_gemm_splitk_in_launch(const egk_gemm_desc* d);
 /* 1 when the tile variant the policy picks for ``d`` can run its ga_mode gather in the epilogue (nothing is launched) */
 int egk_gemm_gather_ok(const egk_gemm_desc* d);
 /* HOST helper of the batch builders (runs on the CPU, touches no device): ``np.stack([rng.randint(h, size = n) for h in

@@ -973,6 +973,64 @@ def test_gemm_f32_pipelined_kernel_bit_equal_to_generic(ops, transA, transB, M, 
         torch.testing.assert_close(outs[1][1], (0.5 * dot + C0.double()).float(), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("transA,transB", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K,splitk,pipe", [(2048, 1024, 1024, 2, 1), (2048, 1024, 3072, 4, 1), (300, 200, 512, 3, 1), (2048, 1024, 2048, 2, 5),
+                                               (1024, 1024, 2048, 4, 3), (2048, 480, 1024, 2, 11), (2048, 1024, 1024, 2, 8), (2048, 1024, 1024, 2, 12),
+                                               (130, 132, 256, 2, 1)])
+def test_gemm_splitk_finished_inside_the_launch_equals_the_reduce_launch(ops, transA, transB, M, N, K, splitk, pipe):
+    """egk_gemm_desc.sk_tickets: the workgroup that stores the last slab of an output tile sums the tile's slabs (slab order) and
+    applies the epilogue -- against the separate reduce launch (egk_gemm_set_pipeline(700)): bias + ReLU + bf16 residual into a
+    bf16 result, alpha + accumulation into an f32 result, the fused bias gradient of the dW form, ragged tiles, every tile
+    variant that takes it -- BIT for bit, repeatedly (the counters come back at zero), and the query agrees with what ran."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + 3 * N + K + splitk)
+
+    def operand(rows, tr):
+        return torch.randn((K, rows) if tr else (rows, K), device=DEV, generator=g).to(BF)
+    A, B = operand(M, transA), operand(N, transB)
+    bias, res = torch.randn(N, device=DEV, generator=g), torch.randn(M, N, device=DEV, generator=g).to(BF)
+    C0, db0 = torch.randn(M, N, device=DEV, generator=g), torch.randn(M, device=DEV, generator=g)
+    outs = {}
+    prev_pipe = lib.egk_gemm_set_pipeline(pipe)
+    prev_on, ops._sk_in_launch["on"] = ops._sk_in_launch["on"], True  # (opt-in: EGK_ENABLE=splitk_in_launch)
+    try:
+        for mode in (701, 700, 701):
+            lib.egk_gemm_set_pipeline(mode)
+            a = torch.empty(M, N, device=DEV, dtype=BF)
+            ops.gemm(M, N, A, A.shape[1], B, B.shape[1], K, a, N, transA=transA, transB=transB, bias=bias, residual=res, ldr=N,
+                     act=1, splitk=splitk)
+            b, db = C0.clone(), db0.clone()
+            kw = dict(dbias=db) if (transA and transB) else {}
+            ops.gemm(M, N, A, A.shape[1], B, B.shape[1], K, b, N, transA=transA, transB=transB, accumulate=True, alpha=0.5,
+                     splitk=splitk, **kw)
+            outs.setdefault(mode, []).append((a, b, db))
+    finally:
+        ops._sk_in_launch["on"] = prev_on
+        lib.egk_gemm_set_pipeline(701)
+        lib.egk_gemm_set_pipeline(prev_pipe)
+    first, sep, again = outs[701][0], outs[700][0], outs[701][1]
+    for x, y, z in zip(first, sep, again):
+        assert torch.equal(x, y) and torch.equal(z, y)
+    key = (torch.device(DEV).index or 0, torch.cuda.current_stream().cuda_stream)
+    tickets = ops._sk_cache.get(key)
+    assert tickets is not None and int(tickets.abs().sum()) == 0
+    if (M, N) == (2048, 1024):  # the shapes of the steps' split contractions: the query says they are finished in the launch
+        d = ops._gemm_desc(M, N, A, A.shape[1], B, B.shape[1], K, torch.empty(M, N, device=DEV, dtype=BF), N, transA=transA, transB=transB)
+        d.splitk = splitk
+        d.ws, d.ws_bytes = ops._p(torch.empty(splitk * M * N, device=DEV)), splitk * M * N * 4
+        d.sk_tickets = ops._p(tickets)
+        prev_pipe = lib.egk_gemm_set_pipeline(pipe)
+        try:
+            assert lib.egk_gemm_splitk_in_launch(_lib.C.byref(d)) == 1
+            d.sk_tickets = None
+            assert lib.egk_gemm_splitk_in_launch(_lib.C.byref(d)) == 0
+        finally:
+            lib.egk_gemm_set_pipeline(prev_pipe)
+    ref = (A.double().t() if transA else A.double()) @ (B.double() if transB else B.double().t())
+    torch.testing.assert_close(first[1].double(), 0.5 * ref + C0.double(), rtol=1e-3, atol=2e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 1024, 2048), (472, 1024, 1024), (128, 256, 4096), (1024, 4608, 6144), (115, 1024, 2048)])
 def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
     """dW launch with dbias: dbias[m] += sum_k dY[k, m], fused into the pipelined kernel (from the dY^T LDS image) or
