@@ -323,7 +323,7 @@ def parse_args(argv=None):
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)  # (this process IS a pre-flight child)
     ap.add_argument("--strict-capture", action="store_true",
                     help="fail instead of falling back (staged graphs -> one-piece graph -> eager) when a capture fails")
-    ap.add_argument("--gemm-knob", type=int, default=None, help="development: value passed to egk_gemm_set_pipeline before the run (A/B on one box)")
+    ap.add_argument("--gemm-knob", type=str, default=None, help="development: value(s, comma list) passed to egk_gemm_set_pipeline before the run (A/B on one box)")
     ap.add_argument("--no-early-adam", action="store_true", help="A/B: one Adam launch after the whole backward")
     ap.add_argument("--force-wgrad-streams", action="store_true", help="A/B: weight gradients on a side stream also for single-task steps")
     ap.add_argument("--egk-tune", default="", help="development: comma list key=value passed to egk_tune (row-kernel grid caps)")
@@ -761,7 +761,8 @@ def main(argv=None):
 
     if args.gemm_knob is not None:
         from egopack_amd import _lib
-        _lib.load().egk_gemm_set_pipeline(args.gemm_knob)
+        for v in str(args.gemm_knob).split(","):
+            _lib.load().egk_gemm_set_pipeline(int(v))
     for kv in filter(None, args.egk_tune.split(",")):
         from egopack_amd import _lib
         k, v = kv.split("=")
