@@ -879,6 +879,32 @@ def _launch_reductions(reds):
             "egk_ln_bwd_reduce_multi")
 
 
+# (experiment) a grouped weight-gradient launch holds every CU for the length of its K walk (6144 rows: 90-130 us) and a launch of
+# the backward chain that arrives meanwhile waits for its workgroups to retire (a 43 us dX contraction took 135 us).
+# EGK_WGRAD_KCHUNKS = n issues the group as n launches over consecutive K ranges, each accumulating into the gradient slots.
+WGRAD_KCHUNKS = int(os.environ.get("EGK_WGRAD_KCHUNKS", "1"))
+
+
+def _k_pieces(chunk):
+    """``chunk`` (parked (args, kw) weight-gradient problems) cut into WGRAD_KCHUNKS lists over consecutive K ranges, or None."""
+    n = WGRAD_KCHUNKS
+    if n <= 1:
+        return None
+    K = chunk[0][0][6]
+    for a, kw in chunk:
+        if not (kw.get("transA") and kw.get("transB") and kw.get("accumulate") and a[6] == K and a[2].dim() == 2 and a[4].dim() == 2
+                and a[2].shape[0] == K and a[4].shape[0] == K and kw.get("K2", 0) in (0, None)):
+            return None
+    step = (K // n + 63) // 64 * 64
+    if step < 512:
+        return None
+    out = []
+    for k0 in range(0, K, step):
+        k1 = min(K, k0 + step)
+        out.append([((a[0], a[1], a[2][k0:k1], a[3], a[4][k0:k1], a[5], k1 - k0, a[7], a[8]), kw) for a, kw in chunk])
+    return out
+
+
 def flush_wgrad(in_backward: bool = True, force: bool = False):
     """Issue what is parked.  On an excluded (task-head) stream nothing is issued -- unless ``force``: the engine's own
     calls from the backward stream (end of a step's backward, the last-weight-gradient hook) must never leave parked work
@@ -892,7 +918,11 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
     def launch():
         for i in range(0, len(items), 8):
             chunk = items[i:i + 8]
-            if len(chunk) == 1:
+            pieces = _k_pieces(chunk) if len(chunk) > 1 else None
+            if pieces is not None:
+                for piece in pieces:
+                    gemm_grouped(piece, four_wave=len(piece) <= 4 and "wg4" not in os.environ.get("EGK_DISABLE", ""))
+            elif len(chunk) == 1:
                 gemm(*chunk[0][0], **chunk[0][1])
             else:
                 # beside the dX chain a group runs on 4-WAVE workgroups also when it has <= 256 tiles (alone the 8-wave
