@@ -787,7 +787,8 @@ class StepBase:
         if segmented:
             from .graphexec import SegmentedGraph
             import os
-            g = SegmentedGraph(g, max_streams=segmented, event_nodes="plan_event_nodes" in os.environ.get("EGK_ENABLE", ""))
+            g = SegmentedGraph(g, max_streams=segmented,
+                               event_nodes=self.segmented_event_nodes or "plan_event_nodes" in os.environ.get("EGK_ENABLE", ""))
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
@@ -1029,6 +1030,7 @@ class StepBase:
     # captured graph: the number of streams of the plan, 0 = the runtime's replay.  EGK_ENABLE=segmented_replay[=N] /
     # EGK_DISABLE=segmented_replay override the attribute.
     segmented_replay = 0
+    segmented_event_nodes = False  # cross-stream edges as event-record / event-wait NODES inside per-stream graphs
 
     def _segmented_replay(self) -> int:
         import os
