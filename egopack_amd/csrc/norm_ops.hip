@@ -255,41 +255,42 @@ __global__ __launch_bounds__(256) void rowln_bwd_group_kernel(const T* __restric
 }
 
 // out_a[c] += sum_b ws[b][0][c]; out_b[c] += sum_b ws[b][1][c]   (fixed order)
-// workgroup = 16 columns x 16 row groups; the 16 partial sums of a column are combined in LDS in group order.
-__global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __restrict__ ws, float* __restrict__ oa,
-                                                              float* __restrict__ ob, int nblk, int cols) {
-    __shared__ float red[2][16][16];
-    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cg;
-    float a = 0.f, d = 0.f;
+// The order (unchanged since round 1, so the bits are): sixteen row groups rg = 0 .. 15, group rg sums rows rg + 16 u + 128 j for
+// u = 0 .. 7 inside j = 0, 1, ...; the sixteen group sums are then added in group order.
+// Sixteen waves per workgroup, wave = row group, a strip of 32 columns: lanes 0-31 sum the dw partials of the strip, lanes 32-63 the
+// db partials (two 128-byte pieces per row), 8 rows in flight per lane; 32 workgroups per 1024-column problem.  The reduction
+// sits between the step's last weight gradient and Adam; 16-column strips on 4-wave workgroups (64-byte pieces) took 13-17 us
+// stand-alone, this takes 8-10 -- but beside the Adam launch that saturates HBM at that point of the step it still takes 13.8.
+constexpr int RED_COLS = 32;
+__device__ __forceinline__ void partial_reduce2_body(const float* __restrict__ ws, float* __restrict__ oa, float* __restrict__ ob,
+                                                     int nblk, int cols, int strip) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int half = lane >> 5;  // 0: the first partial row of a pair (dw), 1: the second (db)
+    const int c = strip * RED_COLS + (lane & 31);
+    float acc = 0.f;
     if (c < cols)
-        for (int k = rg; k < nblk; k += 128) {  // 2 x 8 loads in flight, summed in k order
-            float va[8], vd[8];
+        for (int k = rg; k < nblk; k += 128) {  // 8 loads in flight, summed in k order
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = k + 16 * u < nblk;
-                va[u] = in ? ws[((long long)(k + 16 * u) * 2 + 0) * cols + c] : 0.f;
-                vd[u] = in ? ws[((long long)(k + 16 * u) * 2 + 1) * cols + c] : 0.f;
-            }
+            for (int u = 0; u < 8; ++u) v[u] = k + 16 * u < nblk ? ws[((long long)(k + 16 * u) * 2 + half) * cols + c] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a += va[u];
-                d += vd[u];
-            }
+            for (int u = 0; u < 8; ++u) acc += v[u];
         }
-    red[0][rg][cg] = a;
-    red[1][rg][cg] = d;
+    red[rg][lane] = acc;
     __syncthreads();
     if (rg == 0 && c < cols) {
-        a = d = 0.f;
+        float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            a += red[0][k][cg];
-            d += red[1][k][cg];
-        }
-        if (oa) oa[c] += a;
-        if (ob) ob[c] += d;
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        float* o = half ? ob : oa;
+        if (o) o[c] += t;
     }
+}
+
+__global__ __launch_bounds__(1024) void partial_reduce2_kernel(const float* __restrict__ ws, float* __restrict__ oa,
+                                                              float* __restrict__ ob, int nblk, int cols) {
+    partial_reduce2_body(ws, oa, ob, nblk, cols, blockIdx.x);
 }
 
 // several reductions of that kind in ONE launch (blockIdx.y = problem): the dw / db reductions of the norm layers whose
@@ -302,43 +303,10 @@ struct ReduceBatch {
     int nblk[REDUCE_MAX];
     int cols[REDUCE_MAX];
 };
-__global__ __launch_bounds__(256) void partial_reduce2_multi_kernel(const ReduceBatch B) {
-    __shared__ float red[2][16][16];
+__global__ __launch_bounds__(1024) void partial_reduce2_multi_kernel(const ReduceBatch B) {
     const int p = blockIdx.y;
-    const float* __restrict__ ws = B.ws[p];
-    const int nblk = B.nblk[p], cols = B.cols[p];
-    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cg;
-    if (blockIdx.x * 16 >= cols) return;  // (block-uniform: the grid is sized for the widest problem)
-    float a = 0.f, d = 0.f;
-    if (c < cols)
-        for (int k = rg; k < nblk; k += 128) {  // the summation order of partial_reduce2_kernel: same bits
-            float va[8], vd[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = k + 16 * u < nblk;
-                va[u] = in ? ws[((long long)(k + 16 * u) * 2 + 0) * cols + c] : 0.f;
-                vd[u] = in ? ws[((long long)(k + 16 * u) * 2 + 1) * cols + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a += va[u];
-                d += vd[u];
-            }
-        }
-    red[0][rg][cg] = a;
-    red[1][rg][cg] = d;
-    __syncthreads();
-    if (rg == 0 && c < cols) {
-        a = d = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            a += red[0][k][cg];
-            d += red[1][k][cg];
-        }
-        if (B.oa[p]) B.oa[p][c] += a;
-        if (B.ob[p]) B.ob[p][c] += d;
-    }
+    if ((int)blockIdx.x * RED_COLS >= B.cols[p]) return;  // (block-uniform: the grid is sized for the widest problem)
+    partial_reduce2_body(B.ws[p], B.oa[p], B.ob[p], B.nblk[p], B.cols[p], blockIdx.x);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -966,7 +934,7 @@ int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const floa
     }
     if (dw || db) {
         ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, RED_COLS)), dim3(1024), 0, s, ws, dw, db, grid, cols);
     }
     return check_launch("egk_rowln_bwd");
 }
@@ -981,7 +949,7 @@ int egk_ln_bwd_reduce(egk_stream_t stream, const void* ws, float* dw, float* db,
     // n_seg = 0: egk_rowln_bwd's workspace (partial rows first); n_seg >= 1: egk_graphln_bwd's (segment sums first)
     const float* ws_col = n_seg > 0 ? (const float*)((const char*)ws + (int64_t)grid * n_seg * 2 * 8) : (const float*)ws;
     ProfScope prof(n_seg > 0 ? KID_GRAPHLN_BWD_REDUCE : KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-    hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
+    hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, RED_COLS)), dim3(1024), 0, s, ws_col, dw, db, grid, cols);
     return check_launch("egk_ln_bwd_reduce");
 }
 
@@ -1007,7 +975,7 @@ int egk_ln_bwd_reduce_multi(egk_stream_t stream, const void* const* ws, float* c
     if (max_cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, bytes);
-    hipLaunchKernelGGL(partial_reduce2_multi_kernel, dim3(cdiv(max_cols, 16), count), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(partial_reduce2_multi_kernel, dim3(cdiv(max_cols, RED_COLS), count), dim3(1024), 0, s, B);
     return check_launch("egk_ln_bwd_reduce_multi");
 }
 
@@ -1133,7 +1101,7 @@ int egk_graphln_bwd_finish(egk_stream_t stream, const void* dy, const void* x, c
     }
     if (dw || db) {
         ProfScope prof(KID_GRAPHLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);
-        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, ws_col, dw, db, grid, cols);
+        hipLaunchKernelGGL(partial_reduce2_kernel, dim3(cdiv(cols, RED_COLS)), dim3(1024), 0, s, ws_col, dw, db, grid, cols);
     }
     return check_launch("egk_graphln_bwd_finish");
 }
