@@ -784,20 +784,31 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
             lv[s] = INFINITY;
             li[s] = 0x7fffffff;
         }
-        for (int base = lane * 4; base < K; base += 256) {
-            float dv[4], bv4[4];
+        // four steps of 256 columns are REQUESTED before the first is examined (a row is 16 dependent round trips otherwise:
+        // 26-51 us for 2048 rows of 4096 against 8 us of bytes); examined in column order, as before
+        for (int base0 = lane * 4; base0 < K; base0 += 1024) {
+          float dq[4][4], bq[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int base = base0 + 256 * u;
             if (vec && base + 4 <= K) {
                 const float4 a = *reinterpret_cast<const float4*>(dr + base);
                 const float4 b = *reinterpret_cast<const float4*>(b_inv + base);
-                dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w;
-                bv4[0] = b.x; bv4[1] = b.y; bv4[2] = b.z; bv4[3] = b.w;
+                dq[u][0] = a.x; dq[u][1] = a.y; dq[u][2] = a.z; dq[u][3] = a.w;
+                bq[u][0] = b.x; bq[u][1] = b.y; bq[u][2] = b.z; bq[u][3] = b.w;
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    dv[t] = base + t < K ? dr[base + t] : 0.f;
-                    bv4[t] = base + t < K ? b_inv[base + t] : 0.f;
+                    dq[u][t] = base + t < K ? dr[base + t] : 0.f;
+                    bq[u][t] = base + t < K ? b_inv[base + t] : 0.f;
                 }
             }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int base = base0 + 256 * u;
+            const float (&dv)[4] = dq[u];
+            const float (&bv4)[4] = bq[u];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = base + t;
@@ -816,6 +827,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
                     }
                 }
             }
+          }
         }
         for (int sel = 0; sel < k; ++sel) {
             float bv = lv[0];
