@@ -471,3 +471,28 @@ def test_bench_names_one_pmc_file_per_configuration():
     c5 = bench.parse_args(["--workload", "mtl4", "--T", "256", "--batch", "16"])
     assert bench.pmc_file(c4).name == "pmc_egopack_oscc_B64_T32_H1024_Hp1024_bf16.json"
     assert bench.pmc_file(c5).name == "pmc_mtl4_B16_T256_H1024_Hp1024_bf16.json"
+
+
+def test_weight_gradient_k_pieces_partition_the_walk(monkeypatch):
+    """ops._k_pieces (EGK_WGRAD_KCHUNKS, an opt-in experiment): a parked group of dW problems cut into launches over consecutive K
+    ranges -- every piece views the operands' rows [k0, k1) (no copy), the ranges are multiples of 64 and cover K exactly once, and
+    problems the cut does not apply to (another layout, no accumulation, short K) leave the group whole."""
+    from egopack_amd import ops
+    K, M, N = 6144, 32, 48
+    dY, X, W = torch.randn(K, M), torch.randn(K, N), torch.zeros(M, N)
+    kw = dict(transA=True, transB=True, accumulate=True)
+    chunk = [((M, N, dY, M, X, N, K, W, N), kw), ((M, N, dY, M, X, N, K, W, N), dict(kw, dbias=torch.zeros(M)))]
+    monkeypatch.setattr(ops, "WGRAD_KCHUNKS", 1)
+    assert ops._k_pieces(chunk) is None
+    monkeypatch.setattr(ops, "WGRAD_KCHUNKS", 3)
+    pieces = ops._k_pieces(chunk)
+    assert len(pieces) == 3 and all(len(p) == 2 for p in pieces)
+    covered = 0
+    for p in pieces:
+        (m, n, a, lda, b, ldb, k, out, ldc), kwp = p[0]
+        assert (m, n, lda, ldb, ldc) == (M, N, M, N, N) and k % 64 == 0 and a.shape[0] == k == b.shape[0] and kwp is kw
+        assert a.data_ptr() == dY.data_ptr() + covered * M * 4 and b.data_ptr() == X.data_ptr() + covered * N * 4 and out is W
+        covered += k
+    assert covered == K
+    assert ops._k_pieces([((M, N, dY, M, X, N, K, W, N), dict(kw, accumulate=False))]) is None
+    assert ops._k_pieces([((M, N, dY[:1024], M, X[:1024], N, 1024, W, N), kw)] * 2) is None  # pieces shorter than 512 rows
