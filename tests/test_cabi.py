@@ -47,6 +47,12 @@ def test_argument_errors_are_reported_without_a_gpu():
     n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     assert lib.egk_prof_get(0, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)) == 0
     assert name.value.decode().startswith("gemm")
+    # the segmented-replay plan and the in-launch split-K query reject their bad arguments the same way (no HIP call made)
+    plan = ctypes.c_void_p()
+    assert lib.egk_graph_plan_create(None, 4, 0, ctypes.byref(plan)) == -1 and "bad arguments" in _lib.last_error() and not plan
+    assert lib.egk_graph_plan_launch(None, None) == -1 and "null plan" in _lib.last_error()
+    lib.egk_graph_plan_destroy(None)  # (a no-op)
+    assert lib.egk_gemm_splitk_in_launch(None) == 0
 
 
 def test_heavy_row_threshold_is_shared_by_the_csr_builder_and_the_kernel():
