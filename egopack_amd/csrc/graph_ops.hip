@@ -668,11 +668,13 @@ __global__ __launch_bounds__(256) void segmax_fwd_kernel(const T* __restrict__ x
 // 16 rows out).  Workgroup = (segment, block of 256 columns); thread (cg = tid & 63, rl = tid >> 6) walks rows r0 + rl, r0 + rl
 // + 4, ... eight at a time for columns 4 cg .. 4 cg + 3; the four lanes meet through LDS: the larger value wins, on equal
 // values the SMALLER row -- the first occurrence, which is what the serial walk (strict >) keeps.  cols % 4 == 0.
-template <typename T>
-__global__ __launch_bounds__(256) void segmax_fwd_v4_kernel(const T* __restrict__ x, const int* __restrict__ ptr,
-                                                            T* __restrict__ out, int* __restrict__ arg, int n_seg, int cols) {
-    __shared__ float sv[3][64][4];
-    __shared__ int sa[3][64][4];
+// RL row lanes (waves) per workgroup: 4, or 16 when the launch has few segments (16 sequences of 256 nodes: 64 workgroups of 4
+// waves walked 8 dependent rounds of loads each -- 44 us on the critical path of config 5 between the heads and backward).
+template <typename T, int RL>
+__global__ __launch_bounds__(64 * RL) void segmax_fwd_v4_kernel(const T* __restrict__ x, const int* __restrict__ ptr,
+                                                                T* __restrict__ out, int* __restrict__ arg, int n_seg, int cols) {
+    __shared__ float sv[RL - 1][64][4];
+    __shared__ int sa[RL - 1][64][4];
     const int sg = blockIdx.y, cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + cg * 4;
     const bool live = c < cols;
@@ -680,20 +682,20 @@ __global__ __launch_bounds__(256) void segmax_fwd_v4_kernel(const T* __restrict_
     float best[4] = {0.f, 0.f, 0.f, 0.f};  // empty segment -> 0 (scatter 'amax' into zeros, include_self=False)
     int a[4] = {-1, -1, -1, -1};
     if (live) {
-        for (int r = r0 + rl; r < r1; r += 32) {
+        for (int r = r0 + rl; r < r1; r += 8 * RL) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (r + 4 * u < r1) v[u] = ld4t(x + (long long)(r + 4 * u) * cols, c, cols, true);
+                if (r + RL * u < r1) v[u] = ld4t(x + (long long)(r + RL * u) * cols, c, cols, true);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (r + 4 * u < r1) {
+                if (r + RL * u < r1) {
                     const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         if (a[t] < 0 || e[t] > best[t]) {
                             best[t] = e[t];
-                            a[t] = r + 4 * u;
+                            a[t] = r + RL * u;
                         }
                 }
         }
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256) void segmax_fwd_v4_kernel(const T* __restrict_
     __syncthreads();
     if (rl == 0 && live) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < RL - 1; ++q)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float v = sv[q][cg][t];
@@ -1318,8 +1320,12 @@ int egk_segment_max_fwd(egk_stream_t stream, const void* x, const int32_t* ptr, 
     const int ebytes = dtype == EGK_BF16 ? 2 : 4;
     if (cols % 4 == 0 && (reinterpret_cast<uintptr_t>(x) % (4 * ebytes)) == 0 && (reinterpret_cast<uintptr_t>(out) % (4 * ebytes)) == 0 &&
         (reinterpret_cast<uintptr_t>(arg) & 15) == 0) {
-        EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_fwd_v4_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)x, ptr,
-                                                 (T*)out, arg, n_seg, cols));
+        if (n_seg < 128)  // (few segments: sixteen row lanes per workgroup)
+            EGK_DISPATCH_T(dtype, hipLaunchKernelGGL((segmax_fwd_v4_kernel<T, 16>), dim3(cdiv(cols, 256), n_seg), dim3(1024), 0, s,
+                                                     (const T*)x, ptr, (T*)out, arg, n_seg, cols));
+        else
+            EGK_DISPATCH_T(dtype, hipLaunchKernelGGL((segmax_fwd_v4_kernel<T, 4>), dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s,
+                                                     (const T*)x, ptr, (T*)out, arg, n_seg, cols));
         return check_launch("egk_segment_max_fwd");
     }
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_fwd_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)x, ptr,

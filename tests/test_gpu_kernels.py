@@ -1659,10 +1659,12 @@ def test_sage_layer_with_the_gather_in_the_contraction_epilogue_is_bit_identical
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("lens,cols", [((256,) * 16, 1024), ((32,) * 64, 1024), ((1, 0, 7, 300, 33), 260), ((5, 9), 250)])
+@pytest.mark.parametrize("lens,cols", [((256,) * 16, 1024), ((32,) * 64, 1024), ((1, 0, 7, 300, 33), 260), ((5, 9), 250),
+                                       ((32, 0, 9, 40) * 40, 512)])
 def test_segment_max_rows_shared_by_four_lanes(ops, lens, cols, dt):
-    """The per-sequence max pool with a segment's rows shared by four row lanes (egk_segment_max_fwd; BASELINE config 5 pools
-    256-node sequences): values AND arg-max rows equal the serial first-occurrence rule -- ties (bf16 values repeat a lot at
+    """The per-sequence max pool with a segment's rows shared by four row lanes -- sixteen when the launch has fewer than 128
+    segments -- (egk_segment_max_fwd; BASELINE config 5 pools 16 sequences of 256 nodes): values AND arg-max rows equal the serial
+    first-occurrence rule -- ties (bf16 values repeat a lot at
     T = 256) go to the smallest row -- empty segments give zeros / -1, widths that are not a multiple of 4 take the
     thread-per-column kernel."""
     g = gen(sum(lens) + cols)
