@@ -791,6 +791,108 @@ static inline int row_grid_wide(int rows) {  // pure streaming row kernels
     return g < 1 ? 1 : (g > g_cap_wide ? g_cap_wide : g);
 }
 
+// ---- two-logit classifier + cross entropy over FEW rows (the OSCC head: one row per sequence), loss AND gradients in one launch --
+// logits[r, c] = f[r, :] . w[c, :] + bias[c];  loss[r] = lse - (1 - eps) z_y - eps / 2 (z_0 + z_1)  (0 for y = -1): ce_fwd_kernel;
+// g[r, c] = seed (softmax_c - (c == y ? 1 - eps : 0) - eps / 2) rounded to T (ce_bwd_kernel + the operand cast of the contraction
+// path);  df[r, :] = g[r, 0] w[0, :] + g[r, 1] w[1, :];  dw[c, :] += sum_r g[r, c] f[r, :];  db[c] += sum_r g[r, c], rows in order.
+// ONE workgroup, a thread per four columns of every row -- eleven launches of the
+// contraction path (a split 16 x 2 x 1024 contraction and its reduce, loss, loss gradient, cast, dX, two column sums, dW) sat on
+// the critical path of BASELINE config 5 between the backbone's forward and backward.
+constexpr int CE2_MAX_ROWS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_ce2_kernel(const T* __restrict__ f, const T* __restrict__ w, const float* __restrict__ bias,
+                                                         const long long* __restrict__ y, float* __restrict__ logits,
+                                                         float* __restrict__ loss, T* __restrict__ df, float* __restrict__ dw,
+                                                         float* __restrict__ db, int rows, int cols, float smoothing, float seed) {
+    // column-parallel: a thread owns four columns (per pass of 1024) for EVERY row, sixteen rows at a time -- all their loads in
+    // flight together; a row's two dot products meet through wave sums + LDS.  (A wave per row walked the rows one dependent
+    // round trip after the other: 40 us for 16 x 1024.)
+    constexpr int RC = 16;
+    __shared__ float gq[CE2_MAX_ROWS][2];
+    __shared__ float part[WPB][RC][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (cols & 3) == 0;
+    const float sm = smoothing > 0.f ? smoothing * 0.5f : 0.f;
+    for (int r0 = 0; r0 < rows; r0 += RC) {
+        float p0[RC], p1[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) p0[r] = p1[r] = 0.f;
+        for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+            const float4 w0 = ld4t(w, c, cols, vec), w1 = ld4t(w + cols, c, cols, vec);
+            float4 x[RC];
+#pragma unroll
+            for (int r = 0; r < RC; ++r)
+                x[r] = r0 + r < rows ? ld4t(f + (long long)(r0 + r) * cols, c, cols, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                p0[r] = fmaf(x[r].x, w0.x, p0[r]); p0[r] = fmaf(x[r].y, w0.y, p0[r]);
+                p0[r] = fmaf(x[r].z, w0.z, p0[r]); p0[r] = fmaf(x[r].w, w0.w, p0[r]);
+                p1[r] = fmaf(x[r].x, w1.x, p1[r]); p1[r] = fmaf(x[r].y, w1.y, p1[r]);
+                p1[r] = fmaf(x[r].z, w1.z, p1[r]); p1[r] = fmaf(x[r].w, w1.w, p1[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const float s0 = wave_sum(p0[r]), s1 = wave_sum(p1[r]);
+            if (lane == 0) {
+                part[wave][r][0] = s0;
+                part[wave][r][1] = s1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < RC && r0 + (int)threadIdx.x < rows) {
+            const int r = threadIdx.x, row = r0 + r;
+            const float z0 = ((part[0][r][0] + part[1][r][0]) + (part[2][r][0] + part[3][r][0])) + (bias ? bias[0] : 0.f);
+            const float z1 = ((part[0][r][1] + part[1][r][1]) + (part[2][r][1] + part[3][r][1])) + (bias ? bias[1] : 0.f);
+            logits[row * 2 + 0] = z0;
+            logits[row * 2 + 1] = z1;
+            const float mx = fmaxf(z0, z1);
+            const float l = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+            const long long t = y[row];
+            const bool live = t >= 0 && t < 2;
+            loss[row] = live ? l - (1.f - smoothing) * (t == 0 ? z0 : z1) - (smoothing > 0.f ? sm * (z0 + z1) : 0.f) : 0.f;
+            T g0, g1;  // the gradient in the operand element type
+            st1t(&g0, live ? seed * (expf(z0 - l) - (t == 0 ? 1.f - smoothing : 0.f) - sm) : 0.f);
+            st1t(&g1, live ? seed * (expf(z1 - l) - (t == 1 ? 1.f - smoothing : 0.f) - sm) : 0.f);
+            gq[row][0] = ld1t(&g0);
+            gq[row][1] = ld1t(&g1);
+        }
+        __syncthreads();
+    }
+    if (!df) return;
+    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        const float4 w0 = ld4t(w, c, cols, vec), w1 = ld4t(w + cols, c, cols, vec);
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        for (int r0 = 0; r0 < rows; r0 += RC) {
+            float4 x[RC];
+#pragma unroll
+            for (int r = 0; r < RC; ++r)
+                x[r] = r0 + r < rows ? ld4t(f + (long long)(r0 + r) * cols, c, cols, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                if (r0 + r >= rows) break;
+                const float g0 = gq[r0 + r][0], g1 = gq[r0 + r][1];
+                st4t(df + (long long)(r0 + r) * cols, c, cols, vec,
+                     make_float4(fmaf(g1, w1.x, g0 * w0.x), fmaf(g1, w1.y, g0 * w0.y), fmaf(g1, w1.z, g0 * w0.z), fmaf(g1, w1.w, g0 * w0.w)));
+                a0.x = fmaf(g0, x[r].x, a0.x); a0.y = fmaf(g0, x[r].y, a0.y); a0.z = fmaf(g0, x[r].z, a0.z); a0.w = fmaf(g0, x[r].w, a0.w);
+                a1.x = fmaf(g1, x[r].x, a1.x); a1.y = fmaf(g1, x[r].y, a1.y); a1.z = fmaf(g1, x[r].z, a1.z); a1.w = fmaf(g1, x[r].w, a1.w);
+            }
+        }
+        const float v0[4] = {a0.x, a0.y, a0.z, a0.w}, v1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (c + t < cols) {
+                dw[c + t] += v0[t];
+                dw[cols + c + t] += v1[t];
+            }
+    }
+    if (db && threadIdx.x < 2) {
+        float t = 0.f;
+        for (int row = 0; row < rows; ++row) t += gq[row][threadIdx.x];
+        db[threadIdx.x] += t;
+    }
+}
+
 }  // namespace egk
 
 using namespace egk;
@@ -1134,6 +1236,22 @@ int egk_rowdot_bce(egk_stream_t stream, const void* f, const void* w, const floa
                                                  WPB * (NV * 256 + 4) * sizeof(float), s, (const T*)f,
                                                  (const T*)w, bias, (const long long*)y, logits, loss, (T*)df, ws, rows, cols, seed));
     return check_launch("egk_rowdot_bce");
+}
+
+int32_t egk_rowdot_ce2_max_rows(void) { return CE2_MAX_ROWS; }
+
+int egk_rowdot_ce2(egk_stream_t stream, const void* f, const void* w, const float* bias, const int64_t* y, float* logits, float* loss,
+                   void* df, float* dw, float* db, int32_t rows, int32_t cols, float smoothing, float seed, int32_t dtype) {
+    EGK_REQUIRE(f && w && y && logits && loss, "egk_rowdot_ce2: null pointer");
+    EGK_REQUIRE(!df || dw, "egk_rowdot_ce2: gradients need dw");
+    EGK_REQUIRE(rows >= 0 && rows <= CE2_MAX_ROWS && cols >= 1, "egk_rowdot_ce2: at most %d rows", CE2_MAX_ROWS);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    ProfScope prof(KID_CE_FWD, s, 4.0 * rows * cols * (df ? 3 : 1), eb * rows * cols * (df ? 3 : 1));
+    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(rowdot_ce2_kernel<T>, dim3(1), dim3(256), 0, s, (const T*)f, (const T*)w, bias,
+                                             (const long long*)y, logits, loss, (T*)df, dw, db, rows, cols, smoothing, seed));
+    return check_launch("egk_rowdot_ce2");
 }
 
 int egk_rowdot_reduce(egk_stream_t stream, const float* ws, float* dw, float* db, int32_t rows, int32_t cols) {

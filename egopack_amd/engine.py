@@ -1109,6 +1109,14 @@ class MTLStep(StepBase):
         return (self.one_pass_heads and hasattr(self.tasks[t], "fused_head_loss") and type(self.criteria[t]) is BCEWithLogitsNone
                 and "rowdot_head" not in getattr(self, "_dev_off", ()))
 
+    def _one_pass_oscc_ok(self, t: str) -> bool:
+        """The OSCC head (max pool -> 2-logit classifier -> cross entropy, one loss element per SEQUENCE) as pool + one launch
+        (ops.linear2_ce): its eleven short launches sat on the critical path of the 4-task step between forward and backward."""
+        from .criterion import CrossEntropyNone
+        return (t == "oscc" and self.one_pass_heads and hasattr(self.tasks[t], "fused_head_loss")
+                and type(self.criteria[t]) is CrossEntropyNone and getattr(self, "_fused_loss", True)
+                and "rowdot_head" not in getattr(self, "_dev_off", ()) and "oscc_one_pass" not in getattr(self, "_dev_off", ()))
+
     grouped_classifiers = True
 
     def _banked_tasks(self, order, proj_leaves):
@@ -1151,14 +1159,24 @@ class MTLStep(StepBase):
             # AR / LTA: one loss element per node, back-propagated below with the constant w_t / numel -- known before the
             # loss is computed, so the cross entropy emits its gradient in the same launch (ops.loss_seed)
             n_loss = leaf.shape[0] if (t in ("ar", "lta", "pnr") and getattr(self, "_fused_loss", True)) else 0
+            oscc_one = self._one_pass_oscc_ok(t) and batches[t].y.dim() == 1
+            if oscc_one:
+                n_loss = int(batches[t].y.numel())  # one loss element per sequence
             with ops.loss_seed(self.weights[t] / n_loss if n_loss else None):
                 task, d = self.tasks[t], batches[t]
                 f = leaf if grouped else task.forward_features(leaf)  # grouped: ``leaf`` is the projected feature block
                 one_pass = None
-                if n_loss and self._one_pass_head_ok(t):
+                if oscc_one:
+                    one_pass = task.fused_head_loss(f, d, d.y, getattr(self.criteria[t], "label_smoothing", 0.0))
+                elif n_loss and self._one_pass_head_ok(t):
                     one_pass = task.fused_head_loss(f, d.y)  # one-logit classifier + BCE + their gradients: one row pass
                 if one_pass is not None:
                     v, logits = one_pass
+                elif oscc_one:  # (did not apply after all: the contraction path WITHOUT an announced seed, as before)
+                    with ops.loss_seed(None):
+                        logits = task.forward_logits(f, d)
+                        v = self.criteria[t](logits, d.y)
+                    n_loss = 0
                 else:
                     logits = task.forward_logits(f, d) if t == "oscc" else task.forward_logits(f)
                     v = self.criteria[t](logits, d.y)

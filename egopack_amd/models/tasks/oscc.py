@@ -47,6 +47,17 @@ class OSCCTask(ProjectionTask):
             logits = fuse_logits(logits, aux, self.average_logits)
         return logits
 
+    def fused_head_loss(self, features: torch.Tensor, batch, targets: torch.Tensor, smoothing: float = 0.0):
+        """(loss vector, logits) of ``CrossEntropy(reduction='none', ignore_index=-1)(forward_logits(features, batch), targets)``
+        with the classifier, the loss and their gradients in ONE launch behind the max pool (ops.linear2_ce), or None when it
+        does not apply (classifier dropout active, no announced loss seed, many sequences): a 2-logit classifier over a few
+        pooled rows is eleven short launches of matrix work otherwise."""
+        drop, lin = self.classifier[0], self.classifier[1]
+        if (self.training and getattr(drop, "p", 0) > 0) or not ops.linear2_ce_ok(int(targets.numel()), features, lin.weight):
+            return None
+        pooled = ops.segment_max(features, sequence_ptr(batch))
+        return ops.linear2_ce(pooled, lin.weight, lin.bias, targets, smoothing)
+
     def forward_aux_logits(self, features: torch.Tensor, batch, t: TaskLiteral = "ar", *args, **kwargs):
         if not hasattr(self, "aux_classifiers"):
             raise ValueError("OSCC task has no auxiliary classifiers.")

@@ -2484,6 +2484,59 @@ def linear1_bce(f, W, b, y):
     return _RowDotBCE.apply(f, W, b, y, float(_loss_seed["coef"]))
 
 
+class _RowDotCE2(torch.autograd.Function):
+    """Linear(features, 2) + cross entropy (reduction 'none', ignore_index -1) over FEW rows as ONE launch that also emits the
+    gradients (egk_rowdot_ce2): used when the seed of the loss vector's backward is known (``loss_seed``)."""
+
+    @staticmethod
+    def forward(ctx, f, W, b, y, smoothing, seed):
+        _need_gpu(f, W, y)
+        lib = _lib.load()
+        f = _c(f)
+        rows, cols = f.shape
+        w_op = _c(weight_operand(W, f.dtype))
+        bias = _f32c(b) if b is not None else None
+        y = y.contiguous()
+        logits = torch.empty(rows, 2, dtype=torch.float32, device=f.device)
+        loss = torch.empty(rows, dtype=torch.float32, device=f.device)
+        df = torch.empty_like(f)
+        slot_w, slot_b = _grad_slot(W), _grad_slot(b)
+        dw = slot_w if slot_w is not None else torch.zeros(W.shape, dtype=torch.float32, device=f.device)
+        db = (slot_b if slot_b is not None else torch.zeros(b.shape, dtype=torch.float32, device=f.device)) if b is not None else None
+        _ck(lib.egk_rowdot_ce2(_stream(), _p(f), _p(w_op), _p(bias), _p(y), _p(logits), _p(loss), _p(df), _p(dw), _p(db), rows, cols,
+                               float(smoothing), float(seed), _dt(f)), "egk_rowdot_ce2")
+        ctx.ret = (df, None if slot_w is not None else dw, None if (slot_b is not None or b is None) else db)
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        df, dw, db = ctx.ret  # computed in forward from the announced seed (the constant weight / numel of the objective)
+        ctx.ret = None
+        return df, dw, db, None, None, None
+
+
+def linear2_ce_ok(rows: int, f, W) -> bool:
+    """The one-launch two-logit head applies to ``rows`` pooled rows of the width / element type of ``f``: the backward seed is
+    announced (``loss_seed``), gradients are wanted, few rows, a width the row kernels take."""
+    return bool(_loss_seed["coef"] is not None and torch.is_grad_enabled() and f.is_cuda and f.dim() == 2 and W.dim() == 2
+                and W.shape[0] == 2 and W.shape[1] == f.shape[1] and f.shape[1] <= 4096 and f.shape[1] % 8 == 0
+                and 0 < rows <= _lib.load().egk_rowdot_ce2_max_rows()
+                and (f.dtype == torch.bfloat16 or (f.dtype == torch.float32 and _state["compute"] == F32)))
+
+
+def linear2_ce(f, W, b, y, smoothing: float = 0.0):
+    """(loss [R], logits [R, 2]) of CrossEntropy(reduction='none', ignore_index=-1, label_smoothing)(Linear(H, 2)(f), y) --
+    reference models/tasks/oscc.py:65-79 + main_temporal.py:291 -- in one launch that also writes d f, d W, d b.  Requires
+    ``linear2_ce_ok``."""
+    if not linear2_ce_ok(f.shape[0], f, W):
+        raise RuntimeError("linear2_ce: needs an announced loss seed (ops.loss_seed) and a small device feature matrix")
+    if y.dtype != torch.int64:
+        y = y.to(torch.int64)
+    return _RowDotCE2.apply(f, W, b, y, float(smoothing), float(_loss_seed["coef"]))
+
+
 class _OneHotSigmoid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, y, kind, alpha, gamma):

@@ -311,6 +311,15 @@ int32_t egk_rowdot_ws_rows(int32_t rows);
 int egk_rowdot_bce(egk_stream_t s, const void* f, const void* w, const float* bias, const int64_t* y, float* logits,
                    float* loss, void* df, float* ws, int32_t rows, int32_t cols, float seed, int32_t dtype);
 int egk_rowdot_reduce(egk_stream_t s, const float* ws, float* dw, float* db, int32_t rows, int32_t cols);
+/* Two-logit classifier + cross entropy over FEW rows in one launch (the OSCC head of the multi-task loop: max-pooled sequence
+ * features -> Linear(H, 2) -> nn.CrossEntropyLoss(reduction='none', ignore_index=-1), models/tasks/oscc.py:65-79 +
+ * main_temporal.py:291, :99): logits [rows, 2] = f w^T + bias, loss [rows] as egk_ce_fwd (label smoothing ``smoothing``), and --
+ * df != NULL -- from the announced backward seed: g = seed (softmax - target) rounded to the element type, df = g w,
+ * dw [2, cols] += g^T f, db [2] += column sums of g (rows in order: bitwise reproducible).  f, w, df: element type ``dtype``
+ * (w = the operand copy of the classifier's weight rows).  rows <= egk_rowdot_ce2_max_rows(). */
+int32_t egk_rowdot_ce2_max_rows(void);
+int egk_rowdot_ce2(egk_stream_t s, const void* f, const void* w, const float* bias, const int64_t* y, float* logits, float* loss,
+                   void* df, float* dw, float* db, int32_t rows, int32_t cols, float smoothing, float seed, int32_t dtype);
 /* Grouped row LayerNorm(+ReLU): n_groups (<= 4) consecutive row ranges [row_ptr[g], row_ptr[g+1]) of ONE [rows, cols]
  * matrix, each with its own (w, b) -- the LayerNorms of the per-task projection heads (models/tasks/task.py:20-21) in one
  * launch.  No dropout.  bwd writes dx and per-workgroup partial rows of dw / db:

@@ -653,6 +653,58 @@ def test_one_logit_head_with_bce_in_one_row_pass(ops, rows, cols, mode):
         ops.set_compute("f32")
 
 
+@pytest.mark.parametrize("rows,cols,mode,smoothing", [(16, 1024, "bf16", 0.0), (64, 1024, "bf16", 0.0), (16, 1024, "f32", 0.0),
+                                                      (37, 264, "f32", 0.1), (256, 1024, "bf16", 0.1)])
+def test_two_logit_head_with_cross_entropy_in_one_launch(ops, rows, cols, mode, smoothing):
+    """ops.linear2_ce = CrossEntropy(reduction='none', ignore_index=-1, label_smoothing)(Linear(H, 2)(f), y) -- the OSCC head behind
+    its max pool, models/tasks/oscc.py:65-79 + main_temporal.py:291 -- plus d f, d W, d b for the announced backward seed, in ONE
+    launch: against torch on the same (rounded) operands, with ignored rows, and against the contraction path of this library
+    (the eleven launches it replaces)."""
+    g = gen(rows + cols + int(smoothing * 10))
+    f = torch.randn(rows, cols, generator=g)
+    W, b = torch.randn(2, cols, generator=g) * 0.05, torch.randn(2, generator=g)
+    y = torch.randint(0, 2, (rows,), generator=g)
+    y[::5] = -1  # ignored sequences: loss 0, no gradient, still counted by the caller's mean
+    seed = 0.7 / rows
+    ops.set_compute(mode)
+    try:
+        if mode == "bf16":
+            f, Wr = r16(f), r16(W)
+        else:
+            Wr = W
+        cf, cW, cb = f.clone().requires_grad_(True), Wr.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        z = cf @ cW.t() + cb
+        ref = F.cross_entropy(z, y, reduction="none", ignore_index=-1, label_smoothing=smoothing)
+        ref.backward(torch.full_like(ref, seed))
+        df = f.to(DEV).to(ops.act_dtype()).requires_grad_(True)
+        dW, db = W.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+        with ops.loss_seed(seed):
+            assert ops.linear2_ce_ok(rows, df, dW)
+            loss, logits = ops.linear2_ce(df, dW, db, y.to(DEV), smoothing)
+        loss.backward(torch.full_like(loss, seed))
+        lt = dict(rtol=1e-4, atol=1e-4) if mode == "f32" else dict(rtol=1e-2, atol=2e-2)
+        torch.testing.assert_close(logits.cpu(), z.detach(), **lt)
+        torch.testing.assert_close(loss.detach().cpu(), ref.detach(), **lt)
+        assert float(loss.detach()[::5].abs().max()) == 0.0 and float(df.grad[::5].float().abs().max()) == 0.0
+        gscale, wscale = float(cf.grad.abs().max()), float(cW.grad.abs().max())
+        assert (df.grad.float().cpu() - cf.grad).abs().max() <= (1e-5 if mode == "f32" else 1.5e-2) * gscale
+        assert (dW.grad.cpu() - cW.grad).abs().max() <= (2e-5 if mode == "f32" else 1.5e-2) * wscale
+        assert (db.grad.cpu() - cb.grad).abs().max() <= (2e-5 if mode == "f32" else 1e-2) * max(1.0, float(cb.grad.abs().max()) * 100)
+        # the path it replaces: classifier contraction + cross entropy kernels -- same values up to summation order
+        df2 = f.to(DEV).to(ops.act_dtype()).requires_grad_(True)
+        dW2, db2 = W.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+        z2 = ops.linear(df2, dW2, db2, out_f32=True)
+        l2 = ops.cross_entropy(z2, y.to(DEV), smoothing)
+        l2.backward(torch.full_like(l2, seed))
+        torch.testing.assert_close(loss.detach(), l2.detach(), **(dict(rtol=1e-4, atol=1e-5) if mode == "f32" else dict(rtol=5e-3, atol=5e-3)))
+        assert (df.grad.float() - df2.grad.float()).abs().max().item() <= (1e-5 if mode == "f32" else 1e-2) * gscale
+        assert (dW.grad - dW2.grad).abs().max().item() <= (2e-5 if mode == "f32" else 1e-2) * wscale
+        with ops.loss_seed(seed):  # too many rows for one workgroup: the caller keeps the contraction path
+            assert not ops.linear2_ce_ok(257, df, dW)
+    finally:
+        ops.set_compute("f32")
+
+
 def test_weighted_mean_sum_and_sum_tensors(ops):
     g = gen(54)
     a, b = torch.randn(100, generator=g), torch.randn(37, generator=g)
