@@ -90,7 +90,8 @@ SIGNATURES = {
     "egk_rowdot_bce": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32]),
     "egk_rowdot_reduce": (C.c_int, [vp, vp, vp, vp, i32, i32]),
     "egk_rowdot_ce2_max_rows": (i32, []),
-    "egk_rowdot_ce2": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32]),
+    "egk_rowdot_ce2": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32]),
+    "egk_rowdot_ce2_multi": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, i32]),
     "egk_graphln_stats_blocks": (i32, [i32]),
     "egk_graphln_stats": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32]),
     "egk_graphln_bwd_stats": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, i32]),

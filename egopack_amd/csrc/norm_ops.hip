@@ -795,73 +795,98 @@ static inline int row_grid_wide(int rows) {  // pure streaming row kernels
 // logits[r, c] = f[r, :] . w[c, :] + bias[c];  loss[r] = lse - (1 - eps) z_y - eps / 2 (z_0 + z_1)  (0 for y = -1): ce_fwd_kernel;
 // g[r, c] = seed (softmax_c - (c == y ? 1 - eps : 0) - eps / 2) rounded to T (ce_bwd_kernel + the operand cast of the contraction
 // path);  df[r, :] = g[r, 0] w[0, :] + g[r, 1] w[1, :];  dw[c, :] += sum_r g[r, c] f[r, :];  db[c] += sum_r g[r, c], rows in order.
-// ONE workgroup, a thread per four columns of every row -- eleven launches of the
+// TWO launches (a workgroup per row; a workgroup per 256 columns and source) -- eleven launches of the
 // contraction path (a split 16 x 2 x 1024 contraction and its reduce, loss, loss gradient, cast, dX, two column sums, dW) sat on
 // the critical path of BASELINE config 5 between the backbone's forward and backward.
-constexpr int CE2_MAX_ROWS = 256;
+constexpr int CE2_MAX_ROWS = 256, CE2_MAX_SRC = 4;
+// S sources (the EgoPack head: the primary pooled features and one pooled GraphONE feature per auxiliary task, each with its own
+// classifier; models/tasks/oscc.py:70-78): z = scale * sum_k (f_k w_k^T + bias_k), scale = 1 / S for ``average_logits``; every
+// source receives the SAME rounded logit gradient g (the contraction path casts scale * dlogits once per source: equal values).
+struct CE2Sources {
+    const void* f[CE2_MAX_SRC];
+    const void* w[CE2_MAX_SRC];
+    const float* bias[CE2_MAX_SRC];
+    void* df[CE2_MAX_SRC];
+    float* dw[CE2_MAX_SRC];
+    float* db[CE2_MAX_SRC];
+    int n;
+};
+// Launch 1, one workgroup per ROW, wave k = source k: the row's dot products (a wave walks its source's row, 4 columns per lane and
+// step), the fused logits, the loss, the rounded logit gradient g (also kept in ``gws`` [rows][2] for launch 2), and df_k = g w_k.
 template <typename T>
-__global__ __launch_bounds__(256) void rowdot_ce2_kernel(const T* __restrict__ f, const T* __restrict__ w, const float* __restrict__ bias,
-                                                         const long long* __restrict__ y, float* __restrict__ logits,
-                                                         float* __restrict__ loss, T* __restrict__ df, float* __restrict__ dw,
-                                                         float* __restrict__ db, int rows, int cols, float smoothing, float seed) {
-    // column-parallel: a thread owns four columns (per pass of 1024) for EVERY row, sixteen rows at a time -- all their loads in
-    // flight together; a row's two dot products meet through wave sums + LDS.  (A wave per row walked the rows one dependent
-    // round trip after the other: 40 us for 16 x 1024.)
-    constexpr int RC = 16;
-    __shared__ float gq[CE2_MAX_ROWS][2];
-    __shared__ float part[WPB][RC][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void rowdot_ce2_rows_kernel(const CE2Sources S, const long long* __restrict__ y,
+                                                              float* __restrict__ logits, float* __restrict__ loss,
+                                                              float* __restrict__ gws, int cols, float scale, float smoothing,
+                                                              float seed) {
+    __shared__ float part[CE2_MAX_SRC][2];
+    __shared__ float gsh[2];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, k = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
-    const float sm = smoothing > 0.f ? smoothing * 0.5f : 0.f;
-    for (int r0 = 0; r0 < rows; r0 += RC) {
-        float p0[RC], p1[RC];
-#pragma unroll
-        for (int r = 0; r < RC; ++r) p0[r] = p1[r] = 0.f;
-        for (int c = threadIdx.x * 4; c < cols; c += 1024) {
-            const float4 w0 = ld4t(w, c, cols, vec), w1 = ld4t(w + cols, c, cols, vec);
-            float4 x[RC];
-#pragma unroll
-            for (int r = 0; r < RC; ++r)
-                x[r] = r0 + r < rows ? ld4t(f + (long long)(r0 + r) * cols, c, cols, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int r = 0; r < RC; ++r) {
-                p0[r] = fmaf(x[r].x, w0.x, p0[r]); p0[r] = fmaf(x[r].y, w0.y, p0[r]);
-                p0[r] = fmaf(x[r].z, w0.z, p0[r]); p0[r] = fmaf(x[r].w, w0.w, p0[r]);
-                p1[r] = fmaf(x[r].x, w1.x, p1[r]); p1[r] = fmaf(x[r].y, w1.y, p1[r]);
-                p1[r] = fmaf(x[r].z, w1.z, p1[r]); p1[r] = fmaf(x[r].w, w1.w, p1[r]);
-            }
+    const bool on = k < S.n;
+    const T* __restrict__ f = on ? (const T*)S.f[k] + (long long)row * cols : nullptr;
+    const T* __restrict__ w = on ? (const T*)S.w[k] : nullptr;
+    float p0 = 0.f, p1 = 0.f;
+    if (on)
+        for (int c = lane * 4; c < cols; c += 256) {
+            const float4 x = ld4t(f, c, cols, vec), w0 = ld4t(w, c, cols, vec), w1 = ld4t(w + cols, c, cols, vec);
+            p0 = fmaf(x.x, w0.x, p0); p0 = fmaf(x.y, w0.y, p0); p0 = fmaf(x.z, w0.z, p0); p0 = fmaf(x.w, w0.w, p0);
+            p1 = fmaf(x.x, w1.x, p1); p1 = fmaf(x.y, w1.y, p1); p1 = fmaf(x.z, w1.z, p1); p1 = fmaf(x.w, w1.w, p1);
         }
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-            const float s0 = wave_sum(p0[r]), s1 = wave_sum(p1[r]);
-            if (lane == 0) {
-                part[wave][r][0] = s0;
-                part[wave][r][1] = s1;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < RC && r0 + (int)threadIdx.x < rows) {
-            const int r = threadIdx.x, row = r0 + r;
-            const float z0 = ((part[0][r][0] + part[1][r][0]) + (part[2][r][0] + part[3][r][0])) + (bias ? bias[0] : 0.f);
-            const float z1 = ((part[0][r][1] + part[1][r][1]) + (part[2][r][1] + part[3][r][1])) + (bias ? bias[1] : 0.f);
-            logits[row * 2 + 0] = z0;
-            logits[row * 2 + 1] = z1;
-            const float mx = fmaxf(z0, z1);
-            const float l = mx + logf(expf(z0 - mx) + expf(z1 - mx));
-            const long long t = y[row];
-            const bool live = t >= 0 && t < 2;
-            loss[row] = live ? l - (1.f - smoothing) * (t == 0 ? z0 : z1) - (smoothing > 0.f ? sm * (z0 + z1) : 0.f) : 0.f;
-            T g0, g1;  // the gradient in the operand element type
-            st1t(&g0, live ? seed * (expf(z0 - l) - (t == 0 ? 1.f - smoothing : 0.f) - sm) : 0.f);
-            st1t(&g1, live ? seed * (expf(z1 - l) - (t == 1 ? 1.f - smoothing : 0.f) - sm) : 0.f);
-            gq[row][0] = ld1t(&g0);
-            gq[row][1] = ld1t(&g1);
-        }
-        __syncthreads();
+    p0 = wave_sum(p0);
+    p1 = wave_sum(p1);
+    if (lane == 0) {
+        part[k][0] = on ? p0 + (S.bias[k] ? S.bias[k][0] : 0.f) : 0.f;
+        part[k][1] = on ? p1 + (S.bias[k] ? S.bias[k][1] : 0.f) : 0.f;
     }
-    if (!df) return;
-    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
-        const float4 w0 = ld4t(w, c, cols, vec), w1 = ld4t(w + cols, c, cols, vec);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int q = 0; q < S.n; ++q) {  // source order
+            s0 += part[q][0];
+            s1 += part[q][1];
+        }
+        const float z0 = scale * s0, z1 = scale * s1;
+        logits[row * 2 + 0] = z0;
+        logits[row * 2 + 1] = z1;
+        const float sm = smoothing > 0.f ? smoothing * 0.5f : 0.f;
+        const float mx = fmaxf(z0, z1);
+        const float l = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+        const long long t = y[row];
+        const bool live = t >= 0 && t < 2;
+        loss[row] = live ? l - (1.f - smoothing) * (t == 0 ? z0 : z1) - (smoothing > 0.f ? sm * (z0 + z1) : 0.f) : 0.f;
+        T g0, g1;  // the gradient of every source's logits, in the operand element type
+        st1t(&g0, live ? scale * (seed * (expf(z0 - l) - (t == 0 ? 1.f - smoothing : 0.f) - sm)) : 0.f);
+        st1t(&g1, live ? scale * (seed * (expf(z1 - l) - (t == 1 ? 1.f - smoothing : 0.f) - sm)) : 0.f);
+        gsh[0] = ld1t(&g0);
+        gsh[1] = ld1t(&g1);
+        if (gws) {
+            gws[row * 2 + 0] = gsh[0];
+            gws[row * 2 + 1] = gsh[1];
+        }
+    }
+    if (!gws) return;  // (uniform: forward only)
+    __syncthreads();
+    if (on && S.df[k]) {
+        const float g0 = gsh[0], g1 = gsh[1];
+        T* __restrict__ df = (T*)S.df[k] + (long long)row * cols;
+        for (int c = lane * 4; c < cols; c += 256) {
+            const float4 w0 = ld4t(w, c, cols, vec), w1 = ld4t(w + cols, c, cols, vec);
+            st4t(df, c, cols, vec,
+                 make_float4(fmaf(g1, w1.x, g0 * w0.x), fmaf(g1, w1.y, g0 * w0.y), fmaf(g1, w1.z, g0 * w0.z), fmaf(g1, w1.w, g0 * w0.w)));
+        }
+    }
+}
+
+// Launch 2, workgroup = (256 columns, source): dw_k[c, :] += sum_r g[r, c] f_k[r, :] and db_k += sum_r g[r, :], rows in order,
+// sixteen rows in flight per lane.
+template <typename T>
+__global__ __launch_bounds__(64) void rowdot_ce2_cols_kernel(const CE2Sources S, const float* __restrict__ gws, int rows, int cols) {
+    constexpr int RC = 16;
+    const int k = blockIdx.y, c = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const bool vec = (cols & 3) == 0;
+    const T* __restrict__ f = (const T*)S.f[k];
+    float* __restrict__ dw = S.dw[k];
+    if (dw && c < cols) {
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
         for (int r0 = 0; r0 < rows; r0 += RC) {
             float4 x[RC];
@@ -871,9 +896,7 @@ __global__ __launch_bounds__(256) void rowdot_ce2_kernel(const T* __restrict__ f
 #pragma unroll
             for (int r = 0; r < RC; ++r) {
                 if (r0 + r >= rows) break;
-                const float g0 = gq[r0 + r][0], g1 = gq[r0 + r][1];
-                st4t(df + (long long)(r0 + r) * cols, c, cols, vec,
-                     make_float4(fmaf(g1, w1.x, g0 * w0.x), fmaf(g1, w1.y, g0 * w0.y), fmaf(g1, w1.z, g0 * w0.z), fmaf(g1, w1.w, g0 * w0.w)));
+                const float g0 = gws[(r0 + r) * 2 + 0], g1 = gws[(r0 + r) * 2 + 1];
                 a0.x = fmaf(g0, x[r].x, a0.x); a0.y = fmaf(g0, x[r].y, a0.y); a0.z = fmaf(g0, x[r].z, a0.z); a0.w = fmaf(g0, x[r].w, a0.w);
                 a1.x = fmaf(g1, x[r].x, a1.x); a1.y = fmaf(g1, x[r].y, a1.y); a1.z = fmaf(g1, x[r].z, a1.z); a1.w = fmaf(g1, x[r].w, a1.w);
             }
@@ -886,10 +909,10 @@ __global__ __launch_bounds__(256) void rowdot_ce2_kernel(const T* __restrict__ f
                 dw[cols + c + t] += v1[t];
             }
     }
-    if (db && threadIdx.x < 2) {
+    if (S.db[k] && blockIdx.x == 0 && threadIdx.x < 2) {
         float t = 0.f;
-        for (int row = 0; row < rows; ++row) t += gq[row][threadIdx.x];
-        db[threadIdx.x] += t;
+        for (int row = 0; row < rows; ++row) t += gws[row * 2 + threadIdx.x];
+        S.db[k][threadIdx.x] += t;
     }
 }
 
@@ -1240,18 +1263,48 @@ int egk_rowdot_bce(egk_stream_t stream, const void* f, const void* w, const floa
 
 int32_t egk_rowdot_ce2_max_rows(void) { return CE2_MAX_ROWS; }
 
-int egk_rowdot_ce2(egk_stream_t stream, const void* f, const void* w, const float* bias, const int64_t* y, float* logits, float* loss,
-                   void* df, float* dw, float* db, int32_t rows, int32_t cols, float smoothing, float seed, int32_t dtype) {
-    EGK_REQUIRE(f && w && y && logits && loss, "egk_rowdot_ce2: null pointer");
-    EGK_REQUIRE(!df || dw, "egk_rowdot_ce2: gradients need dw");
-    EGK_REQUIRE(rows >= 0 && rows <= CE2_MAX_ROWS && cols >= 1, "egk_rowdot_ce2: at most %d rows", CE2_MAX_ROWS);
+int egk_rowdot_ce2_multi(egk_stream_t stream, int32_t n_src, const void* const* f, const void* const* w, const float* const* bias,
+                         const int64_t* y, float* logits, float* loss, void* const* df, float* const* dw, float* const* db,
+                         float* gws, int32_t rows, int32_t cols, int32_t average, float smoothing, float seed, int32_t dtype) {
+    // seed < 0 is not a gradient scale: the sign bit of ``average`` is not available either -- the phase rides in bits 1-2 of ``average``
+    const int phase = (average >> 1) & 3;  // 0: both launches; 1: the row launch only; 2: the column launch only (gws from a phase-1 call)
+    average &= 1;
+    EGK_REQUIRE(f && w && y && logits && loss && n_src >= 1 && n_src <= CE2_MAX_SRC, "egk_rowdot_ce2_multi: 1 .. %d sources", CE2_MAX_SRC);
+    EGK_REQUIRE(rows >= 0 && rows <= CE2_MAX_ROWS && cols >= 1, "egk_rowdot_ce2_multi: at most %d rows", CE2_MAX_ROWS);
     if (rows == 0) return 0;
+    CE2Sources S;
+    bool want = false, want_w = false;
+    for (int k = 0; k < CE2_MAX_SRC; ++k) {
+        const bool in = k < n_src;
+        S.f[k] = in ? f[k] : nullptr;
+        S.w[k] = in ? w[k] : nullptr;
+        S.bias[k] = (in && bias) ? bias[k] : nullptr;
+        S.df[k] = (in && df) ? df[k] : nullptr;
+        S.dw[k] = (in && dw) ? dw[k] : nullptr;
+        S.db[k] = (in && db) ? db[k] : nullptr;
+        EGK_REQUIRE(!in || (S.f[k] && S.w[k]), "egk_rowdot_ce2_multi: null source");
+        want = want || S.df[k] || S.dw[k] || S.db[k];
+        want_w = want_w || S.dw[k] || S.db[k];
+    }
+    S.n = n_src;
+    EGK_REQUIRE(!want || gws, "egk_rowdot_ce2_multi: gradients need the [rows][2] workspace");
     hipStream_t s = (hipStream_t)stream;
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
-    ProfScope prof(KID_CE_FWD, s, 4.0 * rows * cols * (df ? 3 : 1), eb * rows * cols * (df ? 3 : 1));
-    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(rowdot_ce2_kernel<T>, dim3(1), dim3(256), 0, s, (const T*)f, (const T*)w, bias,
-                                             (const long long*)y, logits, loss, (T*)df, dw, db, rows, cols, smoothing, seed));
-    return check_launch("egk_rowdot_ce2");
+    ProfScope prof(KID_CE_FWD, s, 4.0 * rows * cols * n_src * (want ? 3 : 1), eb * rows * cols * n_src * (want ? 3 : 1));
+    EGK_DISPATCH_T(dtype, {
+        if (phase != 2)
+            hipLaunchKernelGGL(rowdot_ce2_rows_kernel<T>, dim3(rows), dim3(256), 0, s, S, (const long long*)y, logits, loss,
+                               want ? gws : nullptr, cols, average ? 1.f / n_src : 1.f, smoothing, seed);
+        if (want_w && phase != 1) hipLaunchKernelGGL(rowdot_ce2_cols_kernel<T>, dim3(cdiv(cols, 256), n_src), dim3(64), 0, s, S, gws, rows, cols);
+    });
+    return check_launch("egk_rowdot_ce2_multi");
+}
+
+int egk_rowdot_ce2(egk_stream_t stream, const void* f, const void* w, const float* bias, const int64_t* y, float* logits, float* loss,
+                   void* df, float* dw, float* db, float* gws, int32_t rows, int32_t cols, float smoothing, float seed, int32_t dtype) {
+    EGK_REQUIRE(f && w && y && logits && loss, "egk_rowdot_ce2: null pointer");
+    EGK_REQUIRE(!df || dw, "egk_rowdot_ce2: gradients need dw");
+    return egk_rowdot_ce2_multi(stream, 1, &f, &w, &bias, y, logits, loss, &df, &dw, &db, gws, rows, cols, 0, smoothing, seed, dtype);
 }
 
 int egk_rowdot_reduce(egk_stream_t stream, const float* ws, float* dw, float* db, int32_t rows, int32_t cols) {

@@ -51,7 +51,7 @@ def init_single_rank_group(backend: str = "nccl") -> None:
     dist.init_process_group(backend, rank=0, world_size=1)
 
 
-def quiesce_before_capture(group=None, settle_s: float = 0.35) -> None:
+def quiesce_before_capture(group=None, settle_s: float = 1.0) -> None:
     """Let the RCCL process group's WATCHDOG retire every collective issued so far before a hipGraph capture starts.
 
     Root cause of the round-3 driver abort (reproduced 3 times in 9 on fresh boxes, tools/round4/repro_abort.sh; the C++ trace is

@@ -1387,6 +1387,16 @@ class EgoPackStep(StepBase):
                 aux_in = (dict(zip(others, grouped)) if grouped is not None
                           else {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others})
         aux, closest = self.graphone.interact(aux_in)
+        if (primary == "oscc" and getattr(task, "loss_func", None) == "ce" and hasattr(task, "fused_head_loss") and data.y.dim() == 1
+                and "oscc_one_pass" not in getattr(self, "_dev_off", ()) and "rowdot_head" not in getattr(self, "_dev_off", ())):
+            # the four 2-logit classifiers (primary + one per auxiliary task) behind their max pools, the logit fusion, the loss and
+            # every gradient as ONE launch: the objective is sum_t w_t mean(loss_t), so the loss vector's backward seed is the
+            # constant w / B (ops.loss_seed) -- ~35 short launches of the contraction path otherwise
+            with ops.loss_seed(self.weights[primary] / max(int(data.y.numel()), 1)):
+                one = task.fused_head_loss(f_primary, data, data.y, smoothing=0.1, aux_features=aux,
+                                           aux_streams=getattr(self.graphone, "stream_of", None))
+            if one is not None:
+                return one[0], one[1], aux, closest
         if primary == "oscc":
             logits = task.forward_logits(features=f_primary, batch=data, aux_features=aux)
         else:

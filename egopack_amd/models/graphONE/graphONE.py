@@ -90,6 +90,7 @@ class GraphONE(nn.Module):
             while len(self._task_streams) < len(items):
                 self._task_streams.append(torch.cuda.Stream())
                 ops.exclude_wgrad_streams(self._task_streams[-1:])
+            self.stream_of = {task: st for st, (task, _) in zip(self._task_streams, items)}  # (the stream each output was made on)
             for st, (task, f) in zip(self._task_streams, items):
                 st.wait_event(fork)
                 f.record_stream(st)

@@ -47,16 +47,41 @@ class OSCCTask(ProjectionTask):
             logits = fuse_logits(logits, aux, self.average_logits)
         return logits
 
-    def fused_head_loss(self, features: torch.Tensor, batch, targets: torch.Tensor, smoothing: float = 0.0):
-        """(loss vector, logits) of ``CrossEntropy(reduction='none', ignore_index=-1)(forward_logits(features, batch), targets)``
-        with the classifier, the loss and their gradients in ONE launch behind the max pool (ops.linear2_ce), or None when it
-        does not apply (classifier dropout active, no announced loss seed, many sequences): a 2-logit classifier over a few
-        pooled rows is eleven short launches of matrix work otherwise."""
-        drop, lin = self.classifier[0], self.classifier[1]
-        if (self.training and getattr(drop, "p", 0) > 0) or not ops.linear2_ce_ok(int(targets.numel()), features, lin.weight):
+    def fused_head_loss(self, features: torch.Tensor, batch, targets: torch.Tensor, smoothing: float = 0.0,
+                        aux_features: Optional[Dict[TaskLiteral, torch.Tensor]] = None, aux_streams=None):
+        """(loss vector, logits) of ``CrossEntropy(reduction='none', ignore_index=-1, label_smoothing)(forward_logits(features,
+        batch, aux_features), targets)`` with every classifier, the logit fusion, the loss and their gradients in ONE launch behind
+        the max pools (ops.linear2_ce / linear2_ce_multi), or None when it does not apply (classifier dropout active, no announced
+        loss seed, many sequences, more than three auxiliary tasks): 2-logit classifiers over a few pooled rows are dozens of
+        short launches of matrix work otherwise."""
+        heads = [self.classifier] + ([self.aux_classifiers[t] for t in aux_features] if aux_features else [])
+        feats = [features] + (list(aux_features.values()) if aux_features else [])
+        if len(heads) > 4 or any(self.training and getattr(h[0], "p", 0) > 0 for h in heads):
             return None
-        pooled = ops.segment_max(features, sequence_ptr(batch))
-        return ops.linear2_ce(pooled, lin.weight, lin.bias, targets, smoothing)
+        if not all(ops.linear2_ce_ok(int(targets.numel()), f, h[1].weight) for f, h in zip(feats, heads)):
+            return None
+        ptr = sequence_ptr(batch)
+        # an auxiliary feature is pooled on the stream that made it (``aux_streams``: GraphONE's per-task streams), so that autograd
+        # runs that pool's backward -- the head of the task's GraphONE backward chain -- there too: four pools on one stream hang
+        # the three chains off consecutive nodes of that stream, and the runtime's replay then puts all three on ONE queue
+        names = [None] + (list(aux_features) if aux_features else [])
+        main = torch.cuda.current_stream() if features.is_cuda else None
+        pooled = []
+        for t, f in zip(names, feats):
+            st = aux_streams.get(t) if (aux_streams and t is not None) else None
+            if st is None or main is None:
+                pooled.append(ops.segment_max(f, ptr))
+                continue
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                p = ops.segment_max(f, ptr)
+            main.wait_stream(st)
+            p.record_stream(main)
+            pooled.append(p)
+        if len(heads) == 1:
+            return ops.linear2_ce(pooled[0], heads[0][1].weight, heads[0][1].bias, targets, smoothing)
+        return ops.linear2_ce_multi(pooled, [h[1].weight for h in heads], [h[1].bias for h in heads], targets, smoothing,
+                                    average=bool(getattr(self, "average_logits", False)))
 
     def forward_aux_logits(self, features: torch.Tensor, batch, t: TaskLiteral = "ar", *args, **kwargs):
         if not hasattr(self, "aux_classifiers"):

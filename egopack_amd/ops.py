@@ -2503,8 +2503,9 @@ class _RowDotCE2(torch.autograd.Function):
         slot_w, slot_b = _grad_slot(W), _grad_slot(b)
         dw = slot_w if slot_w is not None else torch.zeros(W.shape, dtype=torch.float32, device=f.device)
         db = (slot_b if slot_b is not None else torch.zeros(b.shape, dtype=torch.float32, device=f.device)) if b is not None else None
-        _ck(lib.egk_rowdot_ce2(_stream(), _p(f), _p(w_op), _p(bias), _p(y), _p(logits), _p(loss), _p(df), _p(dw), _p(db), rows, cols,
-                               float(smoothing), float(seed), _dt(f)), "egk_rowdot_ce2")
+        gws = torch.empty(rows, 2, dtype=torch.float32, device=f.device)
+        _ck(lib.egk_rowdot_ce2(_stream(), _p(f), _p(w_op), _p(bias), _p(y), _p(logits), _p(loss), _p(df), _p(dw), _p(db), _p(gws), rows,
+                               cols, float(smoothing), float(seed), _dt(f)), "egk_rowdot_ce2")
         ctx.ret = (df, None if slot_w is not None else dw, None if (slot_b is not None or b is None) else db)
         ctx.mark_non_differentiable(logits)
         ctx.set_materialize_grads(False)
@@ -2515,6 +2516,60 @@ class _RowDotCE2(torch.autograd.Function):
         df, dw, db = ctx.ret  # computed in forward from the announced seed (the constant weight / numel of the objective)
         ctx.ret = None
         return df, dw, db, None, None, None
+
+
+class _RowDotCE2Multi(torch.autograd.Function):
+    """``_RowDotCE2`` over n sources with their own classifiers: logits = (mean | sum)_k Linear_k(f_k) (egk_rowdot_ce2_multi)."""
+
+    @staticmethod
+    def forward(ctx, y, smoothing, average, seed, n, *tensors):
+        fs, Ws, bs = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        _need_gpu(fs[0], y)
+        lib = _lib.load()
+        fs = [_c(f) for f in fs]
+        rows, cols = fs[0].shape
+        w_ops = [_c(weight_operand(W, fs[0].dtype)) for W in Ws]
+        biases = [(_f32c(b) if b is not None else None) for b in bs]
+        y = y.contiguous()
+        dev = fs[0].device
+        logits = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+        loss = torch.empty(rows, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[5:]
+        need_f, need_w, need_b = need[:n], need[n:2 * n], need[2 * n:3 * n]
+        dfs = [torch.empty_like(f) if nf else None for f, nf in zip(fs, need_f)]
+        slots_w, slots_b = [_grad_slot(W) for W in Ws], [_grad_slot(b) for b in bs]
+        dws = [(sw if sw is not None else torch.zeros(W.shape, dtype=torch.float32, device=dev)) if nw else None
+               for W, sw, nw in zip(Ws, slots_w, need_w)]
+        dbs = [((sb if sb is not None else torch.zeros(b.shape, dtype=torch.float32, device=dev)) if (b is not None and nb) else None)
+               for b, sb, nb in zip(bs, slots_b, need_b)]
+        arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else 0) for t in ts])
+        gws = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+        _ck(lib.egk_rowdot_ce2_multi(_stream(), n, arr(fs), arr(w_ops), arr(biases), _p(y), _p(logits), _p(loss), arr(dfs), arr(dws),
+                                     arr(dbs), _p(gws), rows, cols, int(bool(average)), float(smoothing), float(seed), _dt(fs[0])),
+            "egk_rowdot_ce2_multi")
+        ctx.keep = (fs, w_ops, biases, gws)
+        ctx.ret = (dfs, [None if (sw is not None) else dw for dw, sw in zip(dws, slots_w)],
+                   [None if (sb is not None) else db for db, sb in zip(dbs, slots_b)])
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        dfs, dws, dbs = ctx.ret  # computed in forward from the announced seed
+        ctx.ret = ctx.keep = None
+        return (None, None, None, None, None, *dfs, *dws, *dbs)
+
+
+def linear2_ce_multi(fs, Ws, bs, y, smoothing: float = 0.0, average: bool = False):
+    """(loss [R], logits [R, 2]) of CrossEntropy(reduction='none', ignore_index=-1, label_smoothing)(fuse_k Linear_k(f_k), y) with
+    fuse = mean (``average``) or sum over the sources -- reference models/tasks/oscc.py:65-79 with ``aux_features`` -- in one launch
+    that also writes every d f_k, d W_k, d b_k.  Requires ``linear2_ce_ok`` for every source."""
+    if not all(linear2_ce_ok(f.shape[0], f, W) for f, W in zip(fs, Ws)) or not (1 <= len(fs) <= 4):
+        raise RuntimeError("linear2_ce_multi: needs an announced loss seed (ops.loss_seed) and 1 .. 4 small device feature matrices")
+    if y.dtype != torch.int64:
+        y = y.to(torch.int64)
+    return _RowDotCE2Multi.apply(y, float(smoothing), bool(average), float(_loss_seed["coef"]), len(fs), *fs, *Ws, *bs)
 
 
 def linear2_ce_ok(rows: int, f, W) -> bool:

@@ -316,10 +316,21 @@ int egk_rowdot_reduce(egk_stream_t s, const float* ws, float* dw, float* db, int
  * main_temporal.py:291, :99): logits [rows, 2] = f w^T + bias, loss [rows] as egk_ce_fwd (label smoothing ``smoothing``), and --
  * df != NULL -- from the announced backward seed: g = seed (softmax - target) rounded to the element type, df = g w,
  * dw [2, cols] += g^T f, db [2] += column sums of g (rows in order: bitwise reproducible).  f, w, df: element type ``dtype``
- * (w = the operand copy of the classifier's weight rows).  rows <= egk_rowdot_ce2_max_rows(). */
+ * (w = the operand copy of the classifier's weight rows).  gws: float [rows][2] scratch (the rounded logit gradients between the
+ * row launch and the column launch), required with gradients.  rows <= egk_rowdot_ce2_max_rows(). */
 int32_t egk_rowdot_ce2_max_rows(void);
 int egk_rowdot_ce2(egk_stream_t s, const void* f, const void* w, const float* bias, const int64_t* y, float* logits, float* loss,
-                   void* df, float* dw, float* db, int32_t rows, int32_t cols, float smoothing, float seed, int32_t dtype);
+                   void* df, float* dw, float* db, float* gws, int32_t rows, int32_t cols, float smoothing, float seed, int32_t dtype);
+/* The same with n_src <= 4 sources, each with its own classifier: logits = scale * sum_k (f_k w_k^T + bias_k), scale = 1 / n_src
+ * when ``average`` (the EgoPack head: the primary pooled features + one pooled GraphONE feature per auxiliary task, fused as
+ * ``stack([...]).mean(0)`` / ``.sum(0)``; models/tasks/oscc.py:70-78, main_egopack.py:279), the loss of egk_rowdot_ce2 on them, and
+ * per source df_k = g w_k, dw_k += g^T f_k, db_k += column sums of g with the ONE rounded g = scale * seed (softmax - target).
+ * Pointer arrays of n_src entries (host memory; bias / df / dw / db arrays or entries may be NULL).  ``average`` bit 0: mean
+ * instead of sum; bits 1-2: 0 = both launches, 1 = the row launch only (logits, loss, df, gws), 2 = the column launch only (dw, db
+ * from the gws of an earlier phase-1 call with the same sources): a caller may issue the parameter gradients in its backward. */
+int egk_rowdot_ce2_multi(egk_stream_t s, int32_t n_src, const void* const* f, const void* const* w, const float* const* bias,
+                         const int64_t* y, float* logits, float* loss, void* const* df, float* const* dw, float* const* db,
+                         float* gws, int32_t rows, int32_t cols, int32_t average, float smoothing, float seed, int32_t dtype);
 /* Grouped row LayerNorm(+ReLU): n_groups (<= 4) consecutive row ranges [row_ptr[g], row_ptr[g+1]) of ONE [rows, cols]
  * matrix, each with its own (w, b) -- the LayerNorms of the per-task projection heads (models/tasks/task.py:20-21) in one
  * launch.  No dropout.  bwd writes dx and per-workgroup partial rows of dw / db:

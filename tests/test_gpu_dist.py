@@ -101,6 +101,13 @@ def test_bench_exchange_dry_run_in_both_capture_modes(mode):
     env = {"EGK_TEST_KILL_PROBE": "0"} if mode == "auto_probe_killed" else None
     out, err = _bench(["--exchange-dry-run", "8", "--exchange-graph", "staged" if mode == "staged" else "auto"], env=env)
     xg = out["config"]["exchange_graph"]
+    if mode == "auto" and xg["probe"] != "passed":
+        # a probe child that fails is the case the probe exists for: the run above stayed alive in staged mode.  It must not be
+        # the rule, though: the second attempt has to pass (one full-suite run in eight saw a failing probe on a loaded box)
+        assert xg["mode"] == "staged" and out["config"]["capture"] == "staged graphs" and out["value"] > 0, (xg, err[-2000:])
+        print("first probe did not pass:", xg)
+        out, err = _bench(["--exchange-dry-run", "8", "--exchange-graph", "auto"], env=env)
+        xg = out["config"]["exchange_graph"]
     if mode == "auto":
         assert xg["mode"] == "one" and xg["probe"] == "passed", (xg, err[-2000:])
         assert out["config"]["capture"] == "one graph incl. the gradient exchange"

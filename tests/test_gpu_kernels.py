@@ -705,6 +705,51 @@ def test_two_logit_head_with_cross_entropy_in_one_launch(ops, rows, cols, mode, 
         ops.set_compute("f32")
 
 
+@pytest.mark.parametrize("n_src,average,mode", [(4, True, "bf16"), (4, False, "f32"), (2, True, "f32"), (3, True, "bf16")])
+def test_two_logit_heads_of_several_sources_in_one_launch(ops, n_src, average, mode):
+    """ops.linear2_ce_multi: the EgoPack OSCC head -- the primary pooled features and one pooled GraphONE feature per auxiliary task,
+    each through its own Linear(H, 2), fused as stack(...).mean(0) / .sum(0), cross entropy with label smoothing 0.1
+    (models/tasks/oscc.py:65-96) -- loss AND every gradient in one launch, against torch on the same (rounded) operands; a
+    source that wants no gradient gets none."""
+    rows, cols, smoothing = 64, 1024, 0.1
+    g = gen(n_src * 7 + int(average))
+    fs = [torch.randn(rows, cols, generator=g) for _ in range(n_src)]
+    Ws = [torch.randn(2, cols, generator=g) * 0.05 for _ in range(n_src)]
+    bs = [torch.randn(2, generator=g) for _ in range(n_src)]
+    y = torch.randint(0, 2, (rows,), generator=g)
+    y[3::7] = -1
+    seed = 1.3 / rows
+    ops.set_compute(mode)
+    try:
+        if mode == "bf16":
+            fs, Wr = [r16(f) for f in fs], [r16(W) for W in Ws]
+        else:
+            Wr = Ws
+        cf = [f.clone().requires_grad_(True) for f in fs]
+        cW, cb = [W.clone().requires_grad_(True) for W in Wr], [b.clone().requires_grad_(True) for b in bs]
+        zs = torch.stack([f @ W.t() + b for f, W, b in zip(cf, cW, cb)])
+        z = zs.mean(0) if average else zs.sum(0)
+        ref = F.cross_entropy(z, y, reduction="none", ignore_index=-1, label_smoothing=smoothing)
+        ref.backward(torch.full_like(ref, seed))
+        dfs = [f.to(DEV).to(ops.act_dtype()).requires_grad_(k != 1) for k, f in enumerate(fs)]  # (source 1: no gradient wanted)
+        dWs, dbs = [W.clone().to(DEV).requires_grad_(True) for W in Ws], [b.clone().to(DEV).requires_grad_(True) for b in bs]
+        with ops.loss_seed(seed):
+            loss, logits = ops.linear2_ce_multi(dfs, dWs, dbs, y.to(DEV), smoothing, average=average)
+        loss.backward(torch.full_like(loss, seed))
+        lt = dict(rtol=1e-4, atol=1e-4) if mode == "f32" else dict(rtol=1e-2, atol=3e-2)
+        torch.testing.assert_close(logits.cpu(), z.detach(), **lt)
+        torch.testing.assert_close(loss.detach().cpu(), ref.detach(), **lt)
+        assert dfs[1].grad is None
+        for k in range(n_src):
+            gs, ws_ = float(cf[k].grad.abs().max()), float(cW[k].grad.abs().max())
+            if k != 1:
+                assert (dfs[k].grad.float().cpu() - cf[k].grad).abs().max() <= (1e-5 if mode == "f32" else 1.5e-2) * gs
+            assert (dWs[k].grad.cpu() - cW[k].grad).abs().max() <= (3e-5 if mode == "f32" else 1.5e-2) * ws_
+            assert (dbs[k].grad.cpu() - cb[k].grad).abs().max() <= (3e-5 if mode == "f32" else 1e-2) * max(1.0, float(cb[k].grad.abs().max()) * 100)
+    finally:
+        ops.set_compute("f32")
+
+
 def test_weighted_mean_sum_and_sum_tensors(ops):
     g = gen(54)
     a, b = torch.randn(100, generator=g), torch.randn(37, generator=g)
