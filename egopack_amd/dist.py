@@ -47,8 +47,14 @@ def init_single_rank_group(backend: str = "nccl") -> None:
     if dist.is_initialized():
         return
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(free_port())
-    dist.init_process_group(backend, rank=0, world_size=1)
+    for attempt in range(4):  # (a port found free can be taken before the store binds it: another port then)
+        os.environ["MASTER_PORT"] = str(free_port())
+        try:
+            dist.init_process_group(backend, rank=0, world_size=1)
+            return
+        except Exception as e:  # noqa: BLE001  (DistNetworkError is not importable on every build)
+            if "address already in use" not in str(e).lower() or attempt == 3:
+                raise
 
 
 def quiesce_before_capture(group=None, settle_s: float = 1.0) -> None:

@@ -396,8 +396,8 @@ class StepBase:
         # multi-task steps, 1.8 % on the single-task step (1.236 -> 1.214 ms), neutral on the EgoPack step
         self.wgrad_side_streams = bool(parallel_heads)
         # H x H weight gradients parked and issued four at a time as ONE grouped launch of 256 workgroups (ops._wgrad_defer):
-        # -4 % on the 3-task step, -12 % on the single-task step; the EgoPack step, whose GraphONE chains already keep three
-        # streams busy, measured 3.59 vs 3.46-3.52 ms with it and leaves it off
+        # -4 % on the 3-task step, -12 % on the single-task step; the EgoPack step measured 3.59 vs 3.46-3.52 ms with it in round 1
+        # and left it off until round 4 (EgoPackStep.wgrad_grouping_default)
         self.wgrad_grouping = type(self).wgrad_grouping_default
         self.deferred_forks = type(self).deferred_forks_default
         import os
@@ -409,6 +409,8 @@ class StepBase:
             self.deferred_forks = True
         if "wgrad_grouping" in off:
             self.wgrad_grouping = False
+        if "deferred_forks" in off:
+            self.deferred_forks = False
         if "grouped_heads" in off:
             self.grouped_heads = False
         self._fused_loss = "fused_loss" not in off
@@ -1322,8 +1324,10 @@ class EgoPackStep(StepBase):
     projections DETACHED -> GraphONE.interact -> fused logits -> primary.compute_loss."""
 
     order = ("ar", "oscc", "lta", "pnr")  # order of the loss terms in main_egopack.train
-    wgrad_grouping_default = False
-    deferred_forks_default = False
+    # grouped weight gradients and late forks: OFF until round 4 (3.77-3.89 against 3.62-3.72 ms then); with the OSCC head as six
+    # launches and the three GraphONE backward chains on three queues (DESIGN 10.8) they measure 3.20-3.24 against 3.47-3.48 ms
+    wgrad_grouping_default = True
+    deferred_forks_default = True
     AUX_ORDER = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
                  "pnr": ("ar", "oscc", "lta")}  # main_egopack.py:121-147
 

@@ -28,15 +28,22 @@ def free_port() -> int:
 def run_child(scenario: str, tmp_path, timeout: int = 600, inject: str = ""):
     """(exit code, result dict or None, tail of the child's output)."""
     out = tmp_path / f"{scenario}.json"
-    env = dict(os.environ, EGK_TEST_PORT=str(free_port()), EGK_TEST_INJECT=inject, PYTHONFAULTHANDLER="1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    try:
-        r = subprocess.run([sys.executable, str(REPO / "tests" / "dist_child.py"), scenario, str(out)], env=env,
-                           capture_output=True, text=True, timeout=timeout)
-        rc, tail = r.returncode, (r.stdout[-1500:] + "\n" + r.stderr[-6000:])
-    except subprocess.TimeoutExpired as e:  # (subprocess.run has killed the child)
-        rc, tail = -9, f"timed out after {timeout} s\n{(e.stderr or b'')[-4000:]!r}"
-    res = json.loads(out.read_text()) if out.exists() else None
+    for attempt in range(3):
+        # (a port found free here can be taken before the child binds it: the child then reports EADDRINUSE from its rendezvous --
+        #  a condition of the harness, not an outcome of the scenario -- and gets another port)
+        if out.exists():
+            out.unlink()
+        env = dict(os.environ, EGK_TEST_PORT=str(free_port()), EGK_TEST_INJECT=inject, PYTHONFAULTHANDLER="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            r = subprocess.run([sys.executable, str(REPO / "tests" / "dist_child.py"), scenario, str(out)], env=env,
+                               capture_output=True, text=True, timeout=timeout)
+            rc, tail = r.returncode, (r.stdout[-1500:] + "\n" + r.stderr[-6000:])
+        except subprocess.TimeoutExpired as e:  # (subprocess.run has killed the child)
+            rc, tail = -9, f"timed out after {timeout} s\n{(e.stderr or b'')[-4000:]!r}"
+        res = json.loads(out.read_text()) if out.exists() else None
+        if not (res is not None and "address already in use" in str(res.get("error", "")).lower()):
+            break
     return rc, res, tail
 
 
