@@ -372,6 +372,7 @@ class StepBase:
 
     order: Sequence[str] = TASK_ORDER
     wgrad_grouping_default = True
+    wgrad_group_count = None  # bf16 weight-gradient problems per grouped launch (None: ops.WGRAD_GROUP_COUNT = 6)
     # forked launches (weight gradients, early Adam) issued one launch late so that the dX chain keeps its hardware queue under
     # capture (ops.defer_after_next_launch): -4 % on the multi-task steps, -1.6 % on the single-task step; the EgoPack step,
     # whose GraphONE chains already occupy three queues, measured 4.04 vs 3.51 ms with it and leaves it off
@@ -500,7 +501,7 @@ class StepBase:
         if self.input_hook is not None:
             self.input_hook()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             # (eagerly issued steps end with the same grouped tail launch as captured ones: same tile variants, same bits)
@@ -583,7 +584,7 @@ class StepBase:
         if self.input_hook is not None:
             self.input_hook()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             self._install_tail(self._tail_only_plan([t for t in self.enabled if batches.get(t) is not None]))
@@ -723,7 +724,7 @@ class StepBase:
         opt.sync_hyper_source()  # (the step constants are computed inside the graph from a device-side step counter)
         self._hyper_in_graph = False
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         early = self._early_adam_plan(live) if fuse_adam else None
         try:
@@ -920,7 +921,7 @@ class StepBase:
         self._hyper_in_graph = True
         count = opt.step_count
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         sync.begin_step()
         sync.hyper_ready = True
@@ -1003,7 +1004,7 @@ class StepBase:
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         self._rng_in_graph = False  # (no staged graph advances the Philox offset word: replay() does, also after a one-piece capture)
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             live = [t for t in self.enabled if batches.get(t) is not None]
@@ -1328,6 +1329,7 @@ class EgoPackStep(StepBase):
     # launches and the three GraphONE backward chains on three queues they measure 3.20-3.24 against 3.47-3.48 ms
     wgrad_grouping_default = True
     deferred_forks_default = True
+    wgrad_group_count = 8  # 2048-row batches: eight H x H problems = 512 tiles = two per CU (3.16 -> 3.09 ms; six on the 3-task step)
     AUX_ORDER = {"ar": ("lta", "oscc", "pnr"), "oscc": ("ar", "lta", "pnr"), "lta": ("ar", "oscc", "pnr"),
                  "pnr": ("ar", "oscc", "lta")}  # main_egopack.py:121-147
 

@@ -782,12 +782,16 @@ def _rows_join(forked: bool) -> None:
         main.wait_stream(side)
 
 
-def set_wgrad_grouping(on: bool) -> bool:
-    """Switch the parking queue (engine: at the start and the end of every step); returns the previous setting.  Whatever is
-    still parked is dropped: a step ends with ``join_wgrad`` (which issues it), so something is left only when the step was
-    abandoned by an exception -- its weight gradients must not be accumulated by the next step."""
-    prev = _wq["on"]
+def set_wgrad_grouping(on, count: Optional[int] = None):
+    """Switch the parking queue (engine: at the start and the end of every step); returns the previous setting (hand it back to
+    restore).  ``count``: bf16 problems per grouped launch for this step (None: WGRAD_GROUP_COUNT; EGK_WGRAD_COUNT overrides).
+    Whatever is still parked is dropped: a step ends with ``join_wgrad`` (which issues it), so something is left only when the step
+    was abandoned by an exception -- its weight gradients must not be accumulated by the next step."""
+    prev = (_wq["on"], _wq.get("count"))
+    if isinstance(on, tuple):
+        on, count = on
     _wq["on"] = bool(on)
+    _wq["count"] = None if (count is None or "EGK_WGRAD_COUNT" in os.environ) else int(count)
     _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
     return prev
 
@@ -826,7 +830,7 @@ def _wgrad_defer(args, kw, tensors, park_on_excluded: bool = False, park_only: b
         return True
     # exact-f32 problems are matrix-pipe bound: a launch lasts as long as the workgroups on its fullest CU, so EIGHT H x H
     # problems (512 tiles = two per CU everywhere) where the bf16 launches take six
-    count = F32_WGRAD_GROUP_COUNT if A.dtype == torch.float32 else WGRAD_GROUP_COUNT
+    count = F32_WGRAD_GROUP_COUNT if A.dtype == torch.float32 else (_wq.get("count") or WGRAD_GROUP_COUNT)
     if len(_wq["items"]) >= count or _wq["tiles"] >= 64 * count:
         flush_wgrad()
     # (no end-of-backward join is scheduled for a parked problem: whoever switched the queue on -- engine.StepBase -- ends the
