@@ -1376,7 +1376,11 @@ class EgoPackStep(StepBase):
             out = {}
             for t in live:
                 others = self._aux_names(t)
-                out[t] = {o: self.tasks[o].forward_features(feats[t], out_f32=True) for o in others}
+                # the auxiliary projections of one batch as three grouped launches (+ one operand split) instead of ~5 per task at
+                # the END of the precise chain, which the GraphONE stages wait for
+                grouped = ops.grouped_projection_infer(feats[t], [self.tasks[o].net for o in others], out_f32=True) if len(others) > 1 else None
+                out[t] = (dict(zip(others, grouped)) if grouped is not None
+                          else {o: self.tasks[o].forward_features(feats[t], out_f32=True) for o in others})
         return out
 
     def task_loss(self, primary: str, feat, data, aux_in=None):

@@ -532,14 +532,14 @@ def _gemm_with_stats(args, kw, stats):
     lib = _lib.load()
     d = _gemm_desc(*args, stats=stats, **kw)
     blocks = lib.egk_gemm_stats_blocks(C.byref(d))
-    if blocks > 0 and d.n_extra and "x3_stats_split" in os.environ.get("EGK_ENABLE", ""):
+    if blocks > 0 and d.n_extra and "x3_stats_split" not in os.environ.get("EGK_DISABLE", ""):
         # a three-product contraction (six K sources for a SAGE layer's two-source launch: K = 6144 at H = 1024) of a batch
         # that fills half the chip: the statistics epilogue needs the finished tile, i.e. NO split-K -- 87 us for 2048 x 1024
         # on one workgroup per CU.  When the policy would cut the walk, the cut launch + its reduce + the LayerNorm's own
         # statistics pass are the cheaper chain (the precise pass of the EgoPack step sits on the step's critical path):
-        # config 4 3.70 -> 3.65 ms.  OPT-IN: the other summation order moves the auxiliary features by 1e-6, and with them
-        # WHICH near-ties of the OSCC head's max pool the block-wise parity test lands on (its d_features figure went from
-        # 1.7e-3 to 5.3e-3 against a bound of 5e-3: the same arithmetic, another draw) -- the bound stays, so the default does.
+        # config 4 3.70 -> 3.65 ms.  (Opt-in until the block-wise parity test of the OSCC head stated its input gradient "up to
+        # near-ties of the max pool": the other summation order moves the auxiliary features by 1e-6 and with them WHICH one to
+        # three near-tie pairs the draw contains -- 1.7e-3 .. 6.5e-3 over all rows, 1.66e-3 over the rows no tie touches.)
         if lib.egk_gemm_splitk(d.M, d.N, _desc_k(d), d.compute) > 1:
             blocks = 0
     if blocks <= 0:
@@ -1542,7 +1542,12 @@ def grouped_projection_infer(x, nets, out_f32: bool = False):
     auxiliary task).  ``out_f32``: the last contraction keeps its f32 accumulators (the prototype search ranks those).
     None when the heads do not qualify (bf16 activations, equal widths in multiples of 64, 2 .. 8 heads, no active dropout)."""
     G = len(nets)
-    if not (2 <= G <= 8) or x.dim() != 2 or not x.is_cuda or x.dtype != torch.bfloat16 or x.shape[0] == 0:
+    # f32 activations inside a precise_scope (compute mode 'bf16x3': every contraction as three bf16 products of split operands):
+    # the same three grouped launches with f32 in between, + ONE split launch for the second contraction's operand block
+    x3 = x.dtype == torch.float32 and _state["compute"] == X3 and _x3["cache"] is not None and out_f32
+    if not (2 <= G <= 8) or x.dim() != 2 or not x.is_cuda or not (x.dtype == torch.bfloat16 or x3) or x.shape[0] == 0:
+        return None
+    if x3 and "x3_grouped_aux" in os.environ.get("EGK_DISABLE", ""):
         return None
     dims = None
     for net in nets:
@@ -1558,6 +1563,27 @@ def grouped_projection_infer(x, nets, out_f32: bool = False):
     lib = _lib.load()
     x = _c(x)
     M, (H, H1, H2) = x.shape[0], dims
+    if x3:
+        if M % 8 or H % 64 or H1 % 64:
+            return None
+        h1 = torch.empty((G * M, H1), dtype=torch.float32, device=x.device)
+        a = torch.empty_like(h1)
+        f = torch.empty((G * M, H2), dtype=torch.float32, device=x.device)
+        mean = torch.empty(G * M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        gemm_grouped([((M, H1, x, H, net[1].weight, H, H, h1[g * M:(g + 1) * M], H1), dict(bias=_f32c(net[1].bias), compute=X3))
+                      for g, net in enumerate(nets)])
+        lw, lb = [_f32c(net[2].weight) for net in nets], [_f32c(net[2].bias) for net in nets]
+        row_ptr = (C.c_int32 * (G + 1))(*[g * M for g in range(G + 1)])
+        _ck(lib.egk_rowln_group_fwd(_stream(), _p(h1), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(a), _p(mean), _p(rstd), H1,
+                                    float(nets[0][2].eps), 1, _dt(h1)), "egk_rowln_group_fwd")
+        hi, lo = _split_rows(a, G * M, H1, H1)  # ONE launch; the groups' row blocks are registered as already split
+        for g in range(G):
+            ag = a[g * M:(g + 1) * M]
+            _x3["cache"][(ag.data_ptr(), M, H1, H1, ag._version)] = (hi[g * M:(g + 1) * M], lo[g * M:(g + 1) * M], a)
+        gemm_grouped([((M, H2, a[g * M:(g + 1) * M], H1, net[4].weight, H1, H1, f[g * M:(g + 1) * M], H2),
+                       dict(bias=_f32c(net[4].bias), compute=X3)) for g, net in enumerate(nets)])
+        return [f[g * M:(g + 1) * M] for g in range(G)]
     cmp = _compute_for(x)
     h1 = torch.empty((G * M, H1), dtype=x.dtype, device=x.device)
     a = torch.empty_like(h1)

@@ -297,7 +297,8 @@ def test_oscc_head_with_fused_auxiliary_logits_block(c4):
             aux = {t: a.detach().clone() for t, a in aux.items()}
         _zero(task)
         fin = feat.clone().requires_grad_(True)
-        logits = task.forward_logits(features=task.forward_features(fin), batch=d, aux_features=aux)
+        pf = task.forward_features(fin)
+        logits = task.forward_logits(features=pf, batch=d, aux_features=aux)
         loss = task.compute_loss(logits, d.y)
         loss.mean().backward()
         ops.join_wgrad()
@@ -306,10 +307,38 @@ def test_oscc_head_with_fused_auxiliary_logits_block(c4):
     tsd = _leaf(task.state_dict())
     fc = feat.float().cpu().requires_grad_(True)
     with S.bf16_storage():
-        lg = O.oscc_logits(tsd, O.projection_features(tsd, fc), d.batch.cpu(), {t: a.float().cpu() for t, a in aux.items()}, True,
-                           num_graphs=d.num_graphs)
+        pf_or = O.projection_features(tsd, fc)
+        lg = O.oscc_logits(tsd, pf_or, d.batch.cpu(), {t: a.float().cpu() for t, a in aux.items()}, True, num_graphs=d.num_graphs)
         ls = O.oscc_loss(lg, d.y.cpu(), "ce")
         ls.mean().backward()
     want = {k: v.grad for k, v in tsd.items() if v.requires_grad and v.grad is not None}
-    want.update(d_features=fc.grad, loss=ls.detach(), logits=lg.detach())
-    _check("OSCC head + fused auxiliary logits", got, want)
+    want.update(loss=ls.detach(), logits=lg.detach())
+    # The input gradient is exact UP TO NEAR-TIES OF THE MAX POOL.  The pool routes a column's gradient to ONE row of its sequence;
+    # the projected features are bf16 on both sides and differ in the last bit for ~0.3 % of the elements, so in a few (sequence,
+    # column) pairs the product's winner and the model's are different rows whose values are one bf16 step apart.  Every op between
+    # the input and the pool is row-wise: such a pair contaminates the gradient ROWS of its two candidates and nothing else.  So:
+    # (a) the pairs are few and each IS a near-tie in the model's own features; (b) every other row agrees within BLOCK_TOL.  (The
+    # all-rows figure moved between 1.7e-3 and 5.3e-3 with 1e-6 changes of the inputs -- which near-ties the draw contains.)
+    ptr = d.ptr.cpu().tolist() if hasattr(d, "ptr") else None
+    if ptr is None:
+        counts = torch.bincount(d.batch.cpu())
+        ptr = [0, *counts.cumsum(0).tolist()]
+    a, b = pf.detach().float().cpu(), pf_or.detach().float()
+    arg_p = torch.stack([a[s:e].max(0).indices + s for s, e in zip(ptr[:-1], ptr[1:])])  # first occurrence, as the kernel
+    arg_o = torch.stack([b[s:e].max(0).indices + s for s, e in zip(ptr[:-1], ptr[1:])])
+    flip = arg_p != arg_o
+    frac = float(flip.float().mean())
+    cols = torch.arange(b.shape[1]).expand_as(arg_o)
+    gap = (b[arg_o[flip], cols[flip]] - b[arg_p[flip], cols[flip]]).abs()
+    step = b[arg_o[flip], cols[flip]].abs() * 2.0 ** -7 + 1e-12  # one bf16 step at that magnitude
+    assert frac < 5e-3, frac
+    assert bool((gap <= step).all()), (float((gap / step).max()), int(flip.sum()))
+    clean = torch.ones(a.shape[0], dtype=torch.bool)
+    clean[arg_p[flip]] = False
+    clean[arg_o[flip]] = False
+    dfe_clean = _rel(fin.grad.float().cpu()[clean], fc.grad[clean])
+    dfe_all = _rel(fin.grad.float().cpu(), fc.grad)
+    _report("OSCC head: input gradient up to max-pool near-ties", {"pairs_flipped": frac, "rows_clean": float(clean.float().mean()),
+                                                                   "d_features_clean_rows": dfe_clean, "d_features_all_rows": dfe_all})
+    assert float(clean.float().mean()) > 0.9 and dfe_clean < BLOCK_TOL, (dfe_clean, dfe_all, frac)
+    _check("OSCC head + fused auxiliary logits", got_wo := {k: v for k, v in got.items() if k != "d_features"}, want)
