@@ -35,11 +35,19 @@ for r in rows:
 out.append("\n## bf16 mode, block by block (teacher-forced backward against the storage model)\n")
 out.append("| block | worst entry | median over its tensors |")
 out.append("|---|---|---:|")
+ties = []
 for b in blk:
+    if "pairs_flipped" in b:  # the OSCC head's input gradient, stated up to near-ties of the max pool
+        ties.append(b)
+        continue
     vals = {k: v for k, v in b.items() if k != "block" and isinstance(v, (int, float))}
     if vals:
         k = max(vals, key=vals.get)
         out.append(f"| {b['block']} | {vals[k]:.1e} ({k}) | {statistics.median(vals.values()):.1e} |")
+for b in ties:
+    out.append(f"\n{b['block']}: {b['pairs_flipped']:.1e} of the (sequence, column) pairs route their gradient to another row than the model's "
+               f"(each a tie within one bf16 step in the model's own features); the {b['rows_clean']:.4f} of the rows no such pair touches agree to "
+               f"{b['d_features_clean_rows']:.1e}, all rows to {b['d_features_all_rows']:.1e}.")
 out.append("\n## the index op (GraphONE nearest prototypes, K = 4096, k = 4, H = 1024; BASELINE #4): exact up to ties below 1e-5\n")
 for r in rows:
     if r["mode"].endswith("indices"):
