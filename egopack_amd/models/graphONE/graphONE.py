@@ -83,6 +83,9 @@ class GraphONE(nn.Module):
             raise ValueError(f"Unknown distance function: {self.distance_func}")  # reference graphONE.py:131
         output, closest = {}, {}
         items = list(features.items())
+        grouped = self._grouped_interaction(items)
+        if grouped is not None:
+            return grouped
         if self.parallel_tasks and len(items) > 1 and items[0][1].is_cuda:
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event()
@@ -104,6 +107,51 @@ class GraphONE(nn.Module):
             return output, closest
         for task, f in items:
             output[task], closest[task] = self._task_interaction(task, f)
+        return output, closest
+
+    def _grouped_interaction(self, items):
+        """The interaction of all tasks as ONE chain of grouped launches (ops.graphone_stages) when it qualifies -- equal row
+        counts, bf16 activations, frozen banks, parameters in the optimizer's flat buffers (the EgoPack training step) -- else
+        None: G chains over a third of the rows each fill the chip worse than one chain over all of them, and a captured step
+        has ~100 launches fewer.  The prototype searches stay one per task, side by side on the task streams."""
+        if len(items) < 2 or not items[0][1].is_cuda or not torch.is_grad_enabled():
+            return None
+        tasks = [t for t, _ in items]
+        feats = [f for _, f in items]
+        if (any(f.requires_grad for f in feats) or any(f.dim() != 2 or f.shape != feats[0].shape for f in feats)
+                or feats[0].shape[0] % 64 or feats[0].shape[1] % 64):
+            return None
+        banks = [self.embeddings[t].weight for t in tasks]
+        stage_lists = [self.conv_stages[t] for t in tasks]
+        if not ops.graphone_stages_ok(len(items), feats[0].shape[0], feats[0].shape[1], banks, stage_lists, self.freeze):
+            return None
+        main = torch.cuda.current_stream()
+        nn_idx = {}
+        if self.parallel_tasks:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            while len(self._task_streams) < len(items):
+                self._task_streams.append(torch.cuda.Stream())
+                ops.exclude_wgrad_streams(self._task_streams[-1:])
+            for st, (task, f) in zip(self._task_streams, items):
+                st.wait_event(fork)
+                f.record_stream(st)
+                with torch.cuda.stream(st):
+                    nn_idx[task] = ops.nearest_prototypes(f.detach(), self.embeddings[task].weight, self.k, self.distance_func,
+                                                          self._bank_norm(task))
+            f_act = ops.to_act_rows(feats)  # (on the caller's stream, beside the searches)
+            for st, (task, _) in zip(self._task_streams, items):
+                main.wait_stream(st)
+                nn_idx[task].record_stream(main)
+        else:
+            f_act = ops.to_act_rows(feats)
+            for task, f in items:
+                nn_idx[task] = ops.nearest_prototypes(f.detach(), self.embeddings[task].weight, self.k, self.distance_func,
+                                                      self._bank_norm(task))
+        self.stream_of = {}  # (every output is made on the caller's stream)
+        outs = ops.graphone_stages(f_act, banks, [nn_idx[t] for t in tasks], stage_lists, self.residual)
+        output = dict(zip(tasks, outs))
+        closest = {t: [nn_idx[t][:, 0]] * self.depth for t in tasks}
         return output, closest
 
     def _task_interaction(self, task: str, features: torch.Tensor):

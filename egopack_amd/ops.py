@@ -1638,6 +1638,192 @@ def grouped_projection(xs, nets, compute=None):
     return _GroupedProjection.apply(len(xs), _compute_for(xs[0]) if compute is None else compute, float(nets[0][2].eps), *xs, *args)
 
 
+# ---- GraphONE: the stages of several auxiliary tasks as ONE chain of grouped launches --------------------------------------
+class _GraphOneStages(torch.autograd.Function):
+    """The D stages of G auxiliary tasks' GraphONE interaction (reference models/graphONE/graphONE.py:94-115, the N feature
+    rows only -- see models/graphONE/graphONE.py here) as one chain of launches over all tasks: per stage G max aggregations,
+    ONE grouped two-source contraction, ONE grouped row LayerNorm + ReLU, ONE grouped contraction (+ bias + residual) forward;
+    backward per stage one grouped dX contraction, one grouped LayerNorm backward, one grouped launch of the 2 G dX
+    contractions of the SAGE layer (the residual's gradient added in the epilogue) and ONE aggregation backward over all tasks;
+    the 3 G weight gradients of a stage are parked for grouped launches -- instead of G chains of 4 D forward / ~12 D backward
+    launches on G streams, each a contraction over a third of the rows.
+    Inputs: f0 [G * N, H] (task g = rows g N .. (g + 1) N), per task a frozen f32 bank and nn [N, k]; per (stage, task) the
+    parameters (Wl, Wr, ln_w, ln_b, W3, b3).  Parameter gradients accumulate in place (flat gradient slots)."""
+
+    @staticmethod
+    def forward(ctx, f0, G, D, N, residual, eps, compute, banks, nns, *params):
+        lib = _lib.load()
+        f0 = _c(f0)
+        dt, dev = f0.dtype, f0.device
+        H = f0.shape[1]
+        P = [[params[(s * G + g) * 6:(s * G + g) * 6 + 6] for g in range(G)] for s in range(D)]
+        H1 = P[0][0][0].shape[0]
+        k = nns[0].shape[1]
+        row_ptr = (C.c_int32 * (G + 1))(*[g * N for g in range(G + 1)])
+        sl = lambda t, g: t[g * N:(g + 1) * N]
+        saved, ops_w = [], []
+        f = f0
+        for s in range(D):
+            m = torch.empty_like(f)
+            arg = torch.empty((G * N, H), dtype=torch.uint8, device=dev)
+            for g in range(G):
+                _ck(lib.egk_gather_max_fwd(_stream(), _p(sl(f, g)), _p(banks[g]), _p(nns[g]), _p(sl(m, g)), _p(sl(arg, g)), N, H, k,
+                                           _dt(f)), "egk_gather_max_fwd")
+            Wl = [weight_operand(P[s][g][0], dt) for g in range(G)]
+            Wr = [weight_operand(P[s][g][1], dt) for g in range(G)]
+            W3 = [weight_operand(P[s][g][4], dt) for g in range(G)]
+            h = torch.empty((G * N, H1), dtype=dt, device=dev)
+            gemm_grouped([((N, H1, sl(m, g), H, Wl[g], H, H, sl(h, g), H1),
+                           dict(A2=sl(f, g), lda2=H, B2=Wr[g], ldb2=H, K2=H, compute=compute)) for g in range(G)])
+            a = torch.empty_like(h)
+            mean = torch.empty(G * N, dtype=torch.float32, device=dev)
+            rstd = torch.empty_like(mean)
+            lw, lb = [_f32c(P[s][g][2]) for g in range(G)], [_f32c(P[s][g][3]) for g in range(G)]
+            _ck(lib.egk_rowln_group_fwd(_stream(), _p(h), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(a), _p(mean), _p(rstd), H1,
+                                        eps, 1, _dt(h)), "egk_rowln_group_fwd")
+            out = torch.empty((G * N, H), dtype=dt, device=dev)
+            gemm_grouped([((N, H, sl(a, g), H1, W3[g], H1, H1, sl(out, g), H),
+                           dict(bias=_f32c(P[s][g][5]), residual=sl(f, g) if residual else None, ldr=H, compute=compute))
+                          for g in range(G)])
+            saved += [f, m, arg, h, a, mean, rstd]
+            ops_w.append((Wl, Wr, W3, lw, lb))
+            f = out
+        ctx.dims, ctx.residual, ctx.compute, ctx.k = (G, D, N, H, H1), residual, compute, k
+        ctx.P, ctx.ops_w = P, ops_w
+        ctx.save_for_backward(*saved)
+        return tuple(sl(f, g) for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        G, D, N, H, H1 = ctx.dims
+        saved, P, cmp = ctx.saved_tensors, ctx.P, ctx.compute
+        dt, dev = saved[0].dtype, saved[0].device
+        sl = lambda t, g: t[g * N:(g + 1) * N]
+        row_ptr = (C.c_int32 * (G + 1))(*[g * N for g in range(G + 1)])
+        dy = [_operand_rows(d if d is not None else torch.zeros((N, H), dtype=dt, device=dev), dt) for d in dys]
+        slots = [[[_grad_slot(p) for p in P[s][g]] for g in range(G)] for s in range(D)]
+        if any(x is None for ss in slots for sg in ss for x in sg):
+            raise RuntimeError("graphone_stages: the parameters need in-place gradient slots (optim.FlatAdam materialised)")
+        need_f0 = ctx.needs_input_grad[0]
+        a0, m0 = saved[4], saved[1]
+        park = (_wgrad_groupable(H, H1, dy[0], dy[0].stride(0), a0, H1, N, cmp) and _wgrad_groupable(H1, H, a0, H1, m0, H, N, cmp)
+                and all(d.stride(0) % 8 == 0 and d.data_ptr() % 16 == 0 for d in dy))
+        pending, reds = [], []  # without the parking queue: grouped launches of <= 8 on the side stream, below
+
+        def wgrad(pa, pk, keep):
+            if not (park and _wgrad_defer(pa, pk, keep, park_on_excluded=True)):
+                pending.append((pa, pk, keep))
+        df = None
+        for s in reversed(range(D)):
+            f, m, arg, h, a, mean, rstd = saved[7 * s:7 * s + 7]
+            Wl, Wr, W3, lw, lb = ctx.ops_w[s]
+            da = torch.empty_like(a)
+            gemm_grouped([((N, H1, dy[g], dy[g].stride(0), W3[g], H1, H, sl(da, g), H1), dict(transB=True, compute=cmp)) for g in range(G)])
+            for g in range(G):
+                wgrad((H, H1, dy[g], dy[g].stride(0), sl(a, g), H1, N, slots[s][g][4], H1),
+                      dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[s][g][5]), (dy[g], a))
+            dh = torch.empty_like(h)
+            grid = lib.egk_rowln_bwd_ws_rows(N)
+            ws = torch.empty(G * grid * 2 * H1 * 4, dtype=torch.uint8, device=dev)
+            _ck(lib.egk_rowln_group_bwd(_stream(), _p(da), _p(h), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(mean), _p(rstd),
+                                        _p(dh), _p(ws), H1, 1, _dt(h)), "egk_rowln_group_bwd")
+            for g in range(G):
+                red = (ws[g * grid * 2 * H1 * 4:], slots[s][g][2], slots[s][g][3], N, H1, 0)
+                if park:
+                    _wgrad_defer_reduce(*red)
+                else:
+                    reds.append(red)
+            if s > 0 or need_f0:
+                dm = torch.empty((G * N, H), dtype=dt, device=dev)
+                df = torch.empty_like(dm)
+                gemm_grouped([((N, H, sl(dh, g), H1, Wl[g], H, H1, sl(dm, g), H), dict(transB=True, compute=cmp)) for g in range(G)]
+                             + [((N, H, sl(dh, g), H1, Wr[g], H, H1, sl(df, g), H),
+                                 dict(transB=True, compute=cmp, residual=dy[g] if ctx.residual else None, ldr=dy[g].stride(0)))
+                                for g in range(G)])
+                _ck(lib.egk_gather_max_bwd(_stream(), _p(dm), _p(arg), _p(df), G * N, H, ctx.k, 1, _dt(dm)), "egk_gather_max_bwd")
+            for g in range(G):
+                wgrad((H1, H, sl(dh, g), H1, sl(m, g), H, N, slots[s][g][0], H),
+                      dict(transA=True, transB=True, accumulate=True, compute=cmp), (dh, m))
+                wgrad((H1, H, sl(dh, g), H1, sl(f, g), H, N, slots[s][g][1], H),
+                      dict(transA=True, transB=True, accumulate=True, compute=cmp), (dh, f))
+            if s > 0:
+                dy = [sl(df, g) for g in range(G)]
+        for i in range(0, len(pending), 8):
+            chunk = pending[i:i + 8]
+            keep = tuple(t for _, _, kp in chunk for t in kp)
+            _wgrad_launch(True, keep, lambda chunk=chunk: gemm_grouped([(pa, pk) for pa, pk, _ in chunk]))
+        if reds:
+            _wgrad_launch(True, tuple(r[0] for r in reds), lambda: _launch_reductions(reds))
+        return (df if need_f0 else None, *([None] * (8 + 6 * G * D)))
+
+
+def graphone_stages_ok(G: int, N: int, H: int, banks, stage_lists, freeze: bool) -> bool:
+    """Whether ``graphone_stages`` can serve an interaction of G tasks with N feature rows of width H each: 2 .. 4 tasks, bf16
+    activations, N a multiple of 64 (the K axis of the weight gradients), widths in multiples of 64, frozen banks, and every
+    stage parameter living in the optimizer's flat buffers (in-place gradient slots)."""
+    if not (2 <= G <= 4) or not freeze or _state["act"] != torch.bfloat16 or "graphone_grouped" in os.environ.get("EGK_DISABLE", ""):
+        return False
+    if N <= 0 or N % 64 or H % 64 or any(b.requires_grad or b.dim() != 2 or b.shape[1] != H or not b.is_cuda for b in banks):
+        return False
+    D = len(stage_lists[0])
+    H1 = stage_lists[0][0].module_0.lin_l.weight.shape[0]
+    if D == 0 or H1 % 64 or H1 > 4096:
+        return False
+    for stages in stage_lists:
+        if len(stages) != D:
+            return False
+        for st in stages:
+            c, ln, l3 = st.module_0, st.module_1, st.module_3
+            if (c.lin_l.weight.shape != (H1, H) or c.lin_r.weight.shape != (H1, H) or c.lin_l.bias is not None
+                    or l3.weight.shape != (H, H1) or l3.bias is None or ln.weight.shape != (H1,)):
+                return False
+            for p in (c.lin_l.weight, c.lin_r.weight, ln.weight, ln.bias, l3.weight, l3.bias):
+                if _grad_slot(p) is None or not p.requires_grad:
+                    return False
+    return True
+
+
+def to_act_rows(feats):
+    """[sum rows, H] activation-type copy of several row blocks of one width, one below the other: ONE conversion launch when the
+    blocks already are consecutive slices of one buffer (the grouped auxiliary projections), one per block otherwise."""
+    want = _state["act"]
+    f0 = feats[0]
+    base = f0._base
+    H = f0.shape[1]
+    rows = [f.shape[0] for f in feats]
+    if base is not None and base.dim() == 2 and base.is_contiguous() and base.shape == (sum(rows), H):
+        off, whole = base.data_ptr(), True
+        for f in feats:
+            whole = whole and f._base is base and f.is_contiguous() and f.data_ptr() == off
+            off += f.shape[0] * H * base.element_size()
+        if whole:
+            return base if base.dtype == want else cast_raw(base, want)
+    out = torch.empty((sum(rows), H), dtype=want, device=f0.device)
+    r0 = 0
+    for f in feats:
+        f = _rm(f)
+        _ck(_lib.load().egk_cast_rows(_stream(), _p(f), _dt(f), f.stride(0), _p(out[r0:]), _dt(out), H, f.shape[0], H, 0), "egk_cast_rows")
+        r0 += f.shape[0]
+    return out
+
+
+def graphone_stages(f0, banks, nns, stage_lists, residual: bool):
+    """[f_g after D stages] for the G tasks' features f0 [G * N, H] (activation type; see ``_GraphOneStages``; ask
+    ``graphone_stages_ok`` first)."""
+    G, D = len(banks), len(stage_lists[0])
+    N = f0.shape[0] // G
+    params = []
+    for s in range(D):
+        for g in range(G):
+            st = stage_lists[g][s]
+            params += [st.module_0.lin_l.weight, st.module_0.lin_r.weight, st.module_1.weight, st.module_1.bias, st.module_3.weight,
+                       st.module_3.bias]
+    eps = float(stage_lists[0][0].module_1.eps)
+    return list(_GraphOneStages.apply(f0, G, D, N, bool(residual), eps, _compute_for(f0), [_f32c(b.detach()) for b in banks],
+                                      [n.contiguous() for n in nns], *params))
+
+
 # ---- row LayerNorm (+ReLU, +dropout) ------------------------------------------------------------------
 class _RowLN(torch.autograd.Function):
     @staticmethod

@@ -661,6 +661,72 @@ def test_grouped_launches_equal_the_per_problem_launches(A, what):
     assert rel < 2e-3, rel
 
 
+@pytest.mark.parametrize("residual", [True, False])
+def test_graphone_stages_of_all_tasks_as_one_grouped_chain(A, residual, monkeypatch):
+    """GraphONE.interact inside engine.EgoPackStep with the stages of the three auxiliary tasks as ONE chain of grouped launches
+    (ops.graphone_stages) against the same step with one chain per task (EGK_DISABLE=graphone_grouped): loss vector, logits
+    and every parameter after 3 Adam steps (bf16 mode: same kernel bodies with other tile variants -> f32 accumulation-order
+    noise, then bf16 rounding).  The per-task interaction is the one the reference-control-flow fixtures pin."""
+    import argparse
+    import bench
+    from egopack_amd.models.graphONE.graphONE import GraphONE
+
+    def run(grouped):
+        if grouped:
+            monkeypatch.delenv("EGK_DISABLE", raising=False)
+        else:
+            monkeypatch.setenv("EGK_DISABLE", "graphone_grouped")
+        args = argparse.Namespace(hidden=256, trn_hidden=256, dropout=0.0, compute="bf16", workload="egopack_oscc", batch=8, T=16)
+        A.ops.set_compute("bf16")
+        A.ops.manual_seed(11)
+        model, tasks, crit, weights, dev, merged = bench.build_workload(args, 0, torch.device(DEV))
+        model.to(DEV).train()
+        for t in tasks.values():
+            t.to(DEV).train()
+        gen = torch.Generator(device=DEV)
+        gen.manual_seed(7)
+        banks = {t: torch.randn(96, 256, device=DEV, generator=gen) for t in ("ar", "lta", "pnr")}
+        torch.manual_seed(5)
+        gone = GraphONE(banks, features_size=256, hidden_size=256, k=4, depth=2, residual=residual).to(DEV)
+        params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters()), *gone.parameters()]
+        opt = A.FlatAdam(params, lr=1e-3, weight_decay=1e-5)
+        step = A.engine.EgoPackStep(model, tasks, gone, weights, opt, backprop_temporal_graph=True, temporal_graph_train_mode=False)
+        before = {k: v.clone() for k, v in gone.state_dict().items()}
+        used = []
+        orig = A.ops.graphone_stages
+
+        def spy(*a, **k):
+            used.append(1)
+            return orig(*a, **k)
+        A.ops.graphone_stages = spy
+        try:
+            outs = [step.step(dev, merged) for _ in range(3)]
+        finally:
+            A.ops.graphone_stages = orig
+        torch.cuda.synchronize()
+        return outs, opt.flat_p.clone(), len(used), before, {k: v.clone() for k, v in gone.state_dict().items()}
+
+    try:
+        (o1, p1, n1, b1, g1), (o0, p0, n0, b0, g0) = run(True), run(False)
+    finally:
+        A.ops.set_compute("bf16")
+    # the first step builds the optimizer's flat buffers on the per-task path; the grouped chain runs from the second on
+    assert n0 == 0 and n1 == 2, (n0, n1)
+    for (t1, v1), (t0, v0) in zip(o1, o0):
+        torch.testing.assert_close(t1, t0, rtol=2e-3, atol=2e-3)
+        for k in v0:
+            torch.testing.assert_close(v1[k], v0[k], rtol=2e-2, atol=2e-2)
+    assert float((p1 - p0).norm() / p0.norm()) < 2e-3
+    for k in g0:  # GraphONE's own parameters: trained by both paths, by the same amounts (Adam: three steps of ~lr each)
+        assert torch.equal(b1[k], b0[k])
+        if "embeddings" in k:
+            assert torch.equal(g1[k], b1[k]) and torch.equal(g0[k], b0[k])  # (frozen banks)
+            continue
+        d1, d0 = (g1[k] - b1[k]).float(), (g0[k] - b0[k]).float()
+        assert float(d0.norm()) > 0, k
+        assert float((d1 - d0).norm() / d0.norm()) < 0.1, (k, float((d1 - d0).norm() / d0.norm()))
+
+
 def test_parked_weight_gradients_survive_an_aliased_backward_stream(A):
     """Pooled HIP stream handles are reused: the backward stream of a step (a graph-capture stream) can carry a handle that
     an earlier step registered as a task-head stream.  Work parked for the grouped weight-gradient launch must still be
