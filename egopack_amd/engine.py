@@ -761,6 +761,7 @@ class StepBase:
                 if early is not None:
                     early["rng"] = "rng_in_graph" not in getattr(self, "_dev_off", ()) and "rng_early" not in getattr(self, "_dev_off", ())
                     ops.set_last_wgrad_hook(early["param"], early["hook"])
+                    ops.set_graphone_backward_hook(early.get("graphone_hook"))
                     if early["tail"]:
                         g0 = opt.flat_g.data_ptr()
                         ops.set_last_wgrad_tail(g0 + 4 * early["lo"], g0 + 4 * early["hi"])
@@ -773,6 +774,10 @@ class StepBase:
                     if early is not None and early["fired"]:
                         torch.cuda.current_stream().wait_stream(early["stream"])
                         opt.launch(None, early["lo"], early["hi"])
+                    elif early is not None and early.get("done"):  # (a slice was stepped, the last weight gradient's hook never ran)
+                        torch.cuda.current_stream().wait_stream(early["stream"])
+                        for a, b in _minus([(0, opt.flat_p.numel())], early["done"]):
+                            opt.launch(None, a, b)
                     else:
                         opt.launch()
                     ops.stamp("adam_done")
@@ -784,6 +789,7 @@ class StepBase:
                     self._rng_in_graph = True
         finally:
             ops.set_last_wgrad_hook(None, None)
+            ops.set_graphone_backward_hook(None)
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
@@ -872,11 +878,16 @@ class StepBase:
                 plan["stream"].wait_event(ev)
                 if side is not None:
                     plan["stream"].wait_stream(side)
+                for st in self._gradient_branch_streams():  # (branches of backward that nothing has joined into ``main`` yet)
+                    with torch.cuda.stream(st):
+                        live_branch = torch.cuda.is_current_stream_capturing()
+                    if live_branch:
+                        plan["stream"].wait_stream(st)
                 with torch.cuda.stream(plan["stream"]):
                     if plan.get("rng"):  # the dropout offset word moves on here, beside the last weight gradient, instead of
                         ops.advance_rng_device(opt.flat_p.device)  # as a launch of its own behind Adam at the tail of the step
-                    opt.launch(None, 0, lo)
-                    opt.launch(None, hi, total)
+                    for a, b in _minus([(0, lo), (hi, total)], plan.get("done", ())):  # (``done``: slices stepped earlier in the step)
+                        opt.launch(None, a, b)
             if plan.get("rng"):
                 plan["rng_done"] = True  # (every dropout launch of the step has been issued: this is backward's end)
             ops.defer_after_next_launch(issue)
@@ -889,6 +900,11 @@ class StepBase:
 
     def _early_adam_ok(self) -> bool:
         return bool(self.early_adam)
+
+    def _gradient_branch_streams(self):
+        """Streams on which parts of backward may still be running when the LAST weight gradient of the step is launched (the
+        early optimizer slice waits for them)."""
+        return []
 
     # The N-rank step as ONE hipGraph: the three stages, the region-wise collectives between them (communication stream, forked
     # and joined inside the capture) and the per-chunk Adam launches.  Three graph launches + ~13 collectives + ~13 Adam
@@ -1319,6 +1335,23 @@ class MTLStep(StepBase):
             self._stage_join()
 
 
+def _minus(ranges, holes):
+    """The element ranges ``ranges`` without the ranges ``holes`` (lists of [lo, hi))."""
+    out = list(ranges)
+    for h0, h1 in holes:
+        nxt = []
+        for a, b in out:
+            if h1 <= a or b <= h0:
+                nxt.append((a, b))
+                continue
+            if a < h0:
+                nxt.append((a, h0))
+            if h1 < b:
+                nxt.append((h1, b))
+        out = nxt
+    return [(a, b) for a, b in out if b > a]
+
+
 class EgoPackStep(StepBase):
     """One novel-task step of main_egopack.train with late fusion (BASELINE configs 4, 5; reference
     main_egopack.py:45-159): backbone (train/eval mode and grad mode as configured) -> primary projection; aux
@@ -1357,6 +1390,55 @@ class EgoPackStep(StepBase):
     # consume the same values (rounded to the activation type).
     precise_search = True
     precise_stream = True  # the precise pass on its own stream beside the training pass's forward (False: in line, A/B)
+    # Adam over everything but the temporal pooling's slots beside the step's last weight-gradient launch (StepBase._early_adam_plan):
+    # the step is ONE backward() call whose last node is the first TRN linear -- every other node has been issued by then, on
+    # the backward stream or on the branch streams below, which the optimizer slice waits for.  Config 4: 55 M parameters,
+    # Adam alone at the end of the step lasted 261 us of 2.84 ms
+    early_adam = True
+
+    def _early_adam_ok(self) -> bool:
+        return bool(self.early_adam and self.backprop and "early_adam" not in getattr(self, "_dev_off", ()))
+
+    def _gradient_branch_streams(self):
+        return [*getattr(self.graphone, "_task_streams", ()), *getattr(self, "_head_streams", ())]
+
+    def _early_adam_plan(self, live):
+        """+ OPT-IN (EGK_ENABLE=graphone_adam) GraphONE's own slice: its stage parameters (half of the step's parameters in config
+        4) have their final gradients when the grouped GraphONE backward returns (ops.set_graphone_backward_hook) -- Adam over
+        that slice then runs beside the backbone's backward instead of in the step's tail.  Measured: the tail shrinks from 275 to
+        114 us and the backbone's backward grows by as much (2.746-2.751 against 2.72-2.80 ms, tools/round4/c4_g1adam_ab.sh) --
+        the memory-bound launch slows the chain it runs beside, as in the headline step (_early_adam_plan)."""
+        import os
+        plan = super()._early_adam_plan(live)
+        opt = self.optimizer
+        if plan is None or "graphone_adam" not in os.environ.get("EGK_ENABLE", "") or len(live) != 1:
+            return plan
+        params = [p for p in self.graphone.parameters() if p.requires_grad and id(p) in opt._slot_of]
+        if not params:
+            return plan
+        g0, g1 = opt.region_of(params)
+        slots = [opt._slot_of[id(p)] for p in params]
+        if not (g1 > g0 and g0 % 8 == 0 and g1 % 8 == 0 and sum(n for _, n in slots) == g1 - g0 and (g1 <= plan["lo"] or g0 >= plan["hi"])):
+            return plan
+        plan["done"] = []
+
+        def graphone_done():
+            if plan["fired"] or plan["done"]:
+                return
+            ops.flush_wgrad(force=True)  # (what the interaction left parked; issued behind the backward stream's next launch)
+            main = torch.cuda.current_stream()
+
+            def issue(ev):
+                side = ops.wgrad_side_stream(main)
+                plan["stream"].wait_event(ev)
+                if side is not None:
+                    plan["stream"].wait_stream(side)
+                with torch.cuda.stream(plan["stream"]):
+                    opt.launch(None, g0, g1)
+            ops.defer_after_next_launch(issue)
+            plan["done"].append((g0, g1))
+        plan["graphone_hook"] = graphone_done
+        return plan
 
     def _precise_on(self) -> bool:
         return bool(self.precise_search and ops.get_compute() in ("bf16", "bf16_f32act") and "precise_search" not in getattr(self, "_dev_off", ()))

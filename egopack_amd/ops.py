@@ -922,6 +922,7 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
     def launch():
         for i in range(0, len(items), 8):
             chunk = items[i:i + 8]
+            stamp("wgrad_group", seq=True)
             pieces = _k_pieces(chunk) if len(chunk) > 1 else None
             if pieces is not None:
                 for piece in pieces:
@@ -1639,6 +1640,15 @@ def grouped_projection(xs, nets, compute=None):
 
 
 # ---- GraphONE: the stages of several auxiliary tasks as ONE chain of grouped launches --------------------------------------
+_g1_hook = {"fn": None}
+
+
+def set_graphone_backward_hook(fn) -> None:
+    """``fn()`` is called on the backward stream at the end of the grouped GraphONE backward (``_GraphOneStages``), when every
+    gradient of the stage parameters is either issued or parked -- the engine starts the optimizer on that region there."""
+    _g1_hook["fn"] = fn
+
+
 class _GraphOneStages(torch.autograd.Function):
     """The D stages of G auxiliary tasks' GraphONE interaction (reference models/graphONE/graphONE.py:94-115, the N feature
     rows only -- see models/graphONE/graphONE.py here) as one chain of launches over all tasks: per stage G max aggregations,
@@ -1719,6 +1729,7 @@ class _GraphOneStages(torch.autograd.Function):
             f, m, arg, h, a, mean, rstd = saved[7 * s:7 * s + 7]
             Wl, Wr, W3, lw, lb = ctx.ops_w[s]
             da = torch.empty_like(a)
+            stamp("graphone_bwd_stage", seq=True)
             gemm_grouped([((N, H1, dy[g], dy[g].stride(0), W3[g], H1, H, sl(da, g), H1), dict(transB=True, compute=cmp)) for g in range(G)])
             for g in range(G):
                 wgrad((H, H1, dy[g], dy[g].stride(0), sl(a, g), H1, N, slots[s][g][4], H1),
@@ -1749,6 +1760,8 @@ class _GraphOneStages(torch.autograd.Function):
                       dict(transA=True, transB=True, accumulate=True, compute=cmp), (dh, f))
             if s > 0:
                 dy = [sl(df, g) for g in range(G)]
+        if park and _g1_hook["fn"] is not None:
+            _g1_hook["fn"]()  # (every gradient of the interaction's parameters has been issued or parked: engine.EgoPackStep)
         for i in range(0, len(pending), 8):
             chunk = pending[i:i + 8]
             keep = tuple(t for _, _, kp in chunk for t in kp)
