@@ -766,6 +766,9 @@ def main(argv=None):
     for kv in filter(None, args.egk_tune.split(",")):
         from egopack_amd import _lib
         k, v = kv.split("=")
+        if k == "gather_max":  # (development: 0 = the generic max-aggregation kernel, bit-identical)
+            _lib.load().egk_gather_max_tune(int(v))
+            continue
         _lib.load().egk_tune(int(k), int(v))
     from egopack_amd import ops
     if args.ln_reduce_inline:

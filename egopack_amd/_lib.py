@@ -106,6 +106,8 @@ SIGNATURES = {
     "egk_csr_heavy_ws_bytes": (i64, [i32, i32]),
     "egk_csr_heavy_threshold": (i32, []),
     "egk_gather_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    "egk_gather_max_group_fwd": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32]),
+    "egk_gather_max_tune": (C.c_int, [i32]),
     "egk_gather_max_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),
     "egk_segment_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
     "egk_segment_max_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),

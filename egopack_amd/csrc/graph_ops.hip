@@ -614,6 +614,57 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const T* __restrict
     }
 }
 
+// The same op with every load of a row requested up front: the generic kernel walks k + 1 sources x cols / 256 column steps as
+// a chain of dependent loads (one wave per row: ~15 us for 2048 rows whatever the bandwidth); here the k neighbour indices are
+// read first and then U column steps x (K + 1) sources are in flight together.  Same comparisons in the same order (prototype
+// edges first, self loop last, first maximum wins): bit-identical values and winners.  Rows of up to 4 GROUPS (tasks: own bank
+// and neighbour lists, ``rows`` rows each, f / m / arg one block below the other) in one launch.
+struct GatherMaxGroups {
+    const float* bank[4];
+    const long long* nn[4];
+    int n_groups, rows;
+};
+
+template <typename T, int K, int U>
+__global__ __launch_bounds__(256) void gather_max_fwd_u_kernel(const T* __restrict__ f, GatherMaxGroups gg, T* __restrict__ m,
+                                                               uint8_t* __restrict__ arg, int rows_total, int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows_total; row += gridDim.x * WPB) {
+        const int g = row / gg.rows, r = row - g * gg.rows;
+        const float* __restrict__ bank = g == 0 ? gg.bank[0] : g == 1 ? gg.bank[1] : g == 2 ? gg.bank[2] : gg.bank[3];
+        const long long* __restrict__ nn = (g == 0 ? gg.nn[0] : g == 1 ? gg.nn[1] : g == 2 ? gg.nn[2] : gg.nn[3]) + (long long)r * K;
+        const float* src[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) src[j] = bank + nn[j] * cols;
+        const T* self = f + (long long)row * cols;
+        for (int c0 = lane * 4; c0 < cols; c0 += 256 * U) {
+            float4 v[U][K + 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) v[u][j] = ld4(src[j], c0 + 256 * u, cols, true);
+                v[u][K] = ld4(self, c0 + 256 * u, cols, true);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                uint32_t a4 = 0;
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    const float4 x = v[u][j];
+                    if (x.x > best.x) { best.x = x.x; a4 = (a4 & ~0x000000ffu) | (uint32_t)j; }
+                    if (x.y > best.y) { best.y = x.y; a4 = (a4 & ~0x0000ff00u) | ((uint32_t)j << 8); }
+                    if (x.z > best.z) { best.z = x.z; a4 = (a4 & ~0x00ff0000u) | ((uint32_t)j << 16); }
+                    if (x.w > best.w) { best.w = x.w; a4 = (a4 & ~0xff000000u) | ((uint32_t)j << 24); }
+                }
+                const int c = c0 + 256 * u;
+                st4(m + (long long)row * cols, c, cols, true, best);
+                *reinterpret_cast<uint32_t*>(arg + (long long)row * cols + c) = a4;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const T* __restrict__ dm, const uint8_t* __restrict__ arg,
                                                              T* __restrict__ df, long long n, int k, int accumulate) {
@@ -1072,6 +1123,35 @@ static inline int row_grid(int rows) {
 int g_graph_rows_v2 = 1;  // development knob (egk_tune 3, set from norm_ops.hip): the rows1024.h kernels of this file
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static int g_gather_max_up_front = 1;  // development knob (egk_tune 7): 0 = the generic kernel everywhere
+
+// Whether the loads-up-front kernel takes this shape; launches it when it does.
+template <typename T>
+static bool gather_max_up_front(hipStream_t s, const T* f, const GatherMaxGroups& gg, T* m, uint8_t* arg, int cols, int k) {
+    const int steps = cols / 256;
+    const uintptr_t amask = 4 * sizeof(T) - 1;  // (four elements per lane and access)
+    if (!g_gather_max_up_front || cols % 256 || (reinterpret_cast<uintptr_t>(m) & amask) || (reinterpret_cast<uintptr_t>(f) & amask) ||
+        (reinterpret_cast<uintptr_t>(arg) & 3))
+        return false;
+    for (int g = 0; g < gg.n_groups; ++g)
+        if (!al16(gg.bank[g])) return false;
+    const int total = gg.n_groups * gg.rows;
+    if (k == 4 && steps % 4 == 0)
+        hipLaunchKernelGGL((gather_max_fwd_u_kernel<T, 4, 4>), dim3(row_grid(total)), dim3(256), 0, s, f, gg, m, arg, total, cols);
+    else if (k == 4 && steps % 2 == 0)
+        hipLaunchKernelGGL((gather_max_fwd_u_kernel<T, 4, 2>), dim3(row_grid(total)), dim3(256), 0, s, f, gg, m, arg, total, cols);
+    else if (k == 8 && steps % 2 == 0)
+        hipLaunchKernelGGL((gather_max_fwd_u_kernel<T, 8, 2>), dim3(row_grid(total)), dim3(256), 0, s, f, gg, m, arg, total, cols);
+    else if (k == 4)
+        hipLaunchKernelGGL((gather_max_fwd_u_kernel<T, 4, 1>), dim3(row_grid(total)), dim3(256), 0, s, f, gg, m, arg, total, cols);
+    else if (k == 8)
+        hipLaunchKernelGGL((gather_max_fwd_u_kernel<T, 8, 1>), dim3(row_grid(total)), dim3(256), 0, s, f, gg, m, arg, total, cols);
+    else
+        return false;
+    return true;
+}
+
+
 }  // namespace egk
 
 using namespace egk;
@@ -1286,6 +1366,42 @@ int egk_csr_gather_banded(egk_stream_t stream, const void* x, const int32_t* row
     return csr_gather_impl(stream, x, rowptr, col, nullptr, nullptr, out, rows, cols, dtype, heavy_rows, n_heavy, ws, heavy_mode, band);
 }
 
+int egk_gather_max_tune(int32_t up_front) {
+    const int prev = g_gather_max_up_front;
+    if (up_front >= 0) g_gather_max_up_front = up_front != 0;
+    return prev;
+}
+
+int egk_gather_max_group_fwd(egk_stream_t stream, const void* f, const float* const* banks, const int64_t* const* nns,
+                             int32_t n_groups, void* m, uint8_t* arg, int32_t rows, int32_t cols, int32_t k, int32_t dtype) {
+    EGK_REQUIRE(f && banks && nns && m && arg, "egk_gather_max_group_fwd: null pointer");
+    EGK_REQUIRE(n_groups >= 1 && n_groups <= 4, "egk_gather_max_group_fwd: 1 .. 4 groups");
+    EGK_REQUIRE(k >= 0 && k < 255, "egk_gather_max_group_fwd: k out of range");
+    for (int g = 0; g < n_groups; ++g) EGK_REQUIRE(banks[g] && nns[g], "egk_gather_max_group_fwd: null pointer");
+    if (rows == 0 || cols == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    GatherMaxGroups gg;
+    gg.n_groups = n_groups; gg.rows = rows;
+    for (int g = 0; g < 4; ++g) {
+        gg.bank[g] = banks[g < n_groups ? g : 0];
+        gg.nn[g] = (const long long*)nns[g < n_groups ? g : 0];
+    }
+    const int ebytes = dtype == EGK_BF16 ? 2 : 4;
+    {
+        ProfScope prof(KID_GATHER_MAX_FWD, s, 0, (4.0 * (k + 2) + 1.0) * rows * cols * n_groups);
+        bool done = false;
+        EGK_DISPATCH_T(dtype, done = gather_max_up_front<T>(s, (const T*)f, gg, (T*)m, arg, cols, k));
+        if (done) return check_launch("egk_gather_max_group_fwd");
+    }
+    for (int g = 0; g < n_groups; ++g) {  // shapes the grouped kernel does not take: one generic launch per group
+        const long long off = (long long)g * rows * cols;
+        const int rc = egk_gather_max_fwd(stream, (const char*)f + off * ebytes, banks[g], nns[g], (char*)m + off * ebytes, arg + off,
+                                          rows, cols, k, dtype);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int egk_gather_max_fwd(egk_stream_t stream, const void* f, const float* bank, const int64_t* nn, void* m, uint8_t* arg,
                        int32_t rows, int32_t cols, int32_t k, int32_t dtype) {
     EGK_REQUIRE(f && bank && nn && m && arg, "egk_gather_max_fwd: null pointer");
@@ -1293,6 +1409,14 @@ int egk_gather_max_fwd(egk_stream_t stream, const void* f, const float* bank, co
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_GATHER_MAX_FWD, s, 0, (4.0 * (k + 2) + 1.0) * rows * cols);
+    {
+        GatherMaxGroups gg;
+        gg.n_groups = 1; gg.rows = rows;
+        for (int g = 0; g < 4; ++g) { gg.bank[g] = bank; gg.nn[g] = (const long long*)nn; }
+        bool done = false;
+        EGK_DISPATCH_T(dtype, done = gather_max_up_front<T>(s, (const T*)f, gg, (T*)m, arg, cols, k));
+        if (done) return check_launch("egk_gather_max_fwd");
+    }
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(gather_max_fwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)f, bank,
                                              (const long long*)nn, (T*)m, arg, rows, cols, k));
     return check_launch("egk_gather_max_fwd");

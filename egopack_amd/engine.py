@@ -760,7 +760,7 @@ class StepBase:
                     self._install_tail(self._tail_only_plan(live))
                 if early is not None:
                     early["rng"] = "rng_in_graph" not in getattr(self, "_dev_off", ()) and "rng_early" not in getattr(self, "_dev_off", ())
-                    ops.set_last_wgrad_hook(early["param"], early["hook"])
+                    ops.set_last_wgrad_hook(early["param"], early["hook"], pre=self._join_gradient_branches)
                     ops.set_graphone_backward_hook(early.get("graphone_hook"))
                     if early["tail"]:
                         g0 = opt.flat_g.data_ptr()
@@ -878,11 +878,6 @@ class StepBase:
                 plan["stream"].wait_event(ev)
                 if side is not None:
                     plan["stream"].wait_stream(side)
-                for st in self._gradient_branch_streams():  # (branches of backward that nothing has joined into ``main`` yet)
-                    with torch.cuda.stream(st):
-                        live_branch = torch.cuda.is_current_stream_capturing()
-                    if live_branch:
-                        plan["stream"].wait_stream(st)
                 with torch.cuda.stream(plan["stream"]):
                     if plan.get("rng"):  # the dropout offset word moves on here, beside the last weight gradient, instead of
                         ops.advance_rng_device(opt.flat_p.device)  # as a launch of its own behind Adam at the tail of the step
@@ -902,9 +897,20 @@ class StepBase:
         return bool(self.early_adam)
 
     def _gradient_branch_streams(self):
-        """Streams on which parts of backward may still be running when the LAST weight gradient of the step is launched (the
-        early optimizer slice waits for them)."""
+        """Streams on which parts of backward may still be running when the LAST weight gradient of the step is launched."""
         return []
+
+    def _join_gradient_branches(self) -> None:
+        """Called on the backward stream right before the step's last weight gradient (ops.set_last_wgrad_hook ``pre``): the
+        branches of a one-call backward that run on other streams are joined HERE -- what they parked for the grouped
+        weight-gradient launches (operands made on their streams) is issued next, and the optimizer slice that starts beside the
+        last weight gradient reads every gradient they wrote.  (Autograd itself joins them only when backward() returns.)"""
+        main = torch.cuda.current_stream()
+        for st in self._gradient_branch_streams():
+            with torch.cuda.stream(st):
+                live_branch = torch.cuda.is_current_stream_capturing()
+            if live_branch and st != main:
+                main.wait_stream(st)
 
     # The N-rank step as ONE hipGraph: the three stages, the region-wise collectives between them (communication stream, forked
     # and joined inside the capture) and the per-chunk Adam launches.  Three graph launches + ~13 collectives + ~13 Adam

@@ -969,10 +969,12 @@ def _take_tail_items():
     return items, extra
 
 
-def set_last_wgrad_hook(param, hook) -> None:
+def set_last_wgrad_hook(param, hook, pre=None) -> None:
     """``hook()`` is called (on the backward stream) just before the weight-gradient launch of ``param`` -- the engine
-    marks the LAST weight gradient of the step with it to start the optimizer on everything else meanwhile."""
-    _last_wgrad["param"], _last_wgrad["hook"] = param, hook
+    marks the LAST weight gradient of the step with it to start the optimizer on everything else meanwhile.  ``pre()`` runs
+    first, before what is parked is issued: a step whose backward has branches on other streams that nothing has joined yet
+    joins them there (parked problems of those branches read operands made on their streams)."""
+    _last_wgrad["param"], _last_wgrad["hook"], _last_wgrad["pre"] = param, hook, pre
     if hook is None:
         _last_wgrad["tail"] = None
 
@@ -1135,6 +1137,8 @@ class _Linear(torch.autograd.Function):
             last = Wp is _last_wgrad["param"] and _last_wgrad["hook"] is not None
             tail_items, tail_extra = [], []
             if last:
+                if _last_wgrad.get("pre") is not None:
+                    _last_wgrad["pre"]()
                 tail_items, tail_extra = _take_tail_items()  # (issued below; the argument tuples keep their operands alive)
                 flush_wgrad(force=True)  # (the hook starts the optimizer on every other slot: their gradients must be issued)
                 _last_wgrad["hook"]()
@@ -1676,9 +1680,8 @@ class _GraphOneStages(torch.autograd.Function):
         for s in range(D):
             m = torch.empty_like(f)
             arg = torch.empty((G * N, H), dtype=torch.uint8, device=dev)
-            for g in range(G):
-                _ck(lib.egk_gather_max_fwd(_stream(), _p(sl(f, g)), _p(banks[g]), _p(nns[g]), _p(sl(m, g)), _p(sl(arg, g)), N, H, k,
-                                           _dt(f)), "egk_gather_max_fwd")
+            _ck(lib.egk_gather_max_group_fwd(_stream(), _p(f), _ptr_array(banks), _ptr_array(nns), G, _p(m), _p(arg), N, H, k, _dt(f)),
+                "egk_gather_max_group_fwd")
             Wl = [weight_operand(P[s][g][0], dt) for g in range(G)]
             Wr = [weight_operand(P[s][g][1], dt) for g in range(G)]
             W3 = [weight_operand(P[s][g][4], dt) for g in range(G)]

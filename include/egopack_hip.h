@@ -391,6 +391,14 @@ int egk_gather_max_fwd(egk_stream_t s, const void* f, const float* bank, const i
                        int32_t rows, int32_t cols, int32_t k, int32_t dtype);
 int egk_gather_max_bwd(egk_stream_t s, const void* dm, const uint8_t* arg, void* df, int32_t rows, int32_t cols,
                        int32_t k, int32_t accumulate, int32_t dtype);
+/* egk_gather_max_fwd for the rows of 1 .. 4 GROUPS in one launch (GraphONE.interact's auxiliary tasks, graphONE.py:76-85: each
+ * task has its own bank and neighbour lists): group g owns rows [g * rows, (g + 1) * rows) of f / m / arg.  Same values and
+ * winners as one egk_gather_max_fwd call per group. */
+int egk_gather_max_group_fwd(egk_stream_t s, const void* f, const float* const* banks, const int64_t* const* nns,
+                             int32_t n_groups, void* m, uint8_t* arg, int32_t rows, int32_t cols, int32_t k, int32_t dtype);
+/* Development knob: 1 (default) = rows whose loads are all requested up front (k = 4 / 8, cols a multiple of 256), 0 = the generic
+ * kernel everywhere (bit-identical); < 0 only reads.  Returns the previous setting. */
+int egk_gather_max_tune(int32_t up_front);
 
 /* global_max_pool over contiguous sequences (oscc.py:68,85): out[b,:] = max_{n in [ptr[b],ptr[b+1])} x[n,:];
  * arg[b,c] = winning row.  bwd scatters dout to the winners (dx zero elsewhere). */

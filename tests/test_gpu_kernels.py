@@ -436,6 +436,50 @@ def test_gather_max_fwd_bwd(ops):
     assert torch.equal(df.grad.cpu(), cf.grad)
 
 
+@pytest.mark.parametrize("k,H", [(4, 1024), (4, 512), (4, 256), (8, 1024), (8, 256), (3, 1024), (4, 320)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_gather_max_of_several_tasks_in_one_launch_with_every_load_up_front(ops, k, H, dt):
+    """egk_gather_max_group_fwd (the rows of G tasks, each with its own bank and neighbour lists, in one launch; k = 4 / 8 and widths
+    in multiples of 256 on the kernel that requests every load of a row up front) against one generic launch per task
+    (egk_gather_max_tune(0)): values and winners bit for bit, ties included (features copied from bank rows); k = 3 and width 320
+    take the generic kernel inside the grouped entry point."""
+    import ctypes as C
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(33)
+    G, N, K = 3, 130, 57
+    banks = [torch.randn(K, H, generator=g).to(DEV) for _ in range(G)]
+    nns = [torch.stack([torch.randperm(K, generator=g)[:k] for _ in range(N)]).to(DEV) for _ in range(G)]
+    f = torch.randn(G * N, H, generator=g)
+    f[5] = banks[0][nns[0][5, 1]].cpu()  # exact ties with a prototype row: the prototype (earlier message) wins
+    f = f.to(dt).to(DEV)
+    dti = ops.BF16 if dt == torch.bfloat16 else ops.F32
+    st = torch.cuda.current_stream().cuda_stream
+    ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    def grouped():
+        m, arg = torch.empty_like(f), torch.empty((G * N, H), dtype=torch.uint8, device=DEV)
+        rc = lib.egk_gather_max_group_fwd(st, f.data_ptr(), ptrs(banks), ptrs(nns), G, m.data_ptr(), arg.data_ptr(), N, H, k, dti)
+        assert rc == 0, _lib.last_error()
+        return m, arg
+    m1, a1 = grouped()
+    prev = lib.egk_gather_max_tune(0)
+    try:
+        m0, a0 = torch.empty_like(f), torch.empty((G * N, H), dtype=torch.uint8, device=DEV)
+        for i in range(G):
+            rc = lib.egk_gather_max_fwd(st, f[i * N:].data_ptr(), banks[i].data_ptr(), nns[i].data_ptr(), m0[i * N:].data_ptr(),
+                                        a0[i * N:].data_ptr(), N, H, k, dti)
+            assert rc == 0, _lib.last_error()
+        m2, a2 = grouped()  # (the grouped entry point on the generic kernel)
+    finally:
+        lib.egk_gather_max_tune(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(m1, m0) and torch.equal(a1, a0) and torch.equal(m2, m0) and torch.equal(a2, a0)
+    ref = torch.cat([torch.cat([banks[i][nns[i]], f[i * N:(i + 1) * N].float().unsqueeze(1)], 1).max(1).values for i in range(G)])
+    assert torch.equal(m1.float(), ref.to(dt).float())
+    assert int(a1[5].ne(k).sum()) > 0
+
+
 def test_segment_max_fwd_bwd(ops):
     g = gen(32)
     ptr = torch.tensor([0, 4, 4, 9, 20], dtype=torch.int32)  # one empty sequence -> zeros
