@@ -53,6 +53,14 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.egk_graph_plan_launch(None, None) == -1 and "null plan" in _lib.last_error()
     lib.egk_graph_plan_destroy(None)  # (a no-op)
     assert lib.egk_gemm_splitk_in_launch(None) == 0
+    # the grouped max aggregation: null pointers and a group count outside 1 .. 4
+    buf = (ctypes.c_void_p * 4)(1, 1, 1, 1)
+    assert lib.egk_gather_max_group_fwd(None, None, buf, buf, 2, None, None, 8, 256, 4, 1) == -1 and "null pointer" in _lib.last_error()
+    one = ctypes.c_void_p(1)
+    assert lib.egk_gather_max_group_fwd(None, one, buf, buf, 5, one, one, 8, 256, 4, 1) == -1 and "1 .. 4 groups" in _lib.last_error()
+    assert lib.egk_gather_max_group_fwd(None, one, buf, buf, 3, one, one, 0, 256, 4, 1) == 0  # (no rows: nothing launched)
+    prev = lib.egk_gather_max_tune(-1)
+    assert prev in (0, 1) and lib.egk_gather_max_tune(0) == prev and lib.egk_gather_max_tune(prev) == 0
 
 
 def test_heavy_row_threshold_is_shared_by_the_csr_builder_and_the_kernel():

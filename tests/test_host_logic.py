@@ -496,3 +496,12 @@ def test_weight_gradient_k_pieces_partition_the_walk(monkeypatch):
     assert covered == K
     assert ops._k_pieces([((M, N, dY, M, X, N, K, W, N), dict(kw, accumulate=False))]) is None
     assert ops._k_pieces([((M, N, dY[:1024], M, X[:1024], N, 1024, W, N), kw)] * 2) is None  # pieces shorter than 512 rows
+
+
+def test_ranges_minus_holes():
+    """engine._minus: the optimizer slices that are left when parts of the flat buffers were stepped earlier in the step."""
+    from egopack_amd.engine import _minus
+    assert _minus([(0, 100), (200, 300)], [(50, 60), (250, 400)]) == [(0, 50), (60, 100), (200, 250)]
+    assert _minus([(0, 100)], []) == [(0, 100)] and _minus([(0, 100)], [(0, 100)]) == []
+    assert _minus([(0, 8), (8, 8)], [(100, 200)]) == [(0, 8)]
+    assert _minus([(0, 100)], [(10, 20), (15, 30), (90, 120)]) == [(0, 10), (30, 90)]
