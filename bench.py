@@ -105,7 +105,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(sds, names, dev, weights, sample_batch=None, budget_s=20.0):
+def cpu_baseline(sds, names, dev, weights, sample_batch=None, budget_s=20.0, egopack=None):
     """The CPU oracle (oracle/path.py, checker code) timed on the host cores on a BOUNDED sample of the
     same workload: the same step (fp32, forward + backward + torch.optim.Adam, same tasks, same T and
     model) on the FULL batch of B sequences per task (graph-LayerNorm couples the samples of a batch:
@@ -115,8 +115,9 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=None, budget_s=20.0):
     from oracle import pyg_ops as P
     cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
-    leaf = {g: {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("frequency") else v.clone())
-                for k, v in sd.items()} for g, sd in sds.items()}
+    leaf = {g: {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith("frequency")
+                                                      and not k.startswith("embeddings.")) else v.clone())
+                for k, v in sd.items()} for g, sd in sds.items()}  # (GraphONE's prototype banks are frozen: graphONE.py:48)
     batches = {}
     for t, d in dev.items():
         B, n = d.num_graphs, d.pos.shape[0]
@@ -134,7 +135,17 @@ def cpu_baseline(sds, names, dev, weights, sample_batch=None, budget_s=20.0):
 
     def one():
         opt.zero_grad()
-        total, _ = O.mtl_objective(leaf["temporal_graph"], {t: leaf[n] for t, n in names.items()}, batches, weights)
+        if egopack is not None:
+            # the novel-task step of BASELINE config 4 (reference main_egopack.py:45-61,64-159): backbone forward, the detached
+            # auxiliary projections -> GraphONE over the frozen banks -> fused logits -> the primary task's loss; backward; Adam
+            d = batches[egopack["primary"]]
+            feat = O.graph_forward(leaf["temporal_graph"], d.x, d.pos, d.edge_index, 3)
+            loss, _, _, _ = O.egopack_task_loss(egopack["primary"], {t: leaf[n] for t, n in names.items()}, leaf["graphone"], feat,
+                                                d.batch, d.y, egopack["others"], egopack["k"], egopack["depth"], True, True,
+                                                num_graphs=d.num_graphs)
+            total = weights[egopack["primary"]] * loss.mean()
+        else:
+            total, _ = O.mtl_objective(leaf["temporal_graph"], {t: leaf[n] for t, n in names.items()}, batches, weights)
         total.backward()
         opt.step()
 
@@ -456,7 +467,7 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
     model, tasks, crit, weights, dev, merged = build_workload(args, rank, device)
     names = {"ar": "task/recognition", "oscc": "task/oscc", "lta": "task/lta", "pnr": "task/pnr"}
     sds = None
-    if rank == 0 and world == 1 and want_cpu and not args.no_cpu_baseline and args.workload in ("mtl", "ar", "mtl4"):
+    if rank == 0 and world == 1 and want_cpu and not args.no_cpu_baseline and args.workload in ("mtl", "ar", "mtl4", "egopack_oscc"):
         sds = {"temporal_graph": {k: v.clone() for k, v in model.state_dict().items()}}
         for t, n in names.items():
             sds[n] = {k: v.clone() for k, v in tasks[t].state_dict().items()}
@@ -485,6 +496,8 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
         graphone = GraphONE(banks, features_size=args.hidden, hidden_size=args.hidden, k=args.graphone_k,
                             depth=args.graphone_depth, residual=True).to(device)
         params += list(graphone.parameters())
+        if sds is not None:
+            sds["graphone"] = {k: v.detach().cpu().clone() for k, v in graphone.state_dict().items()}
         opt = FlatAdam(params, lr=1e-5, weight_decay=1e-5)
         step = engine.EgoPackStep(model, tasks, graphone, weights, opt, backprop_temporal_graph=True,
                                   temporal_graph_train_mode=False, sync=sync)
@@ -678,13 +691,21 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
             try:
                 rl2, _ = roofline(ops, eager_step, args.compute, args=args)
                 if rl and rl2:
-                    rl["replay_dominant"] = {k: rl2[k] for k in ("kernel", "rocprof_symbol", "bound", "achieved", "peak", "unit", "frac",
-                                                                 "avg_launch_us", "launches_per_step", "alg_per_launch", "traffic")
-                                             if k in rl2}
-                    rl["replay_dominant"]["timing"] = ("HIP events on each launch's own stream, eager steps issued with the "
-                                                       "production stream structure (kernels co-run)")
+                    # TOP LEVEL = the kernel with the largest summed time in the step's production stream structure (what a trace of
+                    # the replayed graph shows: round-4 verdict, measurement repair ii); the serialised table's dominant kernel -- the
+                    # figure the committed rocprofv3 --stats summary can be checked against launch by launch -- rides as "serialised"
+                    ser = {k: rl[k] for k in ("kernel", "rocprof_symbol", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                              "launches_per_step", "alg_per_launch", "traffic") if k in rl}
+                    ser["timing"] = "HIP events with every launch of the eager steps on ONE stream (the way rocprofv3 --kernel-trace times them)"
+                    top = {k: rl2[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "rocprof_symbol",
+                                               "launches_per_step", "avg_launch_us", "alg_per_launch") if k in rl2}
+                    top["timing"] = ("HIP events on each launch's own stream, eager steps issued with the production stream structure "
+                                     "(kernels co-run as in the replayed graph); dominant = largest summed time per step")
+                    top["step"] = rl["step"]
+                    top["serialised"] = ser
+                    rl = top
             except Exception as e:  # noqa: BLE001
-                rl["replay_dominant"] = {"error": repr(e)}
+                rl["replay_error"] = repr(e)
         except Exception as e:  # the headline number must still be printed
             rl = {"error": repr(e)}
     if rl and "step" in rl:
@@ -693,12 +714,15 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
     pmc_config = world == 1 and not args.exchange_dry_run and pmc_file(args).exists()
     if rl and "traffic" in rl and not pmc_config:
         rl["traffic"], rl["traffic_source"] = None, f"not measured for this configuration (no profiles/pmc_{pmc_key(args)}.json)"
-        if isinstance(rl.get("replay_dominant"), dict) and "traffic" in rl["replay_dominant"]:
-            rl["replay_dominant"]["traffic"] = None
+        if isinstance(rl.get("serialised"), dict) and "traffic" in rl["serialised"]:
+            rl["serialised"]["traffic"] = None
     cb = None
     if sds is not None:
         try:
-            cb = cpu_baseline(sds, names, dev, weights)
+            ego = None
+            if args.workload == "egopack_oscc":
+                ego = {"primary": "oscc", "others": ("ar", "lta", "pnr"), "k": args.graphone_k, "depth": args.graphone_depth}
+            cb = cpu_baseline(sds, names, dev, weights, egopack=ego)
         except Exception as e:
             cb = {"error": repr(e)}
     # replicated run: finite parameters, the same on every rank (checked over the coordination group)

@@ -383,7 +383,7 @@ __host__ __device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
     return true;
 }
 
-template <int NI, bool GA = false>
+template <int NI, bool GA = false, bool ST = true>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[NI][4], unsigned char* lds, int m0, int n0,
                                                    int wm, int wn, int lr, int lg, int z, int tid, int st_tile = 0) {
     __syncthreads();  // every wave is done with the ring (nothing is in flight: the last tiles were waited for)
@@ -401,7 +401,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     const int c8 = tid & 15, n = n0 + c8 * 8;
     // per-segment sums of the stored result for the graph LayerNorm that consumes it.  A tile spans at most two row segments
     // (checked on the host): s0 = segment of the tile's first row, rel = 0 / 1.
-    const int st_mode = g.splitk == 1 ? g.st_mode : 0;
+    const int st_mode = (ST && g.splitk == 1) ? g.st_mode : 0;  // (ST = false: no statistics and no static LDS in the kernel)
     float sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     int s0 = 0, s_split = 0x7fffffff;
     float st_mu[2] = {0.f, 0.f}, st_ri[2] = {0.f, 0.f}, lw[8], lb[8];
@@ -530,7 +530,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             sa[rel][1] += a2;
         }
     }
-    if (st_mode) {  // block sums in a fixed order: lanes (shuffle tree), then the 4 waves in wave order
+    if constexpr (ST) if (st_mode) {  // block sums in a fixed order: lanes (shuffle tree), then the 4 waves in wave order
         __shared__ double st_red[4][4];
         double v4[4] = {(double)sa[0][0], (double)sa[0][1], (double)sa[1][0], (double)sa[1][1]};
 #pragma unroll
@@ -1231,6 +1231,204 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(con
     gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI>(g, blockIdx.x);
 }
 
+
+// ---- dW form (both operands k-major), deep ring of 32-deep K sub-stages ------------------------------------------------------
+// The weight gradients walk K = all nodes of the batch (6144 .. 16384): every K step pulls 2 x 64 k-rows x 256 B from strips
+// that only the few tiles of one XCD patch share, so its DMA pieces are L2 misses (HBM / memory-side cache latency, 1-2 us
+// under load) -- and the 2-stage ring of gemm_pipe_kernel has ONE 64-deep step (32 KiB per workgroup) in flight: in the step
+// the walk ran at ~2600 cycles per K tile against 1024 of matrix work (profiles/r04_c3_replay_timeline.txt: 157.7 us for
+// 96 K tiles).  Here the ring is cut in NSUB sub-stages of 32 k-rows (A 8 KiB | B 8 KiB): one barrier per sub-stage, NSUB - 1
+// sub-stages in flight behind it (NSUB = 5: 64 KiB per workgroup, 128 KiB per CU with two workgroups -- every byte of LDS).
+// The images, swizzles, fragment reads and the MFMA chain per accumulator are gemm_pipe_kernel's (a sub-stage is one half of
+// its k-major image: the swizzle terms depend on k mod 32 only), the fused bias gradient sums the same k-rows in the same
+// order: results are bit-identical to it.
+template <int NSUB, bool VIRT>
+__device__ __forceinline__ void gemm_tt_sub_body(const GemmArgs& g, const int bid) {
+    constexpr int SUB = 16384, HALF = 8192, KT = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int z, tm, tn;
+    if constexpr (VIRT) tile_of_virtual(g, bid, z, tm, tn);
+    else tile_of(g, bid, z, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt = total_tiles(g, KT);
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
+    const int nsub = 2 * max(t_end - t_begin, 0);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // DMA cursors: pieces 2w, 2w + 1 (4 k-rows of 256 B each) of each operand's sub-image
+    const bf16_t *pa[2], *pb[2];
+    long long sa = 0, sb = 0;
+    int cur_src = -1;
+    auto aim = [&](const bf16_t* (&p)[2], long long& step, const bf16_t* base, long long ld, int row0, int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (2 * w + i) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
+            int col = row0 + c * 8;
+            if (col + 8 > ld) col = 0;  // (beyond the allocated row: feeds output rows that are never stored)
+            p[i] = base + (long long)(k0 + k) * ld + col;
+        }
+        step = 32 * ld;
+    };
+    int slot_in = 0;  // ring slot the next issued sub-stage goes to
+    auto issue = [&](int j) {
+        if ((j & 1) == 0) {
+            int src, tt;
+            source_of<KT>(g, t_begin + (j >> 1), src, tt);
+            if (src != cur_src) {  // (uniform) first tile, or the walk crossed into the next K source
+                aim(pa, sa, (const bf16_t*)g.A[src], g.lda[src], m0, tt * KT);
+                aim(pb, sb, (const bf16_t*)g.B[src], g.ldb[src], n0, tt * KT);
+                cur_src = src;
+            }
+        }
+        unsigned char* sbase = lds + slot_in * SUB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)pa[i], (lds_void_t*)(sbase + (2 * w + i) * 1024), 16, 0, 0);
+            pa[i] += sa;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)pb[i], (lds_void_t*)(sbase + HALF + (2 * w + i) * 1024), 16, 0, 0);
+            pb[i] += sb;
+        }
+        slot_in = slot_in + 1 == NSUB ? 0 : slot_in + 1;
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const unsigned tr_row = (unsigned)((8 * lg + tq) * 256 + (tp & 1) * 8);
+    const unsigned tr_f = (unsigned)(2 * tq + 8 * (lg & 1));
+    unsigned a_tr[4], b_tr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_tr[i] = tr_row + ((((unsigned)(wm * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
+        b_tr[i] = (unsigned)HALF + tr_row + ((((unsigned)(wn * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
+    }
+
+    // fused bias gradient, in gemm_pipe_kernel's order: thread (chunk column bcc, k group bkg) sums k-rows 4 bkg .. 4 bkg + 3 of
+    // every 64-deep K tile -- groups 0-7 (waves 0, 1) live in the even sub-stages, 8-15 (waves 2, 3) in the odd ones
+    const bool do_bias = g.dbias != nullptr && tn == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int bcc = tid & 15, bkg = tid >> 4;
+
+#pragma unroll
+    for (int p = 0; p < NSUB - 1; ++p)
+        if (p < nsub) issue(p);
+    int slot = 0;
+    for (int it = 0; it < nsub; ++it) {
+        const int later = min(NSUB - 2, nsub - 1 - it);  // sub-stages issued behind ``it`` so far (4 pieces per wave each)
+        if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of sub-stage ``it`` landed; the slot read at it - 1 is free
+        if (it + NSUB - 1 < nsub) issue(it + NSUB - 1);
+        const unsigned st = lds_base + slot * SUB;
+        slot = slot + 1 == NSUB ? 0 : slot + 1;
+        uint4 a[4], b[4], bz[4];
+        const bool bias_now = do_bias && ((w >> 1) == (it & 1));  // (wave-uniform)
+        if (bias_now) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = (bkg & 7) * 4 + r;
+                const unsigned ad = st + (unsigned)(k * 256 + ((bcc ^ (2 * (k & 3) + 8 * ((k >> 3) & 1))) << 4));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bz[r]) : "v"(ad));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ad = st + b_tr[j];
+            uint2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+            b[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned ad = st + a_tr[i];
+            uint2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+            a[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        // reads return in issue order: with the last two A fragments (4 reads) outstanding, B and A fragments 0, 1 are back
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]),
+                                                                    acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]),
+                                                                    acc[i][j], 0, 0, 0);
+        if (bias_now) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned wv[4] = {bz[r].x, bz[r].y, bz[r].z, bz[r].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(wv[e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(wv[e] & 0xffff0000u);
+                }
+            }
+        }
+    }
+    if (g.dbias != nullptr && tn == 0) {  // block-uniform
+        __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [16 k groups][128 rows]
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[bkg * 128 + bcc * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 && m0 + tid < g.M) {
+            float t = 0.f;
+            for (int q = 0; q < 16; ++q) t += red[q * 128 + tid];
+            if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
+            else g.dbias[m0 + tid] += t;
+        }
+        __syncthreads();
+    }
+    if (epilogue_rows_ok(g)) gemm_epilogue_rows<4, false, false>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, 0);
+    else gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
+}
+
+template <int NSUB>
+__global__ __launch_bounds__(NTHREADS) void gemm_tt_sub_kernel(const GemmArgs g) {
+    gemm_tt_sub_body<NSUB, false>(g, blockIdx.x);
+}
+template <int NSUB>
+__global__ __launch_bounds__(NTHREADS) void gemm_tt_sub_group_kernel(const GemmGroup gg) {
+    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+    const int q = gg.total >> 3, r = gg.total & 7;
+    if (slot >= q + (xcd < r ? 1 : 0)) return;
+    int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    int pi = 0;
+    for (; pi + 1 < gg.count; ++pi) {  // (uniform scalar walk over <= 8 problems)
+        const int t = gg.p[pi].tiles_m * gg.p[pi].tiles_n;
+        if (v < t) break;
+        v -= t;
+    }
+    gemm_tt_sub_body<NSUB, true>(gg.p[pi], v);
+}
+
 // Fragment reads of the 256 x 256 kernel: fragments FIRST .. FIRST + 3 of k-step S of one operand image (inline asm for
 // the reason given in gemm_pipe_kernel: a plain LDS load would drain the DMA queue first).
 template <bool TR, int FIRST, int S>
@@ -1726,6 +1924,7 @@ static int g_sk_in_launch = 1;      // development knob (egk_gemm_set_pipeline(7
 static int g_wg2_rows64 = 0;        // development knob (egk_gemm_set_pipeline(500 / 501)): variant 12 inside the policy off / on
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
+static int g_tt_sub = 0;            // development knob (egk_gemm_set_pipeline(800 + NSUB): dW-form launches on the sub-staged ring; 800 = off)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
 static bool g_lds_attr_set = false;
 template <int NS, bool TA, bool TB, int KG, int MB = 1>
@@ -1744,6 +1943,7 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     set_lds_attr<2, false, false, 1, 2>(); set_lds_attr<2, false, true, 1, 2>(); set_lds_attr<2, true, true, 1, 2>(); set_lds_attr<2, true, false, 1, 2>();
+    set_lds_attr<3, false, false, 1, 2>(); set_lds_attr<3, false, true, 1, 2>(); set_lds_attr<3, true, true, 1, 2>(); set_lds_attr<3, true, false, 1, 2>();
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1776,11 +1976,16 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_group_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_group_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 800) { g_tt_sub = on - 800; return prev; }
     if (on >= 700) { g_sk_in_launch = on - 700; return prev; }
     if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
     if (on >= 500) { g_wg2_rows64 = on - 500; return prev; }
@@ -2049,7 +2254,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
         }
-        const int mb = variant == 6 ? 2 : 1;
+        const int mb = (variant == 6 || variant == 13) ? 2 : 1;
         if (variant == 12 && (d->st_mode || d->ga_mode)) variant = 11;  // (forced by the knob: the epilogue features win)
         g.tiles_m = variant == 8 ? cdiv(g.M, 96) : (variant == 11 || variant == 12) ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
         if (variant == 7) g.tiles_n = cdiv(g.N, 256);
@@ -2101,6 +2306,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             return EGK_EUNSUPPORTED;
         }
         g.sk_tickets = sk_in_launch ? d->sk_tickets : nullptr;
+        // dW form on the sub-staged ring: wherever the 2-stage 128 x 128 kernel (variant 3) would run
+        const int tt_sub = (d->transA && d->transB && variant == 3 && !g.sk_tickets && (g_tt_sub == 4 || g_tt_sub == 5)) ? g_tt_sub : 0;
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
@@ -2114,6 +2321,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         } else if (variant == 8) {                                                                                        \
             if (d->ga_mode) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3, true>), pgrid, pblock, 2 * 28672, s, g); \
             else hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);           \
+        } else if (variant == 13) {                                                                                       \
+            hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, g);          \
         } else if (variant == 6)                                                                                          \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
         else if (variant == 5)                                                                                            \
@@ -2127,8 +2336,11 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                                        : ((variant == 5 || variant == 12) ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);
-            else if (d->transA && d->transB) EGK_PIPE(true, true);
-            else EGK_PIPE(true, false);
+            else if (d->transA && d->transB) {
+                if (tt_sub == 4) hipLaunchKernelGGL((gemm_tt_sub_kernel<4>), pgrid, pblock, 4 * 16384, s, g);
+                else if (tt_sub == 5) hipLaunchKernelGGL((gemm_tt_sub_kernel<5>), pgrid, pblock, 5 * 16384, s, g);
+                else EGK_PIPE(true, true);
+            } else EGK_PIPE(true, false);
         }
 #undef EGK_PIPE
         if (g.splitk > 1 && !g.sk_tickets) {
@@ -2375,6 +2587,8 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
             else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, gg);
         } else if (!ta && !tb) EGK_PIPE_G(false, false);
         else if (!ta && tb) EGK_PIPE_G(false, true);
+        else if (variant != 5 && packed && pad == 0 && g_tt_sub == 4) hipLaunchKernelGGL((gemm_tt_sub_group_kernel<4>), pgrid, pblock, 4 * 16384, s, gg);
+        else if (variant != 5 && packed && pad == 0 && g_tt_sub == 5) hipLaunchKernelGGL((gemm_tt_sub_group_kernel<5>), pgrid, pblock, 5 * 16384, s, gg);
         else EGK_PIPE_G(true, true);
     }
 #undef EGK_PIPE_G
