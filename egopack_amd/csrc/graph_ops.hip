@@ -908,6 +908,240 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
     }
 }
 
+// ---- nearest prototypes from ONE bf16 product: proven window + exact re-rank -------------------------------------------------
+// The search ranks cos(f_n, p_j) (reference models/graphONE/graphONE.py:119-141,148-151: argsort of 1 - cos).  ``dot1`` is the
+// bf16-MFMA product of hi(f) and hi(P), hi(x) = the bf16 nearest to x: one third of the matrix work of the three-product (f32-grade)
+// contraction.  Its error is bounded per row: dot - dot1 = f_lo . P_hi + f_hi . P_lo + f_lo . P_lo with x_lo = x - hi(x), so by
+// Cauchy-Schwarz |cos - cos1| <= rf (1 + rb) + (1 + rf) rb + rf rb with rf = |f_lo| / |f| (computed here from the row itself) and
+// rb = max_j |p_lo,j| / |p_j| (egk_bf16_residual_ratio, once per bank), plus the f32 accumulation of the H-term product
+// (<= H 2^-24 relative to |f| |p|: 6.1e-5 at H = 1024) -- E below.  With D_k the k-th smallest approximate distance of the row, a
+// prototype whose approximate distance exceeds D_k + 2 E cannot be among the k nearest: its true distance exceeds D_k + E, and k
+// prototypes have true distances <= D_k + E.  Every other prototype (a handful: profiles/r05_window_search.txt) is a CANDIDATE and gets
+// its EXACT product -- f32 operands, double accumulation, one wave per dot -- and the f32 key of topk_kernel; the k nearest candidates
+// in (key, index) order are the result.  No cap on the candidates: a row with many of them is slow, never wrong.
+__device__ __forceinline__ float bf16_rne_f32(float x) {
+    const unsigned u = __float_as_uint(x);
+    return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);  // (finite inputs: features / prototypes)
+}
+
+__global__ __launch_bounds__(256) void bf16_residual_ratio_kernel(const float* __restrict__ x, long long ld, float* __restrict__ r,
+                                                                  int rows, int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        float s2 = 0.f, r2 = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float v = x[(long long)row * ld + c], d = v - bf16_rne_f32(v);
+            s2 += v * v;
+            r2 += d * d;
+        }
+        s2 = wave_sum(s2);
+        r2 = wave_sum(r2);
+        if (lane == 0) r[row] = s2 > 0.f ? sqrtf(r2 / s2) : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void max_of_kernel(const float* __restrict__ r, float* __restrict__ out, int n) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, r[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <int KM>
+__global__ __launch_bounds__(256) void topk_window_kernel(const float* __restrict__ dot1, long long ldd, const float* __restrict__ f,
+                                                          long long ldf, const float* __restrict__ bank, long long ldb,
+                                                          const float* __restrict__ f_inv, const float* __restrict__ b_inv,
+                                                          const float* __restrict__ rb_max, long long* __restrict__ nn,
+                                                          int* __restrict__ cand, int rows, int K, int H, int k, int vec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float rb = rb_max[0];
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const float* dr = dot1 + (long long)row * ldd;
+        const float* fr = f + (long long)row * ldf;
+        const float fi = f_inv[row];
+        // the row's own rounding residual (and the row itself in registers when it fits: H <= 1024, whole float4 groups)
+        const bool in_regs = (H <= 1024) && ((H & 3) == 0) && ((ldf & 3) == 0);
+        float4 fv[4];
+        float s2 = 0.f, r2 = 0.f;
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane * 4 + 256 * u;
+                fv[u] = c < H ? *reinterpret_cast<const float4*>(fr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float e[4] = {fv[u].x, fv[u].y, fv[u].z, fv[u].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float d = e[t] - bf16_rne_f32(e[t]);
+                    s2 += e[t] * e[t];
+                    r2 += d * d;
+                }
+            }
+        } else {
+            for (int c = lane; c < H; c += 64) {
+                const float v = fr[c], d = v - bf16_rne_f32(v);
+                s2 += v * v;
+                r2 += d * d;
+            }
+        }
+        s2 = wave_sum(s2);
+        r2 = wave_sum(r2);
+        const float rf = s2 > 0.f ? sqrtf(r2 / s2) : 0.f;
+        const float E = 1.01f * (rf + rb) + 3.f * rf * rb + (float)H * 6.0e-8f + 2.0e-6f;
+
+        // ---- pass 1: the k-th smallest APPROXIMATE distance (topk_kernel's one-pass lists) ------------------------------------
+        float lv[KM];
+        int li[KM];
+#pragma unroll
+        for (int s = 0; s < KM; ++s) {
+            lv[s] = INFINITY;
+            li[s] = 0x7fffffff;
+        }
+        for (int base0 = lane * 4; base0 < K; base0 += 1024) {
+            float dq[4][4], bq[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int base = base0 + 256 * u;
+                if (vec && base + 4 <= K) {
+                    const float4 a = *reinterpret_cast<const float4*>(dr + base);
+                    const float4 b = *reinterpret_cast<const float4*>(b_inv + base);
+                    dq[u][0] = a.x; dq[u][1] = a.y; dq[u][2] = a.z; dq[u][3] = a.w;
+                    bq[u][0] = b.x; bq[u][1] = b.y; bq[u][2] = b.z; bq[u][3] = b.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dq[u][t] = base + t < K ? dr[base + t] : 0.f;
+                        bq[u][t] = base + t < K ? b_inv[base + t] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = base0 + 256 * u + t;
+                    float d = 1.f - dq[u][t] * fi * bq[u][t];
+                    int dj = j;
+                    if (j < K && (d < lv[KM - 1] || (d == lv[KM - 1] && dj < li[KM - 1]))) {
+#pragma unroll
+                        for (int s = 0; s < KM; ++s) {
+                            const bool before = d < lv[s] || (d == lv[s] && dj < li[s]);
+                            const float tv = lv[s];
+                            const int ti = li[s];
+                            lv[s] = before ? d : tv;
+                            li[s] = before ? dj : ti;
+                            d = before ? tv : d;
+                            dj = before ? ti : dj;
+                        }
+                    }
+                }
+        }
+        float Dk = INFINITY;
+        for (int sel = 0; sel < k; ++sel) {
+            float bv = lv[0];
+            int bi = li[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov < bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            Dk = bv;
+            if (li[0] == bi && bi != 0x7fffffff) {
+#pragma unroll
+                for (int s = 0; s + 1 < KM; ++s) {
+                    lv[s] = lv[s + 1];
+                    li[s] = li[s + 1];
+                }
+                lv[KM - 1] = INFINITY;
+                li[KM - 1] = 0x7fffffff;
+            }
+        }
+        const float T = Dk + 2.f * E;  // (fewer than k finite distances: Dk = inf, every finite one is a candidate)
+
+        // ---- pass 2: exact distances of the candidates; the k nearest of them in (key, index) order (wave-uniform list) --------
+        float ev[KM];
+        int ei[KM];
+#pragma unroll
+        for (int s = 0; s < KM; ++s) {
+            ev[s] = INFINITY;
+            ei[s] = 0x7fffffff;
+        }
+        int n_cand = 0;
+        for (int base0 = 0; base0 < K; base0 += 1024) {
+            float dq[4][4], bq[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int base = base0 + lane * 4 + 256 * u;
+                if (vec && base + 4 <= K) {
+                    const float4 a = *reinterpret_cast<const float4*>(dr + base);
+                    const float4 b = *reinterpret_cast<const float4*>(b_inv + base);
+                    dq[u][0] = a.x; dq[u][1] = a.y; dq[u][2] = a.z; dq[u][3] = a.w;
+                    bq[u][0] = b.x; bq[u][1] = b.y; bq[u][2] = b.z; bq[u][3] = b.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dq[u][t] = base + t < K ? dr[base + t] : 0.f;
+                        bq[u][t] = base + t < K ? b_inv[base + t] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = base0 + lane * 4 + 256 * u + t;
+                    const float d = 1.f - dq[u][t] * fi * bq[u][t];
+                    unsigned long long mask = __ballot(j < K && d <= T);
+                    n_cand += __popcll(mask);
+                    while (mask) {  // (wave-uniform)
+                        const int b = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int jj = base0 + b * 4 + 256 * u + t;
+                        const float* pr = bank + (long long)jj * ldb;
+                        double acc = 0.0;
+                        if (in_regs && (ldb & 3) == 0) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int c = lane * 4 + 256 * q;
+                                if (c < H) {
+                                    const float4 pv = *reinterpret_cast<const float4*>(pr + c);
+                                    acc += (double)fv[q].x * (double)pv.x + (double)fv[q].y * (double)pv.y +
+                                           (double)fv[q].z * (double)pv.z + (double)fv[q].w * (double)pv.w;
+                                }
+                            }
+                        } else {
+                            for (int c = lane; c < H; c += 64) acc += (double)fr[c] * (double)pr[c];
+                        }
+                        acc = wave_sum(acc);
+                        float de = 1.f - (float)acc * fi * b_inv[jj];
+                        int dj = jj;
+                        if (de < ev[KM - 1] || (de == ev[KM - 1] && dj < ei[KM - 1])) {
+#pragma unroll
+                            for (int s = 0; s < KM; ++s) {
+                                const bool before = de < ev[s] || (de == ev[s] && dj < ei[s]);
+                                const float tv = ev[s];
+                                const int ti = ei[s];
+                                ev[s] = before ? de : tv;
+                                ei[s] = before ? dj : ti;
+                                de = before ? tv : de;
+                                dj = before ? ti : dj;
+                            }
+                        }
+                    }
+                }
+        }
+        if (lane == 0) {
+            for (int s = 0; s < k; ++s) nn[(long long)row * k + s] = (s < KM && ei[s] != 0x7fffffff) ? ei[s] : 0;
+            if (cand) cand[row] = n_cand;
+        }
+    }
+}
+
 // ---- prototype bank accumulation (fp64 bank, no atomics) -----------------------------------------------------------
 // reference graphone.py:53: bank += scatter(task_feat, labels, dim_size, reduce="sum") -- the per-batch scatter sums the
 // rows of one label in the feature type (fp32) in node order, then the [size, H] result is added to the fp64 bank.  Here
@@ -1527,6 +1761,36 @@ int egk_topk_smallest(egk_stream_t stream, const float* dot, int64_t ldd, const 
 int egk_topk_smallest_l2(egk_stream_t stream, const float* dot, int64_t ldd, const float* f_sq, const float* b_sq,
                          int64_t* nn, int32_t rows, int32_t K, int32_t k) {
     return topk_launch("egk_topk_smallest_l2", true, stream, dot, ldd, f_sq, b_sq, nn, rows, K, k);
+}
+
+int egk_bf16_residual_ratio(egk_stream_t stream, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols) {
+    EGK_REQUIRE(x && r && rmax, "egk_bf16_residual_ratio: null pointer");
+    EGK_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, "egk_bf16_residual_ratio: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bf16_residual_ratio_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, (long long)ld, r, rows, cols);
+    hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(256), 0, s, r, rmax, rows);
+    return check_launch("egk_bf16_residual_ratio");
+}
+
+int egk_topk_window(egk_stream_t stream, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* bank, int64_t ldb,
+                    const float* f_inv, const float* b_inv, const float* rb_max, int64_t* nn, int32_t* cand, int32_t rows, int32_t K,
+                    int32_t H, int32_t k) {
+    EGK_REQUIRE(dot1 && f && bank && f_inv && b_inv && rb_max && nn, "egk_topk_window: null pointer");
+    EGK_REQUIRE(k >= 1 && k <= 16 && k <= K, "egk_topk_window: k must be in [1, min(16, K)]");
+    EGK_REQUIRE(H >= 1 && ldf >= H && ldb >= H && ldd >= K, "egk_topk_window: bad leading dimension");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_TOPK, s, 0, 8.0 * rows * K);
+    EGK_REQUIRE((uintptr_t)f % 16 == 0 && (uintptr_t)bank % 16 == 0, "egk_topk_window: feature / bank rows must be 16-byte aligned");
+    const int vec = (ldd % 4 == 0) && ((uintptr_t)dot1 % 16 == 0) && ((uintptr_t)b_inv % 16 == 0);
+    const dim3 grid(row_grid(rows)), block(256);
+    if (k <= 4)
+        hipLaunchKernelGGL((topk_window_kernel<4>), grid, block, 0, s, dot1, (long long)ldd, f, (long long)ldf, bank, (long long)ldb, f_inv,
+                           b_inv, rb_max, (long long*)nn, cand, rows, K, H, k, vec);
+    else
+        hipLaunchKernelGGL((topk_window_kernel<16>), grid, block, 0, s, dot1, (long long)ldd, f, (long long)ldf, bank, (long long)ldb, f_inv,
+                           b_inv, rb_max, (long long*)nn, cand, rows, K, H, k, vec);
+    return check_launch("egk_topk_window");
 }
 
 int egk_segment_sum_rows_f64(egk_stream_t stream, const void* x, const int32_t* order, const int32_t* seg_ptr,

@@ -263,6 +263,43 @@ class LTATemporalConnectivity:
 
 
 # --------------------------------------------------------------------------------------------
+# labelled rows of a per-node multi-head label tensor (the heads' row compaction, engine.MTLStep)
+# --------------------------------------------------------------------------------------------
+LIVE_ROWS_MAX_SHARE = 0.75  # compact only when at most this share of the nodes carries a label
+
+
+def live_label_rows(y, n_nodes: int):
+    """The reference labels only some nodes of a task batch: AR the centre node of every sequence (data/ego4d_fho.py:222-223),
+    LTA everything but the two input nodes (:361-362); every other node carries ``ignore_index`` in every head, so its loss is 0
+    and its gradient is 0 (criterion/wrapper.py:67-82, nn.CrossEntropyLoss(ignore_index=-1)) -- while the heads
+    (models/tasks/task.py:17-26, recognition.py:39-59) are ROW-WISE.  A training step can therefore run the heads on the
+    labelled rows only.  Host-side integer work: for ``y`` [N, heads] int64 returns (live_idx [cap] int64, live_inv [N] int64,
+    live_y [cap, heads]) -- the labelled rows in node order, padded with -1 (an all-zero row / an all-ignored label) to a
+    multiple of 64 rows -- or None when y is not such a tensor or more than LIVE_ROWS_MAX_SHARE of the nodes are labelled."""
+    import numpy as np
+    if not torch.is_tensor(y) or y.dim() != 2 or y.shape[0] != n_nodes or n_nodes == 0 or y.is_floating_point() or y.is_cuda:
+        return None
+    ya = y.numpy()
+    rows = np.flatnonzero((ya != -1).any(axis=1))
+    if rows.size > LIVE_ROWS_MAX_SHARE * n_nodes:
+        return None
+    cap = max(64, (rows.size + 63) // 64 * 64)
+    idx = np.full(cap, -1, dtype=np.int64)
+    idx[:rows.size] = rows
+    inv = np.full(n_nodes, -1, dtype=np.int64)
+    inv[rows] = np.arange(rows.size, dtype=np.int64)
+    yl = np.full((cap, ya.shape[1]), -1, dtype=np.int64)
+    yl[:rows.size] = ya[rows]
+    return torch.from_numpy(idx), torch.from_numpy(inv), torch.from_numpy(yl)
+
+
+def _attach_live_rows(out: "Data") -> None:
+    lr = live_label_rows(out.y, int(out.pos.shape[0]))
+    if lr is not None:
+        out.live_idx, out.live_inv, out.live_y = lr
+
+
+# --------------------------------------------------------------------------------------------
 # collation (reference a18: PyG Batch.from_data_list)
 # --------------------------------------------------------------------------------------------
 def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
@@ -290,6 +327,7 @@ def collate(samples: Sequence[Data], with_csr: bool = True) -> Data:
     out.seg_ptr = torch.tensor([0, off], dtype=torch.int32)  # one graph-LayerNorm segment: the whole batch
     # per-sample scalar attributes (pnr_frame, start_frame, end_frame, ...) become [B] tensors, as PyG's collation
     # does for python numbers (utils/dataloading.py:56-70; read by the PNR meter)
+    _attach_live_rows(out)
     known = {"x", "x_idx", "y", "pos", "edge_index", "batch", "ptr", "graph", "num_graphs", "ptr32", "seg_ptr"}
     for key, v in vars(samples[0]).items():
         if key in known or key.startswith("_"):
@@ -1118,6 +1156,7 @@ class SyntheticResidentDataset(SyntheticTaskDataset):
         out.graph = graph
         out.ptr32 = tn(ptr.astype(np.int32))
         out.seg_ptr = tn(np.array([0, n], dtype=np.int32))
+        _attach_live_rows(out)
         for key, v in tb["scalars"].items():
             setattr(out, key, tn(v[idx]))
         return out

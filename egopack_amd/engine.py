@@ -1173,17 +1173,27 @@ class MTLStep(StepBase):
             self._coef_grads = {}
         order = list(leaves)
         nets = [self.tasks[t].net for t in order]
-        grouped = self.grouped_heads and len(order) > 1 and ops.grouped_projection_ok([leaves[t] for t in order], nets)
+        # Row compaction (exact): the heads are row-wise and a node whose labels are all ``ignore_index`` has loss 0 and gradient 0
+        # (AR labels the centre node of a sequence only, data/ego4d_fho.py:222-223): such a task's projection, classifiers, loss and
+        # their backward run on its labelled rows (data.live_label_rows, padded with all-zero rows / ignored labels to a multiple of
+        # 64) and the feature gradient goes back to full height with zero rows elsewhere.  Loss vectors keep one element per node.
+        live = {t: batches[t] for t in order if self._compact_head_ok(t, batches[t], leaves[t])}
+        n_full = {t: leaves[t].shape[0] for t in order}
+        heads_in = {t: (ops.live_rows(leaves[t], live[t].live_idx, live[t].live_inv) if t in live else leaves[t]) for t in order}
+        labels = {t: (live[t].live_y if t in live else batches[t].y) for t in order}
+        full_vector = lambda t, v: ops.expand_rows(v, live[t].live_inv) if t in live else v.detach()
+        grouped = self.grouped_heads and len(order) > 1 and ops.grouped_projection_ok([heads_in[t] for t in order], nets)
         proj = proj_leaves = None
         if grouped:
-            proj = ops.grouped_projection([leaves[t] for t in order], nets)
+            proj = ops.grouped_projection([heads_in[t] for t in order], nets)
             proj_leaves = {t: f.detach().requires_grad_(True) for t, f in zip(order, proj)}
             ops.stamp("heads_proj_fwd_done")
 
         def head(t, leaf):
             # AR / LTA: one loss element per node, back-propagated below with the constant w_t / numel -- known before the
             # loss is computed, so the cross entropy emits its gradient in the same launch (ops.loss_seed)
-            n_loss = leaf.shape[0] if (t in ("ar", "lta", "pnr") and getattr(self, "_fused_loss", True)) else 0
+            # (the loss vector has one element per NODE, so the seed divides by the full node count also for a compacted head)
+            n_loss = n_full[t] if (t in ("ar", "lta", "pnr") and getattr(self, "_fused_loss", True)) else 0
             oscc_one = self._one_pass_oscc_ok(t) and batches[t].y.dim() == 1
             if oscc_one:
                 n_loss = int(batches[t].y.numel())  # one loss element per sequence
@@ -1204,18 +1214,19 @@ class MTLStep(StepBase):
                     n_loss = 0
                 else:
                     logits = task.forward_logits(f, d) if t == "oscc" else task.forward_logits(f)
-                    v = self.criteria[t](logits, d.y)
-            if n_loss and v.numel() != n_loss:
-                raise RuntimeError(f"head {t}: {v.numel()} loss elements where {n_loss} were announced to the fused loss")
+                    v = self.criteria[t](logits, labels[t])
+            n_out = v.numel() if t not in live else n_full[t]  # elements of the loss vector the objective averages over
+            if n_loss and n_out != n_loss:
+                raise RuntimeError(f"head {t}: {n_out} loss elements where {n_loss} were announced to the fused loss")
             if v.numel():
                 # the constant the objective's backward hands this head (w_t / numel): one tensor per task, filled once
-                key = (t, v.numel(), v.dtype, v.device)
+                key = (t, v.numel(), n_out, v.dtype, v.device)
                 g = self._coef_grads.get(key)
-                if g is None or g._egk_coef != self.weights[t] / v.numel():
-                    g = self._coef_grads[key] = torch.full_like(v, self.weights[t] / v.numel(), dtype=v.dtype).detach()
-                    g._egk_coef = self.weights[t] / v.numel()
+                if g is None or g._egk_coef != self.weights[t] / n_out:
+                    g = self._coef_grads[key] = torch.full_like(v, self.weights[t] / n_out, dtype=v.dtype).detach()
+                    g._egk_coef = self.weights[t] / n_out
                 v.backward(gradient=g)
-            return v.detach(), logits
+            return full_vector(t, v), logits
         # the multi-head classifier banks of several tasks (AR and LTA: same widths, own rows and weights) as ONE chain of
         # grouped launches on the main stream -- grouped classifier contraction, one fused cross entropy per task, grouped dX --
         # instead of one chain per task on its own stream (each fork / join of a stream costs more than these launches)
@@ -1224,14 +1235,14 @@ class MTLStep(StepBase):
 
         def banked_chain():
             views = [self.tasks[t].classifiers[0][1].weight._egk_bank_views for t in banked]
-            n_loss = {t: proj_leaves[t].shape[0] for t in banked}
+            n_loss = {t: n_full[t] for t in banked}  # (one loss element per NODE: a compacted head's seed divides by the full count)
             all_logits = ops.grouped_classifier_banks([proj_leaves[t] for t in banked], views,
                                                       fused_loss=getattr(self, "_fused_loss", True))
             vs, gs = [], []
             multi = None
             if getattr(self, "_fused_loss", True) and "ce_multi" not in getattr(self, "_dev_off", ()):
                 # the cross entropies of the banked tasks as ONE launch (each writes its own loss vector and gradient operand)
-                sel = [self.criteria[t].select(logits, batches[t].y) for t, logits in zip(banked, all_logits)]
+                sel = [self.criteria[t].select(logits, labels[t]) for t, logits in zip(banked, all_logits)]
                 if len({s_[2] for s_ in sel}) == 1:
                     multi = ops.cross_entropy_multi([(s_[0], s_[1]) for s_ in sel], [self.weights[t] / n_loss[t] for t in banked],
                                                     sel[0][2])
@@ -1240,20 +1251,20 @@ class MTLStep(StepBase):
                     v = multi[i]
                 else:
                     with ops.loss_seed(self.weights[t] / n_loss[t] if getattr(self, "_fused_loss", True) else None):
-                        v = self.criteria[t](logits, batches[t].y)
-                if v.numel() != n_loss[t]:
-                    raise RuntimeError(f"head {t}: {v.numel()} loss elements where {n_loss[t]} were announced to the fused loss")
-                key = (t, v.numel(), v.dtype, v.device)
+                        v = self.criteria[t](logits, labels[t])
+                if v.numel() != proj_leaves[t].shape[0]:
+                    raise RuntimeError(f"head {t}: {v.numel()} loss elements for {proj_leaves[t].shape[0]} rows")
+                key = (t, v.numel(), n_loss[t], v.dtype, v.device)
                 g = self._coef_grads.get(key)
-                if g is None or g._egk_coef != self.weights[t] / v.numel():
-                    g = self._coef_grads[key] = torch.full_like(v, self.weights[t] / v.numel(), dtype=v.dtype).detach()
-                    g._egk_coef = self.weights[t] / v.numel()
+                if g is None or g._egk_coef != self.weights[t] / n_loss[t]:
+                    g = self._coef_grads[key] = torch.full_like(v, self.weights[t] / n_loss[t], dtype=v.dtype).detach()
+                    g._egk_coef = self.weights[t] / n_loss[t]
                 vs.append(v)
                 gs.append(g)
-                banked_vectors[t] = v.detach()
+                banked_vectors[t] = full_vector(t, v)
             torch.autograd.backward(vs, gs)  # ONE pass: both cross entropies, then the grouped banks' backward once
         with ops.bank_grad_handoff():  # every head's logits feed exactly one loss node here
-            src = proj_leaves if grouped else leaves
+            src = proj_leaves if grouped else heads_in
             rest = {t: f for t, f in src.items() if t not in banked}
             vectors, _ = self._run_heads(rest, head, main_job=banked_chain if banked else None)
             vectors.update(banked_vectors)
@@ -1267,6 +1278,29 @@ class MTLStep(StepBase):
         with torch.no_grad():
             total = self._objective(vectors)
         return total, vectors, leaves
+
+    compact_heads = True  # heads on the labelled rows only (data.live_label_rows); EGK_DISABLE=compact_heads: every row
+
+    def _compact_head_ok(self, t: str, d, leaf) -> bool:
+        """Task ``t``'s head runs on its labelled rows: a multi-head cross-entropy head (MetricSelectorWrapper over
+        CrossEntropyNone with ignore_index -1: the row's loss and gradient are exactly zero when every head's label is -1),
+        no active dropout in the head (its masks are drawn by row position), the batch built by data.collate with its
+        ``live_*`` index arrays on the features' device."""
+        if not self.compact_heads or "compact_heads" in getattr(self, "_dev_off", ()) or t not in ("ar", "lta"):
+            return False
+        idx = getattr(d, "live_idx", None)
+        if idx is None or getattr(d, "live_inv", None) is None or getattr(d, "live_y", None) is None:
+            return False
+        if not (idx.is_cuda and idx.device == leaf.device and d.live_inv.numel() == leaf.shape[0]):
+            return False
+        from .criterion import CrossEntropyNone
+        crit = self.criteria.get(t)
+        if not isinstance(crit, MetricSelectorWrapper) or type(getattr(crit, "criterion", None)) is not CrossEntropyNone:
+            return False
+        # (a row labelled only in a column the wrapper does not select is kept: its loss and gradient are still exactly zero)
+        task = self.tasks[t]
+        drops = [m for m in task.modules() if isinstance(m, torch.nn.Dropout) or type(m).__name__ == "Dropout"]
+        return not (task.training and any(getattr(m, "p", 0) > 0 for m in drops))
 
     headwise_backward = True  # False: one backward() call over all streams (kept for A/B measurements)
     early_adam = True
@@ -1471,10 +1505,11 @@ class EgoPackStep(StepBase):
                           else {o: self.tasks[o].forward_features(feats[t], out_f32=True) for o in others})
         return out
 
-    def task_loss(self, primary: str, feat, data, aux_in=None):
+    def task_loss(self, primary: str, feat, data, aux_in=None, f_primary=None):
         task = self.tasks[primary]
         others = self._aux_names(primary)
-        f_primary = task.forward_features(feat)
+        if f_primary is None:
+            f_primary = task.forward_features(feat)
         if aux_in is None:
             with torch.no_grad():
                 # f32 out of the projections' last contraction: the nearest-prototype search (an index op) ranks the f32
@@ -1545,6 +1580,11 @@ class EgoPackStep(StepBase):
             side.wait_event(fork_ev)
             with torch.cuda.stream(side):
                 precise = self.precise_aux_features(batches, merged, rng_snap=snap)
+        # the primary projection heads need nothing of the precise pass: issued BEFORE the join with its stream, so that they run
+        # beside its tail instead of behind it (profiles/r04_c4_replay_timeline.txt: 896-990 us, 95 us in which nothing else ran)
+        f_prim = {}
+        if side is not None and len(feats) == 1 and "primary_early" not in getattr(self, "_dev_off", ()):
+            f_prim = {t: self.tasks[t].forward_features(f) for t, f in feats.items()}
         if side is not None:
             main.wait_stream(side)
             for d in precise.values():
@@ -1552,7 +1592,7 @@ class EgoPackStep(StepBase):
                     a.record_stream(main)
 
         def head(t, feat):
-            loss, logits, _, _ = self.task_loss(t, feat, batches[t], aux_in=precise.get(t))
+            loss, logits, _, _ = self.task_loss(t, feat, batches[t], aux_in=precise.get(t), f_primary=f_prim.get(t))
             return loss, logits
         vectors, logits_out = self._run_heads(feats, head)
         return self._objective(vectors), vectors, logits_out

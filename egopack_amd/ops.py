@@ -2344,6 +2344,47 @@ def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_s
                            ln_out, ln_in, res_src, getattr(graph, "band", None), int(getattr(graph, "tile_mask", 0) or 0))
 
 
+# ---- labelled rows only (the heads' row compaction) --------------------------------------------------------------------------
+class _LiveRows(torch.autograd.Function):
+    """Rows ``idx`` of x (int64 [cap]; -1 = an all-zero pad row); backward puts the gradient rows back at their places through the
+    inverse map ``inv`` (int64 [N]; -1 = a row that was left out: zero gradient).  Both directions are ``egk_gather_rows``."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv):
+        _need_gpu(x)
+        x = _c(x)
+        out = torch.empty((idx.numel(), x.shape[1]), dtype=x.dtype, device=x.device)
+        _ck(_lib.load().egk_gather_rows(_stream(), _p(x), _dt(x), x.stride(0), x.shape[0], _p(idx), _p(out), _dt(out), idx.numel(),
+                                        x.shape[1]), "egk_gather_rows")
+        ctx.save_for_backward(inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        inv, = ctx.saved_tensors
+        g = _c(g)
+        out = torch.empty((inv.numel(), g.shape[1]), dtype=g.dtype, device=g.device)
+        _ck(_lib.load().egk_gather_rows(_stream(), _p(g), _dt(g), g.stride(0), g.shape[0], _p(inv), _p(out), _dt(out), inv.numel(),
+                                        g.shape[1]), "egk_gather_rows")
+        return out, None, None
+
+
+def live_rows(x, idx, inv):
+    """The labelled rows of a task batch's features (data.live_label_rows) for its row-wise head; see ``_LiveRows``."""
+    return _LiveRows.apply(x, idx, inv)
+
+
+@torch.no_grad()
+def expand_rows(v, inv):
+    """A per-row vector of the compacted batch back at full length: out[i] = v[inv[i]], 0 where inv[i] < 0 (the loss vector of
+    the reference has one element per node, zero on ignored nodes: criterion/wrapper.py:67-82)."""
+    v2 = _c(v.detach().reshape(-1, 1))
+    out = torch.empty((inv.numel(), 1), dtype=v2.dtype, device=v2.device)
+    _ck(_lib.load().egk_gather_rows(_stream(), _p(v2), _dt(v2), 1, v2.shape[0], _p(inv), _p(out), _dt(out), inv.numel(), 1),
+        "egk_gather_rows")
+    return out.reshape(-1)
+
+
 # ---- GraphONE gather-max ------------------------------------------------------------------------------
 @torch.no_grad()
 def _edges_by_prototype(nn: torch.Tensor, K: int):
@@ -3084,6 +3125,34 @@ def row_sq_norm(x):
     return out
 
 
+# The one-product search (egk_topk_window): per bank the bf16 operand hi(P) and the largest rounding residual ratio of its rows,
+# kept while (address, shape, version) stand -- the banks are frozen (graphONE.py:48) unless GraphONE is built with freeze=False.
+_window_search = {"on": "window_search" not in os.environ.get("EGK_DISABLE", "")}
+_window_bank_cache = {}
+_window_stats = {"cand": None}  # development / tests: an int32 [N] tensor here receives the candidates per row of the next search
+
+
+def _window_search_ok(N, K, H, k, f, bank) -> bool:
+    return bool(_window_search["on"] and H % 64 == 0 and H >= 64 and K >= 64 and k <= 16 and f.stride(0) % 4 == 0
+                and bank.stride(0) % 4 == 0 and f.data_ptr() % 16 == 0 and bank.data_ptr() % 16 == 0 and N > 0)
+
+
+def _bank_window_operand(bank):
+    key = (bank.data_ptr(), tuple(bank.shape), bank.device.index)
+    hit = _window_bank_cache.get(key)
+    if hit is not None and hit[0] == bank._version:
+        return hit[1], hit[2]
+    if len(_window_bank_cache) > 64:
+        _window_bank_cache.clear()
+    hi = cast_raw(bank, torch.bfloat16)
+    r = torch.empty(bank.shape[0], dtype=torch.float32, device=bank.device)
+    rmax = torch.empty(1, dtype=torch.float32, device=bank.device)
+    _ck(_lib.load().egk_bf16_residual_ratio(_stream(), _p(bank), bank.stride(0), _p(r), _p(rmax), bank.shape[0], bank.shape[1]),
+        "egk_bf16_residual_ratio")
+    _window_bank_cache[key] = (bank._version, hi, rmax, bank)  # (the bank itself: its address cannot be reused while it is cached)
+    return hi, rmax
+
+
 @torch.no_grad()
 def nearest_prototypes(f, bank, k, distance_func: str = "cosine", bank_norm=None):
     """Indices [N, k] (int64, ascending distance, ties to the lower index) of the k nearest bank rows of every row of
@@ -3106,12 +3175,24 @@ def nearest_prototypes(f, bank, k, distance_func: str = "cosine", bank_norm=None
         bank_norm = norm(bank)
     f_norm = norm(f)
     dot = torch.empty((N, K), dtype=torch.float32, device=f.device)
+    nn = torch.empty((N, k), dtype=torch.int64, device=f.device)
+    if not l2 and _state["compute"] != F32 and _window_search_ok(N, K, H, k, f, bank):
+        # the bf16 modes: ONE bf16 product of the rounded operands, a proven error window per row, the exact distances of the few
+        # prototypes inside it (egk_topk_window) -- a third of the three-product search's matrix work, the same lists
+        hi = cast_raw(f, torch.bfloat16)
+        bank_hi, rb_max = _bank_window_operand(bank)
+        gemm(N, K, hi, H, bank_hi, H, H, dot, K, compute=BF16)
+        cand = _window_stats["cand"]
+        if cand is not None and (cand.numel() != N or cand.device != f.device):
+            cand = None
+        _ck(lib.egk_topk_window(_stream(), _p(dot), K, _p(f), f.stride(0), _p(bank), bank.stride(0), _p(f_norm), _p(bank_norm),
+                                _p(rb_max), _p(nn), _p(cand), N, K, H, k), "egk_topk_window")
+        return nn
     # 'f32' mode: the exact-f32 matrix instructions.  The bf16 modes: the three-product contraction of the f32 values
     # (absolute error of a cosine ~3e-7, against ranking gaps of ~5e-3 between neighbouring prototypes: the lists are those of
     # the exact product wherever its gap exceeds 1e-5) at a fifth of the time -- the N x K x H product was 1 ms of the 3.4 ms
     # EgoPack step on the exact path
     gemm(N, K, f, H, bank, H, H, dot, K, compute=F32 if _state["compute"] == F32 else X3)
-    nn = torch.empty((N, k), dtype=torch.int64, device=f.device)
     fn = lib.egk_topk_smallest_l2 if l2 else lib.egk_topk_smallest
     _ck(fn(_stream(), _p(dot), K, _p(f_norm), _p(bank_norm), _p(nn), N, K, k), "egk_topk_smallest")
     return nn

@@ -418,6 +418,20 @@ int egk_cos_dist(egk_stream_t s, const float* dot, int64_t ldd, const float* f_i
 int egk_topk_smallest(egk_stream_t s, const float* dot, int64_t ldd, const float* f_inv, const float* b_inv,
                       int64_t* nn, int32_t rows, int32_t K, int32_t k);
 
+/* The same selection from ONE bf16 product (reference models/graphONE/graphONE.py:119-141,148-151; replaces the f32-grade product in
+ * front of egk_topk_smallest in the bf16 compute modes): dot1[n,j] = hi(f_n) . hi(p_j), hi(x) = the bf16 nearest to x (bf16 MFMA, f32
+ * accumulation).  Per row the error of cos from dot1 is bounded by E = rf + rb (+ second-order and accumulation terms) with
+ * rf = ||f_n - hi(f_n)|| / ||f_n|| (computed here) and *rb_max = max_j ||p_j - hi(p_j)|| / ||p_j|| (egk_bf16_residual_ratio); every
+ * prototype whose approximate distance is within 2 E of the row's k-th smallest approximate distance gets its EXACT product (f32 rows
+ * f [rows, H], bank [K, H], double accumulation) and egk_topk_smallest's key 1 - dot * f_inv[n] * b_inv[j]; nn[n, 0..k) = the k nearest
+ * of them, ascending, ties -> lower index.  cand[n] (optional) = how many prototypes of row n were re-evaluated.  Rows of f and bank
+ * must be 16-byte aligned. k <= 16. */
+int egk_topk_window(egk_stream_t s, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* bank, int64_t ldb,
+                    const float* f_inv, const float* b_inv, const float* rb_max, int64_t* nn, int32_t* cand, int32_t rows, int32_t K,
+                    int32_t H, int32_t k);
+/* r[j] = ||x_j - hi(x_j)|| / ||x_j|| for the rows of an f32 matrix, *rmax = max_j r[j] (once per prototype bank) */
+int egk_bf16_residual_ratio(egk_stream_t s, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols);
+
 /* distance_func='l2' (graphONE.py:126-127,144-145: cdist / 4096): sq_norm[r] = ||x[r,:]||^2 and
  * dist[n,j] = sqrt(max(f_sq[n] + b_sq[j] - 2 dot[n,j], 0)) / 4096; selection exactly as egk_topk_smallest. */
 int egk_row_sq_norm(egk_stream_t s, const void* x, float* sq_norm, int32_t rows, int32_t cols, int32_t dtype);

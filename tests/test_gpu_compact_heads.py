@@ -1,0 +1,134 @@
+"""The heads' row compaction (engine.MTLStep.compact_heads; reference criterion/wrapper.py:67-82, main_temporal.py:93-126,
+models/tasks/task.py:17-26): a task whose labels are ``ignore_index`` on most nodes (AR: the centre node of every sequence
+only, data/ego4d_fho.py:222-223) runs its row-wise head -- projection, classifiers, cross entropy and their backward -- on the
+labelled rows only.  Everything the step returns and every gradient must be what the all-rows head gives: loss vectors with one
+element per node (zero on ignored nodes), the objective's mean over ALL nodes, zero feature-gradient rows on ignored nodes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def test_live_rows_forward_gathers_and_backward_scatters_with_zero_rows():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import data as D
+    from egopack_amd import ops
+    torch.manual_seed(0)
+    n, H = 96, 1024
+    y = torch.full((n, 2), -1, dtype=torch.long)
+    rows = torch.tensor([3, 17, 18, 40, 95])
+    y[rows, 0] = torch.arange(5)
+    y[rows[:2], 1] = 7
+    idx, inv, yl = D.live_label_rows(y, n)
+    assert idx.shape == (64,) and inv.shape == (n,) and yl.shape == (64, 2)
+    assert idx[:5].tolist() == rows.tolist() and bool((idx[5:] == -1).all())
+    assert torch.equal(yl[:5], y[rows]) and bool((yl[5:] == -1).all())
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(n, H, device=DEV).to(dt).requires_grad_(True)
+        out = ops.live_rows(x, idx.to(DEV), inv.to(DEV))
+        assert torch.equal(out[:5], x.detach()[rows.to(DEV)]) and bool((out[5:] == 0).all())
+        g = torch.randn(64, H, device=DEV).to(dt)
+        out.backward(g)
+        want = torch.zeros(n, H, device=DEV, dtype=dt)
+        want[rows.to(DEV)] = g[:5]
+        assert torch.equal(x.grad, want)
+    v = torch.randn(64, device=DEV)
+    full = ops.expand_rows(v, inv.to(DEV))
+    want = torch.zeros(n, device=DEV)
+    want[rows.to(DEV)] = v[:5]
+    assert torch.equal(full, want)
+
+
+def _build(mode, compact, dropout=0.0):
+    import bench
+    from egopack_amd import engine, ops
+    from egopack_amd.optim import FlatAdam
+    args = bench.parse_args(["--workload", "mtl", "--batch", "8", "--T", "16", "--hidden", "128", "--trn-hidden", "128",
+                             "--dropout", str(dropout)])
+    args.compute = mode
+    ops.set_compute(mode)
+    ops.manual_seed(5)
+    model, tasks, crit, weights, dev, merged = bench.build_workload(args, 0, torch.device(DEV))
+    if mode != "bf16":
+        merged.x = merged.x.float()
+        off = 0
+        for t in ("ar", "lta", "pnr"):
+            n = dev[t].x.shape[0]
+            dev[t].x = merged.x[off:off + n]
+            off += n
+    model.to(DEV).train()
+    for t in tasks.values():
+        t.to(DEV).train()
+    params = [*model.parameters(), *(p for t in tasks.values() for p in t.parameters())]
+    opt = FlatAdam(params, lr=1e-3, weight_decay=1e-5)
+    step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=True)
+    step.compact_heads = compact
+    return step, opt, dev, merged, {"temporal_graph": model, **tasks}
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_heads_on_the_labelled_rows_equal_heads_on_all_rows(mode):
+    """Three steps (the third one on the optimizer's flat buffers: grouped projection heads, classifier banks, fused cross
+    entropies) with the AR head on its 8 labelled rows against the same steps with every head on all 128 rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops
+    prev = ops.get_compute()
+    try:
+        res = {}
+        for compact in (False, True):
+            step, opt, dev, merged, modules = _build(mode, compact)
+            assert getattr(dev["ar"], "live_idx", None) is not None and getattr(dev["lta"], "live_idx", None) is None
+            assert step._compact_head_ok("ar", dev["ar"], torch.empty(dev["ar"].pos.shape[0], 1, device=DEV)) == compact
+            for _ in range(2):
+                step.step(dev, merged)
+            total, vectors = step.forward_backward(dev, merged)
+            torch.cuda.synchronize()
+            grads = {f"{g}/{k}": p.grad.detach().float().cpu().clone() for g, m in modules.items() for k, p in m.named_parameters()
+                     if p.grad is not None}
+            res[compact] = (float(total), {t: v.detach().float().cpu() for t, v in vectors.items()}, grads)
+    finally:
+        ops.set_compute(prev)
+    (t0, v0, g0), (t1, v1, g1) = res[False], res[True]
+    n = v0["ar"].numel()
+    assert v1["ar"].shape == v0["ar"].shape == (n,)  # one loss element per NODE
+    labelled = (v0["ar"] != 0)
+    assert int(labelled.sum()) == 8 and bool((v1["ar"][~labelled] == 0).all())
+    tol = dict(rtol=2e-5, atol=1e-6) if mode == "f32" else dict(rtol=2e-2, atol=2e-3)  # (two Adam steps apart in bf16 storage)
+    for t in v0:
+        torch.testing.assert_close(v1[t], v0[t], **tol, msg=lambda s: f"loss[{t}]: {s}")
+    assert abs(t1 - t0) <= (1e-5 if mode == "f32" else 5e-3) * abs(t0)
+    assert set(g0) == set(g1)
+    worst = 0.0
+    for k in g0:
+        den = float(g0[k].norm())
+        if den > 0:
+            worst = max(worst, float((g1[k] - g0[k]).norm()) / den)
+    assert worst < (1e-4 if mode == "f32" else 6e-2), worst
+
+
+def test_compacted_heads_in_a_captured_step_equal_the_eager_step():
+    """hipGraph replay of the step with the compacted AR head = the eagerly issued steps, bit for bit (bf16 mode)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import ops
+    prev = ops.get_compute()
+    try:
+        out = []
+        for graph in (False, True):
+            step, opt, dev, merged, _ = _build("bf16", True)
+            if graph:
+                step.capture(dev, merged, warmup=2)
+                for _ in range(3):
+                    step.replay()
+            else:
+                for _ in range(5):
+                    step.step(dev, merged)
+            torch.cuda.synchronize()
+            out.append(opt.flat_p.clone())
+    finally:
+        ops.set_compute(prev)
+    assert torch.equal(out[0], out[1])

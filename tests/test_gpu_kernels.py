@@ -1830,3 +1830,66 @@ def test_segment_max_rows_shared_by_four_lanes(ops, lens, cols, dt):
             ref_v[s_], ref_a[s_] = v, (first + a).int()
     assert torch.equal(out.float().cpu(), ref_v)
     assert torch.equal(arg.cpu(), ref_a)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# nearest prototypes from ONE bf16 product + proven window + exact re-rank (egk_topk_window)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,K,H,k", [(300, 4096, 1024, 4), (70, 257, 128, 8), (64, 64, 64, 4), (33, 1000, 1024, 16), (40, 512, 2048, 4)])
+def test_window_search_gives_the_lists_of_the_exact_distances(ops, N, K, H, k):
+    """GraphONE.__compute_edges (reference models/graphONE/graphONE.py:119-141) in the bf16 compute modes: the neighbour lists from
+    the one-product search (bf16 MFMA product of the rounded operands, per-row error window, exact re-rank of the candidates) must
+    be the lists of the exact distances -- including clusters of prototypes that the bf16 product cannot tell apart, exact
+    duplicates (ties -> lower index) and features that are exactly representable in bf16 -- and equal the three-product search
+    wherever the ranking gap exceeds its own noise."""
+    g = gen(N * 7 + K)
+    f, bank = torch.randn(N, H, generator=g), torch.randn(K, H, generator=g)
+    if K >= 256:
+        # rows 0-9 sit next to a cluster of 6 near-identical prototypes (relative spread 2e-3: cosines ~1e-5 apart, two orders
+        # below the resolution of the bf16 product) -- the exact ranking inside the cluster decides the list
+        for r in range(10):
+            j0 = 10 + 7 * r
+            for i in range(1, 6):
+                bank[j0 + i] = bank[j0] + 2e-3 * torch.randn(H, generator=g)
+            f[r] = bank[j0] + 0.5 * torch.randn(H, generator=g)
+        bank[200] = bank[199]  # an exact duplicate: the lower index first
+        f[10] = bank[199] + 0.3 * torch.randn(H, generator=g)
+        f[11] = f[11].to(torch.bfloat16).float()  # rf = 0: the window is the bank's alone
+    fd, bd = f.to(DEV), bank.to(DEV)
+    cand = torch.zeros(N, dtype=torch.int32, device=DEV)
+    with ops.compute_mode("bf16"):
+        ops._window_stats["cand"] = cand
+        try:
+            nn = ops.cosine_topk(fd, bd, k).cpu()
+        finally:
+            ops._window_stats["cand"] = None
+        prev = ops._window_search["on"]
+        ops._window_search["on"] = False
+        try:
+            nn3 = ops.cosine_topk(fd, bd, k).cpu()
+        finally:
+            ops._window_search["on"] = prev
+    fn, bn = f.double() / f.double().norm(dim=1, keepdim=True), bank.double() / bank.double().norm(dim=1, keepdim=True)
+    dist = 1.0 - fn @ bn.T
+    srt, order = torch.sort(dist, dim=1, stable=True)
+    gap = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values
+    cand = cand.cpu()
+    assert int(cand.min()) >= k and float(cand.float().mean()) < max(64, 4 * k), (int(cand.min()), float(cand.float().mean()))
+    safe = gap > 2e-6  # (the f32 key 1 - dot * f_inv * b_inv carries ~1e-7 of rounding: below that a tie is a tie)
+    if K >= 256:
+        assert int(safe[:10].sum()) >= 1  # planted clusters that ARE resolvable in f32 -- and must be resolved (checked below)
+        assert nn[10, :2].tolist() == [199, 200]
+    assert torch.equal(nn[safe], order[safe][:, :k])
+    torch.testing.assert_close(torch.gather(dist, 1, nn), srt[:, :k], rtol=0, atol=1e-6)
+    safe3 = gap > 1e-5  # the three-product search: exact where the gap exceeds ITS noise
+    assert torch.equal(nn[safe3], nn3[safe3])
+
+
+def test_window_search_with_bf16_features_and_ties(ops):
+    """bf16 features (hi(f) = f: no row residual) and a bank with whole groups of identical rows: ties go to the lower index."""
+    bank = torch.randn(64, 64, generator=gen(5))
+    bank[1::2] = bank[0::2]  # 32 pairs of identical prototypes
+    f = (bank[[4, 10, 20]] + 0.1 * torch.randn(3, 64, generator=gen(6))).to(torch.bfloat16)
+    with ops.compute_mode("bf16"):
+        nn = ops.cosine_topk(f.to(DEV), bank.to(DEV), 2).cpu()
+    assert nn.tolist() == [[4, 5], [10, 11], [20, 21]]

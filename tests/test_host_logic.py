@@ -505,3 +505,26 @@ def test_ranges_minus_holes():
     assert _minus([(0, 100)], []) == [(0, 100)] and _minus([(0, 100)], [(0, 100)]) == []
     assert _minus([(0, 8), (8, 8)], [(100, 200)]) == [(0, 8)]
     assert _minus([(0, 100)], [(10, 20), (15, 30), (90, 120)]) == [(0, 10), (30, 90)]
+
+
+def test_live_label_rows_of_a_multi_head_label_tensor():
+    """data.live_label_rows: the nodes with a label in any head, in node order, padded to 64 rows with -1; absent when most nodes
+    are labelled (LTA) or the labels are not per node and head (OSCC, PNR); collate attaches the arrays to AR batches."""
+    from egopack_amd import data as D
+    y = torch.full((40, 2), -1, dtype=torch.long)
+    y[5, 0], y[5, 1], y[22, 1] = 3, 9, 4
+    idx, inv, yl = D.live_label_rows(y, 40)
+    assert idx.tolist() == [5, 22] + [-1] * 62
+    assert inv[5] == 0 and inv[22] == 1 and int((inv == -1).sum()) == 38
+    assert yl[:2].tolist() == [[3, 9], [-1, 4]] and bool((yl[2:] == -1).all())
+    assert D.live_label_rows(torch.zeros(40, 2, dtype=torch.long), 40) is None        # every node labelled
+    assert D.live_label_rows(torch.zeros(40, dtype=torch.long), 40) is None           # PNR: one label per node, no heads
+    assert D.live_label_rows(torch.zeros(5, dtype=torch.long), 40) is None            # OSCC: one label per sequence
+    none = D.live_label_rows(torch.full((40, 2), -1, dtype=torch.long), 40)           # nothing labelled: 64 pad rows
+    assert none[0].shape == (64,) and bool((none[0] == -1).all())
+    for task, want in (("ar", True), ("lta", False), ("pnr", False), ("oscc", False)):
+        ds = D.SyntheticTaskDataset(task, 4, 16, 3, 8, (7, 11), k=1, seed=3)
+        b = D.collate([ds[i] for i in range(4)])
+        assert (getattr(b, "live_idx", None) is not None) == want, task
+        if want:
+            assert b.live_idx[:4].tolist() == [8, 24, 40, 56] and b.live_inv.shape == (64,) and torch.equal(b.live_y[:4], b.y[b.live_idx[:4]])
