@@ -293,10 +293,26 @@ def live_label_rows(y, n_nodes: int):
     return torch.from_numpy(idx), torch.from_numpy(inv), torch.from_numpy(yl)
 
 
+def live_rows_progression(live_idx):
+    """(first, step, count) when the labelled rows are an arithmetic progression that fills the padded list (count a multiple of
+    64: one labelled node per sequence of equal length -- AR) -- a strided view then stands for the gathered rows -- else None."""
+    idx = live_idx.numpy() if torch.is_tensor(live_idx) else live_idx
+    n = int(idx.shape[0])
+    if n < 2 or idx[-1] < 0:
+        return None
+    step = int(idx[1] - idx[0])
+    if step < 1 or not bool((idx[1:] - idx[:-1] == step).all()):
+        return None
+    return int(idx[0]), step, n
+
+
 def _attach_live_rows(out: "Data") -> None:
     lr = live_label_rows(out.y, int(out.pos.shape[0]))
     if lr is not None:
         out.live_idx, out.live_inv, out.live_y = lr
+        ap = live_rows_progression(out.live_idx)
+        if ap is not None:
+            out.live_ap = ap  # (host integers: known without a device round trip, part of a captured step's signature)
 
 
 # --------------------------------------------------------------------------------------------

@@ -468,9 +468,10 @@ class StepBase:
                 main_job()
         return vectors, extras
 
-    def _objective(self, vectors):
+    def _objective(self, vectors, counts=None):
         order = [t for t in self.enabled if t in vectors]
-        return ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order])
+        return ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order],
+                                     None if counts is None else [counts.get(t) for t in order])
 
     # ---- eager step -------------------------------------------------------------------------------------
     # Exact cross-rank graph-LayerNorm statistics (SURVEY 8e caveat 1, optional): with several ranks every graph LayerNorm
@@ -1179,15 +1180,38 @@ class MTLStep(StepBase):
         # 64) and the feature gradient goes back to full height with zero rows elsewhere.  Loss vectors keep one element per node.
         live = {t: batches[t] for t in order if self._compact_head_ok(t, batches[t], leaves[t])}
         n_full = {t: leaves[t].shape[0] for t in order}
-        heads_in = {t: (ops.live_rows(leaves[t], live[t].live_idx, live[t].live_inv) if t in live else leaves[t]) for t in order}
         labels = {t: (live[t].live_y if t in live else batches[t].y) for t in order}
-        full_vector = lambda t, v: ops.expand_rows(v, live[t].live_inv) if t in live else v.detach()
-        grouped = self.grouped_heads and len(order) > 1 and ops.grouped_projection_ok([heads_in[t] for t in order], nets)
+        compact_v = {}  # the compacted heads' loss vectors as computed (the objective sums these; n_full divides)
+
+        def full_vector(t, v):
+            if t not in live:
+                return v.detach()
+            # one element per node for the caller (meters); the launch feeds nothing on the chain: it rides with the parked weight
+            # gradients' next flush, on their stream
+            compact_v[t] = v.detach()
+            out = torch.empty(n_full[t], dtype=v.dtype, device=v.device)
+            inv, src = live[t].live_inv, compact_v[t]
+            ops.park_rider(lambda: ops.expand_rows(src, inv, out=out), (src, inv, out))
+            return out
+        # (a task whose labelled rows are an arithmetic progression -- one labelled node per sequence -- hands the grouped
+        #  projection its full-height features and a row spec: a strided view stands for the gathered rows, no launch)
+        specs, grouped = {}, False
+        if self.grouped_heads and len(order) > 1:
+            specs = {t: (*live[t].live_ap, live[t].live_inv) for t in live if getattr(live[t], "live_ap", None) is not None}
+            grouped = ops.grouped_projection_ok([leaves[t] for t in order], nets, [specs.get(t) for t in order])
+            if not grouped:
+                specs = {}
+        heads_in = {t: (leaves[t] if (t not in live or t in specs) else ops.live_rows(leaves[t], live[t].live_idx, live[t].live_inv))
+                    for t in order}
+        if self.grouped_heads and len(order) > 1 and not grouped:
+            grouped = ops.grouped_projection_ok([heads_in[t] for t in order], nets)
         proj = proj_leaves = None
         if grouped:
-            proj = ops.grouped_projection([heads_in[t] for t in order], nets)
+            proj = ops.grouped_projection([heads_in[t] for t in order], nets, specs=[specs.get(t) for t in order])
             proj_leaves = {t: f.detach().requires_grad_(True) for t, f in zip(order, proj)}
             ops.stamp("heads_proj_fwd_done")
+        else:
+            specs = {}
 
         def head(t, leaf):
             # AR / LTA: one loss element per node, back-propagated below with the constant w_t / numel -- known before the
@@ -1276,7 +1300,8 @@ class MTLStep(StepBase):
                 outs = dict(zip(order, proj))
                 torch.autograd.backward([outs[t] for t in live], [proj_leaves[t].grad for t in live])
         with torch.no_grad():
-            total = self._objective(vectors)
+            total = self._objective({t: compact_v.get(t, v) for t, v in vectors.items()},
+                                    {t: (n_full[t] if t in compact_v else None) for t in vectors})
         return total, vectors, leaves
 
     compact_heads = True  # heads on the labelled rows only (data.live_label_rows); EGK_DISABLE=compact_heads: every row

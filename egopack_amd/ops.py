@@ -739,7 +739,7 @@ def _wgrad_launch(in_place: bool, tensors, launch, in_backward: bool = True):
 # step, all competing with the dX chain for the CUs).  With the queue on, such launches are PARKED (operands kept alive)
 # and issued SIX AT A TIME as one grouped launch on the side stream: 384 workgroups, no slabs, no reduce launch, a sixth
 # of the forks.  ``flush_wgrad`` issues what is parked (fewer than four at the end of backward).
-_wq = {"on": False, "items": [], "tiles": 0, "hold": [], "extra": []}
+_wq = {"on": False, "items": [], "tiles": 0, "hold": [], "extra": [], "riders": []}
 # Six per launch: alone, six H x H problems in one launch of two 4-wave workgroups per CU run at 900 TF/s against 740 for
 # four on one 8-wave workgroup per CU (tools/gemm_group_bench.py: x4 70 us, x6 85 us, x8 133 us at K = 6144).  Inside the
 # step: 4 / 5 / 6 / 7 / 8 -> 1.558 / 1.60 / 1.538 / 1.60 / 1.595 ms (three alternating rounds of 200 steps; 12 H x H weight
@@ -792,8 +792,19 @@ def set_wgrad_grouping(on, count: Optional[int] = None):
         on, count = on
     _wq["on"] = bool(on)
     _wq["count"] = None if (count is None or "EGK_WGRAD_COUNT" in os.environ) else int(count)
-    _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
+    _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"], _wq["riders"] = [], [], [], 0, []
     return prev
+
+
+def park_rider(fn, hold=()) -> None:
+    """``fn()`` -- a launch that feeds nothing on the backward chain (a reported vector, say) -- rides with the next flush of the
+    parked weight gradients: issued on their side stream, in front of the grouped launch.  Run at once when nothing can be parked
+    (queue or side streams off, or on a task-head stream, whose parked work is issued by another stream)."""
+    if not (_wq["on"] and _wgrad["enabled"]) or _on_excluded_stream():
+        fn()
+        return
+    _wq.setdefault("riders", []).append(fn)
+    _wq["hold"].extend(t for t in hold if t is not None)
 
 
 def _wgrad_groupable(M, N, A, lda, B, ldb, K, compute=None) -> bool:
@@ -914,12 +925,14 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
     calls from the backward stream (end of a step's backward, the last-weight-gradient hook) must never leave parked work
     behind, whatever stream handle the backward stream happens to have (a capture stream may alias a pooled handle that an
     earlier step registered as excluded)."""
-    items, hold, extra = _wq["items"], _wq["hold"], _wq["extra"]
-    if (not items and not extra) or (_on_excluded_stream() and not force):  # (a head stream never issues what others parked)
+    items, hold, extra, riders = _wq["items"], _wq["hold"], _wq["extra"], _wq.get("riders") or []
+    if (not items and not extra and not riders) or (_on_excluded_stream() and not force):  # (a head stream never issues what others parked)
         return
-    _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"] = [], [], [], 0
+    _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"], _wq["riders"] = [], [], [], 0, []
 
     def launch():
+        for fn in riders:
+            fn()
         for i in range(0, len(items), 8):
             chunk = items[i:i + 8]
             stamp("wgrad_group", seq=True)
@@ -1451,9 +1464,12 @@ class _GroupedProjection(torch.autograd.Function):
     Parameter gradients accumulate in place (the optimizer's flat gradient slots must exist)."""
 
     @staticmethod
-    def forward(ctx, G, compute, eps, *args):
+    def forward(ctx, G, compute, eps, specs, *args):
         lib = _lib.load()
-        xs = [_c(x) for x in args[:G]]
+        full = [_c(x) for x in args[:G]]
+        # a group with a row spec (first, step, count, inv) consumes rows first + i * step, i < count, of its input -- a strided view,
+        # no copy: the contractions take any row stride -- and its feature gradient goes back to full height through ``inv``
+        xs = [x if sp is None else x[sp[0]::sp[1]][:sp[2]] for x, sp in zip(full, specs)]
         params = [args[G + 6 * g: G + 6 * g + 6] for g in range(G)]
         dt, dev = xs[0].dtype, xs[0].device
         rows = [x.shape[0] for x in xs]
@@ -1470,7 +1486,7 @@ class _GroupedProjection(torch.autograd.Function):
         f = torch.empty((n, H2), dtype=dt, device=dev)
         mean = torch.empty(n, dtype=torch.float32, device=dev)
         rstd = torch.empty_like(mean)
-        gemm_grouped([((rows[g], H1, xs[g], H, W1o[g], H, H, h1[ptr[g]:ptr[g + 1]], H1),
+        gemm_grouped([((rows[g], H1, xs[g], xs[g].stride(0), W1o[g], H, H, h1[ptr[g]:ptr[g + 1]], H1),
                        dict(bias=_f32c(params[g][1]), compute=compute)) for g in range(G)])
         lw, lb = [_f32c(p[2]) for p in params], [_f32c(p[3]) for p in params]
         row_ptr = (C.c_int32 * (G + 1))(*ptr)
@@ -1479,7 +1495,8 @@ class _GroupedProjection(torch.autograd.Function):
         gemm_grouped([((rows[g], H2, a[ptr[g]:ptr[g + 1]], H1, W2o[g], H1, H1, f[ptr[g]:ptr[g + 1]], H2),
                        dict(bias=_f32c(params[g][5]), compute=compute)) for g in range(G)])
         ctx.G, ctx.compute, ctx.ptr, ctx.dims, ctx.params = G, compute, ptr, (H, H1, H2), params
-        ctx.save_for_backward(h1, a, mean, rstd, *xs, *W1o, *W2o, *lw, *lb)
+        ctx.specs, ctx.full_rows = specs, [x.shape[0] for x in full]
+        ctx.save_for_backward(h1, a, mean, rstd, *full, *W1o, *W2o, *lw, *lb, *[sp[3] for sp in specs if sp is not None])
         return tuple(f[ptr[g]:ptr[g + 1]] for g in range(G))
 
     @staticmethod
@@ -1487,7 +1504,9 @@ class _GroupedProjection(torch.autograd.Function):
         lib = _lib.load()
         G, ptr, (H, H1, H2), params = ctx.G, ctx.ptr, ctx.dims, ctx.params
         h1, a, mean, rstd, *rest = ctx.saved_tensors
-        xs, W1o, W2o, lw, lb = (rest[i * G:(i + 1) * G] for i in range(5))
+        full, W1o, W2o, lw, lb = (rest[i * G:(i + 1) * G] for i in range(5))
+        specs, invs = ctx.specs, list(rest[5 * G:])
+        xs = [x if sp is None else x[sp[0]::sp[1]][:sp[2]] for x, sp in zip(full, specs)]
         dt, dev = h1.dtype, h1.device
         rows = [ptr[g + 1] - ptr[g] for g in range(G)]
         dfs = [_operand_rows(d if d is not None else torch.zeros((rows[g], H2), dtype=dt, device=dev), dt) for g, d in enumerate(dfs)]
@@ -1523,12 +1542,28 @@ class _GroupedProjection(torch.autograd.Function):
         else:
             _wgrad_launch(True, (ws,), lambda: _launch_reductions(reds))
         dxs = [None] * G
-        if any(ctx.needs_input_grad[3:3 + G]):
-            dx = torch.empty((ptr[-1], H), dtype=dt, device=dev)
-            gemm_grouped([((rows[g], H, dh1[ptr[g]:ptr[g + 1]], H1, W1o[g], H, H1, dx[ptr[g]:ptr[g + 1]], H),
+        if any(ctx.needs_input_grad[4:4 + G]):
+            # ONE buffer for the feature gradients of all groups at their FULL heights, consecutive (the fused backbone pass takes
+            # it back without a copy, _SplitRows.backward); a group with a row spec gets its dx rows in a scratch block and one
+            # launch puts them at their places with zero rows elsewhere (egk_gather_rows through the inverse map)
+            fptr = [0]
+            for n_ in ctx.full_rows:
+                fptr.append(fptr[-1] + n_)
+            dx = torch.empty((fptr[-1], H), dtype=dt, device=dev)
+            scratch = {g: torch.empty((rows[g], H), dtype=dt, device=dev) for g in range(G) if specs[g] is not None}
+            dst = [scratch[g] if g in scratch else dx[fptr[g]:fptr[g + 1]] for g in range(G)]
+            gemm_grouped([((rows[g], H, dh1[ptr[g]:ptr[g + 1]], H1, W1o[g], H, H1, dst[g], H),
                            dict(transB=True, compute=cmp)) for g in range(G)])
-            dxs = [dx[ptr[g]:ptr[g + 1]] for g in range(G)]
-        dw1 = [((H1, H, dh1[ptr[g]:ptr[g + 1]], H1, xs[g], H, rows[g], slots[g][0], H),
+            k_inv = 0
+            for g in range(G):
+                if g in scratch:
+                    inv = invs[k_inv]
+                    k_inv += 1
+                    blk = dx[fptr[g]:fptr[g + 1]]
+                    _ck(lib.egk_gather_rows(_stream(), _p(scratch[g]), _dt(dx), H, rows[g], _p(inv), _p(blk), _dt(dx), blk.shape[0], H),
+                        "egk_gather_rows")
+            dxs = [dx[fptr[g]:fptr[g + 1]] for g in range(G)]
+        dw1 = [((H1, H, dh1[ptr[g]:ptr[g + 1]], H1, xs[g], xs[g].stride(0), rows[g], slots[g][0], H),
                 dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][1])) for g in range(G)]
         if proj_park and all(_wgrad_groupable(*pa[:7]) for pa, _ in dw1):
             for g, (pa, pk) in enumerate(dw1):
@@ -1536,7 +1571,7 @@ class _GroupedProjection(torch.autograd.Function):
                     raise RuntimeError("grouped_projection: a weight gradient announced as parkable was refused")
         else:
             _wgrad_launch(True, (dh1, *xs), lambda: gemm_grouped(dw1))
-        return (None, None, None, *dxs, *([None] * (6 * G)))
+        return (None, None, None, None, *dxs, *([None] * (6 * G)))
 
 
 @torch.no_grad()
@@ -1606,7 +1641,7 @@ def grouped_projection_infer(x, nets, out_f32: bool = False):
     return [f[g * M:(g + 1) * M] for g in range(G)]
 
 
-def grouped_projection_ok(xs, nets) -> bool:
+def grouped_projection_ok(xs, nets, specs=None) -> bool:
     """Whether ``grouped_projection`` can serve these task batches: bf16 activations, 2 .. 4 standard projection heads
     (Dropout(0 / eval) -> Linear -> LayerNorm -> ReLU -> Linear) of equal widths, every width a multiple of 64 (whole K
     tiles of the pipelined contraction), every batch a multiple of 64 rows (the K axis of its weight gradient), and the
@@ -1614,14 +1649,18 @@ def grouped_projection_ok(xs, nets) -> bool:
     if not (2 <= len(xs) <= 4) or any(x.dtype != torch.bfloat16 or not x.is_cuda or x.dim() != 2 for x in xs):
         return False
     dims = None
-    for x, net in zip(xs, nets):
+    specs = specs or [None] * len(xs)
+    for x, net, sp in zip(xs, nets, specs):
         if len(net) != 5 or (net[0].p > 0 and net[0].training):
             return False
         l1, ln, l2 = net[1], net[2], net[4]
         d = (l1.in_features, l1.out_features, l2.out_features)
         if dims is None:
             dims = d
-        if d != dims or l2.in_features != d[1] or x.shape[1] != d[0] or any(v % 64 for v in d) or x.shape[0] % 64 or x.shape[0] == 0:
+        n_rows = x.shape[0] if sp is None else sp[2]
+        if sp is not None and not (sp[0] >= 0 and sp[1] >= 1 and sp[0] + (sp[2] - 1) * sp[1] < x.shape[0] and sp[3].numel() == x.shape[0]):
+            return False
+        if d != dims or l2.in_features != d[1] or x.shape[1] != d[0] or any(v % 64 for v in d) or n_rows % 64 or n_rows == 0:
             return False
         if d[1] > 4096 or l1.bias is None or l2.bias is None:
             return False
@@ -1633,14 +1672,17 @@ def grouped_projection_ok(xs, nets) -> bool:
     return True
 
 
-def grouped_projection(xs, nets, compute=None):
+def grouped_projection(xs, nets, compute=None, specs=None):
     """f_g = net_g(x_g) for the projection heads ``nets`` (ProjectionTask.net) of several task batches: see
-    ``_GroupedProjection``.  Call ``grouped_projection_ok`` first."""
+    ``_GroupedProjection``.  Call ``grouped_projection_ok`` first.  ``specs[g]`` = (first, step, count, inv int64 [rows of x_g]) or
+    None: head g runs on rows first + i * step (i < count) of x_g only -- the labelled rows of a task that labels one node per
+    sequence (data.live_label_rows) -- and returns [count, H]; the gradient of x_g has zero rows elsewhere."""
     args = []
     for net in nets:
         l1, ln, l2 = net[1], net[2], net[4]
         args += [l1.weight, l1.bias, ln.weight, ln.bias, l2.weight, l2.bias]
-    return _GroupedProjection.apply(len(xs), _compute_for(xs[0]) if compute is None else compute, float(nets[0][2].eps), *xs, *args)
+    specs = tuple(specs) if specs is not None else (None,) * len(xs)
+    return _GroupedProjection.apply(len(xs), _compute_for(xs[0]) if compute is None else compute, float(nets[0][2].eps), specs, *xs, *args)
 
 
 # ---- GraphONE: the stages of several auxiliary tasks as ONE chain of grouped launches --------------------------------------
@@ -2375,14 +2417,15 @@ def live_rows(x, idx, inv):
 
 
 @torch.no_grad()
-def expand_rows(v, inv):
+def expand_rows(v, inv, out=None):
     """A per-row vector of the compacted batch back at full length: out[i] = v[inv[i]], 0 where inv[i] < 0 (the loss vector of
     the reference has one element per node, zero on ignored nodes: criterion/wrapper.py:67-82)."""
     v2 = _c(v.detach().reshape(-1, 1))
-    out = torch.empty((inv.numel(), 1), dtype=v2.dtype, device=v2.device)
+    if out is None:
+        out = torch.empty(inv.numel(), dtype=v2.dtype, device=v2.device)
     _ck(_lib.load().egk_gather_rows(_stream(), _p(v2), _dt(v2), 1, v2.shape[0], _p(inv), _p(out), _dt(out), inv.numel(), 1),
         "egk_gather_rows")
-    return out.reshape(-1)
+    return out
 
 
 # ---- GraphONE gather-max ------------------------------------------------------------------------------
@@ -2964,13 +3007,13 @@ def relu(x):
 
 class _WeightedMeanSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weights, *vectors):
+    def forward(ctx, weights, counts, *vectors):
         _need_gpu(*vectors)
         import ctypes as C_
         lib = _lib.load()
         k = len(vectors)
         vs = [_f32c(v) for v in vectors]
-        coefs = [w / max(v.numel(), 1) for w, v in zip(weights, vs)]
+        coefs = [w / max(v.numel() if c is None else c, 1) for w, v, c in zip(weights, vs, counts)]
         out = torch.empty(1, dtype=torch.float32, device=vs[0].device)
         xs = (C_.c_void_p * k)(*[v.data_ptr() if v.numel() else None for v in vs])
         ns = (C_.c_int64 * k)(*[v.numel() for v in vs])
@@ -2990,13 +3033,16 @@ class _WeightedMeanSum(torch.autograd.Function):
         ns = (C_.c_int64 * k)(*[d.numel() for d in grads])
         cf = (C_.c_float * k)(*ctx.coefs)
         _ck(lib.egk_fill_scaled_multi(_stream(), _p(g), cf, outs, ns, k), "egk_fill_scaled_multi")
-        return (None, *grads)
+        return (None, None, *grads)
 
 
-def weighted_mean_sum(vectors, weights):
+def weighted_mean_sum(vectors, weights, counts=None):
     """sum_i weights[i] * vectors[i].mean()  -- the training objective of main_temporal.py:99-128
-    (``torch.stack([w * l.mean() ...]).sum()``) as deterministic single-workgroup reductions."""
-    return _WeightedMeanSum.apply(tuple(float(w) for w in weights), *vectors)
+    (``torch.stack([w * l.mean() ...]).sum()``) as deterministic single-workgroup reductions.  ``counts[i]`` (optional): the
+    number of elements the mean of vector i divides by, when the vector holds only the non-zero ones (a compacted head's loss
+    vector: the ignored nodes' zeros are left out of the sum, not of the mean)."""
+    counts = tuple(counts) if counts is not None else (None,) * len(vectors)
+    return _WeightedMeanSum.apply(tuple(float(w) for w in weights), counts, *vectors)
 
 
 class _SumTensors(torch.autograd.Function):
