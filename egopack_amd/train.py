@@ -44,7 +44,7 @@ def seed_everything(cfg, rank: int):
         import numpy as np
         np.random.seed(cfg.seed)
         torch.manual_seed(cfg.seed)  # identical parameter init on every rank
-        ops.manual_seed(cfg.seed * 7919 + rank)  # dropout streams differ per rank
+        ops.manual_seed(cfg.seed * 7919 + rank + int(cfg.get("dropout_seed_offset", 0) or 0))  # dropout streams differ per rank
 
 
 def task_weights(cfg) -> Dict[str, float]:
