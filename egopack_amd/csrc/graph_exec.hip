@@ -81,6 +81,9 @@ int clone_node(hipGraph_t dst, hipGraphNode_t src, hipGraphNode_t prev, hipGraph
             hipKernelNodeParams p;
             EGK_HIP(hipGraphKernelNodeGetParams(src, &p), "egk_graph_plan_create: hipGraphKernelNodeGetParams");
             EGK_HIP(hipGraphAddKernelNode(out, dst, deps, ndeps, &p), "egk_graph_plan_create: hipGraphAddKernelNode");
+            // launch attributes of the captured node (priority, cooperative launch, ...) travel with the clone; a runtime that
+            // does not know the call leaves the defaults, which is what every launch of this library uses
+            (void)hipGraphKernelNodeCopyAttributes(src, *out);
             return 0;
         }
         case hipGraphNodeTypeMemset: {

@@ -398,7 +398,11 @@ __global__ void adam_hyper_kernel(const float* __restrict__ src, long long* __re
 template <typename GT>  // GT: element type of the gradient buffer (f32, or bf16 after a compressed all-reduce)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, const float* __restrict__ hyper,
-                                                   float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow) {
+                                                   float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow,
+                                                   long long* __restrict__ bump_word, long long bump) {
+    // (egk_adam_step_bump: a device-side counter that moves on once per step -- the Philox offset word of the step's dropout
+    //  launches -- rides in this launch instead of costing one of its own)
+    if (bump_word && blockIdx.x == 0 && threadIdx.x == 0) *bump_word += bump;
     const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
     const float step = lr / bc1;
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
@@ -681,6 +685,23 @@ int egk_copy_blocks(egk_stream_t stream, const void* const* srcs, const int64_t*
     return check_launch("egk_copy_blocks");
 }
 
+// the flat gradient buffer cleared by a launch of the library (16-byte stores; the buffer is 16-byte aligned and padded)
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p, long long n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) p[i] = z;
+}
+
+int egk_zero_fill(egk_stream_t stream, void* p, int64_t bytes) {
+    EGK_REQUIRE(p || bytes == 0, "egk_zero_fill: null pointer");
+    EGK_REQUIRE(((uintptr_t)p & 15) == 0 && (bytes & 15) == 0 && bytes >= 0, "egk_zero_fill: 16-byte aligned buffer of whole 16-byte groups");
+    if (bytes == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n16 = bytes / 16;
+    const long long blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, (uint4*)p, n16);
+    return check_launch("egk_zero_fill");
+}
+
 int egk_adam_hyper(egk_stream_t stream, const float* src, int64_t* t_dev, double beta1, double beta2, float* hyper) {
     EGK_REQUIRE(src && t_dev && hyper, "egk_adam_hyper: null pointer");
     hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, (long long*)t_dev, beta1, beta2, hyper);
@@ -689,6 +710,12 @@ int egk_adam_hyper(egk_stream_t stream, const float* src, int64_t* t_dev, double
 
 int egk_adam_step(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow) {
+    return egk_adam_step_bump(stream, p, g, g_dtype, m, v, n, hyper, beta1, beta2, eps, weight_decay, bf16_shadow, nullptr, 0);
+}
+
+int egk_adam_step_bump(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
+                       const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow,
+                       int64_t* bump_word, int64_t bump) {
     EGK_REQUIRE(p && g && m && v && hyper, "egk_adam_step: null pointer");
     EGK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "egk_adam_step: buffers must be 16-byte aligned");
@@ -697,7 +724,8 @@ int egk_adam_step(egk_stream_t stream, float* p, const void* g, int32_t g_dtype,
     EGK_REQUIRE(!bf16_shadow || ((uintptr_t)bf16_shadow & 7) == 0, "egk_adam_step: shadow must be 8-byte aligned");
     ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * n);
     EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(ew_grid(n, 4)), dim3(256), 0, s, p, (const T*)g, m, v,
-                                               (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow));
+                                               (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow,
+                                               (long long*)bump_word, (long long)bump));
     return check_launch("egk_adam_step");
 }
 }

@@ -131,9 +131,19 @@ class CSRGraph:
 TILE_HEIGHTS = (64, 96, 128)  # output-tile heights of the pipelined contraction (csrc/gemm.hip): bits of CSRGraph.tile_mask
 
 
-def tile_locality_mask(rowptr, col) -> int:
+def _tile_mask_wanted() -> bool:
+    """The mask's only consumer is the opt-in gather-in-epilogue fusion (EGK_ENABLE=gather_fusion, measured slower: DESIGN 10.4):
+    the loaders do not pay an np.repeat over all edges + three comparisons per batch for a switch that is off."""
+    from . import ops
+    return bool(ops._gather_fusion["on"])
+
+
+def tile_locality_mask(rowptr, col, force: bool = False) -> int:
     """Bit b is set when no edge of the by-target CSR (rowptr, col) joins two nodes on different sides of a multiple of
-    TILE_HEIGHTS[b] rows.  Host arrays only (a device-side CSR reports 0: nothing is fused)."""
+    TILE_HEIGHTS[b] rows.  Host arrays only (a device-side CSR reports 0: nothing is fused).  Computed only while its consumer
+    is switched on (``_tile_mask_wanted``) or when ``force``d: 0 otherwise."""
+    if not (force or _tile_mask_wanted()):
+        return 0
     if torch.is_tensor(rowptr):
         if rowptr.device.type != "cpu":
             return 0

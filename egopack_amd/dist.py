@@ -68,7 +68,9 @@ def quiesce_before_capture(group=None, settle_s: float = 1.0) -> None:
     with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing stream"), the watchdog
     rethrows on its own thread and std::terminate aborts the process -- hundreds of milliseconds later, wherever the main
     thread happens to be.  A device synchronisation makes every pending work complete; one watchdog sweep later they are gone.
-    No-op without an RCCL group."""
+    No-op without an RCCL group.  The settle time is a HEURISTIC -- one watchdog sweep (~100 ms period) is assumed to finish within
+    ``settle_s``; the process group offers no call that waits for its watchdog's list to drain -- so only captures that record
+    collectives pay it (engine.StepBase.capture), and those are opt-in behind a per-rank probe process (bench.one_graph_probe)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     try:
@@ -382,7 +384,18 @@ class GradSync:
         n = opt.flat_m.numel()
         per, lo, hi, body = self.shard_bounds(n)
         real = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        if per and real == self.world:
+        if not (per and real == self.world):
+            if real == 1 and self.world == 1:
+                opt._moments_sharded = False
+                return
+            # nothing can be gathered (an empty shard, or the group's real size is not the world the update was sharded for: the
+            # exchange dry run): the moments of the other ranks' slices are NOT in this process -- the flag stays set, so that
+            # FlatAdam.state_dict() keeps refusing to serialise partial moments
+            import warnings
+            warnings.warn("GradSync.gather_moments: the sharded Adam moments cannot be gathered on this group "
+                          f"(group size {real}, sharded for {self.world}); a checkpoint would hold partial moments")
+            return
+        if True:
             native = opt.flat_m.is_cuda and dist.get_backend(self.group) == "nccl"
             for buf in (opt.flat_m, opt.flat_v):
                 if native:

@@ -468,6 +468,12 @@ class StepBase:
                 main_job()
         return vectors, extras
 
+    def _scope_streams(self) -> None:
+        """This step's own head / task / side streams are the excluded ones from here on (ops.scope_excluded_streams)."""
+        g1 = getattr(self, "graphone", None)
+        ops.scope_excluded_streams([*getattr(self, "_head_streams", ()), *(getattr(g1, "_task_streams", ()) if g1 is not None else ()),
+                                    getattr(self, "_precise_side", None)])
+
     def _objective(self, vectors, counts=None):
         order = [t for t in self.enabled if t in vectors]
         return ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order],
@@ -501,6 +507,7 @@ class StepBase:
         self.optimizer.zero_grad()
         if self.input_hook is not None:
             self.input_hook()
+        self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
@@ -584,6 +591,7 @@ class StepBase:
         self.optimizer.zero_grad()
         if self.input_hook is not None:
             self.input_hook()
+        self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
@@ -703,16 +711,20 @@ class StepBase:
         if self.fused and len(live) > 1 and merged is None:  # index work must stay outside the capture
             merged = merge_batches([batches[t] for t in live]).to(batches[live[0]].pos.device)
         if warmup > 0 or not getattr(opt, "materialised", True):
-            side = torch.cuda.Stream()
+            self._scope_streams()
+            side = ops.unexcluded_stream()  # (a pooled handle that is not one of this step's head / task streams)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(max(warmup, 1)):  # also materialises the flat buffers
                     self.step(batches, merged)
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.sync is not None and self.sync.world > 1:
-            # the eager steps above issued collectives: the process group's watchdog must have retired them before a capture
-            # may take the communicator's stream into capture mode (dist.quiesce_before_capture: the round-3 abort)
+        if self.sync is not None and self.sync.world > 1 and ((self._use_stages() and self._one_graph_exchange_ok()) or self._exact_ln_on()):
+            # the eager steps above issued collectives and THIS capture records collectives (the opt-in one-graph exchange, the
+            # exact cross-rank LayerNorm statistics): the process group's watchdog must have retired the eager ones before the
+            # capture takes the communicator's stream into capture mode (dist.quiesce_before_capture: the round-3 abort).  The
+            # staged graphs -- the N-rank default -- and the one-piece captures issue their collectives BETWEEN graph launches and
+            # never capture that stream: they do not pay the settle time (a heuristic: one watchdog sweep, see the docstring).
             self.sync.quiesce()
         if hasattr(opt, "invalidate_lo_shadows"):
             opt.invalidate_lo_shadows()  # (a captured step must contain every refresh of the low halves it relies on)
@@ -724,6 +736,7 @@ class StepBase:
         g = torch.cuda.CUDAGraph(keep_graph=True) if segmented else torch.cuda.CUDAGraph()
         opt.sync_hyper_source()  # (the step constants are computed inside the graph from a device-side step counter)
         self._hyper_in_graph = False
+        self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
@@ -736,7 +749,7 @@ class StepBase:
                 hyper_here = fuse_adam and "hyper_in_graph" not in getattr(self, "_dev_off", ())
                 self._hyper_in_graph = hyper_here
                 if "zero_stream" in getattr(self, "_dev_off", ()):
-                    opt.flat_g.zero_()
+                    opt.zero_flat_grads()
                     if hyper_here:
                         opt.prepare_hyper(in_capture=True)
                 else:
@@ -746,7 +759,7 @@ class StepBase:
                     def issue_zero(ev):  # (behind the forward pass's first launch: see ops.defer_after_next_launch)
                         self._zero_stream.wait_event(ev)
                         with torch.cuda.stream(self._zero_stream):
-                            opt.flat_g.zero_()
+                            opt.zero_flat_grads()
                             if hyper_here:  # the step's Adam constants: one thread, beside the forward pass
                                 opt.prepare_hyper(in_capture=True)
                     if "zero_deferred" in getattr(self, "_dev_off", ()):
@@ -771,21 +784,28 @@ class StepBase:
                 ops.set_last_wgrad_hook(None, None)
                 ops.join_wgrad(force=True)
                 ops.stamp("backward_done")
+                # the Philox offset word of the dropout launches moves on INSIDE the graph (beside nothing that reads it: every
+                # dropout launch of the step is done when the optimizer starts): replay k draws the masks of offset base + k * stride
+                # without a separate launch in front of every replay -- and without a launch of its own: it rides in an optimizer
+                # launch (egk_adam_step_bump)
+                rng_here = "rng_in_graph" not in getattr(self, "_dev_off", ()) and not (early is not None and early.get("rng_done"))
+                bump = (ops.rng_device_offset(opt.flat_p.device), ops.RNG_DEVICE_STRIDE) if rng_here else None
                 if fuse_adam:
                     if early is not None and early["fired"]:
                         torch.cuda.current_stream().wait_stream(early["stream"])
-                        opt.launch(None, early["lo"], early["hi"])
+                        opt.launch(None, early["lo"], early["hi"], bump=bump if early["hi"] > early["lo"] else None)
+                        bump = None if early["hi"] > early["lo"] else bump
                     elif early is not None and early.get("done"):  # (a slice was stepped, the last weight gradient's hook never ran)
                         torch.cuda.current_stream().wait_stream(early["stream"])
                         for a, b in _minus([(0, opt.flat_p.numel())], early["done"]):
-                            opt.launch(None, a, b)
+                            opt.launch(None, a, b, bump=bump)
+                            bump = None
                     else:
-                        opt.launch()
+                        opt.launch(bump=bump)
+                        bump = None
                     ops.stamp("adam_done")
-                # the Philox offset word of the dropout launches moves on INSIDE the graph (last node, beside nothing that reads
-                # it): replay k draws the masks of offset base + k * stride without a separate launch in front of every replay
                 if "rng_in_graph" not in getattr(self, "_dev_off", ()):
-                    if not (early is not None and early.get("rng_done")):
+                    if bump is not None:
                         ops.advance_rng_device(opt.flat_p.device)
                     self._rng_in_graph = True
         finally:
@@ -797,8 +817,14 @@ class StepBase:
         if segmented:
             from .graphexec import SegmentedGraph
             import os
-            g = SegmentedGraph(g, max_streams=segmented,
-                               event_nodes=self.segmented_event_nodes or "plan_event_nodes" in os.environ.get("EGK_ENABLE", ""))
+            try:
+                g = SegmentedGraph(g, max_streams=segmented,
+                                   event_nodes=self.segmented_event_nodes or "plan_event_nodes" in os.environ.get("EGK_ENABLE", ""))
+            except Exception as e:  # noqa: BLE001
+                # the plan could not be built from this capture (a node type the plan does not clone): the capture itself is
+                # intact -- replay it the runtime's way (the opt-in mode is an optimisation, not a requirement)
+                self.capture_notes = [*getattr(self, "capture_notes", []), f"segmented replay unavailable ({e!r}): runtime replay"]
+                g.instantiate()
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
@@ -880,10 +906,14 @@ class StepBase:
                 if side is not None:
                     plan["stream"].wait_stream(side)
                 with torch.cuda.stream(plan["stream"]):
-                    if plan.get("rng"):  # the dropout offset word moves on here, beside the last weight gradient, instead of
-                        ops.advance_rng_device(opt.flat_p.device)  # as a launch of its own behind Adam at the tail of the step
+                    # the dropout offset word moves on here, beside the last weight gradient (every dropout launch of the step
+                    # is long done), INSIDE the first optimizer launch: no launch of its own
+                    bump = (ops.rng_device_offset(opt.flat_p.device), ops.RNG_DEVICE_STRIDE) if plan.get("rng") else None
                     for a, b in _minus([(0, lo), (hi, total)], plan.get("done", ())):  # (``done``: slices stepped earlier in the step)
-                        opt.launch(None, a, b)
+                        opt.launch(None, a, b, bump=bump)
+                        bump = None
+                    if bump is not None:  # (no slice left to step here: the word still moves on)
+                        ops.advance_rng_device(opt.flat_p.device)
             if plan.get("rng"):
                 plan["rng_done"] = True  # (every dropout launch of the step has been issued: this is backward's end)
             ops.defer_after_next_launch(issue)
@@ -943,6 +973,7 @@ class StepBase:
         opt.sync_hyper_source()
         self._hyper_in_graph = True
         count = opt.step_count
+        self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
@@ -960,7 +991,7 @@ class StepBase:
                 def issue_zero(ev):
                     self._zero_stream.wait_event(ev)
                     with torch.cuda.stream(self._zero_stream):
-                        opt.flat_g.zero_()
+                        opt.zero_flat_grads()
                         opt.prepare_hyper(in_capture=True)  # (the step's Adam constants, from the device-side step counter)
                 ops.stamp("step_start")
                 ops.defer_after_next_launch(issue_zero)
@@ -1026,6 +1057,7 @@ class StepBase:
         opt = self.optimizer
         gs = [torch.cuda.CUDAGraph() for _ in range(3)]
         self._rng_in_graph = False  # (no staged graph advances the Philox offset word: replay() does, also after a one-piece capture)
+        self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
@@ -1033,7 +1065,7 @@ class StepBase:
             live = [t for t in self.enabled if batches.get(t) is not None]
             cap = ops.unexcluded_stream()  # (one capture stream for the three graphs, never a registered head / task stream)
             with torch.cuda.graph(gs[0], stream=cap, capture_error_mode=CAPTURE_MODE):
-                opt.flat_g.zero_()
+                opt.zero_flat_grads()
                 if self.input_hook is not None:
                     self.input_hook()
                 total, vectors = self._stage_a(batches, merged)

@@ -212,7 +212,10 @@ def rng_device_offset(device) -> torch.Tensor:
     return t
 
 
-def advance_rng_device(device, stride: int = 1 << 40):
+RNG_DEVICE_STRIDE = 1 << 40
+
+
+def advance_rng_device(device, stride: int = RNG_DEVICE_STRIDE):
     rng_device_offset(device).add_(stride)
 
 
@@ -537,9 +540,10 @@ def _gemm_with_stats(args, kw, stats):
         # that fills half the chip: the statistics epilogue needs the finished tile, i.e. NO split-K -- 87 us for 2048 x 1024
         # on one workgroup per CU.  When the policy would cut the walk, the cut launch + its reduce + the LayerNorm's own
         # statistics pass are the cheaper chain (the precise pass of the EgoPack step sits on the step's critical path):
-        # config 4 3.70 -> 3.65 ms.  (Opt-in until the block-wise parity test of the OSCC head stated its input gradient "up to
-        # near-ties of the max pool": the other summation order moves the auxiliary features by 1e-6 and with them WHICH one to
-        # three near-tie pairs the draw contains -- 1.7e-3 .. 6.5e-3 over all rows, 1.66e-3 over the rows no tie touches.)
+        # config 4 3.70 -> 3.65 ms.  ON BY DEFAULT since late round 4 (EGK_DISABLE=x3_stats_split turns it off; DESIGN 10.8,
+        # profiles/r04_switches.txt): it was opt-in until the block-wise parity test of the OSCC head stated its input gradient "up
+        # to near-ties of the max pool" -- the other summation order moves the auxiliary features by 1e-6 and with them WHICH one to
+        # three near-tie pairs the draw contains (1.7e-3 .. 6.5e-3 over all rows, 1.66e-3 over the rows no tie touches).
         if lib.egk_gemm_splitk(d.M, d.N, _desc_k(d), d.compute) > 1:
             blocks = 0
     if blocks <= 0:
@@ -681,6 +685,14 @@ def exclude_wgrad_streams(streams) -> None:
     for st in streams:
         _wgrad["exclude"].add((st.device.index, st.cuda_stream))
 
+
+
+def scope_excluded_streams(streams) -> None:
+    """The excluded set becomes exactly ``streams`` (a step calls this with ITS head / task / side streams when it starts issuing:
+    stream handles are pooled and handed out round-robin, so in a process that builds many steps -- a test suite -- the handles
+    excluded by steps long gone would otherwise pile up until every stream of the pool, the backward stream of the next step
+    included, counts as a head stream and its weight gradients take other launch paths than the same step in a fresh process)."""
+    _wgrad["exclude"] = {(st.device.index, st.cuda_stream) for st in streams if st is not None}
 
 
 def unexcluded_stream() -> torch.cuda.Stream:

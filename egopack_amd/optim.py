@@ -261,7 +261,16 @@ class FlatAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         if not self.materialised:
             return super().zero_grad(set_to_none=True)
-        self.flat_g.zero_()
+        self.zero_flat_grads()
+
+    def zero_flat_grads(self) -> None:
+        """The flat gradient buffer cleared by one launch of the library (capturable)."""
+        g = self.flat_g
+        nbytes = g.numel() * g.element_size()
+        if nbytes % 16 or g.data_ptr() % 16:
+            g.zero_()
+            return
+        _ck(_lib.load().egk_zero_fill(_stream(), _p(g), nbytes), "egk_zero_fill")
 
     # The step constants {lr, 1-b1^t, sqrt(1-b2^t), grad_scale} are computed ON THE DEVICE (egk_adam_hyper) from a device-side
     # step counter and a two-float source {lr, grad_scale}: the launch is a node of a captured step, so a replay needs no
@@ -300,10 +309,11 @@ class FlatAdam(torch.optim.Optimizer):
         """A replayed graph that contains the constants launch has been enqueued: the device counter moves on with it."""
         self._t_mirror += 1
 
-    def launch(self, grads=None, lo: int = 0, hi=None):
+    def launch(self, grads=None, lo: int = 0, hi=None, bump=None):
         """The kernel launch alone (capturable).  ``grads``: the buffer to read gradients from (default the f32
         flat buffer; dist.GradSync hands in its bf16 copy after a compressed all-reduce).  ``[lo, hi)``: element range
-        of the flat buffers to update (multiples of 8; the pipelined gradient exchange steps chunk by chunk)."""
+        of the flat buffers to update (multiples of 8; the pipelined gradient exchange steps chunk by chunk).
+        ``bump`` = (int64 device word, stride): the word moves on by ``stride`` inside this launch (egk_adam_step_bump)."""
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         grads = self.flat_g if grads is None else grads
@@ -313,6 +323,12 @@ class FlatAdam(torch.optim.Optimizer):
         sl = slice(lo, hi)
         if self._lo_fresh:
             self._lo_fresh = []  # (the parameters move: every low half is stale)
+        if bump is not None:
+            _ck(_lib.load().egk_adam_step_bump(_stream(), _p(self.flat_p[sl]), _p(grads[sl]), 1 if grads.dtype == torch.bfloat16 else 0,
+                                               _p(self.flat_m[sl]), _p(self.flat_v[sl]), hi - lo, _p(self._hyper), b1, b2,
+                                               g["eps"], g["weight_decay"], _p(self.flat_w16[sl]), _p(bump[0]), int(bump[1])),
+                "egk_adam_step_bump")
+            return
         _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p[sl]), _p(grads[sl]), 1 if grads.dtype == torch.bfloat16 else 0,
                                       _p(self.flat_m[sl]), _p(self.flat_v[sl]), hi - lo, _p(self._hyper), b1, b2,
                                       g["eps"], g["weight_decay"], _p(self.flat_w16[sl])),

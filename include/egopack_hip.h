@@ -527,6 +527,10 @@ int egk_fill_scaled(egk_stream_t s, const float* scalar, float coef, float* out,
 /* out[0] (+)= scale * sum(x[0..n))  -- loss.mean() * weight, deterministic single-block tree */
 int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float scale, int32_t accumulate);
 
+/* p[0 .. bytes) = 0 (16-byte aligned, whole 16-byte groups): ``optimizer.zero_grad()`` of the flat gradient buffer
+ * (reference main_temporal.py:77) as a launch of the library */
+int egk_zero_fill(egk_stream_t s, void* p, int64_t bytes);
+
 /* ---- optimiser  torch.optim.Adam (L2 weight decay)  configs/defaults.yaml:17-20 ----------
  * One launch over the flat parameter / gradient / moment buffers.  hyper (device, float[4]) =
  * {lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale}: rewritten by the host between graph replays.
@@ -537,6 +541,11 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
  * launch -- the operand the bf16 contractions read (no separate cast pass over the weights). */
 int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
+/* the same launch, and *bump_word += bump by one thread of it (n > 0): a device-side per-step counter -- the Philox offset word the
+ * step's dropout launches add to their offsets -- moves on inside the optimizer's launch instead of in a launch of its own */
+int egk_adam_step_bump(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
+                       const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow,
+                       int64_t* bump_word, int64_t bump);
 /* The constants of the NEXT step computed on the device: t = ++(*t_dev) (device int64: optimizer steps taken so far);
  * hyper[4] = {src[0] = lr, 1 - beta1^t, sqrt(1 - beta2^t), src[1] = grad_scale} (double pow / sqrt, rounded to f32 once, as
  * torch.optim.Adam's bias corrections are).  One thread; a node of the captured step, so that a graph replay needs no

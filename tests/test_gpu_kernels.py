@@ -1756,9 +1756,15 @@ def test_sage_layer_with_the_gather_in_the_contraction_epilogue_is_bit_identical
         else:
             parts.append(D.radius_band_edges(torch.arange(T), 1) + n)
         n += T
-    graph = D.build_csr(torch.cat(parts, 1), n)
+    prev_on = ops._gather_fusion["on"]
+    ops._gather_fusion["on"] = True  # (the tile-locality mask is computed only while its consumer is switched on)
+    try:
+        graph = D.build_csr(torch.cat(parts, 1), n)
+    finally:
+        ops._gather_fusion["on"] = prev_on
     expect_mask = {32: 7, 48: 2, 256: 0}[T]
     assert graph.tile_mask == expect_mask
+    assert prev_on or D.build_csr(torch.cat(parts, 1), n).tile_mask == 0  # (switched off: not computed)
     graph = graph.to(DEV)
     torch.manual_seed(7)
     conv = SAGEConv(H, H, project=True).to(DEV)
