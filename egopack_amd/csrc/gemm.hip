@@ -1429,6 +1429,194 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tt_sub_group_kernel(const GemmG
     gemm_tt_sub_body<NSUB, true>(gg.p[pi], v);
 }
 
+// ---- 256 x 128 tile, two PING-PONG wave groups (large outputs) ---------------------------------------------------------------
+// The 4-wave kernel above reaches ~65 % matrix-pipe utilisation because its DMA issue (a wave is held ~68 cycles per 1-KiB piece),
+// its LDS fragment reads and its MFMAs overlap only as far as the two co-resident workgroups of a CU happen to drift apart;
+// the 8-wave 256 x 128 tile (MB = 2) runs all eight waves in lock step and is slower still.  Here the two waves of a SIMD take
+// EXPLICIT turns (MI355X_MICROARCH.md, "Two waves per SIMD"): group A (waves 0-3, rows 0-127) and group B (waves 4-7, rows
+// 128-255) share the B image and alternate, one barrier per phase,
+//     phase 2i     A: LOAD(i)      B: COMPUTE(i - 1)
+//     phase 2i + 1 A: COMPUTE(i)   B: LOAD(i)
+// LOAD(i) = issue this wave's 6 DMA pieces of tile i + 2, read the 16 fragments of tile i (both k-steps) into registers;
+// COMPUTE(i) = 32 MFMAs.  A SIMD's matrix pipe always has ONE wave in its MFMA block while the other one waits on the
+// vector-memory path and LDS.  3-stage ring of (A image 32 KiB | B image 16 KiB) = 144 KiB, one workgroup per CU; a stage is
+// rewritten two phases after its last reader finished (lgkmcnt(0) in front of the barrier).  Images, swizzles and the MFMA
+// chain per accumulator are gemm_pipe_kernel's: results are bit-identical to it and to the generic kernel.
+template <bool TRA, bool TRB>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g) {
+    constexpr int NS = 3, IMG = 16384, IMG_A = 2 * IMG, STAGE = IMG_A + IMG, NI = 4, NPB = 2, LOADS = NI + NPB, KT = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int z, tm, tn;
+    tile_of(g, blockIdx.x, z, tm, tn);
+    const int m0 = tm * 256, n0 = tn * BN;
+    const int nkt = total_tiles(g, KT);
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
+    const int nt = max(t_end - t_begin, 0);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w >> 2;             // 0: group A (rows 0-127 of the tile), 1: group B (rows 128-255)
+    const int wm = w >> 1, wn = w & 1;  // wm: 64-row band 0 .. 3
+    const int lr = lane & 15, lg = lane >> 4;
+
+    OperandCursor<TRA, NI> ca;
+    OperandCursor<TRB, NPB> cb;
+    int cur_src = -1;
+    auto issue = [&](int i) {
+        int src, tt;
+        source_of<KT>(g, t_begin + i, src, tt);
+        if (src != cur_src) {  // (uniform) first tile, or the walk crossed from one K source into the next
+            ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, tt * KT, w * NI, lane, 1);
+            cb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, tt * KT, w * NPB, lane, 1);
+            cur_src = src;
+        }
+        unsigned char* sbase = lds + (i % NS) * STAGE;
+        ca.issue(sbase, w * NI);
+        cb.issue(sbase + IMG_A, w * NPB);
+    };
+
+    f32x4 acc[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
+    const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
+    const unsigned a_rm = (unsigned)((wm * 64 + lr) * ROWB) + rm_sw;
+    const unsigned b_rm = (unsigned)((wn * 64 + lr) * ROWB) + rm_sw;
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const unsigned tr_row = (unsigned)((8 * lg + tq) * 256 + (tp & 1) * 8);
+    const unsigned tr_f = (unsigned)(2 * tq + 8 * (lg & 1));
+    unsigned a_tr[4], b_tr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_tr[i] = (unsigned)((wm >> 1) * IMG) + tr_row + ((((unsigned)((wm & 1) * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
+        b_tr[i] = tr_row + ((((unsigned)(wn * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
+    }
+    // fused bias gradient (dW form), as gemm_pipe_kernel's tall tile: the threads of group x sum sub-image x of the k-major A image
+    const bool do_bias = TRA && g.dbias != nullptr && tn == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int bcc = tid & 15, bkg = (tid & 255) >> 4;
+
+    if (nt > 0) issue(0);
+    if (nt > 1) issue(1);
+    uint4 a0[4], a1[4], b0[4], b1[4], bz[4];
+    for (int p = 0; p <= 2 * nt; ++p) {
+        if ((p & 1) == 0) {
+            // in front of an even phase 2i every wave has waited for ITS pieces of tile i (read by group A in this phase, by group
+            // B in the next): the only pieces that may still be in flight are those of tile i + 1
+            if ((p >> 1) + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const int q = p - grp;  // this group's own phase: even -> LOAD(q / 2), odd -> COMPUTE((q - 1) / 2)
+        if (q < 0 || q >= 2 * nt) continue;  // (group B sits out phase 0, group A the last one)
+        if ((q & 1) == 0) {
+            const int i = q >> 1;
+            if (i + 2 < nt) issue(i + 2);
+            const unsigned stA = lds_base + (i % NS) * STAGE, stB = stA + IMG_A;
+            if constexpr (TRA) {
+                if (do_bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = bkg * 4 + r;
+                        const unsigned ad = stA + (unsigned)(grp * IMG + k * 256 + ((bcc ^ (2 * (k & 3) + 8 * ((k >> 3) & 1))) << 4));
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(bz[r]) : "v"(ad));
+                    }
+                }
+            }
+            if constexpr (TRA) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const unsigned ad = stA + a_tr[ii];
+                    uint2 lo, hi;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+                    a0[ii] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(lo) : "v"(ad));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(hi) : "v"(ad));
+                    a1[ii] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a0[ii]) : "v"(stA + a_rm), "n"(ii * 2048));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a1[ii]) : "v"((stA + a_rm) ^ 64u), "n"(ii * 2048));
+                }
+            }
+            if constexpr (TRB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned ad = stB + b_tr[j];
+                    uint2 lo, hi;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
+                    b0[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(lo) : "v"(ad));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(hi) : "v"(ad));
+                    b1[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0[j]) : "v"(stB + b_rm), "n"(j * 2048));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1[j]) : "v"((stB + b_rm) ^ 64u), "n"(j * 2048));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: the stage is free after the next barrier
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TRA) {
+                if (do_bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned wv[4] = {bz[r].x, bz[r].y, bz[r].z, bz[r].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bsum[2 * e] += __uint_as_float(wv[e] << 16);
+                            bsum[2 * e + 1] += __uint_as_float(wv[e] & 0xffff0000u);
+                        }
+                    }
+                }
+            }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0[j]), __builtin_bit_cast(bf16x8, a0[i]),
+                                                                        acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1[j]), __builtin_bit_cast(bf16x8, a1[i]),
+                                                                        acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (TRA) {
+        if (g.dbias != nullptr && tn == 0) {  // block-uniform
+            __syncthreads();                  // every wave is done with the ring: f32 scratch [2 sub-images][16 k groups][128 rows]
+            float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(grp * 16 + bkg) * 128 + bcc * 8 + e] = bsum[e];
+            __syncthreads();
+            if (tid < 256 && m0 + tid < g.M) {
+                const int q0 = (tid >> 7) * 16;
+                float t = 0.f;
+                for (int q = 0; q < 16; ++q) t += red[(q0 + q) * 128 + (tid & 127)];
+                if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
+                else g.dbias[m0 + tid] += t;
+            }
+            __syncthreads();
+        }
+    }
+    gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
+}
+
 // Fragment reads of the 256 x 256 kernel: fragments FIRST .. FIRST + 3 of k-step S of one operand image (inline asm for
 // the reason given in gemm_pipe_kernel: a plain LDS load would drain the DMA queue first).
 template <bool TR, int FIRST, int S>
@@ -1976,6 +2164,10 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
     (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
     (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_group_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
@@ -2254,7 +2446,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
         }
-        const int mb = (variant == 6 || variant == 13) ? 2 : 1;
+        const int mb = (variant == 6 || variant == 13 || variant == 14) ? 2 : 1;
         if (variant == 12 && (d->st_mode || d->ga_mode)) variant = 11;  // (forced by the knob: the epilogue features win)
         g.tiles_m = variant == 8 ? cdiv(g.M, 96) : (variant == 11 || variant == 12) ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
         if (variant == 7) g.tiles_n = cdiv(g.N, 256);
@@ -2321,6 +2513,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         } else if (variant == 8) {                                                                                        \
             if (d->ga_mode) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3, true>), pgrid, pblock, 2 * 28672, s, g); \
             else hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);           \
+        } else if (variant == 14) {                                                                                       \
+            hipLaunchKernelGGL((gemm_pp_kernel<TA, TB>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, g);                     \
         } else if (variant == 13) {                                                                                       \
             hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, g);          \
         } else if (variant == 6)                                                                                          \

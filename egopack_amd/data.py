@@ -275,7 +275,9 @@ class LTATemporalConnectivity:
 # --------------------------------------------------------------------------------------------
 # labelled rows of a per-node multi-head label tensor (the heads' row compaction, engine.MTLStep)
 # --------------------------------------------------------------------------------------------
-LIVE_ROWS_MAX_SHARE = 0.75  # compact only when at most this share of the nodes carries a label
+import os as _os
+# compact only when at most this share of the nodes carries a label (EGK_LIVE_SHARE: development knob)
+LIVE_ROWS_MAX_SHARE = float(_os.environ.get("EGK_LIVE_SHARE", "0.75"))
 
 
 def live_label_rows(y, n_nodes: int):

@@ -543,7 +543,12 @@ class StepBase:
         """Forward + backward of the objective (gradients accumulate into the parameters' slots): (objective, loss vectors)."""
         total, vectors, _ = self.losses(batches, merged)
         self._join_zero()
-        total.backward()
+        # (the seed of the objective's backward is a persistent 1.0: ``backward()`` without it fills a fresh tensor with a torch
+        #  kernel on the chain, between the loss and the first backward launch)
+        one = getattr(self, "_grad_one", None)
+        if one is None or one.device != total.device or one.dtype != total.dtype:
+            one = self._grad_one = torch.ones((), dtype=total.dtype, device=total.device)
+        total.backward(gradient=one)
         return total, vectors
 
     # ---- staged backward: gradient exchange overlapped with the rest of backward --------------------------------------
@@ -1332,8 +1337,18 @@ class MTLStep(StepBase):
                 outs = dict(zip(order, proj))
                 torch.autograd.backward([outs[t] for t in live], [proj_leaves[t].grad for t in live])
         with torch.no_grad():
-            total = self._objective({t: compact_v.get(t, v) for t, v in vectors.items()},
-                                    {t: (n_full[t] if t in compact_v else None) for t in vectors})
+            # the reported objective feeds nothing on the chain (every head's backward started from its known seed): its one-workgroup
+            # reduction rides with the parked weight gradients' next flush, on their stream, instead of sitting between the heads'
+            # backward and the backbone's
+            src = {t: compact_v.get(t, v) for t, v in vectors.items()}
+            cnt = {t: (n_full[t] if t in compact_v else None) for t in vectors}
+            if "objective_rider" in getattr(self, "_dev_off", ()) or not src:
+                total = self._objective(src, cnt)
+            else:
+                order = [t for t in self.enabled if t in src]
+                total = torch.empty((), dtype=torch.float32, device=src[order[0]].device)
+                ops.park_rider(lambda: ops.weighted_mean_sum_into(total, [src[t] for t in order], [self.weights[t] for t in order],
+                                                                  [cnt[t] for t in order]), (total, *[src[t] for t in order]))
         return total, vectors, leaves
 
     compact_heads = True  # heads on the labelled rows only (data.live_label_rows); EGK_DISABLE=compact_heads: every row

@@ -3048,6 +3048,21 @@ class _WeightedMeanSum(torch.autograd.Function):
         return (None, None, *grads)
 
 
+@torch.no_grad()
+def weighted_mean_sum_into(out, vectors, weights, counts=None):
+    """``weighted_mean_sum`` without autograd, written into ``out`` (an f32 tensor of one element)."""
+    import ctypes as C_
+    k = len(vectors)
+    vs = [_f32c(v) for v in vectors]
+    counts = counts if counts is not None else [None] * k
+    coefs = [float(w) / max(v.numel() if c is None else c, 1) for w, v, c in zip(weights, vs, counts)]
+    xs = (C_.c_void_p * k)(*[v.data_ptr() if v.numel() else None for v in vs])
+    ns = (C_.c_int64 * k)(*[v.numel() for v in vs])
+    cf = (C_.c_float * k)(*coefs)
+    _ck(_lib.load().egk_weighted_sums(_stream(), xs, ns, cf, k, _p(out)), "egk_weighted_sums")
+    return out
+
+
 def weighted_mean_sum(vectors, weights, counts=None):
     """sum_i weights[i] * vectors[i].mean()  -- the training objective of main_temporal.py:99-128
     (``torch.stack([w * l.mean() ...]).sum()``) as deterministic single-workgroup reductions.  ``counts[i]`` (optional): the
