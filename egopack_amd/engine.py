@@ -740,6 +740,7 @@ class StepBase:
         segmented = self._segmented_replay()
         g = torch.cuda.CUDAGraph(keep_graph=True) if segmented else torch.cuda.CUDAGraph()
         opt.sync_hyper_source()  # (the step constants are computed inside the graph from a device-side step counter)
+        ops.rng_device_offset(opt.flat_p.device)  # (the dropout offset word exists BEFORE the capture: created inside, its fill is a node)
         self._hyper_in_graph = False
         self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
