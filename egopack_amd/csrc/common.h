@@ -91,6 +91,8 @@ bool prof_on();
 void prof_begin(int kid, hipStream_t s, double flops, double bytes);
 void prof_end(hipStream_t s);
 
+void set_zero_fill_blocks(int n);  // loss_optim.hip: workgroup cap of egk_zero_fill (egk_tune key 5)
+
 struct ProfScope {
     hipStream_t s;
     bool on;

@@ -450,6 +450,9 @@ static inline int row_grid(int rows) {
 
 using namespace egk;
 
+static int g_zero_fill_blocks = 0;  // development knob: egk_tune(5, workgroups); 0 = default
+namespace egk { void set_zero_fill_blocks(int n) { g_zero_fill_blocks = n; } }
+
 extern "C" {
 
 int egk_ce_fwd(egk_stream_t stream, const float* logits, int64_t ld, const int64_t* y, int64_t y_stride, float* loss,
@@ -698,7 +701,12 @@ int egk_zero_fill(egk_stream_t stream, void* p, int64_t bytes) {
     hipStream_t s = (hipStream_t)stream;
     const long long n16 = bytes / 16;
     const long long blocks = (n16 + 255) / 256;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, (uint4*)p, n16);
+    // A GENTLE fill: the captured step clears the gradient buffer beside its forward pass, with ~0.4 ms to spare -- at full
+    // rate (4096 workgroups, 5 TB/s) the 100 MB burst doubled the HBM-bound row kernel it ran beside (positional-encoding add
+    // 7.2 -> 15.7 us, profiles/r05_c3_replay_timeline.txt at 141 us); egk_tune(5, n) sets the workgroup cap.
+    // Same box, three alternating rounds of the headline step: 4096 workgroups 1.407-1.417 ms, 192: 1.399-1.413, 64: 1.401-1.408
+    const long long cap = g_zero_fill_blocks > 0 ? g_zero_fill_blocks : 64;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks > cap ? cap : blocks)), dim3(256), 0, s, (uint4*)p, n16);
     return check_launch("egk_zero_fill");
 }
 
