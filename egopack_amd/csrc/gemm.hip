@@ -1619,11 +1619,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g) {
 
 // Fragment reads of the 256 x 256 kernel: fragments FIRST .. FIRST + 3 of k-step S of one operand image (inline asm for
 // the reason given in gemm_pipe_kernel: a plain LDS load would drain the DMA queue first).
-template <bool TR, int FIRST, int S>
+template <bool TR, int FIRST, int S, int CNT = 4>
 __device__ __forceinline__ void read_frags4(uint4 (&dst)[4], unsigned st, unsigned rm, const unsigned* tr) {
     if constexpr (TR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < CNT; ++i) {
             const unsigned ad = st + tr[FIRST + i];
             uint2 lo, hi;
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ad), "n"(S * 8192));
@@ -1633,12 +1633,13 @@ __device__ __forceinline__ void read_frags4(uint4 (&dst)[4], unsigned st, unsign
     } else {
         const unsigned ad = S ? ((st + rm) ^ 64u) : (st + rm);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[i]) : "v"(ad), "n"((FIRST + i) * 2048));
+        for (int i = 0; i < CNT; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[i]) : "v"(ad), "n"((FIRST + i) * 2048));
     }
 }
-__device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[8][4], int i0, const uint4 (&a)[4], const uint4 (&b)[4]) {
+template <int NI, int CNT = 4>
+__device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[NI][4], int i0, const uint4 (&a)[4], const uint4 (&b)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CNT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]),
@@ -1660,14 +1661,18 @@ __device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[8][4], int i0, const uint4
 // against is ~1.7 PFLOP/s, not 2.5.
 // Only whole tiles (M, N multiples of 256) of outputs that fill the chip with them, and a long K walk (host policy); no
 // fused bias gradient (dW outputs are far too small to come here).
-template <bool TRA, bool TRB, int DMA_NBE = 8>
+// NI = MFMA row fragments per wave: 8 -> 256-row tiles; 6 -> 192 x 256 tiles (row-major A only), for outputs whose 256-row tiling
+// leaves the last round half empty: 6144 x 4096 is 384 tiles of 256 rows (1.5 rounds of 256 CUs = two rounds of 256 rows) but 512
+// tiles of 192 rows (two whole rounds of 192 rows): the A image then fills 24 of its 32 KiB.
+template <bool TRA, bool TRB, int DMA_NBE = 8, int NI = 8>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
-    constexpr int IMG = 16384, IMG_OP = 2 * IMG, STAGE = 2 * IMG_OP, KT = 64, NI = 8;
+    static_assert(NI == 8 || (NI == 6 && !TRA), "192-row tiles: row-major A");
+    constexpr int IMG = 16384, IMG_OP = 2 * IMG, STAGE = 2 * IMG_OP, KT = 64, HF = NI / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     int z, tm, tn;
     tile_of(g, blockIdx.x, z, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * (32 * NI), n0 = tn * 256;
     const int nkt = total_tiles(g, KT);
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int t_begin = z * per, t_end = min(nkt, t_begin + per);
@@ -1737,7 +1742,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
         baseB += TRB ? KT * ldb_b : KT * 2;
     };
     auto issue_early = [&](unsigned char* stage) {
-        issue_pieces(integral_constant<bool, TRA>{}, integral_constant<int, 8>{}, baseA, lda_b, voffA, w * 8, stage);
+        issue_pieces(integral_constant<bool, TRA>{}, integral_constant<int, NI>{}, baseA, lda_b, voffA, w * NI, stage);
         issue_pieces(integral_constant<bool, TRB>{}, integral_constant<int, NBE>{}, baseB, ldb_b, voffB, w * NBE, stage + IMG_OP);
     };
     auto issue_late = [&](unsigned char* stage) {
@@ -1754,7 +1759,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
 
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
     const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
-    const unsigned a_rm = (unsigned)(wm * IMG + lr * ROWB) + rm_sw;
+    const unsigned a_rm = (unsigned)((wm * 16 * NI + lr) * ROWB) + rm_sw;  // (NI = 8: wm * IMG; the sub-images are contiguous)
     const unsigned b_rm = (unsigned)((wn >> 1) * IMG + ((wn & 1) * 64 + lr) * ROWB) + rm_sw;
     const int tq = (lane & 15) >> 2, tp = lane & 3;
     const unsigned tr_row = (unsigned)((8 * lg + tq) * 256 + (tp & 1) * 8);
@@ -1795,30 +1800,30 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
         // (two B sets, two A halves) beside the 128 accumulators, so two waves per SIMD fit in the register file.
         const unsigned stA = lds_base + (it & 1) * STAGE, stB = stA + IMG_OP;
         uint4 b0[4], b1[4], alo[4], ahi[4];
-        constexpr int NA = TRA ? 8 : 4, NB = TRB ? 8 : 4;  // read instructions per group of 4 fragments
+        constexpr int NA = TRA ? 8 : HF, NB = TRB ? 8 : 4;  // read instructions per group of fragments (A: HF fragments, B: 4)
         read_frags4<TRB, 0, 0>(b0, stB, b_rm, b_tr);
-        read_frags4<TRA, 0, 0>(alo, stA, a_rm, a_tr);
-        read_frags4<TRA, 4, 0>(ahi, stA, a_rm, a_tr);
+        read_frags4<TRA, 0, 0, HF>(alo, stA, a_rm, a_tr);
+        read_frags4<TRA, HF, 0, HF>(ahi, stA, a_rm, a_tr);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA) : "memory");  // reads return in issue order: b0, alo are back
         __builtin_amdgcn_sched_barrier(0);
         EGK_STAMP(s3);
-        mfma_4x4(acc, 0, alo, b0);
+        mfma_4x4<NI, HF>(acc, 0, alo, b0);
         __builtin_amdgcn_sched_barrier(0);
         read_frags4<TRB, 0, 1>(b1, stB, b_rm, b_tr);
-        read_frags4<TRA, 0, 1>(alo, stA, a_rm, a_tr);
+        read_frags4<TRA, 0, 1, HF>(alo, stA, a_rm, a_tr);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA + NB > 15 ? 15 : NA + NB) : "memory");  // ahi (k-step 0) is back
         __builtin_amdgcn_sched_barrier(0);
-        mfma_4x4(acc, 4, ahi, b0);
+        mfma_4x4<NI, HF>(acc, HF, ahi, b0);
         __builtin_amdgcn_sched_barrier(0);
         if (more && !early) issue_late(nxt);
         if (more) advance();
-        read_frags4<TRA, 4, 1>(ahi, stA, a_rm, a_tr);
+        read_frags4<TRA, HF, 1, HF>(ahi, stA, a_rm, a_tr);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA) : "memory");  // b1, alo (k-step 1) are back
         __builtin_amdgcn_sched_barrier(0);
-        mfma_4x4(acc, 0, alo, b1);
+        mfma_4x4<NI, HF>(acc, 0, alo, b1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        mfma_4x4(acc, 4, ahi, b1);
+        mfma_4x4<NI, HF>(acc, HF, ahi, b1);
 #ifdef EGK_GEMM_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         EGK_STAMP(s4);
@@ -1833,7 +1838,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs g) {
     }
 #endif
 #undef EGK_STAMP
-    gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 128, wn * 64, lr, lg, z);
+    gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
 }
 
 // ---- exact-f32 pipelined contraction: f32 operands in memory, every K source a multiple of 32 -----------------------------
@@ -2136,6 +2141,8 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, false, 8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, true, 8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -2441,15 +2448,26 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             if (g.splitk == 1 && !g.dbias && g.M % 256 == 0 && g.N % 256 == 0 && t256 >= 192 && K >= 3072 &&
                 10 * t256 >= 9 * 256 * ((t256 + 255) / 256))
                 variant = 7;
+            // ... and 192 x 256 tiles (row-major A) where THEY fill their rounds and the 256-row tiles do not: 6144 x 4096 is 384
+            // tiles of 256 rows (1.5 rounds: the makespan of two) but 512 of 192 rows (two whole rounds of 3/4 the height)
+            const long long t192 = (long long)cdiv(g.M, 192) * cdiv(g.N, 256);
+            // (tools/round5/pp_bench.py, us: 6144 x 4096 x 4608 199 vs 211-263 on 128-row tiles, x 4096 180 vs 190, the dX form 185 vs
+            //  190, 6144 x 4096 x 1024 63.3 vs 66.7; 6144 x 1024 outputs are 128 such tiles and stay on 96-row tiles)
+            if (variant != 7 && !d->transA && g.splitk == 1 && !g.dbias && g.M % 192 == 0 && g.N % 256 == 0 && t192 >= 192 && K >= 1024 &&
+                10 * t192 >= 9 * 256 * ((t192 + 255) / 256))
+                variant = 15;
         } else if ((variant == 8 || variant == 11 || variant == 12) && d->transA) {
             variant = 3;  // the forced variants exist for row-major A only
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
+        } else if (variant == 15 && (d->transA || g.dbias || g.M % 192 != 0 || g.N % 256 != 0)) {
+            variant = 3;  // whole 192 x 256 tiles of a row-major A only
         }
         const int mb = (variant == 6 || variant == 13 || variant == 14) ? 2 : 1;
         if (variant == 12 && (d->st_mode || d->ga_mode)) variant = 11;  // (forced by the knob: the epilogue features win)
-        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : (variant == 11 || variant == 12) ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256) : cdiv(g.M, BM * mb);
-        if (variant == 7) g.tiles_n = cdiv(g.N, 256);
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : (variant == 11 || variant == 12) ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256)
+                    : variant == 15 ? cdiv(g.M, 192) : cdiv(g.M, BM * mb);
+        if (variant == 7 || variant == 15) g.tiles_n = cdiv(g.N, 256);
 #ifdef EGK_GEMM_STAMPS
         if (variant != 7 && !g.dbias && d->ws) {
             const int64_t slab = g.splitk > 1 ? (int64_t)g.splitk * d->M * d->N * 4 : 0;
@@ -2481,7 +2499,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                            epilogue_rows_ok(g) && (d->ga_tile_mask & ga_bit) && aligned16(d->ga_out) && d->ga_ld % (g.c_bf16 ? 8 : 4) == 0 &&
                            (d->ga_mode != 2 || aligned16(d->ga_gate));
         // split-K finished in the launch (sk_tickets): the reduce kernel's vector path, every tile variant but the 256 x 256 one
-        const bool sk_in_launch = g.splitk > 1 && d->sk_tickets != nullptr && variant != 7 && (g.N & 3) == 0 && g.c_vec &&
+        const bool sk_in_launch = g.splitk > 1 && d->sk_tickets != nullptr && variant != 7 && variant != 15 && (g.N & 3) == 0 && g.c_vec &&
                                   (!g.residual || g.r_vec) && g_sk_in_launch;
         if (query_blocks) {
             *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
@@ -2503,7 +2521,9 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
-        if (variant == 7) {                                                                                               \
+        if (variant == 15) {                                                                                              \
+            hipLaunchKernelGGL((gemm_big_kernel<false, TB, 8, 6>), pgrid, dim3(512), 131072, s, g);                       \
+        } else if (variant == 7) {                                                                                        \
             hipLaunchKernelGGL((gemm_big_kernel<TA, TB>), pgrid, dim3(512), 131072, s, g);                                \
         } else if (variant == 12) {                                                                                       \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 2, 1, 2>), pgrid, dim3(2 * NTHREADS), 4 * 24576, s, g);    \
@@ -2526,7 +2546,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, g);                     \
     } while (0)
         {
-            ProfScope prof(variant == 7 ? KID_GEMM_BF16_NN_T256 + layout : variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
+            ProfScope prof((variant == 7 || variant == 15) ? KID_GEMM_BF16_NN_T256 + layout : variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
                                        : ((variant == 5 || variant == 12) ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);

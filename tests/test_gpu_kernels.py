@@ -995,7 +995,7 @@ def test_gather_segmax_dropout_relu_bf16_activations(ops):
 
 @pytest.mark.parametrize("transA,transB", [(False, True), (True, True), (True, False)])
 @pytest.mark.parametrize("M,N,K1,K2", [(304, 200, 256, 0), (128, 128, 64, 0), (264, 136, 128, 192), (1024, 1024, 2048, 0),
-                                       (472, 1024, 1024, 0), (1024, 480, 512, 0)])
+                                       (472, 1024, 1024, 0), (1024, 480, 512, 0), (768, 512, 256, 128)])
 def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, transB, M, N, K1, K2):
     """dX / dW forms of the LDS-DMA kernel (k-major LDS images read with ds_read_b64_tr_b16) against the generic
     register-transposing kernel: bit-identical for every ring depth, incl. two-source K, split-K and f32 accumulation
@@ -1011,7 +1011,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
     A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
     C0 = torch.randn(M, N, device=DEV, generator=g)
     outs = {}
-    for pipe in (3, 2, 4, 6, 13, 14, 7, 8, 11, 0, 5, 12, 1, 55):
+    for pipe in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11, 0, 5, 12, 1, 55):
         prev = lib.egk_gemm_set_pipeline(5 if pipe == 55 else pipe)
         try:
             out = C0.clone()
@@ -1020,7 +1020,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
             outs[pipe] = out
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    for v in (3, 2, 4, 6, 13, 14, 7, 8, 11):  # one wave group (14: two ping-pong groups over DIFFERENT rows): the MFMA chain of the
+    for v in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11):  # one wave group (14: two ping-pong groups over DIFFERENT rows): the MFMA chain of the
         assert torch.equal(outs[v], outs[0]), v  # generic kernel per accumulator, whatever the tile / ring depth
     assert torch.equal(outs[5], outs[55])
     # 64-row tiles with two wave groups (12; row-major A only): the same even / odd K sums as (5), whatever the tile height
@@ -1033,7 +1033,8 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(300, 200, 256, 0), (128, 128, 64, 0), (257, 129, 128, 192), (2048, 1024, 1024, 0),
-                                       (6144, 1024, 1024, 1024), (130, 478, 1024, 0), (16384, 1024, 512, 0), (12200, 1100, 128, 64)])
+                                       (6144, 1024, 1024, 1024), (130, 478, 1024, 0), (16384, 1024, 512, 0), (12200, 1100, 128, 64),
+                                       (768, 512, 256, 128)])
 def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     """The LDS-DMA pipelined kernel (bf16 row-major operands, K % 64 == 0) issues the same MFMA chain per
     accumulator as the generic kernel: results must be BIT-identical, for bf16 and f32 outputs, with the
@@ -1048,7 +1049,7 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     bias = torch.randn(N, device=DEV, generator=g)
     res = torch.randn(M, N, device=DEV, generator=g).to(BF)
     outs = {}
-    for pipe in (3, 6, 13, 14, 7, 8, 11, 0, 5, 12, 1):
+    for pipe in (3, 6, 13, 14, 7, 15, 8, 11, 0, 5, 12, 1):
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             for dt in (BF, torch.float32):
@@ -1063,7 +1064,8 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
         assert torch.equal(outs[(6, dt)], outs[(0, dt)]) and torch.equal(outs[(8, dt)], outs[(0, dt)]) and torch.equal(outs[(11, dt)], outs[(0, dt)])  # 256- / 96- / 64-row tiles
         assert torch.equal(outs[(7, dt)], outs[(0, dt)])  # 256 x 256 tiles (the policy's choice for the two large outputs)
         assert torch.equal(outs[(13, dt)], outs[(0, dt)]) and torch.equal(outs[(14, dt)], outs[(0, dt)])  # 256 x 128: 3-stage ring; ping-pong groups
-        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11, 7))
+        assert torch.equal(outs[(15, dt)], outs[(0, dt)])  # 192 x 256 tiles (M % 192 == 0, N % 256 == 0: the (768, 512) case; 128 x 128 otherwise)
+        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11, 7, 15))
         assert torch.equal(outs[(12, dt)], outs[(5, dt)])  # 64-row tiles, two wave groups: the even / odd K sums of (5)
     # two wave groups: even / odd K tiles summed separately
     torch.testing.assert_close(outs[(5, torch.float32)], outs[(0, torch.float32)], rtol=1e-5, atol=2e-3)

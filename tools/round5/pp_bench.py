@@ -12,7 +12,7 @@ from egopack_amd import _lib, ops
 
 lib = _lib.load()
 dev, bf = "cuda", torch.bfloat16
-variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "3,6,13,14,7,1").split(",")]
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "3,6,13,14,7,15,1").split(",")]
 SHAPES = [("fwd TRN1 Hp4096", 6144, 4096, 4608, False, False), ("fwd TRN2 Hp4096", 6144, 4096, 4096, False, False),
           ("dX TRN2 Hp4096", 6144, 4096, 4096, False, True), ("dW TRN2 Hp4096", 4096, 4096, 6144, True, True),
           ("dW TRN1 Hp4096", 4096, 4608, 6144, True, True), ("fwd TRN3 Hp4096", 6144, 1024, 4096, False, False),
