@@ -399,7 +399,7 @@ template <typename GT>  // GT: element type of the gradient buffer (f32, or bf16
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, const float* __restrict__ hyper,
                                                    float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow,
-                                                   long long* __restrict__ bump_word, long long bump) {
+                                                   bf16_t* __restrict__ shadow_lo, long long* __restrict__ bump_word, long long bump) {
     // (egk_adam_step_bump: a device-side counter that moves on once per step -- the Philox offset word of the step's dropout
     //  launches -- rides in this launch instead of costing one of its own)
     if (bump_word && blockIdx.x == 0 && threadIdx.x == 0) *bump_word += bump;
@@ -425,6 +425,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             *reinterpret_cast<float4*>(m + i) = mv;
             *reinterpret_cast<float4*>(v + i) = vv;
             if (shadow) st4t(shadow + i, 0, 4, true, pv);
+            if (shadow_lo) {  // the LOW halves of the three-product contractions' weight operands: bf16(p - bf16(p)), egk_split_bf16's bits
+                const float lo4[4] = {pp[0] - bf2f(f2bf(pp[0])), pp[1] - bf2f(f2bf(pp[1])), pp[2] - bf2f(f2bf(pp[2])), pp[3] - bf2f(f2bf(pp[3]))};
+                st4t(shadow_lo + i, 0, 4, true, make_float4(lo4[0], lo4[1], lo4[2], lo4[3]));
+            }
         } else {
             for (long long j = i; j < n; ++j) {
                 const float gg = ld1t(g + j) * gs + wd * p[j];
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                 v[j] = v[j] * b2 + (1.f - b2) * gg * gg;
                 p[j] = p[j] - step * (m[j] / (sqrtf(v[j]) / bc2s + eps));
                 if (shadow) shadow[j] = f2bf(p[j]);
+                if (shadow_lo) shadow_lo[j] = f2bf(p[j] - bf2f(f2bf(p[j])));
             }
         }
     }
@@ -718,22 +723,23 @@ int egk_adam_hyper(egk_stream_t stream, const float* src, int64_t* t_dev, double
 
 int egk_adam_step(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow) {
-    return egk_adam_step_bump(stream, p, g, g_dtype, m, v, n, hyper, beta1, beta2, eps, weight_decay, bf16_shadow, nullptr, 0);
+    return egk_adam_step_bump(stream, p, g, g_dtype, m, v, n, hyper, beta1, beta2, eps, weight_decay, bf16_shadow, nullptr, nullptr, 0);
 }
 
 int egk_adam_step_bump(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                        const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow,
-                       int64_t* bump_word, int64_t bump) {
+                       void* bf16_lo_shadow, int64_t* bump_word, int64_t bump) {
     EGK_REQUIRE(p && g && m && v && hyper, "egk_adam_step: null pointer");
     EGK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "egk_adam_step: buffers must be 16-byte aligned");
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     EGK_REQUIRE(!bf16_shadow || ((uintptr_t)bf16_shadow & 7) == 0, "egk_adam_step: shadow must be 8-byte aligned");
-    ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * n);
+    EGK_REQUIRE(!bf16_lo_shadow || ((uintptr_t)bf16_lo_shadow & 7) == 0, "egk_adam_step: low-half shadow must be 8-byte aligned");
+    ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (bf16_lo_shadow ? 2.0 : 0.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * n);
     EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(ew_grid(n, 4)), dim3(256), 0, s, p, (const T*)g, m, v,
                                                (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow,
-                                               (long long*)bump_word, (long long)bump));
+                                               (bf16_t*)bf16_lo_shadow, (long long*)bump_word, (long long)bump));
     return check_launch("egk_adam_step");
 }
 }

@@ -468,6 +468,10 @@ class StepBase:
                 main_job()
         return vectors, extras
 
+    def _adam_keeps_lo(self) -> bool:
+        opt = self.optimizer
+        return bool(getattr(opt, "adam_writes_lo", False) and getattr(opt, "flat_w16lo", None) is not None)
+
     def _scope_streams(self) -> None:
         """This step's own head / task / side streams are the excluded ones from here on (ops.scope_excluded_streams)."""
         g1 = getattr(self, "graphone", None)
@@ -731,9 +735,12 @@ class StepBase:
             # staged graphs -- the N-rank default -- and the one-piece captures issue their collectives BETWEEN graph launches and
             # never capture that stream: they do not pay the settle time (a heuristic: one watchdog sweep, see the docstring).
             self.sync.quiesce()
-        if hasattr(opt, "invalidate_lo_shadows"):
+        if hasattr(opt, "invalidate_lo_shadows") and not self._adam_keeps_lo():
             opt.invalidate_lo_shadows()  # (a captured step must contain every refresh of the low halves it relies on)
+        # (when the Adam launch itself writes the low halves -- FlatAdam.adam_writes_lo, once they exist -- the warm-up steps left
+        #  them fresh and every replay's Adam leaves them fresh for the next one: no split launch in the captured step)
         self._graph_has_exchange = False
+        self._graph_adam_lo = False
         if self._use_stages():
             return self._capture_staged(batches, merged)
         fuse_adam = self.sync is None or self.sync.world <= 1
@@ -832,6 +839,7 @@ class StepBase:
                 self.capture_notes = [*getattr(self, "capture_notes", []), f"segmented replay unavailable ({e!r}): runtime replay"]
                 g.instantiate()
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
+        self._graph_adam_lo = bool(fuse_adam and self._adam_keeps_lo())  # (the captured Adam launches write the low halves)
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
         # (in particular the merged batch -- CSR arrays, positions, segment pointers -- when it was built here)
         self._static_in = (batches, merged)
@@ -1051,6 +1059,7 @@ class StepBase:
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), True
+        self._graph_adam_lo = self._adam_keeps_lo()  # (every chunk's captured Adam launch writes the low halves of its slice)
         self._graph_has_exchange = True
         self._static_in = (batches, merged, self._stage_state, self._cuts)
         return g
@@ -1129,8 +1138,12 @@ class StepBase:
                 self._graph.replay()
             opt.step_count += 1
             # the graph's Adam launch moved flat_p on the DEVICE without opt.launch() running on the host: every low half a
-            # 'bf16x3' contraction marked fresh before this replay (validation's precise pass between two epochs) is stale now
-            opt.invalidate_lo_shadows()
+            # 'bf16x3' contraction marked fresh before this replay (validation's precise pass between two epochs) is stale now --
+            # unless the captured Adam launches write the low halves themselves: then ALL of them are fresh behind a replay
+            if getattr(self, "_graph_adam_lo", False):
+                opt._lo_fresh = [(0, opt.flat_p.numel())]
+            else:
+                opt.invalidate_lo_shadows()
         else:
             self._graph.replay()
             self.sync.reduce_and_step(opt)

@@ -19,6 +19,20 @@ from . import _lib
 from .ops import _ck, _p, _stream
 
 
+def _minus_ranges(ranges, lo, hi):
+    """``ranges`` ([a, b) pairs) without [lo, hi)."""
+    out = []
+    for a, b in ranges:
+        if b <= lo or hi <= a:
+            out.append((a, b))
+            continue
+        if a < lo:
+            out.append((a, lo))
+        if hi < b:
+            out.append((hi, b))
+    return out
+
+
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable[torch.Tensor], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0):
@@ -230,8 +244,20 @@ class FlatAdam(torch.optim.Optimizer):
                 p._egk_lo = (view, (lambda o=off, m=n: self._lo_is_fresh(o, m)), (lambda q=p: self.refresh_lo_shadows([q])))
         return True
 
+    # Once the low halves exist the Adam launch keeps them: it writes bf16(p - bf16(p)) of the slice it updates beside the bf16
+    # shadow (+ 2 B per parameter on a 30 B pass), so the precise pass at the head of the NEXT step finds them fresh instead of
+    # splitting the backbone's 17 M parameters in a launch of its own at the head of the step's critical chain (38 us in BASELINE
+    # config 4, profiles/r04_c4_replay_timeline.txt at 118 us).  EGK_DISABLE=adam_lo: the round-4 behaviour.
+    adam_writes_lo = "adam_lo" not in __import__("os").environ.get("EGK_DISABLE", "")
+
     def _lo_is_fresh(self, off: int, n: int) -> bool:
-        return any(lo <= off and off + n <= hi for lo, hi in self._lo_fresh)
+        # (fresh ranges may have been cut by partial updates: a slot is fresh when the union of the ranges covers it)
+        need = [(off, off + n)]
+        for lo, hi in self._lo_fresh:
+            need = [piece for a, b in need for piece in ((a, min(b, lo)), (max(a, hi), b)) if piece[1] > piece[0]]
+            if not need:
+                return True
+        return not need
 
     def invalidate_lo_shadows(self):
         self._lo_fresh = []
@@ -241,7 +267,7 @@ class FlatAdam(torch.optim.Optimizer):
         if not self.ensure_lo_shadows():
             return
         lo, hi = (0, self.flat_p.numel()) if params is None else self.region_of(list(params))
-        if hi <= lo:
+        if hi <= lo or self._lo_is_fresh(lo, hi - lo):
             return
         _ck(_lib.load().egk_split_bf16(_stream(), _p(self.flat_p[lo:hi]), hi - lo, None, _p(self.flat_w16lo[lo:hi]), hi - lo, 1, hi - lo),
             "egk_split_bf16")
@@ -321,12 +347,17 @@ class FlatAdam(torch.optim.Optimizer):
         if hi <= lo:
             return
         sl = slice(lo, hi)
-        if self._lo_fresh:
+        lo16 = self.flat_w16lo[sl] if (self.flat_w16lo is not None and self.adam_writes_lo) else None
+        if lo16 is not None:
+            # the launch also writes the low halves of the slice it updates (egk_adam_step_bump): that slice is fresh, the rest as it was
+            self._lo_fresh = _minus_ranges(self._lo_fresh, lo, hi) + [(lo, hi)]
+        elif self._lo_fresh:
             self._lo_fresh = []  # (the parameters move: every low half is stale)
-        if bump is not None:
+        if bump is not None or lo16 is not None:
             _ck(_lib.load().egk_adam_step_bump(_stream(), _p(self.flat_p[sl]), _p(grads[sl]), 1 if grads.dtype == torch.bfloat16 else 0,
                                                _p(self.flat_m[sl]), _p(self.flat_v[sl]), hi - lo, _p(self._hyper), b1, b2,
-                                               g["eps"], g["weight_decay"], _p(self.flat_w16[sl]), _p(bump[0]), int(bump[1])),
+                                               g["eps"], g["weight_decay"], _p(self.flat_w16[sl]), _p(lo16),
+                                               _p(bump[0]) if bump is not None else None, int(bump[1]) if bump is not None else 0),
                 "egk_adam_step_bump")
             return
         _ck(_lib.load().egk_adam_step(_stream(), _p(self.flat_p[sl]), _p(grads[sl]), 1 if grads.dtype == torch.bfloat16 else 0,

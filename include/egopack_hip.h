@@ -541,11 +541,14 @@ int egk_zero_fill(egk_stream_t s, void* p, int64_t bytes);
  * launch -- the operand the bf16 contractions read (no separate cast pass over the weights). */
 int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow);
-/* the same launch, and *bump_word += bump by one thread of it (n > 0): a device-side per-step counter -- the Philox offset word the
- * step's dropout launches add to their offsets -- moves on inside the optimizer's launch instead of in a launch of its own */
+/* the same launch with two riders: bf16_lo_shadow (or NULL) receives bf16(p - bf16(p)) of the updated parameters -- the LOW halves
+ * of the weight operands of the three-product (f32-grade) contractions, egk_split_bf16's bits, so that the forward-only precise
+ * pass of the next step needs no split launch over the weights; and *bump_word += bump (bump_word or NULL) by one thread of the
+ * launch (n > 0): a device-side per-step counter -- the Philox offset word the step's dropout launches add to their offsets --
+ * moves on inside the optimizer's launch instead of in a launch of its own */
 int egk_adam_step_bump(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                        const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow,
-                       int64_t* bump_word, int64_t bump);
+                       void* bf16_lo_shadow, int64_t* bump_word, int64_t bump);
 /* The constants of the NEXT step computed on the device: t = ++(*t_dev) (device int64: optimizer steps taken so far);
  * hyper[4] = {src[0] = lr, 1 - beta1^t, sqrt(1 - beta2^t), src[1] = grad_scale} (double pow / sqrt, rounded to f32 once, as
  * torch.optim.Adam's bias corrections are).  One thread; a node of the captured step, so that a graph replay needs no

@@ -152,7 +152,8 @@ def test_linear_backward_in_three_product_mode_is_f32_grade(ops):
 
 def test_three_product_linear_uses_the_optimizers_halves(ops):
     """A Linear whose weight lives in FlatAdam's flat buffers: hi = the bf16 shadow the Adam kernel keeps, lo = the flat low
-    buffer (refreshed on demand, stale after every optimizer launch)."""
+    buffer -- refreshed on demand the first time, then kept by the Adam launch itself (round 5; with ``adam_writes_lo`` off:
+    stale after every optimizer launch and refreshed by the next use)."""
     from egopack_amd.models.layers import Linear
     from egopack_amd.optim import FlatAdam
     torch.manual_seed(3)
@@ -171,6 +172,11 @@ def test_three_product_linear_uses_the_optimizers_halves(ops):
     assert _rel(run().cpu(), ref()) < 3e-5
     off, _ = opt._slot_of[id(lin.weight)]
     assert opt.flat_w16lo is not None and opt._lo_is_fresh(off, lin.weight.numel())
+    lin.weight.grad.normal_()
+    opt.step()  # parameters move: the Adam launch wrote the new low halves itself
+    assert opt._lo_is_fresh(off, lin.weight.numel())
+    assert _rel(run().cpu(), ref()) < 3e-5
+    opt.adam_writes_lo = False  # (instance override: the round-4 behaviour)
     lin.weight.grad.normal_()
     opt.step()  # parameters move: the low halves are stale and must be refreshed by the next use
     assert not opt._lo_fresh
@@ -287,3 +293,40 @@ def test_split_tee_stores_the_halves_of_the_split_launch(ops, cols, monkeypatch)
     with pytest.raises(RuntimeError, match="split tee"):
         ops.row_layernorm(x.to(torch.bfloat16), w, b, 1e-5, relu=True)
     assert _lib.load().egk_tee_split_next(None, None, 0) == 0
+
+
+def test_adam_launch_keeps_the_low_halves_of_the_weight_operands():
+    """Once the low halves of the three-product contractions' weight operands exist (FlatAdam.ensure_lo_shadows), the Adam launch
+    writes them for the slice it updates (egk_adam_step_bump): after a step they equal egk_split_bf16 of the updated parameters
+    bit for bit, are marked fresh (no split launch at the head of the next precise pass), and a partial update leaves the other
+    slices' state as it was."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import _lib, ops
+    from egopack_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(64, 96, device="cuda")), torch.nn.Parameter(torch.randn(40, device="cuda")),
+          torch.nn.Parameter(torch.randn(128, 64, device="cuda"))]
+    opt = FlatAdam(ps, lr=1e-2, weight_decay=1e-4)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.step()  # (materialises the flat buffers)
+    assert opt.flat_w16lo is None
+    assert opt.ensure_lo_shadows() and not opt._lo_is_fresh(0, opt.flat_p.numel())
+    opt.flat_g.normal_()
+    opt.step()
+    n = opt.flat_p.numel()
+    assert opt._lo_is_fresh(0, n)
+    want_lo = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    assert _lib.load().egk_split_bf16(ops._stream(), ops._p(opt.flat_p), n, None, ops._p(want_lo), n, 1, n) == 0
+    assert torch.equal(opt.flat_w16lo, want_lo)
+    assert torch.equal(opt.flat_w16, opt.flat_p.to(torch.bfloat16))
+    # a partial update: its slice is fresh and right, a foreign write to the parameters invalidates everything
+    opt.flat_g.normal_()
+    opt.prepare_hyper()
+    opt.launch(None, 0, 64 * 96)
+    assert opt._lo_is_fresh(0, 64 * 96) and opt._lo_is_fresh(0, n)
+    assert _lib.load().egk_split_bf16(ops._stream(), ops._p(opt.flat_p), n, None, ops._p(want_lo), n, 1, n) == 0
+    assert torch.equal(opt.flat_w16lo, want_lo)
+    opt.refresh_shadows()
+    assert not opt._lo_is_fresh(0, 8)
