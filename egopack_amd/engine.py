@@ -1632,7 +1632,12 @@ class EgoPackStep(StepBase):
         first = next((b for b in batches.values() if b is not None), None)
         on_side = (self._precise_on() and self.precise_stream and first is not None and first.pos.is_cuda
                    and "precise_stream" not in getattr(self, "_dev_off", ()))
-        late = on_side and "precise_late_fork" not in getattr(self, "_dev_off", ())
+        # Which chain is CREATED first keeps the launch queue under capture.  Rounds 3-4 created the training pass's
+        # forward chain first (``late``: 3.73 -> 3.69 ms then, a tie in round 4); with the split launch over the weights gone from
+        # the head of the precise pass and the primary projection beside it, the precise pass IS the step's critical chain and goes
+        # first: 2.529-2.549 against 2.565-2.586 ms (four alternating rounds).  EGK_ENABLE=precise_late_fork: the old order.
+        import os
+        late = on_side and "precise_late_fork" in os.environ.get("EGK_ENABLE", "")
         if self._precise_on() and not late:
             if on_side:
                 # the precise pass is a chain of ~50 launches over the same few thousand rows as the training pass's forward:

@@ -35,7 +35,8 @@ class TRNPooling(TemporalPooling):
             if x.shape[1] != self.num_segments or x.shape[2] != self.input_size:
                 raise ValueError(f"expected [N, {self.num_segments}, {self.input_size}], got {tuple(x.shape)}")
             x = x.reshape(x.shape[0], -1)  # 'bs segments h -> bs (segments h)': a view of contiguous rows
-        return ops.to_act(x)  # no-op when the loader already delivers the mode's element type
+        return ops.to_act(x, lazy=True)  # no-op when the loader already delivers the mode's element type; the result goes
+        # straight into the first contraction (ops.to_act: a bf16 input of the three-product mode is then never widened in memory)
 
     def forward(self, x, *_):
         """``x``: [N, S, F] or a list of such blocks (fused multi-task pass: rows are concatenated in

@@ -71,8 +71,21 @@ def _need_gpu(*ts):
                 "no CPU fallback -- the CPU oracle under oracle/ is test infrastructure only")
 
 
+def _materialise_virtual(t: torch.Tensor) -> None:
+    """A lazily widened activation (``to_act(..., lazy=True)``: an f32 tensor whose bf16 source is known and whose own values
+    were never written) is about to be READ as f32: write it now."""
+    src = t._egk_bf16_src
+    t._egk_virtual = False
+    _ck(_lib.load().egk_cast(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(src.data_ptr()), BF16,
+                             C.c_void_p(t.data_ptr()), F32, src.numel()), "egk_cast")
+
+
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if getattr(t, "_egk_virtual", False):  # (any kernel that takes this tensor's pointer reads its f32 values)
+        _materialise_virtual(t)
+    return C.c_void_p(t.data_ptr())
 
 
 def _stream():
@@ -146,12 +159,16 @@ def _dt(t: torch.Tensor) -> int:
 def _c(t: torch.Tensor) -> torch.Tensor:
     """contiguous activation (f32 or bf16)"""
     _dt(t)
+    if getattr(t, "_egk_virtual", False):
+        _materialise_virtual(t)
     return t if t.is_contiguous() else t.contiguous()
 
 
 def _rm(t: torch.Tensor) -> torch.Tensor:
     """row-major 2-D matrix with unit column stride (any row stride: padded logits are views)"""
     _dt(t)
+    if getattr(t, "_egk_virtual", False):
+        _materialise_virtual(t)
     if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
         return t
     return t.contiguous()
@@ -276,13 +293,22 @@ class _Cast(torch.autograd.Function):
         return cast_raw(g, ctx.src), None
 
 
-def to_act(x: torch.Tensor) -> torch.Tensor:
-    """Bring an activation to the element type of the current mode (no-op when it already has it)."""
+def to_act(x: torch.Tensor, lazy: bool = False) -> torch.Tensor:
+    """Bring an activation to the element type of the current mode (no-op when it already has it).  ``lazy``: the caller hands
+    the result straight to a contraction (the temporal pooling's first Linear).  In the three-product mode a bf16 input IS the
+    high half of its widening and has no low half, so that contraction never reads the widened f32 values: the f32 tensor is then
+    only allocated, and written when anything else asks for its pointer (``_p`` / ``_c`` / ``_rm``) -- 15 us and 38 MB at the head
+    of the precise pass of BASELINE config 4 (EGK_DISABLE=x3_lazy_input: always written)."""
     want = _state["act"]
     if x.dtype == want:
         return x
     if x.requires_grad:
         return _Cast.apply(x, want)
+    if (lazy and _state["compute"] == X3 and want == torch.float32 and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_cuda
+            and x.is_contiguous() and not torch.is_grad_enabled() and "x3_lazy_input" not in os.environ.get("EGK_DISABLE", "")):
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        y._egk_bf16_src, y._egk_virtual = x, True
+        return y
     y = cast_raw(x, want)
     if _state["compute"] == X3 and x.dtype == torch.bfloat16:
         y._egk_bf16_src = x if x.is_contiguous() else x.contiguous()  # (its lo half is zero: one product less, no split pass)
@@ -1089,7 +1115,8 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32, ln_in=None, res_sink=None):
         _need_gpu(x, W)
-        x = _c(x)
+        if not (compute == X3 and getattr(x, "_egk_virtual", False) and x.is_contiguous()):
+            x = _c(x)  # (a lazily widened bf16 input stays unwritten: the three-product contraction reads its bf16 source)
         M, K1 = x.shape
         N = W.shape[0]
         Wop = weight_operand(W, x.dtype)

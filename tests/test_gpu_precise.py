@@ -183,6 +183,30 @@ def test_three_product_linear_uses_the_optimizers_halves(ops):
     assert _rel(run().cpu(), ref()) < 3e-5
 
 
+def test_a_bf16_input_of_the_precise_pass_is_widened_only_on_demand(ops, monkeypatch):
+    """``ops.to_act(x, lazy=True)`` inside ``precise_scope``: an f32 tensor that is never written while only three-product
+    contractions consume it (they read the bf16 source), the same bits as the eagerly widened input, and written the moment
+    anything else takes its pointer."""
+    from egopack_amd.models.layers import Linear
+    torch.manual_seed(21)
+    lin = Linear(1536, 512).to(DEV)
+    x = torch.randn(192, 1536, device=DEV).to(torch.bfloat16)
+    with torch.no_grad(), ops.compute_mode("bf16"), ops.precise_scope():
+        lazy = ops.to_act(x, lazy=True)
+        assert lazy.dtype == torch.float32 and getattr(lazy, "_egk_virtual", False)
+        lazy.fill_(float("nan"))  # whatever the allocation held: the contraction must not read it
+        y_lazy = lin(lazy)
+        assert lazy._egk_virtual  # still not written
+        y_eager = lin(ops.to_act(x))
+        assert torch.equal(y_lazy, y_eager) and torch.isfinite(y_lazy).all()
+        c = ops._c(lazy)  # any other consumer: written first
+        assert not lazy._egk_virtual and torch.equal(c, x.float())
+        monkeypatch.setenv("EGK_DISABLE", "x3_lazy_input")
+        assert not getattr(ops.to_act(x, lazy=True), "_egk_virtual", False)
+    with torch.no_grad(), ops.compute_mode("bf16"):
+        assert ops.to_act(x, lazy=True) is x  # outside the precise pass: the mode's own element type
+
+
 def test_backbone_in_three_product_mode_matches_the_f32_oracle(ops, golden):
     """Graph.forward + a projection head under ``precise_scope`` (bf16 input features, as the bf16 training pass stores them)
     against the CPU oracle in f32: the features that rank the prototypes.  H = 256 so that every contraction takes the
