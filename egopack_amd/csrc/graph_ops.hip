@@ -949,15 +949,26 @@ __global__ __launch_bounds__(256) void max_of_kernel(const float* __restrict__ r
     if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// Several searches in one launch: rows [g * rows_per_group, (g + 1) * rows_per_group) of dot1 / f / f_inv / nn belong to bank g (the
+// auxiliary tasks of one EgoPack batch: their feature rows are consecutive blocks of one buffer).
+struct TopkWindowBanks {
+    const float* bank[8];
+    const float* b_inv[8];
+    const float* rb_max[8];
+    int rows_per_group;
+};
+
 template <int KM>
 __global__ __launch_bounds__(256) void topk_window_kernel(const float* __restrict__ dot1, long long ldd, const float* __restrict__ f,
-                                                          long long ldf, const float* __restrict__ bank, long long ldb,
-                                                          const float* __restrict__ f_inv, const float* __restrict__ b_inv,
-                                                          const float* __restrict__ rb_max, long long* __restrict__ nn,
+                                                          long long ldf, TopkWindowBanks tb, long long ldb,
+                                                          const float* __restrict__ f_inv, long long* __restrict__ nn,
                                                           int* __restrict__ cand, int rows, int K, int H, int k, int vec) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float rb = rb_max[0];
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const int grp = row / tb.rows_per_group;  // (wave-uniform)
+        const float* __restrict__ bank = tb.bank[grp];
+        const float* __restrict__ b_inv = tb.b_inv[grp];
+        const float rb = tb.rb_max[grp][0];
         const float* dr = dot1 + (long long)row * ldd;
         const float* fr = f + (long long)row * ldf;
         const float fi = f_inv[row];
@@ -1779,18 +1790,45 @@ int egk_topk_window(egk_stream_t stream, const float* dot1, int64_t ldd, const f
     EGK_REQUIRE(k >= 1 && k <= 16 && k <= K, "egk_topk_window: k must be in [1, min(16, K)]");
     EGK_REQUIRE(H >= 1 && ldf >= H && ldb >= H && ldd >= K, "egk_topk_window: bad leading dimension");
     if (rows == 0) return 0;
+    const float* banks[1] = {bank};
+    const float* b_invs[1] = {b_inv};
+    const float* rb_maxs[1] = {rb_max};
+    return egk_topk_window_group(stream, dot1, ldd, f, ldf, banks, ldb, f_inv, b_invs, rb_maxs, nn, cand, 1, rows, K, H, k);
+}
+
+int egk_topk_window_group(egk_stream_t stream, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* const* banks,
+                          int64_t ldb, const float* f_inv, const float* const* b_invs, const float* const* rb_maxs, int64_t* nn,
+                          int32_t* cand, int32_t n_groups, int32_t rows_per_group, int32_t K, int32_t H, int32_t k) {
+    EGK_REQUIRE(dot1 && f && banks && f_inv && b_invs && rb_maxs && nn, "egk_topk_window_group: null pointer");
+    EGK_REQUIRE(n_groups >= 1 && n_groups <= 8, "egk_topk_window_group: 1..8 groups");
+    EGK_REQUIRE(k >= 1 && k <= 16 && k <= K, "egk_topk_window_group: k must be in [1, min(16, K)]");
+    EGK_REQUIRE(H >= 1 && ldf >= H && ldb >= H && ldd >= K, "egk_topk_window_group: bad leading dimension");
+    if (rows_per_group == 0) return 0;
+    EGK_REQUIRE(rows_per_group > 0, "egk_topk_window_group: negative row count");
+    const int rows = n_groups * rows_per_group;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_TOPK, s, 0, 8.0 * rows * K);
-    EGK_REQUIRE((uintptr_t)f % 16 == 0 && (uintptr_t)bank % 16 == 0, "egk_topk_window: feature / bank rows must be 16-byte aligned");
-    const int vec = (ldd % 4 == 0) && ((uintptr_t)dot1 % 16 == 0) && ((uintptr_t)b_inv % 16 == 0);
+    TopkWindowBanks tb;
+    int vec = (ldd % 4 == 0) && ((uintptr_t)dot1 % 16 == 0);
+    for (int g = 0; g < 8; ++g) {
+        const int src = g < n_groups ? g : 0;
+        EGK_REQUIRE(banks[src] && b_invs[src] && rb_maxs[src], "egk_topk_window_group: null bank pointer");
+        EGK_REQUIRE((uintptr_t)banks[src] % 16 == 0, "egk_topk_window_group: bank rows must be 16-byte aligned");
+        tb.bank[g] = banks[src];
+        tb.b_inv[g] = b_invs[src];
+        tb.rb_max[g] = rb_maxs[src];
+        vec = vec && ((uintptr_t)b_invs[src] % 16 == 0);
+    }
+    tb.rows_per_group = rows_per_group;
+    EGK_REQUIRE((uintptr_t)f % 16 == 0, "egk_topk_window_group: feature rows must be 16-byte aligned");
     const dim3 grid(row_grid(rows)), block(256);
     if (k <= 4)
-        hipLaunchKernelGGL((topk_window_kernel<4>), grid, block, 0, s, dot1, (long long)ldd, f, (long long)ldf, bank, (long long)ldb, f_inv,
-                           b_inv, rb_max, (long long*)nn, cand, rows, K, H, k, vec);
+        hipLaunchKernelGGL((topk_window_kernel<4>), grid, block, 0, s, dot1, (long long)ldd, f, (long long)ldf, tb, (long long)ldb, f_inv,
+                           (long long*)nn, cand, rows, K, H, k, vec);
     else
-        hipLaunchKernelGGL((topk_window_kernel<16>), grid, block, 0, s, dot1, (long long)ldd, f, (long long)ldf, bank, (long long)ldb, f_inv,
-                           b_inv, rb_max, (long long*)nn, cand, rows, K, H, k, vec);
-    return check_launch("egk_topk_window");
+        hipLaunchKernelGGL((topk_window_kernel<16>), grid, block, 0, s, dot1, (long long)ldd, f, (long long)ldf, tb, (long long)ldb, f_inv,
+                           (long long*)nn, cand, rows, K, H, k, vec);
+    return check_launch("egk_topk_window_group");
 }
 
 int egk_segment_sum_rows_f64(egk_stream_t stream, const void* x, const int32_t* order, const int32_t* seg_ptr,

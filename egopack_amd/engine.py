@@ -1591,6 +1591,17 @@ class EgoPackStep(StepBase):
                           else {o: self.tasks[o].forward_features(feats[t], out_f32=True) for o in others})
         return out
 
+    def _search_ahead(self, precise) -> None:
+        """The prototype searches of the coming ``GraphONE.interact`` calls on the CURRENT stream (the precise pass's): they need
+        the precise features only, so they start when that pass ends -- not behind the join with the training pass's forward chain,
+        which (created second) ends later: profiles/r05_c4_replay_timeline.txt vs r05b: the searches 907 -> 7xx us."""
+        import os
+        self.graphone.drop_searched()
+        if "search_ahead" in os.environ.get("EGK_DISABLE", ""):
+            return
+        for d in precise.values():
+            self.graphone.search_ahead(d)
+
     def task_loss(self, primary: str, feat, data, aux_in=None, f_primary=None):
         task = self.tasks[primary]
         others = self._aux_names(primary)
@@ -1644,12 +1655,13 @@ class EgoPackStep(StepBase):
                 # forked onto its own stream, the two chains run side by side (each alone leaves most of the chip idle)
                 main = torch.cuda.current_stream()
                 if getattr(self, "_precise_side", None) is None:
-                    self._precise_side = torch.cuda.Stream()
+                    self._precise_side = torch.cuda.Stream()  # (a high-priority stream: 5.05-5.26 against 2.53-2.55 ms in the captured step)
                     ops.exclude_wgrad_streams([self._precise_side])
                 side = self._precise_side
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     precise = self.precise_aux_features(batches, merged, rng_snap=snap)
+                    self._search_ahead(precise)
             else:
                 precise = self.precise_aux_features(batches, merged, rng_snap=snap)
         import contextlib
@@ -1671,6 +1683,7 @@ class EgoPackStep(StepBase):
             side.wait_event(fork_ev)
             with torch.cuda.stream(side):
                 precise = self.precise_aux_features(batches, merged, rng_snap=snap)
+                self._search_ahead(precise)
         # the primary projection heads need nothing of the precise pass: issued BEFORE the join with its stream, so that they run
         # beside its tail instead of behind it (profiles/r04_c4_replay_timeline.txt: 896-990 us, 95 us in which nothing else ran)
         f_prim = {}
@@ -1681,6 +1694,10 @@ class EgoPackStep(StepBase):
             for d in precise.values():
                 for a in d.values():
                     a.record_stream(main)
+            for st in self.graphone.ahead_streams():
+                main.wait_stream(st)  # (the searches forked off ``side``; joined HERE, into the origin stream: GraphONE.search_ahead)
+            for a in self.graphone.searched_tensors():
+                a.record_stream(main)
 
         def head(t, feat):
             loss, logits, _, _ = self.task_loss(t, feat, batches[t], aux_in=precise.get(t), f_primary=f_prim.get(t))

@@ -65,6 +65,8 @@ class GraphONE(nn.Module):
         # contractions that each fill half of the chip at best -- run them on one HIP stream per task
         self.parallel_tasks = bool(kwargs.get("parallel_tasks", True))
         self._task_streams: List[torch.cuda.Stream] = []
+        self._searched: Dict[tuple, tuple] = {}  # results of ``search_ahead`` waiting for their ``interact``
+        self._forked = False  # the last ``_search_all`` ran on the task streams
 
     def _bank_norm(self, task: str) -> torch.Tensor:
         """Per-prototype 1/||p|| (cosine) or ||p||^2 (l2): cached while the bank is frozen, recomputed per call otherwise
@@ -125,8 +127,28 @@ class GraphONE(nn.Module):
         stage_lists = [self.conv_stages[t] for t in tasks]
         if not ops.graphone_stages_ok(len(items), feats[0].shape[0], feats[0].shape[1], banks, stage_lists, self.freeze):
             return None
+        ready = self._searched.pop(tuple(id(f) for f in feats), None)
+        nn_idx, f_act = ready[:2] if ready is not None else self._search_all(items)
+        self.stream_of = {}  # (every output is made on the caller's stream)
+        outs = ops.graphone_stages(f_act, banks, [nn_idx[t] for t in tasks], stage_lists, self.residual)
+        output = dict(zip(tasks, outs))
+        closest = {t: [nn_idx[t][:, 0]] * self.depth for t in tasks}
+        return output, closest
+
+    def _search_all(self, items, join: bool = True):
+        """({task: [N, k] prototype indices}, the features in the activation type): the searches side by side on the task streams,
+        forked from the current stream, the cast beside them on the current stream; ``join``: the task streams are joined back into
+        the current stream (else the caller joins ``ahead_streams()`` where the results are consumed)."""
         main = torch.cuda.current_stream()
+        feats = [f for _, f in items]
         nn_idx = {}
+        banks = [self.embeddings[t].weight for t, _ in items]
+        if ops.act_dtype() == torch.bfloat16 and ops.nearest_prototypes_grouped_ok(feats, banks, self.k, self.distance_func):
+            # every task's search as ONE chain of grouped launches on this stream (no fork: ``ahead_streams`` stays empty)
+            lists, f_act = ops.nearest_prototypes_grouped(feats, banks, self.k, [self._bank_norm(t) for t, _ in items])
+            self._forked = False
+            return dict(zip([t for t, _ in items], lists)), f_act
+        self._forked = bool(self.parallel_tasks)
         if self.parallel_tasks:
             fork = torch.cuda.Event()
             fork.record(main)
@@ -141,18 +163,54 @@ class GraphONE(nn.Module):
                                                           self._bank_norm(task))
             f_act = ops.to_act_rows(feats)  # (on the caller's stream, beside the searches)
             for st, (task, _) in zip(self._task_streams, items):
-                main.wait_stream(st)
-                nn_idx[task].record_stream(main)
+                if join:
+                    main.wait_stream(st)
+                    nn_idx[task].record_stream(main)
         else:
             f_act = ops.to_act_rows(feats)
             for task, f in items:
                 nn_idx[task] = ops.nearest_prototypes(f.detach(), self.embeddings[task].weight, self.k, self.distance_func,
                                                       self._bank_norm(task))
-        self.stream_of = {}  # (every output is made on the caller's stream)
-        outs = ops.graphone_stages(f_act, banks, [nn_idx[t] for t in tasks], stage_lists, self.residual)
-        output = dict(zip(tasks, outs))
-        closest = {t: [nn_idx[t][:, 0]] * self.depth for t in tasks}
-        return output, closest
+        return nn_idx, f_act
+
+    def search_ahead(self, features: Dict[str, torch.Tensor]) -> bool:
+        """Run the prototype searches of a coming ``interact(features)`` NOW, forked from the current stream -- the searches need
+        nothing but the features, while ``interact`` is issued where the stages can run, behind whatever else its caller's stream
+        holds: the EgoPack step forks the searches from the stream of the pass that makes the features BEFORE that stream joins the
+        training pass's, so they run beside the training pass's forward chain instead of behind it.  The results are kept for the
+        ``interact`` call over the SAME tensors.  The CALLER joins ``ahead_streams()`` into the stream that calls ``interact``: the
+        task streams are not joined back into the current stream, because under capture this stream may itself be a fork of the
+        capture's origin stream, and ROCm 7.2's capture bookkeeping lists the waiting stream as a parallel stream of the event's
+        stream on EVERY wait of a non-origin stream -- fork A -> B plus join B -> A makes the two lists a cycle and
+        ``hipStreamEndCapture`` recurse until the stack ends.  False: the grouped interaction does not apply (nothing was run)."""
+        items = list(features.items())
+        feats = [f for _, f in items]
+        if (len(items) < 2 or not feats[0].is_cuda or not torch.is_grad_enabled() or any(f.requires_grad for f in feats)
+                or any(f.dim() != 2 or f.shape != feats[0].shape for f in feats) or feats[0].shape[0] % 64 or feats[0].shape[1] % 64
+                or not ops.graphone_stages_ok(len(items), feats[0].shape[0], feats[0].shape[1], [self.embeddings[t].weight for t, _ in items],
+                                              [self.conv_stages[t] for t, _ in items], self.freeze)):
+            return False
+        if self._searched and self._forked:
+            return False  # (one set of task streams: a second pending search would need the first one joined)
+        with torch.no_grad():
+            nn_idx, f_act = self._search_all(items, join=False)
+        self._searched[tuple(id(f) for f in feats)] = (nn_idx, f_act, feats)  # (feats held: their ids stay theirs)
+        return True
+
+    def ahead_streams(self):
+        """The streams pending ``search_ahead`` results were made on, beside the stream ``search_ahead`` was called on."""
+        return list(self._task_streams) if self._searched and self._forked else []
+
+    def drop_searched(self) -> None:
+        """Forget pending ``search_ahead`` results (a result nobody fetched must not outlive its step)."""
+        self._searched.clear()
+
+    def searched_tensors(self):
+        """The tensors of the pending ``search_ahead`` results (for the caller's stream bookkeeping)."""
+        out = []
+        for nn_idx, f_act, _ in self._searched.values():
+            out += list(nn_idx.values()) + list(f_act if isinstance(f_act, (list, tuple)) else [f_act])
+        return out
 
     def _task_interaction(self, task: str, features: torch.Tensor):
         bank = self.embeddings[task].weight

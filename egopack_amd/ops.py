@@ -3298,6 +3298,59 @@ def nearest_prototypes(f, bank, k, distance_func: str = "cosine", bank_norm=None
     return nn
 
 
+def rows_of_one_buffer(feats):
+    """The [sum rows, H] buffer whose consecutive row blocks ``feats`` are (contiguous, in order, nothing else in it), or None."""
+    f0 = feats[0]
+    base = f0._base
+    if base is None or base.dim() != 2 or not base.is_contiguous() or base.shape != (sum(f.shape[0] for f in feats), f0.shape[1]):
+        return None
+    off = base.data_ptr()
+    for f in feats:
+        if f._base is not base or f.dim() != 2 or not f.is_contiguous() or f.data_ptr() != off:
+            return None
+        off += f.shape[0] * f.shape[1] * base.element_size()
+    return base
+
+
+def nearest_prototypes_grouped_ok(feats, banks, k, distance_func: str = "cosine") -> bool:
+    """``nearest_prototypes_grouped`` applies: cosine distance in a bf16 compute mode, f32 feature blocks of equal height that are
+    consecutive rows of one buffer, at most 8 frozen-shape banks of one shape, and the one-product window search takes the shapes."""
+    if distance_func != "cosine" or _state["compute"] == F32 or not 2 <= len(feats) <= 8 or len(banks) != len(feats):
+        return False
+    f0, b0 = feats[0], banks[0]
+    if (f0.dtype != torch.float32 or not f0.is_cuda or any(f.shape != f0.shape for f in feats)
+            or any(b.dtype != torch.float32 or b.shape != b0.shape or not b.is_contiguous() for b in banks)
+            or "grouped_search" in os.environ.get("EGK_DISABLE", "")):
+        return False
+    base = rows_of_one_buffer(feats)
+    return base is not None and _window_search_ok(f0.shape[0], b0.shape[0], f0.shape[1], k, base, b0)
+
+
+@torch.no_grad()
+def nearest_prototypes_grouped(feats, banks, k, bank_norms):
+    """([N, k] index lists of ``nearest_prototypes(feats[g], banks[g], k)`` for every g, the bf16 rounding of all feature rows
+    [G * N, H]) as ONE chain of four launches -- row norms, rounding, a grouped bf16 product, a grouped window search
+    (egk_topk_window_group) -- on the current stream: no fork, so the chain can sit on any stream of a capture (GraphONE.search_ahead),
+    and the rounding is the activation-type copy the GraphONE stages consume.  Requires ``nearest_prototypes_grouped_ok``."""
+    lib = _lib.load()
+    base = rows_of_one_buffer(feats)
+    G, (N, H) = len(feats), feats[0].shape
+    K = banks[0].shape[0]
+    f_norm = row_inv_norm(base)
+    hi = cast_raw(base, torch.bfloat16)
+    ops_b = [_bank_window_operand(b) for b in banks]
+    dot = torch.empty((G * N, K), dtype=torch.float32, device=base.device)
+    nn = torch.empty((G * N, k), dtype=torch.int64, device=base.device)
+    gemm_grouped([((N, K, hi[g * N:(g + 1) * N], H, ops_b[g][0], H, H, dot[g * N:(g + 1) * N], K), {"compute": BF16}) for g in range(G)])
+    cand = _window_stats["cand"]
+    if cand is not None and (cand.numel() != G * N or cand.device != base.device):
+        cand = None
+    arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
+    _ck(lib.egk_topk_window_group(_stream(), _p(dot), K, _p(base), base.stride(0), arr(banks), banks[0].stride(0), _p(f_norm),
+                                  arr(bank_norms), arr([o[1] for o in ops_b]), _p(nn), _p(cand), G, N, K, H, k), "egk_topk_window_group")
+    return [nn[g * N:(g + 1) * N] for g in range(G)], hi
+
+
 def cosine_topk(f, bank, k, bank_inv_norm=None):
     return nearest_prototypes(f, bank, k, "cosine", bank_inv_norm)
 

@@ -429,6 +429,12 @@ int egk_topk_smallest(egk_stream_t s, const float* dot, int64_t ldd, const float
 int egk_topk_window(egk_stream_t s, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* bank, int64_t ldb,
                     const float* f_inv, const float* b_inv, const float* rb_max, int64_t* nn, int32_t* cand, int32_t rows, int32_t K,
                     int32_t H, int32_t k);
+/* n_groups (<= 8) such searches as ONE launch: rows [g * rows_per_group, (g + 1) * rows_per_group) of dot1 / f / f_inv / nn / cand are
+ * searched in banks[g] (all [K, H], row stride ldb) with b_invs[g], rb_maxs[g] -- the auxiliary tasks of one EgoPack batch, whose
+ * feature rows are consecutive blocks of one buffer (graphONE.py:94-115 runs the tasks one after the other). */
+int egk_topk_window_group(egk_stream_t s, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* const* banks,
+                          int64_t ldb, const float* f_inv, const float* const* b_invs, const float* const* rb_maxs, int64_t* nn,
+                          int32_t* cand, int32_t n_groups, int32_t rows_per_group, int32_t K, int32_t H, int32_t k);
 /* r[j] = ||x_j - hi(x_j)|| / ||x_j|| for the rows of an f32 matrix, *rmax = max_j r[j] (once per prototype bank) */
 int egk_bf16_residual_ratio(egk_stream_t s, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols);
 

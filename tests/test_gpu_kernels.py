@@ -1894,6 +1894,31 @@ def test_window_search_gives_the_lists_of_the_exact_distances(ops, N, K, H, k):
     assert torch.equal(nn[safe3], nn3[safe3])
 
 
+@pytest.mark.parametrize("G,N,K,H,k", [(3, 128, 4096, 1024, 4), (2, 64, 257, 128, 8), (4, 192, 512, 256, 4)])
+def test_grouped_window_search_equals_the_searches_one_by_one(ops, G, N, K, H, k):
+    """``ops.nearest_prototypes_grouped`` (the auxiliary tasks of one EgoPack batch as one chain of grouped launches): the lists of
+    ``nearest_prototypes`` per task, bit for bit, and the bf16 rounding of the rows as a by-product."""
+    g = gen(G * 1000 + N + K)
+    base = torch.randn(G * N, H, generator=g).to(DEV)
+    banks = [torch.randn(K, H, generator=g).to(DEV) for _ in range(G)]
+    for b in banks:
+        b[7] = b[6]  # exact duplicates: ties -> lower index
+    base[3] = banks[0][6] + 0.2 * base[3]
+    feats = [base[i * N:(i + 1) * N] for i in range(G)]
+    with ops.compute_mode("bf16"):
+        assert ops.nearest_prototypes_grouped_ok(feats, banks, k)
+        norms = [ops.row_inv_norm(b) for b in banks]
+        lists, hi = ops.nearest_prototypes_grouped(feats, banks, k, norms)
+        one = [ops.nearest_prototypes(f, b, k, "cosine", n) for f, b, n in zip(feats, banks, norms)]
+        assert not ops.nearest_prototypes_grouped_ok([base[:N], base[2 * N:3 * N]] if G > 2 else [base[:N].clone(), base[N:]], banks[:2], k)
+    for a, b in zip(lists, one):
+        assert torch.equal(a, b)
+    assert lists[0][3, :2].tolist() == [6, 7]
+    assert torch.equal(hi, base.to(torch.bfloat16))
+    with ops.compute_mode("f32"):
+        assert not ops.nearest_prototypes_grouped_ok(feats, banks, k)  # the exact-f32 search stays one per task
+
+
 def test_window_search_with_bf16_features_and_ties(ops):
     """bf16 features (hi(f) = f: no row residual) and a bank with whole groups of identical rows: ties go to the lower index."""
     bank = torch.randn(64, 64, generator=gen(5))
