@@ -959,10 +959,11 @@ struct TopkWindowBanks {
 };
 
 template <int KM>
-__global__ __launch_bounds__(256) void topk_window_kernel(const float* __restrict__ dot1, long long ldd, const float* __restrict__ f,
+__global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __restrict__ dot1, long long ldd, const float* __restrict__ f,
                                                           long long ldf, TopkWindowBanks tb, long long ldb,
                                                           const float* __restrict__ f_inv, long long* __restrict__ nn,
                                                           int* __restrict__ cand, int rows, int K, int H, int k, int vec) {
+    __shared__ int s_cand[WPB][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const int grp = row / tb.rows_per_group;  // (wave-uniform)
@@ -1001,14 +1002,10 @@ __global__ __launch_bounds__(256) void topk_window_kernel(const float* __restric
         const float rf = s2 > 0.f ? sqrtf(r2 / s2) : 0.f;
         const float E = 1.01f * (rf + rb) + 3.f * rf * rb + (float)H * 6.0e-8f + 2.0e-6f;
 
-        // ---- pass 1: the k-th smallest APPROXIMATE distance (topk_kernel's one-pass lists) ------------------------------------
-        float lv[KM];
-        int li[KM];
-#pragma unroll
-        for (int s = 0; s < KM; ++s) {
-            lv[s] = INFINITY;
-            li[s] = 0x7fffffff;
-        }
+        // ---- pass 1: an upper bound U of the k-th smallest APPROXIMATE distance: the k-th smallest of the 64 lanes' minima (k distinct
+        // prototypes lie at or below it, so nothing beyond U + 2 E can be among the k nearest; U IS the k-th smallest whenever the k
+        // nearest fall into k different lanes -- 91 % of the rows at k = 4 -- and the next few otherwise: a candidate more) ---------
+        float lmin = INFINITY;
         for (int base0 = lane * 4; base0 < K; base0 += 1024) {
             float dq[4][4], bq[4][4];
 #pragma unroll
@@ -1031,27 +1028,14 @@ __global__ __launch_bounds__(256) void topk_window_kernel(const float* __restric
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int j = base0 + 256 * u + t;
-                    float d = 1.f - dq[u][t] * fi * bq[u][t];
-                    int dj = j;
-                    if (j < K && (d < lv[KM - 1] || (d == lv[KM - 1] && dj < li[KM - 1]))) {
-#pragma unroll
-                        for (int s = 0; s < KM; ++s) {
-                            const bool before = d < lv[s] || (d == lv[s] && dj < li[s]);
-                            const float tv = lv[s];
-                            const int ti = li[s];
-                            lv[s] = before ? d : tv;
-                            li[s] = before ? dj : ti;
-                            d = before ? tv : d;
-                            dj = before ? ti : dj;
-                        }
-                    }
+                    const float d = 1.f - dq[u][t] * fi * bq[u][t];
+                    if (base0 + 256 * u + t < K) lmin = fminf(lmin, d);
                 }
         }
         float Dk = INFINITY;
         for (int sel = 0; sel < k; ++sel) {
-            float bv = lv[0];
-            int bi = li[0];
+            float bv = lmin;
+            int bi = lane;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const float ov = __shfl_xor(bv, o, 64);
@@ -1062,26 +1046,12 @@ __global__ __launch_bounds__(256) void topk_window_kernel(const float* __restric
                 }
             }
             Dk = bv;
-            if (li[0] == bi && bi != 0x7fffffff) {
-#pragma unroll
-                for (int s = 0; s + 1 < KM; ++s) {
-                    lv[s] = lv[s + 1];
-                    li[s] = li[s + 1];
-                }
-                lv[KM - 1] = INFINITY;
-                li[KM - 1] = 0x7fffffff;
-            }
+            if (lane == bi) lmin = INFINITY;
         }
-        const float T = Dk + 2.f * E;  // (fewer than k finite distances: Dk = inf, every finite one is a candidate)
+        const float T = Dk + 2.f * E;  // (fewer than k lanes with a finite minimum: Dk = inf, every finite distance is a candidate)
 
-        // ---- pass 2: exact distances of the candidates; the k nearest of them in (key, index) order (wave-uniform list) --------
-        float ev[KM];
-        int ei[KM];
-#pragma unroll
-        for (int s = 0; s < KM; ++s) {
-            ev[s] = INFINITY;
-            ei[s] = 0x7fffffff;
-        }
+        // ---- pass 2a: the candidates' indices, listed per wave (LDS; more than 64 of them: the rescan below) ------------------------
+        volatile int* cl = s_cand[wave];
         int n_cand = 0;
         for (int base0 = 0; base0 < K; base0 += 1024) {
             float dq[4][4], bq[4][4];
@@ -1107,45 +1077,121 @@ __global__ __launch_bounds__(256) void topk_window_kernel(const float* __restric
                 for (int t = 0; t < 4; ++t) {
                     const int j = base0 + lane * 4 + 256 * u + t;
                     const float d = 1.f - dq[u][t] * fi * bq[u][t];
-                    unsigned long long mask = __ballot(j < K && d <= T);
-                    n_cand += __popcll(mask);
-                    while (mask) {  // (wave-uniform)
-                        const int b = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        const int jj = base0 + b * 4 + 256 * u + t;
-                        const float* pr = bank + (long long)jj * ldb;
-                        double acc = 0.0;
-                        if (in_regs && (ldb & 3) == 0) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int c = lane * 4 + 256 * q;
-                                if (c < H) {
-                                    const float4 pv = *reinterpret_cast<const float4*>(pr + c);
-                                    acc += (double)fv[q].x * (double)pv.x + (double)fv[q].y * (double)pv.y +
-                                           (double)fv[q].z * (double)pv.z + (double)fv[q].w * (double)pv.w;
-                                }
-                            }
-                        } else {
-                            for (int c = lane; c < H; c += 64) acc += (double)fr[c] * (double)pr[c];
-                        }
-                        acc = wave_sum(acc);
-                        float de = 1.f - (float)acc * fi * b_inv[jj];
-                        int dj = jj;
-                        if (de < ev[KM - 1] || (de == ev[KM - 1] && dj < ei[KM - 1])) {
-#pragma unroll
-                            for (int s = 0; s < KM; ++s) {
-                                const bool before = de < ev[s] || (de == ev[s] && dj < ei[s]);
-                                const float tv = ev[s];
-                                const int ti = ei[s];
-                                ev[s] = before ? de : tv;
-                                ei[s] = before ? dj : ti;
-                                de = before ? tv : de;
-                                dj = before ? ti : dj;
-                            }
-                        }
+                    const bool pred = j < K && d <= T;
+                    const unsigned long long mask = __ballot(pred);
+                    if (mask) {  // (wave-uniform)
+                        const int slot = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (pred && slot < 64) cl[slot] = j;
+                        n_cand += __popcll(mask);
                     }
                 }
         }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- pass 2b: exact distances of the candidates; the k nearest of them in (key, index) order (wave-uniform list) -------------
+        float ev[KM];
+        int ei[KM];
+#pragma unroll
+        for (int s = 0; s < KM; ++s) {
+            ev[s] = INFINITY;
+            ei[s] = 0x7fffffff;
+        }
+        auto keep = [&](float de, int dj) {
+            if (de < ev[KM - 1] || (de == ev[KM - 1] && dj < ei[KM - 1])) {
+#pragma unroll
+                for (int s = 0; s < KM; ++s) {
+                    const bool before = de < ev[s] || (de == ev[s] && dj < ei[s]);
+                    const float tv = ev[s];
+                    const int ti = ei[s];
+                    ev[s] = before ? de : tv;
+                    ei[s] = before ? dj : ti;
+                    de = before ? tv : de;
+                    dj = before ? ti : dj;
+                }
+            }
+        };
+        auto one = [&](int jj) {  // one candidate, any shape
+            const float* pr = bank + (long long)jj * ldb;
+            double acc = 0.0;
+            for (int c = lane; c < H; c += 64) acc += (double)fr[c] * (double)pr[c];
+            acc = wave_sum(acc);
+            keep(1.f - (float)acc * fi * b_inv[jj], jj);
+        };
+        if (n_cand > 64) {
+            // a crowded row: every candidate in scan order, one at a time (slow, never wrong)
+            for (int j0 = 0; j0 < K; j0 += 64) {
+                const int j = j0 + lane;
+                const float d = j < K ? 1.f - dr[j] * fi * b_inv[j] : INFINITY;
+                unsigned long long mask = __ballot(j < K && d <= T);
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    one(j0 + b);
+                }
+            }
+        } else if (!(in_regs && (ldb & 3) == 0)) {
+            for (int c = 0; c < n_cand; ++c) one(__builtin_amdgcn_readfirstlane(cl[c]));
+        } else {
+            // four candidates at a time: their rows in TWO rounds of loads (32 registers in flight), the four lane-partial sums folded
+            // TOGETHER -- each of the first two halving steps of the wave hands half of the sums to the partner lane, so four
+            // totals cost 7 exchanges instead of 24 -- candidate i's total ends in lanes 16 i .. 16 i + 15
+            for (int c0 = 0; c0 < n_cand; c0 += 4) {
+                int cj[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cj[i] = c0 + i < n_cand ? __builtin_amdgcn_readfirstlane(cl[c0 + i]) : -1;
+                double acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = 0.0;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float4 pv[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            // unconditional loads (a guarded load is a branch and a wait of its own): an empty slot reads row 0 and
+                            // is dropped below; columns beyond H read the row's last four, against zeros in fv
+                            const int c = min(lane * 4 + 256 * (2 * half + q2), H - 4);
+                            pv[i][q2] = *reinterpret_cast<const float4*>(bank + (long long)max(cj[i], 0) * ldb + c);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_barrier(0);  // (one candidate's widened elements live at a time)
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            const float4 a = fv[2 * half + q2], b = pv[i][q2];
+                            acc[i] += (double)a.x * (double)b.x + (double)a.y * (double)b.y + (double)a.z * (double)b.z +
+                                      (double)a.w * (double)b.w;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                double a2[2], a1;
+                {
+                    const bool hi = lane & 32;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const double recv = __shfl_xor(hi ? acc[i] : acc[i + 2], 32, 64);
+                        a2[i] = (hi ? acc[i + 2] : acc[i]) + recv;
+                    }
+                }
+                {
+                    const bool hi = lane & 16;
+                    const double recv = __shfl_xor(hi ? a2[0] : a2[1], 16, 64);
+                    a1 = (hi ? a2[1] : a2[0]) + recv;
+                }
+                a1 += __shfl_xor(a1, 8, 64);
+                a1 += __shfl_xor(a1, 4, 64);
+                a1 += __shfl_xor(a1, 2, 64);
+                a1 += __shfl_xor(a1, 1, 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double tot = __shfl(a1, 16 * i, 64);
+                    if (cj[i] >= 0) keep(1.f - (float)tot * fi * b_inv[cj[i]], cj[i]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             for (int s = 0; s < k; ++s) nn[(long long)row * k + s] = (s < KM && ei[s] != 0x7fffffff) ? ei[s] : 0;
             if (cand) cand[row] = n_cand;
