@@ -1529,15 +1529,17 @@ class EgoPackStep(StepBase):
         return [*getattr(self.graphone, "_task_streams", ()), *getattr(self, "_head_streams", ())]
 
     def _early_adam_plan(self, live):
-        """+ OPT-IN (EGK_ENABLE=graphone_adam) GraphONE's own slice: its stage parameters (half of the step's parameters in config
+        """+ GraphONE's own slice (EGK_DISABLE=graphone_adam: off): its stage parameters (half of the step's parameters in config
         4) have their final gradients when the grouped GraphONE backward returns (ops.set_graphone_backward_hook) -- Adam over
-        that slice then runs beside the backbone's backward instead of in the step's tail.  Measured: the tail shrinks from 275 to
-        114 us and the backbone's backward grows by as much (2.746-2.751 against 2.72-2.80 ms, tools/round4/c4_g1adam_ab.sh) --
-        the memory-bound launch slows the chain it runs beside, as in the headline step (_early_adam_plan)."""
+        that slice then runs beside the backbone's backward instead of in the step's tail.  Round 4: the tail shrank from 275 to
+        114 us and the backbone's backward grew by as much (2.746-2.751 against 2.72-2.80 ms, tools/round4/c4_g1adam_ab.sh: the
+        memory-bound launch slows the chain it runs beside) -- opt-in then.  Round 5, with the searches grouped and the precise pass
+        first: 2.42-2.45 against 2.475-2.478 ms (three alternating rounds): the default.  Elementwise, the same update bit for bit
+        (tests/test_gpu_configs.py::test_config4_graphone_optimizer_slice_is_the_same_update)."""
         import os
         plan = super()._early_adam_plan(live)
         opt = self.optimizer
-        if plan is None or "graphone_adam" not in os.environ.get("EGK_ENABLE", "") or len(live) != 1:
+        if plan is None or "graphone_adam" in os.environ.get("EGK_DISABLE", "") or len(live) != 1:
             return plan
         params = [p for p in self.graphone.parameters() if p.requires_grad and id(p) in opt._slot_of]
         if not params:

@@ -446,3 +446,25 @@ def test_config4_prototype_indices_in_bf16_mode():
     end_to_end = _rel(logits.float().cpu(), ref["logits"])
     _report(name, "bf16-indices", {"agreement": rates, "logit_rel_end_to_end": end_to_end})
     assert end_to_end < BF16_C4_LOGITS, end_to_end
+
+
+def test_config4_graphone_optimizer_slice_is_the_same_update(monkeypatch):
+    """BASELINE config 4, captured: Adam over GraphONE's slice beside the backbone's backward (the default) leaves the parameters of
+    the step that runs the whole optimizer in its tail, bit for bit, after three replays -- nothing of the slice may start before
+    the stages' weight gradients are final, and nothing may be stepped twice."""
+    def run(off):
+        if off:
+            monkeypatch.setenv("EGK_DISABLE", "graphone_adam")
+        else:
+            monkeypatch.delenv("EGK_DISABLE", raising=False)
+        torch.manual_seed(0)
+        args, step, opt, dev, merged, modules, sds, weights = _build("c4_egopack_oscc_K4096_d3", "bf16")
+        step.capture(dev, merged, warmup=2)
+        for _ in range(3):
+            step.replay()
+        torch.cuda.synchronize()
+        return opt.flat_p.clone(), opt.step_count
+    p_on, n_on = run(False)
+    p_off, n_off = run(True)
+    assert n_on == n_off
+    assert torch.equal(p_on, p_off)
