@@ -111,6 +111,8 @@ SIGNATURES = {
     "egk_gather_max_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),
     "egk_segment_max_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32]),
     "egk_segment_max_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    "egk_segment_max_multi_fwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    "egk_segment_max_multi_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]),
     "egk_row_inv_norm": (C.c_int, [vp, vp, vp, i32, i32, i32]),
     "egk_cos_dist": (C.c_int, [vp, vp, i64, vp, vp, vp, i32, i32]),
     "egk_topk_smallest": (C.c_int, [vp, vp, i64, vp, vp, vp, i32, i32, i32]),

@@ -721,11 +721,28 @@ __global__ __launch_bounds__(256) void segmax_fwd_kernel(const T* __restrict__ x
 // values the SMALLER row -- the first occurrence, which is what the serial walk (strict >) keeps.  cols % 4 == 0.
 // RL row lanes (waves) per workgroup: 4, or 16 when the launch has few segments (16 sequences of 256 nodes: 64 workgroups of 4
 // waves walked 8 dependent rounds of loads each -- 44 us on the critical path of config 5 between the heads and backward).
+// (up to four inputs over the same sequences in one launch -- blockIdx.z picks the input: the OSCC head pools the primary
+//  features and one GraphONE output per auxiliary task, oscc.py:68,85)
+template <typename T>
+struct SegMaxSrcs {
+    const T* x[4];
+    T* out[4];
+    int* arg[4];
+};
+template <typename T>
+struct SegMaxGrads {
+    const T* dout[4];
+    const int* arg[4];
+    T* dx[4];
+};
+
 template <typename T, int RL>
-__global__ __launch_bounds__(64 * RL) void segmax_fwd_v4_kernel(const T* __restrict__ x, const int* __restrict__ ptr,
-                                                                T* __restrict__ out, int* __restrict__ arg, int n_seg, int cols) {
+__global__ __launch_bounds__(64 * RL) void segmax_fwd_v4_kernel(SegMaxSrcs<T> src, const int* __restrict__ ptr, int n_seg, int cols) {
     __shared__ float sv[RL - 1][64][4];
     __shared__ int sa[RL - 1][64][4];
+    const T* __restrict__ x = src.x[blockIdx.z];
+    T* __restrict__ out = src.out[blockIdx.z];
+    int* __restrict__ arg = src.arg[blockIdx.z];
     const int sg = blockIdx.y, cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + cg * 4;
     const bool live = c < cols;
@@ -777,9 +794,10 @@ __global__ __launch_bounds__(64 * RL) void segmax_fwd_v4_kernel(const T* __restr
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ dout, const int* __restrict__ arg,
-                                                         const int* __restrict__ ptr, T* __restrict__ dx, int n_seg,
-                                                         int cols) {
+__global__ __launch_bounds__(256) void segmax_bwd_kernel(SegMaxGrads<T> gr, const int* __restrict__ ptr, int n_seg, int cols) {
+    const T* __restrict__ dout = gr.dout[blockIdx.z];
+    const int* __restrict__ arg = gr.arg[blockIdx.z];
+    T* __restrict__ dx = gr.dx[blockIdx.z];
     const int sg = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
@@ -1729,33 +1747,75 @@ int egk_gather_max_bwd(egk_stream_t stream, const void* dm, const uint8_t* arg, 
 int egk_segment_max_fwd(egk_stream_t stream, const void* x, const int32_t* ptr, void* out, int32_t* arg, int32_t n_seg,
                         int32_t cols, int32_t dtype) {
     EGK_REQUIRE(x && ptr && out && arg, "egk_segment_max_fwd: null pointer");
+    const void* xs[1] = {x};
+    void* outs[1] = {out};
+    int32_t* args[1] = {arg};
+    return egk_segment_max_multi_fwd(stream, xs, ptr, outs, args, 1, n_seg, cols, dtype);
+}
+
+int egk_segment_max_multi_fwd(egk_stream_t stream, const void* const* xs, const int32_t* ptr, void* const* outs, int32_t* const* args,
+                              int32_t n_src, int32_t n_seg, int32_t cols, int32_t dtype) {
+    EGK_REQUIRE(xs && ptr && outs && args, "egk_segment_max_multi_fwd: null pointer");
+    EGK_REQUIRE(n_src >= 1 && n_src <= 4, "egk_segment_max_multi_fwd: 1..4 inputs");
     if (n_seg == 0 || cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_SEGMAX_FWD, s, 0, 0);
     const int ebytes = dtype == EGK_BF16 ? 2 : 4;
-    if (cols % 4 == 0 && (reinterpret_cast<uintptr_t>(x) % (4 * ebytes)) == 0 && (reinterpret_cast<uintptr_t>(out) % (4 * ebytes)) == 0 &&
-        (reinterpret_cast<uintptr_t>(arg) & 15) == 0) {
-        if (n_seg < 128)  // (few segments: sixteen row lanes per workgroup)
-            EGK_DISPATCH_T(dtype, hipLaunchKernelGGL((segmax_fwd_v4_kernel<T, 16>), dim3(cdiv(cols, 256), n_seg), dim3(1024), 0, s,
-                                                     (const T*)x, ptr, (T*)out, arg, n_seg, cols));
-        else
-            EGK_DISPATCH_T(dtype, hipLaunchKernelGGL((segmax_fwd_v4_kernel<T, 4>), dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s,
-                                                     (const T*)x, ptr, (T*)out, arg, n_seg, cols));
+    bool v4 = cols % 4 == 0;
+    for (int i = 0; i < n_src; ++i) {
+        EGK_REQUIRE(xs[i] && outs[i] && args[i], "egk_segment_max_multi_fwd: null input pointer");
+        v4 = v4 && (reinterpret_cast<uintptr_t>(xs[i]) % (4 * ebytes)) == 0 && (reinterpret_cast<uintptr_t>(outs[i]) % (4 * ebytes)) == 0 &&
+             (reinterpret_cast<uintptr_t>(args[i]) & 15) == 0;
+    }
+    if (v4) {
+        EGK_DISPATCH_T(dtype, {
+            SegMaxSrcs<T> src;
+            for (int i = 0; i < 4; ++i) {
+                const int j = i < n_src ? i : 0;
+                src.x[i] = (const T*)xs[j];
+                src.out[i] = (T*)outs[j];
+                src.arg[i] = args[j];
+            }
+            if (n_seg < 128)  // (few segments: sixteen row lanes per workgroup)
+                hipLaunchKernelGGL((segmax_fwd_v4_kernel<T, 16>), dim3(cdiv(cols, 256), n_seg, n_src), dim3(1024), 0, s, src, ptr, n_seg, cols);
+            else
+                hipLaunchKernelGGL((segmax_fwd_v4_kernel<T, 4>), dim3(cdiv(cols, 256), n_seg, n_src), dim3(256), 0, s, src, ptr, n_seg, cols);
+        });
         return check_launch("egk_segment_max_fwd");
     }
-    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_fwd_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)x, ptr,
-                                             (T*)out, arg, n_seg, cols));
+    for (int i = 0; i < n_src; ++i)
+        EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_fwd_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)xs[i], ptr,
+                                                 (T*)outs[i], args[i], n_seg, cols));
     return check_launch("egk_segment_max_fwd");
 }
 
 int egk_segment_max_bwd(egk_stream_t stream, const void* dout, const int32_t* arg, const int32_t* ptr, void* dx,
                         int32_t n_seg, int32_t rows, int32_t cols, int32_t dtype) {
     EGK_REQUIRE(dout && arg && ptr && dx, "egk_segment_max_bwd: null pointer");
+    const void* douts[1] = {dout};
+    const int32_t* args[1] = {arg};
+    void* dxs[1] = {dx};
+    return egk_segment_max_multi_bwd(stream, douts, args, ptr, dxs, 1, n_seg, rows, cols, dtype);
+}
+
+int egk_segment_max_multi_bwd(egk_stream_t stream, const void* const* douts, const int32_t* const* args, const int32_t* ptr,
+                              void* const* dxs, int32_t n_src, int32_t n_seg, int32_t rows, int32_t cols, int32_t dtype) {
+    EGK_REQUIRE(douts && args && ptr && dxs, "egk_segment_max_multi_bwd: null pointer");
+    EGK_REQUIRE(n_src >= 1 && n_src <= 4, "egk_segment_max_multi_bwd: 1..4 inputs");
     if (n_seg == 0 || cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_SEGMAX_BWD, s, 0, 0);
-    EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(segmax_bwd_kernel<T>, dim3(cdiv(cols, 256), n_seg), dim3(256), 0, s, (const T*)dout,
-                                             arg, ptr, (T*)dx, n_seg, cols));
+    for (int i = 0; i < n_src; ++i) EGK_REQUIRE(douts[i] && args[i] && dxs[i], "egk_segment_max_multi_bwd: null input pointer");
+    EGK_DISPATCH_T(dtype, {
+        SegMaxGrads<T> gr;
+        for (int i = 0; i < 4; ++i) {
+            const int j = i < n_src ? i : 0;
+            gr.dout[i] = (const T*)douts[j];
+            gr.arg[i] = args[j];
+            gr.dx[i] = (T*)dxs[j];
+        }
+        hipLaunchKernelGGL(segmax_bwd_kernel<T>, dim3(cdiv(cols, 256), n_seg, n_src), dim3(256), 0, s, gr, ptr, n_seg, cols);
+    });
     return check_launch("egk_segment_max_bwd");
 }
 

@@ -67,6 +67,10 @@ class OSCCTask(ProjectionTask):
         names = [None] + (list(aux_features) if aux_features else [])
         main = torch.cuda.current_stream() if features.is_cuda else None
         pooled = []
+        if main is not None and not (aux_streams and any(aux_streams.get(t) is not None for t in names[1:])):
+            # every input lives on this stream (the grouped GraphONE interaction): the pools of all of them as ONE launch each way
+            pooled = ops.segment_max_multi(feats, ptr)
+            names, feats = [], []
         for t, f in zip(names, feats):
             st = aux_streams.get(t) if (aux_streams and t is not None) else None
             if st is None or main is None:

@@ -2552,6 +2552,45 @@ def segment_max(x, ptr):
     return _SegMax.apply(x, ptr)
 
 
+class _SegMaxMulti(torch.autograd.Function):
+    """``segment_max`` of up to four inputs of one shape over the same sequences: ONE launch forward, ONE backward."""
+
+    @staticmethod
+    def forward(ctx, ptr, *xs):
+        _need_gpu(ptr, *xs)
+        xs = [_c(x) for x in xs]
+        rows, cols = xs[0].shape
+        n_seg = ptr.numel() - 1
+        outs = [torch.empty((n_seg, cols), dtype=xs[0].dtype, device=xs[0].device) for _ in xs]
+        args = torch.empty((len(xs), n_seg, cols), dtype=torch.int32, device=xs[0].device)
+        _ck(_lib.load().egk_segment_max_multi_fwd(_stream(), _ptr_array(xs), _p(ptr), _ptr_array(outs), _ptr_array(list(args)), len(xs), n_seg,
+                                                  cols, _dt(xs[0])), "egk_segment_max_multi_fwd")
+        ctx.rows, ctx.n = rows, len(xs)
+        ctx.save_for_backward(args, ptr)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        args, ptr = ctx.saved_tensors
+        douts = [_c(d) for d in douts]
+        n_seg, cols = douts[0].shape
+        dxs = [torch.empty((ctx.rows, cols), dtype=douts[0].dtype, device=douts[0].device) for _ in douts]
+        _ck(_lib.load().egk_segment_max_multi_bwd(_stream(), _ptr_array(douts), _ptr_array(list(args)), _p(ptr), _ptr_array(dxs), ctx.n, n_seg,
+                                                  ctx.rows, cols, _dt(douts[0])), "egk_segment_max_multi_bwd")
+        return (None, *dxs)
+
+
+def segment_max_multi(xs, ptr):
+    """[segment_max(x, ptr) for x in xs] -- one launch each way when the inputs share shape, element type and device (2 .. 4 of
+    them), the pools one by one otherwise."""
+    xs = list(xs)
+    x0 = xs[0]
+    if (2 <= len(xs) <= 4 and x0.is_cuda and all(x.shape == x0.shape and x.dtype == x0.dtype and x.dim() == 2 for x in xs)
+            and "segmax_multi" not in os.environ.get("EGK_DISABLE", "")):
+        return list(_SegMaxMulti.apply(ptr, *xs))
+    return [segment_max(x, ptr) for x in xs]
+
+
 # ---- losses ---------------------------------------------------------------------------------------------
 def _grad_dtype_of(t: torch.Tensor) -> torch.dtype:
     return getattr(t, "_egk_grad_dtype", torch.float32)

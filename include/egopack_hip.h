@@ -406,6 +406,12 @@ int egk_segment_max_fwd(egk_stream_t s, const void* x, const int32_t* ptr, void*
                         int32_t cols, int32_t dtype);
 int egk_segment_max_bwd(egk_stream_t s, const void* dout, const int32_t* arg, const int32_t* ptr, void* dx,
                         int32_t n_seg, int32_t rows, int32_t cols, int32_t dtype);
+/* The same pools over n_src (<= 4) inputs of one shape and one sequence layout as ONE launch each way (oscc.py:68,85: the OSCC head
+ * pools its own features and one GraphONE output per auxiliary task). */
+int egk_segment_max_multi_fwd(egk_stream_t s, const void* const* xs, const int32_t* ptr, void* const* outs, int32_t* const* args,
+                              int32_t n_src, int32_t n_seg, int32_t cols, int32_t dtype);
+int egk_segment_max_multi_bwd(egk_stream_t s, const void* const* douts, const int32_t* const* args, const int32_t* ptr,
+                              void* const* dxs, int32_t n_src, int32_t n_seg, int32_t rows, int32_t cols, int32_t dtype);
 
 /* ---- cosine k-NN   GraphONE.__compute_edges + cos_dissimilarity  graphONE.py:119-151 ----
  * inv_norm[r] = 1/||x[r,:]||  (rows of features or of the bank) */

@@ -1927,3 +1927,25 @@ def test_window_search_with_bf16_features_and_ties(ops):
     with ops.compute_mode("bf16"):
         nn = ops.cosine_topk(f.to(DEV), bank.to(DEV), 2).cpu()
     assert nn.tolist() == [[4, 5], [10, 11], [20, 21]]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_src,n_seg,T,cols", [(4, 64, 32, 1024), (2, 200, 5, 256), (3, 7, 33, 64)])
+def test_segment_max_of_several_inputs_in_one_launch(ops, dtype, n_src, n_seg, T, cols):
+    """``ops.segment_max_multi`` (the OSCC head's pools of its own features and of one GraphONE output per auxiliary task,
+    reference models/tasks/oscc.py:68,85): values, winners' gradients and zeros elsewhere equal the pools one by one, bit for bit."""
+    g = gen(n_src * 100 + n_seg)
+    ptr = torch.arange(0, (n_seg + 1) * T, T, dtype=torch.int32, device=DEV)
+    xs = [torch.randn(n_seg * T, cols, generator=g).to(DEV).to(dtype) for _ in range(n_src)]
+    xs[0][1] = xs[0][0]  # a tie inside the first sequence: the first occurrence wins
+    dys = [torch.randn(n_seg, cols, generator=g).to(DEV).to(dtype) for _ in range(n_src)]
+    a = [x.clone().requires_grad_(True) for x in xs]
+    b = [x.clone().requires_grad_(True) for x in xs]
+    with ops.compute_mode("bf16" if dtype == torch.bfloat16 else "f32"):
+        ya = ops.segment_max_multi(a, ptr)
+        yb = [ops.segment_max(x, ptr) for x in b]
+        torch.autograd.backward(ya, dys)
+        torch.autograd.backward(yb, dys)
+    for i in range(n_src):
+        assert torch.equal(ya[i], yb[i])
+        assert torch.equal(a[i].grad, b[i].grad)
