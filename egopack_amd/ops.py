@@ -2938,9 +2938,21 @@ class _RowDotCE2Multi(torch.autograd.Function):
                for b, sb, nb in zip(bs, slots_b, need_b)]
         arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else 0) for t in ts])
         gws = torch.empty(rows, 2, dtype=torch.float32, device=dev)
-        _ck(lib.egk_rowdot_ce2_multi(_stream(), n, arr(fs), arr(w_ops), arr(biases), _p(y), _p(logits), _p(loss), arr(dfs), arr(dws),
-                                     arr(dbs), _p(gws), rows, cols, int(bool(average)), float(smoothing), float(seed), _dt(fs[0])),
-            "egk_rowdot_ce2_multi")
+
+        def launch(phase):  # (0: both launches; 1: the row launch -- loss, logits, d f; 2: the column launch -- d W, d b)
+            _ck(lib.egk_rowdot_ce2_multi(_stream(), n, arr(fs), arr(w_ops), arr(biases), _p(y), _p(logits), _p(loss), arr(dfs), arr(dws),
+                                         arr(dbs), _p(gws), rows, cols, int(bool(average)) | (phase << 1), float(smoothing), float(seed),
+                                         _dt(fs[0])), "egk_rowdot_ce2_multi")
+        in_slots = all((dw is None or sw is not None) for dw, sw in zip(dws, slots_w)) and all(
+            (db is None or sb is not None) for db, sb in zip(dbs, slots_b))
+        if in_slots and any(d is not None for d in (*dws, *dbs)) and "ce2_cols_ride" not in os.environ.get("EGK_DISABLE", ""):
+            # the classifiers' gradients feed nothing on the chain and land in the optimizer's slots: their launch (27 us on the
+            # critical chain of BASELINE config 4 between the head and backward) rides with the next flush of the parked weight
+            # gradients (``park_rider``: at once when nothing can be parked)
+            launch(1)
+            park_rider(lambda: launch(2), hold=(*fs, gws, *w_ops))
+        else:
+            launch(0)
         ctx.keep = (fs, w_ops, biases, gws)
         ctx.ret = (dfs, [None if (sw is not None) else dw for dw, sw in zip(dws, slots_w)],
                    [None if (sb is not None) else db for db, sb in zip(dbs, slots_b)])
