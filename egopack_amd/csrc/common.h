@@ -91,6 +91,7 @@ bool prof_on();
 void prof_begin(int kid, hipStream_t s, double flops, double bytes);
 void prof_end(hipStream_t s);
 
+void set_adam_blocks(int n);       // loss_optim.hip: workgroup cap of the Adam launch (egk_tune key 6)
 void set_zero_fill_blocks(int n);  // loss_optim.hip: workgroup cap of egk_zero_fill (egk_tune key 5)
 
 struct ProfScope {

@@ -456,7 +456,9 @@ static inline int row_grid(int rows) {
 using namespace egk;
 
 static int g_zero_fill_blocks = 0;  // development knob: egk_tune(5, workgroups); 0 = default
+static int g_adam_blocks = 0;       // development knob: egk_tune(6, workgroups); 0 = default
 namespace egk { void set_zero_fill_blocks(int n) { g_zero_fill_blocks = n; } }
+namespace egk { void set_adam_blocks(int n) { g_adam_blocks = n; } }
 
 extern "C" {
 
@@ -737,7 +739,13 @@ int egk_adam_step_bump(egk_stream_t stream, float* p, const void* g, int32_t g_d
     EGK_REQUIRE(!bf16_shadow || ((uintptr_t)bf16_shadow & 7) == 0, "egk_adam_step: shadow must be 8-byte aligned");
     EGK_REQUIRE(!bf16_lo_shadow || ((uintptr_t)bf16_lo_shadow & 7) == 0, "egk_adam_step: low-half shadow must be 8-byte aligned");
     ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (bf16_lo_shadow ? 2.0 : 0.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * n);
-    EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(ew_grid(n, 4)), dim3(256), 0, s, p, (const T*)g, m, v,
+    // Workgroup cap: an optimizer slice runs BESIDE weight-gradient launches in every captured step's tail; with every wave slot of
+    // the chip taken by this streaming kernel the short launches queued beside it wait for slots (a 8 us reduction took 135 us,
+    // profiles/r05_c4_replay_timeline.txt)
+    unsigned grid = ew_grid(n, 4);
+    const unsigned cap = g_adam_blocks > 0 ? (unsigned)g_adam_blocks : 4096u;
+    if (grid > cap) grid = cap;
+    EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(grid), dim3(256), 0, s, p, (const T*)g, m, v,
                                                (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow,
                                                (bf16_t*)bf16_lo_shadow, (long long*)bump_word, (long long)bump));
     return check_launch("egk_adam_step");

@@ -941,6 +941,7 @@ int egk_tune(int32_t key, int32_t value) {
     if (key == 2) { const int p = g_cap_wide; g_cap_wide = value; return p; }
     if (key == 3) { const int p = g_graph_rows_v2; g_graph_rows_v2 = value; return p; }  // graph_ops.hip: the rows1024.h kernels
     if (key == 5) { ::egk::set_zero_fill_blocks(value); return 0; }  // loss_optim.hip: workgroups of egk_zero_fill (0 = default)
+    if (key == 6) { ::egk::set_adam_blocks(value); return 0; }       // loss_optim.hip: workgroup cap of the Adam launch (0 = default)
     return -1;
 }
 

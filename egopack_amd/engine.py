@@ -12,6 +12,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Mapping, Optional, Sequence
 
 import torch
@@ -401,7 +402,6 @@ class StepBase:
         # and left it off until round 4 (EgoPackStep.wgrad_grouping_default)
         self.wgrad_grouping = type(self).wgrad_grouping_default
         self.deferred_forks = type(self).deferred_forks_default
-        import os
         off = set(filter(None, os.environ.get("EGK_DISABLE", "").split(",")))  # development: A/B of the grouped paths
         on = set(filter(None, os.environ.get("EGK_ENABLE", "").split(",")))  # development: force a path a step class leaves off
         if "wgrad_grouping" in on:
@@ -792,9 +792,32 @@ class StepBase:
                     if early["tail"]:
                         g0 = opt.flat_g.data_ptr()
                         ops.set_last_wgrad_tail(g0 + 4 * early["lo"], g0 + 4 * early["hi"])
-                total, vectors = self._backward_pass(batches, merged)
+                # (no join with the weight-gradient side stream when a backward() call returns: the gradients are read below, behind
+                #  ``join_wgrad(force=True)`` -- and the late optimizer slices before it, see ``tail_first``)
+                tail_opt = any(k in os.environ.get("EGK_ENABLE", "") for k in ("tail_adam_first", "graphone_adam_on_main"))
+                prev_h = ops.set_wgrad_handoff(True) if (tail_opt and early is not None and not getattr(self, "_handoff", False)) else None
+                try:
+                    total, vectors = self._backward_pass(batches, merged)
+                finally:
+                    if prev_h is not None:
+                        ops.set_wgrad_handoff(prev_h)
                 self._join_zero()  # (a backward path that did not: the memset must at least precede the optimizer)
+                # OPT-IN (EGK_ENABLE=tail_adam_first; measured equal, config 4 2.340 against 2.339 ms: the tail's launches share the
+                # chip whichever queue holds them): when every gradient of the late slice was issued on THIS stream (the tail group),
+                # its optimizer launch follows at once -- not behind the join with the side stream's queue of weight-gradient groups
+                # -- and so do the slices whose gradients were final long ago (EGK_ENABLE=graphone_adam_on_main)
+                tail_first = bool(fuse_adam and early is not None and early["fired"] and early["tail"] and early.get("rng_done")
+                                  and ops.last_wgrad_tail_on_backward_stream() and "tail_adam_first" in os.environ.get("EGK_ENABLE", ""))
                 ops.set_last_wgrad_hook(None, None)
+                if tail_first:
+                    ops.drain_deferred()
+                    if early["hi"] > early["lo"]:
+                        opt.launch(None, early["lo"], early["hi"])
+                if fuse_adam and early is not None and (early["fired"] or early.get("done")):
+                    ops.drain_deferred()
+                    for (a, b), ev in early.pop("tail_slices", ()):
+                        torch.cuda.current_stream().wait_event(ev)
+                        opt.launch(None, a, b)
                 ops.join_wgrad(force=True)
                 ops.stamp("backward_done")
                 # the Philox offset word of the dropout launches moves on INSIDE the graph (beside nothing that reads it: every
@@ -806,8 +829,9 @@ class StepBase:
                 if fuse_adam:
                     if early is not None and early["fired"]:
                         torch.cuda.current_stream().wait_stream(early["stream"])
-                        opt.launch(None, early["lo"], early["hi"], bump=bump if early["hi"] > early["lo"] else None)
-                        bump = None if early["hi"] > early["lo"] else bump
+                        if not tail_first:
+                            opt.launch(None, early["lo"], early["hi"], bump=bump if early["hi"] > early["lo"] else None)
+                            bump = None if early["hi"] > early["lo"] else bump
                     elif early is not None and early.get("done"):  # (a slice was stepped, the last weight gradient's hook never ran)
                         torch.cuda.current_stream().wait_stream(early["stream"])
                         for a, b in _minus([(0, opt.flat_p.numel())], early["done"]):
@@ -829,7 +853,6 @@ class StepBase:
             ops.set_deferred_forks(prev_d)
         if segmented:
             from .graphexec import SegmentedGraph
-            import os
             try:
                 g = SegmentedGraph(g, max_streams=segmented,
                                    event_nodes=self.segmented_event_nodes or "plan_event_nodes" in os.environ.get("EGK_ENABLE", ""))
@@ -973,7 +996,6 @@ class StepBase:
     one_graph_exchange = False
 
     def _one_graph_exchange_ok(self) -> bool:
-        import os
         want = self.one_graph_exchange or "one_graph_exchange" in os.environ.get("EGK_ENABLE", "")
         return bool(want and "one_graph_exchange" not in os.environ.get("EGK_DISABLE", "")
                     and self.sync is not None and self.sync.world > 1 and self.sync.capturable())
@@ -1106,7 +1128,6 @@ class StepBase:
     segmented_event_nodes = False  # cross-stream edges as event-record / event-wait NODES inside per-stream graphs
 
     def _segmented_replay(self) -> int:
-        import os
         if "segmented_replay" in os.environ.get("EGK_DISABLE", ""):
             return 0
         for item in os.environ.get("EGK_ENABLE", "").split(","):
@@ -1536,7 +1557,6 @@ class EgoPackStep(StepBase):
         memory-bound launch slows the chain it runs beside) -- opt-in then.  Round 5, with the searches grouped and the precise pass
         first: 2.42-2.45 against 2.475-2.478 ms (three alternating rounds): the default.  Elementwise, the same update bit for bit
         (tests/test_gpu_configs.py::test_config4_graphone_optimizer_slice_is_the_same_update)."""
-        import os
         plan = super()._early_adam_plan(live)
         opt = self.optimizer
         if plan is None or "graphone_adam" in os.environ.get("EGK_DISABLE", "") or len(live) != 1:
@@ -1550,6 +1570,10 @@ class EgoPackStep(StepBase):
             return plan
         plan["done"] = []
 
+        # (opt-in, measured equal: the slice on the backward stream's tail instead of a stream of its own -- 2.333-2.39 against
+        #  2.348-2.355 ms)
+        on_main = "graphone_adam_on_main" in os.environ.get("EGK_ENABLE", "")
+
         def graphone_done():
             if plan["fired"] or plan["done"]:
                 return
@@ -1558,6 +1582,13 @@ class EgoPackStep(StepBase):
 
             def issue(ev):
                 side = ops.wgrad_side_stream(main)
+                if on_main:
+                    # the slice itself is launched on the backward stream when backward has ended (StepBase.capture: the step's tail),
+                    # behind this point of the side stream -- on a stream of its own the runtime's replay put it into the side
+                    # stream's hardware queue, between the weight-gradient groups it was meant to run beside
+                    # (profiles/r05_c4_replay_timeline.txt)
+                    plan["tail_slices"] = [((g0, g1), (side if side is not None else main).record_event())]
+                    return
                 plan["stream"].wait_event(ev)
                 if side is not None:
                     plan["stream"].wait_stream(side)
@@ -1597,7 +1628,6 @@ class EgoPackStep(StepBase):
         """The prototype searches of the coming ``GraphONE.interact`` calls on the CURRENT stream (the precise pass's): they need
         the precise features only, so they start when that pass ends -- not behind the join with the training pass's forward chain,
         which (created second) ends later: profiles/r05_c4_replay_timeline.txt vs r05b: the searches 907 -> 7xx us."""
-        import os
         self.graphone.drop_searched()
         if "search_ahead" in os.environ.get("EGK_DISABLE", ""):
             return
@@ -1649,7 +1679,6 @@ class EgoPackStep(StepBase):
         # forward chain first (``late``: 3.73 -> 3.69 ms then, a tie in round 4); with the split launch over the weights gone from
         # the head of the precise pass and the primary projection beside it, the precise pass IS the step's critical chain and goes
         # first: 2.529-2.549 against 2.565-2.586 ms (four alternating rounds).  EGK_ENABLE=precise_late_fork: the old order.
-        import os
         late = on_side and "precise_late_fork" in os.environ.get("EGK_ENABLE", "")
         if self._precise_on() and not late:
             if on_side:

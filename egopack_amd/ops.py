@@ -967,6 +967,10 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
     if (not items and not extra and not riders) or (_on_excluded_stream() and not force):  # (a head stream never issues what others parked)
         return
     _wq["items"], _wq["hold"], _wq["extra"], _wq["tiles"], _wq["riders"] = [], [], [], 0, []
+    rng = _last_wgrad["tail"]
+    if rng is not None and (any(rng[0] <= it[0][7].data_ptr() < rng[1] for it in items)
+                            or any(rng[0] <= e[1].data_ptr() < rng[1] or rng[0] <= e[2].data_ptr() < rng[1] for e in extra)):
+        _last_wgrad["leaked"] = True  # (a gradient of the tail range leaves for the side stream: see last_wgrad_tail_on_backward_stream)
 
     def launch():
         for fn in riders:
@@ -992,7 +996,7 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
     _wgrad_launch(True, hold, launch, in_backward)
 
 
-_last_wgrad = {"param": None, "hook": None, "inline": True, "tail": None}
+_last_wgrad = {"param": None, "hook": None, "inline": True, "tail": None, "leaked": False}
 
 
 def set_last_wgrad_tail(lo_ptr: int, hi_ptr: int) -> None:
@@ -1003,6 +1007,15 @@ def set_last_wgrad_tail(lo_ptr: int, hi_ptr: int) -> None:
     gradients as a group of their own 66 us; the three in one launch 123 us (tools/exp/tail_group_bench.py).
     (0, 0): only the last weight gradient itself (the default)."""
     _last_wgrad["tail"] = (int(lo_ptr), int(hi_ptr)) if hi_ptr > lo_ptr else None
+    _last_wgrad["leaked"] = False
+
+
+def last_wgrad_tail_on_backward_stream() -> bool:
+    """Every gradient of the tail range (``set_last_wgrad_tail``) was issued on the BACKWARD stream: no parked problem or reduction
+    of the range left with an earlier flush for the side stream, no weight gradient of the range was launched there directly.  The
+    optimizer slice over the range may then follow the last weight gradient on the backward stream without waiting for the side
+    stream's queue (engine.StepBase: the step's tail)."""
+    return _last_wgrad["tail"] is not None and not _last_wgrad["leaked"]
 
 
 def _take_tail_items():
@@ -1210,6 +1223,9 @@ class _Linear(torch.autograd.Function):
                 if tail_extra:
                     _launch_reductions(tail_extra)
             elif not (in_place and not last and ctx.compute in (BF16, F32) and _wgrad_defer(dw_args, dw_kw, (g, x))):
+                rng = _last_wgrad["tail"]
+                if rng is not None and not last and rng[0] <= out.data_ptr() < rng[1]:
+                    _last_wgrad["leaked"] = True  # (launched below on the side stream)
                 for it in tail_items:  # (not eligible after all: issue what was taken, in order)
                     gemm(*it[0], **it[1])
                 if tail_extra:

@@ -12,8 +12,12 @@ ev.sort()
 # replays are delimited by the Adam kernel (one per step, the last kernel of a replay)
 # (a captured step may issue Adam in several launches: early slices beside the last weight gradient, then the rest --
 #  the step ends with the last Adam launch of such a group)
+#  the step ends with the last Adam launch of such a group; a slice may also run in the MIDDLE of backward (GraphONE's), so the
+#  launches per step are counted against the one hyper-parameter launch every step has, and the ends are taken from the back)
 adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[3]]
-ends = [i for i in adam if not any("adam_kernel" in ev[j][3] for j in range(i + 1, min(i + 4, len(ev))))]
+hyper = sum(1 for e in ev if "adam_hyper_kernel" in e[3])
+per = max(1, round(len(adam) / hyper)) if hyper else 1
+ends = adam[::-1][::per][::-1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 hi = ends[-back]
 lo = ends[-back - 1] + 1
