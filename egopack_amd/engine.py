@@ -796,9 +796,11 @@ class StepBase:
                 #  ``join_wgrad(force=True)`` -- and the late optimizer slices before it, see ``tail_first``)
                 tail_opt = any(k in os.environ.get("EGK_ENABLE", "") for k in ("tail_adam_first", "graphone_adam_on_main"))
                 prev_h = ops.set_wgrad_handoff(True) if (tail_opt and early is not None and not getattr(self, "_handoff", False)) else None
+                self._early = early
                 try:
                     total, vectors = self._backward_pass(batches, merged)
                 finally:
+                    self._early = None
                     if prev_h is not None:
                         ops.set_wgrad_handoff(prev_h)
                 self._join_zero()  # (a backward path that did not: the memset must at least precede the optimizer)
@@ -1415,6 +1417,35 @@ class MTLStep(StepBase):
     def _early_adam_ok(self) -> bool:  # the heads are joined into the main stream before the backbone's backward starts
         return bool(self.early_adam and self.headwise_backward)
 
+    def _heads_adam_slice(self) -> None:
+        """OPT-IN (EGK_ENABLE=heads_adam), captured step with an early optimizer plan: the heads' gradients are final when their
+        parked weight gradients have been flushed -- Adam over their slice of the flat buffers runs beside the backbone's backward
+        instead of in the step's tail (what EgoPackStep does for GraphONE's slice).  Measured on the headline: 1.411-1.419 against
+        1.395-1.398 ms (three alternating rounds) -- the memory-bound launch slows the dX chain by more than the tail gains, as the
+        larger slice did in round 3; not kept as a default."""
+        early = getattr(self, "_early", None)
+        if early is None or early["fired"] or "heads_adam" not in os.environ.get("EGK_ENABLE", ""):
+            return
+        opt = self.optimizer
+        params = [p for t in self.enabled for p in self.tasks[t].parameters() if p.requires_grad and id(p) in opt._slot_of]
+        if not params:
+            return
+        h0, h1 = opt.region_of(params)
+        if not (h1 > h0 and h0 % 8 == 0 and h1 % 8 == 0 and sum(opt._slot_of[id(p)][1] for p in params) == h1 - h0
+                and (h1 <= early["lo"] or h0 >= early["hi"])):
+            return
+        main = torch.cuda.current_stream()
+
+        def issue(ev):  # (behind the backward stream's next launch, i.e. behind the flush above)
+            side = ops.wgrad_side_stream(main)
+            early["stream"].wait_event(ev)
+            if side is not None:
+                early["stream"].wait_stream(side)
+            with torch.cuda.stream(early["stream"]):
+                opt.launch(None, h0, h1)
+        ops.defer_after_next_launch(issue)
+        early.setdefault("done", []).append((h0, h1))
+
     def _backward_pass(self, batches, merged=None):
         if not self.headwise_backward:
             return super()._backward_pass(batches, merged)
@@ -1429,6 +1460,7 @@ class MTLStep(StepBase):
             # links of the backbone's dX chain; left parked, the backbone's first weight gradient would flush nine problems
             # as 8 + 1
             ops.flush_wgrad(in_backward=False, force=True)
+            self._heads_adam_slice()
         order = [t for t in feats if leaves[t].grad is not None]
         torch.autograd.backward([feats[t] for t in order], [leaves[t].grad for t in order])
         return total, vectors
@@ -1649,6 +1681,7 @@ class EgoPackStep(StepBase):
                 aux_in = (dict(zip(others, grouped)) if grouped is not None
                           else {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others})
         aux, closest = self.graphone.interact(aux_in)
+        ops.stamp("stages_done")
         if (primary == "oscc" and getattr(task, "loss_func", None) == "ce" and hasattr(task, "fused_head_loss") and data.y.dim() == 1
                 and "oscc_one_pass" not in getattr(self, "_dev_off", ()) and "rowdot_head" not in getattr(self, "_dev_off", ())):
             # the four 2-logit classifiers (primary + one per auxiliary task) behind their max pools, the logit fusion, the loss and
@@ -1692,7 +1725,9 @@ class EgoPackStep(StepBase):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     precise = self.precise_aux_features(batches, merged, rng_snap=snap)
+                    ops.stamp("precise_done")
                     self._search_ahead(precise)
+                    ops.stamp("search_done")
             else:
                 precise = self.precise_aux_features(batches, merged, rng_snap=snap)
         import contextlib
@@ -1720,8 +1755,10 @@ class EgoPackStep(StepBase):
         f_prim = {}
         if side is not None and len(feats) == 1 and "primary_early" not in getattr(self, "_dev_off", ()):
             f_prim = {t: self.tasks[t].forward_features(f) for t, f in feats.items()}
+        ops.stamp("train_fwd_done")
         if side is not None:
             main.wait_stream(side)
+            ops.stamp("precise_joined")
             for d in precise.values():
                 for a in d.values():
                     a.record_stream(main)

@@ -973,6 +973,7 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
         _last_wgrad["leaked"] = True  # (a gradient of the tail range leaves for the side stream: see last_wgrad_tail_on_backward_stream)
 
     def launch():
+        stamp("wgrad_flush", seq=True)  # (on the side stream: when this flush's launches can start)
         for fn in riders:
             fn()
         for i in range(0, len(items), 8):
@@ -993,6 +994,7 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
                 gemm_grouped(chunk, four_wave=len(chunk) <= 4 and "wg4" not in os.environ.get("EGK_DISABLE", ""))
         if extra:
             _launch_reductions(extra)
+        stamp("wgrad_flush_end", seq=True)
     _wgrad_launch(True, hold, launch, in_backward)
 
 
