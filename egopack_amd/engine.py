@@ -1638,14 +1638,23 @@ class EgoPackStep(StepBase):
         return [t for t in self.AUX_ORDER[primary] if t in self.graphone.task_labels]
 
     @torch.no_grad()
-    def precise_aux_features(self, batches, merged=None, rng_snap=None):
-        """{primary: {aux task: f32 [N, H]}}: the auxiliary projections of every enabled task batch from the 'bf16x3' pass."""
+    def precise_aux_features(self, batches, merged=None, rng_snap=None, tape=None, after_backbone=None):
+        """{primary: {aux task: f32 [N, H]}}: the auxiliary projections of every enabled task batch from the 'bf16x3' pass.
+        ``tape`` (a list): the backbone's nodes leave their results in it (ops.dual_record) for the one-pass step;
+        ``after_backbone()``: called when the backbone's launches have been issued."""
         opt = self.optimizer
         live = [t for t in self.enabled if batches.get(t) is not None]
         with ops.precise_scope(), ops.rng_replay(ops.rng_snapshot() if rng_snap is None else rng_snap):
             if getattr(opt, "materialised", False):
                 opt.refresh_lo_shadows(list(self.model.parameters()))  # the backbone's low halves: one launch
-            feats = self.features(batches, merged)
+            if tape is not None:
+                with ops.dual_record() as rec:
+                    feats = self.features(batches, merged)
+                tape.extend(rec)
+            else:
+                feats = self.features(batches, merged)
+            if after_backbone is not None:
+                after_backbone()
             out = {}
             for t in live:
                 others = self._aux_names(t)
@@ -1655,6 +1664,25 @@ class EgoPackStep(StepBase):
                 out[t] = (dict(zip(others, grouped)) if grouped is not None
                           else {o: self.tasks[o].forward_features(feats[t], out_f32=True) for o in others})
         return out
+
+    one_pass = True  # the bf16 training graph from the precise pass's results instead of a second backbone pass (see _one_pass_ok)
+
+    def _one_pass_ok(self, batches, merged) -> bool:
+        """ONE backbone pass per step (ops.dual_record / dual_replay) applies: a single task batch with bf16 features, gradients
+        through the backbone, no active dropout in it (the keep masks of the two passes would have to be shared), statistics
+        local to the rank.  EGK_DISABLE=one_pass: the two-pass step of rounds 3-5."""
+        if not (self.one_pass and self.backprop) or "one_pass" in os.environ.get("EGK_DISABLE", "") or "one_pass" in getattr(self, "_dev_off", ()):
+            return False
+        live = [batches[t] for t in self.enabled if batches.get(t) is not None]
+        if len(live) != 1 or isinstance(live[0].x, (list, tuple)) or live[0].x.dtype != torch.bfloat16 or ops.graph_ln_exchange_on():
+            return False
+        if ops.get_compute() != "bf16" or getattr(self.model, "stage_cut", None) is not None:
+            return False
+        drops = [m for m in self.model.modules() if type(m).__name__ == "Dropout" or isinstance(m, torch.nn.Dropout)]
+        if self.model.training and any(getattr(m, "p", 0) > 0 for m in drops):
+            return False
+        tp = getattr(self.model, "temporal_pooling", None)
+        return not (self.model.training and float(getattr(tp, "dropout", 0) or 0) > 0)
 
     def _search_ahead(self, precise) -> None:
         """The prototype searches of the coming ``GraphONE.interact`` calls on the CURRENT stream (the precise pass's): they need
@@ -1705,6 +1733,7 @@ class EgoPackStep(StepBase):
         self.graphone.train()
         snap = ops.rng_snapshot()
         precise, side = {}, None
+        tape, gate_ev = None, {}
         first = next((b for b in batches.values() if b is not None), None)
         on_side = (self._precise_on() and self.precise_stream and first is not None and first.pos.is_cuda
                    and "precise_stream" not in getattr(self, "_dev_off", ()))
@@ -1723,8 +1752,19 @@ class EgoPackStep(StepBase):
                     ops.exclude_wgrad_streams([self._precise_side])
                 side = self._precise_side
                 side.wait_stream(main)
+                gate = os.environ.get("EGK_TRAIN_AFTER", "")  # (development: the training pass starts behind this phase of the precise pass)
+                gate_ev = {}
+                if gate:
+                    ops.phase_callbacks({gate: lambda: gate_ev.setdefault("ev", side.record_event())})
+                tape = [] if self._one_pass_ok(batches, merged) else None
                 with torch.cuda.stream(side):
-                    precise = self.precise_aux_features(batches, merged, rng_snap=snap)
+                    try:
+                        precise = self.precise_aux_features(
+                            batches, merged, rng_snap=snap, tape=tape,
+                            after_backbone=(lambda: gate_ev.__setitem__("backbone", side.record_event())) if tape is not None else None)
+                    finally:
+                        if gate:
+                            ops.phase_callbacks(None)
                     ops.stamp("precise_done")
                     self._search_ahead(precise)
                     ops.stamp("search_done")
@@ -1736,8 +1776,24 @@ class EgoPackStep(StepBase):
             main = torch.cuda.current_stream()
             fork_ev = main.record_event()
         # (the two passes draw the same dropout offsets: same keep masks when the backbone is in train mode)
-        with (ops.rng_replay(snap) if self._precise_on() else contextlib.nullcontext()), torch.set_grad_enabled(self.backprop):
-            feats = self.features(batches, merged)
+        if side is not None and "serial_precise" in os.environ.get("EGK_DBG", ""):  # (measurement: the two passes one after the other)
+            torch.cuda.current_stream().wait_stream(side)
+        if side is not None and not late and gate_ev.get("ev") is not None:
+            torch.cuda.current_stream().wait_event(gate_ev["ev"])
+        tape = tape if (side is not None and not late) else None
+        if tape:
+            # ONE backbone pass: the training graph is built from the precise pass's taped results (ops.dual_replay) -- its nodes
+            # launch roundings, no contractions -- behind the precise backbone, beside its auxiliary projections and the searches
+            cur = torch.cuda.current_stream()
+            for _, ts in tape:  # (every node of the replay waits for its own taped node: ops._tape_take)
+                for t in ts.values():
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)
+            with ops.dual_replay(tape), torch.set_grad_enabled(self.backprop):
+                feats = self.features(batches, merged)
+        else:
+            with (ops.rng_replay(snap) if self._precise_on() else contextlib.nullcontext()), torch.set_grad_enabled(self.backprop):
+                feats = self.features(batches, merged)
         if late:
             # the precise pass is CREATED after the training pass's forward chain although it forks from before it: under
             # capture the branch created first keeps the launch queue, and created first the precise pass (700 us of launches)

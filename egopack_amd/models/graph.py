@@ -115,5 +115,6 @@ class Graph(torch.nn.Module):
             c = ops.sage_mean_layer(h, conv, graph, ln_out=req, ln_in=ln_prev, res_src=res if d == 0 else None)
             h, ln_prev = norm(c, seg_ptr, slope, partials=req.get("partials") if req else None, min_seg_rows=min_rows,
                               return_ctx=True)                # SAGEConv -> graph-LN -> LeakyReLU
+            ops.stamp("fwd_sage", seq=True)
         last = getattr(self.net, f"module_{3 * self.depth}")
         return last(h, residual=x, ln_in=ln_prev, res_sink=res)  # x + Linear(h): residual in the epilogue

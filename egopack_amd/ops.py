@@ -1126,6 +1126,88 @@ def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 # ---- Linear (two-source, fused bias / ReLU / residual) ----------------------------------------------
+# ---- one forward pass for two consumers: the precise (three-product) values AND a bf16 autograd graph ---------------------------
+# EgoPack's novel-task step needs the backbone twice: f32-grade features for the prototype search (an index op), and a bf16
+# training graph for backward.  ``dual_record()`` tapes the results of the backbone's nodes while the PRECISE pass runs (no
+# gradient); ``dual_replay(tape)`` then builds the bf16 graph by calling the same forward code, in which every node takes the
+# rounding of the taped result (and the taped statistics) instead of launching its kernels: what backward saves are the bf16
+# roundings of the precise activations, the forward VALUES are the precise ones.  Nodes: _Linear, _RowLN, _PEAdd, _SageMean, _GraphLN
+# (what models.Graph.forward with a TRN pooling issues); the sequences of the two passes must agree node by node (checked).
+_dual = {"tape": None, "replay": None}
+
+
+class dual_record:
+    """``with ops.dual_record() as tape:`` -- inside (the precise pass), the taped nodes append their results to ``tape``."""
+
+    def __enter__(self):
+        self.prev = _dual["tape"]
+        _dual["tape"] = tape = []
+        return tape
+
+    def __exit__(self, *exc):
+        _dual["tape"] = self.prev
+        return False
+
+
+class dual_replay:
+    """``with ops.dual_replay(tape):`` -- inside (the bf16 pass, gradients on), the taped nodes take their results from ``tape``."""
+
+    def __init__(self, tape):
+        self.tape = list(tape)
+
+    def __enter__(self):
+        self.prev = _dual["replay"]
+        _dual["replay"] = self.tape
+        return self
+
+    def __exit__(self, et, ev, tb):
+        left = len(self.tape)
+        _dual["replay"] = self.prev
+        if et is None and left:
+            raise RuntimeError(f"dual_replay: {left} taped node(s) were not consumed: the two passes issued different node sequences")
+        return False
+
+
+def _tape_put(kind: str, **tensors) -> None:
+    """(precise pass) the results of one node; for every f32 matrix whose producer also stored its bf16 halves (the split tee, or a
+    split some contraction asked for since) the high half rides along as '<name>:hi' -- the replay then needs no rounding launch --
+    and an event of the producing stream, so that the replay of THIS node can run as soon as the node has."""
+    if _dual["tape"] is None:
+        return
+    cache = _x3["cache"]
+    if cache is not None:
+        for k, t in list(tensors.items()):
+            if t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous():
+                hit = cache.get((t.data_ptr(), t.shape[0], t.shape[1], t.shape[1], t._version))
+                if hit is not None:
+                    tensors[k + ":hi"] = hit[0]
+    tensors["@event"] = torch.cuda.current_stream().record_event() if next(iter(tensors.values())).is_cuda else None
+    _dual["tape"].append((kind, tensors))
+
+
+def _tape_take(kind: str, like: torch.Tensor):
+    """The taped results of the next node (None outside a replay); ``like``: the node's bf16 input -- shape / type guard."""
+    rp = _dual["replay"]
+    if rp is None:
+        return None
+    if not rp:
+        raise RuntimeError(f"dual_replay: a '{kind}' node has no taped counterpart")
+    k, t = rp.pop(0)
+    if k != kind or like.dtype != torch.bfloat16:
+        raise RuntimeError(f"dual_replay: node '{kind}' ({like.dtype}) met the taped '{k}': the two passes disagree")
+    ev = t.get("@event")
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+    return t
+
+
+def _r16(taped, name: str) -> torch.Tensor:
+    """bf16 rounding (nearest-even: the 'hi' half of the three-product split) of the taped f32 result ``name``: the half its
+    producer stored, or one rounding launch."""
+    hi = taped.get(name + ":hi")
+    return hi if hi is not None else cast_raw(_c(taped[name]), torch.bfloat16)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32, ln_in=None, res_sink=None):
@@ -1142,12 +1224,20 @@ class _Linear(torch.autograd.Function):
             K2 = x2.shape[1]
             W2op = weight_operand(W2, x.dtype)
         res = _c(residual) if residual is not None else None
-        if out_f32 and N % 8:  # logits: pad the row stride so the loss gradient is a 16-byte aligned operand
-            y = torch.empty((M, _pad8(N)), dtype=torch.float32, device=x.device)[:, :N]
+        taped = _tape_take("linear", x) if not out_f32 else None
+        if taped is not None:
+            y = _r16(taped, "y")
+            if tuple(y.shape) != (M, N):
+                raise RuntimeError("dual_replay: a taped linear result has another shape")
         else:
-            y = torch.empty((M, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-        gemm(M, N, x, K1, Wop, K1, K1, y, y.stride(0), A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2,
-             bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
+            if out_f32 and N % 8:  # logits: pad the row stride so the loss gradient is a 16-byte aligned operand
+                y = torch.empty((M, _pad8(N)), dtype=torch.float32, device=x.device)[:, :N]
+            else:
+                y = torch.empty((M, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+            gemm(M, N, x, K1, Wop, K1, K1, y, y.stride(0), A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2,
+                 bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
+            if not out_f32:
+                _tape_put("linear", y=y)
         ctx.relu, ctx.compute = relu, compute
         ctx.ln_in = ln_in if (x2 is None and not relu) else None
         ctx.res_sink = res_sink if residual is not None else None
@@ -1955,11 +2045,17 @@ class _RowLN(torch.autograd.Function):
         seed, off = _next_rng(rows * max(cols, 4096)) if p_eff > 0 else (0, 0)
         wc, bc = _f32c(w), _f32c(b)
         dev_off = _p(rng_device_offset(x.device)) if p_eff > 0 else None
-        tee = _tee_arm(y)
-        _ck(lib.egk_rowln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(mean), _p(rstd), _p(mask), rows, cols, eps,
-                              int(relu), p_eff, seed, off, dev_off, _dt(x)),
-            "egk_rowln_fwd")
-        _tee_done(y, tee)
+        taped = _tape_take("rowln", x) if p_eff == 0 else None
+        if taped is not None:
+            y, mean, rstd = _r16(taped, "y"), taped["mean"], taped["rstd"]
+        else:
+            tee = _tee_arm(y)
+            _ck(lib.egk_rowln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(mean), _p(rstd), _p(mask), rows, cols, eps,
+                                  int(relu), p_eff, seed, off, dev_off, _dt(x)),
+                "egk_rowln_fwd")
+            _tee_done(y, tee)
+            if p_eff == 0:
+                _tape_put("rowln", y=y, mean=mean, rstd=rstd)
         ctx.relu, ctx.p = relu, p_eff
         ctx.params = (w, b)
         ctx.save_for_backward(x, wc, bc, mean, rstd, mask)
@@ -2084,7 +2180,12 @@ class _GraphLN(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty(n_seg * 2, dtype=torch.float32, device=x.device)
         wc, bc = _f32c(w), _f32c(b)
-        if _ln_exchange["fn"] is not None:  # exact cross-rank statistics: local sums -> sum over ranks -> normalise
+        taped = _tape_take("graphln", x) if _ln_exchange["fn"] is None else None
+        if taped is not None:
+            y, stats = _r16(taped, "y"), taped["stats"]
+            if stats.numel() != n_seg * 2:
+                raise RuntimeError("dual_replay: taped graph LayerNorm statistics have another segment count")
+        elif _ln_exchange["fn"] is not None:  # exact cross-rank statistics: local sums -> sum over ranks -> normalise
             nb = lib.egk_graphln_stats_blocks(rows)
             loc = torch.empty(nb * n_seg * 2, dtype=torch.float64, device=x.device)
             _ck(lib.egk_graphln_stats(_stream(), _p(x), _p(seg_ptr), n_seg, rows, cols, _p(loc), _dt(x)), "egk_graphln_stats")
@@ -2103,6 +2204,8 @@ class _GraphLN(torch.autograd.Function):
             _ck(lib.egk_graphln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
                                     slope, _p(ws), _dt(x)), "egk_graphln_fwd")
             _tee_done(y, tee)
+        if taped is None and _ln_exchange["fn"] is None:
+            _tape_put("graphln", y=y, stats=stats)
         ctx.eps, ctx.slope = eps, slope
         ctx.params = (w, b)
         ctx.lnctx = lnctx
@@ -2237,6 +2340,9 @@ class _PEAdd(torch.autograd.Function):
             fid = _pe_freq_id(freq)
             table = _pe_table(freq, fid, pos_range[0], n_pos, cols) if fid is not None else None
         posc, fr = pos.contiguous(), _f32c(freq)
+        taped = _tape_take("pe_add", x)
+        if taped is not None:
+            return _r16(taped, "y")
         tee = _tee_arm(y)
         if table is not None:
             _ck(lib.egk_pe_add_table(_stream(), _p(x), _p(posc), _p(fr), _p(table), int(pos_range[0]), int(n_pos),
@@ -2244,6 +2350,7 @@ class _PEAdd(torch.autograd.Function):
         else:
             _ck(lib.egk_pe_add(_stream(), _p(x), _p(posc), _p(fr), _p(y), rows, cols, _dt(x)), "egk_pe_add")
         _tee_done(y, tee)
+        _tape_put("pe_add", y=y)
         return y
 
     @staticmethod
@@ -2333,21 +2440,31 @@ class _SageMean(torch.autograd.Function):
         # the mean over the in-neighbours of xp inside the projection's epilogue when no edge leaves an output tile (32-node
         # sequences never do): the gather launch and its re-read of xp disappear
         p_args, p_kw = (N, H, h, H, Wp_o, H, H, xp, H), dict(bias=_f32c(bp), act=1, compute=compute)
-        if not (tile_mask and gemm_with_gather(p_args, p_kw, dict(mode=1, tile_mask=tile_mask, rowptr=rowptr, col=col, band=band,
-                                                                    out=agg))):
-            gemm(*p_args, **p_kw)
-            _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode, band)
-        ctx.t_heavy_mode, ctx.tile_mask = t_heavy_mode, tile_mask
+        taped = _tape_take("sage_mean", h)
         Ho = Wl.shape[0]
-        out = torch.empty((N, Ho), dtype=dt, device=h.device)
-        c_args = (N, Ho, agg, H, Wl_o, H, H, out, Ho)
-        c_kw = dict(A2=h, lda2=H, B2=Wr_o, ldb2=H, K2=H, bias=_f32c(bl), compute=compute)
-        if ln_out is not None and _ln_fusion["on"]:
-            # the graph LayerNorm that follows needs (sum, sum of squares) per row segment of ``out``: taken in this epilogue
-            ln_out["partials"] = _gemm_with_stats(c_args, c_kw, dict(mode=1, seg_ptr=ln_out["seg_ptr"], n_seg=ln_out["n_seg"],
-                                                                     min_rows=ln_out["min_rows"]))
+        if taped is not None:
+            xp, agg, out = _r16(taped, "xp"), _r16(taped, "agg"), _r16(taped, "out")
+            if tuple(out.shape) != (N, Ho):
+                raise RuntimeError("dual_replay: a taped SAGE layer result has another shape")
+            if ln_out is not None:
+                ln_out["partials"] = None  # (the graph LayerNorm that follows takes the taped statistics)
+            ctx.t_heavy_mode, ctx.tile_mask = t_heavy_mode, tile_mask
         else:
-            gemm(*c_args, **c_kw)
+            if not (tile_mask and gemm_with_gather(p_args, p_kw, dict(mode=1, tile_mask=tile_mask, rowptr=rowptr, col=col, band=band,
+                                                                        out=agg))):
+                gemm(*p_args, **p_kw)
+                _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode, band)
+            ctx.t_heavy_mode, ctx.tile_mask = t_heavy_mode, tile_mask
+            out = torch.empty((N, Ho), dtype=dt, device=h.device)
+            c_args = (N, Ho, agg, H, Wl_o, H, H, out, Ho)
+            c_kw = dict(A2=h, lda2=H, B2=Wr_o, ldb2=H, K2=H, bias=_f32c(bl), compute=compute)
+            if ln_out is not None and _ln_fusion["on"]:
+                # the graph LayerNorm that follows needs (sum, sum of squares) per row segment of ``out``: taken in this epilogue
+                ln_out["partials"] = _gemm_with_stats(c_args, c_kw, dict(mode=1, seg_ptr=ln_out["seg_ptr"], n_seg=ln_out["n_seg"],
+                                                                         min_rows=ln_out["min_rows"]))
+            else:
+                gemm(*c_args, **c_kw)
+            _tape_put("sage_mean", xp=xp, agg=agg, out=out)
         ctx.ln_in, ctx.res_src = ln_in, res_src
         ctx.compute, ctx.params = compute, (Wp, bp, Wl, bl, Wr)
         ctx.save_for_backward(h, xp, agg, Wp_o, Wl_o, Wr_o, t_rowptr, t_col, t_wgt, t_heavy)
@@ -3479,6 +3596,14 @@ def stamps_enable(device="cuda", slots: int = 256):
 def stamp(name: str, seq: bool = False):
     """``seq``: the name gets a running index per step (reset by stamp("step_start")): stamps inside autograd nodes that
     run once per layer."""
+    cb = _stamps.get("callbacks")
+    if cb:
+        k = _stamps.setdefault("cb_seq", {}).get(name, 0) if seq else None
+        if seq:
+            _stamps["cb_seq"][name] = k + 1
+        fn = cb.get(f"{name}[{k}]" if seq else name)
+        if fn is not None:
+            fn()
     buf = _stamps["buf"]
     if buf is None:
         return
@@ -3495,6 +3620,13 @@ def stamp(name: str, seq: bool = False):
         names.append(name)
         idx = len(names) - 1
     _ck(_lib.load().egk_stamp(_stream(), _p(buf), idx), "egk_stamp")
+
+
+def phase_callbacks(callbacks) -> None:
+    """``{phase name: fn}`` (or None): ``fn()`` runs where the forward / backward code marks that phase with ``stamp(name)`` -- the
+    engine records stream events at phases of one pass to order another pass behind them.  Sequence counters restart here."""
+    _stamps["callbacks"] = dict(callbacks) if callbacks else None
+    _stamps["cb_seq"] = {}
 
 
 def stamps_read():
