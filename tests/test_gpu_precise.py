@@ -354,3 +354,47 @@ def test_adam_launch_keeps_the_low_halves_of_the_weight_operands():
     assert torch.equal(opt.flat_w16lo, want_lo)
     opt.refresh_shadows()
     assert not opt._lo_is_fresh(0, 8)
+
+
+def test_one_pass_backbone_graph_from_the_precise_passs_tape(ops):
+    """ops.dual_record / dual_replay on Graph.forward (TRN pooling, three SAGE layers): the replayed bf16 graph's output IS the
+    rounding of the precise pass's output, every taped node is consumed, the backward of the replayed graph gives the gradients of
+    the plain bf16 pass up to bf16 noise, and a replay against another node sequence is refused."""
+    from egopack_amd import data as D
+    from egopack_amd.models import Graph
+    torch.manual_seed(12)
+    F_IN, S, H = 64, 3, 256
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": H}
+    model = Graph(F_IN, hidden_size=H, depth=3, temporal_pooling=trn, num_segments=S).to(DEV).eval()
+    ds = D.SyntheticTaskDataset("ar", 8, 16, S, F_IN, (13, 17), k=1, seed=5)
+    host = D.collate([ds[i] for i in range(8)])
+    host.x = host.x.to(torch.bfloat16)
+    dev = host.to(DEV)
+    w = torch.randn(dev.pos.shape[0], H, device=DEV)
+    with ops.compute_mode("bf16"):
+        with torch.no_grad(), ops.precise_scope(), ops.dual_record() as tape:
+            f32 = model(dev)
+        kinds = [k for k, _ in tape]
+        assert kinds == ["linear", "rowln", "linear", "rowln", "linear", "pe_add"] + ["sage_mean", "graphln"] * 3 + ["linear"], kinds
+        with ops.dual_replay(tape):
+            f16 = model(dev)
+        assert f16.dtype == torch.bfloat16 and f16.requires_grad and torch.equal(f16, f32.to(torch.bfloat16))
+        (f16.float() * w).sum().backward()
+        got = {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+        model.zero_grad()
+        plain = model(dev)
+        (plain.float() * w).sum().backward()
+        want = {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+        with pytest.raises(RuntimeError, match="dual_replay"):
+            with ops.dual_replay(tape[1:]):
+                model(dev)
+    model.zero_grad()
+    dev.x = dev.x.float()
+    with ops.compute_mode("f32"):
+        (model(dev) * w).sum().backward()
+    ref = {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+    assert _rel(plain.detach().float().cpu(), f32.cpu()) > _rel(f16.detach().float().cpu(), f32.cpu())
+    for k in ref:  # no further from the exact-f32 gradients than the plain bf16 pass is (both carry bf16 rounding in backward)
+        if float(ref[k].norm()) > 1e-6:
+            e1, e0 = _rel(got[k].cpu(), ref[k].cpu()), _rel(want[k].cpu(), ref[k].cpu())
+            assert e1 < max(1.25 * e0, 2e-2), (k, e1, e0)

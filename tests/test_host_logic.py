@@ -528,3 +528,24 @@ def test_live_label_rows_of_a_multi_head_label_tensor():
         assert (getattr(b, "live_idx", None) is not None) == want, task
         if want:
             assert b.live_idx[:4].tolist() == [8, 24, 40, 56] and b.live_inv.shape == (64,) and torch.equal(b.live_y[:4], b.y[b.live_idx[:4]])
+
+
+def test_dual_replay_refuses_a_tape_that_was_not_consumed():
+    """ops.dual_record / dual_replay (the one-pass EgoPack step): the recording scope restores the previous tape, and a replay
+    that leaves taped nodes behind -- the two passes issued different node sequences -- is an error, not a silent mismatch."""
+    import pytest
+    from egopack_amd import ops
+    with ops.dual_record() as tape:
+        assert ops._dual["tape"] is tape
+        with ops.dual_record() as inner:
+            assert ops._dual["tape"] is inner
+        assert ops._dual["tape"] is tape
+    assert ops._dual["tape"] is None
+    with pytest.raises(RuntimeError, match="not consumed"):
+        with ops.dual_replay([("linear", {})]):
+            pass
+    assert ops._dual["replay"] is None
+    with pytest.raises(ValueError):  # (an exception inside the scope is not masked by the left-over check)
+        with ops.dual_replay([("linear", {})]):
+            raise ValueError("x")
+    assert ops._dual["replay"] is None
