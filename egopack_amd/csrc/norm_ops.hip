@@ -254,6 +254,196 @@ __global__ __launch_bounds__(256) void rowln_bwd_group_kernel(const T* __restric
                                 blockIdx.x, gridDim.x, (long long)g * gridDim.x + blockIdx.x);
 }
 
+
+// ---- wide rows (1024 < cols <= 4096, cols a multiple of 1024: the shipped temporal pooling's hidden width 4096) ------------------
+// One wave per row holds a 4096-column row as 16 float4 per lane -- with the affine rows and, backward, the two column-partial rows
+// that is 256-384 registers per lane: one wave per SIMD, spills, a 150 MB backward pass at 270-380 us (profiles/r05 Hp = 4096
+// timeline: the two launches were 650 us of a 3.2 ms step).  Here a WORKGROUP takes a row: wave v holds columns
+// [v cols / 4, (v + 1) cols / 4) as NVW float4 per lane (NVW = cols / 1024 <= 4: the register budget of the 1024-column kernels), the
+// four waves' row sums meet through LDS (wave order: reproducible), two rows in flight per workgroup.  The column partials of
+// dw / db need no combining across waves: every wave owns its columns.  Same dropout mask bits as the one-wave kernel (the Philox
+// counter of a column group does not depend on who draws it).
+template <int NVW, typename T>
+__global__ __launch_bounds__(256) void rowln_fwd_wide_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, T* __restrict__ y,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             uint8_t* __restrict__ mask, int rows, float eps, int relu, float p,
+                                                             uint64_t seed, uint64_t offset, const uint64_t* __restrict__ dev_offset,
+                                                             const SplitTee tee) {
+    __shared__ float part[4][WPB];  // [row in flight x {sum, squares}][wave]
+    constexpr int cols = NVW * 1024, WCOLS = NVW * 256;
+    if (dev_offset) offset += dev_offset[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cw = wave * WCOLS;  // this wave's first column
+    Row<NVW> wv, bv;
+    load_row<NVW>(w + cw, WCOLS, true, lane, wv);
+    load_row<NVW>(b + cw, WCOLS, true, lane, bv);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    auto finish = [&](int row, Row<NVW>& r, float mu, float rs) {
+        if (threadIdx.x == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            const int c0 = cw + (i * 64 + lane) * 4;
+            uint4 rnd = make_uint4(0, 0, 0, 0);
+            // (the one-wave kernel's counter: row * (16 * 64) + column group, 16 = its float4 per lane for every width above 1024)
+            if (p > 0.f) rnd = philox4x32_10(offset + (uint64_t)row * (16 * 64) + (uint64_t)(c0 >> 2), seed);
+            uint32_t keep4 = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float o = (el(r.v[i], t) - mu) * rs * el(wv.v[i], t) + el(bv.v[i], t);
+                if (relu) o = fmaxf(o, 0.f);
+                if (p > 0.f) {
+                    const uint32_t rr = t == 0 ? rnd.x : t == 1 ? rnd.y : t == 2 ? rnd.z : rnd.w;
+                    const bool keep = u01(rr) >= p;
+                    o = keep ? o * inv_keep : 0.f;
+                    keep4 |= (keep ? 1u : 0u) << (8 * t);
+                }
+                el(r.v[i], t) = o;
+            }
+            if (p > 0.f) *reinterpret_cast<uint32_t*>(mask + (long long)row * cols + c0) = keep4;
+        }
+        store_row<NVW>(y + (long long)row * cols + cw, WCOLS, true, lane, r);
+        if (tee.lo) {
+#pragma unroll
+            for (int i = 0; i < NVW; ++i) tee4(tee, row, cw + (i * 64 + lane) * 4, cols, true, r.v[i]);
+        }
+    };
+    for (int row = blockIdx.x; row < rows; row += 2 * gridDim.x) {  // (block-uniform: the barriers below are met by all four waves)
+        const int row2 = row + gridDim.x;
+        const bool two = row2 < rows;
+        Row<NVW> r, r2;
+        load_row<NVW>(x + (long long)row * cols + cw, WCOLS, true, lane, r);
+        if (two) load_row<NVW>(x + (long long)row2 * cols + cw, WCOLS, true, lane, r2);
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+            if (two) s2 += (r2.v[i].x + r2.v[i].y) + (r2.v[i].z + r2.v[i].w);
+        }
+        s = wave_sum(s);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            part[0][wave] = s;
+            part[1][wave] = s2;
+        }
+        __syncthreads();
+        const float mu = (((part[0][0] + part[0][1]) + part[0][2]) + part[0][3]) / cols;
+        const float mu2 = (((part[1][0] + part[1][1]) + part[1][2]) + part[1][3]) / cols;
+        float q = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVW; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float d = el(r.v[i], t) - mu, d2 = el(r2.v[i], t) - mu2;
+                q += d * d;
+                if (two) q2 += d2 * d2;
+            }
+        q = wave_sum(q);
+        q2 = wave_sum(q2);
+        if (lane == 0) {
+            part[2][wave] = q;
+            part[3][wave] = q2;
+        }
+        __syncthreads();
+        const float rs = rsqrtf((((part[2][0] + part[2][1]) + part[2][2]) + part[2][3]) / cols + eps);
+        const float rs2 = rsqrtf((((part[3][0] + part[3][1]) + part[3][2]) + part[3][3]) / cols + eps);
+        finish(row, r, mu, rs);
+        if (two) finish(row2, r2, mu2, rs2);
+        __syncthreads();  // (the next pair of rows rewrites ``part``)
+    }
+}
+
+template <int NVW, typename T>
+__global__ __launch_bounds__(256) void rowln_bwd_wide_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const uint8_t* __restrict__ mask, T* __restrict__ dx,
+                                                             float* __restrict__ ws, int rows, int relu, float p) {
+    __shared__ float part[4][WPB];  // [row in flight x {s1, s2}][wave]
+    constexpr int cols = NVW * 1024, WCOLS = NVW * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cw = wave * WCOLS;
+    Row<NVW> wv, bv, dwp, dbp;
+    load_row<NVW>(w + cw, WCOLS, true, lane, wv);
+    load_row<NVW>(b + cw, WCOLS, true, lane, bv);
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) dwp.v[i] = dbp.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    // first half of a row: g <- dy * w (gated), xr <- x_hat, the column partials, this wave's (s1, s2)
+    auto head = [&](int row, Row<NVW>& g, Row<NVW>& xr, float& s1, float& s2) {
+        const float mu = mean[row], rs = rstd[row];
+        s1 = s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            const int c0 = cw + (i * 64 + lane) * 4;
+            uint32_t keep4 = 0x01010101u;
+            if (p > 0.f) keep4 = *reinterpret_cast<const uint32_t*>(mask + (long long)row * cols + c0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float xh = (el(xr.v[i], t) - mu) * rs;
+                float gg = el(g.v[i], t);
+                if (p > 0.f) gg = ((keep4 >> (8 * t)) & 1) ? gg * inv_keep : 0.f;
+                if (relu && !(xh * el(wv.v[i], t) + el(bv.v[i], t) > 0.f)) gg = 0.f;
+                el(dwp.v[i], t) += gg * xh;
+                el(dbp.v[i], t) += gg;
+                const float dxh = gg * el(wv.v[i], t);
+                s1 += dxh;
+                s2 += dxh * xh;
+                el(g.v[i], t) = dxh;
+                el(xr.v[i], t) = xh;
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+    };
+    auto tail = [&](int row, Row<NVW>& g, const Row<NVW>& xr, float s1, float s2) {
+        const float rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NVW; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) el(g.v[i], t) = rs * (el(g.v[i], t) - s1 - el(xr.v[i], t) * s2);
+        store_row<NVW>(dx + (long long)row * cols + cw, WCOLS, true, lane, g);
+    };
+    for (int row = blockIdx.x; row < rows; row += 2 * gridDim.x) {
+        const int row2 = row + gridDim.x;
+        const bool two = row2 < rows;
+        Row<NVW> g, xr, g2, xr2;
+        load_row<NVW>(dy + (long long)row * cols + cw, WCOLS, true, lane, g);
+        load_row<NVW>(x + (long long)row * cols + cw, WCOLS, true, lane, xr);
+        if (two) {
+            load_row<NVW>(dy + (long long)row2 * cols + cw, WCOLS, true, lane, g2);
+            load_row<NVW>(x + (long long)row2 * cols + cw, WCOLS, true, lane, xr2);
+        }
+        float a1, a2, b1 = 0.f, b2 = 0.f;
+        head(row, g, xr, a1, a2);
+        if (two) head(row2, g2, xr2, b1, b2);
+        if (lane == 0) {
+            part[0][wave] = a1;
+            part[1][wave] = a2;
+            part[2][wave] = b1;
+            part[3][wave] = b2;
+        }
+        __syncthreads();
+        const float t1 = (((part[0][0] + part[0][1]) + part[0][2]) + part[0][3]) / cols;
+        const float t2 = (((part[1][0] + part[1][1]) + part[1][2]) + part[1][3]) / cols;
+        const float u1 = (((part[2][0] + part[2][1]) + part[2][2]) + part[2][3]) / cols;
+        const float u2 = (((part[3][0] + part[3][1]) + part[3][2]) + part[3][3]) / cols;
+        tail(row, g, xr, t1, t2);
+        if (two) tail(row2, g2, xr2, u1, u2);
+        __syncthreads();
+    }
+    // this workgroup's partial rows: every wave owns its columns
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+        const int c = cw + (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(ws + ((long long)blockIdx.x * 2 + 0) * cols + c) = dwp.v[i];
+        *reinterpret_cast<float4*>(ws + ((long long)blockIdx.x * 2 + 1) * cols + c) = dbp.v[i];
+    }
+}
+
 // out_a[c] += sum_b ws[b][0][c]; out_b[c] += sum_b ws[b][1][c]   (fixed order)
 // The order (unchanged since round 1, so the bits are): sixteen row groups rg = 0 .. 15, group rg sums rows rg + 16 u + 128 j for
 // u = 0 .. 7 inside j = 0, 1, ...; the sixteen group sums are then added in group order.
@@ -932,6 +1122,20 @@ using namespace egk;
     }
 // NV (registers per lane) x T (activation element type)
 #define DISPATCH_NV(cols, dtype, ...) EGK_DISPATCH_T(dtype, DISPATCH_NV_(cols, __VA_ARGS__))
+// the workgroup-per-row kernels: cols = 2048 / 3072 / 4096
+#define DISPATCH_NVW_(cols, ...)                                   \
+    switch ((cols) / 1024) {                                       \
+        case 2: { constexpr int NVW = 2; __VA_ARGS__; } break;     \
+        case 3: { constexpr int NVW = 3; __VA_ARGS__; } break;     \
+        default: { constexpr int NVW = 4; __VA_ARGS__; } break;    \
+    }
+static int g_wide_rows = 1;  // development knob (egk_tune 7): 0 = the one-wave-per-row kernels for every width
+static inline bool wide_rows_ok(int cols, const void* in, const void* out, const float* w, const float* b, const uint8_t* mask, int dtype) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    (void)dtype;
+    return g_wide_rows && cols > 1024 && cols <= 4096 && cols % 1024 == 0 && al(in) && al(out) && al(w) && al(b) &&
+           (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0);
+}
 
 extern "C" {
 
@@ -942,6 +1146,7 @@ int egk_tune(int32_t key, int32_t value) {
     if (key == 3) { const int p = g_graph_rows_v2; g_graph_rows_v2 = value; return p; }  // graph_ops.hip: the rows1024.h kernels
     if (key == 5) { ::egk::set_zero_fill_blocks(value); return 0; }  // loss_optim.hip: workgroups of egk_zero_fill (0 = default)
     if (key == 6) { ::egk::set_adam_blocks(value); return 0; }       // loss_optim.hip: workgroup cap of the Adam launch (0 = default)
+    if (key == 7) { const int p = g_wide_rows; g_wide_rows = value; return p; }  // the workgroup-per-row LayerNorm kernels on / off
     return -1;
 }
 
@@ -983,6 +1188,13 @@ int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const floa
     ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
     const SplitTee tee = take_split_tee();
     EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_rowln_fwd: a split tee needs an f32 result");
+    if (wide_rows_ok(cols, x, y, w, b, mask, dtype)) {
+        const int grid = rows < 1536 ? rows : 1536;  // (six workgroups per CU: two rows in flight each)
+        EGK_DISPATCH_T(dtype, DISPATCH_NVW_(cols, hipLaunchKernelGGL((rowln_fwd_wide_kernel<NVW, T>), dim3(grid), dim3(256), 0, s, (const T*)x, w,
+                                                                    b, (T*)y, mean, rstd, mask, rows, eps, relu, p, seed, offset,
+                                                                    dev_offset, tee)));
+        return check_launch("egk_rowln_fwd");
+    }
     DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
                                                  (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset, tee));
     return check_launch("egk_rowln_fwd");
@@ -1055,9 +1267,15 @@ int egk_rowln_bwd(egk_stream_t stream, const void* dy, const void* x, const floa
     const int grid = row_grid(rows);
     {
         ProfScope prof(KID_ROWLN_BWD, s, 0, (dtype == EGK_BF16 ? 6.0 : 12.0) * rows * cols);
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_bwd_kernel<NV, T, FULL>), dim3(grid), dim3(256),
-                                                     WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, mean,
-                                                     rstd, mask, (T*)dx, ws, rows, cols, relu, p));
+        if (wide_rows_ok(cols, dy, dx, w, b, mask, dtype) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+            EGK_DISPATCH_T(dtype, DISPATCH_NVW_(cols, hipLaunchKernelGGL((rowln_bwd_wide_kernel<NVW, T>), dim3(grid), dim3(256), 0, s,
+                                                                        (const T*)dy, (const T*)x, w, b, mean, rstd, mask, (T*)dx, ws,
+                                                                        rows, relu, p)));
+        } else {
+            DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_bwd_kernel<NV, T, FULL>), dim3(grid), dim3(256),
+                                                         WPB * 2 * NV * 256 * sizeof(float), s, (const T*)dy, (const T*)x, w, b, mean,
+                                                         rstd, mask, (T*)dx, ws, rows, cols, relu, p));
+        }
     }
     if (dw || db) {
         ProfScope prof(KID_ROWLN_BWD_REDUCE, s, 0, 8.0 * grid * cols);

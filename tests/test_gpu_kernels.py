@@ -183,7 +183,7 @@ def test_multi_linear_matches_concatenation(ops):
 # ---------------------------------------------------------------------------------------------------------
 # normalisation
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rows,cols", [(37, 40), (64, 32), (130, 1024), (9, 4096), (5, 250)])
+@pytest.mark.parametrize("rows,cols", [(37, 40), (64, 32), (130, 1024), (9, 4096), (5, 250), (130, 2048), (70, 3072), (1031, 4096), (3, 1280)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_rowln_fwd_bwd(ops, rows, cols, relu):
     g = gen(rows * cols)
@@ -932,7 +932,7 @@ def test_linear_autograd_full_bf16(ops):
         torch.testing.assert_close(a.grad.float().cpu(), c.grad, rtol=2e-2, atol=6e-2)
 
 
-@pytest.mark.parametrize("rows,cols", [(37, 40), (130, 1024), (9, 4096)])
+@pytest.mark.parametrize("rows,cols", [(37, 40), (130, 1024), (9, 4096), (515, 4096), (66, 2048)])
 def test_rowln_bf16_activations(ops, rows, cols):
     g = gen(rows + cols + 1)
     x = r16(torch.randn(rows, cols, generator=g) * 2 + 0.3)
@@ -1949,3 +1949,39 @@ def test_segment_max_of_several_inputs_in_one_launch(ops, dtype, n_src, n_seg, T
     for i in range(n_src):
         assert torch.equal(ya[i], yb[i])
         assert torch.equal(a[i].grad, b[i].grad)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(1031, 4096), (64, 2048), (5, 3072)])
+def test_wide_row_layernorm_kernels_against_the_one_wave_kernels(ops, dt, rows, cols):
+    """Rows of 2048 / 3072 / 4096 columns (the shipped temporal pooling is 4096 wide, reference configs/model/temporal_pooling/
+    trn.yaml:3) run on workgroup-per-row kernels (egk_tune 7): the SAME dropout keep masks as the one-wave-per-row kernels (the
+    Philox counter of a column group does not depend on who draws it), outputs / input gradients equal up to the last bits of the
+    row statistics' summation order, parameter gradients up to the order the rows are summed in."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2 + 0.3).to(DEV).to(dt)
+    w, b = torch.randn(cols, generator=g).to(DEV), torch.randn(cols, generator=g).to(DEV)
+    wt = torch.randn(rows, cols, generator=g).to(DEV).to(dt)
+
+    def run(wide):
+        prev = lib.egk_tune(7, int(wide))
+        try:
+            ops.manual_seed(77)
+            xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            with ops.compute_mode("bf16" if dt == torch.bfloat16 else "f32"):
+                y = ops.row_layernorm(xi, wi, bi, 1e-5, relu=True, p=0.25, training=True)
+                mask = ops.last_rowln_mask(y).clone()
+                (y.float() * wt.float()).sum().backward()
+            return y.detach().float(), mask, xi.grad.float(), wi.grad.clone(), bi.grad.clone()
+        finally:
+            lib.egk_tune(7, prev)
+    y1, m1, dx1, dw1, db1 = run(True)
+    y0, m0, dx0, dw0, db0 = run(False)
+    assert torch.equal(m1, m0) and 0.7 < float(m1.float().mean()) < 0.8
+    tol = dict(rtol=2e-2, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y1, y0, **tol)
+    torch.testing.assert_close(dx1, dx0, **(tol if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)))
+    torch.testing.assert_close(dw1, dw0, rtol=1e-3, atol=2e-3 * rows ** 0.5 if dt == torch.float32 else 5e-2 * rows ** 0.5)
+    torch.testing.assert_close(db1, db0, rtol=1e-3, atol=2e-3 * rows ** 0.5 if dt == torch.float32 else 5e-2 * rows ** 0.5)
