@@ -883,7 +883,8 @@ class StepBase:
         tp = getattr(self.model, "temporal_pooling", None)
         first = getattr(tp, "proj", [None])[0] if tp is not None else None
         if (first is None or not hasattr(opt, "region_of") or not getattr(opt, "materialised", False) or not (self.fused or len(live) == 1)
-                or "tail_group" in getattr(self, "_dev_off", ()) or not self.headwise_backward_ok()):
+                or "tail_group" in getattr(self, "_dev_off", ()) or not self.headwise_backward_ok()
+                or first.weight.numel() >= 512 * 128 * 128):  # (a wide first linear's weight gradient stays a launch of its own)
             return None
         params = [p for p in tp.parameters() if p.requires_grad]
         lo, hi = opt.region_of(params)
@@ -922,8 +923,12 @@ class StepBase:
             return (lo, hi) if ok else None
         # the late Adam slice: the whole temporal pooling when its slots are one block (then the step's tail is ONE grouped
         # launch of its weight gradients, ops.set_last_wgrad_tail), else the first linear alone
+        # (a first linear whose weight gradient alone is >= 512 tiles of 128 x 128 -- the shipped pooling width 4096: 1152 -- fills
+        #  the chip by itself: its launch stays alone and the late slice is that layer's, so that Adam over the rest of the pooling
+        #  runs beside it; Hp = 4096 step 2.785-2.796 -> 2.770-2.772 ms.  At Hp = 1024 (288 tiles) the pooling's three weight
+        #  gradients are one grouped launch, 123 against 120 + 66 us.)
         tail = None
-        if "tail_group" not in getattr(self, "_dev_off", ()):
+        if "tail_group" not in getattr(self, "_dev_off", ()) and first.weight.numel() < 512 * 128 * 128:
             tail = region([p for p in tp.parameters() if p.requires_grad])
         reg = tail or region([p for p in (getattr(first, "weight", None), getattr(first, "bias", None)) if p is not None])
         if reg is None:
