@@ -1643,10 +1643,9 @@ class EgoPackStep(StepBase):
         return [t for t in self.AUX_ORDER[primary] if t in self.graphone.task_labels]
 
     @torch.no_grad()
-    def precise_aux_features(self, batches, merged=None, rng_snap=None, tape=None, after_backbone=None):
+    def precise_aux_features(self, batches, merged=None, rng_snap=None, tape=None):
         """{primary: {aux task: f32 [N, H]}}: the auxiliary projections of every enabled task batch from the 'bf16x3' pass.
-        ``tape`` (a list): the backbone's nodes leave their results in it (ops.dual_record) for the one-pass step;
-        ``after_backbone()``: called when the backbone's launches have been issued."""
+        ``tape`` (a list): the backbone's nodes leave their results in it (ops.dual_record) for the one-pass step."""
         opt = self.optimizer
         live = [t for t in self.enabled if batches.get(t) is not None]
         with ops.precise_scope(), ops.rng_replay(ops.rng_snapshot() if rng_snap is None else rng_snap):
@@ -1658,8 +1657,6 @@ class EgoPackStep(StepBase):
                 tape.extend(rec)
             else:
                 feats = self.features(batches, merged)
-            if after_backbone is not None:
-                after_backbone()
             out = {}
             for t in live:
                 others = self._aux_names(t)
@@ -1764,9 +1761,7 @@ class EgoPackStep(StepBase):
                 tape = [] if self._one_pass_ok(batches, merged) else None
                 with torch.cuda.stream(side):
                     try:
-                        precise = self.precise_aux_features(
-                            batches, merged, rng_snap=snap, tape=tape,
-                            after_backbone=(lambda: gate_ev.__setitem__("backbone", side.record_event())) if tape is not None else None)
+                        precise = self.precise_aux_features(batches, merged, rng_snap=snap, tape=tape)
                     finally:
                         if gate:
                             ops.phase_callbacks(None)
