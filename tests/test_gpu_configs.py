@@ -265,7 +265,7 @@ def test_config4_two_pass_step_vs_the_storage_model(monkeypatch):
 # The ONE-pass EgoPack step (engine.EgoPackStep._one_pass_ok; config 4 in bf16 mode): the forward VALUES are the f32-grade pass's,
 # rounded once where they are stored -- the step sits closer to the f32 oracle than the storage model (a chain that rounds at every
 # stored tensor) does, so the triangle does not apply; its own bounds against the f32 oracle = measured x 1.25
-# (profiles/r05_config_parity.md: loss vectors 8.6e-4, worst gradient 0.153 -- the two-pass step: 1.0e-2 / 0.21)
+# (profiles/r05_config_parity.md: loss vectors 8.6e-4, worst gradient 0.153 -- the two-pass step: 8.7e-4 / 0.200)
 ONE_PASS_LOSS, ONE_PASS_GRAD = 1.1e-3, 0.19
 
 
