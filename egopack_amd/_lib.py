@@ -119,6 +119,9 @@ SIGNATURES = {
     "egk_row_sq_norm": (C.c_int, [vp, vp, vp, i32, i32, i32]),
     "egk_topk_smallest_l2": (C.c_int, [vp, vp, i64, vp, vp, vp, i32, i32, i32]),
     "egk_topk_window": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    "egk_gemm_defer_reduce_next": (C.c_int, [i32]),
+    "egk_slab_input_next": (C.c_int, [vp, vp, vp]),
+    "egk_gemm_reduce_slabs": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, i64]),
     "egk_topk_window_group": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]),
     "egk_bf16_residual_ratio": (C.c_int, [vp, vp, i64, vp, vp, i32, i32]),
     "egk_gather_max_bank_grad": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),

@@ -232,7 +232,22 @@ __device__ __forceinline__ void tee4(const SplitTee& t, long long row, int c, in
 // the tee armed by egk_tee_split_next, handed to (and cleared by) the next row-kernel launcher; null pointers when none is armed
 SplitTee take_split_tee();
 bool split_tee_armed();
+
+// One-shot "slab input" of a row kernel (egk_slab_input_next): its f32 input is given as the two K slabs of a split contraction whose
+// reduce launch was left out (egk_gemm_defer_reduce_next): element (r, c) = (x[r, c] + x2[r, c]) + bias[c] -- gemm_splitk_reduce's
+// arithmetic, so the same bits -- and the kernel also stores that value to x_out[r, c] (row stride = cols), so that later readers
+// find the reduced matrix.  x2 == nullptr: a plain input.
+struct SlabInput {
+    const float* x2;
+    const float* bias;
+    float* x_out;
+};
+SlabInput take_slab_input();
+bool slab_input_armed();
+bool take_defer_reduce();  // egk_gemm_defer_reduce_next: the next split-K egk_gemm leaves its slabs unreduced
 void arm_split_tee(bf16_t* hi, bf16_t* lo, long long ld);
+void arm_slab_input(const float* x2, const float* bias, float* x_out);
+void arm_defer_reduce(bool on);
 
 // host-side dispatch on an EGK_F32 / EGK_BF16 activation type: ``using T = ...`` inside CALL
 #define EGK_DISPATCH_T(dtype, ...)                                               \

@@ -2557,7 +2557,11 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             } else EGK_PIPE(true, false);
         }
 #undef EGK_PIPE
-        if (g.splitk > 1 && !g.sk_tickets) {
+        const bool defer = take_defer_reduce();
+        if (defer)
+            EGK_REQUIRE(g.splitk > 1 && !g.sk_tickets && !g.accumulate && g.act == 0 && !g.residual && g.alpha == 1.f && !g.c_bf16 && !g.dbias,
+                        "egk_gemm_defer_reduce_next: a split launch with a plain f32 result (bias only)");
+        if (g.splitk > 1 && !g.sk_tickets && !defer) {
             ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
             const long long total = (long long)g.M * g.N;
             const long long work = (total + 3) / 4;  // element groups of 4 (the vector path; the scalar path strides)
@@ -2614,6 +2618,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             else if (d->transA && d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<true, true>), pgrid, pblock, 65536, s, g);
             else hipLaunchKernelGGL((gemm_pipe_f32_kernel<true, false>), pgrid, pblock, 65536, s, g);
         }
+        EGK_REQUIRE(!take_defer_reduce(), "egk_gemm_defer_reduce_next: only the bf16-operand pipelined launches leave their slabs");
         if (g.splitk > 1) {
             ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
             const long long total = (long long)g.M * g.N;
@@ -2639,6 +2644,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         else if (a16) launch_layout<true, bf16_t, bf16_t>(d, grid, s, g);
         else launch_layout<true, float, float>(d, grid, s, g);
     }
+    EGK_REQUIRE(!take_defer_reduce(), "egk_gemm_defer_reduce_next: only the bf16-operand pipelined launches leave their slabs");
     if (g.splitk > 1) {
         ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
         const long long total = (long long)g.M * g.N;
@@ -2646,6 +2652,27 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                            dim3(256), 0, s, g);
     }
     return check_launch("egk_gemm");
+}
+
+// The reduce launch of a split contraction by itself: C[m, n] = sum_z ws[z][m][n] (slab order) + bias[n] -- for slabs left behind
+// by egk_gemm_defer_reduce_next that no slab-aware row kernel consumed.
+extern "C" int egk_gemm_reduce_slabs(egk_stream_t stream, const float* ws, int32_t splitk, int32_t M, int32_t N, const float* bias,
+                                     float* C, int64_t ldc) {
+    EGK_REQUIRE(ws && C && splitk >= 2 && M >= 0 && N >= 0 && ldc >= N, "egk_gemm_reduce_slabs: bad arguments");
+    if (M == 0 || N == 0) return 0;
+    GemmArgs g{};  // (value-initialised: every epilogue feature off)
+    g.M = M; g.N = N;
+    g.C = C; g.ldc = ldc;
+    g.c_vec = aligned16(C) && ldc % 4 == 0;
+    g.alpha = 1.f;
+    g.bias = bias;
+    g.splitk = splitk;
+    g.ws = const_cast<float*>(ws);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, 4.0 * (splitk + 1) * M * N);
+    const long long work = ((long long)M * N + 3) / 4;
+    hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)), dim3(256), 0, s, g);
+    return check_launch("egk_gemm_reduce_slabs");
 }
 
 // ---- grouped contractions ---------------------------------------------------------------------------------------------

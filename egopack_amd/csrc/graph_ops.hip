@@ -69,7 +69,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pe_add_table_kernel(const T* __restrict__ x, const long long* __restrict__ pos,
                                                            const float* __restrict__ freq, const float* __restrict__ table,
                                                            long long pos_min, int n_pos, T* __restrict__ y, int rows, int cols,
-                                                           const SplitTee tee) {
+                                                           const SplitTee tee, const SlabInput si = SlabInput{nullptr, nullptr, nullptr}) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
     const int half = cols >> 1;
@@ -82,6 +82,17 @@ __global__ __launch_bounds__(256) void pe_add_table_kernel(const T* __restrict__
         T* yr = y + (long long)row * cols;
         for (int c = lane * 4; c < cols; c += 256) {
             float4 v = ld4(xr, c, cols, vec);
+            if constexpr (sizeof(T) == 4) {
+                if (si.x2) {  // the input as two K slabs + bias (egk_slab_input_next): gemm_splitk_reduce's arithmetic, stored for later readers
+                    const float4 v2 = ld4t(si.x2 + (long long)row * cols, c, cols, vec);
+                    v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+                    if (si.bias) {
+                        const float4 bb = ld4t(si.bias, c, cols, vec);
+                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                    }
+                    st4t(si.x_out + (long long)row * cols, c, cols, vec, v);
+                }
+            }
             float4 e;
             if (hit) {
                 e = ld4t(tr, c, cols, vec);
@@ -1599,14 +1610,17 @@ int egk_pe_add_table(egk_stream_t stream, const void* x, const int64_t* pos, con
     ProfScope prof(KID_PE_ADD, s, 0, (dtype == EGK_BF16 ? 4.0 : 8.0) * rows * cols);
     const SplitTee tee = take_split_tee();
     EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_pe_add_table: a split tee needs an f32 result");
+    EGK_REQUIRE(!slab_input_armed() || dtype == EGK_F32, "egk_pe_add_table: a slab input needs an f32 input");
     if (g_graph_rows_v2 && dtype == EGK_BF16 && cols == 1024 && al16(x) && al16(y) && al16(table)) {
         const int g2 = cdiv(rows, 2 * WPB) > 1024 ? 1024 : cdiv(rows, 2 * WPB);
         hipLaunchKernelGGL(pe_add_table_1k_kernel<2>, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, (const long long*)pos, freq, table,
                            (long long)pos_min, n_pos, (bf16_t*)y, rows);
         return check_launch("egk_pe_add_table");
     }
+    const SlabInput si = take_slab_input();
+    EGK_REQUIRE(!si.x2 || (dtype == EGK_F32 && cols % 4 == 0), "egk_pe_add_table: a slab input needs f32 rows of a multiple of 4 columns");
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(pe_add_table_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x,
-                                             (const long long*)pos, freq, table, (long long)pos_min, n_pos, (T*)y, rows, cols, tee));
+                                             (const long long*)pos, freq, table, (long long)pos_min, n_pos, (T*)y, rows, cols, tee, si));
     return check_launch("egk_pe_add_table");
 }
 

@@ -45,7 +45,8 @@ __device__ __forceinline__ void rowln_fwd_body(const T* __restrict__ x, const fl
                                                uint8_t* __restrict__ mask, int row_begin, int rows, int cols, float eps, int relu,
                                                float p, uint64_t seed, uint64_t offset,
                                                const uint64_t* __restrict__ dev_offset, int blk, int nblk,
-                                               const SplitTee tee = SplitTee{nullptr, nullptr, 0}) {
+                                               const SplitTee tee = SplitTee{nullptr, nullptr, 0},
+                                               const SlabInput si = SlabInput{nullptr, nullptr, nullptr}) {
     if (dev_offset) offset += dev_offset[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
@@ -57,6 +58,24 @@ __device__ __forceinline__ void rowln_fwd_body(const T* __restrict__ x, const fl
     for (int row = row_begin + blk * WPB + wave; row < rows; row += nblk * WPB) {
         Row<NV> r;
         load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
+        if constexpr (sizeof(T) == 4) {
+            if (si.x2) {  // the input as two K slabs + bias (egk_slab_input_next): gemm_splitk_reduce's arithmetic, stored for later readers
+                Row<NV> r2;
+                load_row<NV>(si.x2 + (long long)row * cols, cols, vec, lane, r2);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    r.v[i].x += r2.v[i].x; r.v[i].y += r2.v[i].y; r.v[i].z += r2.v[i].z; r.v[i].w += r2.v[i].w;
+                }
+                if (si.bias) {
+                    load_row<NV>(si.bias, cols, vec, lane, r2);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        r.v[i].x += r2.v[i].x; r.v[i].y += r2.v[i].y; r.v[i].z += r2.v[i].z; r.v[i].w += r2.v[i].w;
+                    }
+                }
+                store_row<NV>(si.x_out + (long long)row * cols, cols, vec, lane, r);
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
@@ -114,9 +133,10 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(const T* __restrict__ x,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         uint8_t* __restrict__ mask, int rows, int cols, float eps, int relu,
                                                         float p, uint64_t seed, uint64_t offset,
-                                                        const uint64_t* __restrict__ dev_offset, const SplitTee tee) {
+                                                        const uint64_t* __restrict__ dev_offset, const SplitTee tee,
+                                                        const SlabInput si) {
     rowln_fwd_body<NV, T, FULL>(x, w, b, y, mean, rstd, mask, 0, rows, cols, eps, relu, p, seed, offset, dev_offset, blockIdx.x,
-                                gridDim.x, tee);
+                                gridDim.x, tee, si);
 }
 
 // Grouped row LayerNorm: up to LN_MAX_GROUPS consecutive row ranges of ONE [rows, cols] matrix, each with its own affine
@@ -513,7 +533,8 @@ __device__ __forceinline__ int seg_of(const int* __restrict__ seg_ptr, int n_seg
 // pass 1: per-workgroup per-segment (sum, sumsq) in double -> ws[blk][seg][2]
 template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict__ x, const int* __restrict__ seg_ptr,
-                                                            int n_seg, int rows, int cols, double* __restrict__ ws) {
+                                                            int n_seg, int rows, int cols, double* __restrict__ ws,
+                                                            const SlabInput si = SlabInput{nullptr, nullptr, nullptr}) {
     __shared__ double acc[WPB][MAXSEG][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (FULL) cols = NV * 256;  // exact-width rows: every bounds check below folds away
@@ -536,6 +557,28 @@ __global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict_
             acc[wave][sg][1] += dq;
         }
     };
+    // the input as two K slabs + bias (egk_slab_input_next): gemm_splitk_reduce's arithmetic; the reduced row is stored for the
+    // normalising launch that follows (and every later reader)
+    auto slab_row = [&](int row, Row<NV>& r) {
+        if constexpr (sizeof(T) == 4) {
+            if (si.x2) {
+                Row<NV> t;
+                load_row<NV>(si.x2 + (long long)row * cols, cols, vec, lane, t);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    r.v[i].x += t.v[i].x; r.v[i].y += t.v[i].y; r.v[i].z += t.v[i].z; r.v[i].w += t.v[i].w;
+                }
+                if (si.bias) {
+                    load_row<NV>(si.bias, cols, vec, lane, t);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        r.v[i].x += t.v[i].x; r.v[i].y += t.v[i].y; r.v[i].z += t.v[i].z; r.v[i].w += t.v[i].w;
+                    }
+                }
+                store_row<NV>(si.x_out + (long long)row * cols, cols, vec, lane, r);
+            }
+        }
+    };
     const int stride_rows = gridDim.x * WPB;  // two rows in flight per wave (see rowln_bwd_kernel)
     for (int row = blockIdx.x * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
         Row<NV> r;
@@ -544,9 +587,14 @@ __global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict_
             const int row2 = row + stride_rows;
             Row<NV> r2;
             if (row2 < rows) load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, r2);
+            slab_row(row, r);
             process(row, r);
-            if (row2 < rows) process(row2, r2);
+            if (row2 < rows) {
+                slab_row(row2, r2);
+                process(row2, r2);
+            }
         } else {
+            slab_row(row, r);
             process(row, r);
         }
     }
@@ -1188,7 +1236,9 @@ int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const floa
     ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * rows * cols + (p > 0 ? 1.0 * rows * cols : 0));
     const SplitTee tee = take_split_tee();
     EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_rowln_fwd: a split tee needs an f32 result");
-    if (wide_rows_ok(cols, x, y, w, b, mask, dtype)) {
+    const SlabInput si = take_slab_input();
+    EGK_REQUIRE(!si.x2 || (dtype == EGK_F32 && cols % 4 == 0 && cols <= 1024), "egk_rowln_fwd: a slab input needs f32 rows of <= 1024 columns");
+    if (!si.x2 && wide_rows_ok(cols, x, y, w, b, mask, dtype)) {
         const int grid = rows < 1536 ? rows : 1536;  // (six workgroups per CU: two rows in flight each)
         EGK_DISPATCH_T(dtype, DISPATCH_NVW_(cols, hipLaunchKernelGGL((rowln_fwd_wide_kernel<NVW, T>), dim3(grid), dim3(256), 0, s, (const T*)x, w,
                                                                     b, (T*)y, mean, rstd, mask, rows, eps, relu, p, seed, offset,
@@ -1196,7 +1246,7 @@ int egk_rowln_fwd(egk_stream_t stream, const void* x, const float* w, const floa
         return check_launch("egk_rowln_fwd");
     }
     DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
-                                                 (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset, tee));
+                                                 (T*)y, mean, rstd, mask, rows, cols, eps, relu, p, seed, offset, dev_offset, tee, si));
     return check_launch("egk_rowln_fwd");
 }
 
@@ -1338,16 +1388,21 @@ int egk_graphln_fwd(egk_stream_t stream, const void* x, const float* w, const fl
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows);
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
+    // (a slab input, egk_slab_input_next: the statistics launch reads the two slabs and leaves the reduced matrix in x_out, which the
+    //  normalising launch then reads)
+    const SlabInput si = take_slab_input();
+    EGK_REQUIRE(!si.x2 || (dtype == EGK_F32 && cols % 4 == 0 && cols <= 1024), "egk_graphln_fwd: a slab input needs f32 rows of <= 1024 columns");
     {
         ProfScope prof(KID_GRAPHLN_STATS, s, 0, eb * rows * cols);
         DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_stats_kernel<NV, T, FULL>), dim3(grid), dim3(256), 0, s, (const T*)x, seg_ptr,
-                                                     n_seg, rows, cols, (double*)ws));
+                                                     n_seg, rows, cols, (double*)ws, si));
     }
+    const void* xn = si.x2 ? (const void*)si.x_out : x;
     {
         ProfScope prof(KID_GRAPHLN_FWD, s, 0, 2 * eb * rows * cols);
         const SplitTee tee = take_split_tee();
         EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_graphln_fwd: a split tee needs an f32 result");
-        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)x, w, b,
+        DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((graphln_fwd_kernel<NV, T, FULL>), dim3(row_grid_wide(rows)), dim3(256), 0, s, (const T*)xn, w, b,
                                                      (T*)y, stats, seg_ptr, n_seg, rows, cols, eps, slope, (const double*)ws, grid, tee));
     }
     return check_launch("egk_graphln_fwd");

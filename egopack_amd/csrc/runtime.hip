@@ -19,6 +19,21 @@ SplitTee take_split_tee() {
     return t;
 }
 bool split_tee_armed() { return g_tee.lo != nullptr; }
+static thread_local SlabInput g_slab = {nullptr, nullptr, nullptr};
+static thread_local bool g_defer_reduce = false;
+void arm_slab_input(const float* x2, const float* bias, float* x_out) { g_slab = SlabInput{x2, bias, x_out}; }
+SlabInput take_slab_input() {
+    const SlabInput t = g_slab;
+    g_slab = SlabInput{nullptr, nullptr, nullptr};
+    return t;
+}
+bool slab_input_armed() { return g_slab.x2 != nullptr; }
+void arm_defer_reduce(bool on) { g_defer_reduce = on; }
+bool take_defer_reduce() {
+    const bool t = g_defer_reduce;
+    g_defer_reduce = false;
+    return t;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -241,6 +256,19 @@ int egk_tee_split_next(void* hi, void* lo, int64_t ld) {
     EGK_REQUIRE((hi && lo && ld > 0) || (!hi && !lo), "egk_tee_split_next: both halves (8-byte aligned) and a row stride, or NULL, NULL to disarm");
     EGK_REQUIRE(((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7) == 0, "egk_tee_split_next: halves must be 8-byte aligned");
     egk::arm_split_tee((egk::bf16_t*)hi, (egk::bf16_t*)lo, (long long)ld);
+    return 0;
+}
+
+int egk_slab_input_next(const float* x2, const float* bias, float* x_out) {
+    EGK_REQUIRE((x2 && x_out) || (!x2 && !bias && !x_out), "egk_slab_input_next: the second slab and the output, or NULLs to disarm");
+    EGK_REQUIRE(((reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(x_out)) & 15) == 0,
+                "egk_slab_input_next: 16-byte aligned pointers");
+    egk::arm_slab_input(x2, bias, x_out);
+    return 0;
+}
+
+int egk_gemm_defer_reduce_next(int32_t on) {
+    egk::arm_defer_reduce(on != 0);
     return 0;
 }
 

@@ -80,11 +80,51 @@ def _materialise_virtual(t: torch.Tensor) -> None:
                              C.c_void_p(t.data_ptr()), F32, src.numel()), "egk_cast")
 
 
+def _materialise_slabs(t: torch.Tensor) -> None:
+    """The result of a split contraction whose reduce launch was left out (``gemm(defer_reduce=True)``: its two K slabs sit in a
+    private workspace) is about to be read by something that does not take slabs: run the reduce launch now."""
+    ws, M, N, bias = t._egk_slabs
+    t._egk_slabs = None
+    _ck(_lib.load().egk_gemm_reduce_slabs(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.data_ptr()), 2, M, N,
+                                          C.c_void_p(bias.data_ptr()) if bias is not None else None, C.c_void_p(t.data_ptr()), N),
+        "egk_gemm_reduce_slabs")
+    _slabs_written(t)
+
+
+def _slabs_written(t: torch.Tensor) -> None:
+    """``t`` now holds the reduced matrix: a taped node that recorded it earlier (ops.dual_record) is ready from HERE on."""
+    ent = getattr(t, "_egk_tape_entry", None)
+    if ent is not None:
+        ent["@event"] = torch.cuda.current_stream().record_event()
+        t._egk_tape_entry = None
+
+
+def _slab_consumer(x: torch.Tensor, cols_max: int = 1024):
+    """(pointer to pass as the row kernel's input, True) after arming the one-shot slab input for ``x`` -- the f32 result of a
+    split contraction whose reduce was deferred -- or (None, False): the caller goes on with ``x`` as it is (``_c`` / ``_p``
+    materialise it).  The armed kernel reads slab 0 + slab 1 + bias and stores the reduced matrix into ``x``."""
+    sl = getattr(x, "_egk_slabs", None)
+    if sl is None:
+        return None, False
+    ws, M, N, bias = sl
+    if not (x.is_contiguous() and x.dim() == 2 and tuple(x.shape) == (M, N) and N <= cols_max and N % 4 == 0):
+        return None, False
+    x._egk_slabs = None
+    rc = _lib.load().egk_slab_input_next(C.c_void_p(ws.data_ptr() + 4 * M * N), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                         C.c_void_p(x.data_ptr()))
+    if rc != 0:
+        raise RuntimeError(f"egk_slab_input_next failed (code {rc}): {_lib.last_error()}")
+    x._egk_slab_keep = (ws, bias)  # (alive until the tensor goes: the armed launch reads them)
+    return C.c_void_p(ws.data_ptr()), True
+
+
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
     if getattr(t, "_egk_virtual", False):  # (any kernel that takes this tensor's pointer reads its f32 values)
         _materialise_virtual(t)
+    if getattr(t, "_egk_slabs", None) is not None:
+        _materialise_slabs(t)
     return C.c_void_p(t.data_ptr())
 
 
@@ -161,6 +201,8 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     _dt(t)
     if getattr(t, "_egk_virtual", False):
         _materialise_virtual(t)
+    if getattr(t, "_egk_slabs", None) is not None:
+        _materialise_slabs(t)
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -169,6 +211,8 @@ def _rm(t: torch.Tensor) -> torch.Tensor:
     _dt(t)
     if getattr(t, "_egk_virtual", False):
         _materialise_virtual(t)
+    if getattr(t, "_egk_slabs", None) is not None:
+        _materialise_slabs(t)
     if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
         return t
     return t.contiguous()
@@ -555,6 +599,18 @@ def _tee_done(y: torch.Tensor, halves) -> None:
         _x3["cache"][(y.data_ptr(), rows, cols, cols, y._version)] = (halves[0], halves[1], y)
 
 
+def _gemm_deferrable(args, kw) -> None:
+    """``gemm(*args, **kw)`` of the precise pass (no gradient, inside a precise_scope, a plain f32 result with at most a bias): a
+    launch that splits K in two leaves its slabs to the row kernel that reads the result next (``out._egk_slabs``, ``_slab_consumer``)."""
+    M, N, out = args[0], args[1], args[7]
+    defer = (kw.get("compute") == X3 and _slab_defer["on"] and _x3["cache"] is not None and not torch.is_grad_enabled()
+             and not kw.get("act") and kw.get("residual") is None and not kw.get("accumulate") and out.dtype == torch.float32
+             and out.is_contiguous() and args[8] == N and N <= 1024 and N % 4 == 0)
+    ws = gemm(*args, defer_reduce=defer, **kw)
+    if ws is not None:
+        out._egk_slabs = (ws, M, N, kw.get("bias"))
+
+
 def _gemm_with_stats(args, kw, stats):
     """``gemm(*args, **kw)`` with the epilogue statistics ``stats`` if the tile variant of this launch can take them:
     returns (partials, blocks) or None (plain launch done instead).  No split-K (the statistics need the finished tile)."""
@@ -573,7 +629,7 @@ def _gemm_with_stats(args, kw, stats):
         if lib.egk_gemm_splitk(d.M, d.N, _desc_k(d), d.compute) > 1:
             blocks = 0
     if blocks <= 0:
-        gemm(*args, **kw)
+        _gemm_deferrable(args, kw)
         return None
     ws = torch.empty(blocks * stats["n_seg"] * 2, dtype=torch.float64, device=args[7].device)
     d.st_ws = _p(ws)
@@ -638,19 +694,33 @@ def _sk_tickets(M: int, N: int, device):
     return buf
 
 
-def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, **kw):
+def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, defer_reduce=False, **kw):
+    """``defer_reduce``: if the launch splits K in two, leave the slabs in a workspace of their own and do not launch the reduce
+    (egk_gemm_defer_reduce_next) -- returns that workspace ([2][M][N] f32; ``out`` is NOT written, the bias NOT applied), else None."""
     lib = _lib.load()
     d = _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, **kw)
     sk = lib.egk_gemm_splitk(M, N, _desc_k(d), d.compute) if allow_splitk else 1
     d.splitk = sk if splitk is None else int(splitk)
     need = lib.egk_gemm_ws_bytes(C.byref(d))
+    deferred = None
     if need:
-        ws = workspace(need, out.device)
+        if (defer_reduce and d.splitk == 2 and not _sk_in_launch["on"] and d.compute == BF16 and d.c_dtype == F32 and ldc == N
+                and need == 8 * M * N):
+            ws = deferred = torch.empty(need, dtype=torch.uint8, device=out.device)
+        else:
+            ws = workspace(need, out.device)
         d.ws, d.ws_bytes = _p(ws), ws.numel()
-    if d.splitk > 1:
+    if d.splitk > 1 and deferred is None:
         d.sk_tickets = _p(_sk_tickets(M, N, out.device))
-    _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
-    _x3_release()
+    if deferred is not None:
+        lib.egk_gemm_defer_reduce_next(1)
+    try:
+        _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
+    finally:
+        if deferred is not None:
+            lib.egk_gemm_defer_reduce_next(0)
+        _x3_release()
+    return deferred
 
 
 def gemm_grouped(problems, four_wave: bool = False):
@@ -1134,6 +1204,7 @@ def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # roundings of the precise activations, the forward VALUES are the precise ones.  Nodes: _Linear, _RowLN, _PEAdd, _SageMean, _GraphLN
 # (what models.Graph.forward with a TRN pooling issues); the sequences of the two passes must agree node by node (checked).
 _dual = {"tape": None, "replay": None}
+_slab_defer = {"on": "slab_defer" not in os.environ.get("EGK_DISABLE", "")}  # the precise pass's split contractions without reduce launches
 
 
 class dual_record:
@@ -1181,6 +1252,9 @@ def _tape_put(kind: str, **tensors) -> None:
                 hit = cache.get((t.data_ptr(), t.shape[0], t.shape[1], t.shape[1], t._version))
                 if hit is not None:
                     tensors[k + ":hi"] = hit[0]
+    for t in list(tensors.values()):
+        if getattr(t, "_egk_slabs", None) is not None:
+            t._egk_tape_entry = tensors  # (its reduced values are written later: ``_slabs_written`` moves the event there)
     tensors["@event"] = torch.cuda.current_stream().record_event() if next(iter(tensors.values())).is_cuda else None
     _dual["tape"].append((kind, tensors))
 
@@ -1234,8 +1308,15 @@ class _Linear(torch.autograd.Function):
                 y = torch.empty((M, _pad8(N)), dtype=torch.float32, device=x.device)[:, :N]
             else:
                 y = torch.empty((M, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-            gemm(M, N, x, K1, Wop, K1, K1, y, y.stride(0), A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2,
-                 bias=_f32c(b) if b is not None else None, residual=res, ldr=N, act=1 if relu else 0, compute=compute)
+            bias_c = _f32c(b) if b is not None else None
+            # the precise pass (no gradient, inside a precise_scope): a launch that splits K leaves its slabs for the row kernel
+            # that reads the result next (row LayerNorm, graph LayerNorm, PE add: ``_slab_consumer``) instead of a reduce launch
+            defer = (compute == X3 and _slab_defer["on"] and _x3["cache"] is not None and not torch.is_grad_enabled() and not relu
+                     and res is None and y.dtype == torch.float32 and y.is_contiguous() and N <= 1024 and N % 4 == 0)
+            ws = gemm(M, N, x, K1, Wop, K1, K1, y, y.stride(0), A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2, bias=bias_c, residual=res,
+                      ldr=N, act=1 if relu else 0, compute=compute, defer_reduce=defer)
+            if ws is not None:
+                y._egk_slabs = (ws, M, N, bias_c)
             if not out_f32:
                 _tape_put("linear", y=y)
         ctx.relu, ctx.compute = relu, compute
@@ -2035,7 +2116,9 @@ class _RowLN(torch.autograd.Function):
     def forward(ctx, x, w, b, eps, relu, p, training):
         _need_gpu(x, w)
         lib = _lib.load()
-        x = _c(x)
+        slabbed = getattr(x, "_egk_slabs", None) is not None and _dual["replay"] is None
+        if not slabbed:
+            x = _c(x)
         rows, cols = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -2050,10 +2133,13 @@ class _RowLN(torch.autograd.Function):
             y, mean, rstd = _r16(taped, "y"), taped["mean"], taped["rstd"]
         else:
             tee = _tee_arm(y)
-            _ck(lib.egk_rowln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(mean), _p(rstd), _p(mask), rows, cols, eps,
+            xin, took = _slab_consumer(x) if slabbed else (None, False)  # (the reduce of the contraction that made x rides here)
+            _ck(lib.egk_rowln_fwd(_stream(), xin if took else _p(x), _p(wc), _p(bc), _p(y), _p(mean), _p(rstd), _p(mask), rows, cols, eps,
                                   int(relu), p_eff, seed, off, dev_off, _dt(x)),
                 "egk_rowln_fwd")
             _tee_done(y, tee)
+            if took:
+                _slabs_written(x)
             if p_eff == 0:
                 _tape_put("rowln", y=y, mean=mean, rstd=rstd)
         ctx.relu, ctx.p = relu, p_eff
@@ -2174,7 +2260,10 @@ class _GraphLN(torch.autograd.Function):
     def forward(ctx, x, w, b, seg_ptr, eps, slope, partials=None, lnctx=None):
         _need_gpu(x, w, seg_ptr)
         lib = _lib.load()
-        x = _c(x)
+        slabbed = (getattr(x, "_egk_slabs", None) is not None and _dual["replay"] is None and partials is None
+                   and _ln_exchange["fn"] is None)
+        if not slabbed:
+            x = _c(x)
         rows, cols = x.shape
         n_seg = seg_ptr.numel() - 1
         y = torch.empty_like(x)
@@ -2201,9 +2290,12 @@ class _GraphLN(torch.autograd.Function):
         else:
             ws = workspace(lib.egk_graphln_ws_bytes(rows, cols, n_seg), x.device)
             tee = _tee_arm(y)
-            _ck(lib.egk_graphln_fwd(_stream(), _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
+            xin, took = _slab_consumer(x) if slabbed else (None, False)  # (the statistics launch reduces the slabs on its way)
+            _ck(lib.egk_graphln_fwd(_stream(), xin if took else _p(x), _p(wc), _p(bc), _p(y), _p(stats), _p(seg_ptr), n_seg, rows, cols, eps,
                                     slope, _p(ws), _dt(x)), "egk_graphln_fwd")
             _tee_done(y, tee)
+            if took:
+                _slabs_written(x)
         if taped is None and _ln_exchange["fn"] is None:
             _tape_put("graphln", y=y, stats=stats)
         ctx.eps, ctx.slope = eps, slope
@@ -2330,7 +2422,9 @@ class _PEAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, freq, pos_range):
         _need_gpu(x, pos, freq)
-        x = _c(x)
+        slabbed = getattr(x, "_egk_slabs", None) is not None and _dual["replay"] is None
+        if not slabbed:
+            x = _c(x)
         rows, cols = x.shape
         y = torch.empty_like(x)
         lib = _lib.load()
@@ -2343,10 +2437,16 @@ class _PEAdd(torch.autograd.Function):
         taped = _tape_take("pe_add", x)
         if taped is not None:
             return _r16(taped, "y")
+        if slabbed and table is None:
+            x = _c(x)  # (the direct evaluation takes no slabs: reduce first)
+            slabbed = False
         tee = _tee_arm(y)
         if table is not None:
-            _ck(lib.egk_pe_add_table(_stream(), _p(x), _p(posc), _p(fr), _p(table), int(pos_range[0]), int(n_pos),
+            xin, took = _slab_consumer(x) if slabbed else (None, False)
+            _ck(lib.egk_pe_add_table(_stream(), xin if took else _p(x), _p(posc), _p(fr), _p(table), int(pos_range[0]), int(n_pos),
                                      _p(y), rows, cols, _dt(x)), "egk_pe_add_table")
+            if took:
+                _slabs_written(x)
         else:
             _ck(lib.egk_pe_add(_stream(), _p(x), _p(posc), _p(fr), _p(y), rows, cols, _dt(x)), "egk_pe_add")
         _tee_done(y, tee)
@@ -2463,7 +2563,7 @@ class _SageMean(torch.autograd.Function):
                 ln_out["partials"] = _gemm_with_stats(c_args, c_kw, dict(mode=1, seg_ptr=ln_out["seg_ptr"], n_seg=ln_out["n_seg"],
                                                                          min_rows=ln_out["min_rows"]))
             else:
-                gemm(*c_args, **c_kw)
+                _gemm_deferrable(c_args, c_kw)
             _tape_put("sage_mean", xp=xp, agg=agg, out=out)
         ctx.ln_in, ctx.res_src = ln_in, res_src
         ctx.compute, ctx.params = compute, (Wp, bp, Wl, bl, Wr)

@@ -74,6 +74,20 @@ void egk_graph_plan_destroy(egk_graph_plan* plan);
  * models/graph.py:53-63 feeding models/graphONE/graphONE.py:119-141) are exactly these row kernels.  NULL, NULL disarms. */
 int egk_tee_split_next(void* hi, void* lo, int64_t ld);
 
+/* Split-K contractions of the forward-only precise pass WITHOUT their reduce launch (11 such launches of ~6 us sat on that pass's
+ * chain in BASELINE config 4, each in front of a row kernel that reads the reduced matrix once):
+ *   egk_gemm_defer_reduce_next(1): the NEXT egk_gemm call of this host thread, if it splits K (bf16-operand pipelined launch, f32
+ *     result, no accumulate / activation / residual / alpha), leaves its slabs in the caller's workspace ws = [splitk][M][N] and
+ *     does not launch gemm_splitk_reduce; the bias is not applied either.
+ *   egk_slab_input_next(x2, bias, x_out): the NEXT call of egk_rowln_fwd, egk_graphln_fwd or egk_pe_add_table (f32 rows of <= 1024
+ *     columns, a multiple of 4) reads its input as (x[r, c] + x2[r, c]) + bias[c] -- the reduce launch's arithmetic, the same bits --
+ *     and stores that value to x_out[r, c] for later readers (reference: the Linear in front of nn.LayerNorm / gnn.LayerNorm /
+ *     PositionalEncoding in models/temporal_pooling/trn_pooling.py:28-45, models/graph.py:39-63).  NULLs disarm.
+ *   egk_gemm_reduce_slabs: the reduce launch by itself, for slabs nobody consumed that way. */
+int egk_gemm_defer_reduce_next(int32_t on);
+int egk_slab_input_next(const float* x2, const float* bias, float* x_out);
+int egk_gemm_reduce_slabs(egk_stream_t s, const float* ws, int32_t splitk, int32_t M, int32_t N, const float* bias, float* C, int64_t ldc);
+
 /* ---- dense contractions (MFMA) ---------------------------------------------------------
  * C[M,N] = act(alpha * (op(A) . op(B)^T) + (accumulate ? C : 0) + bias[n]) + residual[m,n]
  * where the contraction runs over K = K1 + K2 with a two-source split:

@@ -398,3 +398,51 @@ def test_one_pass_backbone_graph_from_the_precise_passs_tape(ops):
         if float(ref[k].norm()) > 1e-6:
             e1, e0 = _rel(got[k].cpu(), ref[k].cpu()), _rel(want[k].cpu(), ref[k].cpu())
             assert e1 < max(1.25 * e0, 2e-2), (k, e1, e0)
+
+
+def test_precise_pass_without_reduce_launches_is_the_same_pass(ops):
+    """The precise pass's contractions that split K leave their two slabs to the row kernel that reads the result next (row
+    LayerNorm, graph LayerNorm, PE add: egk_gemm_defer_reduce_next / egk_slab_input_next) instead of launching the reduce: same
+    arithmetic in the same order ((slab 0 + slab 1) + bias), so the pass's output, every taped tensor and the statistics are the
+    SAME BITS as with the reduce launches -- at the size where the policy splits (2048 rows, H = 1024)."""
+    from egopack_amd import data as D
+    from egopack_amd.models import Graph
+    torch.manual_seed(3)
+    F_IN, S, H = 256, 3, 1024
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": H}
+    model = Graph(F_IN, hidden_size=H, depth=3, temporal_pooling=trn, num_segments=S).to(DEV).eval()
+    ds = D.SyntheticTaskDataset("ar", 64, 32, S, F_IN, (13, 17), k=1, seed=5)
+    host = D.collate([ds[i] for i in range(64)])
+    host.x = host.x.to(torch.bfloat16)
+    dev = host.to(DEV)
+    taken = []
+    real = ops._slab_consumer
+
+    def counting(x, cols_max=1024):
+        out = real(x, cols_max)
+        taken.append(out[1])
+        return out
+
+    def run(on):
+        prev = ops._slab_defer["on"]
+        ops._slab_defer["on"] = on
+        try:
+            with ops.compute_mode("bf16"), torch.no_grad(), ops.precise_scope(), ops.dual_record() as tape:
+                f = model(dev)
+            torch.cuda.synchronize()
+            return f.clone(), [(k, {n: t.clone() for n, t in ts.items() if torch.is_tensor(t)}) for k, ts in tape]
+        finally:
+            ops._slab_defer["on"] = prev
+    ops._slab_consumer = counting
+    try:
+        f1, t1 = run(True)
+    finally:
+        ops._slab_consumer = real
+    f0, t0 = run(False)
+    assert sum(taken) >= 5, taken  # (two row LayerNorms, the PE add, three graph LayerNorms at this size)
+    assert torch.equal(f1, f0)
+    assert [k for k, _ in t1] == [k for k, _ in t0]
+    for (k, a), (_, b) in zip(t1, t0):
+        assert a.keys() == b.keys(), k
+        for n in a:
+            assert torch.equal(a[n], b[n]), (k, n)
