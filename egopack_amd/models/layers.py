@@ -11,8 +11,9 @@ class Linear(nn.Linear):
     """nn.Linear / gnn.Linear parameters (kaiming-uniform(a=sqrt 5), bias U(+-1/sqrt(fan_in)));
     forward = one MFMA launch with the bias (and optional ReLU / residual) in the epilogue."""
 
-    def forward(self, x, residual=None, relu=False, out_f32=False, ln_in=None, res_sink=None):
-        return ops.linear(x, self.weight, self.bias, residual=residual, relu=relu, out_f32=out_f32, ln_in=ln_in, res_sink=res_sink)
+    def forward(self, x, residual=None, relu=False, out_f32=False, ln_in=None, res_sink=None, slab_ok=False):
+        return ops.linear(x, self.weight, self.bias, residual=residual, relu=relu, out_f32=out_f32, ln_in=ln_in, res_sink=res_sink,
+                          slab_ok=slab_ok)
 
 
 class LayerNorm(nn.LayerNorm):

@@ -45,7 +45,7 @@ class TRNPooling(TemporalPooling):
         if isinstance(x, (list, tuple)):
             h0 = ops.multi_linear([self._rows(b) for b in x], p[0].weight, p[0].bias)
         else:
-            h0 = p[0](self._rows(x))
+            h0 = p[0](self._rows(x), slab_ok=True)  # (read by the LayerNorm below and by nothing else: ops.linear)
         h = p[1](h0, relu=True, p=self.dropout)
-        h = p[5](p[4](h), relu=True, p=self.dropout)
+        h = p[5](p[4](h, slab_ok=True), relu=True, p=self.dropout)
         return p[8](h)

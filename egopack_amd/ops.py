@@ -80,6 +80,25 @@ def _materialise_virtual(t: torch.Tensor) -> None:
                              C.c_void_p(t.data_ptr()), F32, src.numel()), "egk_cast")
 
 
+_slab_pending = []  # weak references to results whose reduce launch is still owed (``precise_scope`` settles them on its way out)
+
+
+def _slab_mark(t: torch.Tensor, ws, M: int, N: int, bias) -> None:
+    import weakref
+    t._egk_slabs = (ws, M, N, bias)
+    _slab_pending.append(weakref.ref(t))
+
+
+def _slabs_settle() -> None:
+    """Run the reduce launch of every result that still owes one (nobody slab-aware read it): nothing unreduced outlives the
+    scope it was made in."""
+    pending, _slab_pending[:] = list(_slab_pending), []
+    for r in pending:
+        t = r()
+        if t is not None and getattr(t, "_egk_slabs", None) is not None:
+            _materialise_slabs(t)
+
+
 def _materialise_slabs(t: torch.Tensor) -> None:
     """The result of a split contraction whose reduce launch was left out (``gemm(defer_reduce=True)``: its two K slabs sit in a
     private workspace) is about to be read by something that does not take slabs: run the reduce launch now."""
@@ -475,6 +494,7 @@ class precise_scope:
         return self
 
     def __exit__(self, *a):
+        _slabs_settle()
         set_compute(self.prev_mode)
         _x3["cache"] = self.prev_cache
 
@@ -599,16 +619,17 @@ def _tee_done(y: torch.Tensor, halves) -> None:
         _x3["cache"][(y.data_ptr(), rows, cols, cols, y._version)] = (halves[0], halves[1], y)
 
 
-def _gemm_deferrable(args, kw) -> None:
+def _gemm_deferrable(args, kw, slab_ok: bool = True) -> None:
     """``gemm(*args, **kw)`` of the precise pass (no gradient, inside a precise_scope, a plain f32 result with at most a bias): a
-    launch that splits K in two leaves its slabs to the row kernel that reads the result next (``out._egk_slabs``, ``_slab_consumer``)."""
+    launch that splits K in two leaves its slabs to the row kernel that reads the result next (``out._egk_slabs``, ``_slab_consumer``)
+    -- when the caller knows that such a kernel is what follows (``slab_ok``)."""
     M, N, out = args[0], args[1], args[7]
-    defer = (kw.get("compute") == X3 and _slab_defer["on"] and _x3["cache"] is not None and not torch.is_grad_enabled()
+    defer = (slab_ok and kw.get("compute") == X3 and _slab_defer["on"] and _x3["cache"] is not None and not torch.is_grad_enabled()
              and not kw.get("act") and kw.get("residual") is None and not kw.get("accumulate") and out.dtype == torch.float32
              and out.is_contiguous() and args[8] == N and N <= 1024 and N % 4 == 0)
     ws = gemm(*args, defer_reduce=defer, **kw)
     if ws is not None:
-        out._egk_slabs = (ws, M, N, kw.get("bias"))
+        _slab_mark(out, ws, M, N, kw.get("bias"))
 
 
 def _gemm_with_stats(args, kw, stats):
@@ -1284,7 +1305,7 @@ def _r16(taped, name: str) -> torch.Tensor:
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32, ln_in=None, res_sink=None):
+    def forward(ctx, x, W, b, x2, W2, residual, relu, compute, out_f32, ln_in=None, res_sink=None, slab_ok=False):
         _need_gpu(x, W)
         if not (compute == X3 and getattr(x, "_egk_virtual", False) and x.is_contiguous()):
             x = _c(x)  # (a lazily widened bf16 input stays unwritten: the three-product contraction reads its bf16 source)
@@ -1311,12 +1332,14 @@ class _Linear(torch.autograd.Function):
             bias_c = _f32c(b) if b is not None else None
             # the precise pass (no gradient, inside a precise_scope): a launch that splits K leaves its slabs for the row kernel
             # that reads the result next (row LayerNorm, graph LayerNorm, PE add: ``_slab_consumer``) instead of a reduce launch
-            defer = (compute == X3 and _slab_defer["on"] and _x3["cache"] is not None and not torch.is_grad_enabled() and not relu
-                     and res is None and y.dtype == torch.float32 and y.is_contiguous() and N <= 1024 and N % 4 == 0)
+            # -- ONLY where the caller says that such a kernel is what reads the result (``slab_ok``): an unreduced tensor must never
+            # reach anything that reads memory without asking this module for the pointer (torch operators, .cpu())
+            defer = (slab_ok and compute == X3 and _slab_defer["on"] and _x3["cache"] is not None and not torch.is_grad_enabled()
+                     and not relu and res is None and y.dtype == torch.float32 and y.is_contiguous() and N <= 1024 and N % 4 == 0)
             ws = gemm(M, N, x, K1, Wop, K1, K1, y, y.stride(0), A2=x2, lda2=K2, B2=W2op, ldb2=K2, K2=K2, bias=bias_c, residual=res,
                       ldr=N, act=1 if relu else 0, compute=compute, defer_reduce=defer)
             if ws is not None:
-                y._egk_slabs = (ws, M, N, bias_c)
+                _slab_mark(y, ws, M, N, bias_c)
             if not out_f32:
                 _tape_put("linear", y=y)
         ctx.relu, ctx.compute = relu, compute
@@ -1421,7 +1444,7 @@ class _Linear(torch.autograd.Function):
             # which adds it in its dX epilogue) instead of to autograd, which would add the two gradients of x in a pass
             ctx.res_sink["dy"] = dres
             dres = None
-        return dx, dW, db, dx2, dW2, dres, None, None, None, None, None
+        return dx, dW, db, dx2, dW2, dres, None, None, None, None, None, None
 
 
 def _compute_for(x):
@@ -1605,13 +1628,17 @@ def grouped_classifier_banks(xs, views_list, fused_loss: bool = False, compute=N
     return outs
 
 
-def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False, ln_in=None, res_sink=None):
+def linear(x, W, b=None, *, x2=None, W2=None, residual=None, relu=False, compute=None, out_f32=False, ln_in=None, res_sink=None,
+           slab_ok=False):
     """y = relu?(x @ W.T (+ x2 @ W2.T) + b) (+ residual): one MFMA launch.  ``out_f32`` keeps the result
     in f32 whatever the activation type (logits).  ``ln_in``: the context of the graph LayerNorm that produced x
     (``graph_layernorm_lrelu(..., return_ctx=True)``): its backward sums are then taken in this layer's dX epilogue.
     ``res_sink``: a dict -- in backward the gradient of ``residual`` is put there (key 'dy') instead of being returned to
-    autograd; the caller guarantees that a node earlier in the graph (``sage_mean_layer(..., res_src=)``) adds it."""
-    return _Linear.apply(x, W, b, x2, W2, residual, relu, _compute_for(x) if compute is None else compute, out_f32, ln_in, res_sink)
+    autograd; the caller guarantees that a node earlier in the graph (``sage_mean_layer(..., res_src=)``) adds it.
+    ``slab_ok``: the caller hands the result STRAIGHT to ``row_layernorm`` / ``graph_layernorm_lrelu`` / ``pe_add`` and to nothing
+    else -- in the forward-only precise pass a launch that splits K may then leave its slabs to that kernel (``_slab_consumer``)."""
+    return _Linear.apply(x, W, b, x2, W2, residual, relu, _compute_for(x) if compute is None else compute, out_f32, ln_in, res_sink,
+                         bool(slab_ok))
 
 
 class _MultiLinear(torch.autograd.Function):
@@ -2563,7 +2590,7 @@ class _SageMean(torch.autograd.Function):
                 ln_out["partials"] = _gemm_with_stats(c_args, c_kw, dict(mode=1, seg_ptr=ln_out["seg_ptr"], n_seg=ln_out["n_seg"],
                                                                          min_rows=ln_out["min_rows"]))
             else:
-                _gemm_deferrable(c_args, c_kw)
+                _gemm_deferrable(c_args, c_kw, slab_ok=ln_out is not None)  # (``ln_out``: a graph LayerNorm is what reads ``out``)
             _tape_put("sage_mean", xp=xp, agg=agg, out=out)
         ctx.ln_in, ctx.res_src = ln_in, res_src
         ctx.compute, ctx.params = compute, (Wp, bp, Wl, bl, Wr)

@@ -439,10 +439,52 @@ def test_precise_pass_without_reduce_launches_is_the_same_pass(ops):
     finally:
         ops._slab_consumer = real
     f0, t0 = run(False)
-    assert sum(taken) >= 5, taken  # (two row LayerNorms, the PE add, three graph LayerNorms at this size)
+    assert sum(taken) >= 4, taken  # (the row LayerNorms behind launches that split K in two, three graph LayerNorms at this size)
     assert torch.equal(f1, f0)
     assert [k for k, _ in t1] == [k for k, _ in t0]
     for (k, a), (_, b) in zip(t1, t0):
         assert a.keys() == b.keys(), k
         for n in a:
             assert torch.equal(a[n], b[n]), (k, n)
+
+
+def test_slab_aware_row_kernels_equal_the_reduce_launch(ops):
+    """ops.linear(slab_ok=True) inside a precise_scope at a size where the launch splits K in two, followed by each slab-aware
+    consumer (row LayerNorm, graph LayerNorm + LeakyReLU, PE add): the consumer's result AND the linear's result (which the
+    consumer stores on its way) equal the path with the reduce launch, bit for bit; a result that nobody slab-aware reads is
+    reduced when anything asks for its pointer, and at the latest when the scope ends (never readable unreduced)."""
+    torch.manual_seed(9)
+    M, K, N = 2048, 1024, 1024
+    x = torch.randn(M, K, device=DEV)
+    W, b = torch.randn(N, K, device=DEV) * 0.03, torch.randn(N, device=DEV)
+    lw, lb = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    seg = torch.tensor([0, 700, M], dtype=torch.int32, device=DEV)
+    pos = torch.arange(M, device=DEV, dtype=torch.int64) % 32
+    freq = torch.logspace(0, 1, N // 2, 1e-4).to(DEV)
+
+    def run(kind, slab_ok):
+        with ops.compute_mode("bf16"), torch.no_grad(), ops.precise_scope():
+            y = ops.linear(x, W, b, slab_ok=slab_ok)
+            owed = getattr(y, "_egk_slabs", None) is not None
+            if kind == "rowln":
+                z = ops.row_layernorm(y, lw, lb, 1e-5, relu=True)
+            elif kind == "graphln":
+                z = ops.graph_layernorm_lrelu(y, lw, lb, seg, 1e-5, 0.2)
+            elif kind == "pe":
+                z = ops.pe_add(y, pos, freq, (0, 31))
+            elif kind == "pointer":
+                z = ops.cast_raw(y, torch.bfloat16)  # (not slab-aware: asks for the pointer -> the reduce launch runs first)
+            else:
+                z = None  # nobody reads it inside the scope
+            still = getattr(y, "_egk_slabs", None) is not None
+        assert getattr(y, "_egk_slabs", None) is None  # settled by the scope at the latest
+        torch.cuda.synchronize()
+        return y.clone(), None if z is None else z.clone(), owed, still
+    for kind in ("rowln", "graphln", "pe", "pointer", "escape"):
+        y1, z1, owed1, still1 = run(kind, True)
+        y0, z0, owed0, still0 = run(kind, False)
+        assert owed1 and not owed0, kind  # (the flagged launch split K in two and left its slabs)
+        assert still1 == (kind == "escape"), kind
+        assert torch.equal(y1, y0), kind
+        if z1 is not None:
+            assert torch.equal(z1, z0), kind
