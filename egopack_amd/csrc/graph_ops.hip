@@ -992,7 +992,8 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
                                                           long long ldf, TopkWindowBanks tb, long long ldb,
                                                           const float* __restrict__ f_inv, long long* __restrict__ nn,
                                                           int* __restrict__ cand, int rows, int K, int H, int k, int vec) {
-    __shared__ int s_cand[WPB][64];
+    constexpr int CAND_CAP = 512;  // candidates listed per row (real prototype banks: 30-90 per row, up to ~200; beyond: the rescan)
+    __shared__ int s_cand[WPB][CAND_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         const int grp = row / tb.rows_per_group;  // (wave-uniform)
@@ -1079,7 +1080,7 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
         }
         const float T = Dk + 2.f * E;  // (fewer than k lanes with a finite minimum: Dk = inf, every finite distance is a candidate)
 
-        // ---- pass 2a: the candidates' indices, listed per wave (LDS; more than 64 of them: the rescan below) ------------------------
+        // ---- pass 2a: the candidates' indices, listed per wave (LDS; more than CAND_CAP of them: the rescan below) -----------------
         volatile int* cl = s_cand[wave];
         int n_cand = 0;
         for (int base0 = 0; base0 < K; base0 += 1024) {
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
                     const unsigned long long mask = __ballot(pred);
                     if (mask) {  // (wave-uniform)
                         const int slot = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        if (pred && slot < 64) cl[slot] = j;
+                        if (pred && slot < CAND_CAP) cl[slot] = j;
                         n_cand += __popcll(mask);
                     }
                 }
@@ -1146,7 +1147,7 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
             acc = wave_sum(acc);
             keep(1.f - (float)acc * fi * b_inv[jj], jj);
         };
-        if (n_cand > 64) {
+        if (n_cand > CAND_CAP) {
             // a crowded row: every candidate in scan order, one at a time (slow, never wrong)
             for (int j0 = 0; j0 < K; j0 += 64) {
                 const int j = j0 + lane;

@@ -152,9 +152,63 @@ class StagedBatches:
             done.record(self.copy_stream)
         return staged, done
 
+    def _ahead(self):
+        """``_fetch`` results from a worker thread, up to two steps ahead.  The host side of a step of the headline workload --
+        whole-batch builders 0.65 ms, packing + staging 0.55 ms, ~2700 Python calls -- was issued by the training thread behind
+        its own ``train_step``: 1.6-1.9 ms per step against 1.41 ms of device time, a host-bound loop (main_temporal.py at 75 % of
+        the bench line, main_egopack.py -- 1 ms of hipGraphLaunch per replay -- at 65 %).  The worker builds and stages while the
+        training thread sits in the graph launch (which releases the interpreter lock).  Captures use the thread-local capture
+        mode (CAPTURE_MODE), the copy stream and its allocations are this iterator's own, the library's one-shot launch state
+        is per host thread: the worker's launches are legal at any time.  EGK_DISABLE=stage_thread: the in-line fetch."""
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=2), threading.Event()
+        dev = torch.device(self.device)
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                if dev.type == "cuda":
+                    torch.cuda.set_device(dev)
+                while not stop.is_set():
+                    item = self._fetch()
+                    if not put(item) or item is None:
+                        return
+            except BaseException as e:  # noqa: BLE001  (handed to the consumer, which re-raises it)
+                put(e)
+        th = threading.Thread(target=work, name="egk-stage", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                if item is None:
+                    return
+                yield item
+        finally:
+            stop.set()
+            th.join(timeout=5.0)
+
     def __iter__(self):
-        nxt = self._fetch()
-        while nxt is not None:
+        if self.copy_stream is not None and "stage_thread" not in os.environ.get("EGK_DISABLE", ""):
+            source = self._ahead()
+        else:
+            def inline():
+                nxt = self._fetch()
+                while nxt is not None:
+                    yield nxt
+                    nxt = self._fetch()  # issued right after the consumer launched its step: overlaps it
+            source = inline()
+        for nxt in source:
             (batches, merged), done = nxt
             if done is not None:
                 cur = torch.cuda.current_stream()
@@ -169,7 +223,6 @@ class StagedBatches:
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(cur)  # allocated on the copy stream, consumed here
             yield batches, merged
-            nxt = self._fetch()  # issued right after the consumer launched its step: overlaps it
 
 
 # ---- static-shape batches: what a captured step may be replayed on ----------------------------------------------------

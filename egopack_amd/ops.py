@@ -3658,9 +3658,16 @@ def nearest_prototypes_grouped(feats, banks, k, bank_norms):
     cand = _window_stats["cand"]
     if cand is not None and (cand.numel() != G * N or cand.device != base.device):
         cand = None
+    dbg = "window_cand" in os.environ.get("EGK_DBG", "") and not torch.cuda.is_current_stream_capturing()
+    if dbg and cand is None:
+        cand = torch.zeros(G * N, dtype=torch.int32, device=base.device)
     arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
     _ck(lib.egk_topk_window_group(_stream(), _p(dot), K, _p(base), base.stride(0), arr(banks), banks[0].stride(0), _p(f_norm),
                                   arr(bank_norms), arr([o[1] for o in ops_b]), _p(nn), _p(cand), G, N, K, H, k), "egk_topk_window_group")
+    if dbg:
+        c = cand.view(G, N).float()
+        print(f"[window_cand] K={K} k={k}: candidates per row mean {[round(float(v), 1) for v in c.mean(1)]} max {[int(v) for v in c.max(1).values]} "
+              f"rb_max {[float(o[1]) for o in ops_b]}", flush=True)
     return [nn[g * N:(g + 1) * N] for g in range(G)], hi
 
 

@@ -71,6 +71,22 @@ def live(workers: int, steps: int):
     hosts = (dict(zip(order, b)) for b in D.multiloader([loaders.get(t) for t in order], [w[t] for t in order]))
     warm, n, t0 = 30, 0, None
     prof = None
+    parts = {"replay": 0.0, "fetch": 0.0, "train_step": 0.0}
+    if "--parts" in sys.argv:  # host time per step of the graph launch, the fetch of the next batch and train_step as a whole
+        real_replay, real_fetch, real_ts = step.replay, engine.StagedBatches._fetch, step.train_step
+
+        def timed(name, fn):
+            def w(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    if t0 is not None:
+                        parts[name] += time.perf_counter() - t
+            return w
+        step.replay = timed("replay", real_replay)
+        engine.StagedBatches._fetch = timed("fetch", real_fetch)
+        step.train_step = timed("train_step", real_ts)
     for batches, merged in engine.StagedBatches(hosts, dev, order, fused=True, store=store, dtype=ops.act_dtype()):
         if n == warm:
             torch.cuda.synchronize()
@@ -88,6 +104,8 @@ def live(workers: int, steps: int):
                 import pstats
                 prof.disable()
                 pstats.Stats(prof).sort_stats("cumtime").print_stats(40)
+            if "--parts" in sys.argv:
+                print("host ms / step: " + ", ".join(f"{k} {v * 1e3 / steps:.3f}" for k, v in parts.items()), flush=True)
             print(f"live loaders (workers per loader = {workers}): {ms:.3f} ms/step ({192 / ms * 1e3:.0f} clip-seqs/s), "
                   f"replayed {step.loop_counts['replayed']} / eager {step.loop_counts['eager']}", flush=True)
     for dl in loaders.values():
