@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("n_extra", i32), ("xK", i32 * 4), ("xA", vp * 4), ("xB", vp * 4), ("xlda", i64 * 4), ("xldb", i64 * 4),
         ("ga_mode", i32), ("ga_tile_mask", i32), ("ga_skip_c", i32), ("ga_rowptr", vp), ("ga_col", vp), ("ga_wgt", vp),
         ("ga_band", vp), ("ga_gate", vp), ("ga_out", vp), ("ga_ld", i64),
-        ("sk_tickets", vp),
+        ("sk_tickets", vp), ("op_f16", i32),
     ]
 
 
@@ -123,6 +123,9 @@ SIGNATURES = {
     "egk_slab_input_next": (C.c_int, [vp, vp, vp]),
     "egk_gemm_reduce_slabs": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, i64]),
     "egk_topk_window_group": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]),
+    "egk_topk_window_group16": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32]),
+    "egk_residual_ratio16": (C.c_int, [vp, vp, i64, vp, vp, i32, i32, i32]),
+    "egk_cast_f16": (C.c_int, [vp, vp, vp, i64]),
     "egk_bf16_residual_ratio": (C.c_int, [vp, vp, i64, vp, vp, i32, i32]),
     "egk_gather_max_bank_grad": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     "egk_segment_sum_rows_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32]),

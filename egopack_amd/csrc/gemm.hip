@@ -814,7 +814,17 @@ struct OperandCursor {
 // MB = 2, KG = 1: 8 waves as 4 x 2 over a 256 x 128 tile, one workgroup per CU.  A CU takes in ~70 GB/s from L2
 //         whatever the kernel does (MI355X_MICROARCH.md, gather-into-LDS table), so bytes fetched per flop bound the
 //         rate: 48 KiB per K tile for 2 x the flops of the 32 KiB of a 128 x 128 tile.  For large outputs.
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false, bool GA = false>
+// F16: the 16-bit operands are IEEE half (v_mfma_f32_16x16x32_f16) instead of bf16 -- same images, same fragment reads, same
+// accumulation; 11 significand bits instead of 8: the one-product screen of the nearest-prototype search (egk_topk_window) gets an
+// error window eight times narrower.  Only the instantiations the host asks for (gemm_f16 below) exist.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const uint4& b, const uint4& a, const f32x4& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+}
+
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false, bool GA = false, bool F16 = false>
 __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid) {
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
@@ -1000,16 +1010,14 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0[j]),
-                                                                    __builtin_bit_cast(bf16x8, a0[i]), acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(b0[j], a0[i], acc[i][j]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1[j]),
-                                                                    __builtin_bit_cast(bf16x8, a1[i]), acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(b1[j], a1[i], acc[i][j]);
         if constexpr (TRA) {
             if (do_bias) {  // (the reads above completed at the lgkmcnt(0))
 #pragma unroll
@@ -1188,9 +1196,9 @@ __device__ __forceinline__ void splitk_finish_in_launch(const GemmArgs& g, int b
     }
 }
 
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool GA = false>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool GA = false, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
-    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, GA>(g, blockIdx.x);
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, GA, F16>(g, blockIdx.x);
     if constexpr (!GA) {
         if (g.sk_tickets != nullptr) splitk_finish_in_launch<32 * NI * MB>(g, blockIdx.x);  // (uniform; only with splitk > 1)
     }
@@ -1210,7 +1218,7 @@ struct GemmGroup {
     GemmArgs p[MAX_GROUPS];
     int packed, count, total;  // packed placement: number of problems, total tile count
 };
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(const GemmGroup gg) {
     if (gg.packed) {
         const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
@@ -1223,12 +1231,12 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(con
             if (v < t) break;
             v -= t;
         }
-        gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, true>(gg.p[pi], v);
+        gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, true, false, F16>(gg.p[pi], v);
         return;
     }
     const GemmArgs& g = gg.p[blockIdx.y];
     if ((int)blockIdx.x >= g.tiles_m * g.tiles_n * g.splitk) return;
-    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI>(g, blockIdx.x);
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, false, F16>(g, blockIdx.x);
 }
 
 
@@ -2148,6 +2156,7 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 1, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -2322,6 +2331,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
     EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
     EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
     EGK_REQUIRE(d->compute == EGK_COMPUTE_F32 || d->compute == EGK_COMPUTE_BF16, "egk_gemm: bad compute type");
+    EGK_REQUIRE(!d->op_f16, "egk_gemm: op_f16 is a grouped-launch feature (egk_gemm_grouped with >= 2 problems)");
     const bool a16 = d->a_dtype == EGK_BF16, b16 = d->b_dtype == EGK_BF16;
     EGK_REQUIRE((d->a_dtype == EGK_F32 || a16) && (d->b_dtype == EGK_F32 || b16) &&
                     (d->c_dtype == EGK_F32 || d->c_dtype == EGK_BF16) &&
@@ -2725,6 +2735,8 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     GemmGroup gg;
     const bool ta = descs[0].transA != 0, tb = descs[0].transB != 0;
     const bool f32g = descs[0].compute == EGK_COMPUTE_F32;
+    const bool f16 = descs[0].op_f16 != 0;
+    EGK_REQUIRE(!f16 || (!ta && !tb && !f32g), "egk_gemm_grouped: op_f16 takes row-major 16-bit operands");
     double flops = 0, bytes = 0;
     long long t128 = 0, t96 = 0, t64 = 0;
     int min_nkt = 1 << 30;
@@ -2732,6 +2744,8 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         const egk_gemm_desc* d = descs + i;
         EGK_REQUIRE((d->transA != 0) == ta && (d->transB != 0) == tb, "egk_gemm_grouped: the problems must share one layout");
         EGK_REQUIRE((d->compute == EGK_COMPUTE_F32) == f32g, "egk_gemm_grouped: the problems must share one compute type");
+        EGK_REQUIRE((d->op_f16 != 0) == f16, "egk_gemm_grouped: the problems must agree on op_f16");
+        EGK_REQUIRE(!f16 || (!d->st_mode && !d->ga_mode && !d->dbias && d->n_extra == 0), "egk_gemm_grouped: op_f16 has no statistics / gather / bias-gradient epilogue");
         const int rc = fill_group_args(d, gg.p[i]);
         if (rc) return rc;
         int K = d->K1 + d->K2;
@@ -2781,6 +2795,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     }
     if (g_use_pipe == 3 || g_use_pipe == 5) variant = g_use_pipe;
     if ((g_use_pipe == 8 || g_use_pipe == 11) && !ta) variant = g_use_pipe;
+    if (f16) variant = 3;  // (one instantiation: 128 x 128 tiles, one wave group)
     int max_wg = 0, total = 0;
     for (int i = 0; i < count; ++i) {
         GemmArgs& g = gg.p[i];
@@ -2820,7 +2835,10 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     }
     {
         ProfScope prof(KID_GEMM_BF16_GROUP_NN + layout, s, flops, bytes);  // (layout 0 nn, 1 nt, 2 tt)
-        if (!ta && variant == 11) {
+        if (f16) {
+            ensure_lds_attr();
+            hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 4, true>), pgrid, pblock, 2 * 32768, s, gg);
+        } else if (!ta && variant == 11) {
             if (!tb) hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);
             else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);
         } else if (!ta && variant == 8) {

@@ -953,19 +953,40 @@ __device__ __forceinline__ float bf16_rne_f32(float x) {
     return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);  // (finite inputs: features / prototypes)
 }
 
+// (the f16 screen: the IEEE-half nearest to x -- inf beyond 65504, which makes the residual ratio, the window and with it the
+//  candidate list unbounded: slow, never wrong)
+__device__ __forceinline__ float f16_rne_f32(float x) { return (float)(_Float16)x; }
+template <bool F16>
+__device__ __forceinline__ float round16(float x) { return F16 ? f16_rne_f32(x) : bf16_rne_f32(x); }
+
+template <bool F16>
 __global__ __launch_bounds__(256) void bf16_residual_ratio_kernel(const float* __restrict__ x, long long ld, float* __restrict__ r,
                                                                   int rows, int cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
         float s2 = 0.f, r2 = 0.f;
         for (int c = lane; c < cols; c += 64) {
-            const float v = x[(long long)row * ld + c], d = v - bf16_rne_f32(v);
+            const float v = x[(long long)row * ld + c], d = v - round16<F16>(v);
             s2 += v * v;
             r2 += d * d;
         }
         s2 = wave_sum(s2);
         r2 = wave_sum(r2);
         if (lane == 0) r[row] = s2 > 0.f ? sqrtf(r2 / s2) : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long n) {
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            const _Float16 h[4] = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<uint2*>(y + i) = *reinterpret_cast<const uint2*>(h);
+        } else {
+            for (long long j = i; j < n; ++j) {
+                const _Float16 h = (_Float16)x[j];
+                y[j] = *reinterpret_cast<const unsigned short*>(&h);
+            }
+        }
     }
 }
 __global__ __launch_bounds__(256) void max_of_kernel(const float* __restrict__ r, float* __restrict__ out, int n) {
@@ -985,6 +1006,7 @@ struct TopkWindowBanks {
     const float* b_inv[8];
     const float* rb_max[8];
     int rows_per_group;
+    int screen_f16;  // dot1 came from IEEE-half roundings of the operands (else bf16): the row's own residual is taken accordingly
 };
 
 template <int KM>
@@ -1015,14 +1037,14 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
                 const float e[4] = {fv[u].x, fv[u].y, fv[u].z, fv[u].w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float d = e[t] - bf16_rne_f32(e[t]);
+                    const float d = e[t] - (tb.screen_f16 ? f16_rne_f32(e[t]) : bf16_rne_f32(e[t]));
                     s2 += e[t] * e[t];
                     r2 += d * d;
                 }
             }
         } else {
             for (int c = lane; c < H; c += 64) {
-                const float v = fr[c], d = v - bf16_rne_f32(v);
+                const float v = fr[c], d = v - (tb.screen_f16 ? f16_rne_f32(v) : bf16_rne_f32(v));
                 s2 += v * v;
                 r2 += d * d;
             }
@@ -1107,7 +1129,7 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
                 for (int t = 0; t < 4; ++t) {
                     const int j = base0 + lane * 4 + 256 * u + t;
                     const float d = 1.f - dq[u][t] * fi * bq[u][t];
-                    const bool pred = j < K && d <= T;
+                    const bool pred = j < K && !(d > T);  // (a NaN screen value -- an operand beyond the half range -- is a candidate)
                     const unsigned long long mask = __ballot(pred);
                     if (mask) {  // (wave-uniform)
                         const int slot = n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -1152,7 +1174,7 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
             for (int j0 = 0; j0 < K; j0 += 64) {
                 const int j = j0 + lane;
                 const float d = j < K ? 1.f - dr[j] * fi * b_inv[j] : INFINITY;
-                unsigned long long mask = __ballot(j < K && d <= T);
+                unsigned long long mask = __ballot(j < K && !(d > T));
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -1896,12 +1918,28 @@ int egk_topk_smallest_l2(egk_stream_t stream, const float* dot, int64_t ldd, con
 }
 
 int egk_bf16_residual_ratio(egk_stream_t stream, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols) {
-    EGK_REQUIRE(x && r && rmax, "egk_bf16_residual_ratio: null pointer");
-    EGK_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, "egk_bf16_residual_ratio: bad shape");
+    return egk_residual_ratio16(stream, x, ld, r, rmax, rows, cols, 0);
+}
+
+int egk_residual_ratio16(egk_stream_t stream, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols, int32_t f16) {
+    EGK_REQUIRE(x && r && rmax, "egk_residual_ratio16: null pointer");
+    EGK_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, "egk_residual_ratio16: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bf16_residual_ratio_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, (long long)ld, r, rows, cols);
+    if (f16) hipLaunchKernelGGL(bf16_residual_ratio_kernel<true>, dim3(row_grid(rows)), dim3(256), 0, s, x, (long long)ld, r, rows, cols);
+    else hipLaunchKernelGGL(bf16_residual_ratio_kernel<false>, dim3(row_grid(rows)), dim3(256), 0, s, x, (long long)ld, r, rows, cols);
     hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(256), 0, s, r, rmax, rows);
-    return check_launch("egk_bf16_residual_ratio");
+    return check_launch("egk_residual_ratio16");
+}
+
+int egk_cast_f16(egk_stream_t stream, const float* x, void* y, int64_t n) {
+    EGK_REQUIRE(x && y && n >= 0, "egk_cast_f16: bad arguments");
+    EGK_REQUIRE(((reinterpret_cast<uintptr_t>(x) & 15) | (reinterpret_cast<uintptr_t>(y) & 7)) == 0, "egk_cast_f16: unaligned buffers");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, x, (unsigned short*)y,
+                       (long long)n);
+    return check_launch("egk_cast_f16");
 }
 
 int egk_topk_window(egk_stream_t stream, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* bank, int64_t ldb,
@@ -1920,6 +1958,12 @@ int egk_topk_window(egk_stream_t stream, const float* dot1, int64_t ldd, const f
 int egk_topk_window_group(egk_stream_t stream, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* const* banks,
                           int64_t ldb, const float* f_inv, const float* const* b_invs, const float* const* rb_maxs, int64_t* nn,
                           int32_t* cand, int32_t n_groups, int32_t rows_per_group, int32_t K, int32_t H, int32_t k) {
+    return egk_topk_window_group16(stream, dot1, ldd, f, ldf, banks, ldb, f_inv, b_invs, rb_maxs, nn, cand, n_groups, rows_per_group, K, H, k, 0);
+}
+
+int egk_topk_window_group16(egk_stream_t stream, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* const* banks,
+                            int64_t ldb, const float* f_inv, const float* const* b_invs, const float* const* rb_maxs, int64_t* nn,
+                            int32_t* cand, int32_t n_groups, int32_t rows_per_group, int32_t K, int32_t H, int32_t k, int32_t screen_f16) {
     EGK_REQUIRE(dot1 && f && banks && f_inv && b_invs && rb_maxs && nn, "egk_topk_window_group: null pointer");
     EGK_REQUIRE(n_groups >= 1 && n_groups <= 8, "egk_topk_window_group: 1..8 groups");
     EGK_REQUIRE(k >= 1 && k <= 16 && k <= K, "egk_topk_window_group: k must be in [1, min(16, K)]");
@@ -1941,6 +1985,7 @@ int egk_topk_window_group(egk_stream_t stream, const float* dot1, int64_t ldd, c
         vec = vec && ((uintptr_t)b_invs[src] % 16 == 0);
     }
     tb.rows_per_group = rows_per_group;
+    tb.screen_f16 = screen_f16 ? 1 : 0;
     EGK_REQUIRE((uintptr_t)f % 16 == 0, "egk_topk_window_group: feature rows must be 16-byte aligned");
     const dim3 grid(row_grid(rows)), block(256);
     if (k <= 4)

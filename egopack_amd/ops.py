@@ -407,7 +407,7 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
                transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-               dbias=None, into=None, stats=None, gather=None):
+               dbias=None, into=None, stats=None, gather=None, op_f16=False):
     """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array).  ``stats``: per-segment sums of
     the result for the graph LayerNorm that consumes it, taken in the epilogue (``_ln_stats_request``)."""
     op_dt = _dt(A1)
@@ -442,6 +442,7 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
     for i, (xa, xlda, xb, xldb, xk) in enumerate(extra):
         d.xA[i], d.xB[i], d.xlda[i], d.xldb[i], d.xK[i] = xa.data_ptr(), xb.data_ptr(), xlda, xldb, xk
     d.c_dtype = _dt(out)
+    d.op_f16 = 1 if op_f16 else 0  # (grouped launches: the 16-bit operands hold IEEE half values, see nearest_prototypes_grouped)
     d.compute = compute
     d.C, d.ldc = _p(out), ldc
     d.accumulate, d.act, d.alpha = int(accumulate), act, alpha
@@ -3541,6 +3542,7 @@ def row_sq_norm(x):
 # The one-product search (egk_topk_window): per bank the bf16 operand hi(P) and the largest rounding residual ratio of its rows,
 # kept while (address, shape, version) stand -- the banks are frozen (graphONE.py:48) unless GraphONE is built with freeze=False.
 _window_search = {"on": "window_search" not in os.environ.get("EGK_DISABLE", "")}
+_window_f16 = {"on": "window_f16" not in os.environ.get("EGK_DISABLE", "")}  # the grouped search's screen on the f16 matrix instructions
 _window_bank_cache = {}
 _window_stats = {"cand": None}  # development / tests: an int32 [N] tensor here receives the candidates per row of the next search
 
@@ -3550,18 +3552,27 @@ def _window_search_ok(N, K, H, k, f, bank) -> bool:
                 and bank.stride(0) % 4 == 0 and f.data_ptr() % 16 == 0 and bank.data_ptr() % 16 == 0 and N > 0)
 
 
-def _bank_window_operand(bank):
-    key = (bank.data_ptr(), tuple(bank.shape), bank.device.index)
+def _cast_f16_bits(x: torch.Tensor) -> torch.Tensor:
+    """IEEE-half rounding of an f32 matrix, held in a bf16-TYPED tensor (16-bit words: the contraction descriptors know one 16-bit
+    storage type; ``op_f16`` tells the launch what the words mean)."""
+    x = _c(x)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _ck(_lib.load().egk_cast_f16(_stream(), _p(x), _p(y), x.numel()), "egk_cast_f16")
+    return y
+
+
+def _bank_window_operand(bank, f16: bool = False):
+    key = (bank.data_ptr(), tuple(bank.shape), bank.device.index, bool(f16))
     hit = _window_bank_cache.get(key)
     if hit is not None and hit[0] == bank._version:
         return hit[1], hit[2]
     if len(_window_bank_cache) > 64:
         _window_bank_cache.clear()
-    hi = cast_raw(bank, torch.bfloat16)
+    hi = _cast_f16_bits(bank) if f16 else cast_raw(bank, torch.bfloat16)
     r = torch.empty(bank.shape[0], dtype=torch.float32, device=bank.device)
     rmax = torch.empty(1, dtype=torch.float32, device=bank.device)
-    _ck(_lib.load().egk_bf16_residual_ratio(_stream(), _p(bank), bank.stride(0), _p(r), _p(rmax), bank.shape[0], bank.shape[1]),
-        "egk_bf16_residual_ratio")
+    _ck(_lib.load().egk_residual_ratio16(_stream(), _p(bank), bank.stride(0), _p(r), _p(rmax), bank.shape[0], bank.shape[1], int(f16)),
+        "egk_residual_ratio16")
     _window_bank_cache[key] = (bank._version, hi, rmax, bank)  # (the bank itself: its address cannot be reused while it is cached)
     return hi, rmax
 
@@ -3651,10 +3662,16 @@ def nearest_prototypes_grouped(feats, banks, k, bank_norms):
     K = banks[0].shape[0]
     f_norm = row_inv_norm(base)
     hi = cast_raw(base, torch.bfloat16)
-    ops_b = [_bank_window_operand(b) for b in banks]
+    # the screen's product from IEEE-half roundings (f16 matrix instructions: 11 significand bits, a window ~8 x narrower than
+    # bf16's -- the prototype banks of a trained model put 30-90 prototypes inside the bf16 window of a row); values beyond the
+    # half range make that row's window unbounded (slow, never wrong).  EGK_DISABLE=window_f16: the bf16 screen.
+    f16 = _window_f16["on"]
+    scr = _cast_f16_bits(base) if f16 else hi
+    ops_b = [_bank_window_operand(b, f16) for b in banks]
     dot = torch.empty((G * N, K), dtype=torch.float32, device=base.device)
     nn = torch.empty((G * N, k), dtype=torch.int64, device=base.device)
-    gemm_grouped([((N, K, hi[g * N:(g + 1) * N], H, ops_b[g][0], H, H, dot[g * N:(g + 1) * N], K), {"compute": BF16}) for g in range(G)])
+    gemm_grouped([((N, K, scr[g * N:(g + 1) * N], H, ops_b[g][0], H, H, dot[g * N:(g + 1) * N], K), {"compute": BF16, "op_f16": f16})
+                  for g in range(G)])
     cand = _window_stats["cand"]
     if cand is not None and (cand.numel() != G * N or cand.device != base.device):
         cand = None
@@ -3662,8 +3679,9 @@ def nearest_prototypes_grouped(feats, banks, k, bank_norms):
     if dbg and cand is None:
         cand = torch.zeros(G * N, dtype=torch.int32, device=base.device)
     arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
-    _ck(lib.egk_topk_window_group(_stream(), _p(dot), K, _p(base), base.stride(0), arr(banks), banks[0].stride(0), _p(f_norm),
-                                  arr(bank_norms), arr([o[1] for o in ops_b]), _p(nn), _p(cand), G, N, K, H, k), "egk_topk_window_group")
+    _ck(lib.egk_topk_window_group16(_stream(), _p(dot), K, _p(base), base.stride(0), arr(banks), banks[0].stride(0), _p(f_norm),
+                                    arr(bank_norms), arr([o[1] for o in ops_b]), _p(nn), _p(cand), G, N, K, H, k, int(f16)),
+        "egk_topk_window_group16")
     if dbg:
         c = cand.view(G, N).float()
         print(f"[window_cand] K={K} k={k}: candidates per row mean {[round(float(v), 1) for v in c.mean(1)]} max {[int(v) for v in c.max(1).values]} "

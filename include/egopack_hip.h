@@ -184,6 +184,11 @@ typedef struct egk_gemm_desc {
      * in-launch path does not take (N not a multiple of 4, unaligned C / residual, the 256 x 256 tile, f32 operands): the reduce
      * launch as before.  egk_gemm_splitk_in_launch() says which. */
     int32_t* sk_tickets;
+    /* 1: the 16-bit operands (a_dtype = b_dtype = EGK_BF16 as the storage width) hold IEEE half values and the launch multiplies
+     * them on the f16 matrix instructions (f32 accumulation): 11 significand bits instead of bf16's 8 -- the one-product screen of
+     * the nearest-prototype search (egk_topk_window_group, screen_f16).  egk_gemm_grouped only, row-major A and B, no split-K /
+     * statistics / gather epilogue; every problem of the launch must agree. */
+    int32_t op_f16;
 } egk_gemm_desc;
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
@@ -455,6 +460,16 @@ int egk_topk_window(egk_stream_t s, const float* dot1, int64_t ldd, const float*
 int egk_topk_window_group(egk_stream_t s, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* const* banks,
                           int64_t ldb, const float* f_inv, const float* const* b_invs, const float* const* rb_maxs, int64_t* nn,
                           int32_t* cand, int32_t n_groups, int32_t rows_per_group, int32_t K, int32_t H, int32_t k);
+/* The same search with the screen's product taken from IEEE-HALF roundings of the operands (screen_f16 = 1; egk_cast_f16,
+ * egk_gemm_grouped with op_f16, egk_residual_ratio16(..., 1)): 11 significand bits instead of bf16's 8 make the proven window
+ * about eight times narrower -- real prototype banks (thousands of class prototypes of trained features) put 30-90 prototypes
+ * inside the bf16 window of a row, 4-12 inside the f16 one.  Same lists (the candidates' distances are exact either way). */
+int egk_topk_window_group16(egk_stream_t s, const float* dot1, int64_t ldd, const float* f, int64_t ldf, const float* const* banks,
+                            int64_t ldb, const float* f_inv, const float* const* b_invs, const float* const* rb_maxs, int64_t* nn,
+                            int32_t* cand, int32_t n_groups, int32_t rows_per_group, int32_t K, int32_t H, int32_t k, int32_t screen_f16);
+int egk_residual_ratio16(egk_stream_t s, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols, int32_t f16);
+/* y[i] = the IEEE half nearest to x[i] (round to nearest even; inf beyond 65504), stored as 16-bit words */
+int egk_cast_f16(egk_stream_t s, const float* x, void* y, int64_t n);
 /* r[j] = ||x_j - hi(x_j)|| / ||x_j|| for the rows of an f32 matrix, *rmax = max_j r[j] (once per prototype bank) */
 int egk_bf16_residual_ratio(egk_stream_t s, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols);
 

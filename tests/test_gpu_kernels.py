@@ -1985,3 +1985,41 @@ def test_wide_row_layernorm_kernels_against_the_one_wave_kernels(ops, dt, rows, 
     torch.testing.assert_close(dx1, dx0, **(tol if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)))
     torch.testing.assert_close(dw1, dw0, rtol=1e-3, atol=2e-3 * rows ** 0.5 if dt == torch.float32 else 5e-2 * rows ** 0.5)
     torch.testing.assert_close(db1, db0, rtol=1e-3, atol=2e-3 * rows ** 0.5 if dt == torch.float32 else 5e-2 * rows ** 0.5)
+
+
+def test_f16_screen_of_the_grouped_search_keeps_the_lists_and_shrinks_the_window(ops):
+    """The grouped search's one-product screen on the f16 matrix instructions (ops._window_f16; egk_cast_f16, egk_gemm_grouped
+    with op_f16, egk_topk_window_group16): the SAME lists as the bf16 screen -- both windows are proven, the candidates' distances
+    are exact either way -- with far fewer candidates on a bank of near-duplicate prototypes; rows with values beyond the half
+    range (their f16 image is inf: an unbounded window) are still ranked exactly."""
+    G, N, K, H, k = 3, 256, 2048, 1024, 4
+    g = gen(4242)
+    centres = torch.randn(64, H, generator=g)
+    banks = [(centres[torch.randint(0, 64, (K,), generator=g)] + 0.3 * torch.randn(K, H, generator=g)).to(DEV) for _ in range(G)]
+    base = (centres[torch.randint(0, 64, (G * N,), generator=g)] + 0.2 * torch.randn(G * N, H, generator=g)).to(DEV)
+    base[5] *= 3.0e4  # |x| up to ~1e5: beyond the half range
+    feats = [base[i * N:(i + 1) * N] for i in range(G)]
+    cand = torch.zeros(G * N, dtype=torch.int32, device=DEV)
+    out = {}
+    with ops.compute_mode("bf16"):
+        norms = [ops.row_inv_norm(b) for b in banks]
+        for f16 in (True, False):
+            prev = ops._window_f16["on"]
+            ops._window_f16["on"], ops._window_stats["cand"] = f16, cand
+            try:
+                lists, _ = ops.nearest_prototypes_grouped(feats, banks, k, norms)
+                torch.cuda.synchronize()
+                out[f16] = (torch.cat(lists).cpu(), cand.clone().cpu())
+            finally:
+                ops._window_f16["on"], ops._window_stats["cand"] = prev, None
+    assert torch.equal(out[True][0], out[False][0])
+    c16, cbf = out[True][1].float(), out[False][1].float()
+    keep = torch.ones(G * N, dtype=torch.bool)
+    keep[5] = False
+    assert float(c16[keep].mean()) < 0.6 * float(cbf[keep].mean()), (float(c16[keep].mean()), float(cbf[keep].mean()))
+    assert int(c16[5]) == K  # the overflowing row: every prototype is a candidate
+    fn, bn = base.double().cpu(), banks[0].double().cpu()
+    d = 1.0 - (fn[:N] / fn[:N].norm(dim=1, keepdim=True)) @ (bn / bn.norm(dim=1, keepdim=True)).T
+    srt, order = torch.sort(d, dim=1, stable=True)
+    safe = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values > 2e-6
+    assert bool(safe[5]) and torch.equal(out[True][0][:N][safe], order[safe][:, :k])
