@@ -159,7 +159,10 @@ class StagedBatches:
         the bench line, main_egopack.py -- 1 ms of hipGraphLaunch per replay -- at 65 %).  The worker builds and stages while the
         training thread sits in the graph launch (which releases the interpreter lock).  Captures use the thread-local capture
         mode (CAPTURE_MODE), the copy stream and its allocations are this iterator's own, the library's one-shot launch state
-        is per host thread: the worker's launches are legal at any time.  EGK_DISABLE=stage_thread: the in-line fetch."""
+        is per host thread: the worker's launches are legal at any time.  OPT-IN (EGK_ENABLE=stage_thread): measured on one box,
+        alternating, main_temporal.py 1.600 / 1.684 ms per step with the thread against 1.554 / 1.630 in line, main_egopack.py
+        2.69 both ways (tools/round5/ab_stage_thread.sh) -- two Python threads share one interpreter lock, and the fetch is
+        mostly interpreter work."""
         import queue
         import threading
         q, stop = queue.Queue(maxsize=2), threading.Event()
@@ -199,7 +202,7 @@ class StagedBatches:
             th.join(timeout=5.0)
 
     def __iter__(self):
-        if self.copy_stream is not None and "stage_thread" not in os.environ.get("EGK_DISABLE", ""):
+        if self.copy_stream is not None and "stage_thread" in os.environ.get("EGK_ENABLE", ""):
             source = self._ahead()
         else:
             def inline():
