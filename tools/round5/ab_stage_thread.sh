@@ -2,9 +2,9 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 G="dataset_recognition=synthetic_resident dataset_lta=synthetic_resident dataset_oscc=synthetic_resident dataset_pnr=synthetic_resident"
 S="dataset_recognition.T=32 dataset_lta.T=32 dataset_oscc.T=32 dataset_pnr.T=32 dataset_recognition.n_videos=8 dataset_lta.n_videos=8 dataset_oscc.n_videos=8 dataset_pnr.n_videos=8 dataset_recognition.frames=4000 dataset_lta.frames=4000 dataset_oscc.frames=4000 dataset_pnr.frames=4000"
 C="k=1 batch_size=64 synthetic_samples=16384 synthetic_val_samples=64 model.hidden_size=1024 model.temporal_pooling.hidden_size=1024 compute=bf16 checkpoint_dir=/tmp/ck"
-for r in 1 2; do for e in X=1 EGK_DISABLE=stage_thread; do
+for r in 1 2; do for e in X=1 EGK_ENABLE=stage_thread; do
   env $e timeout 900 python main_temporal.py $G $S $C num_epochs=1 enabled_tasks=[ar,lta,pnr] save_model=True 2>&1 | grep "steady state" | sed "s/^.*steady state/$e steady state/" | cut -c1-120
 done; done
-for r in 1 2; do for e in X=1 EGK_DISABLE=stage_thread; do
+for r in 1 2; do for e in X=1 EGK_ENABLE=stage_thread; do
   env $e timeout 900 python main_egopack.py $G $S $C num_epochs=1 enabled_tasks=[oscc] enable_graphone=True resume_from=/tmp/ck/MTL_ar-lta-pnr/checkpoint.pth graphone.k=4 graphone.depth=3 graphone.residual=True save_model=False 2>&1 | grep "steady state" | sed "s/^.*steady state/egopack $e steady state/" | cut -c1-120
 done; done

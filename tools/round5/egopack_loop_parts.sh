@@ -3,4 +3,4 @@ G="dataset_recognition=synthetic_resident dataset_lta=synthetic_resident dataset
 S="dataset_recognition.T=32 dataset_lta.T=32 dataset_oscc.T=32 dataset_pnr.T=32 dataset_recognition.n_videos=8 dataset_lta.n_videos=8 dataset_oscc.n_videos=8 dataset_pnr.n_videos=8 dataset_recognition.frames=4000 dataset_lta.frames=4000 dataset_oscc.frames=4000 dataset_pnr.frames=4000"
 C="k=1 batch_size=64 synthetic_samples=8192 synthetic_val_samples=64 model.hidden_size=1024 model.temporal_pooling.hidden_size=1024 compute=bf16 checkpoint_dir=/tmp/ck"
 timeout 900 python main_temporal.py $G $S $C num_epochs=1 enabled_tasks=[ar,lta,pnr] save_model=True > gpurun_out/p1.log 2>&1
-for e in EGK_DISABLE=stage_thread X=1; do env $e python tools/round5/egopack_loop_parts.py 2>&1 | grep -E "parts|steady"; done
+for e in X=1 EGK_ENABLE=stage_thread; do env $e python tools/round5/egopack_loop_parts.py 2>&1 | grep -E "parts|steady"; done
