@@ -213,15 +213,16 @@ def pmc_traffic(kernel: str, args=None):
         return None
     try:
         pmc = json.loads(f.read_text())
-        tot = 0.0
-        hit = False
+        # several instantiations can share the live timer's name (e.g. the grouped launch with bf16 and with f16 operands): the
+        # launch-weighted mean per counter over all of them, then the sum of the counters
+        byts, launches = {}, {}
         for name, ctrs in pmc.items():
-            if name.startswith("_"):
+            if name.startswith("_") or sym not in name:
                 continue
-            if sym in name:
-                hit = True
-                tot += sum(c["bytes_per_launch"] for c in ctrs.values())
-        return tot if hit else None
+            for ctr, c in ctrs.items():
+                byts[ctr] = byts.get(ctr, 0.0) + c["bytes_per_launch"] * c["launches"]
+                launches[ctr] = launches.get(ctr, 0) + c["launches"]
+        return sum(byts[c] / launches[c] for c in byts if launches[c]) if byts else None
     except Exception:
         return None
 
