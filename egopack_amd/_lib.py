@@ -126,6 +126,7 @@ SIGNATURES = {
     "egk_topk_window_group16": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32]),
     "egk_residual_ratio16": (C.c_int, [vp, vp, i64, vp, vp, i32, i32, i32]),
     "egk_cast_f16": (C.c_int, [vp, vp, vp, i64]),
+    "egk_row_inv_norm_cast": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
     "egk_bf16_residual_ratio": (C.c_int, [vp, vp, i64, vp, vp, i32, i32]),
     "egk_gather_max_bank_grad": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     "egk_segment_sum_rows_f64": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32]),

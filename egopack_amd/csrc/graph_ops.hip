@@ -835,6 +835,31 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const T* __restrict__
     }
 }
 
+// the grouped search's three passes over the f32 feature rows as one: 1 / |row| (row_inv_norm_kernel's arithmetic: the same bits),
+// the bf16 rounding (the activation-type copy the GraphONE stages read) and -- h16 != nullptr -- the IEEE-half rounding (the screen's
+// operand on the f16 matrix instructions)
+__global__ __launch_bounds__(256) void row_inv_norm_cast_kernel(const float* __restrict__ x, float* __restrict__ inv,
+                                                                bf16_t* __restrict__ hi, unsigned short* __restrict__ h16, int rows,
+                                                                int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+        const long long base = (long long)row * cols;
+        float s = 0.f;
+        for (int c = lane * 4; c < cols; c += 256) {  // (cols % 4 == 0: checked by the launcher)
+            const float4 v = ld4(x + base, c, cols, true);
+            s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            *reinterpret_cast<uint2*>(hi + base + c) = make_uint2((unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16),
+                                                                  (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16));
+            if (h16) {
+                const _Float16 h[4] = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                *reinterpret_cast<uint2*>(h16 + base + c) = *reinterpret_cast<const uint2*>(h);
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) inv[row] = 1.f / sqrtf(s);
+    }
+}
+
 __global__ __launch_bounds__(256) void cos_dist_kernel(const float* __restrict__ dot, long long ldd,
                                                        const float* __restrict__ f_inv, const float* __restrict__ b_inv,
                                                        float* __restrict__ dist, int rows, int K) {
@@ -1864,6 +1889,18 @@ int egk_row_inv_norm(egk_stream_t stream, const void* x, float* inv_norm, int32_
     EGK_DISPATCH_T(dtype, hipLaunchKernelGGL(row_inv_norm_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, s, (const T*)x, inv_norm,
                                              rows, cols, 0));
     return check_launch("egk_row_inv_norm");
+}
+
+int egk_row_inv_norm_cast(egk_stream_t stream, const float* x, float* inv_norm, void* hi, void* h16, int32_t rows, int32_t cols) {
+    EGK_REQUIRE(x && inv_norm && hi, "egk_row_inv_norm_cast: null pointer");
+    EGK_REQUIRE(cols % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)hi % 8 == 0) && ((uintptr_t)h16 % 8 == 0),
+                "egk_row_inv_norm_cast: rows of a multiple of 4 columns, 16-byte aligned input, 8-byte aligned outputs");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(KID_ROW_INV_NORM, s, 0, (h16 ? 8.0 : 6.0) * rows * cols);
+    hipLaunchKernelGGL(row_inv_norm_cast_kernel, dim3(row_grid(rows)), dim3(256), 0, s, x, inv_norm, (bf16_t*)hi, (unsigned short*)h16,
+                       rows, cols);
+    return check_launch("egk_row_inv_norm_cast");
 }
 
 int egk_row_sq_norm(egk_stream_t stream, const void* x, float* sq_norm, int32_t rows, int32_t cols, int32_t dtype) {

@@ -150,10 +150,10 @@ struct RowLNGroups {
 template <int NV, typename T, bool FULL>
 __global__ __launch_bounds__(256) void rowln_fwd_group_kernel(const T* __restrict__ x, const RowLNGroups G, T* __restrict__ y,
                                                               float* __restrict__ mean, float* __restrict__ rstd, int cols,
-                                                              float eps, int relu) {
+                                                              float eps, int relu, const SplitTee tee) {
     const int g = blockIdx.y;
     rowln_fwd_body<NV, T, FULL>(x, G.w[g], G.b[g], y, mean, rstd, nullptr, G.row0[g], G.row0[g + 1], cols, eps, relu, 0.f, 0, 0,
-                                nullptr, blockIdx.x, gridDim.x);
+                                nullptr, blockIdx.x, gridDim.x, tee);
 }
 
 // dx for one row + per-wave column partials of dw/db, combined per workgroup through LDS.
@@ -1282,8 +1282,10 @@ int egk_rowln_group_fwd(egk_stream_t stream, const void* x, const float* const* 
     const double eb = dtype == EGK_BF16 ? 2.0 : 4.0;
     ProfScope prof(KID_ROWLN_FWD, s, 0, 2 * eb * (row_ptr[n_groups] - row_ptr[0]) * cols);
     const int per = cdiv(row_grid_wide(row_ptr[n_groups] - row_ptr[0]), n_groups);
+    const SplitTee tee = take_split_tee();  // (the halves are indexed by the row of the shared [rows, cols] buffer, as y is)
+    EGK_REQUIRE(!tee.lo || dtype == EGK_F32, "egk_rowln_group_fwd: a split tee needs an f32 result");
     DISPATCH_NV(cols, dtype, hipLaunchKernelGGL((rowln_fwd_group_kernel<NV, T, FULL>), dim3(per < 1 ? 1 : per, n_groups), dim3(256), 0,
-                                                 s, (const T*)x, G, (T*)y, mean, rstd, cols, eps, relu));
+                                                 s, (const T*)x, G, (T*)y, mean, rstd, cols, eps, relu, tee));
     return check_launch("egk_rowln_group_fwd");
 }
 

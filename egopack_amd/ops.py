@@ -1871,9 +1871,11 @@ def grouped_projection_infer(x, nets, out_f32: bool = False):
                       for g, net in enumerate(nets)])
         lw, lb = [_f32c(net[2].weight) for net in nets], [_f32c(net[2].bias) for net in nets]
         row_ptr = (C.c_int32 * (G + 1))(*[g * M for g in range(G + 1)])
+        # the LayerNorm launch also stores the halves of its result (egk_tee_split_next; EGK_DISABLE=group_ln_tee: a split launch)
+        halves = _tee_arm(a) if "group_ln_tee" not in os.environ.get("EGK_DISABLE", "") else None
         _ck(lib.egk_rowln_group_fwd(_stream(), _p(h1), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(a), _p(mean), _p(rstd), H1,
                                     float(nets[0][2].eps), 1, _dt(h1)), "egk_rowln_group_fwd")
-        hi, lo = _split_rows(a, G * M, H1, H1)  # ONE launch; the groups' row blocks are registered as already split
+        hi, lo = halves if halves is not None else _split_rows(a, G * M, H1, H1)  # the groups' row blocks are registered as split
         for g in range(G):
             ag = a[g * M:(g + 1) * M]
             _x3["cache"][(ag.data_ptr(), M, H1, H1, ag._version)] = (hi[g * M:(g + 1) * M], lo[g * M:(g + 1) * M], a)
@@ -3660,13 +3662,20 @@ def nearest_prototypes_grouped(feats, banks, k, bank_norms):
     base = rows_of_one_buffer(feats)
     G, (N, H) = len(feats), feats[0].shape
     K = banks[0].shape[0]
-    f_norm = row_inv_norm(base)
-    hi = cast_raw(base, torch.bfloat16)
     # the screen's product from IEEE-half roundings (f16 matrix instructions: 11 significand bits, a window ~8 x narrower than
     # bf16's -- the prototype banks of a trained model put 30-90 prototypes inside the bf16 window of a row); values beyond the
     # half range make that row's window unbounded (slow, never wrong).  EGK_DISABLE=window_f16: the bf16 screen.
     f16 = _window_f16["on"]
-    scr = _cast_f16_bits(base) if f16 else hi
+    if base.is_contiguous() and H % 4 == 0 and "search_prep" not in os.environ.get("EGK_DISABLE", ""):
+        # row norms, the bf16 rounding and the half rounding in ONE pass over the rows (egk_row_inv_norm_cast: the bits of the three)
+        f_norm = torch.empty(G * N, dtype=torch.float32, device=base.device)
+        hi = torch.empty((G * N, H), dtype=torch.bfloat16, device=base.device)
+        scr = torch.empty_like(hi) if f16 else hi
+        _ck(lib.egk_row_inv_norm_cast(_stream(), _p(base), _p(f_norm), _p(hi), _p(scr) if f16 else None, G * N, H), "egk_row_inv_norm_cast")
+    else:
+        f_norm = row_inv_norm(base)
+        hi = cast_raw(base, torch.bfloat16)
+        scr = _cast_f16_bits(base) if f16 else hi
     ops_b = [_bank_window_operand(b, f16) for b in banks]
     dot = torch.empty((G * N, K), dtype=torch.float32, device=base.device)
     nn = torch.empty((G * N, k), dtype=torch.int64, device=base.device)

@@ -470,6 +470,10 @@ int egk_topk_window_group16(egk_stream_t s, const float* dot1, int64_t ldd, cons
 int egk_residual_ratio16(egk_stream_t s, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols, int32_t f16);
 /* y[i] = the IEEE half nearest to x[i] (round to nearest even; inf beyond 65504), stored as 16-bit words */
 int egk_cast_f16(egk_stream_t s, const float* x, void* y, int64_t n);
+/* The grouped search's three passes over its contiguous f32 feature rows as ONE launch: inv_norm as egk_row_inv_norm (same bits),
+ * hi = the bf16 rounding (what egk_cast writes), h16 (may be NULL) = the IEEE-half rounding (what egk_cast_f16 writes).
+ * cols % 4 == 0.  Replaces three launches in front of the screen's product (graphONE.py:119-141). */
+int egk_row_inv_norm_cast(egk_stream_t s, const float* x, float* inv_norm, void* hi, void* h16, int32_t rows, int32_t cols);
 /* r[j] = ||x_j - hi(x_j)|| / ||x_j|| for the rows of an f32 matrix, *rmax = max_j r[j] (once per prototype bank) */
 int egk_bf16_residual_ratio(egk_stream_t s, const float* x, int64_t ld, float* r, float* rmax, int32_t rows, int32_t cols);
 

@@ -384,6 +384,58 @@ def test_grouped_projection_infer_equals_the_heads_one_by_one(ops):
         ops.set_compute("f32")
 
 
+def test_precise_grouped_projection_takes_its_operand_halves_from_the_layernorm_launch(ops, monkeypatch):
+    """Inside a precise scope the grouped row LayerNorm of ``ops.grouped_projection_infer`` also stores the bf16 halves of its
+    result (egk_tee_split_next -> egk_rowln_group_fwd) instead of a split launch of its own: the same bits as with the split
+    launch (EGK_DISABLE=x3_tee), and close to the f32 evaluation of the heads (reference models/tasks/task.py:17-26)."""
+    from egopack_amd.models.tasks import LTATask, PNRTask, RecognitionTask
+    torch.manual_seed(5)
+    tasks = [RecognitionTask(256, 256, (7, 11)), LTATask(256, 256, (7, 11)), PNRTask(256, 256)]
+    for t in tasks:
+        t.to(DEV).eval()
+        for p in t.parameters():
+            p.requires_grad_(False)
+    x = torch.randn(136, 256, device=DEV)
+    out = {}
+    for tee in (True, False):
+        if not tee:
+            monkeypatch.setenv("EGK_DISABLE", "x3_tee")
+        with ops.precise_scope():
+            got = ops.grouped_projection_infer(x, [t.net for t in tasks], out_f32=True)
+        assert got is not None
+        out[tee] = [g.clone() for g in got]
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+    for t, g in zip(tasks, out[True]):
+        h = torch.nn.functional.linear(x, t.net[1].weight, t.net[1].bias)
+        h = torch.relu(torch.nn.functional.layer_norm(h, (h.shape[1],), t.net[2].weight, t.net[2].bias, t.net[2].eps))
+        ref = torch.nn.functional.linear(h, t.net[4].weight, t.net[4].bias)
+        torch.testing.assert_close(g, ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("rows,cols,f16", [(6144, 1024, True), (6144, 1024, False), (37, 260, True), (5, 4, True)])
+def test_search_prep_launch_equals_its_three_passes(ops, rows, cols, f16):
+    """egk_row_inv_norm_cast (the grouped prototype search's row norms, bf16 rounding and half rounding in one pass over the
+    feature rows; reference models/graphONE/graphONE.py:119-151) against egk_row_inv_norm / egk_cast / egk_cast_f16: the same
+    bits, values beyond the half range included."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(rows, cols, generator=gen(rows + cols)).to(DEV)
+    x[0, 0], x[rows - 1, cols - 1] = 1.0e5, -7.0e-6  # inf in half / a half subnormal
+    inv = torch.empty(rows, dtype=torch.float32, device=DEV)
+    hi = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    h16 = torch.empty_like(hi) if f16 else None
+    rc = lib.egk_row_inv_norm_cast(ops._stream(), ops._p(x), ops._p(inv), ops._p(hi), ops._p(h16) if f16 else None, rows, cols)
+    assert rc == 0, _lib.last_error()
+    assert torch.equal(inv, ops.row_inv_norm(x))
+    assert torch.equal(hi.view(torch.int16), ops.cast_raw(x, torch.bfloat16).view(torch.int16))
+    if f16:
+        assert torch.equal(h16.view(torch.int16), ops._cast_f16_bits(x).view(torch.int16))
+        assert torch.equal(h16.view(torch.float16).float().cpu(), x.cpu().to(torch.float16).float())
+    bad = lib.egk_row_inv_norm_cast(ops._stream(), ops._p(x), ops._p(inv), ops._p(hi), None, rows, cols - 1)
+    assert bad != 0 and "multiple of 4" in _lib.last_error()
+
+
 def test_pe_add(ops):
     g = gen(9)
     x = torch.randn(50, 64, generator=g)
