@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("n_extra", i32), ("xK", i32 * 4), ("xA", vp * 4), ("xB", vp * 4), ("xlda", i64 * 4), ("xldb", i64 * 4),
         ("ga_mode", i32), ("ga_tile_mask", i32), ("ga_skip_c", i32), ("ga_rowptr", vp), ("ga_col", vp), ("ga_wgt", vp),
         ("ga_band", vp), ("ga_gate", vp), ("ga_out", vp), ("ga_ld", i64),
-        ("sk_tickets", vp), ("op_f16", i32),
+        ("sk_tickets", vp), ("op_f16", i32), ("adam_epi", vp),
     ]
 
 
@@ -160,6 +160,7 @@ SIGNATURES = {
     "egk_adam_step": (C.c_int, [vp, vp, vp, i32, vp, vp, i64, vp, f32, f32, f32, f32, vp]),
     "egk_zero_fill": (C.c_int, [vp, vp, i64]),
     "egk_adam_step_bump": (C.c_int, [vp, vp, vp, i32, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, vp, i64]),
+    "egk_adam_step_ranges": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, vp, vp, i64]),
     "egk_adam_hyper": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
 }
 

@@ -249,6 +249,32 @@ void arm_split_tee(bf16_t* hi, bf16_t* lo, long long ld);
 void arm_slab_input(const float* x2, const float* bias, float* x_out);
 void arm_defer_reduce(bool on);
 
+// ---- Adam on one element (torch.optim.Adam single-tensor formulas, L2 weight decay): the ONE definition the optimizer kernels and the
+// weight-gradient epilogue share, so that a parameter stepped in either place gets the same bits --------------------------------------
+struct AdamConsts {
+    float step, bc2s, gs, b1, b2, eps, wd;  // step = lr / (1 - b1^t), bc2s = sqrt(1 - b2^t), gs = gradient scale
+};
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const AdamConsts& c) {
+#pragma clang fp contract(off)  // (no fused multiply-adds: which products the compiler fuses depends on the code around the inlined body)
+    const float gg = g * c.gs + c.wd * p;
+    m = m + (gg - m) * (1.f - c.b1);          // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * c.b2 + (1.f - c.b2) * gg * gg;    // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(v) / c.bc2s + c.eps;
+    p = p - c.step * (m / denom);
+}
+// Adam inside the epilogue of the weight-gradient contraction that produces the gradient (egk_gemm_desc.adam_epi; a struct in
+// DEVICE memory, built once per parameter): the launch stores the gradient tile as always and steps the parameter, its moments and
+// its bf16 operand copies at the same [row, column] of buffers laid out like C (row stride = ldc).
+struct AdamEpi {
+    float* p;
+    float* m;
+    float* v;
+    bf16_t* shadow;       // bf16(p), may be null
+    bf16_t* shadow_lo;    // bf16(p - bf16(p)), may be null
+    const float* hyper;   // egk_adam_hyper's {lr, 1 - b1^t, sqrt(1 - b2^t), grad_scale}
+    float b1, b2, eps, wd;
+};
+
 // host-side dispatch on an EGK_F32 / EGK_BF16 activation type: ``using T = ...`` inside CALL
 #define EGK_DISPATCH_T(dtype, ...)                                               \
     do {                                                                         \

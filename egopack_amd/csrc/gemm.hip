@@ -77,6 +77,8 @@ struct GemmArgs {
     long long ga_ld;
     // split-K finished inside the launch (egk_gemm_desc.sk_tickets): one arrival counter per output tile, zero on entry and exit
     int* sk_tickets;
+    // Adam on the stored tile (egk_gemm_desc.adam_epi): C is the parameter's gradient; p / m / v / the bf16 copies are laid out like C
+    const AdamEpi* adam;
 };
 
 // Workgroup -> (slab z, tile row, tile column) for a 1-D launch of tiles_m * tiles_n * splitk workgroups.
@@ -292,6 +294,57 @@ __device__ __forceinline__ void load_operand(const void* base, long long ld, int
     else load_rowmajor<BF16C, T>((const T*)base, ld, rows_total, row0, k0, klim, vec, out);
 }
 
+// Adam on CNT consecutive elements of one row whose gradient values o[] the epilogue is about to store (AdamEpi; the buffers are
+// laid out like C: element (m, n) at m * ldc + n).  ``vec``: whole 16-byte groups, aligned.
+template <int CNT>
+__device__ __forceinline__ void adam_epilogue(const GemmArgs& g, const float* o, int m, int n, int cnt, bool vec) {
+    const AdamEpi& a = *g.adam;
+    const AdamConsts ac{a.hyper[0] / a.hyper[1], a.hyper[2], a.hyper[3], a.b1, a.b2, a.eps, a.wd};
+    const long long at = (long long)m * g.ldc + n;
+    float pv[CNT], mv[CNT], vv[CNT];
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < CNT / 4; ++q) {
+            const float4 p4 = *reinterpret_cast<const float4*>(a.p + at + 4 * q), m4 = *reinterpret_cast<const float4*>(a.m + at + 4 * q),
+                         v4 = *reinterpret_cast<const float4*>(a.v + at + 4 * q);
+            pv[4 * q] = p4.x; pv[4 * q + 1] = p4.y; pv[4 * q + 2] = p4.z; pv[4 * q + 3] = p4.w;
+            mv[4 * q] = m4.x; mv[4 * q + 1] = m4.y; mv[4 * q + 2] = m4.z; mv[4 * q + 3] = m4.w;
+            vv[4 * q] = v4.x; vv[4 * q + 1] = v4.y; vv[4 * q + 2] = v4.z; vv[4 * q + 3] = v4.w;
+        }
+#pragma unroll
+        for (int t = 0; t < CNT; ++t) adam_update(pv[t], o[t], mv[t], vv[t], ac);
+#pragma unroll
+        for (int q = 0; q < CNT / 4; ++q) {
+            *reinterpret_cast<float4*>(a.p + at + 4 * q) = make_float4(pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]);
+            *reinterpret_cast<float4*>(a.m + at + 4 * q) = make_float4(mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
+            *reinterpret_cast<float4*>(a.v + at + 4 * q) = make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
+            if (a.shadow) {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(pv[4 * q]) | ((unsigned)f32_to_bf16(pv[4 * q + 1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(pv[4 * q + 2]) | ((unsigned)f32_to_bf16(pv[4 * q + 3]) << 16);
+                *reinterpret_cast<uint2*>(a.shadow + at + 4 * q) = pk;
+            }
+            if (a.shadow_lo) {
+                float l[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) l[t] = pv[4 * q + t] - bf16_to_f32(f32_to_bf16(pv[4 * q + t]));
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(l[0]) | ((unsigned)f32_to_bf16(l[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(l[2]) | ((unsigned)f32_to_bf16(l[3]) << 16);
+                *reinterpret_cast<uint2*>(a.shadow_lo + at + 4 * q) = pk;
+            }
+        }
+    } else {
+        for (int t = 0; t < CNT && t < cnt; ++t) {
+            float pp = a.p[at + t], mm = a.m[at + t], v1 = a.v[at + t];
+            adam_update(pp, o[t], mm, v1, ac);
+            a.p[at + t] = pp; a.m[at + t] = mm; a.v[at + t] = v1;
+            if (a.shadow) a.shadow[at + t] = f32_to_bf16(pp);
+            if (a.shadow_lo) a.shadow_lo[at + t] = f32_to_bf16(pp - bf16_to_f32(f32_to_bf16(pp)));
+        }
+    }
+}
+
 // Epilogue shared by the contraction kernels.  D^T layout: lane holds C[m = .. + lr][n = .. + 4*lg + t], t = 0..3.
 template <int NI, int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[NI][NJ], int m0, int n0, int wm_off,
@@ -359,6 +412,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                 if (full && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
                 else
                     for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = o[t];
+                if (g.adam) adam_epilogue<4>(g, o, m, n, g.N - n, full && g.c_vec);
             }
         }
     }
@@ -485,6 +539,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             float* cp = (float*)g.C + (long long)m * g.ldc + n;
             *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
             *reinterpret_cast<float4*>(cp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            if (g.adam) adam_epilogue<8>(g, o, m, n, 8, true);
         }
         if (ga_mode) {  // park the stored values where the raw accumulators were (this thread's own two slots)
             *reinterpret_cast<f32x4*>(stage + row * 128 + (((2 * c8) ^ (row & 15)) << 2)) = f32x4{o[0], o[1], o[2], o[3]};
@@ -2376,6 +2431,9 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         EGK_REQUIRE(d->st_mode == 1 || (d->st_x && d->st_stats && d->st_w && d->st_b), "egk_gemm: st_mode 2 needs x, stats, w, b");
     }
     g.sk_tickets = nullptr;
+    g.adam = (const AdamEpi*)d->adam_epi;
+    EGK_REQUIRE(!g.adam || (g.splitk == 1 && !g.c_bf16 && !d->ga_mode && !d->st_mode && d->alpha == 1.f && d->act == 0 && !d->residual && !d->bias),
+                "egk_gemm: adam_epi needs a plain f32 gradient store (no split-K, activation, residual, statistics or gather)");
     g.ga_mode = d->ga_mode; g.ga_skip_c = d->ga_mode ? d->ga_skip_c : 0;
     g.ga_rowptr = d->ga_rowptr; g.ga_col = d->ga_col; g.ga_wgt = d->ga_wgt; g.ga_band = d->ga_band;
     g.ga_gate = d->ga_gate; g.ga_out = d->ga_out; g.ga_ld = d->ga_ld;
@@ -2722,6 +2780,9 @@ static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     g.rows_epilogue = g_rows_epilogue;
     g.ga_mode = 0; g.ga_skip_c = 0; g.ga_rowptr = nullptr; g.ga_col = nullptr; g.ga_wgt = nullptr; g.ga_band = nullptr;
     g.ga_gate = nullptr; g.ga_out = nullptr; g.ga_ld = 0; g.sk_tickets = nullptr;
+    g.adam = (const AdamEpi*)d->adam_epi;
+    EGK_REQUIRE(!g.adam || (!g.c_bf16 && d->alpha == 1.f && d->act == 0 && !d->residual && !d->bias),
+                "egk_gemm_grouped: adam_epi needs a plain f32 gradient store");
     g.st_mode = 0; g.st_nseg = 0; g.st_seg_ptr = nullptr; g.st_ws = nullptr; g.st_x = nullptr; g.st_ldx = 0;
     g.st_stats = nullptr; g.st_w = nullptr; g.st_b = nullptr; g.st_slope = 0.f;
     EGK_REQUIRE(d->st_mode == 0, "egk_gemm_grouped: no segment statistics in a grouped launch");

@@ -395,18 +395,12 @@ __global__ void adam_hyper_kernel(const float* __restrict__ src, long long* __re
 }
 
 // ---- Adam (torch.optim.Adam single-tensor formulas, L2 weight decay) ----------------------------------------
-template <typename GT>  // GT: element type of the gradient buffer (f32, or bf16 after a compressed all-reduce)
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long long n, const float* __restrict__ hyper,
-                                                   float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow,
-                                                   bf16_t* __restrict__ shadow_lo, long long* __restrict__ bump_word, long long bump) {
-    // (egk_adam_step_bump: a device-side counter that moves on once per step -- the Philox offset word of the step's dropout
-    //  launches -- rides in this launch instead of costing one of its own)
-    if (bump_word && blockIdx.x == 0 && threadIdx.x == 0) *bump_word += bump;
-    const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
-    const float step = lr / bc1;
-    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
-         i += (long long)gridDim.x * blockDim.x * 4) {
+// the elements [0, n) of one span, grid-stride over ``nblk`` workgroups (adam_kernel: the whole slice; adam_ranges_kernel: one range)
+template <typename GT>
+__device__ __forceinline__ void adam_span(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                          long long n, const AdamConsts& ac, bf16_t* __restrict__ shadow, bf16_t* __restrict__ shadow_lo,
+                                          int blk, int nblk) {
+    for (long long i = ((long long)blk * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)nblk * blockDim.x * 4) {
         if (i + 4 <= n) {
             float4 pv = *reinterpret_cast<float4*>(p + i);
             const float4 gv = ld4t(g + i, 0, 4, true);
@@ -414,13 +408,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             float4 vv = *reinterpret_cast<float4*>(v + i);
             float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float gg = gp[t] * gs + wd * pp[t];
-                mp[t] = mp[t] + (gg - mp[t]) * (1.f - b1);   // exp_avg.lerp_(grad, 1 - beta1)
-                vp[t] = vp[t] * b2 + (1.f - b2) * gg * gg;   // mul_(beta2).addcmul_(g, g, 1 - beta2)
-                const float denom = sqrtf(vp[t]) / bc2s + eps;
-                pp[t] = pp[t] - step * (mp[t] / denom);
-            }
+            for (int t = 0; t < 4; ++t) adam_update(pp[t], gp[t], mp[t], vp[t], ac);
             *reinterpret_cast<float4*>(p + i) = pv;
             *reinterpret_cast<float4*>(m + i) = mv;
             *reinterpret_cast<float4*>(v + i) = vv;
@@ -431,15 +419,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             }
         } else {
             for (long long j = i; j < n; ++j) {
-                const float gg = ld1t(g + j) * gs + wd * p[j];
-                m[j] = m[j] + (gg - m[j]) * (1.f - b1);
-                v[j] = v[j] * b2 + (1.f - b2) * gg * gg;
-                p[j] = p[j] - step * (m[j] / (sqrtf(v[j]) / bc2s + eps));
+                adam_update(p[j], ld1t(g + j), m[j], v[j], ac);
                 if (shadow) shadow[j] = f2bf(p[j]);
                 if (shadow_lo) shadow_lo[j] = f2bf(p[j] - bf2f(f2bf(p[j])));
             }
         }
     }
+}
+
+template <typename GT>  // GT: element type of the gradient buffer (f32, or bf16 after a compressed all-reduce)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, const float* __restrict__ hyper,
+                                                   float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow,
+                                                   bf16_t* __restrict__ shadow_lo, long long* __restrict__ bump_word, long long bump) {
+    // (egk_adam_step_bump: a device-side counter that moves on once per step -- the Philox offset word of the step's dropout
+    //  launches -- rides in this launch instead of costing one of its own)
+    if (bump_word && blockIdx.x == 0 && threadIdx.x == 0) *bump_word += bump;
+    const AdamConsts ac{hyper[0] / hyper[1], hyper[2], hyper[3], b1, b2, eps, wd};
+    adam_span(p, g, m, v, n, ac, shadow, shadow_lo, blockIdx.x, gridDim.x);
+}
+
+// Adam over up to ADAM_MAX_RANGES element ranges of the flat buffers as ONE launch (blockIdx.y = range): what is left of a slice
+// once the weight matrices stepped inside their gradient launches (AdamEpi) are taken out -- biases, LayerNorm parameters, padding
+constexpr int ADAM_MAX_RANGES = 48;
+struct AdamRanges {
+    long long begin[ADAM_MAX_RANGES], len[ADAM_MAX_RANGES];
+};
+template <typename GT>
+__global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const AdamRanges R, const float* __restrict__ hyper,
+                                                          float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow,
+                                                          bf16_t* __restrict__ shadow_lo, long long* __restrict__ bump_word, long long bump) {
+    if (bump_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump_word += bump;
+    const AdamConsts ac{hyper[0] / hyper[1], hyper[2], hyper[3], b1, b2, eps, wd};
+    const long long o = R.begin[blockIdx.y];
+    adam_span(p + o, g + o, m + o, v + o, R.len[blockIdx.y], ac, shadow ? shadow + o : nullptr, shadow_lo ? shadow_lo + o : nullptr,
+              blockIdx.x, gridDim.x);
 }
 
 static inline unsigned ew_grid(long long n, int per_thread) {
@@ -749,5 +764,31 @@ int egk_adam_step_bump(egk_stream_t stream, float* p, const void* g, int32_t g_d
                                                (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow,
                                                (bf16_t*)bf16_lo_shadow, (long long*)bump_word, (long long)bump));
     return check_launch("egk_adam_step");
+}
+
+int egk_adam_step_ranges(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, const int64_t* begin,
+                         const int64_t* len, int32_t n_ranges, const float* hyper, float beta1, float beta2, float eps,
+                         float weight_decay, void* bf16_shadow, void* bf16_lo_shadow, int64_t* bump_word, int64_t bump) {
+    EGK_REQUIRE(p && g && m && v && hyper && begin && len, "egk_adam_step_ranges: null pointer");
+    EGK_REQUIRE(n_ranges >= 1 && n_ranges <= ADAM_MAX_RANGES, "egk_adam_step_ranges: 1 .. %d ranges per launch", ADAM_MAX_RANGES);
+    hipStream_t s = (hipStream_t)stream;
+    AdamRanges R;
+    long long longest = 0, total = 0;
+    for (int i = 0; i < ADAM_MAX_RANGES; ++i) {
+        R.begin[i] = i < n_ranges ? begin[i] : 0;
+        R.len[i] = i < n_ranges ? len[i] : 0;
+        if (i < n_ranges) {
+            EGK_REQUIRE(begin[i] >= 0 && len[i] >= 0 && begin[i] % 4 == 0, "egk_adam_step_ranges: ranges start at multiples of 4 elements");
+            longest = len[i] > longest ? len[i] : longest;
+            total += len[i];
+        }
+    }
+    ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (bf16_lo_shadow ? 2.0 : 0.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * total);
+    unsigned gx = ew_grid(longest, 4);
+    if (gx > 512u) gx = 512u;
+    EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_ranges_kernel<T>, dim3(gx, n_ranges), dim3(256), 0, s, p, (const T*)g, m, v, R, hyper,
+                                               beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow, (bf16_t*)bf16_lo_shadow,
+                                               (long long*)bump_word, (long long)bump));
+    return check_launch("egk_adam_step_ranges");
 }
 }

@@ -810,6 +810,17 @@ class StepBase:
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         early = self._early_adam_plan(live) if fuse_adam else None
+        # Adam inside the weight-gradient launches (FlatAdam.epilogue_begin): only where every weight matrix gets its gradient from
+        # ONE launch per step (the fused backbone pass or a single task) and the optimizer runs inside the graph (one rank).
+        # OPT-IN (EGK_ENABLE=adam_epilogue): bit-identical, and measured SLOWER -- headline 1.514-1.517 against 1.409-1.416 ms
+        # (tools/round5/ab_c3.sh): the optimizer's HBM-bound pass used to run BESIDE the matrix-bound tail group; inside the
+        # epilogue the same traffic is a burst at the end of every tile, while that workgroup's matrix pipe idles
+        epi_prev = None
+        if (fuse_adam and self.adam_epilogue and (self.fused or len(live) == 1) and hasattr(opt, "epilogue_begin")
+                and "adam_epilogue" in os.environ.get("EGK_ENABLE", "")):
+            prov, unclaim = opt.epilogue_begin()
+            if prov is not None:
+                epi_prev = ops.set_adam_epilogue(prov, unclaim)
         try:
             with torch.cuda.graph(g, stream=ops.unexcluded_stream(), capture_error_mode=CAPTURE_MODE):
                 ops.stamp("step_start")
@@ -909,6 +920,9 @@ class StepBase:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
+            if epi_prev is not None:
+                ops.set_adam_epilogue(*epi_prev)
+                self._adam_epilogue_ranges = opt.epilogue_end(keep=True)
         if segmented:
             from .graphexec import SegmentedGraph
             try:
@@ -930,6 +944,7 @@ class StepBase:
     # for steps that have JOINED every other gradient producer into the backward stream by then (MTLStep with its
     # head-wise backward does; a step whose branches are still running on their own streams at that point must not)
     early_adam = False
+    adam_epilogue = False  # (MTLStep: weight matrices stepped inside their gradient launches, optim.FlatAdam.epilogue_begin)
 
     def _tail_only_plan(self, live):
         """(first TRN weight, flat range of the temporal pooling's slots) when the step can end with ONE grouped launch of the
@@ -1474,6 +1489,7 @@ class MTLStep(StepBase):
 
     headwise_backward = True  # False: one backward() call over all streams (kept for A/B measurements)
     early_adam = True
+    adam_epilogue = True
 
     def _early_adam_ok(self) -> bool:  # the heads are joined into the main stream before the backbone's backward starts
         return bool(self.early_adam and self.headwise_backward)

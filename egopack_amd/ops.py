@@ -407,7 +407,7 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
                transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-               dbias=None, into=None, stats=None, gather=None, op_f16=False):
+               dbias=None, into=None, stats=None, gather=None, op_f16=False, adam_ok=True):
     """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array).  ``stats``: per-segment sums of
     the result for the graph LayerNorm that consumes it, taken in the epilogue (``_ln_stats_request``)."""
     op_dt = _dt(A1)
@@ -451,6 +451,13 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
     d.splitk = 1
     d.dbias = _p(dbias)
     d.ws, d.ws_bytes = None, 0
+    # Adam inside the weight-gradient launch (egk_gemm_desc.adam_epi): a dW-form launch that accumulates into a parameter's slot of
+    # the flat gradient buffer steps that parameter in its epilogue when the step installed a provider (engine.StepBase.capture)
+    d.adam_epi = None
+    prov = _adam_epi["provider"]
+    if (prov is not None and adam_ok and transA and transB and accumulate and compute == BF16 and bias is None and residual is None and act == 0
+            and alpha == 1.0 and stats is None and gather is None and out.dtype == torch.float32):
+        d.adam_epi = prov(out, M, N, ldc)
     d.st_mode = 0
     if stats is not None:
         d.st_mode, d.st_nseg, d.st_min_seg_rows = stats["mode"], stats["n_seg"], stats["min_rows"]
@@ -716,6 +723,18 @@ def _sk_tickets(M: int, N: int, device):
     return buf
 
 
+_adam_epi = {"provider": None, "unclaim": None}
+
+
+def set_adam_epilogue(provider, unclaim=None):
+    """``provider(out, M, N, ldc) -> device address of an egk_adam_epi or None`` for dW-form launches whose result ``out`` is a
+    parameter's gradient slot (optim.FlatAdam.epilogue_provider); ``unclaim(out)``: the launch splits K after all, the claim is
+    void.  None switches the feature off.  Returns the previous pair."""
+    prev = (_adam_epi["provider"], _adam_epi["unclaim"])
+    _adam_epi["provider"], _adam_epi["unclaim"] = provider, unclaim
+    return prev
+
+
 def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=None, defer_reduce=False, **kw):
     """``defer_reduce``: if the launch splits K in two, leave the slabs in a workspace of their own and do not launch the reduce
     (egk_gemm_defer_reduce_next) -- returns that workspace ([2][M][N] f32; ``out`` is NOT written, the bias NOT applied), else None."""
@@ -723,6 +742,9 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=No
     d = _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, **kw)
     sk = lib.egk_gemm_splitk(M, N, _desc_k(d), d.compute) if allow_splitk else 1
     d.splitk = sk if splitk is None else int(splitk)
+    if d.adam_epi and d.splitk > 1:  # (a lone launch that splits K: its gradient is final only after the reduce -- the optimizer's own pass)
+        d.adam_epi = None
+        _adam_epi["unclaim"](out)
     need = lib.egk_gemm_ws_bytes(C.byref(d))
     deferred = None
     if need:
@@ -1691,7 +1713,7 @@ class _MultiLinear(torch.autograd.Function):
                 off = 0
                 for x, m in zip(xs, ctx.rows):
                     gemm(N, K, dy[off:off + m], N, x, K, m, out, K, transA=True, transB=True, accumulate=True,
-                         compute=ctx.compute)
+                         compute=ctx.compute, adam_ok=len(xs) == 1)  # (several launches add up one gradient: not final in any of them)
                     off += m
             _wgrad_launch(slot is not None, (dy, *xs), launch_dw)
             dW = None if slot is not None else out

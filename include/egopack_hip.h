@@ -189,7 +189,24 @@ typedef struct egk_gemm_desc {
      * the nearest-prototype search (egk_topk_window_group, screen_f16).  egk_gemm_grouped only, row-major A and B, no split-K /
      * statistics / gather epilogue; every problem of the launch must agree. */
     int32_t op_f16;
+    /* Adam INSIDE the weight-gradient launch (NULL: off).  C is a parameter's f32 gradient (the dW form of a linear layer,
+     * trn_pooling.py:28-45 / models/graph.py:39-48 backward; torch.optim.Adam of configs/defaults.yaml:17-20): the epilogue stores the
+     * gradient tile as always and, from the same registers, steps the parameter, its moments and its bf16 operand copies at the
+     * same [row, column] -- egk_adam_step's arithmetic on the same values: the same bits, without the optimizer's pass over the
+     * gradient.  Points to an egk_adam_epi in DEVICE memory (it is read by the kernel; build it once per parameter).  Needs a plain
+     * f32 store: no split-K, bias, activation, residual, statistics or gather; the buffers are laid out like C (row stride ldc). */
+    const void* adam_epi;
 } egk_gemm_desc;
+/* what egk_gemm_desc.adam_epi points to (device memory; 64 bytes) */
+typedef struct {
+    float* p;
+    float* m;
+    float* v;
+    void* bf16_shadow;       /* bf16(p), may be NULL */
+    void* bf16_lo_shadow;    /* bf16(p - bf16(p)), may be NULL */
+    const float* hyper;      /* egk_adam_hyper's output */
+    float beta1, beta2, eps, weight_decay;
+} egk_adam_epi;
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
@@ -594,6 +611,12 @@ int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, floa
 int egk_adam_step_bump(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                        const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow,
                        void* bf16_lo_shadow, int64_t* bump_word, int64_t bump);
+/* egk_adam_step_bump over n_ranges (1 .. 48) element ranges [begin[i], begin[i] + len[i]) of the same buffers as ONE launch: what is
+ * left of an optimizer slice once the matrices stepped inside their gradient launches (egk_gemm_desc.adam_epi) are taken out --
+ * biases, LayerNorm parameters, slot padding.  begin[i] % 4 == 0; begin / len are HOST arrays (copied into the launch). */
+int egk_adam_step_ranges(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, const int64_t* begin,
+                         const int64_t* len, int32_t n_ranges, const float* hyper, float beta1, float beta2, float eps,
+                         float weight_decay, void* bf16_shadow, void* bf16_lo_shadow, int64_t* bump_word, int64_t bump);
 /* The constants of the NEXT step computed on the device: t = ++(*t_dev) (device int64: optimizer steps taken so far);
  * hyper[4] = {src[0] = lr, 1 - beta1^t, sqrt(1 - beta2^t), src[1] = grad_scale} (double pow / sqrt, rounded to f32 once, as
  * torch.optim.Adam's bias corrections are).  One thread; a node of the captured step, so that a graph replay needs no
