@@ -1617,6 +1617,83 @@ def test_pe_add_table_is_bit_identical_to_the_direct_evaluation(ops, dt):
                                rtol=1e-2 if dt == torch.bfloat16 else 1e-5, atol=1e-2 if dt == torch.bfloat16 else 1e-5)
 
 
+def _adam_case(n, seed):
+    g = gen(seed)
+    p, gr = torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    m, v = (0.1 * torch.randn(n, generator=g)).to(DEV), (0.01 * torch.rand(n, generator=g)).to(DEV)
+    hyper = torch.tensor([1e-3, 1.0 - 0.9 ** 3, (1.0 - 0.999 ** 3) ** 0.5, 0.5], dtype=torch.float32, device=DEV)
+    return p, gr, m, v, hyper
+
+
+def test_adam_over_ranges_equals_one_launch_per_range(ops):
+    """egk_adam_step_ranges (what an optimizer slice launches once the matrices stepped inside their gradient contractions are taken
+    out: torch.optim.Adam, configs/defaults.yaml:17-20): the bits of egk_adam_step_bump range by range, nothing outside the ranges
+    touched, the rider word moved on once -- also by a launch whose only range is empty."""
+    import ctypes as C
+    from egopack_amd import _lib
+    lib = _lib.load()
+    n = 20000
+    p, gr, m, v, hyper = _adam_case(n, 3)
+    ranges = [(0, 40), (64, 1000), (2048, 4), (4096, 5003), (12000, 0), (16000, 4000)]
+    sh, lo = torch.zeros(n, dtype=torch.bfloat16, device=DEV), torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    word = torch.zeros(1, dtype=torch.int64, device=DEV)
+    a = [t.clone() for t in (p, m, v, sh, lo)]
+    bg, ln = (C.c_int64 * len(ranges))(*[b for b, _ in ranges]), (C.c_int64 * len(ranges))(*[k for _, k in ranges])
+    rc = lib.egk_adam_step_ranges(ops._stream(), ops._p(a[0]), ops._p(gr), 0, ops._p(a[1]), ops._p(a[2]), bg, ln, len(ranges), ops._p(hyper),
+                                  0.9, 0.999, 1e-8, 1e-5, ops._p(a[3]), ops._p(a[4]), ops._p(word), 7)
+    assert rc == 0, _lib.last_error()
+    b = [t.clone() for t in (p, m, v, sh, lo)]
+    for b0, k in ranges:
+        if k:
+            sl = slice(b0, b0 + k)
+            rc = lib.egk_adam_step_bump(ops._stream(), ops._p(b[0][sl]), ops._p(gr[sl]), 0, ops._p(b[1][sl]), ops._p(b[2][sl]), k, ops._p(hyper),
+                                        0.9, 0.999, 1e-8, 1e-5, ops._p(b[3][sl]), ops._p(b[4][sl]), None, 0)
+            assert rc == 0, _lib.last_error()
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
+    assert torch.equal(a[0][40:64], p[40:64]) and torch.equal(a[0][9099:12000], p[9099:12000]) and int(word.item()) == 7
+    one = (C.c_int64 * 1)(0), (C.c_int64 * 1)(0)
+    assert lib.egk_adam_step_ranges(ops._stream(), ops._p(a[0]), ops._p(gr), 0, ops._p(a[1]), ops._p(a[2]), one[0], one[1], 1, ops._p(hyper),
+                                    0.9, 0.999, 1e-8, 1e-5, ops._p(a[3]), ops._p(a[4]), ops._p(word), 7) == 0
+    assert int(word.item()) == 14 and torch.equal(a[0], b[0])
+    odd = (C.c_int64 * 1)(6), (C.c_int64 * 1)(10)
+    assert lib.egk_adam_step_ranges(ops._stream(), ops._p(a[0]), ops._p(gr), 0, ops._p(a[1]), ops._p(a[2]), odd[0], odd[1], 1, ops._p(hyper),
+                                    0.9, 0.999, 1e-8, 1e-5, None, None, None, 0) != 0 and "multiples of 4" in _lib.last_error()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 2048), (130, 72, 512), (64, 100, 256), (40, 144, 192)])
+def test_weight_gradient_launch_with_adam_in_its_epilogue(ops, M, N, K):
+    """egk_gemm_desc.adam_epi: the dW-form contraction dW[M, N] = dY[K, M]^T x[K, N] (reference trn_pooling.py:28-45 backward) stores
+    its gradient and steps the parameter, its moments and its bf16 copies in the epilogue -- the bits of the contraction followed by
+    egk_adam_step_bump over the matrix; both epilogue forms (whole rows through LDS where N % 8 == 0, four columns per lane else)."""
+    import struct
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(M + N + K)
+    dy, x = torch.randn(K, M, generator=g).to(DEV).to(torch.bfloat16), torch.randn(K, N, generator=g).to(DEV).to(torch.bfloat16)
+    p, _, m, v, hyper = _adam_case(M * N, 5)
+    sh, lo = torch.zeros(M * N, dtype=torch.bfloat16, device=DEV), torch.zeros(M * N, dtype=torch.bfloat16, device=DEV)
+    ga, gb = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    a = [t.clone() for t in (p, m, v, sh, lo)]
+    epi = torch.frombuffer(bytearray(struct.pack("<6Q4f", a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
+                                                 hyper.data_ptr(), 0.9, 0.999, 1e-8, 1e-5)), dtype=torch.uint8).to(DEV)
+    calls = []
+    prev = ops.set_adam_epilogue(lambda out, mm, nn, ldc: (calls.append((mm, nn)), epi.data_ptr())[1], lambda out: calls.append("void"))
+    try:
+        ops.gemm(M, N, dy, M, x, N, K, ga, N, transA=True, transB=True, accumulate=True, compute=ops.BF16, allow_splitk=False)
+    finally:
+        ops.set_adam_epilogue(*prev)
+    assert calls == [(M, N)]
+    b = [t.clone() for t in (p, m, v, sh, lo)]
+    ops.gemm(M, N, dy, M, x, N, K, gb, N, transA=True, transB=True, accumulate=True, compute=ops.BF16, allow_splitk=False)
+    assert lib.egk_adam_step_bump(ops._stream(), ops._p(b[0]), ops._p(gb), 0, ops._p(b[1]), ops._p(b[2]), M * N, ops._p(hyper), 0.9, 0.999,
+                                  1e-8, 1e-5, ops._p(b[3]), ops._p(b[4]), None, 0) == 0
+    assert torch.equal(ga, gb)
+    for t, u, name in zip(a, b, ("p", "m", "v", "bf16", "bf16 low half")):
+        assert torch.equal(t.view(torch.int16) if t.dtype == torch.bfloat16 else t, u.view(torch.int16) if u.dtype == torch.bfloat16 else u), name
+    assert not torch.equal(a[0], p)
+
+
 def test_adam_step_constants_are_computed_on_the_device_and_follow_lr_and_the_step_count(ops):
     """egk_adam_hyper: hyper = {lr, 1 - b1^t, sqrt(1 - b2^t), grad_scale} from a device-side step counter -- the host's
     double arithmetic rounded to f32 once -- so that a captured step carries the launch and a replay needs no host -> device
