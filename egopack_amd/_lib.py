@@ -159,6 +159,7 @@ SIGNATURES = {
     "egk_sum_scale": (C.c_int, [vp, vp, vp, i64, f32, i32]),
     "egk_adam_step": (C.c_int, [vp, vp, vp, i32, vp, vp, i64, vp, f32, f32, f32, f32, vp]),
     "egk_zero_fill": (C.c_int, [vp, vp, i64]),
+    "egk_zero_fill_ranges": (C.c_int, [vp, vp, vp, vp, i32]),
     "egk_adam_step_bump": (C.c_int, [vp, vp, vp, i32, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, vp, i64]),
     "egk_adam_step_ranges": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, vp, vp, i64]),
     "egk_adam_hyper": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),

@@ -732,6 +732,37 @@ int egk_zero_fill(egk_stream_t stream, void* p, int64_t bytes) {
     return check_launch("egk_zero_fill");
 }
 
+// up to ADAM_MAX_RANGES byte ranges of one buffer cleared by ONE launch (blockIdx.y = range): the gradient slots that are still
+// accumulated into once the matrices whose ONE weight-gradient launch stores its result are left alone (FlatAdam.store_slots)
+__global__ __launch_bounds__(256) void zero_ranges_kernel(unsigned char* __restrict__ base, const AdamRanges R) {
+    uint4* p = reinterpret_cast<uint4*>(base + R.begin[blockIdx.y]);
+    const long long n16 = R.len[blockIdx.y] >> 4;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) p[i] = z;
+}
+
+int egk_zero_fill_ranges(egk_stream_t stream, void* base, const int64_t* begin, const int64_t* bytes, int32_t n_ranges) {
+    EGK_REQUIRE(base && begin && bytes, "egk_zero_fill_ranges: null pointer");
+    EGK_REQUIRE(n_ranges >= 1 && n_ranges <= ADAM_MAX_RANGES, "egk_zero_fill_ranges: 1 .. %d ranges per launch", ADAM_MAX_RANGES);
+    EGK_REQUIRE(((uintptr_t)base & 15) == 0, "egk_zero_fill_ranges: 16-byte aligned buffer");
+    AdamRanges R;
+    long long longest = 0;
+    for (int i = 0; i < ADAM_MAX_RANGES; ++i) {
+        R.begin[i] = i < n_ranges ? begin[i] : 0;
+        R.len[i] = i < n_ranges ? bytes[i] : 0;
+        if (i < n_ranges) {
+            EGK_REQUIRE(begin[i] >= 0 && bytes[i] >= 0 && begin[i] % 16 == 0 && bytes[i] % 16 == 0,
+                        "egk_zero_fill_ranges: ranges of whole 16-byte groups");
+            longest = bytes[i] > longest ? bytes[i] : longest;
+        }
+    }
+    if (longest == 0) return 0;
+    long long gx = (longest / 16 + 255) / 256;
+    if (gx > 16) gx = 16;  // (gentle, as egk_zero_fill: it runs beside the forward pass)
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)gx, n_ranges), dim3(256), 0, (hipStream_t)stream, (unsigned char*)base, R);
+    return check_launch("egk_zero_fill_ranges");
+}
+
 int egk_adam_hyper(egk_stream_t stream, const float* src, int64_t* t_dev, double beta1, double beta2, float* hyper) {
     EGK_REQUIRE(src && t_dev && hyper, "egk_adam_hyper: null pointer");
     hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, (long long*)t_dev, beta1, beta2, hyper);

@@ -587,7 +587,16 @@ class StepBase:
     def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
         if self._use_stages():
             return self._staged_step(batches, merged)
-        total, vectors = self.forward_backward(batches, merged)
+        opt = self.optimizer
+        learn = (getattr(opt, "materialised", False) and hasattr(opt, "learn_begin") and not torch.cuda.is_current_stream_capturing()
+                 and "grad_store" not in os.environ.get("EGK_DISABLE", ""))
+        prev = ops.set_adam_epilogue(opt.learn_begin(), None) if learn else None  # (which gradient slots have ONE writer per step)
+        try:
+            total, vectors = self.forward_backward(batches, merged)
+        finally:
+            if learn:
+                ops.set_adam_epilogue(*prev)
+                opt.learn_end()
         self._exchange_and_update()
         return total.detach(), {t: v.detach() for t, v in vectors.items()}
 
@@ -815,7 +824,14 @@ class StepBase:
         # OPT-IN (EGK_ENABLE=adam_epilogue): bit-identical, and measured SLOWER -- headline 1.514-1.517 against 1.409-1.416 ms
         # (tools/round5/ab_c3.sh): the optimizer's HBM-bound pass used to run BESIDE the matrix-bound tail group; inside the
         # epilogue the same traffic is a burst at the end of every tile, while that workgroup's matrix pipe idles
-        epi_prev = None
+        epi_prev = store_prev = None
+        # gradient slots with one writer per step (learnt from the eager steps above, FlatAdam.learn_begin) are stored, not cleared +
+        # accumulated: the step's buffer clear shrinks to what is still added into (EGK_DISABLE=grad_store)
+        if (fuse_adam and hasattr(opt, "store_begin") and "grad_store" not in os.environ.get("EGK_DISABLE", "")
+                and "adam_epilogue" not in os.environ.get("EGK_ENABLE", "")):
+            sprov = opt.store_begin()
+            if sprov is not None:
+                store_prev = ops.set_adam_epilogue(sprov, None)
         if (fuse_adam and self.adam_epilogue and (self.fused or len(live) == 1) and hasattr(opt, "epilogue_begin")
                 and "adam_epilogue" in os.environ.get("EGK_ENABLE", "")):
             prov, unclaim = opt.epilogue_begin()
@@ -923,6 +939,11 @@ class StepBase:
             if epi_prev is not None:
                 ops.set_adam_epilogue(*epi_prev)
                 self._adam_epilogue_ranges = opt.epilogue_end(keep=True)
+            if store_prev is not None:
+                ops.set_adam_epilogue(*store_prev)
+                import sys
+                opt.store_end(ok=sys.exc_info()[0] is None)  # (checks that every slot left uncleared was written exactly once)
+                self._grad_store_slots = len(opt.store_slots)
         if segmented:
             from .graphexec import SegmentedGraph
             try:

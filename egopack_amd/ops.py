@@ -457,7 +457,11 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
     prov = _adam_epi["provider"]
     if (prov is not None and adam_ok and transA and transB and accumulate and compute == BF16 and bias is None and residual is None and act == 0
             and alpha == 1.0 and stats is None and gather is None and out.dtype == torch.float32):
-        d.adam_epi = prov(out, M, N, ldc)
+        r = prov(out, M, N, ldc)
+        if r == "store":  # this launch is the ONLY writer of the slot in this step: it stores (the slot is not cleared, FlatAdam.store_begin)
+            d.accumulate = 0
+        else:
+            d.adam_epi = r
     d.st_mode = 0
     if stats is not None:
         d.st_mode, d.st_nseg, d.st_min_seg_rows = stats["mode"], stats["n_seg"], stats["min_rows"]
@@ -744,7 +748,8 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=No
     d.splitk = sk if splitk is None else int(splitk)
     if d.adam_epi and d.splitk > 1:  # (a lone launch that splits K: its gradient is final only after the reduce -- the optimizer's own pass)
         d.adam_epi = None
-        _adam_epi["unclaim"](out)
+        if _adam_epi["unclaim"] is not None:
+            _adam_epi["unclaim"](out)
     need = lib.egk_gemm_ws_bytes(C.byref(d))
     deferred = None
     if need:

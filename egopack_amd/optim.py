@@ -293,6 +293,8 @@ class FlatAdam(torch.optim.Optimizer):
         """The flat gradient buffer cleared by one launch of the library (capturable)."""
         g = self.flat_g
         nbytes = g.numel() * g.element_size()
+        if nbytes % 16 == 0 and g.data_ptr() % 16 == 0 and self._zero_all_but_stored():
+            return
         if nbytes % 16 or g.data_ptr() % 16:
             g.zero_()
             return
@@ -386,6 +388,83 @@ class FlatAdam(torch.optim.Optimizer):
         self._epi_ranges = sorted(claims.items()) if keep else []
         self._epi_claims = None
         return self._epi_ranges
+
+    # -- gradient slots with ONE writer per step: stored, not accumulated -----------------------------------------------------------
+    # The flat gradient buffer is cleared every step (100-260 MB beside the forward pass) so that the weight-gradient launches can
+    # ADD into it -- which also makes each of them read its zeros back.  A weight matrix whose gradient comes from exactly one
+    # launch per step needs neither: that launch stores.  Which slots those are is LEARNT from an eager step (every dW-form launch
+    # into a parameter's slot is counted; a slot counted once qualifies) and CHECKED in the capture: a stored slot written twice,
+    # or not at all, is an error -- never a silently wrong gradient.  Captured single-rank steps only (engine.StepBase.capture).
+    def _matrix_index(self):
+        idx = getattr(self, "_mat_index", None)
+        if idx is None:
+            idx = self._mat_index = {self._slot_of[id(p)][0]: tuple(p.shape) for p in self.active
+                                     if p.dim() == 2 and getattr(p, "_egk_bank", None) is None}
+        return idx
+
+    def learn_begin(self):
+        """Provider for ops.set_adam_epilogue during an EAGER step: counts the launches per matrix slot, changes nothing."""
+        idx, g0, counts = self._matrix_index(), self.flat_g.data_ptr(), {}
+        self._learn_counts = counts
+
+        def provider(out, M, N, ldc):
+            d = out.data_ptr() - g0
+            if d >= 0 and d % 4 == 0 and ldc == N and idx.get(d // 4) == (M, N):
+                counts[d // 4] = counts.get(d // 4, 0) + 1
+            return None
+        return provider
+
+    def learn_end(self):
+        idx = self._matrix_index()
+        self.store_slots = {off: idx[off][0] * idx[off][1] for off, c in (getattr(self, "_learn_counts", None) or {}).items() if c == 1}
+        self._learn_counts = None
+
+    def store_begin(self):
+        """Provider for a CAPTURE: 'store' for the learnt single-writer slots; ``zero_flat_grads`` leaves them out meanwhile."""
+        slots = getattr(self, "store_slots", None)
+        if not slots:
+            return None
+        idx, g0 = self._matrix_index(), self.flat_g.data_ptr()
+        self._store_claims, self._store_active = set(), True
+
+        def provider(out, M, N, ldc):
+            d = out.data_ptr() - g0
+            if d < 0 or d % 4 or ldc != N or (d // 4) not in slots or idx.get(d // 4) != (M, N):
+                return None
+            if d // 4 in self._store_claims:
+                raise RuntimeError("grad_store: a gradient slot learnt as written once per step is written twice in the captured step "
+                                   "(set EGK_DISABLE=grad_store)")
+            self._store_claims.add(d // 4)
+            return "store"
+        return provider
+
+    def store_end(self, ok: bool = True):
+        claims, self._store_active = getattr(self, "_store_claims", None), False
+        self._store_claims = None
+        if ok and claims is not None and claims != set(self.store_slots):
+            raise RuntimeError(f"grad_store: {len(set(self.store_slots) - claims)} gradient slot(s) left uncleared were not written by the "
+                               "captured step (set EGK_DISABLE=grad_store)")
+
+    def _zero_all_but_stored(self) -> bool:
+        if not getattr(self, "_store_active", False):
+            return False
+        import ctypes as C
+        total, at, rest = self.flat_g.numel(), 0, []
+        for off in sorted(self.store_slots):
+            n = self.store_slots[off]
+            a, b = (off + 3) // 4 * 4, (off + n) // 4 * 4  # (whole 16-byte groups INSIDE the slot stay uncleared; its ragged ends are cleared)
+            if b <= a:
+                continue
+            if a > at:
+                rest.append((at, a - at))
+            at = b
+        if total > at:
+            rest.append((at, total - at))
+        for i in range(0, len(rest), 48):
+            part = rest[i:i + 48]
+            bg, ln = (C.c_int64 * len(part))(*[4 * b for b, _ in part]), (C.c_int64 * len(part))(*[4 * n for _, n in part])
+            _ck(_lib.load().egk_zero_fill_ranges(_stream(), _p(self.flat_g), bg, ln, len(part)), "egk_zero_fill_ranges")
+        return True
 
     def _without_epilogue(self, lo, hi):
         """[lo, hi) minus the ranges claimed so far in this capture, as (begin, length) pairs."""

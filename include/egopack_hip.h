@@ -592,6 +592,11 @@ int egk_sum_scale(egk_stream_t s, const float* x, float* out, int64_t n, float s
 /* p[0 .. bytes) = 0 (16-byte aligned, whole 16-byte groups): ``optimizer.zero_grad()`` of the flat gradient buffer
  * (reference main_temporal.py:77) as a launch of the library */
 int egk_zero_fill(egk_stream_t s, void* p, int64_t bytes);
+/* n_ranges (1 .. 48) byte ranges [begin[i], begin[i] + bytes[i]) of ``base`` cleared by ONE launch (whole 16-byte groups; HOST
+ * arrays): the gradient slots that are still ACCUMULATED into, once the weight matrices whose single gradient launch stores its
+ * result (accumulate = 0) need no clear (egopack_amd.optim.FlatAdam.store_slots; the reference's optimizer.zero_grad(),
+ * main_temporal.py:76). */
+int egk_zero_fill_ranges(egk_stream_t s, void* base, const int64_t* begin, const int64_t* bytes, int32_t n_ranges);
 
 /* ---- optimiser  torch.optim.Adam (L2 weight decay)  configs/defaults.yaml:17-20 ----------
  * One launch over the flat parameter / gradient / moment buffers.  hyper (device, float[4]) =
