@@ -1661,6 +1661,28 @@ def test_adam_over_ranges_equals_one_launch_per_range(ops):
                                     0.9, 0.999, 1e-8, 1e-5, None, None, None, 0) != 0 and "multiples of 4" in _lib.last_error()
 
 
+def test_zero_fill_over_ranges_clears_the_ranges_and_nothing_else(ops):
+    """egk_zero_fill_ranges (the step's gradient clear once the single-writer slots are left out; optimizer.zero_grad(), reference
+    main_temporal.py:76): whole 16-byte groups of up to 48 ranges in one launch, everything else untouched; ragged or too many
+    ranges are refused."""
+    import ctypes as C
+    from egopack_amd import _lib
+    lib = _lib.load()
+    buf = torch.arange(1, 100001, dtype=torch.float32, device=DEV)
+    want = buf.clone()
+    ranges = [(0, 16), (64, 4000), (8192, 0), (20000, 80000 - 20000), (99996, 4)]
+    for b, n in ranges:
+        want[b:b + n] = 0
+    bg, ln = (C.c_int64 * len(ranges))(*[4 * b for b, _ in ranges]), (C.c_int64 * len(ranges))(*[4 * n for _, n in ranges])
+    assert lib.egk_zero_fill_ranges(ops._stream(), ops._p(buf), bg, ln, len(ranges)) == 0, _lib.last_error()
+    assert torch.equal(buf, want)
+    odd = (C.c_int64 * 1)(8), (C.c_int64 * 1)(16)
+    assert lib.egk_zero_fill_ranges(ops._stream(), ops._p(buf), odd[0], odd[1], 1) != 0 and "16-byte" in _lib.last_error()
+    many = (C.c_int64 * 49)(*([0] * 49)), (C.c_int64 * 49)(*([16] * 49))
+    assert lib.egk_zero_fill_ranges(ops._stream(), ops._p(buf), many[0], many[1], 49) != 0
+    assert torch.equal(buf, want)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 1024, 2048), (130, 72, 512), (64, 100, 256), (40, 144, 192)])
 def test_weight_gradient_launch_with_adam_in_its_epilogue(ops, M, N, K):
     """egk_gemm_desc.adam_epi: the dW-form contraction dW[M, N] = dY[K, M]^T x[K, N] (reference trn_pooling.py:28-45 backward) stores
