@@ -785,12 +785,14 @@ int egk_adam_step_bump(egk_stream_t stream, float* p, const void* g, int32_t g_d
     EGK_REQUIRE(!bf16_shadow || ((uintptr_t)bf16_shadow & 7) == 0, "egk_adam_step: shadow must be 8-byte aligned");
     EGK_REQUIRE(!bf16_lo_shadow || ((uintptr_t)bf16_lo_shadow & 7) == 0, "egk_adam_step: low-half shadow must be 8-byte aligned");
     ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (bf16_lo_shadow ? 2.0 : 0.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * n);
-    // Workgroup cap: an optimizer slice runs BESIDE weight-gradient launches in every captured step's tail; with every wave slot of
-    // the chip taken by this streaming kernel the short launches queued beside it wait for slots (a 8 us reduction took 135 us,
-    // profiles/r05_c4_replay_timeline.txt)
-    unsigned grid = ew_grid(n, 4);
-    const unsigned cap = g_adam_blocks > 0 ? (unsigned)g_adam_blocks : 4096u;
-    if (grid > cap) grid = cap;
+    // Workgroups: one 1024-element group per workgroup up to 32768 of them (egk_tune(6, n) sets the cap).  An optimizer slice runs
+    // BESIDE weight-gradient launches in every captured step's tail; round 5 first capped it at 4096 (a 8 us reduction queued beside
+    // it had waited 135 us for wave slots) and, once the gradient buffer was no longer cleared and read back, measured the wide grid
+    // ahead again: headline 1.365-1.379 against 1.374-1.386 ms, config 4 2.180-2.182 against 2.191-2.206, Hp = 4096 2.722 against
+    // 2.751 (narrower is clearly worse: 1024 workgroups 1.405-1.414, 512 1.447)
+    const long long want = (n / 4 + 255) / 256;
+    const long long cap = g_adam_blocks > 0 ? g_adam_blocks : 32768;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : want > cap ? cap : want);
     EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_kernel<T>, dim3(grid), dim3(256), 0, s, p, (const T*)g, m, v,
                                                (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow,
                                                (bf16_t*)bf16_lo_shadow, (long long*)bump_word, (long long)bump));
