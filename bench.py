@@ -629,7 +629,9 @@ def measure(args, rank, world, device, steps, warmup, want_roofline=True, want_c
         blocks.append(over_ranks(timed_block(), torch.distributed.ReduceOp.MAX))
     srt = sorted(blocks)
     ms = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-    timing = {"timed_s": sum(blocks) * steps * 1e-3, "timed_blocks": len(blocks), "block_ms_min": srt[0], "block_ms_max": srt[-1]}
+    # ``steps`` of the JSON line stays K (the contract's block length); ``steps_timed`` = K x blocks is what was really timed
+    timing = {"timed_s": sum(blocks) * steps * 1e-3, "timed_blocks": len(blocks), "steps_timed": steps * len(blocks),
+              "block_ms_min": srt[0], "block_ms_max": srt[-1]}
 
     # N ranks: what the gradient exchange costs the step BEYOND what backward hides -- the same steps with the collectives
     # left out of the exchange path (conversion, stream hand-offs, per-chunk Adam all still run: GradSync.skip_collectives)

@@ -368,7 +368,7 @@ class GradSync:
             gather_params()
         opt.refresh_shadows()  # the bf16 operand copies of the slices other ranks stepped
         opt.step_count += 1
-        opt._moments_sharded = self.world > 1  # (FlatAdam.state_dict refuses until gather_moments has run)
+        opt._moments_sharded = self.world > 1 and per > 0  # (FlatAdam.state_dict refuses until gather_moments has run)
 
     def gather_moments(self, opt) -> None:
         """Sharded update: all-gather every rank's slice of the Adam moments so that each rank holds the full flat_m / flat_v
@@ -384,6 +384,9 @@ class GradSync:
         n = opt.flat_m.numel()
         per, lo, hi, body = self.shard_bounds(n)
         real = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if not per and real == self.world:
+            opt._moments_sharded = False  # (fewer than 8 * world elements: the whole buffer is all-reduced and stepped on every rank)
+            return
         if not (per and real == self.world):
             if real == 1 and self.world == 1:
                 opt._moments_sharded = False
@@ -395,17 +398,16 @@ class GradSync:
             warnings.warn("GradSync.gather_moments: the sharded Adam moments cannot be gathered on this group "
                           f"(group size {real}, sharded for {self.world}); a checkpoint would hold partial moments")
             return
-        if True:
-            native = opt.flat_m.is_cuda and dist.get_backend(self.group) == "nccl"
-            for buf in (opt.flat_m, opt.flat_v):
-                if native:
-                    dist.all_gather_into_tensor(buf[:body], buf[lo:hi].clone(), group=self.group)
-                else:
-                    mine = buf[lo:hi].cpu() if buf.is_cuda else buf[lo:hi].clone()
-                    parts = [torch.empty_like(mine) for _ in range(self.world)]
-                    dist.all_gather(parts, mine, group=self.group)
-                    for r, part in enumerate(parts):
-                        buf[r * per:(r + 1) * per].copy_(part)
+        native = opt.flat_m.is_cuda and dist.get_backend(self.group) == "nccl"
+        for buf in (opt.flat_m, opt.flat_v):
+            if native:
+                dist.all_gather_into_tensor(buf[:body], buf[lo:hi].clone(), group=self.group)
+            else:
+                mine = buf[lo:hi].cpu() if buf.is_cuda else buf[lo:hi].clone()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                for r, part in enumerate(parts):
+                    buf[r * per:(r + 1) * per].copy_(part)
         opt._moments_sharded = False
 
     def reduce_and_step(self, opt) -> None:

@@ -291,7 +291,11 @@ def _fast_key(batches, merged):
         if not k or not torch.is_tensor(x):
             return None
         y = getattr(b, "y", None)
-        parts.append((name, k, tuple(x.shape), x.dtype, tuple(y.shape) if torch.is_tensor(y) else None))
+        # the labelled-row set of a compacted head is baked into a capture too (the strided row view ``live_ap`` and the padded
+        # height of ``live_idx`` / ``live_y``): it depends on label VALUES, which the structure fingerprint does not cover
+        li = getattr(b, "live_idx", None)
+        parts.append((name, k, tuple(x.shape), x.dtype, tuple(y.shape) if torch.is_tensor(y) else None,
+                      getattr(b, "live_ap", None), tuple(li.shape) if torch.is_tensor(li) else None))
     return tuple(parts)
 
 
@@ -587,18 +591,48 @@ class StepBase:
     def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
         if self._use_stages():
             return self._staged_step(batches, merged)
-        opt = self.optimizer
-        learn = (getattr(opt, "materialised", False) and hasattr(opt, "learn_begin") and not torch.cuda.is_current_stream_capturing()
-                 and "grad_store" not in os.environ.get("EGK_DISABLE", ""))
-        prev = ops.set_adam_epilogue(opt.learn_begin(), None) if learn else None  # (which gradient slots have ONE writer per step)
-        try:
+        with self._learn_single_writers():
             total, vectors = self.forward_backward(batches, merged)
-        finally:
-            if learn:
-                ops.set_adam_epilogue(*prev)
-                opt.learn_end()
         self._exchange_and_update()
         return total.detach(), {t: v.detach() for t, v in vectors.items()}
+
+    # ---- gradient slots with one writer per step: stored, not cleared + accumulated (optim.FlatAdam.learn_begin / store_begin) ------
+    # Learnt from the EAGER steps of every execution structure (one-piece and staged), applied to every CAPTURE (one rank, the
+    # staged graphs of the N-rank step, the one-graph exchange): the gradient exchange reads the flat buffer region by region
+    # once backward has finished it -- whether a slot was cleared and added into or stored makes no difference to what it reads.
+    def _learn_single_writers(self):
+        import contextlib
+        opt = self.optimizer
+
+        @contextlib.contextmanager
+        def scope():
+            learn = (getattr(opt, "materialised", False) and hasattr(opt, "learn_begin") and not torch.cuda.is_current_stream_capturing()
+                     and "grad_store" not in os.environ.get("EGK_DISABLE", ""))
+            prev = ops.set_adam_epilogue(opt.learn_begin(), None) if learn else None  # (which gradient slots have ONE writer per step)
+            try:
+                yield
+            finally:
+                if learn:
+                    ops.set_adam_epilogue(*prev)
+                    opt.learn_end()
+        return scope()
+
+    def _grad_store_begin(self):
+        """Install the 'store' provider for a capture (None: off / nothing learnt); ``zero_flat_grads`` leaves the stored slots out
+        until ``_grad_store_end``."""
+        opt = self.optimizer
+        if (getattr(self, "_grad_store_off", False) or not hasattr(opt, "store_begin") or "grad_store" in os.environ.get("EGK_DISABLE", "")
+                or "adam_epilogue" in os.environ.get("EGK_ENABLE", "")):
+            return None
+        prov = opt.store_begin()
+        return None if prov is None else ops.set_adam_epilogue(prov, None)
+
+    def _grad_store_end(self, prev) -> None:
+        if prev is not None:
+            import sys
+            ops.set_adam_epilogue(*prev)
+            self.optimizer.store_end(ok=sys.exc_info()[0] is None)  # (checks that every slot left uncleared was written exactly once)
+            self._grad_store_slots = len(self.optimizer.store_slots)
 
     def _join_zero(self):
         """Captured steps clear the gradient buffer on a side stream beside the forward pass: wait for it before the first
@@ -671,7 +705,7 @@ class StepBase:
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             self._install_tail(self._tail_only_plan([t for t in self.enabled if batches.get(t) is not None]))
-            with self._ln_exchange_scope():
+            with self._ln_exchange_scope(), self._learn_single_writers():
                 total, vectors = self._stage_a(batches, merged)
                 self._exchange_region(regions[0])
                 self._stage_b()
@@ -776,7 +810,25 @@ class StepBase:
     # ---- hipGraph capture ---------------------------------------------------------------------------------
     def capture(self, batches: Mapping[str, Data], merged: Optional[Data] = None, warmup: int = 2):
         """Capture forward+backward(+Adam if no gradient exchange) for THESE device tensors (static
-        shapes and addresses: refill them in place between replays)."""
+        shapes and addresses: refill them in place between replays).
+
+        The stored gradient slots (``_grad_store_begin``) are whatever the last EAGER step learnt; when the captured batches
+        write them differently (another live-task set: MTL loaders of unequal length, per-task backbone passes) the provider or
+        its end-of-capture check raises -- the capture is then taken once more with every slot cleared and accumulated, and
+        ``capture_notes`` says so: a slower step, never a crash of the training loop and never a wrong gradient."""
+        try:
+            return self._capture_once(batches, merged, warmup)
+        except RuntimeError as e:
+            if not str(e).startswith("grad_store:") or getattr(self, "_grad_store_off", False):
+                raise
+            if self.sync is not None and self.sync.world > 1 and self._one_graph_exchange_ok():
+                raise  # (a failed capture that holds collectives is not retried in this process: see one_graph_exchange)
+            torch.cuda.synchronize()
+            self._grad_store_off = True
+            self.capture_notes = [*getattr(self, "capture_notes", []), f"stored gradient slots off for this step ({e})"]
+            return self._capture_once(batches, merged, 0)
+
+    def _capture_once(self, batches, merged, warmup):
         opt = self.optimizer
         if self._exact_ln_on() and not self._one_graph_exchange_ok():
             raise RuntimeError("exact_graph_ln sums the graph-LayerNorm statistics over the ranks inside the step: this process "
@@ -824,14 +876,11 @@ class StepBase:
         # OPT-IN (EGK_ENABLE=adam_epilogue): bit-identical, and measured SLOWER -- headline 1.514-1.517 against 1.409-1.416 ms
         # (tools/round5/ab_c3.sh): the optimizer's HBM-bound pass used to run BESIDE the matrix-bound tail group; inside the
         # epilogue the same traffic is a burst at the end of every tile, while that workgroup's matrix pipe idles
-        epi_prev = store_prev = None
+        epi_prev = None
         # gradient slots with one writer per step (learnt from the eager steps above, FlatAdam.learn_begin) are stored, not cleared +
-        # accumulated: the step's buffer clear shrinks to what is still added into (EGK_DISABLE=grad_store)
-        if (fuse_adam and hasattr(opt, "store_begin") and "grad_store" not in os.environ.get("EGK_DISABLE", "")
-                and "adam_epilogue" not in os.environ.get("EGK_ENABLE", "")):
-            sprov = opt.store_begin()
-            if sprov is not None:
-                store_prev = ops.set_adam_epilogue(sprov, None)
+        # accumulated: the step's buffer clear shrinks to what is still added into (EGK_DISABLE=grad_store); also when the
+        # optimizer follows a gradient exchange outside the graph
+        store_prev = self._grad_store_begin()
         if (fuse_adam and self.adam_epilogue and (self.fused or len(live) == 1) and hasattr(opt, "epilogue_begin")
                 and "adam_epilogue" in os.environ.get("EGK_ENABLE", "")):
             prov, unclaim = opt.epilogue_begin()
@@ -939,11 +988,7 @@ class StepBase:
             if epi_prev is not None:
                 ops.set_adam_epilogue(*epi_prev)
                 self._adam_epilogue_ranges = opt.epilogue_end(keep=True)
-            if store_prev is not None:
-                ops.set_adam_epilogue(*store_prev)
-                import sys
-                opt.store_end(ok=sys.exc_info()[0] is None)  # (checks that every slot left uncleared was written exactly once)
-                self._grad_store_slots = len(opt.store_slots)
+            self._grad_store_end(store_prev)
         if segmented:
             from .graphexec import SegmentedGraph
             try:
@@ -1116,6 +1161,7 @@ class StepBase:
         sync.hyper_ready = True
         self._handoff = "wgrad_handoff" not in getattr(self, "_dev_off", ())
         prev_h = ops.set_wgrad_handoff(self._handoff)
+        store_prev = self._grad_store_begin()  # (single-writer gradient slots are stored: the collectives read final values either way)
         try:
             with torch.cuda.graph(g, stream=ops.unexcluded_stream(), capture_error_mode=CAPTURE_MODE):
                 # (the gradient buffer is cleared beside the forward pass, as in the one-rank capture: joined by _join_zero()
@@ -1179,6 +1225,7 @@ class StepBase:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
+            self._grad_store_end(store_prev)
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), True
         self._graph_adam_lo = self._adam_keeps_lo()  # (every chunk's captured Adam launch writes the low halves of its slice)
         self._graph_has_exchange = True
@@ -1197,14 +1244,29 @@ class StepBase:
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
+        store_prev = self._grad_store_begin()  # (one provider over the three captures: every learnt slot is written in exactly one of them)
         try:
             live = [t for t in self.enabled if batches.get(t) is not None]
             cap = ops.unexcluded_stream()  # (one capture stream for the three graphs, never a registered head / task stream)
             with torch.cuda.graph(gs[0], stream=cap, capture_error_mode=CAPTURE_MODE):
-                opt.zero_flat_grads()
+                # the gradient buffer is cleared BESIDE the forward pass, as in the one-rank capture (a fork and a join inside
+                # the first graph; _stage_a joins it before the heads' backward writes the first gradient)
+                if "zero_stream" in getattr(self, "_dev_off", ()):
+                    opt.zero_flat_grads()
+                else:
+                    if not hasattr(self, "_zero_stream"):
+                        self._zero_stream = torch.cuda.Stream()
+
+                    def issue_zero(ev):
+                        self._zero_stream.wait_event(ev)
+                        with torch.cuda.stream(self._zero_stream):
+                            opt.zero_flat_grads()
+                    ops.defer_after_next_launch(issue_zero)
+                    self._zero_pending = True
                 if self.input_hook is not None:
                     self.input_hook()
                 total, vectors = self._stage_a(batches, merged)
+                self._join_zero()  # (a stage A that did not: the fork must end inside this graph)
             pool = gs[0].pool()
             with torch.cuda.graph(gs[1], pool=pool, stream=cap, capture_error_mode=CAPTURE_MODE):
                 self._install_tail(self._tail_only_plan(live))  # (stage B ends with the stack's flush, stage C is the tail launch)
@@ -1216,6 +1278,7 @@ class StepBase:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
+            self._grad_store_end(store_prev)
         self._graph, self._static_out, self._fuse_adam = gs, (total, vectors), False
         self._static_in = (batches, merged, self._stage_state, self._cuts)  # everything the graphs read stays alive
         return gs

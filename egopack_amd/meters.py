@@ -6,12 +6,13 @@ the rank of the ground-truth class, and all top-k accuracies, per-class recalls 
 it kept in small device tensors -- nothing is copied to the host before ``compute`` / ``get_logs``.
 
     reference class (ego4d.py)        here                 keys kept
-    Ego4dRecognitionMeter :34-203     RecognitionMeter     verbs/nouns_top{1,2,3,5}, verbs/nouns_mc, *_class_acc, loss
+    Ego4dRecognitionMeter :34-203     RecognitionMeter     verbs/nouns_top{1,2,3,5}, verbs/nouns_mc, *_class_acc,
+                                                           *_calibration_erorr (the reference's spelling), *_brier_score, loss
     Ego4dAnticipationMeter :206-289   AnticipationMeter    *_accuracy_top{1,2,3,5}, *_recall_top{1,2,3,5}, loss
     Ego4dOSCCMeter :292-318           OSCCMeter            accuracy, loss
     Ego4dPNRMeter :321-377            PNRMeter             accuracy, recall, auroc, localization_error, loss
     Ego4dLTAMeter :380-453            LTAMeter             verbs_ed, nouns_ed (+ verbs/nouns_top1), loss
-Dropped: confusion matrices, calibration / Brier scores, per-class loss tables, feature dumps (reporting only).
+Dropped: confusion matrices, per-class loss tables, feature dumps (reporting only).
 
 Several ranks (SURVEY §8(e) caveat 5): every meter is a set of SUMS (integer counts, float64 loss / distance sums) plus,
 for the PNR AUROC, a list of scores.  ``merge`` adds another meter's state, ``all_reduce`` does the same across the
@@ -94,6 +95,53 @@ class _HeadCounts:
         """average="macro" (= utils/meters/utils.py topk_recall): mean over the classes that occurred."""
         seen = self.support > 0
         return float(self.class_accuracy(k)[seen].mean()) if bool(seen.any()) else 0.0
+
+
+class _Calibration:
+    """torchmetrics MulticlassCalibrationError(num_classes, n_bins, norm, ignore_index=-1) as the reference builds it
+    (utils/meters/ego4d.py:52-53, :66-67: 15 bins / l1 = the expected calibration error; 1 bin / l2 = its "Brier score") as
+    per-bin SUMS on the device -- count, confidence sum, hit count -- so that it merges across shards like every other meter
+    (torchmetrics keeps the confidence of every sample and bins at compute time: the same bins, the same sums)."""
+
+    def __init__(self, n_bins: int, norm: str, device):
+        if norm not in ("l1", "l2", "max"):
+            raise ValueError(norm)
+        self.n_bins, self.norm = n_bins, norm
+        self.bounds = torch.linspace(0, 1, n_bins + 1, dtype=torch.float32, device=device)
+        self.count = torch.zeros(n_bins + 1, dtype=torch.int64, device=device)  # (+1: a confidence of exactly 1 has its own bin)
+        self.hits = torch.zeros(n_bins + 1, dtype=torch.int64, device=device)
+        self.conf = torch.zeros(n_bins + 1, dtype=torch.float64, device=device)
+
+    def update(self, logits: torch.Tensor, labels: torch.Tensor):
+        p = logits.detach().float()
+        labels = labels.to(torch.int64)
+        in_unit = ((p >= 0) & (p <= 1)).all()  # (scores that already are probabilities are taken as they are)
+        p = torch.where(in_unit, p, p.softmax(1))
+        conf, pred = p.max(dim=1)
+        ok = labels != -1
+        w = ok.to(torch.float64)
+        idx = (torch.bucketize(conf, self.bounds, right=True) - 1).clamp_(0, self.n_bins)
+        self.count += torch.bincount(idx, weights=w, minlength=self.n_bins + 1).to(torch.int64)
+        self.hits += torch.bincount(idx, weights=w * (pred == labels).to(torch.float64), minlength=self.n_bins + 1).to(torch.int64)
+        self.conf += torch.bincount(idx, weights=w * conf.double(), minlength=self.n_bins + 1)
+
+    def tensors(self) -> List[torch.Tensor]:
+        return [self.count, self.hits, self.conf]
+
+    def compute(self) -> float:
+        cnt = self.count.double()
+        total = float(cnt.sum())
+        if total == 0:
+            return 0.0
+        acc = torch.nan_to_num(self.hits.double() / cnt)
+        conf = torch.nan_to_num(self.conf / cnt)
+        share = cnt / total
+        if self.norm == "l1":
+            return float((acc - conf).abs().mul(share).sum())
+        if self.norm == "max":
+            return float((acc - conf).abs().max())
+        ce = float(((acc - conf) ** 2 * share).sum())
+        return ce ** 0.5 if ce > 0 else 0.0
 
 
 class BaseMeter:
@@ -200,16 +248,29 @@ class _VerbNounMeter(BaseMeter):
 
 
 class RecognitionMeter(_VerbNounMeter):
+    def __init__(self, dataset, *args, **kwargs) -> None:
+        super().__init__(dataset, *args, **kwargs)
+        # ego4d.py:52-53 / :66-67: calibration error (15 bins, l1) and "Brier score" (1 bin, l2) per head
+        self.calibration = {h: (_Calibration(15, "l1", self.device), _Calibration(1, "l2", self.device)) for h in ("verbs", "nouns")}
+
+    def _sums(self):
+        return [*super()._sums(), *(t for h in ("verbs", "nouns") for c in self.calibration[h] for t in c.tensors())]
+
     @torch.no_grad()
     def update(self, logits, labels, *args, **kwargs) -> None:
         super().update(labels, *args, **kwargs)
         self._count(logits, labels)
+        for h, i in (("verbs", self.idx_verbs), ("nouns", self.idx_nouns)):
+            for c in self.calibration[h]:
+                c.update(logits[i], labels[:, i])
 
     def print_logs(self):
         v, n = self.verbs, self.nouns
         return [f"Verbs Top-1: {v.accuracy(1) * 100:.2f}, Top-2: {v.accuracy(2) * 100:.2f}, Top-3: {v.accuracy(3) * 100:.2f}, Top-5: {v.accuracy(5) * 100:.2f}",
                 f"Nouns Top-1: {n.accuracy(1) * 100:.2f}, Top-2: {n.accuracy(2) * 100:.2f}, Top-3: {n.accuracy(3) * 100:.2f}, Top-5: {n.accuracy(5) * 100:.2f}",
                 f"Verbs Mean class: {v.mean_class() * 100:.2f}", f"Nouns Mean class: {n.mean_class() * 100:.2f}",
+                f"Verbs Brier score: {self.calibration['verbs'][1].compute():.4f}",
+                f"Nouns Brier score: {self.calibration['nouns'][1].compute():.4f}",
                 *super().print_logs()]
 
     def get_logs(self, *args, **kwargs):
@@ -219,6 +280,8 @@ class RecognitionMeter(_VerbNounMeter):
             out[f"{name}_mc"] = h.mean_class()
             out[f"{name}_class_acc"] = {"top-1": h.class_accuracy(1).cpu(), "top-2": h.class_accuracy(2).cpu(),
                                         "top-5": h.class_accuracy(5).cpu(), "support": h.support.cpu()}
+            out[f"{name}_calibration_erorr"] = self.calibration[name][0].compute()  # (sic: the reference's key, ego4d.py:174)
+            out[f"{name}_brier_score"] = self.calibration[name][1].compute()
         return {**out, **super().get_logs()}
 
 

@@ -3602,7 +3602,10 @@ def _bank_window_operand(bank, f16: bool = False):
     rmax = torch.empty(1, dtype=torch.float32, device=bank.device)
     _ck(_lib.load().egk_residual_ratio16(_stream(), _p(bank), bank.stride(0), _p(r), _p(rmax), bank.shape[0], bank.shape[1], int(f16)),
         "egk_residual_ratio16")
-    _window_bank_cache[key] = (bank._version, hi, rmax, bank)  # (the bank itself: its address cannot be reused while it is cached)
+    if not torch.cuda.is_current_stream_capturing():
+        # (tensors made inside a hipGraph capture live in the graph's pool and hold values only after a replay: never cached --
+        #  as ``weight_operand`` does with the frozen weights' copies)
+        _window_bank_cache[key] = (bank._version, hi, rmax, bank)  # (the bank itself: its address cannot be reused while it is cached)
     return hi, rmax
 
 

@@ -279,6 +279,10 @@ class FlatAdam(torch.optim.Optimizer):
         if self.flat_w16 is not None:
             _ck(_lib.load().egk_cast(_stream(), _p(self.flat_p), 0, _p(self.flat_w16), 1, self.flat_p.numel()), "egk_cast")
         self._lo_fresh = []
+        if self.flat_w16lo is not None and self.adam_writes_lo:
+            # a captured step whose Adam launches keep the low halves holds NO split launch (engine.StepBase.capture): an
+            # out-of-band write to the parameters (checkpoint load, a restored snapshot) must leave them fresh itself
+            self.refresh_lo_shadows()
 
     @property
     def materialised(self) -> bool:

@@ -44,7 +44,9 @@ def seed_everything(cfg, rank: int):
         import numpy as np
         np.random.seed(cfg.seed)
         torch.manual_seed(cfg.seed)  # identical parameter init on every rank
-        ops.manual_seed(cfg.seed * 7919 + rank + int(cfg.get("dropout_seed_offset", 0) or 0))  # dropout streams differ per rank
+        # dropout streams differ per rank; ``dropout_seed_offset`` (the noise-floor runs of the metric comparison) is mixed in with a
+        # stride no rank count reaches, so offset k on rank r is not rank r + k's stream of the base run
+        ops.manual_seed(cfg.seed * 7919 + rank + int(cfg.get("dropout_seed_offset", 0) or 0) * 1000003)
 
 
 def task_weights(cfg) -> Dict[str, float]:

@@ -15,21 +15,47 @@ def _eval_mode(model, primary_task, other_tasks, graphone):
         graphone.eval()
 
 
+# bf16 modes with a GraphONE: the backbone runs ONCE -- the forward-only precise ('bf16x3') pass tapes its nodes' results and the
+# bf16 pass takes their roundings instead of launching its kernels (ops.dual_record / dual_replay, what engine.EgoPackStep's
+# one-pass step does).  False: the two passes of rounds 3-5 (kept for the A/B test).
+ONE_PASS = True
+
+
+def _one_pass_ok(model, data) -> bool:
+    from . import ops
+    x = getattr(data, "x", None)
+    return bool(ONE_PASS and ops.get_compute() == "bf16" and torch.is_tensor(x) and x.dtype == torch.bfloat16 and not model.training
+                and not ops.graph_ln_exchange_on() and getattr(model, "stage_cut", None) is None)
+
+
 def _logits(model, data, primary_task, other_tasks, graphone, late_fusion, needs_batch: bool):
     """validate.py:34-53 / :85-100 / :130-145.  ``late_fusion=False`` with a GraphONE takes the elementwise max of the
     primary and aux features before the classifier, as the reference does."""
-    feat = model(data)
-    feat_primary = primary_task.forward_features(feat)
+    from . import ops
     batch = getattr(data, "batch", None)
-    if graphone is not None:
-        from . import ops
-        if ops.get_compute() in ("bf16", "bf16_f32act"):
-            # the features behind the nearest-prototype search (an index op) come from a forward-only 'bf16x3' pass: f32-grade
-            # values, so that the neighbour lists are the reference's also with bf16 activations (engine.EgoPackStep)
-            with ops.precise_scope():
+    feat_secondary = None
+    if graphone is not None and ops.get_compute() in ("bf16", "bf16_f32act"):
+        # the features behind the nearest-prototype search (an index op) come from a forward-only 'bf16x3' pass: f32-grade
+        # values, so that the neighbour lists are the reference's also with bf16 activations (engine.EgoPackStep)
+        tape = [] if _one_pass_ok(model, data) else None
+        with ops.precise_scope():
+            if tape is not None:
+                with ops.dual_record() as rec:
+                    feat_hp = model(data)
+                tape.extend(rec)
+            else:
                 feat_hp = model(data)
-                feat_secondary = {task.name: task.forward_features(feat_hp, out_f32=True) for task in other_tasks}
+            feat_secondary = {task.name: task.forward_features(feat_hp, out_f32=True) for task in other_tasks}
+        if tape:
+            with ops.dual_replay(tape):  # (the bf16 features = roundings of the precise pass's results: no second backbone pass)
+                feat = model(data)
         else:
+            feat = model(data)
+    else:
+        feat = model(data)
+    feat_primary = primary_task.forward_features(feat)
+    if graphone is not None:
+        if feat_secondary is None:
             feat_secondary = {task.name: task.forward_features(feat, out_f32=True) for task in other_tasks}  # (f32 for the search)
         feat_secondary, *_ = graphone.interact(feat_secondary)
         # post_features as the reference hands them to the meter (validate.py:43): [N, 1 + aux, H]

@@ -173,7 +173,7 @@ def radius_graph(
     max_num_neighbors: int = 32,
 ) -> torch.Tensor:
     """torch_cluster.radius_graph(flow='source_to_target') on 1-D / [N,1] positions:
-    all (source j, target i) with ||pos_i - pos_j|| <= r inside one batch element, grouped
+    all (source j, target i) with ||pos_i - pos_j|| < r (strict, as torch_cluster's radius test: SURVEY A.9) inside one batch element, grouped
     by target, at most max_num_neighbors per target (never binding for the band graphs the
     reference builds: r = k + 0.5, k <= 2).  Neighbour order inside a target group is
     KD-tree dependent in torch_cluster; here it is ascending source index.
@@ -182,7 +182,7 @@ def radius_graph(
     p = pos.reshape(pos.shape[0], -1).to(torch.float64)
     n = p.shape[0]
     d = torch.cdist(p, p)
-    adj = d <= r
+    adj = d < r
     if batch is not None:
         adj &= batch.view(-1, 1) == batch.view(1, -1)
     if not loop:

@@ -79,6 +79,11 @@ def test_recognition_meter_matches_reference_topk_functions(M, golden):
     assert m.verbs.mean_class(5) == pytest.approx(g["recall"][5], abs=1e-12)
     assert float(logs["verbs_class_acc"]["top-1"][3]) == pytest.approx(g["class3"][0], abs=1e-12)
     assert logs["nouns_top1"] == 0.0 and logs["loss"] == pytest.approx(0.25) and m.counter == scores.shape[0]
+    # calibration error / "Brier score" (ego4d.py:52-53, :66-67) against the restated torchmetrics definition
+    assert logs["verbs_calibration_erorr"] == pytest.approx(OM.multiclass_calibration_error(scores.numpy(), labels.numpy()), abs=1e-6)
+    assert logs["verbs_brier_score"] == pytest.approx(OM.multiclass_calibration_error(scores.numpy(), labels.numpy(), 1, "l2"), abs=1e-6)
+    assert logs["nouns_calibration_erorr"] == 0.0 and logs["nouns_brier_score"] == 0.0  # every noun label ignored
+    assert any(ln.startswith("Verbs Brier score") for ln in m.print_logs())
 
 
 def test_pnr_meter_matches_reference_meter_and_oracle(M, golden):
@@ -267,3 +272,56 @@ def test_batch_sharded_bank_pass_sums_to_the_single_pass_banks(M):
     for k in whole:
         assert merged[k].shape == whole[k].shape
         torch.testing.assert_close(merged[k], whole[k], rtol=1e-6, atol=1e-7)
+
+
+def test_validation_with_graphone_runs_the_backbone_once_in_bf16_mode(M):
+    """validation with a GraphONE in bf16 mode ran the backbone twice (precise pass + bf16 pass).  Now the
+    bf16 features are the roundings of the precise pass's taped results (validate.ONE_PASS, ops.dual_record / dual_replay):
+    same neighbour lists (they come from the precise pass either way), logits within bf16 rounding of the two-pass ones and
+    no further from the f32 run than those, and the backbone's contractions are launched once."""
+    from egopack_amd.models.graphONE.graphONE import GraphONE
+    H, K = 128, 256
+    torch.manual_seed(3)
+    ds = M.data.SyntheticTaskDataset("oscc", 16, 8, 3, 64, (7, 11), k=1, seed=4)
+    model = M.Graph(64, hidden_size=H, depth=2, temporal_pooling={**TRN_CFG, "hidden_size": H}, num_segments=3).to(DEV)
+    aux = ("ar", "lta", "pnr")
+    primary = M.OSCCTask(H, H, aux_tasks=aux, average_logits=True).to(DEV)
+    others = [M.RecognitionTask(H, H, (7, 11)).to(DEV), M.LTATask(H, H, (7, 11)).to(DEV), M.PNRTask(H, H).to(DEV)]
+    for t, n in zip(others, aux):
+        t.name = n
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    banks = {n: torch.randn(K, H, device=DEV, generator=gen) for n in aux}
+    g1 = GraphONE(banks, features_size=H, hidden_size=H, k=4, depth=2, residual=True).to(DEV)
+
+    def run(mode, one_pass):
+        dl = M.data.build_dataloader(ds, 8, False, 0, False, 1)
+        rec = _Recorder()
+        prev, M.validate.ONE_PASS = M.validate.ONE_PASS, one_pass
+        try:
+            with M.ops.compute_mode(mode):
+                batches = []
+                for b in dl:
+                    b = b.to(DEV)
+                    if mode == "bf16":
+                        b.x = b.x.to(torch.bfloat16)
+                    batches.append(b)
+                M.ops.prof_reset()
+                M.ops.prof_enable(True)
+                M.validate.validate(0, model, batches, rec, primary, other_tasks=others, graphone=g1, late_fusion=True, device=DEV)
+                torch.cuda.synchronize()
+                M.ops.prof_enable(False)
+                launches = sum(v["launches"] for k, v in M.ops.prof_report().items() if k.startswith("gemm"))
+                M.ops.prof_reset()
+        finally:
+            M.validate.ONE_PASS = prev
+        return [c[0].float().cpu() for c in rec.calls], [c[4].float().cpu() for c in rec.calls], launches
+
+    f32, _, _ = run("f32", True)
+    two, two_feat, n_two = run("bf16", False)
+    one, one_feat, n_one = run("bf16", True)
+    assert n_one < n_two, (n_one, n_two)  # the bf16 backbone pass launches no contraction of its own
+    for a, b, r in zip(one, two, f32):
+        torch.testing.assert_close(a, b, rtol=0, atol=6e-2)
+        assert float((a - r).abs().max()) <= float((b - r).abs().max()) * 1.5 + 1e-2
+    for a, b in zip(one_feat, two_feat):  # post-features [N, 1 + aux, H]: the aux parts come from the precise pass in both
+        assert float((a - b).norm() / b.norm()) < 3e-2

@@ -549,3 +549,24 @@ def test_dual_replay_refuses_a_tape_that_was_not_consumed():
         with ops.dual_replay([("linear", {})]):
             raise ValueError("x")
     assert ops._dual["replay"] is None
+
+
+def test_fast_key_sees_the_labelled_row_set_of_a_compacted_head():
+    """two AR batches with the same graph structure, feature shape and label shape but another labelled-row set
+    (a sequence whose centre labels are all -1) differ in what a capture bakes in (the strided row view, the padded height of
+    the labelled-row arrays): the cheap key must differ wherever the full signature does."""
+    from egopack_amd import engine as E
+    ds = D.SyntheticTaskDataset("ar", 64, 8, 3, 8, (7, 11), k=1, seed=3)  # 64 labelled rows: the padded list IS a progression
+    a, b = D.collate([ds[i] for i in range(64)]), D.collate([ds[i] for i in range(64)])
+    row = int(b.live_idx[1])
+    b.y[row] = -1  # the second sequence loses its label: three labelled rows, no arithmetic progression over the padded list
+    D._attach_live_rows(b)
+    if getattr(b, "live_ap", None) is not None and D.live_rows_progression(b.live_idx) is None:
+        del b.live_ap
+    for x in (a, b):
+        x._struct_key = 77
+        x.x = torch.zeros(x.pos.shape[0], 3, 8)
+    assert getattr(a, "live_ap", None) != getattr(b, "live_ap", None)
+    assert E.batch_signature({"ar": a}) != E.batch_signature({"ar": b})
+    assert E._fast_key({"ar": a}, None) != E._fast_key({"ar": b}, None)
+    assert E._fast_key({"ar": a}, None) == E._fast_key({"ar": a}, None)

@@ -66,3 +66,35 @@ def test_binary_stats_and_auroc_known_answers():
     # pairs (pos, neg): 0.9>{.8,.3,.3}=3, 0.5>{.3,.3}=2, 0.4>{.3,.3}=2 -> 7/9
     assert OM.binary_auroc(p, t) == pytest.approx(7 / 9)
     assert OM.binary_auroc(np.array([0.5, 0.5]), np.array([1, 0])) == pytest.approx(0.5)
+
+
+def test_calibration_error_known_answers_and_the_device_sums():
+    """MulticlassCalibrationError as the reference builds it (utils/meters/ego4d.py:52-53,66-67; torchmetrics 1.0.1 is absent:
+    parity unpinned, so hand-derived answers): probabilities are taken as they are, logits go through a softmax, ignored rows
+    drop out, the 15-bin l1 error weighs |accuracy - confidence| by the bin shares, one bin / l2 is |mean acc - mean conf|."""
+    p = np.array([[0.9, 0.1], [0.6, 0.4], [0.3, 0.7], [0.2, 0.8], [0.5, 0.5]], dtype=np.float32)
+    y = np.array([0, 1, 1, 0, -1])
+    # bins of width 1/15: conf 0.9 -> bin 13 (hit), 0.6 -> bin 9 (miss), 0.7 -> bin 10 (hit), 0.8 -> bin 12 (miss); row 4 ignored
+    want = (abs(1 - 0.9) + abs(0 - 0.6) + abs(1 - 0.7) + abs(0 - 0.8)) / 4
+    assert OM.multiclass_calibration_error(p, y) == pytest.approx(want, abs=1e-6)
+    assert OM.multiclass_calibration_error(p, y, n_bins=1, norm="l2") == pytest.approx(abs(0.5 - 0.75), abs=1e-6)
+    assert OM.multiclass_calibration_error(p, y, norm="max") == pytest.approx(0.8, abs=1e-6)
+    sure = np.array([[1.0, 0.0], [1.0, 0.0]], dtype=np.float32)  # confidence exactly 1: a bin of its own, perfectly calibrated
+    assert OM.multiclass_calibration_error(sure, np.array([0, 0])) == 0.0
+    logits = np.log(np.array([[0.9, 0.1], [0.6, 0.4], [0.3, 0.7], [0.2, 0.8]], dtype=np.float64)) + 3.0  # softmax gives p back
+    assert OM.multiclass_calibration_error(logits, y[:4]) == pytest.approx(want, abs=1e-6)
+    assert OM.multiclass_calibration_error(p[:0], y[:0]) == 0.0
+    # the product meter's per-bin sums (plain tensor ops: runs on the CPU too), fed in two pieces, equal the one-shot oracle
+    from egopack_amd.meters import _Calibration
+    gen = torch.Generator().manual_seed(11)
+    s = torch.randn(500, 13, generator=gen) * 2
+    t = torch.randint(-1, 13, (500,), generator=gen)
+    for n_bins, norm in ((15, "l1"), (1, "l2"), (15, "max")):
+        c = _Calibration(n_bins, norm, "cpu")
+        c.update(s[:200], t[:200])
+        c.update(s[200:], t[200:])
+        assert c.compute() == pytest.approx(OM.multiclass_calibration_error(s.numpy(), t.numpy(), n_bins, norm), abs=1e-6)
+    probs = torch.rand(40, 13, generator=gen) * 0.9  # scores inside [0, 1]: taken as they are, no softmax
+    other = _Calibration(15, "l1", "cpu")
+    other.update(probs, t[:40])
+    assert other.compute() == pytest.approx(OM.multiclass_calibration_error(probs.numpy(), t[:40].numpy()), abs=1e-6)

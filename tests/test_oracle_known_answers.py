@@ -117,3 +117,79 @@ def test_compute_edges_known_answer():
     edges, closest = O.compute_edges(f, bank, k=2)
     assert closest.tolist() == [[0, 3], [1, 3]]
     assert edges.tolist() == [[0, 3, 1, 3], [4, 4, 5, 5]]
+
+
+# ---- independent second formulations: a slip in a restated leaf cannot pass both its own statement and these ----
+def _dense_adjacency(edge_index, n):
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((edge_index[1], edge_index[0]), torch.ones(edge_index.shape[1], dtype=torch.float64), accumulate=True)
+    return a  # a[i, j] = number of edges j -> i
+
+
+def test_sage_mean_equals_the_dense_normalised_adjacency_product():
+    """SAGEConv(mean, root_weight, project) as D^-1 A relu(X Wp^T + bp) Wl^T + bl + X Wr^T with a dense adjacency (multi-edges
+    counted, isolated nodes: zero row) -- no scatter, no index_select."""
+    gen = torch.Generator().manual_seed(21)
+    n, c, h = 23, 6, 5
+    x = torch.randn(n, c, generator=gen, dtype=torch.float64)
+    ei = torch.randint(0, n, (2, 70), generator=gen)
+    ei = ei[:, ei[1] != 7]  # node 7 has no in-edge
+    wl, bl, wr = torch.randn(h, c, generator=gen, dtype=torch.float64), torch.randn(h, generator=gen, dtype=torch.float64), torch.randn(h, c, generator=gen, dtype=torch.float64)
+    wp, bp = torch.randn(c, c, generator=gen, dtype=torch.float64), torch.randn(c, generator=gen, dtype=torch.float64)
+    a = _dense_adjacency(ei, n)
+    norm = a / a.sum(1, keepdim=True).clamp(min=1)
+    want = norm @ torch.relu(x @ wp.t() + bp) @ wl.t() + bl + x @ wr.t()
+    torch.testing.assert_close(P.sage_conv(x, ei, wl, bl, wr, wp, bp, "mean"), want, rtol=1e-12, atol=1e-12)
+    want_plain = norm @ x @ wl.t() + x @ wr.t()
+    torch.testing.assert_close(P.sage_conv(x, ei, wl, None, wr, None, None, "mean"), want_plain, rtol=1e-12, atol=1e-12)
+    assert bool((norm[7] == 0).all())
+
+
+def test_sage_max_equals_a_masked_dense_maximum():
+    gen = torch.Generator().manual_seed(22)
+    n, c = 17, 4
+    x = torch.randn(n, c, generator=gen, dtype=torch.float64)
+    ei = P.add_remaining_self_loops(torch.randint(0, n, (2, 40), generator=gen), n)
+    wl, wr = torch.randn(3, c, generator=gen, dtype=torch.float64), torch.randn(3, c, generator=gen, dtype=torch.float64)
+    mask = _dense_adjacency(ei, n) > 0  # [target, source]
+    m = torch.where(mask[:, :, None], x[None, :, :], torch.full((), -float("inf"), dtype=torch.float64)).max(1).values
+    torch.testing.assert_close(P.sage_conv(x, ei, wl, None, wr, None, None, "max"), m @ wl.t() + x @ wr.t(), rtol=1e-12, atol=1e-12)
+
+
+def test_graph_layer_norm_equals_layer_norm_over_the_flattened_tensor_with_the_eps_moved_to_the_std():
+    """mode='graph' = ONE normalisation over all N * C elements.  F.layer_norm over the flattened tensor is that with eps inside
+    the square root: y_ln = (x - m) / sqrt(v + e); PyG divides by (sqrt(v) + e) -- so y = y_ln * sqrt(v + e) / (sqrt(v) + e)."""
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(19, 8, generator=gen, dtype=torch.float64) * 3 + 1.5
+    w, b = torch.randn(8, generator=gen, dtype=torch.float64), torch.randn(8, generator=gen, dtype=torch.float64)
+    eps = 1e-5
+    y_ln = torch.nn.functional.layer_norm(x.reshape(-1), (x.numel(),), eps=eps).reshape(x.shape)
+    v = x.var(unbiased=False)
+    want = y_ln * torch.sqrt(v + eps) / (torch.sqrt(v) + eps) * w + b
+    torch.testing.assert_close(P.graph_layer_norm(x, w, b, eps), want, rtol=1e-12, atol=1e-12)
+    # the eps placement is visible on a nearly constant tensor: the two conventions differ by orders of magnitude there
+    tiny = torch.full((4, 8), 2.0, dtype=torch.float64) + 1e-7 * torch.randn(4, 8, generator=gen, dtype=torch.float64)
+    got = P.graph_layer_norm(tiny, torch.ones(8, dtype=torch.float64), torch.zeros(8, dtype=torch.float64), eps)
+    inside = torch.nn.functional.layer_norm(tiny.reshape(-1), (32,), eps=eps).reshape(4, 8)
+    assert float(got.abs().max()) > 100 * float(inside.abs().max())  # (sqrt(v + e) / (sqrt(v) + e) ~ 300 at std 1e-7)
+
+
+def test_positional_encoding_equals_the_complex_exponential():
+    f = P.positional_encoding_frequency(16)
+    assert float(f[0]) == 1.0 and abs(float(f[-1]) - 1e-4) < 1e-10  # logspace(0, 1, C/2, base): base^0 .. base^1
+    pos = torch.tensor([-3.0, 0.0, 1.0, 7.5])
+    z = torch.exp(1j * (pos.double()[:, None] * f.double()[None, :]))
+    want = torch.cat([z.imag, z.real], -1).float()  # [sin | cos]
+    torch.testing.assert_close(P.positional_encoding(pos, f), want, rtol=1e-6, atol=1e-6)
+
+
+def test_radius_graph_equals_a_brute_force_strict_test():
+    """torch_cluster's radius test is strict: at the reference's r = k + 0.5 on integer positions both conventions
+    agree; at an integer r they differ -- the restatement must be the strict one."""
+    pos = torch.tensor([0, 1, 2, 4, 0, 1])
+    batch = torch.tensor([0, 0, 0, 0, 1, 1])
+    for r in (1.5, 2.0, 2.5):
+        want = {(j, i) for i in range(6) for j in range(6) if i != j and int(batch[i]) == int(batch[j]) and abs(int(pos[i]) - int(pos[j])) < r}
+        got = set(map(tuple, P.radius_graph(pos, r, batch).t().tolist()))
+        assert got == want, r
+    assert (2, 0) not in set(map(tuple, P.radius_graph(pos, 2.0, batch).t().tolist()))  # |0 - 2| = r: not an edge
