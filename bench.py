@@ -179,6 +179,7 @@ ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pip
                 "gemm_bf16_tt_g2": _pipe("true", "true", 2), "gemm_bf16_tn_g2": _pipe("true", "false", 2),
                 "gemm_bf16_nn_r96": _pipe("false", "false", 1, 3), "gemm_bf16_nt_r96": _pipe("false", "true", 1, 3),
                 "gemm_bf16_nn_r64": _pipe("false", "false", 1, 2), "gemm_bf16_nt_r64": _pipe("false", "true", 1, 2),
+                "gemm_bf16_nn_r192": "gemm_pipe_kernel<3, false, false, 1, 2, 3", "gemm_bf16_nt_r192": "gemm_pipe_kernel<3, false, true, 1, 2, 3",
                 "gemm_bf16_nn_t256": "gemm_big_kernel<false, false", "gemm_bf16_nt_t256": "gemm_big_kernel<false, true",
                 "gemm_bf16_tt_t256": "gemm_big_kernel<true, true", "gemm_bf16_tn_t256": "gemm_big_kernel<true, false",
                 "gemm_bf16_group_nn": "gemm_pipe_group_kernel<2, false, false", "gemm_bf16_group_nt": "gemm_pipe_group_kernel<2, false, true",

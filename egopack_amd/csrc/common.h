@@ -46,6 +46,8 @@ enum KernelId {
     KID_GEMM_BF16_NT_R96,
     KID_GEMM_BF16_NN_R64,  // 64-row tiles: launches of at most 128 tiles of 128 rows, one 4-wave workgroup per CU
     KID_GEMM_BF16_NT_R64,
+    KID_GEMM_BF16_NN_R192, // 192 x 128 tiles, one 8-wave workgroup per CU on a 3-stage ring: outputs of ~256 such tiles (6144 x 1024)
+    KID_GEMM_BF16_NT_R192,
     KID_GEMM_BF16_NN_T256, // 256 x 256 tiles, one 8-wave workgroup per CU: outputs of >= ~200 such tiles
     KID_GEMM_BF16_NT_T256,
     KID_GEMM_BF16_TT_T256,

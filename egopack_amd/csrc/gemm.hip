@@ -437,9 +437,12 @@ __host__ __device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
     return true;
 }
 
-template <int NI, bool GA = false, bool ST = true>
+// MBW = 2: the 8-wave tall tiles (waves as 4 x 2 over 32 * NI * 2 rows): the same staging image with twice the rows, read out 32
+// rows per pass by the 512 threads; the statistics of the 8 waves are summed in wave order, pairwise.
+template <int NI, bool GA = false, bool ST = true, int MBW = 1>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[NI][4], unsigned char* lds, int m0, int n0,
                                                    int wm, int wn, int lr, int lg, int z, int tid, int st_tile = 0) {
+    static_assert(MBW == 1 || !GA, "the row gather in the epilogue exists for the 4-wave tiles only");
     __syncthreads();  // every wave is done with the ring (nothing is in flight: the last tiles were waited for)
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -481,7 +484,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     }
 #pragma unroll
     for (int it = 0; it < 2 * NI; ++it) {
-        const int row = it * 16 + (tid >> 4), m = m0 + row;
+        const int row = it * (16 * MBW) + (tid >> 4), m = m0 + row;
         if (m >= g.M || !st_cols) continue;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * 128 + (((2 * c8) ^ (row & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * 128 + (((2 * c8 + 1) ^ (row & 15)) << 2));
@@ -586,7 +589,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
         }
     }
     if constexpr (ST) if (st_mode) {  // block sums in a fixed order: lanes (shuffle tree), then the 4 waves in wave order
-        __shared__ double st_red[4][4];
+        __shared__ double st_red[4 * MBW][4];
         double v4[4] = {(double)sa[0][0], (double)sa[0][1], (double)sa[1][0], (double)sa[1][1]};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -600,7 +603,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
         if (tid < g.st_nseg * 2) {
             const int sg = tid >> 1, k = tid & 1, rel = sg - s0;
             double t_ = 0.0;
-            if (rel == 0 || rel == 1) t_ = (st_red[0][rel * 2 + k] + st_red[1][rel * 2 + k]) + (st_red[2][rel * 2 + k] + st_red[3][rel * 2 + k]);
+            if (rel == 0 || rel == 1) {
+                t_ = (st_red[0][rel * 2 + k] + st_red[1][rel * 2 + k]) + (st_red[2][rel * 2 + k] + st_red[3][rel * 2 + k]);
+                if constexpr (MBW == 2)
+                    t_ += (st_red[4][rel * 2 + k] + st_red[5][rel * 2 + k]) + (st_red[6][rel * 2 + k] + st_red[7][rel * 2 + k]);
+            }
             g.st_ws[((long long)st_tile * g.st_nseg + sg) * 2 + k] = t_;
         }
     }
@@ -884,9 +891,11 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
     // 128-row tiling leaves the CUs unevenly loaded (6144 x 1024: 384 tiles = 1.5 per CU; 512 tiles of 96 x 128 = 2)
-    static_assert(NI == 4 || ((NI == 3 || NI == 2) && !TRA && MB == 1 && (KG == 1 || NI == 2)),
-                  "96- / 64-row tiles: row-major A; two wave groups with 64-row tiles only");
-    constexpr int IMG = 16384, IMG_A = NI == 4 ? MB * IMG : NI * 4096, STAGE = IMG_A + IMG;
+    // MB = 2 with NI = 3: 192 x 128 tiles, 8 waves as 4 x 2 (48 x 64 each) -- 6144 x 1024 outputs are exactly 256 of them, one
+    // per CU, at 40 KiB per K tile for 1.5 x the flops of the 128 x 128 tile's 32 KiB
+    static_assert(NI == 4 || ((NI == 3 || NI == 2) && !TRA && ((MB == 1 && (KG == 1 || NI == 2)) || (MB == 2 && KG == 1 && NI == 3))),
+                  "96- / 64-row tiles: row-major A; two wave groups with 64-row tiles only; the tall 8-wave tile with NI = 3");
+    constexpr int IMG = 16384, IMG_A = NI == 4 ? MB * IMG : MB * NI * 4096, STAGE = IMG_A + IMG;
     constexpr int NPB = 4 / MB;        // B pieces per wave per tile
     constexpr int LOADS = NI + NPB;    // wave-instructions per wave per tile
     constexpr int WG = 4 * MB;         // waves per wave group
@@ -1112,6 +1121,10 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     if constexpr (KG == 1) {
         if constexpr (MB == 1) {
             if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, GA>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
+            else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
+        } else if constexpr (NI == 3) {  // 192 x 128: the staging image (96 KiB f32) fits the 3-stage ring
+            static_assert(NSTAGE * STAGE >= 192 * 512, "the rows epilogue stages the whole tile in the ring");
+            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, false, true, 2>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
             else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         } else {
             gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
@@ -2182,6 +2195,7 @@ static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(1
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static int g_tt_sub = 0;            // development knob (egk_gemm_set_pipeline(800 + NSUB): dW-form launches on the sub-staged ring; 800 = off)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
+static int g_r192 = 1;              // development knob (egk_gemm_set_pipeline(900 / 901)): 192 x 128 tiles (variant 16) inside the policy off / on
 static bool g_lds_attr_set = false;
 template <int NS, bool TA, bool TB, int KG, int MB = 1>
 static void set_lds_attr() {
@@ -2226,6 +2240,8 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_group_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<3, false, false, 1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<3, false, true, 1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
     // the instantiations with the row gather in the epilogue (96- and 64-row tiles, row-major A)
@@ -2248,6 +2264,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 900) { g_r192 = on - 900; return prev; }
     if (on >= 800) { g_tt_sub = on - 800; return prev; }
     if (on >= 700) { g_sk_in_launch = on - 700; return prev; }
     if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
@@ -2258,7 +2275,8 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     if (on >= 100) { g_group_m_override = on - 100; return prev; }
     // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
     // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 7 always the 256 x 256 tile (no fused
-    // bias gradient: falls back to 3 with one); 8 / 11 the 96 x 128 / 64 x 128 tile where legal (row-major A)
+    // bias gradient: falls back to 3 with one); 8 / 11 the 96 x 128 / 64 x 128 tile where legal (row-major A); 16 the 192 x 128
+    // tile (8 waves, 3-stage ring) where legal (row-major A, no split-K)
     g_use_pipe = on;
     return prev;
 }
@@ -2497,6 +2515,12 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                     // ceil(tiles / 256) tiles' worth of bytes on the fullest CU (6144 x 1024: 2 x 32 KiB per K tile with
                     // 384 tiles of 128 rows, 2 x 28 KiB with 512 tiles of 96 rows)
                     if (((t96 + 255) / 256) * 28 < ((t128 + 255) / 256) * 32) variant = 8;
+                    // ... or ONE 8-wave workgroup per CU on 192 x 128 tiles with a 3-stage ring (two K tiles = 80 KiB in flight
+                    // per CU): 40 KiB per K tile and round of 256 tiles -- 6144 x 1024 is exactly one round (256 tiles) where the
+                    // 96-row tiles are two co-resident workgroups of 28 KiB each
+                    const long long t192 = (long long)cdiv(g.M, 192) * g.tiles_n;
+                    const long long cur = variant == 8 ? ((t96 + 255) / 256) * 28 : ((t128 + 255) / 256) * 32;
+                    if (g_r192 && !d->ga_mode && t192 > 192 && ((t192 + 255) / 256) * 40 < cur) variant = 16;
                 } else if (t64 <= 256 && t64 > t128) {
                     // at most 128 tiles: 64-row tiles put one 4-wave workgroup on twice as many CUs instead of one
                     // 8-wave (two wave groups) workgroup on half of them (2048 x 1024 x 1024: 10.6 vs 12.4 us)
@@ -2524,8 +2548,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             if (variant != 7 && !d->transA && g.splitk == 1 && !g.dbias && g.M % 192 == 0 && g.N % 256 == 0 && t192 >= 192 && K >= 1024 &&
                 10 * t192 >= 9 * 256 * ((t192 + 255) / 256))
                 variant = 15;
-        } else if ((variant == 8 || variant == 11 || variant == 12) && d->transA) {
-            variant = 3;  // the forced variants exist for row-major A only
+        } else if ((variant == 8 || variant == 11 || variant == 12 || variant == 16) && (d->transA || (variant == 16 && (g.splitk > 1 || d->ga_mode)))) {
+            variant = 3;  // the forced variants exist for row-major A only (16: unsplit, no row gather in the epilogue)
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
         } else if (variant == 15 && (d->transA || g.dbias || g.M % 192 != 0 || g.N % 256 != 0)) {
@@ -2534,7 +2558,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         const int mb = (variant == 6 || variant == 13 || variant == 14) ? 2 : 1;
         if (variant == 12 && (d->st_mode || d->ga_mode)) variant = 11;  // (forced by the knob: the epilogue features win)
         g.tiles_m = variant == 8 ? cdiv(g.M, 96) : (variant == 11 || variant == 12) ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256)
-                    : variant == 15 ? cdiv(g.M, 192) : cdiv(g.M, BM * mb);
+                    : (variant == 15 || variant == 16) ? cdiv(g.M, 192) : cdiv(g.M, BM * mb);
         if (variant == 7 || variant == 15) g.tiles_n = cdiv(g.N, 256);
 #ifdef EGK_GEMM_STAMPS
         if (variant != 7 && !g.dbias && d->ws) {
@@ -2556,8 +2580,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
 
         // segment statistics in the epilogue: the 4-wave variants that write their tile out through LDS in whole rows, unsplit,
         // and tiles that span at most two row segments
-        const int tile_rows = variant == 8 ? 96 : (variant == 11 || variant == 12) ? 64 : 128;
-        const bool st_ok = (variant == 2 || variant == 3 || variant == 4 || variant == 8 || variant == 11) && g.splitk == 1 &&
+        const int tile_rows = variant == 8 ? 96 : (variant == 11 || variant == 12) ? 64 : variant == 16 ? 192 : 128;
+        const bool st_ok = (variant == 2 || variant == 3 || variant == 4 || variant == 8 || variant == 11 || variant == 16) && g.splitk == 1 &&
                            epilogue_rows_ok(g) && d->st_min_seg_rows >= tile_rows &&
                            (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % (g.c_bf16 ? 8 : 4) == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
         // row gather in the epilogue: the same variants; every edge inside one tile of this height (ga_tile_mask bit 0 / 1 / 2 =
@@ -2589,7 +2613,9 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
-        if (variant == 15) {                                                                                              \
+        if (variant == 16) {                                                                                              \
+            hipLaunchKernelGGL((gemm_pipe_kernel<3, false, TB, 1, 2, 3>), pgrid, dim3(2 * NTHREADS), 3 * 40960, s, g);    \
+        } else if (variant == 15) {                                                                                       \
             hipLaunchKernelGGL((gemm_big_kernel<false, TB, 8, 6>), pgrid, dim3(512), 131072, s, g);                       \
         } else if (variant == 7) {                                                                                        \
             hipLaunchKernelGGL((gemm_big_kernel<TA, TB>), pgrid, dim3(512), 131072, s, g);                                \
@@ -2615,6 +2641,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
     } while (0)
         {
             ProfScope prof((variant == 7 || variant == 15) ? KID_GEMM_BF16_NN_T256 + layout : variant == 8 ? KID_GEMM_BF16_NN_R96 + layout : variant == 11 ? KID_GEMM_BF16_NN_R64 + layout
+                                       : variant == 16 ? KID_GEMM_BF16_NN_R192 + layout
                                        : ((variant == 5 || variant == 12) ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);

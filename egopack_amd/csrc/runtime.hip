@@ -48,6 +48,7 @@ static const char* const kNames[KID_COUNT] = {
     "gemm_bf16_nn", "gemm_bf16_nt", "gemm_bf16_tt", "gemm_bf16_tn",
     "gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tt", "gemm_f32_tn",
     "gemm_bf16_nn_g2", "gemm_bf16_nt_g2", "gemm_bf16_tt_g2", "gemm_bf16_tn_g2", "gemm_bf16_nn_r96", "gemm_bf16_nt_r96", "gemm_bf16_nn_r64", "gemm_bf16_nt_r64",
+    "gemm_bf16_nn_r192", "gemm_bf16_nt_r192",
     "gemm_bf16_nn_t256", "gemm_bf16_nt_t256", "gemm_bf16_tt_t256", "gemm_bf16_tn_t256",
     "gemm_bf16_group_nn", "gemm_bf16_group_nt", "gemm_bf16_group_tt",
     "gemm_bf16_generic", "gemm_splitk_reduce",
