@@ -110,6 +110,29 @@ struct ProfScope {
 // ---- device helpers ------------------------------------------------------------------------
 constexpr int WAVE = 64;
 
+// ---- row ownership shared by the launches of a chain ---------------------------------------------------------------------------
+// The hardware deals consecutive workgroups round-robin over the 8 XCDs (blockIdx % 8 = XCD; MI355X_MICROARCH.md, workgroup
+// dispatch) and every XCD has its own L2.  A tensor that one launch writes and the next one reads is served from the READER's L2
+// when the same XCD wrote those rows, and across the fabric otherwise -- measured (tools/exp/xcd_affinity.hip, a [6144, 1024] bf16
+// tensor read and another written per launch): 4.0-4.4 us when producer and consumer agree on who owns a row, 8.3-11.2 us when they
+// do not.  So every row kernel of the step gives XCD x the CONTIGUOUS rows [x * per, (x + 1) * per), per = ceil(rows / 8) rounded up
+// to whole workgroup passes -- the rows whose output tiles the contraction kernels hand to XCD x (gemm.hip: group_m = tiles_m / 8)
+// -- instead of dealing the rows round-robin with the workgroups.  Placement is a speed matter only: which workgroup computes a row
+// never changes the row's result.  Launches without whole rounds of 8 workgroups keep the round-robin walk.
+struct RowWalk {
+    int first, end, step;  // this wave's rows: first, first + step, first + 2 * step, ... < end
+};
+__device__ __forceinline__ RowWalk row_walk(int blk, int nblk, int row0, int rows, int wave, int wpb) {
+    if (nblk >= 8 && (nblk & 7) == 0) {
+        const int xcd = blk & 7, slot = blk >> 3, nslot = nblk >> 3;
+        const int per = (((rows - row0 + 7) >> 3) + wpb - 1) / wpb * wpb;
+        const int b = row0 + xcd * per;
+        const int e = b + per < rows ? b + per : rows;
+        return RowWalk{b + slot * wpb + wave, e, nslot * wpb};
+    }
+    return RowWalk{row0 + blk * wpb + wave, rows, nblk * wpb};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -589,7 +589,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
         }
     }
     if constexpr (ST) if (st_mode) {  // block sums in a fixed order: lanes (shuffle tree), then the 4 waves in wave order
-        __shared__ double st_red[4 * MBW][4];
+        // (the 8-wave tile keeps the wave partials behind its staging image in the ring -- every byte of the CU's LDS may belong to
+        //  the dynamic ring there (a 4-stage ring is 160 KiB): no static allocation)
+        __shared__ double st_red_static[MBW == 1 ? 4 : 1][4];
+        double (*st_red)[4] = st_red_static;
+        if constexpr (MBW == 2) st_red = reinterpret_cast<double (*)[4]>(lds + 32 * NI * MBW * 512);
         double v4[4] = {(double)sa[0][0], (double)sa[0][1], (double)sa[1][0], (double)sa[1][1]};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -892,7 +896,10 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
     // 128-row tiling leaves the CUs unevenly loaded (6144 x 1024: 384 tiles = 1.5 per CU; 512 tiles of 96 x 128 = 2)
     // MB = 2 with NI = 3: 192 x 128 tiles, 8 waves as 4 x 2 (48 x 64 each) -- 6144 x 1024 outputs are exactly 256 of them, one
-    // per CU, at 40 KiB per K tile for 1.5 x the flops of the 128 x 128 tile's 32 KiB
+    // per CU, at 40 KiB per K tile for 1.5 x the flops of the 128 x 128 tile's 32 KiB.  Measured (tools/round6/r192_bench.py): alone
+    // it runs at the 96-row tiles' rate (20.9 against 19.6 us at K = 1024, 59.5 against 59.2 at K = 4608), in the step 1.340 against
+    // 1.365 ms.  Built beside it and NOT kept: a 4-stage ring (every byte of LDS: 20.7 us, the step 1.345) and waves 4-7 staggered by
+    // half a K tile against their SIMD partners (fragments held across the barrier: 23.7 us, 256 registers + spills, the step 1.45).
     static_assert(NI == 4 || ((NI == 3 || NI == 2) && !TRA && ((MB == 1 && (KG == 1 || NI == 2)) || (MB == 2 && KG == 1 && NI == 3))),
                   "96- / 64-row tiles: row-major A; two wave groups with 64-row tiles only; the tall 8-wave tile with NI = 3");
     constexpr int IMG = 16384, IMG_A = NI == 4 ? MB * IMG : MB * NI * 4096, STAGE = IMG_A + IMG;
@@ -978,6 +985,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     const int bcc = tid & 15, bkg = (tid & 255) >> 4;
     const int bsub = MB == 2 ? (tid >> 8) : 0;  // tall tile: threads 256.. sum the second 128-row sub-image
 
+    uint4 a0[4], a1[4], b0[4], b1[4];  // fragments of one K tile (a*[NI..3] stay unused for 96-row tiles)
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
         if (p < nt) issue(p, p);
@@ -993,13 +1001,12 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
 #ifdef EGK_GEMM_STAMPS
         if (it == 0) ps_first = __builtin_amdgcn_s_memtime();
 #endif
+        const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG_A;
         if (it + NSTAGE - 1 < nt) issue(it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
         if (KG > 1 && it >= nt) continue;  // (wave-group uniform) odd tile count: the last round is group 0's only
 
         // Fragment reads as inline asm: hipcc cannot prove that a plain ds_read does not alias the LDS-DMA writes
         // in flight and would put s_waitcnt vmcnt(0) in front of it, draining the prefetched tiles.
-        const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG_A;
-        uint4 a0[4], a1[4], b0[4], b1[4];  // (a*[NI..3] stay unused for 96-row tiles)
         uint4 bz[4];
         if constexpr (TRA) {
             if (do_bias) {
@@ -1123,7 +1130,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
             if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, GA>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
             else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         } else if constexpr (NI == 3) {  // 192 x 128: the staging image (96 KiB f32) fits the 3-stage ring
-            static_assert(NSTAGE * STAGE >= 192 * 512, "the rows epilogue stages the whole tile in the ring");
+            static_assert(NSTAGE * STAGE >= 192 * 512 + 256, "the rows epilogue stages the whole tile (+ the wave partials) in the ring");
             if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, false, true, 2>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
             else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         } else {
@@ -2195,6 +2202,7 @@ static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(1
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static int g_tt_sub = 0;            // development knob (egk_gemm_set_pipeline(800 + NSUB): dW-form launches on the sub-staged ring; 800 = off)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
+static int g_row_affinity = 1;      // development knob (egk_gemm_set_pipeline(950 / 951)): XCD x owns a contiguous eighth of the tile rows off / on
 static int g_r192 = 1;              // development knob (egk_gemm_set_pipeline(900 / 901)): 192 x 128 tiles (variant 16) inside the policy off / on
 static bool g_lds_attr_set = false;
 template <int NS, bool TA, bool TB, int KG, int MB = 1>
@@ -2264,6 +2272,7 @@ static void ensure_lds_attr() {
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
 extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
+    if (on >= 950) { g_row_affinity = on - 950; return prev; }
     if (on >= 900) { g_r192 = on - 900; return prev; }
     if (on >= 800) { g_tt_sub = on - 800; return prev; }
     if (on >= 700) { g_sk_in_launch = on - 700; return prev; }
@@ -2276,7 +2285,8 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     // 0 generic kernel only; 1 default policy; 2 always 3-stage; 3 always 2-stage; 4 always 4-stage (all 128 x 128,
     // one wave group); 5 always two wave groups; 6 always the 256 x 128 tile (2-stage); 7 always the 256 x 256 tile (no fused
     // bias gradient: falls back to 3 with one); 8 / 11 the 96 x 128 / 64 x 128 tile where legal (row-major A); 16 the 192 x 128
-    // tile (8 waves, 3-stage ring) where legal (row-major A, no split-K)
+    // tile (8 waves, 3-stage ring) where legal (row-major A, no split-K); 900 / 901: variant 16 inside the policy off / on;
+    // 950 / 951: XCD x owns a contiguous eighth of the tile rows (row-major A) off / on
     g_use_pipe = on;
     return prev;
 }
@@ -2520,7 +2530,9 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                     // 96-row tiles are two co-resident workgroups of 28 KiB each
                     const long long t192 = (long long)cdiv(g.M, 192) * g.tiles_n;
                     const long long cur = variant == 8 ? ((t96 + 255) / 256) * 28 : ((t128 + 255) / 256) * 32;
-                    if (g_r192 && !d->ga_mode && t192 > 192 && ((t192 + 255) / 256) * 40 < cur) variant = 16;
+                    // (ONE round only: 8192 x 1024 -- 344 tiles, two rounds of which the second is a third full -- measured 32.6 us
+                    //  against 22.3 on 128-row tiles; BASELINE config 5's 16384 rows 3.08 against 2.92 ms per step)
+                    if (g_r192 && !d->ga_mode && t192 > 192 && t192 <= 256 && 40 < cur) variant = 16;
                 } else if (t64 <= 256 && t64 > t128) {
                     // at most 128 tiles: 64-row tiles put one 4-wave workgroup on twice as many CUs instead of one
                     // 8-wave (two wave groups) workgroup on half of them (2048 x 1024 x 1024: 10.6 vs 12.4 us)
@@ -2548,7 +2560,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             if (variant != 7 && !d->transA && g.splitk == 1 && !g.dbias && g.M % 192 == 0 && g.N % 256 == 0 && t192 >= 192 && K >= 1024 &&
                 10 * t192 >= 9 * 256 * ((t192 + 255) / 256))
                 variant = 15;
-        } else if ((variant == 8 || variant == 11 || variant == 12 || variant == 16) && (d->transA || (variant == 16 && (g.splitk > 1 || d->ga_mode)))) {
+        } else if ((variant == 8 || variant == 11 || variant == 12 || variant == 16) &&
+                   (d->transA || (variant == 16 && (g.splitk > 1 || d->ga_mode)))) {
             variant = 3;  // the forced variants exist for row-major A only (16: unsplit, no row gather in the epilogue)
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
@@ -2575,6 +2588,13 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             int gm = 1;
             while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
             g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
+            // Row-major A (forward / dX forms: the output rows ARE the rows of the chain's activations): XCD x takes the tile rows
+            // [x * tiles_m / 8, (x + 1) * tiles_m / 8) with ALL their tile columns -- the contiguous eighth of the rows that the row
+            // kernels in front of and behind this launch give to XCD x (common.h, row_walk): its A strips were written, and its output
+            // rows will be read, by workgroups of the SAME XCD, i.e. through that XCD's own L2 instead of across the fabric
+            // (tools/exp/xcd_affinity.hip: 4.0-4.4 us against 8.3-11.2 us for a 12.6 MB hand-off).  Every XCD then streams the whole
+            // B operand (weights: 2-9 MB, shared by its 32 workgroups K tile by K tile).
+            if (g_row_affinity && !d->transA && g.splitk == 1 && g.tiles_m % 8 == 0) g.group_m = g.tiles_m / 8;
             if (g_group_m_override > 0) g.group_m = g_group_m_override < g.tiles_m ? g_group_m_override : g.tiles_m;
         }
 
@@ -2683,6 +2703,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
             int gm = 1;
             while ((gm + 1) * (gm + 1) <= per_xcd) ++gm;
             g.group_m = gm < g.tiles_m ? gm : g.tiles_m;
+            if (g_row_affinity && !d->transA && g.splitk == 1 && g.tiles_m % 8 == 0) g.group_m = g.tiles_m / 8;  // (as for the bf16 kernel)
         }
         const bool st_ok = g.splitk == 1 && epilogue_rows_ok(g) && d->st_min_seg_rows >= (r96 ? 96 : 128) &&
                            (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % 4 == 0 && aligned16(d->st_w) && aligned16(d->st_b)));

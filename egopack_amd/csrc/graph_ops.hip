@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void pe_add_kernel(const T* __restrict__ x, co
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
     const int half = cols >> 1;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const float p = (float)pos[row];
         const T* xr = x + (long long)row * cols;
         T* yr = y + (long long)row * cols;
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(256) void pe_add_table_kernel(const T* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
     const int half = cols >> 1;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const long long pr = pos[row];
         const long long ti = pr - pos_min;
         const bool hit = ti >= 0 && ti < n_pos;  // (wave-uniform)
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const T* __restrict__ x
     const int bid = blockIdx.x - n_block_rows, nblk = gridDim.x - n_block_rows;
     if (threadIdx.x == 0) n_heavy = 0;
     __syncthreads();
-    for (int row = bid * WPB + wave; row < rows; row += nblk * WPB) {
+    const RowWalk rw = (n_block_rows & 7) == 0 ? row_walk(bid, nblk, 0, rows, wave, WPB) : RowWalk{bid * WPB + wave, rows, nblk * WPB};
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         if (band) {
             // BANDED row (data.build_csr): its neighbours are a subset of {row - 1, row, row + 1}, named by three bits -- no
             // rowptr / col fetches, the neighbour rows are requested at once.  Added in ascending order, which is the order
@@ -330,16 +333,17 @@ __global__ __launch_bounds__(256) void csr_gather_band_1k_kernel(const bf16_t* _
                                                                  const int* __restrict__ col, const unsigned char* __restrict__ band,
                                                                  bf16_t* __restrict__ out, int rows, int skip_above) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gw = blockIdx.x * WPB + wave, W = gridDim.x * WPB;
-    for (int base = gw; base < rows; base += RB * W) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    const int W = rw.step, rend = rw.end;
+    for (int base = rw.first; base < rend; base += RB * W) {
         unsigned code[RB];
 #pragma unroll
-        for (int k = 0; k < RB; ++k) code[k] = base + k * W < rows ? band[base + k * W] : 0u;
+        for (int k = 0; k < RB; ++k) code[k] = base + k * W < rend ? band[base + k * W] : 0u;
         r1k::Raw nb[RB][3];
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int row = base + k * W;
-            if (row < rows && code[k] != 0xFFu) {
+            if (row < rend && code[k] != 0xFFu) {
                 const bf16_t* r0 = x + (long long)row * r1k::COLS;
                 if (code[k] & 1u) nb[k][0] = r1k::ld_raw(r0 - r1k::COLS, lane);
                 if (code[k] & 2u) nb[k][1] = r1k::ld_raw(r0, lane);
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void csr_gather_band_1k_kernel(const bf16_t* _
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int row = base + k * W;
-            if (row >= rows) break;
+            if (row >= rend) break;
             float acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -445,7 +449,9 @@ __global__ __launch_bounds__(256, 5) void csr_gather_1k_kernel(const bf16_t* __r
         return;
     }
     const int bid = blockIdx.x - n_block_rows, nblk = gridDim.x - n_block_rows;
-    for (int row = bid * WPB + wave; row < rows; row += nblk * WPB) {  // (row is wave-uniform: scalar fetches below)
+    // (XCD-contiguous row ownership -- common.h -- when the listed rows in front keep blockIdx % 8 == bid % 8)
+    const RowWalk rw = (n_block_rows & 7) == 0 ? row_walk(bid, nblk, 0, rows, wave, WPB) : RowWalk{bid * WPB + wave, rows, nblk * WPB};
+    for (int row = rw.first; row < rw.end; row += rw.step) {  // (row is wave-uniform: scalar fetches below)
         const int e0 = rowptr[row], e1 = rowptr[row + 1];
         if (e1 - e0 > skip_above) continue;  // listed by the host
         r1k::Raw gt;
@@ -492,20 +498,21 @@ __global__ __launch_bounds__(256) void pe_add_table_1k_kernel(const bf16_t* __re
                                                               const float* __restrict__ freq, const float* __restrict__ table,
                                                               long long pos_min, int n_pos, bf16_t* __restrict__ y, int rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gw = blockIdx.x * WPB + wave, W = gridDim.x * WPB;
-    for (int base = gw; base < rows; base += RB * W) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    const int W = rw.step, rend = rw.end;
+    for (int base = rw.first; base < rend; base += RB * W) {
         r1k::Raw raw[RB];
         long long pr[RB];
 #pragma unroll
         for (int k = 0; k < RB; ++k)
-            if (base + k * W < rows) {
+            if (base + k * W < rend) {
                 raw[k] = r1k::ld_raw(x + (long long)(base + k * W) * r1k::COLS, lane);
                 pr[k] = pos[base + k * W];
             }
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int row = base + k * W;
-            if (row >= rows) break;
+            if (row >= rend) break;
             const long long ti = pr[k] - pos_min;
             const bool hit = ti >= 0 && ti < n_pos;  // (wave-uniform)
             float v[16], e[16];
@@ -602,7 +609,8 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const T* __restrict
                                                              uint8_t* __restrict__ arg, int rows, int cols, int k) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         for (int c = lane * 4; c < cols; c += 256) {
             // message order of the reference: prototype edges first, the self loop appended last
             // (add_remaining_self_loops); first maximum wins on ties.
@@ -640,7 +648,8 @@ template <typename T, int K, int U>
 __global__ __launch_bounds__(256) void gather_max_fwd_u_kernel(const T* __restrict__ f, GatherMaxGroups gg, T* __restrict__ m,
                                                                uint8_t* __restrict__ arg, int rows_total, int cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows_total; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows_total, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const int g = row / gg.rows, r = row - g * gg.rows;
         const float* __restrict__ bank = g == 0 ? gg.bank[0] : g == 1 ? gg.bank[1] : g == 2 ? gg.bank[2] : gg.bank[3];
         const long long* __restrict__ nn = (g == 0 ? gg.nn[0] : g == 1 ? gg.nn[1] : g == 2 ? gg.nn[2] : gg.nn[3]) + (long long)r * K;
@@ -824,7 +833,8 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const T* __restrict__
                                                            int cols, int squared) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = (cols & 3) == 0;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         float s = 0.f;
         for (int c = lane * 4; c < cols; c += 256) {
             const float4 v = ld4(x + (long long)row * cols, c, cols, vec);
@@ -842,7 +852,8 @@ __global__ __launch_bounds__(256) void row_inv_norm_cast_kernel(const float* __r
                                                                 bf16_t* __restrict__ hi, unsigned short* __restrict__ h16, int rows,
                                                                 int cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const long long base = (long long)row * cols;
         float s = 0.f;
         for (int c = lane * 4; c < cols; c += 256) {  // (cols % 4 == 0: checked by the launcher)
@@ -881,7 +892,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dot
                                                    const float* __restrict__ f_inv, const float* __restrict__ b_inv,
                                                    long long* __restrict__ nn, int rows, int K, int k, int vec) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const float* dr = dot + (long long)row * ldd;
         const float fi = f_inv[row];
         float lv[KM];
@@ -988,7 +1000,8 @@ template <bool F16>
 __global__ __launch_bounds__(256) void bf16_residual_ratio_kernel(const float* __restrict__ x, long long ld, float* __restrict__ r,
                                                                   int rows, int cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         float s2 = 0.f, r2 = 0.f;
         for (int c = lane; c < cols; c += 64) {
             const float v = x[(long long)row * ld + c], d = v - round16<F16>(v);
@@ -1042,7 +1055,8 @@ __global__ __launch_bounds__(256, 3) void topk_window_kernel(const float* __rest
     constexpr int CAND_CAP = 512;  // candidates listed per row (real prototype banks: 30-90 per row, up to ~200; beyond: the rescan)
     __shared__ int s_cand[WPB][CAND_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const int grp = row / tb.rows_per_group;  // (wave-uniform)
         const float* __restrict__ bank = tb.bank[grp];
         const float* __restrict__ b_inv = tb.b_inv[grp];
@@ -1407,7 +1421,8 @@ template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_rows_kernel(const S* __restrict__ src, long long lds_, D* __restrict__ dst,
                                                         long long ldd, int rows, int cols, int zero_cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         for (int c = lane; c < cols; c += 64) st1t(dst + (long long)row * ldd + c, ld1t(src + (long long)row * lds_ + c));
         for (int c = cols + lane; c < zero_cols; c += 64) st1t(dst + (long long)row * ldd + c, 0.f);
     }
@@ -1423,7 +1438,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const S* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int V = 16 / sizeof(S);  // source elements per 16 bytes
     const bool vec = (cols % V == 0) && (ld % V == 0);
-    for (long long row = (long long)blockIdx.x * WPB + wave; row < n; row += (long long)gridDim.x * WPB) {
+    // (XCD x writes a contiguous eighth of the output rows -- the rows the first contraction's tiles of XCD x read: common.h)
+    const RowWalk rw = n < (1ll << 30) ? row_walk(blockIdx.x, gridDim.x, 0, (int)n, wave, WPB) : RowWalk{0, 0, 1};
+    const long long first = n < (1ll << 30) ? rw.first : (long long)blockIdx.x * WPB + wave;
+    const long long end = n < (1ll << 30) ? rw.end : n, step = n < (1ll << 30) ? rw.step : (long long)gridDim.x * WPB;
+    for (long long row = first; row < end; row += step) {
         const long long src = idx[row];
         D* o = out + row * cols;
         if (src < 0 || src >= table_rows) {

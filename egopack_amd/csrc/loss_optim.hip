@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
                                                      float* __restrict__ lse, int rows, int C, float smoothing,
                                                      int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const float* lr = logits + (long long)row * ld;
         float mx = -INFINITY;
         for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
                                                      T* __restrict__ dlogits, long long ldd, int rows, int C,
                                                      float smoothing) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const float* lr = logits + (long long)row * ld;
         T* dr = dlogits + (long long)row * ldd;
         const long long t = y[(long long)row * ys];
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CEHeads H, int n_he
                                                        float* __restrict__ loss, T* __restrict__ dlogits, long long ldd, int rows,
                                                        float smoothing, float gscale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         float total = 0.f;
         for (int h = 0; h < n_heads; ++h) {
             const float* lr = H.logits[h] + (long long)row * H.ld[h];
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256) void ce_fused_multi_kernel(const CETasks P, fl
     float* __restrict__ loss = P.loss[k];
     T* __restrict__ dlogits = (T*)P.dlogits[k];
     const float gscale = P.gscale[k];
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         float total = 0.f;
         for (int h = 0; h < n_heads; ++h) {  // (the arithmetic of ce_fused_kernel, statement for statement)
             const float* lr = H.logits[h] + (long long)row * H.ld[h];

@@ -55,7 +55,8 @@ __device__ __forceinline__ void rowln_fwd_body(const T* __restrict__ x, const fl
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    for (int row = row_begin + blk * WPB + wave; row < rows; row += nblk * WPB) {
+    const RowWalk rw = row_walk(blk, nblk, row_begin, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         Row<NV> r;
         load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
         if constexpr (sizeof(T) == 4) {
@@ -215,20 +216,21 @@ __device__ __forceinline__ void rowln_bwd_body(const T* __restrict__ dy, const T
     };
     // TWO rows in flight per wave (a wave walks rows / (4 * grid) of them; with one row's loads outstanding at a
     // time the walk is latency bound).  Wide rows (NV > 4) keep one row in flight: registers.
-    const int stride_rows = nblk * WPB;
-    for (int row = row_begin + blk * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
+    const RowWalk rw = row_walk(blk, nblk, row_begin, rows, wave, WPB);
+    const int stride_rows = rw.step;
+    for (int row = rw.first; row < rw.end; row += (NV <= 4 ? 2 : 1) * stride_rows) {
         Row<NV> g, xr;
         load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
         load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
         if constexpr (NV <= 4) {
             const int row2 = row + stride_rows;
             Row<NV> g2, xr2;
-            if (row2 < rows) {
+            if (row2 < rw.end) {
                 load_row<NV>(dy + (long long)row2 * cols, cols, vec, lane, g2);
                 load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, xr2);
             }
             process(row, g, xr);
-            if (row2 < rows) process(row2, g2, xr2);
+            if (row2 < rw.end) process(row2, g2, xr2);
         } else {
             process(row, g, xr);
         }
@@ -331,9 +333,10 @@ __global__ __launch_bounds__(256) void rowln_fwd_wide_kernel(const T* __restrict
             for (int i = 0; i < NVW; ++i) tee4(tee, row, cw + (i * 64 + lane) * 4, cols, true, r.v[i]);
         }
     };
-    for (int row = blockIdx.x; row < rows; row += 2 * gridDim.x) {  // (block-uniform: the barriers below are met by all four waves)
-        const int row2 = row + gridDim.x;
-        const bool two = row2 < rows;
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, 0, 1);  // (a workgroup per row; XCD x owns a contiguous eighth of them)
+    for (int row = rw.first; row < rw.end; row += 2 * rw.step) {  // (block-uniform: the barriers below are met by all four waves)
+        const int row2 = row + rw.step;
+        const bool two = row2 < rw.end;
         Row<NVW> r, r2;
         load_row<NVW>(x + (long long)row * cols + cw, WCOLS, true, lane, r);
         if (two) load_row<NVW>(x + (long long)row2 * cols + cw, WCOLS, true, lane, r2);
@@ -427,9 +430,10 @@ __global__ __launch_bounds__(256) void rowln_bwd_wide_kernel(const T* __restrict
             for (int t = 0; t < 4; ++t) el(g.v[i], t) = rs * (el(g.v[i], t) - s1 - el(xr.v[i], t) * s2);
         store_row<NVW>(dx + (long long)row * cols + cw, WCOLS, true, lane, g);
     };
-    for (int row = blockIdx.x; row < rows; row += 2 * gridDim.x) {
-        const int row2 = row + gridDim.x;
-        const bool two = row2 < rows;
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, 0, 1);
+    for (int row = rw.first; row < rw.end; row += 2 * rw.step) {
+        const int row2 = row + rw.step;
+        const bool two = row2 < rw.end;
         Row<NVW> g, xr, g2, xr2;
         load_row<NVW>(dy + (long long)row * cols + cw, WCOLS, true, lane, g);
         load_row<NVW>(x + (long long)row * cols + cw, WCOLS, true, lane, xr);
@@ -579,17 +583,18 @@ __global__ __launch_bounds__(256) void graphln_stats_kernel(const T* __restrict_
             }
         }
     };
-    const int stride_rows = gridDim.x * WPB;  // two rows in flight per wave (see rowln_bwd_kernel)
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);  // (XCD x owns a contiguous eighth of the rows: common.h)
+    const int stride_rows = rw.step;  // two rows in flight per wave (see rowln_bwd_kernel)
+    for (int row = rw.first; row < rw.end; row += (NV <= 4 ? 2 : 1) * stride_rows) {
         Row<NV> r;
         load_row<NV>(x + (long long)row * cols, cols, vec, lane, r);
         if constexpr (NV <= 4) {
             const int row2 = row + stride_rows;
             Row<NV> r2;
-            if (row2 < rows) load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, r2);
+            if (row2 < rw.end) load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, r2);
             slab_row(row, r);
             process(row, r);
-            if (row2 < rows) {
+            if (row2 < rw.end) {
                 slab_row(row2, r2);
                 process(row2, r2);
             }
@@ -672,7 +677,8 @@ __global__ __launch_bounds__(256) void graphln_fwd_kernel(const T* __restrict__ 
     Row<NV> wv, bv;
     load_row<NV>(w, cols, vec, lane, wv);
     load_row<NV>(b, cols, vec, lane, bv);
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const int sg = seg_of(seg_ptr, n_seg, row);
         const float mu = st[sg][0], ri = st[sg][1];
         Row<NV> r;
@@ -736,20 +742,21 @@ __global__ __launch_bounds__(256) void graphln_bwd_stats_kernel(const T* __restr
         }
     };
     // two rows in flight per wave (see rowln_bwd_kernel)
-    const int stride_rows = gridDim.x * WPB;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += (NV <= 4 ? 2 : 1) * stride_rows) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);
+    const int stride_rows = rw.step;
+    for (int row = rw.first; row < rw.end; row += (NV <= 4 ? 2 : 1) * stride_rows) {
         Row<NV> g, xr;
         load_row<NV>(dy + (long long)row * cols, cols, vec, lane, g);
         load_row<NV>(x + (long long)row * cols, cols, vec, lane, xr);
         if constexpr (NV <= 4) {
             const int row2 = row + stride_rows;
             Row<NV> g2, xr2;
-            if (row2 < rows) {
+            if (row2 < rw.end) {
                 load_row<NV>(dy + (long long)row2 * cols, cols, vec, lane, g2);
                 load_row<NV>(x + (long long)row2 * cols, cols, vec, lane, xr2);
             }
             process(row, g, xr);
-            if (row2 < rows) process(row2, g2, xr2);
+            if (row2 < rw.end) process(row2, g2, xr2);
         } else {
             process(row, g, xr);
         }
@@ -817,7 +824,8 @@ __global__ __launch_bounds__(256) void graphln_bwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NV; ++i) dwp.v[i] = dbp.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         const int sg = seg_of(seg_ptr, n_seg, row);
         const float mu = sc[sg][0], ri = sc[sg][1], c1 = sc[sg][2], c2 = sc[sg][3];
         Row<NV> g, xr;
@@ -940,7 +948,8 @@ __global__ __launch_bounds__(256) void rowdot_bce_kernel(const T* __restrict__ f
     for (int i = 0; i < NV; ++i) acc.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     float gsum = 0.f;
     const float b0 = bias ? bias[0] : 0.f;
-    for (int row = blockIdx.x * WPB + wave; row < rows; row += gridDim.x * WPB) {
+    const RowWalk rw = row_walk(blockIdx.x, gridDim.x, 0, rows, wave, WPB);
+    for (int row = rw.first; row < rw.end; row += rw.step) {
         Row<NV> r;
         load_row<NV>(f + (long long)row * cols, cols, vec, lane, r);
         float d = 0.f;

@@ -1063,7 +1063,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
     A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
     C0 = torch.randn(M, N, device=DEV, generator=g)
     outs = {}
-    for pipe in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11, 0, 5, 12, 1, 55):
+    for pipe in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11, 16, 0, 5, 12, 1, 55):
         prev = lib.egk_gemm_set_pipeline(5 if pipe == 55 else pipe)
         try:
             out = C0.clone()
@@ -1072,7 +1072,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
             outs[pipe] = out
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    for v in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11):  # one wave group (14: two ping-pong groups over DIFFERENT rows): the MFMA chain of the
+    for v in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11, 16):  # one wave group (14: two ping-pong groups over DIFFERENT rows; 16: 192 x 128 tiles on 8 waves, row-major A): the MFMA chain of the
         assert torch.equal(outs[v], outs[0]), v  # generic kernel per accumulator, whatever the tile / ring depth
     assert torch.equal(outs[5], outs[55])
     # 64-row tiles with two wave groups (12; row-major A only): the same even / odd K sums as (5), whatever the tile height
@@ -1101,7 +1101,7 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     bias = torch.randn(N, device=DEV, generator=g)
     res = torch.randn(M, N, device=DEV, generator=g).to(BF)
     outs = {}
-    for pipe in (3, 6, 13, 14, 7, 15, 8, 11, 0, 5, 12, 1):
+    for pipe in (3, 6, 13, 14, 7, 15, 8, 11, 16, 0, 5, 12, 1):
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             for dt in (BF, torch.float32):
@@ -1117,7 +1117,8 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
         assert torch.equal(outs[(7, dt)], outs[(0, dt)])  # 256 x 256 tiles (the policy's choice for the two large outputs)
         assert torch.equal(outs[(13, dt)], outs[(0, dt)]) and torch.equal(outs[(14, dt)], outs[(0, dt)])  # 256 x 128: 3-stage ring; ping-pong groups
         assert torch.equal(outs[(15, dt)], outs[(0, dt)])  # 192 x 256 tiles (M % 192 == 0, N % 256 == 0: the (768, 512) case; 128 x 128 otherwise)
-        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11, 7, 15))
+        assert torch.equal(outs[(16, dt)], outs[(0, dt)])  # 192 x 128 tiles, 8 waves, 3-stage ring (ragged M / N included)
+        assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11, 7, 15, 16))
         assert torch.equal(outs[(12, dt)], outs[(5, dt)])  # 64-row tiles, two wave groups: the even / odd K sums of (5)
     # two wave groups: even / odd K tiles summed separately
     torch.testing.assert_close(outs[(5, torch.float32)], outs[(0, torch.float32)], rtol=1e-5, atol=2e-3)
