@@ -38,9 +38,7 @@ class GemmDesc(C.Structure):
         ("st_mode", i32), ("st_nseg", i32), ("st_min_seg_rows", i32), ("st_seg_ptr", vp), ("st_ws", vp), ("st_x", vp),
         ("st_ldx", i64), ("st_stats", vp), ("st_w", vp), ("st_b", vp), ("st_slope", f32),
         ("n_extra", i32), ("xK", i32 * 4), ("xA", vp * 4), ("xB", vp * 4), ("xlda", i64 * 4), ("xldb", i64 * 4),
-        ("ga_mode", i32), ("ga_tile_mask", i32), ("ga_skip_c", i32), ("ga_rowptr", vp), ("ga_col", vp), ("ga_wgt", vp),
-        ("ga_band", vp), ("ga_gate", vp), ("ga_out", vp), ("ga_ld", i64),
-        ("sk_tickets", vp), ("op_f16", i32), ("adam_epi", vp),
+        ("op_f16", i32),
     ]
 
 
@@ -61,15 +59,8 @@ SIGNATURES = {
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egk_stamp": (C.c_int, [vp, vp, i32]),
     "egk_tee_split_next": (C.c_int, [vp, vp, i64]),
-    "egk_graph_plan_create": (C.c_int, [vp, i32, i32, vp]),
-    "egk_graph_plan_info": (C.c_int, [vp, vp, vp, vp, vp]),
-    "egk_graph_plan_segment": (C.c_int, [vp, i32, vp]),
-    "egk_graph_plan_launch": (C.c_int, [vp, vp]),
-    "egk_graph_plan_destroy": (None, [vp]),
     "egk_gemm": (C.c_int, [vp, C.POINTER(GemmDesc)]),
     "egk_gemm_stats_blocks": (C.c_int, [C.POINTER(GemmDesc)]),
-    "egk_gemm_splitk_in_launch": (C.c_int, [C.POINTER(GemmDesc)]),
-    "egk_gemm_gather_ok": (C.c_int, [C.POINTER(GemmDesc)]),
     "egk_gemm_grouped": (C.c_int, [vp, C.POINTER(GemmDesc), i32]),
     "egk_gemm_ws_bytes": (i64, [C.POINTER(GemmDesc)]),
     "egk_gemm_splitk": (C.c_int, [i32, i32, i32, i32]),
@@ -161,7 +152,6 @@ SIGNATURES = {
     "egk_zero_fill": (C.c_int, [vp, vp, i64]),
     "egk_zero_fill_ranges": (C.c_int, [vp, vp, vp, vp, i32]),
     "egk_adam_step_bump": (C.c_int, [vp, vp, vp, i32, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, vp, i64]),
-    "egk_adam_step_ranges": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, vp, vp, i64]),
     "egk_adam_hyper": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
 }
 

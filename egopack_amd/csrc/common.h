@@ -287,19 +287,6 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
     const float denom = sqrtf(v) / c.bc2s + c.eps;
     p = p - c.step * (m / denom);
 }
-// Adam inside the epilogue of the weight-gradient contraction that produces the gradient (egk_gemm_desc.adam_epi; a struct in
-// DEVICE memory, built once per parameter): the launch stores the gradient tile as always and steps the parameter, its moments and
-// its bf16 operand copies at the same [row, column] of buffers laid out like C (row stride = ldc).
-struct AdamEpi {
-    float* p;
-    float* m;
-    float* v;
-    bf16_t* shadow;       // bf16(p), may be null
-    bf16_t* shadow_lo;    // bf16(p - bf16(p)), may be null
-    const float* hyper;   // egk_adam_hyper's {lr, 1 - b1^t, sqrt(1 - b2^t), grad_scale}
-    float b1, b2, eps, wd;
-};
-
 // host-side dispatch on an EGK_F32 / EGK_BF16 activation type: ``using T = ...`` inside CALL
 #define EGK_DISPATCH_T(dtype, ...)                                               \
     do {                                                                         \

@@ -66,19 +66,6 @@ struct GemmArgs {
     const float* st_w;
     const float* st_b;
     float st_slope;
-    // row gather of the result inside the rows epilogue (egk_gemm_desc.ga_*)
-    int ga_mode, ga_skip_c;
-    const int* ga_rowptr;
-    const int* ga_col;
-    const float* ga_wgt;
-    const unsigned char* ga_band;
-    const void* ga_gate;
-    void* ga_out;
-    long long ga_ld;
-    // split-K finished inside the launch (egk_gemm_desc.sk_tickets): one arrival counter per output tile, zero on entry and exit
-    int* sk_tickets;
-    // Adam on the stored tile (egk_gemm_desc.adam_epi): C is the parameter's gradient; p / m / v / the bf16 copies are laid out like C
-    const AdamEpi* adam;
 };
 
 // Workgroup -> (slab z, tile row, tile column) for a 1-D launch of tiles_m * tiles_n * splitk workgroups.
@@ -294,57 +281,6 @@ __device__ __forceinline__ void load_operand(const void* base, long long ld, int
     else load_rowmajor<BF16C, T>((const T*)base, ld, rows_total, row0, k0, klim, vec, out);
 }
 
-// Adam on CNT consecutive elements of one row whose gradient values o[] the epilogue is about to store (AdamEpi; the buffers are
-// laid out like C: element (m, n) at m * ldc + n).  ``vec``: whole 16-byte groups, aligned.
-template <int CNT>
-__device__ __forceinline__ void adam_epilogue(const GemmArgs& g, const float* o, int m, int n, int cnt, bool vec) {
-    const AdamEpi& a = *g.adam;
-    const AdamConsts ac{a.hyper[0] / a.hyper[1], a.hyper[2], a.hyper[3], a.b1, a.b2, a.eps, a.wd};
-    const long long at = (long long)m * g.ldc + n;
-    float pv[CNT], mv[CNT], vv[CNT];
-    if (vec) {
-#pragma unroll
-        for (int q = 0; q < CNT / 4; ++q) {
-            const float4 p4 = *reinterpret_cast<const float4*>(a.p + at + 4 * q), m4 = *reinterpret_cast<const float4*>(a.m + at + 4 * q),
-                         v4 = *reinterpret_cast<const float4*>(a.v + at + 4 * q);
-            pv[4 * q] = p4.x; pv[4 * q + 1] = p4.y; pv[4 * q + 2] = p4.z; pv[4 * q + 3] = p4.w;
-            mv[4 * q] = m4.x; mv[4 * q + 1] = m4.y; mv[4 * q + 2] = m4.z; mv[4 * q + 3] = m4.w;
-            vv[4 * q] = v4.x; vv[4 * q + 1] = v4.y; vv[4 * q + 2] = v4.z; vv[4 * q + 3] = v4.w;
-        }
-#pragma unroll
-        for (int t = 0; t < CNT; ++t) adam_update(pv[t], o[t], mv[t], vv[t], ac);
-#pragma unroll
-        for (int q = 0; q < CNT / 4; ++q) {
-            *reinterpret_cast<float4*>(a.p + at + 4 * q) = make_float4(pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]);
-            *reinterpret_cast<float4*>(a.m + at + 4 * q) = make_float4(mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
-            *reinterpret_cast<float4*>(a.v + at + 4 * q) = make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
-            if (a.shadow) {
-                uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(pv[4 * q]) | ((unsigned)f32_to_bf16(pv[4 * q + 1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(pv[4 * q + 2]) | ((unsigned)f32_to_bf16(pv[4 * q + 3]) << 16);
-                *reinterpret_cast<uint2*>(a.shadow + at + 4 * q) = pk;
-            }
-            if (a.shadow_lo) {
-                float l[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) l[t] = pv[4 * q + t] - bf16_to_f32(f32_to_bf16(pv[4 * q + t]));
-                uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(l[0]) | ((unsigned)f32_to_bf16(l[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(l[2]) | ((unsigned)f32_to_bf16(l[3]) << 16);
-                *reinterpret_cast<uint2*>(a.shadow_lo + at + 4 * q) = pk;
-            }
-        }
-    } else {
-        for (int t = 0; t < CNT && t < cnt; ++t) {
-            float pp = a.p[at + t], mm = a.m[at + t], v1 = a.v[at + t];
-            adam_update(pp, o[t], mm, v1, ac);
-            a.p[at + t] = pp; a.m[at + t] = mm; a.v[at + t] = v1;
-            if (a.shadow) a.shadow[at + t] = f32_to_bf16(pp);
-            if (a.shadow_lo) a.shadow_lo[at + t] = f32_to_bf16(pp - bf16_to_f32(f32_to_bf16(pp)));
-        }
-    }
-}
-
 // Epilogue shared by the contraction kernels.  D^T layout: lane holds C[m = .. + lr][n = .. + 4*lg + t], t = 0..3.
 template <int NI, int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[NI][NJ], int m0, int n0, int wm_off,
@@ -412,7 +348,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                 if (full && g.c_vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
                 else
                     for (int t = 0; t < 4 && n + t < g.N; ++t) cp[t] = o[t];
-                if (g.adam) adam_epilogue<4>(g, o, m, n, g.N - n, full && g.c_vec);
             }
         }
     }
@@ -439,10 +374,9 @@ __host__ __device__ __forceinline__ bool epilogue_rows_ok(const GemmArgs& g) {
 
 // MBW = 2: the 8-wave tall tiles (waves as 4 x 2 over 32 * NI * 2 rows): the same staging image with twice the rows, read out 32
 // rows per pass by the 512 threads; the statistics of the 8 waves are summed in wave order, pairwise.
-template <int NI, bool GA = false, bool ST = true, int MBW = 1>
+template <int NI, bool ST = true, int MBW = 1>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x4 (&acc)[NI][4], unsigned char* lds, int m0, int n0,
                                                    int wm, int wn, int lr, int lg, int z, int tid, int st_tile = 0) {
-    static_assert(MBW == 1 || !GA, "the row gather in the epilogue exists for the 4-wave tiles only");
     __syncthreads();  // every wave is done with the ring (nothing is in flight: the last tiles were waited for)
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -473,10 +407,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
         }
     }
     const bool st_cols = n < g.N;
-    // (GA: the instantiations launched with a row gather in the epilogue -- its index batch costs ~30 registers that the
-    //  other launches, two workgroups per CU at <= 256 registers per lane, must not pay)
-    const int ga_mode = (GA && g.splitk == 1) ? g.ga_mode : 0;
-    if (n >= g.N && !st_mode && !ga_mode) return;  // (N % 8 == 0: a group of 8 columns is all in or all out)
+    if (n >= g.N && !st_mode) return;  // (N % 8 == 0: a group of 8 columns is all in or all out)
     float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (g.bias && g.splitk == 1) {
         const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
@@ -529,8 +460,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
             pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
             pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
-            if (!g.ga_skip_c) *reinterpret_cast<uint4*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
-            if (st_mode || ga_mode) {  // the sums / the gather are those of the values a reader of C would READ: the rounded ones
+            *reinterpret_cast<uint4*>((bf16_t*)g.C + (long long)m * g.ldc + n) = pk;
+            if (st_mode) {  // the sums are those of the values a reader of C would READ: the rounded ones
                 const unsigned pw[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -538,15 +469,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
                     o[2 * t + 1] = __uint_as_float(pw[t] & 0xffff0000u);
                 }
             }
-        } else if (!g.ga_skip_c) {
+        } else {
             float* cp = (float*)g.C + (long long)m * g.ldc + n;
             *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
             *reinterpret_cast<float4*>(cp + 4) = make_float4(o[4], o[5], o[6], o[7]);
-            if (g.adam) adam_epilogue<8>(g, o, m, n, 8, true);
-        }
-        if (ga_mode) {  // park the stored values where the raw accumulators were (this thread's own two slots)
-            *reinterpret_cast<f32x4*>(stage + row * 128 + (((2 * c8) ^ (row & 15)) << 2)) = f32x4{o[0], o[1], o[2], o[3]};
-            *reinterpret_cast<f32x4*>(stage + row * 128 + (((2 * c8 + 1) ^ (row & 15)) << 2)) = f32x4{o[4], o[5], o[6], o[7]};
         }
         if (st_mode == 1) {
             const int rel = m >= s_split ? 1 : 0;
@@ -613,105 +539,6 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
                     t_ += (st_red[4][rel * 2 + k] + st_red[5][rel * 2 + k]) + (st_red[6][rel * 2 + k] + st_red[7][rel * 2 + k]);
             }
             g.st_ws[((long long)st_tile * g.st_nseg + sg) * 2 + k] = t_;
-        }
-    }
-    if constexpr (GA) if (ga_mode) {
-        // The neighbour aggregation of the stored tile (egk_gemm_desc.ga_*): every edge of a row of this tile ends inside the
-        // tile (host-checked), so the rows come from LDS.  Added in edge order with the arithmetic of csr_gather_kernel.
-        // Every index this thread needs -- codes / row pointers of its 2 * NI rows, then the first four (column, weight)
-        // pairs of each row and the gate rows -- is requested in ONE batch per level (a dependent chain per row cost more
-        // than the separate gather launch: 43 against 19 + 16 us for the gated transposed gather).
-        constexpr int NR = 2 * NI;
-        unsigned code[NR];
-        int re0[NR], re1[NR];
-#pragma unroll
-        for (int it = 0; it < NR; ++it) {
-            const int m = m0 + it * 16 + (tid >> 4);
-            const bool live = m < g.M && st_cols;
-            code[it] = (ga_mode == 1 && g.ga_band && live) ? g.ga_band[m] : 0xFFu;
-            re0[it] = re1[it] = 0;
-            if (live && code[it] == 0xFFu) {
-                re0[it] = g.ga_rowptr[m];
-                re1[it] = g.ga_rowptr[m + 1];
-            }
-        }
-        // (two pairs per row in the batch: a band row has at most three neighbours, the third and later ones are fetched in the
-        //  loop below; the batch must fit in the registers the accumulators left behind -- two workgroups share a CU)
-        constexpr int NE = 2;
-        int ec[NR][NE];
-        float ew[NR][NE];
-        uint4 gq[NR];
-#pragma unroll
-        for (int it = 0; it < NR; ++it) {
-            const int m = m0 + it * 16 + (tid >> 4);
-            const bool live = m < g.M && st_cols;
-#pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                const bool has = re0[it] + u < re1[it];
-                ec[it][u] = has ? g.ga_col[re0[it] + u] : 0;
-                ew[it][u] = (has && ga_mode == 2) ? g.ga_wgt[re0[it] + u] : 1.f;
-            }
-            if (ga_mode == 2 && live && g.c_bf16)
-                gq[it] = *reinterpret_cast<const uint4*>((const bf16_t*)g.ga_gate + (long long)m * g.ga_ld + n);
-        }
-        __syncthreads();  // (the parked values of every thread are in place)
-#pragma unroll
-        for (int it = 0; it < NR; ++it) {
-            const int row = it * 16 + (tid >> 4), m = m0 + row;
-            if (m >= g.M || !st_cols) continue;
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            auto add_row = [&](int lrow, float w) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lrow * 128 + (((2 * c8) ^ (lrow & 15)) << 2));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lrow * 128 + (((2 * c8 + 1) ^ (lrow & 15)) << 2));
-                acc[0] += w * lo[0]; acc[1] += w * lo[1]; acc[2] += w * lo[2]; acc[3] += w * lo[3];
-                acc[4] += w * hi[0]; acc[5] += w * hi[1]; acc[6] += w * hi[2]; acc[7] += w * hi[3];
-            };
-            int cnt;
-            if (code[it] != 0xFFu) {  // (mode 1 only)
-                if (code[it] & 1u) add_row(row - 1, 1.f);
-                if (code[it] & 2u) add_row(row, 1.f);
-                if (code[it] & 4u) add_row(row + 1, 1.f);
-                cnt = __popc(code[it] & 7u);
-            } else {
-                cnt = re1[it] - re0[it];
-#pragma unroll
-                for (int u = 0; u < NE; ++u)
-                    if (u < cnt) add_row(ec[it][u] - m0, ew[it][u]);
-                for (int e = re0[it] + NE; e < re1[it]; ++e) add_row(g.ga_col[e] - m0, ga_mode == 2 ? g.ga_wgt[e] : 1.f);
-            }
-            if (ga_mode == 1) {
-                const float mean_w = cnt ? 1.f / (float)cnt : 0.f;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] *= mean_w;
-            } else {
-                float gv[8];
-                if (g.c_bf16) {
-                    const unsigned rw[4] = {gq[it].x, gq[it].y, gq[it].z, gq[it].w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        gv[2 * t] = __uint_as_float(rw[t] << 16);
-                        gv[2 * t + 1] = __uint_as_float(rw[t] & 0xffff0000u);
-                    }
-                } else {  // (exact-f32 mode: fetched here)
-                    const float* gp = (const float*)g.ga_gate + (long long)m * g.ga_ld + n;
-                    const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
-                    gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] = gv[t] > 0.f ? acc[t] : 0.f;
-            }
-            if (g.c_bf16) {
-                uint4 pk;
-                pk.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
-                pk.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
-                pk.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
-                *reinterpret_cast<uint4*>((bf16_t*)g.ga_out + (long long)m * g.ga_ld + n) = pk;
-            } else {
-                float* op = (float*)g.ga_out + (long long)m * g.ga_ld + n;
-                *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            }
         }
     }
 }
@@ -890,7 +717,7 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& b, const uint4& a, const f3
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
 }
 
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false, bool GA = false, bool F16 = false>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false, bool F16 = false>
 __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid) {
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
@@ -1127,11 +954,11 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     }
     if constexpr (KG == 1) {
         if constexpr (MB == 1) {
-            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, GA>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
+            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
             else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         } else if constexpr (NI == 3) {  // 192 x 128: the staging image (96 KiB f32) fits the 3-stage ring
             static_assert(NSTAGE * STAGE >= 192 * 512 + 256, "the rows epilogue stages the whole tile (+ the wave partials) in the ring");
-            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, false, true, 2>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
+            if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, true, 2>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
             else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
         } else {
             gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
@@ -1226,57 +1053,9 @@ __device__ __forceinline__ void splitk_finish_group(const GemmArgs& g, int m, in
     }
 }
 
-// Split-K finished INSIDE the launch: every workgroup has stored its slab tile; it takes a ticket of its output tile, and the
-// workgroup that takes the LAST one (all splitk slabs of the tile are in memory: release fence before the ticket, acquire fence
-// behind it) sums the slabs in slab order and applies the epilogue -- gemm_splitk_reduce's arithmetic, so the same bits whichever
-// workgroup arrives last -- and hands the ticket counter back at zero.  One launch and one launch boundary less per
-// contraction (a step of 2048-row sequences has ~60 of them on its chains: BASELINE config 4) -- and MEASURED SLOWER there
-// (4.50 ms against 3.62; 3.89 with the fences compiled out): the last workgroup of a tile sums S x 32-64 KiB alone, behind a
-// device-scope atomic and an L2 write-back, where the reduce launch uses the whole chip.  Opt-in (EGK_ENABLE=splitk_in_launch).
-template <int ROWS>
-__device__ __forceinline__ void splitk_finish_in_launch(const GemmArgs& g, int bid) {
-    // (no static LDS here: the contraction's fragment addressing XORs absolute LDS addresses and relies on the dynamic
-    //  array starting at LDS address 0; the ring is dead by now, its first word takes the flag)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    volatile int& is_last = *reinterpret_cast<volatile int*>(lds);
-    int z, tm, tn;
-    tile_of(g, bid, z, tm, tn);
-    __syncthreads();  // every thread's slab stores have left the CU (workgroup-scope release: the vector L1 writes through)
-    if (threadIdx.x == 0) {
-        __threadfence();  // device-scope release, ONCE per workgroup: the XCD's L2 writes its dirty lines back
-        int* t = g.sk_tickets + tm * g.tiles_n + tn;
-        const int prev = atomicAdd(t, 1);
-        is_last = prev == g.splitk - 1;
-        if (is_last) {
-            *t = 0;           // (nobody else touches this counter any more in this launch)
-            __threadfence();  // device-scope acquire: this CU's L1 and the XCD's L2 drop what they hold of the other slabs
-        }
-    }
-    __syncthreads();
-    if (!is_last) return;
-    const int m0 = tm * ROWS, n0 = tn * BN;
-    const long long total = (long long)g.M * g.N;
-    for (int q = threadIdx.x; q < ROWS * (BN / 4); q += blockDim.x) {
-        const int m = m0 + (q >> 5), n = n0 + ((q & 31) << 2);
-        if (m < g.M && n < g.N) splitk_finish_group(g, m, n, total);
-    }
-    if (g.dbias && g.ws_bias && tn == 0) {
-        for (int r = threadIdx.x; r < ROWS; r += blockDim.x) {
-            const int m = m0 + r;
-            if (m >= g.M) continue;
-            float t = 0.f;
-            for (int zz = 0; zz < g.splitk; ++zz) t += g.ws_bias[(long long)zz * g.M + m];
-            g.dbias[m] += t;
-        }
-    }
-}
-
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool GA = false, bool F16 = false>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
-    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, GA, F16>(g, blockIdx.x);
-    if constexpr (!GA) {
-        if (g.sk_tickets != nullptr) splitk_finish_in_launch<32 * NI * MB>(g, blockIdx.x);  // (uniform; only with splitk > 1)
-    }
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, F16>(g, blockIdx.x);
 }
 
 // Grouped launch: up to MAX_GROUPS independent contractions of the SAME layout / element types / tile variant in one
@@ -1306,399 +1085,14 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(con
             if (v < t) break;
             v -= t;
         }
-        gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, true, false, F16>(gg.p[pi], v);
+        gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, true, F16>(gg.p[pi], v);
         return;
     }
     const GemmArgs& g = gg.p[blockIdx.y];
     if ((int)blockIdx.x >= g.tiles_m * g.tiles_n * g.splitk) return;
-    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, false, F16>(g, blockIdx.x);
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, F16>(g, blockIdx.x);
 }
 
-
-// ---- dW form (both operands k-major), deep ring of 32-deep K sub-stages ------------------------------------------------------
-// The weight gradients walk K = all nodes of the batch (6144 .. 16384): every K step pulls 2 x 64 k-rows x 256 B from strips
-// that only the few tiles of one XCD patch share, so its DMA pieces are L2 misses (HBM / memory-side cache latency, 1-2 us
-// under load) -- and the 2-stage ring of gemm_pipe_kernel has ONE 64-deep step (32 KiB per workgroup) in flight: in the step
-// the walk ran at ~2600 cycles per K tile against 1024 of matrix work (profiles/r04_c3_replay_timeline.txt: 157.7 us for
-// 96 K tiles).  Here the ring is cut in NSUB sub-stages of 32 k-rows (A 8 KiB | B 8 KiB): one barrier per sub-stage, NSUB - 1
-// sub-stages in flight behind it (NSUB = 5: 64 KiB per workgroup, 128 KiB per CU with two workgroups -- every byte of LDS).
-// The images, swizzles, fragment reads and the MFMA chain per accumulator are gemm_pipe_kernel's (a sub-stage is one half of
-// its k-major image: the swizzle terms depend on k mod 32 only), the fused bias gradient sums the same k-rows in the same
-// order: results are bit-identical to it.
-template <int NSUB, bool VIRT>
-__device__ __forceinline__ void gemm_tt_sub_body(const GemmArgs& g, const int bid) {
-    constexpr int SUB = 16384, HALF = 8192, KT = 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int z, tm, tn;
-    if constexpr (VIRT) tile_of_virtual(g, bid, z, tm, tn);
-    else tile_of(g, bid, z, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nkt = total_tiles(g, KT);
-    const int per = (nkt + g.splitk - 1) / g.splitk;
-    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
-    const int nsub = 2 * max(t_end - t_begin, 0);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int lr = lane & 15, lg = lane >> 4;
-
-    // DMA cursors: pieces 2w, 2w + 1 (4 k-rows of 256 B each) of each operand's sub-image
-    const bf16_t *pa[2], *pb[2];
-    long long sa = 0, sb = 0;
-    int cur_src = -1;
-    auto aim = [&](const bf16_t* (&p)[2], long long& step, const bf16_t* base, long long ld, int row0, int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = (2 * w + i) * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ (2 * (k & 3) + 8 * ((k >> 3) & 1));
-            int col = row0 + c * 8;
-            if (col + 8 > ld) col = 0;  // (beyond the allocated row: feeds output rows that are never stored)
-            p[i] = base + (long long)(k0 + k) * ld + col;
-        }
-        step = 32 * ld;
-    };
-    int slot_in = 0;  // ring slot the next issued sub-stage goes to
-    auto issue = [&](int j) {
-        if ((j & 1) == 0) {
-            int src, tt;
-            source_of<KT>(g, t_begin + (j >> 1), src, tt);
-            if (src != cur_src) {  // (uniform) first tile, or the walk crossed into the next K source
-                aim(pa, sa, (const bf16_t*)g.A[src], g.lda[src], m0, tt * KT);
-                aim(pb, sb, (const bf16_t*)g.B[src], g.ldb[src], n0, tt * KT);
-                cur_src = src;
-            }
-        }
-        unsigned char* sbase = lds + slot_in * SUB;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)pa[i], (lds_void_t*)(sbase + (2 * w + i) * 1024), 16, 0, 0);
-            pa[i] += sa;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)pb[i], (lds_void_t*)(sbase + HALF + (2 * w + i) * 1024), 16, 0, 0);
-            pb[i] += sb;
-        }
-        slot_in = slot_in + 1 == NSUB ? 0 : slot_in + 1;
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const unsigned tr_row = (unsigned)((8 * lg + tq) * 256 + (tp & 1) * 8);
-    const unsigned tr_f = (unsigned)(2 * tq + 8 * (lg & 1));
-    unsigned a_tr[4], b_tr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_tr[i] = tr_row + ((((unsigned)(wm * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
-        b_tr[i] = (unsigned)HALF + tr_row + ((((unsigned)(wn * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
-    }
-
-    // fused bias gradient, in gemm_pipe_kernel's order: thread (chunk column bcc, k group bkg) sums k-rows 4 bkg .. 4 bkg + 3 of
-    // every 64-deep K tile -- groups 0-7 (waves 0, 1) live in the even sub-stages, 8-15 (waves 2, 3) in the odd ones
-    const bool do_bias = g.dbias != nullptr && tn == 0;
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int bcc = tid & 15, bkg = tid >> 4;
-
-#pragma unroll
-    for (int p = 0; p < NSUB - 1; ++p)
-        if (p < nsub) issue(p);
-    int slot = 0;
-    for (int it = 0; it < nsub; ++it) {
-        const int later = min(NSUB - 2, nsub - 1 - it);  // sub-stages issued behind ``it`` so far (4 pieces per wave each)
-        if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's pieces of sub-stage ``it`` landed; the slot read at it - 1 is free
-        if (it + NSUB - 1 < nsub) issue(it + NSUB - 1);
-        const unsigned st = lds_base + slot * SUB;
-        slot = slot + 1 == NSUB ? 0 : slot + 1;
-        uint4 a[4], b[4], bz[4];
-        const bool bias_now = do_bias && ((w >> 1) == (it & 1));  // (wave-uniform)
-        if (bias_now) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = (bkg & 7) * 4 + r;
-                const unsigned ad = st + (unsigned)(k * 256 + ((bcc ^ (2 * (k & 3) + 8 * ((k >> 3) & 1))) << 4));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(bz[r]) : "v"(ad));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned ad = st + b_tr[j];
-            uint2 lo, hi;
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
-            b[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned ad = st + a_tr[i];
-            uint2 lo, hi;
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
-            a[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-        // reads return in issue order: with the last two A fragments (4 reads) outstanding, B and A fragments 0, 1 are back
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]),
-                                                                    acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 2; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]),
-                                                                    acc[i][j], 0, 0, 0);
-        if (bias_now) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned wv[4] = {bz[r].x, bz[r].y, bz[r].z, bz[r].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bsum[2 * e] += __uint_as_float(wv[e] << 16);
-                    bsum[2 * e + 1] += __uint_as_float(wv[e] & 0xffff0000u);
-                }
-            }
-        }
-    }
-    if (g.dbias != nullptr && tn == 0) {  // block-uniform
-        __syncthreads();                  // every wave is done with the ring: reuse it as f32 scratch [16 k groups][128 rows]
-        float* red = reinterpret_cast<float*>(lds);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[bkg * 128 + bcc * 8 + e] = bsum[e];
-        __syncthreads();
-        if (tid < 128 && m0 + tid < g.M) {
-            float t = 0.f;
-            for (int q = 0; q < 16; ++q) t += red[q * 128 + tid];
-            if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
-            else g.dbias[m0 + tid] += t;
-        }
-        __syncthreads();
-    }
-    if (epilogue_rows_ok(g)) gemm_epilogue_rows<4, false, false>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, 0);
-    else gemm_epilogue<4, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
-}
-
-template <int NSUB>
-__global__ __launch_bounds__(NTHREADS) void gemm_tt_sub_kernel(const GemmArgs g) {
-    gemm_tt_sub_body<NSUB, false>(g, blockIdx.x);
-}
-template <int NSUB>
-__global__ __launch_bounds__(NTHREADS) void gemm_tt_sub_group_kernel(const GemmGroup gg) {
-    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-    const int q = gg.total >> 3, r = gg.total & 7;
-    if (slot >= q + (xcd < r ? 1 : 0)) return;
-    int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    int pi = 0;
-    for (; pi + 1 < gg.count; ++pi) {  // (uniform scalar walk over <= 8 problems)
-        const int t = gg.p[pi].tiles_m * gg.p[pi].tiles_n;
-        if (v < t) break;
-        v -= t;
-    }
-    gemm_tt_sub_body<NSUB, true>(gg.p[pi], v);
-}
-
-// ---- 256 x 128 tile, two PING-PONG wave groups (large outputs) ---------------------------------------------------------------
-// The 4-wave kernel above reaches ~65 % matrix-pipe utilisation because its DMA issue (a wave is held ~68 cycles per 1-KiB piece),
-// its LDS fragment reads and its MFMAs overlap only as far as the two co-resident workgroups of a CU happen to drift apart;
-// the 8-wave 256 x 128 tile (MB = 2) runs all eight waves in lock step and is slower still.  Here the two waves of a SIMD take
-// EXPLICIT turns (MI355X_MICROARCH.md, "Two waves per SIMD"): group A (waves 0-3, rows 0-127) and group B (waves 4-7, rows
-// 128-255) share the B image and alternate, one barrier per phase,
-//     phase 2i     A: LOAD(i)      B: COMPUTE(i - 1)
-//     phase 2i + 1 A: COMPUTE(i)   B: LOAD(i)
-// LOAD(i) = issue this wave's 6 DMA pieces of tile i + 2, read the 16 fragments of tile i (both k-steps) into registers;
-// COMPUTE(i) = 32 MFMAs.  A SIMD's matrix pipe always has ONE wave in its MFMA block while the other one waits on the
-// vector-memory path and LDS.  3-stage ring of (A image 32 KiB | B image 16 KiB) = 144 KiB, one workgroup per CU; a stage is
-// rewritten two phases after its last reader finished (lgkmcnt(0) in front of the barrier).  Images, swizzles and the MFMA
-// chain per accumulator are gemm_pipe_kernel's: results are bit-identical to it and to the generic kernel.
-template <bool TRA, bool TRB>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g) {
-    constexpr int NS = 3, IMG = 16384, IMG_A = 2 * IMG, STAGE = IMG_A + IMG, NI = 4, NPB = 2, LOADS = NI + NPB, KT = 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int z, tm, tn;
-    tile_of(g, blockIdx.x, z, tm, tn);
-    const int m0 = tm * 256, n0 = tn * BN;
-    const int nkt = total_tiles(g, KT);
-    const int per = (nkt + g.splitk - 1) / g.splitk;
-    const int t_begin = z * per, t_end = min(nkt, t_begin + per);
-    const int nt = max(t_end - t_begin, 0);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = w >> 2;             // 0: group A (rows 0-127 of the tile), 1: group B (rows 128-255)
-    const int wm = w >> 1, wn = w & 1;  // wm: 64-row band 0 .. 3
-    const int lr = lane & 15, lg = lane >> 4;
-
-    OperandCursor<TRA, NI> ca;
-    OperandCursor<TRB, NPB> cb;
-    int cur_src = -1;
-    auto issue = [&](int i) {
-        int src, tt;
-        source_of<KT>(g, t_begin + i, src, tt);
-        if (src != cur_src) {  // (uniform) first tile, or the walk crossed from one K source into the next
-            ca.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, tt * KT, w * NI, lane, 1);
-            cb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, tt * KT, w * NPB, lane, 1);
-            cur_src = src;
-        }
-        unsigned char* sbase = lds + (i % NS) * STAGE;
-        ca.issue(sbase, w * NI);
-        cb.issue(sbase + IMG_A, w * NPB);
-    };
-
-    f32x4 acc[NI][4];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
-    const unsigned rm_sw = (unsigned)((lg ^ ((lr >> 1) & 7)) << 4);
-    const unsigned a_rm = (unsigned)((wm * 64 + lr) * ROWB) + rm_sw;
-    const unsigned b_rm = (unsigned)((wn * 64 + lr) * ROWB) + rm_sw;
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const unsigned tr_row = (unsigned)((8 * lg + tq) * 256 + (tp & 1) * 8);
-    const unsigned tr_f = (unsigned)(2 * tq + 8 * (lg & 1));
-    unsigned a_tr[4], b_tr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_tr[i] = (unsigned)((wm >> 1) * IMG) + tr_row + ((((unsigned)((wm & 1) * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
-        b_tr[i] = tr_row + ((((unsigned)(wn * 8 + 2 * i + (tp >> 1))) ^ tr_f) << 4);
-    }
-    // fused bias gradient (dW form), as gemm_pipe_kernel's tall tile: the threads of group x sum sub-image x of the k-major A image
-    const bool do_bias = TRA && g.dbias != nullptr && tn == 0;
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int bcc = tid & 15, bkg = (tid & 255) >> 4;
-
-    if (nt > 0) issue(0);
-    if (nt > 1) issue(1);
-    uint4 a0[4], a1[4], b0[4], b1[4], bz[4];
-    for (int p = 0; p <= 2 * nt; ++p) {
-        if ((p & 1) == 0) {
-            // in front of an even phase 2i every wave has waited for ITS pieces of tile i (read by group A in this phase, by group
-            // B in the next): the only pieces that may still be in flight are those of tile i + 1
-            if ((p >> 1) + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        const int q = p - grp;  // this group's own phase: even -> LOAD(q / 2), odd -> COMPUTE((q - 1) / 2)
-        if (q < 0 || q >= 2 * nt) continue;  // (group B sits out phase 0, group A the last one)
-        if ((q & 1) == 0) {
-            const int i = q >> 1;
-            if (i + 2 < nt) issue(i + 2);
-            const unsigned stA = lds_base + (i % NS) * STAGE, stB = stA + IMG_A;
-            if constexpr (TRA) {
-                if (do_bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int k = bkg * 4 + r;
-                        const unsigned ad = stA + (unsigned)(grp * IMG + k * 256 + ((bcc ^ (2 * (k & 3) + 8 * ((k >> 3) & 1))) << 4));
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(bz[r]) : "v"(ad));
-                    }
-                }
-            }
-            if constexpr (TRA) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const unsigned ad = stA + a_tr[ii];
-                    uint2 lo, hi;
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
-                    a0[ii] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(lo) : "v"(ad));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(hi) : "v"(ad));
-                    a1[ii] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-            } else {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a0[ii]) : "v"(stA + a_rm), "n"(ii * 2048));
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a1[ii]) : "v"((stA + a_rm) ^ 64u), "n"(ii * 2048));
-                }
-            }
-            if constexpr (TRB) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned ad = stB + b_tr[j];
-                    uint2 lo, hi;
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(ad));
-                    b0[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(lo) : "v"(ad));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(hi) : "v"(ad));
-                    b1[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0[j]) : "v"(stB + b_rm), "n"(j * 2048));
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1[j]) : "v"((stB + b_rm) ^ 64u), "n"(j * 2048));
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: the stage is free after the next barrier
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (TRA) {
-                if (do_bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned wv[4] = {bz[r].x, bz[r].y, bz[r].z, bz[r].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            bsum[2 * e] += __uint_as_float(wv[e] << 16);
-                            bsum[2 * e + 1] += __uint_as_float(wv[e] & 0xffff0000u);
-                        }
-                    }
-                }
-            }
-        } else {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0[j]), __builtin_bit_cast(bf16x8, a0[i]),
-                                                                        acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1[j]), __builtin_bit_cast(bf16x8, a1[i]),
-                                                                        acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if constexpr (TRA) {
-        if (g.dbias != nullptr && tn == 0) {  // block-uniform
-            __syncthreads();                  // every wave is done with the ring: f32 scratch [2 sub-images][16 k groups][128 rows]
-            float* red = reinterpret_cast<float*>(lds);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[(grp * 16 + bkg) * 128 + bcc * 8 + e] = bsum[e];
-            __syncthreads();
-            if (tid < 256 && m0 + tid < g.M) {
-                const int q0 = (tid >> 7) * 16;
-                float t = 0.f;
-                for (int q = 0; q < 16; ++q) t += red[(q0 + q) * 128 + (tid & 127)];
-                if (g.splitk > 1) g.ws_bias[(long long)z * g.M + m0 + tid] = t;
-                else g.dbias[m0 + tid] += t;
-            }
-            __syncthreads();
-        }
-    }
-    gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 64, wn * 64, lr, lg, z);
-}
 
 // Fragment reads of the 256 x 256 kernel: fragments FIRST .. FIRST + 3 of k-step S of one operand image (inline asm for
 // the reason given in gemm_pipe_kernel: a plain LDS load would drain the DMA queue first).
@@ -1981,7 +1375,7 @@ __device__ __forceinline__ void read_step32(float (&f)[NF][4], unsigned st, unsi
 // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only) for outputs whose 128-row tiling
 // loads the CUs unevenly -- two co-resident workgroups share a CU's matrix pipes, so a launch takes as long as the rows on its
 // fullest CU: 6144 x 1024 is 384 tiles of 128 rows (2 x 128 rows on half of the CUs) but 512 tiles of 96 rows (2 x 96 everywhere).
-template <bool TRA, bool TRB, int NI = 4, bool VIRT = false, bool GA = false>
+template <bool TRA, bool TRB, int NI = 4, bool VIRT = false>
 __device__ __forceinline__ void gemm_pipe_f32_body(const GemmArgs& g, const int bid) {
     static_assert(NI == 4 || (NI == 3 && !TRA), "96-row tiles: row-major A");
     constexpr int IMG = 16384, IMG_A = NI * 4096, STAGE = IMG_A + IMG, KT = 32;
@@ -2111,13 +1505,13 @@ __device__ __forceinline__ void gemm_pipe_f32_body(const GemmArgs& g, const int 
             __syncthreads();
         }
     }
-    if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI, GA>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
+    if (epilogue_rows_ok(g)) gemm_epilogue_rows<NI>(g, acc, lds, m0, n0, wm, wn, lr, lg, z, tid, tm * g.tiles_n + tn);
     else gemm_epilogue<NI, 4>(g, acc, m0, n0, wm * 16 * NI, wn * 64, lr, lg, z);
 }
 
-template <bool TRA, bool TRB, int NI = 4, bool GA = false>
+template <bool TRA, bool TRB, int NI = 4>
 __global__ __launch_bounds__(NTHREADS) void gemm_pipe_f32_kernel(const GemmArgs g) {
-    gemm_pipe_f32_body<TRA, TRB, NI, false, GA>(g, blockIdx.x);
+    gemm_pipe_f32_body<TRA, TRB, NI, false>(g, blockIdx.x);
 }
 
 // grouped launch of exact-f32 contractions (the weight gradients of the reference-precision step): XCD-packed placement
@@ -2196,11 +1590,9 @@ static int g_use_pipe = 1;
 // in a replay) -- development knob egk_gemm_set_pipeline(400 + tenths of a microsecond).
 static double g_reduce_fixed_us = 3.5;
 static int g_group_tt_pad_kb = 0;   // development knob (egk_gemm_set_pipeline(600 + KiB)): extra dynamic LDS of queued weight-gradient groups
-static int g_sk_in_launch = 1;      // development knob (egk_gemm_set_pipeline(700 / 701)): split-K finished inside the launch off / on
 static int g_wg2_rows64 = 0;        // development knob (egk_gemm_set_pipeline(500 / 501)): variant 12 inside the policy off / on
 static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(100 + group_m); 100 = policy)
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
-static int g_tt_sub = 0;            // development knob (egk_gemm_set_pipeline(800 + NSUB): dW-form launches on the sub-staged ring; 800 = off)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
 static int g_row_affinity = 1;      // development knob (egk_gemm_set_pipeline(950 / 951)): XCD x owns a contiguous eighth of the tile rows off / on
 static int g_r192 = 1;              // development knob (egk_gemm_set_pipeline(900 / 901)): 192 x 128 tiles (variant 16) inside the policy off / on
@@ -2213,15 +1605,11 @@ static void set_lds_attr() {
 static void ensure_lds_attr() {
     if (g_lds_attr_set) return;
     set_lds_attr<2, false, false, 1>(); set_lds_attr<2, false, true, 1>(); set_lds_attr<2, true, true, 1>(); set_lds_attr<2, true, false, 1>();
-    set_lds_attr<3, false, false, 1>(); set_lds_attr<3, false, true, 1>(); set_lds_attr<3, true, true, 1>(); set_lds_attr<3, true, false, 1>();
-    set_lds_attr<4, false, false, 1>(); set_lds_attr<4, false, true, 1>(); set_lds_attr<4, true, true, 1>(); set_lds_attr<4, true, false, 1>();
     set_lds_attr<2, false, false, 2>(); set_lds_attr<2, false, true, 2>(); set_lds_attr<2, true, true, 2>(); set_lds_attr<2, true, false, 2>();
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    set_lds_attr<2, false, false, 1, 2>(); set_lds_attr<2, false, true, 1, 2>(); set_lds_attr<2, true, true, 1, 2>(); set_lds_attr<2, true, false, 1, 2>();
-    set_lds_attr<3, false, false, 1, 2>(); set_lds_attr<3, false, true, 1, 2>(); set_lds_attr<3, true, true, 1, 2>(); set_lds_attr<3, true, false, 1, 2>();
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -2252,21 +1640,6 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<3, false, true, 1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
-    // the instantiations with the row gather in the epilogue (96- and 64-row tiles, row-major A)
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 1, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 1, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_group_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
-    (void)hipFuncSetAttribute((const void*)egk::gemm_tt_sub_group_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
     g_lds_attr_set = true;
 }
 // development knob (A/B runs in one process): 0 routes every contraction through the generic kernel
@@ -2274,8 +1647,7 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
     if (on >= 950) { g_row_affinity = on - 950; return prev; }
     if (on >= 900) { g_r192 = on - 900; return prev; }
-    if (on >= 800) { g_tt_sub = on - 800; return prev; }
-    if (on >= 700) { g_sk_in_launch = on - 700; return prev; }
+    if (on >= 700) return prev;  // (700 / 80x: knobs of variants that no longer exist)
     if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
     if (on >= 500) { g_wg2_rows64 = on - 500; return prev; }
     if (on >= 400) { g_reduce_fixed_us = (on - 400) * 0.1; return prev; }
@@ -2383,34 +1755,20 @@ static int fill_sources(const egk_gemm_desc* d, GemmArgs& g, int ea, int eb, Sou
     return 0;
 }
 
-static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather = nullptr, int* query_sk = nullptr);
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks);
 
 extern "C" int egk_gemm(egk_stream_t stream, const egk_gemm_desc* d) { return gemm_core(stream, d, nullptr); }
-
-// 1 when the launch of ``d`` would run its ga_mode row gather in the epilogue (the 4-wave tile variants that write their tile out
-// through LDS, unsplit, every edge inside one tile: ga_tile_mask).  Nothing is launched.
-extern "C" int egk_gemm_gather_ok(const egk_gemm_desc* d) {
-    int blocks = 0, ok = 0;
-    const int rc = gemm_core(nullptr, d, &blocks, &ok);
-    return rc == 0 ? ok : 0;
-}
 
 // Number of per-tile partial blocks [blocks][st_nseg][2] a launch of ``d`` with st_mode != 0 writes to st_ws -- 0 when the
 // tile variant the policy picks for ``d`` cannot (the caller then runs the LayerNorm's own statistics pass).  Nothing is
 // launched.
-extern "C" int egk_gemm_splitk_in_launch(const egk_gemm_desc* d) {
-    int blocks = 0, ga = 0, sk = 0;
-    const int rc = gemm_core(nullptr, d, &blocks, &ga, &sk);
-    return rc == 0 ? sk : 0;
-}
-
 extern "C" int egk_gemm_stats_blocks(const egk_gemm_desc* d) {
     int blocks = 0;
     const int rc = gemm_core(nullptr, d, &blocks);
     return rc == 0 ? blocks : 0;
 }
 
-static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks, int* query_gather, int* query_sk) {
+static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blocks) {
     EGK_REQUIRE(d != nullptr, "egk_gemm: null descriptor");
     EGK_REQUIRE(d->M >= 0 && d->N >= 0 && d->K1 >= 0 && d->K2 >= 0, "egk_gemm: negative size");
     EGK_REQUIRE(d->compute == EGK_COMPUTE_F32 || d->compute == EGK_COMPUTE_BF16, "egk_gemm: bad compute type");
@@ -2458,20 +1816,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         EGK_REQUIRE(d->st_nseg >= 1 && d->st_nseg <= 16 && d->st_seg_ptr && (query_blocks || d->st_ws), "egk_gemm: st_* segments / workspace");
         EGK_REQUIRE(d->st_mode == 1 || (d->st_x && d->st_stats && d->st_w && d->st_b), "egk_gemm: st_mode 2 needs x, stats, w, b");
     }
-    g.sk_tickets = nullptr;
-    g.adam = (const AdamEpi*)d->adam_epi;
-    EGK_REQUIRE(!g.adam || (g.splitk == 1 && !g.c_bf16 && !d->ga_mode && !d->st_mode && d->alpha == 1.f && d->act == 0 && !d->residual && !d->bias),
-                "egk_gemm: adam_epi needs a plain f32 gradient store (no split-K, activation, residual, statistics or gather)");
-    g.ga_mode = d->ga_mode; g.ga_skip_c = d->ga_mode ? d->ga_skip_c : 0;
-    g.ga_rowptr = d->ga_rowptr; g.ga_col = d->ga_col; g.ga_wgt = d->ga_wgt; g.ga_band = d->ga_band;
-    g.ga_gate = d->ga_gate; g.ga_out = d->ga_out; g.ga_ld = d->ga_ld;
-    if (d->ga_mode) {
-        EGK_REQUIRE(d->ga_mode == 1 || d->ga_mode == 2, "egk_gemm: ga_mode must be 0, 1 or 2");
-        EGK_REQUIRE(d->ga_rowptr && d->ga_col && d->ga_out, "egk_gemm: ga_mode needs rowptr, col and an output");
-        EGK_REQUIRE(d->ga_mode == 1 || (d->ga_wgt && d->ga_gate), "egk_gemm: ga_mode 2 needs the edge weights and the gate tensor");
-    }
     if (query_blocks) *query_blocks = 0;
-    if (query_gather) *query_gather = 0;
     const long long K = src.k_total;
     const double flops = 2.0 * d->M * d->N * K;
     const double bytes = (a16 ? 2.0 : 4.0) * ((double)d->M * K + (double)d->N * K) + (g.c_bf16 ? 2.0 : 4.0) * d->M * d->N;
@@ -2532,7 +1877,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                     const long long cur = variant == 8 ? ((t96 + 255) / 256) * 28 : ((t128 + 255) / 256) * 32;
                     // (ONE round only: 8192 x 1024 -- 344 tiles, two rounds of which the second is a third full -- measured 32.6 us
                     //  against 22.3 on 128-row tiles; BASELINE config 5's 16384 rows 3.08 against 2.92 ms per step)
-                    if (g_r192 && !d->ga_mode && t192 > 192 && t192 <= 256 && 40 < cur) variant = 16;
+                    if (g_r192 && t192 > 192 && t192 <= 256 && 40 < cur) variant = 16;
                 } else if (t64 <= 256 && t64 > t128) {
                     // at most 128 tiles: 64-row tiles put one 4-wave workgroup on twice as many CUs instead of one
                     // 8-wave (two wave groups) workgroup on half of them (2048 x 1024 x 1024: 10.6 vs 12.4 us)
@@ -2540,7 +1885,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                     // ... and BOTH where the epilogue needs no finished tile in one wave group (no LayerNorm statistics, no row
                     // gather): 64-row tiles on every CU, two wave groups per workgroup walking alternate K tiles -- the lone
                     // 4-wave workgroup of (11) leaves its CU's DMA / LDS / matrix phases unoverlapped
-                    if (g_wg2_rows64 && !d->st_mode && !d->ga_mode && nkt_slab >= 8) variant = 12;
+                    if (g_wg2_rows64 && !d->st_mode && nkt_slab >= 8) variant = 12;
                 }
             }
             // large outputs with a long K walk: 256 x 256 tiles, one 8-wave workgroup per CU, when whole tiles fill at least
@@ -2561,17 +1906,18 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                 10 * t192 >= 9 * 256 * ((t192 + 255) / 256))
                 variant = 15;
         } else if ((variant == 8 || variant == 11 || variant == 12 || variant == 16) &&
-                   (d->transA || (variant == 16 && (g.splitk > 1 || d->ga_mode)))) {
-            variant = 3;  // the forced variants exist for row-major A only (16: unsplit, no row gather in the epilogue)
+                   (d->transA || (variant == 16 && g.splitk > 1))) {
+            variant = 3;  // the forced variants exist for row-major A only (16: unsplit)
         } else if (variant == 7 && (g.dbias || g.M % 256 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 256 x 256 tiles only, no fused bias gradient
         } else if (variant == 15 && (d->transA || g.dbias || g.M % 192 != 0 || g.N % 256 != 0)) {
             variant = 3;  // whole 192 x 256 tiles of a row-major A only
         }
-        const int mb = (variant == 6 || variant == 13 || variant == 14) ? 2 : 1;
-        if (variant == 12 && (d->st_mode || d->ga_mode)) variant = 11;  // (forced by the knob: the epilogue features win)
+        if (variant != 3 && variant != 5 && variant != 7 && variant != 8 && variant != 11 && variant != 12 && variant != 15 && variant != 16)
+            variant = 3;  // (a forced value that names no tile variant: the 2-stage 128 x 128 kernel)
+        if (variant == 12 && d->st_mode) variant = 11;  // (forced by the knob: the epilogue statistics win)
         g.tiles_m = variant == 8 ? cdiv(g.M, 96) : (variant == 11 || variant == 12) ? cdiv(g.M, 64) : variant == 7 ? cdiv(g.M, 256)
-                    : (variant == 15 || variant == 16) ? cdiv(g.M, 192) : cdiv(g.M, BM * mb);
+                    : (variant == 15 || variant == 16) ? cdiv(g.M, 192) : cdiv(g.M, BM);
         if (variant == 7 || variant == 15) g.tiles_n = cdiv(g.N, 256);
 #ifdef EGK_GEMM_STAMPS
         if (variant != 7 && !g.dbias && d->ws) {
@@ -2601,35 +1947,17 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         // segment statistics in the epilogue: the 4-wave variants that write their tile out through LDS in whole rows, unsplit,
         // and tiles that span at most two row segments
         const int tile_rows = variant == 8 ? 96 : (variant == 11 || variant == 12) ? 64 : variant == 16 ? 192 : 128;
-        const bool st_ok = (variant == 2 || variant == 3 || variant == 4 || variant == 8 || variant == 11 || variant == 16) && g.splitk == 1 &&
+        const bool st_ok = (variant == 3 || variant == 8 || variant == 11 || variant == 16) && g.splitk == 1 &&
                            epilogue_rows_ok(g) && d->st_min_seg_rows >= tile_rows &&
                            (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % (g.c_bf16 ? 8 : 4) == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
-        // row gather in the epilogue: the same variants; every edge inside one tile of this height (ga_tile_mask bit 0 / 1 / 2 =
-        // 64 / 96 / 128 rows); whole 8-column groups of 16-byte aligned rows for the output and the gate
-        const int ga_bit = tile_rows == 64 ? 1 : 2;
-        const bool ga_ok = (variant == 8 || variant == 11) && g.splitk == 1 &&  // (96- / 64-row tiles: the 128-row ones have no registers to spare)
-                           epilogue_rows_ok(g) && (d->ga_tile_mask & ga_bit) && aligned16(d->ga_out) && d->ga_ld % (g.c_bf16 ? 8 : 4) == 0 &&
-                           (d->ga_mode != 2 || aligned16(d->ga_gate));
-        // split-K finished in the launch (sk_tickets): the reduce kernel's vector path, every tile variant but the 256 x 256 one
-        const bool sk_in_launch = g.splitk > 1 && d->sk_tickets != nullptr && variant != 7 && variant != 15 && (g.N & 3) == 0 && g.c_vec &&
-                                  (!g.residual || g.r_vec) && g_sk_in_launch;
         if (query_blocks) {
             *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
-            if (query_gather) *query_gather = (d->ga_mode && ga_ok) ? 1 : 0;
-            if (query_sk) *query_sk = sk_in_launch ? 1 : 0;
             return 0;
         }
         if (d->st_mode && !st_ok) {
             set_error("egk_gemm: st_mode %d is not available for this launch (ask egk_gemm_stats_blocks first)", d->st_mode);
             return EGK_EUNSUPPORTED;
         }
-        if (d->ga_mode && !ga_ok) {
-            set_error("egk_gemm: ga_mode %d is not available for this launch (ask egk_gemm_gather_ok first)", d->ga_mode);
-            return EGK_EUNSUPPORTED;
-        }
-        g.sk_tickets = sk_in_launch ? d->sk_tickets : nullptr;
-        // dW form on the sub-staged ring: wherever the 2-stage 128 x 128 kernel (variant 3) would run
-        const int tt_sub = (d->transA && d->transB && variant == 3 && !g.sk_tickets && (g_tt_sub == 4 || g_tt_sub == 5)) ? g_tt_sub : 0;
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
@@ -2642,21 +1970,11 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         } else if (variant == 12) {                                                                                       \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 2, 1, 2>), pgrid, dim3(2 * NTHREADS), 4 * 24576, s, g);    \
         } else if (variant == 11) {                                                                                       \
-            if (d->ga_mode) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2, true>), pgrid, pblock, 2 * 24576, s, g); \
-            else hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);           \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, g);                \
         } else if (variant == 8) {                                                                                        \
-            if (d->ga_mode) hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3, true>), pgrid, pblock, 2 * 28672, s, g); \
-            else hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);           \
-        } else if (variant == 14) {                                                                                       \
-            hipLaunchKernelGGL((gemm_pp_kernel<TA, TB>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, g);                     \
-        } else if (variant == 13) {                                                                                       \
-            hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, g);          \
-        } else if (variant == 6)                                                                                          \
-            hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 2>), pgrid, dim3(2 * NTHREADS), 2 * 49152, s, g);          \
-        else if (variant == 5)                                                                                            \
+            hipLaunchKernelGGL((gemm_pipe_kernel<2, false, TB, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, g);                \
+        } else if (variant == 5)                                                                                          \
             hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 2, 1>), pgrid, dim3(2 * NTHREADS), 4 * 32768, s, g);          \
-        else if (variant == 4) hipLaunchKernelGGL((gemm_pipe_kernel<4, TA, TB, 1, 1>), pgrid, pblock, 4 * 32768, s, g);   \
-        else if (variant == 2) hipLaunchKernelGGL((gemm_pipe_kernel<3, TA, TB, 1, 1>), pgrid, pblock, 3 * 32768, s, g);   \
         else hipLaunchKernelGGL((gemm_pipe_kernel<2, TA, TB, 1, 1>), pgrid, pblock, 2 * 32768, s, g);                     \
     } while (0)
         {
@@ -2665,18 +1983,15 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                                        : ((variant == 5 || variant == 12) ? KID_GEMM_BF16_NN_G2 : KID_GEMM_BF16_NN) + layout, s, flops, bytes);
             if (!d->transA && !d->transB) EGK_PIPE(false, false);
             else if (!d->transA && d->transB) EGK_PIPE(false, true);
-            else if (d->transA && d->transB) {
-                if (tt_sub == 4) hipLaunchKernelGGL((gemm_tt_sub_kernel<4>), pgrid, pblock, 4 * 16384, s, g);
-                else if (tt_sub == 5) hipLaunchKernelGGL((gemm_tt_sub_kernel<5>), pgrid, pblock, 5 * 16384, s, g);
-                else EGK_PIPE(true, true);
-            } else EGK_PIPE(true, false);
+            else if (d->transA && d->transB) EGK_PIPE(true, true);
+            else EGK_PIPE(true, false);
         }
 #undef EGK_PIPE
         const bool defer = take_defer_reduce();
         if (defer)
-            EGK_REQUIRE(g.splitk > 1 && !g.sk_tickets && !g.accumulate && g.act == 0 && !g.residual && g.alpha == 1.f && !g.c_bf16 && !g.dbias,
+            EGK_REQUIRE(g.splitk > 1 && !g.accumulate && g.act == 0 && !g.residual && g.alpha == 1.f && !g.c_bf16 && !g.dbias,
                         "egk_gemm_defer_reduce_next: a split launch with a plain f32 result (bias only)");
-        if (g.splitk > 1 && !g.sk_tickets && !defer) {
+        if (g.splitk > 1 && !defer) {
             ProfScope prof(KID_GEMM_SPLITK_REDUCE, s, 0, slab_bytes);
             const long long total = (long long)g.M * g.N;
             const long long work = (total + 3) / 4;  // element groups of 4 (the vector path; the scalar path strides)
@@ -2707,27 +2022,18 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         }
         const bool st_ok = g.splitk == 1 && epilogue_rows_ok(g) && d->st_min_seg_rows >= (r96 ? 96 : 128) &&
                            (d->st_mode != 2 || (aligned16(d->st_x) && d->st_ldx % 4 == 0 && aligned16(d->st_w) && aligned16(d->st_b)));
-        const bool ga_ok = r96 && g.splitk == 1 && epilogue_rows_ok(g) && (d->ga_tile_mask & 2) && aligned16(d->ga_out) &&
-                           d->ga_ld % (g.c_bf16 ? 8 : 4) == 0 && (d->ga_mode != 2 || aligned16(d->ga_gate));
         if (query_blocks) {
             *query_blocks = (d->st_mode && st_ok) ? g.tiles_m * g.tiles_n : 0;
-            if (query_gather) *query_gather = (d->ga_mode && ga_ok) ? 1 : 0;
             return 0;
         }
         if (d->st_mode && !st_ok) {
             set_error("egk_gemm: st_mode %d is not available for this launch (ask egk_gemm_stats_blocks first)", d->st_mode);
             return EGK_EUNSUPPORTED;
         }
-        if (d->ga_mode && !ga_ok) {
-            set_error("egk_gemm: ga_mode %d is not available for this launch (ask egk_gemm_gather_ok first)", d->ga_mode);
-            return EGK_EUNSUPPORTED;
-        }
         const dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk), pblock(NTHREADS);
         {
             ProfScope prof(KID_GEMM_F32_NN + layout, s, flops, bytes);
-            if (r96 && d->ga_mode && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false, 3, true>), pgrid, pblock, 2 * 28672, s, g);
-            else if (r96 && d->ga_mode) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true, 3, true>), pgrid, pblock, 2 * 28672, s, g);
-            else if (r96 && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false, 3>), pgrid, pblock, 2 * 28672, s, g);
+            if (r96 && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false, 3>), pgrid, pblock, 2 * 28672, s, g);
             else if (r96) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true, 3>), pgrid, pblock, 2 * 28672, s, g);
             else if (!d->transA && !d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, false>), pgrid, pblock, 65536, s, g);
             else if (!d->transA && d->transB) hipLaunchKernelGGL((gemm_pipe_f32_kernel<false, true>), pgrid, pblock, 65536, s, g);
@@ -2744,11 +2050,7 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         }
         return check_launch("egk_gemm");
     }
-    if (query_blocks) return 0;  // (the generic kernel has no statistics / gather epilogue: 0 blocks, not ok)
-    if (d->ga_mode) {
-        set_error("egk_gemm: ga_mode %d is not available on the generic kernel (ask egk_gemm_gather_ok first)", d->ga_mode);
-        return EGK_EUNSUPPORTED;
-    }
+    if (query_blocks) return 0;  // (the generic kernel has no statistics epilogue: 0 blocks, not ok)
     if (d->st_mode) {
         set_error("egk_gemm: st_mode %d is not available on the generic kernel (ask egk_gemm_stats_blocks first)", d->st_mode);
         return EGK_EUNSUPPORTED;
@@ -2826,11 +2128,6 @@ static int fill_group_args(const egk_gemm_desc* d, GemmArgs& g) {
     g.ws = nullptr;
     g.dbias = d->dbias; g.ws_bias = nullptr;
     g.rows_epilogue = g_rows_epilogue;
-    g.ga_mode = 0; g.ga_skip_c = 0; g.ga_rowptr = nullptr; g.ga_col = nullptr; g.ga_wgt = nullptr; g.ga_band = nullptr;
-    g.ga_gate = nullptr; g.ga_out = nullptr; g.ga_ld = 0; g.sk_tickets = nullptr;
-    g.adam = (const AdamEpi*)d->adam_epi;
-    EGK_REQUIRE(!g.adam || (!g.c_bf16 && d->alpha == 1.f && d->act == 0 && !d->residual && !d->bias),
-                "egk_gemm_grouped: adam_epi needs a plain f32 gradient store");
     g.st_mode = 0; g.st_nseg = 0; g.st_seg_ptr = nullptr; g.st_ws = nullptr; g.st_x = nullptr; g.st_ldx = 0;
     g.st_stats = nullptr; g.st_w = nullptr; g.st_b = nullptr; g.st_slope = 0.f;
     EGK_REQUIRE(d->st_mode == 0, "egk_gemm_grouped: no segment statistics in a grouped launch");
@@ -2854,7 +2151,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         EGK_REQUIRE((d->transA != 0) == ta && (d->transB != 0) == tb, "egk_gemm_grouped: the problems must share one layout");
         EGK_REQUIRE((d->compute == EGK_COMPUTE_F32) == f32g, "egk_gemm_grouped: the problems must share one compute type");
         EGK_REQUIRE((d->op_f16 != 0) == f16, "egk_gemm_grouped: the problems must agree on op_f16");
-        EGK_REQUIRE(!f16 || (!d->st_mode && !d->ga_mode && !d->dbias && d->n_extra == 0), "egk_gemm_grouped: op_f16 has no statistics / gather / bias-gradient epilogue");
+        EGK_REQUIRE(!f16 || (!d->st_mode && !d->dbias && d->n_extra == 0), "egk_gemm_grouped: op_f16 has no statistics / bias-gradient epilogue");
         const int rc = fill_group_args(d, gg.p[i]);
         if (rc) return rc;
         int K = d->K1 + d->K2;
@@ -2955,8 +2252,6 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
             else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, gg);
         } else if (!ta && !tb) EGK_PIPE_G(false, false);
         else if (!ta && tb) EGK_PIPE_G(false, true);
-        else if (variant != 5 && packed && pad == 0 && g_tt_sub == 4) hipLaunchKernelGGL((gemm_tt_sub_group_kernel<4>), pgrid, pblock, 4 * 16384, s, gg);
-        else if (variant != 5 && packed && pad == 0 && g_tt_sub == 5) hipLaunchKernelGGL((gemm_tt_sub_group_kernel<5>), pgrid, pblock, 5 * 16384, s, gg);
         else EGK_PIPE_G(true, true);
     }
 #undef EGK_PIPE_G

@@ -399,7 +399,7 @@ __global__ void adam_hyper_kernel(const float* __restrict__ src, long long* __re
 }
 
 // ---- Adam (torch.optim.Adam single-tensor formulas, L2 weight decay) ----------------------------------------
-// the elements [0, n) of one span, grid-stride over ``nblk`` workgroups (adam_kernel: the whole slice; adam_ranges_kernel: one range)
+// the elements [0, n) of one span, grid-stride over ``nblk`` workgroups (adam_kernel: the whole slice)
 template <typename GT>
 __device__ __forceinline__ void adam_span(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                           long long n, const AdamConsts& ac, bf16_t* __restrict__ shadow, bf16_t* __restrict__ shadow_lo,
@@ -441,24 +441,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (bump_word && blockIdx.x == 0 && threadIdx.x == 0) *bump_word += bump;
     const AdamConsts ac{hyper[0] / hyper[1], hyper[2], hyper[3], b1, b2, eps, wd};
     adam_span(p, g, m, v, n, ac, shadow, shadow_lo, blockIdx.x, gridDim.x);
-}
-
-// Adam over up to ADAM_MAX_RANGES element ranges of the flat buffers as ONE launch (blockIdx.y = range): what is left of a slice
-// once the weight matrices stepped inside their gradient launches (AdamEpi) are taken out -- biases, LayerNorm parameters, padding
-constexpr int ADAM_MAX_RANGES = 48;
-struct AdamRanges {
-    long long begin[ADAM_MAX_RANGES], len[ADAM_MAX_RANGES];
-};
-template <typename GT>
-__global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
-                                                          float* __restrict__ v, const AdamRanges R, const float* __restrict__ hyper,
-                                                          float b1, float b2, float eps, float wd, bf16_t* __restrict__ shadow,
-                                                          bf16_t* __restrict__ shadow_lo, long long* __restrict__ bump_word, long long bump) {
-    if (bump_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump_word += bump;
-    const AdamConsts ac{hyper[0] / hyper[1], hyper[2], hyper[3], b1, b2, eps, wd};
-    const long long o = R.begin[blockIdx.y];
-    adam_span(p + o, g + o, m + o, v + o, R.len[blockIdx.y], ac, shadow ? shadow + o : nullptr, shadow_lo ? shadow_lo + o : nullptr,
-              blockIdx.x, gridDim.x);
 }
 
 static inline unsigned ew_grid(long long n, int per_thread) {
@@ -736,9 +718,13 @@ int egk_zero_fill(egk_stream_t stream, void* p, int64_t bytes) {
     return check_launch("egk_zero_fill");
 }
 
-// up to ADAM_MAX_RANGES byte ranges of one buffer cleared by ONE launch (blockIdx.y = range): the gradient slots that are still
+// up to ZERO_MAX_RANGES byte ranges of one buffer cleared by ONE launch (blockIdx.y = range): the gradient slots that are still
 // accumulated into once the matrices whose ONE weight-gradient launch stores its result are left alone (FlatAdam.store_slots)
-__global__ __launch_bounds__(256) void zero_ranges_kernel(unsigned char* __restrict__ base, const AdamRanges R) {
+constexpr int ZERO_MAX_RANGES = 48;
+struct ByteRanges {
+    long long begin[ZERO_MAX_RANGES], len[ZERO_MAX_RANGES];
+};
+__global__ __launch_bounds__(256) void zero_ranges_kernel(unsigned char* __restrict__ base, const ByteRanges R) {
     uint4* p = reinterpret_cast<uint4*>(base + R.begin[blockIdx.y]);
     const long long n16 = R.len[blockIdx.y] >> 4;
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -747,11 +733,11 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(unsigned char* __restr
 
 int egk_zero_fill_ranges(egk_stream_t stream, void* base, const int64_t* begin, const int64_t* bytes, int32_t n_ranges) {
     EGK_REQUIRE(base && begin && bytes, "egk_zero_fill_ranges: null pointer");
-    EGK_REQUIRE(n_ranges >= 1 && n_ranges <= ADAM_MAX_RANGES, "egk_zero_fill_ranges: 1 .. %d ranges per launch", ADAM_MAX_RANGES);
+    EGK_REQUIRE(n_ranges >= 1 && n_ranges <= ZERO_MAX_RANGES, "egk_zero_fill_ranges: 1 .. %d ranges per launch", ZERO_MAX_RANGES);
     EGK_REQUIRE(((uintptr_t)base & 15) == 0, "egk_zero_fill_ranges: 16-byte aligned buffer");
-    AdamRanges R;
+    ByteRanges R;
     long long longest = 0;
-    for (int i = 0; i < ADAM_MAX_RANGES; ++i) {
+    for (int i = 0; i < ZERO_MAX_RANGES; ++i) {
         R.begin[i] = i < n_ranges ? begin[i] : 0;
         R.len[i] = i < n_ranges ? bytes[i] : 0;
         if (i < n_ranges) {
@@ -801,31 +787,5 @@ int egk_adam_step_bump(egk_stream_t stream, float* p, const void* g, int32_t g_d
                                                (long long)n, hyper, beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow,
                                                (bf16_t*)bf16_lo_shadow, (long long*)bump_word, (long long)bump));
     return check_launch("egk_adam_step");
-}
-
-int egk_adam_step_ranges(egk_stream_t stream, float* p, const void* g, int32_t g_dtype, float* m, float* v, const int64_t* begin,
-                         const int64_t* len, int32_t n_ranges, const float* hyper, float beta1, float beta2, float eps,
-                         float weight_decay, void* bf16_shadow, void* bf16_lo_shadow, int64_t* bump_word, int64_t bump) {
-    EGK_REQUIRE(p && g && m && v && hyper && begin && len, "egk_adam_step_ranges: null pointer");
-    EGK_REQUIRE(n_ranges >= 1 && n_ranges <= ADAM_MAX_RANGES, "egk_adam_step_ranges: 1 .. %d ranges per launch", ADAM_MAX_RANGES);
-    hipStream_t s = (hipStream_t)stream;
-    AdamRanges R;
-    long long longest = 0, total = 0;
-    for (int i = 0; i < ADAM_MAX_RANGES; ++i) {
-        R.begin[i] = i < n_ranges ? begin[i] : 0;
-        R.len[i] = i < n_ranges ? len[i] : 0;
-        if (i < n_ranges) {
-            EGK_REQUIRE(begin[i] >= 0 && len[i] >= 0 && begin[i] % 4 == 0, "egk_adam_step_ranges: ranges start at multiples of 4 elements");
-            longest = len[i] > longest ? len[i] : longest;
-            total += len[i];
-        }
-    }
-    ProfScope prof(KID_ADAM, s, 0, ((bf16_shadow ? 26.0 : 24.0) + (bf16_lo_shadow ? 2.0 : 0.0) + (g_dtype == EGK_BF16 ? 2.0 : 4.0)) * total);
-    unsigned gx = ew_grid(longest, 4);
-    if (gx > 512u) gx = 512u;
-    EGK_DISPATCH_T(g_dtype, hipLaunchKernelGGL(adam_ranges_kernel<T>, dim3(gx, n_ranges), dim3(256), 0, s, p, (const T*)g, m, v, R, hyper,
-                                               beta1, beta2, eps, weight_decay, (bf16_t*)bf16_shadow, (bf16_t*)bf16_lo_shadow,
-                                               (long long*)bump_word, (long long)bump));
-    return check_launch("egk_adam_step_ranges");
 }
 }

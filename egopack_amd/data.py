@@ -111,52 +111,17 @@ class CSRGraph:
     # i - 1, bit 1: i, bit 2: i + 1), 0xFF for any other row -- egk_csr_gather_banded reads the neighbours of a coded row
     # without fetching rowptr / col (a radius-1 temporal graph is banded everywhere but at the LTA forecast nodes)
     band: Optional[torch.Tensor] = None
-    # bit 0 / 1 / 2: no edge crosses a multiple of 64 / 96 / 128 rows (``tile_locality_mask``) -- a contraction whose output
-    # tiles are that high can then aggregate the neighbours of its own result inside its epilogue (egk_gemm_desc.ga_*).
-    # Sequences of 32 nodes collated back to back never cross any of them.
-    tile_mask: int = 0
 
     def _map(self, f):
         return CSRGraph(*(f(t) for t in (self.rowptr, self.col, self.t_rowptr, self.t_col, self.t_wgt)), self.num_nodes,
                         *(f(t) if t is not None else None for t in (self.heavy, self.t_heavy)), self.heavy_mode, self.t_heavy_mode,
-                        f(self.band) if self.band is not None else None, self.tile_mask)
+                        f(self.band) if self.band is not None else None)
 
     def to(self, device, non_blocking: bool = False):
         return self._map(lambda t: t.to(device, non_blocking=non_blocking))
 
     def pin_memory(self):
         return self._map(lambda t: t.pin_memory())
-
-
-TILE_HEIGHTS = (64, 96, 128)  # output-tile heights of the pipelined contraction (csrc/gemm.hip): bits of CSRGraph.tile_mask
-
-
-def _tile_mask_wanted() -> bool:
-    """The mask's only consumer is the opt-in gather-in-epilogue fusion (EGK_ENABLE=gather_fusion, measured slower: DESIGN 10.4):
-    the loaders do not pay an np.repeat over all edges + three comparisons per batch for a switch that is off."""
-    from . import ops
-    return bool(ops._gather_fusion["on"])
-
-
-def tile_locality_mask(rowptr, col, force: bool = False) -> int:
-    """Bit b is set when no edge of the by-target CSR (rowptr, col) joins two nodes on different sides of a multiple of
-    TILE_HEIGHTS[b] rows.  Host arrays only (a device-side CSR reports 0: nothing is fused).  Computed only while its consumer
-    is switched on (``_tile_mask_wanted``) or when ``force``d: 0 otherwise."""
-    if not (force or _tile_mask_wanted()):
-        return 0
-    if torch.is_tensor(rowptr):
-        if rowptr.device.type != "cpu":
-            return 0
-        rowptr, col = rowptr.numpy(), col.numpy()
-    rowptr, col = np.asarray(rowptr, dtype=np.int64), np.asarray(col, dtype=np.int64)
-    if col.size == 0:
-        return (1 << len(TILE_HEIGHTS)) - 1
-    row = np.repeat(np.arange(rowptr.size - 1, dtype=np.int64), np.diff(rowptr))
-    mask = 0
-    for b, h in enumerate(TILE_HEIGHTS):
-        if bool((row // h == col // h).all()):
-            mask |= 1 << b
-    return mask
 
 
 def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
@@ -178,8 +143,7 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
     t_heavy = torch.nonzero(deg_out > HEAVY_DEGREE).flatten().int()
     mode = lambda deg, listed: int(listed.numel() > 0 and int(deg.max()) <= HEAVY_IN_LAUNCH_DEGREE)
     return CSRGraph(rowptr.int(), col.int(), t_rowptr.int(), t_col.int(), t_wgt, int(num_nodes), heavy, t_heavy,
-                    mode(deg_in, heavy), mode(deg_out, t_heavy), band_codes(rowptr, col, num_nodes),
-                    tile_locality_mask(rowptr, col))
+                    mode(deg_in, heavy), mode(deg_out, t_heavy), band_codes(rowptr, col, num_nodes))
 
 
 def band_codes(rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int) -> torch.Tensor:
@@ -428,7 +392,7 @@ def concat_csr(graphs: Sequence[CSRGraph]) -> CSRGraph:
     rowptr_all, col_all = ptr("rowptr"), ids("col")
     return CSRGraph(rowptr_all, col_all, ptr("t_rowptr"), ids("t_col"), torch.cat([g.t_wgt for g in graphs]),
                     sum(g.num_nodes for g in graphs), heavy, t_heavy, mode([g.heavy for g in graphs], "heavy_mode"),
-                    mode([g.t_heavy for g in graphs], "t_heavy_mode"), band, tile_locality_mask(rowptr_all, col_all))
+                    mode([g.t_heavy for g in graphs], "t_heavy_mode"), band)
 
 
 class PinnedRing:
@@ -638,33 +602,29 @@ def pack_features(batches: Sequence[Data], dtype=None, device=None, pin: bool = 
 # --------------------------------------------------------------------------------------------
 # loaders
 # --------------------------------------------------------------------------------------------
-class multiloader:
-    """Zip several loaders; restart exhausted ones until every enabled loader has completed once
-    (reference utils/dataloading.py:8-47).  Loaders that are None or have weight <= 0 yield None."""
+def multiloader(loaders, weights):
+    """One tuple of batches per step from several loaders walked side by side (reference utils/dataloading.py:8-47): slot i is
+    ``None`` for a loader that is None or has weight <= 0; a loader that runs out is started again -- its first batch takes the
+    slot -- until EVERY active loader has run out at least once; the step in which the last of them runs out ends the walk (what the
+    earlier slots of that step had drawn is dropped, as in the reference).  A generator: the state is its frame."""
+    active = [i for i, (ld, w) in enumerate(zip(loaders, weights)) if ld is not None and w > 0]
+    walks = {i: iter(loaders[i]) for i in active}
+    pending = set(active)  # loaders that have not run out yet
+    while pending:  # (no active loader at all: nothing to walk -- the reference's class would hand out empty steps for ever)
+        step = [None] * len(loaders)
+        for i in active:
+            batch = next(walks[i], _EXHAUSTED)
+            if batch is _EXHAUSTED:
+                pending.discard(i)
+                if not pending:
+                    return
+                walks[i] = iter(loaders[i])
+                batch = next(walks[i])
+            step[i] = batch
+        yield tuple(step)
 
-    def __init__(self, loaders, weights):
-        self.loaders, self.weights = loaders, weights
-        self.iterators = [iter(l) if (l is not None and w > 0) else None for l, w in zip(loaders, weights)]
-        self.completed = [it is None for it in self.iterators]
 
-    def __iter__(self):
-        return self
-
-    def __next__(self):
-        out = []
-        for i in range(len(self.loaders)):
-            if self.iterators[i] is None:
-                out.append(None)
-                continue
-            try:
-                out.append(next(self.iterators[i]))
-            except StopIteration:
-                self.completed[i] = True
-                if all(self.completed):
-                    raise StopIteration
-                self.iterators[i] = iter(self.loaders[i])
-                out.append(next(self.iterators[i]))
-        return tuple(out)
+_EXHAUSTED = object()
 
 
 class BatchLoader:
@@ -1080,7 +1040,7 @@ class GraphTemplates:
         t_heavy, t_mode = listed(t["THV"], t["nth"], t["tdmax"])
         i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32))
         graph = CSRGraph(i32(rowptr), i32(col), i32(t_rowptr), i32(t_col), torch.from_numpy(np.ascontiguousarray(t_wgt)), B * T,
-                         heavy, t_heavy, mode, t_mode, torch.from_numpy(np.ascontiguousarray(band)), tile_locality_mask(rowptr, col))
+                         heavy, t_heavy, mode, t_mode, torch.from_numpy(np.ascontiguousarray(band)))
         out = (torch.from_numpy(np.ascontiguousarray(ei)), graph)
         if len(self._assembled) < 64:
             self._assembled[key] = out

@@ -15,6 +15,8 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import switches
+
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
     """(rank, local_rank, world_size) from the torchrun environment; initialises the process group
@@ -126,7 +128,7 @@ class GradSync:
         if compress not in ("none", "bf16"):
             raise ValueError(compress)
         self.world, self.group, self.compress = world_size, group, compress
-        self.shard_update = ("sharded_update" in os.environ.get("EGK_ENABLE", "")) if shard_update is None else bool(shard_update)
+        self.shard_update = (switches.enabled("sharded_update")) if shard_update is None else bool(shard_update)
         self.chunk_elems = max(8, (int(chunk_mb * (1 << 20) / 4) + 7) // 8 * 8)  # chunk starts stay 32-byte aligned
         self._side = None
         self._g16 = None
@@ -136,7 +138,7 @@ class GradSync:
         # OPT-IN (EGK_ENABLE=adam_behind_collective or the attribute): the Adam writes (f32 parameters, bf16 shadows) then run
         # concurrently with the remaining backward graphs, and that ordering has never executed against real RCCL peers --
         # the default issues every slice after the last stage, behind its collective's event
-        self.adam_behind_collective = "adam_behind_collective" in os.environ.get("EGK_ENABLE", "")
+        self.adam_behind_collective = switches.enabled("adam_behind_collective")
         self.hyper_ready = False  # set by a caller that has prepared the step's Adam constants itself (a captured exchange)
 
     def quiesce(self) -> None:

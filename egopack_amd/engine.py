@@ -17,7 +17,7 @@ from typing import Dict, Mapping, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import ops, switches
 from .data import Data, merge_batches
 from .criterion import MetricSelectorWrapper
 from .dist import GradSync
@@ -152,66 +152,13 @@ class StagedBatches:
             done.record(self.copy_stream)
         return staged, done
 
-    def _ahead(self):
-        """``_fetch`` results from a worker thread, up to two steps ahead.  The host side of a step of the headline workload --
-        whole-batch builders 0.65 ms, packing + staging 0.55 ms, ~2700 Python calls -- was issued by the training thread behind
-        its own ``train_step``: 1.6-1.9 ms per step against 1.41 ms of device time, a host-bound loop (main_temporal.py at 75 % of
-        the bench line, main_egopack.py -- 1 ms of hipGraphLaunch per replay -- at 65 %).  The worker builds and stages while the
-        training thread sits in the graph launch (which releases the interpreter lock).  Captures use the thread-local capture
-        mode (CAPTURE_MODE), the copy stream and its allocations are this iterator's own, the library's one-shot launch state
-        is per host thread: the worker's launches are legal at any time.  OPT-IN (EGK_ENABLE=stage_thread): measured on one box,
-        alternating, main_temporal.py 1.600 / 1.684 ms per step with the thread against 1.554 / 1.630 in line, main_egopack.py
-        2.69 both ways (tools/round5/ab_stage_thread.sh) -- two Python threads share one interpreter lock, and the fetch is
-        mostly interpreter work."""
-        import queue
-        import threading
-        q, stop = queue.Queue(maxsize=2), threading.Event()
-        dev = torch.device(self.device)
-
-        def put(item):
-            while not stop.is_set():
-                try:
-                    q.put(item, timeout=0.1)
-                    return True
-                except queue.Full:
-                    continue
-            return False
-
-        def work():
-            try:
-                if dev.type == "cuda":
-                    torch.cuda.set_device(dev)
-                while not stop.is_set():
-                    item = self._fetch()
-                    if not put(item) or item is None:
-                        return
-            except BaseException as e:  # noqa: BLE001  (handed to the consumer, which re-raises it)
-                put(e)
-        th = threading.Thread(target=work, name="egk-stage", daemon=True)
-        th.start()
-        try:
-            while True:
-                item = q.get()
-                if isinstance(item, BaseException):
-                    raise item
-                if item is None:
-                    return
-                yield item
-        finally:
-            stop.set()
-            th.join(timeout=5.0)
-
     def __iter__(self):
-        if self.copy_stream is not None and "stage_thread" in os.environ.get("EGK_ENABLE", ""):
-            source = self._ahead()
-        else:
-            def inline():
-                nxt = self._fetch()
-                while nxt is not None:
-                    yield nxt
-                    nxt = self._fetch()  # issued right after the consumer launched its step: overlaps it
-            source = inline()
-        for nxt in source:
+        def inline():
+            nxt = self._fetch()
+            while nxt is not None:
+                yield nxt
+                nxt = self._fetch()  # issued right after the consumer launched its step: overlaps it
+        for nxt in inline():
             (batches, merged), done = nxt
             if done is not None:
                 cur = torch.cuda.current_stream()
@@ -462,22 +409,16 @@ class StepBase:
         # and left it off until round 4 (EgoPackStep.wgrad_grouping_default)
         self.wgrad_grouping = type(self).wgrad_grouping_default
         self.deferred_forks = type(self).deferred_forks_default
-        off = set(filter(None, os.environ.get("EGK_DISABLE", "").split(",")))  # development: A/B of the grouped paths
-        on = set(filter(None, os.environ.get("EGK_ENABLE", "").split(",")))  # development: force a path a step class leaves off
-        if "wgrad_grouping" in on:
-            self.wgrad_grouping = True
-        if "deferred_forks" in on:
-            self.deferred_forks = True
-        if "wgrad_grouping" in off:
-            self.wgrad_grouping = False
-        if "deferred_forks" in off:
-            self.deferred_forks = False
-        if "grouped_heads" in off:
+        # development switches (egopack_amd/switches.py): the environment overrides the step class's defaults
+        for name in ("wgrad_grouping", "deferred_forks"):
+            forced = switches.override(name)
+            if forced is not None:
+                setattr(self, name, forced)
+        if not switches.enabled("grouped_heads"):
             self.grouped_heads = False
-        self._fused_loss = "fused_loss" not in off
-        if "ln_fusion" in off:
+        self._fused_loss = switches.enabled("fused_loss")
+        if not switches.enabled("ln_fusion"):
             ops._ln_fusion["on"] = False
-        self._dev_off = off
 
     # ---- backbone ------------------------------------------------------------------------------------
     def features(self, batches: Mapping[str, Data], merged: Optional[Data] = None) -> Dict[str, torch.Tensor]:
@@ -607,13 +548,13 @@ class StepBase:
         @contextlib.contextmanager
         def scope():
             learn = (getattr(opt, "materialised", False) and hasattr(opt, "learn_begin") and not torch.cuda.is_current_stream_capturing()
-                     and "grad_store" not in os.environ.get("EGK_DISABLE", ""))
-            prev = ops.set_adam_epilogue(opt.learn_begin(), None) if learn else None  # (which gradient slots have ONE writer per step)
+                     and switches.enabled("grad_store"))
+            prev = ops.set_grad_slot_provider(opt.learn_begin()) if learn else None  # (which gradient slots have ONE writer per step)
             try:
                 yield
             finally:
                 if learn:
-                    ops.set_adam_epilogue(*prev)
+                    ops.set_grad_slot_provider(prev)
                     opt.learn_end()
         return scope()
 
@@ -621,16 +562,17 @@ class StepBase:
         """Install the 'store' provider for a capture (None: off / nothing learnt); ``zero_flat_grads`` leaves the stored slots out
         until ``_grad_store_end``."""
         opt = self.optimizer
-        if (getattr(self, "_grad_store_off", False) or not hasattr(opt, "store_begin") or "grad_store" in os.environ.get("EGK_DISABLE", "")
-                or "adam_epilogue" in os.environ.get("EGK_ENABLE", "")):
+        if getattr(self, "_grad_store_off", False) or not hasattr(opt, "store_begin") or not switches.enabled("grad_store"):
             return None
         prov = opt.store_begin()
-        return None if prov is None else ops.set_adam_epilogue(prov, None)
+        if prov is None:
+            return None
+        return (ops.set_grad_slot_provider(prov),)
 
     def _grad_store_end(self, prev) -> None:
         if prev is not None:
             import sys
-            ops.set_adam_epilogue(*prev)
+            ops.set_grad_slot_provider(prev[0])
             self.optimizer.store_end(ok=sys.exc_info()[0] is None)  # (checks that every slot left uncleared was written exactly once)
             self._grad_store_slots = len(self.optimizer.store_slots)
 
@@ -861,8 +803,7 @@ class StepBase:
         if self._use_stages():
             return self._capture_staged(batches, merged)
         fuse_adam = self.sync is None or self.sync.world <= 1
-        segmented = self._segmented_replay()
-        g = torch.cuda.CUDAGraph(keep_graph=True) if segmented else torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph()
         opt.sync_hyper_source()  # (the step constants are computed inside the graph from a device-side step counter)
         ops.rng_device_offset(opt.flat_p.device)  # (the dropout offset word exists BEFORE the capture: created inside, its fill is a node)
         self._hyper_in_graph = False
@@ -871,29 +812,18 @@ class StepBase:
         prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         early = self._early_adam_plan(live) if fuse_adam else None
-        # Adam inside the weight-gradient launches (FlatAdam.epilogue_begin): only where every weight matrix gets its gradient from
-        # ONE launch per step (the fused backbone pass or a single task) and the optimizer runs inside the graph (one rank).
-        # OPT-IN (EGK_ENABLE=adam_epilogue): bit-identical, and measured SLOWER -- headline 1.514-1.517 against 1.409-1.416 ms
-        # (tools/round5/ab_c3.sh): the optimizer's HBM-bound pass used to run BESIDE the matrix-bound tail group; inside the
-        # epilogue the same traffic is a burst at the end of every tile, while that workgroup's matrix pipe idles
-        epi_prev = None
         # gradient slots with one writer per step (learnt from the eager steps above, FlatAdam.learn_begin) are stored, not cleared +
         # accumulated: the step's buffer clear shrinks to what is still added into (EGK_DISABLE=grad_store); also when the
         # optimizer follows a gradient exchange outside the graph
         store_prev = self._grad_store_begin()
-        if (fuse_adam and self.adam_epilogue and (self.fused or len(live) == 1) and hasattr(opt, "epilogue_begin")
-                and "adam_epilogue" in os.environ.get("EGK_ENABLE", "")):
-            prov, unclaim = opt.epilogue_begin()
-            if prov is not None:
-                epi_prev = ops.set_adam_epilogue(prov, unclaim)
         try:
             with torch.cuda.graph(g, stream=ops.unexcluded_stream(), capture_error_mode=CAPTURE_MODE):
                 ops.stamp("step_start")
                 # the gradient buffer is cleared BESIDE the forward pass (nothing writes a gradient before the first backward
                 # launch): 100 MB of memset off the chain's head; joined in _join_zero() before backward starts
-                hyper_here = fuse_adam and "hyper_in_graph" not in getattr(self, "_dev_off", ())
+                hyper_here = fuse_adam and switches.enabled("hyper_in_graph")
                 self._hyper_in_graph = hyper_here
-                if "zero_stream" in getattr(self, "_dev_off", ()):
+                if not switches.enabled("zero_stream"):
                     opt.zero_flat_grads()
                     if hyper_here:
                         opt.prepare_hyper(in_capture=True)
@@ -907,7 +837,7 @@ class StepBase:
                             opt.zero_flat_grads()
                             if hyper_here:  # the step's Adam constants: one thread, beside the forward pass
                                 opt.prepare_hyper(in_capture=True)
-                    if "zero_deferred" in getattr(self, "_dev_off", ()):
+                    if not switches.enabled("zero_deferred"):
                         issue_zero(torch.cuda.current_stream().record_event())
                     else:
                         ops.defer_after_next_launch(issue_zero)
@@ -918,54 +848,30 @@ class StepBase:
                 if early is None and not fuse_adam:
                     self._install_tail(self._tail_only_plan(live))
                 if early is not None:
-                    early["rng"] = "rng_in_graph" not in getattr(self, "_dev_off", ()) and "rng_early" not in getattr(self, "_dev_off", ())
+                    early["rng"] = switches.enabled("rng_in_graph") and switches.enabled("rng_early")
                     ops.set_last_wgrad_hook(early["param"], early["hook"], pre=self._join_gradient_branches)
                     ops.set_graphone_backward_hook(early.get("graphone_hook"))
                     if early["tail"]:
                         g0 = opt.flat_g.data_ptr()
                         ops.set_last_wgrad_tail(g0 + 4 * early["lo"], g0 + 4 * early["hi"])
                 # (no join with the weight-gradient side stream when a backward() call returns: the gradients are read below, behind
-                #  ``join_wgrad(force=True)`` -- and the late optimizer slices before it, see ``tail_first``)
-                tail_opt = any(k in os.environ.get("EGK_ENABLE", "") for k in ("tail_adam_first", "graphone_adam_on_main"))
-                prev_h = ops.set_wgrad_handoff(True) if (tail_opt and early is not None and not getattr(self, "_handoff", False)) else None
-                self._early = early
-                try:
-                    total, vectors = self._backward_pass(batches, merged)
-                finally:
-                    self._early = None
-                    if prev_h is not None:
-                        ops.set_wgrad_handoff(prev_h)
+                #  ``join_wgrad(force=True)``)
+                total, vectors = self._backward_pass(batches, merged)
                 self._join_zero()  # (a backward path that did not: the memset must at least precede the optimizer)
-                # OPT-IN (EGK_ENABLE=tail_adam_first; measured equal, config 4 2.340 against 2.339 ms: the tail's launches share the
-                # chip whichever queue holds them): when every gradient of the late slice was issued on THIS stream (the tail group),
-                # its optimizer launch follows at once -- not behind the join with the side stream's queue of weight-gradient groups
-                # -- and so do the slices whose gradients were final long ago (EGK_ENABLE=graphone_adam_on_main)
-                tail_first = bool(fuse_adam and early is not None and early["fired"] and early["tail"] and early.get("rng_done")
-                                  and ops.last_wgrad_tail_on_backward_stream() and "tail_adam_first" in os.environ.get("EGK_ENABLE", ""))
                 ops.set_last_wgrad_hook(None, None)
-                if tail_first:
-                    ops.drain_deferred()
-                    if early["hi"] > early["lo"]:
-                        opt.launch(None, early["lo"], early["hi"])
-                if fuse_adam and early is not None and (early["fired"] or early.get("done")):
-                    ops.drain_deferred()
-                    for (a, b), ev in early.pop("tail_slices", ()):
-                        torch.cuda.current_stream().wait_event(ev)
-                        opt.launch(None, a, b)
                 ops.join_wgrad(force=True)
                 ops.stamp("backward_done")
                 # the Philox offset word of the dropout launches moves on INSIDE the graph (beside nothing that reads it: every
                 # dropout launch of the step is done when the optimizer starts): replay k draws the masks of offset base + k * stride
                 # without a separate launch in front of every replay -- and without a launch of its own: it rides in an optimizer
                 # launch (egk_adam_step_bump)
-                rng_here = "rng_in_graph" not in getattr(self, "_dev_off", ()) and not (early is not None and early.get("rng_done"))
+                rng_here = switches.enabled("rng_in_graph") and not (early is not None and early.get("rng_done"))
                 bump = (ops.rng_device_offset(opt.flat_p.device), ops.RNG_DEVICE_STRIDE) if rng_here else None
                 if fuse_adam:
                     if early is not None and early["fired"]:
                         torch.cuda.current_stream().wait_stream(early["stream"])
-                        if not tail_first:
-                            opt.launch(None, early["lo"], early["hi"], bump=bump if early["hi"] > early["lo"] else None)
-                            bump = None if early["hi"] > early["lo"] else bump
+                        opt.launch(None, early["lo"], early["hi"], bump=bump if early["hi"] > early["lo"] else None)
+                        bump = None if early["hi"] > early["lo"] else bump
                     elif early is not None and early.get("done"):  # (a slice was stepped, the last weight gradient's hook never ran)
                         torch.cuda.current_stream().wait_stream(early["stream"])
                         for a, b in _minus([(0, opt.flat_p.numel())], early["done"]):
@@ -975,7 +881,7 @@ class StepBase:
                         opt.launch(bump=bump)
                         bump = None
                     ops.stamp("adam_done")
-                if "rng_in_graph" not in getattr(self, "_dev_off", ()):
+                if switches.enabled("rng_in_graph"):
                     if bump is not None:
                         ops.advance_rng_device(opt.flat_p.device)
                     self._rng_in_graph = True
@@ -985,20 +891,7 @@ class StepBase:
             ops.set_wgrad_side_streams(prev)
             ops.set_wgrad_grouping(prev_g)
             ops.set_deferred_forks(prev_d)
-            if epi_prev is not None:
-                ops.set_adam_epilogue(*epi_prev)
-                self._adam_epilogue_ranges = opt.epilogue_end(keep=True)
             self._grad_store_end(store_prev)
-        if segmented:
-            from .graphexec import SegmentedGraph
-            try:
-                g = SegmentedGraph(g, max_streams=segmented,
-                                   event_nodes=self.segmented_event_nodes or "plan_event_nodes" in os.environ.get("EGK_ENABLE", ""))
-            except Exception as e:  # noqa: BLE001
-                # the plan could not be built from this capture (a node type the plan does not clone): the capture itself is
-                # intact -- replay it the runtime's way (the opt-in mode is an optimisation, not a requirement)
-                self.capture_notes = [*getattr(self, "capture_notes", []), f"segmented replay unavailable ({e!r}): runtime replay"]
-                g.instantiate()
         self._graph, self._static_out, self._fuse_adam = g, (total, vectors), fuse_adam
         self._graph_adam_lo = bool(fuse_adam and self._adam_keeps_lo())  # (the captured Adam launches write the low halves)
         # the graph holds raw addresses: keep every tensor it reads alive for as long as the graph exists
@@ -1010,7 +903,6 @@ class StepBase:
     # for steps that have JOINED every other gradient producer into the backward stream by then (MTLStep with its
     # head-wise backward does; a step whose branches are still running on their own streams at that point must not)
     early_adam = False
-    adam_epilogue = False  # (MTLStep: weight matrices stepped inside their gradient launches, optim.FlatAdam.epilogue_begin)
 
     def _tail_only_plan(self, live):
         """(first TRN weight, flat range of the temporal pooling's slots) when the step can end with ONE grouped launch of the
@@ -1020,7 +912,7 @@ class StepBase:
         tp = getattr(self.model, "temporal_pooling", None)
         first = getattr(tp, "proj", [None])[0] if tp is not None else None
         if (first is None or not hasattr(opt, "region_of") or not getattr(opt, "materialised", False) or not (self.fused or len(live) == 1)
-                or "tail_group" in getattr(self, "_dev_off", ()) or not self.headwise_backward_ok()
+                or not switches.enabled("tail_group") or not self.headwise_backward_ok()
                 or first.weight.numel() >= 512 * 128 * 128):  # (a wide first linear's weight gradient stays a launch of its own)
             return None
         params = [p for p in tp.parameters() if p.requires_grad]
@@ -1065,7 +957,7 @@ class StepBase:
         #  runs beside it; Hp = 4096 step 2.785-2.796 -> 2.770-2.772 ms.  At Hp = 1024 (288 tiles) the pooling's three weight
         #  gradients are one grouped launch, 123 against 120 + 66 us.)
         tail = None
-        if "tail_group" not in getattr(self, "_dev_off", ()) and first.weight.numel() < 512 * 128 * 128:
+        if switches.enabled("tail_group") and first.weight.numel() < 512 * 128 * 128:
             tail = region([p for p in tp.parameters() if p.requires_grad])
         reg = tail or region([p for p in (getattr(first, "weight", None), getattr(first, "bias", None)) if p is not None])
         if reg is None:
@@ -1140,9 +1032,9 @@ class StepBase:
     one_graph_exchange = False
 
     def _one_graph_exchange_ok(self) -> bool:
-        want = self.one_graph_exchange or "one_graph_exchange" in os.environ.get("EGK_ENABLE", "")
-        return bool(want and "one_graph_exchange" not in os.environ.get("EGK_DISABLE", "")
-                    and self.sync is not None and self.sync.world > 1 and self.sync.capturable())
+        forced = switches.override("one_graph_exchange")  # (EGK_ENABLE / EGK_DISABLE win over the attribute)
+        want = self.one_graph_exchange if forced is None else forced
+        return bool(want and self.sync is not None and self.sync.world > 1 and self.sync.capturable())
 
     def _capture_exchange_graph(self, batches, merged):
         opt, sync = self.optimizer, self.sync
@@ -1159,7 +1051,7 @@ class StepBase:
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         sync.begin_step()
         sync.hyper_ready = True
-        self._handoff = "wgrad_handoff" not in getattr(self, "_dev_off", ())
+        self._handoff = switches.enabled("wgrad_handoff")
         prev_h = ops.set_wgrad_handoff(self._handoff)
         store_prev = self._grad_store_begin()  # (single-writer gradient slots are stored: the collectives read final values either way)
         try:
@@ -1192,7 +1084,7 @@ class StepBase:
                 fired = []
 
                 def early_adam_hook():
-                    if fired or "exchange_early_adam" in getattr(self, "_dev_off", ()):
+                    if fired or not switches.enabled("exchange_early_adam"):
                         return
                     fired.append(True)
                     if not hasattr(self, "_adam_stream"):
@@ -1212,7 +1104,7 @@ class StepBase:
                 self._exchange_region(regions[2])
                 sync.finish_and_step(opt)
                 ops.stamp("adam_done")
-                if "rng_in_graph" not in getattr(self, "_dev_off", ()):
+                if switches.enabled("rng_in_graph"):
                     ops.advance_rng_device(opt.flat_p.device)
                     self._rng_in_graph = True
         finally:
@@ -1251,7 +1143,7 @@ class StepBase:
             with torch.cuda.graph(gs[0], stream=cap, capture_error_mode=CAPTURE_MODE):
                 # the gradient buffer is cleared BESIDE the forward pass, as in the one-rank capture (a fork and a join inside
                 # the first graph; _stage_a joins it before the heads' backward writes the first gradient)
-                if "zero_stream" in getattr(self, "_dev_off", ()):
+                if not switches.enabled("zero_stream"):
                     opt.zero_flat_grads()
                 else:
                     if not hasattr(self, "_zero_stream"):
@@ -1282,20 +1174,6 @@ class StepBase:
         self._graph, self._static_out, self._fuse_adam = gs, (total, vectors), False
         self._static_in = (batches, merged, self._stage_state, self._cuts)  # everything the graphs read stays alive
         return gs
-
-    # Replay through a plan of single-stream graphs (graphexec.SegmentedGraph) instead of the runtime's own replay of the
-    # captured graph: the number of streams of the plan, 0 = the runtime's replay.  EGK_ENABLE=segmented_replay[=N] /
-    # EGK_DISABLE=segmented_replay override the attribute.
-    segmented_replay = 0
-    segmented_event_nodes = False  # cross-stream edges as event-record / event-wait NODES inside per-stream graphs
-
-    def _segmented_replay(self) -> int:
-        if "segmented_replay" in os.environ.get("EGK_DISABLE", ""):
-            return 0
-        for item in os.environ.get("EGK_ENABLE", "").split(","):
-            if item.startswith("segmented_replay"):
-                return int(item.split("=")[1]) if "=" in item else 4
-        return int(self.segmented_replay)
 
     def replay(self):
         """One training step from the captured graph(s)."""
@@ -1367,7 +1245,7 @@ class MTLStep(StepBase):
     def _one_pass_head_ok(self, t: str) -> bool:
         from .criterion import BCEWithLogitsNone
         return (self.one_pass_heads and hasattr(self.tasks[t], "fused_head_loss") and type(self.criteria[t]) is BCEWithLogitsNone
-                and "rowdot_head" not in getattr(self, "_dev_off", ()))
+                and switches.enabled("rowdot_head"))
 
     def _one_pass_oscc_ok(self, t: str) -> bool:
         """The OSCC head (max pool -> 2-logit classifier -> cross entropy, one loss element per SEQUENCE) as pool + one launch
@@ -1375,13 +1253,13 @@ class MTLStep(StepBase):
         from .criterion import CrossEntropyNone
         return (t == "oscc" and self.one_pass_heads and hasattr(self.tasks[t], "fused_head_loss")
                 and type(self.criteria[t]) is CrossEntropyNone and getattr(self, "_fused_loss", True)
-                and "rowdot_head" not in getattr(self, "_dev_off", ()) and "oscc_one_pass" not in getattr(self, "_dev_off", ()))
+                and switches.enabled("rowdot_head") and switches.enabled("oscc_one_pass"))
 
     grouped_classifiers = True
 
     def _banked_tasks(self, order, proj_leaves):
         """Tasks whose multi-head classifier banks can share grouped launches (ops.grouped_classifier_banks): at least two."""
-        if not self.grouped_classifiers or "grouped_classifiers" in getattr(self, "_dev_off", ()):
+        if not self.grouped_classifiers or not switches.enabled("grouped_classifiers"):
             return []
         cand = []
         for t in order:
@@ -1498,7 +1376,7 @@ class MTLStep(StepBase):
                                                       fused_loss=getattr(self, "_fused_loss", True))
             vs, gs = [], []
             multi = None
-            if getattr(self, "_fused_loss", True) and "ce_multi" not in getattr(self, "_dev_off", ()):
+            if getattr(self, "_fused_loss", True) and switches.enabled("ce_multi"):
                 # the cross entropies of the banked tasks as ONE launch (each writes its own loss vector and gradient operand)
                 sel = [self.criteria[t].select(logits, labels[t]) for t, logits in zip(banked, all_logits)]
                 if len({s_[2] for s_ in sel}) == 1:
@@ -1539,7 +1417,7 @@ class MTLStep(StepBase):
             # backward and the backbone's
             src = {t: compact_v.get(t, v) for t, v in vectors.items()}
             cnt = {t: (n_full[t] if t in compact_v else None) for t in vectors}
-            if "objective_rider" in getattr(self, "_dev_off", ()) or not src:
+            if not switches.enabled("objective_rider") or not src:
                 total = self._objective(src, cnt)
             else:
                 order = [t for t in self.enabled if t in src]
@@ -1555,7 +1433,7 @@ class MTLStep(StepBase):
         CrossEntropyNone with ignore_index -1: the row's loss and gradient are exactly zero when every head's label is -1),
         no active dropout in the head (its masks are drawn by row position), the batch built by data.collate with its
         ``live_*`` index arrays on the features' device."""
-        if not self.compact_heads or "compact_heads" in getattr(self, "_dev_off", ()) or t not in ("ar", "lta"):
+        if not self.compact_heads or not switches.enabled("compact_heads") or t not in ("ar", "lta"):
             return False
         idx = getattr(d, "live_idx", None)
         if idx is None or getattr(d, "live_inv", None) is None or getattr(d, "live_y", None) is None:
@@ -1573,39 +1451,9 @@ class MTLStep(StepBase):
 
     headwise_backward = True  # False: one backward() call over all streams (kept for A/B measurements)
     early_adam = True
-    adam_epilogue = True
 
     def _early_adam_ok(self) -> bool:  # the heads are joined into the main stream before the backbone's backward starts
         return bool(self.early_adam and self.headwise_backward)
-
-    def _heads_adam_slice(self) -> None:
-        """OPT-IN (EGK_ENABLE=heads_adam), captured step with an early optimizer plan: the heads' gradients are final when their
-        parked weight gradients have been flushed -- Adam over their slice of the flat buffers runs beside the backbone's backward
-        instead of in the step's tail (what EgoPackStep does for GraphONE's slice).  Measured on the headline: 1.411-1.419 against
-        1.395-1.398 ms (three alternating rounds) -- the memory-bound launch slows the dX chain by more than the tail gains, as the
-        larger slice did in round 3; not kept as a default."""
-        early = getattr(self, "_early", None)
-        if early is None or early["fired"] or "heads_adam" not in os.environ.get("EGK_ENABLE", ""):
-            return
-        opt = self.optimizer
-        params = [p for t in self.enabled for p in self.tasks[t].parameters() if p.requires_grad and id(p) in opt._slot_of]
-        if not params:
-            return
-        h0, h1 = opt.region_of(params)
-        if not (h1 > h0 and h0 % 8 == 0 and h1 % 8 == 0 and sum(opt._slot_of[id(p)][1] for p in params) == h1 - h0
-                and (h1 <= early["lo"] or h0 >= early["hi"])):
-            return
-        main = torch.cuda.current_stream()
-
-        def issue(ev):  # (behind the backward stream's next launch, i.e. behind the flush above)
-            side = ops.wgrad_side_stream(main)
-            early["stream"].wait_event(ev)
-            if side is not None:
-                early["stream"].wait_stream(side)
-            with torch.cuda.stream(early["stream"]):
-                opt.launch(None, h0, h1)
-        ops.defer_after_next_launch(issue)
-        early.setdefault("done", []).append((h0, h1))
 
     def _backward_pass(self, batches, merged=None):
         if not self.headwise_backward:
@@ -1616,12 +1464,11 @@ class MTLStep(StepBase):
         self._join_zero()
         total, vectors, leaves = self._heads_forward_backward(feats)
         ops.stamp("heads_done")
-        if "heads_flush" not in getattr(self, "_dev_off", ()):
+        if switches.enabled("heads_flush"):
             # the heads' parked weight gradients (classifier banks, projections) go out as one launch NOW, beside the first
             # links of the backbone's dX chain; left parked, the backbone's first weight gradient would flush nine problems
             # as 8 + 1
             ops.flush_wgrad(in_backward=False, force=True)
-            self._heads_adam_slice()
         order = [t for t in feats if leaves[t].grad is not None]
         torch.autograd.backward([feats[t] for t in order], [leaves[t].grad for t in order])
         return total, vectors
@@ -1737,7 +1584,7 @@ class EgoPackStep(StepBase):
     early_adam = True
 
     def _early_adam_ok(self) -> bool:
-        return bool(self.early_adam and self.backprop and "early_adam" not in getattr(self, "_dev_off", ()))
+        return bool(self.early_adam and self.backprop and switches.enabled("early_adam"))
 
     def _gradient_branch_streams(self):
         return [*getattr(self.graphone, "_task_streams", ()), *getattr(self, "_head_streams", ())]
@@ -1752,7 +1599,7 @@ class EgoPackStep(StepBase):
         (tests/test_gpu_configs.py::test_config4_graphone_optimizer_slice_is_the_same_update)."""
         plan = super()._early_adam_plan(live)
         opt = self.optimizer
-        if plan is None or "graphone_adam" in os.environ.get("EGK_DISABLE", "") or len(live) != 1:
+        if plan is None or not switches.enabled("graphone_adam") or len(live) != 1:
             return plan
         params = [p for p in self.graphone.parameters() if p.requires_grad and id(p) in opt._slot_of]
         if not params:
@@ -1763,10 +1610,6 @@ class EgoPackStep(StepBase):
             return plan
         plan["done"] = []
 
-        # (opt-in, measured equal: the slice on the backward stream's tail instead of a stream of its own -- 2.333-2.39 against
-        #  2.348-2.355 ms)
-        on_main = "graphone_adam_on_main" in os.environ.get("EGK_ENABLE", "")
-
         def graphone_done():
             if plan["fired"] or plan["done"]:
                 return
@@ -1775,13 +1618,6 @@ class EgoPackStep(StepBase):
 
             def issue(ev):
                 side = ops.wgrad_side_stream(main)
-                if on_main:
-                    # the slice itself is launched on the backward stream when backward has ended (StepBase.capture: the step's tail),
-                    # behind this point of the side stream -- on a stream of its own the runtime's replay put it into the side
-                    # stream's hardware queue, between the weight-gradient groups it was meant to run beside
-                    # (profiles/r05_c4_replay_timeline.txt)
-                    plan["tail_slices"] = [((g0, g1), (side if side is not None else main).record_event())]
-                    return
                 plan["stream"].wait_event(ev)
                 if side is not None:
                     plan["stream"].wait_stream(side)
@@ -1793,7 +1629,7 @@ class EgoPackStep(StepBase):
         return plan
 
     def _precise_on(self) -> bool:
-        return bool(self.precise_search and ops.get_compute() in ("bf16", "bf16_f32act") and "precise_search" not in getattr(self, "_dev_off", ()))
+        return bool(self.precise_search and ops.get_compute() in ("bf16", "bf16_f32act") and switches.enabled("precise_search"))
 
     def _aux_names(self, primary: str):
         return [t for t in self.AUX_ORDER[primary] if t in self.graphone.task_labels]
@@ -1829,7 +1665,7 @@ class EgoPackStep(StepBase):
         """ONE backbone pass per step (ops.dual_record / dual_replay) applies: a single task batch with bf16 features, gradients
         through the backbone, no active dropout in it (the keep masks of the two passes would have to be shared), statistics
         local to the rank.  EGK_DISABLE=one_pass: the two-pass step of rounds 3-5."""
-        if not (self.one_pass and self.backprop) or "one_pass" in os.environ.get("EGK_DISABLE", "") or "one_pass" in getattr(self, "_dev_off", ()):
+        if not (self.one_pass and self.backprop) or not switches.enabled("one_pass") or not switches.enabled("one_pass"):
             return False
         live = [batches[t] for t in self.enabled if batches.get(t) is not None]
         if len(live) != 1 or isinstance(live[0].x, (list, tuple)) or live[0].x.dtype != torch.bfloat16 or ops.graph_ln_exchange_on():
@@ -1847,7 +1683,7 @@ class EgoPackStep(StepBase):
         the precise features only, so they start when that pass ends -- not behind the join with the training pass's forward chain,
         which (created second) ends later: profiles/r05_c4_replay_timeline.txt vs r05b: the searches 907 -> 7xx us."""
         self.graphone.drop_searched()
-        if "search_ahead" in os.environ.get("EGK_DISABLE", ""):
+        if not switches.enabled("search_ahead"):
             return
         for d in precise.values():
             self.graphone.search_ahead(d)
@@ -1862,14 +1698,14 @@ class EgoPackStep(StepBase):
                 # f32 out of the projections' last contraction: the nearest-prototype search (an index op) ranks the f32
                 # accumulators in every compute mode; GraphONE brings them to the activation type for its stages
                 grouped = None
-                if "grouped_aux" not in getattr(self, "_dev_off", ()):
+                if switches.enabled("grouped_aux"):
                     grouped = ops.grouped_projection_infer(ops.to_act(feat), [self.tasks[t].net for t in others], out_f32=True)
                 aux_in = (dict(zip(others, grouped)) if grouped is not None
                           else {t: self.tasks[t].forward_features(feat, out_f32=True) for t in others})
         aux, closest = self.graphone.interact(aux_in)
         ops.stamp("stages_done")
         if (primary == "oscc" and getattr(task, "loss_func", None) == "ce" and hasattr(task, "fused_head_loss") and data.y.dim() == 1
-                and "oscc_one_pass" not in getattr(self, "_dev_off", ()) and "rowdot_head" not in getattr(self, "_dev_off", ())):
+                and switches.enabled("oscc_one_pass") and switches.enabled("rowdot_head")):
             # the four 2-logit classifiers (primary + one per auxiliary task) behind their max pools, the logit fusion, the loss and
             # every gradient as ONE launch: the objective is sum_t w_t mean(loss_t), so the loss vector's backward seed is the
             # constant w / B (ops.loss_seed) -- ~35 short launches of the contraction path otherwise
@@ -1894,13 +1730,10 @@ class EgoPackStep(StepBase):
         tape, gate_ev = None, {}
         first = next((b for b in batches.values() if b is not None), None)
         on_side = (self._precise_on() and self.precise_stream and first is not None and first.pos.is_cuda
-                   and "precise_stream" not in getattr(self, "_dev_off", ()))
-        # Which chain is CREATED first keeps the launch queue under capture.  Rounds 3-4 created the training pass's
-        # forward chain first (``late``: 3.73 -> 3.69 ms then, a tie in round 4); with the split launch over the weights gone from
-        # the head of the precise pass and the primary projection beside it, the precise pass IS the step's critical chain and goes
-        # first: 2.529-2.549 against 2.565-2.586 ms (four alternating rounds).  EGK_ENABLE=precise_late_fork: the old order.
-        late = on_side and "precise_late_fork" in os.environ.get("EGK_ENABLE", "")
-        if self._precise_on() and not late:
+                   and switches.enabled("precise_stream"))
+        # Which chain is CREATED first keeps the launch queue under capture: the precise pass IS the step's critical chain and goes
+        # first (2.529-2.549 against 2.565-2.586 ms with the training pass's forward chain created first, four alternating rounds).
+        if self._precise_on():
             if on_side:
                 # the precise pass is a chain of ~50 launches over the same few thousand rows as the training pass's forward:
                 # forked onto its own stream, the two chains run side by side (each alone leaves most of the chip idle)
@@ -1927,16 +1760,12 @@ class EgoPackStep(StepBase):
             else:
                 precise = self.precise_aux_features(batches, merged, rng_snap=snap)
         import contextlib
-        fork_ev = None
-        if late:  # (the fork point: before the training pass's first launch)
-            main = torch.cuda.current_stream()
-            fork_ev = main.record_event()
         # (the two passes draw the same dropout offsets: same keep masks when the backbone is in train mode)
-        if side is not None and "serial_precise" in os.environ.get("EGK_DBG", ""):  # (measurement: the two passes one after the other)
+        if side is not None and switches.debug("serial_precise"):  # (measurement: the two passes one after the other)
             torch.cuda.current_stream().wait_stream(side)
-        if side is not None and not late and gate_ev.get("ev") is not None:
+        if side is not None and gate_ev.get("ev") is not None:
             torch.cuda.current_stream().wait_event(gate_ev["ev"])
-        tape = tape if (side is not None and not late) else None
+        tape = tape if side is not None else None
         if tape:
             # ONE backbone pass: the training graph is built from the precise pass's taped results (ops.dual_replay) -- its nodes
             # launch roundings, no contractions -- behind the precise backbone, beside its auxiliary projections and the searches
@@ -1950,22 +1779,10 @@ class EgoPackStep(StepBase):
         else:
             with (ops.rng_replay(snap) if self._precise_on() else contextlib.nullcontext()), torch.set_grad_enabled(self.backprop):
                 feats = self.features(batches, merged)
-        if late:
-            # the precise pass is CREATED after the training pass's forward chain although it forks from before it: under
-            # capture the branch created first keeps the launch queue, and created first the precise pass (700 us of launches)
-            # kept it -- the training pass's first contraction started when the precise backbone pass had finished
-            if getattr(self, "_precise_side", None) is None:
-                self._precise_side = torch.cuda.Stream()
-                ops.exclude_wgrad_streams([self._precise_side])
-            side = self._precise_side
-            side.wait_event(fork_ev)
-            with torch.cuda.stream(side):
-                precise = self.precise_aux_features(batches, merged, rng_snap=snap)
-                self._search_ahead(precise)
         # the primary projection heads need nothing of the precise pass: issued BEFORE the join with its stream, so that they run
         # beside its tail instead of behind it (profiles/r04_c4_replay_timeline.txt: 896-990 us, 95 us in which nothing else ran)
         f_prim = {}
-        if side is not None and len(feats) == 1 and "primary_early" not in getattr(self, "_dev_off", ()):
+        if side is not None and len(feats) == 1 and switches.enabled("primary_early"):
             f_prim = {t: self.tasks[t].forward_features(f) for t, f in feats.items()}
         ops.stamp("train_fwd_done")
         if side is not None:

@@ -18,7 +18,7 @@ import logging
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, switches
 from ..data import build_csr
 from .layers import Dropout, GraphLayerNorm, Linear, PositionalEncoding, SAGEConv
 
@@ -93,7 +93,7 @@ class Graph(torch.nn.Module):
                 pass
         pr = getattr(data, "pos_range", None)  # (min, max) of the positions, known on the host for collated batches
         import os
-        if "pe_table" in os.environ.get("EGK_DISABLE", ""):
+        if not switches.enabled("pe_table"):
             pr = None
         h = self.positional_encoding.add_to(x, data.pos, tuple(pr) if pr is not None else None)
         # the graph LayerNorm's per-segment sums ride on the epilogue of the contraction that produces its input (forward:

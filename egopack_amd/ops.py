@@ -25,7 +25,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, switches
 
 F32, BF16 = 0, 1  # EGK_COMPUTE_* and EGK_F32 / EGK_BF16 element types
 X3 = 2            # host-side pseudo compute type: f32 values contracted as three bf16 products per K source (``_x3_expand``)
@@ -157,7 +157,7 @@ def _stream():
 # other pays a cross-queue hand-off.  A backward pass naturally issues the forked weight gradient first, so the dX CHAIN
 # was the child that hopped, at every fork (tools/exp/fork_order.py: 12 links with a forked weight-gradient launch each,
 # 601 us per replay side-launch-first, 500 us chain-first).
-_deferred = {"items": [], "busy": False, "on": "fork_order" not in os.environ.get("EGK_DISABLE", "")}
+_deferred = {"items": [], "busy": False, "on": switches.enabled("fork_order")}
 
 
 def set_deferred_forks(on: bool) -> bool:
@@ -165,7 +165,7 @@ def set_deferred_forks(on: bool) -> bool:
     queued is dropped: a step ends with ``join_wgrad`` (which drains the queue), so something is left only when the step
     was abandoned by an exception -- its launches must not surface in the next step."""
     prev = _deferred["on"]
-    _deferred["on"] = bool(on) and "fork_order" not in os.environ.get("EGK_DISABLE", "")
+    _deferred["on"] = bool(on) and switches.enabled("fork_order")
     _deferred["items"] = []
     return prev
 
@@ -368,7 +368,7 @@ def to_act(x: torch.Tensor, lazy: bool = False) -> torch.Tensor:
     if x.requires_grad:
         return _Cast.apply(x, want)
     if (lazy and _state["compute"] == X3 and want == torch.float32 and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_cuda
-            and x.is_contiguous() and not torch.is_grad_enabled() and "x3_lazy_input" not in os.environ.get("EGK_DISABLE", "")):
+            and x.is_contiguous() and not torch.is_grad_enabled() and switches.enabled("x3_lazy_input")):
         y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         y._egk_bf16_src, y._egk_virtual = x, True
         return y
@@ -407,7 +407,7 @@ def weight_operand(W: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # ---- raw GEMM ------------------------------------------------------------------------------------
 def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=None, ldb2=0, K2=0, transA=False,
                transB=False, bias=None, residual=None, ldr=0, act=0, accumulate=False, alpha=1.0, compute=None,
-               dbias=None, into=None, stats=None, gather=None, op_f16=False, adam_ok=True):
+               dbias=None, into=None, stats=None, op_f16=False, slot_final=True):
     """Fill an ``egk_gemm_desc`` (a fresh one, or ``into``: an element of a descriptor array).  ``stats``: per-segment sums of
     the result for the graph LayerNorm that consumes it, taken in the epilogue (``_ln_stats_request``)."""
     op_dt = _dt(A1)
@@ -451,17 +451,14 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
     d.splitk = 1
     d.dbias = _p(dbias)
     d.ws, d.ws_bytes = None, 0
-    # Adam inside the weight-gradient launch (egk_gemm_desc.adam_epi): a dW-form launch that accumulates into a parameter's slot of
-    # the flat gradient buffer steps that parameter in its epilogue when the step installed a provider (engine.StepBase.capture)
-    d.adam_epi = None
-    prov = _adam_epi["provider"]
-    if (prov is not None and adam_ok and transA and transB and accumulate and compute == BF16 and bias is None and residual is None and act == 0
-            and alpha == 1.0 and stats is None and gather is None and out.dtype == torch.float32):
-        r = prov(out, M, N, ldc)
-        if r == "store":  # this launch is the ONLY writer of the slot in this step: it stores (the slot is not cleared, FlatAdam.store_begin)
+    # A dW-form launch that accumulates into a parameter's slot of the flat gradient buffer STORES instead when the step installed a
+    # provider that says this launch is the slot's only writer in this step (engine.StepBase._grad_store_begin, optim.FlatAdam.store_begin);
+    # ``slot_final`` False: several launches add up this gradient -- the provider is not asked
+    prov = _slot_provider["provider"]
+    if (prov is not None and slot_final and transA and transB and accumulate and compute == BF16 and bias is None and residual is None and act == 0
+            and alpha == 1.0 and stats is None and out.dtype == torch.float32):
+        if prov(out, M, N, ldc) == "store":
             d.accumulate = 0
-        else:
-            d.adam_epi = r
     d.st_mode = 0
     if stats is not None:
         d.st_mode, d.st_nseg, d.st_min_seg_rows = stats["mode"], stats["n_seg"], stats["min_rows"]
@@ -470,12 +467,6 @@ def _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, A2=None, lda2=0, B2=No
             x = stats["x"]
             d.st_x, d.st_ldx, d.st_stats = _p(x), x.stride(0), _p(stats["stats"])
             d.st_w, d.st_b, d.st_slope = _p(stats["w"]), _p(stats["b"]), stats["slope"]
-    d.ga_mode = 0
-    if gather is not None:  # the neighbour aggregation of the result inside the epilogue (egk_gemm_desc.ga_*)
-        go = gather["out"]
-        d.ga_mode, d.ga_tile_mask, d.ga_skip_c = gather["mode"], gather["tile_mask"], int(gather.get("skip_c", False))
-        d.ga_rowptr, d.ga_col, d.ga_wgt = _p(gather["rowptr"]), _p(gather["col"]), _p(gather.get("wgt"))
-        d.ga_band, d.ga_gate, d.ga_out, d.ga_ld = _p(gather.get("band")), _p(gather.get("gate")), _p(go), go.stride(0)
     return d
 
 
@@ -614,7 +605,7 @@ def _tee_arm(y: torch.Tensor):
     then needs no egk_split_bf16 launch of its own (12 such launches sat on the precise pass's chain in BASELINE config 4).
     -> the halves, for ``_tee_done`` right after the launch, or None (not in a scope, not an f32 matrix, switched off)."""
     if (_x3["cache"] is None or _state["compute"] != X3 or y.dtype != torch.float32 or y.dim() != 2 or not y.is_contiguous()
-            or y.numel() == 0 or "x3_tee" in os.environ.get("EGK_DISABLE", "")):
+            or y.numel() == 0 or not switches.enabled("x3_tee")):
         return None
     rows, cols = y.shape
     hi = torch.empty((rows, cols), dtype=torch.bfloat16, device=y.device)
@@ -650,7 +641,7 @@ def _gemm_with_stats(args, kw, stats):
     lib = _lib.load()
     d = _gemm_desc(*args, stats=stats, **kw)
     blocks = lib.egk_gemm_stats_blocks(C.byref(d))
-    if blocks > 0 and d.n_extra and "x3_stats_split" not in os.environ.get("EGK_DISABLE", ""):
+    if blocks > 0 and d.n_extra and switches.enabled("x3_stats_split"):
         # a three-product contraction (six K sources for a SAGE layer's two-source launch: K = 6144 at H = 1024) of a batch
         # that fills half the chip: the statistics epilogue needs the finished tile, i.e. NO split-K -- 87 us for 2048 x 1024
         # on one workgroup per CU.  When the policy would cut the walk, the cut launch + its reduce + the LayerNorm's own
@@ -671,71 +662,15 @@ def _gemm_with_stats(args, kw, stats):
     return ws, blocks
 
 
-# OPT-IN (EGK_ENABLE=gather_fusion).  Measured in round 4 on the headline step, same box, alternating: 1.474-1.477 ms with the
-# separate gather launches, 1.486-1.500 with the gathers in the epilogues -- the projection + gather pair took 33-35 us fused
-# against 25 + 12 separate, but the gated transposed gather 43-48 against 19 + 16: the epilogue's gather phase keeps a
-# workgroup's LDS and registers while its matrix pipes idle, and in backward the separate launch runs BESIDE weight-gradient
-# contractions that fill those pipes.  Kept behind the switch (and tested) as the measured alternative.
-_gather_fusion = {"on": "gather_fusion" in os.environ.get("EGK_ENABLE", "")}
+_slot_provider = {"provider": None}
 
 
-def gemm_with_gather(args, kw, gather, stats=None) -> bool:
-    """``gemm(*args, **kw)`` with the row gather ``gather`` of its result taken in the epilogue (egk_gemm_desc.ga_*) when the
-    tile variant of this launch can: True if it did (the gather's output is written; with ``skip_c`` the result itself is
-    not), False if nothing was launched (the caller runs the contraction and the gather launch).  No split-K."""
-    if not _gather_fusion["on"] or not gather.get("tile_mask"):
-        return False
-    lib = _lib.load()
-    d = _gemm_desc(*args, gather=gather, stats=stats, **kw)
-    if lib.egk_gemm_splitk(d.M, d.N, _desc_k(d), d.compute) > 1:
-        return False  # (a launch the policy would cut along K: its tiles are finished by the reduce launch)
-    if not lib.egk_gemm_gather_ok(C.byref(d)):
-        return False
-    if stats is not None:
-        blocks = lib.egk_gemm_stats_blocks(C.byref(d))
-        if blocks <= 0:
-            return False
-        ws = torch.empty(blocks * stats["n_seg"] * 2, dtype=torch.float64, device=args[7].device)
-        d.st_ws = _p(ws)
-        stats["result"] = (ws, blocks)
-    _ck(lib.egk_gemm(_stream(), C.byref(d)), "egk_gemm")
-    _x3_release()
-    return True
-
-
-_SK_TICKETS = 1 << 16
-_sk_cache = {}
-# OPT-IN (EGK_ENABLE=splitk_in_launch): bit-identical to the reduce launch and measured SLOWER -- the workgroup that arrives last
-# sums its tile's slabs alone while the reduce launch spreads that over the chip (BASELINE config 4: 4.50 ms against 3.62; 3.89
-# even with the device-scope fences compiled out), DESIGN 10.9
-_sk_in_launch = {"on": "splitk_in_launch" in os.environ.get("EGK_ENABLE", "")}
-
-
-def _sk_tickets(M: int, N: int, device):
-    """The arrival counters of a split contraction that is finished inside its launch (egk_gemm_desc.sk_tickets): one zeroed
-    int32 buffer per (device, stream) -- launches on one stream run one after the other and each hands its counters back at
-    zero.  None when the buffer would have to be created inside a capture (the reduce launch is used)."""
-    if not _sk_in_launch["on"] or ((M + 63) // 64) * ((N + 127) // 128) > _SK_TICKETS:
-        return None
-    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
-    buf = _sk_cache.get(key)
-    if buf is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        buf = torch.zeros(_SK_TICKETS, dtype=torch.int32, device=device)
-        _sk_cache[key] = buf
-    return buf
-
-
-_adam_epi = {"provider": None, "unclaim": None}
-
-
-def set_adam_epilogue(provider, unclaim=None):
-    """``provider(out, M, N, ldc) -> device address of an egk_adam_epi or None`` for dW-form launches whose result ``out`` is a
-    parameter's gradient slot (optim.FlatAdam.epilogue_provider); ``unclaim(out)``: the launch splits K after all, the claim is
-    void.  None switches the feature off.  Returns the previous pair."""
-    prev = (_adam_epi["provider"], _adam_epi["unclaim"])
-    _adam_epi["provider"], _adam_epi["unclaim"] = provider, unclaim
+def set_grad_slot_provider(provider):
+    """``provider(out, M, N, ldc) -> "store" | None`` for dW-form launches whose result ``out`` is a parameter's gradient slot
+    (optim.FlatAdam.learn_begin: counts the launches per slot during an eager step; .store_begin: answers "store" for the slots
+    learnt as written once per step).  None switches it off.  Returns the previous provider."""
+    prev = _slot_provider["provider"]
+    _slot_provider["provider"] = provider
     return prev
 
 
@@ -746,21 +681,15 @@ def gemm(M, N, A1, lda1, B1, ldb1, K1, out, ldc, *, allow_splitk=True, splitk=No
     d = _gemm_desc(M, N, A1, lda1, B1, ldb1, K1, out, ldc, **kw)
     sk = lib.egk_gemm_splitk(M, N, _desc_k(d), d.compute) if allow_splitk else 1
     d.splitk = sk if splitk is None else int(splitk)
-    if d.adam_epi and d.splitk > 1:  # (a lone launch that splits K: its gradient is final only after the reduce -- the optimizer's own pass)
-        d.adam_epi = None
-        if _adam_epi["unclaim"] is not None:
-            _adam_epi["unclaim"](out)
     need = lib.egk_gemm_ws_bytes(C.byref(d))
     deferred = None
     if need:
-        if (defer_reduce and d.splitk == 2 and not _sk_in_launch["on"] and d.compute == BF16 and d.c_dtype == F32 and ldc == N
+        if (defer_reduce and d.splitk == 2 and d.compute == BF16 and d.c_dtype == F32 and ldc == N
                 and need == 8 * M * N):
             ws = deferred = torch.empty(need, dtype=torch.uint8, device=out.device)
         else:
             ws = workspace(need, out.device)
         d.ws, d.ws_bytes = _p(ws), ws.numel()
-    if d.splitk > 1 and deferred is None:
-        d.sk_tickets = _p(_sk_tickets(M, N, out.device))
     if deferred is not None:
         lib.egk_gemm_defer_reduce_next(1)
     try:
@@ -969,7 +898,7 @@ def _wgrad_groupable(M, N, A, lda, B, ldb, K, compute=None) -> bool:
         return False
     if A.dtype == torch.bfloat16:
         ok = K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0
-    elif A.dtype == torch.float32 and compute == F32 and "f32_wgrad_groups" not in os.environ.get("EGK_DISABLE", ""):
+    elif A.dtype == torch.float32 and compute == F32 and switches.enabled("f32_wgrad_groups"):
         ok = K % 32 == 0 and lda % 4 == 0 and ldb % 4 == 0  # exact-f32 problems: the grouped f32 kernel (egk_gemm_grouped)
     else:
         return False
@@ -1101,7 +1030,7 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
             pieces = _k_pieces(chunk) if len(chunk) > 1 else None
             if pieces is not None:
                 for piece in pieces:
-                    gemm_grouped(piece, four_wave=len(piece) <= 4 and "wg4" not in os.environ.get("EGK_DISABLE", ""))
+                    gemm_grouped(piece, four_wave=len(piece) <= 4 and switches.enabled("wg4"))
             elif len(chunk) == 1:
                 gemm(*chunk[0][0], **chunk[0][1])
             else:
@@ -1110,7 +1039,7 @@ def flush_wgrad(in_backward: bool = True, force: bool = False):
                 # 2 x 208 VGPRs of every SIMD of its CU and the chain's row kernels (96-193 VGPRs) wait for it to leave --
                 # a 13 us row-LayerNorm backward took 82 us behind such a launch; 4 waves leave 304.  Step 1.511 -> 1.498 ms
                 # (six alternating runs of 300 steps, every pair)
-                gemm_grouped(chunk, four_wave=len(chunk) <= 4 and "wg4" not in os.environ.get("EGK_DISABLE", ""))
+                gemm_grouped(chunk, four_wave=len(chunk) <= 4 and switches.enabled("wg4"))
         if extra:
             _launch_reductions(extra)
         stamp("wgrad_flush_end", seq=True)
@@ -1253,7 +1182,7 @@ def _match(g: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 # roundings of the precise activations, the forward VALUES are the precise ones.  Nodes: _Linear, _RowLN, _PEAdd, _SageMean, _GraphLN
 # (what models.Graph.forward with a TRN pooling issues); the sequences of the two passes must agree node by node (checked).
 _dual = {"tape": None, "replay": None}
-_slab_defer = {"on": "slab_defer" not in os.environ.get("EGK_DISABLE", "")}  # the precise pass's split contractions without reduce launches
+_slab_defer = {"on": switches.enabled("slab_defer")}  # the precise pass's split contractions without reduce launches
 
 
 class dual_record:
@@ -1569,7 +1498,7 @@ def classifier_bank(x, anchor, views, compute=None):
     return outs
 
 
-_banks_ride = {"on": "banks_ride" not in os.environ.get("EGK_DISABLE", "")}  # development knob
+_banks_ride = {"on": switches.enabled("banks_ride")}  # development knob
 
 
 class _GroupedBanks(torch.autograd.Function):
@@ -1718,7 +1647,7 @@ class _MultiLinear(torch.autograd.Function):
                 off = 0
                 for x, m in zip(xs, ctx.rows):
                     gemm(N, K, dy[off:off + m], N, x, K, m, out, K, transA=True, transB=True, accumulate=True,
-                         compute=ctx.compute, adam_ok=len(xs) == 1)  # (several launches add up one gradient: not final in any of them)
+                         compute=ctx.compute, slot_final=len(xs) == 1)  # (several launches add up one gradient: not final in any of them)
                     off += m
             _wgrad_launch(slot is not None, (dy, *xs), launch_dw)
             dW = None if slot is not None else out
@@ -1800,7 +1729,7 @@ class _GroupedProjection(torch.autograd.Function):
         da = torch.empty_like(a)
         gemm_grouped([((rows[g], H1, dfs[g], dfs[g].stride(0), W2o[g], H1, H2, da[ptr[g]:ptr[g + 1]], H1),
                        dict(transB=True, compute=cmp)) for g in range(G)])
-        proj_park = "proj_park" not in os.environ.get("EGK_DISABLE", "")
+        proj_park = switches.enabled("proj_park")
         dw2 = [((H2, H1, dfs[g], dfs[g].stride(0), a[ptr[g]:ptr[g + 1]], H1, rows[g], slots[g][4], H1),
                 dict(transA=True, transB=True, accumulate=True, compute=cmp, dbias=slots[g][5])) for g in range(G)]
         proj_park = proj_park and all(_wgrad_groupable(*pa[:7]) for pa, _ in dw2)  # (the parking queue must be on and take them)
@@ -1870,7 +1799,7 @@ def grouped_projection_infer(x, nets, out_f32: bool = False):
     x3 = x.dtype == torch.float32 and _state["compute"] == X3 and _x3["cache"] is not None and out_f32
     if not (2 <= G <= 8) or x.dim() != 2 or not x.is_cuda or not (x.dtype == torch.bfloat16 or x3) or x.shape[0] == 0:
         return None
-    if x3 and "x3_grouped_aux" in os.environ.get("EGK_DISABLE", ""):
+    if x3 and not switches.enabled("x3_grouped_aux"):
         return None
     dims = None
     for net in nets:
@@ -1899,7 +1828,7 @@ def grouped_projection_infer(x, nets, out_f32: bool = False):
         lw, lb = [_f32c(net[2].weight) for net in nets], [_f32c(net[2].bias) for net in nets]
         row_ptr = (C.c_int32 * (G + 1))(*[g * M for g in range(G + 1)])
         # the LayerNorm launch also stores the halves of its result (egk_tee_split_next; EGK_DISABLE=group_ln_tee: a split launch)
-        halves = _tee_arm(a) if "group_ln_tee" not in os.environ.get("EGK_DISABLE", "") else None
+        halves = _tee_arm(a) if switches.enabled("group_ln_tee") else None
         _ck(lib.egk_rowln_group_fwd(_stream(), _p(h1), _ptr_array(lw), _ptr_array(lb), row_ptr, G, _p(a), _p(mean), _p(rstd), H1,
                                     float(nets[0][2].eps), 1, _dt(h1)), "egk_rowln_group_fwd")
         hi, lo = halves if halves is not None else _split_rows(a, G * M, H1, H1)  # the groups' row blocks are registered as split
@@ -2105,7 +2034,7 @@ def graphone_stages_ok(G: int, N: int, H: int, banks, stage_lists, freeze: bool)
     """Whether ``graphone_stages`` can serve an interaction of G tasks with N feature rows of width H each: 2 .. 4 tasks, bf16
     activations, N a multiple of 64 (the K axis of the weight gradients), widths in multiples of 64, frozen banks, and every
     stage parameter living in the optimizer's flat buffers (in-place gradient slots)."""
-    if not (2 <= G <= 4) or not freeze or _state["act"] != torch.bfloat16 or "graphone_grouped" in os.environ.get("EGK_DISABLE", ""):
+    if not (2 <= G <= 4) or not freeze or _state["act"] != torch.bfloat16 or not switches.enabled("graphone_grouped"):
         return False
     if N <= 0 or N % 64 or H % 64 or any(b.requires_grad or b.dim() != 2 or b.shape[1] != H or not b.is_cuda for b in banks):
         return False
@@ -2547,7 +2476,7 @@ def _csr_gather(x, rowptr, col, wgt, gate, out, heavy=None, heavy_mode=0, band=N
     _tee_done(out, tee)
 
 
-_banded = {"on": "banded_gather" not in os.environ.get("EGK_DISABLE", "")}  # development knob
+_banded = {"on": switches.enabled("banded_gather")}  # development knob
 
 
 class _CSRMean(torch.autograd.Function):
@@ -2585,7 +2514,7 @@ class _SageMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, Wp, bp, Wl, bl, Wr, rowptr, col, t_rowptr, t_col, t_wgt, compute, heavy=None, t_heavy=None,
-                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None, res_src=None, band=None, tile_mask=0):
+                heavy_mode=0, t_heavy_mode=0, ln_out=None, ln_in=None, res_src=None, band=None):
         _need_gpu(h, Wp, Wl, Wr)
         lib = _lib.load()
         h = _c(h)
@@ -2594,8 +2523,6 @@ class _SageMean(torch.autograd.Function):
         Wp_o, Wl_o, Wr_o = weight_operand(Wp, dt), weight_operand(Wl, dt), weight_operand(Wr, dt)
         xp = torch.empty_like(h)
         agg = torch.empty_like(h)
-        # the mean over the in-neighbours of xp inside the projection's epilogue when no edge leaves an output tile (32-node
-        # sequences never do): the gather launch and its re-read of xp disappear
         p_args, p_kw = (N, H, h, H, Wp_o, H, H, xp, H), dict(bias=_f32c(bp), act=1, compute=compute)
         taped = _tape_take("sage_mean", h)
         Ho = Wl.shape[0]
@@ -2605,13 +2532,11 @@ class _SageMean(torch.autograd.Function):
                 raise RuntimeError("dual_replay: a taped SAGE layer result has another shape")
             if ln_out is not None:
                 ln_out["partials"] = None  # (the graph LayerNorm that follows takes the taped statistics)
-            ctx.t_heavy_mode, ctx.tile_mask = t_heavy_mode, tile_mask
+            ctx.t_heavy_mode = t_heavy_mode
         else:
-            if not (tile_mask and gemm_with_gather(p_args, p_kw, dict(mode=1, tile_mask=tile_mask, rowptr=rowptr, col=col, band=band,
-                                                                        out=agg))):
-                gemm(*p_args, **p_kw)
-                _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode, band)
-            ctx.t_heavy_mode, ctx.tile_mask = t_heavy_mode, tile_mask
+            gemm(*p_args, **p_kw)
+            _csr_gather(xp, rowptr, col, None, None, agg, heavy, heavy_mode, band)
+            ctx.t_heavy_mode = t_heavy_mode
             out = torch.empty((N, Ho), dtype=dt, device=h.device)
             c_args = (N, Ho, agg, H, Wl_o, H, H, out, Ho)
             c_kw = dict(A2=h, lda2=H, B2=Wr_o, ldb2=H, K2=H, bias=_f32c(bl), compute=compute)
@@ -2672,12 +2597,8 @@ class _SageMean(torch.autograd.Function):
         d_agg = torch.empty_like(h)
         d_pre = torch.empty_like(h)  # gradient at the projection's pre-activation: transposed gather gated by xp > 0
         a_args, a_kw = (N, H, g, g.stride(0), Wl_o, H, Ho, d_agg, H), dict(transB=True, compute=ctx.compute)
-        # ... inside the epilogue of the contraction that produces d_agg when no edge leaves an output tile (d_agg itself is
-        # then never stored: nothing else reads it)
-        if not (ctx.tile_mask and gemm_with_gather(a_args, a_kw, dict(mode=2, tile_mask=ctx.tile_mask, rowptr=t_rowptr, col=t_col,
-                                                                        wgt=t_wgt, gate=xp, out=d_pre, skip_c=True))):
-            gemm(*a_args, **a_kw)
-            _csr_gather(d_agg, t_rowptr, t_col, t_wgt, xp, d_pre, t_heavy, ctx.t_heavy_mode)
+        gemm(*a_args, **a_kw)
+        _csr_gather(d_agg, t_rowptr, t_col, t_wgt, xp, d_pre, t_heavy, ctx.t_heavy_mode)
         d_h = None
         if ctx.needs_input_grad[0]:
             d_h = torch.empty_like(h)
@@ -2700,7 +2621,7 @@ class _SageMean(torch.autograd.Function):
             # the FIRST layer of the stack (its backward is the stack's last): what is parked goes out now, beside the temporal
             # pooling's backward chain -- the step's tail launch then holds the temporal pooling's weight gradients only
             flush_wgrad()
-        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
+        return (d_h, rWp, rbp, rWl, rbl, rWr, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_src=None):
@@ -2714,7 +2635,7 @@ def sage_mean_layer(h, conv, graph, compute=None, ln_out=None, ln_in=None, res_s
                            graph.rowptr, graph.col, graph.t_rowptr, graph.t_col, graph.t_wgt,
                            _compute_for(h) if compute is None else compute, getattr(graph, "heavy", None),
                            getattr(graph, "t_heavy", None), getattr(graph, "heavy_mode", 0), getattr(graph, "t_heavy_mode", 0),
-                           ln_out, ln_in, res_src, getattr(graph, "band", None), int(getattr(graph, "tile_mask", 0) or 0))
+                           ln_out, ln_in, res_src, getattr(graph, "band", None))
 
 
 # ---- labelled rows only (the heads' row compaction) --------------------------------------------------------------------------
@@ -2878,7 +2799,7 @@ def segment_max_multi(xs, ptr):
     xs = list(xs)
     x0 = xs[0]
     if (2 <= len(xs) <= 4 and x0.is_cuda and all(x.shape == x0.shape and x.dtype == x0.dtype and x.dim() == 2 for x in xs)
-            and "segmax_multi" not in os.environ.get("EGK_DISABLE", "")):
+            and switches.enabled("segmax_multi")):
         return list(_SegMaxMulti.apply(ptr, *xs))
     return [segment_max(x, ptr) for x in xs]
 
@@ -3237,7 +3158,7 @@ class _RowDotCE2Multi(torch.autograd.Function):
                                          _dt(fs[0])), "egk_rowdot_ce2_multi")
         in_slots = all((dw is None or sw is not None) for dw, sw in zip(dws, slots_w)) and all(
             (db is None or sb is not None) for db, sb in zip(dbs, slots_b))
-        if in_slots and any(d is not None for d in (*dws, *dbs)) and "ce2_cols_ride" not in os.environ.get("EGK_DISABLE", ""):
+        if in_slots and any(d is not None for d in (*dws, *dbs)) and switches.enabled("ce2_cols_ride"):
             # the classifiers' gradients feed nothing on the chain and land in the optimizer's slots: their launch (27 us on the
             # critical chain of BASELINE config 4 between the head and backward) rides with the next flush of the parked weight
             # gradients (``park_rider``: at once when nothing can be parked)
@@ -3570,8 +3491,8 @@ def row_sq_norm(x):
 
 # The one-product search (egk_topk_window): per bank the bf16 operand hi(P) and the largest rounding residual ratio of its rows,
 # kept while (address, shape, version) stand -- the banks are frozen (graphONE.py:48) unless GraphONE is built with freeze=False.
-_window_search = {"on": "window_search" not in os.environ.get("EGK_DISABLE", "")}
-_window_f16 = {"on": "window_f16" not in os.environ.get("EGK_DISABLE", "")}  # the grouped search's screen on the f16 matrix instructions
+_window_search = {"on": switches.enabled("window_search")}
+_window_f16 = {"on": switches.enabled("window_f16")}  # the grouped search's screen on the f16 matrix instructions
 _window_bank_cache = {}
 _window_stats = {"cand": None}  # development / tests: an int32 [N] tensor here receives the candidates per row of the next search
 
@@ -3676,7 +3597,7 @@ def nearest_prototypes_grouped_ok(feats, banks, k, distance_func: str = "cosine"
     f0, b0 = feats[0], banks[0]
     if (f0.dtype != torch.float32 or not f0.is_cuda or any(f.shape != f0.shape for f in feats)
             or any(b.dtype != torch.float32 or b.shape != b0.shape or not b.is_contiguous() for b in banks)
-            or "grouped_search" in os.environ.get("EGK_DISABLE", "")):
+            or not switches.enabled("grouped_search")):
         return False
     base = rows_of_one_buffer(feats)
     return base is not None and _window_search_ok(f0.shape[0], b0.shape[0], f0.shape[1], k, base, b0)
@@ -3696,7 +3617,7 @@ def nearest_prototypes_grouped(feats, banks, k, bank_norms):
     # bf16's -- the prototype banks of a trained model put 30-90 prototypes inside the bf16 window of a row); values beyond the
     # half range make that row's window unbounded (slow, never wrong).  EGK_DISABLE=window_f16: the bf16 screen.
     f16 = _window_f16["on"]
-    if base.is_contiguous() and H % 4 == 0 and "search_prep" not in os.environ.get("EGK_DISABLE", ""):
+    if base.is_contiguous() and H % 4 == 0 and switches.enabled("search_prep"):
         # row norms, the bf16 rounding and the half rounding in ONE pass over the rows (egk_row_inv_norm_cast: the bits of the three)
         f_norm = torch.empty(G * N, dtype=torch.float32, device=base.device)
         hi = torch.empty((G * N, H), dtype=torch.bfloat16, device=base.device)
@@ -3714,7 +3635,7 @@ def nearest_prototypes_grouped(feats, banks, k, bank_norms):
     cand = _window_stats["cand"]
     if cand is not None and (cand.numel() != G * N or cand.device != base.device):
         cand = None
-    dbg = "window_cand" in os.environ.get("EGK_DBG", "") and not torch.cuda.is_current_stream_capturing()
+    dbg = switches.debug("window_cand") and not torch.cuda.is_current_stream_capturing()
     if dbg and cand is None:
         cand = torch.zeros(G * N, dtype=torch.int32, device=base.device)
     arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])

@@ -15,7 +15,7 @@ from typing import Iterable, List
 
 import torch
 
-from . import _lib
+from . import _lib, switches
 from .ops import _ck, _p, _stream
 
 
@@ -248,7 +248,7 @@ class FlatAdam(torch.optim.Optimizer):
     # shadow (+ 2 B per parameter on a 30 B pass), so the precise pass at the head of the NEXT step finds them fresh instead of
     # splitting the backbone's 17 M parameters in a launch of its own at the head of the step's critical chain (38 us in BASELINE
     # config 4, profiles/r04_c4_replay_timeline.txt at 118 us).  EGK_DISABLE=adam_lo: the round-4 behaviour.
-    adam_writes_lo = "adam_lo" not in __import__("os").environ.get("EGK_DISABLE", "")
+    adam_writes_lo = switches.enabled("adam_lo")
 
     def _lo_is_fresh(self, off: int, n: int) -> bool:
         # (fresh ranges may have been cut by partial updates: a slot is fresh when the union of the ranges covers it)
@@ -341,64 +341,12 @@ class FlatAdam(torch.optim.Optimizer):
         """A replayed graph that contains the constants launch has been enqueued: the device counter moves on with it."""
         self._t_mirror += 1
 
-    # -- Adam inside the weight-gradient launches (egk_gemm_desc.adam_epi) ------------------------------------------------------------
-    # A captured single-rank step may let the dW contraction of a weight matrix step that matrix in its epilogue: the gradient tile is
-    # in registers, the optimizer's pass over it (16 B read + 14 B written per element, HBM-bound, at the step's tail) shrinks to the
-    # parameters no contraction produces (biases, LayerNorm weights, padding).  ``epilogue_begin`` builds one egk_adam_epi per
-    # eligible matrix in device memory and returns (provider, unclaim) for ops.set_adam_epilogue; every claim is a range that
-    # ``launch`` then leaves out.  A slot claimed twice (a weight whose gradient is accumulated by two launches) is an error.
-    def epilogue_begin(self):
-        import struct
-        g = self.param_groups[0]
-        b1, b2 = g["betas"]
-        lo_ok = self.flat_w16lo is not None and self.adam_writes_lo
-        rows, self._epi_slots = [], {}
-        base = {k: getattr(self, k).data_ptr() for k in ("flat_p", "flat_m", "flat_v", "flat_w16")}
-        for p in self.active:
-            if p.dim() != 2 or p.shape[1] % 8 or p.numel() < 64 * 64 or getattr(p, "_egk_bank", None) is not None:
-                continue
-            off, _ = self._slot_of[id(p)]
-            rows.append(struct.pack("<6Q4f", base["flat_p"] + 4 * off, base["flat_m"] + 4 * off, base["flat_v"] + 4 * off,
-                                    base["flat_w16"] + 2 * off, (self.flat_w16lo.data_ptr() + 2 * off) if lo_ok else 0,
-                                    self._hyper.data_ptr(), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"])))
-            self._epi_slots[off] = (len(rows) - 1, tuple(p.shape))
-        if not rows:
-            return None, None
-        self._epi_table = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(self.flat_p.device)
-        self._epi_claims = {}
-        g0, tab = self.flat_g.data_ptr(), self._epi_table.data_ptr()
-
-        def provider(out, M, N, ldc):
-            d = out.data_ptr() - g0
-            if d < 0 or d % 4 or ldc != N:
-                return None
-            ent = self._epi_slots.get(d // 4)
-            if ent is None or ent[1] != (M, N):
-                return None
-            if d // 4 in self._epi_claims:
-                raise RuntimeError("adam_epilogue: a gradient slot is written by two launches of one step (a weight used twice): "
-                                   "do not set EGK_ENABLE=adam_epilogue for this model")
-            self._epi_claims[d // 4] = M * N
-            return tab + 64 * ent[0]
-
-        def unclaim(out):
-            self._epi_claims.pop((out.data_ptr() - g0) // 4, None)
-        return provider, unclaim
-
-    def epilogue_end(self, keep: bool):
-        """The capture is over: ``keep`` -- the claimed ranges are what the graph's epilogues step (``launch`` calls recorded INTO the
-        graph already left them out); the table stays alive with the graph."""
-        claims = getattr(self, "_epi_claims", None) or {}
-        self._epi_ranges = sorted(claims.items()) if keep else []
-        self._epi_claims = None
-        return self._epi_ranges
-
     # -- gradient slots with ONE writer per step: stored, not accumulated -----------------------------------------------------------
     # The flat gradient buffer is cleared every step (100-260 MB beside the forward pass) so that the weight-gradient launches can
     # ADD into it -- which also makes each of them read its zeros back.  A weight matrix whose gradient comes from exactly one
     # launch per step needs neither: that launch stores.  Which slots those are is LEARNT from an eager step (every dW-form launch
     # into a parameter's slot is counted; a slot counted once qualifies) and CHECKED in the capture: a stored slot written twice,
-    # or not at all, is an error -- never a silently wrong gradient.  Captured single-rank steps only (engine.StepBase.capture).
+    # or not at all, is an error -- never a silently wrong gradient.  Every capture: one rank, the staged graphs, the one-graph exchange.
     def _matrix_index(self):
         idx = getattr(self, "_mat_index", None)
         if idx is None:
@@ -407,7 +355,7 @@ class FlatAdam(torch.optim.Optimizer):
         return idx
 
     def learn_begin(self):
-        """Provider for ops.set_adam_epilogue during an EAGER step: counts the launches per matrix slot, changes nothing."""
+        """Provider for ops.set_grad_slot_provider during an EAGER step: counts the launches per matrix slot, changes nothing."""
         idx, g0, counts = self._matrix_index(), self.flat_g.data_ptr(), {}
         self._learn_counts = counts
 
@@ -470,24 +418,6 @@ class FlatAdam(torch.optim.Optimizer):
             _ck(_lib.load().egk_zero_fill_ranges(_stream(), _p(self.flat_g), bg, ln, len(part)), "egk_zero_fill_ranges")
         return True
 
-    def _without_epilogue(self, lo, hi):
-        """[lo, hi) minus the ranges claimed so far in this capture, as (begin, length) pairs."""
-        claims = getattr(self, "_epi_claims", None)
-        if not claims:
-            return None
-        out, at = [], lo
-        for b, n in sorted(claims.items()):
-            if b + n <= lo or b >= hi:
-                continue
-            if b < lo or b + n > hi:
-                raise RuntimeError("adam_epilogue: an optimizer slice cuts through a matrix stepped in its gradient launch")
-            if b > at:
-                out.append((at, b - at))
-            at = b + n
-        if hi > at:
-            out.append((at, hi - at))
-        return out
-
     def launch(self, grads=None, lo: int = 0, hi=None, bump=None):
         """The kernel launch alone (capturable).  ``grads``: the buffer to read gradients from (default the f32
         flat buffer; dist.GradSync hands in its bf16 copy after a compressed all-reduce).  ``[lo, hi)``: element range
@@ -506,21 +436,6 @@ class FlatAdam(torch.optim.Optimizer):
             self._lo_fresh = _minus_ranges(self._lo_fresh, lo, hi) + [(lo, hi)]
         elif self._lo_fresh:
             self._lo_fresh = []  # (the parameters move: every low half is stale)
-        rest = self._without_epilogue(lo, hi)
-        if rest is not None:
-            # what the weight-gradient launches did not step themselves (biases, LayerNorm parameters, padding): one launch per 48 ranges
-            import ctypes as C
-            rest = rest or [(lo, 0)]  # (nothing left: the launch still carries the bump)
-            for i in range(0, len(rest), 48):
-                part = rest[i:i + 48]
-                bg, ln = (C.c_int64 * len(part))(*[b for b, _ in part]), (C.c_int64 * len(part))(*[n for _, n in part])
-                _ck(_lib.load().egk_adam_step_ranges(_stream(), _p(self.flat_p), _p(grads), 1 if grads.dtype == torch.bfloat16 else 0,
-                                                     _p(self.flat_m), _p(self.flat_v), bg, ln, len(part), _p(self._hyper), b1, b2,
-                                                     g["eps"], g["weight_decay"], _p(self.flat_w16),
-                                                     _p(self.flat_w16lo) if lo16 is not None else None,
-                                                     _p(bump[0]) if (bump is not None and i == 0) else None,
-                                                     int(bump[1]) if (bump is not None and i == 0) else 0), "egk_adam_step_ranges")
-            return
         if bump is not None or lo16 is not None:
             _ck(_lib.load().egk_adam_step_bump(_stream(), _p(self.flat_p[sl]), _p(grads[sl]), 1 if grads.dtype == torch.bfloat16 else 0,
                                                _p(self.flat_m[sl]), _p(self.flat_v[sl]), hi - lo, _p(self._hyper), b1, b2,

@@ -9,8 +9,7 @@ A switch is a boolean with a default; the environment overrides it by EXACT name
 The code asks ``switches.enabled("name")``; a name that is not registered here is a programming error (KeyError), and a name
 in the environment that is not registered is reported once (``check_env``) instead of being silently ignored -- the former
 ``"name" in os.environ.get("EGK_DISABLE", "")`` tests matched SUBSTRINGS (``oscc_one_pass`` also switched ``one_pass`` off).
-Default-off entries are measured alternatives that are bit-identical to the default path and slower (or equal) in the step; they
-stay because a test pins their equality or a tool A/Bs them.  Numeric knobs with their own variable are listed in ``KNOBS``.
+Default-off entries are the N-rank modes that a caller (or bench.py's probe) opts into.  Numeric knobs with their own variable are listed in ``KNOBS``.
 ``python -m egopack_amd.switches`` prints the table.
 """
 from __future__ import annotations
@@ -77,11 +76,6 @@ REGISTRY = {
     "one_graph_exchange": (False, "N ranks: ONE hipGraph incl. the RCCL collectives (bench.py's probe decides; the attribute also sets it)"),
     "sharded_update": (False, "N ranks: reduce-scatter -> Adam on 1 / world of the buffers -> all-gather instead of all-reduce + full Adam"),
     "adam_behind_collective": (False, "N ranks: every chunk's Adam slice right behind its collective on the communication stream"),
-    # ---- measured alternatives: bit-identical, slower or equal in the step (default off) -----------------------------------------
-    "heads_adam": (False, "Adam over the heads' slice beside the backbone's backward (1.41-1.42 against 1.395-1.398 ms)"),
-    "tail_adam_first": (False, "the late optimizer slice in front of the side-stream join (2.340 against 2.339 ms)"),
-    "graphone_adam_on_main": (False, "GraphONE's optimizer slice on the backward stream's tail (equal)"),
-    "precise_late_fork": (False, "the precise pass is created after the training pass's forward chain (rounds 3-4 order)"),
 }
 
 DEBUG = {

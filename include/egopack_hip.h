@@ -48,23 +48,6 @@ int egk_prof_get(int id, char* name, int name_len, int64_t* launches, double* to
  * the stream reaches it -- phase boundaries of a captured step timed in place (tools/phase_stamps.py). */
 int egk_stamp(egk_stream_t s, uint64_t* buf, int32_t idx);
 
-/* ---- segmented replay of a captured step ---------------------------------------------------------------------------
- * The reference steps eagerly (main_temporal.py:78-104, main_egopack.py:72-99: one Python call per op); this library's step is
- * captured once and replayed.  The HIP runtime replays a captured graph that sits on ONE stream through a batch path (0.6 us of
- * host time per node) but enqueues the nodes of any graph with a fork one by one, chain after chain in creation order (2.8-4.2
- * us per node: a step of 330 short launches on four streams is bound by that for its first 1.4 ms).  A plan cuts the captured
- * graph (hipGraph_t; kernel, memset, memcpy and empty nodes) into its maximal fork-free paths, builds one single-stream graph
- * per path and replays them on up to max_streams streams with one event per edge that crosses streams: same nodes, same
- * arguments, same edges -- bit-identical results.  The plan holds copies of the nodes' parameters, not the graph: the memory the
- * nodes address (the capture's pool) must outlive it.  egk_graph_plan_launch enqueues on ``stream`` (+ the plan's own side
- * streams, which start behind ``stream`` and are joined into it) and returns; not thread-safe per plan. */
-typedef struct egk_graph_plan egk_graph_plan;
-int egk_graph_plan_create(void* hip_graph, int32_t max_streams, int32_t event_nodes, egk_graph_plan** out);
-int egk_graph_plan_info(const egk_graph_plan* plan, int32_t* nodes, int32_t* segments, int32_t* streams, int32_t* cross_edges);
-/* desc[0..3] = number of nodes, stream index (0 = the launch stream), number of event waits, 1 if an event is recorded behind it */
-int egk_graph_plan_segment(const egk_graph_plan* plan, int32_t segment, int32_t* desc);
-int egk_graph_plan_launch(egk_graph_plan* plan, egk_stream_t stream);
-void egk_graph_plan_destroy(egk_graph_plan* plan);
 
 /* One-shot "split tee" for the three-product contractions (egk_split_bf16's halves without its launch): the NEXT call, on this
  * host thread, of egk_rowln_fwd, egk_graphln_fwd, egk_graphln_fwd_apply, egk_pe_add, egk_pe_add_table, egk_csr_gather or
@@ -159,62 +142,16 @@ typedef struct egk_gemm_desc {
     const void* xA[4];
     const void* xB[4];
     int64_t xlda[4], xldb[4];
-    /* Row gather of the RESULT inside the epilogue (SAGEConv's neighbour aggregation, models/graph.py:42 via PyG
-     * SAGEConv.propagate: the launch that follows the projection forward, and the one that follows dX of lin_l backward):
-     *   ga_mode 1  ga_out[m] = mean over the CSR row m of C[ga_col[e]]   (C = relu(h Wp^T + bp); egk_csr_gather / _banded)
-     *   ga_mode 2  ga_out[m] = (ga_gate[m] > 0) ? sum over row m of ga_wgt[e] * C[ga_col[e]] : 0   (its backward: the transposed
-     *              gather with weights 1 / deg(target), gated by the projection's ReLU)
-     * in C's element type and leading dimension ga_ld, added in edge order -- the sums of the separate gather launch bit for
-     * bit -- from the tile the epilogue already holds in LDS, so the gather launch and its re-read of C disappear.  Only when
-     * every edge stays inside ONE output tile: the caller passes ga_tile_mask (bit 0 / 1 / 2: no edge crosses a multiple of
-     * 64 / 96 / 128 rows; 32-node sequences never do) and asks egk_gemm_gather_ok() first.  ga_band (uint8 [M], optional,
-     * mode 1): egk_csr_gather_banded's neighbour codes.  ga_skip_c: do not store C itself (mode 2: nothing else reads it). */
-    int32_t ga_mode, ga_tile_mask, ga_skip_c;
-    const int32_t* ga_rowptr;
-    const int32_t* ga_col;
-    const float* ga_wgt;
-    const uint8_t* ga_band;
-    const void* ga_gate;
-    void* ga_out;
-    int64_t ga_ld;
-    /* Split-K finished inside the launch: sk_tickets = int32 [ceil(M / 64) * ceil(N / 128)] (enough for every tile height),
-     * caller-owned, ZERO on entry and left zero on exit, not shared with a launch that may run at the same time (another stream).
-     * The workgroup that stores the last slab of an output tile sums the tile's slabs in slab order and applies the epilogue
-     * (the separate reduce launch's arithmetic: the same bits) -- one launch less per split contraction.  NULL, or a shape the
-     * in-launch path does not take (N not a multiple of 4, unaligned C / residual, the 256 x 256 tile, f32 operands): the reduce
-     * launch as before.  egk_gemm_splitk_in_launch() says which. */
-    int32_t* sk_tickets;
     /* 1: the 16-bit operands (a_dtype = b_dtype = EGK_BF16 as the storage width) hold IEEE half values and the launch multiplies
      * them on the f16 matrix instructions (f32 accumulation): 11 significand bits instead of bf16's 8 -- the one-product screen of
      * the nearest-prototype search (egk_topk_window_group, screen_f16).  egk_gemm_grouped only, row-major A and B, no split-K /
-     * statistics / gather epilogue; every problem of the launch must agree. */
+     * statistics epilogue; every problem of the launch must agree. */
     int32_t op_f16;
-    /* Adam INSIDE the weight-gradient launch (NULL: off).  C is a parameter's f32 gradient (the dW form of a linear layer,
-     * trn_pooling.py:28-45 / models/graph.py:39-48 backward; torch.optim.Adam of configs/defaults.yaml:17-20): the epilogue stores the
-     * gradient tile as always and, from the same registers, steps the parameter, its moments and its bf16 operand copies at the
-     * same [row, column] -- egk_adam_step's arithmetic on the same values: the same bits, without the optimizer's pass over the
-     * gradient.  Points to an egk_adam_epi in DEVICE memory (it is read by the kernel; build it once per parameter).  Needs a plain
-     * f32 store: no split-K, bias, activation, residual, statistics or gather; the buffers are laid out like C (row stride ldc). */
-    const void* adam_epi;
 } egk_gemm_desc;
-/* what egk_gemm_desc.adam_epi points to (device memory; 64 bytes) */
-typedef struct {
-    float* p;
-    float* m;
-    float* v;
-    void* bf16_shadow;       /* bf16(p), may be NULL */
-    void* bf16_lo_shadow;    /* bf16(p - bf16(p)), may be NULL */
-    const float* hyper;      /* egk_adam_hyper's output */
-    float beta1, beta2, eps, weight_decay;
-} egk_adam_epi;
 /* workspace bytes a descriptor needs (split-K slabs + bias-gradient partials / column-sum scratch) */
 int64_t egk_gemm_ws_bytes(const egk_gemm_desc* d);
 int egk_gemm(egk_stream_t s, const egk_gemm_desc* d);
 int egk_gemm_stats_blocks(const egk_gemm_desc* d);
-/* 1 when egk_gemm(d) would finish its split-K inside the launch (d->sk_tickets set, splitk > 1, eligible shape) */
-int egk_gemm_splitk_in_launch(const egk_gemm_desc* d);
-/* 1 when the tile variant the policy picks for ``d`` can run its ga_mode gather in the epilogue (nothing is launched) */
-int egk_gemm_gather_ok(const egk_gemm_desc* d);
 /* HOST helper of the batch builders (runs on the CPU, touches no device): ``np.stack([rng.randint(h, size = n) for h in
  * high])`` of numpy's legacy RandomState on the generator's own state -- MT19937, mt_key[624] + *mt_pos as
  * ``RandomState.get_state()`` returns them, both advanced in place (per value: v = next_uint32 & mask until v <= high - 1; a
@@ -616,12 +553,6 @@ int egk_adam_step(egk_stream_t s, float* p, const void* g, int32_t g_dtype, floa
 int egk_adam_step_bump(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, int64_t n,
                        const float* hyper, float beta1, float beta2, float eps, float weight_decay, void* bf16_shadow,
                        void* bf16_lo_shadow, int64_t* bump_word, int64_t bump);
-/* egk_adam_step_bump over n_ranges (1 .. 48) element ranges [begin[i], begin[i] + len[i]) of the same buffers as ONE launch: what is
- * left of an optimizer slice once the matrices stepped inside their gradient launches (egk_gemm_desc.adam_epi) are taken out --
- * biases, LayerNorm parameters, slot padding.  begin[i] % 4 == 0; begin / len are HOST arrays (copied into the launch). */
-int egk_adam_step_ranges(egk_stream_t s, float* p, const void* g, int32_t g_dtype, float* m, float* v, const int64_t* begin,
-                         const int64_t* len, int32_t n_ranges, const float* hyper, float beta1, float beta2, float eps,
-                         float weight_decay, void* bf16_shadow, void* bf16_lo_shadow, int64_t* bump_word, int64_t bump);
 /* The constants of the NEXT step computed on the device: t = ++(*t_dev) (device int64: optimizer steps taken so far);
  * hyper[4] = {src[0] = lr, 1 - beta1^t, sqrt(1 - beta2^t), src[1] = grad_scale} (double pow / sqrt, rounded to f32 once, as
  * torch.optim.Adam's bias corrections are).  One thread; a node of the captured step, so that a graph replay needs no

@@ -1063,7 +1063,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
     A2, B2 = (operand(M, K2, transA), operand(N, K2, transB)) if K2 else (None, None)
     C0 = torch.randn(M, N, device=DEV, generator=g)
     outs = {}
-    for pipe in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11, 16, 0, 5, 12, 1, 55):
+    for pipe in (3, 7, 15, 8, 11, 16, 0, 5, 12, 1, 55):
         prev = lib.egk_gemm_set_pipeline(5 if pipe == 55 else pipe)
         try:
             out = C0.clone()
@@ -1072,7 +1072,7 @@ def test_gemm_pipelined_transposed_operands_bit_equal_to_generic(ops, transA, tr
             outs[pipe] = out
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    for v in (3, 2, 4, 6, 13, 14, 7, 15, 8, 11, 16):  # one wave group (14: two ping-pong groups over DIFFERENT rows; 16: 192 x 128 tiles on 8 waves, row-major A): the MFMA chain of the
+    for v in (3, 7, 15, 8, 11, 16):  # one wave group (16: 192 x 128 tiles on 8 waves, row-major A): the MFMA chain of the
         assert torch.equal(outs[v], outs[0]), v  # generic kernel per accumulator, whatever the tile / ring depth
     assert torch.equal(outs[5], outs[55])
     # 64-row tiles with two wave groups (12; row-major A only): the same even / odd K sums as (5), whatever the tile height
@@ -1101,7 +1101,7 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
     bias = torch.randn(N, device=DEV, generator=g)
     res = torch.randn(M, N, device=DEV, generator=g).to(BF)
     outs = {}
-    for pipe in (3, 6, 13, 14, 7, 15, 8, 11, 16, 0, 5, 12, 1):
+    for pipe in (3, 7, 15, 8, 11, 16, 0, 5, 12, 1):
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             for dt in (BF, torch.float32):
@@ -1113,9 +1113,8 @@ def test_gemm_pipelined_kernel_bit_equal_to_generic(ops, M, N, K1, K2):
             lib.egk_gemm_set_pipeline(prev)
     for dt in (BF, torch.float32):
         assert torch.equal(outs[(3, dt)], outs[(0, dt)])
-        assert torch.equal(outs[(6, dt)], outs[(0, dt)]) and torch.equal(outs[(8, dt)], outs[(0, dt)]) and torch.equal(outs[(11, dt)], outs[(0, dt)])  # 256- / 96- / 64-row tiles
+        assert torch.equal(outs[(8, dt)], outs[(0, dt)]) and torch.equal(outs[(11, dt)], outs[(0, dt)])  # 96- / 64-row tiles
         assert torch.equal(outs[(7, dt)], outs[(0, dt)])  # 256 x 256 tiles (the policy's choice for the two large outputs)
-        assert torch.equal(outs[(13, dt)], outs[(0, dt)]) and torch.equal(outs[(14, dt)], outs[(0, dt)])  # 256 x 128: 3-stage ring; ping-pong groups
         assert torch.equal(outs[(15, dt)], outs[(0, dt)])  # 192 x 256 tiles (M % 192 == 0, N % 256 == 0: the (768, 512) case; 128 x 128 otherwise)
         assert torch.equal(outs[(16, dt)], outs[(0, dt)])  # 192 x 128 tiles, 8 waves, 3-stage ring (ragged M / N included)
         assert any(torch.equal(outs[(1, dt)], outs[(v, dt)]) for v in (5, 3, 8, 11, 7, 15, 16))
@@ -1170,64 +1169,6 @@ def test_gemm_f32_pipelined_kernel_bit_equal_to_generic(ops, transA, transB, M, 
         torch.testing.assert_close(outs[1][1], (0.5 * dot + C0.double()).float(), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("transA,transB", [(False, False), (False, True), (True, True)])
-@pytest.mark.parametrize("M,N,K,splitk,pipe", [(2048, 1024, 1024, 2, 1), (2048, 1024, 3072, 4, 1), (300, 200, 512, 3, 1), (2048, 1024, 2048, 2, 5),
-                                               (1024, 1024, 2048, 4, 3), (2048, 480, 1024, 2, 11), (2048, 1024, 1024, 2, 8), (2048, 1024, 1024, 2, 12),
-                                               (130, 132, 256, 2, 1)])
-def test_gemm_splitk_finished_inside_the_launch_equals_the_reduce_launch(ops, transA, transB, M, N, K, splitk, pipe):
-    """egk_gemm_desc.sk_tickets: the workgroup that stores the last slab of an output tile sums the tile's slabs (slab order) and
-    applies the epilogue -- against the separate reduce launch (egk_gemm_set_pipeline(700)): bias + ReLU + bf16 residual into a
-    bf16 result, alpha + accumulation into an f32 result, the fused bias gradient of the dW form, ragged tiles, every tile
-    variant that takes it -- BIT for bit, repeatedly (the counters come back at zero), and the query agrees with what ran."""
-    from egopack_amd import _lib
-    lib = _lib.load()
-    g = torch.Generator(device=DEV).manual_seed(M + 3 * N + K + splitk)
-
-    def operand(rows, tr):
-        return torch.randn((K, rows) if tr else (rows, K), device=DEV, generator=g).to(BF)
-    A, B = operand(M, transA), operand(N, transB)
-    bias, res = torch.randn(N, device=DEV, generator=g), torch.randn(M, N, device=DEV, generator=g).to(BF)
-    C0, db0 = torch.randn(M, N, device=DEV, generator=g), torch.randn(M, device=DEV, generator=g)
-    outs = {}
-    prev_pipe = lib.egk_gemm_set_pipeline(pipe)
-    prev_on, ops._sk_in_launch["on"] = ops._sk_in_launch["on"], True  # (opt-in: EGK_ENABLE=splitk_in_launch)
-    try:
-        for mode in (701, 700, 701):
-            lib.egk_gemm_set_pipeline(mode)
-            a = torch.empty(M, N, device=DEV, dtype=BF)
-            ops.gemm(M, N, A, A.shape[1], B, B.shape[1], K, a, N, transA=transA, transB=transB, bias=bias, residual=res, ldr=N,
-                     act=1, splitk=splitk)
-            b, db = C0.clone(), db0.clone()
-            kw = dict(dbias=db) if (transA and transB) else {}
-            ops.gemm(M, N, A, A.shape[1], B, B.shape[1], K, b, N, transA=transA, transB=transB, accumulate=True, alpha=0.5,
-                     splitk=splitk, **kw)
-            outs.setdefault(mode, []).append((a, b, db))
-    finally:
-        ops._sk_in_launch["on"] = prev_on
-        lib.egk_gemm_set_pipeline(701)
-        lib.egk_gemm_set_pipeline(prev_pipe)
-    first, sep, again = outs[701][0], outs[700][0], outs[701][1]
-    for x, y, z in zip(first, sep, again):
-        assert torch.equal(x, y) and torch.equal(z, y)
-    key = (torch.device(DEV).index or 0, torch.cuda.current_stream().cuda_stream)
-    tickets = ops._sk_cache.get(key)
-    assert tickets is not None and int(tickets.abs().sum()) == 0
-    if (M, N) == (2048, 1024):  # the shapes of the steps' split contractions: the query says they are finished in the launch
-        d = ops._gemm_desc(M, N, A, A.shape[1], B, B.shape[1], K, torch.empty(M, N, device=DEV, dtype=BF), N, transA=transA, transB=transB)
-        d.splitk = splitk
-        d.ws, d.ws_bytes = ops._p(torch.empty(splitk * M * N, device=DEV)), splitk * M * N * 4
-        d.sk_tickets = ops._p(tickets)
-        prev_pipe = lib.egk_gemm_set_pipeline(pipe)
-        try:
-            assert lib.egk_gemm_splitk_in_launch(_lib.C.byref(d)) == 1
-            d.sk_tickets = None
-            assert lib.egk_gemm_splitk_in_launch(_lib.C.byref(d)) == 0
-        finally:
-            lib.egk_gemm_set_pipeline(prev_pipe)
-    ref = (A.double().t() if transA else A.double()) @ (B.double() if transB else B.double().t())
-    torch.testing.assert_close(first[1].double(), 0.5 * ref + C0.double(), rtol=1e-3, atol=2e-2)
-
-
 @pytest.mark.parametrize("M,N,K", [(1024, 1024, 2048), (472, 1024, 1024), (128, 256, 4096), (1024, 4608, 6144), (115, 1024, 2048)])
 def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
     """dW launch with dbias: dbias[m] += sum_k dY[k, m], fused into the pipelined kernel (from the dY^T LDS image) or
@@ -1242,7 +1183,7 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
     ref_w = (dY.double().t() @ X.double() + W0.double()).float()
     ref_b = (dY.double().sum(0) + b0.double()).float()
     res = {}
-    for pipe in (3, 6, 7, 0, 5, 1):  # (7 has no fused bias gradient: it must hand the launch to 3)
+    for pipe in (3, 7, 0, 5, 1):  # (7 has no fused bias gradient: it must hand the launch to 3)
         prev = lib.egk_gemm_set_pipeline(pipe)
         try:
             w, b = W0.clone(), b0.clone()
@@ -1252,7 +1193,7 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
             lib.egk_gemm_set_pipeline(prev)
     assert torch.equal(res[3][0], res[0][0]) and torch.equal(res[6][0], res[0][0]) and torch.equal(res[7][0], res[0][0])
     assert torch.equal(res[7][1], res[3][1])
-    for pipe in (3, 6, 7, 0, 5, 1):
+    for pipe in (3, 7, 0, 5, 1):
         torch.testing.assert_close(res[pipe][0], ref_w, rtol=2e-3, atol=2e-2)
         torch.testing.assert_close(res[pipe][1], ref_b, rtol=1e-3, atol=2e-2)
 
@@ -1626,42 +1567,6 @@ def _adam_case(n, seed):
     return p, gr, m, v, hyper
 
 
-def test_adam_over_ranges_equals_one_launch_per_range(ops):
-    """egk_adam_step_ranges (what an optimizer slice launches once the matrices stepped inside their gradient contractions are taken
-    out: torch.optim.Adam, configs/defaults.yaml:17-20): the bits of egk_adam_step_bump range by range, nothing outside the ranges
-    touched, the rider word moved on once -- also by a launch whose only range is empty."""
-    import ctypes as C
-    from egopack_amd import _lib
-    lib = _lib.load()
-    n = 20000
-    p, gr, m, v, hyper = _adam_case(n, 3)
-    ranges = [(0, 40), (64, 1000), (2048, 4), (4096, 5003), (12000, 0), (16000, 4000)]
-    sh, lo = torch.zeros(n, dtype=torch.bfloat16, device=DEV), torch.zeros(n, dtype=torch.bfloat16, device=DEV)
-    word = torch.zeros(1, dtype=torch.int64, device=DEV)
-    a = [t.clone() for t in (p, m, v, sh, lo)]
-    bg, ln = (C.c_int64 * len(ranges))(*[b for b, _ in ranges]), (C.c_int64 * len(ranges))(*[k for _, k in ranges])
-    rc = lib.egk_adam_step_ranges(ops._stream(), ops._p(a[0]), ops._p(gr), 0, ops._p(a[1]), ops._p(a[2]), bg, ln, len(ranges), ops._p(hyper),
-                                  0.9, 0.999, 1e-8, 1e-5, ops._p(a[3]), ops._p(a[4]), ops._p(word), 7)
-    assert rc == 0, _lib.last_error()
-    b = [t.clone() for t in (p, m, v, sh, lo)]
-    for b0, k in ranges:
-        if k:
-            sl = slice(b0, b0 + k)
-            rc = lib.egk_adam_step_bump(ops._stream(), ops._p(b[0][sl]), ops._p(gr[sl]), 0, ops._p(b[1][sl]), ops._p(b[2][sl]), k, ops._p(hyper),
-                                        0.9, 0.999, 1e-8, 1e-5, ops._p(b[3][sl]), ops._p(b[4][sl]), None, 0)
-            assert rc == 0, _lib.last_error()
-    for x, y in zip(a, b):
-        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
-    assert torch.equal(a[0][40:64], p[40:64]) and torch.equal(a[0][9099:12000], p[9099:12000]) and int(word.item()) == 7
-    one = (C.c_int64 * 1)(0), (C.c_int64 * 1)(0)
-    assert lib.egk_adam_step_ranges(ops._stream(), ops._p(a[0]), ops._p(gr), 0, ops._p(a[1]), ops._p(a[2]), one[0], one[1], 1, ops._p(hyper),
-                                    0.9, 0.999, 1e-8, 1e-5, ops._p(a[3]), ops._p(a[4]), ops._p(word), 7) == 0
-    assert int(word.item()) == 14 and torch.equal(a[0], b[0])
-    odd = (C.c_int64 * 1)(6), (C.c_int64 * 1)(10)
-    assert lib.egk_adam_step_ranges(ops._stream(), ops._p(a[0]), ops._p(gr), 0, ops._p(a[1]), ops._p(a[2]), odd[0], odd[1], 1, ops._p(hyper),
-                                    0.9, 0.999, 1e-8, 1e-5, None, None, None, 0) != 0 and "multiples of 4" in _lib.last_error()
-
-
 def test_zero_fill_over_ranges_clears_the_ranges_and_nothing_else(ops):
     """egk_zero_fill_ranges (the step's gradient clear once the single-writer slots are left out; optimizer.zero_grad(), reference
     main_temporal.py:76): whole 16-byte groups of up to 48 ranges in one launch, everything else untouched; ragged or too many
@@ -1682,39 +1587,6 @@ def test_zero_fill_over_ranges_clears_the_ranges_and_nothing_else(ops):
     many = (C.c_int64 * 49)(*([0] * 49)), (C.c_int64 * 49)(*([16] * 49))
     assert lib.egk_zero_fill_ranges(ops._stream(), ops._p(buf), many[0], many[1], 49) != 0
     assert torch.equal(buf, want)
-
-
-@pytest.mark.parametrize("M,N,K", [(256, 1024, 2048), (130, 72, 512), (64, 100, 256), (40, 144, 192)])
-def test_weight_gradient_launch_with_adam_in_its_epilogue(ops, M, N, K):
-    """egk_gemm_desc.adam_epi: the dW-form contraction dW[M, N] = dY[K, M]^T x[K, N] (reference trn_pooling.py:28-45 backward) stores
-    its gradient and steps the parameter, its moments and its bf16 copies in the epilogue -- the bits of the contraction followed by
-    egk_adam_step_bump over the matrix; both epilogue forms (whole rows through LDS where N % 8 == 0, four columns per lane else)."""
-    import struct
-    from egopack_amd import _lib
-    lib = _lib.load()
-    g = gen(M + N + K)
-    dy, x = torch.randn(K, M, generator=g).to(DEV).to(torch.bfloat16), torch.randn(K, N, generator=g).to(DEV).to(torch.bfloat16)
-    p, _, m, v, hyper = _adam_case(M * N, 5)
-    sh, lo = torch.zeros(M * N, dtype=torch.bfloat16, device=DEV), torch.zeros(M * N, dtype=torch.bfloat16, device=DEV)
-    ga, gb = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
-    a = [t.clone() for t in (p, m, v, sh, lo)]
-    epi = torch.frombuffer(bytearray(struct.pack("<6Q4f", a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
-                                                 hyper.data_ptr(), 0.9, 0.999, 1e-8, 1e-5)), dtype=torch.uint8).to(DEV)
-    calls = []
-    prev = ops.set_adam_epilogue(lambda out, mm, nn, ldc: (calls.append((mm, nn)), epi.data_ptr())[1], lambda out: calls.append("void"))
-    try:
-        ops.gemm(M, N, dy, M, x, N, K, ga, N, transA=True, transB=True, accumulate=True, compute=ops.BF16, allow_splitk=False)
-    finally:
-        ops.set_adam_epilogue(*prev)
-    assert calls == [(M, N)]
-    b = [t.clone() for t in (p, m, v, sh, lo)]
-    ops.gemm(M, N, dy, M, x, N, K, gb, N, transA=True, transB=True, accumulate=True, compute=ops.BF16, allow_splitk=False)
-    assert lib.egk_adam_step_bump(ops._stream(), ops._p(b[0]), ops._p(gb), 0, ops._p(b[1]), ops._p(b[2]), M * N, ops._p(hyper), 0.9, 0.999,
-                                  1e-8, 1e-5, ops._p(b[3]), ops._p(b[4]), None, 0) == 0
-    assert torch.equal(ga, gb)
-    for t, u, name in zip(a, b, ("p", "m", "v", "bf16", "bf16 low half")):
-        assert torch.equal(t.view(torch.int16) if t.dtype == torch.bfloat16 else t, u.view(torch.int16) if u.dtype == torch.bfloat16 else u), name
-    assert not torch.equal(a[0], p)
 
 
 def test_adam_step_constants_are_computed_on_the_device_and_follow_lr_and_the_step_count(ops):
@@ -1887,77 +1759,6 @@ def test_rows1024_general_gather_at_96_registers_against_the_generic_kernel(ops,
     if gated:
         ref = torch.where(gate.double().cpu() > 0, ref, torch.zeros_like(ref))
     torch.testing.assert_close(outs[0].float().cpu(), ref.float(), **OUT16)
-
-
-@pytest.mark.parametrize("mode", ["bf16", "f32"])
-@pytest.mark.parametrize("n_seq,T,lta", [(192, 32, False), (192, 32, True), (256, 32, True), (128, 48, False), (128, 32, False), (24, 256, False)])
-def test_sage_layer_with_the_gather_in_the_contraction_epilogue_is_bit_identical(ops, mode, n_seq, T, lta):
-    """SAGEConv(project=True, mean) forward and backward with the neighbour aggregation taken INSIDE the epilogue of the
-    contraction that produces its input (egk_gemm_desc.ga_mode 1: mean over in-neighbours of relu(h Wp^T + bp); ga_mode 2: the
-    gated transposed gather of d_agg, which is then never stored) against the separate gather launches: the same sums in the
-    same order -- every output and gradient bit for bit.  Band sequences and LTA sequences (general rows, the fan-out node's
-    31 out-edges), 96- and 128-row tiles, 48-node sequences (local to 96-row tiles only), and shapes where the fusion does not
-    apply (two-wave-group variant at 4096 rows; 256-node sequences cross every tile) and the call falls back by itself."""
-    from egopack_amd import data as D
-    from egopack_amd.models.layers import SAGEConv
-    g = gen(n_seq * T + lta)
-    H = 1024 if mode == "bf16" else 256
-    parts, n = [], 0
-    for i in range(n_seq):
-        if lta and i % 3 == 0:
-            y = torch.stack([torch.randint(1, 5, (T,), generator=g), torch.randint(0, 5, (T,), generator=g)], 1)
-            y[:T - 12] = -1
-            parts.append(D.lta_connectivity_edges(torch.arange(T), y, 1.5 if i % 2 else float(T)) + n)
-        else:
-            parts.append(D.radius_band_edges(torch.arange(T), 1) + n)
-        n += T
-    prev_on = ops._gather_fusion["on"]
-    ops._gather_fusion["on"] = True  # (the tile-locality mask is computed only while its consumer is switched on)
-    try:
-        graph = D.build_csr(torch.cat(parts, 1), n)
-    finally:
-        ops._gather_fusion["on"] = prev_on
-    expect_mask = {32: 7, 48: 2, 256: 0}[T]
-    assert graph.tile_mask == expect_mask
-    assert prev_on or D.build_csr(torch.cat(parts, 1), n).tile_mask == 0  # (switched off: not computed)
-    graph = graph.to(DEV)
-    torch.manual_seed(7)
-    conv = SAGEConv(H, H, project=True).to(DEV)
-    dt = BF if mode == "bf16" else torch.float32
-    h0 = torch.randn(n, H, generator=g).to(DEV).to(dt)
-    gy = torch.randn(n, H, generator=g).to(DEV).to(dt)
-    outs = {}
-    with ops.compute_mode(mode):
-        for fused in (True, False):
-            prev = ops._gather_fusion["on"]
-            ops._gather_fusion["on"] = fused
-            try:
-                h = h0.clone().requires_grad_(True)
-                for p in conv.parameters():
-                    p.grad = None
-                out = ops.sage_mean_layer(h, conv, graph)
-                out.backward(gy)
-                torch.cuda.synchronize()
-                outs[fused] = [out.detach().clone(), h.grad.clone(), *(p.grad.clone() for p in conv.parameters())]
-            finally:
-                ops._gather_fusion["on"] = prev
-    # Band-only batches: every row is summed in edge order by both paths -- bit for bit.  LTA batches have rows of 13 .. 24
-    # edges, which the separate gather launch sums cooperatively (edge e -> wave e % 4, partials combined in wave order:
-    # csr_gather_kernel's HEAVY rows) while the epilogue adds them in edge order, the order of the reference's scatter: those
-    # rows may differ by one rounding of the stored type, and so may what is downstream of them.
-    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
-        if not lta:
-            assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
-        else:
-            scale = float(b.float().abs().max())
-            tol = (2.0 ** -6 if mode == "bf16" else 2.0 ** -18) * scale
-            assert float((a.float() - b.float()).abs().max()) <= tol, (i, float((a.float() - b.float()).abs().max()), scale)
-    # ... and the layer itself against the oracle's SAGEConv on the same (rounded) inputs
-    ei = torch.cat(parts, 1)
-    sd = {k: v.detach().float().cpu() for k, v in conv.state_dict().items()}
-    ref = P.sage_conv(h0.float().cpu(), ei, sd["lin_l.weight"], sd["lin_l.bias"], sd["lin_r.weight"], sd["lin.weight"], sd["lin.bias"],
-                      aggr="mean")
-    torch.testing.assert_close(outs[True][0].float().cpu(), ref, **(dict(rtol=3e-2, atol=3e-2) if mode == "bf16" else dict(rtol=2e-4, atol=2e-4)))
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])

@@ -446,59 +446,6 @@ def test_captured_step_equals_eager_step(A, golden):
     torch.testing.assert_close(p_graph, p_eager, rtol=0, atol=1e-6)
 
 
-def test_adam_inside_the_weight_gradient_launches_gives_the_optimizer_launch_s_bits(monkeypatch):
-    """OPT-IN (EGK_ENABLE=adam_epilogue; measured slower on the headline step): the captured bf16 multi-task step steps its weight
-    matrices in the epilogue of their gradient contractions (egk_gemm_desc.adam_epi; torch.optim.Adam of configs/defaults.yaml:17-20
-    on the dW of trn_pooling.py:28-45 / models/graph.py:39-48) and the rest of the flat buffers in one ranged launch
-    (egk_adam_step_ranges): parameters, both moments, the bf16 operand copies and the stored gradients equal, bit for bit, those of
-    the same captured step with the optimizer's own pass over everything (the default).  Dropout is on: the Philox offset word
-    moves on inside the ranged launch as it does inside the plain one."""
-    import bench
-    from egopack_amd import engine, ops
-    from egopack_amd.optim import FlatAdam
-    prev = ops.get_compute()
-
-    def run(on):
-        if on:
-            monkeypatch.setenv("EGK_ENABLE", "adam_epilogue")
-        else:
-            monkeypatch.delenv("EGK_ENABLE", raising=False)
-        args = bench.parse_args(["--workload", "mtl", "--batch", "64", "--T", "16", "--hidden", "128", "--trn-hidden", "256",
-                                 "--dropout", "0.5"])
-        args.compute = "bf16"
-        ops.set_compute("bf16")
-        ops.manual_seed(11)
-        model, tasks, crit, weights, dev, merged = bench.build_workload(args, 0, torch.device(DEV))
-        model.to(DEV).train()
-        for t in tasks.values():
-            t.to(DEV).train()
-        opt = FlatAdam([*model.parameters(), *(p for t in tasks.values() for p in t.parameters())], lr=1e-3, weight_decay=1e-5)
-        step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=True)
-        step.capture(dev, merged, warmup=2)
-        for _ in range(3):
-            step.replay()
-        torch.cuda.synchronize()
-        claimed = list(getattr(step, "_adam_epilogue_ranges", []))
-        return [t.clone().cpu() for t in (opt.flat_p, opt.flat_m, opt.flat_v, opt.flat_w16.view(torch.int16), opt.flat_g)], claimed, opt
-
-    try:
-        got, claimed, opt = run(True)
-        ref, none, _ = run(False)
-    finally:
-        ops.set_compute(prev)
-    assert not none
-    big = [p for p in opt.active if p.dim() == 2 and p.shape[1] % 8 == 0 and p.numel() >= 64 * 64 and getattr(p, "_egk_bank", None) is None]
-    assert len(big) >= 10 and len(claimed) >= len(big) - 2, (len(claimed), len(big))  # (a lone launch that splits K keeps the plain path)
-    assert sum(n for _, n in claimed) > 0.8 * sum(p.numel() for p in big)
-    inside = torch.zeros(got[0].numel(), dtype=torch.bool)
-    for b0, n in claimed:
-        inside[b0:b0 + n] = True
-    for a, b, name in zip(got, ref, ("p", "m", "v", "bf16 copy", "gradient")):
-        bad = a != b
-        assert not bool(bad.any()), (name, int(bad.sum()), int((bad & inside).sum()), float((a.float() - b.float()).abs().max()),
-                                     float(b.float().abs().max()))
-
-
 @pytest.mark.parametrize("workload", ["mtl", "egopack_oscc"])
 def test_single_writer_gradient_slots_are_stored_not_cleared_and_accumulated(workload, monkeypatch):
     """Captured one-rank steps leave the gradient slots that ONE weight-gradient launch writes per step (learnt from an eager step,

@@ -570,3 +570,43 @@ def test_fast_key_sees_the_labelled_row_set_of_a_compacted_head():
     assert E.batch_signature({"ar": a}) != E.batch_signature({"ar": b})
     assert E._fast_key({"ar": a}, None) != E._fast_key({"ar": b}, None)
     assert E._fast_key({"ar": a}, None) == E._fast_key({"ar": a}, None)
+
+
+def test_switch_registry_covers_every_switch_the_code_reads(monkeypatch):
+    """egopack_amd/switches.py is the ONE place a development switch is declared: every name the package asks for is registered,
+    nothing else reads EGK_ENABLE / EGK_DISABLE / EGK_DBG, names match exactly (no substrings), an unknown name in the environment
+    is reported, and the tri-state override leaves per-class defaults alone when the environment says nothing."""
+    import re
+    import warnings
+    from pathlib import Path
+    from egopack_amd import switches
+    root = Path(switches.__file__).resolve().parent
+    asked, raw = set(), []
+    for f in [*root.glob("*.py"), *root.glob("models/**/*.py"), root.parent / "bench.py", root.parent / "main_temporal.py", root.parent / "main_egopack.py"]:
+        text = f.read_text()
+        if f.name != "switches.py":
+            raw += [f"{f.name}: {m}" for m in re.findall(r'environ\S*\("EGK_(?:ENABLE|DISABLE|DBG)"', text)]
+        if f.name == "switches.py":
+            continue
+        asked |= set(re.findall(r'switches\.(?:enabled|override|value)\("([a-z_0-9]+)"\)', text))
+        asked |= set(re.findall(r'for name in \(("[a-z_0-9", ]+)\):\n\s+forced = switches\.override\(name\)', text) and ["wgrad_grouping", "deferred_forks"])
+        for name in re.findall(r'switches\.debug\("([a-z_0-9]+)"\)', text):
+            assert name in switches.DEBUG, name
+    assert not raw, raw
+    assert asked and asked <= set(switches.REGISTRY), asked - set(switches.REGISTRY)
+    assert set(switches.REGISTRY) <= asked, f"registered but never read: {set(switches.REGISTRY) - asked}"
+    monkeypatch.delenv("EGK_ENABLE", raising=False)
+    monkeypatch.setenv("EGK_DISABLE", "oscc_one_pass")
+    assert not switches.enabled("oscc_one_pass") and switches.enabled("one_pass")  # (exact names: the substring bug of rounds 3-5)
+    assert switches.override("wgrad_grouping") is None
+    monkeypatch.setenv("EGK_ENABLE", "sharded_update,wgrad_grouping")
+    assert switches.enabled("sharded_update") and switches.override("wgrad_grouping") is True
+    monkeypatch.setenv("EGK_DISABLE", "no_such_switch")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        switches.enabled("grad_store")
+    assert any("no_such_switch" in str(x.message) for x in w)
+    import pytest
+    with pytest.raises(KeyError):
+        switches.enabled("not_registered")
+    assert "grad_store" in switches.table()
