@@ -612,8 +612,7 @@ class StepBase:
             return False
         if self.staged is None and (self.sync is None or self.sync.world <= 1):
             return False
-        if self.sync is not None and getattr(self.sync, "shard_update", False):
-            return False  # (the sharded update exchanges the whole buffer once: one-piece backward)
+        # (the sharded update is region-wise too: each region is reduce-scattered when backward has finished it, dist.GradSync.start)
         return self._stage_regions() is not None
 
     def _exchange_region(self, region):

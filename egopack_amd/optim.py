@@ -273,16 +273,21 @@ class FlatAdam(torch.optim.Optimizer):
             "egk_split_bf16")
         self._lo_fresh.append((lo, hi))
 
-    def refresh_shadows(self):
-        """Re-derive the bf16 operand copies from the f32 parameters (after load_state_dict or any other
-        write to the parameters that did not go through ``step``)."""
+    def refresh_shadows(self, lo: int = 0, hi=None):
+        """Re-derive the bf16 operand copies of flat_p[lo:hi] (default: everything) from the f32 parameters: after
+        load_state_dict, the all-gather of a sharded update, or any other write to the parameters that did not go through ``step``."""
+        hi = self.flat_p.numel() if hi is None else hi
+        if hi <= lo:
+            return
         if self.flat_w16 is not None:
-            _ck(_lib.load().egk_cast(_stream(), _p(self.flat_p), 0, _p(self.flat_w16), 1, self.flat_p.numel()), "egk_cast")
-        self._lo_fresh = []
+            _ck(_lib.load().egk_cast(_stream(), _p(self.flat_p[lo:hi]), 0, _p(self.flat_w16[lo:hi]), 1, hi - lo), "egk_cast")
+        self._lo_fresh = _minus_ranges(self._lo_fresh, lo, hi)
         if self.flat_w16lo is not None and self.adam_writes_lo:
             # a captured step whose Adam launches keep the low halves holds NO split launch (engine.StepBase.capture): an
-            # out-of-band write to the parameters (checkpoint load, a restored snapshot) must leave them fresh itself
-            self.refresh_lo_shadows()
+            # out-of-band write to the parameters (checkpoint load, a restored snapshot, gathered slices) leaves them fresh itself
+            _ck(_lib.load().egk_split_bf16(_stream(), _p(self.flat_p[lo:hi]), hi - lo, None, _p(self.flat_w16lo[lo:hi]), hi - lo, 1, hi - lo),
+                "egk_split_bf16")
+            self._lo_fresh.append((lo, hi))
 
     @property
     def materialised(self) -> bool:

@@ -1191,7 +1191,7 @@ def test_gemm_dw_with_fused_bias_gradient(ops, M, N, K):
             res[pipe] = (w, b)
         finally:
             lib.egk_gemm_set_pipeline(prev)
-    assert torch.equal(res[3][0], res[0][0]) and torch.equal(res[6][0], res[0][0]) and torch.equal(res[7][0], res[0][0])
+    assert torch.equal(res[3][0], res[0][0]) and torch.equal(res[7][0], res[0][0])
     assert torch.equal(res[7][1], res[3][1])
     for pipe in (3, 7, 0, 5, 1):
         torch.testing.assert_close(res[pipe][0], ref_w, rtol=2e-3, atol=2e-2)

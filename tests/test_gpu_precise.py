@@ -352,8 +352,16 @@ def test_adam_launch_keeps_the_low_halves_of_the_weight_operands():
     assert opt._lo_is_fresh(0, 64 * 96) and opt._lo_is_fresh(0, n)
     assert _lib.load().egk_split_bf16(ops._stream(), ops._p(opt.flat_p), n, None, ops._p(want_lo), n, 1, n) == 0
     assert torch.equal(opt.flat_w16lo, want_lo)
+    # an out-of-band write to the parameters (checkpoint load, a restored snapshot): refresh_shadows rebuilds BOTH copies -- a captured
+    # step whose Adam launches keep the low halves holds no split launch that would
+    with torch.no_grad():
+        opt.flat_p.mul_(1.5)
     opt.refresh_shadows()
-    assert not opt._lo_is_fresh(0, 8)
+    assert opt._lo_is_fresh(0, n)
+    assert _lib.load().egk_split_bf16(ops._stream(), ops._p(opt.flat_p), n, None, ops._p(want_lo), n, 1, n) == 0
+    assert torch.equal(opt.flat_w16lo, want_lo) and torch.equal(opt.flat_w16, opt.flat_p.to(torch.bfloat16))
+    opt.refresh_shadows(8, 64)  # (a range: the gathered slices of a sharded update)
+    assert opt._lo_is_fresh(0, n) and torch.equal(opt.flat_w16lo, want_lo)
 
 
 def test_one_pass_backbone_graph_from_the_precise_passs_tape(ops):
