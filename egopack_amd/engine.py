@@ -666,7 +666,17 @@ class StepBase:
         if hasattr(opt, "materialised") and not opt.materialised:
             opt._materialise()
         if self.sync is not None and self.sync.world > 1:
-            self.sync.reduce_and_step(opt)  # chunked: Adam of chunk i overlaps the collectives of the later chunks
+            regions = self._stage_regions() if getattr(self.sync, "shard_update", False) else None
+            if regions is not None:
+                # sharded update: WHICH rank steps which slice must not depend on how the step was issued -- the moments of a slice
+                # live on its rank -- so a one-piece backward (the first step, before the flat buffers exist) shards region by
+                # region exactly as the staged steps that follow it do
+                self.sync.begin_step()
+                for region in regions:
+                    self.sync.start(opt, *region)
+                self.sync.finish_and_step(opt)
+            else:
+                self.sync.reduce_and_step(opt)  # chunked: Adam of chunk i overlaps the collectives of the later chunks
         else:
             opt.step()
 
@@ -1206,7 +1216,7 @@ class StepBase:
                 opt.invalidate_lo_shadows()
         else:
             self._graph.replay()
-            self.sync.reduce_and_step(opt)
+            self._exchange_and_update()  # (one-piece graph, the exchange and the optimizer behind it)
         return self._static_out[0]
 
 

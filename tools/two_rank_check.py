@@ -195,6 +195,19 @@ def worker(args):
                               "replayed_vs_eager_max_abs": float((pg - pe).abs().max())}
         out["sharded_update"] = {"capture": shard[1], "ranks_bit_identical": shard[2],
                                  "vs_allreduce_replay_max_abs": float((shard[0] - pg).abs().max())}
+        if os.environ.get("EGK_DBG_SHARD"):
+            bad = ((shard[0] - pg).abs() > 1e-6).nonzero().flatten()
+            print("[dbg] n", pg.numel(), "bad", bad.numel(), "first", bad[:5].tolist(), "last", bad[-5:].tolist(), file=sys.stderr, flush=True)
+            runs, prev, start = [], None, None
+            for i in bad.tolist():
+                if prev is None or i != prev + 1:
+                    if start is not None:
+                        runs.append((start, prev + 1))
+                    start = i
+                prev = i
+            if start is not None:
+                runs.append((start, prev + 1))
+            print("[dbg] runs", runs[:20], len(runs), file=sys.stderr, flush=True)
         out["config"] = dict(hidden=args.hidden, batch_per_rank=B, T=args.T, steps=args.steps, mode="f32", tasks=list(ORDER))
         e, l = out["exact"], out["local"]
         ok = (e["objective_rel"] <= 1e-6 and e["grad_rel"] <= 2e-3 and e["param_frac_within_2e-4"] >= 0.999
