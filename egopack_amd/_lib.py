@@ -42,6 +42,26 @@ class GemmDesc(C.Structure):
     ]
 
 
+class HostDataset(C.Structure):
+    """struct egk_host_dataset (include/egopack_hip.h): the per-sample tables of a resident dataset."""
+    _fields_ = [("T", i32), ("S", i32), ("train", i32), ("y_heads", i32), ("L", i64), ("y_elems", i64), ("heavy_in_launch", i64),
+                ("live_share", C.c_double),
+                ("y", vp), ("pos", vp), ("tau", vp), ("first", vp), ("vlen", vp), ("starts", vp), ("ends", vp),
+                ("n_tmpl", i64), ("e_max", i64), ("h_max", i64), ("th_max", i64),
+                ("t_e", vp), ("t_ei", vp), ("t_col", vp), ("t_tcol", vp), ("t_tw", vp), ("t_rp", vp), ("t_trp", vp), ("t_band", vp),
+                ("t_nh", vp), ("t_nth", vp), ("t_hv", vp), ("t_thv", vp), ("t_dmax", vp), ("t_tdmax", vp)]
+
+
+class HostBatch(C.Structure):
+    """struct egk_host_batch (include/egopack_hip.h): the caller-allocated arrays of one batch + what the call reports."""
+    _fields_ = [("E", i64), ("heavy_cap", i64), ("t_heavy_cap", i64), ("live_cap", i64),
+                ("y", vp), ("pos", vp), ("batch", vp), ("ptr", vp), ("ptr32", vp), ("x_idx", vp), ("edge_index", vp),
+                ("rowptr", vp), ("col", vp), ("t_rowptr", vp), ("t_col", vp), ("t_wgt", vp), ("band", vp), ("heavy", vp), ("t_heavy", vp),
+                ("live_idx", vp), ("live_inv", vp), ("live_y", vp),
+                ("n_heavy", i64), ("n_t_heavy", i64), ("n_live", i64), ("pos_min", i64), ("pos_max", i64),
+                ("heavy_mode", i32), ("t_heavy_mode", i32)]
+
+
 class CETask(C.Structure):
     """struct egk_ce_task (include/egopack_hip.h)."""
     _fields_ = [("logits", vp * 4), ("ld", i64 * 4), ("C", i32 * 4), ("pad", i32 * 4), ("dcol", i64 * 4), ("n_heads", i32),
@@ -136,6 +156,7 @@ SIGNATURES = {
     "egk_split_bf16": (C.c_int, [vp, vp, i64, vp, vp, i64, i64, i64]),
     "egk_host_bounded_draws": (i64, [vp, vp, vp, i64, i32, vp]),
     "egk_host_window_rows": (i64, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "egk_host_build_batch": (i64, [C.POINTER(HostDataset), vp, vp, vp, i64, C.POINTER(HostBatch)]),
     "egk_tune": (C.c_int, [i32, i32]),
     "egk_weighted_sums": (C.c_int, [vp, vp, vp, vp, i32, vp]),
     "egk_fill_scaled_multi": (C.c_int, [vp, vp, vp, vp, vp, i32]),

@@ -206,47 +206,158 @@ int64_t egk_host_bounded_draws(uint32_t* mt_key, int32_t* mt_pos, const int64_t*
  * sampling = linspace + size / n / 2), numpy's slice clipping of [start, end) to the video, and -1 rows where the reference's
  * np.take raises (empty window, an index == size).  ``random``: draws from the MT19937 state (advanced in place; NULL allowed
  * otherwise).  out int64 [W][n].  0, or -2 for a bound beyond 32 bits, -3 bad arguments. */
+static inline int64_t window_rows_one(MT& mt, int64_t first_row, int64_t vl, int64_t start, int64_t end, int32_t n, int32_t random,
+                                      int64_t* o) {
+    int64_t lo = start < 0 ? 0 : start, hi = end < 0 ? 0 : end;
+    lo = lo > vl ? vl : lo;
+    hi = hi > vl ? vl : hi;
+    const int64_t size = hi > lo ? hi - lo : 0;
+    bool bad = size == 0;
+    if (!bad) {
+        const double step = (double)size / (double)n;
+        const int64_t avg = size / n;
+        uint32_t rng = 0, mask = 0;
+        if (random && avg > 1) {
+            if (avg - 1 > 0xFFFFFFFFLL) return -2;
+            rng = (uint32_t)(avg - 1);
+            mask = mask_of(rng);
+        }
+        for (int32_t i = 0; i < n; ++i) {
+            int64_t idx;
+            if (random && avg > 0) {
+                const uint32_t v = avg > 1 ? mt.bounded(rng, mask) : 0u;
+                double x = (double)i * step + (double)v;
+                x = x < 0.0 ? 0.0 : (x > (double)size ? (double)size : x);
+                idx = (int64_t)nearbyint(x);
+            } else {
+                idx = (int64_t)floor((double)i * step);
+                if (!random) idx += size / n / 2;
+            }
+            if (idx >= size) bad = true;
+            o[i] = first_row + lo + idx;
+        }
+    }
+    if (bad)
+        for (int32_t i = 0; i < n; ++i) o[i] = -1;
+    return 0;
+}
+
 int64_t egk_host_window_rows(uint32_t* mt_key, int32_t* mt_pos, const int64_t* first_row, const int64_t* video_len,
                              const int64_t* start, const int64_t* end, int64_t W, int32_t n, int32_t random, int64_t* out) {
     if (!first_row || !video_len || !start || !end || !out || n <= 0 || W < 0) return -3;
     if (random && (!mt_key || !mt_pos || *mt_pos < 0 || *mt_pos > 624)) return -3;
     MT mt{mt_key, random ? *mt_pos : 0};
     for (int64_t w = 0; w < W; ++w) {
-        const int64_t vl = video_len[w];
-        int64_t lo = start[w] < 0 ? 0 : start[w], hi = end[w] < 0 ? 0 : end[w];
-        lo = lo > vl ? vl : lo;
-        hi = hi > vl ? vl : hi;
-        const int64_t size = hi > lo ? hi - lo : 0;
-        int64_t* o = out + w * n;
-        bool bad = size == 0;
-        if (!bad) {
-            const double step = (double)size / (double)n;
-            const int64_t avg = size / n;
-            uint32_t rng = 0, mask = 0;
-            if (random && avg > 1) {
-                if (avg - 1 > 0xFFFFFFFFLL) return -2;
-                rng = (uint32_t)(avg - 1);
-                mask = mask_of(rng);
-            }
-            for (int32_t i = 0; i < n; ++i) {
-                int64_t idx;
-                if (random && avg > 0) {
-                    const uint32_t v = avg > 1 ? mt.bounded(rng, mask) : 0u;
-                    double x = (double)i * step + (double)v;
-                    x = x < 0.0 ? 0.0 : (x > (double)size ? (double)size : x);
-                    idx = (int64_t)nearbyint(x);
-                } else {
-                    idx = (int64_t)floor((double)i * step);
-                    if (!random) idx += size / n / 2;
-                }
-                if (idx >= size) bad = true;
-                o[i] = first_row[w] + lo + idx;
-            }
-        }
-        if (bad)
-            for (int32_t i = 0; i < n; ++i) o[i] = -1;
+        const int64_t rc = window_rows_one(mt, first_row[w], video_len[w], start[w], end[w], n, random, out + w * n);
+        if (rc) return rc;
     }
     if (random) *mt_pos = mt.pos;
+    return 0;
+}
+
+/* One whole batch of a resident dataset in ONE host call (egopack_amd.data.SyntheticResidentDataset.batch, field for field).  The
+ * reference builds a batch sample by sample in Python -- Dataset.__getitem__ (data/base_dataset.py:128-155: np.take over sampled
+ * frame indices), the transform's edge list, PyG's Batch.from_data_list (utils/dataloading.py:56-70); here the dataset's per-sample
+ * tables (labels, positions, window bounds, graph TEMPLATES with their CSR arrays in both orientations) are gathered, offset and
+ * concatenated by this function.  It touches no Python object: ctypes releases the interpreter lock for its duration.  Consumes the
+ * MT19937 stream exactly as the per-window calls do.  Output arrays are the caller's (sizes: egk_host_batch in the header). */
+int64_t egk_host_build_batch(const egk_host_dataset* d, uint32_t* mt_key, int32_t* mt_pos, const int64_t* idx, int64_t B,
+                             egk_host_batch* o) {
+    if (!d || !idx || !o || B < 0 || d->T <= 0 || d->S <= 0 || d->y_elems < 0) return -3;
+    if (d->train && (!mt_key || !mt_pos || *mt_pos < 0 || *mt_pos > 624)) return -3;
+    const int64_t T = d->T, n = B * T;
+    for (int64_t b = 0; b < B; ++b)
+        if (idx[b] < 0 || idx[b] >= d->L || d->tau[idx[b]] < 0 || d->tau[idx[b]] >= d->n_tmpl) return -4;
+    // ---- store rows of the B * T action windows (window by window, in batch order: the stream position of the per-sample calls)
+    MT mt{mt_key, d->train ? *mt_pos : 0};
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t s = idx[b];
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t rc = window_rows_one(mt, d->first[s], d->vlen[s], d->starts[s * T + t], d->ends[s * T + t], d->S, d->train,
+                                               o->x_idx + (b * T + t) * d->S);
+            if (rc) return rc;
+        }
+    }
+    if (d->train) *mt_pos = mt.pos;
+    // ---- labels, positions, sequence ids
+    int64_t pmin = 0, pmax = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t s = idx[b];
+        for (int64_t e = 0; e < d->y_elems; ++e) o->y[b * d->y_elems + e] = d->y[s * d->y_elems + e];
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t p = d->pos[s * T + t];
+            o->pos[b * T + t] = p;
+            o->batch[b * T + t] = b;
+            if ((b | t) == 0 || p < pmin) pmin = p;
+            if ((b | t) == 0 || p > pmax) pmax = p;
+        }
+        o->ptr[b] = b * T;
+        o->ptr32[b] = (int32_t)(b * T);
+    }
+    o->ptr[B] = n;
+    o->ptr32[B] = (int32_t)n;
+    o->pos_min = pmin;
+    o->pos_max = pmax;
+    // ---- the batch graph: the samples' templates, node ids shifted by b * T, edge ids by the edges in front (data.GraphTemplates.assemble)
+    int64_t E = 0, nh = 0, nth = 0, dmax = 0, tdmax = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t k = d->tau[idx[b]];
+        E += d->t_e[k];
+        nh += d->t_nh[k];
+        nth += d->t_nth[k];
+        dmax = d->t_dmax[k] > dmax ? d->t_dmax[k] : dmax;
+        tdmax = d->t_tdmax[k] > tdmax ? d->t_tdmax[k] : tdmax;
+    }
+    if (E != o->E || nh > o->heavy_cap || nth > o->t_heavy_cap) return -5;  // (the caller sized the arrays from the same tables)
+    int64_t eoff = 0, hh = 0, th = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t k = d->tau[idx[b]], e = d->t_e[k], noff = b * T;
+        const int64_t* ei = d->t_ei + k * 2 * d->e_max;
+        for (int64_t p = 0; p < e; ++p) {
+            o->edge_index[eoff + p] = ei[p] + noff;
+            o->edge_index[E + eoff + p] = ei[d->e_max + p] + noff;
+            o->col[eoff + p] = (int32_t)(d->t_col[k * d->e_max + p] + noff);
+            o->t_col[eoff + p] = (int32_t)(d->t_tcol[k * d->e_max + p] + noff);
+            o->t_wgt[eoff + p] = d->t_tw[k * d->e_max + p];
+        }
+        for (int64_t i = 0; i < T; ++i) {
+            o->rowptr[noff + i] = (int32_t)(d->t_rp[k * (T + 1) + i] + eoff);
+            o->t_rowptr[noff + i] = (int32_t)(d->t_trp[k * (T + 1) + i] + eoff);
+            o->band[noff + i] = d->t_band[k * T + i];
+        }
+        for (int64_t q = 0; q < d->t_nh[k]; ++q) o->heavy[hh++] = (int32_t)(d->t_hv[k * d->h_max + q] + noff);
+        for (int64_t q = 0; q < d->t_nth[k]; ++q) o->t_heavy[th++] = (int32_t)(d->t_thv[k * d->th_max + q] + noff);
+        eoff += e;
+    }
+    o->rowptr[n] = (int32_t)E;
+    o->t_rowptr[n] = (int32_t)E;
+    o->n_heavy = nh;
+    o->n_t_heavy = nth;
+    o->heavy_mode = nh ? (dmax <= d->heavy_in_launch ? 1 : 0) : 0;
+    o->t_heavy_mode = nth ? (tdmax <= d->heavy_in_launch ? 1 : 0) : 0;
+    // ---- labelled rows of a per-node multi-head label tensor (data.live_label_rows): rows with a label in any head, in node order
+    o->n_live = -1;
+    if (d->y_heads > 0 && d->y_elems == T * d->y_heads && o->live_idx && o->live_inv && o->live_y) {
+        const int64_t H = d->y_heads;
+        int64_t cnt = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            bool any = false;
+            for (int64_t h = 0; h < H; ++h) any = any || o->y[r * H + h] != -1;
+            o->live_inv[r] = any ? cnt : -1;
+            if (any) o->live_idx[cnt++] = r;
+        }
+        if ((double)cnt <= d->live_share * (double)n) {
+            int64_t cap = (cnt + 63) / 64 * 64;
+            cap = cap < 64 ? 64 : cap;
+            if (cap > o->live_cap) return -5;
+            for (int64_t q = 0; q < cap; ++q) {
+                const int64_t r = q < cnt ? o->live_idx[q] : -1;
+                if (q >= cnt) o->live_idx[q] = -1;
+                for (int64_t h = 0; h < H; ++h) o->live_y[q * H + h] = r >= 0 ? o->y[r * H + h] : -1;
+            }
+            o->n_live = cnt;
+        }
+    }
     return 0;
 }
 

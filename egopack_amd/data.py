@@ -1117,7 +1117,105 @@ class SyntheticResidentDataset(SyntheticTaskDataset):
                 starts=np.stack([w[1] for w in self.windows]).astype(np.int64), ends=np.stack([w[2] for w in self.windows]).astype(np.int64))
         return tb
 
+    # -- the same batch from ONE native call (egk_host_build_batch): the loops' default ---------------------------------------------
+    # The vectorised builder below costs 0.2-0.3 ms of interpreter time per task batch -- with three live loaders more than half of
+    # what the training thread has per 1.3 ms step -- so the entry points ran 10-17 % behind the bench lines.  The per-sample tables are
+    # handed to the library once; a batch is then a handful of output allocations + one call that holds no Python object.
+    native_batches = True  # False: the numpy builder (the two are tested equal, field for field and in the random stream)
+
+    def _native_tables(self):
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        nt = getattr(self, "_native", None)
+        if nt is None:
+            tb = self._tables()
+            t = tb["tmpl"].tables()
+            c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+            y = tb["y"]
+            keep = dict(y=c(y.reshape(y.shape[0], -1), np.int64), pos=c(tb["pos"], np.int64), tau=c(tb["tau"], np.int64),
+                        first=c(tb["first"], np.int64), vlen=c(tb["vlen"], np.int64), starts=c(tb["starts"], np.int64),
+                        ends=c(tb["ends"], np.int64), t_e=c(t["e"], np.int64), t_ei=c(t["EI"], np.int64), t_col=c(t["COL"], np.int64),
+                        t_tcol=c(t["TCOL"], np.int64), t_tw=c(t["TW"], np.float32), t_rp=c(t["RP"], np.int64), t_trp=c(t["TRP"], np.int64),
+                        t_band=c(t["BAND"], np.uint8), t_nh=c(t["nh"], np.int64), t_nth=c(t["nth"], np.int64), t_hv=c(t["HV"], np.int64),
+                        t_thv=c(t["THV"], np.int64), t_dmax=c(t["dmax"], np.int64), t_tdmax=c(t["tdmax"], np.int64))
+            heads = int(y.shape[2]) if (y.ndim == 3 and y.shape[1] == self.T) else 0
+            d = _lib.HostDataset(T=self.T, S=self.S, train=int(self.split == "train"), y_heads=heads, L=int(y.shape[0]),
+                                 y_elems=int(keep["y"].shape[1]), heavy_in_launch=int(HEAVY_IN_LAUNCH_DEGREE),
+                                 live_share=float(LIVE_ROWS_MAX_SHARE), n_tmpl=int(keep["t_e"].shape[0]), e_max=int(keep["t_ei"].shape[2]),
+                                 h_max=int(keep["t_hv"].shape[1]), th_max=int(keep["t_thv"].shape[1]),
+                                 **{k: v.ctypes.data for k, v in keep.items()})
+            nt = self._native = dict(desc=d, keep=keep, y_shape=tuple(y.shape[1:]), heads=heads, n_templates=len(tb["tmpl"].items),
+                                     hil=int(HEAVY_IN_LAUNCH_DEGREE), share=float(LIVE_ROWS_MAX_SHARE))
+        return nt
+
     def batch(self, chunk) -> Data:
+        """The batch ``collate([self[i] for i in chunk])`` builds -- field for field, consuming ``self.rng`` exactly as the per-sample
+        calls do: by the library's host builder (``native_batches``), else by ``batch_numpy``."""
+        if not self.native_batches:
+            return self.batch_numpy(chunk)
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        from .feature_store import _mt_commit, _mt_state
+        tb = self._tables()
+        nt = self._native_tables()
+        if (nt["n_templates"] != len(tb["tmpl"].items) or nt["hil"] != int(HEAVY_IN_LAUNCH_DEGREE)
+                or nt["share"] != float(LIVE_ROWS_MAX_SHARE)):
+            self._native = None  # (the tables or a module-level threshold moved: hand them over again)
+            nt = self._native_tables()
+        keep, heads = nt["keep"], nt["heads"]
+        idx = np.ascontiguousarray(list(chunk) if not isinstance(chunk, np.ndarray) else chunk, dtype=np.int64)
+        B, T, S = int(idx.shape[0]), self.T, self.S
+        n = B * T
+        tau = keep["tau"][idx]
+        E = int(keep["t_e"][tau].sum())
+        nh, nth = int(keep["t_nh"][tau].sum()), int(keep["t_nth"][tau].sum())
+        live_cap = max(64, (n + 63) // 64 * 64) if heads else 0
+        e = np.empty
+        y = e((B, keep["y"].shape[1]), np.int64)
+        pos, bvec, ptr, ptr32 = e(n, np.int64), e(n, np.int64), e(B + 1, np.int64), e(B + 1, np.int32)
+        x_idx, ei = e((n, S), np.int64), e((2, E), np.int64)
+        rowptr, col, t_rowptr, t_col = e(n + 1, np.int32), e(E, np.int32), e(n + 1, np.int32), e(E, np.int32)
+        t_wgt, band, heavy, t_heavy = e(E, np.float32), e(n, np.uint8), e(nh, np.int32), e(nth, np.int32)
+        live_idx = e(live_cap, np.int64) if heads else None
+        live_inv = e(n, np.int64) if heads else None
+        live_y = e((live_cap, heads), np.int64) if heads else None
+        p = lambda a: a.ctypes.data if a is not None and a.size else (a.ctypes.data if a is not None else None)
+        ob = _lib.HostBatch(E=E, heavy_cap=nh, t_heavy_cap=nth, live_cap=live_cap, y=p(y), pos=p(pos), batch=p(bvec), ptr=p(ptr), ptr32=p(ptr32),
+                            x_idx=p(x_idx), edge_index=p(ei), rowptr=p(rowptr), col=p(col), t_rowptr=p(t_rowptr), t_col=p(t_col), t_wgt=p(t_wgt),
+                            band=p(band), heavy=p(heavy), t_heavy=p(t_heavy), live_idx=p(live_idx), live_inv=p(live_inv), live_y=p(live_y))
+        if self.split == "train":
+            state, key, mpos = _mt_state(self.rng)
+            rc = int(_lib.load().egk_host_build_batch(C.byref(nt["desc"]), key.ctypes.data, mpos.ctypes.data, idx.ctypes.data, B, C.byref(ob)))
+            if rc == 0:
+                _mt_commit(self.rng, state, key, mpos)
+        else:
+            rc = int(_lib.load().egk_host_build_batch(C.byref(nt["desc"]), None, None, idx.ctypes.data, B, C.byref(ob)))
+        if rc != 0:
+            raise ValueError(f"egk_host_build_batch failed (code {rc})")
+        tn = torch.from_numpy
+        ys = nt["y_shape"]
+        yv = y.reshape(-1, *ys[1:]) if (len(ys) >= 1 and ys != (1,)) else y.reshape(-1)
+        out = Data(x=None, y=tn(yv), pos=tn(pos), edge_index=tn(ei), batch=tn(bvec), ptr=tn(ptr), num_graphs=B)
+        if n:
+            out.pos_range = (int(ob.pos_min), int(ob.pos_max))
+        out.x_idx = tn(x_idx)
+        out.graph = CSRGraph(tn(rowptr), tn(col), tn(t_rowptr), tn(t_col), tn(t_wgt), n, tn(heavy), tn(t_heavy),
+                             int(ob.heavy_mode), int(ob.t_heavy_mode), tn(band))
+        out.ptr32 = tn(ptr32)
+        out.seg_ptr = tn(np.array([0, n], dtype=np.int32))
+        if heads and ob.n_live >= 0:
+            cap = max(64, (int(ob.n_live) + 63) // 64 * 64)
+            out.live_idx, out.live_inv, out.live_y = tn(live_idx[:cap]), tn(live_inv), tn(live_y[:cap])
+            ap = live_rows_progression(out.live_idx)
+            if ap is not None:
+                out.live_ap = ap
+        for key_, v in tb["scalars"].items():
+            setattr(out, key_, tn(np.ascontiguousarray(v[idx])))
+        return out
+
+    def batch_numpy(self, chunk) -> Data:
         """``collate([self[i] for i in chunk])`` -- field for field, and consuming ``self.rng`` exactly as the per-sample calls
         do -- assembled with vector arithmetic."""
         import numpy as np

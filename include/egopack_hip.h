@@ -168,6 +168,70 @@ int64_t egk_host_bounded_draws(uint32_t* mt_key, int32_t* mt_pos, const int64_t*
 int64_t egk_host_window_rows(uint32_t* mt_key, int32_t* mt_pos, const int64_t* first_row, const int64_t* video_len,
                              const int64_t* start, const int64_t* end, int64_t W, int32_t n, int32_t random, int64_t* out);
 
+/* A whole batch of a device-resident dataset in ONE host call (egopack_amd.data.SyntheticResidentDataset.batch field for field;
+ * reference: Dataset.__getitem__ data/base_dataset.py:128-155 + the transform's edges + PyG Batch.from_data_list,
+ * utils/dataloading.py:56-70, done sample by sample in Python).  ``egk_host_dataset``: the dataset's per-sample tables, built once
+ * (they are functions of its seed); ``egk_host_batch``: caller-allocated outputs.  Holds no Python object (ctypes drops the
+ * interpreter lock for the call).  0, -2 / -3 as egk_host_window_rows, -4 a sample or template index out of range, -5 an output
+ * array sized for another batch. */
+typedef struct {
+    int32_t T, S;                /* nodes per sample, segments per node */
+    int32_t train;               /* random segment sampling (consumes the MT19937 stream) */
+    int32_t y_heads;             /* > 0: labels are [T, y_heads] per sample (AR / LTA): the labelled-row lists are built too */
+    int64_t L, y_elems;          /* samples; int64 label elements per sample */
+    int64_t heavy_in_launch;     /* data.HEAVY_IN_LAUNCH_DEGREE */
+    double live_share;           /* data.LIVE_ROWS_MAX_SHARE */
+    const int64_t* y;            /* [L][y_elems] */
+    const int64_t* pos;          /* [L][T] */
+    const int64_t* tau;          /* [L] graph template of each sample */
+    const int64_t* first;        /* [L] first store row of the sample's video */
+    const int64_t* vlen;         /* [L] frames of that video */
+    const int64_t* starts;       /* [L][T] window bounds */
+    const int64_t* ends;
+    int64_t n_tmpl, e_max, h_max, th_max;
+    const int64_t* t_e;          /* [n_tmpl] edges */
+    const int64_t* t_ei;         /* [n_tmpl][2][e_max] edge lists (source row, target row) */
+    const int64_t* t_col;        /* [n_tmpl][e_max] CSR by target */
+    const int64_t* t_tcol;       /* [n_tmpl][e_max] CSR by source */
+    const float* t_tw;           /* [n_tmpl][e_max] 1 / in-degree of the target */
+    const int64_t* t_rp;         /* [n_tmpl][T + 1] */
+    const int64_t* t_trp;
+    const uint8_t* t_band;       /* [n_tmpl][T] */
+    const int64_t* t_nh;         /* [n_tmpl] listed heavy rows per orientation */
+    const int64_t* t_nth;
+    const int64_t* t_hv;         /* [n_tmpl][h_max] */
+    const int64_t* t_thv;        /* [n_tmpl][th_max] */
+    const int64_t* t_dmax;       /* [n_tmpl] largest degree per orientation */
+    const int64_t* t_tdmax;
+} egk_host_dataset;
+typedef struct {
+    int64_t E;                   /* in: edges of this batch (sum of t_e over its samples: the arrays below are sized by it) */
+    int64_t heavy_cap, t_heavy_cap, live_cap;   /* in: capacities of heavy / t_heavy / live_idx, live_y */
+    int64_t* y;                  /* [B][y_elems] */
+    int64_t* pos;                /* [B * T] */
+    int64_t* batch;              /* [B * T] */
+    int64_t* ptr;                /* [B + 1] */
+    int32_t* ptr32;              /* [B + 1] */
+    int64_t* x_idx;              /* [B * T][S] store rows (-1: an all-zero clip) */
+    int64_t* edge_index;         /* [2][E] */
+    int32_t* rowptr;             /* [B * T + 1] */
+    int32_t* col;                /* [E] */
+    int32_t* t_rowptr;
+    int32_t* t_col;
+    float* t_wgt;                /* [E] */
+    uint8_t* band;               /* [B * T] */
+    int32_t* heavy;              /* [heavy_cap] */
+    int32_t* t_heavy;
+    int64_t* live_idx;           /* [live_cap] or NULL */
+    int64_t* live_inv;           /* [B * T] or NULL */
+    int64_t* live_y;             /* [live_cap][y_heads] or NULL */
+    /* out */
+    int64_t n_heavy, n_t_heavy, n_live /* -1: not a compactable label tensor, or too many labelled rows */, pos_min, pos_max;
+    int32_t heavy_mode, t_heavy_mode;
+} egk_host_batch;
+int64_t egk_host_build_batch(const egk_host_dataset* ds, uint32_t* mt_key, int32_t* mt_pos, const int64_t* idx, int64_t B,
+                             egk_host_batch* out);
+
 /* x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): the two bf16 operands that stand for an f32
  * matrix in a three-product contraction (egk_gemm_desc extra sources).  src f32 [rows, cols] with leading dimension ld_src;
  * hi (may be NULL: only lo is wanted, e.g. when hi is the bf16 copy the optimizer already keeps) and lo bf16 [rows, cols]

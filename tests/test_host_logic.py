@@ -342,6 +342,33 @@ def test_resident_dataset_batch_builder_equals_collating_its_items(task, T, spli
         _same_fields(ref, got)
 
 
+@pytest.mark.parametrize("task", ["ar", "lta", "pnr", "oscc"])
+@pytest.mark.parametrize("T,split", [(4, "train"), (9, "train"), (22, "val"), (32, "train")])
+def test_native_batch_builder_equals_the_numpy_builder_and_the_collated_items(task, T, split):
+    """``SyntheticResidentDataset.batch`` is ONE native call (egk_host_build_batch: window rows on the dataset's
+    own MT19937 stream, labels, positions, the batch graph from the samples' templates in both CSR orientations, band codes,
+    heavy-row lists, labelled-row lists).  Field for field -- values, dtypes, shapes -- the numpy builder's batch and
+    ``collate`` of the items, with the sampling stream left where they leave it; bad indices are refused."""
+    import numpy as np
+    mk = lambda: D.SyntheticResidentDataset(task, 40, T, seed=4, split=split, n_videos=3, frames=900)
+    nat, vec, per = mk(), mk(), mk()
+    vec.native_batches = False
+    assert nat.native_batches
+    for chunk in ([0, 1, 2, 3, 4, 5, 6, 7], [39, 3, 17], [12], [5, 5, 5], list(range(40))):
+        a, b = nat.batch(chunk), vec.batch(chunk)
+        _same_fields(b, a)
+        _same_fields(D.collate([per[i] for i in chunk]), a)
+        for k in ("y", "pos", "edge_index", "x_idx", "ptr32"):
+            assert getattr(a, k).dtype == getattr(b, k).dtype and getattr(a, k).is_contiguous()
+        for f in ("rowptr", "col", "t_rowptr", "t_col", "t_wgt", "band", "heavy", "t_heavy"):
+            assert getattr(a.graph, f).dtype == getattr(b.graph, f).dtype, f
+        assert (getattr(a, "live_ap", None), a.graph.heavy_mode, a.graph.t_heavy_mode) == (getattr(b, "live_ap", None), b.graph.heavy_mode, b.graph.t_heavy_mode)
+    sa, sb, sp = nat.rng.get_state(), vec.rng.get_state(), per.rng.get_state()
+    assert sa[2] == sb[2] == sp[2] and np.array_equal(sa[1], sb[1]) and np.array_equal(sa[1], sp[1])
+    with pytest.raises((ValueError, IndexError)):
+        nat.batch([0, 40])
+
+
 def test_pack_data_round_trip_is_one_buffer_per_batch():
     b = _lta_batch(31)
     buf, spec = D.pack_data(b)
