@@ -59,6 +59,21 @@ class HostBatch(C.Structure):
                 ("rowptr", vp), ("col", vp), ("t_rowptr", vp), ("t_col", vp), ("t_wgt", vp), ("band", vp), ("heavy", vp), ("t_heavy", vp),
                 ("live_idx", vp), ("live_inv", vp), ("live_y", vp),
                 ("n_heavy", i64), ("n_t_heavy", i64), ("n_live", i64), ("pos_min", i64), ("pos_max", i64),
+                ("heavy_mode", i32), ("t_heavy_mode", i32), ("edge_cap", i64), ("live_ap_first", i64), ("live_ap_step", i64)]
+
+
+class HostPart(C.Structure):
+    """struct egk_host_part (include/egopack_hip.h): one task batch as the merged batch's builder reads it."""
+    _fields_ = [("n_nodes", i64), ("E", i64), ("n_heavy", i64), ("n_t_heavy", i64), ("edge_stride", i64), ("pos_min", i64), ("pos_max", i64),
+                ("pos", vp), ("edge_index", vp), ("rowptr", vp), ("col", vp), ("t_rowptr", vp), ("t_col", vp), ("t_wgt", vp), ("band", vp),
+                ("heavy", vp), ("t_heavy", vp), ("heavy_mode", i32), ("t_heavy_mode", i32)]
+
+
+class HostMerged(C.Structure):
+    """struct egk_host_merged (include/egopack_hip.h)."""
+    _fields_ = [("edge_cap", i64), ("pos", vp), ("edge_index", vp), ("rowptr", vp), ("col", vp), ("t_rowptr", vp), ("t_col", vp),
+                ("t_wgt", vp), ("band", vp), ("heavy", vp), ("t_heavy", vp), ("seg_ptr", vp),
+                ("n_nodes", i64), ("E", i64), ("min_seg_rows", i64), ("pos_min", i64), ("pos_max", i64),
                 ("heavy_mode", i32), ("t_heavy_mode", i32)]
 
 
@@ -157,8 +172,11 @@ SIGNATURES = {
     "egk_host_bounded_draws": (i64, [vp, vp, vp, i64, i32, vp]),
     "egk_host_window_rows": (i64, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "egk_host_build_batch": (i64, [C.POINTER(HostDataset), vp, vp, vp, i64, C.POINTER(HostBatch)]),
+    "egk_host_batch_sizes": (i64, [C.POINTER(HostDataset), vp, i64, vp]),
+    "egk_host_merge_batches": (i64, [C.POINTER(HostPart), i32, C.POINTER(HostMerged)]),
     "egk_tune": (C.c_int, [i32, i32]),
     "egk_weighted_sums": (C.c_int, [vp, vp, vp, vp, i32, vp]),
+    "egk_weighted_sums_acc": (C.c_int, [vp, vp, vp, vp, i32, vp, vp]),
     "egk_fill_scaled_multi": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     "egk_copy_blocks": (C.c_int, [vp, vp, vp, vp, i32]),
     "egk_gather_rows": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, i32, i64, i32]),

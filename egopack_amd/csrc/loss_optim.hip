@@ -335,7 +335,7 @@ struct VecList {
     int count;
 };
 
-__global__ __launch_bounds__(1024) void weighted_sums_kernel(const VecList v, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void weighted_sums_kernel(const VecList v, float* __restrict__ out, double* __restrict__ acc) {
     __shared__ float part[16];
     float total = 0.f;
     for (int k = 0; k < v.count; ++k) {
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(1024) void weighted_sums_kernel(const VecList v, fl
         if (threadIdx.x == 0) {
             float t = 0.f;
             for (int i = 0; i < 16; ++i) t += part[i];
+            if (acc) acc[k] += (double)t;  // (running per-vector sums over the steps of a training loop: egk_weighted_sums_acc)
             t *= v.coef[k];
             total = k ? total + t : t;
         }
@@ -643,6 +644,11 @@ int egk_sum_scale(egk_stream_t stream, const float* x, float* out, int64_t n, fl
 
 int egk_weighted_sums(egk_stream_t stream, const float* const* xs, const int64_t* ns, const float* coefs, int32_t count,
                       float* out) {
+    return egk_weighted_sums_acc(stream, xs, ns, coefs, count, out, nullptr);
+}
+
+int egk_weighted_sums_acc(egk_stream_t stream, const float* const* xs, const int64_t* ns, const float* coefs, int32_t count,
+                          float* out, double* acc) {
     EGK_REQUIRE(xs && ns && coefs && out, "egk_weighted_sums: null pointer");
     EGK_REQUIRE(count >= 1 && count <= MAXVEC, "egk_weighted_sums: 1..%d vectors", MAXVEC);
     VecList v{};
@@ -655,7 +661,7 @@ int egk_weighted_sums(egk_stream_t stream, const float* const* xs, const int64_t
     v.count = count;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(KID_SUM_SCALE, s, 0, bytes);
-    hipLaunchKernelGGL(weighted_sums_kernel, dim3(1), dim3(1024), 0, s, v, out);
+    hipLaunchKernelGGL(weighted_sums_kernel, dim3(1), dim3(1024), 0, s, v, out, acc);
     return check_launch("egk_weighted_sums");
 }
 

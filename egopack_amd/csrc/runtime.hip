@@ -309,13 +309,15 @@ int64_t egk_host_build_batch(const egk_host_dataset* d, uint32_t* mt_key, int32_
         tdmax = d->t_tdmax[k] > tdmax ? d->t_tdmax[k] : tdmax;
     }
     if (E != o->E || nh > o->heavy_cap || nth > o->t_heavy_cap) return -5;  // (the caller sized the arrays from the same tables)
+    if (o->edge_cap && o->edge_cap < E) return -5;
+    const int64_t ES = o->edge_cap ? o->edge_cap : E;  // row stride of edge_index
     int64_t eoff = 0, hh = 0, th = 0;
     for (int64_t b = 0; b < B; ++b) {
         const int64_t k = d->tau[idx[b]], e = d->t_e[k], noff = b * T;
         const int64_t* ei = d->t_ei + k * 2 * d->e_max;
         for (int64_t p = 0; p < e; ++p) {
             o->edge_index[eoff + p] = ei[p] + noff;
-            o->edge_index[E + eoff + p] = ei[d->e_max + p] + noff;
+            o->edge_index[ES + eoff + p] = ei[d->e_max + p] + noff;
             o->col[eoff + p] = (int32_t)(d->t_col[k * d->e_max + p] + noff);
             o->t_col[eoff + p] = (int32_t)(d->t_tcol[k * d->e_max + p] + noff);
             o->t_wgt[eoff + p] = d->t_tw[k * d->e_max + p];
@@ -329,6 +331,13 @@ int64_t egk_host_build_batch(const egk_host_dataset* d, uint32_t* mt_key, int32_
         for (int64_t q = 0; q < d->t_nth[k]; ++q) o->t_heavy[th++] = (int32_t)(d->t_thv[k * d->th_max + q] + noff);
         eoff += e;
     }
+    for (int64_t p = E; p < ES; ++p) {  // (entries of the capacity regions no row range reaches)
+        o->edge_index[p] = 0;
+        o->edge_index[ES + p] = 0;
+        o->col[p] = 0;
+        o->t_col[p] = 0;
+        o->t_wgt[p] = 0.0f;
+    }
     o->rowptr[n] = (int32_t)E;
     o->t_rowptr[n] = (int32_t)E;
     o->n_heavy = nh;
@@ -337,6 +346,7 @@ int64_t egk_host_build_batch(const egk_host_dataset* d, uint32_t* mt_key, int32_
     o->t_heavy_mode = nth ? (tdmax <= d->heavy_in_launch ? 1 : 0) : 0;
     // ---- labelled rows of a per-node multi-head label tensor (data.live_label_rows): rows with a label in any head, in node order
     o->n_live = -1;
+    o->live_ap_first = o->live_ap_step = 0;
     if (d->y_heads > 0 && d->y_elems == T * d->y_heads && o->live_idx && o->live_inv && o->live_y) {
         const int64_t H = d->y_heads;
         int64_t cnt = 0;
@@ -356,8 +366,111 @@ int64_t egk_host_build_batch(const egk_host_dataset* d, uint32_t* mt_key, int32_
                 for (int64_t h = 0; h < H; ++h) o->live_y[q * H + h] = r >= 0 ? o->y[r * H + h] : -1;
             }
             o->n_live = cnt;
+            if (cap >= 2 && cnt == cap) {  // data.live_rows_progression: the padded list is full and evenly spaced
+                const int64_t step = o->live_idx[1] - o->live_idx[0];
+                bool ap = step >= 1;
+                for (int64_t q = 1; ap && q < cap; ++q) ap = o->live_idx[q] - o->live_idx[q - 1] == step;
+                if (ap) {
+                    o->live_ap_first = o->live_idx[0];
+                    o->live_ap_step = step;
+                }
+            }
         }
     }
+    return 0;
+}
+
+int64_t egk_host_batch_sizes(const egk_host_dataset* d, const int64_t* idx, int64_t B, int64_t* out4) {
+    if (!d || !idx || !out4 || B < 0 || d->T <= 0) return -3;
+    const int64_t T = d->T, n = B * T;
+    int64_t E = 0, nh = 0, nth = 0, live = -1;
+    for (int64_t b = 0; b < B; ++b) {
+        if (idx[b] < 0 || idx[b] >= d->L || d->tau[idx[b]] < 0 || d->tau[idx[b]] >= d->n_tmpl) return -4;
+        const int64_t k = d->tau[idx[b]];
+        E += d->t_e[k];
+        nh += d->t_nh[k];
+        nth += d->t_nth[k];
+    }
+    if (d->y_heads > 0 && d->y_elems == T * d->y_heads) {
+        const int64_t H = d->y_heads;
+        int64_t cnt = 0;
+        for (int64_t b = 0; b < B; ++b) {
+            const int64_t* y = d->y + idx[b] * d->y_elems;
+            for (int64_t t = 0; t < T; ++t) {
+                bool any = false;
+                for (int64_t h = 0; h < H; ++h) any = any || y[t * H + h] != -1;
+                cnt += any;
+            }
+        }
+        if ((double)cnt <= d->live_share * (double)n) live = cnt;
+    }
+    out4[0] = E;
+    out4[1] = nh;
+    out4[2] = nth;
+    out4[3] = live;
+    return 0;
+}
+
+/* data.merge_batches / concat_csr in one host call: see the header. */
+int64_t egk_host_merge_batches(const egk_host_part* parts, int32_t count, egk_host_merged* o) {
+    if (!parts || !o || count <= 0) return -3;
+    int64_t N = 0, E = 0;
+    for (int32_t i = 0; i < count; ++i) {
+        if (parts[i].n_nodes < 0 || parts[i].E < 0 || parts[i].edge_stride < parts[i].E) return -3;
+        N += parts[i].n_nodes;
+        E += parts[i].E;
+    }
+    if (o->edge_cap && o->edge_cap < E) return -5;
+    const int64_t ES = o->edge_cap ? o->edge_cap : E;
+    int64_t noff = 0, eoff = 0, hh = 0, th = 0, min_rows = 0;
+    bool h_rows = false, h_all1 = true, th_rows = false, th_all1 = true;
+    for (int32_t i = 0; i < count; ++i) {
+        const egk_host_part& p = parts[i];
+        for (int64_t r = 0; r < p.n_nodes; ++r) {
+            o->pos[noff + r] = p.pos[r];
+            o->rowptr[noff + r] = (int32_t)(p.rowptr[r] + eoff);
+            o->t_rowptr[noff + r] = (int32_t)(p.t_rowptr[r] + eoff);
+            o->band[noff + r] = p.band[r];
+        }
+        for (int64_t e = 0; e < p.E; ++e) {
+            o->edge_index[eoff + e] = p.edge_index[e] + noff;
+            o->edge_index[ES + eoff + e] = p.edge_index[p.edge_stride + e] + noff;
+            o->col[eoff + e] = (int32_t)(p.col[e] + noff);
+            o->t_col[eoff + e] = (int32_t)(p.t_col[e] + noff);
+            o->t_wgt[eoff + e] = p.t_wgt[e];
+        }
+        for (int64_t q = 0; q < p.n_heavy; ++q) o->heavy[hh++] = (int32_t)(p.heavy[q] + noff);
+        for (int64_t q = 0; q < p.n_t_heavy; ++q) o->t_heavy[th++] = (int32_t)(p.t_heavy[q] + noff);
+        if (p.n_heavy) {
+            h_rows = true;
+            h_all1 = h_all1 && p.heavy_mode == 1;
+        }
+        if (p.n_t_heavy) {
+            th_rows = true;
+            th_all1 = th_all1 && p.t_heavy_mode == 1;
+        }
+        o->seg_ptr[i] = (int32_t)noff;
+        if (i == 0 || p.n_nodes < min_rows) min_rows = p.n_nodes;
+        if (i == 0 || p.pos_min < o->pos_min) o->pos_min = p.pos_min;
+        if (i == 0 || p.pos_max > o->pos_max) o->pos_max = p.pos_max;
+        noff += p.n_nodes;
+        eoff += p.E;
+    }
+    for (int64_t e = E; e < ES; ++e) {
+        o->edge_index[e] = 0;
+        o->edge_index[ES + e] = 0;
+        o->col[e] = 0;
+        o->t_col[e] = 0;
+        o->t_wgt[e] = 0.0f;
+    }
+    o->seg_ptr[count] = (int32_t)N;
+    o->rowptr[N] = (int32_t)E;
+    o->t_rowptr[N] = (int32_t)E;
+    o->n_nodes = N;
+    o->E = E;
+    o->min_seg_rows = min_rows;
+    o->heavy_mode = h_rows && h_all1 ? 1 : 0;
+    o->t_heavy_mode = th_rows && th_all1 ? 1 : 0;
     return 0;
 }
 

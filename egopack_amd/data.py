@@ -40,6 +40,8 @@ class Data:
     def to(self, device, non_blocking: bool = False):
         out = Data()
         for k, v in self.materialise().__dict__.items():
+            if k == "_arena":
+                continue
             if torch.is_tensor(v) or isinstance(v, CSRGraph):
                 v = v.to(device, non_blocking=non_blocking)
             elif isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
@@ -60,12 +62,15 @@ class LazyData(Data):
     individual tensors, and building them costs more host time per step than the copy they describe.  ``fill()`` returns the
     fields; attributes assigned before the first use (the feature block, fingerprints) take precedence."""
 
+    fills = 0  # batches whose views were built (tests: a replayed training step builds none)
+
     def __init__(self, fill):
         self.__dict__["_fill"] = fill
 
     def materialise(self):
         fill = self.__dict__.pop("_fill", None)
         if fill is not None:
+            LazyData.fills += 1
             for k, v in fill().items():
                 self.__dict__.setdefault(k, v)
         return self
@@ -336,6 +341,8 @@ def merge_batches(batches: Sequence[Data]) -> Data:
     positions / edges are concatenated with node offsets, and ``seg_ptr`` keeps the per-task row
     segments so that graph-LayerNorm statistics stay per task batch, as in the reference where every
     task batch is a separate backbone call (main_temporal.py:87-90)."""
+    if batches and all(b.__dict__.get("_arena") is not None and b.__dict__["_arena"].layout.kind == "task" for b in batches):
+        return _merge_arenas(batches)
     poss, eis, seg = [], [], [0]
     off = 0
     for b in batches:
@@ -448,6 +455,210 @@ class BlobRef:
         self.names = None  # what the caller calls the batches of the transfer, in order (task names, "merged")
 
 
+# ---- batches built INTO one byte buffer (the native builders) ---------------------------------------------------------------------
+# ``to_device_packed`` walks ~60 tensors per step to lay them out in one transfer buffer, and the builders allocate those tensors
+# one by one: together ~0.8 ms of interpreter time per step of the headline workload, which no training loop ever looks at (a
+# replayed step copies the transfer's buffer as a whole).  The native builders therefore write a batch's arrays straight into ONE
+# buffer at the offsets of an ``ArenaLayout`` (each array 256-byte aligned, edge-sized arrays in regions of their capacity, cleared
+# behind E); the host batch is a ``LazyData`` whose tensors are views of that buffer, built only when somebody reads a field;
+# ``merge_batches`` builds the merged batch the same way and ``to_device_packed`` moves such batches with ONE memcpy each.
+_NP_OF = {torch.int64: "int64", torch.int32: "int32", torch.uint8: "uint8", torch.float32: "float32", torch.float64: "float64",
+          torch.int16: "int16", torch.int8: "int8", torch.bool: "bool"}
+
+
+class ArenaLayout:
+    """Offsets of a batch's arrays in one buffer.  ``fields``: (name, shape, torch dtype, edge) -- ``edge``: the last axis is an
+    edge count; the region then has ``edge_cap`` entries per row and the logical array is its first E."""
+
+    def __init__(self, kind: str, fields, edge_cap: int):
+        import numpy as np
+        self.kind, self.edge_cap = kind, int(edge_cap)
+        self.fields, self.offs, off = [], {}, 0
+        for name, shape, dt, edge in fields:
+            cap = self.edge_cap if edge else 0
+            stored = (*shape[:-1], cap) if cap else tuple(shape)
+            nbytes = int(np.prod(stored, dtype=np.int64)) * torch.empty(0, dtype=dt).element_size()
+            self.fields.append((name, off, tuple(shape), dt, cap, nbytes))
+            self.offs[name] = off
+            off += (nbytes + 255) // 256 * 256
+        self.total = max(off, 256)
+        self.token = hash((kind, tuple((n, o, (*sh[:-1], c) if c else sh, str(dt)) for n, o, sh, dt, c, _ in self.fields)))
+
+    def views(self, buf: torch.Tensor, base: int, E: int, static: bool = False, only=None) -> dict:
+        """name -> tensor view of ``buf`` (uint8, host or device) for a batch whose arena starts at byte ``base``; edge-sized
+        arrays as [..., :E] of their region (``static``: the whole region -- the private buffers of a captured step)."""
+        out = {}
+        for name, off, shape, dt, cap, nbytes in self.fields:
+            if only is not None and name not in only:
+                continue
+            if not nbytes:
+                out[name] = torch.empty((*shape[:-1], E) if cap else shape, dtype=dt, device=buf.device)
+            elif cap:
+                region = buf[base + off:base + off + nbytes].view(dt).view((*shape[:-1], cap))
+                out[name] = region if static else region[..., :E]
+            else:
+                out[name] = buf[base + off:base + off + nbytes].view(dt).view(shape)
+        return out
+
+
+class Arena:
+    """One host batch in one buffer: ``buf`` (numpy uint8), its layout, the edge count, and the plain values that are not
+    arrays (``meta``: num_graphs, pos_range, heavy-row modes, ...; part of a transfer's signature)."""
+
+    def __init__(self, buf, layout: ArenaLayout, E: int, meta: dict):
+        self.buf, self.layout, self.E, self.meta = buf, layout, int(E), meta
+        self.sig = tuple(sorted(meta.items()))
+
+    def addr(self, name: str) -> int:
+        return self.buf.ctypes.data + self.layout.offs[name]
+
+
+_ARENA_EAGER = ("num_graphs", "pos_range", "live_ap", "num_segments", "min_seg_rows")
+
+
+def _arena_fields(layout: ArenaLayout, meta: dict, buf: torch.Tensor, base: int, E: int, static: bool = False) -> dict:
+    """The fields of a batch (task batch or merged batch) as views of ``buf``, in the order the tensor-by-tensor builders set them."""
+    v = layout.views(buf, base, E, static)
+    g = CSRGraph(v["graph.rowptr"], v["graph.col"], v["graph.t_rowptr"], v["graph.t_col"], v["graph.t_wgt"], meta["num_nodes"],
+                 v["graph.heavy"], v["graph.t_heavy"], meta["heavy_mode"], meta["t_heavy_mode"], v["graph.band"])
+    if layout.kind == "merged":
+        out = dict(x=None, pos=v["pos"], edge_index=v["edge_index"], graph=g, seg_ptr=v["seg_ptr"],
+                   num_segments=meta["num_segments"], min_seg_rows=meta["min_seg_rows"])
+        if "pos_range" in meta:
+            out["pos_range"] = meta["pos_range"]
+        return out
+    out = dict(x=None, y=v["y"], pos=v["pos"], edge_index=v["edge_index"], batch=v["batch"], ptr=v["ptr"], num_graphs=meta["num_graphs"])
+    if "pos_range" in meta:
+        out["pos_range"] = meta["pos_range"]
+    out.update(x_idx=v["x_idx"], graph=g, ptr32=v["ptr32"], seg_ptr=v["seg_ptr"])
+    if "live_idx" in v:
+        out.update(live_idx=v["live_idx"], live_inv=v["live_inv"], live_y=v["live_y"])
+        if "live_ap" in meta:
+            out["live_ap"] = meta["live_ap"]
+    for name in v:
+        if name.startswith("attr."):
+            out[name[5:]] = v[name]
+    return out
+
+
+def arena_batch(arena: Arena) -> "LazyData":
+    """The host batch of an arena: fields are views of its buffer, built on first use."""
+    host = torch.from_numpy(arena.buf)
+    out = LazyData(lambda: _arena_fields(arena.layout, arena.meta, host, 0, arena.E))
+    d = out.__dict__
+    d["_arena"] = arena
+    d["x"] = None
+    for k in _ARENA_EAGER:
+        if k in arena.meta:
+            d[k] = arena.meta[k]
+    if arena.layout.kind == "task":  # (the staging path reads the store rows of every step: one view, not the batch's twenty)
+        d["x_idx"] = arena.layout.views(host, 0, arena.E, only=("x_idx",))["x_idx"]
+    return out
+
+
+def _merge_arenas(batches: Sequence["Data"]) -> "Data":
+    """``merge_batches`` for batches that live in arenas: ONE host call (egk_host_merge_batches) writes the merged batch's arena."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    ars = [b._arena for b in batches]
+    k = len(ars)
+    parts = (_lib.HostPart * k)()
+    N = E = nh = nth = 0
+    for p, a in zip(parts, ars):
+        m, lay = a.meta, a.layout
+        p.n_nodes, p.E, p.n_heavy, p.n_t_heavy = m["num_nodes"], a.E, m["n_heavy"], m["n_t_heavy"]
+        p.edge_stride = lay.edge_cap or a.E
+        p.pos_min, p.pos_max = m["pos_range"]
+        p.heavy_mode, p.t_heavy_mode = m["heavy_mode"], m["t_heavy_mode"]
+        base = a.buf.ctypes.data
+        for name, fld in _PART_PTRS:
+            setattr(p, fld, base + lay.offs[name])
+        N, E, nh, nth = N + p.n_nodes, E + a.E, nh + p.n_heavy, nth + p.n_t_heavy
+    key = (k, N, edge_capacity(E), nh, nth)
+    lay = _merged_layouts.get(key)
+    if lay is None:
+        i64, i32 = torch.int64, torch.int32
+        lay = _merged_layouts[key] = ArenaLayout("merged", [
+            ("pos", (N,), i64, False), ("edge_index", (2, E), i64, True), ("graph.rowptr", (N + 1,), i32, False),
+            ("graph.col", (E,), i32, True), ("graph.t_rowptr", (N + 1,), i32, False), ("graph.t_col", (E,), i32, True),
+            ("graph.t_wgt", (E,), torch.float32, True), ("graph.heavy", (nh,), i32, False), ("graph.t_heavy", (nth,), i32, False),
+            ("graph.band", (N,), torch.uint8, False), ("seg_ptr", (k + 1,), i32, False)], edge_capacity(E))
+    buf = np.empty(lay.total, dtype=np.uint8)
+    base = buf.ctypes.data
+    om = _lib.HostMerged(edge_cap=lay.edge_cap, **{fld: base + lay.offs[name] for name, fld in _MERGED_PTRS})
+    rc = int(_lib.load().egk_host_merge_batches(parts, k, C.byref(om)))
+    if rc != 0:
+        raise ValueError(f"egk_host_merge_batches failed (code {rc})")
+    meta = dict(num_nodes=N, n_heavy=nh, n_t_heavy=nth, heavy_mode=int(om.heavy_mode), t_heavy_mode=int(om.t_heavy_mode),
+                num_segments=k, min_seg_rows=int(om.min_seg_rows), pos_range=(int(om.pos_min), int(om.pos_max)))
+    out = arena_batch(Arena(buf, lay, E, meta))
+    xs = [b.__dict__.get("x") for b in batches]
+    base_x = batches[0].__dict__.get("x_base")
+    out.x = base_x if (base_x is not None and all(b.__dict__.get("x_base") is base_x for b in batches)
+                       and base_x.shape[0] == N) else xs
+    return out
+
+
+_merged_layouts = {}
+_BATCH_PTRS = (("y", "y"), ("pos", "pos"), ("batch", "batch"), ("ptr", "ptr"), ("ptr32", "ptr32"), ("x_idx", "x_idx"),
+               ("edge_index", "edge_index"), ("graph.rowptr", "rowptr"), ("graph.col", "col"), ("graph.t_rowptr", "t_rowptr"),
+               ("graph.t_col", "t_col"), ("graph.t_wgt", "t_wgt"), ("graph.band", "band"), ("graph.heavy", "heavy"),
+               ("graph.t_heavy", "t_heavy"))
+_BATCH_PTRS_LIVE = (*_BATCH_PTRS, ("live_idx", "live_idx"), ("live_inv", "live_inv"), ("live_y", "live_y"))
+_PART_PTRS = (("pos", "pos"), ("edge_index", "edge_index"), ("graph.rowptr", "rowptr"), ("graph.col", "col"),
+              ("graph.t_rowptr", "t_rowptr"), ("graph.t_col", "t_col"), ("graph.t_wgt", "t_wgt"), ("graph.band", "band"),
+              ("graph.heavy", "heavy"), ("graph.t_heavy", "t_heavy"))
+_MERGED_PTRS = (*_PART_PTRS, ("seg_ptr", "seg_ptr"))
+
+
+def _pack_arenas(datas, device, non_blocking: bool, on_gpu: bool) -> List["Data"]:
+    """``to_device_packed`` for batches that live in arenas: one memcpy per batch into the page-locked transfer buffer, one
+    host-to-device copy, lazy views of the device buffer."""
+    ars = [d._arena for d in datas]
+    bases, total = [], 0
+    for a in ars:
+        bases.append(total)
+        total += (a.layout.total + 255) // 256 * 256
+    size = (total + 65535) // 65536 * 65536
+    if on_gpu:
+        host, slot = _pinned_ring.get((size,), torch.uint8)
+    else:
+        host, slot = torch.empty(size, dtype=torch.uint8), None
+    hn = host.numpy()
+    for a, b in zip(ars, bases):
+        hn[b:b + a.layout.total] = a.buf
+    if on_gpu:
+        dev = host.to(device, non_blocking=non_blocking)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        slot[1] = ev
+    else:
+        dev = host.clone()
+    specs = [(a.layout, a.meta, b, a.E) for a, b in zip(ars, bases)]  # (the host buffers are not kept alive by the transfer)
+
+    def rebuild(buf, static: bool = False, lazy: bool = False):
+        outs = []
+        for lay, meta, b, E in specs:
+            if lazy:
+                ld = LazyData(lambda lay=lay, meta=meta, b=b, E=E: _arena_fields(lay, meta, buf, b, E, static))
+                ld.__dict__["x"] = None
+                for k in _ARENA_EAGER:
+                    if k in meta:
+                        ld.__dict__[k] = meta[k]
+                if lay.kind == "task":
+                    ld.__dict__["x_idx"] = lay.views(buf, b, E, static, only=("x_idx",))["x_idx"]
+                outs.append(ld)
+            else:
+                outs.append(Data(**_arena_fields(lay, meta, buf, b, E, static)))
+        return outs
+    outs = rebuild(dev, lazy=True)
+    ref = BlobRef(dev, tuple((a.layout.token, b, a.sig) for a, b in zip(ars, bases)), rebuild)
+    for o in outs:
+        o._blob = ref
+    return outs
+
+
 def to_device_packed(datas: Sequence["Data"], device, non_blocking: bool = True, pack_on_cpu: bool = False) -> List["Data"]:
     """``[d.to(device) for d in datas]`` with ONE host-to-device copy: every tensor of the batches (labels, positions,
     CSR arrays, per-sample attributes ...) is laid out in one page-locked byte buffer of ``_pinned_ring`` and the device
@@ -460,6 +671,8 @@ def to_device_packed(datas: Sequence["Data"], device, non_blocking: bool = True,
     on_gpu = torch.device(device).type == "cuda"
     if not on_gpu and not pack_on_cpu:
         return [d.to(device, non_blocking=non_blocking) for d in datas]
+    if datas and all(d.__dict__.get("_arena") is not None for d in datas):
+        return _pack_arenas(datas, device, non_blocking, on_gpu)
     items = []  # (tensor, byte offset, capacity of the last axis or 0)
     total = 0
     sig = []
@@ -492,7 +705,7 @@ def to_device_packed(datas: Sequence["Data"], device, non_blocking: bool = True,
             # the scalars themselves (engine.batch_signature descends into them): part of the layout signature too
             sig.append((path, tuple(v)))
         return ("o", v, None)
-    plans = [{k: walk(v, f"{i}.{k}") for k, v in d.materialise().__dict__.items()} for i, d in enumerate(datas)]
+    plans = [{k: walk(v, f"{i}.{k}") for k, v in d.materialise().__dict__.items() if k != "_arena"} for i, d in enumerate(datas)]
     if total == 0:
         return [d.to(device, non_blocking=non_blocking) for d in datas]
     # (staging size rounded up to 64 KiB: batches whose edge counts differ by a few entries reuse one ring of buffers
@@ -785,7 +998,7 @@ def pack_data(d: "Data"):
         if isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
             return ("l", [plan(t) for t in v])
         return ("o", v)
-    spec = {k: walk(v) for k, v in d.materialise().__dict__.items()}
+    spec = {k: walk(v) for k, v in d.materialise().__dict__.items() if k != "_arena"}
     buf = torch.empty(max(total, 1), dtype=torch.uint8)
     for t, off in items:
         n = t.numel() * t.element_size()
@@ -1146,12 +1359,14 @@ class SyntheticResidentDataset(SyntheticTaskDataset):
                                  h_max=int(keep["t_hv"].shape[1]), th_max=int(keep["t_thv"].shape[1]),
                                  **{k: v.ctypes.data for k, v in keep.items()})
             nt = self._native = dict(desc=d, keep=keep, y_shape=tuple(y.shape[1:]), heads=heads, n_templates=len(tb["tmpl"].items),
-                                     hil=int(HEAVY_IN_LAUNCH_DEGREE), share=float(LIVE_ROWS_MAX_SHARE))
+                                     hil=int(HEAVY_IN_LAUNCH_DEGREE), share=float(LIVE_ROWS_MAX_SHARE), layouts={},
+                                     sizes=np.empty(4, dtype=np.int64))
         return nt
 
     def batch(self, chunk) -> Data:
         """The batch ``collate([self[i] for i in chunk])`` builds -- field for field, consuming ``self.rng`` exactly as the per-sample
-        calls do: by the library's host builder (``native_batches``), else by ``batch_numpy``."""
+        calls do: by the library's host builder (``native_batches``) straight into ONE buffer (``Arena``: the fields are views of it,
+        built when read), else by ``batch_numpy``."""
         if not self.native_batches:
             return self.batch_numpy(chunk)
         import ctypes as C
@@ -1164,55 +1379,57 @@ class SyntheticResidentDataset(SyntheticTaskDataset):
                 or nt["share"] != float(LIVE_ROWS_MAX_SHARE)):
             self._native = None  # (the tables or a module-level threshold moved: hand them over again)
             nt = self._native_tables()
-        keep, heads = nt["keep"], nt["heads"]
         idx = np.ascontiguousarray(list(chunk) if not isinstance(chunk, np.ndarray) else chunk, dtype=np.int64)
-        B, T, S = int(idx.shape[0]), self.T, self.S
-        n = B * T
-        tau = keep["tau"][idx]
-        E = int(keep["t_e"][tau].sum())
-        nh, nth = int(keep["t_nh"][tau].sum()), int(keep["t_nth"][tau].sum())
-        live_cap = max(64, (n + 63) // 64 * 64) if heads else 0
-        e = np.empty
-        y = e((B, keep["y"].shape[1]), np.int64)
-        pos, bvec, ptr, ptr32 = e(n, np.int64), e(n, np.int64), e(B + 1, np.int64), e(B + 1, np.int32)
-        x_idx, ei = e((n, S), np.int64), e((2, E), np.int64)
-        rowptr, col, t_rowptr, t_col = e(n + 1, np.int32), e(E, np.int32), e(n + 1, np.int32), e(E, np.int32)
-        t_wgt, band, heavy, t_heavy = e(E, np.float32), e(n, np.uint8), e(nh, np.int32), e(nth, np.int32)
-        live_idx = e(live_cap, np.int64) if heads else None
-        live_inv = e(n, np.int64) if heads else None
-        live_y = e((live_cap, heads), np.int64) if heads else None
-        p = lambda a: a.ctypes.data if a is not None and a.size else (a.ctypes.data if a is not None else None)
-        ob = _lib.HostBatch(E=E, heavy_cap=nh, t_heavy_cap=nth, live_cap=live_cap, y=p(y), pos=p(pos), batch=p(bvec), ptr=p(ptr), ptr32=p(ptr32),
-                            x_idx=p(x_idx), edge_index=p(ei), rowptr=p(rowptr), col=p(col), t_rowptr=p(t_rowptr), t_col=p(t_col), t_wgt=p(t_wgt),
-                            band=p(band), heavy=p(heavy), t_heavy=p(t_heavy), live_idx=p(live_idx), live_inv=p(live_inv), live_y=p(live_y))
-        if self.split == "train":
-            state, key, mpos = _mt_state(self.rng)
-            rc = int(_lib.load().egk_host_build_batch(C.byref(nt["desc"]), key.ctypes.data, mpos.ctypes.data, idx.ctypes.data, B, C.byref(ob)))
-            if rc == 0:
-                _mt_commit(self.rng, state, key, mpos)
-        else:
-            rc = int(_lib.load().egk_host_build_batch(C.byref(nt["desc"]), None, None, idx.ctypes.data, B, C.byref(ob)))
+        B, T, S, heads = int(idx.shape[0]), self.T, self.S, nt["heads"]
+        if B == 0:
+            return self.batch_numpy(chunk)
+        lib, n = _lib.load(), B * T
+        sizes = nt["sizes"]
+        rc = int(lib.egk_host_batch_sizes(C.byref(nt["desc"]), idx.ctypes.data, B, sizes.ctypes.data))
         if rc != 0:
+            raise ValueError(f"batch: sample index out of range (egk_host_batch_sizes: code {rc})")
+        E, nh, nth, n_live = (int(v) for v in sizes)
+        live_cap = max(64, (n_live + 63) // 64 * 64) if n_live >= 0 else 0
+        key = (B, edge_capacity(E), nh, nth, live_cap)
+        lay = nt["layouts"].get(key)
+        if lay is None:
+            i64, i32 = torch.int64, torch.int32
+            ys = nt["y_shape"]
+            y_shape = (n, *ys[1:]) if (len(ys) >= 1 and ys != (1,)) else (B * int(np.prod(ys, dtype=np.int64)),)
+            fields = [("y", y_shape, i64, False), ("pos", (n,), i64, False), ("edge_index", (2, E), i64, True), ("batch", (n,), i64, False),
+                      ("ptr", (B + 1,), i64, False), ("x_idx", (n, S), i64, False), ("graph.rowptr", (n + 1,), i32, False),
+                      ("graph.col", (E,), i32, True), ("graph.t_rowptr", (n + 1,), i32, False), ("graph.t_col", (E,), i32, True),
+                      ("graph.t_wgt", (E,), torch.float32, True), ("graph.heavy", (nh,), i32, False), ("graph.t_heavy", (nth,), i32, False),
+                      ("graph.band", (n,), torch.uint8, False), ("ptr32", (B + 1,), i32, False), ("seg_ptr", (2,), i32, False)]
+            if live_cap:
+                fields += [("live_idx", (live_cap,), i64, False), ("live_inv", (n,), i64, False), ("live_y", (live_cap, heads), i64, False)]
+            fields += [(f"attr.{k}", (B,), torch.from_numpy(v[:1]).dtype, False) for k, v in tb["scalars"].items()]
+            lay = nt["layouts"][key] = ArenaLayout("task", fields, edge_capacity(E))
+        buf = np.empty(lay.total, dtype=np.uint8)
+        base, offs = buf.ctypes.data, lay.offs
+        ob = _lib.HostBatch(E=E, heavy_cap=nh, t_heavy_cap=nth, live_cap=live_cap, edge_cap=lay.edge_cap,
+                            **{fld: base + offs[name] for name, fld in (_BATCH_PTRS_LIVE if live_cap else _BATCH_PTRS)})
+        if self.split == "train":
+            state, mkey, mpos = _mt_state(self.rng)
+            rc = int(lib.egk_host_build_batch(C.byref(nt["desc"]), mkey.ctypes.data, mpos.ctypes.data, idx.ctypes.data, B, C.byref(ob)))
+            if rc == 0:
+                _mt_commit(self.rng, state, mkey, mpos)
+        else:
+            rc = int(lib.egk_host_build_batch(C.byref(nt["desc"]), None, None, idx.ctypes.data, B, C.byref(ob)))
+        if rc != 0 or int(ob.n_live) != n_live:
             raise ValueError(f"egk_host_build_batch failed (code {rc})")
-        tn = torch.from_numpy
-        ys = nt["y_shape"]
-        yv = y.reshape(-1, *ys[1:]) if (len(ys) >= 1 and ys != (1,)) else y.reshape(-1)
-        out = Data(x=None, y=tn(yv), pos=tn(pos), edge_index=tn(ei), batch=tn(bvec), ptr=tn(ptr), num_graphs=B)
-        if n:
-            out.pos_range = (int(ob.pos_min), int(ob.pos_max))
-        out.x_idx = tn(x_idx)
-        out.graph = CSRGraph(tn(rowptr), tn(col), tn(t_rowptr), tn(t_col), tn(t_wgt), n, tn(heavy), tn(t_heavy),
-                             int(ob.heavy_mode), int(ob.t_heavy_mode), tn(band))
-        out.ptr32 = tn(ptr32)
-        out.seg_ptr = tn(np.array([0, n], dtype=np.int32))
-        if heads and ob.n_live >= 0:
-            cap = max(64, (int(ob.n_live) + 63) // 64 * 64)
-            out.live_idx, out.live_inv, out.live_y = tn(live_idx[:cap]), tn(live_inv), tn(live_y[:cap])
-            ap = live_rows_progression(out.live_idx)
-            if ap is not None:
-                out.live_ap = ap
-        for key_, v in tb["scalars"].items():
-            setattr(out, key_, tn(np.ascontiguousarray(v[idx])))
+        seg = buf[offs["seg_ptr"]:offs["seg_ptr"] + 8].view(np.int32)
+        seg[0], seg[1] = 0, n
+        for k, v in tb["scalars"].items():
+            o = offs[f"attr.{k}"]
+            buf[o:o + B * v.itemsize].view(v.dtype)[:] = v[idx]
+        meta = dict(num_graphs=B, num_nodes=n, n_heavy=nh, n_t_heavy=nth, heavy_mode=int(ob.heavy_mode), t_heavy_mode=int(ob.t_heavy_mode),
+                    pos_range=(int(ob.pos_min), int(ob.pos_max)))
+        if live_cap and ob.live_ap_step > 0:
+            meta["live_ap"] = (int(ob.live_ap_first), int(ob.live_ap_step), live_cap)
+        out = arena_batch(Arena(buf, lay, E, meta))
+        # graph-structure fingerprint (engine.structure_key): the samples' graph templates determine the edges, B and T the sequences
+        out.__dict__["_struct_key"] = hash((id(self), B, nt["keep"]["tau"][idx].tobytes())) or 1
         return out
 
     def batch_numpy(self, chunk) -> Data:

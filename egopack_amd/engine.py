@@ -13,6 +13,8 @@
 from __future__ import annotations
 
 import os
+import queue
+import threading
 from typing import Dict, Mapping, Optional, Sequence
 
 import torch
@@ -30,6 +32,8 @@ STRUCTURE_FIELDS = ("edge_index", "batch", "ptr", "ptr32", "graph")
 
 def structure_key(b: Data) -> int:
     """Host-side fingerprint of a batch's graph structure: sequence boundaries and edges (the CSR arrays derive from them)."""
+    if b.__dict__.get("_arena") is not None and b.__dict__.get("_struct_key"):
+        return b.__dict__["_struct_key"]  # (the native builder's: a hash of the samples' graph templates)
     parts = []
     for name in ("edge_index", "ptr"):
         v = getattr(b, name, None)
@@ -50,6 +54,8 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, 
     live = [t for t in order if host.get(t) is not None]
     resident = store is not None and all(getattr(host[t], "x", None) is None and getattr(host[t], "x_idx", None) is not None
                                          for t in live)
+    if resident and all(host[t].__dict__.get("_arena") is not None for t in live):
+        return _stage_arenas([host[t] for t in live], live, device, store, dtype)
     if resident:
         idx = torch.cat([host[t].x_idx for t in live])
         if pin and idx.device.type == "cpu":
@@ -101,7 +107,37 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, 
     return dev, md
 
 
+def _stage_arenas(hs, live, device, store, dtype):
+    """``stage_batches`` for batches the native builder wrote into arenas (data.Arena): the merged batch comes from one host call,
+    every batch travels as one memcpy into the transfer buffer -- the store rows with it -- and the packed feature block is gathered
+    task by task from the device copy of those rows.  No tensor of the step is touched on the host."""
+    from .data import to_device_packed
+    merged = merge_batches(hs)
+    merged.x = None
+    moved = to_device_packed([*hs, merged], device)
+    rows = [h._arena.meta["num_nodes"] for h in hs]
+    idx0 = moved[0].__dict__["x_idx"]
+    dbuf = torch.empty((sum(rows), idx0.shape[1], store.features_size), dtype=dtype or store.table.dtype, device=idx0.device)
+    dev, off = {}, 0
+    for t, n, h, d in zip(live, rows, hs, moved[:-1]):
+        store.gather(d.__dict__["x_idx"], out=dbuf[off:off + n], dtype=dtype)
+        d.x = dbuf[off:off + n]
+        d.x_base = dbuf
+        d._struct_key = h.__dict__.get("_struct_key", 0)
+        dev[t] = d
+        off += n
+    md = moved[-1]
+    md.x = md.x_base = dbuf
+    if getattr(md, "_blob", None) is not None:
+        md._blob.names = [*live, "merged"]
+    md._struct_key = hash(tuple(dev[t]._struct_key for t in live)) or 1
+    return dev, md
+
+
 _COPY_STREAMS = {}  # device index -> the staging copy stream (StagedBatches)
+
+
+STAGE_LOCK = threading.RLock()  # held by StagedBatches' thread while it stages, and by eager steps / captures (see ``_ahead``)
 
 
 class StagedBatches:
@@ -111,8 +147,10 @@ class StagedBatches:
     ``stage_batches`` returns them (``merged`` None for a single task / per-task backbone passes), already ordered behind
     the copy on the consumer's stream."""
 
-    def __init__(self, host_iter, device, order=TASK_ORDER, fused: bool = True, store=None, dtype=None):
+    def __init__(self, host_iter, device, order=TASK_ORDER, fused: bool = True, store=None, dtype=None, depth: Optional[int] = None):
         self.it, self.device, self.order, self.fused, self.store, self.dtype = iter(host_iter), device, order, fused, store, dtype
+        # steps staged ahead by the staging thread (0: staged inline, right behind the consumer's launch of the step before)
+        self.depth = (2 if switches.enabled("staging_thread") else 0) if depth is None else int(depth)
         # ONE copy stream per device for the life of the process: the caching allocator keeps a pool per stream, so a fresh
         # stream per epoch stranded every epoch's staging blocks in a pool nobody allocates from again (reserved memory grew
         # by ~130 MB per epoch of the headline workload while the allocated bytes stayed flat)
@@ -152,13 +190,64 @@ class StagedBatches:
             done.record(self.copy_stream)
         return staged, done
 
+    def _ahead(self):
+        """``_fetch`` results from a thread of their own, ``depth`` steps ahead (None ends the walk, an exception is re-raised in
+        the consumer).  The thread holds ``STAGE_LOCK`` while it stages: eager steps and captures take the same lock, so that
+        nothing of another thread touches the HIP runtime while a capture is open and the launch-order bookkeeping of ``ops``
+        has ONE writer; replays of the captured step -- every steady-state step -- do not take it and overlap the staging."""
+        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def produce():
+            try:
+                torch.cuda.set_device(self.copy_stream.device)
+                while not stop.is_set():
+                    with STAGE_LOCK:
+                        nxt = self._fetch()
+                    if not put(nxt) or nxt is None:
+                        return
+            except BaseException as e:  # noqa: BLE001 (handed to the consumer)
+                put(e)
+        if switches.debug("stage_profile"):
+            inner = produce
+
+            def produce():  # noqa: F811 (development: where the staging thread's time goes)
+                import cProfile
+                import pstats
+                pr = cProfile.Profile()
+                try:
+                    pr.runcall(inner)
+                finally:
+                    pstats.Stats(pr).sort_stats("tottime").print_stats(35)
+        th = threading.Thread(target=produce, name="egk-staging", daemon=True)
+        th.start()
+        try:
+            while True:
+                nxt = q.get()
+                if nxt is None:
+                    return
+                if isinstance(nxt, BaseException):
+                    raise nxt
+                yield nxt
+        finally:
+            stop.set()
+            th.join(timeout=10.0)
+
     def __iter__(self):
         def inline():
             nxt = self._fetch()
             while nxt is not None:
                 yield nxt
                 nxt = self._fetch()  # issued right after the consumer launched its step: overlaps it
-        for nxt in inline():
+        for nxt in (self._ahead() if (self.copy_stream is not None and self.depth > 0) else inline()):
             (batches, merged), done = nxt
             if done is not None:
                 cur = torch.cuda.current_stream()
@@ -479,6 +568,47 @@ class StepBase:
         ops.scope_excluded_streams([*getattr(self, "_head_streams", ()), *(getattr(g1, "_task_streams", ()) if g1 is not None else ()),
                                     getattr(self, "_precise_side", None)])
 
+    # ---- running per-task loss sums (what a training loop logs per epoch: reference main_temporal.py:129-134) -----------------------
+    # The reference keeps them with ``.item()`` per step; kept as ``sum()`` + ``add_`` launches between two replays of the captured
+    # step they were nine launches (48 us) on the stream every replay waits for.  They accumulate INSIDE the step instead: one f64
+    # slot per enabled task, added to by the objective's launch (or a one-workgroup launch of their own) beside the parked weight
+    # gradients; the host only counts elements.  ``loss_sums()`` reads (and clears) them: one synchronisation per epoch.
+    def _loss_acc_for(self, device):
+        acc = getattr(self, "_loss_acc", None)
+        if acc is None or acc.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the loss accumulators must exist before a capture (run one eager step, or loss_sums(), first)")
+            acc = self._loss_acc = torch.zeros(max(len(self.enabled), 1), dtype=torch.float64, device=device)
+            self._loss_scratch = torch.zeros(1, dtype=torch.float32, device=device)
+        return acc
+
+    @torch.no_grad()
+    def _ride_loss_sums(self, vectors) -> None:
+        live = [v for v in vectors.values() if v is not None]
+        if not live or not live[0].is_cuda:
+            return
+        acc, order = self._loss_acc_for(live[0].device), list(self.enabled)
+        src = {t: v.detach() for t, v in vectors.items()}
+        ops.park_rider(lambda: ops.weighted_mean_sum_into(self._loss_scratch, [src.get(t) for t in order], [0.0] * len(order), acc=acc),
+                       tuple(src.values()))
+
+    def _count_losses(self, vectors) -> None:
+        cnt = self.__dict__.setdefault("_loss_counts", {})
+        for t, v in vectors.items():
+            cnt[t] = cnt.get(t, 0) + int(v.numel())
+
+    def loss_sums(self, reset: bool = True) -> Dict[str, tuple]:
+        """{task: (sum of its per-element losses, elements)} over the steps since the last reset (one device synchronisation)."""
+        acc = getattr(self, "_loss_acc", None)
+        cnt = self.__dict__.setdefault("_loss_counts", {})
+        vals = acc.tolist() if acc is not None else [0.0] * len(self.enabled)
+        out = {t: (float(vals[k]), int(cnt.get(t, 0))) for k, t in enumerate(self.enabled)}
+        if reset:
+            if acc is not None:
+                acc.zero_()
+            cnt.clear()
+        return out
+
     def _objective(self, vectors, counts=None):
         order = [t for t in self.enabled if t in vectors]
         return ops.weighted_mean_sum([vectors[t] for t in order], [self.weights[t] for t in order],
@@ -530,12 +660,16 @@ class StepBase:
         return total, vectors
 
     def step(self, batches: Mapping[str, Data], merged: Optional[Data] = None):
-        if self._use_stages():
-            return self._staged_step(batches, merged)
-        with self._learn_single_writers():
-            total, vectors = self.forward_backward(batches, merged)
-        self._exchange_and_update()
-        return total.detach(), {t: v.detach() for t, v in vectors.items()}
+        with STAGE_LOCK:
+            if self._use_stages():
+                out = self._staged_step(batches, merged)
+            else:
+                with self._learn_single_writers():
+                    total, vectors = self.forward_backward(batches, merged)
+                self._exchange_and_update()
+                out = total.detach(), {t: v.detach() for t, v in vectors.items()}
+            self._count_losses(out[1])
+            return out
 
     # ---- gradient slots with one writer per step: stored, not cleared + accumulated (optim.FlatAdam.learn_begin / store_begin) ------
     # Learnt from the EAGER steps of every execution structure (one-piece and staged), applied to every CAPTURE (one rank, the
@@ -587,6 +721,7 @@ class StepBase:
     def _backward_pass(self, batches, merged=None):
         """Forward + backward of the objective (gradients accumulate into the parameters' slots): (objective, loss vectors)."""
         total, vectors, _ = self.losses(batches, merged)
+        self._ride_loss_sums(vectors)
         self._join_zero()
         # (the seed of the objective's backward is a persistent 1.0: ``backward()`` without it fills a fresh tensor with a torch
         #  kernel on the chain, between the loss and the first backward launch)
@@ -767,20 +902,22 @@ class StepBase:
         write them differently (another live-task set: MTL loaders of unequal length, per-task backbone passes) the provider or
         its end-of-capture check raises -- the capture is then taken once more with every slot cleared and accumulated, and
         ``capture_notes`` says so: a slower step, never a crash of the training loop and never a wrong gradient."""
-        try:
-            return self._capture_once(batches, merged, warmup)
-        except RuntimeError as e:
-            if not str(e).startswith("grad_store:") or getattr(self, "_grad_store_off", False):
-                raise
-            if self.sync is not None and self.sync.world > 1 and self._one_graph_exchange_ok():
-                raise  # (a failed capture that holds collectives is not retried in this process: see one_graph_exchange)
-            torch.cuda.synchronize()
-            self._grad_store_off = True
-            self.capture_notes = [*getattr(self, "capture_notes", []), f"stored gradient slots off for this step ({e})"]
-            return self._capture_once(batches, merged, 0)
+        with STAGE_LOCK:  # (a staging thread makes no HIP call while a capture is open: StagedBatches._ahead)
+            try:
+                return self._capture_once(batches, merged, warmup)
+            except RuntimeError as e:
+                if not str(e).startswith("grad_store:") or getattr(self, "_grad_store_off", False):
+                    raise
+                if self.sync is not None and self.sync.world > 1 and self._one_graph_exchange_ok():
+                    raise  # (a failed capture that holds collectives is not retried in this process: see one_graph_exchange)
+                torch.cuda.synchronize()
+                self._grad_store_off = True
+                self.capture_notes = [*getattr(self, "capture_notes", []), f"stored gradient slots off for this step ({e})"]
+                return self._capture_once(batches, merged, 0)
 
     def _capture_once(self, batches, merged, warmup):
         opt = self.optimizer
+        self._loss_acc_for(next(self.model.parameters()).device)  # (the running loss sums' slots: allocated outside the capture)
         if self._exact_ln_on() and not self._one_graph_exchange_ok():
             raise RuntimeError("exact_graph_ln sums the graph-LayerNorm statistics over the ranks inside the step: this process "
                                "group's collectives cannot be captured in a hipGraph -- use step() / train_step() (eager) in this mode")
@@ -1186,6 +1323,7 @@ class StepBase:
 
     def replay(self):
         """One training step from the captured graph(s)."""
+        self._count_losses(self._static_out[1])
         opt = self.optimizer
         if not getattr(self, "_rng_in_graph", False):
             ops.advance_rng_device(opt.flat_p.device)
@@ -1428,11 +1566,16 @@ class MTLStep(StepBase):
             cnt = {t: (n_full[t] if t in compact_v else None) for t in vectors}
             if not switches.enabled("objective_rider") or not src:
                 total = self._objective(src, cnt)
+                self._ride_loss_sums(src)
             else:
-                order = [t for t in self.enabled if t in src]
-                total = torch.empty((), dtype=torch.float32, device=src[order[0]].device)
-                ops.park_rider(lambda: ops.weighted_mean_sum_into(total, [src[t] for t in order], [self.weights[t] for t in order],
-                                                                  [cnt[t] for t in order]), (total, *[src[t] for t in order]))
+                # (every enabled task has its slot in the launch -- absent ones add exactly 0 -- so that the running per-task loss
+                #  sums, ``loss_sums``, accumulate in the same launch at fixed positions)
+                order = list(self.enabled)
+                total = torch.empty((), dtype=torch.float32, device=next(iter(src.values())).device)
+                acc = self._loss_acc_for(total.device)
+                ops.park_rider(lambda: ops.weighted_mean_sum_into(total, [src.get(t) for t in order], [self.weights[t] for t in order],
+                                                                  [cnt.get(t) for t in order], acc=acc),
+                               (total, *[src[t] for t in order if t in src]))
         return total, vectors, leaves
 
     compact_heads = True  # heads on the labelled rows only (data.live_label_rows); EGK_DISABLE=compact_heads: every row

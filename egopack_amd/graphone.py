@@ -70,4 +70,6 @@ def build_graphone(model, ar_task, tasks: List, dataloader, device="cuda", group
         dist.all_reduce(count, group=group)
         for bank in banks.values():  # |V|*|N| x H fp64 each (450 MB at Ego4D sizes): one collective per task, once
             dist.all_reduce(bank, group=group)
-    return finalise_banks(banks, count)
+    out = finalise_banks(banks, count)
+    logger.info("prototype banks: %s", ", ".join(f"{k} {tuple(v.shape)}" for k, v in out.items()))
+    return out

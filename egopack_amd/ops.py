@@ -3340,17 +3340,23 @@ class _WeightedMeanSum(torch.autograd.Function):
 
 
 @torch.no_grad()
-def weighted_mean_sum_into(out, vectors, weights, counts=None):
-    """``weighted_mean_sum`` without autograd, written into ``out`` (an f32 tensor of one element)."""
+def weighted_mean_sum_into(out, vectors, weights, counts=None, acc=None):
+    """``weighted_mean_sum`` without autograd, written into ``out`` (an f32 tensor of one element).  ``acc`` (f64 [len(vectors)],
+    optional): acc[k] += vectors[k].sum() in the same launch -- the running loss sums of a training loop (a ``None`` vector adds 0)."""
     import ctypes as C_
     k = len(vectors)
-    vs = [_f32c(v) for v in vectors]
+    vs = [_f32c(v) if v is not None else None for v in vectors]
     counts = counts if counts is not None else [None] * k
-    coefs = [float(w) / max(v.numel() if c is None else c, 1) for w, v, c in zip(weights, vs, counts)]
-    xs = (C_.c_void_p * k)(*[v.data_ptr() if v.numel() else None for v in vs])
-    ns = (C_.c_int64 * k)(*[v.numel() for v in vs])
+    coefs = [0.0 if v is None else float(w) / max(v.numel() if c is None else c, 1) for w, v, c in zip(weights, vs, counts)]
+    xs = (C_.c_void_p * k)(*[v.data_ptr() if (v is not None and v.numel()) else None for v in vs])
+    ns = (C_.c_int64 * k)(*[v.numel() if v is not None else 0 for v in vs])
     cf = (C_.c_float * k)(*coefs)
-    _ck(_lib.load().egk_weighted_sums(_stream(), xs, ns, cf, k, _p(out)), "egk_weighted_sums")
+    if acc is None:
+        _ck(_lib.load().egk_weighted_sums(_stream(), xs, ns, cf, k, _p(out)), "egk_weighted_sums")
+    else:
+        if acc.dtype != torch.float64 or acc.numel() < k or not acc.is_contiguous():
+            raise ValueError("weighted_mean_sum_into: acc must be a contiguous float64 tensor with one element per vector")
+        _ck(_lib.load().egk_weighted_sums_acc(_stream(), xs, ns, cf, k, _p(out), _p(acc)), "egk_weighted_sums_acc")
     return out
 
 

@@ -41,6 +41,7 @@ REGISTRY = {
     "grad_store": (True, "gradient slots with one writer per step are stored, not cleared and accumulated (every capture)"),
     "zero_stream": (True, "the gradient buffer is cleared beside the forward pass on a stream of its own"),
     "zero_deferred": (True, "... issued behind the forward pass's first launch"),
+    "staging_thread": (True, "training loops: the next steps' batches are built and copied by a thread of their own, two steps ahead"),
     "hyper_in_graph": (True, "the step's Adam constants are computed inside the captured graph"),
     "rng_in_graph": (True, "the dropout offset word moves on inside the captured graph"),
     "rng_early": (True, "... inside the first optimizer launch beside the last weight gradient"),
@@ -81,6 +82,7 @@ REGISTRY = {
 DEBUG = {
     "window_cand": "print the candidate statistics of eager window searches",
     "serial_precise": "measurement: the precise pass and the training pass one after the other",
+    "stage_profile": "print a cProfile of the staging thread (engine.StagedBatches) when a training loop's epoch ends",
 }
 
 # numeric / string knobs with a variable of their own (development A/B; defaults in the code that reads them)

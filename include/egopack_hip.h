@@ -228,9 +228,56 @@ typedef struct {
     /* out */
     int64_t n_heavy, n_t_heavy, n_live /* -1: not a compactable label tensor, or too many labelled rows */, pos_min, pos_max;
     int32_t heavy_mode, t_heavy_mode;
+    /* in: 0 = edge_index is [2][E]; > 0 = the edge-sized arrays live in regions of this CAPACITY (>= E) of a packed transfer
+     * buffer (data.EDGE_BUCKET): edge_index is [2][edge_cap] and entries E .. edge_cap of edge_index / col / t_col / t_wgt are
+     * cleared, as data.to_device_packed does */
+    int64_t edge_cap;
+    /* out: the padded labelled-row list is the arithmetic progression first, first + step, ... (data.live_rows_progression);
+     * step 0: it is not */
+    int64_t live_ap_first, live_ap_step;
 } egk_host_batch;
 int64_t egk_host_build_batch(const egk_host_dataset* ds, uint32_t* mt_key, int32_t* mt_pos, const int64_t* idx, int64_t B,
                              egk_host_batch* out);
+/* What the caller sizes a batch's arrays by, from the dataset's tables alone: out4 = {E, listed heavy rows, listed heavy rows of
+ * the transposed orientation, labelled rows (-1 as n_live above)}.  0 / -3 / -4 as egk_host_build_batch. */
+int64_t egk_host_batch_sizes(const egk_host_dataset* ds, const int64_t* idx, int64_t B, int64_t* out4);
+
+/* The merged batch of a fused backbone pass from its task batches in ONE host call (egopack_amd.data.merge_batches / concat_csr
+ * field for field; the reference runs the backbone per task batch, main_temporal.py:87-90): positions concatenated, edge lists and
+ * both CSR orientations concatenated with node / edge offsets, the heavy-row lists shifted, segment boundaries.  ``parts``: the
+ * task batches in order (pointers as egk_host_batch filled them; edge_stride = the row stride of their edge_index). */
+typedef struct {
+    int64_t n_nodes, E, n_heavy, n_t_heavy, edge_stride, pos_min, pos_max;
+    const int64_t* pos;
+    const int64_t* edge_index;
+    const int32_t* rowptr;
+    const int32_t* col;
+    const int32_t* t_rowptr;
+    const int32_t* t_col;
+    const float* t_wgt;
+    const uint8_t* band;
+    const int32_t* heavy;
+    const int32_t* t_heavy;
+    int32_t heavy_mode, t_heavy_mode;
+} egk_host_part;
+typedef struct {
+    int64_t edge_cap;            /* in: as egk_host_batch.edge_cap (0: [2][sum E]) */
+    int64_t* pos;                /* [sum n] */
+    int64_t* edge_index;
+    int32_t* rowptr;             /* [sum n + 1] */
+    int32_t* col;
+    int32_t* t_rowptr;
+    int32_t* t_col;
+    float* t_wgt;
+    uint8_t* band;               /* [sum n] */
+    int32_t* heavy;              /* [sum n_heavy] */
+    int32_t* t_heavy;
+    int32_t* seg_ptr;            /* [count + 1] */
+    /* out */
+    int64_t n_nodes, E, min_seg_rows, pos_min, pos_max;
+    int32_t heavy_mode, t_heavy_mode;
+} egk_host_merged;
+int64_t egk_host_merge_batches(const egk_host_part* parts, int32_t count, egk_host_merged* out);
 
 /* x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): the two bf16 operands that stand for an f32
  * matrix in a three-product contraction (egk_gemm_desc extra sources).  src f32 [rows, cols] with leading dimension ld_src;
@@ -627,6 +674,10 @@ int egk_adam_hyper(egk_stream_t s, const float* src, int64_t* t_dev, double beta
  * out[0] = sum_k coefs[k] * sum(xs[k][0..ns[k])), terms added in k order (count <= 8; xs / ns / coefs are HOST arrays);
  * backward: outs[k][i] = scalar[0] * coefs[k]. */
 int egk_weighted_sums(egk_stream_t s, const float* const* xs, const int64_t* ns, const float* coefs, int32_t count, float* out);
+/* ... and acc[k] += sum(xs[k]) (device double[count], may be NULL): the per-task loss sums a training loop logs per epoch
+ * (main_temporal.py:129-134 keeps them with .item() per step) accumulate inside the step instead of in launches between steps. */
+int egk_weighted_sums_acc(egk_stream_t s, const float* const* xs, const int64_t* ns, const float* coefs, int32_t count, float* out,
+                          double* acc);
 int egk_fill_scaled_multi(egk_stream_t s, const float* scalar, const float* coefs, float* const* outs, const int64_t* ns,
                           int32_t count);
 /* dst = srcs[0] | srcs[1] | ... : count <= 8 contiguous blocks of nbytes[k] bytes each, a NULL source zero-fills its

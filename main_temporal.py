@@ -37,20 +37,14 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda", store=No
     for t in step.tasks.values():
         t.train()
     order = ("ar", "lta", "oscc", "pnr")
-    it, sums, counts = 0, {t: None for t in order}, {t: 0 for t in order}  # loss sums stay on the device until the epoch ends
+    it = 0
+    step.loss_sums()  # (clears the per-task loss sums: they accumulate inside the step, on the device, until the epoch ends)
     hosts = (dict(zip(order, batch)) for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]))
-    # batch i + 1 is collated and copied to the device (copy stream) while step i runs
+    # batch i + 1 is built and copied to the device (staging thread, copy stream) while step i runs
     mark = None  # (iteration, wall clock, sequences so far) once the eager steps and the capture are behind: steady-state rate
     seqs = 0
     for batches, merged in engine.StagedBatches(hosts, device, order, fused=step.fused, store=store, dtype=ops.act_dtype()):
-        total, vectors = step.train_step(batches, merged)  # eager for the first steps, then the captured step
-        for t, v in vectors.items():  # (no host synchronisation per step: the next batch is staged while this one runs)
-            s_ = v.detach().sum(dtype=torch.float64)
-            if sums[t] is None:
-                sums[t] = s_
-            else:
-                sums[t].add_(s_)
-            counts[t] += v.numel()
+        step.train_step(batches, merged)  # eager for the first steps, then the captured step (no launch of this loop between two)
         seqs += sum(int(b.num_graphs) for b in batches.values() if b is not None)
         it += 1
         if it == RATE_WARMUP_STEPS and torch.cuda.is_available():
@@ -63,7 +57,7 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda", store=No
                     "device memory %.0f MB allocated, %.0f MB reserved", epoch, dt * 1e3 / (it - mark[0]), (seqs - mark[2]) / dt,
                     it - mark[0], mark[0], torch.cuda.memory_allocated() / 2 ** 20, torch.cuda.memory_reserved() / 2 ** 20)
     logger.info("epoch %d: %d iterations, train loss %s", epoch, it,
-                {t: round(float(sums[t]) / max(counts[t], 1), 4) for t in order if counts[t]})
+                {t: round(s_ / max(n_, 1), 4) for t, (s_, n_) in step.loss_sums().items() if n_})
     lc = getattr(step, "loop_counts", None)
     if lc is not None:  # how many steps replayed the captured graph and how many ran eagerly (shape changes, warm-up)
         logger.info("epoch %d: %d steps replayed the captured step, %d ran eagerly", epoch, lc["replayed"], lc["eager"])

@@ -143,6 +143,14 @@ def test_train_step_replays_the_captured_step_on_static_shape_batches():
                 total, vectors = step.train_step(batches, merged)
                 losses.append((float(total), {t: v.clone() for t, v in vectors.items()}))
         torch.cuda.synchronize()
+        # the running per-task loss sums accumulate inside the step (eager and replayed alike): what a loop that sums the returned
+        # vectors step by step would log
+        sums = step.loss_sums()
+        for t in ("ar", "lta", "pnr"):
+            want = sum(float(v[t].double().sum()) for _, v in losses)
+            assert sums[t][1] == sum(v[t].numel() for _, v in losses)
+            assert abs(sums[t][0] - want) <= 1e-5 * max(abs(want), 1.0), (t, sums[t], want)
+        assert "oscc" not in sums and step.loss_sums()["ar"] == (0.0, 0)  # (enabled tasks only; reading clears them)
         return opt.flat_p.clone(), losses, step
 
     p_eager, l_eager, _ = run(False)
@@ -153,6 +161,64 @@ def test_train_step_replays_the_captured_step_on_static_shape_batches():
         assert ta == tb
         for t in va:
             assert torch.equal(va[t], vb[t]), t
+
+
+def test_arena_staging_with_the_staging_thread_trains_like_the_tensor_by_tensor_path():
+    """The live loops' staging: resident datasets whose batches the native builder writes into ONE buffer each
+    (data.Arena), the merged batch from one host call, one memcpy per batch into the transfer buffer, the feature block gathered
+    from the device copy of the store rows, all of it on a thread of its own two steps ahead -- against the numpy builder with
+    tensor-by-tensor merge / packing staged inline: the same parameters after the same steps, bit for bit, and a replayed step
+    builds no tensor view on the host."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from egopack_amd import data as D
+    from egopack_amd import engine, ops
+    from egopack_amd import train as T
+    from egopack_amd.criterion import BCEWithLogitsNone, CrossEntropyNone, MetricSelectorWrapper
+    from egopack_amd.models import Graph
+    from egopack_amd.models.tasks import LTATask, OSCCTask, PNRTask, RecognitionTask
+    from egopack_amd.optim import FlatAdam
+    H, heads, order = 64, (7, 11), ("ar", "lta", "oscc", "pnr")
+    trn = {"_target_": "egopack_amd.models.temporal_pooling.trn_pooling.TRNPooling", "dropout": 0.0, "hidden_size": H}
+
+    class DS:
+        has_joint_label, num_labels = False, 2
+
+    def run(native, depth):
+        torch.manual_seed(3)
+        model = Graph(48, hidden_size=H, depth=2, temporal_pooling=trn, num_segments=3).cuda()
+        tasks = {"ar": RecognitionTask(H, H, heads).cuda(), "oscc": OSCCTask(H, H).cuda(), "lta": LTATask(H, H, heads).cuda(),
+                 "pnr": PNRTask(H, H).cuda()}
+        crit = {"ar": MetricSelectorWrapper(CrossEntropyNone(), DS()), "lta": MetricSelectorWrapper(CrossEntropyNone(), DS()),
+                "oscc": CrossEntropyNone(), "pnr": BCEWithLogitsNone()}
+        live = [*model.parameters(), *(p for t in ("ar", "lta", "pnr") for p in tasks[t].parameters())]
+        opt = FlatAdam(live, lr=1e-3, weight_decay=1e-5)
+        weights = {"ar": 1.0, "lta": 0.5, "pnr": 2.0, "oscc": 0.0}
+        step = engine.MTLStep(model, tasks, crit, weights, opt, fused_backbone=True)
+        dsets = {t: D.SyntheticResidentDataset(t, 48, 8, 3, 48, heads, k=1, seed=11, split="train", n_videos=3, frames=500)
+                 for t in ("ar", "lta", "pnr")}
+        for d in dsets.values():
+            d.native_batches = native
+        with ops.compute_mode("f32"):
+            store = T.build_feature_store(dsets, "cuda")
+            loaders = {t: D.build_dataloader(d, 4, True, 0, True, seed=5) for t, d in dsets.items()}
+            hosts = (dict(zip(order, b)) for b in D.multiloader([loaders.get(t) for t in order], [weights[t] for t in order]))
+            fills, n = [], 0
+            for batches, merged in engine.StagedBatches(hosts, "cuda", order, fused=True, store=store, dtype=ops.act_dtype(), depth=depth):
+                before = D.LazyData.fills
+                step.train_step(batches, merged)
+                n += 1
+                if n > step.graph_after + 2:
+                    fills.append(D.LazyData.fills - before)
+        torch.cuda.synchronize()
+        return opt.flat_p.clone(), step, fills, n
+
+    p_ref, step_ref, _, n_ref = run(False, 0)
+    p_new, step_new, fills, n_new = run(True, 2)
+    assert n_ref == n_new == 12 and step_new.loop_counts["replayed"] >= 8
+    assert torch.equal(p_new, p_ref)
+    if D.SyntheticResidentDataset.native_batches:
+        assert fills and max(fills) == 0, fills  # (the staging thread may be mid-step: it builds no view either)
 
 
 @pytest.mark.timeout(600)

@@ -358,8 +358,8 @@ def test_native_batch_builder_equals_the_numpy_builder_and_the_collated_items(ta
         a, b = nat.batch(chunk), vec.batch(chunk)
         _same_fields(b, a)
         _same_fields(D.collate([per[i] for i in chunk]), a)
-        for k in ("y", "pos", "edge_index", "x_idx", "ptr32"):
-            assert getattr(a, k).dtype == getattr(b, k).dtype and getattr(a, k).is_contiguous()
+        for k in ("y", "pos", "edge_index", "x_idx", "ptr32"):  # (edge_index: the first E columns of its [2, capacity] region)
+            assert getattr(a, k).dtype == getattr(b, k).dtype and (k == "edge_index" or getattr(a, k).is_contiguous())
         for f in ("rowptr", "col", "t_rowptr", "t_col", "t_wgt", "band", "heavy", "t_heavy"):
             assert getattr(a.graph, f).dtype == getattr(b.graph, f).dtype, f
         assert (getattr(a, "live_ap", None), a.graph.heavy_mode, a.graph.t_heavy_mode) == (getattr(b, "live_ap", None), b.graph.heavy_mode, b.graph.t_heavy_mode)
@@ -367,6 +367,52 @@ def test_native_batch_builder_equals_the_numpy_builder_and_the_collated_items(ta
     assert sa[2] == sb[2] == sp[2] and np.array_equal(sa[1], sb[1]) and np.array_equal(sa[1], sp[1])
     with pytest.raises((ValueError, IndexError)):
         nat.batch([0, 40])
+
+
+def test_arena_batches_merge_and_pack_like_the_tensor_by_tensor_path():
+    """The native builder writes a batch into ONE buffer (data.Arena) and hands out a lazy batch; ``merge_batches`` of such batches
+    is one host call (egk_host_merge_batches) and ``to_device_packed`` one memcpy per batch.  Against the numpy builder + tensor-by-
+    tensor merge + generic packing: the same fields (values, dtypes, shapes; edge-sized arrays at capacity in the static views), one
+    layout signature for steps whose edge counts differ inside a capacity bucket, and no tensor view is built by the staging itself."""
+    import numpy as np
+    from egopack_amd.engine import structure_key
+    tasks = ["ar", "lta", "pnr", "oscc"]
+    mk = lambda t: D.SyntheticResidentDataset(t, 96, 16, seed=3, split="train", n_videos=4, frames=600)
+    nat, vec = {t: mk(t) for t in tasks}, {t: mk(t) for t in tasks}
+    rng = np.random.default_rng(0)
+    sigs, keys = set(), set()
+    for it in range(5):
+        chunks = {t: rng.integers(0, 96, 32) for t in tasks}
+        xa = [nat[t].batch(chunks[t]) for t in tasks]
+        xb = [vec[t].batch_numpy(chunks[t]) for t in tasks]
+        assert all(b.__dict__.get("_arena") is not None and "_fill" in b.__dict__ for b in xa)
+        assert all(structure_key(b) == b.__dict__["_struct_key"] for b in xa)
+        keys.add(structure_key(xa[1]))
+        for b in xa + xb:
+            b.x = torch.empty(0)
+        ma, mb = D.merge_batches(xa), D.merge_batches(xb)
+        assert ma.__dict__.get("_arena") is not None and mb.__dict__.get("_arena") is None
+        for b in xa + xb + [ma, mb]:
+            b.x = None
+        fills = D.LazyData.fills
+        pa = D.to_device_packed([*xa, ma], "cpu", pack_on_cpu=True)
+        assert D.LazyData.fills == fills and all("_fill" in b.__dict__ for b in [*xa, ma, *pa])  # nothing was looked at
+        pb = D.to_device_packed([*xb, mb], "cpu", pack_on_cpu=True)
+        ref = pa[0]._blob
+        assert all(p._blob is ref for p in pa) and ref.gsig is not None
+        sigs.add((ref.gsig, ref.dev.shape))
+        assert pa[0].num_graphs == 32 and "_fill" in pa[0].__dict__  # plain values are there without building the views
+        for u, v in zip(pa, pb):
+            _same_fields(v, u)
+        for u, v in zip(ref.rebuild(ref.dev.clone(), True), pb[0]._blob.rebuild(pb[0]._blob.dev.clone(), True)):
+            _same_fields(v, u)  # static views: capacity shapes
+        _same_fields(mb, ma)
+    # LTA's edge count moves with the labels of a batch, the capacity bucket does not; the structure fingerprints do differ
+    assert len(sigs) == 1 and len(keys) == 5
+    # a batch of another size is another layout; an index out of range is refused before anything is written
+    assert nat["ar"].batch([1, 2, 3])._arena.layout is not xa[0]._arena.layout
+    with pytest.raises(ValueError):
+        nat["ar"].batch([0, 96])
 
 
 def test_pack_data_round_trip_is_one_buffer_per_batch():
