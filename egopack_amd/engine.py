@@ -159,7 +159,10 @@ class StagedBatches:
             key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
             self.copy_stream = _COPY_STREAMS.get(key)
             if self.copy_stream is None:
-                self.copy_stream = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+                # (a priority stream: the runtime keeps hardware queues per priority level, so the staging launches do not sit in a
+                #  queue behind a branch of the replayed graph that is waiting for its dependencies)
+                prio = int(switches.value("staging_priority", -1)) if switches.enabled("staging_priority") else 0
+                self.copy_stream = _COPY_STREAMS[key] = torch.cuda.Stream(device=device, priority=prio)
 
     def _stage(self, host):
         live = {t: b for t, b in host.items() if b is not None}
@@ -254,6 +257,7 @@ class StagedBatches:
                 cur.wait_event(done)
                 ref = _shared_blob(batches, merged)
                 if ref is not None:  # every tensor but the features is a view of the transfer's one buffer
+                    ref.ready = done  # (what a consumer on another stream waits for: StepBase._input_slot)
                     used = [ref.dev, *(getattr(b, k, None) for b in [*batches.values(), merged] if b is not None
                                        for k in ("x", "x_base"))]
                 else:
@@ -845,19 +849,12 @@ class StepBase:
         # device-to-device copy of the byte buffer + one of the feature block instead of a copy per tensor, no signature walk
         ref = _shared_blob(batches, merged)
         if ref is not None and st is not None and st.get("gsig") == ref.gsig and st["xkey"] == _feature_key(batches, merged):
-            with torch.no_grad():
-                st["blob"].copy_(ref.dev, non_blocking=True)
-                if merged is not None:
-                    st["merged"].x.copy_(merged.x, non_blocking=True)
-                    st["merged"]._struct_key = getattr(merged, "_struct_key", 0)
-                for t, b in batches.items():
-                    if b is not None:
-                        if merged is None:
-                            st["batches"][t].x.copy_(b.x, non_blocking=True)
-                        st["batches"][t]._struct_key = getattr(b, "_struct_key", 0)
+            slot = self._input_slot(st, ref, batches, merged)
             st["fast"] = None
             self.loop_counts["replayed"] += 1
+            self._select_slot(slot)
             total = self.replay()
+            slot["done"] = torch.cuda.current_stream().record_event()  # (this slot's buffers are read until here)
             return total.detach(), {t: v.detach() for t, v in self._static_out[1].items()}
         # equal structure fingerprints (stage_batches attaches them) + equal feature shapes = equal signature: the walk over
         # every tensor of the step's batches (0.2-0.3 ms of host time per step) is skipped for such a step
@@ -878,6 +875,7 @@ class StepBase:
                                        "fast": fast}
             if blob is not None:
                 st.update(blob=blob, gsig=ref.gsig, xkey=_feature_key(batches, merged))
+            st["slots"] = [self._slot_of_capture(blob, static_b, static_m)]
             if st["sig"] != sig:  # (cannot happen: the clones mirror the originals)
                 self._train_static = None
                 self.loop_counts["eager"] += 1
@@ -890,8 +888,76 @@ class StepBase:
             if fast is not None and st.get("fast") != fast:
                 st["fast"] = fast  # (the static buffers now hold this structure)
         self.loop_counts["replayed"] += 1
+        self._select_slot(st["slots"][0])
         total = self.replay()
+        st["slots"][0]["done"] = torch.cuda.current_stream().record_event()
         return total.detach(), {t: v.detach() for t, v in self._static_out[1].items()}
+
+    # ---- two captured steps on alternating input buffers ------------------------------------------------------------------------------
+    # A replay reads its batch from fixed buffers, and it reads the feature block at both ends of the step (first contraction, last
+    # weight gradient): the next batch cannot be written there while the step runs, and written between two replays the copies (57 MB
+    # of features + the index buffer) were 30 us on the stream both replays are ordered on.  A loop that feeds packed transfers
+    # (data.to_device_packed) therefore captures the step TWICE, on two sets of input buffers, and alternates: while the replay on
+    # one set runs, the next batch is copied into the other on a stream of its own (behind the event that ends the last replay that
+    # read that set, and behind the staging of the batch).  The two graphs share everything else -- parameters, optimizer state,
+    # gradient buffer, dropout offset word, loss accumulators -- and run one after the other on the training stream.
+    double_buffered_inputs = None  # None: switches.enabled("double_buffered_inputs") for one-rank steps whose optimizer is in the graph
+
+    def _slot_of_capture(self, blob, static_b, static_m) -> dict:
+        return {"graph": self._graph, "out": self._static_out, "static_in": getattr(self, "_static_in", None), "blob": blob,
+                "batches": static_b, "merged": static_m, "done": None}
+
+    def _select_slot(self, slot) -> None:
+        self._graph, self._static_out, self._static_in = slot["graph"], slot["out"], slot["static_in"]
+
+    def _double_buffer_ok(self) -> bool:
+        on = self.double_buffered_inputs
+        on = switches.enabled("double_buffered_inputs") if on is None else bool(on)
+        return bool(on and getattr(self, "_fuse_adam", False) and not isinstance(self._graph, list))
+
+    def _input_slot(self, st, ref, batches, merged) -> dict:
+        """The set of input buffers this step's replay reads, holding this step's batch (see above)."""
+        slots = st["slots"]
+        cur = torch.cuda.current_stream()
+        if self._double_buffer_ok():
+            k = st["turn"] = (st.get("turn", 0) + 1) % 2
+            if k == len(slots):  # the second capture, on private copies of THIS batch (they hold its values: nothing to fill)
+                self._select_slot(slots[0])
+                blob, static_b, static_m = _static_from_blob(ref, batches, merged)
+                self.capture(static_b, static_m, warmup=0)
+                slots.append(self._slot_of_capture(blob, static_b, static_m))
+                return slots[k]
+        else:
+            k = 0
+        slot = slots[k]
+        side = cur
+        if len(slots) > 1:
+            if not hasattr(self, "_input_stream"):
+                self._input_stream = torch.cuda.Stream(priority=-1 if switches.enabled("staging_priority") else 0)
+            side = self._input_stream
+            ready = getattr(ref, "ready", None)
+            if ready is not None:
+                side.wait_event(ready)  # (the staging of this batch: engine.StagedBatches)
+            else:
+                side.wait_stream(cur)  # (staged on the training stream by the caller)
+            if slot["done"] is not None:
+                side.wait_event(slot["done"])
+        with torch.no_grad(), torch.cuda.stream(side):
+            slot["blob"].copy_(ref.dev, non_blocking=True)
+            if merged is not None:
+                slot["merged"].x.copy_(merged.x, non_blocking=True)
+                slot["merged"]._struct_key = getattr(merged, "_struct_key", 0)
+            for t, b in batches.items():
+                if b is not None:
+                    if merged is None:
+                        slot["batches"][t].x.copy_(b.x, non_blocking=True)
+                    slot["batches"][t]._struct_key = getattr(b, "_struct_key", 0)
+        if side is not cur:
+            for v in (ref.dev, getattr(merged, "x", None), *(getattr(b, "x", None) for b in batches.values() if b is not None)):
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(side)
+            cur.wait_event(side.record_event())
+        return slot
 
     # ---- hipGraph capture ---------------------------------------------------------------------------------
     def capture(self, batches: Mapping[str, Data], merged: Optional[Data] = None, warmup: int = 2):
