@@ -44,7 +44,7 @@ def structure_key(b: Data) -> int:
     return hash(tuple(parts)) or 1
 
 
-def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, dtype=None):
+def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, dtype=None, features: bool = True):
     """Host -> device transfer of one step's task batches for the fused pass: the feature blocks are packed
     into ONE (pinned) buffer and moved with ONE copy; the returned per-task batches view row ranges of the
     device buffer and ``merged`` exposes the whole buffer (first contraction at M = all nodes).
@@ -55,7 +55,7 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, 
     resident = store is not None and all(getattr(host[t], "x", None) is None and getattr(host[t], "x_idx", None) is not None
                                          for t in live)
     if resident and all(host[t].__dict__.get("_arena") is not None for t in live):
-        return _stage_arenas([host[t] for t in live], live, device, store, dtype)
+        return _stage_arenas([host[t] for t in live], live, device, store, dtype, features)
     if resident:
         idx = torch.cat([host[t].x_idx for t in live])
         if pin and idx.device.type == "cpu":
@@ -107,31 +107,60 @@ def stage_batches(host, device, order=TASK_ORDER, pin: bool = True, store=None, 
     return dev, md
 
 
-def _stage_arenas(hs, live, device, store, dtype):
+def _stage_arenas(hs, live, device, store, dtype, features: bool = True):
     """``stage_batches`` for batches the native builder wrote into arenas (data.Arena): the merged batch comes from one host call,
     every batch travels as one memcpy into the transfer buffer -- the store rows with it -- and the packed feature block is gathered
-    task by task from the device copy of those rows.  No tensor of the step is touched on the host."""
+    task by task from the device copy of those rows.  No tensor of the step is touched on the host.  ``features=False``: the block
+    is NOT gathered here -- the transfer carries the store (``BlobRef.store``) and whoever consumes the batches gathers the rows
+    where it wants them (a captured training step: straight into its idle input buffers, StepBase._input_slot;
+    ``ensure_features`` for anything else)."""
     from .data import to_device_packed
     merged = merge_batches(hs)
     merged.x = None
     moved = to_device_packed([*hs, merged], device)
     rows = [h._arena.meta["num_nodes"] for h in hs]
     idx0 = moved[0].__dict__["x_idx"]
-    dbuf = torch.empty((sum(rows), idx0.shape[1], store.features_size), dtype=dtype or store.table.dtype, device=idx0.device)
+    x_dtype = dtype or store.table.dtype
+    dbuf = torch.empty((sum(rows), idx0.shape[1], store.features_size), dtype=x_dtype, device=idx0.device) if features else None
     dev, off = {}, 0
     for t, n, h, d in zip(live, rows, hs, moved[:-1]):
-        store.gather(d.__dict__["x_idx"], out=dbuf[off:off + n], dtype=dtype)
-        d.x = dbuf[off:off + n]
+        if features:
+            store.gather(d.__dict__["x_idx"], out=dbuf[off:off + n], dtype=dtype)
+            d.x = dbuf[off:off + n]
         d.x_base = dbuf
         d._struct_key = h.__dict__.get("_struct_key", 0)
         dev[t] = d
         off += n
     md = moved[-1]
     md.x = md.x_base = dbuf
-    if getattr(md, "_blob", None) is not None:
-        md._blob.names = [*live, "merged"]
+    ref = getattr(md, "_blob", None)
+    if ref is not None:
+        ref.names = [*live, "merged"]
+        ref.store, ref.x_dtype = store, x_dtype  # (what a consumer that gathers the rows itself needs)
     md._struct_key = hash(tuple(dev[t]._struct_key for t in live)) or 1
     return dev, md
+
+
+def ensure_features(batches, merged=None) -> None:
+    """Give batches that were staged without their feature block (``stage_batches(features=False)``) the block: gathered from the
+    transfer's store on the current stream (no-op for batches that have it)."""
+    live = [(t, b) for t, b in batches.items() if b is not None]
+    if not live or all(b.__dict__.get("x") is not None for _, b in live):
+        return
+    ref = _shared_blob(batches, merged)
+    store = getattr(ref, "store", None) if ref is not None else None
+    if store is None:
+        raise RuntimeError("batches without features and without a feature store to gather them from")
+    idx = [b.__dict__["x_idx"] for _, b in live]
+    dbuf = torch.empty((sum(i.shape[0] for i in idx), idx[0].shape[1], store.features_size), dtype=ref.x_dtype, device=idx[0].device)
+    off = 0
+    for (t, b), i in zip(live, idx):
+        n = i.shape[0]
+        store.gather(i, out=dbuf[off:off + n], dtype=ref.x_dtype)
+        b.x, b.x_base = dbuf[off:off + n], (dbuf if merged is not None else None)
+        off += n
+    if merged is not None:
+        merged.x = merged.x_base = dbuf
 
 
 _COPY_STREAMS = {}  # device index -> the staging copy stream (StagedBatches)
@@ -147,8 +176,12 @@ class StagedBatches:
     ``stage_batches`` returns them (``merged`` None for a single task / per-task backbone passes), already ordered behind
     the copy on the consumer's stream."""
 
-    def __init__(self, host_iter, device, order=TASK_ORDER, fused: bool = True, store=None, dtype=None, depth: Optional[int] = None):
+    def __init__(self, host_iter, device, order=TASK_ORDER, fused: bool = True, store=None, dtype=None, depth: Optional[int] = None,
+                 step=None):
         self.it, self.device, self.order, self.fused, self.store, self.dtype = iter(host_iter), device, order, fused, store, dtype
+        # the training step these batches feed (optional): once it gathers the store rows into its own input buffers
+        # (``StepBase.gathers_inputs``) the feature block is no longer gathered here
+        self.step = step
         # steps staged ahead by the staging thread (0: staged inline, right behind the consumer's launch of the step before)
         self.depth = (2 if switches.enabled("staging_thread") else 0) if depth is None else int(depth)
         # ONE copy stream per device for the life of the process: the caching allocator keeps a pool per stream, so a fresh
@@ -166,16 +199,21 @@ class StagedBatches:
 
     def _stage(self, host):
         live = {t: b for t, b in host.items() if b is not None}
+        features = not (self.store is not None and getattr(self.step, "gathers_inputs", False))
         if self.fused and len(live) > 1:
-            return stage_batches(live, self.device, self.order, store=self.store, dtype=self.dtype)
+            return stage_batches(live, self.device, self.order, store=self.store, dtype=self.dtype, features=features)
         from .data import to_device_packed
         moved = to_device_packed([live[t] for t in live], self.device)  # (one copy for all of a step's tensors)
-        if moved and getattr(moved[0], "_blob", None) is not None:
-            moved[0]._blob.names = list(live)
+        ref = getattr(moved[0], "_blob", None) if moved else None
+        if ref is not None:
+            ref.names = list(live)
+            if self.store is not None:
+                ref.store, ref.x_dtype = self.store, self.dtype or self.store.table.dtype
         for t, d in zip(live, moved):
             d._struct_key = structure_key(live[t])
             if self.store is not None and getattr(d, "x", None) is None and getattr(d, "x_idx", None) is not None:
-                d.x = self.store.gather(d.x_idx, dtype=self.dtype)  # features from the device-resident table
+                if features or ref is None or "x_idx" not in d.__dict__:
+                    d.x = self.store.gather(d.x_idx, dtype=self.dtype)  # features from the device-resident table
         return dict(zip(live, moved)), None
 
     def _fetch(self):
@@ -349,8 +387,30 @@ def _shared_blob(batches, merged):
 
 
 def _feature_key(batches, merged):
-    return tuple((name, tuple(b.x.shape), b.x.dtype) for name, b in [*sorted(batches.items()), ("merged", merged)]
-                 if b is not None and torch.is_tensor(getattr(b, "x", None)))
+    """(name, shape, dtype) of every feature block of a step's batches -- also for batches staged without their block
+    (``stage_batches(features=False)``): its shape follows from the store rows, its type is the transfer's."""
+    ref = None
+    out = []
+    for name, b in [*sorted(batches.items()), ("merged", merged)]:
+        if b is None:
+            continue
+        x = b.__dict__.get("x", None) if "x" in b.__dict__ else getattr(b, "x", None)
+        if torch.is_tensor(x):
+            out.append((name, tuple(x.shape), x.dtype))
+            continue
+        ref = ref or _shared_blob(batches, merged)
+        store = getattr(ref, "store", None) if ref is not None else None
+        if store is None:
+            continue
+        if name == "merged":
+            idx = [bb.__dict__.get("x_idx") for _, bb in sorted(batches.items()) if bb is not None]
+            if all(torch.is_tensor(i) for i in idx):
+                out.append((name, (sum(i.shape[0] for i in idx), idx[0].shape[1], store.features_size), ref.x_dtype))
+        else:
+            i = b.__dict__.get("x_idx")
+            if torch.is_tensor(i):
+                out.append((name, (*i.shape, store.features_size), ref.x_dtype))
+    return tuple(out)
 
 
 def _static_from_blob(ref, batches, merged):
@@ -837,17 +897,23 @@ class StepBase:
         self._steps_seen = getattr(self, "_steps_seen", 0) + 1
         if not hasattr(self, "loop_counts"):
             self.loop_counts = {"replayed": 0, "eager": 0}  # per training loop; the entry points log and reset it per epoch
-        if (not self.use_graph or self._steps_seen <= self.graph_after or not next(iter(batches.values())).x.is_cuda
+        st = getattr(self, "_train_static", None)
+        ref = _shared_blob(batches, merged)
+        if not (ref is not None and st is not None and self.use_graph and st.get("gsig") == ref.gsig and len(st.get("slots", ())) > 1
+                and st["xkey"] == _feature_key(batches, merged)):
+            ensure_features(batches, merged)  # (staged without their feature block, and this step is not a replay that gathers it)
+        first = next(iter(batches.values()))
+        on_device = first.x.is_cuda if torch.is_tensor(first.__dict__.get("x", None) if "x" in first.__dict__ else first.x) else (
+            ref is not None and ref.dev.is_cuda)
+        if (not self.use_graph or self._steps_seen <= self.graph_after or not on_device
                 or (self._exact_ln_on() and not self._one_graph_exchange_ok())):
             self.loop_counts["eager"] += 1
             return self.step(batches, merged)
         if self.fused and len([t for t in self.enabled if batches.get(t) is not None]) > 1 and merged is None:
             self.loop_counts["eager"] += 1
             return self.step(batches, merged)  # (the caller did not stage a merged batch: nothing static to replay on)
-        st = getattr(self, "_train_static", None)
         # batches out of ONE packed transfer (data.to_device_packed) with the layout the static buffers were built from: one
         # device-to-device copy of the byte buffer + one of the feature block instead of a copy per tensor, no signature walk
-        ref = _shared_blob(batches, merged)
         if ref is not None and st is not None and st.get("gsig") == ref.gsig and st["xkey"] == _feature_key(batches, merged):
             slot = self._input_slot(st, ref, batches, merged)
             st["fast"] = None
@@ -902,6 +968,7 @@ class StepBase:
     # read that set, and behind the staging of the batch).  The two graphs share everything else -- parameters, optimizer state,
     # gradient buffer, dropout offset word, loss accumulators -- and run one after the other on the training stream.
     double_buffered_inputs = None  # None: switches.enabled("double_buffered_inputs") for one-rank steps whose optimizer is in the graph
+    gathers_inputs = False  # set once the step gathers the store rows into its own input buffers (see _input_slot)
 
     def _slot_of_capture(self, blob, static_b, static_m) -> dict:
         return {"graph": self._graph, "out": self._static_out, "static_in": getattr(self, "_static_in", None), "blob": blob,
@@ -942,16 +1009,25 @@ class StepBase:
                 side.wait_stream(cur)  # (staged on the training stream by the caller)
             if slot["done"] is not None:
                 side.wait_event(slot["done"])
+        store = getattr(ref, "store", None)
         with torch.no_grad(), torch.cuda.stream(side):
             slot["blob"].copy_(ref.dev, non_blocking=True)
             if merged is not None:
-                slot["merged"].x.copy_(merged.x, non_blocking=True)
+                if torch.is_tensor(merged.__dict__.get("x")):
+                    slot["merged"].x.copy_(merged.x, non_blocking=True)
                 slot["merged"]._struct_key = getattr(merged, "_struct_key", 0)
             for t, b in batches.items():
                 if b is not None:
-                    if merged is None:
-                        slot["batches"][t].x.copy_(b.x, non_blocking=True)
-                    slot["batches"][t]._struct_key = getattr(b, "_struct_key", 0)
+                    dst = slot["batches"][t]
+                    if not torch.is_tensor(b.__dict__.get("x")):
+                        # staged without its feature block: the store rows (they arrived with the transfer) are gathered straight
+                        # into this set's block -- one pass over the rows instead of a gather + a copy of the block
+                        store.gather(b.__dict__["x_idx"], out=dst.x, dtype=dst.x.dtype)
+                    elif merged is None:
+                        dst.x.copy_(b.x, non_blocking=True)
+                    dst._struct_key = getattr(b, "_struct_key", 0)
+        if len(slots) > 1 and store is not None and switches.enabled("step_gathers_inputs"):
+            self.gathers_inputs = True  # (from now on a StagedBatches that feeds this step leaves the gathers to it)
         if side is not cur:
             for v in (ref.dev, getattr(merged, "x", None), *(getattr(b, "x", None) for b in batches.values() if b is not None)):
                 if torch.is_tensor(v) and v.is_cuda:

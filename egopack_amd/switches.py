@@ -43,6 +43,7 @@ REGISTRY = {
     "zero_deferred": (True, "... issued behind the forward pass's first launch"),
     "staging_thread": (True, "training loops: the next steps' batches are built and copied by a thread of their own, two steps ahead"),
     "double_buffered_inputs": (True, "training loops: the step is captured twice, on alternating input buffers filled beside the running replay"),
+    "step_gathers_inputs": (True, "training loops: the replayed step gathers the store rows straight into its idle input buffers (no staged feature block)"),
     "staging_priority": (True, "training loops: the staging copy stream and the input-buffer stream are priority streams (hardware queues of their own)"),
     "hyper_in_graph": (True, "the step's Adam constants are computed inside the captured graph"),
     "rng_in_graph": (True, "the dropout offset word moves on inside the captured graph"),

@@ -64,7 +64,7 @@ def train(epoch, step: engine.EgoPackStep, loaders, weights, device="cuda", stor
     it, seqs, mark = 0, 0, None
     hosts = (dict(zip(order, batch)) for batch in multiloader([loaders[t] for t in order], [weights[t] for t in order]))
     # batch i + 1 is collated and copied to the device (copy stream) while step i runs; per-task backbone passes here
-    for batches, _ in engine.StagedBatches(hosts, device, order, fused=False, store=store, dtype=ops.act_dtype()):
+    for batches, _ in engine.StagedBatches(hosts, device, order, fused=False, store=store, dtype=ops.act_dtype(), step=step):
         total, _ = step.train_step(batches)  # eager for the first steps, then the captured step
         seqs += sum(int(b.num_graphs) for b in batches.values() if b is not None)
         it += 1

@@ -43,7 +43,7 @@ def train(epoch, step: engine.MTLStep, loaders, weights, device="cuda", store=No
     # batch i + 1 is built and copied to the device (staging thread, copy stream) while step i runs
     mark = None  # (iteration, wall clock, sequences so far) once the eager steps and the capture are behind: steady-state rate
     seqs = 0
-    for batches, merged in engine.StagedBatches(hosts, device, order, fused=step.fused, store=store, dtype=ops.act_dtype()):
+    for batches, merged in engine.StagedBatches(hosts, device, order, fused=step.fused, store=store, dtype=ops.act_dtype(), step=step):
         step.train_step(batches, merged)  # eager for the first steps, then the captured step (no launch of this loop between two)
         seqs += sum(int(b.num_graphs) for b in batches.values() if b is not None)
         it += 1

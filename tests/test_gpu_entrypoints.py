@@ -204,7 +204,8 @@ def test_arena_staging_with_the_staging_thread_trains_like_the_tensor_by_tensor_
             loaders = {t: D.build_dataloader(d, 4, True, 0, True, seed=5) for t, d in dsets.items()}
             hosts = (dict(zip(order, b)) for b in D.multiloader([loaders.get(t) for t in order], [weights[t] for t in order]))
             fills, n = [], 0
-            for batches, merged in engine.StagedBatches(hosts, "cuda", order, fused=True, store=store, dtype=ops.act_dtype(), depth=depth):
+            for batches, merged in engine.StagedBatches(hosts, "cuda", order, fused=True, store=store, dtype=ops.act_dtype(), depth=depth,
+                                                        step=step if native else None):
                 before = D.LazyData.fills
                 step.train_step(batches, merged)
                 n += 1
@@ -216,6 +217,7 @@ def test_arena_staging_with_the_staging_thread_trains_like_the_tensor_by_tensor_
     p_ref, step_ref, _, n_ref = run(False, 0)
     p_new, step_new, fills, n_new = run(True, 2)
     assert n_ref == n_new == 12 and step_new.loop_counts["replayed"] >= 8
+    assert step_new.gathers_inputs and not step_ref.gathers_inputs  # (the last steps' feature blocks were gathered by the step itself)
     assert torch.equal(p_new, p_ref)
     if D.SyntheticResidentDataset.native_batches:
         assert fills and max(fills) == 0, fills  # (the staging thread may be mid-step: it builds no view either)
