@@ -533,7 +533,23 @@ class StepBase:
 
     order: Sequence[str] = TASK_ORDER
     wgrad_grouping_default = True
-    wgrad_group_count = None  # bf16 weight-gradient problems per grouped launch (None: ops.WGRAD_GROUP_COUNT = 6)
+    wgrad_group_count = None  # bf16 weight-gradient problems per grouped launch (None: _wgrad_count's policy)
+
+    def _wgrad_count(self, batches, merged=None):
+        """H x H weight-gradient problems per grouped launch.  Eight problems are 512 tiles = two whole rounds of the chip (16.4 us per
+        problem at 6144 rows against 20 for six = 1.5 rounds), but such a launch holds EVERY CU for its whole K walk and the backward
+        chain's launches wait behind it: worth it while the walk is short.  Measured, 6 against 8 on one box, alternating
+        (tools/round6/wgrad_count_ab*.sh): fused three-task step at 6144 rows 1.308 -> 1.287 ms (its 8-rank dry run 1.360 -> 1.317,
+        sharded 1.282 -> 1.247), four tasks at 8192 rows 1.636 -> 1.644, at 16384 rows 2.945 -> 3.013, one task at 2048 rows
+        0.837 -> 0.847 -- so: eight for a fused multi-task pass of fewer than 8192 rows, else the module default (six)."""
+        if self.wgrad_group_count is not None:
+            return self.wgrad_group_count
+        live = [b for b in batches.values() if b is not None]
+        if self.fused and merged is not None and len(live) > 1:
+            rows = getattr(merged, "pos", None)
+            if rows is not None and int(rows.shape[0]) < 8192:
+                return 8
+        return None
     # forked launches (weight gradients, early Adam) issued one launch late so that the dX chain keeps its hardware queue under
     # capture (ops.defer_after_next_launch): -4 % on the multi-task steps, -1.6 % on the single-task step; the EgoPack step,
     # whose GraphONE chains already occupy three queues, measured 4.04 vs 3.51 ms with it and leaves it off
@@ -708,7 +724,7 @@ class StepBase:
             self.input_hook()
         self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self._wgrad_count(batches, merged))
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             # (eagerly issued steps end with the same grouped tail launch as captured ones: same tile variants, same bits)
@@ -841,7 +857,7 @@ class StepBase:
             self.input_hook()
         self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self._wgrad_count(batches, merged))
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         try:
             self._install_tail(self._tail_only_plan([t for t in self.enabled if batches.get(t) is not None]))
@@ -1097,7 +1113,7 @@ class StepBase:
         self._hyper_in_graph = False
         self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self._wgrad_count(batches, merged))
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         early = self._early_adam_plan(live) if fuse_adam else None
         # gradient slots with one writer per step (learnt from the eager steps above, FlatAdam.learn_begin) are stored, not cleared +
@@ -1335,7 +1351,7 @@ class StepBase:
         count = opt.step_count
         self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self._wgrad_count(batches, merged))
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         sync.begin_step()
         sync.hyper_ready = True
@@ -1422,7 +1438,7 @@ class StepBase:
         self._rng_in_graph = False  # (no staged graph advances the Philox offset word: replay() does, also after a one-piece capture)
         self._scope_streams()
         prev = ops.set_wgrad_side_streams(self.wgrad_side_streams)
-        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self.wgrad_group_count)
+        prev_g = ops.set_wgrad_grouping(self.wgrad_grouping, self._wgrad_count(batches, merged))
         prev_d = ops.set_deferred_forks(self.deferred_forks)
         store_prev = self._grad_store_begin()  # (one provider over the three captures: every learnt slot is written in exactly one of them)
         try:
