@@ -183,7 +183,8 @@ ROCPROF_NAME = {"gemm_bf16_nn": _pipe("false", "false", 1), "gemm_bf16_nt": _pip
                 "gemm_bf16_nn_t256": "gemm_big_kernel<false, false", "gemm_bf16_nt_t256": "gemm_big_kernel<false, true",
                 "gemm_bf16_tt_t256": "gemm_big_kernel<true, true", "gemm_bf16_tn_t256": "gemm_big_kernel<true, false",
                 "gemm_bf16_group_nn": "gemm_pipe_group_kernel<2, false, false", "gemm_bf16_group_nt": "gemm_pipe_group_kernel<2, false, true",
-                "gemm_bf16_group_tt": "gemm_pipe_group_kernel<2, true, true",
+                # (the weight-gradient groups run on two instantiations: 128 x 128 tiles, and 256 x 128 tiles where those load the CUs unevenly)
+                "gemm_bf16_group_tt": "gemm_pipe_group_kernel<2, true, true | gemm_pipe_group_kernel<3, true, true",
                 "gemm_bf16_generic": "gemm_kernel<true", "gemm_splitk_reduce": "gemm_splitk_reduce",
                 "adam": "adam_kernel<", "csr_gather": "csr_gather_"}
 
@@ -218,7 +219,7 @@ def pmc_traffic(kernel: str, args=None):
         # launch-weighted mean per counter over all of them, then the sum of the counters
         byts, launches = {}, {}
         for name, ctrs in pmc.items():
-            if name.startswith("_") or sym not in name:
+            if name.startswith("_") or not any(part in name for part in sym.split(" | ")):
                 continue
             for ctr, c in ctrs.items():
                 byts[ctr] = byts.get(ctr, 0.0) + c["bytes_per_launch"] * c["launches"]

@@ -1595,6 +1595,7 @@ static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(1
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
 static int g_row_affinity = 1;      // development knob (egk_gemm_set_pipeline(950 / 951)): XCD x owns a contiguous eighth of the tile rows off / on
+static int g_tt_tall = 1;           // development knob (egk_gemm_set_pipeline(850 / 851)): 256 x 128 tiles for weight-gradient groups that leave the second workgroup slot of many CUs empty, off / on
 static int g_r192 = 1;              // development knob (egk_gemm_set_pipeline(900 / 901)): 192 x 128 tiles (variant 16) inside the policy off / on
 static bool g_lds_attr_set = false;
 template <int NS, bool TA, bool TB, int KG, int MB = 1>
@@ -1625,6 +1626,7 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<3, true, true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1647,6 +1649,7 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
     if (on >= 950) { g_row_affinity = on - 950; return prev; }
     if (on >= 900) { g_r192 = on - 900; return prev; }
+    if (on >= 850) { g_tt_tall = on - 850; return prev; }
     if (on >= 700) return prev;  // (700 / 80x: knobs of variants that no longer exist)
     if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
     if (on >= 500) { g_wg2_rows64 = on - 500; return prev; }
@@ -2144,7 +2147,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     const bool f16 = descs[0].op_f16 != 0;
     EGK_REQUIRE(!f16 || (!ta && !tb && !f32g), "egk_gemm_grouped: op_f16 takes row-major 16-bit operands");
     double flops = 0, bytes = 0;
-    long long t128 = 0, t96 = 0, t64 = 0;
+    long long t128 = 0, t96 = 0, t64 = 0, t256 = 0;
     int min_nkt = 1 << 30;
     for (int i = 0; i < count; ++i) {
         const egk_gemm_desc* d = descs + i;
@@ -2160,6 +2163,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         bytes += 2.0 * ((double)d->M * K + (double)d->N * K) + (gg.p[i].c_bf16 ? 2.0 : 4.0) * d->M * d->N;
         const int tn = cdiv(d->N, BN);
         t128 += (long long)cdiv(d->M, 128) * tn; t96 += (long long)cdiv(d->M, 96) * tn; t64 += (long long)cdiv(d->M, 64) * tn;
+        t256 += (long long)cdiv(d->M, 256) * tn;
         min_nkt = K / 64 < min_nkt ? K / 64 : min_nkt;
     }
     ensure_lds_attr();
@@ -2199,13 +2203,20 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
             variant = 11;
         }
     }
+    // weight-gradient groups (A^T B): two 128 x 128 workgroups share a CU, so a launch lasts as long as a doubly loaded CU whatever its
+    // tile count between 257 and 512; when that count leaves the second slot of many CUs empty (the pooling's three weight gradients:
+    // 416 tiles) and the 256 x 128 tiling fits one workgroup per CU, the tall tile (8 waves, 3-stage ring, 48 KiB per K tile for twice
+    // the flops) is one even round instead.  Long K walks only: same box, alternating, 6144 rows 1.291 -> 1.284 ms, 16384 rows
+    // 2.947 -> 2.934, 2048 rows 0.842 -> 0.863 (its 3-stage fill and 256-row epilogue outweigh 32 K tiles).
+    if (ta && tb && g_tt_tall && t128 > 256 && t128 <= 448 && t256 <= 256 && min_nkt >= 64) variant = 13;
     if (g_use_pipe == 3 || g_use_pipe == 5) variant = g_use_pipe;
+    if (g_use_pipe == 13 && ta && tb) variant = 13;
     if ((g_use_pipe == 8 || g_use_pipe == 11) && !ta) variant = g_use_pipe;
     if (f16) variant = 3;  // (one instantiation: 128 x 128 tiles, one wave group)
     int max_wg = 0, total = 0;
     for (int i = 0; i < count; ++i) {
         GemmArgs& g = gg.p[i];
-        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : cdiv(g.M, BM);
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : variant == 13 ? cdiv(g.M, 256) : cdiv(g.M, BM);
         g.tiles_n = cdiv(g.N, BN);
         total += g.tiles_m * g.tiles_n;
     }
@@ -2240,7 +2251,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         if (side) pad = g_group_tt_pad_kb * 1024;
     }
     {
-        ProfScope prof(KID_GEMM_BF16_GROUP_NN + layout, s, flops, bytes);  // (layout 0 nn, 1 nt, 2 tt)
+        ProfScope prof(KID_GEMM_BF16_GROUP_NN + layout, s, flops, bytes);  // (layout 0 nn, 1 nt, 2 tt; the tall weight-gradient tile included)
         if (f16) {
             ensure_lds_attr();
             hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 4, true>), pgrid, pblock, 2 * 32768, s, gg);
@@ -2252,6 +2263,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
             else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 3>), pgrid, pblock, 2 * 28672, s, gg);
         } else if (!ta && !tb) EGK_PIPE_G(false, false);
         else if (!ta && tb) EGK_PIPE_G(false, true);
+        else if (variant == 13) hipLaunchKernelGGL((gemm_pipe_group_kernel<3, true, true, 1, 2>), pgrid, dim3(2 * NTHREADS), 3 * 49152, s, gg);
         else EGK_PIPE_G(true, true);
     }
 #undef EGK_PIPE_G

@@ -1415,6 +1415,48 @@ def test_gemm_grouped_equals_separate_contractions(ops, layout, sizes):
         torch.testing.assert_close(out.float(), one.float(), rtol=1e-5, atol=1e-4 if out.dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("with_dbias", [False, True])
+def test_gemm_grouped_tall_tiles_for_uneven_weight_gradient_groups_bit_equal(ops, with_dbias):
+    """A weight-gradient group whose 128 x 128 tiling leaves the second workgroup slot of many CUs empty (the temporal pooling's three
+    weight gradients: 288 + 64 + 64 tiles) runs on 256 x 128 tiles (8 waves, 3-stage ring; egk_gemm_set_pipeline(850 / 851) off / on):
+    the same accumulation order per output element -- bit for bit the 128 x 128 launch, fused bias gradient included."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(77)
+    sizes = [(1024, 4608, 4096), (1024, 1024, 4096), (1024, 1024, 4096)]  # (K walks of >= 64 tiles: the policy's range)
+    outs = {}
+    for knob in (850, 851):
+        lib.egk_gemm_set_pipeline(knob)
+        try:
+            g.manual_seed(77)
+            probs, res = [], []
+            for (M, N, K) in sizes:
+                A = torch.randn(K, M, generator=g).to(torch.bfloat16).to(DEV)  # dY [rows, M]
+                B = torch.randn(K, N, generator=g).to(torch.bfloat16).to(DEV)  # X  [rows, N]
+                c = torch.randn(M, N, generator=g).to(DEV)
+                b = torch.randn(M, generator=g).to(DEV)
+                kw = dict(transA=True, transB=True, compute=ops.BF16, accumulate=True)
+                if with_dbias:
+                    kw["dbias"] = b
+                probs.append(((M, N, A, A.stride(0), B, B.stride(0), K, c, N), kw))
+                res.append((c, b))
+            ops.gemm_grouped(probs)
+            torch.cuda.synchronize()
+            outs[knob] = [(c.clone(), b.clone()) for c, b in res]
+        finally:
+            lib.egk_gemm_set_pipeline(851)
+    for (c0, b0), (c1, b1), (M, N, K) in zip(outs[850], outs[851], sizes):
+        assert torch.equal(c0, c1), (M, N, K)
+        assert torch.equal(b0, b1), (M, N, K)
+    # and the values: against the fp64 product for the first problem
+    g.manual_seed(77)
+    M, N, K = sizes[0]
+    A = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    B = torch.randn(K, N, generator=g).to(torch.bfloat16)
+    c = torch.randn(M, N, generator=g)
+    torch.testing.assert_close(outs[851][0][0].double().cpu(), A.double().t() @ B.double() + c.double(), rtol=1e-3, atol=2e-2)
+
+
 def test_gemm_grouped_rejects_what_it_cannot_run(ops):
     A = torch.randn(64, 96, device=DEV).to(torch.bfloat16)  # K = 96 is not a multiple of 64
     B = torch.randn(64, 96, device=DEV).to(torch.bfloat16)
