@@ -708,6 +708,10 @@ def gemm_grouped(problems, four_wave: bool = False):
     arr = (_lib.GemmDesc * len(problems))()
     for i, (a, kw) in enumerate(problems):
         _gemm_desc(*a, into=arr[i], **kw)
+    if switches.debug("group_shapes") and not torch.cuda.is_current_stream_capturing():
+        lay = ("t" if problems[0][1].get("transA") else "n") + ("t" if problems[0][1].get("transB") else "n")
+        print(f"[group_shapes] {lay} x{len(problems)}: " + ", ".join(f"{a[0]}x{a[1]}x{a[6]}" for a, _ in problems)
+              + f"  ({sum(((a[0] + 127) // 128) * ((a[1] + 127) // 128) for a, _ in problems)} tiles of 128 x 128)", flush=True)
     prev = None
     if four_wave:  # launch-shape hint: the 4-wave 128 x 128 variant whatever the tile count (the two-wave-group variant it
         prev = lib.egk_gemm_set_pipeline(3)  # replaces splits K over its two groups: same sums in another order)

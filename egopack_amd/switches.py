@@ -85,6 +85,7 @@ REGISTRY = {
 DEBUG = {
     "window_cand": "print the candidate statistics of eager window searches",
     "serial_precise": "measurement: the precise pass and the training pass one after the other",
+    "group_shapes": "print the problems of every grouped contraction launch issued outside a capture",
     "stage_profile": "print a cProfile of the staging thread (engine.StagedBatches) when a training loop's epoch ends",
 }
 
