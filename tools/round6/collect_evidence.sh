@@ -17,4 +17,5 @@ cp gpurun_out/r06_xcd_affinity.txt profiles/r06_xcd_affinity.txt
 cp gpurun_out/r06_gemm_phases.txt profiles/r06_gemm_phases.txt
 tail -1 gpurun_out/r06_two_rank_check.json > profiles/r06_two_rank_check.json
 cp gpurun_out/r06_gpu_tests.log profiles/r06_gpu_tests.log
+for f in r06_main_temporal_live.log r06_main_egopack_live.log r06_loop_gap.txt r06_loop_gap_egopack.txt r06_window_cand.txt r06_entry_loops.txt; do cp gpurun_out/$f profiles/$f; done
 git status --short profiles | head -40

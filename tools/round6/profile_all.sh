@@ -33,5 +33,10 @@ done
 python3 tools/round6/r192_bench.py --variants 8,16,1 > gpurun_out/r06_r192_bench.txt 2>&1
 tools/exp/build/xcd_affinity > gpurun_out/r06_xcd_affinity.txt 2>&1
 for v in 8 16; do for K in 1024 2048 4608; do python3 tools/gemm_stamps.py --phases 6144 1024 $K 0 0 1 $v 2>&1 | grep -v "amdgpu.ids"; done; done > gpurun_out/r06_gemm_phases.txt
+# the live loops: steady-state rates next to the bench lines, what the device does between two replays, the prototype search's candidates
+bash tools/round6/entry_loops.sh > gpurun_out/r06_entry_loops.txt 2>&1
+bash tools/round6/loop_gap.sh > /dev/null 2>&1
+bash tools/round6/loop_gap.sh 5 egopack > /dev/null 2>&1
+bash tools/round6/window_cand.sh > /dev/null 2>&1
 python3 tools/two_rank_check.py > gpurun_out/r06_two_rank_check.json 2> gpurun_out/r06_two_rank_check.err
 python3 -m pytest tests/ -x -q -m gpu > gpurun_out/r06_gpu_tests.log 2>&1; tail -3 gpurun_out/r06_gpu_tests.log
