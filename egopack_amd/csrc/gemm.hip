@@ -2203,10 +2203,10 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
             variant = 11;
         }
     }
-    // weight-gradient groups (A^T B): two 128 x 128 workgroups share a CU, so a launch lasts as long as a doubly loaded CU whatever its
-    // tile count between 257 and 512; when that count leaves the second slot of many CUs empty (the pooling's three weight gradients:
-    // 416 tiles) and the 256 x 128 tiling fits one workgroup per CU, the tall tile (8 waves, 3-stage ring, 48 KiB per K tile for twice
-    // the flops) is one even round instead.  Long K walks only: same box, alternating, 6144 rows 1.291 -> 1.284 ms, 16384 rows
+    // weight-gradient groups (A^T B): a CU works on one 128 x 128 workgroup at a time (272 registers per lane), so a launch of 257 ..
+    // 512 tiles takes two rounds whatever its tile count; when that count leaves many CUs idle in the second round (the pooling's
+    // three weight gradients: 416 tiles) and the 256 x 128 tiling fits one workgroup per CU, the tall tile (8 waves, 3-stage ring,
+    // 48 KiB per K tile for twice the flops) is one round instead.  Long K walks only: same box, alternating, 6144 rows 1.291 -> 1.284 ms, 16384 rows
     // 2.947 -> 2.934, 2048 rows 0.842 -> 0.863 (its 3-stage fill and 256-row epilogue outweigh 32 K tiles).
     if (ta && tb && g_tt_tall && t128 > 256 && t128 <= 448 && t256 <= 256 && min_nkt >= 64) variant = 13;
     if (g_use_pipe == 3 || g_use_pipe == 5) variant = g_use_pipe;

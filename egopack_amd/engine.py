@@ -537,8 +537,8 @@ class StepBase:
 
     def _wgrad_count(self, batches, merged=None):
         """H x H weight-gradient problems per grouped launch.  Eight problems are 512 tiles = two whole rounds of the chip (16.4 us per
-        problem at 6144 rows against 20 for six = 1.5 rounds), but such a launch holds EVERY CU for its whole K walk and the backward
-        chain's launches wait behind it: worth it while the walk is short.  Measured, 6 against 8 on one box, alternating
+        problem at 6144 rows against 20 for six = 1.5 rounds), but such a launch holds EVERY CU for both rounds and the backward chain's
+        launches wait behind it: worth it while the K walk is short.  Measured, 6 against 8 on one box, alternating
         (tools/round6/wgrad_count_ab*.sh): fused three-task step at 6144 rows 1.308 -> 1.287 ms (its 8-rank dry run 1.360 -> 1.317,
         sharded 1.282 -> 1.247), four tasks at 8192 rows 1.636 -> 1.644, at 16384 rows 2.945 -> 3.013, one task at 2048 rows
         0.837 -> 0.847 -- so: eight for a fused multi-task pass of fewer than 8192 rows, else the module default (six)."""
