@@ -717,8 +717,11 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& b, const uint4& a, const f3
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
 }
 
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false, bool F16 = false>
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool VIRT = false, bool F16 = false, int LW = 0>
 __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid) {
+    // LW > 0: LW extra LOADER waves issue every LDS-DMA piece of the workgroup; the WG * KG compute waves only read fragments and
+    // feed the matrix pipe.  A piece holds the wave that issues it until the CU's vector-memory path accepts it (100 - 185 cycles
+    // inside a loaded phase): on the compute waves those cycles sit between a tile's barrier and its first MFMA.
     static_assert(KG == 1 || MB == 1, "wave groups and the tall tile are alternatives");
     // NI = MFMA row fragments per wave: 4 -> 128-row tiles; 3 -> 96-row tiles (row-major A only), for outputs whose
     // 128-row tiling leaves the CUs unevenly loaded (6144 x 1024: 384 tiles = 1.5 per CU; 512 tiles of 96 x 128 = 2)
@@ -779,6 +782,43 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
         cb.issue(sbase + IMG_A, w * NPB);
     };
 
+    if constexpr (LW > 0) {
+        static_assert(KG == 1 && (WG * NI) % LW == 0 && (WG * NPB) % LW == 0, "loader waves: one wave group, pieces divisible among the loaders");
+        if (wall >= WG) {  // (wave-uniform) a loader wave: pieces [L * PA, (L + 1) * PA) of the A image, [L * PB, ..) of the B image
+            constexpr int PA = WG * NI / LW, PB = WG * NPB / LW;
+            const int L = wall - WG;
+            OperandCursor<TRA, PA> la;
+            OperandCursor<TRB, PB> lb;
+            int lsrc = -1;
+            auto lissue = [&](int i, int stage) {
+                const int t = t_begin + i;
+                int src, tt;
+                source_of<KT>(g, t, src, tt);
+                if (src != lsrc) {
+                    const int k0 = tt * KT;
+                    la.init((const bf16_t*)g.A[src], g.lda[src], g.M, m0, k0, L * PA, lane, 1);
+                    lb.init((const bf16_t*)g.B[src], g.ldb[src], g.N, n0, k0, L * PB, lane, 1);
+                    lsrc = src;
+                }
+                unsigned char* sbase = ring + stage * STAGE;
+                la.issue(sbase, L * PA);
+                lb.issue(sbase + IMG_A, L * PB);
+            };
+#pragma unroll
+            for (int p = 0; p < NSTAGE - 1; ++p)
+                if (p < nt) lissue(p, p);
+            for (int it = 0; it < rounds; ++it) {
+                const int later = min(NSTAGE - 2, nt - 1 - it);
+                if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PA + PB)) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // tile ``it`` is in LDS for everybody; the stage read at it - 1 is free
+                if (it + NSTAGE - 1 < nt) lissue(it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
+            }
+            return;  // (the epilogue's barriers count the surviving waves only)
+        }
+    }
+
     f32x4 acc[NI][4];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -813,23 +853,29 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmArgs& g, const int bid)
     const int bsub = MB == 2 ? (tid >> 8) : 0;  // tall tile: threads 256.. sum the second 128-row sub-image
 
     uint4 a0[4], a1[4], b0[4], b1[4];  // fragments of one K tile (a*[NI..3] stay unused for 96-row tiles)
+    if constexpr (LW == 0) {
 #pragma unroll
-    for (int p = 0; p < NSTAGE - 1; ++p)
-        if (p < nt) issue(p, p);
+        for (int p = 0; p < NSTAGE - 1; ++p)
+            if (p < nt) issue(p, p);
+    }
     for (int it = 0; it < rounds; ++it) {
         // tile ``it`` has landed once this wave has at most the pieces of the LATER tiles already issued
         // (min(NSTAGE-2, nt-1-it) tiles x LOADS pieces) outstanding
-        const int later = min(NSTAGE - 2, nt - 1 - it);
-        if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory");
-        else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (LW == 0) {
+            const int later = min(NSTAGE - 2, nt - 1 - it);
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();  // every wave's pieces of tile ``it`` landed; the stage read at it-1 is free
 #ifdef EGK_GEMM_STAMPS
         if (it == 0) ps_first = __builtin_amdgcn_s_memtime();
 #endif
         const unsigned stA = lds_base + (it % NSTAGE) * STAGE, stB = stA + IMG_A;
-        if (it + NSTAGE - 1 < nt) issue(it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
+        if constexpr (LW == 0) {
+            if (it + NSTAGE - 1 < nt) issue(it + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
+        }
         if (KG > 1 && it >= nt) continue;  // (wave-group uniform) odd tile count: the last round is group 0's only
 
         // Fragment reads as inline asm: hipcc cannot prove that a plain ds_read does not alias the LDS-DMA writes
@@ -1053,9 +1099,9 @@ __device__ __forceinline__ void splitk_finish_group(const GemmArgs& g, int m, in
     }
 }
 
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool F16 = false>
-__global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_kernel(const GemmArgs g) {
-    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, F16>(g, blockIdx.x);
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool F16 = false, int LW = 0>
+__global__ __launch_bounds__(NTHREADS * KG * MB + 64 * LW) void gemm_pipe_kernel(const GemmArgs g) {
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, F16, LW>(g, blockIdx.x);
 }
 
 // Grouped launch: up to MAX_GROUPS independent contractions of the SAME layout / element types / tile variant in one
@@ -1072,8 +1118,8 @@ struct GemmGroup {
     GemmArgs p[MAX_GROUPS];
     int packed, count, total;  // packed placement: number of problems, total tile count
 };
-template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool F16 = false>
-__global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(const GemmGroup gg) {
+template <int NSTAGE, bool TRA, bool TRB, int KG, int MB, int NI = 4, bool F16 = false, int LW = 0>
+__global__ __launch_bounds__(NTHREADS * KG * MB + 64 * LW) void gemm_pipe_group_kernel(const GemmGroup gg) {
     if (gg.packed) {
         const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
         const int q = gg.total >> 3, r = gg.total & 7;
@@ -1085,12 +1131,12 @@ __global__ __launch_bounds__(NTHREADS * KG * MB) void gemm_pipe_group_kernel(con
             if (v < t) break;
             v -= t;
         }
-        gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, true, F16>(gg.p[pi], v);
+        gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, true, F16, LW>(gg.p[pi], v);
         return;
     }
     const GemmArgs& g = gg.p[blockIdx.y];
     if ((int)blockIdx.x >= g.tiles_m * g.tiles_n * g.splitk) return;
-    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, F16>(g, blockIdx.x);
+    gemm_pipe_body<NSTAGE, TRA, TRB, KG, MB, NI, false, F16, LW>(g, blockIdx.x);
 }
 
 
@@ -1595,6 +1641,7 @@ static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(1
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
 static int g_row_affinity = 1;      // development knob (egk_gemm_set_pipeline(950 / 951)): XCD x owns a contiguous eighth of the tile rows off / on
+static int g_r192_loaders = 1;      // development knob (egk_gemm_set_pipeline(870 / 871)): the 192 x 128 tile with four loader waves (variant 19) off / on
 static int g_tt_tall = 1;           // development knob (egk_gemm_set_pipeline(850 / 851)): 256 x 128 tiles for weight-gradient groups that leave the second workgroup slot of many CUs empty, off / on
 static int g_r192 = 1;              // development knob (egk_gemm_set_pipeline(900 / 901)): 192 x 128 tiles (variant 16) inside the policy off / on
 static bool g_lds_attr_set = false;
@@ -1640,6 +1687,8 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<3, false, false, 1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<3, false, true, 1, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<3, false, false, 1, 2, 3, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<3, false, true, 1, 2, 3, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, false, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_kernel<2, false, true, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
     g_lds_attr_set = true;
@@ -1649,6 +1698,7 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     const int prev = g_use_pipe;
     if (on >= 950) { g_row_affinity = on - 950; return prev; }
     if (on >= 900) { g_r192 = on - 900; return prev; }
+    if (on >= 870) { g_r192_loaders = on - 870; return prev; }
     if (on >= 850) { g_tt_tall = on - 850; return prev; }
     if (on >= 700) return prev;  // (700 / 80x: knobs of variants that no longer exist)
     if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
@@ -1881,6 +1931,9 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                     // (ONE round only: 8192 x 1024 -- 344 tiles, two rounds of which the second is a third full -- measured 32.6 us
                     //  against 22.3 on 128-row tiles; BASELINE config 5's 16384 rows 3.08 against 2.92 ms per step)
                     if (g_r192 && t192 > 192 && t192 <= 256 && 40 < cur) variant = 16;
+                    // ... with loader waves (below) also several rounds, when the last one is at least 60 % full: 16384 x 1024 (688 tiles,
+                    // 2.7 rounds) BASELINE config 5 2.938 -> 2.901 ms (knob 900: all of variant 16 off)
+                    if (g_r192 && g_r192_loaders && t192 > 256 && (t192 % 256 == 0 || t192 % 256 >= 150) && nkt_slab >= 8) variant = 16;
                 } else if (t64 <= 256 && t64 > t128) {
                     // at most 128 tiles: 64-row tiles put one 4-wave workgroup on twice as many CUs instead of one
                     // 8-wave (two wave groups) workgroup on half of them (2048 x 1024 x 1024: 10.6 vs 12.4 us)
@@ -1964,7 +2017,9 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
         dim3 pgrid(g.tiles_m * g.tiles_n * g.splitk);
 #define EGK_PIPE(TA, TB)                                                                                                  \
     do {                                                                                                                  \
-        if (variant == 16) {                                                                                              \
+        if (variant == 16 && g_r192_loaders && nkt_slab >= 4) {                                                           \
+            hipLaunchKernelGGL((gemm_pipe_kernel<3, false, TB, 1, 2, 3, false, 4>), pgrid, dim3(2 * NTHREADS + 256), 3 * 40960, s, g); \
+        } else if (variant == 16) {                                                                                       \
             hipLaunchKernelGGL((gemm_pipe_kernel<3, false, TB, 1, 2, 3>), pgrid, dim3(2 * NTHREADS), 3 * 40960, s, g);    \
         } else if (variant == 15) {                                                                                       \
             hipLaunchKernelGGL((gemm_big_kernel<false, TB, 8, 6>), pgrid, dim3(512), 131072, s, g);                       \

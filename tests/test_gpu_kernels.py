@@ -1457,6 +1457,36 @@ def test_gemm_grouped_tall_tiles_for_uneven_weight_gradient_groups_bit_equal(ops
     torch.testing.assert_close(outs[851][0][0].double().cpu(), A.double().t() @ B.double() + c.double(), rtol=1e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(6144, 1024, 1024), (6000, 1024, 2048), (16384, 1024, 1024), (6144, 2048, 256), (6144, 1024, 4608)])
+def test_gemm_192_row_tile_with_loader_waves_bit_equal(ops, tb, M, N, K):
+    """The 192 x 128 tile with four LOADER waves (they issue every LDS-DMA piece of the workgroup; the eight compute waves only read
+    fragments and feed the matrix pipe; egk_gemm_set_pipeline(870 / 871) off / on) against the same tile whose compute waves issue
+    their own pieces: the same accumulation order per element -- bit for bit, bias + activation epilogue included, ragged row counts
+    and several rounds of tiles included."""
+    from egopack_amd import _lib
+    lib = _lib.load()
+    g = gen(M + N + K + int(tb))
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    B = torch.randn((K, N) if tb else (N, K), generator=g).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    outs = {}
+    prev = lib.egk_gemm_set_pipeline(16)
+    try:
+        for knob in (870, 871):
+            lib.egk_gemm_set_pipeline(knob)
+            out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+            ops.gemm(M, N, A, K, B, B.shape[1], K, out, N, transB=tb, bias=bias, act=1, compute=ops.BF16, allow_splitk=False)
+            torch.cuda.synchronize()
+            outs[knob] = out
+    finally:
+        lib.egk_gemm_set_pipeline(871)
+        lib.egk_gemm_set_pipeline(prev)
+    assert torch.equal(outs[870], outs[871])
+    ref = torch.relu(A.double().cpu() @ (B.double().cpu() if tb else B.double().cpu().t()) + bias.double().cpu())
+    torch.testing.assert_close(outs[871].double().cpu(), ref, rtol=2e-2, atol=2e-1)
+
+
 def test_gemm_grouped_rejects_what_it_cannot_run(ops):
     A = torch.randn(64, 96, device=DEV).to(torch.bfloat16)  # K = 96 is not a multiple of 64
     B = torch.randn(64, 96, device=DEV).to(torch.bfloat16)
