@@ -1641,6 +1641,7 @@ static int g_group_m_override = 0;  // development knob (egk_gemm_set_pipeline(1
 static int g_rows_epilogue = 1;     // development knob (egk_gemm_set_pipeline(200 / 201): direct / row-contiguous epilogue)
 static int g_group_packed = 1;      // development knob (egk_gemm_set_pipeline(300 / 301): spread / XCD-packed placement of grouped launches)
 static int g_row_affinity = 1;      // development knob (egk_gemm_set_pipeline(950 / 951)): XCD x owns a contiguous eighth of the tile rows off / on
+static int g_group_r192 = 1;        // development knob (egk_gemm_set_pipeline(860 / 861)): the 192 x 128 tile for one-round row-major-A groups off / on
 static int g_r192_loaders = 1;      // development knob (egk_gemm_set_pipeline(870 / 871)): the 192 x 128 tile with four loader waves (variant 19) off / on
 static int g_tt_tall = 1;           // development knob (egk_gemm_set_pipeline(850 / 851)): 256 x 128 tiles for weight-gradient groups that leave the second workgroup slot of many CUs empty, off / on
 static int g_r192 = 1;              // development knob (egk_gemm_set_pipeline(900 / 901)): 192 x 128 tiles (variant 16) inside the policy off / on
@@ -1674,6 +1675,8 @@ static void ensure_lds_attr() {
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<3, true, true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<3, false, false, 1, 2, 3, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
+    (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<3, false, true, 1, 2, 3, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_group_kernel<2, false, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void*)egk::gemm_pipe_f32_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1699,6 +1702,7 @@ extern "C" int egk_gemm_set_pipeline(int32_t on) {
     if (on >= 950) { g_row_affinity = on - 950; return prev; }
     if (on >= 900) { g_r192 = on - 900; return prev; }
     if (on >= 870) { g_r192_loaders = on - 870; return prev; }
+    if (on >= 860) { g_group_r192 = on - 860; return prev; }
     if (on >= 850) { g_tt_tall = on - 850; return prev; }
     if (on >= 700) return prev;  // (700 / 80x: knobs of variants that no longer exist)
     if (on >= 600) { g_group_tt_pad_kb = on - 600; return prev; }
@@ -2202,8 +2206,8 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     const bool f16 = descs[0].op_f16 != 0;
     EGK_REQUIRE(!f16 || (!ta && !tb && !f32g), "egk_gemm_grouped: op_f16 takes row-major 16-bit operands");
     double flops = 0, bytes = 0;
-    long long t128 = 0, t96 = 0, t64 = 0, t256 = 0;
-    int min_nkt = 1 << 30;
+    long long t128 = 0, t96 = 0, t64 = 0, t256 = 0, t192 = 0;
+    int min_nkt = 1 << 30, any_extra = 0;
     for (int i = 0; i < count; ++i) {
         const egk_gemm_desc* d = descs + i;
         EGK_REQUIRE((d->transA != 0) == ta && (d->transB != 0) == tb, "egk_gemm_grouped: the problems must share one layout");
@@ -2219,6 +2223,8 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         const int tn = cdiv(d->N, BN);
         t128 += (long long)cdiv(d->M, 128) * tn; t96 += (long long)cdiv(d->M, 96) * tn; t64 += (long long)cdiv(d->M, 64) * tn;
         t256 += (long long)cdiv(d->M, 256) * tn;
+        t192 += (long long)cdiv(d->M, 192) * tn;
+        any_extra |= d->n_extra > 0;
         min_nkt = K / 64 < min_nkt ? K / 64 : min_nkt;
     }
     ensure_lds_attr();
@@ -2264,6 +2270,11 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     // 48 KiB per K tile for twice the flops) is one round instead.  Long K walks only: same box, alternating, 6144 rows 1.291 -> 1.284 ms, 16384 rows
     // 2.947 -> 2.934, 2048 rows 0.842 -> 0.863 (its 3-stage fill and 256-row epilogue outweigh 32 K tiles).
     if (ta && tb && g_tt_tall && t128 > 256 && t128 <= 448 && t256 <= 256 && min_nkt >= 64) variant = 13;
+    // row-major A: the 192 x 128 tile with loader waves (egk_gemm's variant 16) when the group is ONE round of such tiles that more
+    // than half fills the chip and 128- / 96-row tiles would take more than one (the projection heads of three task batches:
+    // 64 + 2048 + 2048 rows = 184 tiles against 264 / 360)
+    // (not for the three-product groups of the precise pass: BASELINE config 4 2.113 -> 2.124 ms with them)
+    if (!ta && !f16 && !any_extra && g_r192 && g_r192_loaders && g_group_r192 && t192 > 128 && t192 <= 256 && t128 > 256 && min_nkt >= 8) variant = 16;
     if (g_use_pipe == 3 || g_use_pipe == 5) variant = g_use_pipe;
     if (g_use_pipe == 13 && ta && tb) variant = 13;
     if ((g_use_pipe == 8 || g_use_pipe == 11) && !ta) variant = g_use_pipe;
@@ -2271,7 +2282,7 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
     int max_wg = 0, total = 0;
     for (int i = 0; i < count; ++i) {
         GemmArgs& g = gg.p[i];
-        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : variant == 13 ? cdiv(g.M, 256) : cdiv(g.M, BM);
+        g.tiles_m = variant == 8 ? cdiv(g.M, 96) : variant == 11 ? cdiv(g.M, 64) : variant == 13 ? cdiv(g.M, 256) : variant == 16 ? cdiv(g.M, 192) : cdiv(g.M, BM);
         g.tiles_n = cdiv(g.N, BN);
         total += g.tiles_m * g.tiles_n;
     }
@@ -2310,6 +2321,9 @@ extern "C" int egk_gemm_grouped(egk_stream_t stream, const egk_gemm_desc* descs,
         if (f16) {
             ensure_lds_attr();
             hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 4, true>), pgrid, pblock, 2 * 32768, s, gg);
+        } else if (!ta && variant == 16) {
+            if (!tb) hipLaunchKernelGGL((gemm_pipe_group_kernel<3, false, false, 1, 2, 3, false, 4>), pgrid, dim3(2 * NTHREADS + 256), 3 * 40960, s, gg);
+            else hipLaunchKernelGGL((gemm_pipe_group_kernel<3, false, true, 1, 2, 3, false, 4>), pgrid, dim3(2 * NTHREADS + 256), 3 * 40960, s, gg);
         } else if (!ta && variant == 11) {
             if (!tb) hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, false, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);
             else hipLaunchKernelGGL((gemm_pipe_group_kernel<2, false, true, 1, 1, 2>), pgrid, pblock, 2 * 24576, s, gg);

@@ -1380,7 +1380,8 @@ def test_csr_gather_rows_with_hundreds_of_edges(ops, dtype, T, B):
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", ["nn", "nt", "tt"])
 @pytest.mark.parametrize("sizes", [[(2048, 1024, 1024)] * 3, [(256, 128, 64), (192, 256, 64), (64, 128, 128), (448, 128, 64)],
-                                   [(6144, 1024, 1024), (2048, 1024, 1024)]])
+                                   [(6144, 1024, 1024), (2048, 1024, 1024)],
+                                   [(64, 1024, 1024), (2048, 1024, 1024), (2048, 1024, 1024)]])  # (the heads' group: 192-row tiles + loaders)
 def test_gemm_grouped_equals_separate_contractions(ops, layout, sizes):
     """egk_gemm_grouped (one launch, blockIdx.y = problem) against the fp64 product of the bf16-rounded operands, and
     against egk_gemm problem by problem (same kernel body; the tile variant may differ: fp32 accumulation-order noise only)."""
@@ -1412,7 +1413,9 @@ def test_gemm_grouped_equals_separate_contractions(ops, layout, sizes):
     for out, one, ref in zip(outs, singles, refs):
         tol = dict(rtol=1e-3, atol=1e-3) if out.dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
         torch.testing.assert_close(out.double().cpu(), ref, **tol)
-        torch.testing.assert_close(out.float(), one.float(), rtol=1e-5, atol=1e-4 if out.dtype == torch.float32 else 2e-2)
+        # (bf16 results: another tile variant = another f32 accumulation order = now and then the neighbouring bf16 value)
+        torch.testing.assert_close(out.float(), one.float(), rtol=1e-5 if out.dtype == torch.float32 else 8e-3,
+                                   atol=1e-4 if out.dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("with_dbias", [False, True])
