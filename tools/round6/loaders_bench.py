@@ -42,16 +42,16 @@ for M in (6144, 192, 6000):
         B = torch.randn((K, N) if tB else (N, K), device=dev).to(dt)
         bias = torch.randn(N, device=dev)
         outs = {}
-        for knob in (870, 871, 872):
+        for knob in (870, 871):
             lib.egk_gemm_set_pipeline(knob)
             out = torch.zeros(M, N, device=dev, dtype=dt)
             ops.gemm(M, N, A, K, B, B.shape[1], K, out, N, transB=tB, bias=bias, act=1, compute=ops.BF16)
             torch.cuda.synchronize()
             outs[knob] = out
-        same = torch.equal(outs[870], outs[871]) and torch.equal(outs[870], outs[872])
+        same = torch.equal(outs[870], outs[871])
         cells = []
         if M == 6144:
-            for knob in (870, 871, 872):
+            for knob in (870, 871):
                 lib.egk_gemm_set_pipeline(knob)
                 out = torch.empty(M, N, device=dev, dtype=dt)
                 us = time_us(lambda: ops.gemm(M, N, A, K, B, B.shape[1], K, out, N, transB=tB, bias=bias, act=1, compute=ops.BF16))
