@@ -1935,9 +1935,8 @@ static int gemm_core(egk_stream_t stream, const egk_gemm_desc* d, int* query_blo
                     // (ONE round only: 8192 x 1024 -- 344 tiles, two rounds of which the second is a third full -- measured 32.6 us
                     //  against 22.3 on 128-row tiles; BASELINE config 5's 16384 rows 3.08 against 2.92 ms per step)
                     if (g_r192 && t192 > 192 && t192 <= 256 && 40 < cur) variant = 16;
-                    // ... with loader waves (below) also several rounds, when the last one is at least 60 % full: 16384 x 1024 (688 tiles,
-                    // 2.7 rounds) BASELINE config 5 2.938 -> 2.901 ms (knob 900: all of variant 16 off)
-                    if (g_r192 && g_r192_loaders && t192 > 256 && (t192 % 256 == 0 || t192 % 256 >= 150) && nkt_slab >= 8) variant = 16;
+                    // (several rounds of this tile with its loader waves -- 16384 x 1024: 688 tiles, 2.7 rounds -- measured 2.938 -> 2.901 ms
+                    //  for BASELINE config 5 on one box and 2.93 -> 3.03 on two others: one round only)
                 } else if (t64 <= 256 && t64 > t128) {
                     // at most 128 tiles: 64-row tiles put one 4-wave workgroup on twice as many CUs instead of one
                     // 8-wave (two wave groups) workgroup on half of them (2048 x 1024 x 1024: 10.6 vs 12.4 us)
